@@ -1,0 +1,88 @@
+"""Synthetic SMB-decoder batches with the layout the reference's data path produces.
+
+The reference's datasets are git-LFS pointers, so every parity and
+throughput run uses synthetic sequences with the *format* of
+``SMBExplicitDatasetForDecoder`` + ``DecoderOnlyCollator``
+(ref:SeqRec/datasets/SMB_dataset.py:194-248,586-610; ref:SeqRec/datasets/collator.py:55-107):
+
+* item = ``<behavior_b><a_i><b_j><c_k><d_l>`` -> 5 tokens; sequence = n items, right padded
+  with the pad id (4); no BOS/EOS appended;
+* token ids: 0..13 specials, semantic code (level l, code c) -> 14 + cb*l + c,
+  behaviour b -> 14 + 4*cb + b (cb = codebook size, 256 in the shipped recipe);
+* ``actions`` = behaviour *level* of the token's item (here level == b), padded with 100;
+* ``labels`` = input_ids with pad and behaviour tokens replaced by -100
+  (collator.py:68-73 with ignore_behavior_tokens);
+* ``session_ids`` / ``extended_session_ids`` are present but unused by Qwen3Multi.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence
+
+import torch
+
+PAD_ID = 4
+EOS_ID = 8
+N_SPECIAL = 14
+TOKENS_PER_ITEM = 5
+
+
+def vocab_size(codebook: int = 256, num_behavior: int = 3) -> int:
+    return N_SPECIAL + 4 * codebook + num_behavior
+
+
+def behavior_token(b: int, codebook: int = 256) -> int:
+    return N_SPECIAL + 4 * codebook + b
+
+
+def behavior_maps(codebook: int = 256, num_behavior: int = 3) -> Dict[int, int]:
+    """token id -> behaviour index, what train_SMB_decoder.py:321-333 stores in the config."""
+    return {behavior_token(b, codebook): b for b in range(num_behavior)}
+
+
+def make_batch(batch_size: int, n_items: int = 101, codebook: int = 256, num_behavior: int = 3,
+               ragged: bool = False, min_items: int = 2, seed: int = 20251114,
+               behavior_probs: Optional[Sequence[float]] = None,
+               pad_rows: Optional[Dict[int, int]] = None) -> Dict[str, torch.Tensor]:
+    """One collated batch (CPU int64 tensors).
+
+    ``ragged``: n_items ~ U{min_items..n_items} per row, right padded to the batch max.
+    ``pad_rows``: {row: items_to_drop} for hand-placed padding (used by the golden fixtures).
+    ``behavior_probs``: categorical over behaviours (default uniform).
+    """
+    g = torch.Generator().manual_seed(seed)
+    if behavior_probs is None:
+        behavior_probs = [1.0 / num_behavior] * num_behavior
+    probs = torch.tensor(behavior_probs, dtype=torch.float64)
+    lens = torch.full((batch_size,), n_items, dtype=torch.int64)
+    if ragged:
+        lens = torch.randint(min_items, n_items + 1, (batch_size,), generator=g)
+    if pad_rows:
+        for r, drop in pad_rows.items():
+            lens[r] = max(1, n_items - drop)
+    max_items = int(lens.max())
+    S = max_items * TOKENS_PER_ITEM
+    beh = torch.multinomial(probs.expand(batch_size, -1), max_items, replacement=True, generator=g)
+    codes = torch.randint(0, codebook, (batch_size, max_items, 4), generator=g)
+    item_tok = torch.empty(batch_size, max_items, TOKENS_PER_ITEM, dtype=torch.int64)
+    item_tok[:, :, 0] = N_SPECIAL + 4 * codebook + beh
+    for l in range(4):
+        item_tok[:, :, 1 + l] = N_SPECIAL + codebook * l + codes[:, :, l]
+    ids = item_tok.reshape(batch_size, S)
+    actions = beh.repeat_interleave(TOKENS_PER_ITEM, dim=1)
+    valid = (torch.arange(max_items)[None, :] < lens[:, None]).repeat_interleave(TOKENS_PER_ITEM, dim=1)
+    ids = torch.where(valid, ids, torch.full_like(ids, PAD_ID))
+    actions = torch.where(valid, actions, torch.full_like(actions, 100))
+    labels = ids.clone()
+    labels[~valid] = -100
+    labels[:, ::TOKENS_PER_ITEM] = -100          # behaviour tokens are not predicted
+    item_index = torch.arange(S) // TOKENS_PER_ITEM
+    session = torch.where(valid, item_index[None, :].expand(batch_size, S), torch.zeros_like(ids))
+    ext = torch.where(valid, torch.arange(S)[None, :].expand(batch_size, S), torch.zeros_like(ids))
+    return {
+        "input_ids": ids.contiguous(),
+        "attention_mask": valid.to(torch.int64).contiguous(),
+        "actions": actions.contiguous(),
+        "labels": labels.contiguous(),
+        "session_ids": session.contiguous(),
+        "extended_session_ids": ext.contiguous(),
+    }

@@ -1,0 +1,375 @@
+"""CPU oracle for GAMER's Qwen3Multi SMB-decoder train step.
+
+TEST INFRASTRUCTURE ONLY.  This is an independent CPU (PyTorch fp32/fp64) restatement of the
+reference's algorithm for the hot path.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it; the product package ``gamer_amd`` never
+does (it fails loudly when the HIP library is missing instead of falling back to this).
+
+Pinning: ``oracle/make_golden.py`` (build container only) imports the real reference from
+``/root/reference`` and writes the fixtures under ``tests/golden/``; ``tests/test_oracle.py``
+checks this restatement against them (logits <= 1e-5 abs, every parameter gradient <= 1e-4
+rel).  The reference ships no tests of its own for this path, so the
+fixtures generated from the reference's execution are the pin.
+
+Reference sites restated (``ref:`` = wzf2000/GAMER):
+  router        ref:SeqRec/models/generative/Qwen3Multi/router.py:74-201
+  masks         ref:SeqRec/models/generative/Qwen3Multi/model.py:573-630 (cross), :691-741 (self)
+  attention     ref:SeqRec/models/generative/Qwen3Multi/model.py:75-150
+  decoder layer ref:SeqRec/models/generative/Qwen3Multi/model.py:186-247
+  sparse FFN    ref:SeqRec/models/generative/Qwen3Moe/FFN.py:25-27,53-72
+  model forward ref:SeqRec/models/generative/Qwen3Multi/model.py:744-880
+  head + loss   ref:SeqRec/models/generative/Qwen3Multi/model.py:904-922,928-1013
+  RMSNorm/RoPE/CE: third-party ``transformers`` (pinned 4.51.0 in ref:requirements.txt:9):
+                models/qwen3/modeling_qwen3.py (Qwen3RMSNorm, rotate_half, apply_rotary_pos_emb,
+                Qwen3RotaryEmbedding), loss/loss_utils.py (ForCausalLMLoss, fixed_cross_entropy).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class OracleConfig:
+    """The hyper-parameters of ref:config/s2s-models/Qwen3Multi/config.json plus the fields
+    ref:SeqRec/tasks/train_SMB_decoder.py:335-360 adds at run time."""
+    vocab_size: int = 1041
+    hidden_size: int = 256
+    num_hidden_layers: int = 8
+    num_attention_heads: int = 6
+    num_key_value_heads: int = 3
+    head_dim: int = 64
+    intermediate_size: int = 512
+    moe_intermediate_size: int = 256
+    behavior_embedding_dim: int = 64
+    behavior_injection_decoder: List[int] = field(default_factory=lambda: [0, 1, 2, 3])
+    cross_attention_decoder: List[int] = field(default_factory=lambda: [4, 5, 6, 7])
+    dropout_rate: float = 0.2
+    attention_dropout: float = 0.2
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1e6
+    pad_token_id: int = 4
+    eos_token_id: int = 8
+    num_behavior: int = 3
+    behavior_maps: Dict[int, int] = field(default_factory=lambda: {1038: 0, 1039: 1, 1040: 2})
+    num_positions: int = 5
+    num_experts: int = 6
+
+    @staticmethod
+    def from_dict(d: dict) -> "OracleConfig":
+        keys = OracleConfig.__dataclass_fields__.keys()
+        kw = {k: d[k] for k in keys if k in d}
+        if "behavior_maps" in kw:
+            kw["behavior_maps"] = {int(k): int(v) for k, v in kw["behavior_maps"].items()}
+        return OracleConfig(**kw)
+
+
+# --------------------------------------------------------------------------------------
+# integer part
+# --------------------------------------------------------------------------------------
+def router(input_ids: torch.Tensor, cfg: OracleConfig):
+    """router.py:74-201 for the training call (cache_position = arange(S), no user token).
+
+    Returns (position_index, behavior_index, action_index), each [B,S] int64.
+    """
+    B, S = input_ids.shape
+    P = cfg.num_positions
+    t = torch.arange(S)
+    special = (input_ids == cfg.pad_token_id) | (input_ids == cfg.eos_token_id)
+    # router.py:50-58 table = (arange(P)+1).repeat(n_items) ++ [0]; :104 zero at pad/eos
+    pos = ((t % P) + 1).unsqueeze(0).expand(B, S).clone()
+    pos[special] = 0
+    # router.py:158-195: behaviour token of each item -> map+1, repeated over the item
+    first = (t // P) * P                      # index of the item's behaviour token
+    beh_tok = input_ids[:, first]             # [B,S]
+    act = beh_tok.clone()                     # tokens outside the map keep their raw value (:170-171)
+    for tok, emb_id in cfg.behavior_maps.items():
+        act[beh_tok == tok] = emb_id + 1
+    act = act.clone()
+    act[special] = 0
+    beh = act.clone()
+    beh[:, (t % P) == 0] = 0                  # router.py:139
+    return pos, beh, act
+
+
+def mask_predicates(attention_mask: torch.Tensor, actions: torch.Tensor):
+    """model.py:691-741 (self) and :573-630 (cross) as boolean 'allowed' predicates [B,S,S]
+    (query i, key j) plus the 'row has no allowed key' flags [B,S]."""
+    B, S = attention_mask.shape
+    keep = attention_mask.bool()
+    i = torch.arange(S).view(1, S, 1)
+    j = torch.arange(S).view(1, 1, S)
+    causal = j <= i
+    self_ok = causal & keep[:, None, :]
+    cross_ok = causal & (actions[:, None, :] < actions[:, :, None]) & keep[:, None, :]
+    return self_ok, cross_ok
+
+
+# --------------------------------------------------------------------------------------
+# float part
+# --------------------------------------------------------------------------------------
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    """Qwen3RMSNorm.forward: fp32 variance, cast back, then multiply by the weight."""
+    dt = x.dtype
+    xf = x.to(torch.float32) if dt != torch.float64 else x
+    var = xf.pow(2).mean(-1, keepdim=True)
+    xf = xf * torch.rsqrt(var + eps)
+    return w * xf.to(dt)
+
+
+def rope_tables(S: int, dh: int, theta: float, dtype=torch.float32):
+    """Qwen3RotaryEmbedding.forward with position_ids = arange(S) (model.py:787-794,819)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, dh, 2, dtype=torch.int64).to(torch.float32) / dh))
+    pos = torch.arange(S, dtype=torch.float32)
+    freqs = pos[:, None] * inv_freq[None, :]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+def apply_rope(x, cos, sin):
+    """x [B,S,heads,dh]; cos/sin [S,dh]."""
+    return x * cos[None, :, None, :] + rotate_half(x) * sin[None, :, None, :]
+
+
+def _dropout(x, p, training):
+    return F.dropout(x, p, training) if (training and p > 0) else x
+
+
+def attention(h, sd, prefix, ok, cfg: OracleConfig, cos, sin, act_idx=None, training=False):
+    """Qwen3MultiAttention.forward (model.py:75-150) with the additive finfo.min mask folded in.
+
+    A query row with no allowed key ends up with every masked score equal to finfo.min, so the
+    softmax is uniform over all S keys (future and padded ones included) while autograd still
+    passes d(score) through the addition; ``s - s.detach()`` reproduces exactly that.
+    """
+    B, S, _ = h.shape
+    nq, nkv, dh = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    cross = act_idx is not None
+    q = F.linear(h, sd[prefix + "q_proj.weight"]).view(B, S, nq, dh)
+    k = F.linear(h, sd[prefix + "k_proj.weight"]).view(B, S, nkv, dh)
+    v = F.linear(h, sd[prefix + "v_proj.weight"]).view(B, S, nkv, dh)
+    if cross:
+        q = q + sd[prefix + "q_behavior_embedding.weight"][act_idx].view(B, S, nq, dh)
+        k = k + sd[prefix + "k_behavior_embedding.weight"][act_idx].view(B, S, nkv, dh)
+        v = v + sd[prefix + "v_behavior_embedding.weight"][act_idx].view(B, S, nkv, dh)
+    q = apply_rope(rmsnorm(q, sd[prefix + "q_norm.weight"], cfg.rms_norm_eps), cos, sin)
+    k = apply_rope(rmsnorm(k, sd[prefix + "k_norm.weight"], cfg.rms_norm_eps), cos, sin)
+    rep = nq // nkv
+    kq = k.repeat_interleave(rep, dim=2)          # query head n uses kv head n // rep
+    vq = v.repeat_interleave(rep, dim=2)
+    s = torch.einsum("bind,bjnd->bnij", q, kq) * (dh ** -0.5)
+    empty = ~ok.any(-1)                           # [B,S]
+    okb = ok[:, None, :, :]
+    s_norm = s.masked_fill(~okb, float("-inf"))
+    s_empty = s - s.detach()
+    s_eff = torch.where(empty[:, None, :, None], s_empty, s_norm)
+    p = torch.softmax(s_eff, dim=-1)
+    p = _dropout(p, cfg.attention_dropout, training)
+    o = torch.einsum("bnij,bjnd->bind", p, vq).reshape(B, S, nq * dh)
+    out = F.linear(o, sd[prefix + "o_proj.weight"])
+    if cross:
+        out = out * F.silu(F.linear(h, sd[prefix + "gating.weight"]))
+    return out
+
+
+def sparse_mlp(h, sd, prefix, pos_idx, beh_idx, cfg: OracleConfig, inject: bool, training=False):
+    """MyQwen3SparseMLP.forward (FFN.py:53-72): every token goes through exactly one expert,
+    chosen by its position index; layers in behavior_injection_decoder concatenate a
+    behaviour embedding first."""
+    if inject:
+        h = torch.cat((h, sd[prefix + "behavior_embedding.weight"][beh_idx]), dim=-1)
+    out = torch.zeros(h.shape[:-1] + (cfg.moe_intermediate_size,), dtype=h.dtype)
+    for e in range(cfg.num_experts):
+        sel = pos_idx == e
+        if not bool(sel.any()):
+            continue
+        x = h[sel]
+        ep = f"{prefix}experts.expert_{e}."
+        g = F.linear(x, sd[ep + "gate_proj.weight"])
+        u = F.linear(x, sd[ep + "up_proj.weight"])
+        m = _dropout(F.silu(g) * u, cfg.dropout_rate, training)
+        out[sel] = F.linear(m, sd[ep + "down_proj.weight"])
+    return out
+
+
+def forward(sd: Dict[str, torch.Tensor], cfg: OracleConfig, input_ids, attention_mask, actions,
+            labels=None, temperature: float = 1.0, num_items_in_batch: Optional[float] = None,
+            training: bool = False, return_hidden: bool = False):
+    """Qwen3MultiWithTemperature.forward (model.py:928-1013).
+
+    ``sd`` uses the reference's state-dict key names.  Returns a dict with ``logits`` (divided
+    by the temperature when labels are given, as the reference's in-place ``logits /= T`` does),
+    ``loss`` (or None), and optionally the per-layer hidden states and the router maps.
+    """
+    B, S = input_ids.shape
+    if attention_mask is None:
+        attention_mask = torch.ones_like(input_ids)
+    dtype = sd["model.embed_tokens.weight"].dtype
+    pos_idx, beh_idx, act_idx = router(input_ids, cfg)
+    self_ok, cross_ok = mask_predicates(attention_mask, actions)
+    cos, sin = rope_tables(S, cfg.head_dim, cfg.rope_theta, dtype)
+    # nn.Embedding(vocab, H, padding_idx=pad) (model.py:263): the gather-side gradient of the pad row is dropped
+    x = F.embedding(input_ids, sd["model.embed_tokens.weight"], padding_idx=cfg.pad_token_id)
+    hidden = [] if return_hidden else None      # model.py:822-873: input of every layer + final norm
+    eps = cfg.rms_norm_eps
+    for l in range(cfg.num_hidden_layers):
+        lp = f"model.layers.{l}."
+        if return_hidden:
+            hidden.append(x)
+        h = rmsnorm(x, sd[lp + "input_layernorm.weight"], eps)
+        a = attention(h, sd, lp + "self_attn.", self_ok, cfg, cos, sin, None, training)
+        x = x + _dropout(a, cfg.dropout_rate, training)
+        if l in cfg.cross_attention_decoder:
+            h = rmsnorm(x, sd[lp + "post_self_attention_layernorm.weight"], eps)
+            a = attention(h, sd, lp + "cross_attn.", cross_ok, cfg, cos, sin, act_idx, training)
+            x = x + _dropout(a, cfg.dropout_rate, training)
+        h = rmsnorm(x, sd[lp + "post_cross_attention_layernorm.weight"], eps)
+        m = sparse_mlp(h, sd, lp + "mlp.", pos_idx, beh_idx, cfg,
+                       l in cfg.behavior_injection_decoder, training)
+        x = x + _dropout(m, cfg.dropout_rate, training)
+    xn = rmsnorm(x, sd["model.norm.weight"], eps)
+    if return_hidden:
+        hidden.append(xn)
+    head = sd.get("lm_head.weight", sd["model.embed_tokens.weight"])
+    logits = F.linear(xn, head)
+    loss = None
+    if labels is not None:
+        logits = logits / temperature                      # model.py:913 (in place upstream)
+        shift = F.pad(labels, (0, 1), value=-100)[:, 1:]    # loss_utils.py: shift left, pad -100
+        flat = logits.reshape(-1, logits.shape[-1]).float() if dtype != torch.float64 \
+            else logits.reshape(-1, logits.shape[-1])
+        tgt = shift.reshape(-1)
+        if num_items_in_batch is not None:
+            loss = F.cross_entropy(flat, tgt, ignore_index=-100, reduction="sum") / num_items_in_batch
+        else:
+            loss = F.cross_entropy(flat, tgt, ignore_index=-100, reduction="mean")
+    out = {"logits": logits, "loss": loss, "router": (pos_idx, beh_idx, act_idx)}
+    if return_hidden:
+        out["hidden_states"] = hidden
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# parameters / update (for gradient parity and the CPU baseline)
+# --------------------------------------------------------------------------------------
+def param_shapes(cfg: OracleConfig) -> Dict[str, tuple]:
+    """Key -> shape of every distinct parameter (tied lm_head omitted), in the reference's
+    state-dict order (model.py:38-66,161-176,263-285; FFN.py:19-21,42-51)."""
+    H, dh = cfg.hidden_size, cfg.head_dim
+    nq, nkv, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size
+    Eb, NB = cfg.behavior_embedding_dim, cfg.num_behavior
+    shapes = {"model.embed_tokens.weight": (cfg.vocab_size, H)}
+    for l in range(cfg.num_hidden_layers):
+        lp = f"model.layers.{l}."
+        cross = l in cfg.cross_attention_decoder
+        inject = l in cfg.behavior_injection_decoder
+        for a in (["self_attn", "cross_attn"] if cross else ["self_attn"]):
+            ap = lp + a + "."
+            shapes[ap + "q_proj.weight"] = (nq * dh, H)
+            shapes[ap + "k_proj.weight"] = (nkv * dh, H)
+            shapes[ap + "v_proj.weight"] = (nkv * dh, H)
+            shapes[ap + "o_proj.weight"] = (H, nq * dh)
+            shapes[ap + "q_norm.weight"] = (dh,)
+            shapes[ap + "k_norm.weight"] = (dh,)
+            if a == "cross_attn":
+                shapes[ap + "q_behavior_embedding.weight"] = (NB + 1, nq * Eb)
+                shapes[ap + "k_behavior_embedding.weight"] = (NB + 1, nkv * Eb)
+                shapes[ap + "v_behavior_embedding.weight"] = (NB + 1, nkv * Eb)
+                shapes[ap + "gating.weight"] = (H, H)
+        if cross:
+            shapes[lp + "post_self_attention_layernorm.weight"] = (H,)
+        din = cfg.moe_intermediate_size + (Eb if inject else 0)
+        for e in range(cfg.num_experts):
+            ep = f"{lp}mlp.experts.expert_{e}."
+            shapes[ep + "gate_proj.weight"] = (I, din)
+            shapes[ep + "up_proj.weight"] = (I, din)
+            shapes[ep + "down_proj.weight"] = (cfg.moe_intermediate_size, I)
+        if inject:
+            shapes[lp + "mlp.behavior_embedding.weight"] = (NB + 1, Eb)
+        shapes[lp + "input_layernorm.weight"] = (H,)
+        shapes[lp + "post_cross_attention_layernorm.weight"] = (H,)
+    shapes["model.norm.weight"] = (H,)
+    return shapes
+
+
+def init_state_dict(cfg: OracleConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Deterministic fill shared by the fixtures and the tests: parameters visited in sorted key
+    order, normal(0, 0.02) from one seeded generator; RMSNorm weights are 1 + normal(0, 0.1)
+    (non-trivial so that norm-weight handling is actually exercised); padding row of the
+    embedding zeroed.  This is NOT the HF initialiser (SURVEY.md section 8(a) note) — parity
+    tests always load explicit weights."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    shapes = param_shapes(cfg)
+    for k in sorted(shapes):
+        shp = shapes[k]
+        if len(shp) == 1:
+            sd[k] = (1.0 + 0.1 * torch.randn(shp, generator=g, dtype=torch.float64)).to(dtype)
+        else:
+            sd[k] = (0.02 * torch.randn(shp, generator=g, dtype=torch.float64)).to(dtype)
+    sd["model.embed_tokens.weight"][cfg.pad_token_id].zero_()
+    return sd
+
+
+NO_DECAY_SUFFIXES = ("layernorm.weight", "_norm.weight", "model.norm.weight")
+
+
+def is_no_decay(key: str) -> bool:
+    """HF Trainer.get_decay_parameter_names: RMSNorm/LayerNorm weights and biases get no weight
+    decay (transformers/trainer.py get_decay_parameter_names; trainer_pt_utils.get_parameter_names
+    with forbidden 'norm' name patterns).  Embeddings and linear weights are decayed."""
+    return key.endswith(NO_DECAY_SUFFIXES)
+
+
+def loss_and_grads(sd, cfg, batch, temperature=1.0, num_items_in_batch=None, training=False):
+    """Forward + autograd backward; returns (loss, {key: grad}, forward-output) with the tied
+    table's gradient under 'model.embed_tokens.weight' (head wgrad over all rows + gather
+    scatter-add with the padding row's contribution dropped, as nn.Embedding(padding_idx) does)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if k != "lm_head.weight"}
+    view = dict(leaves)
+    view["lm_head.weight"] = leaves["model.embed_tokens.weight"]
+    out = forward(view, cfg, batch["input_ids"], batch.get("attention_mask"), batch["actions"],
+                  labels=batch.get("labels"), temperature=temperature,
+                  num_items_in_batch=num_items_in_batch, training=training)
+    out["loss"].backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
+    return out["loss"].detach(), grads, out
+
+
+def clip_and_adamw(params: Dict[str, torch.Tensor], grads, m, v, step: int, lr: float,
+                   beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, max_norm=1.0):
+    """HF Trainer update (transformers/trainer.py: clip_grad_norm_(max_norm) then
+    torch.optim.AdamW.step; ref:SeqRec/tasks/train_SMB_decoder.py:396-428 picks adamw_torch).
+    ``step`` is 1-based.  Updates params/m/v in place, returns the pre-clip global grad norm."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    for k, p in params.items():
+        g = grads[k] * coef
+        wd = 0.0 if is_no_decay(k) else weight_decay
+        p.mul_(1.0 - lr * wd)
+        m[k].mul_(beta1).add_(g, alpha=1.0 - beta1)
+        v[k].mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+        denom = (v[k].sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(m[k], denom, value=-lr / bc1)
+    return total
+
+
+def cosine_lr(step: int, base_lr: float, warmup_steps: int, total_steps: int) -> float:
+    """transformers.get_cosine_schedule_with_warmup (HF Trainer default for lr_scheduler_type
+    'cosine', ref:SeqRec/tasks/train_SMB_decoder.py:396-428); ``step`` = number of optimizer
+    steps already taken."""
+    if step < warmup_steps:
+        return base_lr * step / max(1, warmup_steps)
+    prog = (step - warmup_steps) / max(1, total_steps - warmup_steps)
+    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))

@@ -1,0 +1,97 @@
+"""The oracle (CPU restatement) against the fixtures generated from the real reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.qwen3multi_oracle import (OracleConfig, forward, init_state_dict, loss_and_grads, router)
+
+
+def _setup(golden, name):
+    z, meta = golden(name)
+    cfg = OracleConfig.from_dict(meta["config"])
+    sd = init_state_dict(cfg, seed=meta["weight_seed"])
+    batch = {k: torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "actions", "labels")}
+    return z, meta, cfg, sd, batch
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "full"])
+def test_weight_fill_is_reproducible(golden, name):
+    z, meta, cfg, sd, _ = _setup(golden, name)
+    keys = [str(k) for k in z["weight_keys"]]
+    assert keys == sorted(sd)
+    sums = np.array([[float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in keys])
+    np.testing.assert_allclose(sums, z["weight_checksums"], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "full"])
+def test_router_bit_exact(golden, name):
+    z, meta, cfg, sd, batch = _setup(golden, name)
+    pos, beh, act = router(batch["input_ids"], cfg)
+    assert np.array_equal(pos.numpy(), z["router_position"].astype(np.int64))
+    assert np.array_equal(beh.numpy(), z["router_behavior"].astype(np.int64))
+    assert np.array_equal(act.numpy(), z["router_action"].astype(np.int64))
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_forward_full_tensors(golden, name):
+    z, meta, cfg, sd, batch = _setup(golden, name)
+    with torch.no_grad():
+        out = forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["actions"], return_hidden=True)
+        np.testing.assert_allclose(out["logits"].numpy(), z["logits_raw"], atol=1e-5, rtol=0)
+        np.testing.assert_allclose(out["hidden_states"][-1].numpy(), z["hidden_last"], atol=1e-5, rtol=0)
+        np.testing.assert_allclose(out["hidden_states"][1].numpy(), z["hidden_layer1"], atol=1e-5, rtol=0)
+        out_l = forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["actions"],
+                        labels=batch["labels"], temperature=meta["temperature"])
+        np.testing.assert_allclose(out_l["logits"].numpy(), z["logits_scaled"], atol=1e-5, rtol=0)
+        assert abs(float(out_l["loss"]) - float(z["loss_mean"])) < 2e-6
+        out_n = forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["actions"],
+                        labels=batch["labels"], temperature=meta["temperature"],
+                        num_items_in_batch=float(z["num_items"]))
+        assert abs(float(out_n["loss"]) - float(z["loss_sum"])) < 2e-6
+
+
+def test_forward_full_config_samples(golden):
+    z, meta, cfg, sd, batch = _setup(golden, "full")
+    with torch.no_grad():
+        out = forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["actions"], return_hidden=True)
+        np.testing.assert_allclose(out["logits"][:, ::37, ::53].numpy(), z["logits_raw_sample"], atol=1e-5, rtol=0)
+        hs = np.array([float(h.double().sum()) for h in out["hidden_states"]])
+        np.testing.assert_allclose(hs, z["hidden_sum"], rtol=1e-4, atol=1e-2)
+        out_l = forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["actions"],
+                        labels=batch["labels"], temperature=meta["temperature"])
+        assert abs(float(out_l["loss"]) - float(z["loss_mean"])) < 2e-6
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "full"])
+def test_gradients(golden, name):
+    z, meta, cfg, sd, batch = _setup(golden, name)
+    loss, grads, _ = loss_and_grads(sd, cfg, batch, temperature=meta["temperature"])
+    assert abs(float(loss) - float(z["loss_train_mode"])) < 2e-6
+    gkeys = [str(k) for k in z["grad_keys"]]
+    assert gkeys == sorted(grads)
+    norms = np.array([float(grads[k].double().norm()) for k in gkeys])
+    np.testing.assert_allclose(norms, z["grad_norms"], rtol=1e-4, atol=1e-9)
+    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())))
+    assert abs(gn - float(z["global_grad_norm"])) < 1e-5 * float(z["global_grad_norm"])
+    for k in z.files:
+        if k.startswith("grad::"):
+            ref = z[k]
+            got = grads[k[6:]].numpy()
+            scale = max(np.abs(ref).max(), 1e-12)
+            assert np.abs(got - ref).max() <= 1e-4 * scale + 1e-9, k
+        elif k.startswith("gradsample::"):
+            g = grads[k[12:]]
+            got = g[::max(1, g.shape[0] // 8), ::max(1, g.shape[1] // 8)].numpy()
+            ref = z[k]
+            scale = max(np.abs(ref).max(), 1e-12)
+            assert np.abs(got - ref).max() <= 1e-4 * scale + 1e-9, k
+
+
+def test_empty_rows_exist_in_fixtures(golden):
+    """The cross-attention fixtures must exercise the 'no allowed key -> uniform over all S keys' rule."""
+    from oracle.qwen3multi_oracle import mask_predicates
+    z, meta, cfg, sd, batch = _setup(golden, "small")
+    _, cross_ok = mask_predicates(batch["attention_mask"], batch["actions"])
+    empty = ~cross_ok.any(-1)
+    nonpad = batch["attention_mask"].bool()
+    assert bool((empty & nonpad).any()) and bool((~empty & nonpad).any())
