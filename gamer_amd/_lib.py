@@ -1,0 +1,126 @@
+"""ctypes binding of libgamer_hip.so (the C ABI declared in include/gamer_hip.h).
+
+There is deliberately no fallback: if the library is missing or an entry point fails, a
+RuntimeError is raised.  The CPU oracle under ``oracle/`` is test infrastructure and is never
+imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgamer_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gamer_hip.h")
+
+_lib: Optional[C.CDLL] = None
+
+c_void_p, c_int, c_float, c_int64, c_uint64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64
+
+
+class GemmDesc(C.Structure):
+    """Mirror of gamer_gemm_desc."""
+    _fields_ = [
+        ("A", c_void_p), ("a_rs", c_int64), ("a_ks", c_int64),
+        ("B", c_void_p), ("b_rs", c_int64), ("b_ks", c_int64),
+        ("C", c_void_p), ("ldc", c_int64),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("alpha", c_float),
+        ("accumulate", c_int),
+        ("groups", c_int),
+        ("group_mode", c_int),
+        ("group_offsets", c_void_p),
+        ("strideB", c_int64), ("strideC", c_int64),
+        ("kchunk", c_int),
+    ]
+
+
+P, I, F, L, U = c_void_p, c_int, c_float, c_int64, c_uint64
+
+# name -> argtypes (everything returns int except the two noted below)
+_SIGNATURES = {
+    "gamer_router_fwd": [P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P],
+    "gamer_expert_lists": [P, I, I, I, P, P, P, P, P],
+    "gamer_embedding_fwd": [P, P, I, I, I, P, P],
+    "gamer_embedding_bwd": [P, P, I, I, I, I, P, P],
+    "gamer_rmsnorm_fwd": [P, P, I, I, F, P, P, I, P],
+    "gamer_rmsnorm_bwd": [P, P, P, I, P, I, I, F, I, P, P, I, P],
+    "gamer_colsum_reduce": [P, I, I, I, P, P],
+    "gamer_rowtable_fwd": [P, P, P, I, I, P, I, I, P],
+    "gamer_rowtable_bwd": [P, I, I, P, P, I, I, I, P, P],
+    "gamer_gemm_f32": [C.POINTER(GemmDesc), P],
+    "gamer_qknorm_rope_fwd": [P, I, I, I, I, P, P, F, P, P, P, P, P, P, P, P, P],
+    "gamer_qknorm_rope_bwd": [P, P, P, I, I, I, I, P, P, F, P, P, P, P, P, I, P, P, P, P, P, P, P],
+    "gamer_attn_fwd": [P, I, P, I, P, I, P, P, P, P, I, I, I, I, F, F, U, P, P, P],
+    "gamer_attn_bwd": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P],
+    "gamer_residual_dropout_fwd": [P, P, P, I, I, F, U, P],
+    "gamer_residual_dropout_bwd": [P, P, I, I, F, U, P, P],
+    "gamer_swiglu_fwd": [P, P, L, F, U, P, P],
+    "gamer_swiglu_bwd": [P, P, P, L, F, U, P],
+    "gamer_silu_gate_fwd": [P, P, L, P, P],
+    "gamer_silu_gate_bwd": [P, P, P, L, P, P, P],
+    "gamer_ce_fwd": [P, I, P, I, I, I, F, I, P, P, P, P, P],
+    "gamer_ce_bwd": [P, I, P, I, I, I, F, I, P, P, F, F, P],
+    "gamer_sumsq": [P, L, P, I, P],
+    "gamer_adamw": [P, P, P, P, L, L, F, F, F, F, F, I, F, F, P, I, P, P],
+    "gamer_fill_f32": [P, L, F, P],
+}
+
+
+def header_symbols():
+    """Names of every entry point declared in include/gamer_hip.h."""
+    txt = open(HEADER_PATH).read()
+    return sorted(set(re.findall(r"\b(gamer_[a-z0-9_]+)\s*\(", txt)) - {"gamer_gemm_desc"})
+
+
+def load(build_if_missing: bool = False) -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if build_if_missing:
+            from . import build as _build
+            _build.build()
+        else:
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m gamer_amd.build` "
+                "(gamer_amd has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.gamer_abi_version.restype = c_int
+    lib.gamer_abi_version.argtypes = []
+    lib.gamer_last_error.restype = C.c_char_p
+    lib.gamer_last_error.argtypes = []
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = c_int
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, name: str):
+    if rc != 0:
+        msg = load().gamer_last_error().decode(errors="replace")
+        raise RuntimeError(f"{name} failed (rc={rc}): {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    """hipStream_t of torch's current stream (so kernels order with torch ops on that stream)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    check(rc, name)

@@ -1,0 +1,718 @@
+// Multi-behaviour flash attention for gfx950, fp32 MFMA (v_mfma_f32_32x32x2_f32), head_dim 64.
+//
+// Replaces sdpa_attention_forward + the two additive [B,1,S,S] masks of the reference
+// (ref:SeqRec/models/generative/Qwen3Multi/model.py:133-143, 573-630, 691-741): the masks are the
+// predicate  allowed(i,j) = j<=i && kl[j] < ql[i]  evaluated in registers, and a query row that has
+// no allowed key ("empty" row, flagged by the router kernel) gets p = 1/S over ALL S keys exactly as
+// the reference's finfo.min mask does, in the forward and in both backward kernels.
+//
+// Data flow per workgroup (4 waves).  G = nq/nkv query heads share one K/V head:
+//   fwd / dq : workgroup = (b, kv head, tile of (4/G)*32 queries); wave = (query head, 32 queries);
+//              K/V tiles of 32 keys stream through LDS (double buffered), shared by the 4 waves.
+//              S^T = K Q^T puts the query on the lane, so the softmax state is lane-local and the
+//              accumulator registers are directly the B operand of the second MFMA
+//              (O^T += V^T P^T,  dQ^T += K^T dS^T): no LDS round trip for P.
+//   dkv      : workgroup = (b, kv head, tile of (4/G)*32 keys); wave = (query head, 32 keys);
+//              Q/dO tiles of 32 queries stream through LDS; S = Q K^T puts the key on the lane and
+//              dV^T += dO^T P, dK^T += Q^T dS accumulate in registers; the G heads are summed
+//              through LDS at the end.  No atomics anywhere (dQ is recomputed in its own kernel).
+#include "common.h"
+
+namespace gamer {
+
+constexpr int AT_THREADS = 256;
+constexpr int KLD = 68;                 // floats per row of a [32][64] tile image read as MFMA fragments
+constexpr int INT_BIG_A = 0x7fffffff;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int rowmap(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// tile of 32 rows x 64 floats: thread -> 2 float4 (f = tid + 256*jj: row f>>4, quad f&15)
+__device__ __forceinline__ void load_tile32(const float* __restrict__ base, int64_t ld, int r0, int r_end, int tid,
+                                            float4 (&rg)[2]) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int f = tid + AT_THREADS * jj;
+        const int row = r0 + (f >> 4);
+        rg[jj] = row < r_end ? *reinterpret_cast<const float4*>(base + (int64_t)row * ld + ((f & 15) << 2))
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int LD>
+__device__ __forceinline__ void store_tile32(float* __restrict__ lds, int tid, const float4 (&rg)[2]) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int f = tid + AT_THREADS * jj;
+        *reinterpret_cast<float4*>(lds + (f >> 4) * LD + ((f & 15) << 2)) = rg[jj];
+    }
+}
+
+// =============================================================================================
+// forward
+// =============================================================================================
+template <int G>
+__global__ void __launch_bounds__(AT_THREADS, 2)
+attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
+                const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
+                int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+                float* __restrict__ o, float* __restrict__ lse) {
+    constexpr int NSUB = 4 / G;
+    constexpr int R = NSUB * 32;
+    __shared__ __attribute__((aligned(16))) float Ks[2][32 * KLD];
+    __shared__ __attribute__((aligned(16))) float Vs[2][32 * 64];
+    __shared__ int32_t kls[2][32];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int hg = w / NSUB, sub = w % NSUB;
+    const int b = blockIdx.z, kvh = blockIdx.y, q0 = blockIdx.x * R;
+    const int head = kvh * G + hg;
+    const int r = lane & 31, h = lane >> 5;
+    const int iq = q0 + sub * 32 + r;
+    const bool valid_q = iq < S;
+    const int iqc = valid_q ? iq : S - 1;
+    const int64_t tok = (int64_t)b * S + iqc;
+
+    float qf[8][4];
+    {
+        const float* qrow = q + tok * ldq + head * 64;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const float4 t4 = *reinterpret_cast<const float4*>(qrow + 8 * kk + 4 * h);
+            qf[kk][0] = t4.x * scale; qf[kk][1] = t4.y * scale; qf[kk][2] = t4.z * scale; qf[kk][3] = t4.w * scale;
+        }
+    }
+    const int my_ql = ql ? ql[tok] : 1;
+    const bool my_empty = valid_q && row_empty[tok] != 0;
+    const int wave_q_hi = min(S - 1, q0 + sub * 32 + 31);
+    const bool wave_has_empty = __any(my_empty ? 1 : 0) != 0;
+    const bool block_has_empty = __syncthreads_or(my_empty ? 1 : 0) != 0;
+    const int n_all = (S + 31) / 32;
+    const int n_causal = (min(S, q0 + R) + 31) / 32;
+    const int n_iter = block_has_empty ? n_all : n_causal;
+    const float invS = 1.f / (float)S;
+    const DropoutRng rng(p_drop, seed);
+    const uint64_t drop_row = ((uint64_t)((int64_t)b * nq + head) * S + (uint64_t)iqc) * (uint64_t)S;
+
+    const float* kbase = k + (int64_t)b * S * ldk + kvh * 64;
+    const float* vbase = v + (int64_t)b * S * ldv + kvh * 64;
+    const int32_t* klb = kl + (int64_t)b * S;
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+
+    float4 rk[2], rv[2];
+    int rkl = INT_BIG_A;
+    load_tile32(kbase, ldk, 0, S, tid, rk);
+    load_tile32(vbase, ldv, 0, S, tid, rv);
+    if (tid < 32) rkl = tid < S ? klb[tid] : INT_BIG_A;
+    store_tile32<KLD>(Ks[0], tid, rk);
+    store_tile32<64>(Vs[0], tid, rv);
+    if (tid < 32) kls[0][tid] = rkl;
+    __syncthreads();
+
+    for (int jt = 0; jt < n_iter; ++jt) {
+        const int cur = jt & 1;
+        const bool more = jt + 1 < n_iter;
+        const int j0 = jt * 32;
+        if (more) {
+            load_tile32(kbase, ldk, j0 + 32, S, tid, rk);
+            load_tile32(vbase, ldv, j0 + 32, S, tid, rv);
+            if (tid < 32) rkl = (j0 + 32 + tid) < S ? klb[j0 + 32 + tid] : INT_BIG_A;
+        }
+        const bool beyond = j0 > wave_q_hi;                // every key of the tile is in every row's future
+        if (!(beyond && !wave_has_empty)) {
+            f32x16 st;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st[i] = 0.f;
+            if (!beyond) {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float4 kf = *reinterpret_cast<const float4*>(&Ks[cur][r * KLD + 8 * kk + 4 * h]);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[kk][0], st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[kk][1], st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kk][2], st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kk][3], st, 0, 0, 0);
+                }
+            }
+            // masking: st[reg] is the score of key j0 + rowmap(reg,h) for this lane's query
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int key = rowmap(reg, h);
+                const int j = j0 + key;
+                const bool allowed = (j <= iq) && (kls[cur][key] < my_ql) && valid_q;
+                st[reg] = allowed ? st[reg] : -INFINITY;
+                mloc = fmaxf(mloc, st[reg]);
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);
+            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+            float alpha = __expf(m_run - m_safe);           // m_run = -inf -> 0
+            float rowsum = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                float pe = __expf(st[reg] - m_safe);        // masked -> exp(-inf) = 0
+                if (my_empty) pe = (j0 + rowmap(reg, h) < S) ? invS : 0.f;
+                rowsum += pe;
+                st[reg] = pe;
+            }
+            rowsum += __shfl_xor(rowsum, 32, 64);
+            if (my_empty) alpha = 1.f;
+            l_run = l_run * alpha + rowsum;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+            if (rng.on) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) st[reg] *= rng.mult(drop_row + (uint64_t)(j0 + rowmap(reg, h)));
+            }
+            // O^T[d][query] += sum_key V[key][d] * P[query][key]
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int key = rowmap(reg, h);
+                const float a0 = Vs[cur][key * 64 + r];
+                const float a1 = Vs[cur][key * 64 + 32 + r];
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, st[reg], oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, st[reg], oacc[1], 0, 0, 0);
+            }
+        }
+        if (more) {
+            store_tile32<KLD>(Ks[cur ^ 1], tid, rk);
+            store_tile32<64>(Vs[cur ^ 1], tid, rv);
+            if (tid < 32) kls[cur ^ 1][tid] = rkl;
+        }
+        __syncthreads();
+    }
+
+    if (valid_q) {
+        const float linv = my_empty ? 1.f : (l_run > 0.f ? 1.f / l_run : 0.f);
+        float* orow = o + tok * (int64_t)nq * 64 + head * 64;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 t4;
+                t4.x = oacc[dh][4 * g4 + 0] * linv; t4.y = oacc[dh][4 * g4 + 1] * linv;
+                t4.z = oacc[dh][4 * g4 + 2] * linv; t4.w = oacc[dh][4 * g4 + 3] * linv;
+                *reinterpret_cast<float4*>(orow + 32 * dh + 8 * g4 + 4 * h) = t4;
+            }
+        }
+        if (h == 0) lse[((int64_t)b * nq + head) * S + iq] = my_empty ? 0.f : (m_run + __logf(l_run));
+    }
+}
+
+// delta[b,h,i] = sum_d dO * O
+__global__ void __launch_bounds__(AT_THREADS)
+attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o, int B, int S, int nq,
+                  float* __restrict__ delta) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * AT_THREADS + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * AT_THREADS) >> 6;
+    const int64_t total = (int64_t)B * S * nq;
+    for (int64_t i = wave; i < total; i += nwaves) {
+        const int64_t t = i / nq;
+        const int hd = (int)(i % nq);
+        const float pv = o[t * nq * 64 + hd * 64 + lane] * d_o[t * nq * 64 + hd * 64 + lane];
+        const float s = wave_sum(pv);
+        if (lane == 0) {
+            const int64_t b = t / S, ii = t % S;
+            delta[(b * nq + hd) * S + ii] = s;
+        }
+    }
+}
+
+// =============================================================================================
+// backward: dQ
+// =============================================================================================
+template <int G>
+__global__ void __launch_bounds__(AT_THREADS, 2)
+attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                   const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
+                   const float* __restrict__ lse, const float* __restrict__ delta,
+                   const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
+                   const int32_t* __restrict__ row_empty, int S, int nq, int nkv, float scale,
+                   float p_drop, uint64_t seed, float* __restrict__ dq, int lddq) {
+    constexpr int NSUB = 4 / G;
+    constexpr int R = NSUB * 32;
+    __shared__ __attribute__((aligned(16))) float Ks[2][32 * KLD];
+    __shared__ __attribute__((aligned(16))) float Vs[2][32 * KLD];
+    __shared__ int32_t kls[2][32];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int hg = w / NSUB, sub = w % NSUB;
+    const int b = blockIdx.z, kvh = blockIdx.y, q0 = blockIdx.x * R;
+    const int head = kvh * G + hg;
+    const int r = lane & 31, h = lane >> 5;
+    const int iq = q0 + sub * 32 + r;
+    const bool valid_q = iq < S;
+    const int iqc = valid_q ? iq : S - 1;
+    const int64_t tok = (int64_t)b * S + iqc;
+
+    float qf[8][4], dof[8][4];
+    {
+        const float* qrow = q + tok * ldq + head * 64;
+        const float* drow = d_o + tok * (int64_t)nq * 64 + head * 64;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const float4 t4 = *reinterpret_cast<const float4*>(qrow + 8 * kk + 4 * h);
+            qf[kk][0] = t4.x * scale; qf[kk][1] = t4.y * scale; qf[kk][2] = t4.z * scale; qf[kk][3] = t4.w * scale;
+            const float4 u4 = *reinterpret_cast<const float4*>(drow + 8 * kk + 4 * h);
+            dof[kk][0] = u4.x; dof[kk][1] = u4.y; dof[kk][2] = u4.z; dof[kk][3] = u4.w;
+        }
+    }
+    const int my_ql = ql ? ql[tok] : 1;
+    const bool my_empty = valid_q && row_empty[tok] != 0;
+    const float my_lse = lse[((int64_t)b * nq + head) * S + iqc];
+    const float my_delta = delta[((int64_t)b * nq + head) * S + iqc];
+    const int wave_q_hi = min(S - 1, q0 + sub * 32 + 31);
+    const bool wave_has_empty = __any(my_empty ? 1 : 0) != 0;
+    const bool block_has_empty = __syncthreads_or(my_empty ? 1 : 0) != 0;
+    const int n_all = (S + 31) / 32;
+    const int n_causal = (min(S, q0 + R) + 31) / 32;
+    const int n_iter = block_has_empty ? n_all : n_causal;
+    const float invS = 1.f / (float)S;
+    const DropoutRng rng(p_drop, seed);
+    const uint64_t drop_row = ((uint64_t)((int64_t)b * nq + head) * S + (uint64_t)iqc) * (uint64_t)S;
+
+    const float* kbase = k + (int64_t)b * S * ldk + kvh * 64;
+    const float* vbase = v + (int64_t)b * S * ldv + kvh * 64;
+    const int32_t* klb = kl + (int64_t)b * S;
+
+    f32x16 dqacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
+
+    float4 rk[2], rv[2];
+    int rkl = INT_BIG_A;
+    load_tile32(kbase, ldk, 0, S, tid, rk);
+    load_tile32(vbase, ldv, 0, S, tid, rv);
+    if (tid < 32) rkl = tid < S ? klb[tid] : INT_BIG_A;
+    store_tile32<KLD>(Ks[0], tid, rk);
+    store_tile32<KLD>(Vs[0], tid, rv);
+    if (tid < 32) kls[0][tid] = rkl;
+    __syncthreads();
+
+    for (int jt = 0; jt < n_iter; ++jt) {
+        const int cur = jt & 1;
+        const bool more = jt + 1 < n_iter;
+        const int j0 = jt * 32;
+        if (more) {
+            load_tile32(kbase, ldk, j0 + 32, S, tid, rk);
+            load_tile32(vbase, ldv, j0 + 32, S, tid, rv);
+            if (tid < 32) rkl = (j0 + 32 + tid) < S ? klb[j0 + 32 + tid] : INT_BIG_A;
+        }
+        const bool beyond = j0 > wave_q_hi;
+        if (!(beyond && !wave_has_empty)) {
+            f32x16 st, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+            if (!beyond) {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float4 kf = *reinterpret_cast<const float4*>(&Ks[cur][r * KLD + 8 * kk + 4 * h]);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[kk][0], st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[kk][1], st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kk][2], st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kk][3], st, 0, 0, 0);
+                }
+            }
+            // dP^T[key][query] = sum_d V[key][d] dO[query][d]
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float4 vf = *reinterpret_cast<const float4*>(&Vs[cur][r * KLD + 8 * kk + 4 * h]);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, dof[kk][0], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, dof[kk][1], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, dof[kk][2], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, dof[kk][3], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int key = rowmap(reg, h);
+                const int j = j0 + key;
+                const bool allowed = (j <= iq) && (kls[cur][key] < my_ql) && valid_q;
+                float pe = allowed ? __expf(st[reg] - my_lse) : 0.f;
+                if (my_empty) pe = (j < S) ? invS : 0.f;
+                const float mult = rng.on ? rng.mult(drop_row + (uint64_t)j) : 1.f;
+                st[reg] = pe * (mult * dp[reg] - my_delta);      // dS^T
+            }
+            // dQ^T[d][query] += sum_key K[key][d] dS^T[key][query]
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int key = rowmap(reg, h);
+                const float a0 = Ks[cur][key * KLD + r];
+                const float a1 = Ks[cur][key * KLD + 32 + r];
+                dqacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, st[reg], dqacc[0], 0, 0, 0);
+                dqacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, st[reg], dqacc[1], 0, 0, 0);
+            }
+        }
+        if (more) {
+            store_tile32<KLD>(Ks[cur ^ 1], tid, rk);
+            store_tile32<KLD>(Vs[cur ^ 1], tid, rv);
+            if (tid < 32) kls[cur ^ 1][tid] = rkl;
+        }
+        __syncthreads();
+    }
+
+    if (valid_q) {
+        float* drow = dq + tok * lddq + head * 64;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 t4;
+                t4.x = dqacc[dh][4 * g4 + 0] * scale; t4.y = dqacc[dh][4 * g4 + 1] * scale;
+                t4.z = dqacc[dh][4 * g4 + 2] * scale; t4.w = dqacc[dh][4 * g4 + 3] * scale;
+                *reinterpret_cast<float4*>(drow + 32 * dh + 8 * g4 + 4 * h) = t4;
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// backward: dK, dV
+// =============================================================================================
+template <int G>
+struct DkvSmem {
+    float Kt[(4 / G) * 32 * KLD];      // this workgroup's keys, fragment image (read every tile: keeps 64 VGPRs free)
+    float Vt[(4 / G) * 32 * KLD];
+    float Qs[G][32 * KLD];
+    float dOs[G][32 * KLD];
+    float lse_s[G][32];
+    float delta_s[G][32];
+    int32_t ql_s[32];
+    int32_t empty_s[32];
+};
+
+template <int G>
+__global__ void __launch_bounds__(AT_THREADS, 2)
+attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                    const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
+                    const float* __restrict__ lse, const float* __restrict__ delta,
+                    const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
+                    const int32_t* __restrict__ row_empty, const int32_t* __restrict__ tile_empty,
+                    int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+                    float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv) {
+    constexpr int NSUB = 4 / G;
+    constexpr int R = NSUB * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dkv_raw[];
+    DkvSmem<G>& sm = *reinterpret_cast<DkvSmem<G>*>(dkv_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int hg = w / NSUB, sub = w % NSUB;
+    const int b = blockIdx.z, kvh = blockIdx.y, k0 = blockIdx.x * R;
+    const int head = kvh * G + hg;
+    const int r = lane & 31, h = lane >> 5;
+    const int jk = k0 + sub * 32 + r;                 // this lane's key
+    const bool valid_k = jk < S;
+    const int jkc = valid_k ? jk : S - 1;
+    const int64_t ktok = (int64_t)b * S + jkc;
+
+    // stage this workgroup's K and V rows (R keys) once
+    for (int f = tid; f < R * 16; f += AT_THREADS) {
+        const int row = f >> 4, c4 = (f & 15) << 2;
+        const int j = k0 + row;
+        float4 kv4 = make_float4(0.f, 0.f, 0.f, 0.f), vv4 = kv4;
+        if (j < S) {
+            kv4 = *reinterpret_cast<const float4*>(k + ((int64_t)b * S + j) * ldk + kvh * 64 + c4);
+            vv4 = *reinterpret_cast<const float4*>(v + ((int64_t)b * S + j) * ldv + kvh * 64 + c4);
+        }
+        *reinterpret_cast<float4*>(&sm.Kt[row * KLD + c4]) = kv4;
+        *reinterpret_cast<float4*>(&sm.Vt[row * KLD + c4]) = vv4;
+    }
+    const float* Kw = &sm.Kt[(sub * 32 + r) * KLD + 4 * h];
+    const float* Vw = &sm.Vt[(sub * 32 + r) * KLD + 4 * h];
+    const int my_kl = valid_k ? kl[ktok] : INT_BIG_A;
+    const int wave_k_lo = k0 + sub * 32;
+    const float invS = 1.f / (float)S;
+    const DropoutRng rng(p_drop, seed);
+    const uint64_t drop_head = (uint64_t)((int64_t)b * nq + head) * S;
+
+    const int n_qt = (S + 31) / 32;
+    const int qt_begin = k0 / 32;                     // first query tile that can hold i >= k0
+    const int32_t* te = tile_empty + (int64_t)b * n_qt;
+
+    f32x16 dkacc[2], dvacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dkacc[0][i] = 0.f; dkacc[1][i] = 0.f; dvacc[0][i] = 0.f; dvacc[1][i] = 0.f; }
+
+    // staged registers: per head one Q tile and one dO tile (2 float4 each per thread)
+    float4 rq[G][2], rdo[G][2];
+    float rl = 0.f, rd = 0.f;
+    int rql = 1, rem = 0;
+
+    auto next_tile = [&](int qt) {
+        while (qt < n_qt && qt < qt_begin && te[qt] == 0) ++qt;
+        return qt;
+    };
+    auto load_q_tile = [&](int qt) {
+        const int i0 = qt * 32;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int hd = kvh * G + g;
+            load_tile32(q + (int64_t)b * S * ldq + hd * 64, ldq, i0, S, tid, rq[g]);
+            load_tile32(d_o + (int64_t)b * S * nq * 64 + hd * 64, (int64_t)nq * 64, i0, S, tid, rdo[g]);
+        }
+        // per-query scalars: threads 0..G*32-1 take (g, row)
+        if (tid < G * 32) {
+            const int g = tid >> 5, row = tid & 31;
+            const int i = i0 + row;
+            const int hd = kvh * G + g;
+            rl = i < S ? lse[((int64_t)b * nq + hd) * S + i] : 0.f;
+            rd = i < S ? delta[((int64_t)b * nq + hd) * S + i] : 0.f;
+            if (g == 0) {
+                rql = i < S ? (ql ? ql[(int64_t)b * S + i] : 1) : 0;
+                rem = i < S ? row_empty[(int64_t)b * S + i] : 0;
+            }
+        }
+    };
+    auto store_q_tile = [&]() {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            store_tile32<KLD>(sm.Qs[g], tid, rq[g]);
+            store_tile32<KLD>(sm.dOs[g], tid, rdo[g]);
+        }
+        if (tid < G * 32) {
+            const int g = tid >> 5, row = tid & 31;
+            sm.lse_s[g][row] = rl;
+            sm.delta_s[g][row] = rd;
+            if (g == 0) { sm.ql_s[row] = rql; sm.empty_s[row] = rem; }
+        }
+    };
+
+    // No register prefetch across tiles here: the four accumulator tiles already take 64 VGPRs and the
+    // second resident workgroup of the CU covers the load latency.
+    int qt = next_tile(0);
+    while (qt < n_qt) {
+        __syncthreads();                 // previous tile fully consumed (and K/V staging visible)
+        load_q_tile(qt);
+        store_q_tile();
+        __syncthreads();
+        const int i0 = qt * 32;
+        const bool tile_has_empty = te[qt] != 0;
+        const int qt_next = next_tile(qt + 1);
+
+        const bool before = (i0 + 31) < wave_k_lo;   // every query of the tile precedes every key of this wave
+        if (!(before && !tile_has_empty)) {
+            f32x16 st, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+            const float* Qh = sm.Qs[hg];
+            const float* dOh = sm.dOs[hg];
+            if (!before) {
+                // S[query][key] = sum_d Q[query][d] K[key][d]
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(&Qh[r * KLD + 8 * kk + 4 * h]);
+                    const float4 b4 = *reinterpret_cast<const float4*>(Kw + 8 * kk);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, st, 0, 0, 0);
+                }
+            }
+            // dP[query][key] = sum_d dO[query][d] V[key][d]
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&dOh[r * KLD + 8 * kk + 4 * h]);
+                const float4 b4 = *reinterpret_cast<const float4*>(Vw + 8 * kk);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, dp, 0, 0, 0);
+            }
+            // per element: query = i0 + rowmap(reg,h) lives in the register index
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int qb = 8 * g4 + 4 * h;
+                const float4 l4 = *reinterpret_cast<const float4*>(&sm.lse_s[hg][qb]);
+                const float4 d4 = *reinterpret_cast<const float4*>(&sm.delta_s[hg][qb]);
+                const int4 q4 = *reinterpret_cast<const int4*>(&sm.ql_s[qb]);
+                const int4 e4 = *reinterpret_cast<const int4*>(&sm.empty_s[qb]);
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
+                const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
+                const int qlv[4] = {q4.x, q4.y, q4.z, q4.w};
+                const int emv[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int reg = 4 * g4 + e;
+                    const int i = i0 + qb + e;
+                    const bool inq = i < S;
+                    const bool allowed = inq && valid_k && (jk <= i) && (my_kl < qlv[e]);
+                    float pe = allowed ? __expf(st[reg] * scale - lv[e]) : 0.f;
+                    if (emv[e] != 0) pe = (inq && valid_k) ? invS : 0.f;
+                    const float mult = rng.on ? rng.mult((drop_head + (uint64_t)(inq ? i : 0)) * (uint64_t)S + (uint64_t)jkc) : 1.f;
+                    st[reg] = pe * (mult * dp[reg] - dl[e]);     // dS[query][key]
+                    dp[reg] = pe * mult;                          // dropped P[query][key]
+                }
+            }
+            // dV^T[d][key] += sum_query dO[query][d] Pd[query][key] ; dK^T[d][key] += sum_query Q[query][d] dS[query][key]
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int qrow = rowmap(reg, h);
+                const float o0 = dOh[qrow * KLD + r];
+                const float o1 = dOh[qrow * KLD + 32 + r];
+                dvacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(o0, dp[reg], dvacc[0], 0, 0, 0);
+                dvacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o1, dp[reg], dvacc[1], 0, 0, 0);
+                const float q0v = Qh[qrow * KLD + r];
+                const float q1v = Qh[qrow * KLD + 32 + r];
+                dkacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0v, st[reg], dkacc[0], 0, 0, 0);
+                dkacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1v, st[reg], dkacc[1], 0, 0, 0);
+            }
+        }
+        qt = qt_next;
+    }
+
+    // ---- sum the G query heads of this kv head through LDS, then store ---------------------------
+    // LDS image [sub][key 32][128] floats (dK 64 | dV 64) reuses the tile region.
+    float* red = reinterpret_cast<float*>(dkv_raw);
+#pragma unroll
+    for (int gsrc = G - 1; gsrc >= 1; --gsrc) {
+        __syncthreads();
+        if (hg == gsrc) {
+            float* dst = red + (sub * 32 + r) * 132;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d = 32 * dh + 8 * g4 + 4 * h;
+                    *reinterpret_cast<float4*>(dst + d) = make_float4(dkacc[dh][4 * g4], dkacc[dh][4 * g4 + 1],
+                                                                      dkacc[dh][4 * g4 + 2], dkacc[dh][4 * g4 + 3]);
+                    *reinterpret_cast<float4*>(dst + 64 + d) = make_float4(dvacc[dh][4 * g4], dvacc[dh][4 * g4 + 1],
+                                                                           dvacc[dh][4 * g4 + 2], dvacc[dh][4 * g4 + 3]);
+                }
+        }
+        __syncthreads();
+        if (hg == 0) {
+            const float* src = red + (sub * 32 + r) * 132;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d = 32 * dh + 8 * g4 + 4 * h;
+                    const float4 a = *reinterpret_cast<const float4*>(src + d);
+                    const float4 c = *reinterpret_cast<const float4*>(src + 64 + d);
+                    dkacc[dh][4 * g4] += a.x; dkacc[dh][4 * g4 + 1] += a.y; dkacc[dh][4 * g4 + 2] += a.z; dkacc[dh][4 * g4 + 3] += a.w;
+                    dvacc[dh][4 * g4] += c.x; dvacc[dh][4 * g4 + 1] += c.y; dvacc[dh][4 * g4 + 2] += c.z; dvacc[dh][4 * g4 + 3] += c.w;
+                }
+        }
+    }
+    if (hg == 0 && valid_k) {
+        float* dkrow = dk + ktok * lddk + kvh * 64;
+        float* dvrow = dv + ktok * lddv + kvh * 64;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * dh + 8 * g4 + 4 * h;
+                *reinterpret_cast<float4*>(dkrow + d) = make_float4(dkacc[dh][4 * g4] * scale, dkacc[dh][4 * g4 + 1] * scale,
+                                                                    dkacc[dh][4 * g4 + 2] * scale, dkacc[dh][4 * g4 + 3] * scale);
+                *reinterpret_cast<float4*>(dvrow + d) = make_float4(dvacc[dh][4 * g4], dvacc[dh][4 * g4 + 1],
+                                                                    dvacc[dh][4 * g4 + 2], dvacc[dh][4 * g4 + 3]);
+            }
+    }
+}
+
+template <int G>
+static int launch_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl,
+                      const int32_t* ql, const int32_t* row_empty, int B, int S, int nq, int nkv, float scale,
+                      float p_drop, uint64_t seed, float* o, float* lse, hipStream_t st) {
+    constexpr int R = (4 / G) * 32;
+    dim3 grid((S + R - 1) / R, nkv, B);
+    hipLaunchKernelGGL(attn_fwd_kernel<G>, grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S,
+                       nq, nkv, scale, p_drop, seed, o, lse);
+    GAMER_CHECK_LAUNCH("gamer_attn_fwd");
+    return 0;
+}
+
+template <int G>
+static int launch_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* d_o,
+                      const float* lse, const float* delta, const int32_t* kl, const int32_t* ql,
+                      const int32_t* row_empty, const int32_t* tile_empty, int B, int S, int nq, int nkv, float scale,
+                      float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                      hipStream_t st) {
+    constexpr int R = (4 / G) * 32;
+    dim3 grid((S + R - 1) / R, nkv, B);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<G>, grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl,
+                       ql, row_empty, S, nq, nkv, scale, p_drop, seed, dq, lddq);
+    GAMER_CHECK_LAUNCH("gamer_attn_bwd/dq");
+    static bool attr_set = false;
+    auto kfn = attn_bwd_dkv_kernel<G>;
+    size_t shmem = sizeof(DkvSmem<G>);
+    const size_t red_bytes = (size_t)R * 132 * sizeof(float);
+    if (shmem < red_bytes) shmem = red_bytes;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)shmem);
+        if (e != hipSuccess) {
+            set_error("gamer_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(AT_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty,
+                       tile_empty, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv);
+    GAMER_CHECK_LAUNCH("gamer_attn_bwd/dkv");
+    return 0;
+}
+
+}  // namespace gamer
+
+using namespace gamer;
+
+static int check_attn_common(const char* name, const void* q, const void* k, const void* v, const void* kl,
+                             const void* row_empty, int ldq, int ldk, int ldv, int B, int S, int nq, int nkv,
+                             float p_drop) {
+    GAMER_CHECK_ARG(q && k && v && kl && row_empty, "%s: null pointer", name);
+    GAMER_CHECK_ARG(B > 0 && S > 0 && nq > 0 && nkv > 0 && nq % nkv == 0, "%s: bad shape B=%d S=%d nq=%d nkv=%d", name, B, S, nq, nkv);
+    const int G = nq / nkv;
+    GAMER_CHECK_ARG(G == 1 || G == 2, "%s: GQA group %d not built (1 or 2)", name, G);
+    GAMER_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldq >= nq * 64 && ldk >= nkv * 64 && ldv >= nkv * 64,
+                    "%s: bad leading dims ldq=%d ldk=%d ldv=%d", name, ldq, ldk, ldv);
+    GAMER_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v), "%s: q/k/v must be 16-byte aligned", name);
+    GAMER_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "%s: p_drop=%f", name, p_drop);
+    return 0;
+}
+
+extern "C" int gamer_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                              const int32_t* kl, const int32_t* ql, const int32_t* row_empty,
+                              const int32_t* tile_empty, int B, int S, int nq, int nkv, float scale, float p_drop,
+                              uint64_t seed, float* o, float* lse, void* stream) {
+    (void)tile_empty;
+    int rc = check_attn_common("gamer_attn_fwd", q, k, v, kl, row_empty, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
+    if (rc) return rc;
+    GAMER_CHECK_ARG(o && lse && aligned16(o), "gamer_attn_fwd: null/unaligned output");
+    hipStream_t st = (hipStream_t)stream;
+    switch (nq / nkv) {
+        case 1: return launch_fwd<1>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, st);
+        case 2: return launch_fwd<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, st);
+        default: return launch_fwd<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, st);
+    }
+}
+
+extern "C" int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                              const float* o, const float* d_o, const float* lse, const int32_t* kl,
+                              const int32_t* ql, const int32_t* row_empty, const int32_t* tile_empty, int B, int S,
+                              int nq, int nkv, float scale, float p_drop, uint64_t seed, float* delta, float* dq,
+                              int lddq, float* dk, int lddk, float* dv, int lddv, void* stream) {
+    int rc = check_attn_common("gamer_attn_bwd", q, k, v, kl, row_empty, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
+    if (rc) return rc;
+    GAMER_CHECK_ARG(o && d_o && lse && tile_empty && delta && dq && dk && dv, "gamer_attn_bwd: null pointer");
+    GAMER_CHECK_ARG(lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 && aligned16(dq) && aligned16(dk) && aligned16(dv) &&
+                    aligned16(d_o) && aligned16(o),
+                    "gamer_attn_bwd: gradient buffers must be 16-byte aligned with leading dims %% 4 == 0");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t waves = (int64_t)B * S * nq;
+    int blocks = (int)((waves + 3) / 4);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(AT_THREADS), 0, st, o, d_o, B, S, nq, delta);
+    GAMER_CHECK_LAUNCH("gamer_attn_bwd/delta");
+    switch (nq / nkv) {
+        case 1: return launch_bwd<1>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, st);
+        case 2: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, st);
+        default: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, st);
+    }
+}

@@ -1,0 +1,783 @@
+// HBM-bound pieces of the Qwen3Multi decoder layer: embedding, RMSNorm, behaviour tables,
+// q/k norm + RoPE, residual/dropout, SwiGLU, output gate, temperature cross-entropy.
+// Every kernel moves 16 B per lane and reduces with wave shuffles (wave = 64).
+#include "common.h"
+
+namespace gamer {
+
+constexpr int EW_THREADS = 256;
+constexpr int EW_WAVES = EW_THREADS / WAVE;
+
+static inline int grid_for_waves(int64_t n_waves, int max_blocks = 8192) {
+    int64_t blocks = (n_waves + EW_WAVES - 1) / EW_WAVES;
+    if (blocks < 1) blocks = 1;
+    if (blocks > max_blocks) blocks = max_blocks;
+    return (int)blocks;
+}
+static inline int grid_for_threads(int64_t n, int max_blocks = 16384) {
+    int64_t blocks = (n + EW_THREADS - 1) / EW_THREADS;
+    if (blocks < 1) blocks = 1;
+    if (blocks > max_blocks) blocks = max_blocks;
+    return (int)blocks;
+}
+
+// ---------------------------------------------------------------------------------------------
+// embedding
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EW_THREADS)
+embedding_fwd_kernel(const int64_t* __restrict__ ids, const float4* __restrict__ W, int V, int T, int H4,
+                     float4* __restrict__ x) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * EW_THREADS) >> 6;
+    for (int t = wave; t < T; t += nwaves) {
+        const int64_t id = ids[t];
+        const bool ok = id >= 0 && id < V;
+        for (int c = lane; c < H4; c += 64) {
+            float4 v = ok ? W[id * H4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[(int64_t)t * H4 + c] = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(EW_THREADS)
+embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx, int V, int T, int H,
+                     int pad_id, float* __restrict__ dW) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * EW_THREADS) >> 6;
+    for (int t = wave; t < T; t += nwaves) {
+        const int64_t id = ids[t];
+        if (id == pad_id || id < 0 || id >= V) continue;   // wave-uniform
+        for (int c = lane; c < H; c += 64) {
+            atomicAdd(&dW[id * H + c], dx[(int64_t)t * H + c]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm (hidden dim H <= 1024, H % 4 == 0); one wave per row, row cached in registers
+// ---------------------------------------------------------------------------------------------
+constexpr int RMS_MAXC = 4;   // float4 chunks per lane -> H <= 1024
+
+__global__ void __launch_bounds__(EW_THREADS)
+rmsnorm_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, int T, int H4, float inv_h,
+                   float eps, const int32_t* __restrict__ dst_rows, float* __restrict__ y, int ldy) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * EW_THREADS) >> 6;
+    float4 wv[RMS_MAXC];
+#pragma unroll
+    for (int i = 0; i < RMS_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        wv[i] = (c < H4) ? w[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int t = wave; t < T; t += nwaves) {
+        float4 v[RMS_MAXC];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < RMS_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = (c < H4) ? x[(int64_t)t * H4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        }
+        ss = wave_sum(ss);
+        const float rstd = rsqrtf(ss * inv_h + eps);
+        const int64_t r = dst_rows ? dst_rows[t] : t;
+        float4* yrow = reinterpret_cast<float4*>(y + r * ldy);
+#pragma unroll
+        for (int i = 0; i < RMS_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < H4) {
+                float4 o;
+                o.x = wv[i].x * (v[i].x * rstd);
+                o.y = wv[i].y * (v[i].y * rstd);
+                o.z = wv[i].z * (v[i].z * rstd);
+                o.w = wv[i].w * (v[i].w * rstd);
+                yrow[c] = o;
+            }
+        }
+    }
+}
+
+// dx (+)= rstd*(w*dy - xhat*mean(w*dy*xhat)); per-workgroup dw partial sums (deterministic).
+__global__ void __launch_bounds__(EW_THREADS)
+rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, const float* __restrict__ dy,
+                   int lddy, const int32_t* __restrict__ dy_rows, int T, int H4, float inv_h, float eps,
+                   int accumulate_dx, float4* __restrict__ dx, float* __restrict__ dw_partial) {
+    __shared__ float4 red[EW_WAVES][64 * RMS_MAXC];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * EW_THREADS) >> 6;
+    float4 wv[RMS_MAXC], dwacc[RMS_MAXC];
+#pragma unroll
+    for (int i = 0; i < RMS_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        wv[i] = (c < H4) ? w[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        dwacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int t = wave; t < T; t += nwaves) {
+        float4 v[RMS_MAXC], g[RMS_MAXC];
+        float ss = 0.f;
+        const int64_t r = dy_rows ? dy_rows[t] : t;
+        const float4* dyrow = reinterpret_cast<const float4*>(dy + r * lddy);
+#pragma unroll
+        for (int i = 0; i < RMS_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = (c < H4) ? x[(int64_t)t * H4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            g[i] = (c < H4) ? dyrow[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        }
+        ss = wave_sum(ss);
+        const float rstd = rsqrtf(ss * inv_h + eps);
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < RMS_MAXC; ++i) {
+            // xhat
+            v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;
+            dwacc[i].x += g[i].x * v[i].x; dwacc[i].y += g[i].y * v[i].y;
+            dwacc[i].z += g[i].z * v[i].z; dwacc[i].w += g[i].w * v[i].w;
+            g[i].x *= wv[i].x; g[i].y *= wv[i].y; g[i].z *= wv[i].z; g[i].w *= wv[i].w;
+            dot += g[i].x * v[i].x + g[i].y * v[i].y + g[i].z * v[i].z + g[i].w * v[i].w;
+        }
+        dot = wave_sum(dot) * inv_h;
+#pragma unroll
+        for (int i = 0; i < RMS_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < H4) {
+                float4 o;
+                o.x = rstd * (g[i].x - v[i].x * dot);
+                o.y = rstd * (g[i].y - v[i].y * dot);
+                o.z = rstd * (g[i].z - v[i].z * dot);
+                o.w = rstd * (g[i].w - v[i].w * dot);
+                if (accumulate_dx) {
+                    float4 p = dx[(int64_t)t * H4 + c];
+                    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+                }
+                dx[(int64_t)t * H4 + c] = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RMS_MAXC; ++i) red[wib][lane + 64 * i] = dwacc[i];
+    __syncthreads();
+    if (wib == 0) {
+#pragma unroll
+        for (int i = 0; i < RMS_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < H4) {
+                float4 s = red[0][c];
+                for (int ww = 1; ww < EW_WAVES; ++ww) {
+                    float4 o = red[ww][c];
+                    s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+                }
+                reinterpret_cast<float4*>(dw_partial + (int64_t)blockIdx.x * H4 * 4)[c] = s;
+            }
+        }
+    }
+}
+
+__global__ void colsum_reduce_kernel(const float* __restrict__ partial, int rows, int cols, int accumulate,
+                                     float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += partial[(int64_t)r * cols + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small-table rows (behaviour embeddings)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EW_THREADS)
+rowtable_fwd_kernel(const float4* __restrict__ table, const int32_t* __restrict__ idx,
+                    const int32_t* __restrict__ dst_rows, int T, int E4, float* __restrict__ y, int ldy, int col0) {
+    const int64_t total = (int64_t)T * E4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int t = (int)(i / E4);
+        const int c = (int)(i % E4);
+        const int64_t r = dst_rows ? dst_rows[t] : t;
+        reinterpret_cast<float4*>(y + r * ldy + col0)[c] = table[(int64_t)idx[t] * E4 + c];
+    }
+}
+
+constexpr int TBL_MAXROWS = 8;   // num_behavior + 1 <= 8
+
+// dtable[idx[t]][c] += dy[src(t)][col0+c]; per-thread predicated accumulators, LDS combine, one
+// atomic per workgroup per table element.
+__global__ void __launch_bounds__(EW_THREADS)
+rowtable_bwd_kernel(const float* __restrict__ dy, int lddy, int col0, const int32_t* __restrict__ idx,
+                    const int32_t* __restrict__ dy_rows, int T, int E4, int nrows, float* __restrict__ dtable) {
+    extern __shared__ __attribute__((aligned(16))) float lds_tbl[];   // [nrows][E4*4]
+    const int E = E4 * 4;
+    for (int i = threadIdx.x; i < nrows * E; i += EW_THREADS) lds_tbl[i] = 0.f;
+    __syncthreads();
+    const int c = threadIdx.x % E4;
+    const int rl = threadIdx.x / E4;
+    const int rows_per_block = EW_THREADS / E4;
+    float4 acc[TBL_MAXROWS];
+#pragma unroll
+    for (int a = 0; a < TBL_MAXROWS; ++a) acc[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rl < rows_per_block) {
+        for (int64_t t = (int64_t)blockIdx.x * rows_per_block + rl; t < T; t += (int64_t)gridDim.x * rows_per_block) {
+            const int64_t r = dy_rows ? dy_rows[t] : t;
+            const float4 g = reinterpret_cast<const float4*>(dy + r * lddy + col0)[c];
+            const int a_t = idx[t];
+#pragma unroll
+            for (int a = 0; a < TBL_MAXROWS; ++a) {
+                const float m = (a_t == a) ? 1.f : 0.f;
+                acc[a].x += m * g.x; acc[a].y += m * g.y; acc[a].z += m * g.z; acc[a].w += m * g.w;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < TBL_MAXROWS; ++a) {
+            if (a < nrows) {
+                atomicAdd(&lds_tbl[a * E + c * 4 + 0], acc[a].x);
+                atomicAdd(&lds_tbl[a * E + c * 4 + 1], acc[a].y);
+                atomicAdd(&lds_tbl[a * E + c * 4 + 2], acc[a].z);
+                atomicAdd(&lds_tbl[a * E + c * 4 + 3], acc[a].w);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nrows * E; i += EW_THREADS) atomicAdd(&dtable[i], lds_tbl[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// q/k per-head RMSNorm + RoPE (+ behaviour bias), head_dim = 64: one wave per (token, head)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EW_THREADS)
+qknorm_rope_fwd_kernel(float* __restrict__ qkv, int T, int S, int nq, int nkv,
+                       const float* __restrict__ wq, const float* __restrict__ wk, float eps,
+                       const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                       const float* __restrict__ bias_q, const float* __restrict__ bias_k,
+                       const float* __restrict__ bias_v, const int32_t* __restrict__ act_idx,
+                       float* __restrict__ q_rot, float* __restrict__ k_rot) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * EW_THREADS) >> 6;
+    const bool cross = bias_q != nullptr;
+    const int NH = nq + nkv + (cross ? nkv : 0);
+    const int ldqkv = (nq + 2 * nkv) * 64;
+    const float wql = wq[lane], wkl = wk[lane];
+    const int64_t total = (int64_t)T * NH;
+    for (int64_t i = wave; i < total; i += nwaves) {
+        const int t = (int)(i / NH);
+        const int hd = (int)(i % NH);
+        const int a = cross ? act_idx[t] : 0;
+        float* row = qkv + (int64_t)t * ldqkv;
+        if (hd < nq + nkv) {
+            const bool isq = hd < nq;
+            const int col = hd * 64 + lane;              // q heads then k heads are contiguous in qkv
+            float x = row[col];
+            if (cross) x += isq ? bias_q[a * nq * 64 + hd * 64 + lane] : bias_k[a * nkv * 64 + (hd - nq) * 64 + lane];
+            if (cross) row[col] = x;                     // keep the pre-norm (biased) value for the backward
+            const float ss = wave_sum(x * x);
+            const float rstd = rsqrtf(ss * (1.f / 64.f) + eps);
+            const float yv = (isq ? wql : wkl) * (x * rstd);
+            const float partner = __shfl_xor(yv, 32, 64);
+            const float rot = lane < 32 ? -partner : partner;
+            const int pos = t % S;
+            const float o = yv * cos_t[pos * 64 + lane] + rot * sin_t[pos * 64 + lane];
+            if (isq) q_rot[(int64_t)t * nq * 64 + hd * 64 + lane] = o;
+            else k_rot[(int64_t)t * nkv * 64 + (hd - nq) * 64 + lane] = o;
+        } else {
+            const int hv = hd - nq - nkv;
+            const int col = (nq + nkv + hv) * 64 + lane;
+            row[col] += bias_v[a * nkv * 64 + hv * 64 + lane];
+        }
+    }
+}
+
+// Each wave keeps one head for its whole life so that the norm-weight and bias gradients
+// accumulate in registers; one set of atomics per wave at the end.
+__global__ void __launch_bounds__(EW_THREADS)
+qknorm_rope_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dq_rot,
+                       const float* __restrict__ dk_rot, int T, int S, int nq, int nkv,
+                       const float* __restrict__ wq, const float* __restrict__ wk, float eps,
+                       const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                       int cross, const int32_t* __restrict__ act_idx, int nb1,
+                       float* __restrict__ dqkv, float* __restrict__ dwq, float* __restrict__ dwk,
+                       float* __restrict__ dbias_q, float* __restrict__ dbias_k, float* __restrict__ dbias_v,
+                       int waves_per_head) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
+    const int NH = nq + nkv + (cross ? nkv : 0);
+    if (wave >= (int64_t)NH * waves_per_head) return;
+    const int hd = (int)(wave % NH);
+    const int t0 = (int)(wave / NH);
+    const int ldqkv = (nq + 2 * nkv) * 64;
+    float dwacc = 0.f;
+    float dbacc[TBL_MAXROWS];
+#pragma unroll
+    for (int a = 0; a < TBL_MAXROWS; ++a) dbacc[a] = 0.f;
+    if (hd < nq + nkv) {
+        const bool isq = hd < nq;
+        const float wl = isq ? wq[lane] : wk[lane];
+        const int col = hd * 64 + lane;
+        for (int t = t0; t < T; t += waves_per_head) {
+            const float x = qkv[(int64_t)t * ldqkv + col];          // pre-norm value (bias included)
+            const float dout = isq ? dq_rot[(int64_t)t * nq * 64 + hd * 64 + lane]
+                                   : dk_rot[(int64_t)t * nkv * 64 + (hd - nq) * 64 + lane];
+            const int pos = t % S;
+            const float cs = cos_t[pos * 64 + lane], sn = sin_t[pos * 64 + lane];
+            const float dpart = __shfl_xor(dout, 32, 64);
+            // transpose of the rotation: dy_j = dout_j cos_j + (j<32 ? +1 : -1) * dout_partner * sin_j
+            const float dy = dout * cs + (lane < 32 ? dpart : -dpart) * sn;
+            const float ss = wave_sum(x * x);
+            const float rstd = rsqrtf(ss * (1.f / 64.f) + eps);
+            const float xh = x * rstd;
+            dwacc += dy * xh;
+            const float g = dy * wl;
+            const float dot = wave_sum(g * xh) * (1.f / 64.f);
+            const float dx = rstd * (g - xh * dot);
+            dqkv[(int64_t)t * ldqkv + col] = dx;
+            if (cross) {
+                const int a_t = act_idx[t];
+#pragma unroll
+                for (int a = 0; a < TBL_MAXROWS; ++a) dbacc[a] += (a_t == a) ? dx : 0.f;
+            }
+        }
+        atomicAdd(isq ? &dwq[lane] : &dwk[lane], dwacc);
+        if (cross) {
+#pragma unroll
+            for (int a = 0; a < TBL_MAXROWS; ++a) {
+                if (a < nb1) {
+                    if (isq) atomicAdd(&dbias_q[a * nq * 64 + hd * 64 + lane], dbacc[a]);
+                    else atomicAdd(&dbias_k[a * nkv * 64 + (hd - nq) * 64 + lane], dbacc[a]);
+                }
+            }
+        }
+    } else {
+        const int hv = hd - nq - nkv;
+        const int col = (nq + nkv + hv) * 64 + lane;
+        for (int t = t0; t < T; t += waves_per_head) {
+            const float dv = dqkv[(int64_t)t * ldqkv + col];
+            const int a_t = act_idx[t];
+#pragma unroll
+            for (int a = 0; a < TBL_MAXROWS; ++a) dbacc[a] += (a_t == a) ? dv : 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < TBL_MAXROWS; ++a) {
+            if (a < nb1) atomicAdd(&dbias_v[a * nkv * 64 + hv * 64 + lane], dbacc[a]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// residual + dropout, SwiGLU, SiLU gate
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EW_THREADS)
+residual_dropout_fwd_kernel(float4* __restrict__ x, const float4* __restrict__ delta,
+                            const int32_t* __restrict__ src_rows, int T, int H4, float p, uint64_t seed) {
+    const DropoutRng rng(p, seed);
+    const int64_t total = (int64_t)T * H4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int t = (int)(i / H4);
+        const int c = (int)(i % H4);
+        const int64_t r = src_rows ? src_rows[t] : t;
+        const float4 d = delta[r * H4 + c];
+        float4 v = x[i];
+        const uint64_t e = (uint64_t)i * 4;
+        v.x += rng.mult(e) * d.x; v.y += rng.mult(e + 1) * d.y;
+        v.z += rng.mult(e + 2) * d.z; v.w += rng.mult(e + 3) * d.w;
+        x[i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(EW_THREADS)
+residual_dropout_bwd_kernel(const float4* __restrict__ dx, const int32_t* __restrict__ src_rows, int T, int H4,
+                            float p, uint64_t seed, float4* __restrict__ ddelta) {
+    const DropoutRng rng(p, seed);
+    const int64_t total = (int64_t)T * H4;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int t = (int)(i / H4);
+        const int c = (int)(i % H4);
+        const int64_t r = src_rows ? src_rows[t] : t;
+        const float4 g = dx[i];
+        const uint64_t e = (uint64_t)i * 4;
+        float4 o;
+        o.x = rng.mult(e) * g.x; o.y = rng.mult(e + 1) * g.y;
+        o.z = rng.mult(e + 2) * g.z; o.w = rng.mult(e + 3) * g.w;
+        ddelta[r * H4 + c] = o;
+    }
+}
+
+__global__ void __launch_bounds__(EW_THREADS)
+swiglu_fwd_kernel(const float4* __restrict__ g, const float4* __restrict__ u, int64_t n4, float p, uint64_t seed,
+                  float4* __restrict__ hm) {
+    const DropoutRng rng(p, seed);
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
+        const float4 a = g[i], b = u[i];
+        const uint64_t e = (uint64_t)i * 4;
+        float4 o;
+        o.x = rng.mult(e) * (silu_f(a.x) * b.x);
+        o.y = rng.mult(e + 1) * (silu_f(a.y) * b.y);
+        o.z = rng.mult(e + 2) * (silu_f(a.z) * b.z);
+        o.w = rng.mult(e + 3) * (silu_f(a.w) * b.w);
+        hm[i] = o;
+    }
+}
+
+__global__ void __launch_bounds__(EW_THREADS)
+swiglu_bwd_kernel(float4* __restrict__ g, float4* __restrict__ u, const float4* __restrict__ dhm, int64_t n4,
+                  float p, uint64_t seed) {
+    const DropoutRng rng(p, seed);
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
+        const float4 a = g[i], b = u[i], d = dhm[i];
+        const uint64_t e = (uint64_t)i * 4;
+        const float d0 = rng.mult(e) * d.x, d1 = rng.mult(e + 1) * d.y, d2 = rng.mult(e + 2) * d.z,
+                    d3 = rng.mult(e + 3) * d.w;
+        float4 dg, du;
+        dg.x = d0 * b.x * dsilu_f(a.x); du.x = d0 * silu_f(a.x);
+        dg.y = d1 * b.y * dsilu_f(a.y); du.y = d1 * silu_f(a.y);
+        dg.z = d2 * b.z * dsilu_f(a.z); du.z = d2 * silu_f(a.z);
+        dg.w = d3 * b.w * dsilu_f(a.w); du.w = d3 * silu_f(a.w);
+        g[i] = dg;
+        u[i] = du;
+    }
+}
+
+__global__ void __launch_bounds__(EW_THREADS)
+silu_gate_fwd_kernel(const float4* __restrict__ a, const float4* __restrict__ gate, int64_t n4,
+                     float4* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
+        const float4 x = a[i], g = gate[i];
+        float4 o;
+        o.x = x.x * silu_f(g.x); o.y = x.y * silu_f(g.y); o.z = x.z * silu_f(g.z); o.w = x.w * silu_f(g.w);
+        out[i] = o;
+    }
+}
+
+__global__ void __launch_bounds__(EW_THREADS)
+silu_gate_bwd_kernel(const float4* __restrict__ a, const float4* __restrict__ gate, const float4* __restrict__ dout,
+                     int64_t n4, float4* __restrict__ da, float4* __restrict__ dgate) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
+        const float4 x = a[i], g = gate[i], d = dout[i];
+        float4 oa, og;
+        oa.x = d.x * silu_f(g.x); og.x = d.x * x.x * dsilu_f(g.x);
+        oa.y = d.y * silu_f(g.y); og.y = d.y * x.y * dsilu_f(g.y);
+        oa.z = d.z * silu_f(g.z); og.z = d.z * x.z * dsilu_f(g.z);
+        oa.w = d.w * silu_f(g.w); og.w = d.w * x.w * dsilu_f(g.w);
+        da[i] = oa;
+        dgate[i] = og;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// temperature + shifted cross entropy; one wave per row of logits
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EW_THREADS)
+ce_fwd_kernel(float* __restrict__ logits, int ldl, const int64_t* __restrict__ labels, int T, int S, int V,
+              float inv_temp, int ignore_index, float* __restrict__ lse_out, float* __restrict__ row_loss) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * EW_THREADS) >> 6;
+    for (int t = wave; t < T; t += nwaves) {
+        float* row = logits + (int64_t)t * ldl;
+        const int s = t % S;
+        const int64_t tgt = (s + 1 < S) ? labels[t + 1] : (int64_t)ignore_index;
+        const bool valid = tgt != ignore_index && tgt >= 0 && tgt < V;
+        float mx = -INFINITY;
+        float zt = 0.f;
+        for (int c = lane; c < V; c += 64) {
+            const float z = row[c] * inv_temp;
+            row[c] = z;
+            mx = fmaxf(mx, z);
+            if (valid && c == (int)tgt) zt = z;
+        }
+        mx = wave_max(mx);
+        zt = wave_sum(zt);
+        float se = 0.f;
+        for (int c = lane; c < V; c += 64) se += expf(row[c] - mx);
+        se = wave_sum(se);
+        const float lse = mx + logf(se);
+        if (lane == 0) {
+            lse_out[t] = lse;
+            row_loss[t] = valid ? (lse - zt) : 0.f;
+        }
+    }
+}
+
+// deterministic single-workgroup reduction: out[0] = sum(row_loss), out[1] = #valid targets
+__global__ void __launch_bounds__(1024)
+ce_reduce_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__ labels, int T, int S, int V,
+                 int ignore_index, float* __restrict__ loss_sum, float* __restrict__ count) {
+    __shared__ float sh_l[1024];
+    __shared__ float sh_c[1024];
+    float l = 0.f, c = 0.f;
+    for (int t = threadIdx.x; t < T; t += 1024) {
+        l += row_loss[t];
+        const int s = t % S;
+        if (s + 1 < S) {
+            const int64_t tgt = labels[t + 1];
+            if (tgt != ignore_index && tgt >= 0 && tgt < V) c += 1.f;
+        }
+    }
+    sh_l[threadIdx.x] = l;
+    sh_c[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            sh_l[threadIdx.x] += sh_l[threadIdx.x + off];
+            sh_c[threadIdx.x] += sh_c[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        loss_sum[0] = sh_l[0];
+        count[0] = sh_c[0];
+    }
+}
+
+__global__ void __launch_bounds__(EW_THREADS)
+ce_bwd_kernel(float* __restrict__ logits, int ldl, const int64_t* __restrict__ labels, int T, int S, int V,
+              int ignore_index, const float* __restrict__ lse, const float* __restrict__ count_dev,
+              float denom_host, float dloss_over_temp) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * EW_THREADS) >> 6;
+    const float denom = count_dev ? count_dev[0] : denom_host;
+    const float gs = dloss_over_temp / denom;
+    for (int t = wave; t < T; t += nwaves) {
+        float* row = logits + (int64_t)t * ldl;
+        const int s = t % S;
+        const int64_t tgt = (s + 1 < S) ? labels[t + 1] : (int64_t)ignore_index;
+        const bool valid = tgt != ignore_index && tgt >= 0 && tgt < V;
+        const float l = lse[t];
+        for (int c = lane; c < V; c += 64) {
+            float g = 0.f;
+            if (valid) {
+                g = expf(row[c] - l);
+                if (c == (int)tgt) g -= 1.f;
+                g *= gs;
+            }
+            row[c] = g;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(EW_THREADS)
+fill_kernel(float* __restrict__ p, int64_t n, float value) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS)
+        p[i] = value;
+}
+
+}  // namespace gamer
+
+using namespace gamer;
+
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int gamer_embedding_fwd(const int64_t* ids, const float* W, int V, int T, int H, float* x, void* stream) {
+    GAMER_CHECK_ARG(ids && W && x, "gamer_embedding_fwd: null pointer");
+    GAMER_CHECK_ARG(T > 0 && H > 0 && H % 4 == 0 && V > 0, "gamer_embedding_fwd: bad shape T=%d H=%d V=%d", T, H, V);
+    GAMER_CHECK_ARG(aligned16(W) && aligned16(x), "gamer_embedding_fwd: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream),
+                       ids, (const float4*)W, V, T, H / 4, (float4*)x);
+    GAMER_CHECK_LAUNCH("gamer_embedding_fwd");
+    return 0;
+}
+
+extern "C" int gamer_embedding_bwd(const int64_t* ids, const float* dx, int V, int T, int H, int pad_id, float* dW,
+                                   void* stream) {
+    GAMER_CHECK_ARG(ids && dx && dW, "gamer_embedding_bwd: null pointer");
+    GAMER_CHECK_ARG(T > 0 && H > 0 && V > 0, "gamer_embedding_bwd: bad shape T=%d H=%d V=%d", T, H, V);
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream),
+                       ids, dx, V, T, H, pad_id, dW);
+    GAMER_CHECK_LAUNCH("gamer_embedding_bwd");
+    return 0;
+}
+
+extern "C" int gamer_rmsnorm_fwd(const float* x, const float* w, int T, int H, float eps, const int32_t* dst_rows,
+                                 float* y, int ldy, void* stream) {
+    GAMER_CHECK_ARG(x && w && y, "gamer_rmsnorm_fwd: null pointer");
+    GAMER_CHECK_ARG(T > 0 && H > 0 && H % 4 == 0 && H <= 256 * RMS_MAXC && ldy >= H && ldy % 4 == 0,
+                    "gamer_rmsnorm_fwd: bad shape T=%d H=%d ldy=%d (H%%4==0, H<=1024, ldy%%4==0)", T, H, ldy);
+    GAMER_CHECK_ARG(aligned16(x) && aligned16(w) && aligned16(y), "gamer_rmsnorm_fwd: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream),
+                       (const float4*)x, (const float4*)w, T, H / 4, 1.f / (float)H, eps, dst_rows, y, ldy);
+    GAMER_CHECK_LAUNCH("gamer_rmsnorm_fwd");
+    return 0;
+}
+
+extern "C" int gamer_rmsnorm_bwd(const float* x, const float* w, const float* dy, int lddy, const int32_t* dy_rows,
+                                 int T, int H, float eps, int accumulate_dx, float* dx, float* dw_partial,
+                                 int n_partial, void* stream) {
+    GAMER_CHECK_ARG(x && w && dy && dx && dw_partial, "gamer_rmsnorm_bwd: null pointer");
+    GAMER_CHECK_ARG(T > 0 && H > 0 && H % 4 == 0 && H <= 256 * RMS_MAXC && lddy >= H && lddy % 4 == 0 && n_partial > 0,
+                    "gamer_rmsnorm_bwd: bad shape T=%d H=%d lddy=%d n_partial=%d", T, H, lddy, n_partial);
+    GAMER_CHECK_ARG(aligned16(x) && aligned16(w) && aligned16(dy) && aligned16(dx) && aligned16(dw_partial),
+                    "gamer_rmsnorm_bwd: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(n_partial), dim3(EW_THREADS), 0, ST(stream),
+                       (const float4*)x, (const float4*)w, dy, lddy, dy_rows, T, H / 4, 1.f / (float)H, eps,
+                       accumulate_dx, (float4*)dx, dw_partial);
+    GAMER_CHECK_LAUNCH("gamer_rmsnorm_bwd");
+    return 0;
+}
+
+extern "C" int gamer_colsum_reduce(const float* partial, int rows, int cols, int accumulate, float* out, void* stream) {
+    GAMER_CHECK_ARG(partial && out && rows > 0 && cols > 0, "gamer_colsum_reduce: bad arguments");
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, ST(stream), partial, rows, cols,
+                       accumulate, out);
+    GAMER_CHECK_LAUNCH("gamer_colsum_reduce");
+    return 0;
+}
+
+extern "C" int gamer_rowtable_fwd(const float* table, const int32_t* idx, const int32_t* dst_rows, int T, int E,
+                                  float* y, int ldy, int col0, void* stream) {
+    GAMER_CHECK_ARG(table && idx && y, "gamer_rowtable_fwd: null pointer");
+    GAMER_CHECK_ARG(T > 0 && E > 0 && E % 4 == 0 && ldy % 4 == 0 && col0 % 4 == 0 && col0 + E <= ldy,
+                    "gamer_rowtable_fwd: bad shape T=%d E=%d ldy=%d col0=%d", T, E, ldy, col0);
+    hipLaunchKernelGGL(rowtable_fwd_kernel, dim3(grid_for_threads((int64_t)T * E / 4)), dim3(EW_THREADS), 0, ST(stream),
+                       (const float4*)table, idx, dst_rows, T, E / 4, y, ldy, col0);
+    GAMER_CHECK_LAUNCH("gamer_rowtable_fwd");
+    return 0;
+}
+
+extern "C" int gamer_rowtable_bwd(const float* dy, int lddy, int col0, const int32_t* idx, const int32_t* dy_rows,
+                                  int T, int E, int n_rows_table, float* dtable, void* stream) {
+    GAMER_CHECK_ARG(dy && idx && dtable, "gamer_rowtable_bwd: null pointer");
+    GAMER_CHECK_ARG(T > 0 && E > 0 && E % 4 == 0 && E / 4 <= EW_THREADS && lddy % 4 == 0 && col0 % 4 == 0 &&
+                    n_rows_table > 0 && n_rows_table <= TBL_MAXROWS,
+                    "gamer_rowtable_bwd: bad shape T=%d E=%d lddy=%d col0=%d rows=%d (rows<=8)", T, E, lddy, col0, n_rows_table);
+    const int rows_per_block = EW_THREADS / (E / 4);
+    int blocks = (T + rows_per_block - 1) / rows_per_block;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(rowtable_bwd_kernel, dim3(blocks), dim3(EW_THREADS), (size_t)n_rows_table * E * sizeof(float),
+                       ST(stream), dy, lddy, col0, idx, dy_rows, T, E / 4, n_rows_table, dtable);
+    GAMER_CHECK_LAUNCH("gamer_rowtable_bwd");
+    return 0;
+}
+
+extern "C" int gamer_qknorm_rope_fwd(float* qkv, int T, int S, int nq, int nkv, const float* wq, const float* wk,
+                                     float eps, const float* cos_t, const float* sin_t, const float* bias_q,
+                                     const float* bias_k, const float* bias_v, const int32_t* act_idx, float* q_rot,
+                                     float* k_rot, void* stream) {
+    GAMER_CHECK_ARG(qkv && wq && wk && cos_t && sin_t && q_rot && k_rot, "gamer_qknorm_rope_fwd: null pointer");
+    GAMER_CHECK_ARG(T > 0 && S > 0 && nq > 0 && nkv > 0 && T % S == 0, "gamer_qknorm_rope_fwd: bad shape T=%d S=%d nq=%d nkv=%d", T, S, nq, nkv);
+    const bool cross = bias_q != nullptr;
+    GAMER_CHECK_ARG(!cross || (bias_k && bias_v && act_idx), "gamer_qknorm_rope_fwd: cross needs bias_k, bias_v, act_idx");
+    const int NH = nq + nkv + (cross ? nkv : 0);
+    hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3(grid_for_waves((int64_t)T * NH)), dim3(EW_THREADS), 0, ST(stream),
+                       qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot, k_rot);
+    GAMER_CHECK_LAUNCH("gamer_qknorm_rope_fwd");
+    return 0;
+}
+
+extern "C" int gamer_qknorm_rope_bwd(const float* qkv, const float* dq_rot, const float* dk_rot, int T, int S, int nq,
+                                     int nkv, const float* wq, const float* wk, float eps, const float* cos_t,
+                                     const float* sin_t, const float* bias_q, const float* bias_k,
+                                     const int32_t* act_idx, int nb1, float* dqkv, float* dwq, float* dwk,
+                                     float* dbias_q, float* dbias_k, float* dbias_v, void* stream) {
+    GAMER_CHECK_ARG(qkv && dq_rot && dk_rot && wq && wk && cos_t && sin_t && dqkv && dwq && dwk,
+                    "gamer_qknorm_rope_bwd: null pointer");
+    GAMER_CHECK_ARG(T > 0 && S > 0 && nq > 0 && nkv > 0 && T % S == 0, "gamer_qknorm_rope_bwd: bad shape");
+    const int cross = bias_q != nullptr ? 1 : 0;
+    (void)bias_k;
+    GAMER_CHECK_ARG(!cross || (act_idx && dbias_q && dbias_k && dbias_v && nb1 > 0 && nb1 <= TBL_MAXROWS),
+                    "gamer_qknorm_rope_bwd: cross needs act_idx, dbias_*, 0<nb1<=8 (nb1=%d)", nb1);
+    const int NH = nq + nkv + (cross ? nkv : 0);
+    int waves_per_head = 8192 / NH;
+    if (waves_per_head > T) waves_per_head = T;
+    if (waves_per_head < 1) waves_per_head = 1;
+    const int64_t total_waves = (int64_t)NH * waves_per_head;
+    const int blocks = (int)((total_waves + EW_WAVES - 1) / EW_WAVES);
+    hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3(blocks), dim3(EW_THREADS), 0, ST(stream), qkv, dq_rot, dk_rot, T, S,
+                       nq, nkv, wq, wk, eps, cos_t, sin_t, cross, act_idx, nb1, dqkv, dwq, dwk, dbias_q, dbias_k,
+                       dbias_v, waves_per_head);
+    GAMER_CHECK_LAUNCH("gamer_qknorm_rope_bwd");
+    return 0;
+}
+
+extern "C" int gamer_residual_dropout_fwd(float* x, const float* delta, const int32_t* src_rows, int T, int H,
+                                          float p_drop, uint64_t seed, void* stream) {
+    GAMER_CHECK_ARG(x && delta && T > 0 && H > 0 && H % 4 == 0 && p_drop >= 0.f && p_drop < 1.f,
+                    "gamer_residual_dropout_fwd: bad arguments T=%d H=%d p=%f", T, H, p_drop);
+    hipLaunchKernelGGL(residual_dropout_fwd_kernel, dim3(grid_for_threads((int64_t)T * H / 4)), dim3(EW_THREADS), 0,
+                       ST(stream), (float4*)x, (const float4*)delta, src_rows, T, H / 4, p_drop, seed);
+    GAMER_CHECK_LAUNCH("gamer_residual_dropout_fwd");
+    return 0;
+}
+
+extern "C" int gamer_residual_dropout_bwd(const float* dx, const int32_t* src_rows, int T, int H, float p_drop,
+                                          uint64_t seed, float* ddelta, void* stream) {
+    GAMER_CHECK_ARG(dx && ddelta && T > 0 && H > 0 && H % 4 == 0 && p_drop >= 0.f && p_drop < 1.f,
+                    "gamer_residual_dropout_bwd: bad arguments T=%d H=%d p=%f", T, H, p_drop);
+    hipLaunchKernelGGL(residual_dropout_bwd_kernel, dim3(grid_for_threads((int64_t)T * H / 4)), dim3(EW_THREADS), 0,
+                       ST(stream), (const float4*)dx, src_rows, T, H / 4, p_drop, seed, (float4*)ddelta);
+    GAMER_CHECK_LAUNCH("gamer_residual_dropout_bwd");
+    return 0;
+}
+
+extern "C" int gamer_swiglu_fwd(const float* g, const float* u, int64_t n, float p_drop, uint64_t seed, float* hm,
+                                void* stream) {
+    GAMER_CHECK_ARG(g && u && hm && n > 0 && n % 4 == 0 && p_drop >= 0.f && p_drop < 1.f, "gamer_swiglu_fwd: bad arguments");
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream),
+                       (const float4*)g, (const float4*)u, n / 4, p_drop, seed, (float4*)hm);
+    GAMER_CHECK_LAUNCH("gamer_swiglu_fwd");
+    return 0;
+}
+
+extern "C" int gamer_swiglu_bwd(float* g, float* u, const float* dhm, int64_t n, float p_drop, uint64_t seed,
+                                void* stream) {
+    GAMER_CHECK_ARG(g && u && dhm && n > 0 && n % 4 == 0 && p_drop >= 0.f && p_drop < 1.f, "gamer_swiglu_bwd: bad arguments");
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream), (float4*)g,
+                       (float4*)u, (const float4*)dhm, n / 4, p_drop, seed);
+    GAMER_CHECK_LAUNCH("gamer_swiglu_bwd");
+    return 0;
+}
+
+extern "C" int gamer_silu_gate_fwd(const float* a, const float* gate, int64_t n, float* out, void* stream) {
+    GAMER_CHECK_ARG(a && gate && out && n > 0 && n % 4 == 0, "gamer_silu_gate_fwd: bad arguments");
+    hipLaunchKernelGGL(silu_gate_fwd_kernel, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream),
+                       (const float4*)a, (const float4*)gate, n / 4, (float4*)out);
+    GAMER_CHECK_LAUNCH("gamer_silu_gate_fwd");
+    return 0;
+}
+
+extern "C" int gamer_silu_gate_bwd(const float* a, const float* gate, const float* dout, int64_t n, float* da,
+                                   float* dgate, void* stream) {
+    GAMER_CHECK_ARG(a && gate && dout && da && dgate && n > 0 && n % 4 == 0, "gamer_silu_gate_bwd: bad arguments");
+    hipLaunchKernelGGL(silu_gate_bwd_kernel, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream),
+                       (const float4*)a, (const float4*)gate, (const float4*)dout, n / 4, (float4*)da, (float4*)dgate);
+    GAMER_CHECK_LAUNCH("gamer_silu_gate_bwd");
+    return 0;
+}
+
+extern "C" int gamer_ce_fwd(float* logits, int ldl, const int64_t* labels, int B, int S, int V, float temperature,
+                            int ignore_index, float* lse_out, float* row_loss, float* loss_sum, float* count,
+                            void* stream) {
+    GAMER_CHECK_ARG(logits && labels && lse_out && row_loss && loss_sum && count, "gamer_ce_fwd: null pointer");
+    GAMER_CHECK_ARG(B > 0 && S > 0 && V > 0 && ldl >= V && temperature > 0.f, "gamer_ce_fwd: bad shape B=%d S=%d V=%d ldl=%d", B, S, V, ldl);
+    const int T = B * S;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), logits, ldl, labels, T,
+                       S, V, 1.f / temperature, ignore_index, lse_out, row_loss);
+    GAMER_CHECK_LAUNCH("gamer_ce_fwd");
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, ST(stream), row_loss, labels, T, S, V, ignore_index,
+                       loss_sum, count);
+    GAMER_CHECK_LAUNCH("gamer_ce_fwd/reduce");
+    return 0;
+}
+
+extern "C" int gamer_ce_bwd(float* logits, int ldl, const int64_t* labels, int B, int S, int V, float temperature,
+                            int ignore_index, const float* lse, const float* count_dev, float denom_host, float dloss,
+                            void* stream) {
+    GAMER_CHECK_ARG(logits && labels && lse, "gamer_ce_bwd: null pointer");
+    GAMER_CHECK_ARG(B > 0 && S > 0 && V > 0 && ldl >= V && temperature > 0.f, "gamer_ce_bwd: bad shape");
+    GAMER_CHECK_ARG(count_dev || denom_host > 0.f, "gamer_ce_bwd: need count_dev or a positive denom_host");
+    const int T = B * S;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), logits, ldl, labels, T,
+                       S, V, ignore_index, lse, count_dev, denom_host, dloss / temperature);
+    GAMER_CHECK_LAUNCH("gamer_ce_bwd");
+    return 0;
+}
+
+extern "C" int gamer_fill_f32(float* p, int64_t n, float value, void* stream) {
+    GAMER_CHECK_ARG(p && n >= 0, "gamer_fill_f32: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for_threads(n)), dim3(EW_THREADS), 0, ST(stream), p, n, value);
+    GAMER_CHECK_LAUNCH("gamer_fill_f32");
+    return 0;
+}

@@ -1,0 +1,340 @@
+// fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD).
+//
+//   C[m][n] (=|+=) alpha * sum_k A(m,k) * B(n,k)
+//
+// Workgroup tile 128 x 128 x 32, 4 waves as 2 x 2, each wave a 64 x 64 patch = 2 x 2 MFMA tiles of
+// 32 x 32 (64 accumulator registers).  Operand tiles go global -> registers -> LDS (double
+// buffered, one barrier per K-step) with 16-byte accesses on both sides:
+//   * K-contiguous operand ("KC", e.g. activations X[t][k] or weights W[n][k]):
+//       LDS image [row][32+4]; a lane reads one float4 = 4 consecutive k of its row.  The MFMA's two
+//       k slots are the two lane halves, so lane half h takes k = 8*kk + 4*h + s for step s: a
+//       permutation of k that is applied identically to both operands.
+//   * row-contiguous operand ("RC", e.g. W[k][n] in dgrad, dY[t][m] / X[t][n] in wgrad):
+//       LDS image [k][128]; a lane reads 4 scalars (same k permutation), conflict-free because the
+//       32 lanes of a half read 32 consecutive floats.
+// Grouped forms cover the position-routed experts without host synchronisation: segment offsets are
+// read from device memory and surplus workgroups exit.
+#include "common.h"
+
+namespace gamer {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int GEMM_THREADS = 256;
+constexpr int KC_LD = BK + 4;                  // floats per row of a KC tile image
+constexpr int TILE_FLOATS = BM * KC_LD;        // 4608 >= BK*BM (RC image)
+constexpr int GEMM_LDS_BYTES = 4 * TILE_FLOATS * (int)sizeof(float);   // 2 operands x 2 buffers
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmParams {
+    const float* A; int64_t a_rs, a_ks;
+    const float* B; int64_t b_rs, b_ks;
+    float* C; int64_t ldc;
+    int M, N, K;
+    float alpha;
+    int accumulate;
+    int groups;
+    const int32_t* group_offsets;
+    int64_t strideB, strideC;
+    int kchunk;
+    int m_tiles, n_tiles;      // tile counts of the C matrix (mode 1) / upper bound of m tiles (mode 0)
+};
+
+// blockIdx -> logical tile id such that consecutive logical ids run on one XCD (ids are dealt
+// round-robin over the 8 XCDs); bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = id & 7, idx = id >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// ---- global -> registers ---------------------------------------------------------------------
+// KC tile: 128 rows x 32 k; float4 f = tid + 256*j covers row f>>3, k-quad f&7.
+__device__ __forceinline__ void load_kc(const float* __restrict__ p, int64_t rs, int row0, int row_end, int k0,
+                                        int k_end, int tid, float4 (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = tid + GEMM_THREADS * j;
+        const int row = row0 + (f >> 3);
+        const int k = k0 + ((f & 7) << 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < row_end && k < k_end) {
+            v = *reinterpret_cast<const float4*>(p + (int64_t)row * rs + k);
+            if (k + 3 >= k_end) {      // ragged K tail (leading dim is a multiple of 4, so the load is in bounds)
+                if (k + 1 >= k_end) v.y = 0.f;
+                if (k + 2 >= k_end) v.z = 0.f;
+                v.w = 0.f;
+            }
+        }
+        r[j] = v;
+    }
+}
+// RC tile: 32 k x 128 rows; float4 f covers k f>>5, row-quad f&31.
+__device__ __forceinline__ void load_rc(const float* __restrict__ p, int64_t ks, int row0, int row_end, int k0,
+                                        int k_end, int tid, float4 (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = tid + GEMM_THREADS * j;
+        const int k = k0 + (f >> 5);
+        const int row = row0 + ((f & 31) << 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < k_end && row < row_end) {
+            v = *reinterpret_cast<const float4*>(p + (int64_t)k * ks + row);
+            if (row + 3 >= row_end) {
+                if (row + 1 >= row_end) v.y = 0.f;
+                if (row + 2 >= row_end) v.z = 0.f;
+                v.w = 0.f;
+            }
+        }
+        r[j] = v;
+    }
+}
+__device__ __forceinline__ void store_kc(float* __restrict__ lds, int tid, const float4 (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = tid + GEMM_THREADS * j;
+        *reinterpret_cast<float4*>(lds + (f >> 3) * KC_LD + ((f & 7) << 2)) = r[j];
+    }
+}
+__device__ __forceinline__ void store_rc(float* __restrict__ lds, int tid, const float4 (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = tid + GEMM_THREADS * j;
+        *reinterpret_cast<float4*>(lds + (f >> 5) * BM + ((f & 31) << 2)) = r[j];
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row, int kk, int h, float (&f)[4]) {
+    if (KC) {
+        const float4 v = *reinterpret_cast<const float4*>(lds + row * KC_LD + 8 * kk + 4 * h);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f[s] = lds[(8 * kk + 4 * h + s) * BM + row];
+    }
+}
+
+template <bool A_KC, bool B_KC, int MODE>
+__global__ void __launch_bounds__(GEMM_THREADS, 2)
+gemm_f32_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // buffer b: A image at smem + 2*b*TILE_FLOATS, B image right behind it
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+
+    // ---- which tile / which group -------------------------------------------------------------
+    int row0, row_end;          // A/C row range of this tile (mode 0) or C row tile (mode 1)
+    int col0;                   // C column tile start
+    int kbeg, kend;             // contraction range
+    const float* Bp = p.B;
+    float* Cp = p.C;
+    if (MODE == 0) {
+        const int mt = L / p.n_tiles;
+        col0 = (L % p.n_tiles) * BN;
+        int g = 0, seg_beg = 0, seg_end = p.M, tiles_before = 0;
+        bool found = false;
+        if (p.group_offsets) {
+            int prev = p.group_offsets[0];
+            for (int gi = 0; gi < p.groups; ++gi) {
+                const int nxt = p.group_offsets[gi + 1];
+                const int tiles = (nxt - prev + BM - 1) / BM;
+                if (!found && mt < tiles_before + tiles) {
+                    g = gi; seg_beg = prev; seg_end = nxt; found = true;
+                }
+                if (!found) tiles_before += tiles;
+                prev = nxt;
+            }
+        } else {
+            found = mt < (p.M + BM - 1) / BM;
+        }
+        if (!found) return;
+        row0 = seg_beg + (mt - tiles_before) * BM;
+        row_end = seg_end;
+        kbeg = 0;
+        kend = p.K;
+        Bp += (int64_t)g * p.strideB;
+    } else {
+        const int tiles_mn = p.m_tiles * p.n_tiles;
+        const int chunk = L / tiles_mn;
+        const int tile = L % tiles_mn;
+        row0 = (tile / p.n_tiles) * BM;
+        row_end = p.M;
+        col0 = (tile % p.n_tiles) * BN;
+        int g = 0, seg_beg = 0, seg_end = p.K, chunks_before = 0;
+        bool found = false;
+        if (p.group_offsets) {
+            int prev = p.group_offsets[0];
+            for (int gi = 0; gi < p.groups; ++gi) {
+                const int nxt = p.group_offsets[gi + 1];
+                const int chunks = (nxt - prev + p.kchunk - 1) / p.kchunk;
+                if (!found && chunk < chunks_before + chunks) {
+                    g = gi; seg_beg = prev; seg_end = nxt; found = true;
+                }
+                if (!found) chunks_before += chunks;
+                prev = nxt;
+            }
+        } else {
+            found = chunk < (p.K + p.kchunk - 1) / p.kchunk;
+        }
+        if (!found) return;
+        kbeg = seg_beg + (chunk - chunks_before) * p.kchunk;
+        kend = min(seg_end, kbeg + p.kchunk);
+        Cp += (int64_t)g * p.strideC;
+    }
+    const int col_end = p.N;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+    float4 ra[4], rb[4];
+    if (nkt > 0) {
+        if (A_KC) load_kc(p.A, p.a_rs, row0, row_end, kbeg, kend, tid, ra);
+        else load_rc(p.A, p.a_ks, row0, row_end, kbeg, kend, tid, ra);
+        if (B_KC) load_kc(Bp, p.b_rs, col0, col_end, kbeg, kend, tid, rb);
+        else load_rc(Bp, p.b_ks, col0, col_end, kbeg, kend, tid, rb);
+        if (A_KC) store_kc(smem, tid, ra); else store_rc(smem, tid, ra);
+        if (B_KC) store_kc(smem + TILE_FLOATS, tid, rb); else store_rc(smem + TILE_FLOATS, tid, rb);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) {
+            const int k0 = kbeg + (kt + 1) * BK;
+            if (A_KC) load_kc(p.A, p.a_rs, row0, row_end, k0, kend, tid, ra);
+            else load_rc(p.A, p.a_ks, row0, row_end, k0, kend, tid, ra);
+            if (B_KC) load_kc(Bp, p.b_rs, col0, col_end, k0, kend, tid, rb);
+            else load_rc(Bp, p.b_ks, col0, col_end, k0, kend, tid, rb);
+        }
+        const float* as = smem + 2 * cur * TILE_FLOATS;
+        const float* bs = as + TILE_FLOATS;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float af[2][4], bf[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) read_frag<A_KC>(as, wm * 64 + i * 32 + r32, kk, h, af[i]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) read_frag<B_KC>(bs, wn * 64 + j * 32 + r32, kk, h, bf[j]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            float* an = smem + 2 * (cur ^ 1) * TILE_FLOATS;
+            if (A_KC) store_kc(an, tid, ra); else store_rc(an, tid, ra);
+            if (B_KC) store_kc(an + TILE_FLOATS, tid, rb); else store_rc(an + TILE_FLOATS, tid, rb);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[i][j][r] is C[row = (r&3)+8*(r>>2)+4*h][col = lane&31] of its 32x32 tile --
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + wn * 64 + j * 32 + r32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < row_end && col < col_end) {
+                    float* dst = Cp + (int64_t)row * p.ldc + col;
+                    const float v = p.alpha * acc[i][j][r];
+                    if (MODE == 1) atomicAdd(dst, v);
+                    else if (p.accumulate) *dst += v;
+                    else *dst = v;
+                }
+            }
+        }
+    }
+}
+
+template <bool A_KC, bool B_KC, int MODE>
+static int launch_gemm(const GemmParams& p, int blocks, hipStream_t st) {
+    static bool attr_set = false;
+    auto kfn = gemm_f32_kernel<A_KC, B_KC, MODE>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        if (e != hipSuccess) {
+            set_error("gamer_gemm_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, p);
+    GAMER_CHECK_LAUNCH("gamer_gemm_f32");
+    return 0;
+}
+
+}  // namespace gamer
+
+using namespace gamer;
+
+extern "C" int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream) {
+    GAMER_CHECK_ARG(d, "gamer_gemm_f32: null descriptor");
+    GAMER_CHECK_ARG(d->A && d->B && d->C, "gamer_gemm_f32: null matrix pointer");
+    GAMER_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gamer_gemm_f32: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+    GAMER_CHECK_ARG((d->a_rs == 1) != (d->a_ks == 1) || (d->a_rs == 1 && d->a_ks == 1 && (d->M == 1 || d->K == 1)),
+                    "gamer_gemm_f32: exactly one of a_rs/a_ks must be 1 (rs=%lld ks=%lld)", (long long)d->a_rs, (long long)d->a_ks);
+    GAMER_CHECK_ARG((d->b_rs == 1) != (d->b_ks == 1) || (d->b_rs == 1 && d->b_ks == 1 && (d->N == 1 || d->K == 1)),
+                    "gamer_gemm_f32: exactly one of b_rs/b_ks must be 1 (rs=%lld ks=%lld)", (long long)d->b_rs, (long long)d->b_ks);
+    const bool a_kc = d->a_ks == 1, b_kc = d->b_ks == 1;
+    const int64_t a_ld = a_kc ? d->a_rs : d->a_ks, b_ld = b_kc ? d->b_rs : d->b_ks;
+    GAMER_CHECK_ARG(a_ld % 4 == 0 && b_ld % 4 == 0 && d->ldc >= d->N,
+                    "gamer_gemm_f32: leading dims must be multiples of 4 (lda=%lld ldb=%lld ldc=%lld)",
+                    (long long)a_ld, (long long)b_ld, (long long)d->ldc);
+    GAMER_CHECK_ARG(aligned16(d->A) && aligned16(d->B), "gamer_gemm_f32: A and B must be 16-byte aligned");
+    GAMER_CHECK_ARG(d->groups >= 1 && (d->groups == 1 || d->group_offsets), "gamer_gemm_f32: groups=%d needs group_offsets", d->groups);
+    GAMER_CHECK_ARG(d->strideB % 4 == 0, "gamer_gemm_f32: strideB must be a multiple of 4");
+    GAMER_CHECK_ARG(d->group_mode == 0 || d->group_mode == 1, "gamer_gemm_f32: group_mode=%d", d->group_mode);
+
+    GemmParams p;
+    p.A = d->A; p.a_rs = d->a_rs; p.a_ks = d->a_ks;
+    p.B = d->B; p.b_rs = d->b_rs; p.b_ks = d->b_ks;
+    p.C = d->C; p.ldc = d->ldc;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.alpha = d->alpha; p.accumulate = d->accumulate;
+    p.groups = d->groups; p.group_offsets = d->group_offsets;
+    p.strideB = d->strideB; p.strideC = d->strideC;
+    p.kchunk = d->kchunk;
+    p.n_tiles = (d->N + BN - 1) / BN;
+    hipStream_t st = (hipStream_t)stream;
+
+    if (d->group_mode == 0) {
+        p.m_tiles = (d->M + BM - 1) / BM + (d->group_offsets ? d->groups : 0);
+        const int64_t blocks = (int64_t)p.m_tiles * p.n_tiles;
+        GAMER_CHECK_ARG(blocks < (1LL << 31), "gamer_gemm_f32: grid too large");
+        if (a_kc && b_kc) return launch_gemm<true, true, 0>(p, (int)blocks, st);
+        if (a_kc && !b_kc) return launch_gemm<true, false, 0>(p, (int)blocks, st);
+        if (!a_kc && !b_kc) return launch_gemm<false, false, 0>(p, (int)blocks, st);
+        GAMER_CHECK_ARG(false, "gamer_gemm_f32: layout (A row-contiguous, B k-contiguous) is not built");
+    } else {
+        GAMER_CHECK_ARG(!a_kc && !b_kc, "gamer_gemm_f32: group_mode 1 (wgrad) needs row-contiguous A and B");
+        GAMER_CHECK_ARG(d->kchunk >= BK && d->kchunk % BK == 0, "gamer_gemm_f32: kchunk=%d must be a positive multiple of 32", d->kchunk);
+        p.m_tiles = (d->M + BM - 1) / BM;
+        const int64_t chunks = (d->K + d->kchunk - 1) / d->kchunk + (d->group_offsets ? d->groups : 0);
+        const int64_t blocks = chunks * p.m_tiles * p.n_tiles;
+        GAMER_CHECK_ARG(blocks < (1LL << 31), "gamer_gemm_f32: grid too large");
+        return launch_gemm<false, false, 1>(p, (int)blocks, st);
+    }
+    return 0;
+}

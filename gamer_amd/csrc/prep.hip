@@ -1,0 +1,238 @@
+// Router maps, mask-predicate levels, empty-row flags and expert token lists (integer work).
+// Reference behaviour restated: ref:SeqRec/models/generative/Qwen3Multi/router.py:74-201,
+// ref:SeqRec/models/generative/Qwen3Multi/model.py:573-630,691-741,
+// ref:SeqRec/models/generative/Qwen3Moe/FFN.py:63-68.
+#include "common.h"
+
+namespace gamer {
+
+static thread_local char g_err[512] = {0};
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+constexpr int ROUTER_THREADS = 256;
+constexpr int INT_BIG = 0x7fffffff;
+
+// One workgroup per sequence.  LDS prefix-min scan gives min_{j<=i} klevel[j] for the empty flags.
+__global__ void __launch_bounds__(ROUTER_THREADS)
+router_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ attn_mask,
+              const int64_t* __restrict__ actions, const int32_t* __restrict__ lut, int vocab,
+              int S, int P, int pad_id, int eos_id,
+              int32_t* __restrict__ expert, int32_t* __restrict__ beh_idx, int32_t* __restrict__ act_idx,
+              int32_t* __restrict__ kl_self, int32_t* __restrict__ kl_cross, int32_t* __restrict__ ql_cross,
+              int32_t* __restrict__ empty_self, int32_t* __restrict__ empty_cross,
+              int32_t* __restrict__ tile_empty_self, int32_t* __restrict__ tile_empty_cross,
+              int32_t* __restrict__ bad_token) {
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    int32_t* pm_self = smem;            // [S] running min of kl_self
+    int32_t* pm_cross = smem + S;       // [S]
+    int32_t* tmp_a = smem + 2 * S;      // [S] scan ping-pong
+    int32_t* tmp_b = smem + 3 * S;      // [S]
+    const int b = blockIdx.x;
+    const int64_t base = (int64_t)b * S;
+    const int n_tiles = (S + 31) / 32;
+
+    for (int t = threadIdx.x; t < S; t += blockDim.x) {
+        const int64_t id = ids[base + t];
+        const bool special = (id == pad_id) || (id == eos_id);
+        const int e = special ? 0 : (t % P) + 1;
+        // behaviour token of this token's item
+        const int first = (t / P) * P;
+        const int64_t btok = ids[base + first];
+        int a;
+        if (btok >= 0 && btok < vocab && lut[btok] >= 0) {
+            a = lut[btok] + 1;
+        } else {
+            a = 0;
+            if (!special && t == first) atomicAdd(bad_token, 1);
+        }
+        if (special) a = 0;
+        expert[base + t] = e;
+        act_idx[base + t] = a;
+        beh_idx[base + t] = (t % P == 0) ? 0 : a;
+        const bool keep = attn_mask ? (attn_mask[base + t] != 0) : true;
+        int64_t lv64 = actions ? actions[base + t] : 0;
+        if (lv64 > 0x3fffffff) lv64 = 0x3fffffff;
+        if (lv64 < -0x3fffffff) lv64 = -0x3fffffff;
+        const int lv = (int)lv64;
+        const int ks = keep ? 0 : INT_BIG;
+        const int kc = keep ? lv : INT_BIG;
+        kl_self[base + t] = ks;
+        kl_cross[base + t] = kc;
+        ql_cross[base + t] = lv;
+        pm_self[t] = ks;
+        pm_cross[t] = kc;
+    }
+    __syncthreads();
+    // inclusive prefix-min (Hillis-Steele) for both arrays
+    for (int which = 0; which < 2; ++which) {
+        int32_t* src = which ? pm_cross : pm_self;
+        int32_t* a = src;
+        int32_t* bb = tmp_a;
+        for (int off = 1; off < S; off <<= 1) {
+            for (int t = threadIdx.x; t < S; t += blockDim.x) {
+                int v = a[t];
+                if (t >= off) v = min(v, a[t - off]);
+                bb[t] = v;
+            }
+            __syncthreads();
+            int32_t* nx = (bb == tmp_a) ? tmp_b : tmp_a;
+            a = bb;
+            bb = nx;
+        }
+        // copy back if result is not in src
+        if (a != src) {
+            for (int t = threadIdx.x; t < S; t += blockDim.x) src[t] = a[t];
+        }
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < S; t += blockDim.x) {
+        const int lv = ql_cross[base + t];      // written by this same thread above
+        const int es = (pm_self[t] < 1) ? 0 : 1;
+        const int ec = (pm_cross[t] < lv) ? 0 : 1;
+        empty_self[base + t] = es;
+        empty_cross[base + t] = ec;
+        tmp_a[t] = es;
+        tmp_b[t] = ec;
+    }
+    __syncthreads();
+    for (int qt = threadIdx.x; qt < n_tiles; qt += blockDim.x) {
+        int es = 0, ec = 0;
+        for (int t = qt * 32; t < min(S, qt * 32 + 32); ++t) {
+            es |= tmp_a[t];
+            ec |= tmp_b[t];
+        }
+        tile_empty_self[(int64_t)b * n_tiles + qt] = es;
+        tile_empty_cross[(int64_t)b * n_tiles + qt] = ec;
+    }
+}
+
+// ---- expert lists ---------------------------------------------------------------------------
+// pass 1: per-sequence member counts   work[b*E + e]
+__global__ void expert_count_kernel(const int32_t* __restrict__ expert, int S, int E,
+                                    int32_t* __restrict__ work) {
+    __shared__ int cnt[64];
+    const int b = blockIdx.x;
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < S; t += blockDim.x) {
+        atomicAdd(&cnt[expert[(int64_t)b * S + t]], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < E) work[(int64_t)b * E + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// pass 2 (single workgroup): exclusive scan over sequences per expert, then expert bases.
+// work[b*E+e] <- global start slot of (sequence b, expert e); offsets[e] = segment starts.
+__global__ void __launch_bounds__(1024)
+expert_scan_kernel(int B, int E, int T, int32_t* __restrict__ work, int32_t* __restrict__ offsets) {
+    __shared__ int32_t sh[1024];
+    __shared__ int32_t carry;
+    __shared__ int32_t totals[65];
+    const int tid = threadIdx.x;
+    for (int e = 0; e < E; ++e) {
+        if (tid == 0) carry = 0;
+        __syncthreads();
+        for (int b0 = 0; b0 < B; b0 += 1024) {
+            const int b = b0 + tid;
+            const int v = (b < B) ? work[(int64_t)b * E + e] : 0;
+            sh[tid] = v;
+            __syncthreads();
+            for (int off = 1; off < 1024; off <<= 1) {
+                int add = (tid >= off) ? sh[tid - off] : 0;
+                __syncthreads();
+                sh[tid] += add;
+                __syncthreads();
+            }
+            const int incl = sh[tid];
+            const int c = carry;
+            if (b < B) work[(int64_t)b * E + e] = c + incl - v;   // exclusive, within this expert
+            __syncthreads();
+            if (tid == 1023) carry = c + incl;
+            __syncthreads();
+        }
+        if (tid == 0) totals[e] = carry;
+        __syncthreads();
+    }
+    __shared__ int32_t sbase[65];
+    if (tid == 0) {
+        int acc = 0;
+        for (int e = 0; e < E; ++e) {
+            offsets[e] = acc;
+            sbase[e] = acc;
+            acc += totals[e];
+        }
+        offsets[E] = acc;   // == T
+    }
+    __syncthreads();
+    // add the expert base
+    for (int i = tid; i < B * E; i += 1024) {
+        work[i] += sbase[i % E];
+    }
+}
+
+// pass 3: one wave per sequence; lane e (< E) walks the sequence in token order and emits slots.
+__global__ void expert_emit_kernel(const int32_t* __restrict__ expert, int S, int E,
+                                   const int32_t* __restrict__ work,
+                                   int32_t* __restrict__ perm, int32_t* __restrict__ slot) {
+    const int b = blockIdx.x;
+    const int e = threadIdx.x;
+    if (e >= E) return;
+    int next = work[(int64_t)b * E + e];
+    const int64_t base = (int64_t)b * S;
+    for (int t = 0; t < S; ++t) {
+        if (expert[base + t] == e) {
+            perm[next] = (int32_t)(base + t);
+            slot[base + t] = next;
+            ++next;
+        }
+    }
+}
+
+}  // namespace gamer
+
+using namespace gamer;
+
+extern "C" int gamer_abi_version(void) { return GAMER_ABI_VERSION; }
+extern "C" const char* gamer_last_error(void) { return gamer::g_err; }
+
+extern "C" int gamer_router_fwd(const int64_t* ids, const int64_t* attn_mask, const int64_t* actions,
+                                const int32_t* behavior_lut, int vocab, int B, int S, int num_positions,
+                                int pad_id, int eos_id,
+                                int32_t* expert, int32_t* beh_idx, int32_t* act_idx,
+                                int32_t* kl_self, int32_t* kl_cross, int32_t* ql_cross,
+                                int32_t* empty_self, int32_t* empty_cross,
+                                int32_t* tile_empty_self, int32_t* tile_empty_cross,
+                                int32_t* bad_token, void* stream) {
+    GAMER_CHECK_ARG(ids && behavior_lut && expert && beh_idx && act_idx && kl_self && kl_cross &&
+                    ql_cross && empty_self && empty_cross && tile_empty_self && tile_empty_cross && bad_token,
+                    "gamer_router_fwd: null pointer");
+    GAMER_CHECK_ARG(B > 0 && S > 0 && num_positions > 0, "gamer_router_fwd: bad shape B=%d S=%d P=%d", B, S, num_positions);
+    GAMER_CHECK_ARG(S <= 8192, "gamer_router_fwd: S=%d > 8192 unsupported", S);
+    const size_t shmem = (size_t)4 * S * sizeof(int32_t);
+    hipLaunchKernelGGL(router_kernel, dim3(B), dim3(ROUTER_THREADS), shmem, (hipStream_t)stream,
+                       ids, attn_mask, actions, behavior_lut, vocab, S, num_positions, pad_id, eos_id,
+                       expert, beh_idx, act_idx, kl_self, kl_cross, ql_cross, empty_self, empty_cross,
+                       tile_empty_self, tile_empty_cross, bad_token);
+    GAMER_CHECK_LAUNCH("gamer_router_fwd");
+    return 0;
+}
+
+extern "C" int gamer_expert_lists(const int32_t* expert, int B, int S, int num_experts,
+                                  int32_t* perm, int32_t* slot, int32_t* offsets, int32_t* work, void* stream) {
+    GAMER_CHECK_ARG(expert && perm && slot && offsets && work, "gamer_expert_lists: null pointer");
+    GAMER_CHECK_ARG(B > 0 && S > 0 && num_experts > 0 && num_experts <= 64,
+                    "gamer_expert_lists: bad shape B=%d S=%d E=%d", B, S, num_experts);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(expert_count_kernel, dim3(B), dim3(256), 0, st, expert, S, num_experts, work);
+    GAMER_CHECK_LAUNCH("gamer_expert_lists/count");
+    hipLaunchKernelGGL(expert_scan_kernel, dim3(1), dim3(1024), 0, st, B, num_experts, B * S, work, offsets);
+    GAMER_CHECK_LAUNCH("gamer_expert_lists/scan");
+    hipLaunchKernelGGL(expert_emit_kernel, dim3(B), dim3(64), 0, st, expert, S, num_experts, work, perm, slot);
+    GAMER_CHECK_LAUNCH("gamer_expert_lists/emit");
+    return 0;
+}

@@ -1,0 +1,214 @@
+"""Thin tensor-level wrappers over the C ABI (one function per entry point).
+
+All tensors must live on the HIP device, fp32 / int32 / int64 as documented in
+include/gamer_hip.h.  Kernels are enqueued on torch's current stream.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, call, ptr, stream_ptr
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be on the HIP device (gamer_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+# ----------------------------------------------------------------------------------------------
+def router_fwd(ids, attn_mask, actions, behavior_lut, num_positions, pad_id, eos_id, out: dict):
+    B, S = ids.shape
+    _chk(ids, torch.int64, "input_ids")
+    call("gamer_router_fwd", ptr(ids), ptr(attn_mask), ptr(actions), ptr(behavior_lut), behavior_lut.numel(),
+         B, S, num_positions, pad_id, eos_id,
+         ptr(out["expert"]), ptr(out["beh_idx"]), ptr(out["act_idx"]),
+         ptr(out["kl_self"]), ptr(out["kl_cross"]), ptr(out["ql_cross"]),
+         ptr(out["empty_self"]), ptr(out["empty_cross"]),
+         ptr(out["tile_empty_self"]), ptr(out["tile_empty_cross"]), ptr(out["bad_token"]), stream_ptr())
+
+
+def alloc_router_outputs(B, S, device):
+    n_tiles = (S + 31) // 32
+    i32 = dict(dtype=torch.int32, device=device)
+    out = {k: torch.empty(B, S, **i32) for k in
+           ("expert", "beh_idx", "act_idx", "kl_self", "kl_cross", "ql_cross", "empty_self", "empty_cross")}
+    out["tile_empty_self"] = torch.empty(B, n_tiles, **i32)
+    out["tile_empty_cross"] = torch.empty(B, n_tiles, **i32)
+    out["bad_token"] = torch.zeros(1, **i32)
+    return out
+
+
+def expert_lists(expert, num_experts, perm, slot, offsets, work):
+    B, S = expert.shape
+    call("gamer_expert_lists", ptr(expert), B, S, num_experts, ptr(perm), ptr(slot), ptr(offsets), ptr(work),
+         stream_ptr())
+
+
+def embedding_fwd(ids, W, x):
+    T = ids.numel()
+    V, H = W.shape
+    call("gamer_embedding_fwd", ptr(ids), ptr(W), V, T, H, ptr(x), stream_ptr())
+
+
+def embedding_bwd(ids, dx, pad_id, dW):
+    T = ids.numel()
+    V, H = dW.shape
+    call("gamer_embedding_bwd", ptr(ids), ptr(dx), V, T, H, pad_id, ptr(dW), stream_ptr())
+
+
+def rmsnorm_fwd(x, w, eps, y, ldy=None, dst_rows=None):
+    T, H = x.shape
+    call("gamer_rmsnorm_fwd", ptr(x), ptr(w), T, H, eps, ptr(dst_rows), ptr(y), ldy if ldy else y.stride(0),
+         stream_ptr())
+
+
+def rmsnorm_bwd(x, w, dy, lddy, eps, dx, dw_partial, accumulate_dx=True, dy_rows=None):
+    T, H = x.shape
+    call("gamer_rmsnorm_bwd", ptr(x), ptr(w), ptr(dy), lddy, ptr(dy_rows), T, H, eps, 1 if accumulate_dx else 0,
+         ptr(dx), ptr(dw_partial), dw_partial.shape[0], stream_ptr())
+
+
+def colsum_reduce(partial, out, accumulate=False):
+    rows, cols = partial.shape
+    call("gamer_colsum_reduce", ptr(partial), rows, cols, 1 if accumulate else 0, ptr(out), stream_ptr())
+
+
+def rowtable_fwd(table, idx, y, ldy, col0, dst_rows=None):
+    T = idx.numel()
+    E = table.shape[1]
+    call("gamer_rowtable_fwd", ptr(table), ptr(idx), ptr(dst_rows), T, E, ptr(y), ldy, col0, stream_ptr())
+
+
+def rowtable_bwd(dy, lddy, col0, idx, dtable, dy_rows=None):
+    T = idx.numel()
+    rows, E = dtable.shape
+    call("gamer_rowtable_bwd", ptr(dy), lddy, col0, ptr(idx), ptr(dy_rows), T, E, rows, ptr(dtable), stream_ptr())
+
+
+def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=False, groups=1, group_mode=0,
+         group_offsets=None, strideB=0, strideC=0, kchunk=0):
+    """C[m][n] (=|+=) alpha * sum_k A(m,k) B(n,k); see gamer_gemm_desc in include/gamer_hip.h."""
+    d = GemmDesc()
+    d.A = ptr(A); d.a_rs = a_rs; d.a_ks = a_ks
+    d.B = ptr(Bm); d.b_rs = b_rs; d.b_ks = b_ks
+    d.C = ptr(Cm); d.ldc = ldc
+    d.M = M; d.N = N; d.K = K
+    d.alpha = alpha
+    d.accumulate = 1 if accumulate else 0
+    d.groups = groups
+    d.group_mode = group_mode
+    d.group_offsets = ptr(group_offsets)
+    d.strideB = strideB; d.strideC = strideC
+    d.kchunk = kchunk
+    call("gamer_gemm_f32", C.byref(d), stream_ptr())
+
+
+def linear_fwd(x, ldx, W, ldw, y, ldy, M, N, K, accumulate=False, **grp):
+    """y[M,N] = x[M,K] @ W[N,K]^T"""
+    gemm(x, ldx, 1, W, ldw, 1, y, ldy, M, N, K, accumulate=accumulate, **grp)
+
+
+def linear_dgrad(dy, lddy, W, ldw, dx, lddx, M, N_out, K_in, accumulate=False, **grp):
+    """dx[M,K_in] = dy[M,N_out] @ W[N_out,K_in]"""
+    gemm(dy, lddy, 1, W, 1, ldw, dx, lddx, M, K_in, N_out, accumulate=accumulate, **grp)
+
+
+def pick_kchunk(rows: int, tiles: int, target_blocks: int = 1024) -> int:
+    """Contraction chunk for the wgrad split: enough workgroups to fill 256 CUs, multiple of 32."""
+    want = max(1, target_blocks // max(1, tiles))
+    chunk = (rows + want - 1) // want
+    chunk = max(256, ((chunk + 31) // 32) * 32)
+    return chunk
+
+
+def linear_wgrad(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups=1, group_offsets=None, strideC=0, kchunk=None):
+    """dW[N_out,K_in] += dy[rows,N_out]^T @ x[rows,K_in]   (dW must be initialised; fp32 atomics)."""
+    if kchunk is None:
+        tiles = ((N_out + 127) // 128) * ((K_in + 127) // 128)
+        kchunk = pick_kchunk(rows, tiles * max(1, groups) if groups > 1 else tiles)
+    gemm(dy, 1, lddy, x, 1, ldx, dW, lddw, N_out, K_in, rows, groups=groups, group_mode=1,
+         group_offsets=group_offsets, strideC=strideC, kchunk=kchunk)
+
+
+def qknorm_rope_fwd(qkv, S, nq, nkv, wq, wk, eps, cos_t, sin_t, q_rot, k_rot, bias_q=None, bias_k=None, bias_v=None,
+                    act_idx=None):
+    T = qkv.shape[0]
+    call("gamer_qknorm_rope_fwd", ptr(qkv), T, S, nq, nkv, ptr(wq), ptr(wk), eps, ptr(cos_t), ptr(sin_t),
+         ptr(bias_q), ptr(bias_k), ptr(bias_v), ptr(act_idx), ptr(q_rot), ptr(k_rot), stream_ptr())
+
+
+def qknorm_rope_bwd(qkv, dq_rot, dk_rot, S, nq, nkv, wq, wk, eps, cos_t, sin_t, dqkv, dwq, dwk, bias_q=None,
+                    bias_k=None, act_idx=None, nb1=0, dbias_q=None, dbias_k=None, dbias_v=None):
+    T = qkv.shape[0]
+    call("gamer_qknorm_rope_bwd", ptr(qkv), ptr(dq_rot), ptr(dk_rot), T, S, nq, nkv, ptr(wq), ptr(wk), eps,
+         ptr(cos_t), ptr(sin_t), ptr(bias_q), ptr(bias_k), ptr(act_idx), nb1, ptr(dqkv), ptr(dwq), ptr(dwk),
+         ptr(dbias_q), ptr(dbias_k), ptr(dbias_v), stream_ptr())
+
+
+def attn_fwd(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse):
+    call("gamer_attn_fwd", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(kl), ptr(ql), ptr(row_empty), ptr(tile_empty),
+         B, S, nq, nkv, scale, p_drop, seed, ptr(o), ptr(lse), stream_ptr())
+
+
+def attn_bwd(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed,
+             delta, dq, lddq, dk, lddk, dv, lddv):
+    call("gamer_attn_bwd", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), ptr(d_o), ptr(lse), ptr(kl), ptr(ql),
+         ptr(row_empty), ptr(tile_empty), B, S, nq, nkv, scale, p_drop, seed, ptr(delta), ptr(dq), lddq, ptr(dk),
+         lddk, ptr(dv), lddv, stream_ptr())
+
+
+def residual_dropout_fwd(x, delta, p, seed, src_rows=None):
+    T, H = x.shape
+    call("gamer_residual_dropout_fwd", ptr(x), ptr(delta), ptr(src_rows), T, H, p, seed, stream_ptr())
+
+
+def residual_dropout_bwd(dx, p, seed, ddelta, src_rows=None):
+    T, H = dx.shape
+    call("gamer_residual_dropout_bwd", ptr(dx), ptr(src_rows), T, H, p, seed, ptr(ddelta), stream_ptr())
+
+
+def swiglu_fwd(g, u, n, p, seed, hm):
+    call("gamer_swiglu_fwd", ptr(g), ptr(u), n, p, seed, ptr(hm), stream_ptr())
+
+
+def swiglu_bwd(g, u, dhm, n, p, seed):
+    call("gamer_swiglu_bwd", ptr(g), ptr(u), ptr(dhm), n, p, seed, stream_ptr())
+
+
+def silu_gate_fwd(a, gate, out):
+    call("gamer_silu_gate_fwd", ptr(a), ptr(gate), a.numel(), ptr(out), stream_ptr())
+
+
+def silu_gate_bwd(a, gate, dout, da, dgate):
+    call("gamer_silu_gate_bwd", ptr(a), ptr(gate), ptr(dout), a.numel(), ptr(da), ptr(dgate), stream_ptr())
+
+
+def ce_fwd(logits, ldl, labels, V, temperature, ignore_index, lse, row_loss, loss_sum, count):
+    B, S = labels.shape
+    call("gamer_ce_fwd", ptr(logits), ldl, ptr(labels), B, S, V, temperature, ignore_index, ptr(lse), ptr(row_loss),
+         ptr(loss_sum), ptr(count), stream_ptr())
+
+
+def ce_bwd(logits, ldl, labels, V, temperature, ignore_index, lse, count_dev, denom_host, dloss):
+    B, S = labels.shape
+    call("gamer_ce_bwd", ptr(logits), ldl, ptr(labels), B, S, V, temperature, ignore_index, ptr(lse), ptr(count_dev),
+         float(denom_host), float(dloss), stream_ptr())
+
+
+def sumsq(g, partial):
+    call("gamer_sumsq", ptr(g), g.numel(), ptr(partial), partial.numel(), stream_ptr())
+
+
+def adamw(p, g, m, v, n_decay, lr, beta1, beta2, eps, weight_decay, step, max_norm, grad_scale, partial, norm_out):
+    call("gamer_adamw", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), n_decay, lr, beta1, beta2, eps, weight_decay,
+         step, max_norm, grad_scale, ptr(partial), partial.numel(), ptr(norm_out), stream_ptr())
+
+
+def fill(t, value):
+    call("gamer_fill_f32", ptr(t), t.numel(), float(value), stream_ptr())

@@ -1,0 +1,244 @@
+/*
+ * gamer_hip.h -- C ABI of libgamer_hip.so: the MI355X (gfx950) kernels of the Qwen3Multi
+ * SMB-decoder train step.
+ *
+ * The reference (wzf2000/GAMER) is pure Python/PyTorch and has no FFI of its own; the boundary
+ * it exposes for this path is the nn.Module `Qwen3MultiWithTemperature`
+ * (ref:SeqRec/models/generative/Qwen3Multi/model.py:883-1013).  `gamer_amd/` mirrors that module
+ * in Python and drives the entry points below through ctypes (INTEGRATION.md shows the stub).
+ * Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP), fp32 / int32 / int64 as typed, 16-byte aligned;
+ *   - matrices are row-major with an explicit leading dimension (elements) that is a multiple of 4;
+ *   - token-major activations: row t = b*S + s;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - return value: 0 = ok, <0 = bad argument (see gamer_last_error()), >0 = hipError_t;
+ *   - no entry point allocates, frees or synchronises (all are hipGraph-capturable).
+ *   - dropout: keep-mask = hash(seed, element index) >= p*2^32, scale 1/(1-p); the same
+ *     (seed, index) pair regenerates the mask in the backward kernels.  p = 0 disables it.
+ */
+#ifndef GAMER_HIP_H
+#define GAMER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAMER_ABI_VERSION 1
+
+int gamer_abi_version(void);
+/* Thread-local message for the last <0 / >0 return of any entry point. */
+const char* gamer_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Router + mask predicates + expert lists (integer work).
+ * Replaces Qwen3MultiDecoderRouter.forward (ref:.../Qwen3Multi/router.py:74-201) and the mask
+ * builders _update_session_wise_causal_mask / _update_session_multi_cross_mask
+ * (ref:.../Qwen3Multi/model.py:691-741, 573-630): the [B,1,S,S] additive masks are never
+ * materialised; the attention kernels evaluate  allowed(i,j) = j<=i && klevel[j] < qlevel[i].
+ *   ids, attn_mask (may be NULL = all ones), actions (may be NULL = zeros): int64 [B,S]
+ *   behavior_lut: int32 [vocab], token id -> behaviour index (0..NB-1) or -1
+ * outputs, all int32 [B,S]:
+ *   expert      position index 0..num_positions (0 = pad/eos)        (router.py:83-104)
+ *   beh_idx     behaviour index for the FFN injection                 (router.py:110-148)
+ *   act_idx     behaviour index for the cross-attention biases        (router.py:158-195)
+ *   kl_self / kl_cross   key level   (INT32_MAX when attention_mask[j]==0)
+ *   ql_cross             query level (= actions[i]); the self query level is the constant 1
+ *   empty_self / empty_cross   1 when row i has no allowed key (softmax is then uniform over
+ *                              all S keys, see model.py:586-602 + SDPA)
+ *   tile_empty_self / tile_empty_cross  int32 [B, ceil(S/32)]: any empty row in that 32-row tile
+ *   bad_token   int32 [1]: incremented for every behaviour-position token that is neither
+ *               pad/eos nor in behavior_lut (the reference would raise IndexError later)
+ * ---------------------------------------------------------------------------------------- */
+int gamer_router_fwd(const int64_t* ids, const int64_t* attn_mask, const int64_t* actions,
+                     const int32_t* behavior_lut, int vocab, int B, int S, int num_positions,
+                     int pad_id, int eos_id,
+                     int32_t* expert, int32_t* beh_idx, int32_t* act_idx,
+                     int32_t* kl_self, int32_t* kl_cross, int32_t* ql_cross,
+                     int32_t* empty_self, int32_t* empty_cross,
+                     int32_t* tile_empty_self, int32_t* tile_empty_cross,
+                     int32_t* bad_token, void* stream);
+
+/* Expert token lists for the position-routed FFN (replaces the boolean-mask gather/scatter loop of
+ * MyQwen3SparseMLP.forward, ref:SeqRec/models/generative/Qwen3Moe/FFN.py:63-68, and its 6 host
+ * syncs per layer).  Deterministic order: expert-major, then token order.
+ *   expert int32 [T]; perm int32 [T] (sorted slot -> token); slot int32 [T] (token -> sorted slot);
+ *   offsets int32 [num_experts+1]; work int32 [(B+1)*num_experts] scratch.                     */
+int gamer_expert_lists(const int32_t* expert, int B, int S, int num_experts,
+                       int32_t* perm, int32_t* slot, int32_t* offsets, int32_t* work, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Embedding (nn.Embedding(vocab,H,padding_idx), ref:.../Qwen3Multi/model.py:263,779).
+ * bwd: dW[ids[t]] += dx[t] for ids[t] != pad_id (atomic adds into an already initialised dW:
+ * the tied head's wgrad is written first).
+ * ---------------------------------------------------------------------------------------- */
+int gamer_embedding_fwd(const int64_t* ids, const float* W, int V, int T, int H, float* x, void* stream);
+int gamer_embedding_bwd(const int64_t* ids, const float* dx, int V, int T, int H, int pad_id, float* dW,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * RMSNorm over the hidden dim (Qwen3RMSNorm, transformers/models/qwen3/modeling_qwen3.py;
+ * call sites model.py:205,222,239,869).  y[dst(t)] = w * x[t] * rsqrt(mean(x[t]^2)+eps)
+ *   dst_rows: optional int32 [T] row scatter (token -> sorted slot) used for the FFN input;
+ *   ldy: leading dim of y (>= H), lets the FFN input carry the behaviour embedding after col H.
+ * bwd: dx[t] (+)= rstd*(w*dy - xhat*mean(w*dy*xhat)) ; dw_partial[block][H] deterministic partials
+ *   that gamer_colsum_reduce folds into dw.
+ * ---------------------------------------------------------------------------------------- */
+int gamer_rmsnorm_fwd(const float* x, const float* w, int T, int H, float eps,
+                      const int32_t* dst_rows, float* y, int ldy, void* stream);
+int gamer_rmsnorm_bwd(const float* x, const float* w, const float* dy, int lddy,
+                      const int32_t* dy_rows, int T, int H, float eps, int accumulate_dx,
+                      float* dx, float* dw_partial, int n_partial, void* stream);
+/* out[c] (+)= sum_r partial[r][c] */
+int gamer_colsum_reduce(const float* partial, int rows, int cols, int accumulate, float* out,
+                        void* stream);
+
+/* Behaviour-embedding concat for the injected FFN layers (FFN.py:60-62):
+ * y[dst(t)][col0 .. col0+E) = table[idx[t]];   bwd: dtable[idx[t]] += dy[dst(t)][col0..]        */
+int gamer_rowtable_fwd(const float* table, const int32_t* idx, const int32_t* dst_rows, int T, int E,
+                       float* y, int ldy, int col0, void* stream);
+int gamer_rowtable_bwd(const float* dy, int lddy, int col0, const int32_t* idx,
+                       const int32_t* dy_rows, int T, int E, int n_rows_table, float* dtable,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * fp32 MFMA GEMM  (v_mfma_f32_32x32x2_f32; exact fp32, replaces every nn.Linear on the path:
+ * model.py:93-99,145-149,1001 and FFN.py:25-27).
+ *     C[m][n] (=|+=) alpha * sum_k A(m,k) * B(n,k)
+ * Operand element (r,k) lives at ptr[r*rs + k*ks]; exactly one of rs/ks is 1.
+ *   Linear fwd   Y = X W^T      : A = X (ks=1),  B = W (ks=1)
+ *   dgrad        dX = dY W      : A = dY (ks=1), B(n,k) = W[k][n] (rs=1)
+ *   wgrad        dW = dY^T X    : A(m,k) = dY[k][m] (rs=1), B(n,k) = X[k][n] (rs=1)
+ * Grouping (position-routed experts): group_offsets int32 [groups+1] on the DEVICE, or NULL for
+ * one group.
+ *   group_mode 0: rows of A/C are segmented (C rows offsets[g]..offsets[g+1] use B + g*strideB)
+ *   group_mode 1: the contraction index is segmented (wgrad): C + g*strideC = sum over k in
+ *                 segment g; split along k in chunks of `kchunk`, combined with fp32 atomics
+ *                 (C must be zero-initialised or hold the value to accumulate into).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* A; int64_t a_rs, a_ks;
+    const float* B; int64_t b_rs, b_ks;
+    float* C; int64_t ldc;
+    int M, N, K;
+    float alpha;
+    int accumulate;              /* 0: C = , 1: C += (mode 0 only) */
+    int groups;                  /* >= 1 */
+    int group_mode;              /* 0 rows, 1 contraction */
+    const int32_t* group_offsets;/* device, groups+1 entries, or NULL when groups == 1 */
+    int64_t strideB, strideC;    /* elements between consecutive groups */
+    int kchunk;                  /* mode 1: contraction chunk per workgroup (multiple of 32) */
+} gamer_gemm_desc;
+
+int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * q/k per-head RMSNorm + RoPE (+ per-behaviour q/k/v bias for the cross attention)
+ * (model.py:88-101; Qwen3MoeRMSNorm; apply_rotary_pos_emb / rotate_half).
+ *   qkv: [T, (nq+2*nkv)*64] output of the fused q|k|v projection; head_dim is 64.
+ *   cos/sin: [S,64] tables (Qwen3RotaryEmbedding, positions 0..S-1)
+ *   bias_q [NB1, nq*64], bias_k/bias_v [NB1, nkv*64], act_idx int32 [T]  (all NULL for self)
+ *   out: q_rot [T,nq*64], k_rot [T,nkv*64]; v (+bias) is updated in place inside qkv.
+ * bwd: dq_rot, dk_rot -> dqkv[:, :q|k] (pre-norm grads); dv is already in dqkv[:, v];
+ *   dwq/dwk [64] and dbias_* are accumulated with atomics (zero-initialise them).
+ * ---------------------------------------------------------------------------------------- */
+int gamer_qknorm_rope_fwd(float* qkv, int T, int S, int nq, int nkv,
+                          const float* wq, const float* wk, float eps,
+                          const float* cos_t, const float* sin_t,
+                          const float* bias_q, const float* bias_k, const float* bias_v,
+                          const int32_t* act_idx,
+                          float* q_rot, float* k_rot, void* stream);
+int gamer_qknorm_rope_bwd(const float* qkv, const float* dq_rot, const float* dk_rot,
+                          int T, int S, int nq, int nkv,
+                          const float* wq, const float* wk, float eps,
+                          const float* cos_t, const float* sin_t,
+                          const float* bias_q, const float* bias_k,
+                          const int32_t* act_idx, int nb1,
+                          float* dqkv, float* dwq, float* dwk,
+                          float* dbias_q, float* dbias_k, float* dbias_v, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-behaviour flash attention, fp32 MFMA, head_dim 64, GQA group nq/nkv in {1,2,4}.
+ * Replaces sdpa_attention_forward + the additive masks (model.py:133-143): online softmax over
+ * allowed(i,j) = j<=i && kl[j] < ql[i]; rows flagged empty use p = 1/S over all S keys.
+ *   q [T,nq*64] (ldq), k [T,nkv*64] (ldk), v rows at v + t*ldv (ldv lets v live inside qkv)
+ *   ql == NULL means query level 1 for every row (self attention).
+ *   o [T,nq*64]; lse [B,nq,S] (log-sum-exp of the scaled scores; 0 for empty rows)
+ *   dropout on the probabilities: p_drop, seed (attention_dropout, model.py:139)
+ * bwd: delta[b,h,i] = dO.O, then dq (one kernel) and dk/dv (another), no atomics.
+ * ---------------------------------------------------------------------------------------- */
+int gamer_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                   const int32_t* kl, const int32_t* ql, const int32_t* row_empty,
+                   const int32_t* tile_empty,
+                   int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+                   float* o, float* lse, void* stream);
+int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                   const float* o, const float* d_o, const float* lse,
+                   const int32_t* kl, const int32_t* ql, const int32_t* row_empty,
+                   const int32_t* tile_empty,
+                   int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+                   float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise pieces of the decoder layer (model.py:147,217,235,241; FFN.py:25-27).
+ * ---------------------------------------------------------------------------------------- */
+/* x[t] += drop(delta[src(t)])   src_rows optional (token -> sorted slot), n = T*H elements      */
+int gamer_residual_dropout_fwd(float* x, const float* delta, const int32_t* src_rows, int T, int H,
+                               float p_drop, uint64_t seed, void* stream);
+/* ddelta[src(t)] = drop_mask * dx[t]                                                            */
+int gamer_residual_dropout_bwd(const float* dx, const int32_t* src_rows, int T, int H,
+                               float p_drop, uint64_t seed, float* ddelta, void* stream);
+/* hm = drop(silu(g) * u)   (n elements, g/u/hm contiguous)                                      */
+int gamer_swiglu_fwd(const float* g, const float* u, int64_t n, float p_drop, uint64_t seed,
+                     float* hm, void* stream);
+/* in place: g <- dg, u <- du given dhm                                                          */
+int gamer_swiglu_bwd(float* g, float* u, const float* dhm, int64_t n, float p_drop, uint64_t seed,
+                     void* stream);
+/* out = a * silu(gate)  (cross-attention output gate, model.py:147)                              */
+int gamer_silu_gate_fwd(const float* a, const float* gate, int64_t n, float* out, void* stream);
+/* da = dout*silu(gate) ; dgate = dout*a*silu'(gate)                                             */
+int gamer_silu_gate_bwd(const float* a, const float* gate, const float* dout, int64_t n,
+                        float* da, float* dgate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Tied LM head loss: temperature + shifted cross entropy (model.py:904-922;
+ * transformers/loss/loss_utils.py ForCausalLMLoss / fixed_cross_entropy).
+ *   logits [T, ldl] (first V columns valid) are divided by `temperature` IN PLACE (as upstream),
+ *   target of row (b,s) is labels[b][s+1] (ignore_index for s = S-1),
+ *   row_loss [T] per-row CE (0 where ignored), lse_out [T]; loss_sum[0] = sum CE and
+ *   count[0] = #targets != ignore, both reduced in a fixed order (deterministic).
+ * bwd: logits <- (softmax - onehot) * dloss / (denom * temperature), denom = count_dev[0] when
+ *   count_dev != NULL (mean reduction) else denom_host (num_items_in_batch from the trainer).
+ * ---------------------------------------------------------------------------------------- */
+int gamer_ce_fwd(float* logits, int ldl, const int64_t* labels, int B, int S, int V,
+                 float temperature, int ignore_index, float* lse_out, float* row_loss,
+                 float* loss_sum, float* count, void* stream);
+int gamer_ce_bwd(float* logits, int ldl, const int64_t* labels, int B, int S, int V,
+                 float temperature, int ignore_index, const float* lse, const float* count_dev,
+                 float denom_host, float dloss, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * HF Trainer update: clip_grad_norm_(max_norm) + AdamW (transformers/trainer.py;
+ * ref:SeqRec/tasks/train_SMB_decoder.py:396-428).  Flat fp32 buffers of n elements; the first
+ * n_decay elements get weight decay (norm weights live behind them).
+ *   gamer_sumsq: partial[i] = sum of squares of chunk i (n_partial chunks, deterministic)
+ *   gamer_adamw: norm = sqrt(sum partial) ; coef = min(1, max_norm/(norm+1e-6)) ;
+ *                grad_scale multiplies the gradient first (1/world, 1/accum); writes norm_out[0].
+ * ---------------------------------------------------------------------------------------- */
+int gamer_sumsq(const float* g, int64_t n, float* partial, int n_partial, void* stream);
+int gamer_adamw(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay,
+                float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                float max_norm, float grad_scale, const float* partial, int n_partial,
+                float* norm_out, void* stream);
+
+/* misc */
+int gamer_fill_f32(float* p, int64_t n, float value, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAMER_HIP_H */
