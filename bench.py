@@ -1,0 +1,306 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train-step sequences/s of the Qwen3Multi SMB decoder (max_his_len=100).
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N>1 it is launched with
+torch.distributed.run, one rank per GPU (RCCL).  W untimed steps, then exactly K timed steps between
+barrier + synchronize, MAX over ranks, rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): shipped Qwen3Multi architecture (8 layers, hidden 256, 6/3 heads,
+6 position-routed experts, V=1041), fp32, per-GPU micro-batch 1024 sequences x 505 tokens
+(101 items x 5 tokens), synthetic ids, seeded random weights, dropout 0.2 ON, one step =
+forward + backward + (gradient all-reduce) + clip_grad_norm_(1.0) + AdamW.  Weak scaling: the per-GPU
+batch is fixed, the global batch is N x 1024.
+
+Extra objects on the JSON line:
+  roofline     the dominant kernel family (fp32 MFMA GEMM): algorithmic FLOPs of its launches / their
+               summed duration, measured with HIP events on the launch stream inside the timed region
+  cpu_baseline the CPU oracle (a port of the reference algorithm, oracle/) timed on the host cores,
+               rank 0, N=1 only, on a bounded sample (micro-batch 8, same sequence shape)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = 64 FLOP/clk/SIMD
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_flops(cfg, batch) -> dict:
+    """per non-pad token 2*MACs of every projection / expert / head GEMM, plus
+    1536 FLOP per allowed (query, key) pair per attention layer; train step = 3 x forward."""
+    ids, keep, a = batch["input_ids"], batch["attention_mask"].bool(), batch["actions"]
+    H, dh = cfg.hidden_size, cfg.head_dim
+    nq, nkv, I, Eb = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size, cfg.behavior_embedding_dim
+    NQ, NKV = nq * dh, nkv * dh
+    L = cfg.num_hidden_layers
+    n_cross = len(cfg.cross_attention_decoder)
+    n_inj = len(cfg.behavior_injection_decoder)
+    attn_proj = 2 * H * (NQ + 2 * NKV) + 2 * NQ * H
+    f_tok = L * attn_proj + n_cross * (attn_proj + 2 * H * H)
+    f_tok += n_inj * (3 * 2 * (H + Eb) * I - 2 * Eb * I) + (L - n_inj) * 3 * 2 * H * I     # gate+up on Din, down on I
+    f_tok += 2 * H * cfg.vocab_size
+    t_nonpad = int(keep.sum())
+    csum = keep.long().cumsum(1)
+    p_self = int(csum.sum())                                       # sum_i #{j<=i, keep_j} (all query rows)
+    p_cross = 0
+    for lv in torch.unique(a).tolist():
+        less = ((a < lv) & keep).long().cumsum(1)
+        p_cross += int(less[a == lv].sum())
+    pair = 4 * dh * nq
+    f_fwd = t_nonpad * f_tok + pair * (L * p_self + n_cross * p_cross)
+    return dict(per_token=f_tok, fwd=f_fwd, step=3 * f_fwd, tokens=t_nonpad, p_self=p_self, p_cross=p_cross)
+
+
+class KernelTimer:
+    """HIP-event timing of every C-ABI launch on the launch stream (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+        self._next = None
+        self.pairs = {"self": 0, "cross": 0}     # allowed (query, key) pairs of the current batch
+
+    def install(self):
+        from gamer_amd import ops
+        orig_call, orig_gemm = ops.call, ops.gemm
+        timer = self
+
+        def timed_call(name, *args):
+            if not timer.enabled:
+                return orig_call(name, *args)
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            label, flops = timer._next if timer._next else (name.replace("gamer_", ""), 0.0)
+            timer._next = None
+            s.record()
+            orig_call(name, *args)
+            e.record()
+            timer.records.append((label, s, e, flops))
+
+        def timed_gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, **kw):
+            kind = "gemm_fwd" if (a_ks == 1 and b_ks == 1) else ("gemm_dgrad" if a_ks == 1 else "gemm_wgrad")
+            timer._next = (kind, 2.0 * M * N * K)
+            return orig_gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, **kw)
+
+        orig_af, orig_ab = ops.attn_fwd, ops.attn_bwd
+
+        def timed_attn_fwd(q, ldq, k, ldk, v, ldv, kl, ql, *rest):
+            nq = rest[4]
+            pairs = timer.pairs["self" if ql is None else "cross"]
+            timer._next = ("attn_fwd_self" if ql is None else "attn_fwd_cross", 4.0 * 64 * nq * pairs)
+            return orig_af(q, ldq, k, ldk, v, ldv, kl, ql, *rest)
+
+        def timed_attn_bwd(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, *rest):
+            nq = rest[4]
+            pairs = timer.pairs["self" if ql is None else "cross"]
+            # the delta + dq + dkv launches share one entry point; the label goes to the first (delta),
+            # so time the whole call as one record instead
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            was = timer.enabled
+            timer.enabled = False
+            s.record()
+            r = orig_ab(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, *rest)
+            e.record()
+            timer.enabled = was
+            if was:
+                timer.records.append(("attn_bwd_self" if ql is None else "attn_bwd_cross", s, e, 10.0 * 64 * nq * pairs))
+            return r
+
+        ops.call = timed_call
+        ops.gemm = timed_gemm
+        ops.attn_fwd = timed_attn_fwd
+        ops.attn_bwd = timed_attn_bwd
+
+    def summary(self, steps: int):
+        agg = {}
+        for label, s, e, flops in self.records:
+            d = agg.setdefault(label, dict(ms=0.0, flops=0.0, launches=0))
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += flops
+            d["launches"] += 1
+        out = []
+        for label, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            row = dict(kernel=label, ms_per_step=d["ms"] / steps, launches_per_step=d["launches"] / steps,
+                       avg_launch_ms=d["ms"] / d["launches"])
+            if d["flops"] > 0:
+                row["tflops"] = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            out.append(row)
+        return out
+
+
+def cpu_baseline(cfg_dict, seq_items: int, micro_batch: int = 8, timed_steps: int = 2):
+    """The CPU oracle's train step (fwd + bwd + clip + AdamW, dropout on) on this host's cores."""
+    from oracle import qwen3multi_oracle as orc
+    from gamer_amd import synthetic
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ocfg = orc.OracleConfig.from_dict(cfg_dict)
+    sd = orc.init_state_dict(ocfg, seed=0)
+    params = {k: v.clone() for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v = {k: torch.zeros_like(x) for k, x in sd.items()}
+    times = []
+    for step in range(1 + timed_steps):
+        batch = synthetic.make_batch(micro_batch, seq_items, 256, 3, seed=100 + step, behavior_probs=[0.7, 0.25, 0.05])
+        t0 = time.perf_counter()
+        _, grads, _ = orc.loss_and_grads(params, ocfg, batch, temperature=0.7, training=True)
+        orc.clip_and_adamw(params, grads, m, v, step=step + 1, lr=5e-4)
+        times.append(time.perf_counter() - t0)
+    mean = sum(times[1:]) / len(times[1:])
+    return dict(value=micro_batch / mean, unit="sequences/s", cores=cores, kind="port",
+                sample=f"oracle/qwen3multi_oracle.py train step (fwd+bwd+clip+AdamW, dropout 0.2), micro-batch "
+                       f"{micro_batch} x {seq_items * 5} tokens, 1 warm-up + {timed_steps} timed steps, "
+                       f"torch.set_num_threads({cores})")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="per-GPU micro-batch (sequences)")
+    ap.add_argument("--items", type=int, default=101, help="items per sequence (max_his_len + 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--ragged", action="store_true", help="secondary workload: n_items ~ U{2..items}, right padded")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+
+    from gamer_amd import synthetic
+    from gamer_amd.config import synthetic_config
+    from gamer_amd.dp import GradAllReducer
+    from gamer_amd.engine import Engine
+
+    cfg = synthetic_config()
+    if args.no_dropout:
+        cfg.dropout_rate = 0.0
+        cfg.attention_dropout = 0.0
+    eng = Engine(cfg, device=f"cuda:{local_rank}", temperature=0.7)
+    eng.init_weights(seed=0)                     # identical replicas on every rank
+    eng.base_seed = 0x5EED + rank                # independent dropout streams per rank
+    reducer = GradAllReducer(eng.flat_g, eng.layout, cfg.num_hidden_layers) if world > 1 else None
+
+    def make(step):
+        b = synthetic.make_batch(args.batch, args.items, 256, 3, ragged=args.ragged,
+                                 seed=20251114 + 1000 * rank + step, behavior_probs=[0.7, 0.25, 0.05])
+        return {k: v.cuda(non_blocking=True) for k, v in b.items()}
+
+    # inputs are resident in HBM before the timed region starts
+    n_batches = min(args.steps + args.warmup, 4)
+    batches = [make(s) for s in range(n_batches)]
+    cpu_batches = [synthetic.make_batch(args.batch, args.items, 256, 3, ragged=args.ragged,
+                                        seed=20251114 + 1000 * rank + s, behavior_probs=[0.7, 0.25, 0.05])
+                   for s in range(n_batches)]
+    flops = [algorithmic_flops(cfg, b) for b in cpu_batches]
+    timer = KernelTimer()
+    timer.install()
+    lr = 5e-4
+    grad_scale = 1.0                              # gradients are already global means (sum CE / global count)
+
+    def step(i):
+        f = flops[i % n_batches]
+        timer.pairs = {"self": f["p_self"], "cross": f["p_cross"]}
+        return eng.train_step(batches[i % n_batches], lr, reducer=reducer, grad_scale=grad_scale)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        loss = step(i)
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        loss = step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    final_loss = float(loss)
+    eng.check_inputs()
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        seqs = args.batch * world * args.steps
+        step_flops = sum(flops[i % n_batches]["step"] for i in range(args.warmup, args.warmup + args.steps)) / args.steps
+        kernels = timer.summary(args.steps)
+        gemm_rows = [k for k in kernels if k["kernel"].startswith("gemm")]
+        dom = max(gemm_rows, key=lambda k: k["ms_per_step"]) if gemm_rows else None
+        gemm_ms = sum(k["ms_per_step"] for k in gemm_rows)
+        gemm_tf = sum(k["tflops"] * k["ms_per_step"] for k in gemm_rows) / max(gemm_ms, 1e-9)
+        ms_per_step = elapsed / args.steps * 1e3
+        result = {
+            "metric": "train-step sequences/sec, Qwen3Multi SMB decoder, his_len=100",
+            "value": seqs / elapsed,
+            "unit": "sequences/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": ("Qwen3Multi SMB decoder train step (fwd+bwd+clip+AdamW, dropout 0.2), ShortVideoAD-shaped "
+                             f"synthetic ids, per-GPU batch {args.batch} x {args.items * 5} tokens"
+                             + (" ragged" if args.ragged else "") + ", V=1041, fp32"),
+                "global_batch": args.batch * world,
+                "seq_len": args.items * 5,
+                "parallelism": f"dp{world}",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": f"gemm_f32_kernel ({dom['kernel']})" if dom else None,
+                "achieved": dom["tflops"] if dom else None,
+                "peak": FP32_MATRIX_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": dom["tflops"] / FP32_MATRIX_PEAK_TFLOPS if dom else None,
+                "traffic": None,
+                "avg_launch_ms": dom["avg_launch_ms"] if dom else None,
+                "all_gemm_tflops": gemm_tf,
+                "all_gemm_ms_per_step": gemm_ms,
+                "step_algorithmic_tflops": step_flops / (ms_per_step * 1e-3) / 1e12,
+                "step_frac_of_fp32_matrix_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+            },
+            "kernels": kernels[:12],
+            "loss": final_loss,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg.to_dict(), args.items)
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,144 @@
+"""Configuration object with the reference's config.json schema.
+
+Mirrors what ``Qwen3MoeConfig.from_pretrained(config_dir)`` + the run-time mutation in
+ref:SeqRec/tasks/train_SMB_decoder.py:321-360 give the model: the same keys
+(ref:config/s2s-models/Qwen3Multi/config.json), attribute access, ``in`` tests and
+``save_pretrained`` / ``from_pretrained`` round trips, without needing ``transformers``.
+"""
+from __future__ import annotations
+
+import copy
+import json
+import os
+from typing import Any, Dict
+
+_DEFAULTS: Dict[str, Any] = {
+    # ref:config/s2s-models/Qwen3Multi/config.json
+    "architectures": ["Qwen3ForCausalLM"],
+    "mlp_type": "Qwen3",
+    "Moe_behavior_only": False,
+    "moe_intermediate_size": 256,
+    "behavior_injection": True,
+    "behavior_embedding_dim": 64,
+    "sparse_layers_decoder": [0, 1, 2, 3, 4, 5, 6, 7],
+    "behavior_injection_decoder": [0, 1, 2, 3],
+    "cross_attention_decoder": [4, 5, 6, 7],
+    "dropout_rate": 0.2,
+    "attention_bias": False,
+    "attention_dropout": 0.2,
+    "bos_token_id": 4,
+    "pad_token_id": 4,
+    "eos_token_id": 8,
+    "head_dim": 64,
+    "hidden_act": "silu",
+    "hidden_size": 256,
+    "initializer_range": 0.02,
+    "intermediate_size": 512,
+    "max_position_embeddings": 40960,
+    "max_window_layers": 8,
+    "model_type": "qwen3",
+    "num_attention_heads": 6,
+    "num_hidden_layers": 8,
+    "num_key_value_heads": 3,
+    "rms_norm_eps": 1e-6,
+    "rope_scaling": None,
+    "rope_theta": 1000000,
+    "sliding_window": None,
+    "tie_word_embeddings": True,
+    "torch_dtype": "float32",
+    "use_cache": True,
+    "use_sliding_window": False,
+    "vocab_size": 14,
+    # run-time fields (train_SMB_decoder.py:335-360)
+    "num_behavior": 0,
+    "behavior_maps": {},
+    "use_behavior_token": True,
+    "num_positions": 5,
+    "num_experts": 6,
+    "n_positions": 101,
+    "use_user_token": False,
+    "model_max_length": 1024,
+}
+
+
+class Qwen3MultiConfig:
+    """Plain attribute bag with dict semantics (``'num_positions' in config`` works as in HF)."""
+
+    def __init__(self, **kwargs):
+        d = copy.deepcopy(_DEFAULTS)
+        d.update(kwargs)
+        if "sparse_layers_decoder" not in kwargs:
+            d["sparse_layers_decoder"] = list(range(int(d["num_hidden_layers"])))
+        self.__dict__.update(d)
+
+    # --- HF-like surface ---------------------------------------------------------------------
+    def __contains__(self, key):
+        return key in self.__dict__
+
+    def to_dict(self) -> Dict[str, Any]:
+        d = copy.deepcopy(self.__dict__)
+        d["behavior_maps"] = {str(k): int(v) for k, v in d.get("behavior_maps", {}).items()}
+        return d
+
+    @classmethod
+    def from_dict(cls, d: Dict[str, Any]) -> "Qwen3MultiConfig":
+        return cls(**d)
+
+    @classmethod
+    def from_pretrained(cls, path: str) -> "Qwen3MultiConfig":
+        f = os.path.join(path, "config.json") if os.path.isdir(path) else path
+        with open(f) as fh:
+            return cls(**json.load(fh))
+
+    def save_pretrained(self, path: str):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as fh:
+            json.dump(self.to_dict(), fh, indent=2, sort_keys=True)
+
+    # --- validation of what the HIP kernels are built for --------------------------------------
+    def validate(self):
+        if self.mlp_type != "Qwen3":
+            raise ValueError("only mlp_type='Qwen3' (MyQwen3SparseMLP) is implemented")
+        if self.head_dim != 64:
+            raise ValueError("the attention kernels are built for head_dim=64")
+        if self.behavior_embedding_dim != self.head_dim:
+            raise ValueError("behavior_embedding_dim must equal head_dim (q/k/v bias tables are viewed per head)")
+        if self.moe_intermediate_size != self.hidden_size:
+            raise ValueError("moe_intermediate_size must equal hidden_size (expert input/output is the hidden state)")
+        if self.num_attention_heads // self.num_key_value_heads not in (1, 2) or \
+                self.num_attention_heads % self.num_key_value_heads:
+            raise ValueError("GQA group (num_attention_heads / num_key_value_heads) must be 1 or 2")
+        if self.hidden_size % 4 or self.hidden_size > 1024 or self.intermediate_size % 4:
+            raise ValueError("hidden_size must be a multiple of 4 and <= 1024")
+        if self.num_behavior + 1 > 8:
+            raise ValueError("at most 7 behaviours are supported by the bias-gradient kernels")
+        if sorted(self.sparse_layers_decoder) != list(range(self.num_hidden_layers)):
+            raise ValueError("every decoder layer must be sparse (position-routed experts)")
+        if self.Moe_behavior_only or self.use_user_token or not self.use_behavior_token:
+            raise ValueError("only the shipped routing mode is implemented "
+                             "(Moe_behavior_only=False, use_user_token=False, use_behavior_token=True)")
+        if self.num_experts != self.num_positions + 1:
+            raise ValueError("num_experts must be num_positions + 1")
+        if not self.tie_word_embeddings:
+            raise ValueError("lm_head is tied to embed_tokens in this model")
+
+    def behavior_lut(self):
+        """int32 table token id -> behaviour index (or -1), what the router kernel consumes."""
+        import torch
+        lut = torch.full((int(self.vocab_size),), -1, dtype=torch.int32)
+        for tok, idx in self.behavior_maps.items():
+            if 0 <= int(tok) < self.vocab_size:
+                lut[int(tok)] = int(idx)
+        return lut
+
+
+def synthetic_config(codebook: int = 256, num_behavior: int = 3, **overrides) -> Qwen3MultiConfig:
+    """The shipped architecture with the vocabulary of ``gamer_amd.synthetic``."""
+    from . import synthetic
+    cfg = Qwen3MultiConfig(
+        vocab_size=synthetic.vocab_size(codebook, num_behavior),
+        num_behavior=num_behavior,
+        behavior_maps={str(k): v for k, v in synthetic.behavior_maps(codebook, num_behavior).items()},
+        **overrides,
+    )
+    return cfg

@@ -369,8 +369,9 @@ qknorm_rope_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ 
 // residual + dropout, SwiGLU, SiLU gate
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(EW_THREADS)
-residual_dropout_fwd_kernel(float4* __restrict__ x, const float4* __restrict__ delta,
-                            const int32_t* __restrict__ src_rows, int T, int H4, float p, uint64_t seed) {
+residual_dropout_fwd_kernel(const float4* x_in, const float4* __restrict__ delta,
+                            const int32_t* __restrict__ src_rows, int T, int H4, float p, uint64_t seed,
+                            float4* x_out) {
     const DropoutRng rng(p, seed);
     const int64_t total = (int64_t)T * H4;
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
@@ -378,11 +379,11 @@ residual_dropout_fwd_kernel(float4* __restrict__ x, const float4* __restrict__ d
         const int c = (int)(i % H4);
         const int64_t r = src_rows ? src_rows[t] : t;
         const float4 d = delta[r * H4 + c];
-        float4 v = x[i];
+        float4 v = x_in[i];
         const uint64_t e = (uint64_t)i * 4;
         v.x += rng.mult(e) * d.x; v.y += rng.mult(e + 1) * d.y;
         v.z += rng.mult(e + 2) * d.z; v.w += rng.mult(e + 3) * d.w;
-        x[i] = v;
+        x_out[i] = v;
     }
 }
 
@@ -691,12 +692,13 @@ extern "C" int gamer_qknorm_rope_bwd(const float* qkv, const float* dq_rot, cons
     return 0;
 }
 
-extern "C" int gamer_residual_dropout_fwd(float* x, const float* delta, const int32_t* src_rows, int T, int H,
-                                          float p_drop, uint64_t seed, void* stream) {
-    GAMER_CHECK_ARG(x && delta && T > 0 && H > 0 && H % 4 == 0 && p_drop >= 0.f && p_drop < 1.f,
+extern "C" int gamer_residual_dropout_fwd(const float* x_in, const float* delta, const int32_t* src_rows, int T, int H,
+                                          float p_drop, uint64_t seed, float* x_out, void* stream) {
+    GAMER_CHECK_ARG(x_in && x_out && delta && T > 0 && H > 0 && H % 4 == 0 && p_drop >= 0.f && p_drop < 1.f,
                     "gamer_residual_dropout_fwd: bad arguments T=%d H=%d p=%f", T, H, p_drop);
     hipLaunchKernelGGL(residual_dropout_fwd_kernel, dim3(grid_for_threads((int64_t)T * H / 4)), dim3(EW_THREADS), 0,
-                       ST(stream), (float4*)x, (const float4*)delta, src_rows, T, H / 4, p_drop, seed);
+                       ST(stream), (const float4*)x_in, (const float4*)delta, src_rows, T, H / 4, p_drop, seed,
+                       (float4*)x_out);
     GAMER_CHECK_LAUNCH("gamer_residual_dropout_fwd");
     return 0;
 }

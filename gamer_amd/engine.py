@@ -1,0 +1,516 @@
+"""Train-step engine for the Qwen3Multi SMB decoder on MI355X.
+
+Host-side orchestration of the HIP kernels behind the C ABI (``gamer_amd.ops``): explicit
+forward and backward chains over pre-allocated HBM buffers, flat fp32 parameter / gradient /
+Adam-moment buffers, fused clip+AdamW.  No autograd, no host synchronisation in the steady state
+(the reference has >= 48 host syncs per forward from its boolean-mask expert loop,
+ref:SeqRec/models/generative/Qwen3Moe/FFN.py:63-68).
+
+What it computes is Appendix A of SURVEY.md, i.e.
+  ref:SeqRec/models/generative/Qwen3Multi/model.py:744-880 (Qwen3MultiModel.forward),
+  :186-247 (decoder layer), :75-150 (attention), :904-922,928-1013 (head + temperature loss),
+  ref:SeqRec/models/generative/Qwen3Moe/FFN.py:53-72 (position-routed SwiGLU experts),
+and the HF-Trainer update of ref:SeqRec/tasks/train_SMB_decoder.py:396-444.
+
+Data layout in HBM (T = B*S tokens, row t = b*S + s, everything fp32):
+  residual stream   [T,H] snapshots per sub-block (needed by the RMSNorm backward)
+  q|k|v             [T,(nq+2nkv)*64] fused projection output, v consumed in place by attention
+  q_rot, k_rot      [T,nq*64], [T,nkv*64] after per-head RMSNorm + RoPE
+  FFN tensors       expert-sorted order [T,*] (slot = expert-major, token order inside an expert),
+                    so the three expert GEMMs are dense grouped GEMMs with device-side offsets
+  logits            [T, round_up(V,32)]
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .config import Qwen3MultiConfig
+
+IGNORE_INDEX = -100
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class ParamLayout:
+    """Flat fp32 layout of all parameters under the reference's state-dict names.
+
+    Decayed parameters first, RMSNorm weights (no weight decay under HF Trainer) last, so the
+    fused AdamW kernel needs a single boundary.  q/k/v projection weights of one attention are
+    adjacent (one fused [768,256] GEMM operand) and the experts' gate / up / down weights of a layer
+    are stacked per kind (grouped GEMM with a constant stride).
+    """
+
+    def __init__(self, cfg: Qwen3MultiConfig):
+        H, dh = cfg.hidden_size, cfg.head_dim
+        nq, nkv, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size
+        Eb, NB1, E = cfg.behavior_embedding_dim, cfg.num_behavior + 1, cfg.num_experts
+        decay: List[Tuple[str, tuple]] = [("model.embed_tokens.weight", (cfg.vocab_size, H))]
+        nodecay: List[Tuple[str, tuple]] = []
+        for l in range(cfg.num_hidden_layers):
+            lp = f"model.layers.{l}."
+            cross = l in cfg.cross_attention_decoder
+            inject = l in cfg.behavior_injection_decoder
+            for a in (["self_attn", "cross_attn"] if cross else ["self_attn"]):
+                ap = lp + a + "."
+                decay += [(ap + "q_proj.weight", (nq * dh, H)), (ap + "k_proj.weight", (nkv * dh, H)),
+                          (ap + "v_proj.weight", (nkv * dh, H)), (ap + "o_proj.weight", (H, nq * dh))]
+                nodecay += [(ap + "q_norm.weight", (dh,)), (ap + "k_norm.weight", (dh,))]
+                if a == "cross_attn":
+                    decay += [(ap + "gating.weight", (H, H)),
+                              (ap + "q_behavior_embedding.weight", (NB1, nq * Eb)),
+                              (ap + "k_behavior_embedding.weight", (NB1, nkv * Eb)),
+                              (ap + "v_behavior_embedding.weight", (NB1, nkv * Eb))]
+            din = H + (Eb if inject else 0)
+            for kind, shp in (("gate_proj", (I, din)), ("up_proj", (I, din)), ("down_proj", (H, I))):
+                for e in range(E):
+                    decay.append((f"{lp}mlp.experts.expert_{e}.{kind}.weight", shp))
+            if inject:
+                decay.append((lp + "mlp.behavior_embedding.weight", (NB1, Eb)))
+            nodecay.append((lp + "input_layernorm.weight", (H,)))
+            if cross:
+                nodecay.append((lp + "post_self_attention_layernorm.weight", (H,)))
+            nodecay.append((lp + "post_cross_attention_layernorm.weight", (H,)))
+        nodecay.append(("model.norm.weight", (H,)))
+        self.entries: Dict[str, Tuple[int, tuple]] = {}
+        off = 0
+        for name, shp in decay:
+            n = math.prod(shp)
+            assert n % 4 == 0, f"{name}: size {n} is not a multiple of 4"
+            self.entries[name] = (off, shp)
+            off += n
+        self.n_decay = off
+        for name, shp in nodecay:
+            n = math.prod(shp)
+            assert n % 4 == 0
+            self.entries[name] = (off, shp)
+            off += n
+        self.numel = off
+
+    def views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        return {k: flat[o:o + math.prod(s)].view(s) for k, (o, s) in self.entries.items()}
+
+    def span(self, flat: torch.Tensor, first: str, rows: int, cols: int) -> torch.Tensor:
+        """[rows, cols] view that starts at parameter `first` and runs over its successors."""
+        o = self.entries[first][0]
+        return flat[o:o + rows * cols].view(rows, cols)
+
+
+class _LayerW:
+    """Fused weight views of one decoder layer over a flat buffer (parameters or gradients)."""
+
+    def __init__(self, cfg, layout: ParamLayout, flat: torch.Tensor, l: int):
+        H, dh = cfg.hidden_size, cfg.head_dim
+        nq, nkv, I, E = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size, cfg.num_experts
+        QKV = (nq + 2 * nkv) * dh
+        v = layout.views(flat)
+        lp = f"model.layers.{l}."
+        self.cross = l in cfg.cross_attention_decoder
+        self.inject = l in cfg.behavior_injection_decoder
+        self.din = H + (cfg.behavior_embedding_dim if self.inject else 0)
+
+        def attn(prefix):
+            d = dict(qkv=layout.span(flat, prefix + "q_proj.weight", QKV, H), o=v[prefix + "o_proj.weight"],
+                     qn=v[prefix + "q_norm.weight"], kn=v[prefix + "k_norm.weight"])
+            if prefix.endswith("cross_attn."):
+                d.update(gate=v[prefix + "gating.weight"], bq=v[prefix + "q_behavior_embedding.weight"],
+                         bk=v[prefix + "k_behavior_embedding.weight"], bv=v[prefix + "v_behavior_embedding.weight"])
+            return d
+        self.self_attn = attn(lp + "self_attn.")
+        self.cross_attn = attn(lp + "cross_attn.") if self.cross else None
+        self.ln1 = v[lp + "input_layernorm.weight"]
+        self.ln2 = v[lp + "post_self_attention_layernorm.weight"] if self.cross else None
+        self.ln3 = v[lp + "post_cross_attention_layernorm.weight"]
+        self.gate = layout.span(flat, f"{lp}mlp.experts.expert_0.gate_proj.weight", E * I, self.din)
+        self.up = layout.span(flat, f"{lp}mlp.experts.expert_0.up_proj.weight", E * I, self.din)
+        self.down = layout.span(flat, f"{lp}mlp.experts.expert_0.down_proj.weight", E * H, I)
+        self.beh = v[lp + "mlp.behavior_embedding.weight"] if self.inject else None
+
+
+class _Workspace:
+    """All activation / scratch buffers for one (B, S) shape."""
+
+    def __init__(self, cfg: Qwen3MultiConfig, B: int, S: int, device, train: bool):
+        f32 = dict(dtype=torch.float32, device=device)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.B, self.S, self.T = B, S, B * S
+        T, H = self.T, cfg.hidden_size
+        nq, nkv, dh, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size
+        NQ, NKV = nq * dh, nkv * dh
+        QKV = NQ + 2 * NKV
+        L, E = cfg.num_hidden_layers, cfg.num_experts
+        din_max = H + cfg.behavior_embedding_dim
+        self.router = ops.alloc_router_outputs(B, S, device)
+        self.perm = torch.empty(T, **i32)
+        self.slot = torch.empty(T, **i32)
+        self.offsets = torch.empty(E + 1, **i32)
+        self.work = torch.empty((B + 1) * E, **i32)
+        self.ldl = _round_up(cfg.vocab_size, 32)
+        self.logits = torch.empty(T, self.ldl, **f32)
+        self.lse_ce = torch.empty(T, **f32)
+        self.row_loss = torch.empty(T, **f32)
+        self.loss_sum = torch.zeros(1, **f32)
+        self.count = torch.zeros(1, **f32)
+        self.xn = torch.empty(T, H, **f32)
+        # residual stream snapshots: x[l][0] layer input, [1] after self-attn, [2] after cross-attn
+        self.x: List[List[torch.Tensor]] = []
+        self.layers: List[dict] = []
+        keep = train            # eval keeps one set of buffers and reuses it for every layer
+        shared: Optional[dict] = None
+        for l in range(L):
+            cross = l in cfg.cross_attention_decoder
+            inject = l in cfg.behavior_injection_decoder
+            if keep or shared is None:
+                d = dict(
+                    h1=torch.empty(T, H, **f32), qkv=torch.empty(T, QKV, **f32), q=torch.empty(T, NQ, **f32),
+                    k=torch.empty(T, NKV, **f32), ao=torch.empty(T, NQ, **f32), lse=torch.empty(B, nq, S, **f32),
+                    hin=torch.empty(T, din_max, **f32), g=torch.empty(T, I, **f32), u=torch.empty(T, I, **f32))
+                if cross or not keep:
+                    d.update(h2=torch.empty(T, H, **f32), qkv_c=torch.empty(T, QKV, **f32),
+                             q_c=torch.empty(T, NQ, **f32), k_c=torch.empty(T, NKV, **f32),
+                             ao_c=torch.empty(T, NQ, **f32), lse_c=torch.empty(B, nq, S, **f32),
+                             op_c=torch.empty(T, H, **f32), gate_c=torch.empty(T, H, **f32))
+                shared = d
+            self.layers.append(shared if not keep else d)
+            if keep or l == 0:
+                xs = [torch.empty(T, H, **f32), torch.empty(T, H, **f32)]
+                xs.append(torch.empty(T, H, **f32) if (cross or not keep) else None)
+                self.x.append(xs)
+            else:
+                self.x.append(self.x[0])
+        self.x_final = torch.empty(T, H, **f32) if keep else self.x[0][0]
+        # scratch shared by all layers
+        self.tmpH = [torch.empty(T, H, **f32) for _ in range(4)]
+        self.hm = torch.empty(T, I, **f32)
+        if train:
+            self.dx = torch.empty(T, H, **f32)
+            self.dhm = torch.empty(T, I, **f32)
+            self.dhin = torch.empty(T, din_max, **f32)
+            self.dqkv = torch.empty(T, QKV, **f32)
+            self.dq = torch.empty(T, NQ, **f32)
+            self.dk = torch.empty(T, NKV, **f32)
+            self.dao = torch.empty(T, NQ, **f32)
+            self.delta = torch.empty(B, nq, S, **f32)
+            self.norm_partial = torch.empty(512, H, **f32)
+
+
+class Engine:
+    """Owns the flat parameter/gradient/optimizer buffers and runs forward / backward / update."""
+
+    N_NORM_PARTIAL = 512
+    N_SUMSQ_PARTIAL = 1024
+
+    def __init__(self, cfg: Qwen3MultiConfig, device="cuda", temperature: float = 1.0):
+        cfg.validate()
+        if not torch.cuda.is_available():
+            raise RuntimeError("gamer_amd.Engine needs a HIP device (there is no CPU fallback)")
+        from . import _lib
+        _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.temperature = float(temperature)
+        self.layout = ParamLayout(cfg)
+        n = self.layout.numel
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.flat_m: Optional[torch.Tensor] = None
+        self.flat_v: Optional[torch.Tensor] = None
+        self.params = self.layout.views(self.flat_p)
+        self.grads = self.layout.views(self.flat_g)
+        L = cfg.num_hidden_layers
+        self.W = [_LayerW(cfg, self.layout, self.flat_p, l) for l in range(L)]
+        self.G = [_LayerW(cfg, self.layout, self.flat_g, l) for l in range(L)]
+        self.lut = cfg.behavior_lut().to(self.device)
+        self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._ws: Dict[Tuple[int, int, bool], _Workspace] = {}
+        self.ws: Optional[_Workspace] = None
+        self.opt_step = 0
+        self.dropout_step = 0
+        self.base_seed = 0x5EED
+        self.sumsq_partial = torch.empty(self.N_SUMSQ_PARTIAL, dtype=torch.float32, device=self.device)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._saved = None
+
+    # ------------------------------------------------------------------------------------------
+    def init_weights(self, seed: int = 0):
+        """normal(0, initializer_range) for matrices/embeddings, ones for RMSNorm weights, zero padding
+        row (HF _init_weights semantics; the reference's resize_token_embeddings mean-resizing is not
+        reproduced)."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        std = self.cfg.initializer_range
+        for name, (off, shp) in self.layout.entries.items():
+            n = math.prod(shp)
+            if len(shp) == 1:
+                self.flat_p[off:off + n].fill_(1.0)
+            else:
+                self.flat_p[off:off + n].copy_(torch.randn(n, generator=g) * std)
+        self.params["model.embed_tokens.weight"][self.cfg.pad_token_id].zero_()
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        missing = [k for k in self.layout.entries if k not in sd]
+        if missing:
+            raise KeyError(f"missing parameters: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+        for k, p in self.params.items():
+            if tuple(sd[k].shape) != tuple(p.shape):
+                raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != {tuple(p.shape)}")
+            p.copy_(sd[k].to(torch.float32))
+
+    def rope(self, S: int):
+        if S not in self._rope:
+            # Qwen3RotaryEmbedding.forward with position_ids = arange(S), fp32 on the host (bit-identical
+            # to the table the reference builds on CPU).
+            dh, theta = self.cfg.head_dim, float(self.cfg.rope_theta)
+            inv_freq = 1.0 / (theta ** (torch.arange(0, dh, 2, dtype=torch.int64).to(torch.float32) / dh))
+            freqs = torch.arange(S, dtype=torch.float32)[:, None] * inv_freq[None, :]
+            emb = torch.cat((freqs, freqs), dim=-1)
+            self._rope[S] = (emb.cos().to(self.device).contiguous(), emb.sin().to(self.device).contiguous())
+        return self._rope[S]
+
+    def workspace(self, B: int, S: int, train: bool) -> _Workspace:
+        key = (B, S, train)
+        if key not in self._ws:
+            self._ws.clear()                      # one live shape at a time: activations are tens of GB
+            self._ws[key] = _Workspace(self.cfg, B, S, self.device, train)
+        return self._ws[key]
+
+    def _seed(self, layer: int, site: int) -> int:
+        return ((self.base_seed & 0xFFFF) << 48) | ((self.dropout_step & 0xFFFFFFFF) << 16) | (layer << 4) | site
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, input_ids, attention_mask=None, actions=None, labels=None, num_items_in_batch=None,
+                train: bool = False, dropout: Optional[bool] = None):
+        """Returns (loss or None, logits view [B,S,V]).  With labels the logits are divided by the
+        temperature in place, as the reference does (model.py:913).  ``train`` keeps every activation
+        needed by backward(); ``dropout`` defaults to ``train``."""
+        cfg = self.cfg
+        B, S = input_ids.shape
+        if S % cfg.num_positions != 0:
+            raise ValueError(f"sequence length {S} is not a multiple of num_positions={cfg.num_positions} "
+                             "(the router assumes item-aligned sequences, router.py:78-81)")
+        T, H = B * S, cfg.hidden_size
+        nq, nkv, dh, I, E = (cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size,
+                             cfg.num_experts)
+        NQ, NKV = nq * dh, nkv * dh
+        QKV = NQ + 2 * NKV
+        eps = float(cfg.rms_norm_eps)
+        use_drop = train if dropout is None else dropout
+        p_res = float(cfg.dropout_rate) if use_drop else 0.0
+        p_att = float(cfg.attention_dropout) if use_drop else 0.0
+        if use_drop:
+            self.dropout_step += 1
+        ws = self.workspace(B, S, train)
+        self.ws = ws
+        ids = input_ids.to(self.device, torch.int64).contiguous()
+        am = attention_mask.to(self.device, torch.int64).contiguous() if attention_mask is not None else None
+        act = actions.to(self.device, torch.int64).contiguous() if actions is not None else None
+        lab = labels.to(self.device, torch.int64).contiguous() if labels is not None else None
+        r = ws.router
+        r["bad_token"].zero_()
+        ops.router_fwd(ids, am, act, self.lut, cfg.num_positions, cfg.pad_token_id, cfg.eos_token_id, r)
+        ops.expert_lists(r["expert"], E, ws.perm, ws.slot, ws.offsets, ws.work)
+        cos, sin = self.rope(S)
+        scale = float(dh) ** -0.5
+        x = ws.x[0][0]
+        ops.embedding_fwd(ids, self.params["model.embed_tokens.weight"], x)
+        t0, t1 = ws.tmpH[0], ws.tmpH[1]
+        for l in range(cfg.num_hidden_layers):
+            W, A, xs = self.W[l], ws.layers[l], ws.x[l]
+            # ---- self attention (model.py:204-217) ----
+            ops.rmsnorm_fwd(xs[0], W.ln1, eps, A["h1"])
+            ops.linear_fwd(A["h1"], H, W.self_attn["qkv"], H, A["qkv"], QKV, T, QKV, H)
+            ops.qknorm_rope_fwd(A["qkv"], S, nq, nkv, W.self_attn["qn"], W.self_attn["kn"], eps, cos, sin, A["q"], A["k"])
+            ops.attn_fwd(A["q"], NQ, A["k"], NKV, A["qkv"][:, NQ + NKV:], QKV, r["kl_self"], None, r["empty_self"],
+                         r["tile_empty_self"], B, S, nq, nkv, scale, p_att, self._seed(l, 0), A["ao"], A["lse"])
+            ops.linear_fwd(A["ao"], NQ, W.self_attn["o"], NQ, t0, H, T, H, NQ)
+            ops.residual_dropout_fwd(xs[0], t0, p_res, self._seed(l, 1), None, xs[1])
+            xcur = xs[1]
+            # ---- behaviour-level "cross" attention (model.py:220-235) ----
+            if W.cross:
+                C = W.cross_attn
+                ops.rmsnorm_fwd(xs[1], W.ln2, eps, A["h2"])
+                ops.linear_fwd(A["h2"], H, C["qkv"], H, A["qkv_c"], QKV, T, QKV, H)
+                ops.qknorm_rope_fwd(A["qkv_c"], S, nq, nkv, C["qn"], C["kn"], eps, cos, sin, A["q_c"], A["k_c"],
+                                    bias_q=C["bq"], bias_k=C["bk"], bias_v=C["bv"], act_idx=r["act_idx"])
+                ops.attn_fwd(A["q_c"], NQ, A["k_c"], NKV, A["qkv_c"][:, NQ + NKV:], QKV, r["kl_cross"], r["ql_cross"],
+                             r["empty_cross"], r["tile_empty_cross"], B, S, nq, nkv, scale, p_att, self._seed(l, 2),
+                             A["ao_c"], A["lse_c"])
+                ops.linear_fwd(A["ao_c"], NQ, C["o"], NQ, A["op_c"], H, T, H, NQ)
+                ops.linear_fwd(A["h2"], H, C["gate"], H, A["gate_c"], H, T, H, H)
+                ops.silu_gate_fwd(A["op_c"], A["gate_c"], t0)
+                ops.residual_dropout_fwd(xs[1], t0, p_res, self._seed(l, 3), None, xs[2])
+                xcur = xs[2]
+            # ---- position-routed SwiGLU experts (model.py:238-241, FFN.py:53-72) ----
+            din = W.din
+            ops.rmsnorm_fwd(xcur, W.ln3, eps, A["hin"], din, ws.slot)
+            if W.inject:
+                ops.rowtable_fwd(W.beh, r["beh_idx"], A["hin"], din, H, ws.slot)
+            grp = dict(groups=E, group_offsets=ws.offsets)
+            ops.linear_fwd(A["hin"], din, W.gate, din, A["g"], I, T, I, din, strideB=I * din, **grp)
+            ops.linear_fwd(A["hin"], din, W.up, din, A["u"], I, T, I, din, strideB=I * din, **grp)
+            ops.swiglu_fwd(A["g"], A["u"], T * I, p_res, self._seed(l, 4), ws.hm)
+            ops.linear_fwd(ws.hm, I, W.down, I, t1, H, T, H, I, strideB=H * I, **grp)
+            xnext = ws.x[l + 1][0] if l + 1 < cfg.num_hidden_layers else ws.x_final
+            ops.residual_dropout_fwd(xcur, t1, p_res, self._seed(l, 5), ws.slot, xnext)
+        # ---- final norm, tied head, temperature CE (model.py:869,1001,904-922) ----
+        V = cfg.vocab_size
+        ops.rmsnorm_fwd(ws.x_final, self.params["model.norm.weight"], eps, ws.xn)
+        ops.linear_fwd(ws.xn, H, self.params["model.embed_tokens.weight"], H, ws.logits, ws.ldl, T, V, H)
+        loss = None
+        if lab is not None:
+            ops.ce_fwd(ws.logits, ws.ldl, lab, V, self.temperature, IGNORE_INDEX, ws.lse_ce, ws.row_loss, ws.loss_sum,
+                       ws.count)
+            if num_items_in_batch is not None:
+                loss = ws.loss_sum[0] / float(num_items_in_batch)
+            else:
+                loss = ws.loss_sum[0] / ws.count[0]
+        self._saved = dict(ids=ids, labels=lab, num_items=num_items_in_batch, train=train, p_res=p_res, p_att=p_att,
+                           B=B, S=S, dropout_step=self.dropout_step)
+        logits = ws.logits.view(B, S, ws.ldl)[:, :, :V]
+        return loss, logits
+
+    def check_inputs(self):
+        """Host-synchronising validation (what the reference would raise on): unknown behaviour tokens."""
+        n = int(self.ws.router["bad_token"].item())
+        if n:
+            raise IndexError(f"{n} item(s) start with a token that is not in config.behavior_maps "
+                             "(the reference fails with an embedding IndexError, router.py:170-171)")
+
+    # ------------------------------------------------------------------------------------------
+    def zero_grad(self):
+        ops.fill(self.flat_g, 0.0)
+
+    def backward(self, dloss: float = 1.0, layer_done=None):
+        """Accumulates d(loss)*dloss into the flat gradient buffer (call zero_grad() first for a fresh
+        window).  Needs a forward(..., labels=..., train=True) before it.  ``layer_done(l)`` is called as
+        soon as every kernel writing layer l's weight gradients has been enqueued (data-parallel
+        all-reduce overlap, gamer_amd.dp)."""
+        sv = self._saved
+        if sv is None or not sv["train"] or sv["labels"] is None:
+            raise RuntimeError("backward() needs forward(train=True, labels=...) first")
+        cfg, ws = self.cfg, self.ws
+        B, S = sv["B"], sv["S"]
+        T, H = B * S, cfg.hidden_size
+        nq, nkv, dh, I, E = (cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size,
+                             cfg.num_experts)
+        NQ, NKV = nq * dh, nkv * dh
+        QKV = NQ + 2 * NKV
+        NB1 = cfg.num_behavior + 1
+        eps = float(cfg.rms_norm_eps)
+        p_res, p_att = sv["p_res"], sv["p_att"]
+        saved_step = self.dropout_step
+        self.dropout_step = sv["dropout_step"]          # regenerate exactly the forward's masks
+        r = ws.router
+        cos, sin = self.rope(S)
+        scale = float(dh) ** -0.5
+        V = cfg.vocab_size
+        emb = self.params["model.embed_tokens.weight"]
+        demb = self.grads["model.embed_tokens.weight"]
+        NP = ws.norm_partial
+
+        def norm_bwd(xin, w, dy, lddy, dw, accumulate_dx, dy_rows=None):
+            ops.rmsnorm_bwd(xin, w, dy, lddy, eps, ws.dx, NP, accumulate_dx, dy_rows)
+            ops.colsum_reduce(NP, dw, accumulate=True)
+
+        # ---- loss -> logits -> final norm ----
+        if sv["num_items"] is not None:
+            ops.ce_bwd(ws.logits, ws.ldl, sv["labels"], V, self.temperature, IGNORE_INDEX, ws.lse_ce, None,
+                       float(sv["num_items"]), dloss)
+        else:
+            ops.ce_bwd(ws.logits, ws.ldl, sv["labels"], V, self.temperature, IGNORE_INDEX, ws.lse_ce, ws.count, 0.0,
+                       dloss)
+        ops.linear_wgrad(ws.logits, ws.ldl, ws.xn, H, demb, H, T, V, H)
+        t0, t1, t2, t3 = ws.tmpH
+        ops.linear_dgrad(ws.logits, ws.ldl, emb, H, t0, H, T, V, H)
+        norm_bwd(ws.x_final, self.params["model.norm.weight"], t0, H, self.grads["model.norm.weight"], False)
+
+        for l in reversed(range(cfg.num_hidden_layers)):
+            W, G, A, xs = self.W[l], self.G[l], ws.layers[l], ws.x[l]
+            din = W.din
+            grp = dict(groups=E, group_offsets=ws.offsets)
+            xlast = xs[2] if W.cross else xs[1]
+            # ---- experts ----
+            ops.residual_dropout_bwd(ws.dx, p_res, self._seed(l, 5), t0, ws.slot)          # d out_sorted
+            ops.swiglu_fwd(A["g"], A["u"], T * I, p_res, self._seed(l, 4), ws.hm)           # recompute hm
+            ops.linear_wgrad(t0, H, ws.hm, I, G.down, I, T, H, I, strideC=H * I, **grp)
+            ops.linear_dgrad(t0, H, W.down, I, ws.dhm, I, T, H, I, strideB=H * I, **grp)
+            ops.swiglu_bwd(A["g"], A["u"], ws.dhm, T * I, p_res, self._seed(l, 4))          # g <- dg, u <- du
+            ops.linear_wgrad(A["g"], I, A["hin"], din, G.gate, din, T, I, din, strideC=I * din, **grp)
+            ops.linear_wgrad(A["u"], I, A["hin"], din, G.up, din, T, I, din, strideC=I * din, **grp)
+            ops.linear_dgrad(A["g"], I, W.gate, din, ws.dhin, din, T, I, din, strideB=I * din, **grp)
+            ops.linear_dgrad(A["u"], I, W.up, din, ws.dhin, din, T, I, din, accumulate=True, strideB=I * din, **grp)
+            if W.inject:
+                ops.rowtable_bwd(ws.dhin, din, H, r["beh_idx"], G.beh, ws.slot)
+            norm_bwd(xlast, W.ln3, ws.dhin, din, G.ln3, True, ws.slot)
+            # ---- cross attention ----
+            if W.cross:
+                C, GC = W.cross_attn, G.cross_attn
+                ops.residual_dropout_bwd(ws.dx, p_res, self._seed(l, 3), t0)                # d (op * silu(gate))
+                ops.silu_gate_bwd(A["op_c"], A["gate_c"], t0, t1, t2)                       # t1 = d op, t2 = d gate
+                ops.linear_wgrad(t1, H, A["ao_c"], NQ, GC["o"], NQ, T, H, NQ)
+                ops.linear_wgrad(t2, H, A["h2"], H, GC["gate"], H, T, H, H)
+                ops.linear_dgrad(t1, H, C["o"], NQ, ws.dao, NQ, T, H, NQ)
+                ops.attn_bwd(A["q_c"], NQ, A["k_c"], NKV, A["qkv_c"][:, NQ + NKV:], QKV, A["ao_c"], ws.dao, A["lse_c"],
+                             r["kl_cross"], r["ql_cross"], r["empty_cross"], r["tile_empty_cross"], B, S, nq, nkv,
+                             scale, p_att, self._seed(l, 2), ws.delta, ws.dq, NQ, ws.dk, NKV,
+                             ws.dqkv[:, NQ + NKV:], QKV)
+                ops.qknorm_rope_bwd(A["qkv_c"], ws.dq, ws.dk, S, nq, nkv, C["qn"], C["kn"], eps, cos, sin, ws.dqkv,
+                                    GC["qn"], GC["kn"], bias_q=C["bq"], bias_k=C["bk"], act_idx=r["act_idx"], nb1=NB1,
+                                    dbias_q=GC["bq"], dbias_k=GC["bk"], dbias_v=GC["bv"])
+                ops.linear_wgrad(ws.dqkv, QKV, A["h2"], H, GC["qkv"], H, T, QKV, H)
+                ops.linear_dgrad(ws.dqkv, QKV, C["qkv"], H, t3, H, T, QKV, H)
+                ops.linear_dgrad(t2, H, C["gate"], H, t3, H, T, H, H, accumulate=True)
+                norm_bwd(xs[1], W.ln2, t3, H, G.ln2, True)
+            # ---- self attention ----
+            SA, GS = W.self_attn, G.self_attn
+            ops.residual_dropout_bwd(ws.dx, p_res, self._seed(l, 1), t0)
+            ops.linear_wgrad(t0, H, A["ao"], NQ, GS["o"], NQ, T, H, NQ)
+            ops.linear_dgrad(t0, H, SA["o"], NQ, ws.dao, NQ, T, H, NQ)
+            ops.attn_bwd(A["q"], NQ, A["k"], NKV, A["qkv"][:, NQ + NKV:], QKV, A["ao"], ws.dao, A["lse"], r["kl_self"],
+                         None, r["empty_self"], r["tile_empty_self"], B, S, nq, nkv, scale, p_att, self._seed(l, 0),
+                         ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV)
+            ops.qknorm_rope_bwd(A["qkv"], ws.dq, ws.dk, S, nq, nkv, SA["qn"], SA["kn"], eps, cos, sin, ws.dqkv, GS["qn"],
+                                GS["kn"])
+            ops.linear_wgrad(ws.dqkv, QKV, A["h1"], H, GS["qkv"], H, T, QKV, H)
+            ops.linear_dgrad(ws.dqkv, QKV, SA["qkv"], H, t3, H, T, QKV, H)
+            norm_bwd(xs[0], W.ln1, t3, H, G.ln1, True)
+            if layer_done is not None:
+                layer_done(l)
+        ops.embedding_bwd(sv["ids"], ws.dx, cfg.pad_token_id, demb)
+        self.dropout_step = saved_step
+
+    # ------------------------------------------------------------------------------------------
+    def optimizer_step(self, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, max_norm=1.0,
+                       grad_scale: float = 1.0):
+        """clip_grad_norm_(max_norm) + AdamW on the flat buffers (HF Trainer defaults,
+        ref:SeqRec/tasks/train_SMB_decoder.py:396-428).  ``grad_scale`` multiplies the gradient first
+        (1/world_size after a sum all-reduce, 1/accumulation steps)."""
+        if self.flat_m is None:
+            self.flat_m = torch.zeros_like(self.flat_p)
+            self.flat_v = torch.zeros_like(self.flat_p)
+        self.opt_step += 1
+        ops.sumsq(self.flat_g, self.sumsq_partial)
+        ops.adamw(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.layout.n_decay, float(lr), beta1, beta2, eps,
+                  weight_decay, self.opt_step, float(max_norm), float(grad_scale), self.sumsq_partial, self.grad_norm)
+
+    def train_step(self, batch: Dict[str, torch.Tensor], lr: float, num_items_in_batch=None, reducer=None, **opt):
+        """forward + backward (+ data-parallel gradient sum) + update on one micro-batch.
+
+        With a ``gamer_amd.dp.GradAllReducer`` the label count is summed over ranks before the
+        backward (loss = sum CE / global count, HF average_tokens_across_devices) and the per-layer
+        gradient buckets are all-reduced while the remaining layers' backward runs."""
+        loss, _ = self.forward(batch["input_ids"], batch.get("attention_mask"), batch.get("actions"),
+                               labels=batch["labels"], num_items_in_batch=num_items_in_batch, train=True)
+        self.zero_grad()
+        if reducer is not None and num_items_in_batch is None:
+            from .dp import all_reduce_scalar_
+            all_reduce_scalar_(self.ws.count)
+        self.backward(1.0, layer_done=reducer.layer_done if reducer is not None else None)
+        if reducer is not None:
+            reducer.finish()
+        self.optimizer_step(lr, **opt)
+        return loss

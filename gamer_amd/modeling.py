@@ -1,0 +1,173 @@
+"""nn.Module surface of the reference model, backed by the HIP engine.
+
+``Qwen3MultiWithTemperature`` mirrors ref:SeqRec/models/generative/Qwen3Multi/model.py:883-1013:
+same constructor (a config object with the fields of train_SMB_decoder.py:335-360), same
+``set_hyper`` / ``forward`` keyword surface, same state-dict key names (so checkpoints written by
+the reference load unchanged), same return fields (``loss``, ``logits``; tuple and key access).
+Parameters are views into the engine's flat fp32 buffer; the whole forward/backward is one
+``torch.autograd.Function`` so HF ``Trainer`` / DDP can drive it, while ``Engine.train_step`` is the
+fused fast path used by bench.py.  There is no CPU implementation here.
+"""
+from __future__ import annotations
+
+import json
+import os
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .config import Qwen3MultiConfig
+from .engine import Engine
+
+
+class CausalLMOutput(OrderedDict):
+    """Minimal stand-in for transformers' CausalLMOutputWithPast: attribute, key and index access."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return [v for v in self.values() if v is not None][k]
+        return super().__getitem__(k)
+
+
+class _ModelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, input_ids, attention_mask, actions, labels, num_items, *params):
+        eng: Engine = model.engine
+        loss, logits = eng.forward(input_ids, attention_mask, actions, labels=labels, num_items_in_batch=num_items,
+                                   train=True, dropout=model.training)
+        ctx.model = model
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, dloss, _dlogits):
+        eng: Engine = ctx.model.engine
+        eng.zero_grad()
+        eng.backward(float(dloss) if dloss is not None else 0.0)
+        grads = [eng.grads[k].clone() for k in ctx.model._param_keys]
+        return (None, None, None, None, None, None, *grads)
+
+
+class Qwen3MultiWithTemperature(nn.Module):
+    def __init__(self, config: Qwen3MultiConfig, device: str = "cuda"):
+        super().__init__()
+        assert "num_positions" in config and isinstance(config.num_positions, int), \
+            "Config must have 'num_positions' attribute for Qwen3SessionModel."
+        assert "model_max_length" in config and isinstance(config.model_max_length, int), \
+            "Config must have 'model_max_length' attribute for Qwen3SessionModel."
+        self.config = config
+        self.vocab_size = config.vocab_size
+        self.temperature = 1.0
+        self.engine = Engine(config, device=device, temperature=1.0)
+        self.engine.init_weights(seed=0)
+        self._param_keys = list(self.engine.layout.entries.keys())
+        self._register_views()
+
+    def _register_views(self):
+        """nn.Parameters that alias the engine's flat buffer, registered under the reference's names."""
+        self._params_by_key = {}
+        for key in self._param_keys:
+            p = nn.Parameter(self.engine.params[key], requires_grad=True)
+            self._params_by_key[key] = p
+            # nested registration without building the reference's module tree
+            self.register_parameter(key.replace(".", "__"), p)
+
+    # ---- reference surface -------------------------------------------------------------------
+    def set_hyper(self, temperature: float):
+        self.temperature = temperature
+        self.engine.temperature = float(temperature)
+
+    def resize_token_embeddings(self, new_num_tokens: int):
+        if new_num_tokens == self.config.vocab_size:
+            return
+        old = {k: v.detach().clone() for k, v in self.state_dict().items()}
+        self.config.vocab_size = int(new_num_tokens)
+        self.vocab_size = int(new_num_tokens)
+        self.engine = Engine(self.config, device=str(self.engine.device), temperature=self.temperature)
+        self.engine.init_weights(seed=0)
+        for k in list(self._parameters):
+            del self._parameters[k]
+        self._param_keys = list(self.engine.layout.entries.keys())
+        self._register_views()
+        with torch.no_grad():
+            for k, p in self.engine.params.items():
+                if k == "model.embed_tokens.weight":
+                    n = min(p.shape[0], old[k].shape[0])
+                    p[:n].copy_(old[k][:n])
+                else:
+                    p.copy_(old[k])
+
+    def state_dict(self, *args, **kwargs):
+        sd = OrderedDict((k, self._params_by_key[k].detach()) for k in self._param_keys)
+        sd["lm_head.weight"] = sd["model.embed_tokens.weight"]          # tied (model.py:888, config.json:34)
+        return sd
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        sd = {k: v for k, v in state_dict.items() if k != "lm_head.weight"}
+        unexpected = [k for k in sd if k not in self.engine.layout.entries]
+        if strict and unexpected:
+            raise KeyError(f"unexpected keys: {unexpected[:5]}")
+        with torch.no_grad():
+            self.engine.load_state_dict({k: v for k, v in sd.items() if k in self.engine.layout.entries})
+
+    def named_parameters(self, prefix: str = "", recurse: bool = True, remove_duplicate: bool = True):
+        for k in self._param_keys:
+            yield (prefix + k, self._params_by_key[k])
+
+    def save_pretrained(self, path: str):
+        os.makedirs(path, exist_ok=True)
+        self.config.save_pretrained(path)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items() if k != "lm_head.weight"}
+        try:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(path, "model.safetensors"))
+        except ImportError:
+            torch.save(sd, os.path.join(path, "pytorch_model.bin"))
+
+    @classmethod
+    def from_pretrained(cls, path: str, device: str = "cuda"):
+        cfg = Qwen3MultiConfig.from_pretrained(path)
+        model = cls(cfg, device=device)
+        st = os.path.join(path, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
+        model.load_state_dict(sd)
+        return model
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
+                inputs_embeds=None, labels=None, use_cache=None, output_attentions=None, output_hidden_states=None,
+                cache_position=None, logits_to_keep=0, session_ids=None, extended_session_ids=None, actions=None,
+                **kwargs):
+        if (input_ids is None) ^ (inputs_embeds is not None):
+            raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
+        if inputs_embeds is not None or past_key_values is not None or use_cache:
+            raise NotImplementedError("gamer_amd implements the training/scoring forward (no KV cache, no inputs_embeds)")
+        if actions is None:
+            raise ValueError("Qwen3Multi needs `actions` (behaviour level per token) for the cross-attention mask")
+        num_items = kwargs.get("num_items_in_batch", None)
+        if torch.is_tensor(num_items):
+            num_items = float(num_items)
+        eng = self.engine
+        needs_grad = torch.is_grad_enabled() and labels is not None
+        if needs_grad:
+            params = [self._params_by_key[k] for k in self._param_keys]
+            loss, logits = _ModelFn.apply(self, input_ids, attention_mask, actions, labels, num_items, *params)
+        else:
+            with torch.no_grad():
+                loss, logits = eng.forward(input_ids, attention_mask, actions, labels=labels,
+                                           num_items_in_batch=num_items, train=False, dropout=False)
+        if isinstance(logits_to_keep, int) and logits_to_keep > 0:
+            logits = logits[:, -logits_to_keep:, :]
+        return CausalLMOutput(loss=loss, logits=logits, past_key_values=None, hidden_states=None, attentions=None)

@@ -131,7 +131,7 @@ def linear_wgrad(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups=1, group_
     """dW[N_out,K_in] += dy[rows,N_out]^T @ x[rows,K_in]   (dW must be initialised; fp32 atomics)."""
     if kchunk is None:
         tiles = ((N_out + 127) // 128) * ((K_in + 127) // 128)
-        kchunk = pick_kchunk(rows, tiles * max(1, groups) if groups > 1 else tiles)
+        kchunk = pick_kchunk(rows, tiles)     # chunks run over all rows of all groups
     gemm(dy, 1, lddy, x, 1, ldx, dW, lddw, N_out, K_in, rows, groups=groups, group_mode=1,
          group_offsets=group_offsets, strideC=strideC, kchunk=kchunk)
 
@@ -163,9 +163,11 @@ def attn_bwd(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty,
          lddk, ptr(dv), lddv, stream_ptr())
 
 
-def residual_dropout_fwd(x, delta, p, seed, src_rows=None):
+def residual_dropout_fwd(x, delta, p, seed, src_rows=None, out=None):
+    """out = x + drop(delta[src]); out defaults to x (in place)."""
     T, H = x.shape
-    call("gamer_residual_dropout_fwd", ptr(x), ptr(delta), ptr(src_rows), T, H, p, seed, stream_ptr())
+    call("gamer_residual_dropout_fwd", ptr(x), ptr(delta), ptr(src_rows), T, H, p, seed,
+         ptr(out if out is not None else x), stream_ptr())
 
 
 def residual_dropout_bwd(dx, p, seed, ddelta, src_rows=None):

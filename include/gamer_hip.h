@@ -186,9 +186,10 @@ int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float
 /* ------------------------------------------------------------------------------------------
  * Elementwise pieces of the decoder layer (model.py:147,217,235,241; FFN.py:25-27).
  * ---------------------------------------------------------------------------------------- */
-/* x[t] += drop(delta[src(t)])   src_rows optional (token -> sorted slot), n = T*H elements      */
-int gamer_residual_dropout_fwd(float* x, const float* delta, const int32_t* src_rows, int T, int H,
-                               float p_drop, uint64_t seed, void* stream);
+/* x_out[t] = x_in[t] + drop(delta[src(t)])   src_rows optional (token -> sorted slot);
+ * x_out may alias x_in (in place).                                                              */
+int gamer_residual_dropout_fwd(const float* x_in, const float* delta, const int32_t* src_rows, int T,
+                               int H, float p_drop, uint64_t seed, float* x_out, void* stream);
 /* ddelta[src(t)] = drop_mask * dx[t]                                                            */
 int gamer_residual_dropout_bwd(const float* dx, const int32_t* src_rows, int T, int H,
                                float p_drop, uint64_t seed, float* ddelta, void* stream);
