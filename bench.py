@@ -138,12 +138,32 @@ class KernelTimer:
         return out
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def log(msg: str):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(cfg_dict, seq_items: int, micro_batch: int = 8, timed_steps: int = 2):
     """The CPU oracle's train step (fwd + bwd + clip + AdamW, dropout on) on this host's cores."""
     from oracle import qwen3multi_oracle as orc
     from gamer_amd import synthetic
-    cores = os.cpu_count() or 1
+    cores = min(usable_cpus(), 64)
     torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
     ocfg = orc.OracleConfig.from_dict(cfg_dict)
     sd = orc.init_state_dict(ocfg, seed=0)
     params = {k: v.clone() for k, v in sd.items()}
@@ -156,6 +176,10 @@ def cpu_baseline(cfg_dict, seq_items: int, micro_batch: int = 8, timed_steps: in
         _, grads, _ = orc.loss_and_grads(params, ocfg, batch, temperature=0.7, training=True)
         orc.clip_and_adamw(params, grads, m, v, step=step + 1, lr=5e-4)
         times.append(time.perf_counter() - t0)
+        log(f"cpu baseline step {step}: {times[-1]:.2f} s")
+        if step >= 1 and sum(times) > 45.0:        # keep the default run within a few minutes
+            break
+    timed_steps = len(times) - 1
     mean = sum(times[1:]) / len(times[1:])
     return dict(value=micro_batch / mean, unit="sequences/s", cores=cores, kind="port",
                 sample=f"oracle/qwen3multi_oracle.py train step (fwd+bwd+clip+AdamW, dropout 0.2), micro-batch "
@@ -229,9 +253,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f"engine ready, {n_batches} batches resident; warm-up")
     for i in range(args.warmup):
         loss = step(i)
     barrier()
+    log("timed region")
     timer.enabled = True
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
@@ -240,6 +266,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timer.enabled = False
     final_loss = float(loss)
+    log(f"timed region done: {elapsed / args.steps * 1e3:.1f} ms/step")
     eng.check_inputs()
     if world > 1:
         import torch.distributed as dist

@@ -285,7 +285,8 @@ class Engine:
     def forward(self, input_ids, attention_mask=None, actions=None, labels=None, num_items_in_batch=None,
                 train: bool = False, dropout: Optional[bool] = None):
         """Returns (loss or None, logits view [B,S,V]).  With labels the logits are divided by the
-        temperature in place, as the reference does (model.py:913).  ``train`` keeps every activation
+        temperature in place, as the reference does (model.py:913).  The view aliases a workspace
+        buffer: backward() overwrites it with d(logits), the next forward() with new logits.  ``train`` keeps every activation
         needed by backward(); ``dropout`` defaults to ``train``."""
         cfg = self.cfg
         B, S = input_ids.shape

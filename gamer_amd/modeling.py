@@ -43,6 +43,7 @@ class _ModelFn(torch.autograd.Function):
         eng: Engine = model.engine
         loss, logits = eng.forward(input_ids, attention_mask, actions, labels=labels, num_items_in_batch=num_items,
                                    train=True, dropout=model.training)
+        logits = logits.clone()          # Engine.backward() reuses the logits buffer for d(logits)
         ctx.model = model
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(logits)
