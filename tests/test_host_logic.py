@@ -1,0 +1,116 @@
+"""Host-side logic that needs no GPU: config schema, flat parameter layout vs the reference's
+state-dict names, synthetic batch format, algorithmic FLOP accounting."""
+import importlib.util
+import os
+import sys
+
+import pytest
+import torch
+
+from gamer_amd import synthetic
+from gamer_amd.config import Qwen3MultiConfig, synthetic_config
+from gamer_amd.engine import ParamLayout
+from oracle import qwen3multi_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_roundtrip_and_validation(tmp_path):
+    cfg = synthetic_config()
+    cfg.validate()
+    assert cfg.vocab_size == 1041 and "num_positions" in cfg and cfg.num_experts == 6
+    cfg.save_pretrained(str(tmp_path))
+    cfg2 = Qwen3MultiConfig.from_pretrained(str(tmp_path))
+    assert cfg2.to_dict() == cfg.to_dict()
+    bad = synthetic_config(head_dim=32)
+    with pytest.raises(ValueError):
+        bad.validate()
+    lut = cfg.behavior_lut()
+    assert lut.shape == (1041,) and lut[1038] == 0 and lut[1040] == 2 and int((lut >= 0).sum()) == 3
+
+
+def test_reference_config_json_loads_when_present():
+    path = "/root/reference/config/s2s-models/Qwen3Multi"
+    if not os.path.isdir(path):
+        pytest.skip("reference not mounted")
+    cfg = Qwen3MultiConfig.from_pretrained(path)
+    assert cfg.hidden_size == 256 and cfg.cross_attention_decoder == [4, 5, 6, 7] and cfg.vocab_size == 14
+
+
+def test_param_layout_matches_reference_state_dict():
+    cfg = synthetic_config()
+    layout = ParamLayout(cfg)
+    assert layout.numel == 24_535_040                      # parameter count of the reference model
+    shapes = orc.param_shapes(orc.OracleConfig.from_dict(cfg.to_dict()))
+    assert set(layout.entries) == set(shapes)
+    for k, (off, shp) in layout.entries.items():
+        assert tuple(shp) == tuple(shapes[k]), k
+        assert off % 4 == 0
+        assert (off >= layout.n_decay) == orc.is_no_decay(k), k
+    # fused operands are contiguous: q|k|v rows and the stacked experts
+    e = layout.entries
+    q, k_, v = (e[f"model.layers.5.cross_attn.{n}_proj.weight"][0] for n in "qkv")
+    assert k_ - q == 384 * 256 and v - k_ == 192 * 256
+    g0 = e["model.layers.0.mlp.experts.expert_0.gate_proj.weight"][0]
+    g1 = e["model.layers.0.mlp.experts.expert_1.gate_proj.weight"][0]
+    assert g1 - g0 == 512 * 320
+    flat = torch.arange(layout.numel, dtype=torch.float32)
+    views = layout.views(flat)
+    assert views["model.norm.weight"].shape == (256,) and float(views["model.embed_tokens.weight"][0, 0]) == 0.0
+
+
+def test_no_decay_rule_matches_hf_trainer_when_reference_present():
+    """oracle.is_no_decay restates HF Trainer.get_decay_parameter_names for this model."""
+    if not os.path.isdir("/root/reference/SeqRec"):
+        pytest.skip("reference not mounted")
+    try:
+        from transformers import Trainer
+    except Exception:
+        pytest.skip("transformers not importable")
+    from oracle import _ref_loader
+    Model, Cfg = _ref_loader.load_reference_classes()
+    cfg = _ref_loader.reference_config(Cfg, 3, 49, synthetic.behavior_maps(8, 3), num_hidden_layers=5,
+                                       sparse_layers_decoder=[0, 1, 2, 3, 4], cross_attention_decoder=[4])
+    model = Model(cfg)
+    decay = set(Trainer.get_decay_parameter_names(None, model))
+    for name, _ in model.named_parameters():
+        assert (name not in decay) == orc.is_no_decay(name), name
+
+
+def test_synthetic_batch_format():
+    b = synthetic.make_batch(6, 9, 8, 3, ragged=True, seed=4)
+    ids, am, act, lab = b["input_ids"], b["attention_mask"], b["actions"], b["labels"]
+    B, S = ids.shape
+    assert S % 5 == 0 and ids.dtype == torch.int64
+    assert bool(((ids == synthetic.PAD_ID) == (am == 0)).all())
+    assert bool((act[am == 0] == 100).all()) and bool((act[am == 1] <= 2).all())
+    beh = ids[:, ::5]
+    assert bool(((beh >= 14 + 32) | (beh == synthetic.PAD_ID)).all())
+    assert bool((lab[:, ::5] == -100).all()) and bool((lab[am == 0] == -100).all())
+    inner = lab.view(B, -1, 5)[:, :, 1:]
+    assert bool((inner[am.view(B, -1, 5)[:, :, 1:] == 1] >= 14).all())
+    # right padding by whole items
+    lens = am.sum(1)
+    assert bool((lens % 5 == 0).all()) and bool((am[:, :1] == 1).all())
+    # deterministic
+    b2 = synthetic.make_batch(6, 9, 8, 3, ragged=True, seed=4)
+    assert all(torch.equal(b[k], b2[k]) for k in b)
+
+
+def test_algorithmic_flops_match_survey_numbers():
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cfg = synthetic_config()
+    b = synthetic.make_batch(2, 101, 256, 3, seed=0)
+    f = bench.algorithmic_flops(cfg, b)
+    assert f["per_token"] == 14_950_912
+    assert f["p_self"] == 2 * 127_765
+    # brute-force the cross pairs
+    a, keep = b["actions"], b["attention_mask"].bool()
+    S = a.shape[1]
+    i = torch.arange(S).view(1, S, 1)
+    j = torch.arange(S).view(1, 1, S)
+    ok = (j <= i) & (a[:, None, :] < a[:, :, None]) & keep[:, None, :]
+    assert f["p_cross"] == int(ok.sum())
+    assert f["step"] == 3 * f["fwd"]
