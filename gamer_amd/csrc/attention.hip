@@ -17,6 +17,7 @@
 //              dV^T += dO^T P, dK^T += Q^T dS accumulate in registers; the G heads are summed
 //              through LDS at the end.  No atomics anywhere (dQ is recomputed in its own kernel).
 #include "common.h"
+#include <stdlib.h>
 
 namespace gamer {
 
@@ -26,7 +27,46 @@ constexpr int INT_BIG_A = 0x7fffffff;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Optional per-workgroup trace (debug aid for residency studies): when g_trace != nullptr, wave 0 of
+// every forward workgroup records {realtime start, realtime end, HW_ID, XCC_ID} (4 x u64 per workgroup).
+__device__ unsigned long long* g_trace = nullptr;
+
 __device__ __forceinline__ int rowmap(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// Static work partition for persistent workgroups.
+//
+// Measured on MI355X (tools/trace_attn.py): with one workgroup per (sequence, kv head, tile) the causal
+// tiles differ 8x in duration and the in-order round-robin dispatcher (XCD -> SE -> CU) leaves CUs idle
+// behind long workgroups: 1.3 of 2 possible workgroups resident per CU on average, per-CU busy time
+// between 17 % and 98 %.  So the grid is sized to the chip (2 workgroups per CU) and every workgroup
+// walks a list of equal-work items: item = (pair = b*nkv + kvh, u) -> the heavy tile and the matching
+// light tile of that pair, i.e. the same number of inner iterations for every u.
+// Workgroup ids are dealt round-robin over the 8 XCDs, so XCD x = id & 7 takes the pairs = x (mod 8)
+// and its workgroups run all tiles of a pair at the same time: K/V (or Q/dO) of a pair stay in that
+// XCD's L2.  Placement only affects speed, never results.
+struct WorkList {
+    int xcd, pair_slot, u, pairs_per_round, n_pairs, n_tiles;
+    bool valid;
+    __device__ __forceinline__ WorkList(int n_pairs_, int n_tiles_) : n_pairs(n_pairs_), n_tiles(n_tiles_) {
+        const int halves = (n_tiles + 1) >> 1;
+        const int nlocal = (int)gridDim.x >> 3;
+        xcd = blockIdx.x & 7;
+        const int local = blockIdx.x >> 3;
+        pairs_per_round = nlocal / halves;
+        pair_slot = local / halves;
+        u = local % halves;
+        valid = pair_slot < pairs_per_round;
+    }
+    __device__ __forceinline__ int pair_at(int it) const { return (it * pairs_per_round + pair_slot) * 8 + xcd; }
+};
+static inline int worklist_grid(int n_pairs, int n_tiles) {
+    const int halves = (n_tiles + 1) / 2;
+    int per_xcd = (n_pairs + 7) / 8;                     // pairs one XCD has to process
+    int rounds_cap = 64 / halves;                        // 32 CUs x 2 workgroups per XCD
+    if (rounds_cap < 1) rounds_cap = 1;
+    const int ppr = per_xcd < rounds_cap ? per_xcd : rounds_cap;
+    return 8 * ppr * halves;
+}
 
 // tile of 32 rows x 64 floats: thread -> 2 float4 (f = tid + 256*jj: row f>>4, quad f&15)
 __device__ __forceinline__ void load_tile32(const float* __restrict__ base, int64_t ld, int r0, int r_end, int tid,
@@ -51,22 +91,35 @@ __device__ __forceinline__ void store_tile32(float* __restrict__ lds, int tid, c
 // =============================================================================================
 // forward
 // =============================================================================================
-template <int G>
-__global__ void __launch_bounds__(AT_THREADS, 2)
-attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
-                const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
-                const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
-                int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-                float* __restrict__ o, float* __restrict__ lse) {
+// Software pipeline per wave: while the VALU works through softmax(t) (mask, exp2, row sums, dropout),
+// the matrix pipe already runs S^T(t+1) = K(t+1) Q^T into a second accumulator; P(t) V(t) follows.
+// K tiles are therefore staged one iteration earlier than V tiles (K: LDS slot t&1 holds K(t), loaded
+// two iterations ahead; V: slot t&1, one iteration ahead; key levels: ring of 3).
+#define GAMER_QK_TILE(ACC, KSLOT)                                                                   \
+    _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                                \
+        const float4 kf = *reinterpret_cast<const float4*>(&Ks[KSLOT][r * KLD + 8 * kk + 4 * h]);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[kk][0], ACC, 0, 0, 0);                     \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[kk][1], ACC, 0, 0, 0);                     \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kk][2], ACC, 0, 0, 0);                     \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kk][3], ACC, 0, 0, 0);                     \
+    }
+
+template <int G, bool DROP, bool PIPE>
+__device__ __forceinline__ void
+attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+              const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
+              const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
+              int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+              float* __restrict__ o, float* __restrict__ lse, const int pair, const int qtile) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
     __shared__ __attribute__((aligned(16))) float Ks[2][32 * KLD];
     __shared__ __attribute__((aligned(16))) float Vs[2][32 * 64];
-    __shared__ int32_t kls[2][32];
+    __shared__ int32_t kls[3][32];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int hg = w / NSUB, sub = w % NSUB;
-    const int b = blockIdx.z, kvh = blockIdx.y, q0 = blockIdx.x * R;
+    const int b = pair / nkv, kvh = pair % nkv, q0 = qtile * R;
     const int head = kvh * G + hg;
     const int r = lane & 31, h = lane >> 5;
     const int iq = q0 + sub * 32 + r;
@@ -74,13 +127,18 @@ attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ 
     const int iqc = valid_q ? iq : S - 1;
     const int64_t tok = (int64_t)b * S + iqc;
 
+    // scores are kept in the log2 domain: q is pre-scaled by scale*log2(e), p = exp2(s - m)
+    unsigned long long* trace = g_trace;
+    unsigned long long t_start = 0;
+    if (trace) t_start = __builtin_amdgcn_s_memrealtime();
+    const float qs = scale * 1.4426950408889634f;
     float qf[8][4];
     {
         const float* qrow = q + tok * ldq + head * 64;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             const float4 t4 = *reinterpret_cast<const float4*>(qrow + 8 * kk + 4 * h);
-            qf[kk][0] = t4.x * scale; qf[kk][1] = t4.y * scale; qf[kk][2] = t4.z * scale; qf[kk][3] = t4.w * scale;
+            qf[kk][0] = t4.x * qs; qf[kk][1] = t4.y * qs; qf[kk][2] = t4.z * qs; qf[kk][3] = t4.w * qs;
         }
     }
     const int my_ql = ql ? ql[tok] : 1;
@@ -92,8 +150,8 @@ attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ 
     const int n_causal = (min(S, q0 + R) + 31) / 32;
     const int n_iter = block_has_empty ? n_all : n_causal;
     const float invS = 1.f / (float)S;
-    const DropoutRng rng(p_drop, seed);
-    const uint64_t drop_row = ((uint64_t)((int64_t)b * nq + head) * S + (uint64_t)iqc) * (uint64_t)S;
+    const AttnDropout rng(p_drop, seed);
+    const uint32_t rb = rng.row_base((uint32_t)(((int64_t)b * nq + head) * S + iqc));
 
     const float* kbase = k + (int64_t)b * S * ldk + kvh * 64;
     const float* vbase = v + (int64_t)b * S * ldv + kvh * 64;
@@ -106,86 +164,143 @@ attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ 
 
     float4 rk[2], rv[2];
     int rkl = INT_BIG_A;
+    // prologue: K(0), V(0), K(1)
     load_tile32(kbase, ldk, 0, S, tid, rk);
     load_tile32(vbase, ldv, 0, S, tid, rv);
     if (tid < 32) rkl = tid < S ? klb[tid] : INT_BIG_A;
     store_tile32<KLD>(Ks[0], tid, rk);
     store_tile32<64>(Vs[0], tid, rv);
     if (tid < 32) kls[0][tid] = rkl;
+    if (n_iter > 1) {
+        load_tile32(kbase, ldk, 32, S, tid, rk);
+        if (tid < 32) rkl = (32 + tid) < S ? klb[32 + tid] : INT_BIG_A;
+        store_tile32<KLD>(Ks[1], tid, rk);
+        if (tid < 32) kls[1][tid] = rkl;
+    }
     __syncthreads();
 
+    f32x16 st_cur;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st_cur[i] = 0.f;
+    if (!(0 > wave_q_hi)) { GAMER_QK_TILE(st_cur, 0) }
+
     for (int jt = 0; jt < n_iter; ++jt) {
-        const int cur = jt & 1;
-        const bool more = jt + 1 < n_iter;
         const int j0 = jt * 32;
-        if (more) {
-            load_tile32(kbase, ldk, j0 + 32, S, tid, rk);
-            load_tile32(vbase, ldv, j0 + 32, S, tid, rv);
-            if (tid < 32) rkl = (j0 + 32 + tid) < S ? klb[j0 + 32 + tid] : INT_BIG_A;
+        const bool have_next = jt + 1 < n_iter;
+        const bool have_next2 = jt + 2 < n_iter;
+        if (have_next2) {
+            load_tile32(kbase, ldk, j0 + 64, S, tid, rk);
+            if (tid < 32) rkl = (j0 + 64 + tid) < S ? klb[j0 + 64 + tid] : INT_BIG_A;
         }
+        if (have_next) load_tile32(vbase, ldv, j0 + 32, S, tid, rv);
+
         const bool beyond = j0 > wave_q_hi;                // every key of the tile is in every row's future
+        const bool beyond_next = (j0 + 32) > wave_q_hi;
+        const bool with_next = PIPE && have_next && !beyond_next;
+        f32x16 st_next;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st_next[i] = 0.f;
         if (!(beyond && !wave_has_empty)) {
-            f32x16 st;
+            const int32_t* klt = kls[jt % 3];
+            const float* Kn = Ks[(jt + 1) & 1];
+            const float* Vc = Vs[jt & 1];
+            // One basic block per variant: the next tile's 32 QK MFMAs are issued interleaved with this
+            // tile's softmax VALU (the two pipes run concurrently; a wave issues in order, so the
+            // interleave has to be static), then the 32 PV MFMAs.
+            auto tile = [&]<bool WITH_NEXT, bool EMPTY>() {
+                int4 kl4[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) st[i] = 0.f;
-            if (!beyond) {
+                for (int g4 = 0; g4 < 4; ++g4) kl4[g4] = *reinterpret_cast<const int4*>(&klt[8 * g4 + 4 * h]);
+                if (WITH_NEXT) {
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    const float4 kf = *reinterpret_cast<const float4*>(&Ks[cur][r * KLD + 8 * kk + 4 * h]);
-                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[kk][0], st, 0, 0, 0);
-                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[kk][1], st, 0, 0, 0);
-                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kk][2], st, 0, 0, 0);
-                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kk][3], st, 0, 0, 0);
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const float4 kf = *reinterpret_cast<const float4*>(&Kn[r * KLD + 8 * kk + 4 * h]);
+                        st_next = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[kk][0], st_next, 0, 0, 0);
+                        st_next = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[kk][1], st_next, 0, 0, 0);
+                        st_next = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kk][2], st_next, 0, 0, 0);
+                        st_next = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kk][3], st_next, 0, 0, 0);
+                    }
                 }
+                float mloc = -INFINITY;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int key = rowmap(reg, h);
+                    const int klv = (reg & 3) == 0 ? kl4[reg >> 2].x : (reg & 3) == 1 ? kl4[reg >> 2].y
+                                  : (reg & 3) == 2 ? kl4[reg >> 2].z : kl4[reg >> 2].w;
+                    const bool allowed = ((j0 + key) <= iq) & (klv < my_ql) & valid_q;
+                    st_cur[reg] = allowed ? st_cur[reg] : -INFINITY;
+                    mloc = fmaxf(mloc, st_cur[reg]);
+                }
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                const float m_new = fmaxf(m_run, mloc);
+                const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+                float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);        // m_run = -inf -> 0
+                float rowsum = 0.f;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    float pe = __builtin_amdgcn_exp2f(st_cur[reg] - m_safe);   // masked -> exp2(-inf) = 0
+                    if (EMPTY) pe = my_empty ? ((j0 + rowmap(reg, h) < S) ? invS : 0.f) : pe;
+                    rowsum += pe;
+                    st_cur[reg] = pe;
+                }
+                rowsum += __shfl_xor(rowsum, 32, 64);
+                if (EMPTY) alpha = my_empty ? 1.f : alpha;
+                l_run = l_run * alpha + rowsum;
+                m_run = m_new;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+                if (DROP) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg += 2) {
+                        const uint32_t bits = rng.pair_bits(rb, (uint32_t)(j0 + rowmap(reg, h)) >> 1);
+                        st_cur[reg] *= rng.mult_even(bits);
+                        st_cur[reg + 1] *= rng.mult_odd(bits);
+                    }
+                }
+                // O^T[d][query] += sum_key V[key][d] * P[query][key]
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int key = rowmap(reg, h);
+                    const float a0 = Vc[key * 64 + r];
+                    const float a1 = Vc[key * 64 + 32 + r];
+                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, st_cur[reg], oacc[0], 0, 0, 0);
+                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, st_cur[reg], oacc[1], 0, 0, 0);
+                }
+                if (WITH_NEXT) {
+                    // static interleave for the scheduler: 1 MFMA : 14 VALU while the QK chain runs
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, DROP ? 14 : 9, 0);
+                    }
+                }
+            };
+            if (with_next) {
+                if (wave_has_empty) tile.template operator()<true, true>();
+                else tile.template operator()<true, false>();
+            } else {
+                if (wave_has_empty) tile.template operator()<false, true>();
+                else tile.template operator()<false, false>();
             }
-            // masking: st[reg] is the score of key j0 + rowmap(reg,h) for this lane's query
-            float mloc = -INFINITY;
+        } else if (with_next) {
+            // unreachable (a tile beyond the diagonal has no next tile below it) but kept for clarity
+        }
+        if (!PIPE && have_next) {
+            // scores of the next tile, taken BEFORE the barrier: after it other waves may already overwrite
+            // this K slot with K(jt+3)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int key = rowmap(reg, h);
-                const int j = j0 + key;
-                const bool allowed = (j <= iq) && (kls[cur][key] < my_ql) && valid_q;
-                st[reg] = allowed ? st[reg] : -INFINITY;
-                mloc = fmaxf(mloc, st[reg]);
-            }
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float m_new = fmaxf(m_run, mloc);
-            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-            float alpha = __expf(m_run - m_safe);           // m_run = -inf -> 0
-            float rowsum = 0.f;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                float pe = __expf(st[reg] - m_safe);        // masked -> exp(-inf) = 0
-                if (my_empty) pe = (j0 + rowmap(reg, h) < S) ? invS : 0.f;
-                rowsum += pe;
-                st[reg] = pe;
-            }
-            rowsum += __shfl_xor(rowsum, 32, 64);
-            if (my_empty) alpha = 1.f;
-            l_run = l_run * alpha + rowsum;
-            m_run = m_new;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
-            if (rng.on) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) st[reg] *= rng.mult(drop_row + (uint64_t)(j0 + rowmap(reg, h)));
-            }
-            // O^T[d][query] += sum_key V[key][d] * P[query][key]
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int key = rowmap(reg, h);
-                const float a0 = Vs[cur][key * 64 + r];
-                const float a1 = Vs[cur][key * 64 + 32 + r];
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, st[reg], oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, st[reg], oacc[1], 0, 0, 0);
+            for (int i = 0; i < 16; ++i) st_cur[i] = 0.f;
+            if (!beyond_next) {
+                if ((jt + 1) & 1) { GAMER_QK_TILE(st_cur, 1) } else { GAMER_QK_TILE(st_cur, 0) }
             }
         }
-        if (more) {
-            store_tile32<KLD>(Ks[cur ^ 1], tid, rk);
-            store_tile32<64>(Vs[cur ^ 1], tid, rv);
-            if (tid < 32) kls[cur ^ 1][tid] = rkl;
+        if (have_next2) {
+            store_tile32<KLD>(Ks[jt & 1], tid, rk);          // K(jt) is dead: its scores were taken last iteration
+            if (tid < 32) kls[(jt + 2) % 3][tid] = rkl;
         }
+        if (have_next) store_tile32<64>(Vs[(jt + 1) & 1], tid, rv);
         __syncthreads();
+        if (PIPE) st_cur = st_next;
     }
 
     if (valid_q) {
@@ -201,7 +316,40 @@ attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ 
                 *reinterpret_cast<float4*>(orow + 32 * dh + 8 * g4 + 4 * h) = t4;
             }
         }
-        if (h == 0) lse[((int64_t)b * nq + head) * S + iq] = my_empty ? 0.f : (m_run + __logf(l_run));
+        if (trace && tid == 0) {
+            unsigned long long* rec = trace + 4ull * ((size_t)pair * ((S + R - 1) / R) + qtile);
+            rec[0] = t_start;
+            rec[1] = __builtin_amdgcn_s_memrealtime();
+            rec[2] = __builtin_amdgcn_s_getreg(63492);       // HW_REG_HW_ID
+            rec[3] = __builtin_amdgcn_s_getreg(63508);       // HW_REG_XCC_ID
+        }
+        // natural-log LSE of the scaled scores (what the backward kernels consume)
+        if (h == 0) lse[((int64_t)b * nq + head) * S + iq] =
+            my_empty ? 0.f : (m_run + __log2f(l_run)) * 0.6931471805599453f;
+    }
+}
+
+template <int G, bool DROP, int WPS, bool PIPE>
+__global__ void __launch_bounds__(AT_THREADS, WPS)
+attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
+                const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
+                int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+                float* __restrict__ o, float* __restrict__ lse) {
+    constexpr int R = (4 / G) * 32;
+    const int n_tiles = (S + R - 1) / R;
+    const WorkList wl(nbatch * nkv, n_tiles);
+    if (!wl.valid) return;
+    for (int it = 0;; ++it) {
+        const int pair = wl.pair_at(it);
+        if (pair >= wl.n_pairs) break;
+        const int heavy = n_tiles - 1 - wl.u, light = wl.u;       // later query tiles see more keys
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {                    // one inlined body (register pressure)
+            if (pass == 1 && light == heavy) break;
+            attn_fwd_tile<G, DROP, PIPE>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed, o, lse,
+                                         pair, pass == 0 ? heavy : light);
+        }
     }
 }
 
@@ -229,13 +377,13 @@ attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o, in
 // backward: dQ
 // =============================================================================================
 template <int G>
-__global__ void __launch_bounds__(AT_THREADS, 2)
-attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+__device__ __forceinline__ void
+attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                    const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
                    const float* __restrict__ lse, const float* __restrict__ delta,
                    const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                    const int32_t* __restrict__ row_empty, int S, int nq, int nkv, float scale,
-                   float p_drop, uint64_t seed, float* __restrict__ dq, int lddq) {
+                   float p_drop, uint64_t seed, float* __restrict__ dq, int lddq, const int pair, const int qtile) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
     __shared__ __attribute__((aligned(16))) float Ks[2][32 * KLD];
@@ -244,7 +392,7 @@ attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int hg = w / NSUB, sub = w % NSUB;
-    const int b = blockIdx.z, kvh = blockIdx.y, q0 = blockIdx.x * R;
+    const int b = pair / nkv, kvh = pair % nkv, q0 = qtile * R;
     const int head = kvh * G + hg;
     const int r = lane & 31, h = lane >> 5;
     const int iq = q0 + sub * 32 + r;
@@ -275,8 +423,8 @@ attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict
     const int n_causal = (min(S, q0 + R) + 31) / 32;
     const int n_iter = block_has_empty ? n_all : n_causal;
     const float invS = 1.f / (float)S;
-    const DropoutRng rng(p_drop, seed);
-    const uint64_t drop_row = ((uint64_t)((int64_t)b * nq + head) * S + (uint64_t)iqc) * (uint64_t)S;
+    const AttnDropout rng(p_drop, seed);
+    const uint32_t rb = rng.row_base((uint32_t)(((int64_t)b * nq + head) * S + iqc));
 
     const float* kbase = k + (int64_t)b * S * ldk + kvh * 64;
     const float* vbase = v + (int64_t)b * S * ldv + kvh * 64;
@@ -336,7 +484,7 @@ attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict
                 const bool allowed = (j <= iq) && (kls[cur][key] < my_ql) && valid_q;
                 float pe = allowed ? __expf(st[reg] - my_lse) : 0.f;
                 if (my_empty) pe = (j < S) ? invS : 0.f;
-                const float mult = rng.on ? rng.mult(drop_row + (uint64_t)j) : 1.f;
+                const float mult = rng.on ? rng.mult(rb, (uint32_t)j) : 1.f;
                 st[reg] = pe * (mult * dp[reg] - my_delta);      // dS^T
             }
             // dQ^T[d][query] += sum_key K[key][d] dS^T[key][query]
@@ -372,6 +520,31 @@ attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict
     }
 }
 
+template <int G>
+__global__ void __launch_bounds__(AT_THREADS, 2)
+attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                   const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
+                   const float* __restrict__ lse, const float* __restrict__ delta,
+                   const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
+                   const int32_t* __restrict__ row_empty, int nbatch, int S, int nq, int nkv, float scale,
+                   float p_drop, uint64_t seed, float* __restrict__ dq, int lddq) {
+    constexpr int R = (4 / G) * 32;
+    const int n_tiles = (S + R - 1) / R;
+    const WorkList wl(nbatch * nkv, n_tiles);
+    if (!wl.valid) return;
+    for (int it = 0;; ++it) {
+        const int pair = wl.pair_at(it);
+        if (pair >= wl.n_pairs) break;
+        const int heavy = n_tiles - 1 - wl.u, light = wl.u;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1 && light == heavy) break;
+            attn_bwd_dq_tile<G>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed,
+                                dq, lddq, pair, pass == 0 ? heavy : light);
+        }
+    }
+}
+
 // =============================================================================================
 // backward: dK, dV
 // =============================================================================================
@@ -388,14 +561,14 @@ struct DkvSmem {
 };
 
 template <int G>
-__global__ void __launch_bounds__(AT_THREADS, 2)
-attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+__device__ __forceinline__ void
+attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                     const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
                     const float* __restrict__ lse, const float* __restrict__ delta,
                     const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                     const int32_t* __restrict__ row_empty, const int32_t* __restrict__ tile_empty,
                     int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-                    float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv) {
+                    float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const int pair, const int ktile) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char dkv_raw[];
@@ -403,7 +576,8 @@ attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restric
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int hg = w / NSUB, sub = w % NSUB;
-    const int b = blockIdx.z, kvh = blockIdx.y, k0 = blockIdx.x * R;
+    __syncthreads();                 // the previous tile's head reduction may still be reading the LDS region
+    const int b = pair / nkv, kvh = pair % nkv, k0 = ktile * R;
     const int head = kvh * G + hg;
     const int r = lane & 31, h = lane >> 5;
     const int jk = k0 + sub * 32 + r;                 // this lane's key
@@ -428,8 +602,8 @@ attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restric
     const int my_kl = valid_k ? kl[ktok] : INT_BIG_A;
     const int wave_k_lo = k0 + sub * 32;
     const float invS = 1.f / (float)S;
-    const DropoutRng rng(p_drop, seed);
-    const uint64_t drop_head = (uint64_t)((int64_t)b * nq + head) * S;
+    const AttnDropout rng(p_drop, seed);
+    const uint32_t drop_head = (uint32_t)(((int64_t)b * nq + head) * S);
 
     const int n_qt = (S + 31) / 32;
     const int qt_begin = k0 / 32;                     // first query tile that can hold i >= k0
@@ -544,7 +718,7 @@ attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restric
                     const bool allowed = inq && valid_k && (jk <= i) && (my_kl < qlv[e]);
                     float pe = allowed ? __expf(st[reg] * scale - lv[e]) : 0.f;
                     if (emv[e] != 0) pe = (inq && valid_k) ? invS : 0.f;
-                    const float mult = rng.on ? rng.mult((drop_head + (uint64_t)(inq ? i : 0)) * (uint64_t)S + (uint64_t)jkc) : 1.f;
+                    const float mult = rng.on ? rng.mult(rng.row_base(drop_head + (uint32_t)(inq ? i : 0)), (uint32_t)jkc) : 1.f;
                     st[reg] = pe * (mult * dp[reg] - dl[e]);     // dS[query][key]
                     dp[reg] = pe * mult;                          // dropped P[query][key]
                 }
@@ -617,13 +791,47 @@ attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restric
 }
 
 template <int G>
+__global__ void __launch_bounds__(AT_THREADS, 2)
+attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                    const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
+                    const float* __restrict__ lse, const float* __restrict__ delta,
+                    const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
+                    const int32_t* __restrict__ row_empty, const int32_t* __restrict__ tile_empty,
+                    int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+                    float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv) {
+    constexpr int R = (4 / G) * 32;
+    const int n_tiles = (S + R - 1) / R;
+    const WorkList wl(nbatch * nkv, n_tiles);
+    if (!wl.valid) return;
+    for (int it = 0;; ++it) {
+        const int pair = wl.pair_at(it);
+        if (pair >= wl.n_pairs) break;
+        const int heavy = wl.u, light = n_tiles - 1 - wl.u;       // earlier key tiles are seen by more queries
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1 && light == heavy) break;
+            attn_bwd_dkv_tile<G>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv, scale,
+                                 p_drop, seed, dk, lddk, dv, lddv, pair, pass == 0 ? heavy : light);
+        }
+    }
+}
+
+template <int G>
 static int launch_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl,
                       const int32_t* ql, const int32_t* row_empty, int B, int S, int nq, int nkv, float scale,
                       float p_drop, uint64_t seed, float* o, float* lse, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
-    dim3 grid((S + R - 1) / R, nkv, B);
-    hipLaunchKernelGGL(attn_fwd_kernel<G>, grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S,
-                       nq, nkv, scale, p_drop, seed, o, lse);
+    dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
+    // PIPE = false: the software-pipelined variant (next tile's QK MFMAs interleaved with this tile's softmax)
+    // measured slower here (0.95 vs 0.80 ms at B=256): it needs 16 more accumulator registers and spills at
+    // the 256-VGPR budget of two workgroups per CU; with the whole register file (one workgroup per CU) it
+    // loses the second wave per SIMD instead.  Kept as a template parameter for the next round.
+    if (p_drop > 0.f)
+        hipLaunchKernelGGL((attn_fwd_kernel<G, true, 2, false>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv,
+                           kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<G, false, 2, false>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv,
+                           kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse);
     GAMER_CHECK_LAUNCH("gamer_attn_fwd");
     return 0;
 }
@@ -635,9 +843,9 @@ static int launch_bwd(const float* q, int ldq, const float* k, int ldk, const fl
                       float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                       hipStream_t st) {
     constexpr int R = (4 / G) * 32;
-    dim3 grid((S + R - 1) / R, nkv, B);
+    dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
     hipLaunchKernelGGL(attn_bwd_dq_kernel<G>, grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl,
-                       ql, row_empty, S, nq, nkv, scale, p_drop, seed, dq, lddq);
+                       ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd/dq");
     static bool attr_set = false;
     auto kfn = attn_bwd_dkv_kernel<G>;
@@ -654,7 +862,7 @@ static int launch_bwd(const float* q, int ldq, const float* k, int ldk, const fl
         attr_set = true;
     }
     hipLaunchKernelGGL(kfn, grid, dim3(AT_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty,
-                       tile_empty, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv);
+                       tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd/dkv");
     return 0;
 }
@@ -675,6 +883,24 @@ static int check_attn_common(const char* name, const void* q, const void* k, con
     GAMER_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v), "%s: q/k/v must be 16-byte aligned", name);
     GAMER_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "%s: p_drop=%f", name, p_drop);
     return 0;
+}
+
+extern "C" int gamer_debug_set_trace(void* p) {
+    unsigned long long* v = (unsigned long long*)p;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &v, sizeof(v));
+}
+
+// Debug aid (not part of the public header): resident workgroups per CU the runtime reports.
+extern "C" int gamer_debug_attn_occupancy(int which) {
+    int n = -1;
+    hipError_t e = hipSuccess;
+    switch (which) {
+        case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<2, true, 2, false>, AT_THREADS, 0); break;
+        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<2, false, 2, false>, AT_THREADS, 0); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq_kernel<2>, AT_THREADS, 0); break;
+        case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_kernel<2>, AT_THREADS, sizeof(DkvSmem<2>)); break;
+    }
+    return e == hipSuccess ? n : -(int)e;
 }
 
 extern "C" int gamer_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,

@@ -74,6 +74,30 @@ struct DropoutRng {
     }
 };
 
+// Dropout on attention probabilities: one 32-bit hash per (row, key pair) gives the two 16-bit
+// uniform numbers of keys 2*jp and 2*jp+1, so the forward / dQ kernels (key pairs in adjacent
+// accumulator registers of one lane) hash once per two elements.  keep iff u16 >= p*65536.
+struct AttnDropout {
+    uint32_t k0, thr16;
+    float scale;
+    bool on;
+    __device__ __forceinline__ AttnDropout(float p, uint64_t seed) {
+        on = p > 0.f;
+        k0 = mix32((uint32_t)seed ^ 0x9e3779b9U) ^ mix32((uint32_t)(seed >> 32) + 0x7f4a7c15U);
+        thr16 = (uint32_t)(p * 65536.f);
+        scale = on ? 1.f / (1.f - p) : 1.f;
+    }
+    // row = (b*nq + head)*S + i
+    __device__ __forceinline__ uint32_t row_base(uint32_t row) const { return mix32(row * 0x9e3779b1U + k0); }
+    __device__ __forceinline__ uint32_t pair_bits(uint32_t rb, uint32_t jp) const { return mix32(rb + jp * 0x85ebca6bU); }
+    __device__ __forceinline__ float mult_even(uint32_t bits) const { return (bits & 0xffffU) >= thr16 ? scale : 0.f; }
+    __device__ __forceinline__ float mult_odd(uint32_t bits) const { return (bits >> 16) >= thr16 ? scale : 0.f; }
+    __device__ __forceinline__ float mult(uint32_t rb, uint32_t j) const {
+        const uint32_t bits = pair_bits(rb, j >> 1);
+        return (j & 1U) ? mult_odd(bits) : mult_even(bits);
+    }
+};
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 // d/dx silu(x) = s*(1 + x*(1-s)), s = sigmoid(x)
 __device__ __forceinline__ float dsilu_f(float x) {

@@ -354,9 +354,10 @@ def _run_attn(batch, cross, B, S, nq, nkv, p_drop=0.0, seed=1234, q=None, k=None
 
 
 @pytest.mark.parametrize("cross", [False, True])
-@pytest.mark.parametrize("n_items,B", [(7, 3), (20, 2), (101, 2)])
-def test_attention_fwd_bwd(cross, n_items, B):
-    nq, nkv = 2, 1
+@pytest.mark.parametrize("n_items,B,nq,nkv", [(7, 3, 2, 1), (20, 2, 2, 1), (101, 2, 2, 1), (101, 11, 6, 3), (33, 40, 6, 3)])
+def test_attention_fwd_bwd(cross, n_items, B, nq, nkv):
+    """The last two shapes give every persistent workgroup several (pair, tile) items, the regime the
+    train step runs in (LDS reuse across items and tiles)."""
     batch = synthetic.make_batch(B, n_items, 8, 3, seed=7 + n_items, pad_rows={0: max(1, n_items // 3)})
     S = batch["input_ids"].shape[1]
     g = torch.Generator().manual_seed(n_items)
@@ -378,7 +379,7 @@ def test_attention_fwd_bwd(cross, n_items, B):
     e_dq = _rel(res["dq"], leaves[0].grad.reshape(T, -1))
     e_dk = _rel(res["dk"], leaves[1].grad.reshape(T, -1))
     e_dv = _rel(res["dv"], leaves[2].grad.reshape(T, -1))
-    _record(f"attn_cross{int(cross)}_S{S}", dict(o=e_o, lse=e_l, dq=e_dq, dk=e_dk, dv=e_dv,
+    _record(f"attn_cross{int(cross)}_S{S}_B{B}_h{nq}", dict(o=e_o, lse=e_l, dq=e_dq, dk=e_dk, dv=e_dv,
                                                    empty_rows=int(empty.sum())))
     if cross:
         assert int((empty & batch["attention_mask"].bool()).sum()) > 0, "fixture must contain empty rows"
