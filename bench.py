@@ -207,8 +207,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("GAMER_BENCH_FORCE_DIST") == "1"     # exercise the RCCL path on one GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        if force_dist and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
         dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
 
     from gamer_amd import synthetic
@@ -223,7 +226,9 @@ def main():
     eng = Engine(cfg, device=f"cuda:{local_rank}", temperature=0.7)
     eng.init_weights(seed=0)                     # identical replicas on every rank
     eng.base_seed = 0x5EED + rank                # independent dropout streams per rank
-    reducer = GradAllReducer(eng.flat_g, eng.layout, cfg.num_hidden_layers) if world > 1 else None
+    reducer = GradAllReducer(eng.flat_g, eng.layout, cfg.num_hidden_layers) if (world > 1 or force_dist) else None
+    if reducer is not None and force_dist:
+        reducer.world = 2                        # take the collective code path even with one rank
 
     def make(step):
         b = synthetic.make_batch(args.batch, args.items, 256, 3, ragged=args.ragged,
@@ -248,7 +253,7 @@ def main():
         return eng.train_step(batches[i % n_batches], lr, reducer=reducer, grad_scale=grad_scale)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -268,7 +273,7 @@ def main():
     final_loss = float(loss)
     log(f"timed region done: {elapsed / args.steps * 1e3:.1f} ms/step")
     eng.check_inputs()
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -323,8 +328,15 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg.to_dict(), args.items)
-        print(json.dumps(result))
-    if world > 1:
+        # RCCL prints a version banner through C stdio; push it out first so that the JSON line is last
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -11,6 +11,7 @@ all RMSNorm weights) goes last.  ``torch.distributed`` (backend "nccl" = RCCL ov
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -58,6 +59,6 @@ class GradAllReducer:
 def all_reduce_scalar_(t: torch.Tensor, group=None):
     """In-place SUM of a tiny device tensor (the global label count for the loss normalisation,
     HF average_tokens_across_devices semantics)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("GAMER_BENCH_FORCE_DIST") == "1"):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t

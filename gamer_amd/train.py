@@ -1,0 +1,138 @@
+"""Minimal training harness for the SMB decoder on MI355X: the counterpart of
+``TrainSMBDecoder.invoke`` (ref:SeqRec/tasks/train_SMB_decoder.py:139-449) for the hot path only.
+
+Same step semantics as the reference's HF-Trainer run (gradient accumulation, loss = sum CE / number
+of label tokens in the accumulation window across ranks, clip_grad_norm_(1.0), AdamW, cosine schedule
+with warm-up, per-epoch checkpoints with the reference's file layout), flag names reused from the
+reference where they exist.  Data are synthetic (the reference's datasets are git-LFS pointers); one
+process per GPU, launch with torch.distributed.run for more than one.
+
+  python -m gamer_amd.train --max_his_len 100 --per_device_batch_size 128 --gradient_accumulation_steps 4 \
+      --epochs 1 --steps_per_epoch 20 --output_dir /tmp/ckpt
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+
+import torch
+
+from . import synthetic
+from .config import synthetic_config
+from .dp import GradAllReducer, all_reduce_scalar_
+from .engine import Engine
+from .schedule import cosine_with_warmup, warmup_steps_for
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser("train_SMB_decoder (MI355X hot path)")
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--max_his_len", type=int, default=100)
+    ap.add_argument("--per_device_batch_size", type=int, default=128)
+    ap.add_argument("--gradient_accumulation_steps", type=int, default=2)
+    ap.add_argument("--epochs", type=int, default=1)
+    ap.add_argument("--steps_per_epoch", type=int, default=10, help="optimizer steps per synthetic epoch")
+    ap.add_argument("--learning_rate", type=float, default=5e-4)
+    ap.add_argument("--weight_decay", type=float, default=0.01)
+    ap.add_argument("--warmup_ratio", type=float, default=0.1)
+    ap.add_argument("--temperature", type=float, default=0.7)
+    ap.add_argument("--max_grad_norm", type=float, default=1.0)
+    ap.add_argument("--logging_step", type=int, default=30)
+    ap.add_argument("--ragged", action="store_true", help="variable history lengths (right padded)")
+    ap.add_argument("--output_dir", type=str, default="")
+    ap.add_argument("--resume_from_checkpoint", type=str, default="")
+    return ap.parse_args(argv)
+
+
+def save_checkpoint(eng: Engine, path: str, state: dict):
+    os.makedirs(path, exist_ok=True)
+    eng.cfg.save_pretrained(path)
+    from safetensors.torch import save_file
+    save_file({k: v.detach().cpu().contiguous() for k, v in eng.params.items()}, os.path.join(path, "model.safetensors"))
+    torch.save({"m": eng.flat_m.cpu() if eng.flat_m is not None else None,
+                "v": eng.flat_v.cpu() if eng.flat_v is not None else None,
+                "opt_step": eng.opt_step}, os.path.join(path, "optimizer.pt"))
+    with open(os.path.join(path, "trainer_state.json"), "w") as f:
+        json.dump(state, f)
+
+
+def load_checkpoint(eng: Engine, path: str) -> dict:
+    from safetensors.torch import load_file
+    eng.load_state_dict(load_file(os.path.join(path, "model.safetensors")))
+    opt = torch.load(os.path.join(path, "optimizer.pt"), map_location="cpu")
+    if opt["m"] is not None:
+        eng.flat_m = opt["m"].to(eng.device)
+        eng.flat_v = opt["v"].to(eng.device)
+    eng.opt_step = int(opt["opt_step"])
+    with open(os.path.join(path, "trainer_state.json")) as f:
+        return json.load(f)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+    cfg = synthetic_config(n_positions=args.max_his_len + 1)
+    eng = Engine(cfg, device=f"cuda:{local_rank}", temperature=args.temperature)
+    eng.init_weights(seed=args.seed)
+    eng.base_seed = args.seed * 1000 + rank
+    reducer = GradAllReducer(eng.flat_g, eng.layout, cfg.num_hidden_layers) if world > 1 else None
+    total_steps = args.epochs * args.steps_per_epoch
+    warmup = warmup_steps_for(total_steps, args.warmup_ratio)
+    state = {"global_step": 0, "epoch": 0, "log_history": []}
+    if args.resume_from_checkpoint:
+        state = load_checkpoint(eng, args.resume_from_checkpoint)
+    items = args.max_his_len + 1
+    t_last, seq_since = time.time(), 0
+    accum = args.gradient_accumulation_steps
+    while state["global_step"] < total_steps:
+        step = state["global_step"]
+        micro = [synthetic.make_batch(args.per_device_batch_size, items, 256, 3, ragged=args.ragged,
+                                      seed=args.seed + 7919 * (step * accum + a) + 104729 * rank) for a in range(accum)]
+        # label tokens of the whole accumulation window, over all ranks (HF num_items_in_batch)
+        n_items = torch.tensor([float(sum(int((b["labels"][:, 1:] != -100).sum()) for b in micro))], device=eng.device)
+        all_reduce_scalar_(n_items)
+        n_items = float(n_items.item())
+        eng.zero_grad()
+        loss_sum = 0.0
+        for a, b in enumerate(micro):
+            loss, _ = eng.forward(b["input_ids"], b["attention_mask"], b["actions"], labels=b["labels"],
+                                  num_items_in_batch=n_items, train=True)
+            last = a == accum - 1
+            eng.backward(1.0, layer_done=reducer.layer_done if (reducer and last) else None)
+            loss_sum += float(loss) if (step + 1) % args.logging_step == 0 else 0.0
+        if reducer:
+            reducer.finish()
+        lr = cosine_with_warmup(step, args.learning_rate, warmup, total_steps)
+        eng.optimizer_step(lr, weight_decay=args.weight_decay, max_norm=args.max_grad_norm)
+        state["global_step"] = step + 1
+        seq_since += args.per_device_batch_size * accum * world
+        if (step + 1) % args.logging_step == 0 or step + 1 == total_steps:
+            torch.cuda.synchronize()
+            now = time.time()
+            rec = {"step": step + 1, "loss": loss_sum * world if loss_sum else float(loss) * world * accum,
+                   "grad_norm": float(eng.grad_norm), "learning_rate": lr,
+                   "train_samples_per_second": seq_since / max(now - t_last, 1e-9)}
+            state["log_history"].append(rec)
+            if rank == 0:
+                print(json.dumps(rec), flush=True)
+            t_last, seq_since = now, 0
+        if (step + 1) % args.steps_per_epoch == 0:
+            state["epoch"] = (step + 1) // args.steps_per_epoch
+            if args.output_dir and rank == 0:
+                save_checkpoint(eng, os.path.join(args.output_dir, f"checkpoint-{step + 1}"), state)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return state
+
+
+if __name__ == "__main__":
+    main()
