@@ -71,12 +71,17 @@ static inline int worklist_grid(int n_pairs, int n_tiles) {
 // tile of 32 rows x 64 floats: thread -> 2 float4 (f = tid + 256*jj: row f>>4, quad f&15)
 __device__ __forceinline__ void load_tile32(const float* __restrict__ base, int64_t ld, int r0, int r_end, int tid,
                                             float4 (&rg)[2]) {
+    // branch-free (clamped address + select): a conditional load would be branched around and waited
+    // for individually by hipcc
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const int f = tid + AT_THREADS * jj;
         const int row = r0 + (f >> 4);
-        rg[jj] = row < r_end ? *reinterpret_cast<const float4*>(base + (int64_t)row * ld + ((f & 15) << 2))
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool ok = row < r_end;
+        const int rowc = ok ? row : r_end - 1;
+        float4 v = *reinterpret_cast<const float4*>(base + (int64_t)rowc * ld + ((f & 15) << 2));
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        rg[jj] = v;
     }
 }
 template <int LD>

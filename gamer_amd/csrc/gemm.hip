@@ -15,6 +15,7 @@
 // Grouped forms cover the position-routed experts without host synchronisation: segment offsets are
 // read from device memory and surplus workgroups exit.
 #include "common.h"
+#include <stdlib.h>
 
 namespace gamer {
 
@@ -25,6 +26,15 @@ constexpr int TILE_FLOATS = BM * KC_LD;        // 4608 >= BK*BM (RC image)
 constexpr int GEMM_LDS_BYTES = 4 * TILE_FLOATS * (int)sizeof(float);   // 2 operands x 2 buffers
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Diagnostic build only (STAMP = true, selected by gamer_debug_gemm_stamp): wave 0 of every workgroup
+// accumulates shader-clock cycles per phase of the K loop into g_gemm_stamp[8 * blockIdx.x + phase].
+__device__ unsigned long long* g_gemm_stamp = nullptr;
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
 
 struct GemmParams {
     const float* A; int64_t a_rs, a_ks;
@@ -51,6 +61,11 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 
 // ---- global -> registers ---------------------------------------------------------------------
 // KC tile: 128 rows x 32 k; float4 f = tid + 256*j covers row f>>3, k-quad f&7.
+// INTERIOR = the whole 128 x 32 tile is in range: no predicates at all.  On gfx950 the fp32 MFMA runs at
+// the vector rate and every VALU instruction issued beside it costs matrix throughput (measured: a
+// branch-free clamp+select version of these loads, ~100 more VALU per K-step, lowered the GEMM from 98 to
+// 93 TFLOP/s), so the common path keeps the instruction count minimal.
+template <bool INTERIOR>
 __device__ __forceinline__ void load_kc(const float* __restrict__ p, int64_t rs, int row0, int row_end, int k0,
                                         int k_end, int tid, float4 (&r)[4]) {
 #pragma unroll
@@ -58,6 +73,10 @@ __device__ __forceinline__ void load_kc(const float* __restrict__ p, int64_t rs,
         const int f = tid + GEMM_THREADS * j;
         const int row = row0 + (f >> 3);
         const int k = k0 + ((f & 7) << 2);
+        if (INTERIOR) {
+            r[j] = *reinterpret_cast<const float4*>(p + (int64_t)row * rs + k);
+            continue;
+        }
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < row_end && k < k_end) {
             v = *reinterpret_cast<const float4*>(p + (int64_t)row * rs + k);
@@ -71,6 +90,7 @@ __device__ __forceinline__ void load_kc(const float* __restrict__ p, int64_t rs,
     }
 }
 // RC tile: 32 k x 128 rows; float4 f covers k f>>5, row-quad f&31.
+template <bool INTERIOR>
 __device__ __forceinline__ void load_rc(const float* __restrict__ p, int64_t ks, int row0, int row_end, int k0,
                                         int k_end, int tid, float4 (&r)[4]) {
 #pragma unroll
@@ -78,6 +98,10 @@ __device__ __forceinline__ void load_rc(const float* __restrict__ p, int64_t ks,
         const int f = tid + GEMM_THREADS * j;
         const int k = k0 + (f >> 5);
         const int row = row0 + ((f & 31) << 2);
+        if (INTERIOR) {
+            r[j] = *reinterpret_cast<const float4*>(p + (int64_t)k * ks + row);
+            continue;
+        }
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < k_end && row < row_end) {
             v = *reinterpret_cast<const float4*>(p + (int64_t)k * ks + row);
@@ -116,7 +140,7 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row
     }
 }
 
-template <bool A_KC, bool B_KC, int MODE>
+template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP>
 __global__ void __launch_bounds__(GEMM_THREADS, 2)
 gemm_f32_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -200,28 +224,33 @@ gemm_f32_kernel(const GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nkt = (kend - kbeg + BK - 1) / BK;
+    const bool a_in = row0 + BM <= row_end, b_in = col0 + BN <= col_end;     // workgroup-uniform
     float4 ra[4], rb[4];
-    if (nkt > 0) {
-        if (A_KC) load_kc(p.A, p.a_rs, row0, row_end, kbeg, kend, tid, ra);
-        else load_rc(p.A, p.a_ks, row0, row_end, kbeg, kend, tid, ra);
-        if (B_KC) load_kc(Bp, p.b_rs, col0, col_end, kbeg, kend, tid, rb);
-        else load_rc(Bp, p.b_ks, col0, col_end, kbeg, kend, tid, rb);
-        if (A_KC) store_kc(smem, tid, ra); else store_rc(smem, tid, ra);
-        if (B_KC) store_kc(smem + TILE_FLOATS, tid, rb); else store_rc(smem + TILE_FLOATS, tid, rb);
-    }
-    __syncthreads();
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nkt;
-        if (more) {
-            const int k0 = kbeg + (kt + 1) * BK;
-            if (A_KC) load_kc(p.A, p.a_rs, row0, row_end, k0, kend, tid, ra);
-            else load_rc(p.A, p.a_ks, row0, row_end, k0, kend, tid, ra);
-            if (B_KC) load_kc(Bp, p.b_rs, col0, col_end, k0, kend, tid, rb);
-            else load_rc(Bp, p.b_ks, col0, col_end, k0, kend, tid, rb);
+    auto load_tile = [&](int k0) {
+        const bool k_in = k0 + BK <= kend;
+        if (a_in && k_in) {
+            if (A_KC) load_kc<true>(p.A, p.a_rs, row0, row_end, k0, kend, tid, ra);
+            else load_rc<true>(p.A, p.a_ks, row0, row_end, k0, kend, tid, ra);
+        } else {
+            if (A_KC) load_kc<false>(p.A, p.a_rs, row0, row_end, k0, kend, tid, ra);
+            else load_rc<false>(p.A, p.a_ks, row0, row_end, k0, kend, tid, ra);
         }
-        const float* as = smem + 2 * cur * TILE_FLOATS;
+        if (b_in && k_in) {
+            if (B_KC) load_kc<true>(Bp, p.b_rs, col0, col_end, k0, kend, tid, rb);
+            else load_rc<true>(Bp, p.b_ks, col0, col_end, k0, kend, tid, rb);
+        } else {
+            if (B_KC) load_kc<false>(Bp, p.b_rs, col0, col_end, k0, kend, tid, rb);
+            else load_rc<false>(Bp, p.b_ks, col0, col_end, k0, kend, tid, rb);
+        }
+    };
+    auto store_tile = [&](float* dst) {
+        if (A_KC) store_kc(dst, tid, ra); else store_rc(dst, tid, ra);
+        if (B_KC) store_kc(dst + TILE_FLOATS, tid, rb); else store_rc(dst + TILE_FLOATS, tid, rb);
+    };
+    unsigned long long t_ph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t0 = 0, t1 = 0;
+    const unsigned long long t_begin = STAMP ? stamp_now() : 0;
+    auto mfma_tile = [&](const float* as) {
         const float* bs = as + TILE_FLOATS;
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
@@ -238,56 +267,142 @@ gemm_f32_kernel(const GemmParams p) {
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (more) {
-            float* an = smem + 2 * (cur ^ 1) * TILE_FLOATS;
-            if (A_KC) store_kc(an, tid, ra); else store_rc(an, tid, ra);
-            if (B_KC) store_kc(an + TILE_FLOATS, tid, rb); else store_rc(an + TILE_FLOATS, tid, rb);
+    };
+    const bool fast = a_in && b_in && ((kend - kbeg) % BK == 0);
+    if (fast) {
+        // Interior tile: no predicates, per-thread base pointers advanced by BK per step, the eight 16-byte
+        // loads of the next step are the only address-dependent instructions in the loop.
+        const float* pa = A_KC ? p.A + (int64_t)(row0 + (tid >> 3)) * p.a_rs + kbeg + ((tid & 7) << 2)
+                               : p.A + (int64_t)(kbeg + (tid >> 5)) * p.a_ks + row0 + ((tid & 31) << 2);
+        const float* pb = B_KC ? Bp + (int64_t)(col0 + (tid >> 3)) * p.b_rs + kbeg + ((tid & 7) << 2)
+                               : Bp + (int64_t)(kbeg + (tid >> 5)) * p.b_ks + col0 + ((tid & 31) << 2);
+        const int64_t ja = A_KC ? 32 * p.a_rs : 8 * p.a_ks;       // float4 #j sits 32 rows (KC) / 8 k (RC) further
+        const int64_t jb = B_KC ? 32 * p.b_rs : 8 * p.b_ks;
+        const int64_t sa = A_KC ? BK : BK * p.a_ks;               // one K-step
+        const int64_t sb = B_KC ? BK : BK * p.b_ks;
+        auto fast_load = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(pa + j * ja);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rb[j] = *reinterpret_cast<const float4*>(pb + j * jb);
+            pa += sa;
+            pb += sb;
+        };
+        fast_load();
+        store_tile(smem);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < nkt;
+            if (STAMP) { __builtin_amdgcn_sched_barrier(0); t0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+            if (more) fast_load();
+            if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[0] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
+            mfma_tile(smem + 2 * cur * TILE_FLOATS);
+            if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[1] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
+            if (more) store_tile(smem + 2 * (cur ^ 1) * TILE_FLOATS);
+            if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[2] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
+            __syncthreads();
+            if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[3] += t1 - t0; __builtin_amdgcn_sched_barrier(0); }
+        }
+    } else {
+        if (nkt > 0) {
+            load_tile(kbeg);
+            store_tile(smem);
         }
         __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < nkt;
+            if (more) load_tile(kbeg + (kt + 1) * BK);
+            mfma_tile(smem + 2 * cur * TILE_FLOATS);
+            if (more) store_tile(smem + 2 * (cur ^ 1) * TILE_FLOATS);
+            __syncthreads();
+        }
     }
+    const unsigned long long t_loop_end = STAMP ? stamp_now() : 0;
 
     // ---- epilogue: acc[i][j][r] is C[row = (r&3)+8*(r>>2)+4*h][col = lane&31] of its 32x32 tile --
+    const bool interior = a_in && b_in;
+    auto emit = [&](float* dst, float v) {
+        if (MODE == 1) atomicAdd(dst, v);
+        else if (ACCUM) *dst += v;
+        else *dst = v;
+    };
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = col0 + wn * 64 + j * 32 + r32;
+            const int rbase = row0 + wm * 64 + i * 32 + 4 * h;
+            float* cbase = Cp + (int64_t)rbase * p.ldc + col;
+            if (interior) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < row_end && col < col_end) {
-                    float* dst = Cp + (int64_t)row * p.ldc + col;
-                    const float v = p.alpha * acc[i][j][r];
-                    if (MODE == 1) atomicAdd(dst, v);
-                    else if (p.accumulate) *dst += v;
-                    else *dst = v;
+                for (int r = 0; r < 16; ++r) emit(cbase + (int64_t)((r & 3) + 8 * (r >> 2)) * p.ldc, p.alpha * acc[i][j][r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2);
+                    if (rbase + rr < row_end && col < col_end) emit(cbase + (int64_t)rr * p.ldc, p.alpha * acc[i][j][r]);
                 }
             }
         }
     }
+    if (STAMP) {
+        unsigned long long* st = g_gemm_stamp;
+        if (st && tid == 0) {
+            const unsigned long long t_end = stamp_now();
+            unsigned long long* rec = st + 8ull * blockIdx.x;
+            rec[0] = t_ph[0]; rec[1] = t_ph[1]; rec[2] = t_ph[2]; rec[3] = t_ph[3];
+            rec[4] = t_loop_end - t_begin;        // whole K loop
+            rec[5] = t_end - t_loop_end;          // epilogue
+            rec[6] = t_begin;                     // absolute start (for gaps between workgroups)
+            rec[7] = t_end;
+        }
+    }
 }
 
-template <bool A_KC, bool B_KC, int MODE>
-static int launch_gemm(const GemmParams& p, int blocks, hipStream_t st) {
-    static bool attr_set = false;
-    auto kfn = gemm_f32_kernel<A_KC, B_KC, MODE>;
-    if (!attr_set) {
+template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP>
+static int launch_gemm_t(const GemmParams& p, int blocks, hipStream_t st, int lds) {
+    static int attr_lds = 0;
+    auto kfn = gemm_f32_kernel<A_KC, B_KC, MODE, ACCUM, STAMP>;
+    if (attr_lds != lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             set_error("gamer_gemm_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return (int)e;
         }
-        attr_set = true;
+        attr_lds = lds;
     }
-    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, p);
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(GEMM_THREADS), lds, st, p);
     GAMER_CHECK_LAUNCH("gamer_gemm_f32");
     return 0;
+}
+
+template <bool A_KC, bool B_KC, int MODE>
+static int launch_gemm(const GemmParams& p, int blocks, hipStream_t st) {
+    static int stamp = -1, solo = 0;
+    if (stamp < 0) {
+        const char* e = getenv("GAMER_GEMM_STAMP");
+        stamp = (e && e[0] == '1') ? 1 : 0;
+        const char* s2 = getenv("GAMER_GEMM_SOLO");
+        solo = (s2 && s2[0] == '1') ? 1 : 0;
+    }
+    const int lds = solo ? 150 * 1024 : GEMM_LDS_BYTES;          // solo: one workgroup per CU (diagnostics)
+    const bool acc = MODE == 0 && p.accumulate;
+    if (stamp) return launch_gemm_t<A_KC, B_KC, MODE, false, true>(p, blocks, st, lds);
+    if (acc) return launch_gemm_t<A_KC, B_KC, MODE, true, false>(p, blocks, st, lds);
+    return launch_gemm_t<A_KC, B_KC, MODE, false, false>(p, blocks, st, lds);
 }
 
 }  // namespace gamer
 
 using namespace gamer;
+
+extern "C" int gamer_debug_gemm_stamp(void* p) {
+    unsigned long long* v = (unsigned long long*)p;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamp), &v, sizeof(v));
+}
 
 extern "C" int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream) {
     GAMER_CHECK_ARG(d, "gamer_gemm_f32: null descriptor");
