@@ -384,8 +384,8 @@ attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o, in
 template <int G>
 __device__ __forceinline__ void
 attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
-                   const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
-                   const float* __restrict__ lse, const float* __restrict__ delta,
+                   const float* __restrict__ v, int ldv, const float* __restrict__ o, const float* __restrict__ d_o,
+                   const float* __restrict__ lse, float* __restrict__ delta,
                    const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                    const int32_t* __restrict__ row_empty, int S, int nq, int nkv, float scale,
                    float p_drop, uint64_t seed, float* __restrict__ dq, int lddq, const int pair, const int qtile) {
@@ -406,21 +406,26 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
     const int64_t tok = (int64_t)b * S + iqc;
 
     float qf[8][4], dof[8][4];
+    float my_delta = 0.f;                 // delta_i = dO_i . O_i, computed here and published for the dK/dV kernel
     {
         const float* qrow = q + tok * ldq + head * 64;
         const float* drow = d_o + tok * (int64_t)nq * 64 + head * 64;
+        const float* orow = o + tok * (int64_t)nq * 64 + head * 64;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             const float4 t4 = *reinterpret_cast<const float4*>(qrow + 8 * kk + 4 * h);
             qf[kk][0] = t4.x * scale; qf[kk][1] = t4.y * scale; qf[kk][2] = t4.z * scale; qf[kk][3] = t4.w * scale;
             const float4 u4 = *reinterpret_cast<const float4*>(drow + 8 * kk + 4 * h);
             dof[kk][0] = u4.x; dof[kk][1] = u4.y; dof[kk][2] = u4.z; dof[kk][3] = u4.w;
+            const float4 o4 = *reinterpret_cast<const float4*>(orow + 8 * kk + 4 * h);
+            my_delta += u4.x * o4.x + u4.y * o4.y + u4.z * o4.z + u4.w * o4.w;
         }
+        my_delta += __shfl_xor(my_delta, 32, 64);
+        if (valid_q && h == 0) delta[((int64_t)b * nq + head) * S + iq] = my_delta;
     }
     const int my_ql = ql ? ql[tok] : 1;
     const bool my_empty = valid_q && row_empty[tok] != 0;
     const float my_lse = lse[((int64_t)b * nq + head) * S + iqc];
-    const float my_delta = delta[((int64_t)b * nq + head) * S + iqc];
     const int wave_q_hi = min(S - 1, q0 + sub * 32 + 31);
     const bool wave_has_empty = __any(my_empty ? 1 : 0) != 0;
     const bool block_has_empty = __syncthreads_or(my_empty ? 1 : 0) != 0;
@@ -528,8 +533,8 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
 template <int G>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
-                   const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
-                   const float* __restrict__ lse, const float* __restrict__ delta,
+                   const float* __restrict__ v, int ldv, const float* __restrict__ o, const float* __restrict__ d_o,
+                   const float* __restrict__ lse, float* __restrict__ delta,
                    const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                    const int32_t* __restrict__ row_empty, int nbatch, int S, int nq, int nkv, float scale,
                    float p_drop, uint64_t seed, float* __restrict__ dq, int lddq) {
@@ -544,7 +549,7 @@ attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
-            attn_bwd_dq_tile<G>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed,
+            attn_bwd_dq_tile<G>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed,
                                 dq, lddq, pair, pass == 0 ? heavy : light);
         }
     }
@@ -842,15 +847,15 @@ static int launch_fwd(const float* q, int ldq, const float* k, int ldk, const fl
 }
 
 template <int G>
-static int launch_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* d_o,
-                      const float* lse, const float* delta, const int32_t* kl, const int32_t* ql,
+static int launch_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                      const float* d_o, const float* lse, float* delta, const int32_t* kl, const int32_t* ql,
                       const int32_t* row_empty, const int32_t* tile_empty, int B, int S, int nq, int nkv, float scale,
                       float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                       hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<G>, grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl,
-                       ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<G>, grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse, delta,
+                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd/dq");
     static bool attr_set = false;
     auto kfn = attn_bwd_dkv_kernel<G>;
@@ -936,14 +941,9 @@ extern "C" int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, 
                     aligned16(d_o) && aligned16(o),
                     "gamer_attn_bwd: gradient buffers must be 16-byte aligned with leading dims %% 4 == 0");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t waves = (int64_t)B * S * nq;
-    int blocks = (int)((waves + 3) / 4);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(AT_THREADS), 0, st, o, d_o, B, S, nq, delta);
-    GAMER_CHECK_LAUNCH("gamer_attn_bwd/delta");
     switch (nq / nkv) {
-        case 1: return launch_bwd<1>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, st);
-        case 2: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, st);
-        default: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, st);
+        case 1: return launch_bwd<1>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, st);
+        case 2: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, st);
+        default: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, st);
     }
 }

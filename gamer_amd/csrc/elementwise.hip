@@ -247,6 +247,13 @@ rowtable_bwd_kernel(const float* __restrict__ dy, int lddy, int col0, const int3
 // ---------------------------------------------------------------------------------------------
 // q/k per-head RMSNorm + RoPE (+ behaviour bias), head_dim = 64: one wave per (token, head)
 // ---------------------------------------------------------------------------------------------
+// 16 lanes x float4 per (token, head) row, four rows per wave: 16-byte accesses, the 64-wide reductions
+// are four xor-shuffles inside the 16-lane group, the RoPE partner (d +- 32) is lane +- 8 of the group.
+__device__ __forceinline__ float group16_sum(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
 __global__ void __launch_bounds__(EW_THREADS)
 qknorm_rope_fwd_kernel(float* __restrict__ qkv, int T, int S, int nq, int nkv,
                        const float* __restrict__ wq, const float* __restrict__ wk, float eps,
@@ -255,43 +262,64 @@ qknorm_rope_fwd_kernel(float* __restrict__ qkv, int T, int S, int nq, int nkv,
                        const float* __restrict__ bias_v, const int32_t* __restrict__ act_idx,
                        float* __restrict__ q_rot, float* __restrict__ k_rot) {
     const int lane = threadIdx.x & 63;
+    const int g = lane & 15, sub = lane >> 4;
     const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * EW_THREADS) >> 6;
     const bool cross = bias_q != nullptr;
     const int NH = nq + nkv + (cross ? nkv : 0);
     const int ldqkv = (nq + 2 * nkv) * 64;
-    const float wql = wq[lane], wkl = wk[lane];
+    const float4 wq4 = reinterpret_cast<const float4*>(wq)[g], wk4 = reinterpret_cast<const float4*>(wk)[g];
+    const float sgn = g < 8 ? -1.f : 1.f;
     const int64_t total = (int64_t)T * NH;
-    for (int64_t i = wave; i < total; i += nwaves) {
-        const int t = (int)(i / NH);
-        const int hd = (int)(i % NH);
+    for (int64_t i0 = wave * 4; i0 < total; i0 += nwaves * 4) {
+        const int64_t i = i0 + sub;
+        const bool live = i < total;
+        const int64_t ic = live ? i : total - 1;
+        const int t = (int)(ic / NH);
+        const int hd = (int)(ic % NH);
         const int a = cross ? act_idx[t] : 0;
         float* row = qkv + (int64_t)t * ldqkv;
         if (hd < nq + nkv) {
             const bool isq = hd < nq;
-            const int col = hd * 64 + lane;              // q heads then k heads are contiguous in qkv
-            float x = row[col];
-            if (cross) x += isq ? bias_q[a * nq * 64 + hd * 64 + lane] : bias_k[a * nkv * 64 + (hd - nq) * 64 + lane];
-            if (cross) row[col] = x;                     // keep the pre-norm (biased) value for the backward
-            const float ss = wave_sum(x * x);
+            float4* src = reinterpret_cast<float4*>(row + hd * 64) + g;   // q heads then k heads are contiguous
+            float4 x = *src;
+            if (cross) {
+                const float4 b4 = isq ? reinterpret_cast<const float4*>(bias_q + (int64_t)a * nq * 64 + hd * 64)[g]
+                                      : reinterpret_cast<const float4*>(bias_k + (int64_t)a * nkv * 64 + (hd - nq) * 64)[g];
+                x.x += b4.x; x.y += b4.y; x.z += b4.z; x.w += b4.w;
+                if (live) *src = x;                       // keep the pre-norm (biased) value for the backward
+            }
+            const float ss = group16_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
             const float rstd = rsqrtf(ss * (1.f / 64.f) + eps);
-            const float yv = (isq ? wql : wkl) * (x * rstd);
-            const float partner = __shfl_xor(yv, 32, 64);
-            const float rot = lane < 32 ? -partner : partner;
+            const float4 w4 = isq ? wq4 : wk4;
+            float4 y;
+            y.x = w4.x * (x.x * rstd); y.y = w4.y * (x.y * rstd); y.z = w4.z * (x.z * rstd); y.w = w4.w * (x.w * rstd);
+            float4 pr;
+            pr.x = __shfl_xor(y.x, 8, 64); pr.y = __shfl_xor(y.y, 8, 64); pr.z = __shfl_xor(y.z, 8, 64); pr.w = __shfl_xor(y.w, 8, 64);
             const int pos = t % S;
-            const float o = yv * cos_t[pos * 64 + lane] + rot * sin_t[pos * 64 + lane];
-            if (isq) q_rot[(int64_t)t * nq * 64 + hd * 64 + lane] = o;
-            else k_rot[(int64_t)t * nkv * 64 + (hd - nq) * 64 + lane] = o;
+            const float4 c4 = reinterpret_cast<const float4*>(cos_t + pos * 64)[g];
+            const float4 s4 = reinterpret_cast<const float4*>(sin_t + pos * 64)[g];
+            float4 o;
+            o.x = y.x * c4.x + sgn * pr.x * s4.x; o.y = y.y * c4.y + sgn * pr.y * s4.y;
+            o.z = y.z * c4.z + sgn * pr.z * s4.z; o.w = y.w * c4.w + sgn * pr.w * s4.w;
+            if (live) {
+                if (isq) reinterpret_cast<float4*>(q_rot + (int64_t)t * nq * 64 + hd * 64)[g] = o;
+                else reinterpret_cast<float4*>(k_rot + (int64_t)t * nkv * 64 + (hd - nq) * 64)[g] = o;
+            }
         } else {
+            // (only reached when cross) v += bias_v; the shuffles above are skipped by the whole 16-lane group
             const int hv = hd - nq - nkv;
-            const int col = (nq + nkv + hv) * 64 + lane;
-            row[col] += bias_v[a * nkv * 64 + hv * 64 + lane];
+            float4* dst = reinterpret_cast<float4*>(row + (nq + nkv + hv) * 64) + g;
+            const float4 b4 = reinterpret_cast<const float4*>(bias_v + (int64_t)a * nkv * 64 + hv * 64)[g];
+            float4 x = *dst;
+            x.x += b4.x; x.y += b4.y; x.z += b4.z; x.w += b4.w;
+            if (live) *dst = x;
         }
     }
 }
 
-// Each wave keeps one head for its whole life so that the norm-weight and bias gradients
-// accumulate in registers; one set of atomics per wave at the end.
+// Each wave keeps one head for its whole life so that the norm-weight and bias gradients accumulate in
+// registers (four tokens per iteration, one per 16-lane group); one set of atomics per wave at the end.
 __global__ void __launch_bounds__(EW_THREADS)
 qknorm_rope_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dq_rot,
                        const float* __restrict__ dk_rot, int T, int S, int nq, int nkv,
@@ -302,65 +330,97 @@ qknorm_rope_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ 
                        float* __restrict__ dbias_q, float* __restrict__ dbias_k, float* __restrict__ dbias_v,
                        int waves_per_head) {
     const int lane = threadIdx.x & 63;
+    const int g = lane & 15, sub = lane >> 4;
     const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
     const int NH = nq + nkv + (cross ? nkv : 0);
     if (wave >= (int64_t)NH * waves_per_head) return;
     const int hd = (int)(wave % NH);
-    const int t0 = (int)(wave / NH);
+    const int w0 = (int)(wave / NH);
     const int ldqkv = (nq + 2 * nkv) * 64;
-    float dwacc = 0.f;
-    float dbacc[TBL_MAXROWS];
+    float4 dwacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 dbacc[TBL_MAXROWS];
 #pragma unroll
-    for (int a = 0; a < TBL_MAXROWS; ++a) dbacc[a] = 0.f;
+    for (int a = 0; a < TBL_MAXROWS; ++a) dbacc[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float sgn = g < 8 ? 1.f : -1.f;             // transpose of the rotation
     if (hd < nq + nkv) {
         const bool isq = hd < nq;
-        const float wl = isq ? wq[lane] : wk[lane];
-        const int col = hd * 64 + lane;
-        for (int t = t0; t < T; t += waves_per_head) {
-            const float x = qkv[(int64_t)t * ldqkv + col];          // pre-norm value (bias included)
-            const float dout = isq ? dq_rot[(int64_t)t * nq * 64 + hd * 64 + lane]
-                                   : dk_rot[(int64_t)t * nkv * 64 + (hd - nq) * 64 + lane];
-            const int pos = t % S;
-            const float cs = cos_t[pos * 64 + lane], sn = sin_t[pos * 64 + lane];
-            const float dpart = __shfl_xor(dout, 32, 64);
-            // transpose of the rotation: dy_j = dout_j cos_j + (j<32 ? +1 : -1) * dout_partner * sin_j
-            const float dy = dout * cs + (lane < 32 ? dpart : -dpart) * sn;
-            const float ss = wave_sum(x * x);
+        const float4 w4 = isq ? reinterpret_cast<const float4*>(wq)[g] : reinterpret_cast<const float4*>(wk)[g];
+        for (int tb = w0 * 4; tb < T; tb += waves_per_head * 4) {
+            const int t = tb + sub;
+            const bool live = t < T;
+            const int tc = live ? t : T - 1;
+            const float4 x = reinterpret_cast<const float4*>(qkv + (int64_t)tc * ldqkv + hd * 64)[g];   // pre-norm (bias included)
+            const float4 d = isq ? reinterpret_cast<const float4*>(dq_rot + (int64_t)tc * nq * 64 + hd * 64)[g]
+                                 : reinterpret_cast<const float4*>(dk_rot + (int64_t)tc * nkv * 64 + (hd - nq) * 64)[g];
+            const int pos = tc % S;
+            const float4 c4 = reinterpret_cast<const float4*>(cos_t + pos * 64)[g];
+            const float4 s4 = reinterpret_cast<const float4*>(sin_t + pos * 64)[g];
+            float4 dp;
+            dp.x = __shfl_xor(d.x, 8, 64); dp.y = __shfl_xor(d.y, 8, 64); dp.z = __shfl_xor(d.z, 8, 64); dp.w = __shfl_xor(d.w, 8, 64);
+            // dy_j = dout_j cos_j + (j<32 ? +1 : -1) * dout_partner * sin_j
+            float4 dy;
+            dy.x = d.x * c4.x + sgn * dp.x * s4.x; dy.y = d.y * c4.y + sgn * dp.y * s4.y;
+            dy.z = d.z * c4.z + sgn * dp.z * s4.z; dy.w = d.w * c4.w + sgn * dp.w * s4.w;
+            const float ss = group16_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
             const float rstd = rsqrtf(ss * (1.f / 64.f) + eps);
-            const float xh = x * rstd;
-            dwacc += dy * xh;
-            const float g = dy * wl;
-            const float dot = wave_sum(g * xh) * (1.f / 64.f);
-            const float dx = rstd * (g - xh * dot);
-            dqkv[(int64_t)t * ldqkv + col] = dx;
+            float4 xh;
+            xh.x = x.x * rstd; xh.y = x.y * rstd; xh.z = x.z * rstd; xh.w = x.w * rstd;
+            const float lv = live ? 1.f : 0.f;
+            dwacc.x += lv * dy.x * xh.x; dwacc.y += lv * dy.y * xh.y; dwacc.z += lv * dy.z * xh.z; dwacc.w += lv * dy.w * xh.w;
+            float4 gg;
+            gg.x = dy.x * w4.x; gg.y = dy.y * w4.y; gg.z = dy.z * w4.z; gg.w = dy.w * w4.w;
+            const float dot = group16_sum(gg.x * xh.x + gg.y * xh.y + gg.z * xh.z + gg.w * xh.w) * (1.f / 64.f);
+            float4 dx;
+            dx.x = rstd * (gg.x - xh.x * dot); dx.y = rstd * (gg.y - xh.y * dot);
+            dx.z = rstd * (gg.z - xh.z * dot); dx.w = rstd * (gg.w - xh.w * dot);
+            if (live) reinterpret_cast<float4*>(dqkv + (int64_t)t * ldqkv + hd * 64)[g] = dx;
             if (cross) {
-                const int a_t = act_idx[t];
+                const int a_t = live ? act_idx[t] : -1;
 #pragma unroll
-                for (int a = 0; a < TBL_MAXROWS; ++a) dbacc[a] += (a_t == a) ? dx : 0.f;
-            }
-        }
-        atomicAdd(isq ? &dwq[lane] : &dwk[lane], dwacc);
-        if (cross) {
-#pragma unroll
-            for (int a = 0; a < TBL_MAXROWS; ++a) {
-                if (a < nb1) {
-                    if (isq) atomicAdd(&dbias_q[a * nq * 64 + hd * 64 + lane], dbacc[a]);
-                    else atomicAdd(&dbias_k[a * nkv * 64 + (hd - nq) * 64 + lane], dbacc[a]);
+                for (int a = 0; a < TBL_MAXROWS; ++a) {
+                    const float m = (a_t == a) ? 1.f : 0.f;
+                    dbacc[a].x += m * dx.x; dbacc[a].y += m * dx.y; dbacc[a].z += m * dx.z; dbacc[a].w += m * dx.w;
                 }
             }
         }
     } else {
         const int hv = hd - nq - nkv;
-        const int col = (nq + nkv + hv) * 64 + lane;
-        for (int t = t0; t < T; t += waves_per_head) {
-            const float dv = dqkv[(int64_t)t * ldqkv + col];
-            const int a_t = act_idx[t];
+        for (int tb = w0 * 4; tb < T; tb += waves_per_head * 4) {
+            const int t = tb + sub;
+            const bool live = t < T;
+            const int tc = live ? t : T - 1;
+            const float4 dv = reinterpret_cast<const float4*>(dqkv + (int64_t)tc * ldqkv + (nq + nkv + hv) * 64)[g];
+            const int a_t = live ? act_idx[t] : -1;
 #pragma unroll
-            for (int a = 0; a < TBL_MAXROWS; ++a) dbacc[a] += (a_t == a) ? dv : 0.f;
+            for (int a = 0; a < TBL_MAXROWS; ++a) {
+                const float m = (a_t == a) ? 1.f : 0.f;
+                dbacc[a].x += m * dv.x; dbacc[a].y += m * dv.y; dbacc[a].z += m * dv.z; dbacc[a].w += m * dv.w;
+            }
         }
+    }
+    // fold the four 16-lane groups, then one atomic per element from group 0
+    auto fold = [&](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
+    if (hd < nq + nkv) {
+        const bool isq = hd < nq;
+        const float a0 = fold(dwacc.x), a1 = fold(dwacc.y), a2 = fold(dwacc.z), a3 = fold(dwacc.w);
+        if (sub == 0) {
+            float* dw = (isq ? dwq : dwk) + 4 * g;
+            atomicAdd(dw + 0, a0); atomicAdd(dw + 1, a1); atomicAdd(dw + 2, a2); atomicAdd(dw + 3, a3);
+        }
+    }
+    if (cross) {
+        float* base;
+        if (hd < nq) base = dbias_q + hd * 64;
+        else if (hd < nq + nkv) base = dbias_k + (hd - nq) * 64;
+        else base = dbias_v + (hd - nq - nkv) * 64;
+        const int ldb = hd < nq ? nq * 64 : nkv * 64;
 #pragma unroll
         for (int a = 0; a < TBL_MAXROWS; ++a) {
-            if (a < nb1) atomicAdd(&dbias_v[a * nkv * 64 + hv * 64 + lane], dbacc[a]);
+            const float b0 = fold(dbacc[a].x), b1 = fold(dbacc[a].y), b2 = fold(dbacc[a].z), b3 = fold(dbacc[a].w);
+            if (a < nb1 && sub == 0) {
+                float* d = base + (int64_t)a * ldb + 4 * g;
+                atomicAdd(d + 0, b0); atomicAdd(d + 1, b1); atomicAdd(d + 2, b2); atomicAdd(d + 3, b3);
+            }
         }
     }
 }
@@ -661,7 +721,7 @@ extern "C" int gamer_qknorm_rope_fwd(float* qkv, int T, int S, int nq, int nkv, 
     const bool cross = bias_q != nullptr;
     GAMER_CHECK_ARG(!cross || (bias_k && bias_v && act_idx), "gamer_qknorm_rope_fwd: cross needs bias_k, bias_v, act_idx");
     const int NH = nq + nkv + (cross ? nkv : 0);
-    hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3(grid_for_waves((int64_t)T * NH)), dim3(EW_THREADS), 0, ST(stream),
+    hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3(grid_for_waves(((int64_t)T * NH + 3) / 4)), dim3(EW_THREADS), 0, ST(stream),
                        qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot, k_rot);
     GAMER_CHECK_LAUNCH("gamer_qknorm_rope_fwd");
     return 0;
@@ -681,7 +741,7 @@ extern "C" int gamer_qknorm_rope_bwd(const float* qkv, const float* dq_rot, cons
                     "gamer_qknorm_rope_bwd: cross needs act_idx, dbias_*, 0<nb1<=8 (nb1=%d)", nb1);
     const int NH = nq + nkv + (cross ? nkv : 0);
     int waves_per_head = 8192 / NH;
-    if (waves_per_head > T) waves_per_head = T;
+    if (waves_per_head > (T + 3) / 4) waves_per_head = (T + 3) / 4;
     if (waves_per_head < 1) waves_per_head = 1;
     const int64_t total_waves = (int64_t)NH * waves_per_head;
     const int blocks = (int)((total_waves + EW_WAVES - 1) / EW_WAVES);

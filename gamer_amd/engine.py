@@ -169,7 +169,8 @@ class _Workspace:
                 d = dict(
                     h1=torch.empty(T, H, **f32), qkv=torch.empty(T, QKV, **f32), q=torch.empty(T, NQ, **f32),
                     k=torch.empty(T, NKV, **f32), ao=torch.empty(T, NQ, **f32), lse=torch.empty(B, nq, S, **f32),
-                    hin=torch.empty(T, din_max, **f32), g=torch.empty(T, I, **f32), u=torch.empty(T, I, **f32))
+                    hin=torch.empty(T, din_max, **f32), g=torch.empty(T, I, **f32), u=torch.empty(T, I, **f32),
+                    hm=torch.empty(T, I, **f32))
                 if cross or not keep:
                     d.update(h2=torch.empty(T, H, **f32), qkv_c=torch.empty(T, QKV, **f32),
                              q_c=torch.empty(T, NQ, **f32), k_c=torch.empty(T, NKV, **f32),
@@ -186,7 +187,6 @@ class _Workspace:
         self.x_final = torch.empty(T, H, **f32) if keep else self.x[0][0]
         # scratch shared by all layers
         self.tmpH = [torch.empty(T, H, **f32) for _ in range(4)]
-        self.hm = torch.empty(T, I, **f32)
         if train:
             self.dx = torch.empty(T, H, **f32)
             self.dhm = torch.empty(T, I, **f32)
@@ -353,8 +353,8 @@ class Engine:
             grp = dict(groups=E, group_offsets=ws.offsets)
             ops.linear_fwd(A["hin"], din, W.gate, din, A["g"], I, T, I, din, strideB=I * din, **grp)
             ops.linear_fwd(A["hin"], din, W.up, din, A["u"], I, T, I, din, strideB=I * din, **grp)
-            ops.swiglu_fwd(A["g"], A["u"], T * I, p_res, self._seed(l, 4), ws.hm)
-            ops.linear_fwd(ws.hm, I, W.down, I, t1, H, T, H, I, strideB=H * I, **grp)
+            ops.swiglu_fwd(A["g"], A["u"], T * I, p_res, self._seed(l, 4), A["hm"])
+            ops.linear_fwd(A["hm"], I, W.down, I, t1, H, T, H, I, strideB=H * I, **grp)
             xnext = ws.x[l + 1][0] if l + 1 < cfg.num_hidden_layers else ws.x_final
             ops.residual_dropout_fwd(xcur, t1, p_res, self._seed(l, 5), ws.slot, xnext)
         # ---- final norm, tied head, temperature CE (model.py:869,1001,904-922) ----
@@ -436,8 +436,7 @@ class Engine:
             xlast = xs[2] if W.cross else xs[1]
             # ---- experts ----
             ops.residual_dropout_bwd(ws.dx, p_res, self._seed(l, 5), t0, ws.slot)          # d out_sorted
-            ops.swiglu_fwd(A["g"], A["u"], T * I, p_res, self._seed(l, 4), ws.hm)           # recompute hm
-            ops.linear_wgrad(t0, H, ws.hm, I, G.down, I, T, H, I, strideC=H * I, **grp)
+            ops.linear_wgrad(t0, H, A["hm"], I, G.down, I, T, H, I, strideC=H * I, **grp)
             ops.linear_dgrad(t0, H, W.down, I, ws.dhm, I, T, H, I, strideB=H * I, **grp)
             ops.swiglu_bwd(A["g"], A["u"], ws.dhm, T * I, p_res, self._seed(l, 4))          # g <- dg, u <- du
             ops.linear_wgrad(A["g"], I, A["hin"], din, G.gate, din, T, I, din, strideC=I * din, **grp)
