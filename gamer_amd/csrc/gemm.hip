@@ -140,8 +140,8 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row
     }
 }
 
-template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP>
-__global__ void __launch_bounds__(GEMM_THREADS, 2)
+template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF>
+__global__ void __launch_bounds__(GEMM_THREADS, NBUF == 1 ? 3 : 2)
 gemm_f32_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // buffer b: A image at smem + 2*b*TILE_FLOATS, B image right behind it
@@ -288,35 +288,59 @@ gemm_f32_kernel(const GemmParams p) {
             pa += sa;
             pb += sb;
         };
+        if (NBUF == 1) {
+            // one LDS image (36 KB): three workgroups per CU; two barriers per K-step, covered by the other
+            // two waves of the SIMD
+            fast_load();
+            for (int kt = 0; kt < nkt; ++kt) {
+                if (kt > 0) __syncthreads();
+                store_tile(smem);
+                __syncthreads();
+                if (kt + 1 < nkt) fast_load();
+                mfma_tile(smem);
+            }
+        } else {
         fast_load();
-        store_tile(smem);
-        __syncthreads();
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int cur = kt & 1;
-            const bool more = kt + 1 < nkt;
-            if (STAMP) { __builtin_amdgcn_sched_barrier(0); t0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
-            if (more) fast_load();
-            if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[0] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
-            mfma_tile(smem + 2 * cur * TILE_FLOATS);
-            if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[1] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
-            if (more) store_tile(smem + 2 * (cur ^ 1) * TILE_FLOATS);
-            if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[2] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
-            __syncthreads();
-            if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[3] += t1 - t0; __builtin_amdgcn_sched_barrier(0); }
-        }
-    } else {
-        if (nkt > 0) {
-            load_tile(kbeg);
             store_tile(smem);
-        }
-        __syncthreads();
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int cur = kt & 1;
-            const bool more = kt + 1 < nkt;
-            if (more) load_tile(kbeg + (kt + 1) * BK);
-            mfma_tile(smem + 2 * cur * TILE_FLOATS);
-            if (more) store_tile(smem + 2 * (cur ^ 1) * TILE_FLOATS);
             __syncthreads();
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int cur = kt & 1;
+                const bool more = kt + 1 < nkt;
+                if (STAMP) { __builtin_amdgcn_sched_barrier(0); t0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+                if (more) fast_load();
+                if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[0] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
+                mfma_tile(smem + 2 * cur * TILE_FLOATS);
+                if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[1] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
+                if (more) store_tile(smem + 2 * (cur ^ 1) * TILE_FLOATS);
+                if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[2] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
+                __syncthreads();
+                if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[3] += t1 - t0; __builtin_amdgcn_sched_barrier(0); }
+            }
+    }
+    } else {
+        if (NBUF == 1) {
+            if (nkt > 0) load_tile(kbeg);
+            for (int kt = 0; kt < nkt; ++kt) {
+                if (kt > 0) __syncthreads();
+                store_tile(smem);
+                __syncthreads();
+                if (kt + 1 < nkt) load_tile(kbeg + (kt + 1) * BK);
+                mfma_tile(smem);
+            }
+        } else {
+            if (nkt > 0) {
+                load_tile(kbeg);
+                store_tile(smem);
+            }
+            __syncthreads();
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int cur = kt & 1;
+                const bool more = kt + 1 < nkt;
+                if (more) load_tile(kbeg + (kt + 1) * BK);
+                mfma_tile(smem + 2 * cur * TILE_FLOATS);
+                if (more) store_tile(smem + 2 * (cur ^ 1) * TILE_FLOATS);
+                __syncthreads();
+            }
         }
     }
     const unsigned long long t_loop_end = STAMP ? stamp_now() : 0;
@@ -361,10 +385,10 @@ gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP>
+template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF>
 static int launch_gemm_t(const GemmParams& p, int blocks, hipStream_t st, int lds) {
     static int attr_lds = 0;
-    auto kfn = gemm_f32_kernel<A_KC, B_KC, MODE, ACCUM, STAMP>;
+    auto kfn = gemm_f32_kernel<A_KC, B_KC, MODE, ACCUM, STAMP, NBUF>;
     if (attr_lds != lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -381,18 +405,25 @@ static int launch_gemm_t(const GemmParams& p, int blocks, hipStream_t st, int ld
 
 template <bool A_KC, bool B_KC, int MODE>
 static int launch_gemm(const GemmParams& p, int blocks, hipStream_t st) {
-    static int stamp = -1, solo = 0;
+    static int stamp = -1, solo = 0, nbuf = 2;
     if (stamp < 0) {
         const char* e = getenv("GAMER_GEMM_STAMP");
         stamp = (e && e[0] == '1') ? 1 : 0;
         const char* s2 = getenv("GAMER_GEMM_SOLO");
         solo = (s2 && s2[0] == '1') ? 1 : 0;
+        const char* s3 = getenv("GAMER_GEMM_NBUF");
+        nbuf = (s3 && s3[0] == '1') ? 1 : 2;
     }
     const int lds = solo ? 150 * 1024 : GEMM_LDS_BYTES;          // solo: one workgroup per CU (diagnostics)
     const bool acc = MODE == 0 && p.accumulate;
-    if (stamp) return launch_gemm_t<A_KC, B_KC, MODE, false, true>(p, blocks, st, lds);
-    if (acc) return launch_gemm_t<A_KC, B_KC, MODE, true, false>(p, blocks, st, lds);
-    return launch_gemm_t<A_KC, B_KC, MODE, false, false>(p, blocks, st, lds);
+    if (stamp) return launch_gemm_t<A_KC, B_KC, MODE, false, true, 2>(p, blocks, st, lds);
+    if (nbuf == 1) {
+        const int lds1 = 2 * TILE_FLOATS * (int)sizeof(float);
+        if (acc) return launch_gemm_t<A_KC, B_KC, MODE, true, false, 1>(p, blocks, st, lds1);
+        return launch_gemm_t<A_KC, B_KC, MODE, false, false, 1>(p, blocks, st, lds1);
+    }
+    if (acc) return launch_gemm_t<A_KC, B_KC, MODE, true, false, 2>(p, blocks, st, lds);
+    return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2>(p, blocks, st, lds);
 }
 
 }  // namespace gamer

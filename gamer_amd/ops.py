@@ -119,19 +119,20 @@ def linear_dgrad(dy, lddy, W, ldw, dx, lddx, M, N_out, K_in, accumulate=False, *
     gemm(dy, lddy, 1, W, 1, ldw, dx, lddx, M, K_in, N_out, accumulate=accumulate, **grp)
 
 
-def pick_kchunk(rows: int, tiles: int, target_blocks: int = 1024) -> int:
-    """Contraction chunk for the wgrad split: enough workgroups to fill 256 CUs, multiple of 32."""
-    want = max(1, target_blocks // max(1, tiles))
-    chunk = (rows + want - 1) // want
-    chunk = max(256, ((chunk + 31) // 32) * 32)
+def pick_kchunk(rows: int, grouped: bool) -> int:
+    """Token chunk per workgroup of the wgrad split.  Measured on MI355X at T = 517k (tools/wgrad_probe.py):
+    1024 rows for the grouped (expert) form and 2048 for the plain one are within 3 % of the best for every
+    shape on this path; 4k+ chunks lose 15-25 % to the tail (too few, too long workgroups)."""
+    chunk = 1024 if grouped else 2048
+    while chunk > 256 and rows < 64 * chunk:          # small problems: keep >= ~64 chunks
+        chunk //= 2
     return chunk
 
 
 def linear_wgrad(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups=1, group_offsets=None, strideC=0, kchunk=None):
     """dW[N_out,K_in] += dy[rows,N_out]^T @ x[rows,K_in]   (dW must be initialised; fp32 atomics)."""
     if kchunk is None:
-        tiles = ((N_out + 127) // 128) * ((K_in + 127) // 128)
-        kchunk = pick_kchunk(rows, tiles)     # chunks run over all rows of all groups
+        kchunk = pick_kchunk(rows, groups > 1)
     gemm(dy, 1, lddy, x, 1, ldx, dW, lddw, N_out, K_in, rows, groups=groups, group_mode=1,
          group_offsets=group_offsets, strideC=strideC, kchunk=kchunk)
 
