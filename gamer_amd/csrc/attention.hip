@@ -487,13 +487,20 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
                 dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, dof[kk][2], dp, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, dof[kk][3], dp, 0, 0, 0);
             }
+            // key levels of this lane's 16 keys in four 16-byte LDS reads; branch-free predicates (a lazily
+            // evaluated && makes hipcc branch and wait on an LDS read per element)
+            int4 kl4[4];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) kl4[g4] = *reinterpret_cast<const int4*>(&kls[cur][8 * g4 + 4 * h]);
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int key = rowmap(reg, h);
-                const int j = j0 + key;
-                const bool allowed = (j <= iq) && (kls[cur][key] < my_ql) && valid_q;
-                float pe = allowed ? __expf(st[reg] - my_lse) : 0.f;
-                if (my_empty) pe = (j < S) ? invS : 0.f;
+                const int j = j0 + rowmap(reg, h);
+                const int klv = (reg & 3) == 0 ? kl4[reg >> 2].x : (reg & 3) == 1 ? kl4[reg >> 2].y
+                              : (reg & 3) == 2 ? kl4[reg >> 2].z : kl4[reg >> 2].w;
+                const bool allowed = (j <= iq) & (klv < my_ql) & valid_q;
+                float pe = __expf(st[reg] - my_lse);
+                pe = allowed ? pe : 0.f;
+                pe = my_empty ? ((j < S) ? invS : 0.f) : pe;
                 const float mult = rng.on ? rng.mult(rb, (uint32_t)j) : 1.f;
                 st[reg] = pe * (mult * dp[reg] - my_delta);      // dS^T
             }
@@ -725,9 +732,10 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
                     const int reg = 4 * g4 + e;
                     const int i = i0 + qb + e;
                     const bool inq = i < S;
-                    const bool allowed = inq && valid_k && (jk <= i) && (my_kl < qlv[e]);
-                    float pe = allowed ? __expf(st[reg] * scale - lv[e]) : 0.f;
-                    if (emv[e] != 0) pe = (inq && valid_k) ? invS : 0.f;
+                    const bool allowed = inq & valid_k & (jk <= i) & (my_kl < qlv[e]);
+                    float pe = __expf(st[reg] * scale - lv[e]);
+                    pe = allowed ? pe : 0.f;
+                    pe = (emv[e] != 0) ? ((inq & valid_k) ? invS : 0.f) : pe;
                     const float mult = rng.on ? rng.mult(rng.row_base(drop_head + (uint32_t)(inq ? i : 0)), (uint32_t)jkc) : 1.f;
                     st[reg] = pe * (mult * dp[reg] - dl[e]);     // dS[query][key]
                     dp[reg] = pe * mult;                          // dropped P[query][key]
