@@ -157,6 +157,32 @@ def log(msg: str):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def committed_traffic(kernel_substr: str):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summaries of this same command
+    (profiles/*_pmc_{FETCH,WRITE}_SIZE.csv; separate --pmc passes).  gfx950 correction from
+    MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> doubled;
+    WRITE_SIZE is exact; both are in KiB.  Returns None when no profile is committed."""
+    import csv
+    import glob
+    prof = os.path.join(ROOT, "profiles")
+    fetch = sorted(glob.glob(os.path.join(prof, "*_pmc_FETCH_SIZE.csv")))
+    write = sorted(glob.glob(os.path.join(prof, "*_pmc_WRITE_SIZE.csv")))
+    if not fetch or not write:
+        return None
+
+    def avg(path, col):
+        for r in csv.DictReader(open(path)):
+            if kernel_substr in r["kernel"]:
+                return float(r[col])
+        return None
+    f = avg(fetch[-1], "avg_FETCH_SIZE_KB_per_dispatch")
+    w = avg(write[-1], "avg_WRITE_SIZE_KB_per_dispatch")
+    if f is None or w is None:
+        return None
+    return {"bytes_per_launch": (2.0 * f + w) * 1024.0, "source": os.path.basename(fetch[-1]) + " + " + os.path.basename(write[-1]),
+            "fetch_kib_raw": f, "write_kib": w}
+
+
 def cpu_baseline(cfg_dict, seq_items: int, micro_batch: int = 8, timed_steps: int = 2):
     """The CPU oracle's train step (fwd + bwd + clip + AdamW, dropout on) on this host's cores."""
     from oracle import qwen3multi_oracle as orc
@@ -288,6 +314,9 @@ def main():
         gemm_ms = sum(k["ms_per_step"] for k in gemm_rows)
         gemm_tf = sum(k["tflops"] * k["ms_per_step"] for k in gemm_rows) / max(gemm_ms, 1e-9)
         ms_per_step = elapsed / args.steps * 1e3
+        kname = {"gemm_fwd": "gemm_f32_kernel<true, true, 0, false", "gemm_dgrad": "gemm_f32_kernel<true, false, 0, false",
+                 "gemm_wgrad": "gemm_f32_kernel<false, false, 1, false"}.get(dom["kernel"] if dom else "", None)
+        traffic = committed_traffic(kname) if (kname and args.batch == 1024 and args.items == 101) else None
         result = {
             "metric": "train-step sequences/sec, Qwen3Multi SMB decoder, his_len=100",
             "value": seqs / elapsed,
@@ -316,7 +345,9 @@ def main():
                 "peak": FP32_MATRIX_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": dom["tflops"] / FP32_MATRIX_PEAK_TFLOPS if dom else None,
-                "traffic": None,
+                "traffic": traffic["bytes_per_launch"] if traffic else None,
+                "traffic_source": traffic["source"] if traffic else None,
+                "algorithmic_flop_per_launch": (dom["tflops"] * 1e12 * dom["avg_launch_ms"] * 1e-3) if dom else None,
                 "avg_launch_ms": dom["avg_launch_ms"] if dom else None,
                 "all_gemm_tflops": gemm_tf,
                 "all_gemm_ms_per_step": gemm_ms,

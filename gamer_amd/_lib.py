@@ -36,6 +36,10 @@ class GemmDesc(C.Structure):
         ("group_offsets", c_void_p),
         ("strideB", c_int64), ("strideC", c_int64),
         ("kchunk", c_int),
+        ("resid", c_void_p),
+        ("row_map", c_void_p),
+        ("p_drop", c_float),
+        ("seed", c_uint64),
     ]
 
 

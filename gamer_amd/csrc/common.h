@@ -65,7 +65,20 @@ struct DropoutRng {
         thr = t >= 4294967040.f ? 0xffffffffU : (uint32_t)t;
         scale = on ? 1.f / (1.f - p) : 1.f;
     }
-    // multiplier for element idx: 0 (dropped) or 1/(1-p)
+    // multipliers of the four elements 4*idx4 .. 4*idx4+3 (one float4): two hashes -> four 16-bit uniforms,
+    // keep iff u16 >= p*65536.  This is the form every elementwise kernel and the GEMM epilogue use, so a
+    // mask generated in a fused epilogue is regenerated bit-identically by the stand-alone backward kernel.
+    __device__ __forceinline__ void mult4(uint32_t idx4, float (&m)[4]) const {
+        if (!on) { m[0] = m[1] = m[2] = m[3] = 1.f; return; }
+        const uint32_t thr16 = thr >> 16;
+        const uint32_t h1 = mix32(idx4 * 0x9e3779b1U + k0);
+        const uint32_t h2 = mix32(h1 ^ k1);
+        m[0] = (h1 & 0xffffU) >= thr16 ? scale : 0.f;
+        m[1] = (h1 >> 16) >= thr16 ? scale : 0.f;
+        m[2] = (h2 & 0xffffU) >= thr16 ? scale : 0.f;
+        m[3] = (h2 >> 16) >= thr16 ? scale : 0.f;
+    }
+    // multiplier for element idx: 0 (dropped) or 1/(1-p)   (kept for reference; unused by the kernels)
     __device__ __forceinline__ float mult(uint64_t idx) const {
         if (!on) return 1.f;
         uint32_t h = mix32((uint32_t)idx ^ k0);

@@ -440,9 +440,9 @@ residual_dropout_fwd_kernel(const float4* x_in, const float4* __restrict__ delta
         const int64_t r = src_rows ? src_rows[t] : t;
         const float4 d = delta[r * H4 + c];
         float4 v = x_in[i];
-        const uint64_t e = (uint64_t)i * 4;
-        v.x += rng.mult(e) * d.x; v.y += rng.mult(e + 1) * d.y;
-        v.z += rng.mult(e + 2) * d.z; v.w += rng.mult(e + 3) * d.w;
+        float m[4];
+        rng.mult4((uint32_t)i, m);
+        v.x += m[0] * d.x; v.y += m[1] * d.y; v.z += m[2] * d.z; v.w += m[3] * d.w;
         x_out[i] = v;
     }
 }
@@ -457,10 +457,10 @@ residual_dropout_bwd_kernel(const float4* __restrict__ dx, const int32_t* __rest
         const int c = (int)(i % H4);
         const int64_t r = src_rows ? src_rows[t] : t;
         const float4 g = dx[i];
-        const uint64_t e = (uint64_t)i * 4;
+        float m[4];
+        rng.mult4((uint32_t)i, m);
         float4 o;
-        o.x = rng.mult(e) * g.x; o.y = rng.mult(e + 1) * g.y;
-        o.z = rng.mult(e + 2) * g.z; o.w = rng.mult(e + 3) * g.w;
+        o.x = m[0] * g.x; o.y = m[1] * g.y; o.z = m[2] * g.z; o.w = m[3] * g.w;
         ddelta[r * H4 + c] = o;
     }
 }
@@ -471,12 +471,13 @@ swiglu_fwd_kernel(const float4* __restrict__ g, const float4* __restrict__ u, in
     const DropoutRng rng(p, seed);
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
         const float4 a = g[i], b = u[i];
-        const uint64_t e = (uint64_t)i * 4;
+        float m[4];
+        rng.mult4((uint32_t)i, m);
         float4 o;
-        o.x = rng.mult(e) * (silu_f(a.x) * b.x);
-        o.y = rng.mult(e + 1) * (silu_f(a.y) * b.y);
-        o.z = rng.mult(e + 2) * (silu_f(a.z) * b.z);
-        o.w = rng.mult(e + 3) * (silu_f(a.w) * b.w);
+        o.x = m[0] * (silu_f(a.x) * b.x);
+        o.y = m[1] * (silu_f(a.y) * b.y);
+        o.z = m[2] * (silu_f(a.z) * b.z);
+        o.w = m[3] * (silu_f(a.w) * b.w);
         hm[i] = o;
     }
 }
@@ -487,9 +488,9 @@ swiglu_bwd_kernel(float4* __restrict__ g, float4* __restrict__ u, const float4* 
     const DropoutRng rng(p, seed);
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
         const float4 a = g[i], b = u[i], d = dhm[i];
-        const uint64_t e = (uint64_t)i * 4;
-        const float d0 = rng.mult(e) * d.x, d1 = rng.mult(e + 1) * d.y, d2 = rng.mult(e + 2) * d.z,
-                    d3 = rng.mult(e + 3) * d.w;
+        float m[4];
+        rng.mult4((uint32_t)i, m);
+        const float d0 = m[0] * d.x, d1 = m[1] * d.y, d2 = m[2] * d.z, d3 = m[3] * d.w;
         float4 dg, du;
         dg.x = d0 * b.x * dsilu_f(a.x); du.x = d0 * silu_f(a.x);
         dg.y = d1 * b.y * dsilu_f(a.y); du.y = d1 * silu_f(a.y);

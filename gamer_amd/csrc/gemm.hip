@@ -48,6 +48,11 @@ struct GemmParams {
     int64_t strideB, strideC;
     int kchunk;
     int m_tiles, n_tiles;      // tile counts of the C matrix (mode 1) / upper bound of m tiles (mode 0)
+    // fused epilogue (mode 0): C[map(row)] = resid[map(row)] + dropout(alpha*acc)
+    const float* resid;
+    const int32_t* row_map;
+    float p_drop;
+    uint64_t seed;
 };
 
 // blockIdx -> logical tile id such that consecutive logical ids run on one XCD (ids are dealt
@@ -140,7 +145,7 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row
     }
 }
 
-template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF>
+template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, bool EPI>
 __global__ void __launch_bounds__(GEMM_THREADS, NBUF == 1 ? 3 : 2)
 gemm_f32_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -347,26 +352,78 @@ gemm_f32_kernel(const GemmParams p) {
 
     // ---- epilogue: acc[i][j][r] is C[row = (r&3)+8*(r>>2)+4*h][col = lane&31] of its 32x32 tile --
     const bool interior = a_in && b_in;
-    auto emit = [&](float* dst, float v) {
-        if (MODE == 1) atomicAdd(dst, v);
-        else if (ACCUM) *dst += v;
-        else *dst = v;
-    };
+    if (MODE == 0 && NBUF == 2 && interior && (p.ldc & 3) == 0) {
+        // Row-major rewrite through LDS (the K-loop images are dead after its last barrier): each wave
+        // parks its 64x64 patch as [64][68] floats and reads it back one 16-byte row chunk per lane, so the
+        // patch leaves in 16 x 1-KiB store instructions (4 rows x 256 B each) instead of 64 dword stores.
+        float* patch = smem + wid * (64 * 68);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = col0 + wn * 64 + j * 32 + r32;
-            const int rbase = row0 + wm * 64 + i * 32 + 4 * h;
-            float* cbase = Cp + (int64_t)rbase * p.ldc + col;
-            if (interior) {
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) emit(cbase + (int64_t)((r & 3) + 8 * (r >> 2)) * p.ldc, p.alpha * acc[i][j][r]);
+                for (int r = 0; r < 16; ++r)
+                    patch[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + j * 32 + r32] = p.alpha * acc[i][j][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): own LDS writes landed (wave-private patch)
+        const int c4 = (lane & 15) << 2;
+        const DropoutRng rng(EPI ? p.p_drop : 0.f, p.seed);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int lr = (lane >> 4) + 4 * it;             // row inside the patch
+            const float4 v = *reinterpret_cast<const float4*>(patch + lr * 68 + c4);
+            const int row = row0 + wm * 64 + lr;
+            const int col = col0 + wn * 64 + c4;
+            if (EPI) {
+                const int64_t rc = p.row_map ? p.row_map[row] : row;
+                float* dst = Cp + rc * p.ldc + col;
+                const float4 x = *reinterpret_cast<const float4*>(p.resid + rc * p.ldc + col);
+                float m[4];
+                rng.mult4((uint32_t)((rc * p.ldc + col) >> 2), m);
+                float4 o;
+                o.x = x.x + m[0] * v.x; o.y = x.y + m[1] * v.y; o.z = x.z + m[2] * v.z; o.w = x.w + m[3] * v.w;
+                *reinterpret_cast<float4*>(dst) = o;
             } else {
+                float* dst = Cp + (int64_t)row * p.ldc + col;
+                if (ACCUM) {
+                    float4 o = *reinterpret_cast<const float4*>(dst);
+                    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+                    *reinterpret_cast<float4*>(dst) = o;
+                } else {
+                    *reinterpret_cast<float4*>(dst) = v;
+                }
+            }
+        }
+    } else {
+        auto emit = [&](int row, int col, float v) {
+            if (EPI) {
+                const int64_t rc = p.row_map ? p.row_map[row] : row;
+                const int64_t e = rc * p.ldc + col;
+                const DropoutRng rng(p.p_drop, p.seed);
+                float m[4];
+                rng.mult4((uint32_t)(e >> 2), m);
+                Cp[e] = p.resid[e] + m[e & 3] * v;
+            } else {
+                float* dst = Cp + (int64_t)row * p.ldc + col;
+                if (MODE == 1) atomicAdd(dst, v);
+                else if (ACCUM) *dst += v;
+                else *dst = v;
+            }
+        };
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rr = (r & 3) + 8 * (r >> 2);
-                    if (rbase + rr < row_end && col < col_end) emit(cbase + (int64_t)rr * p.ldc, p.alpha * acc[i][j][r]);
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = col0 + wn * 64 + j * 32 + r32;
+                const int rbase = row0 + wm * 64 + i * 32 + 4 * h;
+                if (interior) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) emit(rbase + (r & 3) + 8 * (r >> 2), col, p.alpha * acc[i][j][r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = (r & 3) + 8 * (r >> 2);
+                        if (rbase + rr < row_end && col < col_end) emit(rbase + rr, col, p.alpha * acc[i][j][r]);
+                    }
                 }
             }
         }
@@ -385,10 +442,10 @@ gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF>
+template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, bool EPI = false>
 static int launch_gemm_t(const GemmParams& p, int blocks, hipStream_t st, int lds) {
     static int attr_lds = 0;
-    auto kfn = gemm_f32_kernel<A_KC, B_KC, MODE, ACCUM, STAMP, NBUF>;
+    auto kfn = gemm_f32_kernel<A_KC, B_KC, MODE, ACCUM, STAMP, NBUF, EPI>;
     if (attr_lds != lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -417,6 +474,7 @@ static int launch_gemm(const GemmParams& p, int blocks, hipStream_t st) {
     const int lds = solo ? 150 * 1024 : GEMM_LDS_BYTES;          // solo: one workgroup per CU (diagnostics)
     const bool acc = MODE == 0 && p.accumulate;
     if (stamp) return launch_gemm_t<A_KC, B_KC, MODE, false, true, 2>(p, blocks, st, lds);
+    if (MODE == 0 && p.resid) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, true>(p, blocks, st, lds);
     if (nbuf == 1) {
         const int lds1 = 2 * TILE_FLOATS * (int)sizeof(float);
         if (acc) return launch_gemm_t<A_KC, B_KC, MODE, true, false, 1>(p, blocks, st, lds1);
@@ -462,6 +520,10 @@ extern "C" int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream) {
     p.groups = d->groups; p.group_offsets = d->group_offsets;
     p.strideB = d->strideB; p.strideC = d->strideC;
     p.kchunk = d->kchunk;
+    p.resid = d->resid; p.row_map = d->row_map; p.p_drop = d->p_drop; p.seed = d->seed;
+    GAMER_CHECK_ARG(!d->resid || (d->group_mode == 0 && !d->accumulate && a_kc && b_kc && d->ldc % 4 == 0 &&
+                                  aligned16(d->resid) && aligned16(d->C) && d->p_drop >= 0.f && d->p_drop < 1.f),
+                    "gamer_gemm_f32: the fused residual epilogue needs a Linear-forward layout, ldc %% 4 == 0, no accumulate");
     p.n_tiles = (d->N + BN - 1) / BN;
     hipStream_t st = (hipStream_t)stream;
 

@@ -327,8 +327,9 @@ class Engine:
             ops.qknorm_rope_fwd(A["qkv"], S, nq, nkv, W.self_attn["qn"], W.self_attn["kn"], eps, cos, sin, A["q"], A["k"])
             ops.attn_fwd(A["q"], NQ, A["k"], NKV, A["qkv"][:, NQ + NKV:], QKV, r["kl_self"], None, r["empty_self"],
                          r["tile_empty_self"], B, S, nq, nkv, scale, p_att, self._seed(l, 0), A["ao"], A["lse"])
-            ops.linear_fwd(A["ao"], NQ, W.self_attn["o"], NQ, t0, H, T, H, NQ)
-            ops.residual_dropout_fwd(xs[0], t0, p_res, self._seed(l, 1), None, xs[1])
+            # o_proj with the residual add + dropout fused into the GEMM epilogue (model.py:149,217)
+            ops.gemm(A["ao"], NQ, 1, W.self_attn["o"], NQ, 1, xs[1], H, T, H, NQ, resid=xs[0], p_drop=p_res,
+                     seed=self._seed(l, 1))
             xcur = xs[1]
             # ---- behaviour-level "cross" attention (model.py:220-235) ----
             if W.cross:
@@ -354,9 +355,11 @@ class Engine:
             ops.linear_fwd(A["hin"], din, W.gate, din, A["g"], I, T, I, din, strideB=I * din, **grp)
             ops.linear_fwd(A["hin"], din, W.up, din, A["u"], I, T, I, din, strideB=I * din, **grp)
             ops.swiglu_fwd(A["g"], A["u"], T * I, p_res, self._seed(l, 4), A["hm"])
-            ops.linear_fwd(A["hm"], I, W.down, I, t1, H, T, H, I, strideB=H * I, **grp)
             xnext = ws.x[l + 1][0] if l + 1 < cfg.num_hidden_layers else ws.x_final
-            ops.residual_dropout_fwd(xcur, t1, p_res, self._seed(l, 5), ws.slot, xnext)
+            # down projection: rows are in expert-sorted order, the epilogue scatters them back to token
+            # order through perm while adding the residual and applying dropout (FFN.py:25-27, model.py:241)
+            ops.gemm(A["hm"], I, 1, W.down, I, 1, xnext, H, T, H, I, strideB=H * I, resid=xcur, row_map=ws.perm,
+                     p_drop=p_res, seed=self._seed(l, 5), **grp)
         # ---- final norm, tied head, temperature CE (model.py:869,1001,904-922) ----
         V = cfg.vocab_size
         ops.rmsnorm_fwd(ws.x_final, self.params["model.norm.weight"], eps, ws.xn)

@@ -92,7 +92,7 @@ def rowtable_bwd(dy, lddy, col0, idx, dtable, dy_rows=None):
 
 
 def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=False, groups=1, group_mode=0,
-         group_offsets=None, strideB=0, strideC=0, kchunk=0):
+         group_offsets=None, strideB=0, strideC=0, kchunk=0, resid=None, row_map=None, p_drop=0.0, seed=0):
     """C[m][n] (=|+=) alpha * sum_k A(m,k) B(n,k); see gamer_gemm_desc in include/gamer_hip.h."""
     d = GemmDesc()
     d.A = ptr(A); d.a_rs = a_rs; d.a_ks = a_ks
@@ -106,6 +106,10 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
     d.group_offsets = ptr(group_offsets)
     d.strideB = strideB; d.strideC = strideC
     d.kchunk = kchunk
+    d.resid = ptr(resid)
+    d.row_map = ptr(row_map)
+    d.p_drop = p_drop
+    d.seed = seed
     call("gamer_gemm_f32", C.byref(d), stream_ptr())
 
 

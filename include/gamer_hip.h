@@ -131,6 +131,14 @@ typedef struct {
     const int32_t* group_offsets;/* device, groups+1 entries, or NULL when groups == 1 */
     int64_t strideB, strideC;    /* elements between consecutive groups */
     int kchunk;                  /* mode 1: contraction chunk per workgroup (multiple of 32) */
+    /* Optional fused epilogue of the decoder layer's residual sites (model.py:217,235,241), Linear-forward
+     * layout only:  C[map(m)][n] = resid[map(m)][n] + dropout(alpha * acc[m][n])  with map = row_map
+     * (sorted slot -> token, for the expert down projection) or identity; the dropout mask is the one
+     * gamer_residual_dropout_bwd regenerates from (seed, element index of C).  resid == NULL: plain GEMM. */
+    const float* resid;
+    const int32_t* row_map;
+    float p_drop;
+    uint64_t seed;
 } gamer_gemm_desc;
 
 int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);

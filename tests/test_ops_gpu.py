@@ -210,6 +210,36 @@ def test_gemm_wgrad_splitk(rows, N, K):
     assert e < 5e-6
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.2])
+def test_gemm_fused_residual_epilogue(p_drop):
+    """C[map(m)] = resid[map(m)] + dropout(x W^T): same values and the same mask as GEMM followed by the
+    stand-alone residual kernel (plain and expert-grouped with the sorted-slot -> token map)."""
+    T, N, K, seed = 1000, 256, 384, 4242
+    x, W, resid = torch.randn(T, K), torch.randn(N, K) * 0.1, torch.randn(T, N)
+    y = torch.empty(T, N, device=DEV)
+    ops.linear_fwd(dev(x), K, dev(W), K, y, N, T, N, K)
+    ref = dev(resid.clone())
+    ops.residual_dropout_fwd(ref, y, p_drop, seed)
+    out = torch.full((T, N), 7.0, device=DEV)
+    ops.gemm(dev(x), K, 1, dev(W), K, 1, out, N, T, N, K, resid=dev(resid), p_drop=p_drop, seed=seed)
+    assert float((out - ref).abs().max()) < 1e-5
+    # grouped + row map (the expert down projection): rows in sorted order, output scattered to tokens
+    E, I = 6, 512
+    sizes = [0, 300, 129, 1, 300, 270]
+    offs = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32)
+    perm = torch.randperm(T).int()                   # sorted slot -> token
+    slot = torch.empty(T, dtype=torch.int32); slot[perm.long()] = torch.arange(T, dtype=torch.int32)
+    hm, Wd = torch.randn(T, I), torch.randn(E, N, I) * 0.05
+    yd = torch.empty(T, N, device=DEV)
+    ops.linear_fwd(dev(hm), I, dev(Wd), I, yd, N, T, N, I, groups=E, group_offsets=dev(offs), strideB=N * I)
+    ref2 = dev(resid.clone())
+    ops.residual_dropout_fwd(ref2, yd, p_drop, seed, dev(slot))
+    out2 = torch.full((T, N), 7.0, device=DEV)
+    ops.gemm(dev(hm), I, 1, dev(Wd), I, 1, out2, N, T, N, I, groups=E, group_offsets=dev(offs), strideB=N * I,
+             resid=dev(resid), row_map=dev(perm), p_drop=p_drop, seed=seed)
+    assert float((out2 - ref2).abs().max()) < 1e-5
+
+
 def test_gemm_grouped_experts():
     E, Din, I = 6, 320, 512
     sizes = [0, 700, 129, 1, 300, 128]              # an empty expert, ragged and exact tiles
