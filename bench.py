@@ -88,18 +88,20 @@ class KernelTimer:
 
         def timed_gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, **kw):
             kind = "gemm_fwd" if (a_ks == 1 and b_ks == 1) else ("gemm_dgrad" if a_ks == 1 else "gemm_wgrad")
+            if kw.get("resid") is not None:
+                kind = "gemm_fwd_resid"                 # fused residual + dropout epilogue (a different instantiation)
             timer._next = (kind, 2.0 * M * N * K)
             return orig_gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, **kw)
 
         orig_af, orig_ab = ops.attn_fwd, ops.attn_bwd
 
-        def timed_attn_fwd(q, ldq, k, ldk, v, ldv, kl, ql, *rest):
+        def timed_attn_fwd(q, ldq, k, ldk, v, ldv, kl, ql, *rest, **kw):
             nq = rest[4]
             pairs = timer.pairs["self" if ql is None else "cross"]
             timer._next = ("attn_fwd_self" if ql is None else "attn_fwd_cross", 4.0 * 64 * nq * pairs)
-            return orig_af(q, ldq, k, ldk, v, ldv, kl, ql, *rest)
+            return orig_af(q, ldq, k, ldk, v, ldv, kl, ql, *rest, **kw)
 
-        def timed_attn_bwd(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, *rest):
+        def timed_attn_bwd(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, *rest, **kw):
             nq = rest[4]
             pairs = timer.pairs["self" if ql is None else "cross"]
             # the delta + dq + dkv launches share one entry point; the label goes to the first (delta),
@@ -109,7 +111,7 @@ class KernelTimer:
             was = timer.enabled
             timer.enabled = False
             s.record()
-            r = orig_ab(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, *rest)
+            r = orig_ab(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, *rest, **kw)
             e.record()
             timer.enabled = was
             if was:

@@ -33,6 +33,16 @@ __device__ unsigned long long* g_trace = nullptr;
 
 __device__ __forceinline__ int rowmap(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
+// Optional query-row order (behaviour-level "cross" attention): rows with no allowed key ("empty", p = 1/S
+// over all keys, no scores needed) are moved behind the others inside every sequence, so a 32-row wave tile
+// is (almost always) either all normal rows -> causal key range only, or all empty rows -> no Q.K^T at all.
+// Without it one empty row forces its whole wave through the full key range.  perm == nullptr: identity.
+struct RowOrder {
+    const int32_t* perm;         // [B,S] sorted slot -> position in the sequence
+    const int32_t* tile_kind;    // [B,ceil(S/32)] bit0: has normal rows, bit1: has empty rows
+    const int32_t* tile_maxpos;  // [B,ceil(S/32)] largest position of a normal row in the tile, -1 if none
+};
+
 // Static work partition for persistent workgroups.
 //
 // Measured on MI355X (tools/trace_attn.py): with one workgroup per (sequence, kv head, tile) the causal
@@ -84,6 +94,21 @@ __device__ __forceinline__ void load_tile32(const float* __restrict__ base, int6
         rg[jj] = v;
     }
 }
+// same tile, rows gathered through a slot -> position map (rows >= r_end are zero)
+__device__ __forceinline__ void load_tile32_rows(const float* __restrict__ base, int64_t ld, const int32_t* __restrict__ map,
+                                                 int r0, int r_end, int tid, float4 (&rg)[2]) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int f = tid + AT_THREADS * jj;
+        const int slot = r0 + (f >> 4);
+        const bool ok = slot < r_end;
+        const int pos = map[ok ? slot : r_end - 1];
+        float4 v = *reinterpret_cast<const float4*>(base + (int64_t)pos * ld + ((f & 15) << 2));
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        rg[jj] = v;
+    }
+}
+
 template <int LD>
 __device__ __forceinline__ void store_tile32(float* __restrict__ lds, int tid, const float4 (&rg)[2]) {
 #pragma unroll
@@ -115,7 +140,7 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
               const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
               const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
               int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-              float* __restrict__ o, float* __restrict__ lse, const int pair, const int qtile) {
+              float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int pair, const int qtile) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
     __shared__ __attribute__((aligned(16))) float Ks[2][32 * KLD];
@@ -127,9 +152,12 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
     const int b = pair / nkv, kvh = pair % nkv, q0 = qtile * R;
     const int head = kvh * G + hg;
     const int r = lane & 31, h = lane >> 5;
-    const int iq = q0 + sub * 32 + r;
-    const bool valid_q = iq < S;
-    const int iqc = valid_q ? iq : S - 1;
+    const int slot = q0 + sub * 32 + r;                 // sorted slot of this lane's query row
+    const bool valid_q = slot < S;
+    const int slotc = valid_q ? slot : S - 1;
+    const int iq_raw = ro.perm ? ro.perm[(int64_t)b * S + slotc] : slotc;
+    const int iq = valid_q ? iq_raw : S;                // position in the sequence (S: beyond every key)
+    const int iqc = iq_raw;
     const int64_t tok = (int64_t)b * S + iqc;
 
     // scores are kept in the log2 domain: q is pre-scaled by scale*log2(e), p = exp2(s - m)
@@ -148,11 +176,25 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
     }
     const int my_ql = ql ? ql[tok] : 1;
     const bool my_empty = valid_q && row_empty[tok] != 0;
-    const int wave_q_hi = min(S - 1, q0 + sub * 32 + 31);
-    const bool wave_has_empty = __any(my_empty ? 1 : 0) != 0;
-    const bool block_has_empty = __syncthreads_or(my_empty ? 1 : 0) != 0;
     const int n_all = (S + 31) / 32;
-    const int n_causal = (min(S, q0 + R) + 31) / 32;
+    int wave_q_hi, n_causal;
+    bool wave_has_empty;
+    if (ro.perm) {
+        const int64_t tb = (int64_t)b * n_all + (q0 >> 5);
+        const int wt = min(sub, n_all - 1 - (q0 >> 5));          // tiles past the end: reuse the last one
+        wave_q_hi = (q0 + sub * 32 < S) ? ro.tile_maxpos[tb + wt] : -1;
+        wave_has_empty = (q0 + sub * 32 < S) && (ro.tile_kind[tb + wt] & 2) != 0;
+        int hi = -1;
+#pragma unroll
+        for (int ss = 0; ss < NSUB; ++ss)
+            if (q0 + ss * 32 < S) hi = max(hi, ro.tile_maxpos[tb + ss]);
+        n_causal = hi < 0 ? 0 : (hi >> 5) + 1;
+    } else {
+        wave_q_hi = min(S - 1, q0 + sub * 32 + 31);
+        wave_has_empty = __any(my_empty ? 1 : 0) != 0;
+        n_causal = (min(S, q0 + R) + 31) / 32;
+    }
+    const bool block_has_empty = __syncthreads_or(my_empty ? 1 : 0) != 0;
     const int n_iter = block_has_empty ? n_all : n_causal;
     const float invS = 1.f / (float)S;
     const AttnDropout rng(p_drop, seed);
@@ -329,7 +371,7 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
             rec[3] = __builtin_amdgcn_s_getreg(63508);       // HW_REG_XCC_ID
         }
         // natural-log LSE of the scaled scores (what the backward kernels consume)
-        if (h == 0) lse[((int64_t)b * nq + head) * S + iq] =
+        if (h == 0) lse[((int64_t)b * nq + head) * S + iqc] =
             my_empty ? 0.f : (m_run + __log2f(l_run)) * 0.6931471805599453f;
     }
 }
@@ -340,7 +382,7 @@ attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ 
                 const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
                 const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
                 int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-                float* __restrict__ o, float* __restrict__ lse) {
+                float* __restrict__ o, float* __restrict__ lse, const RowOrder ro) {
     constexpr int R = (4 / G) * 32;
     const int n_tiles = (S + R - 1) / R;
     const WorkList wl(nbatch * nkv, n_tiles);
@@ -353,7 +395,7 @@ attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ 
         for (int pass = 0; pass < 2; ++pass) {                    // one inlined body (register pressure)
             if (pass == 1 && light == heavy) break;
             attn_fwd_tile<G, DROP, PIPE>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed, o, lse,
-                                         pair, pass == 0 ? heavy : light);
+                                         ro, pair, pass == 0 ? heavy : light);
         }
     }
 }
@@ -388,7 +430,8 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
                    const float* __restrict__ lse, float* __restrict__ delta,
                    const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                    const int32_t* __restrict__ row_empty, int S, int nq, int nkv, float scale,
-                   float p_drop, uint64_t seed, float* __restrict__ dq, int lddq, const int pair, const int qtile) {
+                   float p_drop, uint64_t seed, float* __restrict__ dq, int lddq, const RowOrder ro, const int pair,
+                   const int qtile) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
     __shared__ __attribute__((aligned(16))) float Ks[2][32 * KLD];
@@ -400,9 +443,12 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
     const int b = pair / nkv, kvh = pair % nkv, q0 = qtile * R;
     const int head = kvh * G + hg;
     const int r = lane & 31, h = lane >> 5;
-    const int iq = q0 + sub * 32 + r;
-    const bool valid_q = iq < S;
-    const int iqc = valid_q ? iq : S - 1;
+    const int slot = q0 + sub * 32 + r;                 // sorted slot of this lane's query row
+    const bool valid_q = slot < S;
+    const int slotc = valid_q ? slot : S - 1;
+    const int iq_raw = ro.perm ? ro.perm[(int64_t)b * S + slotc] : slotc;
+    const int iq = valid_q ? iq_raw : S;                // position in the sequence (S: beyond every key)
+    const int iqc = iq_raw;
     const int64_t tok = (int64_t)b * S + iqc;
 
     float qf[8][4], dof[8][4];
@@ -421,16 +467,30 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
             my_delta += u4.x * o4.x + u4.y * o4.y + u4.z * o4.z + u4.w * o4.w;
         }
         my_delta += __shfl_xor(my_delta, 32, 64);
-        if (valid_q && h == 0) delta[((int64_t)b * nq + head) * S + iq] = my_delta;
+        if (valid_q && h == 0) delta[((int64_t)b * nq + head) * S + iqc] = my_delta;
     }
     const int my_ql = ql ? ql[tok] : 1;
     const bool my_empty = valid_q && row_empty[tok] != 0;
     const float my_lse = lse[((int64_t)b * nq + head) * S + iqc];
-    const int wave_q_hi = min(S - 1, q0 + sub * 32 + 31);
-    const bool wave_has_empty = __any(my_empty ? 1 : 0) != 0;
-    const bool block_has_empty = __syncthreads_or(my_empty ? 1 : 0) != 0;
     const int n_all = (S + 31) / 32;
-    const int n_causal = (min(S, q0 + R) + 31) / 32;
+    int wave_q_hi, n_causal;
+    bool wave_has_empty;
+    if (ro.perm) {
+        const int64_t tb = (int64_t)b * n_all + (q0 >> 5);
+        const int wt = min(sub, n_all - 1 - (q0 >> 5));          // tiles past the end: reuse the last one
+        wave_q_hi = (q0 + sub * 32 < S) ? ro.tile_maxpos[tb + wt] : -1;
+        wave_has_empty = (q0 + sub * 32 < S) && (ro.tile_kind[tb + wt] & 2) != 0;
+        int hi = -1;
+#pragma unroll
+        for (int ss = 0; ss < NSUB; ++ss)
+            if (q0 + ss * 32 < S) hi = max(hi, ro.tile_maxpos[tb + ss]);
+        n_causal = hi < 0 ? 0 : (hi >> 5) + 1;
+    } else {
+        wave_q_hi = min(S - 1, q0 + sub * 32 + 31);
+        wave_has_empty = __any(my_empty ? 1 : 0) != 0;
+        n_causal = (min(S, q0 + R) + 31) / 32;
+    }
+    const bool block_has_empty = __syncthreads_or(my_empty ? 1 : 0) != 0;
     const int n_iter = block_has_empty ? n_all : n_causal;
     const float invS = 1.f / (float)S;
     const AttnDropout rng(p_drop, seed);
@@ -544,7 +604,7 @@ attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict
                    const float* __restrict__ lse, float* __restrict__ delta,
                    const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                    const int32_t* __restrict__ row_empty, int nbatch, int S, int nq, int nkv, float scale,
-                   float p_drop, uint64_t seed, float* __restrict__ dq, int lddq) {
+                   float p_drop, uint64_t seed, float* __restrict__ dq, int lddq, const RowOrder ro) {
     constexpr int R = (4 / G) * 32;
     const int n_tiles = (S + R - 1) / R;
     const WorkList wl(nbatch * nkv, n_tiles);
@@ -557,7 +617,7 @@ attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
             attn_bwd_dq_tile<G>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed,
-                                dq, lddq, pair, pass == 0 ? heavy : light);
+                                dq, lddq, ro, pair, pass == 0 ? heavy : light);
         }
     }
 }
@@ -575,6 +635,7 @@ struct DkvSmem {
     float delta_s[G][32];
     int32_t ql_s[32];
     int32_t empty_s[32];
+    int32_t pos_s[32];          // position of the staged query rows (S for rows past the end)
 };
 
 template <int G>
@@ -585,7 +646,8 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
                     const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                     const int32_t* __restrict__ row_empty, const int32_t* __restrict__ tile_empty,
                     int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-                    float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const int pair, const int ktile) {
+                    float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const RowOrder ro, const int pair,
+                    const int ktile) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char dkv_raw[];
@@ -623,8 +685,15 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
     const uint32_t drop_head = (uint32_t)(((int64_t)b * nq + head) * S);
 
     const int n_qt = (S + 31) / 32;
-    const int qt_begin = k0 / 32;                     // first query tile that can hold i >= k0
+    const int qt_begin = k0 / 32;                     // first query tile that can hold i >= k0 (identity order)
     const int32_t* te = tile_empty + (int64_t)b * n_qt;
+    const int32_t* tkind = ro.perm ? ro.tile_kind + (int64_t)b * n_qt : nullptr;
+    const int32_t* tmax = ro.perm ? ro.tile_maxpos + (int64_t)b * n_qt : nullptr;
+    const int32_t* pmap = ro.perm ? ro.perm + (int64_t)b * S : nullptr;
+    // a query tile matters to this key tile if it has an empty row (attends every key) or a normal row at
+    // or after the first key
+    auto tile_empty_rows = [&](int qt) { return tkind ? (tkind[qt] & 2) != 0 : te[qt] != 0; };
+    auto tile_last_pos = [&](int qt) { return tkind ? tmax[qt] : min(S - 1, qt * 32 + 31); };
 
     f32x16 dkacc[2], dvacc[2];
 #pragma unroll
@@ -633,10 +702,10 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
     // staged registers: per head one Q tile and one dO tile (2 float4 each per thread)
     float4 rq[G][2], rdo[G][2];
     float rl = 0.f, rd = 0.f;
-    int rql = 1, rem = 0;
+    int rql = 1, rem = 0, rpos = 0;
 
     auto next_tile = [&](int qt) {
-        while (qt < n_qt && qt < qt_begin && te[qt] == 0) ++qt;
+        while (qt < n_qt && !tile_empty_rows(qt) && tile_last_pos(qt) < k0) ++qt;
         return qt;
     };
     auto load_q_tile = [&](int qt) {
@@ -644,19 +713,27 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int hd = kvh * G + g;
-            load_tile32(q + (int64_t)b * S * ldq + hd * 64, ldq, i0, S, tid, rq[g]);
-            load_tile32(d_o + (int64_t)b * S * nq * 64 + hd * 64, (int64_t)nq * 64, i0, S, tid, rdo[g]);
+            if (pmap) {
+                load_tile32_rows(q + (int64_t)b * S * ldq + hd * 64, ldq, pmap, i0, S, tid, rq[g]);
+                load_tile32_rows(d_o + (int64_t)b * S * nq * 64 + hd * 64, (int64_t)nq * 64, pmap, i0, S, tid, rdo[g]);
+            } else {
+                load_tile32(q + (int64_t)b * S * ldq + hd * 64, ldq, i0, S, tid, rq[g]);
+                load_tile32(d_o + (int64_t)b * S * nq * 64 + hd * 64, (int64_t)nq * 64, i0, S, tid, rdo[g]);
+            }
         }
         // per-query scalars: threads 0..G*32-1 take (g, row)
         if (tid < G * 32) {
             const int g = tid >> 5, row = tid & 31;
-            const int i = i0 + row;
+            const int sl = i0 + row;
+            const bool in = sl < S;
+            const int i = in ? (pmap ? pmap[sl] : sl) : 0;          // position of the row
             const int hd = kvh * G + g;
-            rl = i < S ? lse[((int64_t)b * nq + hd) * S + i] : 0.f;
-            rd = i < S ? delta[((int64_t)b * nq + hd) * S + i] : 0.f;
+            rl = in ? lse[((int64_t)b * nq + hd) * S + i] : 0.f;
+            rd = in ? delta[((int64_t)b * nq + hd) * S + i] : 0.f;
             if (g == 0) {
-                rql = i < S ? (ql ? ql[(int64_t)b * S + i] : 1) : 0;
-                rem = i < S ? row_empty[(int64_t)b * S + i] : 0;
+                rql = in ? (ql ? ql[(int64_t)b * S + i] : 1) : 0;
+                rem = in ? row_empty[(int64_t)b * S + i] : 0;
+                rpos = in ? i : S;
             }
         }
     };
@@ -670,7 +747,7 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
             const int g = tid >> 5, row = tid & 31;
             sm.lse_s[g][row] = rl;
             sm.delta_s[g][row] = rd;
-            if (g == 0) { sm.ql_s[row] = rql; sm.empty_s[row] = rem; }
+            if (g == 0) { sm.ql_s[row] = rql; sm.empty_s[row] = rem; sm.pos_s[row] = rpos; }
         }
     };
 
@@ -682,11 +759,10 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
         load_q_tile(qt);
         store_q_tile();
         __syncthreads();
-        const int i0 = qt * 32;
-        const bool tile_has_empty = te[qt] != 0;
+        const bool tile_has_empty = tile_empty_rows(qt);
         const int qt_next = next_tile(qt + 1);
 
-        const bool before = (i0 + 31) < wave_k_lo;   // every query of the tile precedes every key of this wave
+        const bool before = tile_last_pos(qt) < wave_k_lo;   // every normal query of the tile precedes this wave's keys
         if (!(before && !tile_has_empty)) {
             f32x16 st, dp;
 #pragma unroll
@@ -723,6 +799,8 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
                 const float4 d4 = *reinterpret_cast<const float4*>(&sm.delta_s[hg][qb]);
                 const int4 q4 = *reinterpret_cast<const int4*>(&sm.ql_s[qb]);
                 const int4 e4 = *reinterpret_cast<const int4*>(&sm.empty_s[qb]);
+                const int4 p4 = *reinterpret_cast<const int4*>(&sm.pos_s[qb]);
+                const int posv[4] = {p4.x, p4.y, p4.z, p4.w};
                 const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
                 const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
                 const int qlv[4] = {q4.x, q4.y, q4.z, q4.w};
@@ -730,7 +808,7 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int reg = 4 * g4 + e;
-                    const int i = i0 + qb + e;
+                    const int i = posv[e];                          // position of the query row (S if past the end)
                     const bool inq = i < S;
                     const bool allowed = inq & valid_k & (jk <= i) & (my_kl < qlv[e]);
                     float pe = __expf(st[reg] * scale - lv[e]);
@@ -816,7 +894,7 @@ attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restric
                     const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                     const int32_t* __restrict__ row_empty, const int32_t* __restrict__ tile_empty,
                     int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-                    float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv) {
+                    float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const RowOrder ro) {
     constexpr int R = (4 / G) * 32;
     const int n_tiles = (S + R - 1) / R;
     const WorkList wl(nbatch * nkv, n_tiles);
@@ -829,15 +907,55 @@ attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restric
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
             attn_bwd_dkv_tile<G>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv, scale,
-                                 p_drop, seed, dk, lddk, dv, lddv, pair, pass == 0 ? heavy : light);
+                                 p_drop, seed, dk, lddk, dv, lddv, ro, pair, pass == 0 ? heavy : light);
         }
+    }
+}
+
+// Stable partition of the query rows of every sequence: normal rows first (ascending position), empty rows
+// behind them; plus the per-32-slot tile summaries the attention kernels schedule by.
+__global__ void __launch_bounds__(256)
+attn_row_order_kernel(const int32_t* __restrict__ row_empty, int S, int32_t* __restrict__ perm,
+                      int32_t* __restrict__ tile_kind, int32_t* __restrict__ tile_maxpos) {
+    extern __shared__ __attribute__((aligned(16))) int32_t osm[];
+    int32_t* a = osm;            // scan ping
+    int32_t* c = osm + S;        // scan pong
+    int32_t* slot_pos = osm + 2 * S;
+    const int b = blockIdx.x;
+    const int32_t* re = row_empty + (int64_t)b * S;
+    for (int t = threadIdx.x; t < S; t += blockDim.x) a[t] = re[t] ? 0 : 1;
+    __syncthreads();
+    int32_t* src = a;
+    int32_t* dst = c;
+    for (int off = 1; off < S; off <<= 1) {
+        for (int t = threadIdx.x; t < S; t += blockDim.x) dst[t] = src[t] + (t >= off ? src[t - off] : 0);
+        __syncthreads();
+        int32_t* tmp = src; src = dst; dst = tmp;
+    }
+    const int n_normal = src[S - 1];
+    for (int t = threadIdx.x; t < S; t += blockDim.x) {
+        const int incl = src[t];
+        const int sl = re[t] ? n_normal + (t - incl) : incl - 1;
+        slot_pos[sl] = t;
+        perm[(int64_t)b * S + sl] = t;
+    }
+    __syncthreads();
+    const int n_tiles = (S + 31) / 32;
+    for (int qt = threadIdx.x; qt < n_tiles; qt += blockDim.x) {
+        int kind = 0, mx = -1;
+        for (int sl = qt * 32; sl < min(S, qt * 32 + 32); ++sl) {
+            const int pos = slot_pos[sl];
+            if (re[pos]) kind |= 2; else { kind |= 1; mx = max(mx, pos); }
+        }
+        tile_kind[(int64_t)b * n_tiles + qt] = kind;
+        tile_maxpos[(int64_t)b * n_tiles + qt] = mx;
     }
 }
 
 template <int G>
 static int launch_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl,
                       const int32_t* ql, const int32_t* row_empty, int B, int S, int nq, int nkv, float scale,
-                      float p_drop, uint64_t seed, float* o, float* lse, hipStream_t st) {
+                      float p_drop, uint64_t seed, float* o, float* lse, RowOrder ro, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
     // PIPE = false: the software-pipelined variant (next tile's QK MFMAs interleaved with this tile's softmax)
@@ -846,10 +964,10 @@ static int launch_fwd(const float* q, int ldq, const float* k, int ldk, const fl
     // loses the second wave per SIMD instead.  Kept as a template parameter for the next round.
     if (p_drop > 0.f)
         hipLaunchKernelGGL((attn_fwd_kernel<G, true, 2, false>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv,
-                           kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse);
+                           kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro);
     else
         hipLaunchKernelGGL((attn_fwd_kernel<G, false, 2, false>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv,
-                           kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse);
+                           kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro);
     GAMER_CHECK_LAUNCH("gamer_attn_fwd");
     return 0;
 }
@@ -859,11 +977,11 @@ static int launch_bwd(const float* q, int ldq, const float* k, int ldk, const fl
                       const float* d_o, const float* lse, float* delta, const int32_t* kl, const int32_t* ql,
                       const int32_t* row_empty, const int32_t* tile_empty, int B, int S, int nq, int nkv, float scale,
                       float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
-                      hipStream_t st) {
+                      RowOrder ro, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
     hipLaunchKernelGGL(attn_bwd_dq_kernel<G>, grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse, delta,
-                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq);
+                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, ro);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd/dq");
     static bool attr_set = false;
     auto kfn = attn_bwd_dkv_kernel<G>;
@@ -880,7 +998,7 @@ static int launch_bwd(const float* q, int ldq, const float* k, int ldk, const fl
         attr_set = true;
     }
     hipLaunchKernelGGL(kfn, grid, dim3(AT_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty,
-                       tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv);
+                       tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd/dkv");
     return 0;
 }
@@ -900,6 +1018,16 @@ static int check_attn_common(const char* name, const void* q, const void* k, con
                     "%s: bad leading dims ldq=%d ldk=%d ldv=%d", name, ldq, ldk, ldv);
     GAMER_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v), "%s: q/k/v must be 16-byte aligned", name);
     GAMER_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "%s: p_drop=%f", name, p_drop);
+    return 0;
+}
+
+extern "C" int gamer_attn_row_order(const int32_t* row_empty, int B, int S, int32_t* perm, int32_t* tile_kind,
+                                    int32_t* tile_maxpos, void* stream) {
+    GAMER_CHECK_ARG(row_empty && perm && tile_kind && tile_maxpos && B > 0 && S > 0 && S <= 8192,
+                    "gamer_attn_row_order: bad arguments B=%d S=%d", B, S);
+    hipLaunchKernelGGL(attn_row_order_kernel, dim3(B), dim3(256), (size_t)3 * S * sizeof(int32_t), (hipStream_t)stream,
+                       row_empty, S, perm, tile_kind, tile_maxpos);
+    GAMER_CHECK_LAUNCH("gamer_attn_row_order");
     return 0;
 }
 
@@ -924,16 +1052,19 @@ extern "C" int gamer_debug_attn_occupancy(int which) {
 extern "C" int gamer_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                               const int32_t* kl, const int32_t* ql, const int32_t* row_empty,
                               const int32_t* tile_empty, int B, int S, int nq, int nkv, float scale, float p_drop,
-                              uint64_t seed, float* o, float* lse, void* stream) {
+                              uint64_t seed, float* o, float* lse, const int32_t* row_perm, const int32_t* tile_kind,
+                              const int32_t* tile_maxpos, void* stream) {
     (void)tile_empty;
+    GAMER_CHECK_ARG(!row_perm || (tile_kind && tile_maxpos), "gamer_attn_fwd: row_perm needs tile_kind and tile_maxpos");
+    const RowOrder ro{row_perm, tile_kind, tile_maxpos};
     int rc = check_attn_common("gamer_attn_fwd", q, k, v, kl, row_empty, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
     if (rc) return rc;
     GAMER_CHECK_ARG(o && lse && aligned16(o), "gamer_attn_fwd: null/unaligned output");
     hipStream_t st = (hipStream_t)stream;
     switch (nq / nkv) {
-        case 1: return launch_fwd<1>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, st);
-        case 2: return launch_fwd<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, st);
-        default: return launch_fwd<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, st);
+        case 1: return launch_fwd<1>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st);
+        case 2: return launch_fwd<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st);
+        default: return launch_fwd<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st);
     }
 }
 
@@ -941,17 +1072,20 @@ extern "C" int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, 
                               const float* o, const float* d_o, const float* lse, const int32_t* kl,
                               const int32_t* ql, const int32_t* row_empty, const int32_t* tile_empty, int B, int S,
                               int nq, int nkv, float scale, float p_drop, uint64_t seed, float* delta, float* dq,
-                              int lddq, float* dk, int lddk, float* dv, int lddv, void* stream) {
+                              int lddq, float* dk, int lddk, float* dv, int lddv, const int32_t* row_perm,
+                              const int32_t* tile_kind, const int32_t* tile_maxpos, void* stream) {
     int rc = check_attn_common("gamer_attn_bwd", q, k, v, kl, row_empty, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
     if (rc) return rc;
     GAMER_CHECK_ARG(o && d_o && lse && tile_empty && delta && dq && dk && dv, "gamer_attn_bwd: null pointer");
+    GAMER_CHECK_ARG(!row_perm || (tile_kind && tile_maxpos), "gamer_attn_bwd: row_perm needs tile_kind and tile_maxpos");
+    const RowOrder ro{row_perm, tile_kind, tile_maxpos};
     GAMER_CHECK_ARG(lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 && aligned16(dq) && aligned16(dk) && aligned16(dv) &&
                     aligned16(d_o) && aligned16(o),
                     "gamer_attn_bwd: gradient buffers must be 16-byte aligned with leading dims %% 4 == 0");
     hipStream_t st = (hipStream_t)stream;
     switch (nq / nkv) {
-        case 1: return launch_bwd<1>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, st);
-        case 2: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, st);
-        default: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, st);
+        case 1: return launch_bwd<1>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, st);
+        case 2: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, st);
+        default: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, st);
     }
 }

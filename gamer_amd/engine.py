@@ -148,6 +148,9 @@ class _Workspace:
         self.router = ops.alloc_router_outputs(B, S, device)
         self.perm = torch.empty(T, **i32)
         self.slot = torch.empty(T, **i32)
+        n_t32 = (S + 31) // 32
+        # query-row order of the cross attention (normal rows first, empty rows behind)
+        self.cross_order = (torch.empty(B, S, **i32), torch.empty(B, n_t32, **i32), torch.empty(B, n_t32, **i32))
         self.offsets = torch.empty(E + 1, **i32)
         self.work = torch.empty((B + 1) * E, **i32)
         self.ldl = _round_up(cfg.vocab_size, 32)
@@ -314,6 +317,8 @@ class Engine:
         r["bad_token"].zero_()
         ops.router_fwd(ids, am, act, self.lut, cfg.num_positions, cfg.pad_token_id, cfg.eos_token_id, r)
         ops.expert_lists(r["expert"], E, ws.perm, ws.slot, ws.offsets, ws.work)
+        if cfg.cross_attention_decoder:
+            ops.attn_row_order(r["empty_cross"], *ws.cross_order)
         cos, sin = self.rope(S)
         scale = float(dh) ** -0.5
         x = ws.x[0][0]
@@ -340,7 +345,7 @@ class Engine:
                                     bias_q=C["bq"], bias_k=C["bk"], bias_v=C["bv"], act_idx=r["act_idx"])
                 ops.attn_fwd(A["q_c"], NQ, A["k_c"], NKV, A["qkv_c"][:, NQ + NKV:], QKV, r["kl_cross"], r["ql_cross"],
                              r["empty_cross"], r["tile_empty_cross"], B, S, nq, nkv, scale, p_att, self._seed(l, 2),
-                             A["ao_c"], A["lse_c"])
+                             A["ao_c"], A["lse_c"], order=ws.cross_order)
                 ops.linear_fwd(A["ao_c"], NQ, C["o"], NQ, A["op_c"], H, T, H, NQ)
                 ops.linear_fwd(A["h2"], H, C["gate"], H, A["gate_c"], H, T, H, H)
                 ops.silu_gate_fwd(A["op_c"], A["gate_c"], t0)
@@ -460,7 +465,7 @@ class Engine:
                 ops.attn_bwd(A["q_c"], NQ, A["k_c"], NKV, A["qkv_c"][:, NQ + NKV:], QKV, A["ao_c"], ws.dao, A["lse_c"],
                              r["kl_cross"], r["ql_cross"], r["empty_cross"], r["tile_empty_cross"], B, S, nq, nkv,
                              scale, p_att, self._seed(l, 2), ws.delta, ws.dq, NQ, ws.dk, NKV,
-                             ws.dqkv[:, NQ + NKV:], QKV)
+                             ws.dqkv[:, NQ + NKV:], QKV, order=ws.cross_order)
                 ops.qknorm_rope_bwd(A["qkv_c"], ws.dq, ws.dk, S, nq, nkv, C["qn"], C["kn"], eps, cos, sin, ws.dqkv,
                                     GC["qn"], GC["kn"], bias_q=C["bq"], bias_k=C["bk"], act_idx=r["act_idx"], nb1=NB1,
                                     dbias_q=GC["bq"], dbias_k=GC["bk"], dbias_v=GC["bv"])

@@ -156,16 +156,25 @@ def qknorm_rope_bwd(qkv, dq_rot, dk_rot, S, nq, nkv, wq, wk, eps, cos_t, sin_t, 
          ptr(dbias_q), ptr(dbias_k), ptr(dbias_v), stream_ptr())
 
 
-def attn_fwd(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse):
+def attn_row_order(row_empty, perm, tile_kind, tile_maxpos):
+    B, S = row_empty.shape
+    call("gamer_attn_row_order", ptr(row_empty), B, S, ptr(perm), ptr(tile_kind), ptr(tile_maxpos), stream_ptr())
+
+
+def attn_fwd(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse,
+             order=None):
+    """order = (perm, tile_kind, tile_maxpos) from attn_row_order, or None for the natural row order."""
+    pm, tk, tm = order if order is not None else (None, None, None)
     call("gamer_attn_fwd", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(kl), ptr(ql), ptr(row_empty), ptr(tile_empty),
-         B, S, nq, nkv, scale, p_drop, seed, ptr(o), ptr(lse), stream_ptr())
+         B, S, nq, nkv, scale, p_drop, seed, ptr(o), ptr(lse), ptr(pm), ptr(tk), ptr(tm), stream_ptr())
 
 
 def attn_bwd(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed,
-             delta, dq, lddq, dk, lddk, dv, lddv):
+             delta, dq, lddq, dk, lddk, dv, lddv, order=None):
+    pm, tk, tm = order if order is not None else (None, None, None)
     call("gamer_attn_bwd", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), ptr(d_o), ptr(lse), ptr(kl), ptr(ql),
          ptr(row_empty), ptr(tile_empty), B, S, nq, nkv, scale, p_drop, seed, ptr(delta), ptr(dq), lddq, ptr(dk),
-         lddk, ptr(dv), lddv, stream_ptr())
+         lddk, ptr(dv), lddv, ptr(pm), ptr(tk), ptr(tm), stream_ptr())
 
 
 def residual_dropout_fwd(x, delta, p, seed, src_rows=None, out=None):

@@ -176,19 +176,30 @@ int gamer_qknorm_rope_bwd(const float* qkv, const float* dq_rot, const float* dk
  *   ql == NULL means query level 1 for every row (self attention).
  *   o [T,nq*64]; lse [B,nq,S] (log-sum-exp of the scaled scores; 0 for empty rows)
  *   dropout on the probabilities: p_drop, seed (attention_dropout, model.py:139)
- * bwd: delta[b,h,i] = dO.O, then dq (one kernel) and dk/dv (another), no atomics.
+ *   row_perm/tile_kind/tile_maxpos (all NULL = natural order): query-row order from
+ *   gamer_attn_row_order; it only changes which rows share a wave, never the result.
+ * bwd: delta[b,h,i] = dO.O (written by the dq kernel), then dq and dk/dv kernels, no atomics.
  * ---------------------------------------------------------------------------------------- */
+/* Stable partition of every sequence's query rows: rows with an allowed key first (ascending position),
+ * "empty" rows (uniform over all keys, no scores needed) behind them, so that a 32-row wave tile is all
+ * normal (causal key range only) or all empty (no Q.K^T).  perm int32 [B,S] slot -> position;
+ * tile_kind int32 [B,ceil(S/32)] bit0 has normal rows, bit1 has empty rows; tile_maxpos: largest
+ * position of a normal row in the tile or -1.                                                   */
+int gamer_attn_row_order(const int32_t* row_empty, int B, int S, int32_t* perm, int32_t* tile_kind,
+                         int32_t* tile_maxpos, void* stream);
 int gamer_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                    const int32_t* kl, const int32_t* ql, const int32_t* row_empty,
                    const int32_t* tile_empty,
                    int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-                   float* o, float* lse, void* stream);
+                   float* o, float* lse, const int32_t* row_perm, const int32_t* tile_kind,
+                   const int32_t* tile_maxpos, void* stream);
 int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                    const float* o, const float* d_o, const float* lse,
                    const int32_t* kl, const int32_t* ql, const int32_t* row_empty,
                    const int32_t* tile_empty,
                    int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                    float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                   const int32_t* row_perm, const int32_t* tile_kind, const int32_t* tile_maxpos,
                    void* stream);
 
 /* ------------------------------------------------------------------------------------------

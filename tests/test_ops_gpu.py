@@ -351,7 +351,8 @@ def _attn_ref(q, k, v, ok, nq, nkv, scale, mult=None):
     return torch.einsum("bnij,bjnd->bind", pd, vq), lse, empty
 
 
-def _run_attn(batch, cross, B, S, nq, nkv, p_drop=0.0, seed=1234, q=None, k=None, v=None, d_o=None, router=None):
+def _run_attn(batch, cross, B, S, nq, nkv, p_drop=0.0, seed=1234, q=None, k=None, v=None, d_o=None, router=None,
+              use_order=False):
     T = B * S
     if router is None:
         router = ops.alloc_router_outputs(B, S, DEV)
@@ -362,6 +363,12 @@ def _run_attn(batch, cross, B, S, nq, nkv, p_drop=0.0, seed=1234, q=None, k=None
     ql = router["ql_cross"] if cross else None
     re_ = router["empty_cross"] if cross else router["empty_self"]
     te = router["tile_empty_cross"] if cross else router["tile_empty_self"]
+    order = None
+    if use_order:
+        n_t = (S + 31) // 32
+        order = (torch.empty(B, S, dtype=torch.int32, device=DEV), torch.empty(B, n_t, dtype=torch.int32, device=DEV),
+                 torch.empty(B, n_t, dtype=torch.int32, device=DEV))
+        ops.attn_row_order(re_, *order)
     ldv = (nq + 2 * nkv) * 64                       # v lives inside a qkv buffer, as in the model
     qkv = torch.zeros(T, ldv, device=DEV)
     qkv[:, (nq + nkv) * 64:] = dev(v.reshape(T, -1))
@@ -369,8 +376,9 @@ def _run_attn(batch, cross, B, S, nq, nkv, p_drop=0.0, seed=1234, q=None, k=None
     o = torch.empty(T, nq * 64, device=DEV)
     lse = torch.empty(B, nq, S, device=DEV)
     dq_, dk_ = dev(q.reshape(T, -1)), dev(k.reshape(T, -1))
-    ops.attn_fwd(dq_, nq * 64, dk_, nkv * 64, vview, ldv, kl, ql, re_, te, B, S, nq, nkv, 0.125, p_drop, seed, o, lse)
-    res = dict(o=o, lse=lse, router=router)
+    ops.attn_fwd(dq_, nq * 64, dk_, nkv * 64, vview, ldv, kl, ql, re_, te, B, S, nq, nkv, 0.125, p_drop, seed, o, lse,
+                 order=order)
+    res = dict(o=o, lse=lse, router=router, order=order)
     if d_o is not None:
         delta = torch.empty(B, nq, S, device=DEV)
         dq = torch.empty(T, nq * 64, device=DEV)
@@ -378,14 +386,15 @@ def _run_attn(batch, cross, B, S, nq, nkv, p_drop=0.0, seed=1234, q=None, k=None
         dqkv = torch.zeros(T, ldv, device=DEV)
         dvv = dqkv[:, (nq + nkv) * 64:]
         ops.attn_bwd(dq_, nq * 64, dk_, nkv * 64, vview, ldv, o, dev(d_o.reshape(T, -1)), lse, kl, ql, re_, te, B, S, nq,
-                     nkv, 0.125, p_drop, seed, delta, dq, nq * 64, dk, nkv * 64, dvv, ldv)
+                     nkv, 0.125, p_drop, seed, delta, dq, nq * 64, dk, nkv * 64, dvv, ldv, order=order)
         res.update(dq=dq, dk=dk, dv=dvv)
     return res
 
 
+@pytest.mark.parametrize("use_order", [False, True])
 @pytest.mark.parametrize("cross", [False, True])
 @pytest.mark.parametrize("n_items,B,nq,nkv", [(7, 3, 2, 1), (20, 2, 2, 1), (101, 2, 2, 1), (101, 11, 6, 3), (33, 40, 6, 3)])
-def test_attention_fwd_bwd(cross, n_items, B, nq, nkv):
+def test_attention_fwd_bwd(cross, n_items, B, nq, nkv, use_order):
     """The last two shapes give every persistent workgroup several (pair, tile) items, the regime the
     train step runs in (LDS reuse across items and tiles)."""
     batch = synthetic.make_batch(B, n_items, 8, 3, seed=7 + n_items, pad_rows={0: max(1, n_items // 3)})
@@ -400,7 +409,14 @@ def test_attention_fwd_bwd(cross, n_items, B, nq, nkv):
     leaves = [t.double().requires_grad_(True) for t in (q, k, v)]
     o_ref, lse_ref, empty = _attn_ref(*leaves, ok, nq, nkv, 0.125)
     (o_ref * d_o.double()).sum().backward()
-    res = _run_attn(batch, cross, B, S, nq, nkv, q=q, k=k, v=v, d_o=d_o)
+    res = _run_attn(batch, cross, B, S, nq, nkv, q=q, k=k, v=v, d_o=d_o, use_order=use_order)
+    if use_order:
+        # the order is a stable partition: normal rows ascending, then empty rows ascending
+        perm = res["order"][0].cpu().long()
+        em = (~ok.any(-1))
+        for bb in range(B):
+            ref_perm = torch.cat([torch.nonzero(~em[bb]).flatten(), torch.nonzero(em[bb]).flatten()])
+            assert torch.equal(perm[bb], ref_perm)
     T = B * S
     e_o = _rel(res["o"], o_ref.reshape(T, -1))
     ne = ~empty
@@ -409,7 +425,7 @@ def test_attention_fwd_bwd(cross, n_items, B, nq, nkv):
     e_dq = _rel(res["dq"], leaves[0].grad.reshape(T, -1))
     e_dk = _rel(res["dk"], leaves[1].grad.reshape(T, -1))
     e_dv = _rel(res["dv"], leaves[2].grad.reshape(T, -1))
-    _record(f"attn_cross{int(cross)}_S{S}_B{B}_h{nq}", dict(o=e_o, lse=e_l, dq=e_dq, dk=e_dk, dv=e_dv,
+    _record(f"attn_cross{int(cross)}_S{S}_B{B}_h{nq}_ord{int(use_order)}", dict(o=e_o, lse=e_l, dq=e_dq, dk=e_dk, dv=e_dv,
                                                    empty_rows=int(empty.sum())))
     if cross:
         assert int((empty & batch["attention_mask"].bool()).sum()) > 0, "fixture must contain empty rows"
@@ -433,7 +449,9 @@ def test_attention_left_padding_empty_self_rows():
     o_ref, _, empty = _attn_ref(*leaves, self_ok, nq, nkv, 0.125)
     assert int(empty.sum()) == 15
     (o_ref * d_o.double()).sum().backward()
-    res = _run_attn(batch, False, B, S, nq, nkv, q=q, k=k, v=v, d_o=d_o)
+    for use_order in (False, True):
+        res = _run_attn(batch, False, B, S, nq, nkv, q=q, k=k, v=v, d_o=d_o, use_order=use_order)
+        assert _rel(res["o"], o_ref.reshape(B * S, -1)) < 2e-5
     T = B * S
     assert _rel(res["o"], o_ref.reshape(T, -1)) < 2e-5
     assert _rel(res["dq"], leaves[0].grad.reshape(T, -1)) < 5e-5
@@ -441,8 +459,9 @@ def test_attention_left_padding_empty_self_rows():
     assert _rel(res["dv"], leaves[2].grad.reshape(T, -1)) < 5e-5
 
 
+@pytest.mark.parametrize("use_order", [False, True])
 @pytest.mark.parametrize("cross", [False, True])
-def test_attention_dropout_mask_consistent_fwd_bwd(cross):
+def test_attention_dropout_mask_consistent_fwd_bwd(cross, use_order):
     """Recover the keep-mask with q=k=0 and V = one-hot(j) (S <= 64), then check forward and
     backward with that exact mask against the dense reference."""
     B, n_items, nq, nkv, p = 2, 12, 2, 1, 0.2
@@ -455,7 +474,7 @@ def test_attention_dropout_mask_consistent_fwd_bwd(cross):
     zk = torch.zeros(B, S, nkv, 64)
     eye = torch.zeros(B, S, nkv, 64)
     eye[:, torch.arange(S), 0, torch.arange(S)] = 1.0
-    r0 = _run_attn(batch, cross, B, S, nq, nkv, p_drop=p, seed=99, q=zq, k=zk, v=eye)
+    r0 = _run_attn(batch, cross, B, S, nq, nkv, p_drop=p, seed=99, q=zq, k=zk, v=eye, use_order=use_order)
     pd = r0["o"].cpu().view(B, S, nq, 64)[..., :S].permute(0, 2, 1, 3).double()     # [B,nq,S,S] = p~
     p_ref = _attn_ref(zq.double(), zk.double(), eye.double(), ok, nq, nkv, 0.125)
     empty = p_ref[2]
@@ -465,7 +484,7 @@ def test_attention_dropout_mask_consistent_fwd_bwd(cross):
     vals = mult[(punif[:, None] > 0).expand_as(mult)]
     assert bool(((vals - 1.25).abs() < 1e-4).logical_or(vals.abs() < 1e-7).all()), "mask values must be 0 or 1/(1-p)"
     keep_rate = float((vals > 0).double().mean())
-    _record(f"attn_dropout_keep_rate_cross{int(cross)}", keep_rate)
+    _record(f"attn_dropout_keep_rate_cross{int(cross)}_ord{int(use_order)}", keep_rate)
     assert abs(keep_rate - 0.8) < 0.03
     mult = torch.where(mult > 0.5, torch.full_like(mult, 1.25), torch.zeros_like(mult))
     g = torch.Generator().manual_seed(5)
@@ -474,11 +493,11 @@ def test_attention_dropout_mask_consistent_fwd_bwd(cross):
     leaves = [t.double().requires_grad_(True) for t in (q, k, v)]
     o_ref, _, _ = _attn_ref(*leaves, ok, nq, nkv, 0.125, mult=mult)
     (o_ref * d_o.double()).sum().backward()
-    res = _run_attn(batch, cross, B, S, nq, nkv, p_drop=p, seed=99, q=q, k=k, v=v, d_o=d_o)
+    res = _run_attn(batch, cross, B, S, nq, nkv, p_drop=p, seed=99, q=q, k=k, v=v, d_o=d_o, use_order=use_order)
     T = B * S
     e = [_rel(res["o"], o_ref.reshape(T, -1)), _rel(res["dq"], leaves[0].grad.reshape(T, -1)),
          _rel(res["dk"], leaves[1].grad.reshape(T, -1)), _rel(res["dv"], leaves[2].grad.reshape(T, -1))]
-    _record(f"attn_dropout_cross{int(cross)}", e)
+    _record(f"attn_dropout_cross{int(cross)}_ord{int(use_order)}", e)
     assert max(e) < 5e-5
 
 

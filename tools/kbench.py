@@ -62,13 +62,19 @@ def bench_attn(args):
     dqkv = torch.empty_like(qkv)
     dv = dqkv[:, (nq + nkv) * 64:]
     p = args.p
+    n_t = (S + 31) // 32
+    order = (torch.empty(B, S, dtype=torch.int32, device=dev), torch.empty(B, n_t, dtype=torch.int32, device=dev),
+             torch.empty(B, n_t, dtype=torch.int32, device=dev))
+    ops.attn_row_order(r["empty_cross"], *order)
     for name, kl, ql, re_, te, npairs in (("self", r["kl_self"], None, r["empty_self"], r["tile_empty_self"], p_self),
                                           ("cross", r["kl_cross"], r["ql_cross"], r["empty_cross"], r["tile_empty_cross"], p_cross)):
         if args.only and args.only != name:
             continue
-        f = lambda: ops.attn_fwd(q, nq * 64, k, nkv * 64, v, qkv.shape[1], kl, ql, re_, te, B, S, nq, nkv, 0.125, p, 7, o, lse)
+        od = order if (name == "cross" and not args.no_order) else None
+        f = lambda: ops.attn_fwd(q, nq * 64, k, nkv * 64, v, qkv.shape[1], kl, ql, re_, te, B, S, nq, nkv, 0.125, p, 7, o, lse,
+                                 order=od)
         b = lambda: ops.attn_bwd(q, nq * 64, k, nkv * 64, v, qkv.shape[1], o, do, lse, kl, ql, re_, te, B, S, nq, nkv,
-                                 0.125, p, 7, delta, dq, nq * 64, dk, nkv * 64, dv, qkv.shape[1])
+                                 0.125, p, 7, delta, dq, nq * 64, dk, nkv * 64, dv, qkv.shape[1], order=od)
         tf, tb = timeit(f, args.iters), timeit(b, args.iters)
         causal_pairs = B * S * (S + 1) // 2
         print(f"attn_{name}: fwd {tf:.3f} ms ({4 * 64 * nq * npairs / tf / 1e9:.1f} TF alg, "
@@ -143,5 +149,6 @@ if __name__ == "__main__":
     ap.add_argument("--p", type=float, default=0.2)
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--no-order", dest="no_order", action="store_true", help="cross attention without the row order")
     args = ap.parse_args()
     {"attn": bench_attn, "gemm": bench_gemm, "elem": bench_elem}[args.what](args)
