@@ -134,7 +134,7 @@ __device__ __forceinline__ void store_tile32(float* __restrict__ lds, int tid, c
         ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kk][3], ACC, 0, 0, 0);                     \
     }
 
-template <int G, bool DROP, bool PIPE>
+template <int G, bool DROP, bool PIPE, bool ORD>
 __device__ __forceinline__ void
 attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
               const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
@@ -155,7 +155,7 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
     const int slot = q0 + sub * 32 + r;                 // sorted slot of this lane's query row
     const bool valid_q = slot < S;
     const int slotc = valid_q ? slot : S - 1;
-    const int iq_raw = ro.perm ? ro.perm[(int64_t)b * S + slotc] : slotc;
+    const int iq_raw = ORD ? ro.perm[(int64_t)b * S + slotc] : slotc;
     const int iq = valid_q ? iq_raw : S;                // position in the sequence (S: beyond every key)
     const int iqc = iq_raw;
     const int64_t tok = (int64_t)b * S + iqc;
@@ -179,7 +179,7 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
     const int n_all = (S + 31) / 32;
     int wave_q_hi, n_causal;
     bool wave_has_empty;
-    if (ro.perm) {
+    if (ORD) {
         const int64_t tb = (int64_t)b * n_all + (q0 >> 5);
         const int wt = min(sub, n_all - 1 - (q0 >> 5));          // tiles past the end: reuse the last one
         wave_q_hi = (q0 + sub * 32 < S) ? ro.tile_maxpos[tb + wt] : -1;
@@ -376,7 +376,7 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
     }
 }
 
-template <int G, bool DROP, int WPS, bool PIPE>
+template <int G, bool DROP, int WPS, bool PIPE, bool ORD>
 __global__ void __launch_bounds__(AT_THREADS, WPS)
 attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                 const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
@@ -394,7 +394,7 @@ attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ 
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {                    // one inlined body (register pressure)
             if (pass == 1 && light == heavy) break;
-            attn_fwd_tile<G, DROP, PIPE>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed, o, lse,
+            attn_fwd_tile<G, DROP, PIPE, ORD>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed, o, lse,
                                          ro, pair, pass == 0 ? heavy : light);
         }
     }
@@ -423,7 +423,7 @@ attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o, in
 // =============================================================================================
 // backward: dQ
 // =============================================================================================
-template <int G>
+template <int G, bool ORD>
 __device__ __forceinline__ void
 attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                    const float* __restrict__ v, int ldv, const float* __restrict__ o, const float* __restrict__ d_o,
@@ -446,7 +446,7 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
     const int slot = q0 + sub * 32 + r;                 // sorted slot of this lane's query row
     const bool valid_q = slot < S;
     const int slotc = valid_q ? slot : S - 1;
-    const int iq_raw = ro.perm ? ro.perm[(int64_t)b * S + slotc] : slotc;
+    const int iq_raw = ORD ? ro.perm[(int64_t)b * S + slotc] : slotc;
     const int iq = valid_q ? iq_raw : S;                // position in the sequence (S: beyond every key)
     const int iqc = iq_raw;
     const int64_t tok = (int64_t)b * S + iqc;
@@ -475,7 +475,7 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
     const int n_all = (S + 31) / 32;
     int wave_q_hi, n_causal;
     bool wave_has_empty;
-    if (ro.perm) {
+    if (ORD) {
         const int64_t tb = (int64_t)b * n_all + (q0 >> 5);
         const int wt = min(sub, n_all - 1 - (q0 >> 5));          // tiles past the end: reuse the last one
         wave_q_hi = (q0 + sub * 32 < S) ? ro.tile_maxpos[tb + wt] : -1;
@@ -597,7 +597,7 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
     }
 }
 
-template <int G>
+template <int G, bool ORD>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                    const float* __restrict__ v, int ldv, const float* __restrict__ o, const float* __restrict__ d_o,
@@ -616,7 +616,7 @@ attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
-            attn_bwd_dq_tile<G>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed,
+            attn_bwd_dq_tile<G, ORD>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed,
                                 dq, lddq, ro, pair, pass == 0 ? heavy : light);
         }
     }
@@ -638,7 +638,7 @@ struct DkvSmem {
     int32_t pos_s[32];          // position of the staged query rows (S for rows past the end)
 };
 
-template <int G>
+template <int G, bool ORD>
 __device__ __forceinline__ void
 attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                     const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
@@ -685,15 +685,14 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
     const uint32_t drop_head = (uint32_t)(((int64_t)b * nq + head) * S);
 
     const int n_qt = (S + 31) / 32;
-    const int qt_begin = k0 / 32;                     // first query tile that can hold i >= k0 (identity order)
     const int32_t* te = tile_empty + (int64_t)b * n_qt;
-    const int32_t* tkind = ro.perm ? ro.tile_kind + (int64_t)b * n_qt : nullptr;
-    const int32_t* tmax = ro.perm ? ro.tile_maxpos + (int64_t)b * n_qt : nullptr;
-    const int32_t* pmap = ro.perm ? ro.perm + (int64_t)b * S : nullptr;
+    const int32_t* tkind = ORD ? ro.tile_kind + (int64_t)b * n_qt : nullptr;
+    const int32_t* tmax = ORD ? ro.tile_maxpos + (int64_t)b * n_qt : nullptr;
+    const int32_t* pmap = ORD ? ro.perm + (int64_t)b * S : nullptr;
     // a query tile matters to this key tile if it has an empty row (attends every key) or a normal row at
     // or after the first key
-    auto tile_empty_rows = [&](int qt) { return tkind ? (tkind[qt] & 2) != 0 : te[qt] != 0; };
-    auto tile_last_pos = [&](int qt) { return tkind ? tmax[qt] : min(S - 1, qt * 32 + 31); };
+    auto tile_empty_rows = [&](int qt) { return ORD ? (tkind[qt] & 2) != 0 : te[qt] != 0; };
+    auto tile_last_pos = [&](int qt) { return ORD ? tmax[qt] : min(S - 1, qt * 32 + 31); };
 
     f32x16 dkacc[2], dvacc[2];
 #pragma unroll
@@ -713,7 +712,7 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int hd = kvh * G + g;
-            if (pmap) {
+            if (ORD) {
                 load_tile32_rows(q + (int64_t)b * S * ldq + hd * 64, ldq, pmap, i0, S, tid, rq[g]);
                 load_tile32_rows(d_o + (int64_t)b * S * nq * 64 + hd * 64, (int64_t)nq * 64, pmap, i0, S, tid, rdo[g]);
             } else {
@@ -726,7 +725,7 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
             const int g = tid >> 5, row = tid & 31;
             const int sl = i0 + row;
             const bool in = sl < S;
-            const int i = in ? (pmap ? pmap[sl] : sl) : 0;          // position of the row
+            const int i = in ? (ORD ? pmap[sl] : sl) : 0;          // position of the row
             const int hd = kvh * G + g;
             rl = in ? lse[((int64_t)b * nq + hd) * S + i] : 0.f;
             rd = in ? delta[((int64_t)b * nq + hd) * S + i] : 0.f;
@@ -799,7 +798,8 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
                 const float4 d4 = *reinterpret_cast<const float4*>(&sm.delta_s[hg][qb]);
                 const int4 q4 = *reinterpret_cast<const int4*>(&sm.ql_s[qb]);
                 const int4 e4 = *reinterpret_cast<const int4*>(&sm.empty_s[qb]);
-                const int4 p4 = *reinterpret_cast<const int4*>(&sm.pos_s[qb]);
+                int4 p4 = make_int4(0, 0, 0, 0);
+                if (ORD) p4 = *reinterpret_cast<const int4*>(&sm.pos_s[qb]);
                 const int posv[4] = {p4.x, p4.y, p4.z, p4.w};
                 const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
                 const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
@@ -808,7 +808,7 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int reg = 4 * g4 + e;
-                    const int i = posv[e];                          // position of the query row (S if past the end)
+                    const int i = ORD ? posv[e] : min(qt * 32 + qb + e, S);      // query position (S: past the end)
                     const bool inq = i < S;
                     const bool allowed = inq & valid_k & (jk <= i) & (my_kl < qlv[e]);
                     float pe = __expf(st[reg] * scale - lv[e]);
@@ -886,7 +886,7 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
     }
 }
 
-template <int G>
+template <int G, bool ORD>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                     const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
@@ -906,7 +906,7 @@ attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restric
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
-            attn_bwd_dkv_tile<G>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv, scale,
+            attn_bwd_dkv_tile<G, ORD>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv, scale,
                                  p_drop, seed, dk, lddk, dv, lddv, ro, pair, pass == 0 ? heavy : light);
         }
     }
@@ -962,12 +962,11 @@ static int launch_fwd(const float* q, int ldq, const float* k, int ldk, const fl
     // measured slower here (0.95 vs 0.80 ms at B=256): it needs 16 more accumulator registers and spills at
     // the 256-VGPR budget of two workgroups per CU; with the whole register file (one workgroup per CU) it
     // loses the second wave per SIMD instead.  Kept as a template parameter for the next round.
-    if (p_drop > 0.f)
-        hipLaunchKernelGGL((attn_fwd_kernel<G, true, 2, false>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv,
-                           kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro);
-    else
-        hipLaunchKernelGGL((attn_fwd_kernel<G, false, 2, false>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv,
-                           kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro);
+#define GAMER_LAUNCH_FWD(DROPV, ORDV)                                                                              \
+    hipLaunchKernelGGL((attn_fwd_kernel<G, DROPV, 2, false, ORDV>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, \
+                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro)
+    if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD(true, true); else GAMER_LAUNCH_FWD(true, false); }
+    else { if (ro.perm) GAMER_LAUNCH_FWD(false, true); else GAMER_LAUNCH_FWD(false, false); }
     GAMER_CHECK_LAUNCH("gamer_attn_fwd");
     return 0;
 }
@@ -980,25 +979,35 @@ static int launch_bwd(const float* q, int ldq, const float* k, int ldk, const fl
                       RowOrder ro, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<G>, grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse, delta,
-                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, ro);
+    if (ro.perm)
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<G, true>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse,
+                           delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, ro);
+    else
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<G, false>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse,
+                           delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, ro);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd/dq");
-    static bool attr_set = false;
-    auto kfn = attn_bwd_dkv_kernel<G>;
     size_t shmem = sizeof(DkvSmem<G>);
     const size_t red_bytes = (size_t)R * 132 * sizeof(float);
     if (shmem < red_bytes) shmem = red_bytes;
+    static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)shmem);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<G, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<G, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) {
             set_error("gamer_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return (int)e;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kfn, grid, dim3(AT_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty,
-                       tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro);
+    if (ro.perm)
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<G, true>), grid, dim3(AT_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse,
+                           delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro);
+    else
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<G, false>), grid, dim3(AT_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse,
+                           delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd/dkv");
     return 0;
 }
@@ -1041,10 +1050,10 @@ extern "C" int gamer_debug_attn_occupancy(int which) {
     int n = -1;
     hipError_t e = hipSuccess;
     switch (which) {
-        case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<2, true, 2, false>, AT_THREADS, 0); break;
-        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<2, false, 2, false>, AT_THREADS, 0); break;
-        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq_kernel<2>, AT_THREADS, 0); break;
-        case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_kernel<2>, AT_THREADS, sizeof(DkvSmem<2>)); break;
+        case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<2, true, 2, false, false>, AT_THREADS, 0); break;
+        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<2, false, 2, false, false>, AT_THREADS, 0); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq_kernel<2, false>, AT_THREADS, 0); break;
+        case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_kernel<2, false>, AT_THREADS, sizeof(DkvSmem<2>)); break;
     }
     return e == hipSuccess ? n : -(int)e;
 }

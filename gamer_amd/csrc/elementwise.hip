@@ -178,13 +178,24 @@ rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, c
     }
 }
 
-__global__ void colsum_reduce_kernel(const float* __restrict__ partial, int rows, int cols, int accumulate,
-                                     float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// out[c] (+)= sum_r partial[r][c]; one workgroup per 32 columns, 8 row groups per workgroup, fixed order
+__global__ void __launch_bounds__(256)
+colsum_reduce_kernel(const float* __restrict__ partial, int rows, int cols, int accumulate,
+                     float* __restrict__ out) {
+    __shared__ float sh[8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += partial[(int64_t)r * cols + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < cols)
+        for (int r = rg; r < rows; r += 8) s += partial[(int64_t)r * cols + c];
+    sh[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += sh[g][cl];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -681,7 +692,7 @@ extern "C" int gamer_rmsnorm_bwd(const float* x, const float* w, const float* dy
 
 extern "C" int gamer_colsum_reduce(const float* partial, int rows, int cols, int accumulate, float* out, void* stream) {
     GAMER_CHECK_ARG(partial && out && rows > 0 && cols > 0, "gamer_colsum_reduce: bad arguments");
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, ST(stream), partial, rows, cols,
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, ST(stream), partial, rows, cols,
                        accumulate, out);
     GAMER_CHECK_LAUNCH("gamer_colsum_reduce");
     return 0;

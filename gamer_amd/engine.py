@@ -199,7 +199,7 @@ class _Workspace:
             self.dk = torch.empty(T, NKV, **f32)
             self.dao = torch.empty(T, NQ, **f32)
             self.delta = torch.empty(B, nq, S, **f32)
-            self.norm_partial = torch.empty(512, H, **f32)
+            self.norm_partial = torch.empty(2048, H, **f32)
 
 
 class Engine:
