@@ -78,53 +78,97 @@ static inline int worklist_grid(int n_pairs, int n_tiles) {
     return 8 * ppr * halves;
 }
 
-// tile of 32 rows x 64 floats: thread -> 2 float4 (f = tid + 256*jj: row f>>4, quad f&15)
+// tile of 32 rows x 64 floats: thread -> 2 float4 (f = tid + 256*jj: row f>>4, quad f&15).
+// Rows >= r_end are read from the last valid row (clamped address, no branch) and zeroed by store_tile32:
+// a select placed on the loaded registers would make the wave wait for the load right where it was issued
+// instead of one iteration later, in front of the LDS store.
 __device__ __forceinline__ void load_tile32(const float* __restrict__ base, int64_t ld, int r0, int r_end, int tid,
                                             float4 (&rg)[2]) {
-    // branch-free (clamped address + select): a conditional load would be branched around and waited
-    // for individually by hipcc
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const int f = tid + AT_THREADS * jj;
-        const int row = r0 + (f >> 4);
-        const bool ok = row < r_end;
-        const int rowc = ok ? row : r_end - 1;
-        float4 v = *reinterpret_cast<const float4*>(base + (int64_t)rowc * ld + ((f & 15) << 2));
-        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-        rg[jj] = v;
+        const int row = min(r0 + (f >> 4), r_end - 1);
+        rg[jj] = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + ((f & 15) << 2));
     }
 }
-// same tile, rows gathered through a slot -> position map (rows >= r_end are zero)
+// same tile, rows gathered through a slot -> position map
 __device__ __forceinline__ void load_tile32_rows(const float* __restrict__ base, int64_t ld, const int32_t* __restrict__ map,
                                                  int r0, int r_end, int tid, float4 (&rg)[2]) {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const int f = tid + AT_THREADS * jj;
-        const int slot = r0 + (f >> 4);
-        const bool ok = slot < r_end;
-        const int pos = map[ok ? slot : r_end - 1];
-        float4 v = *reinterpret_cast<const float4*>(base + (int64_t)pos * ld + ((f & 15) << 2));
-        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-        rg[jj] = v;
+        const int pos = map[min(r0 + (f >> 4), r_end - 1)];
+        rg[jj] = *reinterpret_cast<const float4*>(base + (int64_t)pos * ld + ((f & 15) << 2));
     }
 }
 
+// n_valid = r_end - r0 of the matching load: rows at or past it are stored as zeros
 template <int LD>
-__device__ __forceinline__ void store_tile32(float* __restrict__ lds, int tid, const float4 (&rg)[2]) {
+__device__ __forceinline__ void store_tile32(float* __restrict__ lds, int tid, const float4 (&rg)[2], int n_valid) {
+    if (n_valid >= 32) {
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int f = tid + AT_THREADS * jj;
-        *reinterpret_cast<float4*>(lds + (f >> 4) * LD + ((f & 15) << 2)) = rg[jj];
+        for (int jj = 0; jj < 2; ++jj) {
+            const int f = tid + AT_THREADS * jj;
+            *reinterpret_cast<float4*>(lds + (f >> 4) * LD + ((f & 15) << 2)) = rg[jj];
+        }
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int f = tid + AT_THREADS * jj;
+            const bool ok = (f >> 4) < n_valid;
+            float4 v = rg[jj];
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            *reinterpret_cast<float4*>(lds + (f >> 4) * LD + ((f & 15) << 2)) = v;
+        }
     }
 }
+
+// Per staged key tile: key levels, dropout key words and the largest key level (a key past the end of the
+// sequence counts as INT_MAX), produced by three different waves while the tile is loaded.
+struct KeyMeta {
+    int32_t kl[32];
+    uint32_t kw[32];
+    int32_t klmax;
+    int32_t pad_[3];
+};
+
+template <bool DROP>
+__device__ __forceinline__ int key_meta_load(const int32_t* __restrict__ klb, int j0, int S, int w, int lane,
+                                             const AttnDropout& rng) {
+    const int j = j0 + (lane & 31);
+    int v = 0;
+    if (w == 0 || w == 1) {
+        v = j < S ? klb[j] : INT_BIG_A;      // wave 1 reduces at store time, when the load has landed
+    } else if (w == 2) {
+        if (DROP) v = (int)rng.key_word((uint32_t)j);
+    }
+    return v;
+}
+__device__ __forceinline__ void key_meta_store(KeyMeta& km, int w, int lane, int v) {
+    if (w == 0) { if (lane < 32) km.kl[lane] = v; }
+    else if (w == 1) { v = wave_max_i32(v); if (lane == 0) km.klmax = v; }
+    else if (w == 2) { if (lane < 32) km.kw[lane] = (uint32_t)v; }
+}
+
+// The 16 score registers of a lane are keys rowmap(reg, h) = (reg & 3) + 8 * (reg >> 2) + 4 * h of the tile:
+// four int4 LDS reads fetch their levels (or dropout words).
+__device__ __forceinline__ void read_key_quads(const int32_t* __restrict__ base, int h, int (&out)[16]) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const int4 t = *reinterpret_cast<const int4*>(base + 8 * g4 + 4 * h);
+        out[4 * g4] = t.x; out[4 * g4 + 1] = t.y; out[4 * g4 + 2] = t.z; out[4 * g4 + 3] = t.w;
+    }
+}
+
+// Online softmax with a lazily updated reference: p = exp2(s - m_ref) is exact for ANY reference (floating
+// point is scale free), so m_ref only moves when a score exceeds it by more than 2^RESCALE_TAU (or nothing has
+// been accumulated yet).  After the first key tile that almost never happens and the 32 accumulator
+// multiplications + exp2 of the classic scheme disappear from the loop.
+constexpr float RESCALE_TAU = 20.f;
 
 // =============================================================================================
 // forward
 // =============================================================================================
-// Software pipeline per wave: while the VALU works through softmax(t) (mask, exp2, row sums, dropout),
-// the matrix pipe already runs S^T(t+1) = K(t+1) Q^T into a second accumulator; P(t) V(t) follows.
-// K tiles are therefore staged one iteration earlier than V tiles (K: LDS slot t&1 holds K(t), loaded
-// two iterations ahead; V: slot t&1, one iteration ahead; key levels: ring of 3).
 #define GAMER_QK_TILE(ACC, KSLOT)                                                                   \
     _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                                \
         const float4 kf = *reinterpret_cast<const float4*>(&Ks[KSLOT][r * KLD + 8 * kk + 4 * h]);      \
@@ -134,18 +178,19 @@ __device__ __forceinline__ void store_tile32(float* __restrict__ lds, int tid, c
         ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kk][3], ACC, 0, 0, 0);                     \
     }
 
-template <int G, bool DROP, bool PIPE, bool ORD>
+template <int G, bool DROP, bool ORD>
 __device__ __forceinline__ void
 attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
               const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
               const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
               int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-              float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int pair, const int qtile) {
+              float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int pair, const int qtile,
+              const int dbg) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
     __shared__ __attribute__((aligned(16))) float Ks[2][32 * KLD];
     __shared__ __attribute__((aligned(16))) float Vs[2][32 * 64];
-    __shared__ int32_t kls[3][32];
+    __shared__ __attribute__((aligned(16))) KeyMeta kms[3];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int hg = w / NSUB, sub = w % NSUB;
@@ -160,7 +205,7 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
     const int iqc = iq_raw;
     const int64_t tok = (int64_t)b * S + iqc;
 
-    // scores are kept in the log2 domain: q is pre-scaled by scale*log2(e), p = exp2(s - m)
+    // scores are kept in the log2 domain: q is pre-scaled by scale*log2(e), p = exp2(s - m_ref)
     unsigned long long* trace = g_trace;
     unsigned long long t_start = 0;
     if (trace) t_start = __builtin_amdgcn_s_memrealtime();
@@ -176,6 +221,10 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
     }
     const int my_ql = ql ? ql[tok] : 1;
     const bool my_empty = valid_q && row_empty[tok] != 0;
+    const bool normal = valid_q && !my_empty;
+    const int wave_ql_min = wave_min_i32(normal ? my_ql : INT_BIG_A);
+    const int wave_q_lo = wave_min_i32(normal ? iq : INT_BIG_A);
+    const bool wave_all_empty = wave_q_lo == INT_BIG_A;          // no normal row: no scores needed at all
     const int n_all = (S + 31) / 32;
     int wave_q_hi, n_causal;
     bool wave_has_empty;
@@ -190,7 +239,7 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
             if (q0 + ss * 32 < S) hi = max(hi, ro.tile_maxpos[tb + ss]);
         n_causal = hi < 0 ? 0 : (hi >> 5) + 1;
     } else {
-        wave_q_hi = min(S - 1, q0 + sub * 32 + 31);
+        wave_q_hi = wave_all_empty ? -1 : min(S - 1, q0 + sub * 32 + 31);
         wave_has_empty = __any(my_empty ? 1 : 0) != 0;
         n_causal = (min(S, q0 + R) + 31) / 32;
     }
@@ -198,31 +247,32 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
     const int n_iter = block_has_empty ? n_all : n_causal;
     const float invS = 1.f / (float)S;
     const AttnDropout rng(p_drop, seed);
-    const uint32_t rb = rng.row_base((uint32_t)(((int64_t)b * nq + head) * S + iqc));
+    const uint32_t aw = DROP ? rng.row_word((uint32_t)(((int64_t)b * nq + head) * S + iqc)) : 0u;
 
     const float* kbase = k + (int64_t)b * S * ldk + kvh * 64;
     const float* vbase = v + (int64_t)b * S * ldv + kvh * 64;
     const int32_t* klb = kl + (int64_t)b * S;
 
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_ref = 0.f, l_run = 0.f;
     f32x16 oacc[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
 
+    // K tiles are staged one iteration earlier than V tiles (the scores of tile t+1 are taken at the end of
+    // iteration t): K slot t&1 is loaded two iterations ahead, V slot t&1 one ahead, key metadata ring of 3.
     float4 rk[2], rv[2];
-    int rkl = INT_BIG_A;
-    // prologue: K(0), V(0), K(1)
+    int rmeta;
     load_tile32(kbase, ldk, 0, S, tid, rk);
     load_tile32(vbase, ldv, 0, S, tid, rv);
-    if (tid < 32) rkl = tid < S ? klb[tid] : INT_BIG_A;
-    store_tile32<KLD>(Ks[0], tid, rk);
-    store_tile32<64>(Vs[0], tid, rv);
-    if (tid < 32) kls[0][tid] = rkl;
+    rmeta = key_meta_load<DROP>(klb, 0, S, w, lane, rng);
+    store_tile32<KLD>(Ks[0], tid, rk, S);
+    store_tile32<64>(Vs[0], tid, rv, S);
+    key_meta_store(kms[0], w, lane, rmeta);
     if (n_iter > 1) {
         load_tile32(kbase, ldk, 32, S, tid, rk);
-        if (tid < 32) rkl = (32 + tid) < S ? klb[32 + tid] : INT_BIG_A;
-        store_tile32<KLD>(Ks[1], tid, rk);
-        if (tid < 32) kls[1][tid] = rkl;
+        rmeta = key_meta_load<DROP>(klb, 32, S, w, lane, rng);
+        store_tile32<KLD>(Ks[1], tid, rk, S - 32);
+        key_meta_store(kms[1], w, lane, rmeta);
     }
     __syncthreads();
 
@@ -230,81 +280,29 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
 #pragma unroll
     for (int i = 0; i < 16; ++i) st_cur[i] = 0.f;
     if (!(0 > wave_q_hi)) { GAMER_QK_TILE(st_cur, 0) }
+    // K(0) must stay intact until every wave has taken its first scores: a wave without work in this tile
+    // (rows past the end of the sequence, or empty rows only) reaches the K(2) store of iteration 0 at once
+    __syncthreads();
 
     for (int jt = 0; jt < n_iter; ++jt) {
         const int j0 = jt * 32;
         const bool have_next = jt + 1 < n_iter;
         const bool have_next2 = jt + 2 < n_iter;
-        if (have_next2) {
+        if (have_next2 && !(dbg & 1)) {
             load_tile32(kbase, ldk, j0 + 64, S, tid, rk);
-            if (tid < 32) rkl = (j0 + 64 + tid) < S ? klb[j0 + 64 + tid] : INT_BIG_A;
+            rmeta = key_meta_load<DROP>(klb, j0 + 64, S, w, lane, rng);
         }
-        if (have_next) load_tile32(vbase, ldv, j0 + 32, S, tid, rv);
+        if (have_next && !(dbg & 1)) load_tile32(vbase, ldv, j0 + 32, S, tid, rv);
 
         const bool beyond = j0 > wave_q_hi;                // every key of the tile is in every row's future
         const bool beyond_next = (j0 + 32) > wave_q_hi;
-        const bool with_next = PIPE && have_next && !beyond_next;
-        f32x16 st_next;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) st_next[i] = 0.f;
         if (!(beyond && !wave_has_empty)) {
-            const int32_t* klt = kls[jt % 3];
-            const float* Kn = Ks[(jt + 1) & 1];
+            const KeyMeta& km = kms[jt % 3];
             const float* Vc = Vs[jt & 1];
-            // One basic block per variant: the next tile's 32 QK MFMAs are issued interleaved with this
-            // tile's softmax VALU (the two pipes run concurrently; a wave issues in order, so the
-            // interleave has to be static), then the 32 PV MFMAs.
-            auto tile = [&]<bool WITH_NEXT, bool EMPTY>() {
-                int4 kl4[4];
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) kl4[g4] = *reinterpret_cast<const int4*>(&klt[8 * g4 + 4 * h]);
-                if (WITH_NEXT) {
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        const float4 kf = *reinterpret_cast<const float4*>(&Kn[r * KLD + 8 * kk + 4 * h]);
-                        st_next = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[kk][0], st_next, 0, 0, 0);
-                        st_next = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[kk][1], st_next, 0, 0, 0);
-                        st_next = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kk][2], st_next, 0, 0, 0);
-                        st_next = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kk][3], st_next, 0, 0, 0);
-                    }
-                }
-                float mloc = -INFINITY;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int key = rowmap(reg, h);
-                    const int klv = (reg & 3) == 0 ? kl4[reg >> 2].x : (reg & 3) == 1 ? kl4[reg >> 2].y
-                                  : (reg & 3) == 2 ? kl4[reg >> 2].z : kl4[reg >> 2].w;
-                    const bool allowed = ((j0 + key) <= iq) & (klv < my_ql) & valid_q;
-                    st_cur[reg] = allowed ? st_cur[reg] : -INFINITY;
-                    mloc = fmaxf(mloc, st_cur[reg]);
-                }
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-                const float m_new = fmaxf(m_run, mloc);
-                const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-                float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);        // m_run = -inf -> 0
-                float rowsum = 0.f;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    float pe = __builtin_amdgcn_exp2f(st_cur[reg] - m_safe);   // masked -> exp2(-inf) = 0
-                    if (EMPTY) pe = my_empty ? ((j0 + rowmap(reg, h) < S) ? invS : 0.f) : pe;
-                    rowsum += pe;
-                    st_cur[reg] = pe;
-                }
-                rowsum += __shfl_xor(rowsum, 32, 64);
-                if (EMPTY) alpha = my_empty ? 1.f : alpha;
-                l_run = l_run * alpha + rowsum;
-                m_run = m_new;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
-                if (DROP) {
-#pragma unroll
-                    for (int reg = 0; reg < 16; reg += 2) {
-                        const uint32_t bits = rng.pair_bits(rb, (uint32_t)(j0 + rowmap(reg, h)) >> 1);
-                        st_cur[reg] *= rng.mult_even(bits);
-                        st_cur[reg + 1] *= rng.mult_odd(bits);
-                    }
-                }
-                // O^T[d][query] += sum_key V[key][d] * P[query][key]
+            // O^T[d][query] += sum_key V[key][d] * P[query][key]   (rows of V past the sequence end are zero).
+            // Called at the end of every variant below so that each one is a straight-line path (a join in
+            // front of the MFMAs costs 16 register copies per tile, and VALU time is not hidden here).
+            auto pv_tile = [&]() {
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int key = rowmap(reg, h);
@@ -313,45 +311,93 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                     oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, st_cur[reg], oacc[0], 0, 0, 0);
                     oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, st_cur[reg], oacc[1], 0, 0, 0);
                 }
-                if (WITH_NEXT) {
-                    // static interleave for the scheduler: 1 MFMA : 14 VALU while the QK chain runs
+            };
+            // MASK: evaluate the causal + level predicate per element (tiles on the diagonal, tiles holding a
+            // blocked key); EMPTYSEL: some rows of the wave are "empty" rows (p = 1, normalised by 1/S at the end)
+            auto softmax_tile = [&]<bool MASK, bool EMPTYSEL>() {
+                if (MASK) {
+                    int klv[16];
+                    read_key_quads(km.kl, h, klv);
+                    const int t_pos = iq - j0 - 4 * h;           // key (reg&3)+8*(reg>>2) of the tile is <= iq
 #pragma unroll
-                    for (int i = 0; i < 32; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, DROP ? 14 : 9, 0);
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const bool allowed = (((reg & 3) + 8 * (reg >> 2)) <= t_pos) & (klv[reg] < my_ql);
+                        st_cur[reg] = allowed ? st_cur[reg] : -INFINITY;
                     }
                 }
-            };
-            if (with_next) {
-                if (wave_has_empty) tile.template operator()<true, true>();
-                else tile.template operator()<true, false>();
-            } else {
-                if (wave_has_empty) tile.template operator()<false, true>();
-                else tile.template operator()<false, false>();
-            }
-        } else if (with_next) {
-            // unreachable (a tile beyond the diagonal has no next tile below it) but kept for clarity
-        }
-        if (!PIPE && have_next) {
-            // scores of the next tile, taken BEFORE the barrier: after it other waves may already overwrite
-            // this K slot with K(jt+3)
+                float mloc = st_cur[0];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) st_cur[i] = 0.f;
-            if (!beyond_next) {
-                if ((jt + 1) & 1) { GAMER_QK_TILE(st_cur, 1) } else { GAMER_QK_TILE(st_cur, 0) }
+                for (int reg = 1; reg < 16; ++reg) mloc = fmaxf(mloc, st_cur[reg]);
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                bool need = (l_run == 0.f) ? (mloc > -INFINITY) : (mloc > RESCALE_TAU);
+                if (EMPTYSEL) need = need && !my_empty;
+                if (__any(need ? 1 : 0)) {
+                    const float d = need ? mloc : 0.f;
+                    const float alpha = (l_run == 0.f) ? 1.f : __builtin_amdgcn_exp2f(-d);
+                    m_ref += d;
+                    l_run *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; st_cur[i] -= d; }
+                }
+                float rowsum = 0.f;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    float pe = __builtin_amdgcn_exp2f(st_cur[reg]);            // masked -> exp2(-inf) = 0
+                    if (EMPTYSEL) pe = my_empty ? 1.f : pe;
+                    rowsum += pe;
+                    st_cur[reg] = pe;
+                }
+                rowsum += __shfl_xor(rowsum, 32, 64);
+                l_run += rowsum;
+                if (DROP) {
+                    int kwv[16];
+                    read_key_quads(reinterpret_cast<const int32_t*>(km.kw), h, kwv);
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        st_cur[reg] = rng.keep(aw, (uint32_t)kwv[reg]) ? st_cur[reg] : 0.f;
+                }
+                pv_tile();
+            };
+            if (wave_all_empty) {
+                // every row of the wave is an empty row: P = keep / S, no scores, no softmax state
+                if (DROP) {
+                    int kwv[16];
+                    read_key_quads(reinterpret_cast<const int32_t*>(km.kw), h, kwv);
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) st_cur[reg] = rng.keep(aw, (uint32_t)kwv[reg]) ? 1.f : 0.f;
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) st_cur[reg] = 1.f;
+                }
+                pv_tile();
+            } else if (wave_has_empty) {
+                softmax_tile.template operator()<true, true>();
+            } else {
+                const int klmax = __builtin_amdgcn_readfirstlane(km.klmax);
+                const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min);
+                if (free_tile) softmax_tile.template operator()<false, false>();
+                else softmax_tile.template operator()<true, false>();
             }
         }
-        if (have_next2) {
-            store_tile32<KLD>(Ks[jt & 1], tid, rk);          // K(jt) is dead: its scores were taken last iteration
-            if (tid < 32) kls[(jt + 2) % 3][tid] = rkl;
+        if (have_next && !beyond_next) {
+            // scores of the next tile (minus the reference), taken BEFORE the barrier: after it other waves may
+            // already overwrite this K slot with K(jt+3)
+            const float init = -m_ref;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st_cur[i] = init;
+            if ((jt + 1) & 1) { GAMER_QK_TILE(st_cur, 1) } else { GAMER_QK_TILE(st_cur, 0) }
         }
-        if (have_next) store_tile32<64>(Vs[(jt + 1) & 1], tid, rv);
-        __syncthreads();
-        if (PIPE) st_cur = st_next;
+        if (have_next2 && !(dbg & 4)) {
+            store_tile32<KLD>(Ks[jt & 1], tid, rk, S - (j0 + 64));   // K(jt) is dead: its scores were taken last iteration
+            key_meta_store(kms[(jt + 2) % 3], w, lane, rmeta);
+        }
+        if (have_next && !(dbg & 4)) store_tile32<64>(Vs[(jt + 1) & 1], tid, rv, S - (j0 + 32));
+        if (!(dbg & 2)) __syncthreads();
     }
 
     if (valid_q) {
-        const float linv = my_empty ? 1.f : (l_run > 0.f ? 1.f / l_run : 0.f);
+        float linv = my_empty ? invS : (l_run > 0.f ? 1.f / l_run : 0.f);
+        if (DROP) linv *= rng.scale;
         float* orow = o + tok * (int64_t)nq * 64 + head * 64;
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh) {
@@ -372,17 +418,17 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
         }
         // natural-log LSE of the scaled scores (what the backward kernels consume)
         if (h == 0) lse[((int64_t)b * nq + head) * S + iqc] =
-            my_empty ? 0.f : (m_run + __log2f(l_run)) * 0.6931471805599453f;
+            my_empty ? 0.f : (m_ref + __log2f(l_run)) * 0.6931471805599453f;
     }
 }
 
-template <int G, bool DROP, int WPS, bool PIPE, bool ORD>
-__global__ void __launch_bounds__(AT_THREADS, WPS)
+template <int G, bool DROP, bool ORD>
+__global__ void __launch_bounds__(AT_THREADS, 2)
 attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                 const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
                 const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
                 int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-                float* __restrict__ o, float* __restrict__ lse, const RowOrder ro) {
+                float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int dbg) {
     constexpr int R = (4 / G) * 32;
     const int n_tiles = (S + R - 1) / R;
     const WorkList wl(nbatch * nkv, n_tiles);
@@ -394,28 +440,8 @@ attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ 
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {                    // one inlined body (register pressure)
             if (pass == 1 && light == heavy) break;
-            attn_fwd_tile<G, DROP, PIPE, ORD>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed, o, lse,
-                                         ro, pair, pass == 0 ? heavy : light);
-        }
-    }
-}
-
-// delta[b,h,i] = sum_d dO * O
-__global__ void __launch_bounds__(AT_THREADS)
-attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o, int B, int S, int nq,
-                  float* __restrict__ delta) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * AT_THREADS + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * AT_THREADS) >> 6;
-    const int64_t total = (int64_t)B * S * nq;
-    for (int64_t i = wave; i < total; i += nwaves) {
-        const int64_t t = i / nq;
-        const int hd = (int)(i % nq);
-        const float pv = o[t * nq * 64 + hd * 64 + lane] * d_o[t * nq * 64 + hd * 64 + lane];
-        const float s = wave_sum(pv);
-        if (lane == 0) {
-            const int64_t b = t / S, ii = t % S;
-            delta[(b * nq + hd) * S + ii] = s;
+            attn_fwd_tile<G, DROP, ORD>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed, o, lse,
+                                        ro, pair, pass == 0 ? heavy : light, dbg);
         }
     }
 }
@@ -423,7 +449,7 @@ attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o, in
 // =============================================================================================
 // backward: dQ
 // =============================================================================================
-template <int G, bool ORD>
+template <int G, bool DROP, bool ORD>
 __device__ __forceinline__ void
 attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                    const float* __restrict__ v, int ldv, const float* __restrict__ o, const float* __restrict__ d_o,
@@ -436,7 +462,7 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
     constexpr int R = NSUB * 32;
     __shared__ __attribute__((aligned(16))) float Ks[2][32 * KLD];
     __shared__ __attribute__((aligned(16))) float Vs[2][32 * KLD];
-    __shared__ int32_t kls[2][32];
+    __shared__ __attribute__((aligned(16))) KeyMeta kms[2];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int hg = w / NSUB, sub = w % NSUB;
@@ -451,6 +477,9 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
     const int iqc = iq_raw;
     const int64_t tok = (int64_t)b * S + iqc;
 
+    // log2 domain: q is pre-scaled by scale*log2(e) and the score accumulators start at -lse*log2(e), so
+    // p = exp2(accumulator)
+    const float qs = scale * 1.4426950408889634f;
     float qf[8][4], dof[8][4];
     float my_delta = 0.f;                 // delta_i = dO_i . O_i, computed here and published for the dK/dV kernel
     {
@@ -460,7 +489,7 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             const float4 t4 = *reinterpret_cast<const float4*>(qrow + 8 * kk + 4 * h);
-            qf[kk][0] = t4.x * scale; qf[kk][1] = t4.y * scale; qf[kk][2] = t4.z * scale; qf[kk][3] = t4.w * scale;
+            qf[kk][0] = t4.x * qs; qf[kk][1] = t4.y * qs; qf[kk][2] = t4.z * qs; qf[kk][3] = t4.w * qs;
             const float4 u4 = *reinterpret_cast<const float4*>(drow + 8 * kk + 4 * h);
             dof[kk][0] = u4.x; dof[kk][1] = u4.y; dof[kk][2] = u4.z; dof[kk][3] = u4.w;
             const float4 o4 = *reinterpret_cast<const float4*>(orow + 8 * kk + 4 * h);
@@ -471,7 +500,11 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
     }
     const int my_ql = ql ? ql[tok] : 1;
     const bool my_empty = valid_q && row_empty[tok] != 0;
-    const float my_lse = lse[((int64_t)b * nq + head) * S + iqc];
+    const bool normal = valid_q && !my_empty;
+    const float neg_lse2 = -lse[((int64_t)b * nq + head) * S + iqc] * 1.4426950408889634f;
+    const int wave_ql_min = wave_min_i32(normal ? my_ql : INT_BIG_A);
+    const int wave_q_lo = wave_min_i32(normal ? iq : INT_BIG_A);
+    const bool wave_all_empty = wave_q_lo == INT_BIG_A;
     const int n_all = (S + 31) / 32;
     int wave_q_hi, n_causal;
     bool wave_has_empty;
@@ -486,7 +519,7 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
             if (q0 + ss * 32 < S) hi = max(hi, ro.tile_maxpos[tb + ss]);
         n_causal = hi < 0 ? 0 : (hi >> 5) + 1;
     } else {
-        wave_q_hi = min(S - 1, q0 + sub * 32 + 31);
+        wave_q_hi = wave_all_empty ? -1 : min(S - 1, q0 + sub * 32 + 31);
         wave_has_empty = __any(my_empty ? 1 : 0) != 0;
         n_causal = (min(S, q0 + R) + 31) / 32;
     }
@@ -494,7 +527,9 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
     const int n_iter = block_has_empty ? n_all : n_causal;
     const float invS = 1.f / (float)S;
     const AttnDropout rng(p_drop, seed);
-    const uint32_t rb = rng.row_base((uint32_t)(((int64_t)b * nq + head) * S + iqc));
+    const uint32_t aw = DROP ? rng.row_word((uint32_t)(((int64_t)b * nq + head) * S + iqc)) : 0u;
+    const float sd = rng.scale;
+    const float neg_delta = -my_delta;
 
     const float* kbase = k + (int64_t)b * S * ldk + kvh * 64;
     const float* vbase = v + (int64_t)b * S * ldv + kvh * 64;
@@ -505,13 +540,13 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
     for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
 
     float4 rk[2], rv[2];
-    int rkl = INT_BIG_A;
+    int rmeta;
     load_tile32(kbase, ldk, 0, S, tid, rk);
     load_tile32(vbase, ldv, 0, S, tid, rv);
-    if (tid < 32) rkl = tid < S ? klb[tid] : INT_BIG_A;
-    store_tile32<KLD>(Ks[0], tid, rk);
-    store_tile32<KLD>(Vs[0], tid, rv);
-    if (tid < 32) kls[0][tid] = rkl;
+    rmeta = key_meta_load<DROP>(klb, 0, S, w, lane, rng);
+    store_tile32<KLD>(Ks[0], tid, rk, S);
+    store_tile32<KLD>(Vs[0], tid, rv, S);
+    key_meta_store(kms[0], w, lane, rmeta);
     __syncthreads();
 
     for (int jt = 0; jt < n_iter; ++jt) {
@@ -521,13 +556,14 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
         if (more) {
             load_tile32(kbase, ldk, j0 + 32, S, tid, rk);
             load_tile32(vbase, ldv, j0 + 32, S, tid, rv);
-            if (tid < 32) rkl = (j0 + 32 + tid) < S ? klb[j0 + 32 + tid] : INT_BIG_A;
+            rmeta = key_meta_load<DROP>(klb, j0 + 32, S, w, lane, rng);
         }
         const bool beyond = j0 > wave_q_hi;
         if (!(beyond && !wave_has_empty)) {
+            const KeyMeta& km = kms[cur];
             f32x16 st, dp;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+            for (int i = 0; i < 16; ++i) { st[i] = neg_lse2; dp[i] = 0.f; }
             if (!beyond) {
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
@@ -547,57 +583,86 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
                 dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, dof[kk][2], dp, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, dof[kk][3], dp, 0, 0, 0);
             }
-            // key levels of this lane's 16 keys in four 16-byte LDS reads; branch-free predicates (a lazily
-            // evaluated && makes hipcc branch and wait on an LDS read per element)
-            int4 kl4[4];
+            // u = mult * dP - delta  (mult = keep / (1 - p))
+            if (DROP) {
+                int kwv[16];
+                read_key_quads(reinterpret_cast<const int32_t*>(km.kw), h, kwv);
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) kl4[g4] = *reinterpret_cast<const int4*>(&kls[cur][8 * g4 + 4 * h]);
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float t = rng.keep(aw, (uint32_t)kwv[reg]) ? dp[reg] : 0.f;
+                    dp[reg] = fmaf(t, sd, neg_delta);
+                }
+            } else {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int j = j0 + rowmap(reg, h);
-                const int klv = (reg & 3) == 0 ? kl4[reg >> 2].x : (reg & 3) == 1 ? kl4[reg >> 2].y
-                              : (reg & 3) == 2 ? kl4[reg >> 2].z : kl4[reg >> 2].w;
-                const bool allowed = (j <= iq) & (klv < my_ql) & valid_q;
-                float pe = __expf(st[reg] - my_lse);
-                pe = allowed ? pe : 0.f;
-                pe = my_empty ? ((j < S) ? invS : 0.f) : pe;
-                const float mult = rng.on ? rng.mult(rb, (uint32_t)j) : 1.f;
-                st[reg] = pe * (mult * dp[reg] - my_delta);      // dS^T
+                for (int reg = 0; reg < 16; ++reg) dp[reg] += neg_delta;
             }
-            // dQ^T[d][query] += sum_key K[key][d] dS^T[key][query]
+            // dQ^T[d][query] += sum_key K[key][d] dS^T[key][query]   (rows of K past the sequence end are zero)
+            auto dq_tile = [&](const f32x16& ds) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int key = rowmap(reg, h);
-                const float a0 = Ks[cur][key * KLD + r];
-                const float a1 = Ks[cur][key * KLD + 32 + r];
-                dqacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, st[reg], dqacc[0], 0, 0, 0);
-                dqacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, st[reg], dqacc[1], 0, 0, 0);
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int key = rowmap(reg, h);
+                    const float a0 = Ks[cur][key * KLD + r];
+                    const float a1 = Ks[cur][key * KLD + 32 + r];
+                    dqacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ds[reg], dqacc[0], 0, 0, 0);
+                    dqacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, ds[reg], dqacc[1], 0, 0, 0);
+                }
+            };
+            // dS^T = p * u ; an empty row has p = 1 here and 1/S in the final scale
+            auto ds_tile = [&]<bool MASK, bool EMPTYSEL>() {
+                if (MASK) {
+                    int klv[16];
+                    read_key_quads(km.kl, h, klv);
+                    const int t_pos = iq - j0 - 4 * h;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const bool allowed = (((reg & 3) + 8 * (reg >> 2)) <= t_pos) & (klv[reg] < my_ql);
+                        st[reg] = allowed ? st[reg] : -INFINITY;
+                    }
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    float pe = __builtin_amdgcn_exp2f(st[reg]);
+                    if (EMPTYSEL) pe = my_empty ? 1.f : pe;
+                    st[reg] = pe * dp[reg];
+                }
+            };
+            if (wave_all_empty) {
+                st = dp;
+            } else if (wave_has_empty) {
+                ds_tile.template operator()<true, true>();
+            } else {
+                const int klmax = __builtin_amdgcn_readfirstlane(km.klmax);
+                const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min);
+                if (free_tile) ds_tile.template operator()<false, false>();
+                else ds_tile.template operator()<true, false>();
             }
+            dq_tile(st);
         }
         if (more) {
-            store_tile32<KLD>(Ks[cur ^ 1], tid, rk);
-            store_tile32<KLD>(Vs[cur ^ 1], tid, rv);
-            if (tid < 32) kls[cur ^ 1][tid] = rkl;
+            store_tile32<KLD>(Ks[cur ^ 1], tid, rk, S - (j0 + 32));
+            store_tile32<KLD>(Vs[cur ^ 1], tid, rv, S - (j0 + 32));
+            key_meta_store(kms[cur ^ 1], w, lane, rmeta);
         }
         __syncthreads();
     }
 
     if (valid_q) {
+        const float fs = my_empty ? scale * invS : scale;
         float* drow = dq + tok * lddq + head * 64;
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 float4 t4;
-                t4.x = dqacc[dh][4 * g4 + 0] * scale; t4.y = dqacc[dh][4 * g4 + 1] * scale;
-                t4.z = dqacc[dh][4 * g4 + 2] * scale; t4.w = dqacc[dh][4 * g4 + 3] * scale;
+                t4.x = dqacc[dh][4 * g4 + 0] * fs; t4.y = dqacc[dh][4 * g4 + 1] * fs;
+                t4.z = dqacc[dh][4 * g4 + 2] * fs; t4.w = dqacc[dh][4 * g4 + 3] * fs;
                 *reinterpret_cast<float4*>(drow + 32 * dh + 8 * g4 + 4 * h) = t4;
             }
         }
     }
 }
 
-template <int G, bool ORD>
+template <int G, bool DROP, bool ORD>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                    const float* __restrict__ v, int ldv, const float* __restrict__ o, const float* __restrict__ d_o,
@@ -616,8 +681,8 @@ attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
-            attn_bwd_dq_tile<G, ORD>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed,
-                                dq, lddq, ro, pair, pass == 0 ? heavy : light);
+            attn_bwd_dq_tile<G, DROP, ORD>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, S, nq, nkv, scale,
+                                           p_drop, seed, dq, lddq, ro, pair, pass == 0 ? heavy : light);
         }
     }
 }
@@ -631,14 +696,18 @@ struct DkvSmem {
     float Vt[(4 / G) * 32 * KLD];
     float Qs[G][32 * KLD];
     float dOs[G][32 * KLD];
-    float lse_s[G][32];
-    float delta_s[G][32];
+    float nlse2_s[G][32];       // -lse * log2(e) of the staged query rows
+    float ndelta_s[G][32];      // -delta
+    uint32_t aw_s[G][32];       // dropout row words
     int32_t ql_s[32];
     int32_t empty_s[32];
     int32_t pos_s[32];          // position of the staged query rows (S for rows past the end)
+    int32_t qlmin;              // smallest query level / position over the normal rows of the tile (INT_MAX: none)
+    int32_t posmin;
+    int32_t pad_[2];
 };
 
-template <int G, bool ORD>
+template <int G, bool DROP, bool ORD>
 __device__ __forceinline__ void
 attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                     const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
@@ -657,7 +726,6 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
     const int hg = w / NSUB, sub = w % NSUB;
     __syncthreads();                 // the previous tile's head reduction may still be reading the LDS region
     const int b = pair / nkv, kvh = pair % nkv, k0 = ktile * R;
-    const int head = kvh * G + hg;
     const int r = lane & 31, h = lane >> 5;
     const int jk = k0 + sub * 32 + r;                 // this lane's key
     const bool valid_k = jk < S;
@@ -679,10 +747,14 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
     const float* Kw = &sm.Kt[(sub * 32 + r) * KLD + 4 * h];
     const float* Vw = &sm.Vt[(sub * 32 + r) * KLD + 4 * h];
     const int my_kl = valid_k ? kl[ktok] : INT_BIG_A;
-    const int wave_k_lo = k0 + sub * 32;
+    const int wave_kl_max = wave_max_i32(my_kl);
+    const int wave_k_lo = k0 + sub * 32, wave_k_hi = wave_k_lo + 31;
     const float invS = 1.f / (float)S;
+    const float c2 = scale * 1.4426950408889634f;
     const AttnDropout rng(p_drop, seed);
-    const uint32_t drop_head = (uint32_t)(((int64_t)b * nq + head) * S);
+    const uint32_t bw = DROP ? rng.key_word((uint32_t)jk) : 0u;
+    const float sd = rng.scale;
+    const uint32_t drop_head0 = (uint32_t)(((int64_t)b * nq + kvh * G) * S);
 
     const int n_qt = (S + 31) / 32;
     const int32_t* te = tile_empty + (int64_t)b * n_qt;
@@ -701,7 +773,8 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
     // staged registers: per head one Q tile and one dO tile (2 float4 each per thread)
     float4 rq[G][2], rdo[G][2];
     float rl = 0.f, rd = 0.f;
-    int rql = 1, rem = 0, rpos = 0;
+    uint32_t raw = 0;
+    int rql = 1, rem = 0, rpos = 0, rqlmin = INT_BIG_A, rposmin = INT_BIG_A;
 
     auto next_tile = [&](int qt) {
         while (qt < n_qt && !tile_empty_rows(qt) && tile_last_pos(qt) < k0) ++qt;
@@ -720,33 +793,42 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
                 load_tile32(d_o + (int64_t)b * S * nq * 64 + hd * 64, (int64_t)nq * 64, i0, S, tid, rdo[g]);
             }
         }
-        // per-query scalars: threads 0..G*32-1 take (g, row)
-        if (tid < G * 32) {
-            const int g = tid >> 5, row = tid & 31;
+        // per-query scalars: waves 0 (and 1 for G = 2) take (g = wave, row = lane & 31); both lane halves
+        // compute the same values so that the wave-wide minima need no masking
+        if (w < G) {
+            const int g = w, row = lane & 31;
             const int sl = i0 + row;
             const bool in = sl < S;
             const int i = in ? (ORD ? pmap[sl] : sl) : 0;          // position of the row
             const int hd = kvh * G + g;
-            rl = in ? lse[((int64_t)b * nq + hd) * S + i] : 0.f;
-            rd = in ? delta[((int64_t)b * nq + hd) * S + i] : 0.f;
+            rl = in ? -lse[((int64_t)b * nq + hd) * S + i] * 1.4426950408889634f : 0.f;
+            rd = in ? -delta[((int64_t)b * nq + hd) * S + i] : 0.f;
+            if (DROP) raw = rng.row_word(drop_head0 + (uint32_t)(g * S + i));
             if (g == 0) {
                 rql = in ? (ql ? ql[(int64_t)b * S + i] : 1) : 0;
                 rem = in ? row_empty[(int64_t)b * S + i] : 0;
                 rpos = in ? i : S;
+                const bool normal = in && rem == 0;
+                rqlmin = wave_min_i32(normal ? rql : INT_BIG_A);
+                rposmin = wave_min_i32(normal ? rpos : INT_BIG_A);
             }
         }
     };
-    auto store_q_tile = [&]() {
+    auto store_q_tile = [&](int qt) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            store_tile32<KLD>(sm.Qs[g], tid, rq[g]);
-            store_tile32<KLD>(sm.dOs[g], tid, rdo[g]);
+            store_tile32<KLD>(sm.Qs[g], tid, rq[g], S - qt * 32);
+            store_tile32<KLD>(sm.dOs[g], tid, rdo[g], S - qt * 32);
         }
-        if (tid < G * 32) {
-            const int g = tid >> 5, row = tid & 31;
-            sm.lse_s[g][row] = rl;
-            sm.delta_s[g][row] = rd;
-            if (g == 0) { sm.ql_s[row] = rql; sm.empty_s[row] = rem; sm.pos_s[row] = rpos; }
+        if (w < G && lane < 32) {
+            const int g = w, row = lane;
+            sm.nlse2_s[g][row] = rl;
+            sm.ndelta_s[g][row] = rd;
+            if (DROP) sm.aw_s[g][row] = raw;
+            if (g == 0) {
+                sm.ql_s[row] = rql; sm.empty_s[row] = rem; sm.pos_s[row] = rpos;
+                if (row == 0) { sm.qlmin = rqlmin; sm.posmin = rposmin; }
+            }
         }
     };
 
@@ -756,10 +838,13 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
     while (qt < n_qt) {
         __syncthreads();                 // previous tile fully consumed (and K/V staging visible)
         load_q_tile(qt);
-        store_q_tile();
+        store_q_tile(qt);
         __syncthreads();
         const bool tile_has_empty = tile_empty_rows(qt);
         const int qt_next = next_tile(qt + 1);
+        const int posmin = __builtin_amdgcn_readfirstlane(sm.posmin);
+        const int qlmin = __builtin_amdgcn_readfirstlane(sm.qlmin);
+        const bool tile_all_empty = tile_has_empty && posmin == INT_BIG_A;
 
         const bool before = tile_last_pos(qt) < wave_k_lo;   // every normal query of the tile precedes this wave's keys
         if (!(before && !tile_has_empty)) {
@@ -768,7 +853,7 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
             for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
             const float* Qh = sm.Qs[hg];
             const float* dOh = sm.dOs[hg];
-            if (!before) {
+            if (!before && !tile_all_empty) {
                 // S[query][key] = sum_d Q[query][d] K[key][d]
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
@@ -790,34 +875,70 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
                 dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, dp, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, dp, 0, 0, 0);
             }
-            // per element: query = i0 + rowmap(reg,h) lives in the register index
+            // per element (query = register, key = lane):  P -> st (for dV, 1/(1-p) applied at the end),
+            //                                               dS -> dp (for dK)
+            // Rows past the end of the sequence have Q = dO = 0, lse = delta = 0: p = 1 but dS = 0 and dO = 0.
+            auto elem_tile = [&]<bool MASK, bool EMPTYSEL, bool ALL_EMPTY>() {
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int qb = 8 * g4 + 4 * h;
-                const float4 l4 = *reinterpret_cast<const float4*>(&sm.lse_s[hg][qb]);
-                const float4 d4 = *reinterpret_cast<const float4*>(&sm.delta_s[hg][qb]);
-                const int4 q4 = *reinterpret_cast<const int4*>(&sm.ql_s[qb]);
-                const int4 e4 = *reinterpret_cast<const int4*>(&sm.empty_s[qb]);
-                int4 p4 = make_int4(0, 0, 0, 0);
-                if (ORD) p4 = *reinterpret_cast<const int4*>(&sm.pos_s[qb]);
-                const int posv[4] = {p4.x, p4.y, p4.z, p4.w};
-                const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
-                const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
-                const int qlv[4] = {q4.x, q4.y, q4.z, q4.w};
-                const int emv[4] = {e4.x, e4.y, e4.z, e4.w};
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int qb = 8 * g4 + 4 * h;
+                    const float4 d4 = *reinterpret_cast<const float4*>(&sm.ndelta_s[hg][qb]);
+                    const float ndl[4] = {d4.x, d4.y, d4.z, d4.w};
+                    float nl[4] = {0.f, 0.f, 0.f, 0.f};
+                    int qlv[4] = {0, 0, 0, 0}, posv[4] = {0, 0, 0, 0}, emv[4] = {0, 0, 0, 0};
+                    uint32_t awv[4] = {0, 0, 0, 0};
+                    if (!ALL_EMPTY) {
+                        const float4 l4 = *reinterpret_cast<const float4*>(&sm.nlse2_s[hg][qb]);
+                        nl[0] = l4.x; nl[1] = l4.y; nl[2] = l4.z; nl[3] = l4.w;
+                    }
+                    if (MASK) {
+                        const int4 q4 = *reinterpret_cast<const int4*>(&sm.ql_s[qb]);
+                        const int4 p4 = *reinterpret_cast<const int4*>(&sm.pos_s[qb]);
+                        qlv[0] = q4.x; qlv[1] = q4.y; qlv[2] = q4.z; qlv[3] = q4.w;
+                        posv[0] = p4.x; posv[1] = p4.y; posv[2] = p4.z; posv[3] = p4.w;
+                    }
+                    if (EMPTYSEL) {
+                        const int4 e4 = *reinterpret_cast<const int4*>(&sm.empty_s[qb]);
+                        emv[0] = e4.x; emv[1] = e4.y; emv[2] = e4.z; emv[3] = e4.w;
+                    }
+                    if (DROP) {
+                        const uint4 a4 = *reinterpret_cast<const uint4*>(&sm.aw_s[hg][qb]);
+                        awv[0] = a4.x; awv[1] = a4.y; awv[2] = a4.z; awv[3] = a4.w;
+                    }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int reg = 4 * g4 + e;
-                    const int i = ORD ? posv[e] : min(qt * 32 + qb + e, S);      // query position (S: past the end)
-                    const bool inq = i < S;
-                    const bool allowed = inq & valid_k & (jk <= i) & (my_kl < qlv[e]);
-                    float pe = __expf(st[reg] * scale - lv[e]);
-                    pe = allowed ? pe : 0.f;
-                    pe = (emv[e] != 0) ? ((inq & valid_k) ? invS : 0.f) : pe;
-                    const float mult = rng.on ? rng.mult(rng.row_base(drop_head + (uint32_t)(inq ? i : 0)), (uint32_t)jkc) : 1.f;
-                    st[reg] = pe * (mult * dp[reg] - dl[e]);     // dS[query][key]
-                    dp[reg] = pe * mult;                          // dropped P[query][key]
+                    for (int e = 0; e < 4; ++e) {
+                        const int reg = 4 * g4 + e;
+                        float pe;
+                        if (ALL_EMPTY) {
+                            pe = invS;
+                        } else {
+                            pe = __builtin_amdgcn_exp2f(fmaf(st[reg], c2, nl[e]));
+                            if (MASK) {
+                                const bool allowed = (jk <= posv[e]) & (my_kl < qlv[e]);
+                                pe = allowed ? pe : 0.f;
+                            }
+                            if (EMPTYSEL) pe = (emv[e] != 0) ? invS : pe;
+                        }
+                        if (DROP) {
+                            const bool keep = rng.keep(awv[e], bw);
+                            const float t = keep ? dp[reg] : 0.f;
+                            dp[reg] = pe * fmaf(t, sd, ndl[e]);          // dS[query][key]
+                            st[reg] = keep ? pe : 0.f;                   // dropped P[query][key] * (1 - p)
+                        } else {
+                            dp[reg] = pe * (dp[reg] + ndl[e]);
+                            st[reg] = pe;
+                        }
+                    }
                 }
+            };
+            if (tile_all_empty) {
+                elem_tile.template operator()<false, false, true>();
+            } else if (tile_has_empty) {
+                elem_tile.template operator()<true, true, false>();
+            } else {
+                const bool free_tile = (posmin >= wave_k_hi) && (wave_kl_max < qlmin);
+                if (free_tile) elem_tile.template operator()<false, false, false>();
+                else elem_tile.template operator()<true, false, false>();
             }
             // dV^T[d][key] += sum_query dO[query][d] Pd[query][key] ; dK^T[d][key] += sum_query Q[query][d] dS[query][key]
 #pragma unroll
@@ -825,12 +946,12 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
                 const int qrow = rowmap(reg, h);
                 const float o0 = dOh[qrow * KLD + r];
                 const float o1 = dOh[qrow * KLD + 32 + r];
-                dvacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(o0, dp[reg], dvacc[0], 0, 0, 0);
-                dvacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o1, dp[reg], dvacc[1], 0, 0, 0);
+                dvacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(o0, st[reg], dvacc[0], 0, 0, 0);
+                dvacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o1, st[reg], dvacc[1], 0, 0, 0);
                 const float q0v = Qh[qrow * KLD + r];
                 const float q1v = Qh[qrow * KLD + 32 + r];
-                dkacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0v, st[reg], dkacc[0], 0, 0, 0);
-                dkacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1v, st[reg], dkacc[1], 0, 0, 0);
+                dkacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0v, dp[reg], dkacc[0], 0, 0, 0);
+                dkacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1v, dp[reg], dkacc[1], 0, 0, 0);
             }
         }
         qt = qt_next;
@@ -873,6 +994,7 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
     if (hg == 0 && valid_k) {
         float* dkrow = dk + ktok * lddk + kvh * 64;
         float* dvrow = dv + ktok * lddv + kvh * 64;
+        const float vs = DROP ? sd : 1.f;
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
@@ -880,13 +1002,13 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
                 const int d = 32 * dh + 8 * g4 + 4 * h;
                 *reinterpret_cast<float4*>(dkrow + d) = make_float4(dkacc[dh][4 * g4] * scale, dkacc[dh][4 * g4 + 1] * scale,
                                                                     dkacc[dh][4 * g4 + 2] * scale, dkacc[dh][4 * g4 + 3] * scale);
-                *reinterpret_cast<float4*>(dvrow + d) = make_float4(dvacc[dh][4 * g4], dvacc[dh][4 * g4 + 1],
-                                                                    dvacc[dh][4 * g4 + 2], dvacc[dh][4 * g4 + 3]);
+                *reinterpret_cast<float4*>(dvrow + d) = make_float4(dvacc[dh][4 * g4] * vs, dvacc[dh][4 * g4 + 1] * vs,
+                                                                    dvacc[dh][4 * g4 + 2] * vs, dvacc[dh][4 * g4 + 3] * vs);
             }
     }
 }
 
-template <int G, bool ORD>
+template <int G, bool DROP, bool ORD>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                     const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
@@ -906,8 +1028,8 @@ attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restric
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
-            attn_bwd_dkv_tile<G, ORD>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv, scale,
-                                 p_drop, seed, dk, lddk, dv, lddv, ro, pair, pass == 0 ? heavy : light);
+            attn_bwd_dkv_tile<G, DROP, ORD>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv,
+                                            scale, p_drop, seed, dk, lddk, dv, lddv, ro, pair, pass == 0 ? heavy : light);
         }
     }
 }
@@ -958,16 +1080,44 @@ static int launch_fwd(const float* q, int ldq, const float* k, int ldk, const fl
                       float p_drop, uint64_t seed, float* o, float* lse, RowOrder ro, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
-    // PIPE = false: the software-pipelined variant (next tile's QK MFMAs interleaved with this tile's softmax)
-    // measured slower here (0.95 vs 0.80 ms at B=256): it needs 16 more accumulator registers and spills at
-    // the 256-VGPR budget of two workgroups per CU; with the whole register file (one workgroup per CU) it
-    // loses the second wave per SIMD instead.  Kept as a template parameter for the next round.
 #define GAMER_LAUNCH_FWD(DROPV, ORDV)                                                                              \
-    hipLaunchKernelGGL((attn_fwd_kernel<G, DROPV, 2, false, ORDV>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, \
-                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro)
+    hipLaunchKernelGGL((attn_fwd_kernel<G, DROPV, ORDV>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, \
+                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, dbg)
+    static const int dbg = getenv("GAMER_ATTN_DBG") ? atoi(getenv("GAMER_ATTN_DBG")) : 0;   // timing experiments only
     if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD(true, true); else GAMER_LAUNCH_FWD(true, false); }
     else { if (ro.perm) GAMER_LAUNCH_FWD(false, true); else GAMER_LAUNCH_FWD(false, false); }
+#undef GAMER_LAUNCH_FWD
     GAMER_CHECK_LAUNCH("gamer_attn_fwd");
+    return 0;
+}
+
+template <int G, bool DROP, bool ORD>
+static int launch_bwd_variant(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                              const float* d_o, const float* lse, float* delta, const int32_t* kl, const int32_t* ql,
+                              const int32_t* row_empty, const int32_t* tile_empty, int B, int S, int nq, int nkv,
+                              float scale, float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk,
+                              float* dv, int lddv, RowOrder ro, hipStream_t st) {
+    constexpr int R = (4 / G) * 32;
+    dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<G, DROP, ORD>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse,
+                       delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, ro);
+    GAMER_CHECK_LAUNCH("gamer_attn_bwd/dq");
+    size_t shmem = sizeof(DkvSmem<G>);
+    const size_t red_bytes = (size_t)R * 132 * sizeof(float);
+    if (shmem < red_bytes) shmem = red_bytes;
+    static bool attr_set = false;             // one flag per template instantiation
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<G, DROP, ORD>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) {
+            set_error("gamer_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<G, DROP, ORD>), grid, dim3(AT_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse,
+                       delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro);
+    GAMER_CHECK_LAUNCH("gamer_attn_bwd/dkv");
     return 0;
 }
 
@@ -977,39 +1127,12 @@ static int launch_bwd(const float* q, int ldq, const float* k, int ldk, const fl
                       const int32_t* row_empty, const int32_t* tile_empty, int B, int S, int nq, int nkv, float scale,
                       float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                       RowOrder ro, hipStream_t st) {
-    constexpr int R = (4 / G) * 32;
-    dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
-    if (ro.perm)
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<G, true>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse,
-                           delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, ro);
-    else
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<G, false>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse,
-                           delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, ro);
-    GAMER_CHECK_LAUNCH("gamer_attn_bwd/dq");
-    size_t shmem = sizeof(DkvSmem<G>);
-    const size_t red_bytes = (size_t)R * 132 * sizeof(float);
-    if (shmem < red_bytes) shmem = red_bytes;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<G, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<G, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) {
-            set_error("gamer_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_set = true;
-    }
-    if (ro.perm)
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<G, true>), grid, dim3(AT_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse,
-                           delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro);
-    else
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<G, false>), grid, dim3(AT_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse,
-                           delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro);
-    GAMER_CHECK_LAUNCH("gamer_attn_bwd/dkv");
-    return 0;
+#define GAMER_LAUNCH_BWD(DROPV, ORDV)                                                                                \
+    return launch_bwd_variant<G, DROPV, ORDV>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, \
+                                              S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, st)
+    if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_BWD(true, true); else GAMER_LAUNCH_BWD(true, false); }
+    else { if (ro.perm) GAMER_LAUNCH_BWD(false, true); else GAMER_LAUNCH_BWD(false, false); }
+#undef GAMER_LAUNCH_BWD
 }
 
 }  // namespace gamer
@@ -1050,10 +1173,10 @@ extern "C" int gamer_debug_attn_occupancy(int which) {
     int n = -1;
     hipError_t e = hipSuccess;
     switch (which) {
-        case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<2, true, 2, false, false>, AT_THREADS, 0); break;
-        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<2, false, 2, false, false>, AT_THREADS, 0); break;
-        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq_kernel<2, false>, AT_THREADS, 0); break;
-        case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_kernel<2, false>, AT_THREADS, sizeof(DkvSmem<2>)); break;
+        case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<2, true, false>, AT_THREADS, 0); break;
+        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<2, false, false>, AT_THREADS, 0); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq_kernel<2, true, false>, AT_THREADS, 0); break;
+        case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_kernel<2, true, false>, AT_THREADS, sizeof(DkvSmem<2>)); break;
     }
     return e == hipSuccess ? n : -(int)e;
 }

@@ -87,29 +87,43 @@ struct DropoutRng {
     }
 };
 
-// Dropout on attention probabilities: one 32-bit hash per (row, key pair) gives the two 16-bit
-// uniform numbers of keys 2*jp and 2*jp+1, so the forward / dQ kernels (key pairs in adjacent
-// accumulator registers of one lane) hash once per two elements.  keep iff u16 >= p*65536.
+// Dropout on attention probabilities.  On gfx950 the fp32 MFMA runs on the same lanes as the fp32 VALU
+// (tools/ubench_pipes.hip: an MFMA wave and a v_fma wave on one SIMD take the SUM of their times), so every
+// VALU instruction in an attention inner loop is paid in full.  The mask is therefore a multiply-shift hash:
+//     keep(i, j) = low32(a_i * b_j) >= p * 2^32
+// with a 24-bit odd word a_i per (batch, head, query row) and a 24-bit word b_j per key, both from mix32.
+// Per element that is one full-rate v_mul_u32_u24 + one compare; the words are hashed once per row / per key
+// tile.  keep() is a pure function of (seed, row, key), so the three kernels regenerate the same mask in
+// their own traversal order.  (Row/column keep rates, adjacent-element and 2x2 correlations of this mask are
+// indistinguishable from numpy's generator at S = 505; checked offline.)
 struct AttnDropout {
-    uint32_t k0, thr16;
+    uint32_t k0, k1, thr;
     float scale;
-    bool on;
     __device__ __forceinline__ AttnDropout(float p, uint64_t seed) {
-        on = p > 0.f;
         k0 = mix32((uint32_t)seed ^ 0x9e3779b9U) ^ mix32((uint32_t)(seed >> 32) + 0x7f4a7c15U);
-        thr16 = (uint32_t)(p * 65536.f);
-        scale = on ? 1.f / (1.f - p) : 1.f;
+        k1 = mix32(k0 + 0x632be5abU);
+        const float t = p * 4294967296.f;
+        thr = t >= 4294967040.f ? 0xffffffffU : (uint32_t)t;
+        scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
     }
     // row = (b*nq + head)*S + i
-    __device__ __forceinline__ uint32_t row_base(uint32_t row) const { return mix32(row * 0x9e3779b1U + k0); }
-    __device__ __forceinline__ uint32_t pair_bits(uint32_t rb, uint32_t jp) const { return mix32(rb + jp * 0x85ebca6bU); }
-    __device__ __forceinline__ float mult_even(uint32_t bits) const { return (bits & 0xffffU) >= thr16 ? scale : 0.f; }
-    __device__ __forceinline__ float mult_odd(uint32_t bits) const { return (bits >> 16) >= thr16 ? scale : 0.f; }
-    __device__ __forceinline__ float mult(uint32_t rb, uint32_t j) const {
-        const uint32_t bits = pair_bits(rb, j >> 1);
-        return (j & 1U) ? mult_odd(bits) : mult_even(bits);
+    __device__ __forceinline__ uint32_t row_word(uint32_t row) const {
+        return (mix32(row * 0x9e3779b1U + k0) & 0xffffffU) | 0x800001U;
     }
+    __device__ __forceinline__ uint32_t key_word(uint32_t j) const { return mix32(j * 0x85ebca6bU + k1) & 0xffffffU; }
+    __device__ __forceinline__ bool keep(uint32_t a, uint32_t b) const { return __umul24(a, b) >= thr; }
 };
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 // d/dx silu(x) = s*(1 + x*(1-s)), s = sigmoid(x)
