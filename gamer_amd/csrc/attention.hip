@@ -184,8 +184,7 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
               const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
               const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
               int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-              float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int pair, const int qtile,
-              const int dbg) {
+              float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int pair, const int qtile) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
     __shared__ __attribute__((aligned(16))) float Ks[2][32 * KLD];
@@ -288,11 +287,11 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
         const int j0 = jt * 32;
         const bool have_next = jt + 1 < n_iter;
         const bool have_next2 = jt + 2 < n_iter;
-        if (have_next2 && !(dbg & 1)) {
+        if (have_next2) {
             load_tile32(kbase, ldk, j0 + 64, S, tid, rk);
             rmeta = key_meta_load<DROP>(klb, j0 + 64, S, w, lane, rng);
         }
-        if (have_next && !(dbg & 1)) load_tile32(vbase, ldv, j0 + 32, S, tid, rv);
+        if (have_next) load_tile32(vbase, ldv, j0 + 32, S, tid, rv);
 
         const bool beyond = j0 > wave_q_hi;                // every key of the tile is in every row's future
         const bool beyond_next = (j0 + 32) > wave_q_hi;
@@ -387,12 +386,12 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
             for (int i = 0; i < 16; ++i) st_cur[i] = init;
             if ((jt + 1) & 1) { GAMER_QK_TILE(st_cur, 1) } else { GAMER_QK_TILE(st_cur, 0) }
         }
-        if (have_next2 && !(dbg & 4)) {
+        if (have_next2) {
             store_tile32<KLD>(Ks[jt & 1], tid, rk, S - (j0 + 64));   // K(jt) is dead: its scores were taken last iteration
             key_meta_store(kms[(jt + 2) % 3], w, lane, rmeta);
         }
-        if (have_next && !(dbg & 4)) store_tile32<64>(Vs[(jt + 1) & 1], tid, rv, S - (j0 + 32));
-        if (!(dbg & 2)) __syncthreads();
+        if (have_next) store_tile32<64>(Vs[(jt + 1) & 1], tid, rv, S - (j0 + 32));
+        __syncthreads();
     }
 
     if (valid_q) {
@@ -428,7 +427,7 @@ attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ 
                 const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
                 const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
                 int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-                float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int dbg) {
+                float* __restrict__ o, float* __restrict__ lse, const RowOrder ro) {
     constexpr int R = (4 / G) * 32;
     const int n_tiles = (S + R - 1) / R;
     const WorkList wl(nbatch * nkv, n_tiles);
@@ -441,7 +440,7 @@ attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ 
         for (int pass = 0; pass < 2; ++pass) {                    // one inlined body (register pressure)
             if (pass == 1 && light == heavy) break;
             attn_fwd_tile<G, DROP, ORD>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed, o, lse,
-                                        ro, pair, pass == 0 ? heavy : light, dbg);
+                                        ro, pair, pass == 0 ? heavy : light);
         }
     }
 }
@@ -564,25 +563,33 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
             f32x16 st, dp;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { st[i] = neg_lse2; dp[i] = 0.f; }
+            // S^T = K Q^T and dP^T[key][query] = sum_d V[key][d] dO[query][d]: two independent accumulation chains,
+            // issued alternately (a single dependent chain of this MFMA runs 5-13 % below the pipe rate)
             if (!beyond) {
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
                     const float4 kf = *reinterpret_cast<const float4*>(&Ks[cur][r * KLD + 8 * kk + 4 * h]);
+                    const float4 vf = *reinterpret_cast<const float4*>(&Vs[cur][r * KLD + 8 * kk + 4 * h]);
                     st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[kk][0], st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, dof[kk][0], dp, 0, 0, 0);
                     st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[kk][1], st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, dof[kk][1], dp, 0, 0, 0);
                     st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kk][2], st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, dof[kk][2], dp, 0, 0, 0);
                     st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kk][3], st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, dof[kk][3], dp, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float4 vf = *reinterpret_cast<const float4*>(&Vs[cur][r * KLD + 8 * kk + 4 * h]);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, dof[kk][0], dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, dof[kk][1], dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, dof[kk][2], dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, dof[kk][3], dp, 0, 0, 0);
                 }
             }
-            // dP^T[key][query] = sum_d V[key][d] dO[query][d]
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const float4 vf = *reinterpret_cast<const float4*>(&Vs[cur][r * KLD + 8 * kk + 4 * h]);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, dof[kk][0], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, dof[kk][1], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, dof[kk][2], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, dof[kk][3], dp, 0, 0, 0);
-            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of the later phases below this point
             // u = mult * dP - delta  (mult = keep / (1 - p))
             if (DROP) {
                 int kwv[16];
@@ -636,6 +643,7 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
                 if (free_tile) ds_tile.template operator()<false, false>();
                 else ds_tile.template operator()<true, false>();
             }
+            __builtin_amdgcn_sched_barrier(0);
             dq_tile(st);
         }
         if (more) {
@@ -853,27 +861,34 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
             for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
             const float* Qh = sm.Qs[hg];
             const float* dOh = sm.dOs[hg];
+            // S[query][key] = sum_d Q[query][d] K[key][d] and dP[query][key] = sum_d dO[query][d] V[key][d]:
+            // two independent accumulation chains, issued alternately
             if (!before && !tile_all_empty) {
-                // S[query][key] = sum_d Q[query][d] K[key][d]
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
                     const float4 a4 = *reinterpret_cast<const float4*>(&Qh[r * KLD + 8 * kk + 4 * h]);
                     const float4 b4 = *reinterpret_cast<const float4*>(Kw + 8 * kk);
+                    const float4 c4 = *reinterpret_cast<const float4*>(&dOh[r * KLD + 8 * kk + 4 * h]);
+                    const float4 d4 = *reinterpret_cast<const float4*>(Vw + 8 * kk);
                     st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c4.x, d4.x, dp, 0, 0, 0);
                     st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c4.y, d4.y, dp, 0, 0, 0);
                     st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c4.z, d4.z, dp, 0, 0, 0);
                     st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c4.w, d4.w, dp, 0, 0, 0);
                 }
-            }
-            // dP[query][key] = sum_d dO[query][d] V[key][d]
+            } else {
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const float4 a4 = *reinterpret_cast<const float4*>(&dOh[r * KLD + 8 * kk + 4 * h]);
-                const float4 b4 = *reinterpret_cast<const float4*>(Vw + 8 * kk);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, dp, 0, 0, 0);
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float4 c4 = *reinterpret_cast<const float4*>(&dOh[r * KLD + 8 * kk + 4 * h]);
+                    const float4 d4 = *reinterpret_cast<const float4*>(Vw + 8 * kk);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c4.x, d4.x, dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c4.y, d4.y, dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c4.z, d4.z, dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(c4.w, d4.w, dp, 0, 0, 0);
+                }
             }
             // per element (query = register, key = lane):  P -> st (for dV, 1/(1-p) applied at the end),
             //                                               dS -> dp (for dK)
@@ -1082,8 +1097,7 @@ static int launch_fwd(const float* q, int ldq, const float* k, int ldk, const fl
     dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
 #define GAMER_LAUNCH_FWD(DROPV, ORDV)                                                                              \
     hipLaunchKernelGGL((attn_fwd_kernel<G, DROPV, ORDV>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, \
-                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, dbg)
-    static const int dbg = getenv("GAMER_ATTN_DBG") ? atoi(getenv("GAMER_ATTN_DBG")) : 0;   // timing experiments only
+                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro)
     if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD(true, true); else GAMER_LAUNCH_FWD(true, false); }
     else { if (ro.perm) GAMER_LAUNCH_FWD(false, true); else GAMER_LAUNCH_FWD(false, false); }
 #undef GAMER_LAUNCH_FWD

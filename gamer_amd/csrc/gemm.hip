@@ -305,7 +305,7 @@ gemm_f32_kernel(const GemmParams p) {
                 mfma_tile(smem);
             }
         } else {
-        fast_load();
+            fast_load();
             store_tile(smem);
             __syncthreads();
             for (int kt = 0; kt < nkt; ++kt) {
@@ -321,7 +321,7 @@ gemm_f32_kernel(const GemmParams p) {
                 __syncthreads();
                 if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[3] += t1 - t0; __builtin_amdgcn_sched_barrier(0); }
             }
-    }
+        }
     } else {
         if (NBUF == 1) {
             if (nkt > 0) load_tile(kbeg);

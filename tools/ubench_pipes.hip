@@ -11,14 +11,33 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-enum Role { IDLE = 0, MFMA32 = 1, VALU = 2, MFMABF = 3, MIXED = 4, MIXEDBF = 5 };
+enum Role { IDLE = 0, MFMA32 = 1, VALU = 2, MFMABF = 3, MIXED = 4, MIXEDBF = 5, CHAIN1 = 6, CHAIN2 = 7 };
 
 __global__ void __launch_bounds__(512) pipes(int role_lo, int role_hi, int iters, int valu_per_mfma, float* out) {
     const int w = threadIdx.x >> 6;
     const int role = w < 4 ? role_lo : role_hi;
     const float x = (float)(threadIdx.x & 7) * 0.25f + 1.f;
     if (role == IDLE) return;
-    if (role == MFMA32) {
+    if (role == CHAIN1 || role == CHAIN2) {
+        // dependent accumulation chains: 4 MFMAs per iteration on one (CHAIN1) or two (CHAIN2) accumulators
+        f32x16 a0 = {0}, a1 = {0};
+        for (int i = 0; i < iters; ++i) {
+            if (role == CHAIN1) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a0, 0, 0, 0);
+            } else {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a1, 0, 0, 0);
+            }
+        }
+        float s = 0.f;
+        for (int i = 0; i < 16; ++i) s += a0[i] + a1[i];
+        if (s == 12345.f) out[threadIdx.x] = s;
+    } else if (role == MFMA32) {
         f32x16 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
         for (int i = 0; i < iters; ++i) {
             a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a0, 0, 0, 0);
@@ -126,6 +145,10 @@ int main() {
         {"VALU x1 wave/SIMD (32*it v_fma)", VALU, IDLE, 0},
         {"VALU x2 waves/SIMD", VALU, VALU, 0},
         {"fp32 MFMA wave + VALU wave", MFMA32, VALU, 0},
+        {"fp32 MFMA 1 dependent chain, 1 wave/SIMD", CHAIN1, IDLE, 0},
+        {"fp32 MFMA 1 dependent chain, 2 waves/SIMD", CHAIN1, CHAIN1, 0},
+        {"fp32 MFMA 2 chains, 1 wave/SIMD", CHAIN2, IDLE, 0},
+        {"fp32 MFMA 2 chains, 2 waves/SIMD", CHAIN2, CHAIN2, 0},
         {"bf16 MFMA x1 wave/SIMD", MFMABF, IDLE, 0},
         {"bf16 MFMA x2 waves/SIMD", MFMABF, MFMABF, 0},
         {"bf16 MFMA wave + VALU wave", MFMABF, VALU, 0},
