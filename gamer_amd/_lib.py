@@ -60,7 +60,7 @@ _SIGNATURES = {
     "gamer_qknorm_rope_fwd": [P, I, I, I, I, P, P, F, P, P, P, P, P, P, P, P, P],
     "gamer_qknorm_rope_bwd": [P, P, P, I, I, I, I, P, P, F, P, P, P, P, P, I, P, P, P, P, P, P, P],
     "gamer_attn_row_order": [P, I, I, P, P, P, P],
-    "gamer_attn_fwd": [P, I, P, I, P, I, P, P, P, P, I, I, I, I, F, F, U, P, P, P, P, P, P],
+    "gamer_attn_fwd": [P, I, P, I, P, I, P, P, P, P, I, I, I, I, F, F, U, P, P, P, P, P, I, P],
     "gamer_attn_bwd": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, P, P, P],
     "gamer_residual_dropout_fwd": [P, P, P, I, I, F, U, P, P],
     "gamer_residual_dropout_bwd": [P, P, I, I, F, U, P, P],
@@ -73,6 +73,8 @@ _SIGNATURES = {
     "gamer_sumsq": [P, L, P, I, P],
     "gamer_adamw": [P, P, P, P, L, L, F, F, F, F, F, I, F, F, P, I, P, P],
     "gamer_fill_f32": [P, L, F, P],
+    "gamer_trie_logprobs": [P, L, P, P, P, P, P, I, I, P, P],
+    "gamer_trie_advance": [P, P, P, P, P, I, P, P],
 }
 
 

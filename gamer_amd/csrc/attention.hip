@@ -184,7 +184,8 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
               const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
               const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
               int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-              float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int pair, const int qtile) {
+              float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int pair, const int qtile,
+              const int uspan) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
     __shared__ __attribute__((aligned(16))) float Ks[2][32 * KLD];
@@ -244,7 +245,11 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
     }
     const bool block_has_empty = __syncthreads_or(my_empty ? 1 : 0) != 0;
     const int n_iter = block_has_empty ? n_all : n_causal;
-    const float invS = 1.f / (float)S;
+    // An empty row is uniform over my_span keys: all S in training (uspan = S); when an evaluation loop re-runs
+    // the whole sequence, over the keys that existed when the reference's cached decode computed the row
+    // (uspan = prompt length for prompt rows, i + 1 for generated rows; model.py:603-617)
+    const int my_span = min(S, max(uspan, iq + 1));
+    const float invS = 1.f / (float)my_span;
     const AttnDropout rng(p_drop, seed);
     const uint32_t aw = DROP ? rng.row_word((uint32_t)(((int64_t)b * nq + head) * S + iqc)) : 0u;
 
@@ -298,6 +303,7 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
         if (!(beyond && !wave_has_empty)) {
             const KeyMeta& km = kms[jt % 3];
             const float* Vc = Vs[jt & 1];
+            const bool full_span = (j0 + 32 <= uspan) || uspan >= S;   // every key of the tile is inside every span
             // O^T[d][query] += sum_key V[key][d] * P[query][key]   (rows of V past the sequence end are zero).
             // Called at the end of every variant below so that each one is a straight-line path (a join in
             // front of the MFMAs costs 16 register copies per tile, and VALU time is not hidden here).
@@ -342,7 +348,10 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     float pe = __builtin_amdgcn_exp2f(st_cur[reg]);            // masked -> exp2(-inf) = 0
-                    if (EMPTYSEL) pe = my_empty ? 1.f : pe;
+                    if (EMPTYSEL) {
+                        const float one = (full_span || (j0 + rowmap(reg, h) < my_span)) ? 1.f : 0.f;
+                        pe = my_empty ? one : pe;
+                    }
                     rowsum += pe;
                     st_cur[reg] = pe;
                 }
@@ -358,7 +367,7 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                 pv_tile();
             };
             if (wave_all_empty) {
-                // every row of the wave is an empty row: P = keep / S, no scores, no softmax state
+                // every row of the wave is an empty row: P = keep / span, no scores, no softmax state
                 if (DROP) {
                     int kwv[16];
                     read_key_quads(reinterpret_cast<const int32_t*>(km.kw), h, kwv);
@@ -367,6 +376,10 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                 } else {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) st_cur[reg] = 1.f;
+                }
+                if (!full_span) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) st_cur[reg] = (j0 + rowmap(reg, h) < my_span) ? st_cur[reg] : 0.f;
                 }
                 pv_tile();
             } else if (wave_has_empty) {
@@ -427,7 +440,7 @@ attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ 
                 const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
                 const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
                 int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-                float* __restrict__ o, float* __restrict__ lse, const RowOrder ro) {
+                float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int uspan) {
     constexpr int R = (4 / G) * 32;
     const int n_tiles = (S + R - 1) / R;
     const WorkList wl(nbatch * nkv, n_tiles);
@@ -440,7 +453,7 @@ attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ 
         for (int pass = 0; pass < 2; ++pass) {                    // one inlined body (register pressure)
             if (pass == 1 && light == heavy) break;
             attn_fwd_tile<G, DROP, ORD>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed, o, lse,
-                                        ro, pair, pass == 0 ? heavy : light);
+                                        ro, pair, pass == 0 ? heavy : light, uspan);
         }
     }
 }
@@ -1092,12 +1105,12 @@ attn_row_order_kernel(const int32_t* __restrict__ row_empty, int S, int32_t* __r
 template <int G>
 static int launch_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl,
                       const int32_t* ql, const int32_t* row_empty, int B, int S, int nq, int nkv, float scale,
-                      float p_drop, uint64_t seed, float* o, float* lse, RowOrder ro, hipStream_t st) {
+                      float p_drop, uint64_t seed, float* o, float* lse, RowOrder ro, int uspan, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
 #define GAMER_LAUNCH_FWD(DROPV, ORDV)                                                                              \
     hipLaunchKernelGGL((attn_fwd_kernel<G, DROPV, ORDV>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, \
-                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro)
+                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, uspan)
     if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD(true, true); else GAMER_LAUNCH_FWD(true, false); }
     else { if (ro.perm) GAMER_LAUNCH_FWD(false, true); else GAMER_LAUNCH_FWD(false, false); }
 #undef GAMER_LAUNCH_FWD
@@ -1199,8 +1212,10 @@ extern "C" int gamer_attn_fwd(const float* q, int ldq, const float* k, int ldk, 
                               const int32_t* kl, const int32_t* ql, const int32_t* row_empty,
                               const int32_t* tile_empty, int B, int S, int nq, int nkv, float scale, float p_drop,
                               uint64_t seed, float* o, float* lse, const int32_t* row_perm, const int32_t* tile_kind,
-                              const int32_t* tile_maxpos, void* stream) {
+                              const int32_t* tile_maxpos, int uniform_len, void* stream) {
     (void)tile_empty;
+    GAMER_CHECK_ARG(uniform_len >= 0 && uniform_len <= S, "gamer_attn_fwd: uniform_len=%d outside 0..S", uniform_len);
+    const int uspan = uniform_len == 0 ? S : uniform_len;
     GAMER_CHECK_ARG(!row_perm || (tile_kind && tile_maxpos), "gamer_attn_fwd: row_perm needs tile_kind and tile_maxpos");
     const RowOrder ro{row_perm, tile_kind, tile_maxpos};
     int rc = check_attn_common("gamer_attn_fwd", q, k, v, kl, row_empty, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
@@ -1208,9 +1223,9 @@ extern "C" int gamer_attn_fwd(const float* q, int ldq, const float* k, int ldk, 
     GAMER_CHECK_ARG(o && lse && aligned16(o), "gamer_attn_fwd: null/unaligned output");
     hipStream_t st = (hipStream_t)stream;
     switch (nq / nkv) {
-        case 1: return launch_fwd<1>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st);
-        case 2: return launch_fwd<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st);
-        default: return launch_fwd<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st);
+        case 1: return launch_fwd<1>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, uspan, st);
+        case 2: return launch_fwd<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, uspan, st);
+        default: return launch_fwd<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, uspan, st);
     }
 }
 

@@ -286,16 +286,24 @@ class Engine:
 
     # ------------------------------------------------------------------------------------------
     def forward(self, input_ids, attention_mask=None, actions=None, labels=None, num_items_in_batch=None,
-                train: bool = False, dropout: Optional[bool] = None):
+                train: bool = False, dropout: Optional[bool] = None, act_zero_col: Optional[int] = None,
+                uniform_len: int = 0):
         """Returns (loss or None, logits view [B,S,V]).  With labels the logits are divided by the
         temperature in place, as the reference does (model.py:913).  The view aliases a workspace
         buffer: backward() overwrites it with d(logits), the next forward() with new logits.  ``train`` keeps every activation
-        needed by backward(); ``dropout`` defaults to ``train``."""
+        needed by backward(); ``dropout`` defaults to ``train``.
+
+        Evaluation only (gamer_amd/decode.py re-runs the whole sequence every generation step): ``act_zero_col``
+        is the column of the prompt's final behaviour token, which the reference's router gives action index 0
+        when the prompt has 5n+1 tokens (router.py:160-163) and which stays that way in its K/V cache;
+        ``uniform_len`` is the prompt length (see gamer_attn_fwd in include/gamer_hip.h)."""
         cfg = self.cfg
         B, S = input_ids.shape
-        if S % cfg.num_positions != 0:
+        if train and S % cfg.num_positions != 0:
             raise ValueError(f"sequence length {S} is not a multiple of num_positions={cfg.num_positions} "
                              "(the router assumes item-aligned sequences, router.py:78-81)")
+        if train and (act_zero_col is not None or uniform_len not in (0, S)):
+            raise ValueError("act_zero_col / uniform_len are evaluation-only options")
         T, H = B * S, cfg.hidden_size
         nq, nkv, dh, I, E = (cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size,
                              cfg.num_experts)
@@ -316,6 +324,8 @@ class Engine:
         r = ws.router
         r["bad_token"].zero_()
         ops.router_fwd(ids, am, act, self.lut, cfg.num_positions, cfg.pad_token_id, cfg.eos_token_id, r)
+        if act_zero_col is not None:
+            r["act_idx"][:, act_zero_col] = 0
         ops.expert_lists(r["expert"], E, ws.perm, ws.slot, ws.offsets, ws.work)
         if cfg.cross_attention_decoder:
             ops.attn_row_order(r["empty_cross"], *ws.cross_order)
@@ -331,7 +341,8 @@ class Engine:
             ops.linear_fwd(A["h1"], H, W.self_attn["qkv"], H, A["qkv"], QKV, T, QKV, H)
             ops.qknorm_rope_fwd(A["qkv"], S, nq, nkv, W.self_attn["qn"], W.self_attn["kn"], eps, cos, sin, A["q"], A["k"])
             ops.attn_fwd(A["q"], NQ, A["k"], NKV, A["qkv"][:, NQ + NKV:], QKV, r["kl_self"], None, r["empty_self"],
-                         r["tile_empty_self"], B, S, nq, nkv, scale, p_att, self._seed(l, 0), A["ao"], A["lse"])
+                         r["tile_empty_self"], B, S, nq, nkv, scale, p_att, self._seed(l, 0), A["ao"], A["lse"],
+                         uniform_len=uniform_len)
             # o_proj with the residual add + dropout fused into the GEMM epilogue (model.py:149,217)
             ops.gemm(A["ao"], NQ, 1, W.self_attn["o"], NQ, 1, xs[1], H, T, H, NQ, resid=xs[0], p_drop=p_res,
                      seed=self._seed(l, 1))
@@ -345,7 +356,7 @@ class Engine:
                                     bias_q=C["bq"], bias_k=C["bk"], bias_v=C["bv"], act_idx=r["act_idx"])
                 ops.attn_fwd(A["q_c"], NQ, A["k_c"], NKV, A["qkv_c"][:, NQ + NKV:], QKV, r["kl_cross"], r["ql_cross"],
                              r["empty_cross"], r["tile_empty_cross"], B, S, nq, nkv, scale, p_att, self._seed(l, 2),
-                             A["ao_c"], A["lse_c"], order=ws.cross_order)
+                             A["ao_c"], A["lse_c"], order=ws.cross_order, uniform_len=uniform_len)
                 ops.linear_fwd(A["ao_c"], NQ, C["o"], NQ, A["op_c"], H, T, H, NQ)
                 ops.linear_fwd(A["h2"], H, C["gate"], H, A["gate_c"], H, T, H, H)
                 ops.silu_gate_fwd(A["op_c"], A["gate_c"], t0)

@@ -162,11 +162,12 @@ def attn_row_order(row_empty, perm, tile_kind, tile_maxpos):
 
 
 def attn_fwd(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse,
-             order=None):
-    """order = (perm, tile_kind, tile_maxpos) from attn_row_order, or None for the natural row order."""
+             order=None, uniform_len=0):
+    """order = (perm, tile_kind, tile_maxpos) from attn_row_order, or None for the natural row order.
+    uniform_len: see include/gamer_hip.h (0 = training semantics)."""
     pm, tk, tm = order if order is not None else (None, None, None)
     call("gamer_attn_fwd", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(kl), ptr(ql), ptr(row_empty), ptr(tile_empty),
-         B, S, nq, nkv, scale, p_drop, seed, ptr(o), ptr(lse), ptr(pm), ptr(tk), ptr(tm), stream_ptr())
+         B, S, nq, nkv, scale, p_drop, seed, ptr(o), ptr(lse), ptr(pm), ptr(tk), ptr(tm), uniform_len, stream_ptr())
 
 
 def attn_bwd(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed,
@@ -228,3 +229,17 @@ def adamw(p, g, m, v, n_decay, lr, beta1, beta2, eps, weight_decay, step, max_no
 
 def fill(t, value):
     call("gamer_fill_f32", ptr(t), t.numel(), float(value), stream_ptr())
+
+
+# ---- evaluation path: trie-constrained beam-search scoring ---------------------------------------
+def trie_logprobs(logits2d, row_index, beam_score, node, child_start, child_tok, V, scores):
+    """scores[n] = log_softmax(logits2d[row_index[n], :V]) + beam_score[n] on the child tokens of trie node[n],
+    -inf elsewhere."""
+    N = row_index.numel()
+    call("gamer_trie_logprobs", ptr(logits2d), logits2d.stride(0), ptr(row_index), ptr(beam_score), ptr(node),
+         ptr(child_start), ptr(child_tok), N, V, ptr(scores), stream_ptr())
+
+
+def trie_advance(node, token, child_start, child_tok, child_node, out):
+    call("gamer_trie_advance", ptr(node), ptr(token), ptr(child_start), ptr(child_tok), ptr(child_node),
+         node.numel(), ptr(out), stream_ptr())

@@ -86,3 +86,61 @@ def make_batch(batch_size: int, n_items: int = 101, codebook: int = 256, num_beh
         "session_ids": session.contiguous(),
         "extended_session_ids": ext.contiguous(),
     }
+
+
+def make_catalogue(n_items: int, codebook: int = 256, seed: int = 7) -> torch.Tensor:
+    """``n_items`` distinct semantic-ID tuples [n_items, 4] (the item universe of an evaluation run)."""
+    g = torch.Generator().manual_seed(seed)
+    seen, rows = set(), []
+    while len(rows) < n_items:
+        c = tuple(torch.randint(0, codebook, (4,), generator=g).tolist())
+        if c not in seen:
+            seen.add(c)
+            rows.append(c)
+    return torch.tensor(rows, dtype=torch.int64)
+
+
+def item_tokens(codes: torch.Tensor, behavior: int, codebook: int = 256) -> torch.Tensor:
+    """[n,4] semantic codes -> [n,5] token ids ``<behavior_b><a><b><c><d>``."""
+    n = codes.shape[0]
+    tok = torch.empty(n, TOKENS_PER_ITEM, dtype=torch.int64)
+    tok[:, 0] = behavior_token(behavior, codebook)
+    for l in range(4):
+        tok[:, 1 + l] = N_SPECIAL + codebook * l + codes[:, l]
+    return tok
+
+
+def make_eval_batch(batch_size: int, max_his: int, catalogue: torch.Tensor, target_behavior: int, codebook: int = 256,
+                    num_behavior: int = 3, min_his: int = 1, seed: int = 1,
+                    behavior_probs: Optional[Sequence[float]] = None) -> Dict[str, torch.Tensor]:
+    """Evaluation prompts with the layout of ``DecoderOnlyTestCollator`` + ``test_single_behavior``
+    (ref:SeqRec/datasets/collator.py:149-207, ref:SeqRec/tasks/test_SMB_decoder.py:98-118): histories of
+    catalogue items, LEFT padded (ids with the pad id, actions with 100), followed by the target behaviour
+    token.  ``targets`` [B,4] are the semantic codes of the held-out item."""
+    g = torch.Generator().manual_seed(seed)
+    if behavior_probs is None:
+        behavior_probs = [1.0 / num_behavior] * num_behavior
+    probs = torch.tensor(behavior_probs, dtype=torch.float64)
+    lens = torch.randint(min_his, max_his + 1, (batch_size,), generator=g)
+    lens[0] = max_his
+    S = max_his * TOKENS_PER_ITEM + 1
+    ids = torch.full((batch_size, S), PAD_ID, dtype=torch.int64)
+    actions = torch.full((batch_size, S), 100, dtype=torch.int64)
+    mask = torch.zeros(batch_size, S, dtype=torch.int64)
+    targets = torch.empty(batch_size, 4, dtype=torch.int64)
+    for b in range(batch_size):
+        n = int(lens[b])
+        pick = torch.randint(0, catalogue.shape[0], (n + 1,), generator=g)
+        beh = torch.multinomial(probs, n, replacement=True, generator=g)
+        start = S - 1 - n * TOKENS_PER_ITEM
+        for i in range(n):
+            ids[b, start + 5 * i: start + 5 * i + 5] = item_tokens(catalogue[pick[i]][None], int(beh[i]), codebook)[0]
+            actions[b, start + 5 * i: start + 5 * i + 5] = int(beh[i])
+        ids[b, S - 1] = behavior_token(target_behavior, codebook)
+        actions[b, S - 1] = target_behavior
+        mask[b, start:] = 1
+        targets[b] = catalogue[pick[n]]
+    pos = torch.arange(S)[None, :].expand(batch_size, S)
+    return {"input_ids": ids, "attention_mask": mask, "actions": actions, "targets": targets,
+            "session_ids": torch.where(mask.bool(), pos // TOKENS_PER_ITEM, torch.zeros_like(ids)),
+            "extended_session_ids": torch.where(mask.bool(), pos, torch.zeros_like(ids))}

@@ -178,6 +178,10 @@ int gamer_qknorm_rope_bwd(const float* qkv, const float* dq_rot, const float* dk
  *   dropout on the probabilities: p_drop, seed (attention_dropout, model.py:139)
  *   row_perm/tile_kind/tile_maxpos (all NULL = natural order): query-row order from
  *   gamer_attn_row_order; it only changes which rows share a wave, never the result.
+ *   uniform_len (fwd only; 0 or S = training semantics): evaluation by re-running the whole sequence each
+ *   generation step.  In the reference's cached decode an empty row is uniform over the keys that existed
+ *   when the row was computed (model.py:603-617), so row i spans max(uniform_len, i+1) keys; pass the
+ *   prompt length.
  * bwd: delta[b,h,i] = dO.O (written by the dq kernel), then dq and dk/dv kernels, no atomics.
  * ---------------------------------------------------------------------------------------- */
 /* Stable partition of every sequence's query rows: rows with an allowed key first (ascending position),
@@ -192,7 +196,7 @@ int gamer_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float
                    const int32_t* tile_empty,
                    int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                    float* o, float* lse, const int32_t* row_perm, const int32_t* tile_kind,
-                   const int32_t* tile_maxpos, void* stream);
+                   const int32_t* tile_maxpos, int uniform_len, void* stream);
 int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                    const float* o, const float* d_o, const float* lse,
                    const int32_t* kl, const int32_t* ql, const int32_t* row_empty,
@@ -254,6 +258,24 @@ int gamer_adamw(float* p, const float* g, float* m, float* v, int64_t n, int64_t
                 float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                 float max_norm, float grad_scale, const float* partial, int n_partial,
                 float* norm_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Evaluation path: trie-constrained beam-search scoring.
+ * Replaces, per generation step, log_softmax(next_token_logits) + PrefixConstrainedLogitsProcessor with
+ * the reference's item Trie (ref:SeqRec/generation/trie.py:5-104; call sites
+ * ref:SeqRec/tasks/test_SMB_decoder.py:120,470-500; HF generation/logits_process.py
+ * PrefixConstrainedLogitsProcessor).  The trie is a CSR array: node 0 is the root, the children of node x are
+ * edges child_start[x] .. child_start[x+1]-1 with token child_tok[e] and target node child_node[e].
+ *   gamer_trie_logprobs: scores[n][0..V) = -inf, then for every child token of node[n]:
+ *       scores[n][tok] = logits[row_index[n]][tok] - logsumexp(logits[row_index[n]][0..V)) + beam_score[n]
+ *       (node[n] < 0: nothing allowed, what Trie.get returns for an unknown prefix)
+ *   gamer_trie_advance:  next[n] = child of node[n] along token[n], or -1
+ * ---------------------------------------------------------------------------------------- */
+int gamer_trie_logprobs(const float* logits, int64_t ld, const int32_t* row_index, const float* beam_score,
+                        const int32_t* node, const int32_t* child_start, const int32_t* child_tok, int N, int V,
+                        float* scores, void* stream);
+int gamer_trie_advance(const int32_t* node, const int64_t* token, const int32_t* child_start,
+                       const int32_t* child_tok, const int32_t* child_node, int N, int32_t* next, void* stream);
 
 /* misc */
 int gamer_fill_f32(float* p, int64_t n, float value, void* stream);

@@ -1,0 +1,119 @@
+"""CPU restatement of the evaluation path (TEST INFRASTRUCTURE ONLY - never imported by gamer_amd/).
+
+* ``ItemTrie``: ref:SeqRec/generation/trie.py:5-104 with ``prefix_allowed_tokens_fn_by_last_token``
+  (:90-104) as test_SMB_decoder.py:470-500 builds it per behaviour: the allowed next tokens are the children of
+  the trie node reached by the tokens generated since the prompt's last item.
+* ``beam_search``: transformers ``GenerationMixin._beam_search`` (third party, pinned 4.51.0 upstream, 5.15.0
+  executed for the fixture) for the call of test_SMB_decoder.py:163-180: ``num_beams`` beams, ``max_new_tokens``
+  steps, no EOS can be produced (the trie never allows it), ``length_penalty`` 1, ``early_stopping`` True:
+      log_probs = log_softmax(logits[:, -1]);  disallowed -> -inf;  + running score;
+      top 2*num_beams over beams x vocab;  running beams = best num_beams;  at the last step the best num_beams
+      candidates are the finished hypotheses with score = sum_logprob / max_new_tokens.
+  The model is re-run on the whole sequence every step (no cache), with the two things a cache freezes passed
+  explicitly: the prompt's last token keeps action index 0 (``act_zero_col``) and an "empty" row stays uniform
+  over the keys that existed when it was computed (``uniform_len``).  That is equivalent to the reference's cached
+  decode (model.py:573-630, 691-741; router.py:83-97) except for ONE reference defect that is deliberately not
+  reproduced: the reference keeps the cross-attention K/V cache on the module (model.py:569, 785, 844-860) and HF
+  only reorders ``past_key_values``, so after a beam re-ordering the cross cache rows of GENERATED positions belong
+  to other beams.  Those keys are masked for every query except "empty" rows (no lower-level key in the prompt),
+  whose uniform attention then averages V rows of the wrong beam.  Rows with a non-empty mask are unaffected.
+* ``ranking``: ref:SeqRec/evaluation/ranking.py:5-90 on token tuples instead of decoded strings.
+
+Pinned by tests/golden/decode_small.npz (oracle/make_golden_decode.py runs the real reference).
+"""
+import math
+from typing import Dict, List, Sequence
+
+import torch
+
+from . import qwen3multi_oracle as orc
+
+
+class ItemTrie:
+    def __init__(self, sequences: Sequence[Sequence[int]]):
+        self.root: Dict[int, dict] = {}
+        for seq in sequences:
+            d = self.root
+            for t in seq:
+                d = d.setdefault(int(t), {})
+
+    def get(self, prefix: Sequence[int]) -> List[int]:
+        d = self.root
+        for t in prefix:
+            if int(t) not in d:
+                return []
+            d = d[int(t)]
+        return list(d.keys())
+
+
+def beam_search(sd, cfg, input_ids, attention_mask, actions, trie: ItemTrie, num_beams: int, max_new_tokens: int = 4,
+                forward=None):
+    """Returns (sequences [B*num_beams, L0+max_new_tokens], sequences_scores [B*num_beams]), best beam first."""
+    B, L0 = input_ids.shape
+    V = sd["model.embed_tokens.weight"].shape[0]
+    K = 2 * num_beams
+    seqs = input_ids[:, None, :].expand(B, num_beams, L0).clone()
+    run_scores = torch.zeros(B, num_beams)
+    run_scores[:, 1:] = -1e9
+    am0, act0 = attention_mask, actions
+    fin_seq, fin_score = None, None
+    for step in range(max_new_tokens):
+        cur = L0 + step
+        flat = seqs.reshape(B * num_beams, cur)
+        am = torch.cat([am0, torch.ones(B, step, dtype=am0.dtype)], 1).repeat_interleave(num_beams, 0)
+        # generated tokens belong to the target item: same behaviour level as its behaviour token
+        act = torch.cat([act0, act0[:, -1:].expand(B, step)], 1).repeat_interleave(num_beams, 0)
+        if forward is None:
+            with torch.no_grad():
+                logits = orc.forward(sd, cfg, flat, am, act, act_zero_col=L0 - 1, uniform_len=L0)["logits"][:, -1].float()
+        else:
+            logits = forward(flat, am, act, L0 - 1)
+        logp = torch.log_softmax(logits, -1)
+        masked = torch.full_like(logp, -math.inf)
+        for n in range(B * num_beams):
+            allowed = trie.get(flat[n, L0 - 1:].tolist())
+            if allowed:
+                masked[n, allowed] = logp[n, allowed]
+        cand = (masked.view(B, num_beams, V) + run_scores[:, :, None]).view(B, num_beams * V)
+        top_s, top_i = torch.topk(cand, K)
+        beam_i, tok = top_i // V, top_i % V
+        cand_seq = torch.cat([torch.gather(seqs, 1, beam_i[:, :, None].expand(B, K, cur)), tok[:, :, None]], 2)
+        if step == max_new_tokens - 1:
+            fin_seq, fin_score = cand_seq[:, :num_beams], top_s[:, :num_beams] / max_new_tokens
+        seqs, run_scores = cand_seq[:, :num_beams].clone(), top_s[:, :num_beams].clone()
+    return fin_seq.reshape(B * num_beams, -1), fin_score.reshape(-1)
+
+
+# ---- ranking.py ------------------------------------------------------------------------------
+def topk_results(pred_items, scores, targets, k: int):
+    """pred_items [B*k, n] token ids, scores [B*k], targets [B, n] -> per sample the hit list ordered by score."""
+    out = []
+    for b in range(len(targets)):
+        rows = [(tuple(int(t) for t in pred_items[b * k + j]), float(scores[b * k + j])) for j in range(k)]
+        rows.sort(key=lambda x: x[1], reverse=True)
+        tgt = tuple(int(t) for t in targets[b])
+        out.append([1 if r[0] == tgt else 0 for r in rows])
+    return out
+
+
+def metrics(topk, names):
+    """Sums over the batch (the reference divides by the sample count at the end), one target per sample."""
+    res = {}
+    for m in names:
+        kind, k = m.lower().split("@")
+        k = int(k)
+        if kind == "hit":
+            res[m] = float(sum(1 for row in topk if sum(row[:k]) > 0))
+        elif kind == "recall":
+            res[m] = float(sum(min(sum(row[:k]), 1) for row in topk))
+        elif kind == "ndcg":
+            tot = 0.0
+            for row in topk:
+                for j, r in enumerate(row[:k]):
+                    if r == 1:
+                        tot += 1.0 / math.log(j + 2, 2)
+                        break
+            res[m] = tot
+        else:
+            raise NotImplementedError(m)
+    return res

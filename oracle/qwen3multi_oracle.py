@@ -144,12 +144,17 @@ def _dropout(x, p, training):
     return F.dropout(x, p, training) if (training and p > 0) else x
 
 
-def attention(h, sd, prefix, ok, cfg: OracleConfig, cos, sin, act_idx=None, training=False):
+def attention(h, sd, prefix, ok, cfg: OracleConfig, cos, sin, act_idx=None, training=False, uniform_len=None):
     """Qwen3MultiAttention.forward (model.py:75-150) with the additive finfo.min mask folded in.
 
     A query row with no allowed key ends up with every masked score equal to finfo.min, so the
     softmax is uniform over all S keys (future and padded ones included) while autograd still
     passes d(score) through the addition; ``s - s.detach()`` reproduces exactly that.
+
+    ``uniform_len`` (evaluation by re-running the whole sequence): in the reference's cached generation an
+    empty row is uniform over the keys that existed WHEN THE ROW WAS COMPUTED - the prompt length L0 for a
+    prompt row, i+1 for a generated row i (model.py:603-617: the cached last mask row grows by one masked
+    key per step) - so row i spans max(uniform_len, i+1) keys.  None = all S keys (training).
     """
     B, S, _ = h.shape
     nq, nkv, dh = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
@@ -171,6 +176,9 @@ def attention(h, sd, prefix, ok, cfg: OracleConfig, cos, sin, act_idx=None, trai
     okb = ok[:, None, :, :]
     s_norm = s.masked_fill(~okb, float("-inf"))
     s_empty = s - s.detach()
+    if uniform_len is not None:
+        span = torch.clamp(torch.arange(S) + 1, min=int(uniform_len))                  # [S] keys seen by row i
+        s_empty = s_empty.masked_fill(torch.arange(S)[None, :] >= span[:, None], float("-inf"))
     s_eff = torch.where(empty[:, None, :, None], s_empty, s_norm)
     p = torch.softmax(s_eff, dim=-1)
     p = _dropout(p, cfg.attention_dropout, training)
@@ -203,8 +211,14 @@ def sparse_mlp(h, sd, prefix, pos_idx, beh_idx, cfg: OracleConfig, inject: bool,
 
 def forward(sd: Dict[str, torch.Tensor], cfg: OracleConfig, input_ids, attention_mask, actions,
             labels=None, temperature: float = 1.0, num_items_in_batch: Optional[float] = None,
-            training: bool = False, return_hidden: bool = False):
+            training: bool = False, return_hidden: bool = False, act_zero_col: Optional[int] = None,
+            uniform_len: Optional[int] = None):
     """Qwen3MultiWithTemperature.forward (model.py:928-1013).
+
+    ``act_zero_col``: evaluation prompts end with the target item's behaviour token (S = 5n+1); the reference's
+    router then looks up only n items (router.py:160-163 with cache_position) and that token gets action index 0,
+    which stays in the cross-attention K/V cache for the whole generation.  Passing the column reproduces it.
+    ``uniform_len``: see ``attention``.
 
     ``sd`` uses the reference's state-dict key names.  Returns a dict with ``logits`` (divided
     by the temperature when labels are given, as the reference's in-place ``logits /= T`` does),
@@ -215,6 +229,9 @@ def forward(sd: Dict[str, torch.Tensor], cfg: OracleConfig, input_ids, attention
         attention_mask = torch.ones_like(input_ids)
     dtype = sd["model.embed_tokens.weight"].dtype
     pos_idx, beh_idx, act_idx = router(input_ids, cfg)
+    if act_zero_col is not None:
+        act_idx = act_idx.clone()
+        act_idx[:, act_zero_col] = 0
     self_ok, cross_ok = mask_predicates(attention_mask, actions)
     cos, sin = rope_tables(S, cfg.head_dim, cfg.rope_theta, dtype)
     # nn.Embedding(vocab, H, padding_idx=pad) (model.py:263): the gather-side gradient of the pad row is dropped
@@ -226,11 +243,11 @@ def forward(sd: Dict[str, torch.Tensor], cfg: OracleConfig, input_ids, attention
         if return_hidden:
             hidden.append(x)
         h = rmsnorm(x, sd[lp + "input_layernorm.weight"], eps)
-        a = attention(h, sd, lp + "self_attn.", self_ok, cfg, cos, sin, None, training)
+        a = attention(h, sd, lp + "self_attn.", self_ok, cfg, cos, sin, None, training, uniform_len)
         x = x + _dropout(a, cfg.dropout_rate, training)
         if l in cfg.cross_attention_decoder:
             h = rmsnorm(x, sd[lp + "post_self_attention_layernorm.weight"], eps)
-            a = attention(h, sd, lp + "cross_attn.", cross_ok, cfg, cos, sin, act_idx, training)
+            a = attention(h, sd, lp + "cross_attn.", cross_ok, cfg, cos, sin, act_idx, training, uniform_len)
             x = x + _dropout(a, cfg.dropout_rate, training)
         h = rmsnorm(x, sd[lp + "post_cross_attention_layernorm.weight"], eps)
         m = sparse_mlp(h, sd, lp + "mlp.", pos_idx, beh_idx, cfg,

@@ -1,0 +1,181 @@
+"""Evaluation path: trie, beam search, ranking metrics.
+
+CPU part: the oracle's beam search (oracle/decode_oracle.py) against tests/golden/decode_small.npz, which holds
+what the REAL reference's ``generate`` returned (oracle/make_golden_decode.py) - as shipped, and with its
+module-level cross-attention cache re-ordered together with the beams.  The product's host logic
+(gamer_amd.decode.ItemTrie, gamer_amd.metrics) against the same fixture.
+GPU part: gamer_amd.decode.beam_search over the HIP engine against the fixture.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gamer_amd import metrics as gm, synthetic
+from gamer_amd.decode import ItemTrie
+from oracle import decode_oracle as dec, qwen3multi_oracle as orc
+
+FX = os.path.join(os.path.dirname(__file__), "golden", "decode_small.npz")
+
+
+def _load():
+    fx = np.load(FX)
+    meta = json.loads(str(fx["meta_json"]))
+    ocfg = orc.OracleConfig.from_dict(meta["config"])
+    sd = orc.init_state_dict(ocfg, seed=meta["weight_seed"])
+    for k, v in sd.items():
+        if v.dim() == 2:
+            sd[k] = v * meta["weight_scale"]
+    sd["model.embed_tokens.weight"][synthetic.PAD_ID] = 0
+    return fx, meta, ocfg, sd
+
+
+def _case(fx, tb):
+    t = lambda k: torch.from_numpy(fx[f"b{tb}_{k}"])
+    return t("input_ids"), t("attention_mask"), t("actions")
+
+
+def _empty_target_rows(am, act):
+    """Samples whose target row has no allowed cross-attention key (no kept key of a lower level)."""
+    lv = act[:, -1:]
+    return ~(((act[:, :-1] < lv) & (am[:, :-1] == 1)).any(1))
+
+
+def _check(seq, sc, fx, tb, tag, rows, beams, tol):
+    rs = torch.from_numpy(fx[f"b{tb}_sequences{tag}"]).view(-1, beams, seq.shape[-1])
+    rsc = torch.from_numpy(fx[f"b{tb}_scores{tag}"]).view(-1, beams)
+    seq, sc = seq.cpu().view(-1, beams, seq.shape[-1]), sc.cpu().double().view(-1, beams)
+    assert rows.any()
+    assert torch.equal(seq[rows], rs[rows]), f"behaviour {tb}{tag}: sequences differ"
+    err = float((sc[rows] - rsc[rows]).abs().max())
+    assert err < tol, f"behaviour {tb}{tag}: score error {err}"
+    return err
+
+
+@pytest.mark.parametrize("tb", [0, 1, 2])
+def test_oracle_beam_search_matches_reference_generate(tb):
+    fx, meta, ocfg, sd = _load()
+    beams, cb = meta["beams"], meta["codebook"]
+    ids, am, act = _case(fx, tb)
+    trie = dec.ItemTrie(synthetic.item_tokens(torch.from_numpy(fx["catalogue"]), tb, cb).tolist())
+    seq, sc = dec.beam_search(sd, ocfg, ids, am, act, trie, beams, 4)
+    empty = _empty_target_rows(am, act)
+    every = torch.ones_like(empty)
+    # with the reference's cross-attention cache re-ordered like past_key_values: every sample
+    _check(seq, sc, fx, tb, "_crossfix", every, beams, 2e-5)
+    # the reference as shipped: every sample whose target row can see a lower-level key
+    if (~empty).any():
+        _check(seq, sc, fx, tb, "", ~empty, beams, 2e-5)
+    if empty.any():
+        # ... and the defect is real: an empty target row moves the reference's own scores by ~1e-2
+        rs = torch.from_numpy(fx[f"b{tb}_scores"]).view(-1, beams)
+        rf = torch.from_numpy(fx[f"b{tb}_scores_crossfix"]).view(-1, beams)
+        assert float((rs[empty] - rf[empty]).abs().max()) > 1e-4
+        assert float((rs[~empty] - rf[~empty]).abs().max() if (~empty).any() else 0.0) < 1e-6
+
+
+def test_metrics_match_reference_ranking():
+    fx, meta, _, _ = _load()
+    beams, cb = meta["beams"], meta["codebook"]
+    for tb in range(meta["num_behavior"]):
+        seqs = torch.from_numpy(fx[f"b{tb}_sequences"])
+        scores = torch.from_numpy(fx[f"b{tb}_scores"])
+        tgt = synthetic.item_tokens(torch.from_numpy(fx[f"b{tb}_targets"]), tb, cb)[:, 1:]
+        targets = [[row.tolist()] for row in tgt]
+        topk = gm.get_topk_results(seqs[:, -4:].tolist(), scores.tolist(), targets, beams)
+        assert np.array_equal(np.array(topk, dtype=np.int8), fx[f"b{tb}_topk"])
+        res = gm.get_metrics_results(topk, meta["metrics"], targets)
+        np.testing.assert_allclose([res[m] for m in meta["metrics"]], fx[f"b{tb}_metrics"], rtol=0, atol=1e-12)
+    # several targets per sample (recall / ndcg normalisation, ranking.py:36-62)
+    topk = [[0, 1, 0, 1, 0], [0, 0, 0, 0, 0]]
+    targets = [[[1], [2], [3]], [[4]]]
+    res = gm.get_metrics_results(topk, ["hit@5", "recall@5", "ndcg@5"], targets)
+    assert res["hit@5"] == 1.0 and abs(res["recall@5"] - 2 / 3) < 1e-12
+    ideal = sum(1 / np.log2(j + 2) for j in range(3))
+    assert abs(res["ndcg@5"] - (1 / np.log2(3) + 1 / np.log2(5)) / ideal) < 1e-12
+
+
+def test_item_trie_host_logic():
+    cat = synthetic.make_catalogue(40, 8, seed=5)
+    items = synthetic.item_tokens(cat, 1, 8).tolist()
+    trie, ref = ItemTrie(items, device="cpu"), dec.ItemTrie(items)
+    g = torch.Generator().manual_seed(0)
+    for _ in range(200):
+        it = items[int(torch.randint(0, len(items), (1,), generator=g))]
+        n = int(torch.randint(0, 6, (1,), generator=g))
+        prefix = it[:n]
+        if int(torch.randint(0, 4, (1,), generator=g)) == 0 and n > 0:
+            prefix = prefix[:-1] + [3]                       # a token no item has there
+        assert trie.get(prefix) == ref.get(prefix)
+    # CSR consistency: the children of every node are exactly its dict
+    cs, ct, cn = trie.child_start.tolist(), trie.child_tok.tolist(), trie.child_node.tolist()
+    for x, d in enumerate(trie.nodes):
+        assert dict(zip(ct[cs[x]:cs[x + 1]], cn[cs[x]:cs[x + 1]])) == d
+    assert trie.get(items[0]) == []                          # a complete item has no continuation
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_trie_kernels_against_host():
+    from gamer_amd import ops
+    dev = "cuda"
+    cat = synthetic.make_catalogue(60, 8, seed=9)
+    items = synthetic.item_tokens(cat, 2, 8).tolist()
+    trie = ItemTrie(items, device=dev)
+    V, N = synthetic.vocab_size(8, 3), 37
+    g = torch.Generator().manual_seed(1)
+    prefixes = []
+    for n in range(N):
+        it = items[int(torch.randint(0, len(items), (1,), generator=g))]
+        prefixes.append(it[:int(torch.randint(0, 5, (1,), generator=g))])
+    node = torch.zeros(N, dtype=torch.int32, device=dev)
+    for depth in range(4):                                   # walk every row to its prefix with the kernel
+        tok = torch.tensor([p[depth] if depth < len(p) else -1 for p in prefixes], device=dev)
+        nxt = torch.empty_like(node)
+        ops.trie_advance(node, tok, trie.child_start, trie.child_tok, trie.child_node, nxt)
+        live = torch.tensor([depth < len(p) for p in prefixes], device=dev)
+        node = torch.where(live, nxt, node)
+    node[5] = -1                                             # unknown prefix: nothing allowed
+    ld = 64
+    logits = torch.randn(3 * N, ld, generator=g).to(dev) * 3
+    rows = torch.randperm(3 * N, generator=g)[:N].to(dev, torch.int32)
+    beam = torch.randn(N, generator=g).to(dev)
+    out = torch.empty(N, V, device=dev)
+    ops.trie_logprobs(logits, rows, beam, node, trie.child_start, trie.child_tok, V, out)
+    ref = torch.full((N, V), float("-inf"), dtype=torch.float64)
+    lp = torch.log_softmax(logits.cpu().double()[rows.cpu().long(), :V], -1) + beam.cpu().double()[:, None]
+    for n in range(N):
+        if n != 5:
+            al = trie.get(prefixes[n])
+            ref[n, al] = lp[n, al]
+    got = out.cpu().double()
+    assert torch.equal(torch.isinf(got), torch.isinf(ref))
+    fin = ~torch.isinf(ref)
+    assert float((got[fin] - ref[fin]).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tb", [0, 1, 2])
+def test_engine_beam_search_matches_reference_generate(tb):
+    from gamer_amd.config import Qwen3MultiConfig
+    from gamer_amd.decode import beam_search
+    from gamer_amd.engine import Engine
+    fx, meta, ocfg, sd = _load()
+    beams, cb = meta["beams"], meta["codebook"]
+    cfg = Qwen3MultiConfig(**meta["config"])
+    eng = Engine(cfg, temperature=0.7)
+    eng.load_state_dict(sd)
+    ids, am, act = _case(fx, tb)
+    trie = ItemTrie(synthetic.item_tokens(torch.from_numpy(fx["catalogue"]), tb, cb).tolist())
+    seq, sc = beam_search(eng, ids, am, act, trie, beams, 4)
+    empty = _empty_target_rows(am, act)
+    _check(seq, sc, fx, tb, "_crossfix", torch.ones_like(empty), beams, 1e-4)
+    if (~empty).any():
+        _check(seq, sc, fx, tb, "", ~empty, beams, 1e-4)
+    # and the oracle on the same inputs, beam for beam
+    oseq, osc = dec.beam_search(sd, ocfg, ids, am, act, dec.ItemTrie(synthetic.item_tokens(
+        torch.from_numpy(fx["catalogue"]), tb, cb).tolist()), beams, 4)
+    assert torch.equal(seq.cpu(), oseq)
+    assert float((sc.cpu() - osc).abs().max()) < 1e-4
