@@ -50,6 +50,8 @@ class ItemTrie:
             start.append(len(tok))
         self.nodes = nodes
         self.n_items = len(sequences)
+        # tokens that end an item, plus the pad id (test_SMB_decoder.py:473-474)
+        self.last_tokens = {int(seq[-1]) for seq in sequences} | {4}
         i32 = dict(dtype=torch.int32, device=device)
         self.child_start = torch.tensor(start, **i32)
         self.child_tok = torch.tensor(tok if tok else [0], **i32)
@@ -62,6 +64,21 @@ class ItemTrie:
             if cur is None:
                 return []
         return list(self.nodes[cur].keys())
+
+
+def prefix_allowed_tokens(trie: ItemTrie):
+    """Callable with the signature of the reference's ``prefix_allowed_tokens_fn_by_last_token`` result
+    (trie.py:90-104) for host-side use; ``Qwen3MultiWithTemperature.generate`` takes the trie it carries."""
+    last_tokens = {seq_last for seq_last in trie.last_tokens}
+
+    def fn(batch_id: int, sentence) -> List[int]:
+        s = [int(t) for t in sentence]
+        i = len(s) - 1
+        while i >= 0 and s[i] not in last_tokens:
+            i -= 1
+        return trie.get(s[i + 1:])
+    fn.trie = trie
+    return fn
 
 
 @torch.no_grad()
@@ -91,13 +108,18 @@ def beam_search(engine, input_ids: torch.Tensor, attention_mask: torch.Tensor, a
     final = None
     for step in range(max_new_tokens):
         cur = L0 + step
-        flat = seqs.reshape(N, cur)
-        am = torch.cat([am0, am0.new_ones(B, step)], 1).repeat_interleave(nb, 0)
-        # generated tokens belong to the target item: same behaviour level as its behaviour token
-        act = torch.cat([act0, act0[:, -1:].expand(B, step)], 1).repeat_interleave(nb, 0)
-        engine.forward(flat, am, act, train=False, act_zero_col=L0 - 1, uniform_len=L0)
+        if step == 0:
+            # all beams of a sample hold the same prompt: run it once (HF runs num_beams copies)
+            engine.forward(ids0, am0, act0, train=False, act_zero_col=L0 - 1, uniform_len=L0)
+            rows = (torch.arange(N, device=dev, dtype=torch.int32) // nb) * cur + (cur - 1)
+        else:
+            flat = seqs.reshape(N, cur)
+            am = torch.cat([am0, am0.new_ones(B, step)], 1).repeat_interleave(nb, 0)
+            # generated tokens belong to the target item: same behaviour level as its behaviour token
+            act = torch.cat([act0, act0[:, -1:].expand(B, step)], 1).repeat_interleave(nb, 0)
+            engine.forward(flat, am, act, train=False, act_zero_col=L0 - 1, uniform_len=L0)
+            rows = torch.arange(N, device=dev, dtype=torch.int32) * cur + (cur - 1)
         ws = engine.ws
-        rows = torch.arange(N, device=dev, dtype=torch.int32) * cur + (cur - 1)
         ops.trie_logprobs(ws.logits, rows, run_scores.reshape(N).contiguous(), node, trie.child_start, trie.child_tok,
                           V, scores)
         top_s, top_i = torch.topk(scores.view(B, nb * V), K)

@@ -324,6 +324,10 @@ class Engine:
         r = ws.router
         r["bad_token"].zero_()
         ops.router_fwd(ids, am, act, self.lut, cfg.num_positions, cfg.pad_token_id, cfg.eos_token_id, r)
+        if act_zero_col is None and S % cfg.num_positions == 1:
+            # the reference's router counts (S + 3) // 5 items (router.py:160-163), so a trailing behaviour token
+            # - an evaluation prompt - gets action index 0
+            act_zero_col = S - 1
         if act_zero_col is not None:
             r["act_idx"][:, act_zero_col] = 0
         ops.expert_lists(r["expert"], E, ws.perm, ws.slot, ws.offsets, ws.work)

@@ -147,6 +147,25 @@ class Qwen3MultiWithTemperature(nn.Module):
         model.load_state_dict(sd)
         return model
 
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, actions=None, max_new_tokens: int = 4, num_beams: int = 1,
+                 num_return_sequences=None, prefix_allowed_tokens_fn=None, trie=None, **kwargs):
+        """The call of test_SMB_decoder.py:163-180: trie-constrained beam search, all beams returned best first.
+        ``trie`` is a ``gamer_amd.decode.ItemTrie`` (or pass ``prefix_allowed_tokens_fn=decode.prefix_allowed_tokens(trie)``,
+        which carries it); arbitrary Python callables are not supported - the constraint runs on the device.
+        Returns an object with ``.sequences`` [B*num_beams, L0+max_new_tokens] and ``.sequences_scores``."""
+        from . import decode
+        if trie is None:
+            trie = getattr(prefix_allowed_tokens_fn, "trie", None)
+        if trie is None:
+            raise NotImplementedError("generate() needs trie=ItemTrie(...) (constrained beam search of the SMB evaluation)")
+        if num_return_sequences not in (None, num_beams):
+            raise NotImplementedError("num_return_sequences must equal num_beams (what the evaluation task uses)")
+        if attention_mask is None or actions is None:
+            raise ValueError("generate() needs attention_mask and actions")
+        seqs, scores = decode.beam_search(self.engine, input_ids, attention_mask, actions, trie, num_beams, max_new_tokens)
+        return CausalLMOutput(sequences=seqs, sequences_scores=scores)
+
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
                 inputs_embeds=None, labels=None, use_cache=None, output_attentions=None, output_hidden_states=None,
                 cache_position=None, logits_to_keep=0, session_ids=None, extended_session_ids=None, actions=None,

@@ -91,6 +91,10 @@ def router(input_ids: torch.Tensor, cfg: OracleConfig):
         act[beh_tok == tok] = emb_id + 1
     act = act.clone()
     act[special] = 0
+    if S % P == 1:
+        # router.py:160-163 looks up (max(cache_position) + P - 1) // P = (S + 3) // 5 items: a trailing behaviour
+        # token (evaluation prompt) falls on the appended "EOS" slot of router.py:176-186 -> action index 0
+        act[:, -1] = 0
     beh = act.clone()
     beh[:, (t % P) == 0] = 0                  # router.py:139
     return pos, beh, act

@@ -179,3 +179,24 @@ def test_engine_beam_search_matches_reference_generate(tb):
         torch.from_numpy(fx["catalogue"]), tb, cb).tolist()), beams, 4)
     assert torch.equal(seq.cpu(), oseq)
     assert float((sc.cpu() - osc).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_evaluate_behavior_matches_reference_metrics():
+    """Behaviour 2 of the fixture: no empty target row, so the reference's own metrics apply unchanged."""
+    from gamer_amd.config import Qwen3MultiConfig
+    from gamer_amd.engine import Engine
+    from gamer_amd.evaluate import evaluate_behavior
+    fx, meta, ocfg, sd = _load()
+    tb, beams, cb = 2, meta["beams"], meta["codebook"]
+    eng = Engine(Qwen3MultiConfig(**meta["config"]), temperature=0.7)
+    eng.load_state_dict(sd)
+    ids, am, act = _case(fx, tb)
+    assert not _empty_target_rows(am, act).any()
+    tgt = synthetic.item_tokens(torch.from_numpy(fx[f"b{tb}_targets"]), tb, cb)[:, 1:]
+    batch = dict(input_ids=ids, attention_mask=am, actions=act, targets=[[row.tolist()] for row in tgt])
+    trie = ItemTrie(synthetic.item_tokens(torch.from_numpy(fx["catalogue"]), tb, cb).tolist())
+    # two batches (the same one twice): sums and sample counts accumulate
+    res = evaluate_behavior(eng, [batch, batch], trie, beams, meta["metrics"])
+    assert res["samples"] == 2 * ids.shape[0]
+    np.testing.assert_allclose([res[m] for m in meta["metrics"]], fx[f"b{tb}_metrics"] / ids.shape[0], atol=1e-12)
