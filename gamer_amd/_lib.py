@@ -75,6 +75,7 @@ _SIGNATURES = {
     "gamer_fill_f32": [P, L, F, P],
     "gamer_trie_logprobs": [P, L, P, P, P, P, P, I, I, P, P],
     "gamer_trie_advance": [P, P, P, P, P, I, P, P],
+    "gamer_attn_decode": [P, I, P, I, P, I, P, P, P, I, I, I, I, P, I, I, I, I, I, F, P, P],
 }
 
 

@@ -12,9 +12,11 @@ test_SMB_decoder.py:470-500): the same sequences in the same order and the same 
 * Beam bookkeeping follows transformers' ``GenerationMixin._beam_search`` for this call: top 2k of k*V
   candidates, the best k continue, the best k of the last step are the hypotheses, score = sum of log-probs /
   number of new tokens.  No EOS can be produced (the trie never allows it).
-* No K/V cache yet: the engine re-runs the whole sequence each step (4 steps).  The two things the reference's
-  cache freezes are passed explicitly (``act_zero_col``, ``uniform_len``; Engine.forward).  One reference defect
-  is NOT reproduced: its cross-attention cache lives on the module and is not re-ordered with the beams
+* K/V cache (``DecodeSession``): the prompt runs once per sample and its keys / values are stored once per sample
+  (the reference stores num_beams copies); a generation step pushes one token per beam through the layers and
+  ``gamer_attn_decode``.  ``use_cache=False`` re-runs the whole sequence each step instead; both give the same
+  beams.  The two things the reference's cache freezes are explicit (``act_zero_col``, ``uniform_len``;
+  Engine.forward).  One reference defect is NOT reproduced: its cross-attention cache lives on the module and is not re-ordered with the beams
   (model.py:569,785,844-860), which perturbs samples whose target row is "empty" (oracle/decode_oracle.py,
   tests/test_decode.py quantify it).
 """
@@ -81,12 +83,135 @@ def prefix_allowed_tokens(trie: ItemTrie):
     return fn
 
 
+class DecodeSession:
+    """K/V cache of one generation run + the single-token forward over it (model.py:118-121, 784-785).
+
+    The prompt is run once per SAMPLE (HF expands it to num_beams copies first) and its keys / values are kept
+    once per sample; only the generated positions are per beam.  ``step`` pushes one token per beam through the
+    layers with the ordinary row kernels (norms, GEMMs with M = B*num_beams rows, SwiGLU) - all new tokens of a
+    step sit at the same position, hence in the same position-routed expert - and ``gamer_attn_decode``."""
+
+    def __init__(self, engine, input_ids, attention_mask, actions, num_beams: int, max_new_tokens: int):
+        cfg, dev = engine.cfg, engine.device
+        self.eng, self.nb, self.tmax = engine, num_beams, max_new_tokens
+        self.B, self.L0 = input_ids.shape
+        B, L0, nb = self.B, self.L0, num_beams
+        self.N = N = B * nb
+        ids0 = input_ids.to(dev, torch.int64)
+        am0 = attention_mask.to(dev, torch.int64)
+        act0 = actions.to(dev, torch.int64)
+        nq, nkv, dh = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        self.NQ, self.NKV = nq * dh, nkv * dh
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.kp: Dict[Tuple[int, str], torch.Tensor] = {}
+        self.vp: Dict[Tuple[int, str], torch.Tensor] = {}
+
+        def sink(layer, kind, k, v):
+            self.kp[(layer, kind)] = k.clone()
+            self.vp[(layer, kind)] = v.contiguous()          # v is a column slice of the qkv buffer
+        engine.forward(ids0, am0, act0, train=False, act_zero_col=L0 - 1, uniform_len=L0, kv_sink=sink)
+        # last-row logits of every sample (copied: the workspace is reused)
+        self.prefill_logits = engine.ws.logits.view(B, L0, -1)[:, -1].clone()
+        # masks of the new rows: self = kept keys; cross = kept keys of a lower level than the target behaviour
+        # (the cached last mask row, model.py:603-617); no allowed key -> uniform over every key
+        lv = act0[:, -1:]
+        self.ok_self = am0.to(torch.int32).contiguous()
+        ok_cross = (am0[:, :] != 0) & (act0 < lv)
+        ok_cross[:, -1] = False
+        self.ok_cross = ok_cross.to(torch.int32).contiguous()
+        self.uniform_cross = (~ok_cross.any(1)).to(torch.int32).contiguous()
+        # router outputs of the generated tokens (router.py:158-195 in decode mode): behaviour index + 1 of the
+        # target item's behaviour token, for the FFN injection and for the cross-attention biases
+        beh = engine.lut[ids0[:, -1]].to(torch.int32) + 1
+        self.beh = beh.repeat_interleave(nb).contiguous()
+        self.gen = {key: (torch.zeros(N, max_new_tokens, self.NKV, **f32), torch.zeros(N, max_new_tokens, self.NKV, **f32))
+                    for key in self.kp}
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        QKV = self.NQ + 2 * self.NKV
+        din_max = H + cfg.behavior_embedding_dim
+        self.buf = dict(x=[torch.empty(N, H, **f32) for _ in range(3)], h=torch.empty(N, H, **f32),
+                        qkv=torch.empty(N, QKV, **f32), q=torch.empty(N, self.NQ, **f32), k=torch.empty(N, self.NKV, **f32),
+                        ao=torch.empty(N, self.NQ, **f32), op=torch.empty(N, H, **f32), gate=torch.empty(N, H, **f32),
+                        t0=torch.empty(N, H, **f32), hin=torch.empty(N, din_max, **f32), g=torch.empty(N, I, **f32),
+                        u=torch.empty(N, I, **f32), hm=torch.empty(N, I, **f32), xn=torch.empty(N, H, **f32),
+                        logits=torch.empty(N, engine.ws.ldl, **f32))
+        self.t = 0
+
+    def reorder(self, parent: torch.Tensor):
+        """Beams were re-ordered: the generated part of the cache follows its beam (the prompt part is shared)."""
+        for key, (kg, vg) in self.gen.items():
+            self.gen[key] = (kg.index_select(0, parent), vg.index_select(0, parent))
+
+    def step(self, tokens: torch.Tensor) -> torch.Tensor:
+        """tokens [N] int64: the token just appended to every beam.  Returns the next-token logits [N, ld]."""
+        eng, cfg, b = self.eng, self.eng.cfg, self.buf
+        N, B, nb, L0 = self.N, self.B, self.nb, self.L0
+        H, I, E = cfg.hidden_size, cfg.intermediate_size, cfg.num_experts
+        nq, nkv, NQ, NKV = cfg.num_attention_heads, cfg.num_key_value_heads, self.NQ, self.NKV
+        QKV = NQ + 2 * NKV
+        eps, scale = float(cfg.rms_norm_eps), float(cfg.head_dim) ** -0.5
+        self.t += 1
+        t = self.t
+        p = L0 + t - 1                                   # position of the new token
+        cos, sin = eng.rope(L0 + self.tmax)
+        cos, sin = cos[p:p + 1], sin[p:p + 1]
+        e = p % cfg.num_positions + 1                    # position-routed expert (router.py:83-104), same for every row
+        x, x1, x2 = b["x"]
+        ops.embedding_fwd(tokens.contiguous(), eng.params["model.embed_tokens.weight"], x)
+
+        def attend(kind, layer, Wa, hin, xin, xout, act_idx):
+            ops.linear_fwd(hin, H, Wa["qkv"], H, b["qkv"], QKV, N, QKV, H)
+            if kind == "cross":
+                ops.qknorm_rope_fwd(b["qkv"], 1, nq, nkv, Wa["qn"], Wa["kn"], eps, cos, sin, b["q"], b["k"],
+                                    bias_q=Wa["bq"], bias_k=Wa["bk"], bias_v=Wa["bv"], act_idx=act_idx)
+            else:
+                ops.qknorm_rope_fwd(b["qkv"], 1, nq, nkv, Wa["qn"], Wa["kn"], eps, cos, sin, b["q"], b["k"])
+            kg, vg = self.gen[(layer, kind)]
+            kg[:, t - 1] = b["k"]
+            vg[:, t - 1] = b["qkv"][:, NQ + NKV:]
+            ops.attn_decode(b["q"], self.kp[(layer, kind)], self.vp[(layer, kind)],
+                            self.ok_self if kind == "self" else self.ok_cross, kg, vg, t, kind == "self",
+                            None if kind == "self" else self.uniform_cross, B, nb, L0, nq, nkv, scale, b["ao"])
+            if kind == "self":
+                ops.gemm(b["ao"], NQ, 1, Wa["o"], NQ, 1, xout, H, N, H, NQ, resid=xin)
+            else:
+                ops.linear_fwd(b["ao"], NQ, Wa["o"], NQ, b["op"], H, N, H, NQ)
+                ops.linear_fwd(hin, H, Wa["gate"], H, b["gate"], H, N, H, H)
+                ops.silu_gate_fwd(b["op"], b["gate"], b["t0"])
+                ops.residual_dropout_fwd(xin, b["t0"], 0.0, 0, None, xout)
+
+        # x holds the layer input and receives the layer output; x1 / x2 are the states after the self / cross block
+        for l in range(cfg.num_hidden_layers):
+            W = eng.W[l]
+            ops.rmsnorm_fwd(x, W.ln1, eps, b["h"])
+            attend("self", l, W.self_attn, b["h"], x, x1, None)
+            xc = x1
+            if W.cross:
+                ops.rmsnorm_fwd(x1, W.ln2, eps, b["h"])
+                attend("cross", l, W.cross_attn, b["h"], x1, x2, self.beh)
+                xc = x2
+            din = W.din
+            ops.rmsnorm_fwd(xc, W.ln3, eps, b["hin"], din)
+            if W.inject:
+                ops.rowtable_fwd(W.beh, self.beh, b["hin"], din, H)
+            ops.linear_fwd(b["hin"], din, W.gate[e * I:(e + 1) * I], din, b["g"], I, N, I, din)
+            ops.linear_fwd(b["hin"], din, W.up[e * I:(e + 1) * I], din, b["u"], I, N, I, din)
+            ops.swiglu_fwd(b["g"], b["u"], N * I, 0.0, 0, b["hm"])
+            ops.gemm(b["hm"], I, 1, W.down[e * H:(e + 1) * H], I, 1, x, H, N, H, I, resid=xc)
+        cur = x
+        ops.rmsnorm_fwd(cur, eng.params["model.norm.weight"], eps, b["xn"])
+        ops.linear_fwd(b["xn"], H, eng.params["model.embed_tokens.weight"], H, b["logits"], b["logits"].stride(0), N,
+                       cfg.vocab_size, H)
+        return b["logits"]
+
+
 @torch.no_grad()
 def beam_search(engine, input_ids: torch.Tensor, attention_mask: torch.Tensor, actions: torch.Tensor, trie: ItemTrie,
-                num_beams: int, max_new_tokens: int = 4) -> Tuple[torch.Tensor, torch.Tensor]:
+                num_beams: int, max_new_tokens: int = 4, use_cache: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """input_ids / attention_mask / actions: [B, L0] left-padded prompts ending with the target behaviour token.
     Returns (sequences [B*num_beams, L0+max_new_tokens] int64, sequences_scores [B*num_beams] fp32), the beams of
-    sample b at rows b*num_beams .., best first - the layout of HF's GenerateBeamOutput."""
+    sample b at rows b*num_beams .., best first - the layout of HF's GenerateBeamOutput.
+    ``use_cache=False`` re-runs the whole sequence every step (the cross-check of the cache path)."""
     dev = engine.device
     B, L0 = input_ids.shape
     V = engine.cfg.vocab_size
@@ -106,9 +231,18 @@ def beam_search(engine, input_ids: torch.Tensor, attention_mask: torch.Tensor, a
     node, nxt = nxt, node
     scores = torch.empty(N, V, device=dev)
     final = None
+    session = DecodeSession(engine, ids0, am0, act0, nb, max_new_tokens) if use_cache else None
+    last_tok = None
     for step in range(max_new_tokens):
         cur = L0 + step
-        if step == 0:
+        if session is not None:
+            if step == 0:
+                logits2d = session.prefill_logits
+                rows = torch.arange(N, device=dev, dtype=torch.int32) // nb
+            else:
+                logits2d = session.step(last_tok)
+                rows = torch.arange(N, device=dev, dtype=torch.int32)
+        elif step == 0:
             # all beams of a sample hold the same prompt: run it once (HF runs num_beams copies)
             engine.forward(ids0, am0, act0, train=False, act_zero_col=L0 - 1, uniform_len=L0)
             rows = (torch.arange(N, device=dev, dtype=torch.int32) // nb) * cur + (cur - 1)
@@ -119,8 +253,9 @@ def beam_search(engine, input_ids: torch.Tensor, attention_mask: torch.Tensor, a
             act = torch.cat([act0, act0[:, -1:].expand(B, step)], 1).repeat_interleave(nb, 0)
             engine.forward(flat, am, act, train=False, act_zero_col=L0 - 1, uniform_len=L0)
             rows = torch.arange(N, device=dev, dtype=torch.int32) * cur + (cur - 1)
-        ws = engine.ws
-        ops.trie_logprobs(ws.logits, rows, run_scores.reshape(N).contiguous(), node, trie.child_start, trie.child_tok,
+        if session is None:
+            logits2d = engine.ws.logits
+        ops.trie_logprobs(logits2d, rows, run_scores.reshape(N).contiguous(), node, trie.child_start, trie.child_tok,
                           V, scores)
         top_s, top_i = torch.topk(scores.view(B, nb * V), K)
         beam_i, tok = top_i // V, top_i % V
@@ -131,6 +266,9 @@ def beam_search(engine, input_ids: torch.Tensor, attention_mask: torch.Tensor, a
         seqs = cand[:, :nb].contiguous()
         run_scores = top_s[:, :nb].contiguous()
         parent = (beam_i[:, :nb] + torch.arange(B, device=dev)[:, None] * nb).reshape(N)
+        last_tok = tok[:, :nb].reshape(N).contiguous()
+        if session is not None:
+            session.reorder(parent)
         ops.trie_advance(node[parent].contiguous(), tok[:, :nb].reshape(N).contiguous(), trie.child_start,
                          trie.child_tok, trie.child_node, nxt)
         node, nxt = nxt.clone(), nxt

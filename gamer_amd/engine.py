@@ -287,7 +287,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     def forward(self, input_ids, attention_mask=None, actions=None, labels=None, num_items_in_batch=None,
                 train: bool = False, dropout: Optional[bool] = None, act_zero_col: Optional[int] = None,
-                uniform_len: int = 0):
+                uniform_len: int = 0, kv_sink=None):
         """Returns (loss or None, logits view [B,S,V]).  With labels the logits are divided by the
         temperature in place, as the reference does (model.py:913).  The view aliases a workspace
         buffer: backward() overwrites it with d(logits), the next forward() with new logits.  ``train`` keeps every activation
@@ -296,7 +296,9 @@ class Engine:
         Evaluation only (gamer_amd/decode.py re-runs the whole sequence every generation step): ``act_zero_col``
         is the column of the prompt's final behaviour token, which the reference's router gives action index 0
         when the prompt has 5n+1 tokens (router.py:160-163) and which stays that way in its K/V cache;
-        ``uniform_len`` is the prompt length (see gamer_attn_fwd in include/gamer_hip.h)."""
+        ``uniform_len`` is the prompt length (see gamer_attn_fwd in include/gamer_hip.h); ``kv_sink(layer, kind, k, v)``
+        receives the keys (after k-norm + RoPE) and values of every attention ("self" / "cross") - the K/V cache of
+        gamer_amd.decode.DecodeSession."""
         cfg = self.cfg
         B, S = input_ids.shape
         if train and S % cfg.num_positions != 0:
@@ -344,6 +346,8 @@ class Engine:
             ops.rmsnorm_fwd(xs[0], W.ln1, eps, A["h1"])
             ops.linear_fwd(A["h1"], H, W.self_attn["qkv"], H, A["qkv"], QKV, T, QKV, H)
             ops.qknorm_rope_fwd(A["qkv"], S, nq, nkv, W.self_attn["qn"], W.self_attn["kn"], eps, cos, sin, A["q"], A["k"])
+            if kv_sink is not None:
+                kv_sink(l, "self", A["k"], A["qkv"][:, NQ + NKV:])
             ops.attn_fwd(A["q"], NQ, A["k"], NKV, A["qkv"][:, NQ + NKV:], QKV, r["kl_self"], None, r["empty_self"],
                          r["tile_empty_self"], B, S, nq, nkv, scale, p_att, self._seed(l, 0), A["ao"], A["lse"],
                          uniform_len=uniform_len)
@@ -358,6 +362,8 @@ class Engine:
                 ops.linear_fwd(A["h2"], H, C["qkv"], H, A["qkv_c"], QKV, T, QKV, H)
                 ops.qknorm_rope_fwd(A["qkv_c"], S, nq, nkv, C["qn"], C["kn"], eps, cos, sin, A["q_c"], A["k_c"],
                                     bias_q=C["bq"], bias_k=C["bk"], bias_v=C["bv"], act_idx=r["act_idx"])
+                if kv_sink is not None:
+                    kv_sink(l, "cross", A["k_c"], A["qkv_c"][:, NQ + NKV:])
                 ops.attn_fwd(A["q_c"], NQ, A["k_c"], NKV, A["qkv_c"][:, NQ + NKV:], QKV, r["kl_cross"], r["ql_cross"],
                              r["empty_cross"], r["tile_empty_cross"], B, S, nq, nkv, scale, p_att, self._seed(l, 2),
                              A["ao_c"], A["lse_c"], order=ws.cross_order, uniform_len=uniform_len)

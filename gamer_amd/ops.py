@@ -243,3 +243,11 @@ def trie_logprobs(logits2d, row_index, beam_score, node, child_start, child_tok,
 def trie_advance(node, token, child_start, child_tok, child_node, out):
     call("gamer_trie_advance", ptr(node), ptr(token), ptr(child_start), ptr(child_tok), ptr(child_node),
          node.numel(), ptr(out), stream_ptr())
+
+
+def attn_decode(q, kp, vp, key_ok, kg, vg, t, gen_ok, uniform, B, nb, L0, nq, nkv, scale, o):
+    """One new token per beam against the prompt cache (per sample) + generated cache (per beam)."""
+    tmax = kg.shape[1]
+    call("gamer_attn_decode", ptr(q), q.stride(0), ptr(kp), kp.stride(0), ptr(vp), vp.stride(0), ptr(key_ok), ptr(kg),
+         ptr(vg), kg.stride(1), tmax, t, 1 if gen_ok else 0, ptr(uniform), B, nb, L0, nq, nkv, scale, ptr(o),
+         stream_ptr())

@@ -277,6 +277,22 @@ int gamer_trie_logprobs(const float* logits, int64_t ld, const int32_t* row_inde
 int gamer_trie_advance(const int32_t* node, const int64_t* token, const int32_t* child_start,
                        const int32_t* child_tok, const int32_t* child_node, int N, int32_t* next, void* stream);
 
+/* Attention of one new token per beam against the K/V cache of a generation run
+ * (Qwen3MultiAttention.forward with past_key_value, ref:.../Qwen3Multi/model.py:118-121; the decode branches of
+ * the mask builders, model.py:603-617 and 718-741).  N = B*nb beams; the prompt part of the cache is stored once
+ * per sample (the reference keeps nb identical copies), the generated part per beam:
+ *   q  [N, nq*64] (ldq)   queries of the new tokens (after q-norm + RoPE at their position)
+ *   kp/vp  prompt keys / values, row b*L0 + j, leading dims ldkp / ldvp
+ *   key_ok int32 [B, L0]  1 = prompt key j may be attended by the new rows of sample b
+ *   kg/vg  generated keys / values, row n*tmax + g (g < t, the new token itself is g = t-1), leading dim ldg
+ *   gen_ok 1 = generated keys are attended (self attention), 0 = masked (cross attention)
+ *   uniform int32 [B] or NULL: 1 = the new rows of sample b have no allowed key -> mean of V over all L0+t keys
+ *   o  [N, nq*64]                                                                                       */
+int gamer_attn_decode(const float* q, int ldq, const float* kp, int ldkp, const float* vp, int ldvp,
+                      const int32_t* key_ok, const float* kg, const float* vg, int ldg, int tmax, int t, int gen_ok,
+                      const int32_t* uniform, int B, int nb, int L0, int nq, int nkv, float scale, float* o,
+                      void* stream);
+
 /* misc */
 int gamer_fill_f32(float* p, int64_t n, float value, void* stream);
 

@@ -170,6 +170,9 @@ def test_engine_beam_search_matches_reference_generate(tb):
     ids, am, act = _case(fx, tb)
     trie = ItemTrie(synthetic.item_tokens(torch.from_numpy(fx["catalogue"]), tb, cb).tolist())
     seq, sc = beam_search(eng, ids, am, act, trie, beams, 4)
+    # the K/V-cache path and the re-run-everything path give the same beams
+    seq_nc, sc_nc = beam_search(eng, ids, am, act, trie, beams, 4, use_cache=False)
+    assert torch.equal(seq, seq_nc) and float((sc - sc_nc).abs().max()) < 2e-5
     empty = _empty_target_rows(am, act)
     _check(seq, sc, fx, tb, "_crossfix", torch.ones_like(empty), beams, 1e-4)
     if (~empty).any():

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--items", type=int, default=20000, help="catalogue size")
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--cpu-users", type=int, default=1)
+    ap.add_argument("--no-cache", dest="no_cache", action="store_true", help="re-run the whole sequence every step")
     args = ap.parse_args()
     cfg = synthetic_config()
     eng = Engine(cfg, temperature=0.7)
@@ -39,7 +40,8 @@ def main():
     trie = ItemTrie(items)
     batch = synthetic.make_eval_batch(args.B, args.his, cat, tb, 256, 3, min_his=args.his, seed=5,
                                       behavior_probs=[0.7, 0.25, 0.05])
-    run = lambda: beam_search(eng, batch["input_ids"], batch["attention_mask"], batch["actions"], trie, args.beams, 4)
+    run = lambda: beam_search(eng, batch["input_ids"], batch["attention_mask"], batch["actions"], trie, args.beams, 4,
+                              use_cache=not args.no_cache)
     run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -50,7 +52,9 @@ def main():
     out = dict(metric="evaluation users/s, Qwen3Multi SMB decoder, trie-constrained beam search", value=args.B / dt,
                unit="users/s", ms_per_batch=dt * 1e3,
                config=dict(workload=f"{args.B} users x {args.beams} beams, history {args.his} items, 4 new tokens, "
-                                    f"catalogue {args.items} items, fp32, no K/V cache (whole sequence re-run per step)"))
+                                    f"catalogue {args.items} items, fp32, " +
+                                    ("whole sequence re-run per step" if args.no_cache else
+                                     "K/V cache: prompt once per sample, generated positions per beam")))
     if args.cpu_users > 0:
         from oracle import decode_oracle as dec, qwen3multi_oracle as orc
         ocfg = orc.OracleConfig.from_dict(cfg.to_dict())
