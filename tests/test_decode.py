@@ -203,3 +203,46 @@ def test_evaluate_behavior_matches_reference_metrics():
     res = evaluate_behavior(eng, [batch, batch], trie, beams, meta["metrics"])
     assert res["samples"] == 2 * ids.shape[0]
     np.testing.assert_allclose([res[m] for m in meta["metrics"]], fx[f"b{tb}_metrics"] / ids.shape[0], atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,nkv,nb,L0,t", [(2, 1, 6, 31, 1), (6, 3, 20, 130, 3), (2, 2, 5, 64, 4)])
+def test_attn_decode_kernel_against_dense(nq, nkv, nb, L0, t):
+    """gamer_attn_decode vs fp64 softmax attention: self (generated keys attended) and cross (generated keys
+    masked, samples without an allowed key uniform over all L0 + t keys)."""
+    from gamer_amd import ops
+    dev, B, tmax = "cuda", 3, 4
+    N, G = B * nb, nq // nkv
+    g = torch.Generator().manual_seed(L0 + t)
+    q = torch.randn(N, nq * 64, generator=g)
+    kp, vp = torch.randn(B * L0, nkv * 64, generator=g), torch.randn(B * L0, nkv * 64, generator=g)
+    kg, vg = torch.randn(N, tmax, nkv * 64, generator=g), torch.randn(N, tmax, nkv * 64, generator=g)
+    ok = (torch.rand(B, L0, generator=g) < 0.6).to(torch.int32)
+    ok[0, :5] = 0                                            # left padding
+    ok[1] = 0                                                # sample 1: nothing allowed
+    ok_self = ok.clone()
+    ok_self[1, -3:] = 1                                      # self attention always has kept keys
+    uniform = (ok.sum(1) == 0).to(torch.int32)
+    vbuf = torch.zeros(B * L0, (nq + 2 * nkv) * 64)          # v lives inside a wider buffer in the engine
+    vbuf[:, (nq + nkv) * 64:] = vp
+    for kind in ("self", "cross"):
+        o = torch.empty(N, nq * 64, device=dev)
+        kok = ok_self if kind == "self" else ok
+        ops.attn_decode(q.to(dev), kp.to(dev), vbuf.to(dev)[:, (nq + nkv) * 64:], kok.to(dev), kg.to(dev), vg.to(dev), t,
+                        kind == "self", None if kind == "self" else uniform.to(dev), B, nb, L0, nq, nkv, 0.125, o)
+        ref = torch.empty(N, nq, 64, dtype=torch.float64)
+        for n in range(N):
+            b = n // nb
+            for hd in range(nq):
+                kv = hd // G
+                keys = torch.cat([kp[b * L0:(b + 1) * L0, kv * 64:(kv + 1) * 64], kg[n, :t, kv * 64:(kv + 1) * 64]]).double()
+                vals = torch.cat([vp[b * L0:(b + 1) * L0, kv * 64:(kv + 1) * 64], vg[n, :t, kv * 64:(kv + 1) * 64]]).double()
+                allowed = torch.cat([kok[b].bool(), torch.full((t,), kind == "self")])
+                if kind == "cross" and uniform[b]:
+                    ref[n, hd] = vals.mean(0)
+                    continue
+                s = (keys @ q[n, hd * 64:(hd + 1) * 64].double()) * 0.125
+                s[~allowed] = float("-inf")
+                ref[n, hd] = torch.softmax(s, 0) @ vals
+        err = float((o.cpu().double().view(N, nq, 64) - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (kind, err)
