@@ -282,6 +282,7 @@ qknorm_rope_fwd_kernel(float* __restrict__ qkv, int T, int S, int nq, int nkv,
     const float4 wq4 = reinterpret_cast<const float4*>(wq)[g], wk4 = reinterpret_cast<const float4*>(wk)[g];
     const float sgn = g < 8 ? -1.f : 1.f;
     const int64_t total = (int64_t)T * NH;
+#pragma unroll 2
     for (int64_t i0 = wave * 4; i0 < total; i0 += nwaves * 4) {
         const int64_t i = i0 + sub;
         const bool live = i < total;
@@ -356,6 +357,7 @@ qknorm_rope_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ 
     if (hd < nq + nkv) {
         const bool isq = hd < nq;
         const float4 w4 = isq ? reinterpret_cast<const float4*>(wq)[g] : reinterpret_cast<const float4*>(wk)[g];
+#pragma unroll 2
         for (int tb = w0 * 4; tb < T; tb += waves_per_head * 4) {
             const int t = tb + sub;
             const bool live = t < T;

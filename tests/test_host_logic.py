@@ -114,3 +114,35 @@ def test_algorithmic_flops_match_survey_numbers():
     ok = (j <= i) & (a[:, None, :] < a[:, :, None]) & keep[:, None, :]
     assert f["p_cross"] == int(ok.sum())
     assert f["step"] == 3 * f["fwd"]
+
+
+def test_attention_dropout_hash_statistics():
+    """numpy restatement of csrc/common.h:AttnDropout (multiply-shift mask: keep(i,j) = low32(a_i*b_j) >= p*2^32).
+    Row / key keep rates, adjacent-element correlations and the 2x2 interaction must look like independent
+    Bernoulli(0.8) draws at the shapes the model uses (S = 505, 6 heads)."""
+    import numpy as np
+
+    def mix32(x):
+        x = x.astype(np.uint64) & 0xffffffff
+        x ^= x >> 16
+        x = (x * 0x7feb352d) & 0xffffffff
+        x ^= x >> 15
+        x = (x * 0x846ca68b) & 0xffffffff
+        x ^= x >> 16
+        return x
+
+    p, S, rows = 0.2, 505, 505 * 6
+    for seed in (1, 0x1234567890ab, (7 << 48) | (3 << 16) | 0x25):
+        k0 = int(mix32(np.array([(seed & 0xffffffff) ^ 0x9e3779b9]))[0]) ^ int(mix32(np.array([((seed >> 32) + 0x7f4a7c15)]))[0])
+        k1 = int(mix32(np.array([k0 + 0x632be5ab]))[0])
+        a = (mix32(np.arange(rows, dtype=np.uint64) * 0x9e3779b1 + k0) & 0xffffff) | 0x800001
+        b = mix32(np.arange(S, dtype=np.uint64) * 0x85ebca6b + k1) & 0xffffff
+        keep = ((a[:, None] * b[None, :]) & 0xffffffff) >= int(p * 2 ** 32)
+        sd_row, sd_col = np.sqrt(0.16 / S), np.sqrt(0.16 / rows)
+        assert abs(keep.mean() - 0.8) < 2e-3
+        assert abs(keep.mean(1).std() - sd_row) < 0.15 * sd_row
+        assert abs(keep.mean(0).std() - sd_col) < 0.25 * sd_col
+        assert abs(np.corrcoef(keep[:, :-1].ravel(), keep[:, 1:].ravel())[0, 1]) < 5e-3
+        assert abs(np.corrcoef(keep[:-1].ravel(), keep[1:].ravel())[0, 1]) < 5e-3
+        quad = (keep[:-1, :-1] & keep[:-1, 1:] & keep[1:, :-1] & keep[1:, 1:]).mean()
+        assert abs(quad - 0.8 ** 4) < 4e-3
