@@ -58,6 +58,30 @@ class _ModelFn(torch.autograd.Function):
         return (None, None, None, None, None, None, *grads)
 
 
+class _Holder(nn.Module):
+    """Name-only node of the parameter tree (the computation lives in the engine)."""
+
+    def forward(self, *args, **kwargs):                      # pragma: no cover
+        raise RuntimeError("holder modules only carry parameter names; call the top-level module")
+
+
+class _NormHolder(_Holder):
+    """Holder of an RMSNorm weight.  Registered with transformers' ALL_LAYERNORM_LAYERS so that Trainer versions
+    that exclude norm weights from weight decay by module TYPE (4.x) do so here as well; 5.x matches by name."""
+
+
+def _is_norm_key(key: str) -> bool:
+    return key.endswith("norm.weight")                       # input_layernorm, post_*_layernorm, q_norm, k_norm, model.norm
+
+
+try:                                                          # best effort: transformers is optional
+    from transformers.pytorch_utils import ALL_LAYERNORM_LAYERS as _ALL_LN
+    if _NormHolder not in _ALL_LN:
+        _ALL_LN.append(_NormHolder)
+except Exception:                                             # noqa: BLE001
+    pass
+
+
 class Qwen3MultiWithTemperature(nn.Module):
     def __init__(self, config: Qwen3MultiConfig, device: str = "cuda"):
         super().__init__()
@@ -74,13 +98,24 @@ class Qwen3MultiWithTemperature(nn.Module):
         self._register_views()
 
     def _register_views(self):
-        """nn.Parameters that alias the engine's flat buffer, registered under the reference's names."""
+        """nn.Parameters that alias the engine's flat buffer, hung on a tree of empty holder modules with the
+        reference's names (``model.layers.0.self_attn.q_proj.weight`` ...).  The tree is what lets code that walks
+        ``named_children()`` / ``_parameters`` - HF ``Trainer.get_decay_parameter_names``, DDP, torch optimizers -
+        see the same names and the same no-weight-decay norms as with the reference module."""
         self._params_by_key = {}
         for key in self._param_keys:
             p = nn.Parameter(self.engine.params[key], requires_grad=True)
             self._params_by_key[key] = p
-            # nested registration without building the reference's module tree
-            self.register_parameter(key.replace(".", "__"), p)
+            parts = key.split(".")
+            node = self
+            for i, name in enumerate(parts[:-1]):
+                child = node._modules.get(name)
+                if child is None:
+                    leaf = i == len(parts) - 2
+                    child = _NormHolder() if (leaf and _is_norm_key(key)) else _Holder()
+                    node.add_module(name, child)
+                node = child
+            node.register_parameter(parts[-1], p)
 
     # ---- reference surface -------------------------------------------------------------------
     def set_hyper(self, temperature: float):
@@ -95,8 +130,8 @@ class Qwen3MultiWithTemperature(nn.Module):
         self.vocab_size = int(new_num_tokens)
         self.engine = Engine(self.config, device=str(self.engine.device), temperature=self.temperature)
         self.engine.init_weights(seed=0)
-        for k in list(self._parameters):
-            del self._parameters[k]
+        for name in list(self._modules):                      # drop the old parameter tree
+            del self._modules[name]
         self._param_keys = list(self.engine.layout.entries.keys())
         self._register_views()
         with torch.no_grad():
@@ -119,10 +154,6 @@ class Qwen3MultiWithTemperature(nn.Module):
             raise KeyError(f"unexpected keys: {unexpected[:5]}")
         with torch.no_grad():
             self.engine.load_state_dict({k: v for k, v in sd.items() if k in self.engine.layout.entries})
-
-    def named_parameters(self, prefix: str = "", recurse: bool = True, remove_duplicate: bool = True):
-        for k in self._param_keys:
-            yield (prefix + k, self._params_by_key[k])
 
     def save_pretrained(self, path: str):
         os.makedirs(path, exist_ok=True)
