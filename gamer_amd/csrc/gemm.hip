@@ -357,33 +357,56 @@ gemm_f32_kernel(const GemmParams p) {
         // parks its 64x64 patch as [64][68] floats and reads it back one 16-byte row chunk per lane, so the
         // patch leaves in 16 x 1-KiB store instructions (4 rows x 256 B each) instead of 64 dword stores.
         float* patch = smem + wid * (64 * 68);
+        // (alpha == 1 for every GEMM of the train step: no multiply; every VALU instruction here is matrix time)
+        if (p.alpha == 1.f) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    patch[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + j * 32 + r32] = p.alpha * acc[i][j][r];
+                    for (int r = 0; r < 16; ++r)
+                        patch[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + j * 32 + r32] = acc[i][j][r];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        patch[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + j * 32 + r32] = p.alpha * acc[i][j][r];
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): own LDS writes landed (wave-private patch)
         const int c4 = (lane & 15) << 2;
         const DropoutRng rng(EPI ? p.p_drop : 0.f, p.seed);
+        // one 64-bit address per wave patch, then a constant stride per store (a per-store row * ldc product costs
+        // two quarter-rate integer multiplies each)
+        const int row_first = row0 + wm * 64 + (lane >> 4);
+        const int col = col0 + wn * 64 + c4;
+        float* dst0 = Cp + (int64_t)row_first * p.ldc + col;
+        const float* res0 = EPI ? p.resid + (int64_t)row_first * p.ldc + col : nullptr;
+        const int64_t step = 4 * p.ldc;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int lr = (lane >> 4) + 4 * it;             // row inside the patch
             const float4 v = *reinterpret_cast<const float4*>(patch + lr * 68 + c4);
-            const int row = row0 + wm * 64 + lr;
-            const int col = col0 + wn * 64 + c4;
             if (EPI) {
-                const int64_t rc = p.row_map ? p.row_map[row] : row;
-                float* dst = Cp + rc * p.ldc + col;
-                const float4 x = *reinterpret_cast<const float4*>(p.resid + rc * p.ldc + col);
+                float* dst = dst0 + it * step;
+                const float* rsrc = res0 + it * step;
+                int64_t e = (int64_t)(row_first + 4 * it) * p.ldc + col;
+                if (p.row_map) {
+                    const int64_t rc = p.row_map[row_first + 4 * it];
+                    e = rc * p.ldc + col;
+                    dst = Cp + e;
+                    rsrc = p.resid + e;
+                }
+                const float4 x = *reinterpret_cast<const float4*>(rsrc);
                 float m[4];
-                rng.mult4((uint32_t)((rc * p.ldc + col) >> 2), m);
+                rng.mult4((uint32_t)(e >> 2), m);
                 float4 o;
                 o.x = x.x + m[0] * v.x; o.y = x.y + m[1] * v.y; o.z = x.z + m[2] * v.z; o.w = x.w + m[3] * v.w;
                 *reinterpret_cast<float4*>(dst) = o;
             } else {
-                float* dst = Cp + (int64_t)row * p.ldc + col;
+                float* dst = dst0 + it * step;
                 if (ACCUM) {
                     float4 o = *reinterpret_cast<const float4*>(dst);
                     o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
