@@ -255,7 +255,11 @@ gemm_f32_kernel(const GemmParams p) {
     unsigned long long t_ph[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t0 = 0, t1 = 0;
     const unsigned long long t_begin = STAMP ? stamp_now() : 0;
+    // a wave whose 64 x 64 patch lies entirely past the edge of C (N = 320 leaves half of the last column tile
+    // empty) issues no MFMAs: its share of the matrix pipe goes to the other resident workgroup
+    const bool wave_live = (row0 + wm * 64 < row_end) && (col0 + wn * 64 < col_end);
     auto mfma_tile = [&](const float* as) {
+        if (!wave_live) return;
         const float* bs = as + TILE_FLOATS;
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
