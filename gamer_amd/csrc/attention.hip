@@ -737,7 +737,7 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
                     const int32_t* __restrict__ row_empty, const int32_t* __restrict__ tile_empty,
                     int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                     float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const RowOrder ro, const int pair,
-                    const int ktile) {
+                    const int ktile, float* __restrict__ ds_out) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char dkv_raw[];
@@ -968,6 +968,14 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
                 if (free_tile) elem_tile.template operator()<false, false, false>();
                 else elem_tile.template operator()<true, false, false>();
             }
+            if (ds_out != nullptr && (k0 >> 5) + sub < n_qt) {
+                // spill dS for the dQ kernel: tile (head, query tile qt, this wave's 32-key tile) as [query][key]
+                // floats; a store instruction writes two 128-byte rows
+                const int head = kvh * G + hg;
+                float* tile = ds_out + ((((int64_t)b * nq + head) * n_qt + qt) * n_qt + (k0 >> 5) + sub) * 1024;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) tile[rowmap(reg, h) * 32 + r] = dp[reg];
+            }
             // dV^T[d][key] += sum_query dO[query][d] Pd[query][key] ; dK^T[d][key] += sum_query Q[query][d] dS[query][key]
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
@@ -1044,7 +1052,8 @@ attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restric
                     const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                     const int32_t* __restrict__ row_empty, const int32_t* __restrict__ tile_empty,
                     int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-                    float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const RowOrder ro) {
+                    float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const RowOrder ro,
+                    float* __restrict__ ds_out) {
     constexpr int R = (4 / G) * 32;
     const int n_tiles = (S + R - 1) / R;
     const WorkList wl(nbatch * nkv, n_tiles);
@@ -1057,7 +1066,171 @@ attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restric
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
             attn_bwd_dkv_tile<G, DROP, ORD>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv,
-                                            scale, p_drop, seed, dk, lddk, dv, lddv, ro, pair, pass == 0 ? heavy : light);
+                                            scale, p_drop, seed, dk, lddk, dv, lddv, ro, pair, pass == 0 ? heavy : light, ds_out);
+        }
+    }
+}
+
+// =============================================================================================
+// backward with a dS spill: delta, then dK/dV (+ dS to HBM), then dQ = dS K from the spilled tiles
+// =============================================================================================
+// The recompute pair above issues 7 matmuls per (query tile, key tile): S and dP twice.  With a workspace of
+// B*nq*ceil(S/32)^2 KiB*4 the dK/dV kernel writes its dS tiles (3 GB per call at B = 1024, hidden behind its
+// MFMA work) and dQ becomes one matmul per tile that streams them back (HBM-bound, ~0.6 ms): 5 matmuls, no
+// second softmax / dropout pass, still no atomics.
+
+// delta[b,h,i] = sum_d dO * O
+__global__ void __launch_bounds__(AT_THREADS)
+attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o, int B, int S, int nq,
+                  float* __restrict__ delta) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane & 15, sub = lane >> 4;                  // 16 lanes x float4 = one head row, 4 rows per wave
+    const int64_t wave = ((int64_t)blockIdx.x * AT_THREADS + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * AT_THREADS) >> 6;
+    const int64_t total = (int64_t)B * S * nq;
+    for (int64_t i0 = wave * 4; i0 < total; i0 += nwaves * 4) {
+        const int64_t i = i0 + sub;
+        const bool live = i < total;
+        const int64_t ic = live ? i : total - 1;
+        const float4 a = reinterpret_cast<const float4*>(o + ic * 64)[g];
+        const float4 c = reinterpret_cast<const float4*>(d_o + ic * 64)[g];
+        float s = a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (live && g == 0) {
+            const int64_t t = i / nq;
+            const int hd = (int)(i % nq);
+            const int64_t bb = t / S, ii = t % S;
+            delta[(bb * nq + hd) * S + ii] = s;
+        }
+    }
+}
+
+template <int G, bool ORD>
+__device__ __forceinline__ void
+attn_bwd_dq2_tile(const float* __restrict__ k, int ldk, const float* __restrict__ ds_in,
+                  const int32_t* __restrict__ row_empty, int S, int nq, int nkv, float scale,
+                  float* __restrict__ dq, int lddq, const RowOrder ro, const int pair, const int qtile) {
+    constexpr int NSUB = 4 / G;
+    constexpr int R = NSUB * 32;
+    __shared__ __attribute__((aligned(16))) float Ks[2][32 * KLD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int hg = w / NSUB, sub = w % NSUB;
+    const int b = pair / nkv, kvh = pair % nkv, q0 = qtile * R;
+    const int head = kvh * G + hg;
+    const int r = lane & 31, h = lane >> 5;
+    const int slot = q0 + sub * 32 + r;
+    const bool valid_q = slot < S;
+    const int slotc = valid_q ? slot : S - 1;
+    const int iqc = ORD ? ro.perm[(int64_t)b * S + slotc] : slotc;
+    const int64_t tok = (int64_t)b * S + iqc;
+    const bool my_empty = valid_q && row_empty[tok] != 0;
+    const int n_all = (S + 31) / 32;
+    const int qt32 = (q0 >> 5) + sub;                            // this wave's 32-row query tile
+    int wave_q_hi, n_causal;
+    bool wave_has_empty;
+    if (ORD) {
+        const int64_t tb = (int64_t)b * n_all + (q0 >> 5);
+        const int wt = min(sub, n_all - 1 - (q0 >> 5));
+        wave_q_hi = (q0 + sub * 32 < S) ? ro.tile_maxpos[tb + wt] : -1;
+        wave_has_empty = (q0 + sub * 32 < S) && (ro.tile_kind[tb + wt] & 2) != 0;
+        int hi = -1;
+#pragma unroll
+        for (int ss = 0; ss < NSUB; ++ss)
+            if (q0 + ss * 32 < S) hi = max(hi, ro.tile_maxpos[tb + ss]);
+        n_causal = hi < 0 ? 0 : (hi >> 5) + 1;
+    } else {
+        wave_q_hi = (q0 + sub * 32 < S) ? min(S - 1, q0 + sub * 32 + 31) : -1;
+        wave_has_empty = __any(my_empty ? 1 : 0) != 0;
+        n_causal = (min(S, q0 + R) + 31) / 32;
+    }
+    const bool block_has_empty = __syncthreads_or(my_empty ? 1 : 0) != 0;
+    const int n_iter = block_has_empty ? n_all : n_causal;
+    const float* kbase = k + (int64_t)b * S * ldk + kvh * 64;
+    // dS tiles of this wave: (head, qt32, key tile jt) -> 1024 floats [query][key]; the lane takes query r and the
+    // keys rowmap(reg, h), i.e. four 16-byte pieces of its row
+    const float* ds_row = ds_in + ((((int64_t)b * nq + head) * n_all + min(qt32, n_all - 1)) * n_all) * 1024 + r * 32 + 4 * h;
+
+    f32x16 dqacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
+    auto live = [&](int jt) { return !((jt * 32 > wave_q_hi) && !wave_has_empty); };   // mirrors the dK/dV kernel
+    auto load_ds = [&](int jt, float4 (&t4)[4]) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) t4[g4] = *reinterpret_cast<const float4*>(ds_row + (int64_t)jt * 1024 + 8 * g4);
+    };
+    // the dS tiles come straight from HBM and one tile of MFMA work (~1 us) is shorter than the load latency:
+    // three tiles are kept in flight per wave
+    float4 rk[2], t0[4], t1[4], t2[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) { t0[g4] = make_float4(0.f, 0.f, 0.f, 0.f); t1[g4] = t0[g4]; t2[g4] = t0[g4]; }
+    load_tile32(kbase, ldk, 0, S, tid, rk);
+    store_tile32<KLD>(Ks[0], tid, rk, S);
+    if (n_iter > 0 && live(0)) load_ds(0, t0);
+    if (n_iter > 1 && live(1)) load_ds(1, t1);
+    if (n_iter > 2 && live(2)) load_ds(2, t2);
+    __syncthreads();
+    // iteration jt consumes ring slot jt % 3 and refills it with tile jt + 3 (no register rotation: a copy of a
+    // register with a load in flight would wait for the load)
+    auto step = [&](int jt, float4 (&tu)[4]) {
+        const int cur = jt & 1;
+        const bool more = jt + 1 < n_iter;
+        if (more) load_tile32(kbase, ldk, jt * 32 + 32, S, tid, rk);
+        if (live(jt)) {
+            const float st[16] = {tu[0].x, tu[0].y, tu[0].z, tu[0].w, tu[1].x, tu[1].y, tu[1].z, tu[1].w,
+                                  tu[2].x, tu[2].y, tu[2].z, tu[2].w, tu[3].x, tu[3].y, tu[3].z, tu[3].w};
+            // dQ^T[d][query] += sum_key K[key][d] dS^T[key][query]   (rows of K past the sequence end are zero)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int key = rowmap(reg, h);
+                const float a0 = Ks[cur][key * KLD + r];
+                const float a1 = Ks[cur][key * KLD + 32 + r];
+                dqacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, st[reg], dqacc[0], 0, 0, 0);
+                dqacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, st[reg], dqacc[1], 0, 0, 0);
+            }
+        }
+        if (jt + 3 < n_iter && live(jt + 3)) load_ds(jt + 3, tu);
+        if (more) store_tile32<KLD>(Ks[cur ^ 1], tid, rk, S - (jt * 32 + 32));
+        __syncthreads();
+    };
+    for (int jt = 0; jt < n_iter; jt += 3) {
+        step(jt, t0);
+        if (jt + 1 < n_iter) step(jt + 1, t1);
+        if (jt + 2 < n_iter) step(jt + 2, t2);
+    }
+    if (valid_q) {
+        float* drow = dq + tok * lddq + head * 64;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 t4;
+                t4.x = dqacc[dh][4 * g4 + 0] * scale; t4.y = dqacc[dh][4 * g4 + 1] * scale;
+                t4.z = dqacc[dh][4 * g4 + 2] * scale; t4.w = dqacc[dh][4 * g4 + 3] * scale;
+                *reinterpret_cast<float4*>(drow + 32 * dh + 8 * g4 + 4 * h) = t4;
+            }
+        }
+    }
+}
+
+template <int G, bool ORD>
+__global__ void __launch_bounds__(AT_THREADS, 2)
+attn_bwd_dq2_kernel(const float* __restrict__ k, int ldk, const float* __restrict__ ds_in,
+                    const int32_t* __restrict__ row_empty, int nbatch, int S, int nq, int nkv, float scale,
+                    float* __restrict__ dq, int lddq, const RowOrder ro) {
+    constexpr int R = (4 / G) * 32;
+    const int n_tiles = (S + R - 1) / R;
+    const WorkList wl(nbatch * nkv, n_tiles);
+    if (!wl.valid) return;
+    for (int it = 0;; ++it) {
+        const int pair = wl.pair_at(it);
+        if (pair >= wl.n_pairs) break;
+        const int heavy = n_tiles - 1 - wl.u, light = wl.u;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1 && light == heavy) break;
+            attn_bwd_dq2_tile<G, ORD>(k, ldk, ds_in, row_empty, S, nq, nkv, scale, dq, lddq, ro, pair,
+                                      pass == 0 ? heavy : light);
         }
     }
 }
@@ -1123,12 +1296,17 @@ static int launch_bwd_variant(const float* q, int ldq, const float* k, int ldk, 
                               const float* d_o, const float* lse, float* delta, const int32_t* kl, const int32_t* ql,
                               const int32_t* row_empty, const int32_t* tile_empty, int B, int S, int nq, int nkv,
                               float scale, float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk,
-                              float* dv, int lddv, RowOrder ro, hipStream_t st) {
+                              float* dv, int lddv, RowOrder ro, float* ds_work, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<G, DROP, ORD>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse,
-                       delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, ro);
-    GAMER_CHECK_LAUNCH("gamer_attn_bwd/dq");
+    if (ds_work == nullptr) {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<G, DROP, ORD>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o,
+                           lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, ro);
+        GAMER_CHECK_LAUNCH("gamer_attn_bwd/dq");
+    } else {
+        hipLaunchKernelGGL(attn_delta_kernel, dim3(2048), dim3(AT_THREADS), 0, st, o, d_o, B, S, nq, delta);
+        GAMER_CHECK_LAUNCH("gamer_attn_bwd/delta");
+    }
     size_t shmem = sizeof(DkvSmem<G>);
     const size_t red_bytes = (size_t)R * 132 * sizeof(float);
     if (shmem < red_bytes) shmem = red_bytes;
@@ -1143,8 +1321,14 @@ static int launch_bwd_variant(const float* q, int ldq, const float* k, int ldk, 
         attr_set = true;
     }
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<G, DROP, ORD>), grid, dim3(AT_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse,
-                       delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro);
+                       delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro,
+                       ds_work);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd/dkv");
+    if (ds_work != nullptr) {
+        hipLaunchKernelGGL((attn_bwd_dq2_kernel<G, ORD>), grid, dim3(AT_THREADS), 0, st, k, ldk, ds_work, row_empty, B, S, nq,
+                           nkv, scale, dq, lddq, ro);
+        GAMER_CHECK_LAUNCH("gamer_attn_bwd/dq2");
+    }
     return 0;
 }
 
@@ -1153,10 +1337,10 @@ static int launch_bwd(const float* q, int ldq, const float* k, int ldk, const fl
                       const float* d_o, const float* lse, float* delta, const int32_t* kl, const int32_t* ql,
                       const int32_t* row_empty, const int32_t* tile_empty, int B, int S, int nq, int nkv, float scale,
                       float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
-                      RowOrder ro, hipStream_t st) {
+                      RowOrder ro, float* ds_work, hipStream_t st) {
 #define GAMER_LAUNCH_BWD(DROPV, ORDV)                                                                                \
     return launch_bwd_variant<G, DROPV, ORDV>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, \
-                                              S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, st)
+                                              S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, ds_work, st)
     if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_BWD(true, true); else GAMER_LAUNCH_BWD(true, false); }
     else { if (ro.perm) GAMER_LAUNCH_BWD(false, true); else GAMER_LAUNCH_BWD(false, false); }
 #undef GAMER_LAUNCH_BWD
@@ -1234,7 +1418,7 @@ extern "C" int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, 
                               const int32_t* ql, const int32_t* row_empty, const int32_t* tile_empty, int B, int S,
                               int nq, int nkv, float scale, float p_drop, uint64_t seed, float* delta, float* dq,
                               int lddq, float* dk, int lddk, float* dv, int lddv, const int32_t* row_perm,
-                              const int32_t* tile_kind, const int32_t* tile_maxpos, void* stream) {
+                              const int32_t* tile_kind, const int32_t* tile_maxpos, float* ds_work, void* stream) {
     int rc = check_attn_common("gamer_attn_bwd", q, k, v, kl, row_empty, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
     if (rc) return rc;
     GAMER_CHECK_ARG(o && d_o && lse && tile_empty && delta && dq && dk && dv, "gamer_attn_bwd: null pointer");
@@ -1245,8 +1429,8 @@ extern "C" int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, 
                     "gamer_attn_bwd: gradient buffers must be 16-byte aligned with leading dims %% 4 == 0");
     hipStream_t st = (hipStream_t)stream;
     switch (nq / nkv) {
-        case 1: return launch_bwd<1>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, st);
-        case 2: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, st);
-        default: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, st);
+        case 1: return launch_bwd<1>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, ds_work, st);
+        case 2: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, ds_work, st);
+        default: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, ds_work, st);
     }
 }

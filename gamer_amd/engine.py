@@ -200,6 +200,11 @@ class _Workspace:
             self.dao = torch.empty(T, NQ, **f32)
             self.delta = torch.empty(B, nq, S, **f32)
             self.norm_partial = torch.empty(2048, H, **f32)
+            # dS spill of the attention backward (5 matmuls per tile pair instead of 7; gamer_attn_bwd):
+            # 6.4 GB at B = 1024, shared by all layers.  GAMER_ATTN_SPILL=0 keeps the two recompute kernels.
+            import os
+            self.ds_work = (torch.empty(ops.attn_ds_work_numel(B, S, nq), **f32)
+                            if os.environ.get("GAMER_ATTN_SPILL", "1") != "0" else None)
 
 
 class Engine:
@@ -486,7 +491,7 @@ class Engine:
                 ops.attn_bwd(A["q_c"], NQ, A["k_c"], NKV, A["qkv_c"][:, NQ + NKV:], QKV, A["ao_c"], ws.dao, A["lse_c"],
                              r["kl_cross"], r["ql_cross"], r["empty_cross"], r["tile_empty_cross"], B, S, nq, nkv,
                              scale, p_att, self._seed(l, 2), ws.delta, ws.dq, NQ, ws.dk, NKV,
-                             ws.dqkv[:, NQ + NKV:], QKV, order=ws.cross_order)
+                             ws.dqkv[:, NQ + NKV:], QKV, order=ws.cross_order, ds_work=ws.ds_work)
                 ops.qknorm_rope_bwd(A["qkv_c"], ws.dq, ws.dk, S, nq, nkv, C["qn"], C["kn"], eps, cos, sin, ws.dqkv,
                                     GC["qn"], GC["kn"], bias_q=C["bq"], bias_k=C["bk"], act_idx=r["act_idx"], nb1=NB1,
                                     dbias_q=GC["bq"], dbias_k=GC["bk"], dbias_v=GC["bv"])
@@ -501,7 +506,7 @@ class Engine:
             ops.linear_dgrad(t0, H, SA["o"], NQ, ws.dao, NQ, T, H, NQ)
             ops.attn_bwd(A["q"], NQ, A["k"], NKV, A["qkv"][:, NQ + NKV:], QKV, A["ao"], ws.dao, A["lse"], r["kl_self"],
                          None, r["empty_self"], r["tile_empty_self"], B, S, nq, nkv, scale, p_att, self._seed(l, 0),
-                         ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV)
+                         ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, ds_work=ws.ds_work)
             ops.qknorm_rope_bwd(A["qkv"], ws.dq, ws.dk, S, nq, nkv, SA["qn"], SA["kn"], eps, cos, sin, ws.dqkv, GS["qn"],
                                 GS["kn"])
             ops.linear_wgrad(ws.dqkv, QKV, A["h1"], H, GS["qkv"], H, T, QKV, H)

@@ -171,11 +171,17 @@ def attn_fwd(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, tile_empty, B, S, nq, nk
 
 
 def attn_bwd(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed,
-             delta, dq, lddq, dk, lddk, dv, lddv, order=None):
+             delta, dq, lddq, dk, lddk, dv, lddv, order=None, ds_work=None):
+    """ds_work: optional fp32 scratch of attn_ds_work_numel(B, S, nq) elements (dS spill, see gamer_hip.h)."""
     pm, tk, tm = order if order is not None else (None, None, None)
     call("gamer_attn_bwd", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), ptr(d_o), ptr(lse), ptr(kl), ptr(ql),
          ptr(row_empty), ptr(tile_empty), B, S, nq, nkv, scale, p_drop, seed, ptr(delta), ptr(dq), lddq, ptr(dk),
-         lddk, ptr(dv), lddv, ptr(pm), ptr(tk), ptr(tm), stream_ptr())
+         lddk, ptr(dv), lddv, ptr(pm), ptr(tk), ptr(tm), ptr(ds_work), stream_ptr())
+
+
+def attn_ds_work_numel(B, S, nq):
+    n = (S + 31) // 32
+    return B * nq * n * n * 1024
 
 
 def residual_dropout_fwd(x, delta, p, seed, src_rows=None, out=None):

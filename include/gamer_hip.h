@@ -182,7 +182,9 @@ int gamer_qknorm_rope_bwd(const float* qkv, const float* dq_rot, const float* dk
  *   generation step.  In the reference's cached decode an empty row is uniform over the keys that existed
  *   when the row was computed (model.py:603-617), so row i spans max(uniform_len, i+1) keys; pass the
  *   prompt length.
- * bwd: delta[b,h,i] = dO.O (written by the dq kernel), then dq and dk/dv kernels, no atomics.
+ * bwd: delta[b,h,i] = dO.O, dq and dk/dv, no atomics.  ds_work == NULL: two recompute kernels (7 matmuls per
+ *   tile pair).  ds_work = B*nq*ceil(S/32)^2*1024 floats of scratch: the dk/dv kernel spills its dS tiles there
+ *   and dq is one matmul per tile that streams them back (5 matmuls; +2 x that many bytes of HBM traffic).
  * ---------------------------------------------------------------------------------------- */
 /* Stable partition of every sequence's query rows: rows with an allowed key first (ascending position),
  * "empty" rows (uniform over all keys, no scores needed) behind them, so that a 32-row wave tile is all
@@ -204,7 +206,7 @@ int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float
                    int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                    float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                    const int32_t* row_perm, const int32_t* tile_kind, const int32_t* tile_maxpos,
-                   void* stream);
+                   float* ds_work, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise pieces of the decoder layer (model.py:147,217,235,241; FFN.py:25-27).

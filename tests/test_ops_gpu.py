@@ -352,7 +352,7 @@ def _attn_ref(q, k, v, ok, nq, nkv, scale, mult=None):
 
 
 def _run_attn(batch, cross, B, S, nq, nkv, p_drop=0.0, seed=1234, q=None, k=None, v=None, d_o=None, router=None,
-              use_order=False):
+              use_order=False, spill=False):
     T = B * S
     if router is None:
         router = ops.alloc_router_outputs(B, S, DEV)
@@ -385,17 +385,19 @@ def _run_attn(batch, cross, B, S, nq, nkv, p_drop=0.0, seed=1234, q=None, k=None
         dk = torch.empty(T, nkv * 64, device=DEV)
         dqkv = torch.zeros(T, ldv, device=DEV)
         dvv = dqkv[:, (nq + nkv) * 64:]
+        ds_work = torch.full((ops.attn_ds_work_numel(B, S, nq),), float("nan"), device=DEV) if spill else None
         ops.attn_bwd(dq_, nq * 64, dk_, nkv * 64, vview, ldv, o, dev(d_o.reshape(T, -1)), lse, kl, ql, re_, te, B, S, nq,
-                     nkv, 0.125, p_drop, seed, delta, dq, nq * 64, dk, nkv * 64, dvv, ldv, order=order)
+                     nkv, 0.125, p_drop, seed, delta, dq, nq * 64, dk, nkv * 64, dvv, ldv, order=order, ds_work=ds_work)
         res.update(dq=dq, dk=dk, dv=dvv)
     return res
 
 
+@pytest.mark.parametrize("spill", [False, True])
 @pytest.mark.parametrize("use_order", [False, True])
 @pytest.mark.parametrize("cross", [False, True])
 @pytest.mark.parametrize("n_items,B,nq,nkv", [(7, 3, 2, 1), (14, 2, 2, 1), (20, 2, 2, 1), (101, 2, 2, 1), (101, 11, 6, 3),
                                               (33, 40, 6, 3)])
-def test_attention_fwd_bwd(cross, n_items, B, nq, nkv, use_order):
+def test_attention_fwd_bwd(cross, n_items, B, nq, nkv, use_order, spill):
     """The last two shapes give every persistent workgroup several (pair, tile) items, the regime the
     train step runs in (LDS reuse across items and tiles).  S = 70 leaves a 32-row wave tile entirely past the
     end of the sequence: its wave has no work and runs ahead of the others (caught an LDS reuse race)."""
@@ -411,7 +413,7 @@ def test_attention_fwd_bwd(cross, n_items, B, nq, nkv, use_order):
     leaves = [t.double().requires_grad_(True) for t in (q, k, v)]
     o_ref, lse_ref, empty = _attn_ref(*leaves, ok, nq, nkv, 0.125)
     (o_ref * d_o.double()).sum().backward()
-    res = _run_attn(batch, cross, B, S, nq, nkv, q=q, k=k, v=v, d_o=d_o, use_order=use_order)
+    res = _run_attn(batch, cross, B, S, nq, nkv, q=q, k=k, v=v, d_o=d_o, use_order=use_order, spill=spill)
     if use_order:
         # the order is a stable partition: normal rows ascending, then empty rows ascending
         perm = res["order"][0].cpu().long()
@@ -427,7 +429,7 @@ def test_attention_fwd_bwd(cross, n_items, B, nq, nkv, use_order):
     e_dq = _rel(res["dq"], leaves[0].grad.reshape(T, -1))
     e_dk = _rel(res["dk"], leaves[1].grad.reshape(T, -1))
     e_dv = _rel(res["dv"], leaves[2].grad.reshape(T, -1))
-    _record(f"attn_cross{int(cross)}_S{S}_B{B}_h{nq}_ord{int(use_order)}", dict(o=e_o, lse=e_l, dq=e_dq, dk=e_dk, dv=e_dv,
+    _record(f"attn_cross{int(cross)}_S{S}_B{B}_h{nq}_ord{int(use_order)}_spill{int(spill)}", dict(o=e_o, lse=e_l, dq=e_dq, dk=e_dk, dv=e_dv,
                                                    empty_rows=int(empty.sum())))
     if cross:
         assert int((empty & batch["attention_mask"].bool()).sum()) > 0, "fixture must contain empty rows"
@@ -461,9 +463,10 @@ def test_attention_left_padding_empty_self_rows():
     assert _rel(res["dv"], leaves[2].grad.reshape(T, -1)) < 5e-5
 
 
+@pytest.mark.parametrize("spill", [False, True])
 @pytest.mark.parametrize("use_order", [False, True])
 @pytest.mark.parametrize("cross", [False, True])
-def test_attention_dropout_mask_consistent_fwd_bwd(cross, use_order):
+def test_attention_dropout_mask_consistent_fwd_bwd(cross, use_order, spill):
     """Recover the keep-mask with q=k=0 and V = one-hot(j) (S <= 64), then check forward and
     backward with that exact mask against the dense reference."""
     B, n_items, nq, nkv, p = 2, 12, 2, 1, 0.2
@@ -495,7 +498,8 @@ def test_attention_dropout_mask_consistent_fwd_bwd(cross, use_order):
     leaves = [t.double().requires_grad_(True) for t in (q, k, v)]
     o_ref, _, _ = _attn_ref(*leaves, ok, nq, nkv, 0.125, mult=mult)
     (o_ref * d_o.double()).sum().backward()
-    res = _run_attn(batch, cross, B, S, nq, nkv, p_drop=p, seed=99, q=q, k=k, v=v, d_o=d_o, use_order=use_order)
+    res = _run_attn(batch, cross, B, S, nq, nkv, p_drop=p, seed=99, q=q, k=k, v=v, d_o=d_o, use_order=use_order,
+                    spill=spill)
     T = B * S
     e = [_rel(res["o"], o_ref.reshape(T, -1)), _rel(res["dq"], leaves[0].grad.reshape(T, -1)),
          _rel(res["dk"], leaves[1].grad.reshape(T, -1)), _rel(res["dv"], leaves[2].grad.reshape(T, -1))]

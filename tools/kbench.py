@@ -75,7 +75,12 @@ def bench_attn(args):
                                  order=od)
         b = lambda: ops.attn_bwd(q, nq * 64, k, nkv * 64, v, qkv.shape[1], o, do, lse, kl, ql, re_, te, B, S, nq, nkv,
                                  0.125, p, 7, delta, dq, nq * 64, dk, nkv * 64, dv, qkv.shape[1], order=od)
+        dsw = torch.empty(ops.attn_ds_work_numel(B, S, nq), device=dev)
+        b2 = lambda: ops.attn_bwd(q, nq * 64, k, nkv * 64, v, qkv.shape[1], o, do, lse, kl, ql, re_, te, B, S, nq, nkv,
+                                  0.125, p, 7, delta, dq, nq * 64, dk, nkv * 64, dv, qkv.shape[1], order=od, ds_work=dsw)
         tf, tb = timeit(f, args.iters), timeit(b, args.iters)
+        tb2 = timeit(b2, args.iters)
+        print(f"attn_{name}: bwd with dS spill {tb2:.3f} ms (recompute {tb:.3f} ms)")
         causal_pairs = B * S * (S + 1) // 2
         print(f"attn_{name}: fwd {tf:.3f} ms ({4 * 64 * nq * npairs / tf / 1e9:.1f} TF alg, "
               f"{4 * 64 * nq * causal_pairs / tf / 1e9:.1f} TF causal-dense)  bwd {tb:.3f} ms "
