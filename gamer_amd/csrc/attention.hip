@@ -970,7 +970,8 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
             }
             if (ds_out != nullptr && (k0 >> 5) + sub < n_qt) {
                 // spill dS for the dQ kernel: tile (head, query tile qt, this wave's 32-key tile) as [query][key]
-                // floats; a store instruction writes two 128-byte rows
+                // floats; a store instruction writes two 128-byte rows (a layout in the reader's register order
+                // makes its loads contiguous but costs this kernel +14 % for 16-byte scattered stores: measured)
                 const int head = kvh * G + hg;
                 float* tile = ds_out + ((((int64_t)b * nq + head) * n_qt + qt) * n_qt + (k0 >> 5) + sub) * 1024;
 #pragma unroll
@@ -1235,6 +1236,118 @@ attn_bwd_dq2_kernel(const float* __restrict__ k, int ldk, const float* __restric
     }
 }
 
+// Streaming form of the dQ kernel for sequences whose K fits in LDS (S <= 573 at head_dim 64): one workgroup per
+// (sample, kv head) keeps ALL its keys in LDS (137 KB at S = 505), so the loop has no staging, no barrier and no
+// branch - four dS loads for tile t+5, 32 LDS fragment reads and 32 MFMAs per step - and each wave keeps five dS
+// tiles (20 KB) in flight: the kernel runs at the rate the spilled dS comes back from HBM.
+template <int G, bool ORD>
+__global__ void __launch_bounds__(AT_THREADS, 1)
+attn_bwd_dq3_kernel(const float* __restrict__ k, int ldk, const float* __restrict__ ds_in,
+                    const int32_t* __restrict__ row_empty, int S, int nq, int nkv, float scale,
+                    float* __restrict__ dq, int lddq, const RowOrder ro) {
+    extern __shared__ __attribute__((aligned(16))) float Kall[];          // [n_all*32][KLD]
+    constexpr int NS = 4 / G;                                              // query-tile streams per head
+    constexpr int RING = 5;                                                // dS tiles in flight per wave
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x / nkv, kvh = blockIdx.x % nkv;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_all = (S + 31) / 32;
+    // fill: eight loads in flight per thread (the matrix pipe idles until K is in place)
+    for (int f0 = tid; f0 < n_all * 32 * 16; f0 += AT_THREADS * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int f = f0 + AT_THREADS * u;
+            const int row = min(f >> 4, S - 1), c4 = (f & 15) << 2;
+            v[u] = *reinterpret_cast<const float4*>(k + ((int64_t)b * S + row) * ldk + kvh * 64 + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int f = f0 + AT_THREADS * u;
+            const int row = f >> 4, c4 = (f & 15) << 2;
+            if (row < n_all * 32) {
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&Kall[row * KLD + c4]) = row < S ? v[u] : z;
+            }
+        }
+    }
+    __syncthreads();
+    const int head = kvh * G + (w % G), stream = w / G;
+    const float* ds_head = ds_in + ((int64_t)b * nq + head) * n_all * n_all * 1024 + r * 32 + 4 * h;
+    for (int m = 0; m * NS < n_all; ++m) {
+        // zigzag over the query tiles so that the streams of a head see the same number of (query, key) tile pairs
+        const int qt = m * NS + ((m & 1) ? NS - 1 - stream : stream);
+        if (qt >= n_all) continue;
+        const int slot = qt * 32 + r;
+        const bool valid_q = slot < S;
+        const int slotc = valid_q ? slot : S - 1;
+        const int iqc = ORD ? ro.perm[(int64_t)b * S + slotc] : slotc;
+        const int64_t tok = (int64_t)b * S + iqc;
+        const bool my_empty = valid_q && row_empty[tok] != 0;
+        int q_hi;
+        bool has_empty;
+        if (ORD) {
+            q_hi = ro.tile_maxpos[(int64_t)b * n_all + qt];
+            has_empty = (ro.tile_kind[(int64_t)b * n_all + qt] & 2) != 0;
+        } else {
+            q_hi = min(S - 1, qt * 32 + 31);
+            has_empty = __any(my_empty ? 1 : 0) != 0;
+        }
+        // the key tiles the dK/dV kernel visited for this query tile (and spilled dS for)
+        const int n_iter = has_empty ? n_all : (q_hi < 0 ? 0 : (q_hi >> 5) + 1);
+        const float* ds_q = ds_head + (int64_t)qt * n_all * 1024;
+        f32x16 dqacc[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
+        auto load_ds = [&](int jt, float4 (&t4)[4]) {                        // tile index clamped: loads are unconditional
+            const float* p = ds_q + (int64_t)min(jt, n_iter - 1) * 1024;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) t4[g4] = *reinterpret_cast<const float4*>(p + 8 * g4);
+        };
+        auto step = [&](int jt, float4 (&tu)[4]) {
+            const float st[16] = {tu[0].x, tu[0].y, tu[0].z, tu[0].w, tu[1].x, tu[1].y, tu[1].z, tu[1].w,
+                                  tu[2].x, tu[2].y, tu[2].z, tu[2].w, tu[3].x, tu[3].y, tu[3].z, tu[3].w};
+            const float* Kt = Kall + jt * 32 * KLD;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int key = rowmap(reg, h);
+                dqacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[key * KLD + r], st[reg], dqacc[0], 0, 0, 0);
+                dqacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[key * KLD + 32 + r], st[reg], dqacc[1], 0, 0, 0);
+            }
+            // pin the refill here: left alone, the scheduler sinks these loads next to their use three steps later
+            __builtin_amdgcn_sched_barrier(0);
+            load_ds(jt + RING, tu);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (n_iter > 0) {
+            float4 ring[RING][4];
+#pragma unroll
+            for (int u = 0; u < RING; ++u) load_ds(u, ring[u]);
+            int jt = 0;
+            for (; jt + RING <= n_iter; jt += RING) {
+#pragma unroll
+                for (int u = 0; u < RING; ++u) step(jt + u, ring[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < RING - 1; ++u)
+                if (jt + u < n_iter) step(jt + u, ring[u]);
+        }
+        if (valid_q) {
+            float* drow = dq + tok * lddq + head * 64;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float4 t4;
+                    t4.x = dqacc[dh][4 * g4 + 0] * scale; t4.y = dqacc[dh][4 * g4 + 1] * scale;
+                    t4.z = dqacc[dh][4 * g4 + 2] * scale; t4.w = dqacc[dh][4 * g4 + 3] * scale;
+                    *reinterpret_cast<float4*>(drow + 32 * dh + 8 * g4 + 4 * h) = t4;
+                }
+            }
+        }
+    }
+}
+
 // Stable partition of the query rows of every sequence: normal rows first (ascending position), empty rows
 // behind them; plus the per-32-slot tile summaries the attention kernels schedule by.
 __global__ void __launch_bounds__(256)
@@ -1325,8 +1438,24 @@ static int launch_bwd_variant(const float* q, int ldq, const float* k, int ldk, 
                        ds_work);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd/dkv");
     if (ds_work != nullptr) {
-        hipLaunchKernelGGL((attn_bwd_dq2_kernel<G, ORD>), grid, dim3(AT_THREADS), 0, st, k, ldk, ds_work, row_empty, B, S, nq,
-                           nkv, scale, dq, lddq, ro);
+        const size_t kall = (size_t)((S + 31) / 32) * 32 * KLD * sizeof(float);
+        if (kall <= 156 * 1024) {
+            static bool attr3 = false;
+            if (!attr3) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq3_kernel<G, ORD>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+                if (e != hipSuccess) {
+                    set_error("gamer_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                    return (int)e;
+                }
+                attr3 = true;
+            }
+            hipLaunchKernelGGL((attn_bwd_dq3_kernel<G, ORD>), dim3(B * nkv), dim3(AT_THREADS), kall, st, k, ldk, ds_work,
+                               row_empty, S, nq, nkv, scale, dq, lddq, ro);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dq2_kernel<G, ORD>), grid, dim3(AT_THREADS), 0, st, k, ldk, ds_work, row_empty, B, S,
+                               nq, nkv, scale, dq, lddq, ro);
+        }
         GAMER_CHECK_LAUNCH("gamer_attn_bwd/dq2");
     }
     return 0;
