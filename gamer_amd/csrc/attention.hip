@@ -1240,30 +1240,31 @@ attn_bwd_dq2_kernel(const float* __restrict__ k, int ldk, const float* __restric
 // (sample, kv head) keeps ALL its keys in LDS (137 KB at S = 505), so the loop has no staging, no barrier and no
 // branch - four dS loads for tile t+5, 32 LDS fragment reads and 32 MFMAs per step - and each wave keeps five dS
 // tiles (20 KB) in flight: the kernel runs at the rate the spilled dS comes back from HBM.
+constexpr int DQ3_THREADS = 512;          // two waves per SIMD: twice the dS tiles in flight per CU
 template <int G, bool ORD>
-__global__ void __launch_bounds__(AT_THREADS, 1)
+__global__ void __launch_bounds__(DQ3_THREADS, 1)
 attn_bwd_dq3_kernel(const float* __restrict__ k, int ldk, const float* __restrict__ ds_in,
                     const int32_t* __restrict__ row_empty, int S, int nq, int nkv, float scale,
                     float* __restrict__ dq, int lddq, const RowOrder ro) {
     extern __shared__ __attribute__((aligned(16))) float Kall[];          // [n_all*32][KLD]
-    constexpr int NS = 4 / G;                                              // query-tile streams per head
+    constexpr int NS = (DQ3_THREADS / 64) / G;                             // query-tile streams per head
     constexpr int RING = 5;                                                // dS tiles in flight per wave
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = blockIdx.x / nkv, kvh = blockIdx.x % nkv;
     const int r = lane & 31, h = lane >> 5;
     const int n_all = (S + 31) / 32;
     // fill: eight loads in flight per thread (the matrix pipe idles until K is in place)
-    for (int f0 = tid; f0 < n_all * 32 * 16; f0 += AT_THREADS * 8) {
+    for (int f0 = tid; f0 < n_all * 32 * 16; f0 += DQ3_THREADS * 8) {
         float4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int f = f0 + AT_THREADS * u;
+            const int f = f0 + DQ3_THREADS * u;
             const int row = min(f >> 4, S - 1), c4 = (f & 15) << 2;
             v[u] = *reinterpret_cast<const float4*>(k + ((int64_t)b * S + row) * ldk + kvh * 64 + c4);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int f = f0 + AT_THREADS * u;
+            const int f = f0 + DQ3_THREADS * u;
             const int row = f >> 4, c4 = (f & 15) << 2;
             if (row < n_all * 32) {
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1450,7 +1451,7 @@ static int launch_bwd_variant(const float* q, int ldq, const float* k, int ldk, 
                 }
                 attr3 = true;
             }
-            hipLaunchKernelGGL((attn_bwd_dq3_kernel<G, ORD>), dim3(B * nkv), dim3(AT_THREADS), kall, st, k, ldk, ds_work,
+            hipLaunchKernelGGL((attn_bwd_dq3_kernel<G, ORD>), dim3(B * nkv), dim3(DQ3_THREADS), kall, st, k, ldk, ds_work,
                                row_empty, S, nq, nkv, scale, dq, lddq, ro);
         } else {
             hipLaunchKernelGGL((attn_bwd_dq2_kernel<G, ORD>), grid, dim3(AT_THREADS), 0, st, k, ldk, ds_work, row_empty, B, S,
