@@ -12,7 +12,11 @@ throughput run uses synthetic sequences with the *format* of
 * ``actions`` = behaviour *level* of the token's item (here level == b), padded with 100;
 * ``labels`` = input_ids with pad and behaviour tokens replaced by -100
   (collator.py:68-73 with ignore_behavior_tokens);
-* ``session_ids`` / ``extended_session_ids`` are present but unused by Qwen3Multi.
+* ``session_ids`` / ``extended_session_ids``: unused by Qwen3Multi (one session per item by default); with
+  ``session_mean`` the items are grouped into sessions of random length the way
+  ``_generate_session_ids`` / ``_generate_extended_session_ids`` (SMB_dataset.py:194-222) lay them out:
+  the raw session id repeated over the item's 5 tokens, and 5 * (session rank) + (token in item) as the
+  RoPE position, both right padded with 0.  This is what Qwen3SessionMulti consumes.
 """
 from __future__ import annotations
 
@@ -42,12 +46,14 @@ def behavior_maps(codebook: int = 256, num_behavior: int = 3) -> Dict[int, int]:
 def make_batch(batch_size: int, n_items: int = 101, codebook: int = 256, num_behavior: int = 3,
                ragged: bool = False, min_items: int = 2, seed: int = 20251114,
                behavior_probs: Optional[Sequence[float]] = None,
-               pad_rows: Optional[Dict[int, int]] = None) -> Dict[str, torch.Tensor]:
+               pad_rows: Optional[Dict[int, int]] = None,
+               session_mean: Optional[float] = None) -> Dict[str, torch.Tensor]:
     """One collated batch (CPU int64 tensors).
 
     ``ragged``: n_items ~ U{min_items..n_items} per row, right padded to the batch max.
     ``pad_rows``: {row: items_to_drop} for hand-placed padding (used by the golden fixtures).
     ``behavior_probs``: categorical over behaviours (default uniform).
+    ``session_mean``: mean number of items per session (None: every item is its own session).
     """
     g = torch.Generator().manual_seed(seed)
     if behavior_probs is None:
@@ -76,8 +82,21 @@ def make_batch(batch_size: int, n_items: int = 101, codebook: int = 256, num_beh
     labels[~valid] = -100
     labels[:, ::TOKENS_PER_ITEM] = -100          # behaviour tokens are not predicted
     item_index = torch.arange(S) // TOKENS_PER_ITEM
-    session = torch.where(valid, item_index[None, :].expand(batch_size, S), torch.zeros_like(ids))
-    ext = torch.where(valid, torch.arange(S)[None, :].expand(batch_size, S), torch.zeros_like(ids))
+    if session_mean is None:
+        session = torch.where(valid, item_index[None, :].expand(batch_size, S), torch.zeros_like(ids))
+        ext = torch.where(valid, torch.arange(S)[None, :].expand(batch_size, S), torch.zeros_like(ids))
+    else:
+        gs = torch.Generator().manual_seed(seed + 7919)      # own stream: the token draws above stay as they were
+        new = torch.rand(batch_size, max_items, generator=gs) < (1.0 / float(session_mean))
+        new[:, 0] = True
+        rank = torch.cumsum(new.to(torch.int64), dim=1) - 1                          # session rank of every item
+        base = torch.randint(0, 4, (batch_size, 1), generator=gs)                    # raw ids need not start at 0
+        gap = torch.randint(1, 3, (batch_size, max_items), generator=gs) * new       # nor be consecutive
+        raw = base + torch.cumsum(gap, dim=1) - gap[:, :1]
+        session = torch.where(valid, raw.repeat_interleave(TOKENS_PER_ITEM, dim=1), torch.zeros_like(ids))
+        tok_in_item = (torch.arange(S) % TOKENS_PER_ITEM)[None, :]
+        ext = torch.where(valid, rank.repeat_interleave(TOKENS_PER_ITEM, dim=1) * TOKENS_PER_ITEM + tok_in_item,
+                          torch.zeros_like(ids))
     return {
         "input_ids": ids.contiguous(),
         "attention_mask": valid.to(torch.int64).contiguous(),

@@ -59,8 +59,9 @@ def _install_shims():
         sys.modules[name] = pkg
 
 
-def load_reference_classes():
-    """Returns (Qwen3MultiWithTemperature, Qwen3MoeConfig) from the reference."""
+def load_reference_classes(session: bool = False):
+    """Returns (Qwen3MultiWithTemperature, Qwen3MoeConfig) from the reference; ``session=True`` returns
+    Qwen3SessionMultiWithTemperature (train_SMB_decoder.py:365-367) instead."""
     if not reference_available():
         raise RuntimeError(f"reference not found under {REF_ROOT}")
     _install_shims()
@@ -72,8 +73,11 @@ def load_reference_classes():
             pkg.__spec__ = importlib.machinery.ModuleSpec(parent, None, is_package=True)
             pkg.__spec__.submodule_search_locations = pkg.__path__
             sys.modules[parent] = pkg
-    from SeqRec.models.generative.Qwen3Multi.model import Qwen3MultiWithTemperature
     from transformers.models.qwen3_moe import Qwen3MoeConfig
+    if session:
+        from SeqRec.models.generative.Qwen3SessionMulti.model import Qwen3SessionMultiWithTemperature
+        return Qwen3SessionMultiWithTemperature, Qwen3MoeConfig
+    from SeqRec.models.generative.Qwen3Multi.model import Qwen3MultiWithTemperature
     return Qwen3MultiWithTemperature, Qwen3MoeConfig
 
 

@@ -46,6 +46,16 @@ CASES = {
         codebook=8, B=3, n_items=9, pad_rows={1: 4, 2: 1}, seed=12, wseed=6, full=True),
     # the shipped architecture, V=1041, S=505 (max_his_len=100), one row padded by 10 items
     "full": dict(dims=dict(), codebook=256, B=4, n_items=101, pad_rows={1: 10}, seed=1, wseed=0, full=False),
+    # Qwen3SessionMulti (same weights, session-wise masks, RoPE positions = extended_session_ids): items grouped
+    # into sessions of random length, raw session ids neither 0-based nor consecutive
+    "session_small": dict(
+        dims=dict(hidden_size=128, num_hidden_layers=4, num_attention_heads=2, num_key_value_heads=1,
+                  head_dim=64, intermediate_size=256, moe_intermediate_size=128, behavior_embedding_dim=64,
+                  behavior_injection_decoder=[0, 1], cross_attention_decoder=[2, 3],
+                  sparse_layers_decoder=[0, 1, 2, 3]),
+        codebook=8, B=4, n_items=15, pad_rows={1: 4, 2: 1}, seed=21, wseed=6, full=True, session_mean=2.5),
+    "session_full": dict(dims=dict(), codebook=256, B=4, n_items=101, pad_rows={1: 10}, seed=2, wseed=0, full=False,
+                         session_mean=4.0),
 }
 
 
@@ -55,7 +65,8 @@ def fp64_checksums(sd):
 
 
 def run_case(name, spec):
-    Model, Cfg = _ref_loader.load_reference_classes()
+    session = spec.get("session_mean") is not None
+    Model, Cfg = _ref_loader.load_reference_classes(session=session)
     cb, NB = spec["codebook"], 3
     V = synthetic.vocab_size(cb, NB)
     bmaps = synthetic.behavior_maps(cb, NB)
@@ -68,7 +79,8 @@ def run_case(name, spec):
     model.set_hyper(0.7)
     missing = model.load_state_dict({**sd, "lm_head.weight": sd["model.embed_tokens.weight"]}, strict=True)
     assert model.lm_head.weight.data_ptr() == model.model.embed_tokens.weight.data_ptr(), "head not tied"
-    batch = synthetic.make_batch(spec["B"], spec["n_items"], cb, NB, seed=spec["seed"], pad_rows=spec["pad_rows"])
+    batch = synthetic.make_batch(spec["B"], spec["n_items"], cb, NB, seed=spec["seed"], pad_rows=spec["pad_rows"],
+                                 session_mean=spec.get("session_mean"))
     fwd_in = dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
                   session_ids=batch["session_ids"], extended_session_ids=batch["extended_session_ids"],
                   actions=batch["actions"])
@@ -99,6 +111,7 @@ def run_case(name, spec):
     res.update(
         input_ids=batch["input_ids"].numpy(), attention_mask=batch["attention_mask"].numpy(),
         actions=batch["actions"].numpy(), labels=batch["labels"].numpy(),
+        session_ids=batch["session_ids"].numpy(), extended_session_ids=batch["extended_session_ids"].numpy(),
         router_position=pos.numpy().astype(np.int16), router_behavior=beh.numpy().astype(np.int16),
         router_action=act.numpy().astype(np.int16),
         loss_mean=np.float64(loss_mean), loss_sum=np.float64(loss_sum), num_items=np.float64(n_items_tok),
@@ -135,6 +148,7 @@ def run_case(name, spec):
                                    "behavior_maps": {str(k): v for k, v in bmaps.items()}},
                 codebook=cb, temperature=0.7, weight_seed=spec["wseed"], batch_seed=spec["seed"],
                 n_items=spec["n_items"], pad_rows={str(k): v for k, v in spec["pad_rows"].items()},
+                model="Qwen3SessionMultiWithTemperature" if session else "Qwen3MultiWithTemperature",
                 generator=dict(torch=torch.__version__, transformers=__import__("transformers").__version__,
                                reference="wzf2000/GAMER @ /root/reference", sdpa_backend_for_grads="MATH"))
     res["meta_json"] = np.array(json.dumps(meta))

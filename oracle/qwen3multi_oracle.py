@@ -19,6 +19,9 @@ Reference sites restated (``ref:`` = wzf2000/GAMER):
   sparse FFN    ref:SeqRec/models/generative/Qwen3Moe/FFN.py:25-27,53-72
   model forward ref:SeqRec/models/generative/Qwen3Multi/model.py:744-880
   head + loss   ref:SeqRec/models/generative/Qwen3Multi/model.py:904-922,928-1013
+  session variant (Qwen3SessionMulti: same weights and layers, session-wise masks, RoPE positions =
+                extended_session_ids)  ref:SeqRec/models/generative/Qwen3SessionMulti/model.py:545-551 (in-item mask),
+                :556-613 (cross), :676-728 (self), :784-806 (both built per forward), :969-984 (positions)
   RMSNorm/RoPE/CE: third-party ``transformers`` (pinned 4.51.0 in ref:requirements.txt:9):
                 models/qwen3/modeling_qwen3.py (Qwen3RMSNorm, rotate_half, apply_rotary_pos_emb,
                 Qwen3RotaryEmbedding), loss/loss_utils.py (ForCausalLMLoss, fixed_cross_entropy).
@@ -113,6 +116,27 @@ def mask_predicates(attention_mask: torch.Tensor, actions: torch.Tensor):
     return self_ok, cross_ok
 
 
+def session_mask_predicates(attention_mask: torch.Tensor, actions: torch.Tensor, session_ids: torch.Tensor, P: int):
+    """Qwen3SessionMulti masks as 'allowed' predicates [B,S,S] (query i, key j).
+
+    self  (model.py:676-728 ``_update_session_wise_causal_mask``): finfo.min * in_item_mask * (sess_j >= sess_i),
+          in_item_mask = 1 - (I + strictly-lower triangle inside every block of P positions) (model.py:545-551):
+          a key is visible when it is the query itself or an earlier token of the query's item, or when it
+          belongs to a strictly earlier session; other items of the query's own session are hidden.
+    cross (model.py:556-613): masked when sess_j >= sess_i or act_j >= act_i.
+    Both then mask padded keys (allowed & attention_mask == 0 -> finfo.min).  Nothing else enforces causality:
+    it follows from session ids that do not decrease along the sequence."""
+    B, S = attention_mask.shape
+    keep = attention_mask.bool()
+    i = torch.arange(S).view(1, S, 1)
+    j = torch.arange(S).view(1, 1, S)
+    in_item = (torch.div(j, P, rounding_mode="floor") == torch.div(i, P, rounding_mode="floor")) & (j <= i)
+    earlier = session_ids[:, None, :] < session_ids[:, :, None]
+    self_ok = (in_item | earlier) & keep[:, None, :]
+    cross_ok = earlier & (actions[:, None, :] < actions[:, :, None]) & keep[:, None, :]
+    return self_ok, cross_ok
+
+
 # --------------------------------------------------------------------------------------
 # float part
 # --------------------------------------------------------------------------------------
@@ -140,7 +164,9 @@ def rotate_half(x):
 
 
 def apply_rope(x, cos, sin):
-    """x [B,S,heads,dh]; cos/sin [S,dh]."""
+    """x [B,S,heads,dh]; cos/sin [S,dh] (positions = arange) or [B,S,dh] (per-token positions)."""
+    if cos.dim() == 3:
+        return x * cos[:, :, None, :] + rotate_half(x) * sin[:, :, None, :]
     return x * cos[None, :, None, :] + rotate_half(x) * sin[None, :, None, :]
 
 
@@ -216,8 +242,11 @@ def sparse_mlp(h, sd, prefix, pos_idx, beh_idx, cfg: OracleConfig, inject: bool,
 def forward(sd: Dict[str, torch.Tensor], cfg: OracleConfig, input_ids, attention_mask, actions,
             labels=None, temperature: float = 1.0, num_items_in_batch: Optional[float] = None,
             training: bool = False, return_hidden: bool = False, act_zero_col: Optional[int] = None,
-            uniform_len: Optional[int] = None):
+            uniform_len: Optional[int] = None, session_ids=None, extended_session_ids=None):
     """Qwen3MultiWithTemperature.forward (model.py:928-1013).
+
+    ``session_ids`` given: the Qwen3SessionMulti variant (``session_mask_predicates``; with
+    ``extended_session_ids`` as the RoPE positions, Qwen3SessionMulti/model.py:983-984).
 
     ``act_zero_col``: evaluation prompts end with the target item's behaviour token (S = 5n+1); the reference's
     router then looks up only n items (router.py:160-163 with cache_position) and that token gets action index 0,
@@ -236,8 +265,16 @@ def forward(sd: Dict[str, torch.Tensor], cfg: OracleConfig, input_ids, attention
     if act_zero_col is not None:
         act_idx = act_idx.clone()
         act_idx[:, act_zero_col] = 0
-    self_ok, cross_ok = mask_predicates(attention_mask, actions)
-    cos, sin = rope_tables(S, cfg.head_dim, cfg.rope_theta, dtype)
+    if session_ids is not None:
+        self_ok, cross_ok = session_mask_predicates(attention_mask, actions, session_ids, cfg.num_positions)
+    else:
+        self_ok, cross_ok = mask_predicates(attention_mask, actions)
+    if extended_session_ids is not None:
+        n_pos = max(S, int(extended_session_ids.max()) + 1)
+        cos, sin = rope_tables(n_pos, cfg.head_dim, cfg.rope_theta, dtype)
+        cos, sin = cos[extended_session_ids], sin[extended_session_ids]       # [B,S,dh]
+    else:
+        cos, sin = rope_tables(S, cfg.head_dim, cfg.rope_theta, dtype)
     # nn.Embedding(vocab, H, padding_idx=pad) (model.py:263): the gather-side gradient of the pad row is dropped
     x = F.embedding(input_ids, sd["model.embed_tokens.weight"], padding_idx=cfg.pad_token_id)
     hidden = [] if return_hidden else None      # model.py:822-873: input of every layer + final norm
@@ -351,7 +388,7 @@ def is_no_decay(key: str) -> bool:
     return key.endswith(NO_DECAY_SUFFIXES)
 
 
-def loss_and_grads(sd, cfg, batch, temperature=1.0, num_items_in_batch=None, training=False):
+def loss_and_grads(sd, cfg, batch, temperature=1.0, num_items_in_batch=None, training=False, session=False):
     """Forward + autograd backward; returns (loss, {key: grad}, forward-output) with the tied
     table's gradient under 'model.embed_tokens.weight' (head wgrad over all rows + gather
     scatter-add with the padding row's contribution dropped, as nn.Embedding(padding_idx) does)."""
@@ -360,7 +397,9 @@ def loss_and_grads(sd, cfg, batch, temperature=1.0, num_items_in_batch=None, tra
     view["lm_head.weight"] = leaves["model.embed_tokens.weight"]
     out = forward(view, cfg, batch["input_ids"], batch.get("attention_mask"), batch["actions"],
                   labels=batch.get("labels"), temperature=temperature,
-                  num_items_in_batch=num_items_in_batch, training=training)
+                  num_items_in_batch=num_items_in_batch, training=training,
+                  session_ids=batch["session_ids"] if session else None,
+                  extended_session_ids=batch["extended_session_ids"] if session else None)
     out["loss"].backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
     return out["loss"].detach(), grads, out

@@ -11,10 +11,20 @@ def _setup(golden, name):
     cfg = OracleConfig.from_dict(meta["config"])
     sd = init_state_dict(cfg, seed=meta["weight_seed"])
     batch = {k: torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "actions", "labels")}
+    if name.startswith("session"):
+        batch["session_ids"] = torch.from_numpy(z["session_ids"])
+        batch["extended_session_ids"] = torch.from_numpy(z["extended_session_ids"])
     return z, meta, cfg, sd, batch
 
 
-@pytest.mark.parametrize("name", ["tiny", "small", "full"])
+def _skw(batch):
+    """session fixtures (Qwen3SessionMulti): the oracle takes the session ids and the RoPE positions"""
+    if "session_ids" not in batch:
+        return {}
+    return dict(session_ids=batch["session_ids"], extended_session_ids=batch["extended_session_ids"])
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "full", "session_small", "session_full"])
 def test_weight_fill_is_reproducible(golden, name):
     z, meta, cfg, sd, _ = _setup(golden, name)
     keys = [str(k) for k in z["weight_keys"]]
@@ -23,7 +33,7 @@ def test_weight_fill_is_reproducible(golden, name):
     np.testing.assert_allclose(sums, z["weight_checksums"], rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("name", ["tiny", "small", "full"])
+@pytest.mark.parametrize("name", ["tiny", "small", "full", "session_small", "session_full"])
 def test_router_bit_exact(golden, name):
     z, meta, cfg, sd, batch = _setup(golden, name)
     pos, beh, act = router(batch["input_ids"], cfg)
@@ -32,40 +42,41 @@ def test_router_bit_exact(golden, name):
     assert np.array_equal(act.numpy(), z["router_action"].astype(np.int64))
 
 
-@pytest.mark.parametrize("name", ["tiny", "small"])
+@pytest.mark.parametrize("name", ["tiny", "small", "session_small"])
 def test_forward_full_tensors(golden, name):
     z, meta, cfg, sd, batch = _setup(golden, name)
     with torch.no_grad():
-        out = forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["actions"], return_hidden=True)
+        out = forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["actions"], return_hidden=True, **_skw(batch))
         np.testing.assert_allclose(out["logits"].numpy(), z["logits_raw"], atol=1e-5, rtol=0)
         np.testing.assert_allclose(out["hidden_states"][-1].numpy(), z["hidden_last"], atol=1e-5, rtol=0)
         np.testing.assert_allclose(out["hidden_states"][1].numpy(), z["hidden_layer1"], atol=1e-5, rtol=0)
         out_l = forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["actions"],
-                        labels=batch["labels"], temperature=meta["temperature"])
+                        labels=batch["labels"], temperature=meta["temperature"], **_skw(batch))
         np.testing.assert_allclose(out_l["logits"].numpy(), z["logits_scaled"], atol=1e-5, rtol=0)
         assert abs(float(out_l["loss"]) - float(z["loss_mean"])) < 2e-6
         out_n = forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["actions"],
                         labels=batch["labels"], temperature=meta["temperature"],
-                        num_items_in_batch=float(z["num_items"]))
+                        num_items_in_batch=float(z["num_items"]), **_skw(batch))
         assert abs(float(out_n["loss"]) - float(z["loss_sum"])) < 2e-6
 
 
-def test_forward_full_config_samples(golden):
-    z, meta, cfg, sd, batch = _setup(golden, "full")
+@pytest.mark.parametrize("name", ["full", "session_full"])
+def test_forward_full_config_samples(golden, name):
+    z, meta, cfg, sd, batch = _setup(golden, name)
     with torch.no_grad():
-        out = forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["actions"], return_hidden=True)
+        out = forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["actions"], return_hidden=True, **_skw(batch))
         np.testing.assert_allclose(out["logits"][:, ::37, ::53].numpy(), z["logits_raw_sample"], atol=1e-5, rtol=0)
         hs = np.array([float(h.double().sum()) for h in out["hidden_states"]])
         np.testing.assert_allclose(hs, z["hidden_sum"], rtol=1e-4, atol=1e-2)
         out_l = forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["actions"],
-                        labels=batch["labels"], temperature=meta["temperature"])
+                        labels=batch["labels"], temperature=meta["temperature"], **_skw(batch))
         assert abs(float(out_l["loss"]) - float(z["loss_mean"])) < 2e-6
 
 
-@pytest.mark.parametrize("name", ["tiny", "small", "full"])
+@pytest.mark.parametrize("name", ["tiny", "small", "full", "session_small", "session_full"])
 def test_gradients(golden, name):
     z, meta, cfg, sd, batch = _setup(golden, name)
-    loss, grads, _ = loss_and_grads(sd, cfg, batch, temperature=meta["temperature"])
+    loss, grads, _ = loss_and_grads(sd, cfg, batch, temperature=meta["temperature"], session="session_ids" in batch)
     assert abs(float(loss) - float(z["loss_train_mode"])) < 2e-6
     gkeys = [str(k) for k in z["grad_keys"]]
     assert gkeys == sorted(grads)
@@ -95,3 +106,20 @@ def test_empty_rows_exist_in_fixtures(golden):
     empty = ~cross_ok.any(-1)
     nonpad = batch["attention_mask"].bool()
     assert bool((empty & nonpad).any()) and bool((~empty & nonpad).any())
+
+
+def test_session_fixture_exercises_the_session_masks(golden):
+    """The session fixture must hold sessions of several items (keys of the query's own session hidden from the
+    self attention), empty cross rows and empty self rows (padded queries), so that every branch of
+    ``session_mask_predicates`` is pinned by the reference's outputs; and the session masks must differ from
+    Qwen3Multi's on it."""
+    from oracle.qwen3multi_oracle import mask_predicates, session_mask_predicates
+    z, meta, cfg, sd, batch = _setup(golden, "session_small")
+    self_ok, cross_ok = session_mask_predicates(batch["attention_mask"], batch["actions"], batch["session_ids"], 5)
+    base_self, base_cross = mask_predicates(batch["attention_mask"], batch["actions"])
+    nonpad = batch["attention_mask"].bool()
+    assert bool((base_self & ~self_ok)[nonpad].any()), "no hidden same-session key"
+    assert bool((base_cross & ~cross_ok)[nonpad].any())
+    assert bool(((~cross_ok.any(-1)) & nonpad).any()) and bool((cross_ok.any(-1) & nonpad).any())
+    assert bool((~self_ok.any(-1) & ~nonpad).any()), "no empty self row among the padded queries"
+    assert not bool((self_ok & ~base_self).any()), "session ids of the fixture must keep the masks causal"
