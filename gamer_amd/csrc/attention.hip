@@ -2,7 +2,8 @@
 //
 // Replaces sdpa_attention_forward + the two additive [B,1,S,S] masks of the reference
 // (ref:SeqRec/models/generative/Qwen3Multi/model.py:133-143, 573-630, 691-741): the masks are the
-// predicate  allowed(i,j) = j<=i && kl[j] < ql[i]  evaluated in registers, and a query row that has
+// predicate  allowed(i,j) = j<=i && kl[j] < ql[i]  evaluated in registers (the Qwen3SessionMulti variant adds a
+// per-query key span, see QuerySpan), and a query row that has
 // no allowed key ("empty" row, flagged by the router kernel) gets p = 1/S over ALL S keys exactly as
 // the reference's finfo.min mask does, in the forward and in both backward kernels.
 //
@@ -41,6 +42,26 @@ struct RowOrder {
     const int32_t* perm;         // [B,S] sorted slot -> position in the sequence
     const int32_t* tile_kind;    // [B,ceil(S/32)] bit0: has normal rows, bit1: has empty rows
     const int32_t* tile_maxpos;  // [B,ceil(S/32)] largest position of a normal row in the tile, -1 if none
+    const int32_t* span;         // [B,S,4] optional per-query key span (QuerySpan); travels with the row metadata
+};
+
+// Session-wise masks (ref:SeqRec/models/generative/Qwen3SessionMulti/model.py:556-613, 676-728) as a per-query
+// key span: key j is allowed iff j <= hi and not (hole_lo <= j < hole_hi) (and kl[j] < ql[i] as always), hi <= i.
+// Kernels instantiated with SPAN = false use hi = i and no hole (Qwen3Multi) and carry none of this.
+struct QuerySpan {
+    int hi, hole_lo, hole_hi;
+    template <bool SPAN>
+    static __device__ __forceinline__ QuerySpan load(const int32_t* __restrict__ span, int64_t tok, int pos, bool valid, int S) {
+        QuerySpan q;
+        q.hi = valid ? pos : S;              // rows past the end: beyond every key (never stored)
+        q.hole_lo = INT_BIG_A;
+        q.hole_hi = 0;
+        if (SPAN && valid) {
+            const int4 t = reinterpret_cast<const int4*>(span)[tok];
+            q.hi = t.x; q.hole_lo = t.y; q.hole_hi = t.z;
+        }
+        return q;
+    }
 };
 
 // Static work partition for persistent workgroups.
@@ -178,7 +199,7 @@ constexpr float RESCALE_TAU = 20.f;
         ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kk][3], ACC, 0, 0, 0);                     \
     }
 
-template <int G, bool DROP, bool ORD>
+template <int G, bool DROP, bool ORD, bool SPAN>
 __device__ __forceinline__ void
 attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
               const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
@@ -222,9 +243,12 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
     const int my_ql = ql ? ql[tok] : 1;
     const bool my_empty = valid_q && row_empty[tok] != 0;
     const bool normal = valid_q && !my_empty;
+    const QuerySpan sp = QuerySpan::load<SPAN>(ro.span, tok, iq_raw, valid_q, S);
     const int wave_ql_min = wave_min_i32(normal ? my_ql : INT_BIG_A);
-    const int wave_q_lo = wave_min_i32(normal ? iq : INT_BIG_A);
+    const int wave_q_lo = wave_min_i32(normal ? sp.hi : INT_BIG_A);   // every key up to here passes every row's limit
     const bool wave_all_empty = wave_q_lo == INT_BIG_A;          // no normal row: no scores needed at all
+    const int wave_hole_lo = SPAN ? wave_min_i32(normal ? sp.hole_lo : INT_BIG_A) : INT_BIG_A;
+    const int wave_hole_hi = SPAN ? wave_max_i32(normal ? sp.hole_hi : 0) : 0;
     const int n_all = (S + 31) / 32;
     int wave_q_hi, n_causal;
     bool wave_has_empty;
@@ -323,10 +347,13 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                 if (MASK) {
                     int klv[16];
                     read_key_quads(km.kl, h, klv);
-                    const int t_pos = iq - j0 - 4 * h;           // key (reg&3)+8*(reg>>2) of the tile is <= iq
+                    const int t_pos = sp.hi - j0 - 4 * h;        // key (reg&3)+8*(reg>>2) of the tile is <= hi (= iq)
+                    const int t_lo = sp.hole_lo - j0 - 4 * h, t_hi = sp.hole_hi - j0 - 4 * h;
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const bool allowed = (((reg & 3) + 8 * (reg >> 2)) <= t_pos) & (klv[reg] < my_ql);
+                        const int ko = (reg & 3) + 8 * (reg >> 2);
+                        bool allowed = (ko <= t_pos) & (klv[reg] < my_ql);
+                        if (SPAN) allowed = allowed & !((ko >= t_lo) & (ko < t_hi));
                         st_cur[reg] = allowed ? st_cur[reg] : -INFINITY;
                     }
                 }
@@ -386,7 +413,8 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                 softmax_tile.template operator()<true, true>();
             } else {
                 const int klmax = __builtin_amdgcn_readfirstlane(km.klmax);
-                const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min);
+                const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min) &&
+                                       (!SPAN || j0 + 31 < wave_hole_lo || j0 >= wave_hole_hi);
                 if (free_tile) softmax_tile.template operator()<false, false>();
                 else softmax_tile.template operator()<true, false>();
             }
@@ -434,7 +462,7 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
     }
 }
 
-template <int G, bool DROP, bool ORD>
+template <int G, bool DROP, bool ORD, bool SPAN>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                 const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
@@ -452,7 +480,7 @@ attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ 
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {                    // one inlined body (register pressure)
             if (pass == 1 && light == heavy) break;
-            attn_fwd_tile<G, DROP, ORD>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed, o, lse,
+            attn_fwd_tile<G, DROP, ORD, SPAN>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed, o, lse,
                                         ro, pair, pass == 0 ? heavy : light, uspan);
         }
     }
@@ -461,7 +489,7 @@ attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ 
 // =============================================================================================
 // backward: dQ
 // =============================================================================================
-template <int G, bool DROP, bool ORD>
+template <int G, bool DROP, bool ORD, bool SPAN>
 __device__ __forceinline__ void
 attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                    const float* __restrict__ v, int ldv, const float* __restrict__ o, const float* __restrict__ d_o,
@@ -485,7 +513,6 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
     const bool valid_q = slot < S;
     const int slotc = valid_q ? slot : S - 1;
     const int iq_raw = ORD ? ro.perm[(int64_t)b * S + slotc] : slotc;
-    const int iq = valid_q ? iq_raw : S;                // position in the sequence (S: beyond every key)
     const int iqc = iq_raw;
     const int64_t tok = (int64_t)b * S + iqc;
 
@@ -513,10 +540,13 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
     const int my_ql = ql ? ql[tok] : 1;
     const bool my_empty = valid_q && row_empty[tok] != 0;
     const bool normal = valid_q && !my_empty;
+    const QuerySpan sp = QuerySpan::load<SPAN>(ro.span, tok, iq_raw, valid_q, S);
     const float neg_lse2 = -lse[((int64_t)b * nq + head) * S + iqc] * 1.4426950408889634f;
     const int wave_ql_min = wave_min_i32(normal ? my_ql : INT_BIG_A);
-    const int wave_q_lo = wave_min_i32(normal ? iq : INT_BIG_A);
+    const int wave_q_lo = wave_min_i32(normal ? sp.hi : INT_BIG_A);
     const bool wave_all_empty = wave_q_lo == INT_BIG_A;
+    const int wave_hole_lo = SPAN ? wave_min_i32(normal ? sp.hole_lo : INT_BIG_A) : INT_BIG_A;
+    const int wave_hole_hi = SPAN ? wave_max_i32(normal ? sp.hole_hi : 0) : 0;
     const int n_all = (S + 31) / 32;
     int wave_q_hi, n_causal;
     bool wave_has_empty;
@@ -632,10 +662,13 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
                 if (MASK) {
                     int klv[16];
                     read_key_quads(km.kl, h, klv);
-                    const int t_pos = iq - j0 - 4 * h;
+                    const int t_pos = sp.hi - j0 - 4 * h;
+                    const int t_lo = sp.hole_lo - j0 - 4 * h, t_hi = sp.hole_hi - j0 - 4 * h;
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const bool allowed = (((reg & 3) + 8 * (reg >> 2)) <= t_pos) & (klv[reg] < my_ql);
+                        const int ko = (reg & 3) + 8 * (reg >> 2);
+                        bool allowed = (ko <= t_pos) & (klv[reg] < my_ql);
+                        if (SPAN) allowed = allowed & !((ko >= t_lo) & (ko < t_hi));
                         st[reg] = allowed ? st[reg] : -INFINITY;
                     }
                 }
@@ -652,7 +685,8 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
                 ds_tile.template operator()<true, true>();
             } else {
                 const int klmax = __builtin_amdgcn_readfirstlane(km.klmax);
-                const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min);
+                const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min) &&
+                                       (!SPAN || j0 + 31 < wave_hole_lo || j0 >= wave_hole_hi);
                 if (free_tile) ds_tile.template operator()<false, false>();
                 else ds_tile.template operator()<true, false>();
             }
@@ -683,7 +717,7 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
     }
 }
 
-template <int G, bool DROP, bool ORD>
+template <int G, bool DROP, bool ORD, bool SPAN>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                    const float* __restrict__ v, int ldv, const float* __restrict__ o, const float* __restrict__ d_o,
@@ -702,7 +736,7 @@ attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
-            attn_bwd_dq_tile<G, DROP, ORD>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, S, nq, nkv, scale,
+            attn_bwd_dq_tile<G, DROP, ORD, SPAN>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, S, nq, nkv, scale,
                                            p_drop, seed, dq, lddq, ro, pair, pass == 0 ? heavy : light);
         }
     }
@@ -722,13 +756,16 @@ struct DkvSmem {
     uint32_t aw_s[G][32];       // dropout row words
     int32_t ql_s[32];
     int32_t empty_s[32];
-    int32_t pos_s[32];          // position of the staged query rows (S for rows past the end)
-    int32_t qlmin;              // smallest query level / position over the normal rows of the tile (INT_MAX: none)
+    int32_t pos_s[32];          // key limit of the staged query rows: their position (QuerySpan::hi), S past the end
+    int32_t hole_lo_s[32];      // QuerySpan hole of the staged query rows (SPAN kernels only)
+    int32_t hole_hi_s[32];
+    int32_t qlmin;              // smallest query level / key limit over the normal rows of the tile (INT_MAX: none)
     int32_t posmin;
-    int32_t pad_[2];
+    int32_t hole_lo_min;        // over the normal rows: smallest hole start, largest hole end
+    int32_t hole_hi_max;
 };
 
-template <int G, bool DROP, bool ORD>
+template <int G, bool DROP, bool ORD, bool SPAN>
 __device__ __forceinline__ void
 attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                     const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
@@ -796,6 +833,7 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
     float rl = 0.f, rd = 0.f;
     uint32_t raw = 0;
     int rql = 1, rem = 0, rpos = 0, rqlmin = INT_BIG_A, rposmin = INT_BIG_A;
+    int rhlo = INT_BIG_A, rhhi = 0, rhlomin = INT_BIG_A, rhhimax = 0;
 
     auto next_tile = [&](int qt) {
         while (qt < n_qt && !tile_empty_rows(qt) && tile_last_pos(qt) < k0) ++qt;
@@ -828,10 +866,16 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
             if (g == 0) {
                 rql = in ? (ql ? ql[(int64_t)b * S + i] : 1) : 0;
                 rem = in ? row_empty[(int64_t)b * S + i] : 0;
-                rpos = in ? i : S;
+                const QuerySpan qs = QuerySpan::load<SPAN>(ro.span, (int64_t)b * S + i, i, in, S);
+                rpos = qs.hi;
                 const bool normal = in && rem == 0;
                 rqlmin = wave_min_i32(normal ? rql : INT_BIG_A);
                 rposmin = wave_min_i32(normal ? rpos : INT_BIG_A);
+                if (SPAN) {
+                    rhlo = qs.hole_lo; rhhi = qs.hole_hi;
+                    rhlomin = wave_min_i32(normal ? rhlo : INT_BIG_A);
+                    rhhimax = wave_max_i32(normal ? rhhi : 0);
+                }
             }
         }
     };
@@ -848,7 +892,11 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
             if (DROP) sm.aw_s[g][row] = raw;
             if (g == 0) {
                 sm.ql_s[row] = rql; sm.empty_s[row] = rem; sm.pos_s[row] = rpos;
-                if (row == 0) { sm.qlmin = rqlmin; sm.posmin = rposmin; }
+                if (SPAN) { sm.hole_lo_s[row] = rhlo; sm.hole_hi_s[row] = rhhi; }
+                if (row == 0) {
+                    sm.qlmin = rqlmin; sm.posmin = rposmin;
+                    if (SPAN) { sm.hole_lo_min = rhlomin; sm.hole_hi_max = rhhimax; }
+                }
             }
         }
     };
@@ -914,6 +962,7 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
                     const float ndl[4] = {d4.x, d4.y, d4.z, d4.w};
                     float nl[4] = {0.f, 0.f, 0.f, 0.f};
                     int qlv[4] = {0, 0, 0, 0}, posv[4] = {0, 0, 0, 0}, emv[4] = {0, 0, 0, 0};
+                    int hlo[4] = {0, 0, 0, 0}, hhi[4] = {0, 0, 0, 0};
                     uint32_t awv[4] = {0, 0, 0, 0};
                     if (!ALL_EMPTY) {
                         const float4 l4 = *reinterpret_cast<const float4*>(&sm.nlse2_s[hg][qb]);
@@ -924,6 +973,12 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
                         const int4 p4 = *reinterpret_cast<const int4*>(&sm.pos_s[qb]);
                         qlv[0] = q4.x; qlv[1] = q4.y; qlv[2] = q4.z; qlv[3] = q4.w;
                         posv[0] = p4.x; posv[1] = p4.y; posv[2] = p4.z; posv[3] = p4.w;
+                        if (SPAN) {
+                            const int4 a4 = *reinterpret_cast<const int4*>(&sm.hole_lo_s[qb]);
+                            const int4 b4 = *reinterpret_cast<const int4*>(&sm.hole_hi_s[qb]);
+                            hlo[0] = a4.x; hlo[1] = a4.y; hlo[2] = a4.z; hlo[3] = a4.w;
+                            hhi[0] = b4.x; hhi[1] = b4.y; hhi[2] = b4.z; hhi[3] = b4.w;
+                        }
                     }
                     if (EMPTYSEL) {
                         const int4 e4 = *reinterpret_cast<const int4*>(&sm.empty_s[qb]);
@@ -942,7 +997,8 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
                         } else {
                             pe = __builtin_amdgcn_exp2f(fmaf(st[reg], c2, nl[e]));
                             if (MASK) {
-                                const bool allowed = (jk <= posv[e]) & (my_kl < qlv[e]);
+                                bool allowed = (jk <= posv[e]) & (my_kl < qlv[e]);
+                                if (SPAN) allowed = allowed & !((jk >= hlo[e]) & (jk < hhi[e]));
                                 pe = allowed ? pe : 0.f;
                             }
                             if (EMPTYSEL) pe = (emv[e] != 0) ? invS : pe;
@@ -964,7 +1020,12 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
             } else if (tile_has_empty) {
                 elem_tile.template operator()<true, true, false>();
             } else {
-                const bool free_tile = (posmin >= wave_k_hi) && (wave_kl_max < qlmin);
+                bool free_tile = (posmin >= wave_k_hi) && (wave_kl_max < qlmin);
+                if (SPAN) {
+                    const int hl = __builtin_amdgcn_readfirstlane(sm.hole_lo_min);
+                    const int hh = __builtin_amdgcn_readfirstlane(sm.hole_hi_max);
+                    free_tile = free_tile && (wave_k_hi < hl || wave_k_lo >= hh);
+                }
                 if (free_tile) elem_tile.template operator()<false, false, false>();
                 else elem_tile.template operator()<true, false, false>();
             }
@@ -1045,7 +1106,7 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
     }
 }
 
-template <int G, bool DROP, bool ORD>
+template <int G, bool DROP, bool ORD, bool SPAN>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                     const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
@@ -1066,7 +1127,7 @@ attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restric
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
-            attn_bwd_dkv_tile<G, DROP, ORD>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv,
+            attn_bwd_dkv_tile<G, DROP, ORD, SPAN>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv,
                                             scale, p_drop, seed, dk, lddk, dv, lddv, ro, pair, pass == 0 ? heavy : light, ds_out);
         }
     }
@@ -1395,17 +1456,19 @@ static int launch_fwd(const float* q, int ldq, const float* k, int ldk, const fl
                       float p_drop, uint64_t seed, float* o, float* lse, RowOrder ro, int uspan, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
-#define GAMER_LAUNCH_FWD(DROPV, ORDV)                                                                              \
-    hipLaunchKernelGGL((attn_fwd_kernel<G, DROPV, ORDV>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, \
+#define GAMER_LAUNCH_FWD(DROPV, ORDV, SPANV)                                                                              \
+    hipLaunchKernelGGL((attn_fwd_kernel<G, DROPV, ORDV, SPANV>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, \
                        kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, uspan)
-    if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD(true, true); else GAMER_LAUNCH_FWD(true, false); }
-    else { if (ro.perm) GAMER_LAUNCH_FWD(false, true); else GAMER_LAUNCH_FWD(false, false); }
+#define GAMER_LAUNCH_FWD2(DROPV, ORDV) do { if (ro.span) GAMER_LAUNCH_FWD(DROPV, ORDV, true); else GAMER_LAUNCH_FWD(DROPV, ORDV, false); } while (0)
+    if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD2(true, true); else GAMER_LAUNCH_FWD2(true, false); }
+    else { if (ro.perm) GAMER_LAUNCH_FWD2(false, true); else GAMER_LAUNCH_FWD2(false, false); }
+#undef GAMER_LAUNCH_FWD2
 #undef GAMER_LAUNCH_FWD
     GAMER_CHECK_LAUNCH("gamer_attn_fwd");
     return 0;
 }
 
-template <int G, bool DROP, bool ORD>
+template <int G, bool DROP, bool ORD, bool SPAN>
 static int launch_bwd_variant(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
                               const float* d_o, const float* lse, float* delta, const int32_t* kl, const int32_t* ql,
                               const int32_t* row_empty, const int32_t* tile_empty, int B, int S, int nq, int nkv,
@@ -1414,7 +1477,7 @@ static int launch_bwd_variant(const float* q, int ldq, const float* k, int ldk, 
     constexpr int R = (4 / G) * 32;
     dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
     if (ds_work == nullptr) {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<G, DROP, ORD>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o,
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<G, DROP, ORD, SPAN>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o,
                            lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, ro);
         GAMER_CHECK_LAUNCH("gamer_attn_bwd/dq");
     } else {
@@ -1426,7 +1489,7 @@ static int launch_bwd_variant(const float* q, int ldq, const float* k, int ldk, 
     if (shmem < red_bytes) shmem = red_bytes;
     static bool attr_set = false;             // one flag per template instantiation
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<G, DROP, ORD>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<G, DROP, ORD, SPAN>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) {
             set_error("gamer_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1434,7 +1497,7 @@ static int launch_bwd_variant(const float* q, int ldq, const float* k, int ldk, 
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<G, DROP, ORD>), grid, dim3(AT_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse,
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<G, DROP, ORD, SPAN>), grid, dim3(AT_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse,
                        delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro,
                        ds_work);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd/dkv");
@@ -1468,12 +1531,15 @@ static int launch_bwd(const float* q, int ldq, const float* k, int ldk, const fl
                       const int32_t* row_empty, const int32_t* tile_empty, int B, int S, int nq, int nkv, float scale,
                       float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                       RowOrder ro, float* ds_work, hipStream_t st) {
-#define GAMER_LAUNCH_BWD(DROPV, ORDV)                                                                                \
-    return launch_bwd_variant<G, DROPV, ORDV>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, \
+#define GAMER_LAUNCH_BWD(DROPV, ORDV, SPANV)                                                                                \
+    return launch_bwd_variant<G, DROPV, ORDV, SPANV>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, \
                                               S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, ds_work, st)
-    if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_BWD(true, true); else GAMER_LAUNCH_BWD(true, false); }
-    else { if (ro.perm) GAMER_LAUNCH_BWD(false, true); else GAMER_LAUNCH_BWD(false, false); }
+#define GAMER_LAUNCH_BWD2(DROPV, ORDV) do { if (ro.span) GAMER_LAUNCH_BWD(DROPV, ORDV, true); else GAMER_LAUNCH_BWD(DROPV, ORDV, false); } while (0)
+    if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_BWD2(true, true); else GAMER_LAUNCH_BWD2(true, false); }
+    else { if (ro.perm) GAMER_LAUNCH_BWD2(false, true); else GAMER_LAUNCH_BWD2(false, false); }
+#undef GAMER_LAUNCH_BWD2
 #undef GAMER_LAUNCH_BWD
+    return -1;      // not reached
 }
 
 }  // namespace gamer
@@ -1514,10 +1580,10 @@ extern "C" int gamer_debug_attn_occupancy(int which) {
     int n = -1;
     hipError_t e = hipSuccess;
     switch (which) {
-        case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<2, true, false>, AT_THREADS, 0); break;
-        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<2, false, false>, AT_THREADS, 0); break;
-        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq_kernel<2, true, false>, AT_THREADS, 0); break;
-        case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_kernel<2, true, false>, AT_THREADS, sizeof(DkvSmem<2>)); break;
+        case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<2, true, false, false>, AT_THREADS, 0); break;
+        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel<2, false, false, false>, AT_THREADS, 0); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq_kernel<2, true, false, false>, AT_THREADS, 0); break;
+        case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_kernel<2, true, false, false>, AT_THREADS, sizeof(DkvSmem<2>)); break;
     }
     return e == hipSuccess ? n : -(int)e;
 }
@@ -1526,12 +1592,13 @@ extern "C" int gamer_attn_fwd(const float* q, int ldq, const float* k, int ldk, 
                               const int32_t* kl, const int32_t* ql, const int32_t* row_empty,
                               const int32_t* tile_empty, int B, int S, int nq, int nkv, float scale, float p_drop,
                               uint64_t seed, float* o, float* lse, const int32_t* row_perm, const int32_t* tile_kind,
-                              const int32_t* tile_maxpos, int uniform_len, void* stream) {
+                              const int32_t* tile_maxpos, int uniform_len, const int32_t* q_span, void* stream) {
     (void)tile_empty;
     GAMER_CHECK_ARG(uniform_len >= 0 && uniform_len <= S, "gamer_attn_fwd: uniform_len=%d outside 0..S", uniform_len);
     const int uspan = uniform_len == 0 ? S : uniform_len;
     GAMER_CHECK_ARG(!row_perm || (tile_kind && tile_maxpos), "gamer_attn_fwd: row_perm needs tile_kind and tile_maxpos");
-    const RowOrder ro{row_perm, tile_kind, tile_maxpos};
+    GAMER_CHECK_ARG(!q_span || aligned16(q_span), "gamer_attn_fwd: q_span must be 16-byte aligned");
+    const RowOrder ro{row_perm, tile_kind, tile_maxpos, q_span};
     int rc = check_attn_common("gamer_attn_fwd", q, k, v, kl, row_empty, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
     if (rc) return rc;
     GAMER_CHECK_ARG(o && lse && aligned16(o), "gamer_attn_fwd: null/unaligned output");
@@ -1548,12 +1615,14 @@ extern "C" int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, 
                               const int32_t* ql, const int32_t* row_empty, const int32_t* tile_empty, int B, int S,
                               int nq, int nkv, float scale, float p_drop, uint64_t seed, float* delta, float* dq,
                               int lddq, float* dk, int lddk, float* dv, int lddv, const int32_t* row_perm,
-                              const int32_t* tile_kind, const int32_t* tile_maxpos, float* ds_work, void* stream) {
+                              const int32_t* tile_kind, const int32_t* tile_maxpos, float* ds_work,
+                              const int32_t* q_span, void* stream) {
     int rc = check_attn_common("gamer_attn_bwd", q, k, v, kl, row_empty, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
     if (rc) return rc;
     GAMER_CHECK_ARG(o && d_o && lse && tile_empty && delta && dq && dk && dv, "gamer_attn_bwd: null pointer");
     GAMER_CHECK_ARG(!row_perm || (tile_kind && tile_maxpos), "gamer_attn_bwd: row_perm needs tile_kind and tile_maxpos");
-    const RowOrder ro{row_perm, tile_kind, tile_maxpos};
+    GAMER_CHECK_ARG(!q_span || aligned16(q_span), "gamer_attn_bwd: q_span must be 16-byte aligned");
+    const RowOrder ro{row_perm, tile_kind, tile_maxpos, q_span};
     GAMER_CHECK_ARG(lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 && aligned16(dq) && aligned16(dk) && aligned16(dv) &&
                     aligned16(d_o) && aligned16(o),
                     "gamer_attn_bwd: gradient buffers must be 16-byte aligned with leading dims %% 4 == 0");

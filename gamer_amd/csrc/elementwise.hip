@@ -271,7 +271,7 @@ qknorm_rope_fwd_kernel(float* __restrict__ qkv, int T, int S, int nq, int nkv,
                        const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                        const float* __restrict__ bias_q, const float* __restrict__ bias_k,
                        const float* __restrict__ bias_v, const int32_t* __restrict__ act_idx,
-                       float* __restrict__ q_rot, float* __restrict__ k_rot) {
+                       float* __restrict__ q_rot, float* __restrict__ k_rot, const int32_t* __restrict__ pos_ids) {
     const int lane = threadIdx.x & 63;
     const int g = lane & 15, sub = lane >> 4;
     const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
@@ -282,7 +282,6 @@ qknorm_rope_fwd_kernel(float* __restrict__ qkv, int T, int S, int nq, int nkv,
     const float4 wq4 = reinterpret_cast<const float4*>(wq)[g], wk4 = reinterpret_cast<const float4*>(wk)[g];
     const float sgn = g < 8 ? -1.f : 1.f;
     const int64_t total = (int64_t)T * NH;
-#pragma unroll 2
     for (int64_t i0 = wave * 4; i0 < total; i0 += nwaves * 4) {
         const int64_t i = i0 + sub;
         const bool live = i < total;
@@ -308,7 +307,7 @@ qknorm_rope_fwd_kernel(float* __restrict__ qkv, int T, int S, int nq, int nkv,
             y.x = w4.x * (x.x * rstd); y.y = w4.y * (x.y * rstd); y.z = w4.z * (x.z * rstd); y.w = w4.w * (x.w * rstd);
             float4 pr;
             pr.x = __shfl_xor(y.x, 8, 64); pr.y = __shfl_xor(y.y, 8, 64); pr.z = __shfl_xor(y.z, 8, 64); pr.w = __shfl_xor(y.w, 8, 64);
-            const int pos = t % S;
+            const int pos = pos_ids ? pos_ids[t] : t % S;        // per-token RoPE position (session model) or the index
             const float4 c4 = reinterpret_cast<const float4*>(cos_t + pos * 64)[g];
             const float4 s4 = reinterpret_cast<const float4*>(sin_t + pos * 64)[g];
             float4 o;
@@ -340,7 +339,7 @@ qknorm_rope_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ 
                        int cross, const int32_t* __restrict__ act_idx, int nb1,
                        float* __restrict__ dqkv, float* __restrict__ dwq, float* __restrict__ dwk,
                        float* __restrict__ dbias_q, float* __restrict__ dbias_k, float* __restrict__ dbias_v,
-                       int waves_per_head) {
+                       int waves_per_head, const int32_t* __restrict__ pos_ids) {
     const int lane = threadIdx.x & 63;
     const int g = lane & 15, sub = lane >> 4;
     const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
@@ -357,7 +356,6 @@ qknorm_rope_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ 
     if (hd < nq + nkv) {
         const bool isq = hd < nq;
         const float4 w4 = isq ? reinterpret_cast<const float4*>(wq)[g] : reinterpret_cast<const float4*>(wk)[g];
-#pragma unroll 2
         for (int tb = w0 * 4; tb < T; tb += waves_per_head * 4) {
             const int t = tb + sub;
             const bool live = t < T;
@@ -365,7 +363,7 @@ qknorm_rope_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ 
             const float4 x = reinterpret_cast<const float4*>(qkv + (int64_t)tc * ldqkv + hd * 64)[g];   // pre-norm (bias included)
             const float4 d = isq ? reinterpret_cast<const float4*>(dq_rot + (int64_t)tc * nq * 64 + hd * 64)[g]
                                  : reinterpret_cast<const float4*>(dk_rot + (int64_t)tc * nkv * 64 + (hd - nq) * 64)[g];
-            const int pos = tc % S;
+            const int pos = pos_ids ? pos_ids[tc] : tc % S;
             const float4 c4 = reinterpret_cast<const float4*>(cos_t + pos * 64)[g];
             const float4 s4 = reinterpret_cast<const float4*>(sin_t + pos * 64)[g];
             float4 dp;
@@ -729,14 +727,14 @@ extern "C" int gamer_rowtable_bwd(const float* dy, int lddy, int col0, const int
 extern "C" int gamer_qknorm_rope_fwd(float* qkv, int T, int S, int nq, int nkv, const float* wq, const float* wk,
                                      float eps, const float* cos_t, const float* sin_t, const float* bias_q,
                                      const float* bias_k, const float* bias_v, const int32_t* act_idx, float* q_rot,
-                                     float* k_rot, void* stream) {
+                                     float* k_rot, const int32_t* pos_ids, void* stream) {
     GAMER_CHECK_ARG(qkv && wq && wk && cos_t && sin_t && q_rot && k_rot, "gamer_qknorm_rope_fwd: null pointer");
     GAMER_CHECK_ARG(T > 0 && S > 0 && nq > 0 && nkv > 0 && T % S == 0, "gamer_qknorm_rope_fwd: bad shape T=%d S=%d nq=%d nkv=%d", T, S, nq, nkv);
     const bool cross = bias_q != nullptr;
     GAMER_CHECK_ARG(!cross || (bias_k && bias_v && act_idx), "gamer_qknorm_rope_fwd: cross needs bias_k, bias_v, act_idx");
     const int NH = nq + nkv + (cross ? nkv : 0);
     hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3(grid_for_waves(((int64_t)T * NH + 3) / 4)), dim3(EW_THREADS), 0, ST(stream),
-                       qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot, k_rot);
+                       qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot, k_rot, pos_ids);
     GAMER_CHECK_LAUNCH("gamer_qknorm_rope_fwd");
     return 0;
 }
@@ -745,7 +743,8 @@ extern "C" int gamer_qknorm_rope_bwd(const float* qkv, const float* dq_rot, cons
                                      int nkv, const float* wq, const float* wk, float eps, const float* cos_t,
                                      const float* sin_t, const float* bias_q, const float* bias_k,
                                      const int32_t* act_idx, int nb1, float* dqkv, float* dwq, float* dwk,
-                                     float* dbias_q, float* dbias_k, float* dbias_v, void* stream) {
+                                     float* dbias_q, float* dbias_k, float* dbias_v, const int32_t* pos_ids,
+                                     void* stream) {
     GAMER_CHECK_ARG(qkv && dq_rot && dk_rot && wq && wk && cos_t && sin_t && dqkv && dwq && dwk,
                     "gamer_qknorm_rope_bwd: null pointer");
     GAMER_CHECK_ARG(T > 0 && S > 0 && nq > 0 && nkv > 0 && T % S == 0, "gamer_qknorm_rope_bwd: bad shape");
@@ -761,7 +760,7 @@ extern "C" int gamer_qknorm_rope_bwd(const float* qkv, const float* dq_rot, cons
     const int blocks = (int)((total_waves + EW_WAVES - 1) / EW_WAVES);
     hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3(blocks), dim3(EW_THREADS), 0, ST(stream), qkv, dq_rot, dk_rot, T, S,
                        nq, nkv, wq, wk, eps, cos_t, sin_t, cross, act_idx, nb1, dqkv, dwq, dwk, dbias_q, dbias_k,
-                       dbias_v, waves_per_head);
+                       dbias_v, waves_per_head, pos_ids);
     GAMER_CHECK_LAUNCH("gamer_qknorm_rope_bwd");
     return 0;
 }

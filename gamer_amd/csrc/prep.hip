@@ -111,6 +111,86 @@ router_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ attn_
     }
 }
 
+// ---- session spans (Qwen3SessionMulti) ------------------------------------------------------
+// ref:SeqRec/models/generative/Qwen3SessionMulti/model.py:545-551 (in-item mask), :556-613 (cross mask),
+// :676-728 (self mask), :983-984 (RoPE positions = extended_session_ids).
+// The reference masks key j for query i unless sess[j] < sess[i] (plus, for the self attention, the keys of the
+// query's own item up to the query).  Session ids that do not decrease along the kept tokens make
+// {kept j : sess[j] < sess[i]} a prefix of the kept keys, so the masks become per-query spans:
+//   lim_i = 1 + last kept j with sess[j] < sess[i]   (0 if none)
+//   self : j <= i, minus the hole [lim_i, first token of i's item)        cross: j <= lim_i - 1 (and kl[j] < ql[i])
+// One workgroup per sequence; each row scans the sequence in LDS (S^2 integer compares, ~0.1 ms at B = 1024).
+// Rows whose span would not be causal / not a prefix (ids out of order) are counted in `violations` and clamped.
+__global__ void __launch_bounds__(ROUTER_THREADS)
+session_span_kernel(const int64_t* __restrict__ sess, const int64_t* __restrict__ ext_ids,
+                    const int64_t* __restrict__ attn_mask, const int32_t* __restrict__ kl_cross,
+                    const int32_t* __restrict__ ql_cross, int S, int P, int n_pos,
+                    int32_t* __restrict__ span_self, int32_t* __restrict__ span_cross, int32_t* __restrict__ pos_ids,
+                    int32_t* __restrict__ empty_self, int32_t* __restrict__ empty_cross,
+                    int32_t* __restrict__ tile_empty_self, int32_t* __restrict__ tile_empty_cross,
+                    int32_t* __restrict__ violations) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sraw[];
+    int64_t* sess_s = reinterpret_cast<int64_t*>(sraw);                 // [S]
+    int32_t* keep_s = reinterpret_cast<int32_t*>(sess_s + S);           // [S]
+    int32_t* klc_s = keep_s + S;                                        // [S] cross key level (INT_MAX if padded)
+    int32_t* es_s = klc_s + S;                                          // [S] empty flags for the tile reduction
+    int32_t* ec_s = es_s + S;
+    const int b = blockIdx.x;
+    const int64_t base = (int64_t)b * S;
+    for (int t = threadIdx.x; t < S; t += blockDim.x) {
+        sess_s[t] = sess[base + t];
+        keep_s[t] = attn_mask ? (attn_mask[base + t] != 0 ? 1 : 0) : 1;
+        klc_s[t] = kl_cross[base + t];
+    }
+    __syncthreads();
+    int bad = 0;
+    for (int i = threadIdx.x; i < S; i += blockDim.x) {
+        const int64_t si = sess_s[i];
+        int last_lt = -1, first_ge = INT_BIG;
+        for (int j = 0; j < S; ++j) {
+            if (keep_s[j]) {
+                if (sess_s[j] < si) last_lt = j;
+                else first_ge = min(first_ge, j);
+            }
+        }
+        if (last_lt > first_ge || last_lt >= i) ++bad;            // not a prefix of the kept keys / not causal
+        const int lim = min(last_lt + 1, i);
+        const int istart = i - i % P;
+        bool any_before = false;
+        int klmin = INT_BIG;
+        for (int j = 0; j < lim; ++j) {
+            any_before |= keep_s[j] != 0;
+            klmin = min(klmin, klc_s[j]);
+        }
+        bool any_item = false;
+        for (int j = istart; j <= i; ++j) any_item |= keep_s[j] != 0;
+        const int es = (any_before || any_item) ? 0 : 1;
+        const int ec = (klmin < ql_cross[base + i]) ? 0 : 1;
+        const bool hole = lim < istart;
+        reinterpret_cast<int4*>(span_self)[base + i] = make_int4(i, hole ? lim : INT_BIG, hole ? istart : 0, 0);
+        reinterpret_cast<int4*>(span_cross)[base + i] = make_int4(lim - 1, INT_BIG, 0, 0);
+        empty_self[base + i] = es;
+        empty_cross[base + i] = ec;
+        es_s[i] = es;
+        ec_s[i] = ec;
+        int64_t p = ext_ids ? ext_ids[base + i] : (int64_t)i;
+        if (p < 0 || p >= n_pos) { ++bad; p = p < 0 ? 0 : n_pos - 1; }
+        pos_ids[base + i] = (int32_t)p;
+    }
+    if (bad) atomicAdd(violations, bad);
+    __syncthreads();
+    const int n_tiles = (S + 31) / 32;
+    for (int qt = threadIdx.x; qt < n_tiles; qt += blockDim.x) {
+        int es = 0, ec = 0;
+        for (int t = qt * 32; t < min(S, qt * 32 + 32); ++t) {
+            es |= es_s[t];
+            ec |= ec_s[t];
+        }
+        tile_empty_self[(int64_t)b * n_tiles + qt] = es;
+        tile_empty_cross[(int64_t)b * n_tiles + qt] = ec;
+    }
+}
+
 // ---- expert lists ---------------------------------------------------------------------------
 // pass 1: per-sequence member counts   work[b*E + e]
 __global__ void expert_count_kernel(const int32_t* __restrict__ expert, int S, int E,
@@ -219,6 +299,28 @@ extern "C" int gamer_router_fwd(const int64_t* ids, const int64_t* attn_mask, co
                        expert, beh_idx, act_idx, kl_self, kl_cross, ql_cross, empty_self, empty_cross,
                        tile_empty_self, tile_empty_cross, bad_token);
     GAMER_CHECK_LAUNCH("gamer_router_fwd");
+    return 0;
+}
+
+extern "C" int gamer_session_spans(const int64_t* session_ids, const int64_t* extended_session_ids,
+                                   const int64_t* attn_mask, const int32_t* kl_cross, const int32_t* ql_cross,
+                                   int B, int S, int num_positions, int n_rope_positions,
+                                   int32_t* span_self, int32_t* span_cross, int32_t* pos_ids,
+                                   int32_t* empty_self, int32_t* empty_cross,
+                                   int32_t* tile_empty_self, int32_t* tile_empty_cross, int32_t* violations,
+                                   void* stream) {
+    GAMER_CHECK_ARG(session_ids && kl_cross && ql_cross && span_self && span_cross && pos_ids && empty_self &&
+                    empty_cross && tile_empty_self && tile_empty_cross && violations,
+                    "gamer_session_spans: null pointer");
+    GAMER_CHECK_ARG(B > 0 && S > 0 && num_positions > 0 && n_rope_positions > 0,
+                    "gamer_session_spans: bad shape B=%d S=%d P=%d n_pos=%d", B, S, num_positions, n_rope_positions);
+    GAMER_CHECK_ARG(S <= 2048, "gamer_session_spans: S=%d > 2048 unsupported", S);
+    const size_t shmem = (size_t)S * (sizeof(int64_t) + 4 * sizeof(int32_t));
+    hipLaunchKernelGGL(session_span_kernel, dim3(B), dim3(ROUTER_THREADS), shmem, (hipStream_t)stream,
+                       session_ids, extended_session_ids, attn_mask, kl_cross, ql_cross, S, num_positions,
+                       n_rope_positions, span_self, span_cross, pos_ids, empty_self, empty_cross,
+                       tile_empty_self, tile_empty_cross, violations);
+    GAMER_CHECK_LAUNCH("gamer_session_spans");
     return 0;
 }
 

@@ -146,6 +146,7 @@ class _Workspace:
         L, E = cfg.num_hidden_layers, cfg.num_experts
         din_max = H + cfg.behavior_embedding_dim
         self.router = ops.alloc_router_outputs(B, S, device)
+        self.session: Optional[dict] = None        # span_self / span_cross / pos_ids of the session variant
         self.perm = torch.empty(T, **i32)
         self.slot = torch.empty(T, **i32)
         n_t32 = (S + 31) // 32
@@ -213,8 +214,14 @@ class Engine:
     N_NORM_PARTIAL = 512
     N_SUMSQ_PARTIAL = 1024
 
-    def __init__(self, cfg: Qwen3MultiConfig, device="cuda", temperature: float = 1.0):
+    def __init__(self, cfg: Qwen3MultiConfig, device="cuda", temperature: float = 1.0, variant: str = "multi"):
+        """``variant``: "multi" = Qwen3Multi (train_SMB_decoder.py:362-364), "session" = Qwen3SessionMulti
+        (train_SMB_decoder.py:365-367): the same parameters and layers with session-wise attention masks and
+        RoPE positions taken from ``extended_session_ids``."""
         cfg.validate()
+        if variant not in ("multi", "session"):
+            raise ValueError(f"unknown variant {variant!r}")
+        self.variant = variant
         if not torch.cuda.is_available():
             raise RuntimeError("gamer_amd.Engine needs a HIP device (there is no CPU fallback)")
         from . import _lib
@@ -292,11 +299,14 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     def forward(self, input_ids, attention_mask=None, actions=None, labels=None, num_items_in_batch=None,
                 train: bool = False, dropout: Optional[bool] = None, act_zero_col: Optional[int] = None,
-                uniform_len: int = 0, kv_sink=None):
+                uniform_len: int = 0, kv_sink=None, session_ids=None, extended_session_ids=None):
         """Returns (loss or None, logits view [B,S,V]).  With labels the logits are divided by the
         temperature in place, as the reference does (model.py:913).  The view aliases a workspace
         buffer: backward() overwrites it with d(logits), the next forward() with new logits.  ``train`` keeps every activation
         needed by backward(); ``dropout`` defaults to ``train``.
+
+        ``session_ids`` / ``extended_session_ids`` [B,S] are required by (and only used in) the "session" variant
+        (Qwen3SessionMulti: session-wise masks, RoPE positions = extended_session_ids).
 
         Evaluation only (gamer_amd/decode.py re-runs the whole sequence every generation step): ``act_zero_col``
         is the column of the prompt's final behaviour token, which the reference's router gives action index 0
@@ -338,6 +348,22 @@ class Engine:
         if act_zero_col is not None:
             r["act_idx"][:, act_zero_col] = 0
         ops.expert_lists(r["expert"], E, ws.perm, ws.slot, ws.offsets, ws.work)
+        span_self = span_cross = pos_ids = None
+        if self.variant == "session":
+            # Qwen3SessionMulti/model.py:784-806: both masks are rebuilt from session_ids on every forward
+            if session_ids is None:
+                raise ValueError("Session IDs must be provided to generate session-wise causal mask.")
+            if kv_sink is not None or uniform_len not in (0, S):
+                raise NotImplementedError("cached generation is not built for the session variant")
+            sid = session_ids.to(self.device, torch.int64).contiguous()
+            ext = (extended_session_ids.to(self.device, torch.int64).contiguous()
+                   if extended_session_ids is not None else None)
+            if ws.session is None:
+                ws.session = ops.alloc_session_outputs(B, S, self.device)
+            ws.session["violations"].zero_()
+            ops.session_spans(sid, ext, am, cfg.num_positions, S, r, ws.session)     # overwrites r["empty_*"]
+            span_self, span_cross, pos_ids = (ws.session["span_self"], ws.session["span_cross"],
+                                              ws.session["pos_ids"])
         if cfg.cross_attention_decoder:
             ops.attn_row_order(r["empty_cross"], *ws.cross_order)
         cos, sin = self.rope(S)
@@ -350,12 +376,13 @@ class Engine:
             # ---- self attention (model.py:204-217) ----
             ops.rmsnorm_fwd(xs[0], W.ln1, eps, A["h1"])
             ops.linear_fwd(A["h1"], H, W.self_attn["qkv"], H, A["qkv"], QKV, T, QKV, H)
-            ops.qknorm_rope_fwd(A["qkv"], S, nq, nkv, W.self_attn["qn"], W.self_attn["kn"], eps, cos, sin, A["q"], A["k"])
+            ops.qknorm_rope_fwd(A["qkv"], S, nq, nkv, W.self_attn["qn"], W.self_attn["kn"], eps, cos, sin, A["q"], A["k"],
+                                pos_ids=pos_ids)
             if kv_sink is not None:
                 kv_sink(l, "self", A["k"], A["qkv"][:, NQ + NKV:])
             ops.attn_fwd(A["q"], NQ, A["k"], NKV, A["qkv"][:, NQ + NKV:], QKV, r["kl_self"], None, r["empty_self"],
                          r["tile_empty_self"], B, S, nq, nkv, scale, p_att, self._seed(l, 0), A["ao"], A["lse"],
-                         uniform_len=uniform_len)
+                         uniform_len=uniform_len, q_span=span_self)
             # o_proj with the residual add + dropout fused into the GEMM epilogue (model.py:149,217)
             ops.gemm(A["ao"], NQ, 1, W.self_attn["o"], NQ, 1, xs[1], H, T, H, NQ, resid=xs[0], p_drop=p_res,
                      seed=self._seed(l, 1))
@@ -366,12 +393,14 @@ class Engine:
                 ops.rmsnorm_fwd(xs[1], W.ln2, eps, A["h2"])
                 ops.linear_fwd(A["h2"], H, C["qkv"], H, A["qkv_c"], QKV, T, QKV, H)
                 ops.qknorm_rope_fwd(A["qkv_c"], S, nq, nkv, C["qn"], C["kn"], eps, cos, sin, A["q_c"], A["k_c"],
-                                    bias_q=C["bq"], bias_k=C["bk"], bias_v=C["bv"], act_idx=r["act_idx"])
+                                    bias_q=C["bq"], bias_k=C["bk"], bias_v=C["bv"], act_idx=r["act_idx"],
+                                    pos_ids=pos_ids)
                 if kv_sink is not None:
                     kv_sink(l, "cross", A["k_c"], A["qkv_c"][:, NQ + NKV:])
                 ops.attn_fwd(A["q_c"], NQ, A["k_c"], NKV, A["qkv_c"][:, NQ + NKV:], QKV, r["kl_cross"], r["ql_cross"],
                              r["empty_cross"], r["tile_empty_cross"], B, S, nq, nkv, scale, p_att, self._seed(l, 2),
-                             A["ao_c"], A["lse_c"], order=ws.cross_order, uniform_len=uniform_len)
+                             A["ao_c"], A["lse_c"], order=ws.cross_order, uniform_len=uniform_len,
+                             q_span=span_cross)
                 ops.linear_fwd(A["ao_c"], NQ, C["o"], NQ, A["op_c"], H, T, H, NQ)
                 ops.linear_fwd(A["h2"], H, C["gate"], H, A["gate_c"], H, T, H, H)
                 ops.silu_gate_fwd(A["op_c"], A["gate_c"], t0)
@@ -414,6 +443,12 @@ class Engine:
         if n:
             raise IndexError(f"{n} item(s) start with a token that is not in config.behavior_maps "
                              "(the reference fails with an embedding IndexError, router.py:170-171)")
+        if self.variant == "session" and self.ws.session is not None:
+            n = int(self.ws.session["violations"].item())
+            if n:
+                raise ValueError(f"{n} row(s) with session ids that decrease along the sequence or RoPE positions "
+                                 "outside [0, S): the session masks are built as causal key spans "
+                                 "(gamer_session_spans), which needs the dataset's layout (SMB_dataset.py:194-222)")
 
     # ------------------------------------------------------------------------------------------
     def zero_grad(self):
@@ -429,6 +464,9 @@ class Engine:
             raise RuntimeError("backward() needs forward(train=True, labels=...) first")
         cfg, ws = self.cfg, self.ws
         B, S = sv["B"], sv["S"]
+        span_self = span_cross = pos_ids = None
+        if self.variant == "session":
+            span_self, span_cross, pos_ids = ws.session["span_self"], ws.session["span_cross"], ws.session["pos_ids"]
         T, H = B * S, cfg.hidden_size
         nq, nkv, dh, I, E = (cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size,
                              cfg.num_experts)
@@ -491,10 +529,10 @@ class Engine:
                 ops.attn_bwd(A["q_c"], NQ, A["k_c"], NKV, A["qkv_c"][:, NQ + NKV:], QKV, A["ao_c"], ws.dao, A["lse_c"],
                              r["kl_cross"], r["ql_cross"], r["empty_cross"], r["tile_empty_cross"], B, S, nq, nkv,
                              scale, p_att, self._seed(l, 2), ws.delta, ws.dq, NQ, ws.dk, NKV,
-                             ws.dqkv[:, NQ + NKV:], QKV, order=ws.cross_order, ds_work=ws.ds_work)
+                             ws.dqkv[:, NQ + NKV:], QKV, order=ws.cross_order, ds_work=ws.ds_work, q_span=span_cross)
                 ops.qknorm_rope_bwd(A["qkv_c"], ws.dq, ws.dk, S, nq, nkv, C["qn"], C["kn"], eps, cos, sin, ws.dqkv,
                                     GC["qn"], GC["kn"], bias_q=C["bq"], bias_k=C["bk"], act_idx=r["act_idx"], nb1=NB1,
-                                    dbias_q=GC["bq"], dbias_k=GC["bk"], dbias_v=GC["bv"])
+                                    dbias_q=GC["bq"], dbias_k=GC["bk"], dbias_v=GC["bv"], pos_ids=pos_ids)
                 ops.linear_wgrad(ws.dqkv, QKV, A["h2"], H, GC["qkv"], H, T, QKV, H)
                 ops.linear_dgrad(ws.dqkv, QKV, C["qkv"], H, t3, H, T, QKV, H)
                 ops.linear_dgrad(t2, H, C["gate"], H, t3, H, T, H, H, accumulate=True)
@@ -506,9 +544,10 @@ class Engine:
             ops.linear_dgrad(t0, H, SA["o"], NQ, ws.dao, NQ, T, H, NQ)
             ops.attn_bwd(A["q"], NQ, A["k"], NKV, A["qkv"][:, NQ + NKV:], QKV, A["ao"], ws.dao, A["lse"], r["kl_self"],
                          None, r["empty_self"], r["tile_empty_self"], B, S, nq, nkv, scale, p_att, self._seed(l, 0),
-                         ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, ds_work=ws.ds_work)
+                         ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, ds_work=ws.ds_work,
+                         q_span=span_self)
             ops.qknorm_rope_bwd(A["qkv"], ws.dq, ws.dk, S, nq, nkv, SA["qn"], SA["kn"], eps, cos, sin, ws.dqkv, GS["qn"],
-                                GS["kn"])
+                                GS["kn"], pos_ids=pos_ids)
             ops.linear_wgrad(ws.dqkv, QKV, A["h1"], H, GS["qkv"], H, T, QKV, H)
             ops.linear_dgrad(ws.dqkv, QKV, SA["qkv"], H, t3, H, T, QKV, H)
             norm_bwd(xs[0], W.ln1, t3, H, G.ln1, True)
@@ -538,7 +577,9 @@ class Engine:
         backward (loss = sum CE / global count, HF average_tokens_across_devices) and the per-layer
         gradient buckets are all-reduced while the remaining layers' backward runs."""
         loss, _ = self.forward(batch["input_ids"], batch.get("attention_mask"), batch.get("actions"),
-                               labels=batch["labels"], num_items_in_batch=num_items_in_batch, train=True)
+                               labels=batch["labels"], num_items_in_batch=num_items_in_batch, train=True,
+                               session_ids=batch.get("session_ids"),
+                               extended_session_ids=batch.get("extended_session_ids"))
         self.zero_grad()
         if reducer is not None and num_items_in_batch is None:
             from .dp import all_reduce_scalar_

@@ -39,10 +39,11 @@ class CausalLMOutput(OrderedDict):
 
 class _ModelFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, input_ids, attention_mask, actions, labels, num_items, *params):
+    def forward(ctx, model, input_ids, attention_mask, actions, labels, num_items, sess, *params):
         eng: Engine = model.engine
         loss, logits = eng.forward(input_ids, attention_mask, actions, labels=labels, num_items_in_batch=num_items,
-                                   train=True, dropout=model.training)
+                                   train=True, dropout=model.training, session_ids=sess[0],
+                                   extended_session_ids=sess[1])
         logits = logits.clone()          # Engine.backward() reuses the logits buffer for d(logits)
         ctx.model = model
         ctx.set_materialize_grads(False)
@@ -55,7 +56,7 @@ class _ModelFn(torch.autograd.Function):
         eng.zero_grad()
         eng.backward(float(dloss) if dloss is not None else 0.0)
         grads = [eng.grads[k].clone() for k in ctx.model._param_keys]
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 class _Holder(nn.Module):
@@ -83,6 +84,8 @@ except Exception:                                             # noqa: BLE001
 
 
 class Qwen3MultiWithTemperature(nn.Module):
+    VARIANT = "multi"
+
     def __init__(self, config: Qwen3MultiConfig, device: str = "cuda"):
         super().__init__()
         assert "num_positions" in config and isinstance(config.num_positions, int), \
@@ -92,7 +95,7 @@ class Qwen3MultiWithTemperature(nn.Module):
         self.config = config
         self.vocab_size = config.vocab_size
         self.temperature = 1.0
-        self.engine = Engine(config, device=device, temperature=1.0)
+        self.engine = Engine(config, device=device, temperature=1.0, variant=self.VARIANT)
         self.engine.init_weights(seed=0)
         self._param_keys = list(self.engine.layout.entries.keys())
         self._register_views()
@@ -128,7 +131,8 @@ class Qwen3MultiWithTemperature(nn.Module):
         old = {k: v.detach().clone() for k, v in self.state_dict().items()}
         self.config.vocab_size = int(new_num_tokens)
         self.vocab_size = int(new_num_tokens)
-        self.engine = Engine(self.config, device=str(self.engine.device), temperature=self.temperature)
+        self.engine = Engine(self.config, device=str(self.engine.device), temperature=self.temperature,
+                             variant=self.VARIANT)
         self.engine.init_weights(seed=0)
         for name in list(self._modules):                      # drop the old parameter tree
             del self._modules[name]
@@ -194,6 +198,8 @@ class Qwen3MultiWithTemperature(nn.Module):
             raise NotImplementedError("num_return_sequences must equal num_beams (what the evaluation task uses)")
         if attention_mask is None or actions is None:
             raise ValueError("generate() needs attention_mask and actions")
+        if self.VARIANT != "multi":
+            raise NotImplementedError("generate() is built for Qwen3Multi only")
         seqs, scores = decode.beam_search(self.engine, input_ids, attention_mask, actions, trie, num_beams, max_new_tokens)
         return CausalLMOutput(sequences=seqs, sequences_scores=scores)
 
@@ -211,14 +217,26 @@ class Qwen3MultiWithTemperature(nn.Module):
         if torch.is_tensor(num_items):
             num_items = float(num_items)
         eng = self.engine
+        sess = (session_ids, extended_session_ids) if self.VARIANT == "session" else (None, None)
         needs_grad = torch.is_grad_enabled() and labels is not None
         if needs_grad:
             params = [self._params_by_key[k] for k in self._param_keys]
-            loss, logits = _ModelFn.apply(self, input_ids, attention_mask, actions, labels, num_items, *params)
+            loss, logits = _ModelFn.apply(self, input_ids, attention_mask, actions, labels, num_items, sess, *params)
         else:
             with torch.no_grad():
                 loss, logits = eng.forward(input_ids, attention_mask, actions, labels=labels,
-                                           num_items_in_batch=num_items, train=False, dropout=False)
+                                           num_items_in_batch=num_items, train=False, dropout=False,
+                                           session_ids=sess[0], extended_session_ids=sess[1])
+        if self.VARIANT == "session":
+            eng.check_inputs()          # session ids out of order cannot be expressed as key spans: raise, do not guess
         if isinstance(logits_to_keep, int) and logits_to_keep > 0:
             logits = logits[:, -logits_to_keep:, :]
         return CausalLMOutput(loss=loss, logits=logits, past_key_values=None, hidden_states=None, attentions=None)
+
+
+class Qwen3SessionMultiWithTemperature(Qwen3MultiWithTemperature):
+    """ref:SeqRec/models/generative/Qwen3SessionMulti/model.py:870-1017 - Qwen3Multi's parameters and layers with
+    session-wise attention masks (a token sees its own item and strictly earlier sessions; the behaviour-level
+    attention additionally needs a lower behaviour level) and RoPE positions = ``extended_session_ids``.
+    ``forward`` needs ``session_ids`` (the reference asserts the same) and validates their order on the host."""
+    VARIANT = "session"

@@ -44,6 +44,26 @@ def alloc_router_outputs(B, S, device):
     return out
 
 
+def alloc_session_outputs(B, S, device):
+    i32 = dict(dtype=torch.int32, device=device)
+    return {"span_self": torch.empty(B, S, 4, **i32), "span_cross": torch.empty(B, S, 4, **i32),
+            "pos_ids": torch.empty(B, S, **i32), "violations": torch.zeros(1, **i32)}
+
+
+def session_spans(session_ids, extended_session_ids, attn_mask, num_positions, n_rope_positions, router: dict,
+                  out: dict):
+    """Qwen3SessionMulti masks as per-query key spans (gamer_session_spans).  Run after router_fwd: overwrites the
+    router's empty_* / tile_empty_* with the session masks' empty rows."""
+    B, S = session_ids.shape
+    _chk(session_ids, torch.int64, "session_ids")
+    if extended_session_ids is not None:
+        _chk(extended_session_ids, torch.int64, "extended_session_ids")
+    call("gamer_session_spans", ptr(session_ids), ptr(extended_session_ids), ptr(attn_mask), ptr(router["kl_cross"]),
+         ptr(router["ql_cross"]), B, S, num_positions, n_rope_positions, ptr(out["span_self"]),
+         ptr(out["span_cross"]), ptr(out["pos_ids"]), ptr(router["empty_self"]), ptr(router["empty_cross"]),
+         ptr(router["tile_empty_self"]), ptr(router["tile_empty_cross"]), ptr(out["violations"]), stream_ptr())
+
+
 def expert_lists(expert, num_experts, perm, slot, offsets, work):
     B, S = expert.shape
     call("gamer_expert_lists", ptr(expert), B, S, num_experts, ptr(perm), ptr(slot), ptr(offsets), ptr(work),
@@ -142,18 +162,19 @@ def linear_wgrad(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups=1, group_
 
 
 def qknorm_rope_fwd(qkv, S, nq, nkv, wq, wk, eps, cos_t, sin_t, q_rot, k_rot, bias_q=None, bias_k=None, bias_v=None,
-                    act_idx=None):
+                    act_idx=None, pos_ids=None):
+    """pos_ids: int32 [T] RoPE table row per token (session model); None = position in the sequence."""
     T = qkv.shape[0]
     call("gamer_qknorm_rope_fwd", ptr(qkv), T, S, nq, nkv, ptr(wq), ptr(wk), eps, ptr(cos_t), ptr(sin_t),
-         ptr(bias_q), ptr(bias_k), ptr(bias_v), ptr(act_idx), ptr(q_rot), ptr(k_rot), stream_ptr())
+         ptr(bias_q), ptr(bias_k), ptr(bias_v), ptr(act_idx), ptr(q_rot), ptr(k_rot), ptr(pos_ids), stream_ptr())
 
 
 def qknorm_rope_bwd(qkv, dq_rot, dk_rot, S, nq, nkv, wq, wk, eps, cos_t, sin_t, dqkv, dwq, dwk, bias_q=None,
-                    bias_k=None, act_idx=None, nb1=0, dbias_q=None, dbias_k=None, dbias_v=None):
+                    bias_k=None, act_idx=None, nb1=0, dbias_q=None, dbias_k=None, dbias_v=None, pos_ids=None):
     T = qkv.shape[0]
     call("gamer_qknorm_rope_bwd", ptr(qkv), ptr(dq_rot), ptr(dk_rot), T, S, nq, nkv, ptr(wq), ptr(wk), eps,
          ptr(cos_t), ptr(sin_t), ptr(bias_q), ptr(bias_k), ptr(act_idx), nb1, ptr(dqkv), ptr(dwq), ptr(dwk),
-         ptr(dbias_q), ptr(dbias_k), ptr(dbias_v), stream_ptr())
+         ptr(dbias_q), ptr(dbias_k), ptr(dbias_v), ptr(pos_ids), stream_ptr())
 
 
 def attn_row_order(row_empty, perm, tile_kind, tile_maxpos):
@@ -162,21 +183,23 @@ def attn_row_order(row_empty, perm, tile_kind, tile_maxpos):
 
 
 def attn_fwd(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse,
-             order=None, uniform_len=0):
+             order=None, uniform_len=0, q_span=None):
     """order = (perm, tile_kind, tile_maxpos) from attn_row_order, or None for the natural row order.
-    uniform_len: see include/gamer_hip.h (0 = training semantics)."""
+    uniform_len: see include/gamer_hip.h (0 = training semantics).
+    q_span: int32 [B,S,4] per-query key spans from session_spans (session model), None = plain causal."""
     pm, tk, tm = order if order is not None else (None, None, None)
     call("gamer_attn_fwd", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(kl), ptr(ql), ptr(row_empty), ptr(tile_empty),
-         B, S, nq, nkv, scale, p_drop, seed, ptr(o), ptr(lse), ptr(pm), ptr(tk), ptr(tm), uniform_len, stream_ptr())
+         B, S, nq, nkv, scale, p_drop, seed, ptr(o), ptr(lse), ptr(pm), ptr(tk), ptr(tm), uniform_len, ptr(q_span),
+         stream_ptr())
 
 
 def attn_bwd(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed,
-             delta, dq, lddq, dk, lddk, dv, lddv, order=None, ds_work=None):
+             delta, dq, lddq, dk, lddk, dv, lddv, order=None, ds_work=None, q_span=None):
     """ds_work: optional fp32 scratch of attn_ds_work_numel(B, S, nq) elements (dS spill, see gamer_hip.h)."""
     pm, tk, tm = order if order is not None else (None, None, None)
     call("gamer_attn_bwd", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), ptr(d_o), ptr(lse), ptr(kl), ptr(ql),
          ptr(row_empty), ptr(tile_empty), B, S, nq, nkv, scale, p_drop, seed, ptr(delta), ptr(dq), lddq, ptr(dk),
-         lddk, ptr(dv), lddv, ptr(pm), ptr(tk), ptr(tm), ptr(ds_work), stream_ptr())
+         lddk, ptr(dv), lddv, ptr(pm), ptr(tk), ptr(tm), ptr(ds_work), ptr(q_span), stream_ptr())
 
 
 def attn_ds_work_numel(B, S, nq):

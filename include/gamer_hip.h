@@ -62,6 +62,29 @@ int gamer_router_fwd(const int64_t* ids, const int64_t* attn_mask, const int64_t
                      int32_t* tile_empty_self, int32_t* tile_empty_cross,
                      int32_t* bad_token, void* stream);
 
+/* Session spans for the Qwen3SessionMulti variant (same weights, session-wise masks;
+ * ref:.../Qwen3SessionMulti/model.py:545-551 in-item mask, :556-613 cross mask, :676-728 self mask, :983-984
+ * RoPE positions = extended_session_ids).  The reference's masks
+ *   self : allowed unless (not (same item and j <= i)) and sess[j] >= sess[i]
+ *   cross: allowed unless sess[j] >= sess[i] or act[j] >= act[i]              (both: padded keys masked)
+ * become per-query key spans when the session ids do not decrease along the kept tokens (the dataset's layout,
+ * SMB_dataset.py:194-222): with lim_i = 1 + last kept j with sess[j] < sess[i],
+ *   span_self [B,S,4] int32 = (i, lim_i, first token of i's item, 0)   keys j <= i except lim_i <= j < item start
+ *   span_cross[B,S,4] int32 = (lim_i - 1, INT32_MAX, 0, 0)             keys j <= lim_i - 1 (and kl[j] < ql[i])
+ * which gamer_attn_fwd / gamer_attn_bwd take as `q_span` (hi, hole_lo, hole_hi, unused).
+ * Call after gamer_router_fwd (kl_cross / ql_cross are inputs): empty_* and tile_empty_* are OVERWRITTEN with the
+ * session masks' empty rows.  pos_ids int32 [B,S] = extended_session_ids clamped to [0, n_rope_positions)
+ * (extended_session_ids NULL: the index in the sequence).  violations int32 [1] is incremented for every row
+ * whose ids are out of order (allowed keys not a causal prefix) or whose position is out of range; such rows
+ * are clamped, the host decides whether to raise.                                                      */
+int gamer_session_spans(const int64_t* session_ids, const int64_t* extended_session_ids,
+                        const int64_t* attn_mask, const int32_t* kl_cross, const int32_t* ql_cross,
+                        int B, int S, int num_positions, int n_rope_positions,
+                        int32_t* span_self, int32_t* span_cross, int32_t* pos_ids,
+                        int32_t* empty_self, int32_t* empty_cross,
+                        int32_t* tile_empty_self, int32_t* tile_empty_cross, int32_t* violations,
+                        void* stream);
+
 /* Expert token lists for the position-routed FFN (replaces the boolean-mask gather/scatter loop of
  * MyQwen3SparseMLP.forward, ref:SeqRec/models/generative/Qwen3Moe/FFN.py:63-68, and its 6 host
  * syncs per layer).  Deterministic order: expert-major, then token order.
@@ -148,6 +171,8 @@ int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);
  * (model.py:88-101; Qwen3MoeRMSNorm; apply_rotary_pos_emb / rotate_half).
  *   qkv: [T, (nq+2*nkv)*64] output of the fused q|k|v projection; head_dim is 64.
  *   cos/sin: [S,64] tables (Qwen3RotaryEmbedding, positions 0..S-1)
+ *   pos_ids: int32 [T] row of the tables for every token, NULL = t % S (Qwen3Multi); the session model passes
+ *            gamer_session_spans' pos_ids
  *   bias_q [NB1, nq*64], bias_k/bias_v [NB1, nkv*64], act_idx int32 [T]  (all NULL for self)
  *   out: q_rot [T,nq*64], k_rot [T,nkv*64]; v (+bias) is updated in place inside qkv.
  * bwd: dq_rot, dk_rot -> dqkv[:, :q|k] (pre-norm grads); dv is already in dqkv[:, v];
@@ -158,7 +183,7 @@ int gamer_qknorm_rope_fwd(float* qkv, int T, int S, int nq, int nkv,
                           const float* cos_t, const float* sin_t,
                           const float* bias_q, const float* bias_k, const float* bias_v,
                           const int32_t* act_idx,
-                          float* q_rot, float* k_rot, void* stream);
+                          float* q_rot, float* k_rot, const int32_t* pos_ids, void* stream);
 int gamer_qknorm_rope_bwd(const float* qkv, const float* dq_rot, const float* dk_rot,
                           int T, int S, int nq, int nkv,
                           const float* wq, const float* wk, float eps,
@@ -166,7 +191,8 @@ int gamer_qknorm_rope_bwd(const float* qkv, const float* dq_rot, const float* dk
                           const float* bias_q, const float* bias_k,
                           const int32_t* act_idx, int nb1,
                           float* dqkv, float* dwq, float* dwk,
-                          float* dbias_q, float* dbias_k, float* dbias_v, void* stream);
+                          float* dbias_q, float* dbias_k, float* dbias_v, const int32_t* pos_ids,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-behaviour flash attention, fp32 MFMA, head_dim 64, GQA group nq/nkv in {1,2,4}.
@@ -182,6 +208,9 @@ int gamer_qknorm_rope_bwd(const float* qkv, const float* dq_rot, const float* dk
  *   generation step.  In the reference's cached decode an empty row is uniform over the keys that existed
  *   when the row was computed (model.py:603-617), so row i spans max(uniform_len, i+1) keys; pass the
  *   prompt length.
+ *   q_span (NULL = Qwen3Multi's plain causal rule): int32 [B,S,4] = (hi, hole_lo, hole_hi, unused) per query
+ *   row, hi <= i: key j is allowed iff j <= hi and not (hole_lo <= j < hole_hi) and kl[j] < ql[i]
+ *   (gamer_session_spans); row_empty / tile_empty must then describe that predicate.
  * bwd: delta[b,h,i] = dO.O, dq and dk/dv, no atomics.  ds_work == NULL: two recompute kernels (7 matmuls per
  *   tile pair).  ds_work = B*nq*ceil(S/32)^2*1024 floats of scratch: the dk/dv kernel spills its dS tiles there
  *   and dq is one matmul per tile that streams them back (5 matmuls; +2 x that many bytes of HBM traffic).
@@ -198,7 +227,7 @@ int gamer_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float
                    const int32_t* tile_empty,
                    int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                    float* o, float* lse, const int32_t* row_perm, const int32_t* tile_kind,
-                   const int32_t* tile_maxpos, int uniform_len, void* stream);
+                   const int32_t* tile_maxpos, int uniform_len, const int32_t* q_span, void* stream);
 int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                    const float* o, const float* d_o, const float* lse,
                    const int32_t* kl, const int32_t* ql, const int32_t* row_empty,
@@ -206,7 +235,7 @@ int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float
                    int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                    float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                    const int32_t* row_perm, const int32_t* tile_kind, const int32_t* tile_maxpos,
-                   float* ds_work, void* stream);
+                   float* ds_work, const int32_t* q_span, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise pieces of the decoder layer (model.py:147,217,235,241; FFN.py:25-27).
