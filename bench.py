@@ -34,7 +34,7 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f
 HBM_PEAK_GBS = 8000.0
 
 
-def algorithmic_flops(cfg, batch) -> dict:
+def algorithmic_flops(cfg, batch, session: bool = False) -> dict:
     """per non-pad token 2*MACs of every projection / expert / head GEMM, plus
     1536 FLOP per allowed (query, key) pair per attention layer; train step = 3 x forward."""
     ids, keep, a = batch["input_ids"], batch["attention_mask"].bool(), batch["actions"]
@@ -49,12 +49,27 @@ def algorithmic_flops(cfg, batch) -> dict:
     f_tok += n_inj * (3 * 2 * (H + Eb) * I - 2 * Eb * I) + (L - n_inj) * 3 * 2 * H * I     # gate+up on Din, down on I
     f_tok += 2 * H * cfg.vocab_size
     t_nonpad = int(keep.sum())
-    csum = keep.long().cumsum(1)
-    p_self = int(csum.sum())                                       # sum_i #{j<=i, keep_j} (all query rows)
-    p_cross = 0
-    for lv in torch.unique(a).tolist():
-        less = ((a < lv) & keep).long().cumsum(1)
-        p_cross += int(less[a == lv].sum())
+    if session:
+        # Qwen3SessionMulti masks: count the allowed pairs per sequence from the oracle-independent definition
+        # (own item up to the query + strictly earlier sessions; cross additionally needs a lower level)
+        p_self = p_cross = 0
+        sess = batch["session_ids"]
+        S = ids.shape[1]
+        i_idx, j_idx = torch.arange(S)[:, None], torch.arange(S)[None, :]
+        in_item = (j_idx // cfg.num_positions == i_idx // cfg.num_positions) & (j_idx <= i_idx)
+        for b0 in range(0, ids.shape[0], 64):
+            sl = slice(b0, b0 + 64)
+            earlier = sess[sl, None, :] < sess[sl, :, None]
+            kp = keep[sl, None, :]
+            p_self += int(((in_item[None] | earlier) & kp).sum())
+            p_cross += int((earlier & (a[sl, None, :] < a[sl, :, None]) & kp).sum())
+    else:
+        csum = keep.long().cumsum(1)
+        p_self = int(csum.sum())                                       # sum_i #{j<=i, keep_j} (all query rows)
+        p_cross = 0
+        for lv in torch.unique(a).tolist():
+            less = ((a < lv) & keep).long().cumsum(1)
+            p_cross += int(less[a == lv].sum())
     pair = 4 * dh * nq
     f_fwd = t_nonpad * f_tok + pair * (L * p_self + n_cross * p_cross)
     return dict(per_token=f_tok, fwd=f_fwd, step=3 * f_fwd, tokens=t_nonpad, p_self=p_self, p_cross=p_cross)
@@ -185,7 +200,7 @@ def committed_traffic(kernel_substr: str):
             "fetch_kib_raw": f, "write_kib": w}
 
 
-def cpu_baseline(cfg_dict, seq_items: int, micro_batch: int = 8, timed_steps: int = 2):
+def cpu_baseline(cfg_dict, seq_items: int, micro_batch: int = 8, timed_steps: int = 2, session_mean=None):
     """The CPU oracle's train step (fwd + bwd + clip + AdamW, dropout on) on this host's cores."""
     from oracle import qwen3multi_oracle as orc
     from gamer_amd import synthetic
@@ -199,9 +214,11 @@ def cpu_baseline(cfg_dict, seq_items: int, micro_batch: int = 8, timed_steps: in
     v = {k: torch.zeros_like(x) for k, x in sd.items()}
     times = []
     for step in range(1 + timed_steps):
-        batch = synthetic.make_batch(micro_batch, seq_items, 256, 3, seed=100 + step, behavior_probs=[0.7, 0.25, 0.05])
+        batch = synthetic.make_batch(micro_batch, seq_items, 256, 3, seed=100 + step, behavior_probs=[0.7, 0.25, 0.05],
+                                     session_mean=session_mean)
         t0 = time.perf_counter()
-        _, grads, _ = orc.loss_and_grads(params, ocfg, batch, temperature=0.7, training=True)
+        _, grads, _ = orc.loss_and_grads(params, ocfg, batch, temperature=0.7, training=True,
+                                         session=session_mean is not None)
         orc.clip_and_adamw(params, grads, m, v, step=step + 1, lr=5e-4)
         times.append(time.perf_counter() - t0)
         log(f"cpu baseline step {step}: {times[-1]:.2f} s")
@@ -225,6 +242,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--ragged", action="store_true", help="secondary workload: n_items ~ U{2..items}, right padded")
+    ap.add_argument("--variant", choices=["multi", "session"], default="multi",
+                    help="secondary workload: 'session' = Qwen3SessionMulti (session-wise masks, same weights)")
+    ap.add_argument("--session-mean", type=float, default=4.0, help="items per session for --variant session")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -251,7 +271,8 @@ def main():
     if args.no_dropout:
         cfg.dropout_rate = 0.0
         cfg.attention_dropout = 0.0
-    eng = Engine(cfg, device=f"cuda:{local_rank}", temperature=0.7)
+    eng = Engine(cfg, device=f"cuda:{local_rank}", temperature=0.7, variant=args.variant)
+    smean = args.session_mean if args.variant == "session" else None
     eng.init_weights(seed=0)                     # identical replicas on every rank
     eng.base_seed = 0x5EED + rank                # independent dropout streams per rank
     reducer = GradAllReducer(eng.flat_g, eng.layout, cfg.num_hidden_layers) if (world > 1 or force_dist) else None
@@ -260,16 +281,18 @@ def main():
 
     def make(step):
         b = synthetic.make_batch(args.batch, args.items, 256, 3, ragged=args.ragged,
-                                 seed=20251114 + 1000 * rank + step, behavior_probs=[0.7, 0.25, 0.05])
+                                 seed=20251114 + 1000 * rank + step, behavior_probs=[0.7, 0.25, 0.05],
+                                 session_mean=smean)
         return {k: v.cuda(non_blocking=True) for k, v in b.items()}
 
     # inputs are resident in HBM before the timed region starts
     n_batches = min(args.steps + args.warmup, 4)
     batches = [make(s) for s in range(n_batches)]
     cpu_batches = [synthetic.make_batch(args.batch, args.items, 256, 3, ragged=args.ragged,
-                                        seed=20251114 + 1000 * rank + s, behavior_probs=[0.7, 0.25, 0.05])
+                                        seed=20251114 + 1000 * rank + s, behavior_probs=[0.7, 0.25, 0.05],
+                                        session_mean=smean)
                    for s in range(n_batches)]
-    flops = [algorithmic_flops(cfg, b) for b in cpu_batches]
+    flops = [algorithmic_flops(cfg, b, session=args.variant == "session") for b in cpu_batches]
     timer = KernelTimer()
     timer.install()
     lr = 5e-4
@@ -320,7 +343,8 @@ def main():
                  "gemm_wgrad": "gemm_f32_kernel<false, false, 1, false"}.get(dom["kernel"] if dom else "", None)
         traffic = committed_traffic(kname) if (kname and args.batch == 1024 and args.items == 101) else None
         result = {
-            "metric": "train-step sequences/sec, Qwen3Multi SMB decoder, his_len=100",
+            "metric": ("train-step sequences/sec, Qwen3Multi SMB decoder, his_len=100" if args.variant == "multi" else
+                       "train-step sequences/sec, Qwen3SessionMulti SMB decoder, his_len=100"),
             "value": seqs / elapsed,
             "unit": "sequences/s",
             "n_gpus": world,
@@ -333,7 +357,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": ("Qwen3Multi SMB decoder train step (fwd+bwd+clip+AdamW, dropout 0.2), ShortVideoAD-shaped "
+                "workload": (("Qwen3Multi" if args.variant == "multi" else
+                              f"Qwen3SessionMulti (sessions of {args.session_mean:g} items on average)") +
+                             " SMB decoder train step (fwd+bwd+clip+AdamW, dropout 0.2), ShortVideoAD-shaped "
                              f"synthetic ids, per-GPU batch {args.batch} x {args.items * 5} tokens"
                              + (" ragged" if args.ragged else "") + ", V=1041, fp32"),
                 "global_batch": args.batch * world,
@@ -360,7 +386,7 @@ def main():
             "loss": final_loss,
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg.to_dict(), args.items)
+            result["cpu_baseline"] = cpu_baseline(cfg.to_dict(), args.items, session_mean=smean)
         # RCCL prints a version banner through C stdio; push it out first so that the JSON line is last
         try:
             import ctypes
