@@ -41,3 +41,27 @@ def evaluate_behavior(engine, batches: Iterable[Dict], trie: ItemTrie, num_beams
     out = {m: sums[m] / max(total, 1) for m in metric_list}
     out["samples"] = total
     return out
+
+
+@torch.no_grad()
+def evaluate_dataset(engine, data, max_his_len: int, behaviors: Sequence[str] = None, num_beams: int = 20,
+                     batch_size: int = 64, metric_list: Sequence[str] = ("hit@1", "hit@5", "hit@10", "ndcg@5", "ndcg@10"),
+                     rank: int = 0, world: int = 1) -> Dict[str, Dict[str, float]]:
+    """``TestSMBDecoder.test`` over a dataset directory (test_SMB_decoder.py:408-440, 455-540): for every behaviour
+    the test users that hold it in their last session, prompts from ``gamer_amd.data.Collator.test`` (history + the
+    behaviour token), beams constrained to that behaviour's item trie.  ``data`` is a ``gamer_amd.data.SMBData``."""
+    from . import data as gdata
+    samples = data.test_samples(max_his_len)
+    coll = gdata.Collator(data)
+    out = {}
+    for beh in (behaviors if behaviors is not None else data.behaviors):
+        sub = samples.filter_by_behavior(beh)
+        trie = ItemTrie(data.candidate_tokens(beh).tolist(), device=engine.device)
+
+        def gen():
+            for idx in gdata.batches(len(sub), batch_size, rank=rank, world=world):
+                inputs, targets = coll.test(sub, idx, behavior=beh)
+                yield {"input_ids": inputs["input_ids"], "attention_mask": inputs["attention_mask"],
+                       "actions": inputs["actions"], "targets": [t.tolist() for t in targets]}
+        out[beh] = evaluate_behavior(engine, gen(), trie, num_beams, metric_list, item_len=data.sole_item_len)
+    return out

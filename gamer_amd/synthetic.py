@@ -163,3 +163,48 @@ def make_eval_batch(batch_size: int, max_his: int, catalogue: torch.Tensor, targ
     return {"input_ids": ids, "attention_mask": mask, "actions": actions, "targets": targets,
             "session_ids": torch.where(mask.bool(), pos // TOKENS_PER_ITEM, torch.zeros_like(ids)),
             "extended_session_ids": torch.where(mask.bool(), pos, torch.zeros_like(ids))}
+
+
+def write_smb_dataset(root: str, name: str, n_users: int = 40, n_items: int = 60, codebook: int = 16,
+                      behavior_level: Optional[Dict[str, int]] = None, max_sessions: int = 7,
+                      max_per_session: int = 4, seed: int = 0, min_sessions: int = 2) -> str:
+    """Write a small session-wise multi-behaviour dataset in the reference's ON-DISK format
+    (ref:docs/datasets.md:57-94; the shipped data files are git-LFS pointers): ``<root>/<name>/<name>.SMB.inter.json``
+    (user -> item ids), ``.SMB.behavior.json`` (user -> behaviour names), ``.SMB.session.json`` (user -> raw session
+    ids, not 0-based), ``.SMB.time.json`` (user -> "%Y-%m-%d %H:%M:%S"), ``.behavior_level.json``, ``.index.json``
+    (item -> 4 semantic-ID tokens).  Users get min_sessions..max_sessions sessions: with two sessions a user has no
+    training prefix (skipped by SMB_dataset.py:567-568) and an empty validation history; single-session users
+    (min_sessions=1) make the reference's test collator fail on an empty history (collator.py:181), so the default
+    leaves them out.  Returns the dataset directory."""
+    import datetime
+    import json
+    import os
+    import random
+    rng = random.Random(seed)
+    if behavior_level is None:
+        behavior_level = {"click": 0, "cart": 1, "buy": 2}
+    names = list(behavior_level)
+    d = os.path.join(root, name)
+    os.makedirs(d, exist_ok=True)
+    index = {str(i): [f"<{c}_{rng.randrange(codebook)}>" for c in "abcd"] for i in range(n_items)}
+    inter, beh, sess, tim = {}, {}, {}, {}
+    for u in range(n_users):
+        n_sess = rng.randint(min_sessions, max_sessions)
+        sid = rng.randint(0, 5)
+        t = datetime.datetime(2024, 1, 1) + datetime.timedelta(minutes=rng.randint(0, 10 ** 5))
+        items, bs, ss, ts = [], [], [], []
+        for _ in range(n_sess):
+            for _ in range(rng.randint(1, max_per_session)):
+                items.append(rng.randrange(n_items))
+                bs.append(rng.choices(names, weights=[6, 2, 1][:len(names)] + [1] * max(0, len(names) - 3))[0])
+                ss.append(sid)
+                t += datetime.timedelta(seconds=rng.randint(30, 4000))
+                ts.append(t.strftime("%Y-%m-%d %H:%M:%S"))
+            sid += rng.randint(1, 3)
+            t += datetime.timedelta(hours=rng.randint(2, 60))
+        inter[str(u)], beh[str(u)], sess[str(u)], tim[str(u)] = items, bs, ss, ts
+    for suffix, obj in ((".SMB.inter.json", inter), (".SMB.behavior.json", beh), (".SMB.session.json", sess),
+                        (".SMB.time.json", tim), (".behavior_level.json", behavior_level), (".index.json", index)):
+        with open(os.path.join(d, name + suffix), "w") as f:
+            json.dump(obj, f)
+    return d

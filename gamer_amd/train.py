@@ -4,11 +4,17 @@
 Same step semantics as the reference's HF-Trainer run (gradient accumulation, loss = sum CE / number
 of label tokens in the accumulation window across ranks, clip_grad_norm_(1.0), AdamW, cosine schedule
 with warm-up, per-epoch checkpoints with the reference's file layout), flag names reused from the
-reference where they exist.  Data are synthetic (the reference's datasets are git-LFS pointers); one
-process per GPU, launch with torch.distributed.run for more than one.
+reference where they exist.  One process per GPU, launch with torch.distributed.run for more than one.
+
+Data: with ``--data_path/--dataset`` a dataset directory in the reference's on-disk format is read by
+``gamer_amd.data`` (``--tasks smb_explicit_decoder[_N]`` as upstream; the reference's own data files are git-LFS
+pointers, ``gamer_amd.synthetic.write_smb_dataset`` writes a stand-in in the same format); without it the batches
+are synthetic tensors of the same layout.
 
   python -m gamer_amd.train --max_his_len 100 --per_device_batch_size 128 --gradient_accumulation_steps 4 \
       --epochs 1 --steps_per_epoch 20 --output_dir /tmp/ckpt
+  python -m gamer_amd.train --data_path ./data --dataset ShortVideoAD --tasks smb_explicit_decoder_4 \
+      --backbone Qwen3Multi --max_his_len 100 --per_device_batch_size 128 --epochs 2
 """
 from __future__ import annotations
 
@@ -41,6 +47,11 @@ def parse_args(argv=None):
     ap.add_argument("--max_grad_norm", type=float, default=1.0)
     ap.add_argument("--logging_step", type=int, default=30)
     ap.add_argument("--ragged", action="store_true", help="variable history lengths (right padded)")
+    ap.add_argument("--data_path", type=str, default="", help="directory holding <dataset>/<dataset>.SMB.*.json")
+    ap.add_argument("--dataset", type=str, default="")
+    ap.add_argument("--index_file", type=str, default=".index.json")
+    ap.add_argument("--tasks", type=str, default="smb_explicit_decoder_4")
+    ap.add_argument("--backbone", type=str, default="Qwen3Multi", choices=["Qwen3Multi", "Qwen3SessionMulti"])
     ap.add_argument("--output_dir", type=str, default="")
     ap.add_argument("--resume_from_checkpoint", type=str, default="")
     return ap.parse_args(argv)
@@ -79,8 +90,29 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
-    cfg = synthetic_config(n_positions=args.max_his_len + 1)
-    eng = Engine(cfg, device=f"cuda:{local_rank}", temperature=args.temperature)
+    variant = "session" if args.backbone == "Qwen3SessionMulti" else "multi"
+    accum = args.gradient_accumulation_steps
+    real = None
+    if args.data_path:
+        # load_SMB_datasets(..., tasks) for the explicit-decoder task family (loading_SMB.py:39-55)
+        from . import data as gdata
+        task = args.tasks.lower()
+        if not task.startswith("smb_explicit_decoder"):
+            raise NotImplementedError(f"tasks={args.tasks}: only smb_explicit_decoder[_N] is built")
+        augment = int(task.split("_")[3]) if task != "smb_explicit_decoder" else None
+        ds = gdata.SMBData(args.data_path, args.dataset, args.index_file)
+        samples = ds.train_samples(args.max_his_len, augment=augment)
+        coll = gdata.Collator(ds)
+        cfg = gdata.model_config(ds, args.max_his_len)
+        per_step = args.per_device_batch_size * accum * world
+        args.steps_per_epoch = max(1, len(samples) // per_step)            # drop_last, as the window needs equal shards
+        real = dict(samples=samples, coll=coll)
+        if rank == 0:
+            print(json.dumps({"dataset": args.dataset, "train_samples": len(samples), "vocab_size": cfg.vocab_size,
+                              "steps_per_epoch": args.steps_per_epoch}), flush=True)
+    else:
+        cfg = synthetic_config(n_positions=args.max_his_len + 1)
+    eng = Engine(cfg, device=f"cuda:{local_rank}", temperature=args.temperature, variant=variant)
     eng.init_weights(seed=args.seed)
     eng.base_seed = args.seed * 1000 + rank
     reducer = GradAllReducer(eng.flat_g, eng.layout, cfg.num_hidden_layers) if world > 1 else None
@@ -91,11 +123,29 @@ def main(argv=None):
         state = load_checkpoint(eng, args.resume_from_checkpoint)
     items = args.max_his_len + 1
     t_last, seq_since = time.time(), 0
-    accum = args.gradient_accumulation_steps
+    epoch_order = {}
+
+    def real_micro(step):
+        """micro-batches of this rank for one optimizer step: a per-epoch permutation (same on every rank), cut into
+        windows of world * accum * batch samples, rank r taking the r-th slice of every micro-batch group"""
+        import numpy as np
+        ep, k = divmod(step, args.steps_per_epoch)
+        if ep not in epoch_order:
+            epoch_order.clear()
+            epoch_order[ep] = np.random.RandomState(args.seed + ep).permutation(len(real["samples"]))
+        bs = args.per_device_batch_size
+        win = epoch_order[ep][k * bs * accum * world:(k + 1) * bs * accum * world]
+        return [real["coll"].train(real["samples"], win[(a * world + rank) * bs:(a * world + rank + 1) * bs])
+                for a in range(accum)]
+
     while state["global_step"] < total_steps:
         step = state["global_step"]
-        micro = [synthetic.make_batch(args.per_device_batch_size, items, 256, 3, ragged=args.ragged,
-                                      seed=args.seed + 7919 * (step * accum + a) + 104729 * rank) for a in range(accum)]
+        if real is not None:
+            micro = real_micro(step)
+        else:
+            micro = [synthetic.make_batch(args.per_device_batch_size, items, 256, 3, ragged=args.ragged,
+                                          seed=args.seed + 7919 * (step * accum + a) + 104729 * rank,
+                                          session_mean=4.0 if variant == "session" else None) for a in range(accum)]
         # label tokens of the whole accumulation window, over all ranks (HF num_items_in_batch)
         n_items = torch.tensor([float(sum(int((b["labels"][:, 1:] != -100).sum()) for b in micro))], device=eng.device)
         all_reduce_scalar_(n_items)
@@ -104,7 +154,8 @@ def main(argv=None):
         loss_sum = 0.0
         for a, b in enumerate(micro):
             loss, _ = eng.forward(b["input_ids"], b["attention_mask"], b["actions"], labels=b["labels"],
-                                  num_items_in_batch=n_items, train=True)
+                                  num_items_in_batch=n_items, train=True, session_ids=b.get("session_ids"),
+                                  extended_session_ids=b.get("extended_session_ids"))
             last = a == accum - 1
             eng.backward(1.0, layer_done=reducer.layer_done if (reducer and last) else None)
             loss_sum += float(loss) if (step + 1) % args.logging_step == 0 else 0.0
@@ -116,6 +167,7 @@ def main(argv=None):
         seq_since += args.per_device_batch_size * accum * world
         if (step + 1) % args.logging_step == 0 or step + 1 == total_steps:
             torch.cuda.synchronize()
+            eng.check_inputs()
             now = time.time()
             rec = {"step": step + 1, "loss": loss_sum * world if loss_sum else float(loss) * world * accum,
                    "grad_norm": float(eng.grad_norm), "learning_rate": lr,

@@ -28,6 +28,38 @@ def test_train_harness_learns_and_resumes(tmp_path):
     assert abs(state2["log_history"][-1]["loss"] - losses[-1]) < 0.15
 
 
+@pytest.mark.parametrize("backbone", ["Qwen3Multi", "Qwen3SessionMulti"])
+def test_train_harness_on_a_dataset_in_the_reference_format(tmp_path, backbone):
+    """--data_path/--dataset/--tasks as upstream: dataset directory (written in the reference's on-disk format) ->
+    gamer_amd.data samples -> collated id tensors -> engine; the loss falls and a checkpoint with the dataset's
+    vocabulary is written."""
+    from gamer_amd import synthetic, train
+    synthetic.write_smb_dataset(str(tmp_path / "data"), "Syn", n_users=300, n_items=200, codebook=32, max_sessions=9, seed=1)
+    out = tmp_path / "ckpt"
+    state = train.main(["--data_path", str(tmp_path / "data"), "--dataset", "Syn", "--tasks", "smb_explicit_decoder_2",
+                        "--backbone", backbone, "--max_his_len", "20", "--per_device_batch_size", "32",
+                        "--gradient_accumulation_steps", "1", "--epochs", "6", "--logging_step", "5",
+                        "--output_dir", str(out)])
+    losses = [r["loss"] for r in state["log_history"]]
+    assert state["global_step"] >= 30 and losses[-1] < losses[0] - 0.3, losses
+    cks = sorted(os.listdir(out))
+    cfg = json.load(open(os.path.join(out, cks[-1], "config.json")))
+    assert cfg["vocab_size"] == 14 + 4 * 32 + 3 and len(cfg["behavior_maps"]) == 3
+    if backbone == "Qwen3Multi":
+        # the evaluation task on the same directory: test split -> prompts -> trie-constrained beams -> metrics
+        from gamer_amd import data as gdata
+        from gamer_amd.evaluate import evaluate_dataset
+        from gamer_amd.modeling import Qwen3MultiWithTemperature
+        model = Qwen3MultiWithTemperature.from_pretrained(os.path.join(out, cks[-1]))
+        ds = gdata.SMBData(str(tmp_path / "data"), "Syn")
+        res = evaluate_dataset(model.engine, ds, 20, num_beams=10, batch_size=50,
+                               metric_list=("hit@1", "hit@10", "ndcg@10", "recall@10"))
+        test = ds.test_samples(20)
+        for beh in ds.behaviors:
+            assert res[beh]["samples"] == len(test.filter_by_behavior(beh))
+            assert 0.0 <= res[beh]["hit@1"] <= res[beh]["hit@10"] <= 1.0 and 0.0 <= res[beh]["ndcg@10"] <= 1.0
+
+
 def test_bench_rccl_path_single_rank():
     env = dict(os.environ, GAMER_BENCH_FORCE_DIST="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--items", "21", "--steps", "2",
