@@ -131,7 +131,8 @@ def item_tokens(codes: torch.Tensor, behavior: int, codebook: int = 256) -> torc
 
 def make_eval_batch(batch_size: int, max_his: int, catalogue: torch.Tensor, target_behavior: int, codebook: int = 256,
                     num_behavior: int = 3, min_his: int = 1, seed: int = 1,
-                    behavior_probs: Optional[Sequence[float]] = None) -> Dict[str, torch.Tensor]:
+                    behavior_probs: Optional[Sequence[float]] = None,
+                    session_mean: Optional[float] = None) -> Dict[str, torch.Tensor]:
     """Evaluation prompts with the layout of ``DecoderOnlyTestCollator`` + ``test_single_behavior``
     (ref:SeqRec/datasets/collator.py:149-207, ref:SeqRec/tasks/test_SMB_decoder.py:98-118): histories of
     catalogue items, LEFT padded (ids with the pad id, actions with 100), followed by the target behaviour
@@ -160,9 +161,30 @@ def make_eval_batch(batch_size: int, max_his: int, catalogue: torch.Tensor, targ
         mask[b, start:] = 1
         targets[b] = catalogue[pick[n]]
     pos = torch.arange(S)[None, :].expand(batch_size, S)
+    if session_mean is None:
+        return {"input_ids": ids, "attention_mask": mask, "actions": actions, "targets": targets,
+                "session_ids": torch.where(mask.bool(), pos // TOKENS_PER_ITEM, torch.zeros_like(ids)),
+                "extended_session_ids": torch.where(mask.bool(), pos, torch.zeros_like(ids))}
+    # Layout of DecoderOnlyTestCollator for the session models (collator.py:176-195): the history's session ids
+    # (0-based, SMB_dataset.py:106) and extended ids, LEFT padded with 0, then max + 1 for the behaviour token
+    gs = torch.Generator().manual_seed(seed + 7919)
+    sess = torch.zeros(batch_size, S, dtype=torch.int64)
+    ext = torch.zeros(batch_size, S, dtype=torch.int64)
+    for b in range(batch_size):
+        n = int(lens[b])
+        new = torch.rand(n, generator=gs) < (1.0 / float(session_mean))
+        new[0] = True
+        gap = torch.randint(1, 3, (n,), generator=gs) * new
+        raw = torch.cumsum(gap, 0) - gap[0]
+        rank = torch.cumsum(new.to(torch.int64), 0) - 1
+        start = S - 1 - n * TOKENS_PER_ITEM
+        sess[b, start:S - 1] = raw.repeat_interleave(TOKENS_PER_ITEM)
+        ext[b, start:S - 1] = (rank.repeat_interleave(TOKENS_PER_ITEM) * TOKENS_PER_ITEM
+                               + torch.arange(TOKENS_PER_ITEM).repeat(n))
+        sess[b, S - 1] = int(raw.max()) + 1
+        ext[b, S - 1] = int(ext[b].max()) + 1
     return {"input_ids": ids, "attention_mask": mask, "actions": actions, "targets": targets,
-            "session_ids": torch.where(mask.bool(), pos // TOKENS_PER_ITEM, torch.zeros_like(ids)),
-            "extended_session_ids": torch.where(mask.bool(), pos, torch.zeros_like(ids))}
+            "session_ids": sess, "extended_session_ids": ext}
 
 
 def write_smb_dataset(root: str, name: str, n_users: int = 40, n_items: int = 60, codebook: int = 16,

@@ -17,6 +17,13 @@
   only reorders ``past_key_values``, so after a beam re-ordering the cross cache rows of GENERATED positions belong
   to other beams.  Those keys are masked for every query except "empty" rows (no lower-level key in the prompt),
   whose uniform attention then averages V rows of the wrong beam.  Rows with a non-empty mask are unaffected.
+* Qwen3SessionMulti (``session_ids`` / ``extended_session_ids`` given): its cached steps use a plain causal self
+  mask and the prompt's last cross-mask row (Qwen3SessionMulti/model.py:598-613, 716-728) and advance the RoPE
+  position by one per generated token from the prompt's largest extended id (:969-982).  Re-running the whole
+  sequence with the TRAINING masks gives exactly that when the generated tokens carry the behaviour token's
+  session id (they sit in its item block and every history key belongs to an earlier session, so the self mask
+  lets them see everything before them; their own session is excluded from the cross mask like the generated keys
+  are in the cached row) and extended ids last + 1, last + 2, ...
 * ``ranking``: ref:SeqRec/evaluation/ranking.py:5-90 on token tuples instead of decoded strings.
 
 Pinned by tests/golden/decode_small.npz (oracle/make_golden_decode.py runs the real reference).
@@ -47,7 +54,7 @@ class ItemTrie:
 
 
 def beam_search(sd, cfg, input_ids, attention_mask, actions, trie: ItemTrie, num_beams: int, max_new_tokens: int = 4,
-                forward=None):
+                forward=None, session_ids=None, extended_session_ids=None):
     """Returns (sequences [B*num_beams, L0+max_new_tokens], sequences_scores [B*num_beams]), best beam first."""
     B, L0 = input_ids.shape
     V = sd["model.embed_tokens.weight"].shape[0]
@@ -63,11 +70,18 @@ def beam_search(sd, cfg, input_ids, attention_mask, actions, trie: ItemTrie, num
         am = torch.cat([am0, torch.ones(B, step, dtype=am0.dtype)], 1).repeat_interleave(num_beams, 0)
         # generated tokens belong to the target item: same behaviour level as its behaviour token
         act = torch.cat([act0, act0[:, -1:].expand(B, step)], 1).repeat_interleave(num_beams, 0)
+        skw = {}
+        if session_ids is not None:
+            sess = torch.cat([session_ids, session_ids[:, -1:].expand(B, step)], 1)
+            ext = torch.cat([extended_session_ids, extended_session_ids[:, -1:] + torch.arange(1, step + 1)[None, :]], 1)
+            skw = dict(session_ids=sess.repeat_interleave(num_beams, 0),
+                       extended_session_ids=ext.repeat_interleave(num_beams, 0))
         if forward is None:
             with torch.no_grad():
-                logits = orc.forward(sd, cfg, flat, am, act, act_zero_col=L0 - 1, uniform_len=L0)["logits"][:, -1].float()
+                logits = orc.forward(sd, cfg, flat, am, act, act_zero_col=L0 - 1, uniform_len=L0,
+                                     **skw)["logits"][:, -1].float()
         else:
-            logits = forward(flat, am, act, L0 - 1)
+            logits = forward(flat, am, act, L0 - 1, **skw)
         logp = torch.log_softmax(logits, -1)
         masked = torch.full_like(logp, -math.inf)
         for n in range(B * num_beams):

@@ -7,8 +7,13 @@ history + target behaviour token, 4 new tokens, beam search constrained by the r
 ``prefix_allowed_tokens_fn_by_last_token`` - and scores the beams with the reference's ``ranking.py``.
 Stores inputs, the item catalogue, the returned sequences / sequences_scores and the metrics.
 
-Usage:  python oracle/make_golden_decode.py        (build container only; writes tests/golden/decode_small.npz)
+``session`` argument: the same through ``Qwen3SessionMultiWithTemperature`` (test_SMB_decoder.py:181-199 passes
+the collator's session_ids / extended_session_ids), histories grouped into sessions of several items.
+
+Usage:  python oracle/make_golden_decode.py [session]   (build container only; writes tests/golden/decode_small.npz
+        or decode_session_small.npz)
 """
+import functools
 import json
 import os
 import sys
@@ -42,8 +47,9 @@ def scaled_state_dict(ocfg):
     return sd
 
 
-def main():
-    Model, Cfg = _ref_loader.load_reference_classes()
+def main(session: bool = False):
+    Model, Cfg = _ref_loader.load_reference_classes(session=session)
+    out_path = OUT.replace("decode_small", "decode_session_small") if session else OUT
     from SeqRec.generation.trie import Trie, prefix_allowed_tokens_fn_by_last_token
     from SeqRec.evaluation.ranking import get_metrics_results, get_topk_results
     V = synthetic.vocab_size(CB, NB)
@@ -58,13 +64,28 @@ def main():
     model.load_state_dict({**sd, "lm_head.weight": sd["model.embed_tokens.weight"]}, strict=True)
     model.eval()
     model.generation_config.pad_token_id = synthetic.PAD_ID
+    if session:
+        # Shim for the installed transformers 5.x: its generate() no longer hands ``cache_position`` to forward(),
+        # which Qwen3SessionMulti/model.py:969-982 relies on to advance the RoPE position of the generated tokens
+        # (the pinned 4.51 passes arange(L0) for the prompt and [L0 + t] afterwards).  Supply exactly that.
+        orig_forward = model.forward
+
+        @functools.wraps(orig_forward)          # generate() validates its kwargs against forward's signature
+        def forward_with_cache_position(*a, **k):
+            pkv = k.get("past_key_values")
+            if k.get("cache_position") is None and pkv is not None and k.get("input_ids") is not None:
+                past = pkv.get_seq_length()
+                k["cache_position"] = torch.arange(past, past + k["input_ids"].shape[1])
+            return orig_forward(*a, **k)
+        model.forward = forward_with_cache_position
     catalogue = synthetic.make_catalogue(N_CAT, CB, seed=3)
     all_item_tokens = [synthetic.item_tokens(catalogue, b, CB).tolist() for b in range(NB)]
     last_token_set = set(t[-1] for beh in all_item_tokens for t in beh)
     last_token_set.add(synthetic.PAD_ID)
     res = dict(catalogue=catalogue.numpy())
     for tb in range(NB):
-        batch = synthetic.make_eval_batch(B, MAX_HIS, catalogue, tb, CB, NB, seed=40 + tb)
+        batch = synthetic.make_eval_batch(B, MAX_HIS, catalogue, tb, CB, NB, seed=40 + tb,
+                                          session_mean=2.0 if session else None)
         trie = Trie(all_item_tokens[tb])
         fn = prefix_allowed_tokens_fn_by_last_token(trie, last_token_set)
         with torch.no_grad():
@@ -109,19 +130,22 @@ def main():
         print(f"behaviour {tb}: min score gap between ranked beams {float(gaps):.3e}; metrics {metrics}")
         res.update({f"b{tb}_input_ids": batch["input_ids"].numpy(), f"b{tb}_attention_mask": batch["attention_mask"].numpy(),
                     f"b{tb}_actions": batch["actions"].numpy(), f"b{tb}_targets": batch["targets"].numpy(),
+                    f"b{tb}_session_ids": batch["session_ids"].numpy(),
+                    f"b{tb}_extended_session_ids": batch["extended_session_ids"].numpy(),
                     f"b{tb}_sequences": seqs.numpy(), f"b{tb}_scores": scores.numpy().astype(np.float64),
                     f"b{tb}_topk": np.array(topk, dtype=np.int8),
                     f"b{tb}_metrics": np.array([metrics[m] for m in METRICS], dtype=np.float64)})
     meta = dict(config={**{k: getattr(ocfg, k) for k in OracleConfig.__dataclass_fields__},
                         "behavior_maps": {str(k): v for k, v in bmaps.items()}},
+                model="Qwen3SessionMultiWithTemperature" if session else "Qwen3MultiWithTemperature",
                 codebook=CB, num_behavior=NB, beams=BEAMS, weight_seed=WSEED, weight_scale=WSCALE, metrics=METRICS,
                 generator=dict(torch=torch.__version__, transformers=__import__("transformers").__version__,
                                reference="wzf2000/GAMER @ /root/reference"))
     res["meta_json"] = np.array(json.dumps(meta))
-    np.savez_compressed(OUT, **res)
-    print("wrote", OUT, os.path.getsize(OUT))
+    np.savez_compressed(out_path, **res)
+    print("wrote", out_path, os.path.getsize(out_path))
 
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    main()
+    main(session="session" in sys.argv[1:])

@@ -18,10 +18,11 @@ from gamer_amd.decode import ItemTrie
 from oracle import decode_oracle as dec, qwen3multi_oracle as orc
 
 FX = os.path.join(os.path.dirname(__file__), "golden", "decode_small.npz")
+FX_SESSION = os.path.join(os.path.dirname(__file__), "golden", "decode_session_small.npz")
 
 
-def _load():
-    fx = np.load(FX)
+def _load(path=FX):
+    fx = np.load(path)
     meta = json.loads(str(fx["meta_json"]))
     ocfg = orc.OracleConfig.from_dict(meta["config"])
     sd = orc.init_state_dict(ocfg, seed=meta["weight_seed"])
@@ -74,6 +75,26 @@ def test_oracle_beam_search_matches_reference_generate(tb):
         rf = torch.from_numpy(fx[f"b{tb}_scores_crossfix"]).view(-1, beams)
         assert float((rs[empty] - rf[empty]).abs().max()) > 1e-4
         assert float((rs[~empty] - rf[~empty]).abs().max() if (~empty).any() else 0.0) < 1e-6
+
+
+@pytest.mark.parametrize("tb", [0, 1, 2])
+def test_oracle_session_beam_search_matches_reference_generate(tb):
+    """Qwen3SessionMultiWithTemperature.generate (fixture from the real class): same rules as above."""
+    fx, meta, ocfg, sd = _load(FX_SESSION)
+    assert meta["model"] == "Qwen3SessionMultiWithTemperature"
+    beams, cb = meta["beams"], meta["codebook"]
+    ids, am, act = _case(fx, tb)
+    sess, ext = torch.from_numpy(fx[f"b{tb}_session_ids"]), torch.from_numpy(fx[f"b{tb}_extended_session_ids"])
+    assert bool((sess[:, :-1].max(1).values + 1 == sess[:, -1]).all())          # the test collator's layout
+    trie = dec.ItemTrie(synthetic.item_tokens(torch.from_numpy(fx["catalogue"]), tb, cb).tolist())
+    seq, sc = dec.beam_search(sd, ocfg, ids, am, act, trie, beams, 4, session_ids=sess, extended_session_ids=ext)
+    empty = _empty_target_rows(am, act)
+    _check(seq, sc, fx, tb, "_crossfix", torch.ones_like(empty), beams, 2e-5)
+    if (~empty).any():
+        _check(seq, sc, fx, tb, "", ~empty, beams, 2e-5)
+    # and the session masks matter on this fixture: Qwen3Multi's masks give other scores
+    _, sc_multi = dec.beam_search(sd, ocfg, ids, am, act, trie, beams, 4)
+    assert float((sc_multi - sc).abs().max()) > 1e-3
 
 
 def test_metrics_match_reference_ranking():
