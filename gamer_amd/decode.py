@@ -91,7 +91,13 @@ class DecodeSession:
     layers with the ordinary row kernels (norms, GEMMs with M = B*num_beams rows, SwiGLU) - all new tokens of a
     step sit at the same position, hence in the same position-routed expert - and ``gamer_attn_decode``."""
 
-    def __init__(self, engine, input_ids, attention_mask, actions, num_beams: int, max_new_tokens: int):
+    def __init__(self, engine, input_ids, attention_mask, actions, num_beams: int, max_new_tokens: int,
+                 session_ids=None, extended_session_ids=None):
+        """``session_ids`` / ``extended_session_ids`` [B, L0] (the test collator's layout, collator.py:176-195) for a
+        "session" engine: the prompt runs with the session masks; the generated tokens then see every kept key in
+        the self attention and the prompt's last cross-mask row in the cross attention, exactly as for Qwen3Multi
+        (Qwen3SessionMulti/model.py:598-613, 716-728), with RoPE positions last extended id + 1, + 2, ...
+        (:969-982)."""
         cfg, dev = engine.cfg, engine.device
         self.eng, self.nb, self.tmax = engine, num_beams, max_new_tokens
         self.B, self.L0 = input_ids.shape
@@ -109,7 +115,17 @@ class DecodeSession:
         def sink(layer, kind, k, v):
             self.kp[(layer, kind)] = k.clone()
             self.vp[(layer, kind)] = v.contiguous()          # v is a column slice of the qkv buffer
-        engine.forward(ids0, am0, act0, train=False, act_zero_col=L0 - 1, uniform_len=L0, kv_sink=sink)
+        self.session = engine.variant == "session"
+        if self.session and (session_ids is None or extended_session_ids is None):
+            raise ValueError("a session engine needs session_ids and extended_session_ids")
+        skw = {}
+        if self.session:
+            sid0 = session_ids.to(dev, torch.int64)
+            ext0 = extended_session_ids.to(dev, torch.int64)
+            skw = dict(session_ids=sid0, extended_session_ids=ext0)
+        engine.forward(ids0, am0, act0, train=False, act_zero_col=L0 - 1, uniform_len=L0, kv_sink=sink, **skw)
+        if self.session:
+            engine.check_inputs()
         # last-row logits of every sample (copied: the workspace is reused)
         self.prefill_logits = engine.ws.logits.view(B, L0, -1)[:, -1].clone()
         # masks of the new rows: self = kept keys; cross = kept keys of a lower level than the target behaviour
@@ -117,6 +133,10 @@ class DecodeSession:
         lv = act0[:, -1:]
         self.ok_self = am0.to(torch.int32).contiguous()
         ok_cross = (am0[:, :] != 0) & (act0 < lv)
+        if self.session:
+            ok_cross &= sid0 < sid0[:, -1:]              # Qwen3SessionMulti/model.py:582-584, last prompt row
+            # RoPE table row of the token generated at step t: the prompt's largest extended id + t
+            self.pos_last = ext0.max(dim=1).values.to(torch.int32).repeat_interleave(nb).contiguous()
         ok_cross[:, -1] = False
         self.ok_cross = ok_cross.to(torch.int32).contiguous()
         self.uniform_cross = (~ok_cross.any(1)).to(torch.int32).contiguous()
@@ -154,7 +174,11 @@ class DecodeSession:
         t = self.t
         p = L0 + t - 1                                   # position of the new token
         cos, sin = eng.rope(L0 + self.tmax)
-        cos, sin = cos[p:p + 1], sin[p:p + 1]
+        pos_ids = None
+        if self.session:
+            pos_ids = (self.pos_last + t).contiguous()   # per beam row; the table is indexed through pos_ids
+        else:
+            cos, sin = cos[p:p + 1], sin[p:p + 1]
         e = p % cfg.num_positions + 1                    # position-routed expert (router.py:83-104), same for every row
         x, x1, x2 = b["x"]
         ops.embedding_fwd(tokens.contiguous(), eng.params["model.embed_tokens.weight"], x)
@@ -163,9 +187,10 @@ class DecodeSession:
             ops.linear_fwd(hin, H, Wa["qkv"], H, b["qkv"], QKV, N, QKV, H)
             if kind == "cross":
                 ops.qknorm_rope_fwd(b["qkv"], 1, nq, nkv, Wa["qn"], Wa["kn"], eps, cos, sin, b["q"], b["k"],
-                                    bias_q=Wa["bq"], bias_k=Wa["bk"], bias_v=Wa["bv"], act_idx=act_idx)
+                                    bias_q=Wa["bq"], bias_k=Wa["bk"], bias_v=Wa["bv"], act_idx=act_idx, pos_ids=pos_ids)
             else:
-                ops.qknorm_rope_fwd(b["qkv"], 1, nq, nkv, Wa["qn"], Wa["kn"], eps, cos, sin, b["q"], b["k"])
+                ops.qknorm_rope_fwd(b["qkv"], 1, nq, nkv, Wa["qn"], Wa["kn"], eps, cos, sin, b["q"], b["k"],
+                                    pos_ids=pos_ids)
             kg, vg = self.gen[(layer, kind)]
             kg[:, t - 1] = b["k"]
             vg[:, t - 1] = b["qkv"][:, NQ + NKV:]
@@ -207,11 +232,13 @@ class DecodeSession:
 
 @torch.no_grad()
 def beam_search(engine, input_ids: torch.Tensor, attention_mask: torch.Tensor, actions: torch.Tensor, trie: ItemTrie,
-                num_beams: int, max_new_tokens: int = 4, use_cache: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+                num_beams: int, max_new_tokens: int = 4, use_cache: bool = True, session_ids=None,
+                extended_session_ids=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """input_ids / attention_mask / actions: [B, L0] left-padded prompts ending with the target behaviour token.
     Returns (sequences [B*num_beams, L0+max_new_tokens] int64, sequences_scores [B*num_beams] fp32), the beams of
     sample b at rows b*num_beams .., best first - the layout of HF's GenerateBeamOutput.
-    ``use_cache=False`` re-runs the whole sequence every step (the cross-check of the cache path)."""
+    ``use_cache=False`` re-runs the whole sequence every step (the cross-check of the cache path).
+    ``session_ids`` / ``extended_session_ids`` [B, L0]: required by a "session" engine (see DecodeSession)."""
     dev = engine.device
     B, L0 = input_ids.shape
     V = engine.cfg.vocab_size
@@ -231,7 +258,25 @@ def beam_search(engine, input_ids: torch.Tensor, attention_mask: torch.Tensor, a
     node, nxt = nxt, node
     scores = torch.empty(N, V, device=dev)
     final = None
-    session = DecodeSession(engine, ids0, am0, act0, nb, max_new_tokens) if use_cache else None
+    sess_variant = engine.variant == "session"
+    if sess_variant:
+        if session_ids is None or extended_session_ids is None:
+            raise ValueError("a session engine needs session_ids and extended_session_ids")
+        sid0 = session_ids.to(dev, torch.int64)
+        ext0 = extended_session_ids.to(dev, torch.int64)
+
+    def session_kw(step, repeat):
+        """ids of prompt + ``step`` generated tokens for the full re-run: the generated tokens carry the behaviour
+        token's session id and the next extended ids, which makes the training masks equal to the cached ones"""
+        if not sess_variant:
+            return {}
+        sid = torch.cat([sid0, sid0[:, -1:].expand(B, step)], 1)
+        ext = torch.cat([ext0, ext0[:, -1:] + torch.arange(1, step + 1, device=dev)[None, :]], 1)
+        if repeat:
+            sid, ext = sid.repeat_interleave(nb, 0), ext.repeat_interleave(nb, 0)
+        return dict(session_ids=sid, extended_session_ids=ext)
+    session = (DecodeSession(engine, ids0, am0, act0, nb, max_new_tokens, session_ids if sess_variant else None,
+                             extended_session_ids if sess_variant else None) if use_cache else None)
     last_tok = None
     for step in range(max_new_tokens):
         cur = L0 + step
@@ -244,14 +289,14 @@ def beam_search(engine, input_ids: torch.Tensor, attention_mask: torch.Tensor, a
                 rows = torch.arange(N, device=dev, dtype=torch.int32)
         elif step == 0:
             # all beams of a sample hold the same prompt: run it once (HF runs num_beams copies)
-            engine.forward(ids0, am0, act0, train=False, act_zero_col=L0 - 1, uniform_len=L0)
+            engine.forward(ids0, am0, act0, train=False, act_zero_col=L0 - 1, uniform_len=L0, **session_kw(0, False))
             rows = (torch.arange(N, device=dev, dtype=torch.int32) // nb) * cur + (cur - 1)
         else:
             flat = seqs.reshape(N, cur)
             am = torch.cat([am0, am0.new_ones(B, step)], 1).repeat_interleave(nb, 0)
             # generated tokens belong to the target item: same behaviour level as its behaviour token
             act = torch.cat([act0, act0[:, -1:].expand(B, step)], 1).repeat_interleave(nb, 0)
-            engine.forward(flat, am, act, train=False, act_zero_col=L0 - 1, uniform_len=L0)
+            engine.forward(flat, am, act, train=False, act_zero_col=L0 - 1, uniform_len=L0, **session_kw(step, True))
             rows = torch.arange(N, device=dev, dtype=torch.int32) * cur + (cur - 1)
         if session is None:
             logits2d = engine.ws.logits

@@ -353,8 +353,6 @@ class Engine:
             # Qwen3SessionMulti/model.py:784-806: both masks are rebuilt from session_ids on every forward
             if session_ids is None:
                 raise ValueError("Session IDs must be provided to generate session-wise causal mask.")
-            if kv_sink is not None or uniform_len not in (0, S):
-                raise NotImplementedError("cached generation is not built for the session variant")
             sid = session_ids.to(self.device, torch.int64).contiguous()
             ext = (extended_session_ids.to(self.device, torch.int64).contiguous()
                    if extended_session_ids is not None else None)

@@ -24,7 +24,8 @@ def evaluate_behavior(engine, batches: Iterable[Dict], trie: ItemTrie, num_beams
     total = 0
     for batch in batches:
         seqs, scores = beam_search(engine, batch["input_ids"], batch["attention_mask"], batch["actions"], trie,
-                                   num_beams, item_len)
+                                   num_beams, item_len, session_ids=batch.get("session_ids"),
+                                   extended_session_ids=batch.get("extended_session_ids"))
         pred = seqs[:, -item_len:].cpu().tolist()
         topk = gm.get_topk_results(pred, scores.cpu().tolist(), batch["targets"], num_beams)
         res = gm.get_metrics_results(topk, metric_list, batch["targets"])
@@ -62,6 +63,8 @@ def evaluate_dataset(engine, data, max_his_len: int, behaviors: Sequence[str] = 
             for idx in gdata.batches(len(sub), batch_size, rank=rank, world=world):
                 inputs, targets = coll.test(sub, idx, behavior=beh)
                 yield {"input_ids": inputs["input_ids"], "attention_mask": inputs["attention_mask"],
-                       "actions": inputs["actions"], "targets": [t.tolist() for t in targets]}
+                       "actions": inputs["actions"], "session_ids": inputs["session_ids"],
+                       "extended_session_ids": inputs["extended_session_ids"],
+                       "targets": [t.tolist() for t in targets]}
         out[beh] = evaluate_behavior(engine, gen(), trie, num_beams, metric_list, item_len=data.sole_item_len)
     return out

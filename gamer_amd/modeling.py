@@ -198,9 +198,9 @@ class Qwen3MultiWithTemperature(nn.Module):
             raise NotImplementedError("num_return_sequences must equal num_beams (what the evaluation task uses)")
         if attention_mask is None or actions is None:
             raise ValueError("generate() needs attention_mask and actions")
-        if self.VARIANT != "multi":
-            raise NotImplementedError("generate() is built for Qwen3Multi only")
-        seqs, scores = decode.beam_search(self.engine, input_ids, attention_mask, actions, trie, num_beams, max_new_tokens)
+        seqs, scores = decode.beam_search(self.engine, input_ids, attention_mask, actions, trie, num_beams, max_new_tokens,
+                                          session_ids=kwargs.get("session_ids"),
+                                          extended_session_ids=kwargs.get("extended_session_ids"))
         return CausalLMOutput(sequences=seqs, sequences_scores=scores)
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,

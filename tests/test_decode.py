@@ -206,6 +206,43 @@ def test_engine_beam_search_matches_reference_generate(tb):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tb", [0, 1, 2])
+def test_engine_session_beam_search_matches_reference_generate(tb):
+    """Qwen3SessionMulti: the session engine's cached generation against the real class's ``generate``, the full
+    re-run path and the oracle; and through the nn.Module's ``generate``."""
+    from gamer_amd.config import Qwen3MultiConfig
+    from gamer_amd.decode import beam_search, prefix_allowed_tokens
+    from gamer_amd.modeling import Qwen3SessionMultiWithTemperature
+    fx, meta, ocfg, sd = _load(FX_SESSION)
+    beams, cb = meta["beams"], meta["codebook"]
+    model = Qwen3SessionMultiWithTemperature(Qwen3MultiConfig(**meta["config"]))
+    model.set_hyper(0.7)
+    model.load_state_dict(sd)
+    eng = model.engine
+    ids, am, act = _case(fx, tb)
+    sess, ext = torch.from_numpy(fx[f"b{tb}_session_ids"]), torch.from_numpy(fx[f"b{tb}_extended_session_ids"])
+    items = synthetic.item_tokens(torch.from_numpy(fx["catalogue"]), tb, cb).tolist()
+    trie = ItemTrie(items)
+    seq, sc = beam_search(eng, ids, am, act, trie, beams, 4, session_ids=sess, extended_session_ids=ext)
+    seq_nc, sc_nc = beam_search(eng, ids, am, act, trie, beams, 4, use_cache=False, session_ids=sess,
+                                extended_session_ids=ext)
+    assert torch.equal(seq, seq_nc) and float((sc - sc_nc).abs().max()) < 2e-5
+    empty = _empty_target_rows(am, act)
+    _check(seq, sc, fx, tb, "_crossfix", torch.ones_like(empty), beams, 1e-4)
+    if (~empty).any():
+        _check(seq, sc, fx, tb, "", ~empty, beams, 1e-4)
+    oseq, osc = dec.beam_search(sd, ocfg, ids, am, act, dec.ItemTrie(items), beams, 4, session_ids=sess,
+                                extended_session_ids=ext)
+    assert torch.equal(seq.cpu(), oseq) and float((sc.cpu() - osc).abs().max()) < 1e-4
+    out = model.generate(input_ids=ids, attention_mask=am, actions=act, session_ids=sess, extended_session_ids=ext,
+                         max_new_tokens=4, prefix_allowed_tokens_fn=prefix_allowed_tokens(trie), num_beams=beams,
+                         num_return_sequences=beams)
+    assert torch.equal(out.sequences, seq) and torch.equal(out.sequences_scores, sc)
+    with pytest.raises(ValueError):
+        beam_search(eng, ids, am, act, trie, beams, 4)                  # the session ids are mandatory
+
+
+@pytest.mark.gpu
 def test_evaluate_behavior_matches_reference_metrics():
     """Behaviour 2 of the fixture: no empty target row, so the reference's own metrics apply unchanged."""
     from gamer_amd.config import Qwen3MultiConfig

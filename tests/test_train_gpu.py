@@ -45,19 +45,17 @@ def test_train_harness_on_a_dataset_in_the_reference_format(tmp_path, backbone):
     cks = sorted(os.listdir(out))
     cfg = json.load(open(os.path.join(out, cks[-1], "config.json")))
     assert cfg["vocab_size"] == 14 + 4 * 32 + 3 and len(cfg["behavior_maps"]) == 3
-    if backbone == "Qwen3Multi":
-        # the evaluation task on the same directory: test split -> prompts -> trie-constrained beams -> metrics
-        from gamer_amd import data as gdata
-        from gamer_amd.evaluate import evaluate_dataset
-        from gamer_amd.modeling import Qwen3MultiWithTemperature
-        model = Qwen3MultiWithTemperature.from_pretrained(os.path.join(out, cks[-1]))
-        ds = gdata.SMBData(str(tmp_path / "data"), "Syn")
-        res = evaluate_dataset(model.engine, ds, 20, num_beams=10, batch_size=50,
-                               metric_list=("hit@1", "hit@10", "ndcg@10", "recall@10"))
-        test = ds.test_samples(20)
-        for beh in ds.behaviors:
-            assert res[beh]["samples"] == len(test.filter_by_behavior(beh))
-            assert 0.0 <= res[beh]["hit@1"] <= res[beh]["hit@10"] <= 1.0 and 0.0 <= res[beh]["ndcg@10"] <= 1.0
+    # the evaluation task on the same directory: test split -> prompts -> trie-constrained beams -> metrics
+    from gamer_amd import data as gdata, modeling
+    from gamer_amd.evaluate import evaluate_dataset
+    model = getattr(modeling, backbone + "WithTemperature").from_pretrained(os.path.join(out, cks[-1]))
+    ds = gdata.SMBData(str(tmp_path / "data"), "Syn")
+    res = evaluate_dataset(model.engine, ds, 20, num_beams=10, batch_size=50,
+                           metric_list=("hit@1", "hit@10", "ndcg@10", "recall@10"))
+    test = ds.test_samples(20)
+    for beh in ds.behaviors:
+        assert res[beh]["samples"] == len(test.filter_by_behavior(beh))
+        assert 0.0 <= res[beh]["hit@1"] <= res[beh]["hit@10"] <= 1.0 and 0.0 <= res[beh]["ndcg@10"] <= 1.0
 
 
 def test_bench_rccl_path_single_rank():
