@@ -74,6 +74,12 @@ _SIGNATURES = {
     "gamer_sumsq": [P, L, P, I, P],
     "gamer_adamw": [P, P, P, P, L, L, F, F, F, F, F, I, F, F, P, I, P, P],
     "gamer_fill_f32": [P, L, F, P],
+    "gamer_bias_act_fwd": [P, P, I, I, I, P, P],
+    "gamer_bias_act_bwd": [P, P, I, I, I, P, P, I, P],
+    "gamer_layernorm_fwd": [P, P, P, P, I, I, F, P, P, P, P, P],
+    "gamer_layernorm_bwd": [P, P, P, P, P, I, I, P, P, P, I, P],
+    "gamer_attn_dense_fwd": [P, I, P, I, P, I, P, P, I, I, I, I, F, F, U, P, I, P, P],
+    "gamer_attn_dense_bwd": [P, I, P, I, P, I, P, P, I, I, I, I, F, F, U, P, P, I, P, P, I, P, I, P, I, P],
     "gamer_trie_logprobs": [P, L, P, P, P, P, P, I, I, P, P],
     "gamer_trie_advance": [P, P, P, P, P, I, P, P],
     "gamer_attn_decode": [P, I, P, I, P, I, P, P, P, I, I, I, I, P, I, I, I, I, I, F, P, P],

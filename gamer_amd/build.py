@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgamer_hip.so")
-SOURCES = ["prep.hip", "elementwise.hip", "gemm.hip", "attention.hip", "optim.hip", "decode.hip"]
+SOURCES = ["prep.hip", "elementwise.hip", "gemm.hip", "attention.hip", "optim.hip", "decode.hip", "modules.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++20", "-Wall", "-Wno-unused-function"]
 
 

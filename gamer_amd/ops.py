@@ -280,3 +280,61 @@ def attn_decode(q, kp, vp, key_ok, kg, vg, t, gen_ok, uniform, B, nb, L0, nq, nk
     call("gamer_attn_decode", ptr(q), q.stride(0), ptr(kp), kp.stride(0), ptr(vp), vp.stride(0), ptr(key_ok), ptr(kg),
          ptr(vg), kg.stride(1), tmax, t, 1 if gen_ok else 0, ptr(uniform), B, nb, L0, nq, nkv, scale, ptr(o),
          stream_ptr())
+
+
+# ---- post-LN encoder of the discriminative baselines (SeqRec/modules/layers/transformer.py) --------------------
+ACTIVATIONS = {"none": 0, "relu": 1, "gelu": 2, "swish": 3, "tanh": 4, "sigmoid": 5, "elu": 6}
+
+
+def bias_act_fwd(x, bias, act: int, y=None):
+    """x[T,N] <- x + bias in place; y = act(x + bias) when given."""
+    T, N = x.shape
+    call("gamer_bias_act_fwd", ptr(x), ptr(bias), T, N, act, ptr(y), stream_ptr())
+
+
+def bias_act_bwd(pre, dy, act: int, dx, db_partial):
+    T, N = dy.shape
+    call("gamer_bias_act_bwd", ptr(pre), ptr(dy), T, N, act, ptr(dx), ptr(db_partial), db_partial.shape[0], stream_ptr())
+
+
+def layernorm_fwd(x, res, w, b, eps, v_out, y, mean, rstd):
+    T, H = x.shape
+    call("gamer_layernorm_fwd", ptr(x), ptr(res), ptr(w), ptr(b), T, H, eps, ptr(v_out), ptr(y), ptr(mean), ptr(rstd),
+         stream_ptr())
+
+
+def layernorm_bwd(v, w, mean, rstd, dy, dx, dw_partial, db_partial):
+    T, H = v.shape
+    call("gamer_layernorm_bwd", ptr(v), ptr(w), ptr(mean), ptr(rstd), ptr(dy), T, H, ptr(dx), ptr(dw_partial),
+         ptr(db_partial), dw_partial.shape[0], stream_ptr())
+
+
+def _mask_strides(mask, B, H, S):
+    """element strides of an additive mask broadcastable to [B,H,S,S] (size-1 dims get stride 0)"""
+    if mask is None:
+        return None, None
+    if mask.dim() != 4 or mask.dtype != torch.float32:
+        raise RuntimeError("attention mask must be a 4-d float32 tensor broadcastable to [B, heads, S, S]")
+    want = (B, H, S, S)
+    st = []
+    for d in range(4):
+        if mask.shape[d] == want[d] and mask.shape[d] != 1:
+            st.append(mask.stride(d))
+        elif mask.shape[d] == 1:
+            st.append(0)
+        else:
+            raise RuntimeError(f"attention mask shape {tuple(mask.shape)} does not broadcast to {want}")
+    return mask, (C.c_int64 * 4)(*st)
+
+
+def attn_dense_fwd(q, k, v, mask, B, S, H, dh, scale, p_drop, seed, o, lse):
+    m, st = _mask_strides(mask, B, H, S)
+    call("gamer_attn_dense_fwd", ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(m), st, B, S, H, dh,
+         scale, p_drop, seed, ptr(o), o.stride(0), ptr(lse), stream_ptr())
+
+
+def attn_dense_bwd(q, k, v, mask, B, S, H, dh, scale, p_drop, seed, o, d_o, lse, dq, dk, dv):
+    m, st = _mask_strides(mask, B, H, S)
+    call("gamer_attn_dense_bwd", ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(m), st, B, S, H, dh,
+         scale, p_drop, seed, ptr(o), ptr(d_o), o.stride(0), ptr(lse), ptr(dq), dq.stride(0), ptr(dk), dk.stride(0),
+         ptr(dv), dv.stride(0), stream_ptr())

@@ -238,6 +238,40 @@ int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float
                    float* ds_work, const int32_t* q_span, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Post-LN BERT-style encoder of the discriminative baselines (SURVEY section 8(f) row 4;
+ * ref:SeqRec/modules/layers/transformer.py:12-183).  The projections and FFN matmuls use gamer_gemm_f32.
+ *   activations (FeedForward.get_hidden_act, :100-109): 0 none, 1 relu, 2 gelu (erf form), 3 swish, 4 tanh,
+ *   5 sigmoid, 6 elu.
+ * bias_act_fwd: x[T,N] <- x + bias (kept for the backward); y = act(x + bias) (y NULL with act 0: bias only).
+ * bias_act_bwd: dx = dy * act'(pre) (dx may alias dy); db_partial [n_partial, N] per-workgroup column sums
+ *   of dx, to be summed with gamer_colsum_reduce (deterministic).
+ * layernorm_fwd: v = x (+ res); y = (v - mean) / sqrt(var + eps) * w + b (biased variance, nn.LayerNorm);
+ *   v_out (optional, may alias x) and mean / rstd [T] are what the backward takes.  H <= 1024.
+ * layernorm_bwd: dx (= d v) and per-workgroup partial sums dw_partial / db_partial [n_partial, H].
+ * attn_dense_fwd/bwd (MultiHeadAttention.forward, :47-78): o = dropout(softmax(q k^T * scale + mask)) v for
+ *   head_dim <= 64 and S <= 128, one workgroup per (batch, head) with the probabilities in LDS; q/k/v/o are
+ *   [B*S, ld] with head h at column h*head_dim; mask is ADDITIVE fp32, element (b,h,i,j) at
+ *   mask[b*strides[0] + h*strides[1] + i*strides[2] + j*strides[3]] (0 strides broadcast; mask NULL: none);
+ *   lse [B,H,S].  The backward recomputes the probabilities and regenerates the dropout mask from the seed.
+ * ---------------------------------------------------------------------------------------- */
+int gamer_bias_act_fwd(float* x, const float* bias, int T, int N, int act, float* y, void* stream);
+int gamer_bias_act_bwd(const float* pre, const float* dy, int T, int N, int act, float* dx,
+                       float* db_partial, int n_partial, void* stream);
+int gamer_layernorm_fwd(const float* x, const float* res, const float* w, const float* b, int T, int H,
+                        float eps, float* v_out, float* y, float* mean, float* rstd, void* stream);
+int gamer_layernorm_bwd(const float* v, const float* w, const float* mean, const float* rstd,
+                        const float* dy, int T, int H, float* dx, float* dw_partial, float* db_partial,
+                        int n_partial, void* stream);
+int gamer_attn_dense_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                         const float* mask, const int64_t* mask_strides, int B, int S, int H, int head_dim,
+                         float scale, float p_drop, uint64_t seed, float* o, int ldo, float* lse, void* stream);
+int gamer_attn_dense_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                         const float* mask, const int64_t* mask_strides, int B, int S, int H, int head_dim,
+                         float scale, float p_drop, uint64_t seed, const float* o, const float* d_o, int ldo,
+                         const float* lse, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Elementwise pieces of the decoder layer (model.py:147,217,235,241; FFN.py:25-27).
  * ---------------------------------------------------------------------------------------- */
 /* x_out[t] = x_in[t] + drop(delta[src(t)])   src_rows optional (token -> sorted slot);
