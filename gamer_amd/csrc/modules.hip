@@ -50,21 +50,37 @@ bias_act_fwd_kernel(float* __restrict__ x, const float* __restrict__ bias, int64
     }
 }
 
-// dx = dy * act'(pre); per-workgroup column sums of dx (bias gradient), reduced by gamer_colsum_reduce
+// dx = dy * act'(pre); per-workgroup column sums of dx (bias gradient), reduced by gamer_colsum_reduce.
+// Threads = (row lane, column): cw = min(N, 256) adjacent columns per row lane (coalesced rows), 256 / cw row lanes
+// walk the workgroup's rows in parallel and are summed through LDS at the end.
 __global__ void __launch_bounds__(MOD_THREADS)
 bias_act_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dy, int T, int N, int act,
                     float* __restrict__ dx, float* __restrict__ db_partial) {
+    __shared__ float red[MOD_THREADS];
+    const int cw = N < MOD_THREADS ? N : MOD_THREADS;
+    const int rl = MOD_THREADS / cw;
+    const int c0 = threadIdx.x % cw, rlane = threadIdx.x / cw;
     const int rows_per_block = (T + gridDim.x - 1) / gridDim.x;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(T, r0 + rows_per_block);
-    for (int c = threadIdx.x; c < N; c += MOD_THREADS) {
+    for (int cb = 0; cb < N; cb += cw) {
+        const int c = cb + c0;
         float acc = 0.f;
-        for (int r = r0; r < r1; ++r) {
-            const int64_t i = (int64_t)r * N + c;
-            const float g = dy[i] * (act == ACT_NONE ? 1.f : act_bwd(pre[i], act));
-            dx[i] = g;
-            acc += g;
+        if (rlane < rl && c < N) {
+            for (int r = r0 + rlane; r < r1; r += rl) {
+                const int64_t i = (int64_t)r * N + c;
+                const float g = dy[i] * (act == ACT_NONE ? 1.f : act_bwd(pre[i], act));
+                dx[i] = g;
+                acc += g;
+            }
         }
-        db_partial[(int64_t)blockIdx.x * N + c] = acc;
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (rlane == 0 && c < N) {
+            float sum = 0.f;
+            for (int k = 0; k < rl; ++k) sum += red[k * cw + c0];
+            db_partial[(int64_t)blockIdx.x * N + c] = sum;
+        }
+        __syncthreads();
     }
 }
 
@@ -166,6 +182,7 @@ layernorm_bwd_kernel(const float* __restrict__ v, const float* __restrict__ w, c
 struct DenseAttnArgs {
     const float *q, *k, *v;      // [B*S, ld*]: head h at column h*dh
     int ldq, ldk, ldv;
+    int stage;                   // 1: the (batch, head) operand tiles fit in LDS next to the probabilities
     const float* mask;           // additive, element (b,h,i,j) at mask[b*mb + h*mh + i*mi + j*mj]; nullptr: none
     int64_t mb, mh, mi, mj;
     int B, S, H, dh;
@@ -173,11 +190,25 @@ struct DenseAttnArgs {
     uint64_t seed;
 };
 
-__device__ __forceinline__ float dense_score(const DenseAttnArgs& a, int b, int h, int i, int j) {
-    const float* qi = a.q + ((int64_t)b * a.S + i) * a.ldq + h * a.dh;
-    const float* kj = a.k + ((int64_t)b * a.S + j) * a.ldk + h * a.dh;
+// [S][dh] operand tile of one (batch, head): either the rows in global memory or a copy in LDS (row stride dh + 1,
+// conflict-free for the column walks below).  The same generic pointer serves both.
+struct OpTile {
+    const float* p;
+    int ld;
+    __device__ __forceinline__ float at(int r, int d) const { return p[(int64_t)r * ld + d]; }
+};
+__device__ __forceinline__ OpTile op_tile(const float* g, int ld, int b, int h, int S, int dh, bool stage, float*& lds_top) {
+    const float* base = g + (int64_t)b * S * ld + h * dh;
+    if (!stage) return OpTile{base, ld};
+    float* dst = lds_top;
+    lds_top += S * (dh + 1);
+    for (int e = threadIdx.x; e < S * dh; e += MOD_THREADS) dst[(e / dh) * (dh + 1) + e % dh] = base[(int64_t)(e / dh) * ld + e % dh];
+    return OpTile{dst, dh + 1};
+}
+
+__device__ __forceinline__ float dense_score(const DenseAttnArgs& a, const OpTile& Q, const OpTile& K, int b, int h, int i, int j) {
     float s = 0.f;
-    for (int d = 0; d < a.dh; ++d) s += qi[d] * kj[d];
+    for (int d = 0; d < a.dh; ++d) s += Q.at(i, d) * K.at(j, d);
     s *= a.scale;
     if (a.mask) s += a.mask[b * a.mb + h * a.mh + i * a.mi + j * a.mj];
     return s;
@@ -185,12 +216,18 @@ __device__ __forceinline__ float dense_score(const DenseAttnArgs& a, int b, int 
 
 __global__ void __launch_bounds__(MOD_THREADS)
 attn_dense_fwd_kernel(const DenseAttnArgs a, float* __restrict__ o, int ldo, float* __restrict__ lse) {
-    extern __shared__ __attribute__((aligned(16))) float P[];           // [S][S]
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* P = lds;                                                      // [S][S]
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const int S = a.S, dh = a.dh;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const DropoutRng rng(a.p_drop, a.seed);
-    for (int e = threadIdx.x; e < S * S; e += MOD_THREADS) P[e] = dense_score(a, b, h, e / S, e % S);
+    float* top = lds + S * S;
+    const OpTile Q = op_tile(a.q, a.ldq, b, h, S, dh, a.stage, top);
+    const OpTile K = op_tile(a.k, a.ldk, b, h, S, dh, a.stage, top);
+    const OpTile V = op_tile(a.v, a.ldv, b, h, S, dh, a.stage, top);
+    __syncthreads();
+    for (int e = threadIdx.x; e < S * S; e += MOD_THREADS) P[e] = dense_score(a, Q, K, b, h, e / S, e % S);
     __syncthreads();
     for (int i = wib; i < S; i += MOD_THREADS / 64) {
         float m = -INFINITY;
@@ -210,7 +247,7 @@ attn_dense_fwd_kernel(const DenseAttnArgs a, float* __restrict__ o, int ldo, flo
     for (int e = threadIdx.x; e < S * dh; e += MOD_THREADS) {
         const int i = e / dh, d = e % dh;
         float acc = 0.f;
-        for (int j = 0; j < S; ++j) acc += P[i * S + j] * a.v[((int64_t)b * S + j) * a.ldv + h * dh + d];
+        for (int j = 0; j < S; ++j) acc += P[i * S + j] * V.at(j, d);
         o[((int64_t)b * S + i) * ldo + h * dh + d] = acc;
     }
 }
@@ -226,17 +263,22 @@ attn_dense_bwd_kernel(const DenseAttnArgs a, const float* __restrict__ o, const 
     float* delta = D + S * S;         // [S]
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
     const DropoutRng rng(a.p_drop, a.seed);
+    float* top = delta + S;
+    const OpTile Q = op_tile(a.q, a.ldq, b, h, S, dh, a.stage, top);
+    const OpTile K = op_tile(a.k, a.ldk, b, h, S, dh, a.stage, top);
+    const OpTile V = op_tile(a.v, a.ldv, b, h, S, dh, a.stage, top);
+    const OpTile G = op_tile(d_o, ldo, b, h, S, dh, a.stage, top);
+    __syncthreads();
     for (int e = threadIdx.x; e < S * S; e += MOD_THREADS) {
         const int i = e / S, j = e % S;
-        const float p = __expf(dense_score(a, b, h, i, j) - lse[((int64_t)b * a.H + h) * S + i]);
+        const float p = __expf(dense_score(a, Q, K, b, h, i, j) - lse[((int64_t)b * a.H + h) * S + i]);
         P[e] = p;
         D[e] = p * rng.mult((((uint64_t)b * a.H + h) * S + i) * S + j);
     }
     for (int i = threadIdx.x; i < S; i += MOD_THREADS) {
         const float* oi = o + ((int64_t)b * S + i) * ldo + h * dh;
-        const float* gi = d_o + ((int64_t)b * S + i) * ldo + h * dh;
         float acc = 0.f;
-        for (int d = 0; d < dh; ++d) acc += oi[d] * gi[d];
+        for (int d = 0; d < dh; ++d) acc += oi[d] * G.at(i, d);
         delta[i] = acc;
     }
     __syncthreads();
@@ -244,17 +286,15 @@ attn_dense_bwd_kernel(const DenseAttnArgs a, const float* __restrict__ o, const 
     for (int e = threadIdx.x; e < S * dh; e += MOD_THREADS) {
         const int j = e / dh, d = e % dh;
         float acc = 0.f;
-        for (int i = 0; i < S; ++i) acc += D[i * S + j] * d_o[((int64_t)b * S + i) * ldo + h * dh + d];
+        for (int i = 0; i < S; ++i) acc += D[i * S + j] * G.at(i, d);
         dv[((int64_t)b * S + j) * lddv + h * dh + d] = acc;
     }
     __syncthreads();
     // dS[i][j] = Pd[i][j] * (dO_i . V_j) - P[i][j] * delta_i
     for (int e = threadIdx.x; e < S * S; e += MOD_THREADS) {
         const int i = e / S, j = e % S;
-        const float* gi = d_o + ((int64_t)b * S + i) * ldo + h * dh;
-        const float* vj = a.v + ((int64_t)b * S + j) * a.ldv + h * dh;
         float dp = 0.f;
-        for (int d = 0; d < dh; ++d) dp += gi[d] * vj[d];
+        for (int d = 0; d < dh; ++d) dp += G.at(i, d) * V.at(j, d);
         D[e] = D[e] * dp - P[e] * delta[i];
     }
     __syncthreads();
@@ -262,8 +302,8 @@ attn_dense_bwd_kernel(const DenseAttnArgs a, const float* __restrict__ o, const 
         const int r = e / dh, d = e % dh;
         float aq = 0.f, ak = 0.f;
         for (int t = 0; t < S; ++t) {
-            aq += D[r * S + t] * a.k[((int64_t)b * S + t) * a.ldk + h * dh + d];       // dQ[r] += dS[r][t] K[t]
-            ak += D[t * S + r] * a.q[((int64_t)b * S + t) * a.ldq + h * dh + d];       // dK[r] += dS[t][r] Q[t]
+            aq += D[r * S + t] * K.at(t, d);       // dQ[r] += dS[r][t] K[t]
+            ak += D[t * S + r] * Q.at(t, d);       // dK[r] += dS[t][r] Q[t]
         }
         dq[((int64_t)b * S + r) * lddq + h * dh + d] = aq * a.scale;
         dk[((int64_t)b * S + r) * lddk + h * dh + d] = ak * a.scale;
@@ -274,6 +314,8 @@ attn_dense_bwd_kernel(const DenseAttnArgs a, const float* __restrict__ o, const 
 
 using namespace gamer;
 #define ST(s) ((hipStream_t)(s))
+
+constexpr size_t DENSE_LDS_MAX = 150 * 1024;      // of the 160 KB per CU
 
 static int mod_grid(int64_t n) {
     int64_t blocks = (n + MOD_THREADS - 1) / MOD_THREADS;
@@ -332,7 +374,7 @@ static int dense_args(const char* name, DenseAttnArgs& a, const float* q, int ld
     GAMER_CHECK_ARG(ldq >= H * dh && ldk >= H * dh && ldv >= H * dh, "%s: bad leading dims", name);
     GAMER_CHECK_ARG(!mask || mask_strides, "%s: a mask needs its four strides", name);
     GAMER_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "%s: p_drop=%f", name, p_drop);
-    a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+    a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.stage = 0;
     a.mask = mask;
     a.mb = mask ? mask_strides[0] : 0; a.mh = mask ? mask_strides[1] : 0;
     a.mi = mask ? mask_strides[2] : 0; a.mj = mask ? mask_strides[3] : 0;
@@ -349,11 +391,14 @@ extern "C" int gamer_attn_dense_fwd(const float* q, int ldq, const float* k, int
                         p_drop, seed);
     if (rc) return rc;
     GAMER_CHECK_ARG(o && lse && ldo >= H * head_dim, "gamer_attn_dense_fwd: bad output");
-    const size_t shmem = (size_t)S * S * sizeof(float);
+    size_t shmem = (size_t)S * S * sizeof(float);
+    const size_t staged = shmem + (size_t)3 * S * (head_dim + 1) * sizeof(float);
+    a.stage = staged <= DENSE_LDS_MAX ? 1 : 0;
+    if (a.stage) shmem = staged;
     static bool attr = false;
     if (!attr) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dense_fwd_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 4);
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)DENSE_LDS_MAX);
         if (e != hipSuccess) { set_error("gamer_attn_dense_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         attr = true;
     }
@@ -372,11 +417,14 @@ extern "C" int gamer_attn_dense_bwd(const float* q, int ldq, const float* k, int
                         p_drop, seed);
     if (rc) return rc;
     GAMER_CHECK_ARG(o && d_o && lse && dq && dk && dv, "gamer_attn_dense_bwd: null pointer");
-    const size_t shmem = ((size_t)2 * S * S + S) * sizeof(float);
+    size_t shmem = ((size_t)2 * S * S + S) * sizeof(float);
+    const size_t staged = shmem + (size_t)4 * S * (head_dim + 1) * sizeof(float);
+    a.stage = staged <= DENSE_LDS_MAX ? 1 : 0;
+    if (a.stage) shmem = staged;
     static bool attr = false;
     if (!attr) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dense_bwd_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (2 * 128 * 128 + 128) * 4);
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)DENSE_LDS_MAX);
         if (e != hipSuccess) { set_error("gamer_attn_dense_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         attr = true;
     }

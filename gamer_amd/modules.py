@@ -25,7 +25,7 @@ from torch.nn import functional as F
 
 from . import ops
 
-_N_PARTIAL = 64
+_N_PARTIAL = 256
 _ACT_BY_FN = {F.relu: "relu", F.gelu: "gelu", F.silu: "swish", F.tanh: "tanh", torch.tanh: "tanh",
               F.sigmoid: "sigmoid", torch.sigmoid: "sigmoid", F.elu: "elu"}
 
