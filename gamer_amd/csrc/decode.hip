@@ -65,106 +65,185 @@ trie_advance_kernel(const int32_t* __restrict__ node, const int64_t* __restrict_
 //
 // The reference expands every prompt to num_beams copies and caches K/V per copy (HF generate); the prompt
 // part of those copies is identical, so here it is stored once per sample ([B, L0] rows) and only the <= 4
-// generated positions are per beam.  One workgroup = (sample, kv head): the prompt K/V tiles go through LDS
-// once and serve all num_beams * G query rows.  HBM-bound on the prompt K/V of one layer (~0.2 GB per call at
-// 256 users), the arithmetic is plain VALU (a few thousand FMAs per lane).
+// generated positions are per beam.  One workgroup = (sample, kv head); its num_beams * G <= 64 query rows are
+// two 32-column MFMA tiles, so the prompt part is the forward kernel's inner loop (S^T = K Q^T with the query
+// on the lane, scores straight into O^T += V^T P^T, v_mfma_f32_32x32x2_f32) with the KEY range split over the
+// four waves: every wave streams its own 32-key tiles through a private LDS region (no workgroup barrier in
+// the loop) and the four partial (max, sum, O) states are merged through LDS at the end, flash-decoding style.
+// (The first version did the dot products on the VALU out of LDS and was LDS-bandwidth bound: 0.39 ms per call
+// at 256 users x 20 beams against 0.1 ms for this one.)
 //   self attention : prompt key j allowed iff key_ok[b][j]; generated keys (own ancestors + itself) allowed
 //   cross attention: prompt key j allowed iff key_ok[b][j] (= kept and lower level than the target behaviour, the
 //                    cached last mask row of model.py:603-617); generated keys masked; uniform[b] = 1 when no key
 //                    is allowed: the row is then the mean of V over ALL L0 + t keys (finfo.min quirk)
-constexpr int DEC_MAXQ = 16;            // query rows per wave (4 waves): num_beams * G <= 64
+constexpr int DEC_MAXQ = 16;            // query rows per wave in the tail (4 waves): num_beams * G <= 64
+constexpr int DEC_KLD = 68;             // floats per row of the K tile image (16-byte aligned rows, conflict-free)
+constexpr int DEC_WAVE_LDS = 32 * DEC_KLD + 32 * 64 + 32;          // K tile + V tile + key_ok tile
+constexpr int DEC_OLD = 65;             // row stride of the merged-state image [64 queries][64 d]
+constexpr int DEC_MERGE_LDS = 4 * (64 * DEC_OLD + 128);
+constexpr int DEC_LDS_FLOATS = DEC_MERGE_LDS > 4 * DEC_WAVE_LDS ? DEC_MERGE_LDS : 4 * DEC_WAVE_LDS;
+
+typedef float dec_f32x16 __attribute__((ext_vector_type(16)));
 
 template <int G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 attn_decode_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ kp, int ldkp,
                    const float* __restrict__ vp, int ldvp, const int32_t* __restrict__ key_ok,
                    const float* __restrict__ kg, const float* __restrict__ vg, int ldg, int tmax, int t, int gen_ok,
                    const int32_t* __restrict__ uniform, int nb, int L0, int nq, int nkv, float scale,
                    float* __restrict__ o) {
-    __shared__ float Ks[64 * 65];
-    __shared__ __attribute__((aligned(16))) float Vs[64 * 64];
-    __shared__ __attribute__((aligned(16))) float qs[64 * 64];
-    __shared__ float ps[4][64];
-    __shared__ int32_t oks[64];
+    extern __shared__ __attribute__((aligned(16))) float dec_lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.x / nkv, kvh = blockIdx.x % nkv;
     const int Qn = nb * G;
     const bool uni = uniform != nullptr && uniform[b] != 0;
-    for (int f = tid; f < Qn * 16; f += 256) {
-        const int qi = f >> 4, c4 = (f & 15) << 2;
-        const int n = b * nb + qi / G, head = kvh * G + qi % G;
-        *reinterpret_cast<float4*>(&qs[qi * 64 + c4]) = *reinterpret_cast<const float4*>(q + (int64_t)n * ldq + head * 64 + c4);
-    }
-    float m[DEC_MAXQ], l[DEC_MAXQ], acc[DEC_MAXQ];
-#pragma unroll
-    for (int i = 0; i < DEC_MAXQ; ++i) { m[i] = -INFINITY; l[i] = 0.f; acc[i] = 0.f; }
-    float vsum = 0.f;                        // sum over the prompt keys of V[j][lane] (uniform rows)
-    for (int j0 = 0; j0 < L0; j0 += 64) {
+    const float c2 = scale * 1.4426950408889634f;               // scores live in the log2 domain
+    float* mrg_m = dec_lds;                                     // [4][64] running max of every wave
+    float* mrg_l = dec_lds + 256;                               // [4][64] running sum
+    float* mrg_o = dec_lds + 512;                               // [4][64][DEC_OLD] partial O
+
+    if (uni) {
+        // mean of V over the prompt keys (+ the generated ones in the tail): wave w sums keys w, w+4, ...
+        float vsum = 0.f;
+        for (int j = w; j < L0; j += 4) vsum += vp[((int64_t)b * L0 + j) * ldvp + kvh * 64 + lane];
+        mrg_o[w * 64 + lane] = vsum;
         __syncthreads();
-        for (int f = tid; f < 64 * 16; f += 256) {
-            const int row = f >> 4, c4 = (f & 15) << 2;
-            const int j = j0 + row;
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (j < L0) {
-                kv = *reinterpret_cast<const float4*>(kp + ((int64_t)b * L0 + j) * ldkp + kvh * 64 + c4);
-                vv = *reinterpret_cast<const float4*>(vp + ((int64_t)b * L0 + j) * ldvp + kvh * 64 + c4);
+    } else {
+        float* Kw = dec_lds + w * DEC_WAVE_LDS;
+        float* Vw = Kw + 32 * DEC_KLD;
+        int32_t* okw = reinterpret_cast<int32_t*>(Vw + 32 * 64);
+        // query fragments of the two 32-column tiles (columns past Qn are zero and never stored)
+        float qf[2][8][4];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int qi = qt * 32 + r;
+            const bool live = qi < Qn;
+            const int qc = live ? qi : 0;
+            const float* qrow = q + (int64_t)(b * nb + qc / G) * ldq + (kvh * G + qc % G) * 64;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float4 t4 = *reinterpret_cast<const float4*>(qrow + 8 * kk + 4 * h);
+                qf[qt][kk][0] = live ? t4.x * c2 : 0.f; qf[qt][kk][1] = live ? t4.y * c2 : 0.f;
+                qf[qt][kk][2] = live ? t4.z * c2 : 0.f; qf[qt][kk][3] = live ? t4.w * c2 : 0.f;
             }
-            Ks[row * 65 + c4] = kv.x; Ks[row * 65 + c4 + 1] = kv.y; Ks[row * 65 + c4 + 2] = kv.z; Ks[row * 65 + c4 + 3] = kv.w;
-            *reinterpret_cast<float4*>(&Vs[row * 64 + c4]) = vv;
         }
-        if (tid < 64) oks[tid] = (j0 + tid < L0) ? key_ok[(int64_t)b * L0 + j0 + tid] : 0;
-        __syncthreads();
-        if (uni) {
-            if (w == 0) for (int j = 0; j < 64; ++j) vsum += Vs[j * 64 + lane];
-            continue;
-        }
-        const bool ok = oks[lane] != 0;
+        float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+        dec_f32x16 oacc[2][2];
 #pragma unroll
-        for (int i = 0; i < DEC_MAXQ; ++i) {
-            const int qi = w + 4 * i;
-            if (qi >= Qn) break;
-            float s = 0.f;
-            for (int d = 0; d < 64; ++d) s += qs[qi * 64 + d] * Ks[lane * 65 + d];
-            s = ok ? s * scale : -INFINITY;
-            const float mt = wave_max(s);
-            if (mt == -INFINITY) continue;                    // nothing allowed in this tile
-            const float mn = fmaxf(m[i], mt);
-            const float alpha = __expf(m[i] - mn);            // m = -inf -> 0
-            const float pe = __expf(s - mn);
-            l[i] = l[i] * alpha + wave_sum(pe);
-            m[i] = mn;
-            ps[w][lane] = pe;
+        for (int i = 0; i < 16; ++i) { oacc[0][0][i] = 0.f; oacc[0][1][i] = 0.f; oacc[1][0][i] = 0.f; oacc[1][1][i] = 0.f; }
+        const int n_tiles = (L0 + 31) >> 5;
+        for (int jt = w; jt < n_tiles; jt += 4) {
+            const int j0 = jt * 32;
+            // this wave's K / V tile: 512 float4 each, 8 per lane; rows past the prompt are zero
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int f = lane + 64 * i, row = f >> 4, c4 = (f & 15) << 2;
+                const int j = j0 + row;
+                float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+                if (j < L0) {
+                    kv = *reinterpret_cast<const float4*>(kp + ((int64_t)b * L0 + j) * ldkp + kvh * 64 + c4);
+                    vv = *reinterpret_cast<const float4*>(vp + ((int64_t)b * L0 + j) * ldvp + kvh * 64 + c4);
+                }
+                *reinterpret_cast<float4*>(&Kw[row * DEC_KLD + c4]) = kv;
+                *reinterpret_cast<float4*>(&Vw[row * 64 + c4]) = vv;
+            }
+            if (lane < 32) okw[lane] = (j0 + lane < L0) ? key_ok[(int64_t)b * L0 + j0 + lane] : 0;
             __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes landed
             __builtin_amdgcn_wave_barrier();
-            float a = acc[i] * alpha;
-            for (int j = 0; j < 64; ++j) a += ps[w][j] * Vs[j * 64 + lane];
-            acc[i] = a;
-            __builtin_amdgcn_wave_barrier();
+            int okv[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int4 t4 = *reinterpret_cast<const int4*>(okw + 8 * g4 + 4 * h);
+                okv[4 * g4] = t4.x; okv[4 * g4 + 1] = t4.y; okv[4 * g4 + 2] = t4.z; okv[4 * g4 + 3] = t4.w;
+            }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                dec_f32x16 st;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) st[i] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const float4 kf = *reinterpret_cast<const float4*>(&Kw[r * DEC_KLD + 8 * kk + 4 * h]);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[qt][kk][0], st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[qt][kk][1], st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[qt][kk][2], st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[qt][kk][3], st, 0, 0, 0);
+                }
+                // register reg of lane (r, h) = score of key (reg&3) + 8*(reg>>2) + 4*h for query column r
+                float mloc = -INFINITY;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    st[reg] = okv[reg] != 0 ? st[reg] : -INFINITY;
+                    mloc = fmaxf(mloc, st[reg]);
+                }
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                const float mn = fmaxf(m_run[qt], mloc);
+                const float base = mn == -INFINITY ? 0.f : mn;               // nothing allowed so far: p = 0
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - base);     // m = -inf -> 0
+                float rowsum = 0.f;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    st[reg] = __builtin_amdgcn_exp2f(st[reg] - base);
+                    rowsum += st[reg];
+                }
+                rowsum += __shfl_xor(rowsum, 32, 64);
+                l_run[qt] = l_run[qt] * alpha + rowsum;
+                m_run[qt] = mn;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { oacc[qt][0][i] *= alpha; oacc[qt][1][i] *= alpha; }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int key = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    oacc[qt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vw[key * 64 + r], st[reg], oacc[qt][0], 0, 0, 0);
+                    oacc[qt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vw[key * 64 + 32 + r], st[reg], oacc[qt][1], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                  // the tile is consumed before the next one overwrites it
         }
-    }
-    if (uni) {                               // wave 0 holds the prompt sum: publish it (block-uniform branch)
-        if (w == 0) ps[0][lane] = vsum;
+        __syncthreads();                                      // every wave is done with its tile region
+        // publish this wave's state: O[query qt*32 + r][d = 32*dh + (reg&3) + 8*(reg>>2) + 4*h]
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            if (h == 0) { mrg_m[w * 64 + qt * 32 + r] = m_run[qt]; mrg_l[w * 64 + qt * 32 + r] = l_run[qt]; }
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    mrg_o[(w * 64 + qt * 32 + r) * DEC_OLD + 32 * dh + (reg & 3) + 8 * (reg >> 2) + 4 * h] = oacc[qt][dh][reg];
+        }
         __syncthreads();
     }
-    // generated positions of each beam (its own ancestors and the new token), then the output
-#pragma unroll
+    // tail: merge the four key ranges, add the generated positions of each beam (its own ancestors and the new
+    // token), normalise and store.  Wave w takes query rows w, w + 4, ...; lane = d.
+#pragma unroll 1
     for (int i = 0; i < DEC_MAXQ; ++i) {
         const int qi = w + 4 * i;
         if (qi >= Qn) break;
         const int n = b * nb + qi / G, head = kvh * G + qi % G;
         float res;
         if (uni) {
-            float a = ps[0][lane];
+            float a = mrg_o[lane] + mrg_o[64 + lane] + mrg_o[128 + lane] + mrg_o[192 + lane];
             for (int g = 0; g < t; ++g) a += vg[((int64_t)n * tmax + g) * ldg + kvh * 64 + lane];
             res = a / (float)(L0 + t);
         } else {
-            float mi = m[i], li = l[i], a = acc[i];
+            float mi = fmaxf(fmaxf(mrg_m[qi], mrg_m[64 + qi]), fmaxf(mrg_m[128 + qi], mrg_m[192 + qi]));
+            float li = 0.f, a = 0.f;
+            if (mi > -INFINITY) {
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const float sc = __builtin_amdgcn_exp2f(mrg_m[ww * 64 + qi] - mi);        // -inf -> 0
+                    li += mrg_l[ww * 64 + qi] * sc;
+                    a += mrg_o[(ww * 64 + qi) * DEC_OLD + lane] * sc;
+                }
+            }
             if (gen_ok) {
+                const float qd = q[(int64_t)n * ldq + head * 64 + lane] * c2;
                 for (int g = 0; g < t; ++g) {
                     const float* krow = kg + ((int64_t)n * tmax + g) * ldg + kvh * 64;
-                    const float s = wave_sum(qs[qi * 64 + lane] * krow[lane]) * scale;
+                    const float s = wave_sum(qd * krow[lane]);
                     const float mn = fmaxf(mi, s);
-                    const float alpha = __expf(mi - mn), pe = __expf(s - mn);
+                    const float alpha = __builtin_amdgcn_exp2f(mi - mn), pe = __builtin_amdgcn_exp2f(s - mn);
                     li = li * alpha + pe;
                     a = a * alpha + pe * vg[((int64_t)n * tmax + g) * ldg + kvh * 64 + lane];
                     mi = mn;
@@ -217,11 +296,25 @@ extern "C" int gamer_attn_decode(const float* q, int ldq, const float* kp, int l
     GAMER_CHECK_ARG(ldq % 4 == 0 && ldkp % 4 == 0 && ldvp % 4 == 0 && aligned16(q) && aligned16(kp) && aligned16(vp),
                     "gamer_attn_decode: q / prompt K / V need 16-byte alignment and leading dims %% 4 == 0");
     dim3 grid(B * nkv);
+    const size_t shmem = (size_t)DEC_LDS_FLOATS * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_kernel<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_kernel<2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) {
+            set_error("gamer_attn_decode: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr = true;
+    }
     if (G == 1)
-        hipLaunchKernelGGL(attn_decode_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, kp, ldkp, vp, ldvp,
+        hipLaunchKernelGGL(attn_decode_kernel<1>, grid, dim3(256), shmem, (hipStream_t)stream, q, ldq, kp, ldkp, vp, ldvp,
                            key_ok, kg, vg, ldg, tmax, t, gen_ok, uniform, nb, L0, nq, nkv, scale, o);
     else
-        hipLaunchKernelGGL(attn_decode_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, kp, ldkp, vp, ldvp,
+        hipLaunchKernelGGL(attn_decode_kernel<2>, grid, dim3(256), shmem, (hipStream_t)stream, q, ldq, kp, ldkp, vp, ldvp,
                            key_ok, kg, vg, ldg, tmax, t, gen_ok, uniform, nb, L0, nq, nkv, scale, o);
     GAMER_CHECK_LAUNCH("gamer_attn_decode");
     return 0;
