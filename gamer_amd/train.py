@@ -52,6 +52,8 @@ def parse_args(argv=None):
     ap.add_argument("--index_file", type=str, default=".index.json")
     ap.add_argument("--tasks", type=str, default="smb_explicit_decoder_4")
     ap.add_argument("--backbone", type=str, default="Qwen3Multi", choices=["Qwen3Multi", "Qwen3SessionMulti"])
+    ap.add_argument("--patience", type=int, default=10, help="early stopping: evaluations without a better eval_loss")
+    ap.add_argument("--save_total_limit", type=int, default=2)
     ap.add_argument("--output_dir", type=str, default="")
     ap.add_argument("--resume_from_checkpoint", type=str, default="")
     return ap.parse_args(argv)
@@ -81,6 +83,24 @@ def load_checkpoint(eng: Engine, path: str) -> dict:
         return json.load(f)
 
 
+@torch.no_grad()
+def evaluate_loss(eng: Engine, samples, coll, batch_size: int, rank: int, world: int) -> float:
+    """eval_loss of the HF Trainer over the validation set (train_SMB_decoder.py:409-416, eval_strategy="epoch"):
+    the mean over samples of their batch's mean loss; every rank takes every world-th batch."""
+    from . import data as gdata
+    tot = torch.zeros(2, dtype=torch.float64, device=eng.device)
+    for idx in gdata.batches(len(samples), batch_size, rank=rank, world=world):
+        b = coll.train(samples, idx)
+        loss, _ = eng.forward(b["input_ids"], b["attention_mask"], b["actions"], labels=b["labels"], train=False,
+                              session_ids=b.get("session_ids"), extended_session_ids=b.get("extended_session_ids"))
+        tot[0] += loss.double() * len(idx)
+        tot[1] += len(idx)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(tot)
+    return float(tot[0] / tot[1].clamp_min(1))
+
+
 def main(argv=None):
     args = parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,7 +126,7 @@ def main(argv=None):
         cfg = gdata.model_config(ds, args.max_his_len)
         per_step = args.per_device_batch_size * accum * world
         args.steps_per_epoch = max(1, len(samples) // per_step)            # drop_last, as the window needs equal shards
-        real = dict(samples=samples, coll=coll)
+        real = dict(samples=samples, coll=coll, valid=ds.valid_samples(args.max_his_len))
         if rank == 0:
             print(json.dumps({"dataset": args.dataset, "train_samples": len(samples), "vocab_size": cfg.vocab_size,
                               "steps_per_epoch": args.steps_per_epoch}), flush=True)
@@ -118,7 +138,8 @@ def main(argv=None):
     reducer = GradAllReducer(eng.flat_g, eng.layout, cfg.num_hidden_layers) if world > 1 else None
     total_steps = args.epochs * args.steps_per_epoch
     warmup = warmup_steps_for(total_steps, args.warmup_ratio)
-    state = {"global_step": 0, "epoch": 0, "log_history": []}
+    state = {"global_step": 0, "epoch": 0, "log_history": [], "best_metric": None, "best_model_checkpoint": None,
+             "evals_without_improvement": 0}
     if args.resume_from_checkpoint:
         state = load_checkpoint(eng, args.resume_from_checkpoint)
     items = args.max_his_len + 1
@@ -178,8 +199,47 @@ def main(argv=None):
             t_last, seq_since = now, 0
         if (step + 1) % args.steps_per_epoch == 0:
             state["epoch"] = (step + 1) // args.steps_per_epoch
-            if args.output_dir and rank == 0:
-                save_checkpoint(eng, os.path.join(args.output_dir, f"checkpoint-{step + 1}"), state)
+            stop = False
+            ck = os.path.join(args.output_dir, f"checkpoint-{step + 1}") if args.output_dir else None
+            if real is not None and len(real["valid"]) > 0:
+                # evaluation + best-checkpoint bookkeeping + early stopping, as the reference's Trainer is set up
+                # (eval/save per epoch, load_best_model_at_end, EarlyStoppingCallback(patience), save_total_limit)
+                ev = evaluate_loss(eng, real["valid"], real["coll"], args.per_device_batch_size, rank, world)
+                rec = {"step": step + 1, "epoch": state["epoch"], "eval_loss": ev}
+                state["log_history"].append(rec)
+                if rank == 0:
+                    print(json.dumps(rec), flush=True)
+                if state["best_metric"] is None or ev < state["best_metric"]:
+                    state["best_metric"], state["best_model_checkpoint"] = ev, ck
+                    state["evals_without_improvement"] = 0
+                else:
+                    state["evals_without_improvement"] += 1
+                    stop = state["evals_without_improvement"] >= args.patience
+            if ck and rank == 0:
+                save_checkpoint(eng, ck, state)
+                import shutil
+                kept = sorted((d for d in os.listdir(args.output_dir) if d.startswith("checkpoint-")),
+                              key=lambda d: int(d.split("-")[1]))
+                best = os.path.basename(state["best_model_checkpoint"]) if state["best_model_checkpoint"] else None
+                for d in kept[:-1]:
+                    if len([x for x in os.listdir(args.output_dir) if x.startswith("checkpoint-")]) <= args.save_total_limit:
+                        break
+                    if d != best:
+                        shutil.rmtree(os.path.join(args.output_dir, d), ignore_errors=True)
+            if stop:
+                break
+    if real is not None and args.output_dir and state.get("best_model_checkpoint"):
+        # load_best_model_at_end + trainer.save_model(output_dir) (train_SMB_decoder.py:417, 446)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        from safetensors.torch import load_file
+        eng.load_state_dict(load_file(os.path.join(state["best_model_checkpoint"], "model.safetensors")))
+        if rank == 0:
+            eng.cfg.save_pretrained(args.output_dir)
+            from safetensors.torch import save_file
+            save_file({k: v.detach().cpu().contiguous() for k, v in eng.params.items()},
+                      os.path.join(args.output_dir, "model.safetensors"))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -17,7 +17,7 @@ def test_train_harness_learns_and_resumes(tmp_path):
     args = ["--max_his_len", "20", "--per_device_batch_size", "16", "--gradient_accumulation_steps", "2", "--epochs", "2",
             "--steps_per_epoch", "12", "--logging_step", "4", "--warmup_ratio", "0.1", "--output_dir", str(tmp_path)]
     state = train.main(args)
-    losses = [r["loss"] for r in state["log_history"]]
+    losses = [r["loss"] for r in state["log_history"] if "loss" in r]
     assert losses[-1] < losses[0] - 0.3, losses            # 24 steps at lr 5e-4 move the loss well below ln(V)
     assert all(r["grad_norm"] > 0 for r in state["log_history"])
     ck = os.path.join(str(tmp_path), "checkpoint-12")
@@ -40,15 +40,19 @@ def test_train_harness_on_a_dataset_in_the_reference_format(tmp_path, backbone):
                         "--backbone", backbone, "--max_his_len", "20", "--per_device_batch_size", "32",
                         "--gradient_accumulation_steps", "1", "--epochs", "6", "--logging_step", "5",
                         "--output_dir", str(out)])
-    losses = [r["loss"] for r in state["log_history"]]
+    losses = [r["loss"] for r in state["log_history"] if "loss" in r]
     assert state["global_step"] >= 30 and losses[-1] < losses[0] - 0.3, losses
-    cks = sorted(os.listdir(out))
-    cfg = json.load(open(os.path.join(out, cks[-1], "config.json")))
+    # per-epoch validation loss, best checkpoint, at most save_total_limit checkpoints, best model in output_dir
+    evals = [r["eval_loss"] for r in state["log_history"] if "eval_loss" in r]
+    assert len(evals) == 6 and evals[-1] < evals[0] and state["best_metric"] == min(evals)
+    cks = sorted(d for d in os.listdir(out) if d.startswith("checkpoint-"))
+    assert 1 <= len(cks) <= 3 and os.path.basename(state["best_model_checkpoint"]) in cks
+    cfg = json.load(open(os.path.join(out, "config.json")))
     assert cfg["vocab_size"] == 14 + 4 * 32 + 3 and len(cfg["behavior_maps"]) == 3
     # the evaluation task on the same directory: test split -> prompts -> trie-constrained beams -> metrics
     from gamer_amd import data as gdata, modeling
     from gamer_amd.evaluate import evaluate_dataset
-    model = getattr(modeling, backbone + "WithTemperature").from_pretrained(os.path.join(out, cks[-1]))
+    model = getattr(modeling, backbone + "WithTemperature").from_pretrained(str(out))
     ds = gdata.SMBData(str(tmp_path / "data"), "Syn")
     res = evaluate_dataset(model.engine, ds, 20, num_beams=10, batch_size=50,
                            metric_list=("hit@1", "hit@10", "ndcg@10", "recall@10"))
