@@ -146,3 +146,31 @@ def test_attention_dropout_hash_statistics():
         assert abs(np.corrcoef(keep[:-1].ravel(), keep[1:].ravel())[0, 1]) < 5e-3
         quad = (keep[:-1, :-1] & keep[:-1, 1:] & keep[1:, :-1] & keep[1:, 1:]).mean()
         assert abs(quad - 0.8 ** 4) < 4e-3
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under gamer_amd/ may import it (statically), and importing the
+    whole product package must not pull it in (dynamically)."""
+    import ast
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "gamer_amd")
+    for fn in sorted(os.listdir(pkg)):
+        if not fn.endswith(".py"):
+            continue
+        tree = ast.parse(open(os.path.join(pkg, fn)).read())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "oracle" or n.startswith("oracle.") for n in names), f"{fn} imports the oracle"
+    code = ("import sys, importlib, pkgutil, gamer_amd\n"
+            "for m in pkgutil.iter_modules(gamer_amd.__path__):\n"
+            "    if m.name not in ('build',): importlib.import_module('gamer_amd.' + m.name)\n"
+            "bad = [k for k in sys.modules if k == 'oracle' or k.startswith('oracle.')]\n"
+            "assert not bad, bad\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
