@@ -216,3 +216,43 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgamer_hip.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+@pytest.mark.parametrize("case", ["single_item", "all_padding_row", "long_sequence"])
+def test_edge_shapes_against_oracle(case):
+    """Edges the data path can produce: a one-item sequence (S = 5), a row that is padding only (every attention
+    row of it is "empty", no label), and a sequence longer than the LDS-resident dQ kernel handles (S = 1000:
+    gamer_attn_bwd falls back to the tiled dQ-from-dS kernel)."""
+    dims = dict(hidden_size=128, num_hidden_layers=4, num_attention_heads=2, num_key_value_heads=1, head_dim=64,
+                intermediate_size=256, moe_intermediate_size=128, behavior_embedding_dim=64,
+                behavior_injection_decoder=[0, 1], cross_attention_decoder=[2, 3], sparse_layers_decoder=[0, 1, 2, 3])
+    cfg = Qwen3MultiConfig(**{**synthetic_cfg_dict(), **dims})
+    ocfg = orc.OracleConfig.from_dict(cfg.to_dict())
+    sd = orc.init_state_dict(ocfg, seed=8)
+    if case == "single_item":
+        batch = synthetic.make_batch(3, 1, 256, 3, seed=5)
+    elif case == "all_padding_row":
+        batch = synthetic.make_batch(3, 6, 256, 3, seed=6)
+        for k, fill in (("input_ids", synthetic.PAD_ID), ("attention_mask", 0), ("actions", 100), ("labels", -100),
+                        ("session_ids", 0), ("extended_session_ids", 0)):
+            batch[k][1] = fill
+    else:
+        batch = synthetic.make_batch(1, 200, 256, 3, seed=7)
+    eng = Engine(cfg, temperature=0.7)
+    eng.load_state_dict(sd)
+    loss_ref, grads_ref, out_ref = orc.loss_and_grads(sd, ocfg, batch, temperature=0.7)
+    loss, logits = eng.forward(batch["input_ids"], batch["attention_mask"], batch["actions"], labels=batch["labels"],
+                               train=True, dropout=False)
+    eng.check_inputs()
+    assert _relmax(logits.cpu().numpy(), out_ref["logits"].detach().numpy()) < 2e-5
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * float(loss_ref)
+    eng.zero_grad()
+    eng.backward(1.0)
+    worst, wk = 0.0, None
+    for k, g in grads_ref.items():
+        e = _relmax(eng.grads[k].cpu().numpy(), g.numpy())
+        if e > worst:
+            worst, wk = e, k
+    _record(f"edge_{case}", dict(worst_grad=worst, key=wk, S=int(batch["input_ids"].shape[1])))
+    assert worst < 1e-3, wk
+    assert all(bool(torch.isfinite(g).all()) for g in eng.grads.values())
