@@ -270,6 +270,27 @@ class SMBData:
                                  act_beh=bh, times=tm, behavior=bh[-1], targets=None))
         return self._build("train", rows, max_his_len)
 
+    def train_samples_per_interaction(self, max_his_len: int) -> SampleSet:
+        """``tasks=smb_explicit`` - BaseSMBDataset._process_train_data (SMB_dataset.py:250-270): every interaction
+        of the training prefix except the user's first one is a target; its history is everything BEFORE ITS SESSION
+        (empty for the first session), and the session ids / times are those of the session's first interaction."""
+        rows = []
+        for uid, inter in self.inters.items():
+            vp = self.valid_pos[uid]
+            if vp <= 0:
+                continue
+            items, behs = inter[:vp], self.behaviors_by_user[uid][:vp]
+            sess, times = self.session[uid], self.time[uid][:vp]
+            first = {}
+            for idx, sid in enumerate(sess[:vp].tolist()):
+                first.setdefault(sid, idx)                         # train_pos (SMB_dataset.py:113-115)
+            for i in range(1, len(items)):
+                pos = first[int(sess[i])]
+                rows.append(dict(user=uid, hist_items=items[:pos], hist_beh=behs[:pos], target=(items[i], behs[i]),
+                                 sids=sess[:pos + 1], act_beh=list(behs[:pos]) + [behs[i]], times=times[:pos + 1],
+                                 behavior=behs[i], targets=None))
+        return self._build("train", rows, max_his_len)
+
     def valid_samples(self, max_his_len: int) -> SampleSet:
         """BaseSMBDataset._process_valid_data (SMB_dataset.py:272-296): every interaction of the validation session
         is a target after the same history; session ids / times are those of the session's first interaction."""
@@ -336,10 +357,10 @@ class Collator:
         self.ignore = list(data.behavior_token_ids.values()) if ignore_behavior_tokens else []
         self.model_max_length = model_max_length
 
-    def train(self, samples: SampleSet, index: Sequence[int]) -> Dict[str, torch.Tensor]:
-        """collator.py:55-107 with only_train_response=False (what SMBExplicitDatasetForDecoder gets,
-        train_SMB_decoder.py:271): right padding; labels = ids with pad and behaviour tokens -> -100; for a
-        validation batch the history is masked as well."""
+    def train(self, samples: SampleSet, index: Sequence[int], only_train_response: bool = False) -> Dict[str, torch.Tensor]:
+        """collator.py:55-107: right padding; labels = ids with pad and behaviour tokens -> -100; the history is
+        masked as well for a validation batch and with ``only_train_response`` (what every dataset other than
+        SMBExplicitDatasetForDecoder gets, train_SMB_decoder.py:271)."""
         sel = np.asarray(index, dtype=np.int64)
         ids, lens, L = _pad_batch(samples.ptr, samples.tokens, sel, self.pad_id, False, np.int64)
         if L > self.model_max_length:
@@ -350,7 +371,7 @@ class Collator:
         labels[ids == self.pad_id] = IGNORE_INDEX
         for t in self.ignore:
             labels[ids == t] = IGNORE_INDEX
-        if samples.mode == "valid":
+        if samples.mode == "valid" or only_train_response:
             labels[np.arange(L)[None, :] < samples.n_history[sel][:, None]] = IGNORE_INDEX
         out = {"input_ids": ids, "attention_mask": am, "labels": labels}
         out["session_ids"] = _pad_batch(samples.ptr, samples.session_ids, sel, 0, False, np.int64)[0]

@@ -117,16 +117,22 @@ def main(argv=None):
         # load_SMB_datasets(..., tasks) for the explicit-decoder task family (loading_SMB.py:39-55)
         from . import data as gdata
         task = args.tasks.lower()
-        if not task.startswith("smb_explicit_decoder"):
-            raise NotImplementedError(f"tasks={args.tasks}: only smb_explicit_decoder[_N] is built")
-        augment = int(task.split("_")[3]) if task != "smb_explicit_decoder" else None
         ds = gdata.SMBData(args.data_path, args.dataset, args.index_file)
-        samples = ds.train_samples(args.max_his_len, augment=augment)
+        only_response = False
+        if task.startswith("smb_explicit_decoder"):
+            augment = int(task.split("_")[3]) if task != "smb_explicit_decoder" else None
+            samples = ds.train_samples(args.max_his_len, augment=augment)
+        elif task == "smb_explicit":
+            # one sample per interaction, loss on the target item only (loading_SMB.py:24-38, train_SMB_decoder.py:271)
+            samples = ds.train_samples_per_interaction(args.max_his_len)
+            only_response = True
+        else:
+            raise NotImplementedError(f"tasks={args.tasks}: smb_explicit and smb_explicit_decoder[_N] are built")
         coll = gdata.Collator(ds)
         cfg = gdata.model_config(ds, args.max_his_len)
         per_step = args.per_device_batch_size * accum * world
         args.steps_per_epoch = max(1, len(samples) // per_step)            # drop_last, as the window needs equal shards
-        real = dict(samples=samples, coll=coll, valid=ds.valid_samples(args.max_his_len))
+        real = dict(samples=samples, coll=coll, valid=ds.valid_samples(args.max_his_len), only_response=only_response)
         if rank == 0:
             print(json.dumps({"dataset": args.dataset, "train_samples": len(samples), "vocab_size": cfg.vocab_size,
                               "steps_per_epoch": args.steps_per_epoch}), flush=True)
@@ -156,8 +162,8 @@ def main(argv=None):
             epoch_order[ep] = np.random.RandomState(args.seed + ep).permutation(len(real["samples"]))
         bs = args.per_device_batch_size
         win = epoch_order[ep][k * bs * accum * world:(k + 1) * bs * accum * world]
-        return [real["coll"].train(real["samples"], win[(a * world + rank) * bs:(a * world + rank + 1) * bs])
-                for a in range(accum)]
+        return [real["coll"].train(real["samples"], win[(a * world + rank) * bs:(a * world + rank + 1) * bs],
+                                   only_train_response=real["only_response"]) for a in range(accum)]
 
     while state["global_step"] < total_steps:
         step = state["global_step"]

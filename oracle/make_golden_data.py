@@ -81,6 +81,17 @@ def main():
             assert batch["split"] == name
             nb += 1
         res[f"n_{name}_batches"] = np.int64(nb)
+    # ---- tasks=smb_explicit: one sample per interaction, only the response is trained (only_train_response=True) ----
+    per_inter = SMBExplicitDataset(mode="train", **kw)
+    coll_r = DecoderOnlyCollator(tok, only_train_response=True, ignore_behavior_tokens=behavior_ids)
+    res["n_train_per_interaction"] = np.int64(len(per_inter))
+    nb = 0
+    for b0 in range(0, len(per_inter), 4 * BATCH):
+        batch = coll_r([per_inter[i] for i in range(b0, min(len(per_inter), b0 + 4 * BATCH))])
+        for k in ("input_ids", "attention_mask", "labels", "session_ids", "extended_session_ids", "actions", "time"):
+            res[f"train_pi/{nb}/{k}"] = batch[k].numpy()
+        nb += 1
+    res["n_train_pi_batches"] = np.int64(nb)
     # ---- test batches through DecoderOnlyTestCollator (test_SMB_decoder.py:430-440), per behaviour ----
     tcoll = DecoderOnlyTestCollator(tok)
     for beh in test.behaviors:

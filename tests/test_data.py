@@ -64,6 +64,23 @@ def test_training_and_validation_batches_bit_exact(fx, mode):
         assert int((ss.ptr[1:] - ss.ptr[:-1]).max()) == (meta["max_his_len"] + 1) * ds.token_count
 
 
+def test_per_interaction_training_batches_bit_exact(fx):
+    """tasks=smb_explicit: SMBExplicitDataset(mode="train") + DecoderOnlyCollator(only_train_response=True); the
+    first session's targets have an empty history."""
+    z, meta, ds = fx
+    ss = ds.train_samples_per_interaction(meta["max_his_len"])
+    assert len(ss) == int(z["n_train_per_interaction"])
+    assert int((ss.n_history == 0).sum()) > 0
+    coll = gdata.Collator(ds)
+    chunks = gdata.batches(len(ss), 4 * meta["batch"])
+    assert len(chunks) == int(z["n_train_pi_batches"])
+    for b, idx in enumerate(chunks):
+        got = coll.train(ss, idx, only_train_response=True)
+        for k in ("input_ids", "attention_mask", "labels", "session_ids", "extended_session_ids", "actions"):
+            assert np.array_equal(got[k].numpy(), z[f"train_pi/{b}/{k}"]), (b, k)
+        assert np.array_equal(got["time"].numpy(), z[f"train_pi/{b}/time"]), b
+
+
 def test_test_batches_targets_and_candidates_bit_exact(fx):
     z, meta, ds = fx
     full = ds.test_samples(meta["max_his_len"])
