@@ -113,6 +113,21 @@ def bench_gemm(args):
               f"{fl / td / 1e9:6.1f} TF | wgrad {tw:.3f} ms {fl / tw / 1e9:6.1f} TF")
 
 
+def bench_gemm_k(args):
+    """Main-loop efficiency vs prologue/epilogue cost: the forward GEMM form at N = 768 with K from 128 to 4096
+    (same number of output tiles, more K-steps per tile)."""
+    T = args.B * args.items * 5
+    T = min(T, 131072)
+    dev = "cuda"
+    N = 768
+    for K in (128, 256, 512, 1024, 2048, 4096):
+        x = torch.randn(T, K, device=dev)
+        W = torch.randn(N, K, device=dev)
+        y = torch.empty(T, N, device=dev)
+        t = timeit(lambda: ops.linear_fwd(x, K, W, K, y, N, T, N, K), args.iters)
+        print(f"gemm fwd T={T} N={N} K={K:5d}: {t:.3f} ms {2.0 * T * N * K / t / 1e9:6.1f} TF  ({K // 32} K-steps per tile)")
+
+
 def bench_elem(args):
     B, S, H, I = args.B, args.items * 5, 256, 512
     T = B * S
@@ -147,7 +162,7 @@ def bench_elem(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["attn", "gemm", "elem"])
+    ap.add_argument("what", choices=["attn", "gemm", "gemmk", "elem"])
     ap.add_argument("--B", type=int, default=256)
     ap.add_argument("--items", type=int, default=101)
     ap.add_argument("--iters", type=int, default=5)
@@ -156,4 +171,4 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     ap.add_argument("--no-order", dest="no_order", action="store_true", help="cross attention without the row order")
     args = ap.parse_args()
-    {"attn": bench_attn, "gemm": bench_gemm, "elem": bench_elem}[args.what](args)
+    {"attn": bench_attn, "gemm": bench_gemm, "gemmk": bench_gemm_k, "elem": bench_elem}[args.what](args)
