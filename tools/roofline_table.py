@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Per-kernel roofline table of one profile set (profiles/<tag>_kernel_stats.csv + _pmc_{FETCH,WRITE}_SIZE.csv +
+_bench_under_rocprof.json): average launch time, HBM bytes per launch from the PMC passes (FETCH doubled per the
+gfx950 note of MI355X_MICROARCH.md, WRITE exact), achieved HBM rate against 8 TB/s, and for the MFMA kernels the
+algorithmic TFLOP/s the bench computed against the fp32 matrix peak.
+
+usage: tools/roofline_table.py r01j        (writes profiles/r01j_roofline.md)
+"""
+import csv
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HBM_PEAK_TBS, FP32_MFMA_PEAK = 8.0, 157.3
+
+
+def short(name: str) -> str:
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", name)          # drop the argument list
+    return name.replace("gamer::", "")
+
+
+def main():
+    tag = sys.argv[1]
+    prof = os.path.join(ROOT, "profiles")
+    stats = list(csv.DictReader(open(os.path.join(prof, f"{tag}_kernel_stats.csv"))))
+    fetch = {r["kernel"]: float(r["avg_FETCH_SIZE_KB_per_dispatch"])
+             for r in csv.DictReader(open(os.path.join(prof, f"{tag}_pmc_FETCH_SIZE.csv")))}
+    write = {r["kernel"]: float(r["avg_WRITE_SIZE_KB_per_dispatch"])
+             for r in csv.DictReader(open(os.path.join(prof, f"{tag}_pmc_WRITE_SIZE.csv")))}
+    bench = json.load(open(os.path.join(prof, f"{tag}_bench_under_rocprof.json")))
+    steps = bench["steps"] + bench["warmup"]
+    tf = {k["kernel"]: k.get("tflops") for k in bench["kernels"]}
+    group = {"gemm_f32_kernel<true, true, 0, false, false, 2, false>": "gemm_fwd",
+             "gemm_f32_kernel<true, true, 0, false, false, 2, true>": "gemm_fwd_resid",
+             "gemm_f32_kernel<true, false, 0": "gemm_dgrad", "gemm_f32_kernel<false, false, 1": "gemm_wgrad",
+             "attn_fwd_kernel<2, true, false": "attn_fwd_self", "attn_fwd_kernel<2, true, true": "attn_fwd_cross"}
+    total = sum(float(r["total_ms"]) for r in stats)
+    lines = [f"# Per-kernel roofline, profile set {tag}", "",
+             f"`python3 bench.py --steps {bench['steps']} --warmup {bench['warmup']} --no-cpu-baseline` under rocprofv3 "
+             f"(kernel trace; FETCH_SIZE and WRITE_SIZE in separate --pmc passes).  {steps} steps, "
+             f"{total / steps:.1f} ms of kernel time per step.  HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE "
+             "(gfx950: FETCH_SIZE counts 64 B per 128-B request).  Peaks: HBM 8 TB/s (6.3 achievable), fp32 MFMA "
+             f"{FP32_MFMA_PEAK} TFLOP/s.", "",
+             "| kernel | launches/step | avg ms | ms/step | HBM GB/launch | HBM TB/s | % of 8 TB/s | alg. TFLOP/s | % of fp32 MFMA |",
+             "|---|---|---|---|---|---|---|---|---|"]
+    for r in stats:
+        ms_step = float(r["total_ms"]) / steps
+        if ms_step < 0.05:
+            continue
+        k = r["kernel"]
+        avg = float(r["avg_ms"])
+        gb = (2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024 / 1e9 if k in fetch or k in write else None
+        tbs = gb / avg if gb is not None else None             # GB / ms = TB/s
+        t = next((tf.get(v) for kk, v in group.items() if kk in k), None)
+        lines.append("| `{}` | {:.1f} | {:.3f} | {:.2f} | {} | {} | {} | {} | {} |".format(
+            short(k)[:70], int(r["calls"]) / steps, avg, ms_step,
+            f"{gb:.2f}" if gb is not None else "-", f"{tbs:.2f}" if tbs is not None else "-",
+            f"{100 * tbs / HBM_PEAK_TBS:.0f}" if tbs is not None else "-",
+            f"{t:.0f}" if t else "-", f"{100 * t / FP32_MFMA_PEAK:.0f}" if t else "-"))
+    out = os.path.join(prof, f"{tag}_roofline.md")
+    open(out, "w").write("\n".join(lines) + "\n")
+    print(open(out).read())
+
+
+if __name__ == "__main__":
+    main()
