@@ -67,8 +67,8 @@ _SIGNATURES = {
     "gamer_residual_dropout_bwd": [P, P, I, I, F, U, P, P],
     "gamer_swiglu_fwd": [P, P, L, F, U, P, P],
     "gamer_swiglu_bwd": [P, P, P, L, F, U, P],
-    "gamer_silu_gate_fwd": [P, P, L, P, P],
-    "gamer_silu_gate_bwd": [P, P, P, L, P, P, P],
+    "gamer_silu_gate_fwd": [P, P, L, P, P, F, U, P],
+    "gamer_silu_gate_bwd": [P, P, P, L, P, P, F, U, P],
     "gamer_ce_fwd": [P, I, P, I, I, I, F, I, P, P, P, P, P],
     "gamer_ce_bwd": [P, I, P, I, I, I, F, I, P, P, F, F, P],
     "gamer_sumsq": [P, L, P, I, P],

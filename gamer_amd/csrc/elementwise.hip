@@ -557,20 +557,35 @@ swiglu_bwd_kernel(float4* __restrict__ g, float4* __restrict__ u, const float4* 
 
 __global__ void __launch_bounds__(EW_THREADS)
 silu_gate_fwd_kernel(const float4* __restrict__ a, const float4* __restrict__ gate, int64_t n4,
-                     float4* __restrict__ out) {
+                     float4* __restrict__ out, const float4* __restrict__ resid, float p, uint64_t seed) {
+    // resid != nullptr: out = resid + dropout(a * silu(gate)) - the residual add of the cross-attention block fused
+    // in (same mask as gamer_residual_dropout_fwd with this seed: element index -> mult4)
+    const DropoutRng rng(resid ? p : 0.f, seed);
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
         const float4 x = a[i], g = gate[i];
         float4 o;
         o.x = x.x * silu_f(g.x); o.y = x.y * silu_f(g.y); o.z = x.z * silu_f(g.z); o.w = x.w * silu_f(g.w);
+        if (resid) {
+            const float4 r = resid[i];
+            float m[4];
+            rng.mult4((uint32_t)i, m);
+            o.x = r.x + m[0] * o.x; o.y = r.y + m[1] * o.y; o.z = r.z + m[2] * o.z; o.w = r.w + m[3] * o.w;
+        }
         out[i] = o;
     }
 }
 
 __global__ void __launch_bounds__(EW_THREADS)
 silu_gate_bwd_kernel(const float4* __restrict__ a, const float4* __restrict__ gate, const float4* __restrict__ dout,
-                     int64_t n4, float4* __restrict__ da, float4* __restrict__ dgate) {
+                     int64_t n4, float4* __restrict__ da, float4* __restrict__ dgate, float p, uint64_t seed) {
+    // p > 0: dout is the gradient of the residual stream; the dropout mask of the fused forward is applied first
+    const DropoutRng rng(p, seed);
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
-        const float4 x = a[i], g = gate[i], d = dout[i];
+        const float4 x = a[i], g = gate[i];
+        float4 d = dout[i];
+        float m[4];
+        rng.mult4((uint32_t)i, m);
+        d.x *= m[0]; d.y *= m[1]; d.z *= m[2]; d.w *= m[3];
         float4 oa, og;
         oa.x = d.x * silu_f(g.x); og.x = d.x * x.x * dsilu_f(g.x);
         oa.y = d.y * silu_f(g.y); og.y = d.y * x.y * dsilu_f(g.y);
@@ -895,19 +910,22 @@ extern "C" int gamer_swiglu_bwd(float* g, float* u, const float* dhm, int64_t n,
     return 0;
 }
 
-extern "C" int gamer_silu_gate_fwd(const float* a, const float* gate, int64_t n, float* out, void* stream) {
-    GAMER_CHECK_ARG(a && gate && out && n > 0 && n % 4 == 0, "gamer_silu_gate_fwd: bad arguments");
+extern "C" int gamer_silu_gate_fwd(const float* a, const float* gate, int64_t n, float* out, const float* resid,
+                                   float p_drop, uint64_t seed, void* stream) {
+    GAMER_CHECK_ARG(a && gate && out && n > 0 && n % 4 == 0 && p_drop >= 0.f && p_drop < 1.f, "gamer_silu_gate_fwd: bad arguments");
     hipLaunchKernelGGL(silu_gate_fwd_kernel, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream),
-                       (const float4*)a, (const float4*)gate, n / 4, (float4*)out);
+                       (const float4*)a, (const float4*)gate, n / 4, (float4*)out, (const float4*)resid, p_drop, seed);
     GAMER_CHECK_LAUNCH("gamer_silu_gate_fwd");
     return 0;
 }
 
 extern "C" int gamer_silu_gate_bwd(const float* a, const float* gate, const float* dout, int64_t n, float* da,
-                                   float* dgate, void* stream) {
-    GAMER_CHECK_ARG(a && gate && dout && da && dgate && n > 0 && n % 4 == 0, "gamer_silu_gate_bwd: bad arguments");
+                                   float* dgate, float p_drop, uint64_t seed, void* stream) {
+    GAMER_CHECK_ARG(a && gate && dout && da && dgate && n > 0 && n % 4 == 0 && p_drop >= 0.f && p_drop < 1.f,
+                    "gamer_silu_gate_bwd: bad arguments");
     hipLaunchKernelGGL(silu_gate_bwd_kernel, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream),
-                       (const float4*)a, (const float4*)gate, (const float4*)dout, n / 4, (float4*)da, (float4*)dgate);
+                       (const float4*)a, (const float4*)gate, (const float4*)dout, n / 4, (float4*)da, (float4*)dgate,
+                       p_drop, seed);
     GAMER_CHECK_LAUNCH("gamer_silu_gate_bwd");
     return 0;
 }

@@ -202,8 +202,7 @@ class DecodeSession:
             else:
                 ops.linear_fwd(b["ao"], NQ, Wa["o"], NQ, b["op"], H, N, H, NQ)
                 ops.linear_fwd(hin, H, Wa["gate"], H, b["gate"], H, N, H, H)
-                ops.silu_gate_fwd(b["op"], b["gate"], b["t0"])
-                ops.residual_dropout_fwd(xin, b["t0"], 0.0, 0, None, xout)
+                ops.silu_gate_fwd(b["op"], b["gate"], xout, resid=xin)
 
         # x holds the layer input and receives the layer output; x1 / x2 are the states after the self / cross block
         for l in range(cfg.num_hidden_layers):

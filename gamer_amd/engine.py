@@ -401,8 +401,8 @@ class Engine:
                              q_span=span_cross)
                 ops.linear_fwd(A["ao_c"], NQ, C["o"], NQ, A["op_c"], H, T, H, NQ)
                 ops.linear_fwd(A["h2"], H, C["gate"], H, A["gate_c"], H, T, H, H)
-                ops.silu_gate_fwd(A["op_c"], A["gate_c"], t0)
-                ops.residual_dropout_fwd(xs[1], t0, p_res, self._seed(l, 3), None, xs[2])
+                # output gate + residual add + dropout in one pass (model.py:147, 235)
+                ops.silu_gate_fwd(A["op_c"], A["gate_c"], xs[2], resid=xs[1], p=p_res, seed=self._seed(l, 3))
                 xcur = xs[2]
             # ---- position-routed SwiGLU experts (model.py:238-241, FFN.py:53-72) ----
             din = W.din
@@ -519,8 +519,8 @@ class Engine:
             # ---- cross attention ----
             if W.cross:
                 C, GC = W.cross_attn, G.cross_attn
-                ops.residual_dropout_bwd(ws.dx, p_res, self._seed(l, 3), t0)                # d (op * silu(gate))
-                ops.silu_gate_bwd(A["op_c"], A["gate_c"], t0, t1, t2)                       # t1 = d op, t2 = d gate
+                # dropout mask of the residual add + gate backward in one pass: t1 = d op, t2 = d gate
+                ops.silu_gate_bwd(A["op_c"], A["gate_c"], ws.dx, t1, t2, p=p_res, seed=self._seed(l, 3))
                 ops.linear_wgrad(t1, H, A["ao_c"], NQ, GC["o"], NQ, T, H, NQ)
                 ops.linear_wgrad(t2, H, A["h2"], H, GC["gate"], H, T, H, H)
                 ops.linear_dgrad(t1, H, C["o"], NQ, ws.dao, NQ, T, H, NQ)

@@ -227,12 +227,14 @@ def swiglu_bwd(g, u, dhm, n, p, seed):
     call("gamer_swiglu_bwd", ptr(g), ptr(u), ptr(dhm), n, p, seed, stream_ptr())
 
 
-def silu_gate_fwd(a, gate, out):
-    call("gamer_silu_gate_fwd", ptr(a), ptr(gate), a.numel(), ptr(out), stream_ptr())
+def silu_gate_fwd(a, gate, out, resid=None, p=0.0, seed=0):
+    """out = a * silu(gate), or resid + dropout(a * silu(gate)) when resid is given (fused residual add)."""
+    call("gamer_silu_gate_fwd", ptr(a), ptr(gate), a.numel(), ptr(out), ptr(resid), p, seed, stream_ptr())
 
 
-def silu_gate_bwd(a, gate, dout, da, dgate):
-    call("gamer_silu_gate_bwd", ptr(a), ptr(gate), ptr(dout), a.numel(), ptr(da), ptr(dgate), stream_ptr())
+def silu_gate_bwd(a, gate, dout, da, dgate, p=0.0, seed=0):
+    """p > 0: dout is the residual-stream gradient and the forward's dropout mask (seed) is applied to it first."""
+    call("gamer_silu_gate_bwd", ptr(a), ptr(gate), ptr(dout), a.numel(), ptr(da), ptr(dgate), p, seed, stream_ptr())
 
 
 def ce_fwd(logits, ldl, labels, V, temperature, ignore_index, lse, row_loss, loss_sum, count):

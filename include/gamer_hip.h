@@ -287,11 +287,13 @@ int gamer_swiglu_fwd(const float* g, const float* u, int64_t n, float p_drop, ui
 /* in place: g <- dg, u <- du given dhm                                                          */
 int gamer_swiglu_bwd(float* g, float* u, const float* dhm, int64_t n, float p_drop, uint64_t seed,
                      void* stream);
-/* out = a * silu(gate)  (cross-attention output gate, model.py:147)                              */
-int gamer_silu_gate_fwd(const float* a, const float* gate, int64_t n, float* out, void* stream);
-/* da = dout*silu(gate) ; dgate = dout*a*silu'(gate)                                             */
+/* out = a * silu(gate)  (cross-attention output gate, model.py:147); with resid != NULL the block's residual add
+ * is fused in: out = resid + drop(a * silu(gate)) (model.py:235), same mask as gamer_residual_dropout_fwd(seed)  */
+int gamer_silu_gate_fwd(const float* a, const float* gate, int64_t n, float* out, const float* resid,
+                        float p_drop, uint64_t seed, void* stream);
+/* d = drop_mask(seed) * dout (p_drop = 0: d = dout); da = d*silu(gate) ; dgate = d*a*silu'(gate)              */
 int gamer_silu_gate_bwd(const float* a, const float* gate, const float* dout, int64_t n,
-                        float* da, float* dgate, void* stream);
+                        float* da, float* dgate, float p_drop, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Tied LM head loss: temperature + shifted cross entropy (model.py:904-922;

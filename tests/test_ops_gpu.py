@@ -570,6 +570,21 @@ def test_swiglu_and_gate():
     da, dgate = torch.empty_like(out), torch.empty_like(out)
     ops.silu_gate_bwd(dev(a), dev(gate), dev(dout), da, dgate)
     assert _rel(da, ar.grad) < 1e-5 and _rel(dgate, gr2.grad) < 1e-5
+    # fused residual add + dropout: the same result (and mask) as silu_gate_fwd followed by residual_dropout_fwd,
+    # and the backward equals residual_dropout_bwd followed by silu_gate_bwd
+    x = torch.randn(n_rows, 256)
+    two = torch.empty_like(out)
+    ops.residual_dropout_fwd(dev(x), out, 0.2, 77, None, two)
+    one = torch.empty_like(out)
+    ops.silu_gate_fwd(dev(a), dev(gate), one, resid=dev(x), p=0.2, seed=77)
+    assert torch.equal(one, two)
+    masked = torch.empty_like(out)
+    ops.residual_dropout_bwd(dev(dout), 0.2, 77, masked)
+    da2, dg2 = torch.empty_like(out), torch.empty_like(out)
+    ops.silu_gate_bwd(dev(a), dev(gate), masked, da2, dg2)
+    da1, dg1 = torch.empty_like(out), torch.empty_like(out)
+    ops.silu_gate_bwd(dev(a), dev(gate), dev(dout), da1, dg1, p=0.2, seed=77)
+    assert torch.equal(da1, da2) and torch.equal(dg1, dg2)
 
 
 @pytest.mark.parametrize("use_count", [True, False])
