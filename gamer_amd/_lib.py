@@ -52,7 +52,7 @@ _SIGNATURES = {
     "gamer_embedding_fwd": [P, P, I, I, I, P, P],
     "gamer_embedding_bwd": [P, P, I, I, I, I, P, P],
     "gamer_rmsnorm_fwd": [P, P, I, I, F, P, P, I, P],
-    "gamer_rmsnorm_bwd": [P, P, P, I, P, I, I, F, I, P, P, I, P],
+    "gamer_rmsnorm_bwd": [P, P, P, I, P, I, I, F, I, P, P, I, P, P, F, U, P],
     "gamer_colsum_reduce": [P, I, I, I, P, P],
     "gamer_rowtable_fwd": [P, P, P, I, I, P, I, I, P],
     "gamer_rowtable_bwd": [P, I, I, P, P, I, I, I, P, P],

@@ -136,7 +136,11 @@ rmsnorm_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, i
 __global__ void __launch_bounds__(EW_THREADS)
 rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, const float* __restrict__ dy,
                    int lddy, const int32_t* __restrict__ dy_rows, int T, int H4, float inv_h, float eps,
-                   int accumulate_dx, float4* __restrict__ dx, float* __restrict__ dw_partial) {
+                   int accumulate_dx, float4* __restrict__ dx, float* __restrict__ dw_partial,
+                   float4* __restrict__ mask_out, const int32_t* __restrict__ mask_rows, float p_drop, uint64_t seed) {
+    // mask_out != nullptr: the next consumer of dx is a residual branch with dropout; its input gradient
+    // mask(seed) * dx is written here (what gamer_residual_dropout_bwd would compute in a second pass over dx)
+    const DropoutRng rng(mask_out ? p_drop : 0.f, seed);
     __shared__ float4 red[EW_WAVES][64 * RMS_MAXC];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
@@ -188,6 +192,12 @@ rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, c
                     o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
                 }
                 dx[(int64_t)t * H4 + c] = o;
+                if (mask_out) {
+                    float m[4];
+                    rng.mult4((uint32_t)((int64_t)t * H4 + c), m);
+                    const int64_t mr = mask_rows ? mask_rows[t] : t;
+                    mask_out[mr * H4 + c] = make_float4(m[0] * o.x, m[1] * o.y, m[2] * o.z, m[3] * o.w);
+                }
             }
         }
     }
@@ -783,7 +793,8 @@ extern "C" int gamer_rmsnorm_fwd(const float* x, const float* w, int T, int H, f
 
 extern "C" int gamer_rmsnorm_bwd(const float* x, const float* w, const float* dy, int lddy, const int32_t* dy_rows,
                                  int T, int H, float eps, int accumulate_dx, float* dx, float* dw_partial,
-                                 int n_partial, void* stream) {
+                                 int n_partial, float* mask_out, const int32_t* mask_rows, float p_drop,
+                                 uint64_t seed, void* stream) {
     GAMER_CHECK_ARG(x && w && dy && dx && dw_partial, "gamer_rmsnorm_bwd: null pointer");
     GAMER_CHECK_ARG(T > 0 && H > 0 && H % 4 == 0 && H <= 256 * RMS_MAXC && lddy >= H && lddy % 4 == 0 && n_partial > 0,
                     "gamer_rmsnorm_bwd: bad shape T=%d H=%d lddy=%d n_partial=%d", T, H, lddy, n_partial);
@@ -791,7 +802,7 @@ extern "C" int gamer_rmsnorm_bwd(const float* x, const float* w, const float* dy
                     "gamer_rmsnorm_bwd: pointers must be 16-byte aligned");
     hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(n_partial), dim3(EW_THREADS), 0, ST(stream),
                        (const float4*)x, (const float4*)w, dy, lddy, dy_rows, T, H / 4, 1.f / (float)H, eps,
-                       accumulate_dx, (float4*)dx, dw_partial);
+                       accumulate_dx, (float4*)dx, dw_partial, (float4*)mask_out, mask_rows, p_drop, seed);
     GAMER_CHECK_LAUNCH("gamer_rmsnorm_bwd");
     return 0;
 }

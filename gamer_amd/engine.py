@@ -483,8 +483,14 @@ class Engine:
         demb = self.grads["model.embed_tokens.weight"]
         NP = ws.norm_partial
 
-        def norm_bwd(xin, w, dy, lddy, dw, accumulate_dx, dy_rows=None):
-            ops.rmsnorm_bwd(xin, w, dy, lddy, eps, ws.dx, NP, accumulate_dx, dy_rows)
+        def norm_bwd(xin, w, dy, lddy, dw, accumulate_dx, dy_rows=None, branch=None):
+            """``branch`` = (seed, rows): the residual branch that consumes the updated dx next; its input gradient
+            dropout_mask(seed) * dx goes to t0 in the same pass (t0 must not be ``dy``)."""
+            if branch is None:
+                ops.rmsnorm_bwd(xin, w, dy, lddy, eps, ws.dx, NP, accumulate_dx, dy_rows)
+            else:
+                ops.rmsnorm_bwd(xin, w, dy, lddy, eps, ws.dx, NP, accumulate_dx, dy_rows, mask_out=ws.tmpH[0],
+                                mask_rows=branch[1], p=p_res, seed=branch[0])
             ops.colsum_reduce(NP, dw, accumulate=True)
 
         # ---- loss -> logits -> final norm ----
@@ -496,16 +502,18 @@ class Engine:
                        dloss)
         ops.linear_wgrad(ws.logits, ws.ldl, ws.xn, H, demb, H, T, V, H)
         t0, t1, t2, t3 = ws.tmpH
-        ops.linear_dgrad(ws.logits, ws.ldl, emb, H, t0, H, T, V, H)
-        norm_bwd(ws.x_final, self.params["model.norm.weight"], t0, H, self.grads["model.norm.weight"], False)
+        L = cfg.num_hidden_layers
+        ops.linear_dgrad(ws.logits, ws.ldl, emb, H, t3, H, T, V, H)
+        # every norm backward that completes dx also emits t0 = mask * dx for the branch that reads dx next
+        norm_bwd(ws.x_final, self.params["model.norm.weight"], t3, H, self.grads["model.norm.weight"], False,
+                 branch=(self._seed(L - 1, 5), ws.slot))
 
         for l in reversed(range(cfg.num_hidden_layers)):
             W, G, A, xs = self.W[l], self.G[l], ws.layers[l], ws.x[l]
             din = W.din
             grp = dict(groups=E, group_offsets=ws.offsets)
             xlast = xs[2] if W.cross else xs[1]
-            # ---- experts ----
-            ops.residual_dropout_bwd(ws.dx, p_res, self._seed(l, 5), t0, ws.slot)          # d out_sorted
+            # ---- experts ----   (t0 = d out_sorted, written by the norm backward that completed dx)
             ops.linear_wgrad(t0, H, A["hm"], I, G.down, I, T, H, I, strideC=H * I, **grp)
             ops.linear_dgrad(t0, H, W.down, I, ws.dhm, I, T, H, I, strideB=H * I, **grp)
             ops.swiglu_bwd(A["g"], A["u"], ws.dhm, T * I, p_res, self._seed(l, 4))          # g <- dg, u <- du
@@ -515,7 +523,8 @@ class Engine:
             ops.linear_dgrad(A["u"], I, W.up, din, ws.dhin, din, T, I, din, accumulate=True, strideB=I * din, **grp)
             if W.inject:
                 ops.rowtable_bwd(ws.dhin, din, H, r["beh_idx"], G.beh, ws.slot)
-            norm_bwd(xlast, W.ln3, ws.dhin, din, G.ln3, True, ws.slot)
+            norm_bwd(xlast, W.ln3, ws.dhin, din, G.ln3, True, ws.slot,
+                     branch=None if W.cross else (self._seed(l, 1), None))
             # ---- cross attention ----
             if W.cross:
                 C, GC = W.cross_attn, G.cross_attn
@@ -534,10 +543,10 @@ class Engine:
                 ops.linear_wgrad(ws.dqkv, QKV, A["h2"], H, GC["qkv"], H, T, QKV, H)
                 ops.linear_dgrad(ws.dqkv, QKV, C["qkv"], H, t3, H, T, QKV, H)
                 ops.linear_dgrad(t2, H, C["gate"], H, t3, H, T, H, H, accumulate=True)
-                norm_bwd(xs[1], W.ln2, t3, H, G.ln2, True)
+                norm_bwd(xs[1], W.ln2, t3, H, G.ln2, True, branch=(self._seed(l, 1), None))
             # ---- self attention ----
             SA, GS = W.self_attn, G.self_attn
-            ops.residual_dropout_bwd(ws.dx, p_res, self._seed(l, 1), t0)
+            # (t0 = mask * dx of this branch, written by the norm backward above)
             ops.linear_wgrad(t0, H, A["ao"], NQ, GS["o"], NQ, T, H, NQ)
             ops.linear_dgrad(t0, H, SA["o"], NQ, ws.dao, NQ, T, H, NQ)
             ops.attn_bwd(A["q"], NQ, A["k"], NKV, A["qkv"][:, NQ + NKV:], QKV, A["ao"], ws.dao, A["lse"], r["kl_self"],
@@ -548,7 +557,7 @@ class Engine:
                                 GS["kn"], pos_ids=pos_ids)
             ops.linear_wgrad(ws.dqkv, QKV, A["h1"], H, GS["qkv"], H, T, QKV, H)
             ops.linear_dgrad(ws.dqkv, QKV, SA["qkv"], H, t3, H, T, QKV, H)
-            norm_bwd(xs[0], W.ln1, t3, H, G.ln1, True)
+            norm_bwd(xs[0], W.ln1, t3, H, G.ln1, True, branch=(self._seed(l - 1, 5), ws.slot) if l > 0 else None)
             if layer_done is not None:
                 layer_done(l)
         ops.embedding_bwd(sv["ids"], ws.dx, cfg.pad_token_id, demb)

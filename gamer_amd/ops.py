@@ -88,10 +88,13 @@ def rmsnorm_fwd(x, w, eps, y, ldy=None, dst_rows=None):
          stream_ptr())
 
 
-def rmsnorm_bwd(x, w, dy, lddy, eps, dx, dw_partial, accumulate_dx=True, dy_rows=None):
+def rmsnorm_bwd(x, w, dy, lddy, eps, dx, dw_partial, accumulate_dx=True, dy_rows=None, mask_out=None, mask_rows=None,
+                p=0.0, seed=0):
+    """mask_out: also write dropout_mask(seed) * dx (the input gradient of the next residual branch), rows scattered
+    through mask_rows when given - the second pass gamer_residual_dropout_bwd would make over dx."""
     T, H = x.shape
     call("gamer_rmsnorm_bwd", ptr(x), ptr(w), ptr(dy), lddy, ptr(dy_rows), T, H, eps, 1 if accumulate_dx else 0,
-         ptr(dx), ptr(dw_partial), dw_partial.shape[0], stream_ptr())
+         ptr(dx), ptr(dw_partial), dw_partial.shape[0], ptr(mask_out), ptr(mask_rows), p, seed, stream_ptr())
 
 
 def colsum_reduce(partial, out, accumulate=False):

@@ -108,13 +108,16 @@ int gamer_embedding_bwd(const int64_t* ids, const float* dx, int V, int T, int H
  *   dst_rows: optional int32 [T] row scatter (token -> sorted slot) used for the FFN input;
  *   ldy: leading dim of y (>= H), lets the FFN input carry the behaviour embedding after col H.
  * bwd: dx[t] (+)= rstd*(w*dy - xhat*mean(w*dy*xhat)) ; dw_partial[block][H] deterministic partials
- *   that gamer_colsum_reduce folds into dw.
+ *   that gamer_colsum_reduce folds into dw.  mask_out (optional): the updated dx is the gradient of the residual
+ *   stream and the next consumer is a residual branch with dropout; its input gradient mask(seed) * dx is written to
+ *   mask_out[mask_rows ? mask_rows[t] : t] in the same pass (= gamer_residual_dropout_bwd(dx, ..., seed)).
  * ---------------------------------------------------------------------------------------- */
 int gamer_rmsnorm_fwd(const float* x, const float* w, int T, int H, float eps,
                       const int32_t* dst_rows, float* y, int ldy, void* stream);
 int gamer_rmsnorm_bwd(const float* x, const float* w, const float* dy, int lddy,
                       const int32_t* dy_rows, int T, int H, float eps, int accumulate_dx,
-                      float* dx, float* dw_partial, int n_partial, void* stream);
+                      float* dx, float* dw_partial, int n_partial,
+                      float* mask_out, const int32_t* mask_rows, float p_drop, uint64_t seed, void* stream);
 /* out[c] (+)= sum_r partial[r][c] */
 int gamer_colsum_reduce(const float* partial, int rows, int cols, int accumulate, float* out,
                         void* stream);

@@ -152,6 +152,16 @@ def test_rmsnorm_fwd_bwd(H):
     e1, e2 = _rel(dx.cpu() - dx0, xr.grad), _rel(dw, wr.grad)
     _record(f"rmsnorm_bwd_H{H}", [e1, e2])
     assert e1 < 1e-5 and e2 < 1e-5
+    # fused branch gradient: mask_out == residual_dropout_bwd of the updated dx (same seed), plain and row-scattered
+    for rows in (None, dev(torch.randperm(T).int())):
+        dxa, dxb = dev(dx0.clone()), dev(dx0.clone())
+        ma, mb = torch.zeros(T, H, device=DEV), torch.zeros(T, H, device=DEV)
+        ops.rmsnorm_bwd(dev(x), dev(w), dev(dy_buf), ldy, 1e-6, dxa, partial, True, dev(dst), mask_out=ma,
+                        mask_rows=rows, p=0.2, seed=123)
+        ops.rmsnorm_bwd(dev(x), dev(w), dev(dy_buf), ldy, 1e-6, dxb, partial, True, dev(dst))
+        ops.residual_dropout_bwd(dxb, 0.2, 123, mb, rows)
+        assert torch.equal(dxa, dxb) and torch.equal(ma, mb)
+        assert 0.15 < float((ma == 0).float().mean()) < 0.25
 
 
 def test_rowtable_fwd_bwd():
