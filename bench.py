@@ -105,6 +105,8 @@ class KernelTimer:
             kind = "gemm_fwd" if (a_ks == 1 and b_ks == 1) else ("gemm_dgrad" if a_ks == 1 else "gemm_wgrad")
             if kw.get("resid") is not None:
                 kind = "gemm_fwd_resid"                 # fused residual + dropout epilogue (a different instantiation)
+            if kw.get("rowdot") is not None:
+                kind = "gemm_dgrad_delta"               # o_proj dgrad that also emits the attention backward's delta
             timer._next = (kind, 2.0 * M * N * K)
             return orig_gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, **kw)
 
@@ -339,8 +341,9 @@ def main():
         gemm_ms = sum(k["ms_per_step"] for k in gemm_rows)
         gemm_tf = sum(k["tflops"] * k["ms_per_step"] for k in gemm_rows) / max(gemm_ms, 1e-9)
         ms_per_step = elapsed / args.steps * 1e3
-        kname = {"gemm_fwd": "gemm_f32_kernel<true, true, 0, false", "gemm_dgrad": "gemm_f32_kernel<true, false, 0, false",
-                 "gemm_wgrad": "gemm_f32_kernel<false, false, 1, false"}.get(dom["kernel"] if dom else "", None)
+        kname = {"gemm_fwd": "gemm_f32_kernel<true, true, 0, false, false, 2, 0>",
+                 "gemm_dgrad": "gemm_f32_kernel<true, false, 0, false, false, 2, 0>",
+                 "gemm_wgrad": "gemm_f32_kernel<false, false, 1, false, false, 2, 0>"}.get(dom["kernel"] if dom else "", None)
         traffic = committed_traffic(kname) if (kname and args.batch == 1024 and args.items == 101) else None
         result = {
             "metric": ("train-step sequences/sec, Qwen3Multi SMB decoder, his_len=100" if args.variant == "multi" else

@@ -40,6 +40,9 @@ class GemmDesc(C.Structure):
         ("row_map", c_void_p),
         ("p_drop", c_float),
         ("seed", c_uint64),
+        ("rowdot_other", c_void_p),
+        ("rowdot_out", c_void_p),
+        ("rowdot_S", c_int),
     ]
 
 
@@ -62,7 +65,7 @@ _SIGNATURES = {
     "gamer_qknorm_rope_bwd": [P, P, P, I, I, I, I, P, P, F, P, P, P, P, P, I, P, P, P, P, P, P, P, P],
     "gamer_attn_row_order": [P, I, I, P, P, P, P],
     "gamer_attn_fwd": [P, I, P, I, P, I, P, P, P, P, I, I, I, I, F, F, U, P, P, P, P, P, I, P, P],
-    "gamer_attn_bwd": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, P, P, P, P, P],
+    "gamer_attn_bwd": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, P, P, P, P, I, P],
     "gamer_residual_dropout_fwd": [P, P, P, I, I, F, U, P, P],
     "gamer_residual_dropout_bwd": [P, P, I, I, F, U, P, P],
     "gamer_swiglu_fwd": [P, P, L, F, U, P, P],

@@ -1473,14 +1473,14 @@ static int launch_bwd_variant(const float* q, int ldq, const float* k, int ldk, 
                               const float* d_o, const float* lse, float* delta, const int32_t* kl, const int32_t* ql,
                               const int32_t* row_empty, const int32_t* tile_empty, int B, int S, int nq, int nkv,
                               float scale, float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk,
-                              float* dv, int lddv, RowOrder ro, float* ds_work, hipStream_t st) {
+                              float* dv, int lddv, RowOrder ro, float* ds_work, int delta_ready, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
     if (ds_work == nullptr) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<G, DROP, ORD, SPAN>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o,
                            lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, ro);
         GAMER_CHECK_LAUNCH("gamer_attn_bwd/dq");
-    } else {
+    } else if (!delta_ready) {
         hipLaunchKernelGGL(attn_delta_kernel, dim3(2048), dim3(AT_THREADS), 0, st, o, d_o, B, S, nq, delta);
         GAMER_CHECK_LAUNCH("gamer_attn_bwd/delta");
     }
@@ -1530,10 +1530,10 @@ static int launch_bwd(const float* q, int ldq, const float* k, int ldk, const fl
                       const float* d_o, const float* lse, float* delta, const int32_t* kl, const int32_t* ql,
                       const int32_t* row_empty, const int32_t* tile_empty, int B, int S, int nq, int nkv, float scale,
                       float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
-                      RowOrder ro, float* ds_work, hipStream_t st) {
+                      RowOrder ro, float* ds_work, int delta_ready, hipStream_t st) {
 #define GAMER_LAUNCH_BWD(DROPV, ORDV, SPANV)                                                                                \
     return launch_bwd_variant<G, DROPV, ORDV, SPANV>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, \
-                                              S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, ds_work, st)
+                                              S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, ds_work, delta_ready, st)
 #define GAMER_LAUNCH_BWD2(DROPV, ORDV) do { if (ro.span) GAMER_LAUNCH_BWD(DROPV, ORDV, true); else GAMER_LAUNCH_BWD(DROPV, ORDV, false); } while (0)
     if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_BWD2(true, true); else GAMER_LAUNCH_BWD2(true, false); }
     else { if (ro.perm) GAMER_LAUNCH_BWD2(false, true); else GAMER_LAUNCH_BWD2(false, false); }
@@ -1616,7 +1616,7 @@ extern "C" int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, 
                               int nq, int nkv, float scale, float p_drop, uint64_t seed, float* delta, float* dq,
                               int lddq, float* dk, int lddk, float* dv, int lddv, const int32_t* row_perm,
                               const int32_t* tile_kind, const int32_t* tile_maxpos, float* ds_work,
-                              const int32_t* q_span, void* stream) {
+                              const int32_t* q_span, int delta_ready, void* stream) {
     int rc = check_attn_common("gamer_attn_bwd", q, k, v, kl, row_empty, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
     if (rc) return rc;
     GAMER_CHECK_ARG(o && d_o && lse && tile_empty && delta && dq && dk && dv, "gamer_attn_bwd: null pointer");
@@ -1628,8 +1628,8 @@ extern "C" int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, 
                     "gamer_attn_bwd: gradient buffers must be 16-byte aligned with leading dims %% 4 == 0");
     hipStream_t st = (hipStream_t)stream;
     switch (nq / nkv) {
-        case 1: return launch_bwd<1>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, ds_work, st);
-        case 2: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, ds_work, st);
-        default: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, ds_work, st);
+        case 1: return launch_bwd<1>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, ds_work, delta_ready, st);
+        case 2: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, ds_work, delta_ready, st);
+        default: return launch_bwd<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, ds_work, delta_ready, st);
     }
 }

@@ -53,6 +53,10 @@ struct GemmParams {
     const int32_t* row_map;
     float p_drop;
     uint64_t seed;
+    // row-dot epilogue (EPI == 2): rowdot_out[b][head][i] = sum over the head's 64 columns of C[m][.] * other[m][.]
+    const float* rowdot_other;
+    float* rowdot_out;
+    int rowdot_S;
 };
 
 // blockIdx -> logical tile id such that consecutive logical ids run on one XCD (ids are dealt
@@ -145,7 +149,9 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row
     }
 }
 
-template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, bool EPI>
+// EPI: 0 plain, 1 residual + dropout (Linear-forward sites of the decoder layer), 2 row-dot ("delta = dO . O" of the
+// attention backward, taken while the o_proj dgrad tile is still in LDS: one pass over dO and one over O less)
+template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, int EPI>
 __global__ void __launch_bounds__(GEMM_THREADS, NBUF == 1 ? 3 : 2)
 gemm_f32_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -364,6 +370,14 @@ gemm_f32_kernel(const GemmParams p) {
         // parks its 64x64 patch as [64][68] floats and reads it back one 16-byte row chunk per lane, so the
         // patch leaves in 16 x 1-KiB store instructions (4 rows x 256 B each) instead of 64 dword stores.
         float* patch = smem + wid * (64 * 68);
+        // row-dot epilogue: the 16 float4 of the other operand are requested now, ahead of the LDS rewrite of the
+        // accumulators, so that they arrive while the patch is written and read back
+        float4 oth[EPI == 2 ? 16 : 1];
+        if (EPI == 2) {
+            const float* ob = p.rowdot_other + (int64_t)(row0 + wm * 64 + (lane >> 4)) * p.ldc + col0 + wn * 64 + ((lane & 15) << 2);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) oth[it] = *reinterpret_cast<const float4*>(ob + (int64_t)it * 4 * p.ldc);
+        }
         // (alpha == 1 for every GEMM of the train step: no multiply; every VALU instruction here is matrix time)
         if (p.alpha == 1.f) {
 #pragma unroll
@@ -384,19 +398,19 @@ gemm_f32_kernel(const GemmParams p) {
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): own LDS writes landed (wave-private patch)
         const int c4 = (lane & 15) << 2;
-        const DropoutRng rng(EPI ? p.p_drop : 0.f, p.seed);
+        const DropoutRng rng(EPI == 1 ? p.p_drop : 0.f, p.seed);
         // one 64-bit address per wave patch, then a constant stride per store (a per-store row * ldc product costs
         // two quarter-rate integer multiplies each)
         const int row_first = row0 + wm * 64 + (lane >> 4);
         const int col = col0 + wn * 64 + c4;
         float* dst0 = Cp + (int64_t)row_first * p.ldc + col;
-        const float* res0 = EPI ? p.resid + (int64_t)row_first * p.ldc + col : nullptr;
+        const float* res0 = EPI == 1 ? p.resid + (int64_t)row_first * p.ldc + col : nullptr;
         const int64_t step = 4 * p.ldc;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int lr = (lane >> 4) + 4 * it;             // row inside the patch
             const float4 v = *reinterpret_cast<const float4*>(patch + lr * 68 + c4);
-            if (EPI) {
+            if (EPI == 1) {
                 float* dst = dst0 + it * step;
                 const float* rsrc = res0 + it * step;
                 int64_t e = (int64_t)(row_first + 4 * it) * p.ldc + col;
@@ -414,6 +428,17 @@ gemm_f32_kernel(const GemmParams p) {
                 *reinterpret_cast<float4*>(dst) = o;
             } else {
                 float* dst = dst0 + it * step;
+                if (EPI == 2) {
+                    // the wave's 64-column patch is exactly one head: 16 lanes hold one row of it
+                    const float4 o4 = oth[EPI == 2 ? it : 0];
+                    float d = v.x * o4.x + v.y * o4.y + v.z * o4.z + v.w * o4.w;
+                    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+                    if ((lane & 15) == 0) {
+                        const int row = row_first + 4 * it;
+                        const int heads = p.N >> 6, head = (col0 + wn * 64) >> 6;
+                        p.rowdot_out[((int64_t)(row / p.rowdot_S) * heads + head) * p.rowdot_S + row % p.rowdot_S] = d;
+                    }
+                }
                 if (ACCUM) {
                     float4 o = *reinterpret_cast<const float4*>(dst);
                     o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
@@ -425,7 +450,7 @@ gemm_f32_kernel(const GemmParams p) {
         }
     } else {
         auto emit = [&](int row, int col, float v) {
-            if (EPI) {
+            if (EPI == 1) {
                 const int64_t rc = p.row_map ? p.row_map[row] : row;
                 const int64_t e = rc * p.ldc + col;
                 const DropoutRng rng(p.p_drop, p.seed);
@@ -472,7 +497,7 @@ gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, bool EPI = false>
+template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, int EPI = 0>
 static int launch_gemm_t(const GemmParams& p, int blocks, hipStream_t st, int lds) {
     static int attr_lds = 0;
     auto kfn = gemm_f32_kernel<A_KC, B_KC, MODE, ACCUM, STAMP, NBUF, EPI>;
@@ -504,7 +529,8 @@ static int launch_gemm(const GemmParams& p, int blocks, hipStream_t st) {
     const int lds = solo ? 150 * 1024 : GEMM_LDS_BYTES;          // solo: one workgroup per CU (diagnostics)
     const bool acc = MODE == 0 && p.accumulate;
     if (stamp) return launch_gemm_t<A_KC, B_KC, MODE, false, true, 2>(p, blocks, st, lds);
-    if (MODE == 0 && p.resid) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, true>(p, blocks, st, lds);
+    if (MODE == 0 && p.resid) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 1>(p, blocks, st, lds);
+    if (MODE == 0 && p.rowdot_out) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 2>(p, blocks, st, lds);
     if (nbuf == 1) {
         const int lds1 = 2 * TILE_FLOATS * (int)sizeof(float);
         if (acc) return launch_gemm_t<A_KC, B_KC, MODE, true, false, 1>(p, blocks, st, lds1);
@@ -551,6 +577,13 @@ extern "C" int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream) {
     p.strideB = d->strideB; p.strideC = d->strideC;
     p.kchunk = d->kchunk;
     p.resid = d->resid; p.row_map = d->row_map; p.p_drop = d->p_drop; p.seed = d->seed;
+    p.rowdot_other = d->rowdot_other; p.rowdot_out = d->rowdot_out; p.rowdot_S = d->rowdot_S;
+    GAMER_CHECK_ARG(!d->rowdot_out || (d->rowdot_other && d->rowdot_S > 0 && d->group_mode == 0 && d->groups == 1 &&
+                                       !d->resid && !d->accumulate && d->M % BM == 0 && d->N % BN == 0 &&
+                                       d->M % d->rowdot_S == 0 && d->ldc % 4 == 0 && aligned16(d->rowdot_other) &&
+                                       aligned16(d->C) && !getenv("GAMER_GEMM_STAMP") && !getenv("GAMER_GEMM_NBUF")),
+                    "gamer_gemm_f32: the row-dot epilogue needs full 128 x 128 tiles (M=%d N=%d), one group, ldc %% 4 == 0",
+                    d->M, d->N);
     GAMER_CHECK_ARG(!d->resid || (d->group_mode == 0 && !d->accumulate && a_kc && b_kc && d->ldc % 4 == 0 &&
                                   aligned16(d->resid) && aligned16(d->C) && d->p_drop >= 0.f && d->p_drop < 1.f),
                     "gamer_gemm_f32: the fused residual epilogue needs a Linear-forward layout, ldc %% 4 == 0, no accumulate");

@@ -482,6 +482,9 @@ class Engine:
         emb = self.params["model.embed_tokens.weight"]
         demb = self.grads["model.embed_tokens.weight"]
         NP = ws.norm_partial
+        # delta = dO . O of the attention backward comes out of the o_proj dgrad GEMM (row-dot epilogue) when the dS-spill
+        # path is in use and every tile of that GEMM is full; otherwise gamer_attn_bwd computes it itself
+        fuse_delta = ws.ds_work is not None and T % 128 == 0 and NQ % 128 == 0
 
         def norm_bwd(xin, w, dy, lddy, dw, accumulate_dx, dy_rows=None, branch=None):
             """``branch`` = (seed, rows): the residual branch that consumes the updated dx next; its input gradient
@@ -532,11 +535,13 @@ class Engine:
                 ops.silu_gate_bwd(A["op_c"], A["gate_c"], ws.dx, t1, t2, p=p_res, seed=self._seed(l, 3))
                 ops.linear_wgrad(t1, H, A["ao_c"], NQ, GC["o"], NQ, T, H, NQ)
                 ops.linear_wgrad(t2, H, A["h2"], H, GC["gate"], H, T, H, H)
-                ops.linear_dgrad(t1, H, C["o"], NQ, ws.dao, NQ, T, H, NQ)
+                ops.linear_dgrad(t1, H, C["o"], NQ, ws.dao, NQ, T, H, NQ,
+                                 rowdot=(A["ao_c"], ws.delta, S) if fuse_delta else None)
                 ops.attn_bwd(A["q_c"], NQ, A["k_c"], NKV, A["qkv_c"][:, NQ + NKV:], QKV, A["ao_c"], ws.dao, A["lse_c"],
                              r["kl_cross"], r["ql_cross"], r["empty_cross"], r["tile_empty_cross"], B, S, nq, nkv,
                              scale, p_att, self._seed(l, 2), ws.delta, ws.dq, NQ, ws.dk, NKV,
-                             ws.dqkv[:, NQ + NKV:], QKV, order=ws.cross_order, ds_work=ws.ds_work, q_span=span_cross)
+                             ws.dqkv[:, NQ + NKV:], QKV, order=ws.cross_order, ds_work=ws.ds_work, q_span=span_cross,
+                             delta_ready=fuse_delta)
                 ops.qknorm_rope_bwd(A["qkv_c"], ws.dq, ws.dk, S, nq, nkv, C["qn"], C["kn"], eps, cos, sin, ws.dqkv,
                                     GC["qn"], GC["kn"], bias_q=C["bq"], bias_k=C["bk"], act_idx=r["act_idx"], nb1=NB1,
                                     dbias_q=GC["bq"], dbias_k=GC["bk"], dbias_v=GC["bv"], pos_ids=pos_ids)
@@ -548,11 +553,11 @@ class Engine:
             SA, GS = W.self_attn, G.self_attn
             # (t0 = mask * dx of this branch, written by the norm backward above)
             ops.linear_wgrad(t0, H, A["ao"], NQ, GS["o"], NQ, T, H, NQ)
-            ops.linear_dgrad(t0, H, SA["o"], NQ, ws.dao, NQ, T, H, NQ)
+            ops.linear_dgrad(t0, H, SA["o"], NQ, ws.dao, NQ, T, H, NQ, rowdot=(A["ao"], ws.delta, S) if fuse_delta else None)
             ops.attn_bwd(A["q"], NQ, A["k"], NKV, A["qkv"][:, NQ + NKV:], QKV, A["ao"], ws.dao, A["lse"], r["kl_self"],
                          None, r["empty_self"], r["tile_empty_self"], B, S, nq, nkv, scale, p_att, self._seed(l, 0),
                          ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, ds_work=ws.ds_work,
-                         q_span=span_self)
+                         q_span=span_self, delta_ready=fuse_delta)
             ops.qknorm_rope_bwd(A["qkv"], ws.dq, ws.dk, S, nq, nkv, SA["qn"], SA["kn"], eps, cos, sin, ws.dqkv, GS["qn"],
                                 GS["kn"], pos_ids=pos_ids)
             ops.linear_wgrad(ws.dqkv, QKV, A["h1"], H, GS["qkv"], H, T, QKV, H)

@@ -115,7 +115,8 @@ def rowtable_bwd(dy, lddy, col0, idx, dtable, dy_rows=None):
 
 
 def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=False, groups=1, group_mode=0,
-         group_offsets=None, strideB=0, strideC=0, kchunk=0, resid=None, row_map=None, p_drop=0.0, seed=0):
+         group_offsets=None, strideB=0, strideC=0, kchunk=0, resid=None, row_map=None, p_drop=0.0, seed=0,
+         rowdot=None):
     """C[m][n] (=|+=) alpha * sum_k A(m,k) B(n,k); see gamer_gemm_desc in include/gamer_hip.h."""
     d = GemmDesc()
     d.A = ptr(A); d.a_rs = a_rs; d.a_ks = a_ks
@@ -133,6 +134,8 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
     d.row_map = ptr(row_map)
     d.p_drop = p_drop
     d.seed = seed
+    if rowdot is not None:                 # (other [M, ldc], out [M / S, N / 64, S], S): see gamer_gemm_desc
+        d.rowdot_other, d.rowdot_out, d.rowdot_S = ptr(rowdot[0]), ptr(rowdot[1]), int(rowdot[2])
     call("gamer_gemm_f32", C.byref(d), stream_ptr())
 
 
@@ -197,12 +200,13 @@ def attn_fwd(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, tile_empty, B, S, nq, nk
 
 
 def attn_bwd(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed,
-             delta, dq, lddq, dk, lddk, dv, lddv, order=None, ds_work=None, q_span=None):
+             delta, dq, lddq, dk, lddk, dv, lddv, order=None, ds_work=None, q_span=None, delta_ready=False):
     """ds_work: optional fp32 scratch of attn_ds_work_numel(B, S, nq) elements (dS spill, see gamer_hip.h)."""
     pm, tk, tm = order if order is not None else (None, None, None)
     call("gamer_attn_bwd", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), ptr(d_o), ptr(lse), ptr(kl), ptr(ql),
          ptr(row_empty), ptr(tile_empty), B, S, nq, nkv, scale, p_drop, seed, ptr(delta), ptr(dq), lddq, ptr(dk),
-         lddk, ptr(dv), lddv, ptr(pm), ptr(tk), ptr(tm), ptr(ds_work), ptr(q_span), stream_ptr())
+         lddk, ptr(dv), lddv, ptr(pm), ptr(tk), ptr(tm), ptr(ds_work), ptr(q_span),
+         1 if (delta_ready and ds_work is not None) else 0, stream_ptr())
 
 
 def attn_ds_work_numel(B, S, nq):

@@ -165,6 +165,14 @@ typedef struct {
     const int32_t* row_map;
     float p_drop;
     uint64_t seed;
+    /* Optional row-dot epilogue (plain layouts, M % 128 == 0, N % 128 == 0, one group): with heads = N / 64,
+     *   rowdot_out[(m / rowdot_S) * heads * rowdot_S + head * rowdot_S + m % rowdot_S] =
+     *       sum over the 64 columns of `head` of C[m][.] * rowdot_other[m][.]      (rowdot_other has leading dim ldc)
+     * i.e. flash attention's delta[b][head][i] = dO . O computed by the o_proj dgrad GEMM that produces dO, while the
+     * tile is still in LDS.  rowdot_out == NULL: off. */
+    const float* rowdot_other;
+    float* rowdot_out;
+    int rowdot_S;
 } gamer_gemm_desc;
 
 int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);
@@ -214,6 +222,8 @@ int gamer_qknorm_rope_bwd(const float* qkv, const float* dq_rot, const float* dk
  *   q_span (NULL = Qwen3Multi's plain causal rule): int32 [B,S,4] = (hi, hole_lo, hole_hi, unused) per query
  *   row, hi <= i: key j is allowed iff j <= hi and not (hole_lo <= j < hole_hi) and kl[j] < ql[i]
  *   (gamer_session_spans); row_empty / tile_empty must then describe that predicate.
+ *   delta_ready (bwd, with ds_work): delta already holds dO.O (the row-dot epilogue of gamer_gemm_f32 on the
+ *   o_proj dgrad wrote it): the delta kernel is skipped.
  * bwd: delta[b,h,i] = dO.O, dq and dk/dv, no atomics.  ds_work == NULL: two recompute kernels (7 matmuls per
  *   tile pair).  ds_work = B*nq*ceil(S/32)^2*1024 floats of scratch: the dk/dv kernel spills its dS tiles there
  *   and dq is one matmul per tile that streams them back (5 matmuls; +2 x that many bytes of HBM traffic).
@@ -238,7 +248,7 @@ int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float
                    int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                    float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                    const int32_t* row_perm, const int32_t* tile_kind, const int32_t* tile_maxpos,
-                   float* ds_work, const int32_t* q_span, void* stream);
+                   float* ds_work, const int32_t* q_span, int delta_ready, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Post-LN BERT-style encoder of the discriminative baselines (SURVEY section 8(f) row 4;

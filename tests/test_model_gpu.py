@@ -218,11 +218,12 @@ def test_missing_library_fails_loudly(monkeypatch):
         _lib.load()
 
 
-@pytest.mark.parametrize("case", ["single_item", "all_padding_row", "long_sequence"])
+@pytest.mark.parametrize("case", ["single_item", "all_padding_row", "long_sequence", "tokens_multiple_of_128"])
 def test_edge_shapes_against_oracle(case):
     """Edges the data path can produce: a one-item sequence (S = 5), a row that is padding only (every attention
-    row of it is "empty", no label), and a sequence longer than the LDS-resident dQ kernel handles (S = 1000:
-    gamer_attn_bwd falls back to the tiled dQ-from-dS kernel)."""
+    row of it is "empty", no label), a sequence longer than the LDS-resident dQ kernel handles (S = 1000:
+    gamer_attn_bwd falls back to the tiled dQ-from-dS kernel), and a token count that is a multiple of 128 (delta of
+    the attention backward fused into the o_proj dgrad GEMM)."""
     dims = dict(hidden_size=128, num_hidden_layers=4, num_attention_heads=2, num_key_value_heads=1, head_dim=64,
                 intermediate_size=256, moe_intermediate_size=128, behavior_embedding_dim=64,
                 behavior_injection_decoder=[0, 1], cross_attention_decoder=[2, 3], sparse_layers_decoder=[0, 1, 2, 3])
@@ -236,8 +237,12 @@ def test_edge_shapes_against_oracle(case):
         for k, fill in (("input_ids", synthetic.PAD_ID), ("attention_mask", 0), ("actions", 100), ("labels", -100),
                         ("session_ids", 0), ("extended_session_ids", 0)):
             batch[k][1] = fill
-    else:
+    elif case == "long_sequence":
         batch = synthetic.make_batch(1, 200, 256, 3, seed=7)
+    else:
+        # B * S = 640: every tile of the o_proj dgrad is full, so delta comes from its row-dot epilogue (the path the
+        # 1024 x 505 train step takes; the fixtures' token counts are not multiples of 128)
+        batch = synthetic.make_batch(16, 8, 256, 3, seed=9, pad_rows={3: 2})
     eng = Engine(cfg, temperature=0.7)
     eng.load_state_dict(sd)
     loss_ref, grads_ref, out_ref = orc.loss_and_grads(sd, ocfg, batch, temperature=0.7)

@@ -207,6 +207,23 @@ def test_gemm_linear_fwd_and_dgrad(M, N, K):
     assert _rel(dx.cpu()[:, :K], 2 * refd) < 2e-6
 
 
+def test_gemm_rowdot_epilogue():
+    """dgrad layout with the row-dot epilogue: C as without it, and out[b][head][i] = C[m, head] . other[m, head]
+    (flash attention's delta from the o_proj dgrad)."""
+    S, B, heads, K = 64, 6, 4, 96
+    M, N = B * S, heads * 64
+    dy, W, other = torch.randn(M, K), torch.randn(K, N), torch.randn(M, N)
+    ref = dy.double() @ W.double()
+    dx = torch.empty(M, N, device=DEV)
+    out = torch.full((B, heads, S), float("nan"), device=DEV)
+    ops.linear_dgrad(dev(dy), K, dev(W), N, dx, N, M, K, N, rowdot=(dev(other), out, S))
+    assert _rel(dx, ref) < 2e-6
+    want = (ref.view(B, S, heads, 64) * other.double().view(B, S, heads, 64)).sum(-1).permute(0, 2, 1)
+    assert _rel(out, want) < 5e-6
+    with pytest.raises(RuntimeError):        # partial tiles are refused, the caller keeps the separate delta kernel
+        ops.linear_dgrad(dev(dy[:100]), K, dev(W), N, dx[:100], N, 100, K, N, rowdot=(dev(other[:100]), out, 50))
+
+
 @pytest.mark.parametrize("rows,N,K", [(5000, 384, 256), (777, 1041, 256), (4100, 512, 320)])
 def test_gemm_wgrad_splitk(rows, N, K):
     ldy, ldx = (N + 3) // 4 * 4, K

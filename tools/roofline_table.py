@@ -33,8 +33,9 @@ def main():
     bench = json.load(open(os.path.join(prof, f"{tag}_bench_under_rocprof.json")))
     steps = bench["steps"] + bench["warmup"]
     tf = {k["kernel"]: k.get("tflops") for k in bench["kernels"]}
-    group = {"gemm_f32_kernel<true, true, 0, false, false, 2, false>": "gemm_fwd",
-             "gemm_f32_kernel<true, true, 0, false, false, 2, true>": "gemm_fwd_resid",
+    group = {"gemm_f32_kernel<true, true, 0, false, false, 2, 0>": "gemm_fwd",
+             "gemm_f32_kernel<true, true, 0, false, false, 2, 1>": "gemm_fwd_resid",
+             "gemm_f32_kernel<true, false, 0, false, false, 2, 2>": "gemm_dgrad_delta",
              "gemm_f32_kernel<true, false, 0": "gemm_dgrad", "gemm_f32_kernel<false, false, 1": "gemm_wgrad",
              "attn_fwd_kernel<2, true, false": "attn_fwd_self", "attn_fwd_kernel<2, true, true": "attn_fwd_cross"}
     total = sum(float(r["total_ms"]) for r in stats)
