@@ -123,11 +123,12 @@ class DecodeSession:
             sid0 = session_ids.to(dev, torch.int64)
             ext0 = extended_session_ids.to(dev, torch.int64)
             skw = dict(session_ids=sid0, extended_session_ids=ext0)
-        engine.forward(ids0, am0, act0, train=False, act_zero_col=L0 - 1, uniform_len=L0, kv_sink=sink, **skw)
+        engine.forward(ids0, am0, act0, train=False, act_zero_col=L0 - 1, uniform_len=L0, kv_sink=sink,
+                       last_row_logits=True, **skw)
         if self.session:
             engine.check_inputs()
-        # last-row logits of every sample (copied: the workspace is reused)
-        self.prefill_logits = engine.ws.logits.view(B, L0, -1)[:, -1].clone()
+        # last-row logits of every sample: the head ran on B rows, not on the whole prompt
+        self.prefill_logits = engine.last_logits_buf
         # masks of the new rows: self = kept keys; cross = kept keys of a lower level than the target behaviour
         # (the cached last mask row, model.py:603-617); no allowed key -> uniform over every key
         lv = act0[:, -1:]

@@ -299,7 +299,8 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     def forward(self, input_ids, attention_mask=None, actions=None, labels=None, num_items_in_batch=None,
                 train: bool = False, dropout: Optional[bool] = None, act_zero_col: Optional[int] = None,
-                uniform_len: int = 0, kv_sink=None, session_ids=None, extended_session_ids=None):
+                uniform_len: int = 0, kv_sink=None, session_ids=None, extended_session_ids=None,
+                last_row_logits: bool = False):
         """Returns (loss or None, logits view [B,S,V]).  With labels the logits are divided by the
         temperature in place, as the reference does (model.py:913).  The view aliases a workspace
         buffer: backward() overwrites it with d(logits), the next forward() with new logits.  ``train`` keeps every activation
@@ -313,7 +314,9 @@ class Engine:
         when the prompt has 5n+1 tokens (router.py:160-163) and which stays that way in its K/V cache;
         ``uniform_len`` is the prompt length (see gamer_attn_fwd in include/gamer_hip.h); ``kv_sink(layer, kind, k, v)``
         receives the keys (after k-norm + RoPE) and values of every attention ("self" / "cross") - the K/V cache of
-        gamer_amd.decode.DecodeSession."""
+        gamer_amd.decode.DecodeSession; ``last_row_logits``: the prompt pass of a generation needs the logits of the
+        last position only (HF's ``logits_to_keep``): final norm and head run on B rows instead of B*S and the
+        returned logits are [B, 1, V]."""
         cfg = self.cfg
         B, S = input_ids.shape
         if train and S % cfg.num_positions != 0:
@@ -420,6 +423,18 @@ class Engine:
                      p_drop=p_res, seed=self._seed(l, 5), **grp)
         # ---- final norm, tied head, temperature CE (model.py:869,1001,904-922) ----
         V = cfg.vocab_size
+        if last_row_logits:
+            if train or lab is not None:
+                raise ValueError("last_row_logits is an evaluation-only option")
+            rows = torch.arange(B, device=self.device) * S + (S - 1)
+            xl = ws.x_final.index_select(0, rows).contiguous()
+            xn = torch.empty_like(xl)
+            ops.rmsnorm_fwd(xl, self.params["model.norm.weight"], eps, xn)
+            small = torch.empty(B, ws.ldl, dtype=torch.float32, device=self.device)
+            ops.linear_fwd(xn, H, self.params["model.embed_tokens.weight"], H, small, ws.ldl, B, V, H)
+            self._saved = None
+            self.last_logits_buf = small               # [B, ldl] (columns >= V are padding), what DecodeSession scores
+            return None, small.view(B, 1, ws.ldl)[:, :, :V]
         ops.rmsnorm_fwd(ws.x_final, self.params["model.norm.weight"], eps, ws.xn)
         ops.linear_fwd(ws.xn, H, self.params["model.embed_tokens.weight"], H, ws.logits, ws.ldl, T, V, H)
         loss = None
