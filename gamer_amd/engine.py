@@ -324,6 +324,8 @@ class Engine:
                              "(the router assumes item-aligned sequences, router.py:78-81)")
         if train and (act_zero_col is not None or uniform_len not in (0, S)):
             raise ValueError("act_zero_col / uniform_len are evaluation-only options")
+        if last_row_logits and (train or labels is not None):
+            raise ValueError("last_row_logits is an evaluation-only option")
         T, H = B * S, cfg.hidden_size
         nq, nkv, dh, I, E = (cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size,
                              cfg.num_experts)
@@ -409,6 +411,25 @@ class Engine:
                 xcur = xs[2]
             # ---- position-routed SwiGLU experts (model.py:238-241, FFN.py:53-72) ----
             din = W.din
+            if last_row_logits and l == cfg.num_hidden_layers - 1:
+                # prompt pass of a generation: after the last layer's K/V are cached only the last position of every
+                # sample is still needed; its FFN is one dense expert on B rows (the prompt ends with a real token,
+                # so the expert is the position's: router.py:83-104)
+                rows = torch.arange(B, device=self.device) * S + (S - 1)
+                e = (S - 1) % cfg.num_positions + 1
+                xl = xcur.index_select(0, rows).contiguous()
+                f32 = dict(dtype=torch.float32, device=self.device)
+                hin = torch.empty(B, din, **f32)
+                ops.rmsnorm_fwd(xl, W.ln3, eps, hin, din)
+                if W.inject:
+                    ops.rowtable_fwd(W.beh, r["beh_idx"].view(-1).index_select(0, rows).contiguous(), hin, din, H)
+                g, u, hm = torch.empty(B, I, **f32), torch.empty(B, I, **f32), torch.empty(B, I, **f32)
+                ops.linear_fwd(hin, din, W.gate[e * I:(e + 1) * I], din, g, I, B, I, din)
+                ops.linear_fwd(hin, din, W.up[e * I:(e + 1) * I], din, u, I, B, I, din)
+                ops.swiglu_fwd(g, u, B * I, 0.0, 0, hm)
+                x_last = torch.empty(B, H, **f32)
+                ops.gemm(hm, I, 1, W.down[e * H:(e + 1) * H], I, 1, x_last, H, B, H, I, resid=xl)
+                break
             ops.rmsnorm_fwd(xcur, W.ln3, eps, A["hin"], din, ws.slot)
             if W.inject:
                 ops.rowtable_fwd(W.beh, r["beh_idx"], A["hin"], din, H, ws.slot)
@@ -424,12 +445,8 @@ class Engine:
         # ---- final norm, tied head, temperature CE (model.py:869,1001,904-922) ----
         V = cfg.vocab_size
         if last_row_logits:
-            if train or lab is not None:
-                raise ValueError("last_row_logits is an evaluation-only option")
-            rows = torch.arange(B, device=self.device) * S + (S - 1)
-            xl = ws.x_final.index_select(0, rows).contiguous()
-            xn = torch.empty_like(xl)
-            ops.rmsnorm_fwd(xl, self.params["model.norm.weight"], eps, xn)
+            xn = torch.empty_like(x_last)
+            ops.rmsnorm_fwd(x_last, self.params["model.norm.weight"], eps, xn)
             small = torch.empty(B, ws.ldl, dtype=torch.float32, device=self.device)
             ops.linear_fwd(xn, H, self.params["model.embed_tokens.weight"], H, small, ws.ldl, B, V, H)
             self._saved = None
