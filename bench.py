@@ -2,20 +2,24 @@
 """Headline benchmark: train-step sequences/s of the Qwen3Multi SMB decoder (max_his_len=100).
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N>1 it is launched with
-torch.distributed.run, one rank per GPU (RCCL).  W untimed steps, then exactly K timed steps between
-barrier + synchronize, MAX over ranks, rank 0 prints ONE JSON line.
+torch.distributed.run, one rank per GPU (RCCL) - and when it is started WITHOUT a launcher (no WORLD_SIZE in the
+environment) it starts the N ranks itself, as ref:scripts/train_SMB_decoder.sh:123-153 does, and relays rank 0's
+line.  W untimed steps, then exactly K timed steps between barrier + synchronize, MAX over ranks, rank 0 prints
+ONE JSON line.
 
 Workload (BASELINE.json configs[1]): shipped Qwen3Multi architecture (8 layers, hidden 256, 6/3 heads,
 6 position-routed experts, V=1041), fp32, per-GPU micro-batch 1024 sequences x 505 tokens
 (101 items x 5 tokens), synthetic ids, seeded random weights, dropout 0.2 ON, one step =
-forward + backward + (gradient all-reduce) + clip_grad_norm_(1.0) + AdamW.  Weak scaling: the per-GPU
-batch is fixed, the global batch is N x 1024.
+forward + backward + (gradient all-reduce) + clip_grad_norm_(1.0) + AdamW.  Default = the north star's strong
+scaling: global batch 1024, per-GPU batch 1024 / N (1024 / 512 / 256 / 128 at 1 / 2 / 4 / 8 GPUs); ``--weak`` keeps
+1024 sequences per GPU (BASELINE configs[2]: 8 x 1024 with ``--dtype bf16``).
 
 Extra objects on the JSON line:
   roofline     the dominant kernel family (fp32 MFMA GEMM): algorithmic FLOPs of its launches / their
                summed duration, measured with HIP events on the launch stream inside the timed region
   cpu_baseline the CPU oracle (a port of the reference algorithm, oracle/) timed on the host cores,
-               rank 0, N=1 only, on a bounded sample (micro-batch 8, same sequence shape)
+               rank 0, N=1 only, on a bounded sample (micro-batch 32, 1 warm-up + 3 timed
+               steps, same sequence shape)
 """
 from __future__ import annotations
 
@@ -202,11 +206,11 @@ def committed_traffic(kernel_substr: str):
             "fetch_kib_raw": f, "write_kib": w}
 
 
-def cpu_baseline(cfg_dict, seq_items: int, micro_batch: int = 8, timed_steps: int = 2, session_mean=None):
+def cpu_baseline(cfg_dict, seq_items: int, micro_batch: int = 32, timed_steps: int = 3, session_mean=None):
     """The CPU oracle's train step (fwd + bwd + clip + AdamW, dropout on) on this host's cores."""
     from oracle import qwen3multi_oracle as orc
     from gamer_amd import synthetic
-    cores = min(usable_cpus(), 64)
+    cores = usable_cpus()
     torch.set_num_threads(cores)
     log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
     ocfg = orc.OracleConfig.from_dict(cfg_dict)
@@ -224,7 +228,7 @@ def cpu_baseline(cfg_dict, seq_items: int, micro_batch: int = 8, timed_steps: in
         orc.clip_and_adamw(params, grads, m, v, step=step + 1, lr=5e-4)
         times.append(time.perf_counter() - t0)
         log(f"cpu baseline step {step}: {times[-1]:.2f} s")
-        if step >= 1 and sum(times) > 45.0:        # keep the default run within a few minutes
+        if step >= 1 and sum(times) > 150.0:       # a slow host: keep the default run within a few minutes
             break
     timed_steps = len(times) - 1
     mean = sum(times[1:]) / len(times[1:])
@@ -234,25 +238,98 @@ def cpu_baseline(cfg_dict, seq_items: int, micro_batch: int = 8, timed_steps: in
                        f"torch.set_num_threads({cores})")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024, help="per-GPU micro-batch (sequences)")
+    ap.add_argument("--global-batch", type=int, default=1024,
+                    help="sequences per optimizer step over ALL GPUs (north star: 1024); per-GPU batch = global / N")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling: every GPU takes --batch sequences (BASELINE configs[2]: 8 x 1024)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="per-GPU micro-batch; implies --weak (default: --global-batch / --gpus)")
     ap.add_argument("--items", type=int, default=101, help="items per sequence (max_his_len + 1)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = BASELINE configs[1] (headline); bf16 = the AMP variant of configs[2]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (and the roofline object)")
     ap.add_argument("--ragged", action="store_true", help="secondary workload: n_items ~ U{2..items}, right padded")
     ap.add_argument("--variant", choices=["multi", "session"], default="multi",
                     help="secondary workload: 'session' = Qwen3SessionMulti (session-wise masks, same weights)")
     ap.add_argument("--session-mean", type=float, default=4.0, help="items per session for --variant session")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.batch is not None:
+        args.weak = True
+    elif args.weak:
+        args.batch = 1024
+    else:
+        if args.global_batch % args.gpus != 0:
+            ap.error(f"--global-batch {args.global_batch} is not divisible by --gpus {args.gpus}")
+        args.batch = args.global_batch // args.gpus
+    return args
 
+
+def launcher_command(n: int, port: int, argv) -> list:
+    """One rank per GPU on this node, as ref:scripts/train_SMB_decoder.sh:123-153 does with torchrun.
+    GAMER_BENCH_LAUNCHER (a command prefix, shlex-split) replaces the torch launcher in tests."""
+    import shlex
+    override = os.environ.get("GAMER_BENCH_LAUNCHER")
+    if override:
+        return shlex.split(override) + [str(n), os.path.abspath(__file__), *argv]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def spawn_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start N fresh rank processes and relay rank 0's
+    JSON line.  Runs before anything in this process has touched the GPU (device_count() does not initialise it);
+    the children are new processes, never an exec of this one."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus and not os.environ.get("GAMER_BENCH_LAUNCHER"):
+        log(f"--gpus {args.gpus} but only {have} HIP device(s) are visible")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = launcher_command(args.gpus, port, argv)
+    log("spawning: " + " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if r.returncode != 0:
+        log(f"launcher exited with {r.returncode}")
+        return r.returncode
+    if line is None:
+        log("no JSON line came back from rank 0")
+        return 3
+    got = json.loads(line).get("n_gpus")
+    if got != args.gpus:
+        log(f"asked for {args.gpus} ranks, the run reports n_gpus={got}")
+        return 4
+    print(line, flush=True)
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
@@ -263,6 +340,8 @@ def main():
         if force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
         dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != world:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {world}")
 
     from gamer_amd import synthetic
     from gamer_amd.config import synthetic_config
@@ -296,7 +375,8 @@ def main():
                    for s in range(n_batches)]
     flops = [algorithmic_flops(cfg, b, session=args.variant == "session") for b in cpu_batches]
     timer = KernelTimer()
-    timer.install()
+    if not args.no_kernel_timing:
+        timer.install()
     lr = 5e-4
     grad_scale = 1.0                              # gradients are already global means (sum CE / global count)
 
@@ -331,6 +411,28 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the collective on its own, outside the timed region: the whole flat gradient (98 MB fp32) in the per-layer
+    # buckets of the train step, back to back; bus bandwidth = 2 (N-1)/N x bytes / time (ring-equivalent convention)
+    allreduce = None
+    if reducer is not None and world > 1:
+        import torch.distributed as dist
+        reps = 5
+        for timed in (False, True):
+            dist.barrier()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(reps if timed else 2):
+                for l in reversed(range(cfg.num_hidden_layers)):
+                    reducer.layer_done(l)
+                reducer.finish()
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - ta
+        t = torch.tensor([tb], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        nbytes = eng.flat_g.numel() * 4
+        ms = float(t.item()) / reps * 1e3
+        allreduce = {"ranks": dist.get_world_size(), "backend": "nccl (RCCL)", "bytes": nbytes, "buckets": cfg.num_hidden_layers + 2,
+                     "ms": ms, "bus_GBps": 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9}
 
     if rank == 0:
         seqs = args.batch * world * args.steps
@@ -355,16 +457,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if args.weak else "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": (("Qwen3Multi" if args.variant == "multi" else
                               f"Qwen3SessionMulti (sessions of {args.session_mean:g} items on average)") +
                              " SMB decoder train step (fwd+bwd+clip+AdamW, dropout 0.2), ShortVideoAD-shaped "
                              f"synthetic ids, per-GPU batch {args.batch} x {args.items * 5} tokens"
-                             + (" ragged" if args.ragged else "") + ", V=1041, fp32"),
+                             + (" ragged" if args.ragged else "") + ", V=1041, " +
+                             ("fp32" if args.dtype == "f32" else "bf16 AMP (fp32 master weights / gradients / moments)")),
                 "global_batch": args.batch * world,
                 "seq_len": args.items * 5,
                 "parallelism": f"dp{world}",
@@ -388,6 +491,10 @@ def main():
             "kernels": kernels[:12],
             "loss": final_loss,
         }
+        if allreduce is not None:
+            result["allreduce"] = allreduce
+        if args.no_kernel_timing:
+            result["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg.to_dict(), args.items, session_mean=smean)
         # RCCL prints a version banner through C stdio; push it out first so that the JSON line is last

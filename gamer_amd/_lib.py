@@ -62,7 +62,7 @@ _SIGNATURES = {
     "gamer_gemm_f32": [C.POINTER(GemmDesc), P],
     "gamer_session_spans": [P, P, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P],
     "gamer_qknorm_rope_fwd": [P, I, I, I, I, P, P, F, P, P, P, P, P, P, P, P, P, P],
-    "gamer_qknorm_rope_bwd": [P, P, P, I, I, I, I, P, P, F, P, P, P, P, P, I, P, P, P, P, P, P, P, P],
+    "gamer_qknorm_rope_bwd": [P, P, P, I, I, I, I, P, P, F, P, P, P, P, P, I, P, P, P, P, P, P, P, P, L, P],
     "gamer_attn_row_order": [P, I, I, P, P, P, P],
     "gamer_attn_fwd": [P, I, P, I, P, I, P, P, P, P, I, I, I, I, F, F, U, P, P, P, P, P, I, P, P],
     "gamer_attn_bwd": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, P, P, P, P, I, P],
@@ -72,6 +72,7 @@ _SIGNATURES = {
     "gamer_swiglu_bwd": [P, P, P, L, F, U, P],
     "gamer_silu_gate_fwd": [P, P, L, P, P, F, U, P],
     "gamer_silu_gate_bwd": [P, P, P, L, P, P, F, U, P],
+    "gamer_check_labels": [P, L, I, I, P, P],
     "gamer_ce_fwd": [P, I, P, I, I, I, F, I, P, P, P, P, P],
     "gamer_ce_bwd": [P, I, P, I, I, I, F, I, P, P, F, F, P],
     "gamer_sumsq": [P, L, P, I, P],
@@ -87,6 +88,12 @@ _SIGNATURES = {
     "gamer_trie_advance": [P, P, P, P, P, I, P, P],
     "gamer_attn_decode": [P, I, P, I, P, I, P, P, P, I, I, I, I, P, I, I, I, I, I, F, P, P],
 }
+
+
+# bf16 twins: same argument kinds as the fp32 entry point (activation pointers are gamer_bf16* instead of float*)
+for _n in ("rmsnorm_fwd", "rmsnorm_bwd", "rowtable_fwd", "rowtable_bwd", "qknorm_rope_fwd", "qknorm_rope_bwd", "swiglu_fwd",
+           "swiglu_bwd", "silu_gate_fwd", "silu_gate_bwd", "ce_fwd", "ce_bwd"):
+    _SIGNATURES[f"gamer_{_n}_bf16"] = _SIGNATURES[f"gamer_{_n}"]
 
 
 def header_symbols():

@@ -35,6 +35,33 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // ---- device helpers -----------------------------------------------------------------------
 constexpr int WAVE = 64;
 
+// bf16 activations (the AMP variant): raw storage type of the C ABI is uint16_t (gamer_bf16), device code uses the
+// compiler's __bf16 so that conversions are v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN).
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x8v __attribute__((ext_vector_type(8)));
+
+// four consecutive elements as a float4 (p aligned to 4 elements): 16-byte access for fp32, 8-byte for bf16
+template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, const float4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float4 v) {
+    const f32x4v f = {v.x, v.y, v.z, v.w};
+    *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(f, bf16x4);
+}
+template <typename T> __device__ __forceinline__ float ld1(const T* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = (T)v; }
+// round a value through the activation type (identity for fp32): mirrors autocast's intermediate bf16 tensors
+template <typename T> __device__ __forceinline__ float round_as(float v) { return (float)(T)v; }
+template <typename T> static inline bool aligned_vec4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(T) - 1)) == 0; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -114,6 +141,11 @@ struct AttnDropout {
     __device__ __forceinline__ bool keep(uint32_t a, uint32_t b) const { return __umul24(a, b) >= thr; }
 };
 
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));

@@ -92,9 +92,10 @@ embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 constexpr int RMS_MAXC = 4;   // float4 chunks per lane -> H <= 1024
 
+template <typename TY>
 __global__ void __launch_bounds__(EW_THREADS)
 rmsnorm_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, int T, int H4, float inv_h,
-                   float eps, const int32_t* __restrict__ dst_rows, float* __restrict__ y, int ldy) {
+                   float eps, const int32_t* __restrict__ dst_rows, TY* __restrict__ y, int ldy) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * EW_THREADS) >> 6;
@@ -116,7 +117,7 @@ rmsnorm_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, i
         ss = wave_sum(ss);
         const float rstd = rsqrtf(ss * inv_h + eps);
         const int64_t r = dst_rows ? dst_rows[t] : t;
-        float4* yrow = reinterpret_cast<float4*>(y + r * ldy);
+        TY* yrow = y + r * ldy;
 #pragma unroll
         for (int i = 0; i < RMS_MAXC; ++i) {
             const int c = lane + 64 * i;
@@ -126,18 +127,19 @@ rmsnorm_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, i
                 o.y = wv[i].y * (v[i].y * rstd);
                 o.z = wv[i].z * (v[i].z * rstd);
                 o.w = wv[i].w * (v[i].w * rstd);
-                yrow[c] = o;
+                st4(yrow + 4 * c, o);
             }
         }
     }
 }
 
 // dx (+)= rstd*(w*dy - xhat*mean(w*dy*xhat)); per-workgroup dw partial sums (deterministic).
+template <typename TG>
 __global__ void __launch_bounds__(EW_THREADS)
-rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, const float* __restrict__ dy,
+rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, const TG* __restrict__ dy,
                    int lddy, const int32_t* __restrict__ dy_rows, int T, int H4, float inv_h, float eps,
                    int accumulate_dx, float4* __restrict__ dx, float* __restrict__ dw_partial,
-                   float4* __restrict__ mask_out, const int32_t* __restrict__ mask_rows, float p_drop, uint64_t seed) {
+                   TG* __restrict__ mask_out, const int32_t* __restrict__ mask_rows, float p_drop, uint64_t seed) {
     // mask_out != nullptr: the next consumer of dx is a residual branch with dropout; its input gradient
     // mask(seed) * dx is written here (what gamer_residual_dropout_bwd would compute in a second pass over dx)
     const DropoutRng rng(mask_out ? p_drop : 0.f, seed);
@@ -157,12 +159,12 @@ rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, c
         float4 v[RMS_MAXC], g[RMS_MAXC];
         float ss = 0.f;
         const int64_t r = dy_rows ? dy_rows[t] : t;
-        const float4* dyrow = reinterpret_cast<const float4*>(dy + r * lddy);
+        const TG* dyrow = dy + r * lddy;
 #pragma unroll
         for (int i = 0; i < RMS_MAXC; ++i) {
             const int c = lane + 64 * i;
             v[i] = (c < H4) ? x[(int64_t)t * H4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-            g[i] = (c < H4) ? dyrow[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            g[i] = (c < H4) ? ld4(dyrow + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
             ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
         }
         ss = wave_sum(ss);
@@ -196,7 +198,7 @@ rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, c
                     float m[4];
                     rng.mult4((uint32_t)((int64_t)t * H4 + c), m);
                     const int64_t mr = mask_rows ? mask_rows[t] : t;
-                    mask_out[mr * H4 + c] = make_float4(m[0] * o.x, m[1] * o.y, m[2] * o.z, m[3] * o.w);
+                    st4(mask_out + (mr * H4 + c) * 4, make_float4(m[0] * o.x, m[1] * o.y, m[2] * o.z, m[3] * o.w));
                 }
             }
         }
@@ -254,15 +256,16 @@ colsum_reduce_kernel(const float* __restrict__ partial, int rows, int cols, int 
 // ---------------------------------------------------------------------------------------------
 // small-table rows (behaviour embeddings)
 // ---------------------------------------------------------------------------------------------
+template <typename TY>
 __global__ void __launch_bounds__(EW_THREADS)
 rowtable_fwd_kernel(const float4* __restrict__ table, const int32_t* __restrict__ idx,
-                    const int32_t* __restrict__ dst_rows, int T, int E4, float* __restrict__ y, int ldy, int col0) {
+                    const int32_t* __restrict__ dst_rows, int T, int E4, TY* __restrict__ y, int ldy, int col0) {
     const int64_t total = (int64_t)T * E4;
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
         const int t = (int)(i / E4);
         const int c = (int)(i % E4);
         const int64_t r = dst_rows ? dst_rows[t] : t;
-        reinterpret_cast<float4*>(y + r * ldy + col0)[c] = table[(int64_t)idx[t] * E4 + c];
+        st4(y + r * ldy + col0 + 4 * c, table[(int64_t)idx[t] * E4 + c]);
     }
 }
 
@@ -270,8 +273,9 @@ constexpr int TBL_MAXROWS = 8;   // num_behavior + 1 <= 8
 
 // dtable[idx[t]][c] += dy[src(t)][col0+c]; per-thread predicated accumulators, LDS combine, one
 // atomic per workgroup per table element.
+template <typename TG>
 __global__ void __launch_bounds__(EW_THREADS)
-rowtable_bwd_kernel(const float* __restrict__ dy, int lddy, int col0, const int32_t* __restrict__ idx,
+rowtable_bwd_kernel(const TG* __restrict__ dy, int lddy, int col0, const int32_t* __restrict__ idx,
                     const int32_t* __restrict__ dy_rows, int T, int E4, int nrows, float* __restrict__ dtable) {
     extern __shared__ __attribute__((aligned(16))) float lds_tbl[];   // [nrows][E4*4]
     const int E = E4 * 4;
@@ -286,7 +290,7 @@ rowtable_bwd_kernel(const float* __restrict__ dy, int lddy, int col0, const int3
     if (rl < rows_per_block) {
         for (int64_t t = (int64_t)blockIdx.x * rows_per_block + rl; t < T; t += (int64_t)gridDim.x * rows_per_block) {
             const int64_t r = dy_rows ? dy_rows[t] : t;
-            const float4 g = reinterpret_cast<const float4*>(dy + r * lddy + col0)[c];
+            const float4 g = ld4(dy + r * lddy + col0 + 4 * c);
             const int a_t = idx[t];
 #pragma unroll
             for (int a = 0; a < TBL_MAXROWS; ++a) {
@@ -318,13 +322,21 @@ __device__ __forceinline__ float group16_sum(float v) {
     return v;
 }
 
+// TA = activation type of qkv / q_rot / k_rot.  With bf16 activations the arithmetic mirrors what the reference does
+// under autocast (ref:SeqRec/tasks/train_SMB_decoder.py:114-118): the projection output is bf16; for the self attention
+// Qwen3MoeRMSNorm sees a bf16 input and rounds the normalised value to bf16 before the fp32 weight multiply; for the
+// cross attention the fp32 behaviour bias is added first, so the norm runs in fp32; RoPE is fp32; SDPA's inputs
+// (q_rot, k_rot, v) are rounded to bf16.  The biased pre-norm values are NOT written back in bf16 (the backward adds
+// the bias again, exactly); the fp32 kernels keep writing them back as in round 1.
+template <typename TA>
 __global__ void __launch_bounds__(EW_THREADS)
-qknorm_rope_fwd_kernel(float* __restrict__ qkv, int T, int S, int nq, int nkv,
+qknorm_rope_fwd_kernel(TA* __restrict__ qkv, int T, int S, int nq, int nkv,
                        const float* __restrict__ wq, const float* __restrict__ wk, float eps,
                        const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                        const float* __restrict__ bias_q, const float* __restrict__ bias_k,
                        const float* __restrict__ bias_v, const int32_t* __restrict__ act_idx,
-                       float* __restrict__ q_rot, float* __restrict__ k_rot, const int32_t* __restrict__ pos_ids) {
+                       TA* __restrict__ q_rot, TA* __restrict__ k_rot, const int32_t* __restrict__ pos_ids) {
+    constexpr bool F32 = sizeof(TA) == 4;
     const int lane = threadIdx.x & 63;
     const int g = lane & 15, sub = lane >> 4;
     const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
@@ -342,22 +354,27 @@ qknorm_rope_fwd_kernel(float* __restrict__ qkv, int T, int S, int nq, int nkv,
         const int t = (int)(ic / NH);
         const int hd = (int)(ic % NH);
         const int a = cross ? act_idx[t] : 0;
-        float* row = qkv + (int64_t)t * ldqkv;
+        TA* row = qkv + (int64_t)t * ldqkv;
         if (hd < nq + nkv) {
             const bool isq = hd < nq;
-            float4* src = reinterpret_cast<float4*>(row + hd * 64) + g;   // q heads then k heads are contiguous
-            float4 x = *src;
+            TA* src = row + hd * 64 + 4 * g;   // q heads then k heads are contiguous
+            float4 x = ld4(src);
             if (cross) {
                 const float4 b4 = isq ? reinterpret_cast<const float4*>(bias_q + (int64_t)a * nq * 64 + hd * 64)[g]
                                       : reinterpret_cast<const float4*>(bias_k + (int64_t)a * nkv * 64 + (hd - nq) * 64)[g];
                 x.x += b4.x; x.y += b4.y; x.z += b4.z; x.w += b4.w;
-                if (live) *src = x;                       // keep the pre-norm (biased) value for the backward
+                if (F32 && live) st4(src, x);             // fp32: keep the pre-norm (biased) value for the backward
             }
             const float ss = group16_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
             const float rstd = rsqrtf(ss * (1.f / 64.f) + eps);
             const float4 w4 = isq ? wq4 : wk4;
+            float4 xn;
+            xn.x = x.x * rstd; xn.y = x.y * rstd; xn.z = x.z * rstd; xn.w = x.w * rstd;
+            if (!F32 && !cross) {                         // Qwen3MoeRMSNorm on a bf16 tensor: .to(input_dtype) before * weight
+                xn.x = round_as<TA>(xn.x); xn.y = round_as<TA>(xn.y); xn.z = round_as<TA>(xn.z); xn.w = round_as<TA>(xn.w);
+            }
             float4 y;
-            y.x = w4.x * (x.x * rstd); y.y = w4.y * (x.y * rstd); y.z = w4.z * (x.z * rstd); y.w = w4.w * (x.w * rstd);
+            y.x = w4.x * xn.x; y.y = w4.y * xn.y; y.z = w4.z * xn.z; y.w = w4.w * xn.w;
             float4 pr;
             pr.x = __shfl_xor(y.x, 8, 64); pr.y = __shfl_xor(y.y, 8, 64); pr.z = __shfl_xor(y.z, 8, 64); pr.w = __shfl_xor(y.w, 8, 64);
             const int pos = pos_ids ? pos_ids[t] : t % S;        // per-token RoPE position (session model) or the index
@@ -367,32 +384,37 @@ qknorm_rope_fwd_kernel(float* __restrict__ qkv, int T, int S, int nq, int nkv,
             o.x = y.x * c4.x + sgn * pr.x * s4.x; o.y = y.y * c4.y + sgn * pr.y * s4.y;
             o.z = y.z * c4.z + sgn * pr.z * s4.z; o.w = y.w * c4.w + sgn * pr.w * s4.w;
             if (live) {
-                if (isq) reinterpret_cast<float4*>(q_rot + (int64_t)t * nq * 64 + hd * 64)[g] = o;
-                else reinterpret_cast<float4*>(k_rot + (int64_t)t * nkv * 64 + (hd - nq) * 64)[g] = o;
+                if (isq) st4(q_rot + (int64_t)t * nq * 64 + hd * 64 + 4 * g, o);
+                else st4(k_rot + (int64_t)t * nkv * 64 + (hd - nq) * 64 + 4 * g, o);
             }
         } else {
             // (only reached when cross) v += bias_v; the shuffles above are skipped by the whole 16-lane group
             const int hv = hd - nq - nkv;
-            float4* dst = reinterpret_cast<float4*>(row + (nq + nkv + hv) * 64) + g;
+            TA* dst = row + (nq + nkv + hv) * 64 + 4 * g;
             const float4 b4 = reinterpret_cast<const float4*>(bias_v + (int64_t)a * nkv * 64 + hv * 64)[g];
-            float4 x = *dst;
+            float4 x = ld4(dst);
             x.x += b4.x; x.y += b4.y; x.z += b4.z; x.w += b4.w;
-            if (live) *dst = x;
+            if (live) st4(dst, x);
         }
     }
 }
 
 // Each wave keeps one head for its whole life so that the norm-weight and bias gradients accumulate in
-// registers (four tokens per iteration, one per 16-lane group); one set of atomics per wave at the end.
+// registers (four tokens per iteration, one per 16-lane group).  At the end every wave writes its sums as one row of
+// `partial` [waves_per_head][NH][1 + nb1][64] (slot 0: norm weight, slots 1..: bias rows) and
+// qknorm_partial_reduce_kernel folds the rows in a fixed order.  (Round 1 finished with same-address float atomics
+// from ~8000 waves into 64 + nb1*64 addresses per head: a 0.4 ms floor per call at every batch size.)
+template <typename TA>
 __global__ void __launch_bounds__(EW_THREADS)
-qknorm_rope_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dq_rot,
-                       const float* __restrict__ dk_rot, int T, int S, int nq, int nkv,
+qknorm_rope_bwd_kernel(const TA* __restrict__ qkv, const TA* __restrict__ dq_rot,
+                       const TA* __restrict__ dk_rot, int T, int S, int nq, int nkv,
                        const float* __restrict__ wq, const float* __restrict__ wk, float eps,
                        const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                       int cross, const int32_t* __restrict__ act_idx, int nb1,
-                       float* __restrict__ dqkv, float* __restrict__ dwq, float* __restrict__ dwk,
-                       float* __restrict__ dbias_q, float* __restrict__ dbias_k, float* __restrict__ dbias_v,
+                       int cross, const float* __restrict__ bias_q, const float* __restrict__ bias_k,
+                       const int32_t* __restrict__ act_idx, int nb1,
+                       TA* __restrict__ dqkv, float* __restrict__ partial,
                        int waves_per_head, const int32_t* __restrict__ pos_ids) {
+    constexpr bool F32 = sizeof(TA) == 4;
     const int lane = threadIdx.x & 63;
     const int g = lane & 15, sub = lane >> 4;
     const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
@@ -413,9 +435,15 @@ qknorm_rope_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ 
             const int t = tb + sub;
             const bool live = t < T;
             const int tc = live ? t : T - 1;
-            const float4 x = reinterpret_cast<const float4*>(qkv + (int64_t)tc * ldqkv + hd * 64)[g];   // pre-norm (bias included)
-            const float4 d = isq ? reinterpret_cast<const float4*>(dq_rot + (int64_t)tc * nq * 64 + hd * 64)[g]
-                                 : reinterpret_cast<const float4*>(dk_rot + (int64_t)tc * nkv * 64 + (hd - nq) * 64)[g];
+            float4 x = ld4(qkv + (int64_t)tc * ldqkv + hd * 64 + 4 * g);   // pre-norm (fp32: bias included)
+            const int a_t = cross ? act_idx[tc] : 0;
+            if (!F32 && cross) {
+                const float4 b4 = isq ? reinterpret_cast<const float4*>(bias_q + (int64_t)a_t * nq * 64 + hd * 64)[g]
+                                      : reinterpret_cast<const float4*>(bias_k + (int64_t)a_t * nkv * 64 + (hd - nq) * 64)[g];
+                x.x += b4.x; x.y += b4.y; x.z += b4.z; x.w += b4.w;
+            }
+            const float4 d = isq ? ld4(dq_rot + (int64_t)tc * nq * 64 + hd * 64 + 4 * g)
+                                 : ld4(dk_rot + (int64_t)tc * nkv * 64 + (hd - nq) * 64 + 4 * g);
             const int pos = pos_ids ? pos_ids[tc] : tc % S;
             const float4 c4 = reinterpret_cast<const float4*>(cos_t + pos * 64)[g];
             const float4 s4 = reinterpret_cast<const float4*>(sin_t + pos * 64)[g];
@@ -430,19 +458,25 @@ qknorm_rope_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ 
             float4 xh;
             xh.x = x.x * rstd; xh.y = x.y * rstd; xh.z = x.z * rstd; xh.w = x.w * rstd;
             const float lv = live ? 1.f : 0.f;
-            dwacc.x += lv * dy.x * xh.x; dwacc.y += lv * dy.y * xh.y; dwacc.z += lv * dy.z * xh.z; dwacc.w += lv * dy.w * xh.w;
+            if (!F32 && !cross) {
+                // the weight multiplied the bf16-rounded normalised value in the forward (the cast's gradient is identity)
+                dwacc.x += lv * dy.x * round_as<TA>(xh.x); dwacc.y += lv * dy.y * round_as<TA>(xh.y);
+                dwacc.z += lv * dy.z * round_as<TA>(xh.z); dwacc.w += lv * dy.w * round_as<TA>(xh.w);
+            } else {
+                dwacc.x += lv * dy.x * xh.x; dwacc.y += lv * dy.y * xh.y; dwacc.z += lv * dy.z * xh.z; dwacc.w += lv * dy.w * xh.w;
+            }
             float4 gg;
             gg.x = dy.x * w4.x; gg.y = dy.y * w4.y; gg.z = dy.z * w4.z; gg.w = dy.w * w4.w;
             const float dot = group16_sum(gg.x * xh.x + gg.y * xh.y + gg.z * xh.z + gg.w * xh.w) * (1.f / 64.f);
             float4 dx;
             dx.x = rstd * (gg.x - xh.x * dot); dx.y = rstd * (gg.y - xh.y * dot);
             dx.z = rstd * (gg.z - xh.z * dot); dx.w = rstd * (gg.w - xh.w * dot);
-            if (live) reinterpret_cast<float4*>(dqkv + (int64_t)t * ldqkv + hd * 64)[g] = dx;
+            if (live) st4(dqkv + (int64_t)t * ldqkv + hd * 64 + 4 * g, dx);
             if (cross) {
-                const int a_t = live ? act_idx[t] : -1;
+                const int a_l = live ? a_t : -1;
 #pragma unroll
                 for (int a = 0; a < TBL_MAXROWS; ++a) {
-                    const float m = (a_t == a) ? 1.f : 0.f;
+                    const float m = (a_l == a) ? 1.f : 0.f;
                     dbacc[a].x += m * dx.x; dbacc[a].y += m * dx.y; dbacc[a].z += m * dx.z; dbacc[a].w += m * dx.w;
                 }
             }
@@ -453,7 +487,7 @@ qknorm_rope_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ 
             const int t = tb + sub;
             const bool live = t < T;
             const int tc = live ? t : T - 1;
-            const float4 dv = reinterpret_cast<const float4*>(dqkv + (int64_t)tc * ldqkv + (nq + nkv + hv) * 64)[g];
+            const float4 dv = ld4(dqkv + (int64_t)tc * ldqkv + (nq + nkv + hv) * 64 + 4 * g);
             const int a_t = live ? act_idx[t] : -1;
 #pragma unroll
             for (int a = 0; a < TBL_MAXROWS; ++a) {
@@ -462,30 +496,63 @@ qknorm_rope_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ 
             }
         }
     }
-    // fold the four 16-lane groups, then one atomic per element from group 0
+    // fold the four 16-lane groups, then group 0 writes this wave's row of partial sums
     auto fold = [&](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
-    if (hd < nq + nkv) {
-        const bool isq = hd < nq;
+    const int SL = 1 + (cross ? nb1 : 0);
+    float* prow = partial + ((int64_t)w0 * NH + hd) * SL * 64;
+    {
         const float a0 = fold(dwacc.x), a1 = fold(dwacc.y), a2 = fold(dwacc.z), a3 = fold(dwacc.w);
-        if (sub == 0) {
-            float* dw = (isq ? dwq : dwk) + 4 * g;
-            atomicAdd(dw + 0, a0); atomicAdd(dw + 1, a1); atomicAdd(dw + 2, a2); atomicAdd(dw + 3, a3);
-        }
+        if (sub == 0) reinterpret_cast<float4*>(prow)[g] = make_float4(a0, a1, a2, a3);      // zeros for the v heads
     }
     if (cross) {
-        float* base;
-        if (hd < nq) base = dbias_q + hd * 64;
-        else if (hd < nq + nkv) base = dbias_k + (hd - nq) * 64;
-        else base = dbias_v + (hd - nq - nkv) * 64;
-        const int ldb = hd < nq ? nq * 64 : nkv * 64;
 #pragma unroll
         for (int a = 0; a < TBL_MAXROWS; ++a) {
             const float b0 = fold(dbacc[a].x), b1 = fold(dbacc[a].y), b2 = fold(dbacc[a].z), b3 = fold(dbacc[a].w);
-            if (a < nb1 && sub == 0) {
-                float* d = base + (int64_t)a * ldb + 4 * g;
-                atomicAdd(d + 0, b0); atomicAdd(d + 1, b1); atomicAdd(d + 2, b2); atomicAdd(d + 3, b3);
-            }
+            if (a < nb1 && sub == 0) reinterpret_cast<float4*>(prow + (1 + a) * 64)[g] = make_float4(b0, b1, b2, b3);
         }
+    }
+}
+
+// dwq[c] += sum over (row, q head) of slot 0; dwk likewise over the k heads; dbias_x[a][head*64 + c] += sum over rows of
+// slot 1 + a.  One workgroup per 32 output columns, 32 row groups, fixed summation order (deterministic).
+__global__ void __launch_bounds__(32 * COLSUM_RG)
+qknorm_partial_reduce_kernel(const float* __restrict__ partial, int n_rows, int nq, int nkv, int cross, int nb1,
+                             float* __restrict__ dwq, float* __restrict__ dwk, float* __restrict__ dbias_q,
+                             float* __restrict__ dbias_k, float* __restrict__ dbias_v) {
+    __shared__ float sh[COLSUM_RG][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int NH = nq + nkv + (cross ? nkv : 0);
+    const int SL = 1 + (cross ? nb1 : 0);
+    const int64_t row_stride = (int64_t)NH * SL * 64;
+    const int col = blockIdx.x * 32 + cl;            // [0,64): dwq, [64,128): dwk, then bias columns (head, a, c)
+    int h0, h1, slot, c;
+    float* dst;
+    if (col < 64) { h0 = 0; h1 = nq; slot = 0; c = col; dst = dwq + c; }
+    else if (col < 128) { h0 = nq; h1 = nq + nkv; slot = 0; c = col - 64; dst = dwk + c; }
+    else {
+        const int b = col - 128;
+        const int hd = b / (nb1 * 64), a = (b / 64) % nb1;
+        c = b % 64; h0 = hd; h1 = hd + 1; slot = 1 + a;
+        if (hd < nq) dst = dbias_q + (int64_t)a * nq * 64 + hd * 64 + c;
+        else if (hd < nq + nkv) dst = dbias_k + (int64_t)a * nkv * 64 + (hd - nq) * 64 + c;
+        else dst = dbias_v + (int64_t)a * nkv * 64 + (hd - nq - nkv) * 64 + c;
+    }
+    const int nh = h1 - h0;
+    const int64_t n_items = (int64_t)n_rows * nh;     // (row, head) pairs to add up
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    auto at = [&](int64_t it) { return partial[(it / nh) * row_stride + ((int64_t)(h0 + it % nh) * SL + slot) * 64 + c]; };
+    int64_t it = rg;
+    for (; it + 3 * COLSUM_RG < n_items; it += 4 * COLSUM_RG) {
+        s0 += at(it); s1 += at(it + COLSUM_RG); s2 += at(it + 2 * COLSUM_RG); s3 += at(it + 3 * COLSUM_RG);
+    }
+    for (; it < n_items; it += COLSUM_RG) s0 += at(it);
+    sh[rg][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int gi = 0; gi < COLSUM_RG; ++gi) t += sh[gi][cl];
+        *dst += t;
     }
 }
 
@@ -529,12 +596,13 @@ residual_dropout_bwd_kernel(const float4* __restrict__ dx, const int32_t* __rest
     }
 }
 
+template <typename TA>
 __global__ void __launch_bounds__(EW_THREADS)
-swiglu_fwd_kernel(const float4* __restrict__ g, const float4* __restrict__ u, int64_t n4, float p, uint64_t seed,
-                  float4* __restrict__ hm) {
+swiglu_fwd_kernel(const TA* __restrict__ g, const TA* __restrict__ u, int64_t n4, float p, uint64_t seed,
+                  TA* __restrict__ hm) {
     const DropoutRng rng(p, seed);
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
-        const float4 a = g[i], b = u[i];
+        const float4 a = ld4(g + 4 * i), b = ld4(u + 4 * i);
         float m[4];
         rng.mult4((uint32_t)i, m);
         float4 o;
@@ -542,16 +610,17 @@ swiglu_fwd_kernel(const float4* __restrict__ g, const float4* __restrict__ u, in
         o.y = m[1] * (silu_f(a.y) * b.y);
         o.z = m[2] * (silu_f(a.z) * b.z);
         o.w = m[3] * (silu_f(a.w) * b.w);
-        hm[i] = o;
+        st4(hm + 4 * i, o);
     }
 }
 
+template <typename TA>
 __global__ void __launch_bounds__(EW_THREADS)
-swiglu_bwd_kernel(float4* __restrict__ g, float4* __restrict__ u, const float4* __restrict__ dhm, int64_t n4,
+swiglu_bwd_kernel(TA* __restrict__ g, TA* __restrict__ u, const TA* __restrict__ dhm, int64_t n4,
                   float p, uint64_t seed) {
     const DropoutRng rng(p, seed);
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
-        const float4 a = g[i], b = u[i], d = dhm[i];
+        const float4 a = ld4(g + 4 * i), b = ld4(u + 4 * i), d = ld4(dhm + 4 * i);
         float m[4];
         rng.mult4((uint32_t)i, m);
         const float d0 = m[0] * d.x, d1 = m[1] * d.y, d2 = m[2] * d.z, d3 = m[3] * d.w;
@@ -560,19 +629,21 @@ swiglu_bwd_kernel(float4* __restrict__ g, float4* __restrict__ u, const float4* 
         dg.y = d1 * b.y * dsilu_f(a.y); du.y = d1 * silu_f(a.y);
         dg.z = d2 * b.z * dsilu_f(a.z); du.z = d2 * silu_f(a.z);
         dg.w = d3 * b.w * dsilu_f(a.w); du.w = d3 * silu_f(a.w);
-        g[i] = dg;
-        u[i] = du;
+        st4(g + 4 * i, dg);
+        st4(u + 4 * i, du);
     }
 }
 
+// TO = type of `out`: the residual stream (fp32) when resid is given, otherwise the activation type
+template <typename TA, typename TO>
 __global__ void __launch_bounds__(EW_THREADS)
-silu_gate_fwd_kernel(const float4* __restrict__ a, const float4* __restrict__ gate, int64_t n4,
-                     float4* __restrict__ out, const float4* __restrict__ resid, float p, uint64_t seed) {
+silu_gate_fwd_kernel(const TA* __restrict__ a, const TA* __restrict__ gate, int64_t n4,
+                     TO* __restrict__ out, const float4* __restrict__ resid, float p, uint64_t seed) {
     // resid != nullptr: out = resid + dropout(a * silu(gate)) - the residual add of the cross-attention block fused
     // in (same mask as gamer_residual_dropout_fwd with this seed: element index -> mult4)
     const DropoutRng rng(resid ? p : 0.f, seed);
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
-        const float4 x = a[i], g = gate[i];
+        const float4 x = ld4(a + 4 * i), g = ld4(gate + 4 * i);
         float4 o;
         o.x = x.x * silu_f(g.x); o.y = x.y * silu_f(g.y); o.z = x.z * silu_f(g.z); o.w = x.w * silu_f(g.w);
         if (resid) {
@@ -581,17 +652,18 @@ silu_gate_fwd_kernel(const float4* __restrict__ a, const float4* __restrict__ ga
             rng.mult4((uint32_t)i, m);
             o.x = r.x + m[0] * o.x; o.y = r.y + m[1] * o.y; o.z = r.z + m[2] * o.z; o.w = r.w + m[3] * o.w;
         }
-        out[i] = o;
+        st4(out + 4 * i, o);
     }
 }
 
+template <typename TA>
 __global__ void __launch_bounds__(EW_THREADS)
-silu_gate_bwd_kernel(const float4* __restrict__ a, const float4* __restrict__ gate, const float4* __restrict__ dout,
-                     int64_t n4, float4* __restrict__ da, float4* __restrict__ dgate, float p, uint64_t seed) {
+silu_gate_bwd_kernel(const TA* __restrict__ a, const TA* __restrict__ gate, const float4* __restrict__ dout,
+                     int64_t n4, TA* __restrict__ da, TA* __restrict__ dgate, float p, uint64_t seed) {
     // p > 0: dout is the gradient of the residual stream; the dropout mask of the fused forward is applied first
     const DropoutRng rng(p, seed);
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
-        const float4 x = a[i], g = gate[i];
+        const float4 x = ld4(a + 4 * i), g = ld4(gate + 4 * i);
         float4 d = dout[i];
         float m[4];
         rng.mult4((uint32_t)i, m);
@@ -601,23 +673,25 @@ silu_gate_bwd_kernel(const float4* __restrict__ a, const float4* __restrict__ ga
         oa.y = d.y * silu_f(g.y); og.y = d.y * x.y * dsilu_f(g.y);
         oa.z = d.z * silu_f(g.z); og.z = d.z * x.z * dsilu_f(g.z);
         oa.w = d.w * silu_f(g.w); og.w = d.w * x.w * dsilu_f(g.w);
-        da[i] = oa;
-        dgate[i] = og;
+        st4(da + 4 * i, oa);
+        st4(dgate + 4 * i, og);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// temperature + shifted cross entropy; one wave per row of logits
+// temperature + shifted cross entropy; one wave per row of logits (TL = fp32, or bf16 as the reference's autocast
+// lm_head produces them; the statistics are fp32 either way, loss_utils.py upcasts)
 // ---------------------------------------------------------------------------------------------
 constexpr int CE_MAXC = 20;              // register-resident rows up to V = 1280 (the shipped vocabulary is 1041)
+template <typename TL>
 __global__ void __launch_bounds__(EW_THREADS)
-ce_fwd_kernel(float* __restrict__ logits, int ldl, const int64_t* __restrict__ labels, int T, int S, int V,
+ce_fwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labels, int T, int S, int V,
               float inv_temp, int ignore_index, float* __restrict__ lse_out, float* __restrict__ row_loss) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * EW_THREADS) >> 6;
     for (int t = wave; t < T; t += nwaves) {
-        float* row = logits + (int64_t)t * ldl;
+        TL* row = logits + (int64_t)t * ldl;
         const int s = t % S;
         const int64_t tgt = (s + 1 < S) ? labels[t + 1] : (int64_t)ignore_index;
         const bool valid = tgt != ignore_index && tgt >= 0 && tgt < V;
@@ -629,12 +703,12 @@ ce_fwd_kernel(float* __restrict__ logits, int ldl, const int64_t* __restrict__ l
 #pragma unroll
             for (int i = 0; i < CE_MAXC; ++i) {
                 const int c = lane + 64 * i;
-                z[i] = c < V ? row[c] * inv_temp : -INFINITY;
+                z[i] = c < V ? round_as<TL>(ld1(row + c) * inv_temp) : -INFINITY;
             }
 #pragma unroll
             for (int i = 0; i < CE_MAXC; ++i) {
                 const int c = lane + 64 * i;
-                if (c < V) row[c] = z[i];
+                if (c < V) st1(row + c, z[i]);
                 mx = fmaxf(mx, z[i]);
                 if (valid && c == (int)tgt) zt = z[i];
             }
@@ -652,15 +726,15 @@ ce_fwd_kernel(float* __restrict__ logits, int ldl, const int64_t* __restrict__ l
             continue;
         }
         for (int c = lane; c < V; c += 64) {
-            const float z = row[c] * inv_temp;
-            row[c] = z;
+            const float z = round_as<TL>(ld1(row + c) * inv_temp);
+            st1(row + c, z);
             mx = fmaxf(mx, z);
             if (valid && c == (int)tgt) zt = z;
         }
         mx = wave_max(mx);
         zt = wave_sum(zt);
         float se = 0.f;
-        for (int c = lane; c < V; c += 64) se += expf(row[c] - mx);
+        for (int c = lane; c < V; c += 64) se += expf(ld1(row + c) - mx);
         se = wave_sum(se);
         const float lse = mx + logf(se);
         if (lane == 0) {
@@ -719,8 +793,9 @@ ce_reduce_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__
     }
 }
 
+template <typename TL>
 __global__ void __launch_bounds__(EW_THREADS)
-ce_bwd_kernel(float* __restrict__ logits, int ldl, const int64_t* __restrict__ labels, int T, int S, int V,
+ce_bwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labels, int T, int S, int V,
               int ignore_index, const float* __restrict__ lse, const float* __restrict__ count_dev,
               float denom_host, float dloss_over_temp) {
     const int lane = threadIdx.x & 63;
@@ -729,7 +804,7 @@ ce_bwd_kernel(float* __restrict__ logits, int ldl, const int64_t* __restrict__ l
     const float denom = count_dev ? count_dev[0] : denom_host;
     const float gs = dloss_over_temp / denom;
     for (int t = wave; t < T; t += nwaves) {
-        float* row = logits + (int64_t)t * ldl;
+        TL* row = logits + (int64_t)t * ldl;
         const int s = t % S;
         const int64_t tgt = (s + 1 < S) ? labels[t + 1] : (int64_t)ignore_index;
         const bool valid = tgt != ignore_index && tgt >= 0 && tgt < V;
@@ -737,11 +812,11 @@ ce_bwd_kernel(float* __restrict__ logits, int ldl, const int64_t* __restrict__ l
         for (int c = lane; c < V; c += 64) {
             float g = 0.f;
             if (valid) {
-                g = expf(row[c] - l);
+                g = expf(ld1(row + c) - l);
                 if (c == (int)tgt) g -= 1.f;
                 g *= gs;
             }
-            row[c] = g;
+            st1(row + c, g);
         }
     }
 }
@@ -779,32 +854,57 @@ extern "C" int gamer_embedding_bwd(const int64_t* ids, const float* dx, int V, i
     return 0;
 }
 
-extern "C" int gamer_rmsnorm_fwd(const float* x, const float* w, int T, int H, float eps, const int32_t* dst_rows,
-                                 float* y, int ldy, void* stream) {
-    GAMER_CHECK_ARG(x && w && y, "gamer_rmsnorm_fwd: null pointer");
+template <typename TY>
+static int rmsnorm_fwd_impl(const char* name, const float* x, const float* w, int T, int H, float eps,
+                            const int32_t* dst_rows, TY* y, int ldy, void* stream) {
+    GAMER_CHECK_ARG(x && w && y, "%s: null pointer", name);
     GAMER_CHECK_ARG(T > 0 && H > 0 && H % 4 == 0 && H <= 256 * RMS_MAXC && ldy >= H && ldy % 4 == 0,
-                    "gamer_rmsnorm_fwd: bad shape T=%d H=%d ldy=%d (H%%4==0, H<=1024, ldy%%4==0)", T, H, ldy);
-    GAMER_CHECK_ARG(aligned16(x) && aligned16(w) && aligned16(y), "gamer_rmsnorm_fwd: pointers must be 16-byte aligned");
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream),
+                    "%s: bad shape T=%d H=%d ldy=%d (H%%4==0, H<=1024, ldy%%4==0)", name, T, H, ldy);
+    GAMER_CHECK_ARG(aligned16(x) && aligned16(w) && aligned_vec4<TY>(y), "%s: pointers must be 16-byte aligned", name);
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel<TY>, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream),
                        (const float4*)x, (const float4*)w, T, H / 4, 1.f / (float)H, eps, dst_rows, y, ldy);
-    GAMER_CHECK_LAUNCH("gamer_rmsnorm_fwd");
+    GAMER_CHECK_LAUNCH(name);
     return 0;
 }
+extern "C" int gamer_rmsnorm_fwd(const float* x, const float* w, int T, int H, float eps, const int32_t* dst_rows,
+                                 float* y, int ldy, void* stream) {
+    return rmsnorm_fwd_impl<float>("gamer_rmsnorm_fwd", x, w, T, H, eps, dst_rows, y, ldy, stream);
+}
+extern "C" int gamer_rmsnorm_fwd_bf16(const float* x, const float* w, int T, int H, float eps, const int32_t* dst_rows,
+                                      gamer_bf16* y, int ldy, void* stream) {
+    return rmsnorm_fwd_impl<bf16_t>("gamer_rmsnorm_fwd_bf16", x, w, T, H, eps, dst_rows, (bf16_t*)y, ldy, stream);
+}
 
+template <typename TG>
+static int rmsnorm_bwd_impl(const char* name, const float* x, const float* w, const TG* dy, int lddy,
+                            const int32_t* dy_rows, int T, int H, float eps, int accumulate_dx, float* dx,
+                            float* dw_partial, int n_partial, TG* mask_out, const int32_t* mask_rows, float p_drop,
+                            uint64_t seed, void* stream) {
+    GAMER_CHECK_ARG(x && w && dy && dx && dw_partial, "%s: null pointer", name);
+    GAMER_CHECK_ARG(T > 0 && H > 0 && H % 4 == 0 && H <= 256 * RMS_MAXC && lddy >= H && lddy % 4 == 0 && n_partial > 0,
+                    "%s: bad shape T=%d H=%d lddy=%d n_partial=%d", name, T, H, lddy, n_partial);
+    GAMER_CHECK_ARG(aligned16(x) && aligned16(w) && aligned_vec4<TG>(dy) && aligned16(dx) && aligned16(dw_partial) &&
+                    aligned_vec4<TG>(mask_out), "%s: pointers must be 16-byte aligned", name);
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<TG>, dim3(n_partial), dim3(EW_THREADS), 0, ST(stream),
+                       (const float4*)x, (const float4*)w, dy, lddy, dy_rows, T, H / 4, 1.f / (float)H, eps,
+                       accumulate_dx, (float4*)dx, dw_partial, mask_out, mask_rows, p_drop, seed);
+    GAMER_CHECK_LAUNCH(name);
+    return 0;
+}
 extern "C" int gamer_rmsnorm_bwd(const float* x, const float* w, const float* dy, int lddy, const int32_t* dy_rows,
                                  int T, int H, float eps, int accumulate_dx, float* dx, float* dw_partial,
                                  int n_partial, float* mask_out, const int32_t* mask_rows, float p_drop,
                                  uint64_t seed, void* stream) {
-    GAMER_CHECK_ARG(x && w && dy && dx && dw_partial, "gamer_rmsnorm_bwd: null pointer");
-    GAMER_CHECK_ARG(T > 0 && H > 0 && H % 4 == 0 && H <= 256 * RMS_MAXC && lddy >= H && lddy % 4 == 0 && n_partial > 0,
-                    "gamer_rmsnorm_bwd: bad shape T=%d H=%d lddy=%d n_partial=%d", T, H, lddy, n_partial);
-    GAMER_CHECK_ARG(aligned16(x) && aligned16(w) && aligned16(dy) && aligned16(dx) && aligned16(dw_partial),
-                    "gamer_rmsnorm_bwd: pointers must be 16-byte aligned");
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(n_partial), dim3(EW_THREADS), 0, ST(stream),
-                       (const float4*)x, (const float4*)w, dy, lddy, dy_rows, T, H / 4, 1.f / (float)H, eps,
-                       accumulate_dx, (float4*)dx, dw_partial, (float4*)mask_out, mask_rows, p_drop, seed);
-    GAMER_CHECK_LAUNCH("gamer_rmsnorm_bwd");
-    return 0;
+    return rmsnorm_bwd_impl<float>("gamer_rmsnorm_bwd", x, w, dy, lddy, dy_rows, T, H, eps, accumulate_dx, dx, dw_partial,
+                                   n_partial, mask_out, mask_rows, p_drop, seed, stream);
+}
+extern "C" int gamer_rmsnorm_bwd_bf16(const float* x, const float* w, const gamer_bf16* dy, int lddy,
+                                      const int32_t* dy_rows, int T, int H, float eps, int accumulate_dx, float* dx,
+                                      float* dw_partial, int n_partial, gamer_bf16* mask_out, const int32_t* mask_rows,
+                                      float p_drop, uint64_t seed, void* stream) {
+    return rmsnorm_bwd_impl<bf16_t>("gamer_rmsnorm_bwd_bf16", x, w, (const bf16_t*)dy, lddy, dy_rows, T, H, eps,
+                                    accumulate_dx, dx, dw_partial, n_partial, (bf16_t*)mask_out, mask_rows, p_drop, seed,
+                                    stream);
 }
 
 extern "C" int gamer_colsum_reduce(const float* partial, int rows, int cols, int accumulate, float* out, void* stream) {
@@ -815,71 +915,139 @@ extern "C" int gamer_colsum_reduce(const float* partial, int rows, int cols, int
     return 0;
 }
 
-extern "C" int gamer_rowtable_fwd(const float* table, const int32_t* idx, const int32_t* dst_rows, int T, int E,
-                                  float* y, int ldy, int col0, void* stream) {
-    GAMER_CHECK_ARG(table && idx && y, "gamer_rowtable_fwd: null pointer");
+template <typename TY>
+static int rowtable_fwd_impl(const char* name, const float* table, const int32_t* idx, const int32_t* dst_rows, int T,
+                             int E, TY* y, int ldy, int col0, void* stream) {
+    GAMER_CHECK_ARG(table && idx && y, "%s: null pointer", name);
     GAMER_CHECK_ARG(T > 0 && E > 0 && E % 4 == 0 && ldy % 4 == 0 && col0 % 4 == 0 && col0 + E <= ldy,
-                    "gamer_rowtable_fwd: bad shape T=%d E=%d ldy=%d col0=%d", T, E, ldy, col0);
-    hipLaunchKernelGGL(rowtable_fwd_kernel, dim3(grid_for_threads((int64_t)T * E / 4)), dim3(EW_THREADS), 0, ST(stream),
-                       (const float4*)table, idx, dst_rows, T, E / 4, y, ldy, col0);
-    GAMER_CHECK_LAUNCH("gamer_rowtable_fwd");
+                    "%s: bad shape T=%d E=%d ldy=%d col0=%d", name, T, E, ldy, col0);
+    hipLaunchKernelGGL(rowtable_fwd_kernel<TY>, dim3(grid_for_threads((int64_t)T * E / 4)), dim3(EW_THREADS), 0,
+                       ST(stream), (const float4*)table, idx, dst_rows, T, E / 4, y, ldy, col0);
+    GAMER_CHECK_LAUNCH(name);
     return 0;
 }
+extern "C" int gamer_rowtable_fwd(const float* table, const int32_t* idx, const int32_t* dst_rows, int T, int E,
+                                  float* y, int ldy, int col0, void* stream) {
+    return rowtable_fwd_impl<float>("gamer_rowtable_fwd", table, idx, dst_rows, T, E, y, ldy, col0, stream);
+}
+extern "C" int gamer_rowtable_fwd_bf16(const float* table, const int32_t* idx, const int32_t* dst_rows, int T, int E,
+                                       gamer_bf16* y, int ldy, int col0, void* stream) {
+    return rowtable_fwd_impl<bf16_t>("gamer_rowtable_fwd_bf16", table, idx, dst_rows, T, E, (bf16_t*)y, ldy, col0, stream);
+}
 
-extern "C" int gamer_rowtable_bwd(const float* dy, int lddy, int col0, const int32_t* idx, const int32_t* dy_rows,
-                                  int T, int E, int n_rows_table, float* dtable, void* stream) {
-    GAMER_CHECK_ARG(dy && idx && dtable, "gamer_rowtable_bwd: null pointer");
+template <typename TG>
+static int rowtable_bwd_impl(const char* name, const TG* dy, int lddy, int col0, const int32_t* idx,
+                             const int32_t* dy_rows, int T, int E, int n_rows_table, float* dtable, void* stream) {
+    GAMER_CHECK_ARG(dy && idx && dtable, "%s: null pointer", name);
     GAMER_CHECK_ARG(T > 0 && E > 0 && E % 4 == 0 && E / 4 <= EW_THREADS && lddy % 4 == 0 && col0 % 4 == 0 &&
                     n_rows_table > 0 && n_rows_table <= TBL_MAXROWS,
-                    "gamer_rowtable_bwd: bad shape T=%d E=%d lddy=%d col0=%d rows=%d (rows<=8)", T, E, lddy, col0, n_rows_table);
+                    "%s: bad shape T=%d E=%d lddy=%d col0=%d rows=%d (rows<=8)", name, T, E, lddy, col0, n_rows_table);
     const int rows_per_block = EW_THREADS / (E / 4);
     int blocks = (T + rows_per_block - 1) / rows_per_block;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(rowtable_bwd_kernel, dim3(blocks), dim3(EW_THREADS), (size_t)n_rows_table * E * sizeof(float),
+    hipLaunchKernelGGL(rowtable_bwd_kernel<TG>, dim3(blocks), dim3(EW_THREADS), (size_t)n_rows_table * E * sizeof(float),
                        ST(stream), dy, lddy, col0, idx, dy_rows, T, E / 4, n_rows_table, dtable);
-    GAMER_CHECK_LAUNCH("gamer_rowtable_bwd");
+    GAMER_CHECK_LAUNCH(name);
     return 0;
 }
+extern "C" int gamer_rowtable_bwd(const float* dy, int lddy, int col0, const int32_t* idx, const int32_t* dy_rows,
+                                  int T, int E, int n_rows_table, float* dtable, void* stream) {
+    return rowtable_bwd_impl<float>("gamer_rowtable_bwd", dy, lddy, col0, idx, dy_rows, T, E, n_rows_table, dtable, stream);
+}
+extern "C" int gamer_rowtable_bwd_bf16(const gamer_bf16* dy, int lddy, int col0, const int32_t* idx,
+                                       const int32_t* dy_rows, int T, int E, int n_rows_table, float* dtable,
+                                       void* stream) {
+    return rowtable_bwd_impl<bf16_t>("gamer_rowtable_bwd_bf16", (const bf16_t*)dy, lddy, col0, idx, dy_rows, T, E,
+                                     n_rows_table, dtable, stream);
+}
 
+template <typename TA>
+static int qknorm_rope_fwd_impl(const char* name, TA* qkv, int T, int S, int nq, int nkv, const float* wq,
+                                const float* wk, float eps, const float* cos_t, const float* sin_t, const float* bias_q,
+                                const float* bias_k, const float* bias_v, const int32_t* act_idx, TA* q_rot, TA* k_rot,
+                                const int32_t* pos_ids, void* stream) {
+    GAMER_CHECK_ARG(qkv && wq && wk && cos_t && sin_t && q_rot && k_rot, "%s: null pointer", name);
+    GAMER_CHECK_ARG(T > 0 && S > 0 && nq > 0 && nkv > 0 && T % S == 0, "%s: bad shape T=%d S=%d nq=%d nkv=%d", name, T, S, nq, nkv);
+    const bool cross = bias_q != nullptr;
+    GAMER_CHECK_ARG(!cross || (bias_k && bias_v && act_idx), "%s: cross needs bias_k, bias_v, act_idx", name);
+    const int NH = nq + nkv + (cross ? nkv : 0);
+    hipLaunchKernelGGL(qknorm_rope_fwd_kernel<TA>, dim3(grid_for_waves(((int64_t)T * NH + 3) / 4)), dim3(EW_THREADS), 0,
+                       ST(stream), qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot,
+                       k_rot, pos_ids);
+    GAMER_CHECK_LAUNCH(name);
+    return 0;
+}
 extern "C" int gamer_qknorm_rope_fwd(float* qkv, int T, int S, int nq, int nkv, const float* wq, const float* wk,
                                      float eps, const float* cos_t, const float* sin_t, const float* bias_q,
                                      const float* bias_k, const float* bias_v, const int32_t* act_idx, float* q_rot,
                                      float* k_rot, const int32_t* pos_ids, void* stream) {
-    GAMER_CHECK_ARG(qkv && wq && wk && cos_t && sin_t && q_rot && k_rot, "gamer_qknorm_rope_fwd: null pointer");
-    GAMER_CHECK_ARG(T > 0 && S > 0 && nq > 0 && nkv > 0 && T % S == 0, "gamer_qknorm_rope_fwd: bad shape T=%d S=%d nq=%d nkv=%d", T, S, nq, nkv);
-    const bool cross = bias_q != nullptr;
-    GAMER_CHECK_ARG(!cross || (bias_k && bias_v && act_idx), "gamer_qknorm_rope_fwd: cross needs bias_k, bias_v, act_idx");
-    const int NH = nq + nkv + (cross ? nkv : 0);
-    hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3(grid_for_waves(((int64_t)T * NH + 3) / 4)), dim3(EW_THREADS), 0, ST(stream),
-                       qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot, k_rot, pos_ids);
-    GAMER_CHECK_LAUNCH("gamer_qknorm_rope_fwd");
-    return 0;
+    return qknorm_rope_fwd_impl<float>("gamer_qknorm_rope_fwd", qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q,
+                                       bias_k, bias_v, act_idx, q_rot, k_rot, pos_ids, stream);
+}
+extern "C" int gamer_qknorm_rope_fwd_bf16(gamer_bf16* qkv, int T, int S, int nq, int nkv, const float* wq,
+                                          const float* wk, float eps, const float* cos_t, const float* sin_t,
+                                          const float* bias_q, const float* bias_k, const float* bias_v,
+                                          const int32_t* act_idx, gamer_bf16* q_rot, gamer_bf16* k_rot,
+                                          const int32_t* pos_ids, void* stream) {
+    return qknorm_rope_fwd_impl<bf16_t>("gamer_qknorm_rope_fwd_bf16", (bf16_t*)qkv, T, S, nq, nkv, wq, wk, eps, cos_t,
+                                        sin_t, bias_q, bias_k, bias_v, act_idx, (bf16_t*)q_rot, (bf16_t*)k_rot, pos_ids,
+                                        stream);
 }
 
+template <typename TA>
+static int qknorm_rope_bwd_impl(const char* name, const TA* qkv, const TA* dq_rot, const TA* dk_rot, int T, int S,
+                                int nq, int nkv, const float* wq, const float* wk, float eps, const float* cos_t,
+                                const float* sin_t, const float* bias_q, const float* bias_k, const int32_t* act_idx,
+                                int nb1, TA* dqkv, float* dwq, float* dwk, float* dbias_q, float* dbias_k,
+                                float* dbias_v, const int32_t* pos_ids, float* partial, int64_t partial_numel,
+                                void* stream) {
+    GAMER_CHECK_ARG(qkv && dq_rot && dk_rot && wq && wk && cos_t && sin_t && dqkv && dwq && dwk && partial,
+                    "%s: null pointer", name);
+    GAMER_CHECK_ARG(T > 0 && S > 0 && nq > 0 && nkv > 0 && T % S == 0, "%s: bad shape", name);
+    const int cross = bias_q != nullptr ? 1 : 0;
+    GAMER_CHECK_ARG(!cross || (bias_k && act_idx && dbias_q && dbias_k && dbias_v && nb1 > 0 && nb1 <= TBL_MAXROWS),
+                    "%s: cross needs bias_k, act_idx, dbias_*, 0<nb1<=8 (nb1=%d)", name, nb1);
+    const int NH = nq + nkv + (cross ? nkv : 0);
+    const int SL = 1 + (cross ? nb1 : 0);
+    int waves_per_head = 8192 / NH;
+    if (waves_per_head > (T + 3) / 4) waves_per_head = (T + 3) / 4;
+    const int64_t cap = partial_numel / ((int64_t)NH * SL * 64);
+    if (waves_per_head > cap) waves_per_head = (int)cap;
+    GAMER_CHECK_ARG(waves_per_head >= 1 && aligned16(partial),
+                    "%s: partial needs at least %d floats, 16-byte aligned (got %lld)", name, NH * SL * 64,
+                    (long long)partial_numel);
+    const int64_t total_waves = (int64_t)NH * waves_per_head;
+    const int blocks = (int)((total_waves + EW_WAVES - 1) / EW_WAVES);
+    hipLaunchKernelGGL(qknorm_rope_bwd_kernel<TA>, dim3(blocks), dim3(EW_THREADS), 0, ST(stream), qkv, dq_rot, dk_rot, T,
+                       S, nq, nkv, wq, wk, eps, cos_t, sin_t, cross, bias_q, bias_k, act_idx, nb1, dqkv, partial,
+                       waves_per_head, pos_ids);
+    GAMER_CHECK_LAUNCH(name);
+    const int cols = 128 + (cross ? NH * nb1 * 64 : 0);
+    hipLaunchKernelGGL(qknorm_partial_reduce_kernel, dim3(cols / 32), dim3(32 * COLSUM_RG), 0, ST(stream), partial,
+                       waves_per_head, nq, nkv, cross, nb1, dwq, dwk, dbias_q, dbias_k, dbias_v);
+    GAMER_CHECK_LAUNCH(name);
+    return 0;
+}
 extern "C" int gamer_qknorm_rope_bwd(const float* qkv, const float* dq_rot, const float* dk_rot, int T, int S, int nq,
                                      int nkv, const float* wq, const float* wk, float eps, const float* cos_t,
                                      const float* sin_t, const float* bias_q, const float* bias_k,
                                      const int32_t* act_idx, int nb1, float* dqkv, float* dwq, float* dwk,
                                      float* dbias_q, float* dbias_k, float* dbias_v, const int32_t* pos_ids,
-                                     void* stream) {
-    GAMER_CHECK_ARG(qkv && dq_rot && dk_rot && wq && wk && cos_t && sin_t && dqkv && dwq && dwk,
-                    "gamer_qknorm_rope_bwd: null pointer");
-    GAMER_CHECK_ARG(T > 0 && S > 0 && nq > 0 && nkv > 0 && T % S == 0, "gamer_qknorm_rope_bwd: bad shape");
-    const int cross = bias_q != nullptr ? 1 : 0;
-    (void)bias_k;
-    GAMER_CHECK_ARG(!cross || (act_idx && dbias_q && dbias_k && dbias_v && nb1 > 0 && nb1 <= TBL_MAXROWS),
-                    "gamer_qknorm_rope_bwd: cross needs act_idx, dbias_*, 0<nb1<=8 (nb1=%d)", nb1);
-    const int NH = nq + nkv + (cross ? nkv : 0);
-    int waves_per_head = 8192 / NH;
-    if (waves_per_head > (T + 3) / 4) waves_per_head = (T + 3) / 4;
-    if (waves_per_head < 1) waves_per_head = 1;
-    const int64_t total_waves = (int64_t)NH * waves_per_head;
-    const int blocks = (int)((total_waves + EW_WAVES - 1) / EW_WAVES);
-    hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3(blocks), dim3(EW_THREADS), 0, ST(stream), qkv, dq_rot, dk_rot, T, S,
-                       nq, nkv, wq, wk, eps, cos_t, sin_t, cross, act_idx, nb1, dqkv, dwq, dwk, dbias_q, dbias_k,
-                       dbias_v, waves_per_head, pos_ids);
-    GAMER_CHECK_LAUNCH("gamer_qknorm_rope_bwd");
-    return 0;
+                                     float* partial, int64_t partial_numel, void* stream) {
+    return qknorm_rope_bwd_impl<float>("gamer_qknorm_rope_bwd", qkv, dq_rot, dk_rot, T, S, nq, nkv, wq, wk, eps, cos_t,
+                                       sin_t, bias_q, bias_k, act_idx, nb1, dqkv, dwq, dwk, dbias_q, dbias_k, dbias_v,
+                                       pos_ids, partial, partial_numel, stream);
+}
+extern "C" int gamer_qknorm_rope_bwd_bf16(const gamer_bf16* qkv, const gamer_bf16* dq_rot, const gamer_bf16* dk_rot,
+                                          int T, int S, int nq, int nkv, const float* wq, const float* wk, float eps,
+                                          const float* cos_t, const float* sin_t, const float* bias_q,
+                                          const float* bias_k, const int32_t* act_idx, int nb1, gamer_bf16* dqkv,
+                                          float* dwq, float* dwk, float* dbias_q, float* dbias_k, float* dbias_v,
+                                          const int32_t* pos_ids, float* partial, int64_t partial_numel, void* stream) {
+    return qknorm_rope_bwd_impl<bf16_t>("gamer_qknorm_rope_bwd_bf16", (const bf16_t*)qkv, (const bf16_t*)dq_rot,
+                                        (const bf16_t*)dk_rot, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k,
+                                        act_idx, nb1, (bf16_t*)dqkv, dwq, dwk, dbias_q, dbias_k, dbias_v, pos_ids,
+                                        partial, partial_numel, stream);
 }
 
 extern "C" int gamer_residual_dropout_fwd(const float* x_in, const float* delta, const int32_t* src_rows, int T, int H,
@@ -903,70 +1071,134 @@ extern "C" int gamer_residual_dropout_bwd(const float* dx, const int32_t* src_ro
     return 0;
 }
 
-extern "C" int gamer_swiglu_fwd(const float* g, const float* u, int64_t n, float p_drop, uint64_t seed, float* hm,
-                                void* stream) {
-    GAMER_CHECK_ARG(g && u && hm && n > 0 && n % 4 == 0 && p_drop >= 0.f && p_drop < 1.f, "gamer_swiglu_fwd: bad arguments");
-    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream),
-                       (const float4*)g, (const float4*)u, n / 4, p_drop, seed, (float4*)hm);
-    GAMER_CHECK_LAUNCH("gamer_swiglu_fwd");
+template <typename TA>
+static int swiglu_fwd_impl(const char* name, const TA* g, const TA* u, int64_t n, float p_drop, uint64_t seed, TA* hm,
+                           void* stream) {
+    GAMER_CHECK_ARG(g && u && hm && n > 0 && n % 4 == 0 && p_drop >= 0.f && p_drop < 1.f, "%s: bad arguments", name);
+    hipLaunchKernelGGL(swiglu_fwd_kernel<TA>, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream), g, u, n / 4,
+                       p_drop, seed, hm);
+    GAMER_CHECK_LAUNCH(name);
     return 0;
 }
+extern "C" int gamer_swiglu_fwd(const float* g, const float* u, int64_t n, float p_drop, uint64_t seed, float* hm,
+                                void* stream) {
+    return swiglu_fwd_impl<float>("gamer_swiglu_fwd", g, u, n, p_drop, seed, hm, stream);
+}
+extern "C" int gamer_swiglu_fwd_bf16(const gamer_bf16* g, const gamer_bf16* u, int64_t n, float p_drop, uint64_t seed,
+                                     gamer_bf16* hm, void* stream) {
+    return swiglu_fwd_impl<bf16_t>("gamer_swiglu_fwd_bf16", (const bf16_t*)g, (const bf16_t*)u, n, p_drop, seed,
+                                   (bf16_t*)hm, stream);
+}
 
+template <typename TA>
+static int swiglu_bwd_impl(const char* name, TA* g, TA* u, const TA* dhm, int64_t n, float p_drop, uint64_t seed,
+                           void* stream) {
+    GAMER_CHECK_ARG(g && u && dhm && n > 0 && n % 4 == 0 && p_drop >= 0.f && p_drop < 1.f, "%s: bad arguments", name);
+    hipLaunchKernelGGL(swiglu_bwd_kernel<TA>, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream), g, u, dhm,
+                       n / 4, p_drop, seed);
+    GAMER_CHECK_LAUNCH(name);
+    return 0;
+}
 extern "C" int gamer_swiglu_bwd(float* g, float* u, const float* dhm, int64_t n, float p_drop, uint64_t seed,
                                 void* stream) {
-    GAMER_CHECK_ARG(g && u && dhm && n > 0 && n % 4 == 0 && p_drop >= 0.f && p_drop < 1.f, "gamer_swiglu_bwd: bad arguments");
-    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream), (float4*)g,
-                       (float4*)u, (const float4*)dhm, n / 4, p_drop, seed);
-    GAMER_CHECK_LAUNCH("gamer_swiglu_bwd");
-    return 0;
+    return swiglu_bwd_impl<float>("gamer_swiglu_bwd", g, u, dhm, n, p_drop, seed, stream);
+}
+extern "C" int gamer_swiglu_bwd_bf16(gamer_bf16* g, gamer_bf16* u, const gamer_bf16* dhm, int64_t n, float p_drop,
+                                     uint64_t seed, void* stream) {
+    return swiglu_bwd_impl<bf16_t>("gamer_swiglu_bwd_bf16", (bf16_t*)g, (bf16_t*)u, (const bf16_t*)dhm, n, p_drop, seed,
+                                   stream);
 }
 
 extern "C" int gamer_silu_gate_fwd(const float* a, const float* gate, int64_t n, float* out, const float* resid,
                                    float p_drop, uint64_t seed, void* stream) {
     GAMER_CHECK_ARG(a && gate && out && n > 0 && n % 4 == 0 && p_drop >= 0.f && p_drop < 1.f, "gamer_silu_gate_fwd: bad arguments");
-    hipLaunchKernelGGL(silu_gate_fwd_kernel, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream),
-                       (const float4*)a, (const float4*)gate, n / 4, (float4*)out, (const float4*)resid, p_drop, seed);
+    hipLaunchKernelGGL((silu_gate_fwd_kernel<float, float>), dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream),
+                       a, gate, n / 4, out, (const float4*)resid, p_drop, seed);
     GAMER_CHECK_LAUNCH("gamer_silu_gate_fwd");
     return 0;
 }
-
-extern "C" int gamer_silu_gate_bwd(const float* a, const float* gate, const float* dout, int64_t n, float* da,
-                                   float* dgate, float p_drop, uint64_t seed, void* stream) {
-    GAMER_CHECK_ARG(a && gate && dout && da && dgate && n > 0 && n % 4 == 0 && p_drop >= 0.f && p_drop < 1.f,
-                    "gamer_silu_gate_bwd: bad arguments");
-    hipLaunchKernelGGL(silu_gate_bwd_kernel, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream),
-                       (const float4*)a, (const float4*)gate, (const float4*)dout, n / 4, (float4*)da, (float4*)dgate,
-                       p_drop, seed);
-    GAMER_CHECK_LAUNCH("gamer_silu_gate_bwd");
+extern "C" int gamer_silu_gate_fwd_bf16(const gamer_bf16* a, const gamer_bf16* gate, int64_t n, float* out,
+                                        const float* resid, float p_drop, uint64_t seed, void* stream) {
+    GAMER_CHECK_ARG(a && gate && out && resid && n > 0 && n % 4 == 0 && p_drop >= 0.f && p_drop < 1.f,
+                    "gamer_silu_gate_fwd_bf16: bad arguments (resid is required: out is the fp32 residual stream)");
+    hipLaunchKernelGGL((silu_gate_fwd_kernel<bf16_t, float>), dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream),
+                       (const bf16_t*)a, (const bf16_t*)gate, n / 4, out, (const float4*)resid, p_drop, seed);
+    GAMER_CHECK_LAUNCH("gamer_silu_gate_fwd_bf16");
     return 0;
 }
 
+template <typename TA>
+static int silu_gate_bwd_impl(const char* name, const TA* a, const TA* gate, const float* dout, int64_t n, TA* da,
+                              TA* dgate, float p_drop, uint64_t seed, void* stream) {
+    GAMER_CHECK_ARG(a && gate && dout && da && dgate && n > 0 && n % 4 == 0 && p_drop >= 0.f && p_drop < 1.f,
+                    "%s: bad arguments", name);
+    hipLaunchKernelGGL(silu_gate_bwd_kernel<TA>, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream), a, gate,
+                       (const float4*)dout, n / 4, da, dgate, p_drop, seed);
+    GAMER_CHECK_LAUNCH(name);
+    return 0;
+}
+extern "C" int gamer_silu_gate_bwd(const float* a, const float* gate, const float* dout, int64_t n, float* da,
+                                   float* dgate, float p_drop, uint64_t seed, void* stream) {
+    return silu_gate_bwd_impl<float>("gamer_silu_gate_bwd", a, gate, dout, n, da, dgate, p_drop, seed, stream);
+}
+extern "C" int gamer_silu_gate_bwd_bf16(const gamer_bf16* a, const gamer_bf16* gate, const float* dout, int64_t n,
+                                        gamer_bf16* da, gamer_bf16* dgate, float p_drop, uint64_t seed, void* stream) {
+    return silu_gate_bwd_impl<bf16_t>("gamer_silu_gate_bwd_bf16", (const bf16_t*)a, (const bf16_t*)gate, dout, n,
+                                      (bf16_t*)da, (bf16_t*)dgate, p_drop, seed, stream);
+}
+
+template <typename TL>
+static int ce_fwd_impl(const char* name, TL* logits, int ldl, const int64_t* labels, int B, int S, int V,
+                       float temperature, int ignore_index, float* lse_out, float* row_loss, float* loss_sum,
+                       float* count, void* stream) {
+    GAMER_CHECK_ARG(logits && labels && lse_out && row_loss && loss_sum && count, "%s: null pointer", name);
+    GAMER_CHECK_ARG(B > 0 && S > 0 && V > 0 && ldl >= V && temperature > 0.f, "%s: bad shape B=%d S=%d V=%d ldl=%d", name, B, S, V, ldl);
+    const int T = B * S;
+    hipLaunchKernelGGL(ce_fwd_kernel<TL>, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), logits, ldl, labels, T,
+                       S, V, 1.f / temperature, ignore_index, lse_out, row_loss);
+    GAMER_CHECK_LAUNCH(name);
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, ST(stream), row_loss, labels, T, S, V, ignore_index,
+                       loss_sum, count);
+    GAMER_CHECK_LAUNCH(name);
+    return 0;
+}
 extern "C" int gamer_ce_fwd(float* logits, int ldl, const int64_t* labels, int B, int S, int V, float temperature,
                             int ignore_index, float* lse_out, float* row_loss, float* loss_sum, float* count,
                             void* stream) {
-    GAMER_CHECK_ARG(logits && labels && lse_out && row_loss && loss_sum && count, "gamer_ce_fwd: null pointer");
-    GAMER_CHECK_ARG(B > 0 && S > 0 && V > 0 && ldl >= V && temperature > 0.f, "gamer_ce_fwd: bad shape B=%d S=%d V=%d ldl=%d", B, S, V, ldl);
-    const int T = B * S;
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), logits, ldl, labels, T,
-                       S, V, 1.f / temperature, ignore_index, lse_out, row_loss);
-    GAMER_CHECK_LAUNCH("gamer_ce_fwd");
-    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, ST(stream), row_loss, labels, T, S, V, ignore_index,
-                       loss_sum, count);
-    GAMER_CHECK_LAUNCH("gamer_ce_fwd/reduce");
-    return 0;
+    return ce_fwd_impl<float>("gamer_ce_fwd", logits, ldl, labels, B, S, V, temperature, ignore_index, lse_out, row_loss,
+                              loss_sum, count, stream);
+}
+extern "C" int gamer_ce_fwd_bf16(gamer_bf16* logits, int ldl, const int64_t* labels, int B, int S, int V,
+                                 float temperature, int ignore_index, float* lse_out, float* row_loss, float* loss_sum,
+                                 float* count, void* stream) {
+    return ce_fwd_impl<bf16_t>("gamer_ce_fwd_bf16", (bf16_t*)logits, ldl, labels, B, S, V, temperature, ignore_index,
+                               lse_out, row_loss, loss_sum, count, stream);
 }
 
+template <typename TL>
+static int ce_bwd_impl(const char* name, TL* logits, int ldl, const int64_t* labels, int B, int S, int V,
+                       float temperature, int ignore_index, const float* lse, const float* count_dev, float denom_host,
+                       float dloss, void* stream) {
+    GAMER_CHECK_ARG(logits && labels && lse, "%s: null pointer", name);
+    GAMER_CHECK_ARG(B > 0 && S > 0 && V > 0 && ldl >= V && temperature > 0.f, "%s: bad shape", name);
+    GAMER_CHECK_ARG(count_dev || denom_host > 0.f, "%s: need count_dev or a positive denom_host", name);
+    const int T = B * S;
+    hipLaunchKernelGGL(ce_bwd_kernel<TL>, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), logits, ldl, labels, T,
+                       S, V, ignore_index, lse, count_dev, denom_host, dloss / temperature);
+    GAMER_CHECK_LAUNCH(name);
+    return 0;
+}
 extern "C" int gamer_ce_bwd(float* logits, int ldl, const int64_t* labels, int B, int S, int V, float temperature,
                             int ignore_index, const float* lse, const float* count_dev, float denom_host, float dloss,
                             void* stream) {
-    GAMER_CHECK_ARG(logits && labels && lse, "gamer_ce_bwd: null pointer");
-    GAMER_CHECK_ARG(B > 0 && S > 0 && V > 0 && ldl >= V && temperature > 0.f, "gamer_ce_bwd: bad shape");
-    GAMER_CHECK_ARG(count_dev || denom_host > 0.f, "gamer_ce_bwd: need count_dev or a positive denom_host");
-    const int T = B * S;
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), logits, ldl, labels, T,
-                       S, V, ignore_index, lse, count_dev, denom_host, dloss / temperature);
-    GAMER_CHECK_LAUNCH("gamer_ce_bwd");
-    return 0;
+    return ce_bwd_impl<float>("gamer_ce_bwd", logits, ldl, labels, B, S, V, temperature, ignore_index, lse, count_dev,
+                              denom_host, dloss, stream);
+}
+extern "C" int gamer_ce_bwd_bf16(gamer_bf16* logits, int ldl, const int64_t* labels, int B, int S, int V,
+                                 float temperature, int ignore_index, const float* lse, const float* count_dev,
+                                 float denom_host, float dloss, void* stream) {
+    return ce_bwd_impl<bf16_t>("gamer_ce_bwd_bf16", (bf16_t*)logits, ldl, labels, B, S, V, temperature, ignore_index, lse,
+                               count_dev, denom_host, dloss, stream);
 }
 
 extern "C" int gamer_fill_f32(float* p, int64_t n, float value, void* stream) {

@@ -273,6 +273,21 @@ __global__ void expert_emit_kernel(const int32_t* __restrict__ expert, int S, in
     }
 }
 
+// Labels outside [0, V) that are not ignore_index: torch's CrossEntropyLoss raises on them (a tokenizer / vocab_size
+// mismatch); the CE kernels skip such rows, so they are counted here and the host raises (Engine.check_inputs).
+__global__ void __launch_bounds__(256)
+check_labels_kernel(const int64_t* __restrict__ labels, int64_t n, int V, int ignore_index, int32_t* __restrict__ bad) {
+    int cnt = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t y = labels[i];
+        cnt += (y != ignore_index && (y < 0 || y >= V)) ? 1 : 0;
+    }
+    if (__any(cnt)) {
+        cnt = wave_sum_i32(cnt);
+        if ((threadIdx.x & 63) == 0) atomicAdd(bad, cnt);
+    }
+}
+
 }  // namespace gamer
 
 using namespace gamer;
@@ -336,5 +351,16 @@ extern "C" int gamer_expert_lists(const int32_t* expert, int B, int S, int num_e
     GAMER_CHECK_LAUNCH("gamer_expert_lists/scan");
     hipLaunchKernelGGL(expert_emit_kernel, dim3(B), dim3(64), 0, st, expert, S, num_experts, work, perm, slot);
     GAMER_CHECK_LAUNCH("gamer_expert_lists/emit");
+    return 0;
+}
+
+extern "C" int gamer_check_labels(const int64_t* labels, int64_t n, int V, int ignore_index, int32_t* bad_label,
+                                  void* stream) {
+    GAMER_CHECK_ARG(labels && bad_label && n > 0 && V > 0, "gamer_check_labels: bad arguments");
+    int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(check_labels_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, labels, n, V,
+                       ignore_index, bad_label);
+    GAMER_CHECK_LAUNCH("gamer_check_labels");
     return 0;
 }

@@ -32,7 +32,9 @@ from . import ops
 class ItemTrie:
     """CSR trie over item token sequences (node 0 = root).  ``get(prefix)`` is the host-side ``Trie.get``."""
 
-    def __init__(self, sequences: Sequence[Sequence[int]], device="cuda"):
+    def __init__(self, sequences: Sequence[Sequence[int]], device="cuda", pad_token_id: int = 4):
+        """``pad_token_id``: the tokenizer's pad id (config.pad_token_id; 4 in the shipped config.json), which
+        test_SMB_decoder.py:473-474 adds to the item-ending tokens."""
         nodes: List[Dict[int, int]] = [{}]
         for seq in sequences:
             cur = 0
@@ -53,7 +55,7 @@ class ItemTrie:
         self.nodes = nodes
         self.n_items = len(sequences)
         # tokens that end an item, plus the pad id (test_SMB_decoder.py:473-474)
-        self.last_tokens = {int(seq[-1]) for seq in sequences} | {4}
+        self.last_tokens = {int(seq[-1]) for seq in sequences} | {int(pad_token_id)}
         i32 = dict(dtype=torch.int32, device=device)
         self.child_start = torch.tensor(start, **i32)
         self.child_tok = torch.tensor(tok if tok else [0], **i32)

@@ -133,11 +133,40 @@ class _LayerW:
 
 
 class _Workspace:
-    """All activation / scratch buffers for one (B, S) shape."""
+    """All activation / scratch buffers of the train step (``train=True``) or of a scoring forward.
 
-    def __init__(self, cfg: Qwen3MultiConfig, B: int, S: int, device, train: bool):
-        f32 = dict(dtype=torch.float32, device=device)
-        i32 = dict(dtype=torch.int32, device=device)
+    Storage is grow-only and shape independent: every buffer is a flat allocation that ``bind(B, S)`` views at the
+    shape of the current batch, so collated batches of varying length (the reference's collator pads to the longest
+    sample of each batch, ref:SeqRec/datasets/collator.py:59-67) reuse one allocation instead of freeing and
+    re-creating tens of GB per micro-batch; ``Engine.reserve`` sizes it once for the largest batch up front.
+    ``act`` is the dtype of the activations the GEMMs read and write: fp32, or bf16 for the AMP variant (the
+    residual stream, the normalisation statistics and everything the optimizer touches stay fp32)."""
+
+    def __init__(self, cfg: Qwen3MultiConfig, device, train: bool, act: torch.dtype = torch.float32):
+        self.cfg, self.device, self.train, self.act = cfg, device, train, act
+        self._store: Dict[str, torch.Tensor] = {}
+        self.B = self.S = self.T = 0
+        self.loss_sum = torch.zeros(1, dtype=torch.float32, device=device)
+        self.count = torch.zeros(1, dtype=torch.float32, device=device)
+        self.session: Optional[dict] = None        # span_self / span_cross / pos_ids of the session variant
+
+    def _buf(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
+        n = math.prod(shape)
+        t = self._store.get(name)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            self._store[name] = None               # release the old block before asking for the larger one
+            t = torch.empty(n, dtype=dtype, device=self.device)
+            self._store[name] = t
+        return t[:n].view(shape)
+
+    def allocated_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._store.values() if t is not None)
+
+    def bind(self, B: int, S: int):
+        if (B, S) == (self.B, self.S):
+            return self
+        cfg, train, act = self.cfg, self.train, self.act
+        f32, i32 = torch.float32, torch.int32
         self.B, self.S, self.T = B, S, B * S
         T, H = self.T, cfg.hidden_size
         nq, nkv, dh, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size
@@ -145,22 +174,30 @@ class _Workspace:
         QKV = NQ + 2 * NKV
         L, E = cfg.num_hidden_layers, cfg.num_experts
         din_max = H + cfg.behavior_embedding_dim
-        self.router = ops.alloc_router_outputs(B, S, device)
-        self.session: Optional[dict] = None        # span_self / span_cross / pos_ids of the session variant
-        self.perm = torch.empty(T, **i32)
-        self.slot = torch.empty(T, **i32)
         n_t32 = (S + 31) // 32
+        buf = self._buf
+        self.router = {k: buf("r_" + k, (B, S), i32) for k in
+                       ("expert", "beh_idx", "act_idx", "kl_self", "kl_cross", "ql_cross", "empty_self", "empty_cross")}
+        self.router["tile_empty_self"] = buf("r_tile_empty_self", (B, n_t32), i32)
+        self.router["tile_empty_cross"] = buf("r_tile_empty_cross", (B, n_t32), i32)
+        if "r_bad_token" not in self._store:
+            self._store["r_bad_token"] = torch.zeros(1, dtype=i32, device=self.device)
+            self._store["r_bad_label"] = torch.zeros(1, dtype=i32, device=self.device)
+        self.router["bad_token"] = self._store["r_bad_token"]
+        self.bad_label = self._store["r_bad_label"]
+        if self.session is not None:
+            self.session = None                    # rebuilt at the new shape by the next session forward
+        self.perm = buf("perm", (T,), i32)
+        self.slot = buf("slot", (T,), i32)
         # query-row order of the cross attention (normal rows first, empty rows behind)
-        self.cross_order = (torch.empty(B, S, **i32), torch.empty(B, n_t32, **i32), torch.empty(B, n_t32, **i32))
-        self.offsets = torch.empty(E + 1, **i32)
-        self.work = torch.empty((B + 1) * E, **i32)
+        self.cross_order = (buf("co_perm", (B, S), i32), buf("co_kind", (B, n_t32), i32), buf("co_maxpos", (B, n_t32), i32))
+        self.offsets = buf("offsets", (E + 1,), i32)
+        self.work = buf("work", ((B + 1) * E,), i32)
         self.ldl = _round_up(cfg.vocab_size, 32)
-        self.logits = torch.empty(T, self.ldl, **f32)
-        self.lse_ce = torch.empty(T, **f32)
-        self.row_loss = torch.empty(T, **f32)
-        self.loss_sum = torch.zeros(1, **f32)
-        self.count = torch.zeros(1, **f32)
-        self.xn = torch.empty(T, H, **f32)
+        self.logits = buf("logits", (T, self.ldl), f32)
+        self.lse_ce = buf("lse_ce", (T,), f32)
+        self.row_loss = buf("row_loss", (T,), f32)
+        self.xn = buf("xn", (T, H), act)
         # residual stream snapshots: x[l][0] layer input, [1] after self-attn, [2] after cross-attn
         self.x: List[List[torch.Tensor]] = []
         self.layers: List[dict] = []
@@ -168,44 +205,46 @@ class _Workspace:
         shared: Optional[dict] = None
         for l in range(L):
             cross = l in cfg.cross_attention_decoder
-            inject = l in cfg.behavior_injection_decoder
+            tag = f"l{l}_" if keep else "l_"
             if keep or shared is None:
                 d = dict(
-                    h1=torch.empty(T, H, **f32), qkv=torch.empty(T, QKV, **f32), q=torch.empty(T, NQ, **f32),
-                    k=torch.empty(T, NKV, **f32), ao=torch.empty(T, NQ, **f32), lse=torch.empty(B, nq, S, **f32),
-                    hin=torch.empty(T, din_max, **f32), g=torch.empty(T, I, **f32), u=torch.empty(T, I, **f32),
-                    hm=torch.empty(T, I, **f32))
+                    h1=buf(tag + "h1", (T, H), act), qkv=buf(tag + "qkv", (T, QKV), act), q=buf(tag + "q", (T, NQ), act),
+                    k=buf(tag + "k", (T, NKV), act), ao=buf(tag + "ao", (T, NQ), act), lse=buf(tag + "lse", (B, nq, S), f32),
+                    hin=buf(tag + "hin", (T, din_max), act), g=buf(tag + "g", (T, I), act), u=buf(tag + "u", (T, I), act),
+                    hm=buf(tag + "hm", (T, I), act))
                 if cross or not keep:
-                    d.update(h2=torch.empty(T, H, **f32), qkv_c=torch.empty(T, QKV, **f32),
-                             q_c=torch.empty(T, NQ, **f32), k_c=torch.empty(T, NKV, **f32),
-                             ao_c=torch.empty(T, NQ, **f32), lse_c=torch.empty(B, nq, S, **f32),
-                             op_c=torch.empty(T, H, **f32), gate_c=torch.empty(T, H, **f32))
+                    d.update(h2=buf(tag + "h2", (T, H), act), qkv_c=buf(tag + "qkv_c", (T, QKV), act),
+                             q_c=buf(tag + "q_c", (T, NQ), act), k_c=buf(tag + "k_c", (T, NKV), act),
+                             ao_c=buf(tag + "ao_c", (T, NQ), act), lse_c=buf(tag + "lse_c", (B, nq, S), f32),
+                             op_c=buf(tag + "op_c", (T, H), act), gate_c=buf(tag + "gate_c", (T, H), act))
                 shared = d
             self.layers.append(shared if not keep else d)
             if keep or l == 0:
-                xs = [torch.empty(T, H, **f32), torch.empty(T, H, **f32)]
-                xs.append(torch.empty(T, H, **f32) if (cross or not keep) else None)
+                xs = [buf(tag + "x0", (T, H), f32), buf(tag + "x1", (T, H), f32)]
+                xs.append(buf(tag + "x2", (T, H), f32) if (cross or not keep) else None)
                 self.x.append(xs)
             else:
                 self.x.append(self.x[0])
-        self.x_final = torch.empty(T, H, **f32) if keep else self.x[0][0]
+        self.x_final = buf("x_final", (T, H), f32) if keep else self.x[0][0]
         # scratch shared by all layers
-        self.tmpH = [torch.empty(T, H, **f32) for _ in range(4)]
+        self.tmpH = [buf(f"tmpH{i}", (T, H), act) for i in range(4)]
         if train:
-            self.dx = torch.empty(T, H, **f32)
-            self.dhm = torch.empty(T, I, **f32)
-            self.dhin = torch.empty(T, din_max, **f32)
-            self.dqkv = torch.empty(T, QKV, **f32)
-            self.dq = torch.empty(T, NQ, **f32)
-            self.dk = torch.empty(T, NKV, **f32)
-            self.dao = torch.empty(T, NQ, **f32)
-            self.delta = torch.empty(B, nq, S, **f32)
-            self.norm_partial = torch.empty(2048, H, **f32)
+            self.dx = buf("dx", (T, H), f32)
+            self.dhm = buf("dhm", (T, I), act)
+            self.dhin = buf("dhin", (T, din_max), act)
+            self.dqkv = buf("dqkv", (T, QKV), act)
+            self.dq = buf("dq", (T, NQ), act)
+            self.dk = buf("dk", (T, NKV), act)
+            self.dao = buf("dao", (T, NQ), act)
+            self.delta = buf("delta", (B, nq, S), f32)
+            self.norm_partial = buf("norm_partial", (2048, H), f32)
+            self.qk_partial = buf("qk_partial", (ops.qknorm_partial_numel(cfg.num_behavior + 1),), f32)
             # dS spill of the attention backward (5 matmuls per tile pair instead of 7; gamer_attn_bwd):
             # 6.4 GB at B = 1024, shared by all layers.  GAMER_ATTN_SPILL=0 keeps the two recompute kernels.
             import os
-            self.ds_work = (torch.empty(ops.attn_ds_work_numel(B, S, nq), **f32)
-                            if os.environ.get("GAMER_ATTN_SPILL", "1") != "0" else None)
+            self.ds_work = (buf("ds_work", (ops.attn_ds_work_numel(B, S, nq),), f32)
+                            if (os.environ.get("GAMER_ATTN_SPILL", "1") != "0" and act == torch.float32) else None)
+        return self
 
 
 class Engine:
@@ -214,14 +253,22 @@ class Engine:
     N_NORM_PARTIAL = 512
     N_SUMSQ_PARTIAL = 1024
 
-    def __init__(self, cfg: Qwen3MultiConfig, device="cuda", temperature: float = 1.0, variant: str = "multi"):
+    def __init__(self, cfg: Qwen3MultiConfig, device="cuda", temperature: float = 1.0, variant: str = "multi",
+                 dtype: str = "f32"):
         """``variant``: "multi" = Qwen3Multi (train_SMB_decoder.py:362-364), "session" = Qwen3SessionMulti
         (train_SMB_decoder.py:365-367): the same parameters and layers with session-wise attention masks and
-        RoPE positions taken from ``extended_session_ids``."""
+        RoPE positions taken from ``extended_session_ids``.
+        ``dtype``: "f32" (default) or "bf16" = the reference's ``--bf16`` run (train_SMB_decoder.py:114-118, 407-408:
+        HF Trainer autocast): bf16 matrix operands and activations, fp32 accumulation, fp32 residual stream,
+        normalisation statistics, loss, master weights, gradients and optimizer state."""
         cfg.validate()
         if variant not in ("multi", "session"):
             raise ValueError(f"unknown variant {variant!r}")
+        if dtype not in ("f32", "bf16"):
+            raise ValueError(f"unknown dtype {dtype!r} (f32 or bf16; the reference's --fp16 is not built)")
         self.variant = variant
+        self.dtype = dtype
+        self.act_dtype = torch.float32 if dtype == "f32" else torch.bfloat16
         if not torch.cuda.is_available():
             raise RuntimeError("gamer_amd.Engine needs a HIP device (there is no CPU fallback)")
         from . import _lib
@@ -242,7 +289,7 @@ class Engine:
         self.G = [_LayerW(cfg, self.layout, self.flat_g, l) for l in range(L)]
         self.lut = cfg.behavior_lut().to(self.device)
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
-        self._ws: Dict[Tuple[int, int, bool], _Workspace] = {}
+        self._ws: Dict[bool, _Workspace] = {}
         self.ws: Optional[_Workspace] = None
         self.opt_step = 0
         self.dropout_step = 0
@@ -287,11 +334,16 @@ class Engine:
         return self._rope[S]
 
     def workspace(self, B: int, S: int, train: bool) -> _Workspace:
-        key = (B, S, train)
-        if key not in self._ws:
-            self._ws.clear()                      # one live shape at a time: activations are tens of GB
-            self._ws[key] = _Workspace(self.cfg, B, S, self.device, train)
-        return self._ws[key]
+        """The train and the scoring workspace live side by side (an epoch's evaluation does not evict the training
+        buffers); each is bound to the shape of the current batch without reallocating (grow-only storage)."""
+        if train not in self._ws:
+            self._ws[train] = _Workspace(self.cfg, self.device, train, self.act_dtype)
+        return self._ws[train].bind(B, S)
+
+    def reserve(self, B: int, S: int, train: bool = True):
+        """Size the workspace once for the largest batch that will be seen (e.g. S = (max_his_len + 1) * num_positions),
+        so that shorter collated batches never allocate."""
+        self.workspace(B, S, train)
 
     def _seed(self, layer: int, site: int) -> int:
         return ((self.base_seed & 0xFFFF) << 48) | ((self.dropout_step & 0xFFFFFFFF) << 16) | (layer << 4) | site
@@ -345,6 +397,9 @@ class Engine:
         lab = labels.to(self.device, torch.int64).contiguous() if labels is not None else None
         r = ws.router
         r["bad_token"].zero_()
+        if lab is not None:
+            ws.bad_label.zero_()
+            ops.check_labels(lab, cfg.vocab_size, IGNORE_INDEX, ws.bad_label)
         ops.router_fwd(ids, am, act, self.lut, cfg.num_positions, cfg.pad_token_id, cfg.eos_token_id, r)
         if act_zero_col is None and S % cfg.num_positions == 1:
             # the reference's router counts (S + 3) // 5 items (router.py:160-163), so a trailing behaviour token
@@ -362,7 +417,12 @@ class Engine:
             ext = (extended_session_ids.to(self.device, torch.int64).contiguous()
                    if extended_session_ids is not None else None)
             if ws.session is None:
-                ws.session = ops.alloc_session_outputs(B, S, self.device)
+                i32 = torch.int32
+                if "s_violations" not in ws._store:
+                    ws._store["s_violations"] = torch.zeros(1, dtype=i32, device=self.device)
+                ws.session = {"span_self": ws._buf("s_span_self", (B, S, 4), i32),
+                              "span_cross": ws._buf("s_span_cross", (B, S, 4), i32),
+                              "pos_ids": ws._buf("s_pos_ids", (B, S), i32), "violations": ws._store["s_violations"]}
             ws.session["violations"].zero_()
             ops.session_spans(sid, ext, am, cfg.num_positions, S, r, ws.session)     # overwrites r["empty_*"]
             span_self, span_cross, pos_ids = (ws.session["span_self"], ws.session["span_cross"],
@@ -473,6 +533,10 @@ class Engine:
         if n:
             raise IndexError(f"{n} item(s) start with a token that is not in config.behavior_maps "
                              "(the reference fails with an embedding IndexError, router.py:170-171)")
+        n = int(self.ws.bad_label.item())
+        if n:
+            raise IndexError(f"{n} label(s) outside [0, vocab_size={self.cfg.vocab_size}) that are not -100 "
+                             "(nn.CrossEntropyLoss raises 'Target out of bounds' in the reference)")
         if self.variant == "session" and self.ws.session is not None:
             n = int(self.ws.session["violations"].item())
             if n:
@@ -576,7 +640,8 @@ class Engine:
                              delta_ready=fuse_delta)
                 ops.qknorm_rope_bwd(A["qkv_c"], ws.dq, ws.dk, S, nq, nkv, C["qn"], C["kn"], eps, cos, sin, ws.dqkv,
                                     GC["qn"], GC["kn"], bias_q=C["bq"], bias_k=C["bk"], act_idx=r["act_idx"], nb1=NB1,
-                                    dbias_q=GC["bq"], dbias_k=GC["bk"], dbias_v=GC["bv"], pos_ids=pos_ids)
+                                    dbias_q=GC["bq"], dbias_k=GC["bk"], dbias_v=GC["bv"], pos_ids=pos_ids,
+                                    partial=ws.qk_partial)
                 ops.linear_wgrad(ws.dqkv, QKV, A["h2"], H, GC["qkv"], H, T, QKV, H)
                 ops.linear_dgrad(ws.dqkv, QKV, C["qkv"], H, t3, H, T, QKV, H)
                 ops.linear_dgrad(t2, H, C["gate"], H, t3, H, T, H, H, accumulate=True)
@@ -591,7 +656,7 @@ class Engine:
                          ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, ds_work=ws.ds_work,
                          q_span=span_self, delta_ready=fuse_delta)
             ops.qknorm_rope_bwd(A["qkv"], ws.dq, ws.dk, S, nq, nkv, SA["qn"], SA["kn"], eps, cos, sin, ws.dqkv, GS["qn"],
-                                GS["kn"], pos_ids=pos_ids)
+                                GS["kn"], pos_ids=pos_ids, partial=ws.qk_partial)
             ops.linear_wgrad(ws.dqkv, QKV, A["h1"], H, GS["qkv"], H, T, QKV, H)
             ops.linear_dgrad(ws.dqkv, QKV, SA["qkv"], H, t3, H, T, QKV, H)
             norm_bwd(xs[0], W.ln1, t3, H, G.ln1, True, branch=(self._seed(l - 1, 5), ws.slot) if l > 0 else None)

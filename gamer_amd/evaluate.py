@@ -57,7 +57,8 @@ def evaluate_dataset(engine, data, max_his_len: int, behaviors: Sequence[str] = 
     out = {}
     for beh in (behaviors if behaviors is not None else data.behaviors):
         sub = samples.filter_by_behavior(beh)
-        trie = ItemTrie(data.candidate_tokens(beh).tolist(), device=engine.device)
+        trie = ItemTrie(data.candidate_tokens(beh).tolist(), device=engine.device,
+                        pad_token_id=engine.cfg.pad_token_id)
 
         def gen():
             for idx in gdata.batches(len(sub), batch_size, rank=rank, world=world):

@@ -227,6 +227,9 @@ class Qwen3MultiWithTemperature(nn.Module):
                 loss, logits = eng.forward(input_ids, attention_mask, actions, labels=labels,
                                            num_items_in_batch=num_items, train=False, dropout=False,
                                            session_ids=sess[0], extended_session_ids=sess[1])
+                # the engine's logits live in a workspace buffer that the next forward overwrites; callers keep
+                # module outputs across batches (HF Trainer.predict / evaluate with compute_metrics), so hand out a copy
+                logits = logits.clone()
         if self.VARIANT == "session":
             eng.check_inputs()          # session ids out of order cannot be expressed as key spans: raise, do not guess
         if isinstance(logits_to_keep, int) and logits_to_keep > 0:

@@ -14,6 +14,15 @@ from . import _lib
 from ._lib import GemmDesc, call, ptr, stream_ptr
 
 
+def _sfx(t: torch.Tensor) -> str:
+    """Entry-point suffix for the activation dtype of ``t``: fp32 -> "", bf16 -> "_bf16" (the AMP variant)."""
+    if t.dtype == torch.float32:
+        return ""
+    if t.dtype == torch.bfloat16:
+        return "_bf16"
+    raise RuntimeError(f"activations must be float32 or bfloat16, got {t.dtype}")
+
+
 def _chk(t: torch.Tensor, dtype, name: str):
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be on the HIP device (gamer_amd has no CPU path)")
@@ -84,7 +93,7 @@ def embedding_bwd(ids, dx, pad_id, dW):
 
 def rmsnorm_fwd(x, w, eps, y, ldy=None, dst_rows=None):
     T, H = x.shape
-    call("gamer_rmsnorm_fwd", ptr(x), ptr(w), T, H, eps, ptr(dst_rows), ptr(y), ldy if ldy else y.stride(0),
+    call("gamer_rmsnorm_fwd" + _sfx(y), ptr(x), ptr(w), T, H, eps, ptr(dst_rows), ptr(y), ldy if ldy else y.stride(0),
          stream_ptr())
 
 
@@ -93,7 +102,7 @@ def rmsnorm_bwd(x, w, dy, lddy, eps, dx, dw_partial, accumulate_dx=True, dy_rows
     """mask_out: also write dropout_mask(seed) * dx (the input gradient of the next residual branch), rows scattered
     through mask_rows when given - the second pass gamer_residual_dropout_bwd would make over dx."""
     T, H = x.shape
-    call("gamer_rmsnorm_bwd", ptr(x), ptr(w), ptr(dy), lddy, ptr(dy_rows), T, H, eps, 1 if accumulate_dx else 0,
+    call("gamer_rmsnorm_bwd" + _sfx(dy), ptr(x), ptr(w), ptr(dy), lddy, ptr(dy_rows), T, H, eps, 1 if accumulate_dx else 0,
          ptr(dx), ptr(dw_partial), dw_partial.shape[0], ptr(mask_out), ptr(mask_rows), p, seed, stream_ptr())
 
 
@@ -105,13 +114,13 @@ def colsum_reduce(partial, out, accumulate=False):
 def rowtable_fwd(table, idx, y, ldy, col0, dst_rows=None):
     T = idx.numel()
     E = table.shape[1]
-    call("gamer_rowtable_fwd", ptr(table), ptr(idx), ptr(dst_rows), T, E, ptr(y), ldy, col0, stream_ptr())
+    call("gamer_rowtable_fwd" + _sfx(y), ptr(table), ptr(idx), ptr(dst_rows), T, E, ptr(y), ldy, col0, stream_ptr())
 
 
 def rowtable_bwd(dy, lddy, col0, idx, dtable, dy_rows=None):
     T = idx.numel()
     rows, E = dtable.shape
-    call("gamer_rowtable_bwd", ptr(dy), lddy, col0, ptr(idx), ptr(dy_rows), T, E, rows, ptr(dtable), stream_ptr())
+    call("gamer_rowtable_bwd" + _sfx(dy), ptr(dy), lddy, col0, ptr(idx), ptr(dy_rows), T, E, rows, ptr(dtable), stream_ptr())
 
 
 def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=False, groups=1, group_mode=0,
@@ -171,16 +180,25 @@ def qknorm_rope_fwd(qkv, S, nq, nkv, wq, wk, eps, cos_t, sin_t, q_rot, k_rot, bi
                     act_idx=None, pos_ids=None):
     """pos_ids: int32 [T] RoPE table row per token (session model); None = position in the sequence."""
     T = qkv.shape[0]
-    call("gamer_qknorm_rope_fwd", ptr(qkv), T, S, nq, nkv, ptr(wq), ptr(wk), eps, ptr(cos_t), ptr(sin_t),
+    call("gamer_qknorm_rope_fwd" + _sfx(qkv), ptr(qkv), T, S, nq, nkv, ptr(wq), ptr(wk), eps, ptr(cos_t), ptr(sin_t),
          ptr(bias_q), ptr(bias_k), ptr(bias_v), ptr(act_idx), ptr(q_rot), ptr(k_rot), ptr(pos_ids), stream_ptr())
 
 
+def qknorm_partial_numel(nb1: int = 0) -> int:
+    """fp32 scratch of qknorm_rope_bwd that never limits its wave count (see gamer_hip.h)."""
+    return 8192 * (1 + nb1) * 64
+
+
 def qknorm_rope_bwd(qkv, dq_rot, dk_rot, S, nq, nkv, wq, wk, eps, cos_t, sin_t, dqkv, dwq, dwk, bias_q=None,
-                    bias_k=None, act_idx=None, nb1=0, dbias_q=None, dbias_k=None, dbias_v=None, pos_ids=None):
+                    bias_k=None, act_idx=None, nb1=0, dbias_q=None, dbias_k=None, dbias_v=None, pos_ids=None,
+                    partial=None):
+    """partial: fp32 scratch for the per-wave sums of the weight / bias gradients (allocated here when None)."""
     T = qkv.shape[0]
-    call("gamer_qknorm_rope_bwd", ptr(qkv), ptr(dq_rot), ptr(dk_rot), T, S, nq, nkv, ptr(wq), ptr(wk), eps,
+    if partial is None:
+        partial = torch.empty(qknorm_partial_numel(nb1), dtype=torch.float32, device=qkv.device)
+    call("gamer_qknorm_rope_bwd" + _sfx(qkv), ptr(qkv), ptr(dq_rot), ptr(dk_rot), T, S, nq, nkv, ptr(wq), ptr(wk), eps,
          ptr(cos_t), ptr(sin_t), ptr(bias_q), ptr(bias_k), ptr(act_idx), nb1, ptr(dqkv), ptr(dwq), ptr(dwk),
-         ptr(dbias_q), ptr(dbias_k), ptr(dbias_v), ptr(pos_ids), stream_ptr())
+         ptr(dbias_q), ptr(dbias_k), ptr(dbias_v), ptr(pos_ids), ptr(partial), partial.numel(), stream_ptr())
 
 
 def attn_row_order(row_empty, perm, tile_kind, tile_maxpos):
@@ -227,32 +245,36 @@ def residual_dropout_bwd(dx, p, seed, ddelta, src_rows=None):
 
 
 def swiglu_fwd(g, u, n, p, seed, hm):
-    call("gamer_swiglu_fwd", ptr(g), ptr(u), n, p, seed, ptr(hm), stream_ptr())
+    call("gamer_swiglu_fwd" + _sfx(g), ptr(g), ptr(u), n, p, seed, ptr(hm), stream_ptr())
 
 
 def swiglu_bwd(g, u, dhm, n, p, seed):
-    call("gamer_swiglu_bwd", ptr(g), ptr(u), ptr(dhm), n, p, seed, stream_ptr())
+    call("gamer_swiglu_bwd" + _sfx(g), ptr(g), ptr(u), ptr(dhm), n, p, seed, stream_ptr())
 
 
 def silu_gate_fwd(a, gate, out, resid=None, p=0.0, seed=0):
     """out = a * silu(gate), or resid + dropout(a * silu(gate)) when resid is given (fused residual add)."""
-    call("gamer_silu_gate_fwd", ptr(a), ptr(gate), a.numel(), ptr(out), ptr(resid), p, seed, stream_ptr())
+    call("gamer_silu_gate_fwd" + _sfx(a), ptr(a), ptr(gate), a.numel(), ptr(out), ptr(resid), p, seed, stream_ptr())
 
 
 def silu_gate_bwd(a, gate, dout, da, dgate, p=0.0, seed=0):
     """p > 0: dout is the residual-stream gradient and the forward's dropout mask (seed) is applied to it first."""
-    call("gamer_silu_gate_bwd", ptr(a), ptr(gate), ptr(dout), a.numel(), ptr(da), ptr(dgate), p, seed, stream_ptr())
+    call("gamer_silu_gate_bwd" + _sfx(a), ptr(a), ptr(gate), ptr(dout), a.numel(), ptr(da), ptr(dgate), p, seed, stream_ptr())
+
+
+def check_labels(labels, V, ignore_index, bad_label):
+    call("gamer_check_labels", ptr(labels), labels.numel(), V, ignore_index, ptr(bad_label), stream_ptr())
 
 
 def ce_fwd(logits, ldl, labels, V, temperature, ignore_index, lse, row_loss, loss_sum, count):
     B, S = labels.shape
-    call("gamer_ce_fwd", ptr(logits), ldl, ptr(labels), B, S, V, temperature, ignore_index, ptr(lse), ptr(row_loss),
+    call("gamer_ce_fwd" + _sfx(logits), ptr(logits), ldl, ptr(labels), B, S, V, temperature, ignore_index, ptr(lse), ptr(row_loss),
          ptr(loss_sum), ptr(count), stream_ptr())
 
 
 def ce_bwd(logits, ldl, labels, V, temperature, ignore_index, lse, count_dev, denom_host, dloss):
     B, S = labels.shape
-    call("gamer_ce_bwd", ptr(logits), ldl, ptr(labels), B, S, V, temperature, ignore_index, ptr(lse), ptr(count_dev),
+    call("gamer_ce_bwd" + _sfx(logits), ptr(logits), ldl, ptr(labels), B, S, V, temperature, ignore_index, ptr(lse), ptr(count_dev),
          float(denom_host), float(dloss), stream_ptr())
 
 

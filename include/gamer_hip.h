@@ -9,7 +9,8 @@
  * Each entry point names the reference code it replaces.
  *
  * Conventions
- *   - every pointer is a DEVICE pointer (HIP), fp32 / int32 / int64 as typed, 16-byte aligned;
+ *   - every pointer is a DEVICE pointer (HIP), fp32 / bf16 / int32 / int64 as typed, 16-byte aligned
+ *     (gamer_bf16 rows: 8-byte aligned, leading dims multiples of 4 elements unless an entry point says more);
  *   - matrices are row-major with an explicit leading dimension (elements) that is a multiple of 4;
  *   - token-major activations: row t = b*S + s;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
@@ -27,7 +28,13 @@
 extern "C" {
 #endif
 
-#define GAMER_ABI_VERSION 1
+#define GAMER_ABI_VERSION 2
+
+/* bf16 activations of the AMP variant (the reference's --bf16 run, ref:SeqRec/tasks/train_SMB_decoder.py:114-118,
+ * 407-408: HF Trainer autocast): raw bfloat16 bits.  Entry points with the suffix _bf16 are the same operation with
+ * every ACTIVATION pointer (GEMM operands / results, what autocast holds in bf16) typed gamer_bf16; parameters, the
+ * residual stream, normalisation statistics, losses, gradients of parameters and optimizer state stay fp32.        */
+typedef uint16_t gamer_bf16;
 
 int gamer_abi_version(void);
 /* Thread-local message for the last <0 / >0 return of any entry point. */
@@ -118,6 +125,13 @@ int gamer_rmsnorm_bwd(const float* x, const float* w, const float* dy, int lddy,
                       const int32_t* dy_rows, int T, int H, float eps, int accumulate_dx,
                       float* dx, float* dw_partial, int n_partial,
                       float* mask_out, const int32_t* mask_rows, float p_drop, uint64_t seed, void* stream);
+/* bf16: y / dy / mask_out are activations (what the next GEMM reads, what a dgrad GEMM wrote); x, dx stay fp32. */
+int gamer_rmsnorm_fwd_bf16(const float* x, const float* w, int T, int H, float eps,
+                           const int32_t* dst_rows, gamer_bf16* y, int ldy, void* stream);
+int gamer_rmsnorm_bwd_bf16(const float* x, const float* w, const gamer_bf16* dy, int lddy,
+                           const int32_t* dy_rows, int T, int H, float eps, int accumulate_dx,
+                           float* dx, float* dw_partial, int n_partial,
+                           gamer_bf16* mask_out, const int32_t* mask_rows, float p_drop, uint64_t seed, void* stream);
 /* out[c] (+)= sum_r partial[r][c] */
 int gamer_colsum_reduce(const float* partial, int rows, int cols, int accumulate, float* out,
                         void* stream);
@@ -129,6 +143,11 @@ int gamer_rowtable_fwd(const float* table, const int32_t* idx, const int32_t* ds
 int gamer_rowtable_bwd(const float* dy, int lddy, int col0, const int32_t* idx,
                        const int32_t* dy_rows, int T, int E, int n_rows_table, float* dtable,
                        void* stream);
+int gamer_rowtable_fwd_bf16(const float* table, const int32_t* idx, const int32_t* dst_rows, int T, int E,
+                            gamer_bf16* y, int ldy, int col0, void* stream);
+int gamer_rowtable_bwd_bf16(const gamer_bf16* dy, int lddy, int col0, const int32_t* idx,
+                            const int32_t* dy_rows, int T, int E, int n_rows_table, float* dtable,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * fp32 MFMA GEMM  (v_mfma_f32_32x32x2_f32; exact fp32, replaces every nn.Linear on the path:
@@ -187,7 +206,14 @@ int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);
  *   bias_q [NB1, nq*64], bias_k/bias_v [NB1, nkv*64], act_idx int32 [T]  (all NULL for self)
  *   out: q_rot [T,nq*64], k_rot [T,nkv*64]; v (+bias) is updated in place inside qkv.
  * bwd: dq_rot, dk_rot -> dqkv[:, :q|k] (pre-norm grads); dv is already in dqkv[:, v];
- *   dwq/dwk [64] and dbias_* are accumulated with atomics (zero-initialise them).
+ *   dwq/dwk [64] and dbias_* are ADDED to (zero-initialise them) in a fixed order: every wave writes its sums to a
+ *   row of `partial` (scratch, partial_numel floats; 8192 * (1 + nb1) * 64 is always enough, a smaller buffer only
+ *   lowers the number of waves; at least (nq + 2 nkv) * (1 + nb1) * 64) and a second kernel folds the rows.
+ * bf16 (gamer_*_bf16): qkv / q_rot / k_rot / dq_rot / dk_rot / dqkv are activations.  The arithmetic follows the
+ *   reference under autocast: self attention = Qwen3MoeRMSNorm on a bf16 tensor (normalised value rounded to bf16
+ *   before the fp32 weight multiply); cross attention = fp32 bias added to the bf16 projection first, norm in fp32;
+ *   RoPE in fp32; q_rot / k_rot / v rounded to bf16 (SDPA's autocast).  The biased pre-norm q/k are not written back
+ *   (the backward re-adds bias_q / bias_k, so both are required there for the cross attention).
  * ---------------------------------------------------------------------------------------- */
 int gamer_qknorm_rope_fwd(float* qkv, int T, int S, int nq, int nkv,
                           const float* wq, const float* wk, float eps,
@@ -203,7 +229,22 @@ int gamer_qknorm_rope_bwd(const float* qkv, const float* dq_rot, const float* dk
                           const int32_t* act_idx, int nb1,
                           float* dqkv, float* dwq, float* dwk,
                           float* dbias_q, float* dbias_k, float* dbias_v, const int32_t* pos_ids,
-                          void* stream);
+                          float* partial, int64_t partial_numel, void* stream);
+int gamer_qknorm_rope_fwd_bf16(gamer_bf16* qkv, int T, int S, int nq, int nkv,
+                               const float* wq, const float* wk, float eps,
+                               const float* cos_t, const float* sin_t,
+                               const float* bias_q, const float* bias_k, const float* bias_v,
+                               const int32_t* act_idx,
+                               gamer_bf16* q_rot, gamer_bf16* k_rot, const int32_t* pos_ids, void* stream);
+int gamer_qknorm_rope_bwd_bf16(const gamer_bf16* qkv, const gamer_bf16* dq_rot, const gamer_bf16* dk_rot,
+                               int T, int S, int nq, int nkv,
+                               const float* wq, const float* wk, float eps,
+                               const float* cos_t, const float* sin_t,
+                               const float* bias_q, const float* bias_k,
+                               const int32_t* act_idx, int nb1,
+                               gamer_bf16* dqkv, float* dwq, float* dwk,
+                               float* dbias_q, float* dbias_k, float* dbias_v, const int32_t* pos_ids,
+                               float* partial, int64_t partial_numel, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-behaviour flash attention, fp32 MFMA, head_dim 64, GQA group nq/nkv in {1,2,4}.
@@ -307,6 +348,16 @@ int gamer_silu_gate_fwd(const float* a, const float* gate, int64_t n, float* out
 /* d = drop_mask(seed) * dout (p_drop = 0: d = dout); da = d*silu(gate) ; dgate = d*a*silu'(gate)              */
 int gamer_silu_gate_bwd(const float* a, const float* gate, const float* dout, int64_t n,
                         float* da, float* dgate, float p_drop, uint64_t seed, void* stream);
+/* bf16: g / u / hm / dhm, a / gate / da / dgate are activations; the gate's `out` and `dout` are the fp32 residual
+ * stream and its gradient (resid is required).  Computed in fp32, rounded once on store.                          */
+int gamer_swiglu_fwd_bf16(const gamer_bf16* g, const gamer_bf16* u, int64_t n, float p_drop, uint64_t seed,
+                          gamer_bf16* hm, void* stream);
+int gamer_swiglu_bwd_bf16(gamer_bf16* g, gamer_bf16* u, const gamer_bf16* dhm, int64_t n, float p_drop,
+                          uint64_t seed, void* stream);
+int gamer_silu_gate_fwd_bf16(const gamer_bf16* a, const gamer_bf16* gate, int64_t n, float* out,
+                             const float* resid, float p_drop, uint64_t seed, void* stream);
+int gamer_silu_gate_bwd_bf16(const gamer_bf16* a, const gamer_bf16* gate, const float* dout, int64_t n,
+                             gamer_bf16* da, gamer_bf16* dgate, float p_drop, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Tied LM head loss: temperature + shifted cross entropy (model.py:904-922;
@@ -318,12 +369,25 @@ int gamer_silu_gate_bwd(const float* a, const float* gate, const float* dout, in
  * bwd: logits <- (softmax - onehot) * dloss / (denom * temperature), denom = count_dev[0] when
  *   count_dev != NULL (mean reduction) else denom_host (num_items_in_batch from the trainer).
  * ---------------------------------------------------------------------------------------- */
+/* bad_label[0] += number of labels that are neither ignore_index nor inside [0, V): the reference's
+ * nn.CrossEntropyLoss raises on those (transformers/loss/loss_utils.py fixed_cross_entropy); gamer_ce_* skip them, so
+ * the host checks this counter and raises (no synchronisation here).                                          */
+int gamer_check_labels(const int64_t* labels, int64_t n, int V, int ignore_index, int32_t* bad_label,
+                       void* stream);
 int gamer_ce_fwd(float* logits, int ldl, const int64_t* labels, int B, int S, int V,
                  float temperature, int ignore_index, float* lse_out, float* row_loss,
                  float* loss_sum, float* count, void* stream);
 int gamer_ce_bwd(float* logits, int ldl, const int64_t* labels, int B, int S, int V,
                  float temperature, int ignore_index, const float* lse, const float* count_dev,
                  float denom_host, float dloss, void* stream);
+/* bf16 logits (what the reference's lm_head returns under autocast; the in-place /temperature rounds to bf16 again,
+ * as upstream); lse / loss / count are fp32 (loss_utils.py upcasts the logits).  bwd writes d(logits) as bf16.     */
+int gamer_ce_fwd_bf16(gamer_bf16* logits, int ldl, const int64_t* labels, int B, int S, int V,
+                      float temperature, int ignore_index, float* lse_out, float* row_loss,
+                      float* loss_sum, float* count, void* stream);
+int gamer_ce_bwd_bf16(gamer_bf16* logits, int ldl, const int64_t* labels, int B, int S, int V,
+                      float temperature, int ignore_index, const float* lse, const float* count_dev,
+                      float denom_host, float dloss, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * HF Trainer update: clip_grad_norm_(max_norm) + AdamW (transformers/trainer.py;
