@@ -11,8 +11,16 @@ Gradient fixtures follow SURVEY.md section 8(a) row G1: every dropout p = 0, for
 under ``sdpa_kernel(SDPBackend.MATH)`` (the reference's default CPU fused SDPA kernel produces
 ill-defined gradients for fully masked rows).
 
+The ``*_bf16`` cases run the SAME reference model under ``torch.autocast("cpu", dtype=torch.bfloat16)`` - what HF
+Trainer does for the reference's ``--bf16`` flag (ref:SeqRec/tasks/train_SMB_decoder.py:114-118, 407-408) - forward
+inside the autocast region, backward outside it.  They pin the AMP variant (BASELINE configs[2]).  Two facts these
+fixtures establish (see oracle/qwen3multi_oracle.py::attention): the additive finfo(float32).min mask becomes -inf in
+bf16 and fully masked ("empty") rows then come out as 0, not as the uniform average of the fp32 run; gradients are the
+same under the default SDPA dispatch and under MATH (both recorded).
+
 Usage:  python oracle/make_golden.py            (writes tests/golden/*.npz)
 """
+import contextlib
 import json
 import os
 import sys
@@ -56,6 +64,14 @@ CASES = {
         codebook=8, B=4, n_items=15, pad_rows={1: 4, 2: 1}, seed=21, wseed=6, full=True, session_mean=2.5),
     "session_full": dict(dims=dict(), codebook=256, B=4, n_items=101, pad_rows={1: 10}, seed=2, wseed=0, full=False,
                          session_mean=4.0),
+    # the reference's --bf16 run (autocast): same inputs and weights as "small" / "full"
+    "small_bf16": dict(
+        dims=dict(hidden_size=128, num_hidden_layers=4, num_attention_heads=2, num_key_value_heads=1,
+                  head_dim=64, intermediate_size=256, moe_intermediate_size=128, behavior_embedding_dim=64,
+                  behavior_injection_decoder=[0, 1], cross_attention_decoder=[2, 3],
+                  sparse_layers_decoder=[0, 1, 2, 3]),
+        codebook=8, B=3, n_items=9, pad_rows={1: 4, 2: 1}, seed=12, wseed=6, full=True, amp=True),
+    "full_bf16": dict(dims=dict(), codebook=256, B=4, n_items=101, pad_rows={1: 10}, seed=1, wseed=0, full=False, amp=True),
 }
 
 
@@ -85,24 +101,35 @@ def run_case(name, spec):
                   session_ids=batch["session_ids"], extended_session_ids=batch["extended_session_ids"],
                   actions=batch["actions"])
     res = {}
+    amp = bool(spec.get("amp"))
+    autocast = (lambda: torch.autocast("cpu", dtype=torch.bfloat16)) if amp else contextlib.nullcontext
     model.eval()
-    with torch.no_grad():
+    with torch.no_grad(), autocast():
         pos, beh, act = model.model.router(batch["input_ids"].clone(),
                                            cache_position=torch.arange(batch["input_ids"].shape[1]))
         out = model(**fwd_in, output_hidden_states=True, use_cache=False)
-        logits_raw = out.logits.clone()
-        hidden = [h.clone() for h in out.hidden_states]
+        logits_raw = out.logits.float().clone()
+        hidden = [h.float().clone() for h in out.hidden_states]
         out_l = model(**fwd_in, labels=batch["labels"], use_cache=False)
         loss_mean = float(out_l.loss)
-        logits_scaled = out_l.logits.clone()
+        logits_scaled = out_l.logits.float().clone()
         n_items_tok = float((batch["labels"][:, 1:] != -100).sum()) * 2.0   # any positive number
         out_n = model(**fwd_in, labels=batch["labels"], use_cache=False, num_items_in_batch=n_items_tok)
         loss_sum = float(out_n.loss)
     # gradients: train mode, dropout 0, MATH backend
     model.train()
     from torch.nn.attention import SDPBackend, sdpa_kernel
+    gnorm_default = None
+    if amp:
+        # what the --bf16 training run executes: default SDPA dispatch, forward under autocast, backward outside
+        with autocast():
+            out_d = model(**fwd_in, labels=batch["labels"], use_cache=False)
+        out_d.loss.backward()
+        gnorm_default = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters())))
+        model.zero_grad()
     with sdpa_kernel(SDPBackend.MATH):
-        out_g = model(**fwd_in, labels=batch["labels"], use_cache=False)
+        with autocast():
+            out_g = model(**fwd_in, labels=batch["labels"], use_cache=False)
         out_g.loss.backward()
     grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
     assert "lm_head.weight" not in grads or grads["lm_head.weight"] is grads.get("lm_head.weight")
@@ -124,6 +151,9 @@ def run_case(name, spec):
         hidden_sum=np.array([float(h.double().sum()) for h in hidden]),
         hidden_abssum=np.array([float(h.double().abs().sum()) for h in hidden]),
     )
+    if amp:
+        res["global_grad_norm_default_sdpa"] = np.float64(gnorm_default)
+        res["logits_dtype"] = np.array(str(out.logits.dtype))
     if spec["full"]:
         res["logits_raw"] = logits_raw.numpy()
         res["logits_scaled"] = logits_scaled.numpy()
@@ -148,6 +178,7 @@ def run_case(name, spec):
                                    "behavior_maps": {str(k): v for k, v in bmaps.items()}},
                 codebook=cb, temperature=0.7, weight_seed=spec["wseed"], batch_seed=spec["seed"],
                 n_items=spec["n_items"], pad_rows={str(k): v for k, v in spec["pad_rows"].items()},
+                autocast="bfloat16" if amp else None,
                 model="Qwen3SessionMultiWithTemperature" if session else "Qwen3MultiWithTemperature",
                 generator=dict(torch=torch.__version__, transformers=__import__("transformers").__version__,
                                reference="wzf2000/GAMER @ /root/reference", sdpa_backend_for_grads="MATH"))

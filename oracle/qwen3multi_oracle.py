@@ -174,8 +174,29 @@ def _dropout(x, p, training):
     return F.dropout(x, p, training) if (training and p > 0) else x
 
 
-def attention(h, sd, prefix, ok, cfg: OracleConfig, cos, sin, act_idx=None, training=False, uniform_len=None):
+BF16 = torch.bfloat16
+
+
+def _linear(x, w, amp: bool):
+    """nn.Linear; under autocast (``amp``) both operands are cast to bf16 and the result is bf16 (fp32 accumulation
+    inside the matmul, one rounding on the way out)."""
+    if amp:
+        return F.linear(x.to(BF16), w.to(BF16))
+    return F.linear(x, w)
+
+
+def attention(h, sd, prefix, ok, cfg: OracleConfig, cos, sin, act_idx=None, training=False, uniform_len=None,
+              amp: bool = False):
     """Qwen3MultiAttention.forward (model.py:75-150) with the additive finfo.min mask folded in.
+
+    ``amp`` = the reference under ``torch.autocast(bfloat16)`` (its ``--bf16`` run, train_SMB_decoder.py:114-118,
+    407-408), restated with explicit casts: projections in bf16; q/k-norm in fp32 on what it is handed (a bf16
+    tensor for the self attention: the normalised value is rounded to bf16 before the fp32 weight multiply; an fp32
+    tensor for the cross attention, where the fp32 behaviour embedding was added first); RoPE in fp32; SDPA's q, k, v
+    AND its additive mask are cast to bf16 - finfo(float32).min is not representable and becomes -inf, and SDPA's
+    softmax returns 0 for a row whose scores are all -inf.  So under bf16 an "empty" query row contributes NOTHING
+    (output 0, no gradient) instead of the uniform average over all keys of the fp32 path.  Verified against the
+    reference executed under autocast on CPU (oracle/make_golden.py, fixtures *_bf16).
 
     A query row with no allowed key ends up with every masked score equal to finfo.min, so the
     softmax is uniform over all S keys (future and padded ones included) while autograd still
@@ -189,9 +210,9 @@ def attention(h, sd, prefix, ok, cfg: OracleConfig, cos, sin, act_idx=None, trai
     B, S, _ = h.shape
     nq, nkv, dh = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     cross = act_idx is not None
-    q = F.linear(h, sd[prefix + "q_proj.weight"]).view(B, S, nq, dh)
-    k = F.linear(h, sd[prefix + "k_proj.weight"]).view(B, S, nkv, dh)
-    v = F.linear(h, sd[prefix + "v_proj.weight"]).view(B, S, nkv, dh)
+    q = _linear(h, sd[prefix + "q_proj.weight"], amp).view(B, S, nq, dh)
+    k = _linear(h, sd[prefix + "k_proj.weight"], amp).view(B, S, nkv, dh)
+    v = _linear(h, sd[prefix + "v_proj.weight"], amp).view(B, S, nkv, dh)
     if cross:
         q = q + sd[prefix + "q_behavior_embedding.weight"][act_idx].view(B, S, nq, dh)
         k = k + sd[prefix + "k_behavior_embedding.weight"][act_idx].view(B, S, nkv, dh)
@@ -201,9 +222,26 @@ def attention(h, sd, prefix, ok, cfg: OracleConfig, cos, sin, act_idx=None, trai
     rep = nq // nkv
     kq = k.repeat_interleave(rep, dim=2)          # query head n uses kv head n // rep
     vq = v.repeat_interleave(rep, dim=2)
-    s = torch.einsum("bind,bjnd->bnij", q, kq) * (dh ** -0.5)
     empty = ~ok.any(-1)                           # [B,S]
     okb = ok[:, None, :, :]
+    if amp:
+        # SDPA under autocast: bf16 operands, fp32 scores / softmax statistics, un-normalised probabilities rounded to
+        # bf16 for the second product (what the fused kernels do), bf16 output; all -inf rows -> 0
+        qb, kb, vb = q.to(BF16).float(), kq.to(BF16).float(), vq.to(BF16).float()
+        s = torch.einsum("bind,bjnd->bnij", qb, kb) * (dh ** -0.5)
+        s = s.masked_fill(~okb, float("-inf"))
+        m = s.amax(-1, keepdim=True)
+        m = torch.where(torch.isinf(m), torch.zeros_like(m), m)
+        e = torch.exp(s - m)                                     # masked -> 0
+        l = e.sum(-1, keepdim=True)
+        e = _dropout(e, cfg.attention_dropout, training)
+        o = torch.einsum("bnij,bjnd->bind", e.to(BF16).float(), vb) / l.clamp_min(1e-30).transpose(1, 2)
+        o = torch.where(empty[:, :, None, None], torch.zeros_like(o), o).to(BF16).reshape(B, S, nq * dh)
+        out = _linear(o, sd[prefix + "o_proj.weight"], amp)
+        if cross:
+            out = out * F.silu(_linear(h, sd[prefix + "gating.weight"], amp))
+        return out
+    s = torch.einsum("bind,bjnd->bnij", q, kq) * (dh ** -0.5)
     s_norm = s.masked_fill(~okb, float("-inf"))
     s_empty = s - s.detach()
     if uniform_len is not None:
@@ -219,7 +257,7 @@ def attention(h, sd, prefix, ok, cfg: OracleConfig, cos, sin, act_idx=None, trai
     return out
 
 
-def sparse_mlp(h, sd, prefix, pos_idx, beh_idx, cfg: OracleConfig, inject: bool, training=False):
+def sparse_mlp(h, sd, prefix, pos_idx, beh_idx, cfg: OracleConfig, inject: bool, training=False, amp: bool = False):
     """MyQwen3SparseMLP.forward (FFN.py:53-72): every token goes through exactly one expert,
     chosen by its position index; layers in behavior_injection_decoder concatenate a
     behaviour embedding first."""
@@ -232,17 +270,17 @@ def sparse_mlp(h, sd, prefix, pos_idx, beh_idx, cfg: OracleConfig, inject: bool,
             continue
         x = h[sel]
         ep = f"{prefix}experts.expert_{e}."
-        g = F.linear(x, sd[ep + "gate_proj.weight"])
-        u = F.linear(x, sd[ep + "up_proj.weight"])
+        g = _linear(x, sd[ep + "gate_proj.weight"], amp)
+        u = _linear(x, sd[ep + "up_proj.weight"], amp)
         m = _dropout(F.silu(g) * u, cfg.dropout_rate, training)
-        out[sel] = F.linear(m, sd[ep + "down_proj.weight"])
+        out[sel] = _linear(m, sd[ep + "down_proj.weight"], amp).to(out.dtype)      # FFN.py:66-68
     return out
 
 
 def forward(sd: Dict[str, torch.Tensor], cfg: OracleConfig, input_ids, attention_mask, actions,
             labels=None, temperature: float = 1.0, num_items_in_batch: Optional[float] = None,
             training: bool = False, return_hidden: bool = False, act_zero_col: Optional[int] = None,
-            uniform_len: Optional[int] = None, session_ids=None, extended_session_ids=None):
+            uniform_len: Optional[int] = None, session_ids=None, extended_session_ids=None, amp: bool = False):
     """Qwen3MultiWithTemperature.forward (model.py:928-1013).
 
     ``session_ids`` given: the Qwen3SessionMulti variant (``session_mask_predicates``; with
@@ -252,6 +290,9 @@ def forward(sd: Dict[str, torch.Tensor], cfg: OracleConfig, input_ids, attention
     router then looks up only n items (router.py:160-163 with cache_position) and that token gets action index 0,
     which stays in the cross-attention K/V cache for the whole generation.  Passing the column reproduces it.
     ``uniform_len``: see ``attention``.
+
+    ``amp``: the reference under ``torch.autocast(bfloat16)`` (see ``attention``); parameters, the residual stream,
+    the norms and the loss stay fp32, the logits come out in bf16 and ``logits /= T`` rounds them once more.
 
     ``sd`` uses the reference's state-dict key names.  Returns a dict with ``logits`` (divided
     by the temperature when labels are given, as the reference's in-place ``logits /= T`` does),
@@ -284,21 +325,21 @@ def forward(sd: Dict[str, torch.Tensor], cfg: OracleConfig, input_ids, attention
         if return_hidden:
             hidden.append(x)
         h = rmsnorm(x, sd[lp + "input_layernorm.weight"], eps)
-        a = attention(h, sd, lp + "self_attn.", self_ok, cfg, cos, sin, None, training, uniform_len)
+        a = attention(h, sd, lp + "self_attn.", self_ok, cfg, cos, sin, None, training, uniform_len, amp)
         x = x + _dropout(a, cfg.dropout_rate, training)
         if l in cfg.cross_attention_decoder:
             h = rmsnorm(x, sd[lp + "post_self_attention_layernorm.weight"], eps)
-            a = attention(h, sd, lp + "cross_attn.", cross_ok, cfg, cos, sin, act_idx, training, uniform_len)
+            a = attention(h, sd, lp + "cross_attn.", cross_ok, cfg, cos, sin, act_idx, training, uniform_len, amp)
             x = x + _dropout(a, cfg.dropout_rate, training)
         h = rmsnorm(x, sd[lp + "post_cross_attention_layernorm.weight"], eps)
         m = sparse_mlp(h, sd, lp + "mlp.", pos_idx, beh_idx, cfg,
-                       l in cfg.behavior_injection_decoder, training)
+                       l in cfg.behavior_injection_decoder, training, amp)
         x = x + _dropout(m, cfg.dropout_rate, training)
     xn = rmsnorm(x, sd["model.norm.weight"], eps)
     if return_hidden:
         hidden.append(xn)
     head = sd.get("lm_head.weight", sd["model.embed_tokens.weight"])
-    logits = F.linear(xn, head)
+    logits = _linear(xn, head, amp)
     loss = None
     if labels is not None:
         logits = logits / temperature                      # model.py:913 (in place upstream)
@@ -388,7 +429,8 @@ def is_no_decay(key: str) -> bool:
     return key.endswith(NO_DECAY_SUFFIXES)
 
 
-def loss_and_grads(sd, cfg, batch, temperature=1.0, num_items_in_batch=None, training=False, session=False):
+def loss_and_grads(sd, cfg, batch, temperature=1.0, num_items_in_batch=None, training=False, session=False,
+                   amp: bool = False):
     """Forward + autograd backward; returns (loss, {key: grad}, forward-output) with the tied
     table's gradient under 'model.embed_tokens.weight' (head wgrad over all rows + gather
     scatter-add with the padding row's contribution dropped, as nn.Embedding(padding_idx) does)."""
@@ -397,7 +439,7 @@ def loss_and_grads(sd, cfg, batch, temperature=1.0, num_items_in_batch=None, tra
     view["lm_head.weight"] = leaves["model.embed_tokens.weight"]
     out = forward(view, cfg, batch["input_ids"], batch.get("attention_mask"), batch["actions"],
                   labels=batch.get("labels"), temperature=temperature,
-                  num_items_in_batch=num_items_in_batch, training=training,
+                  num_items_in_batch=num_items_in_batch, training=training, amp=amp,
                   session_ids=batch["session_ids"] if session else None,
                   extended_session_ids=batch["extended_session_ids"] if session else None)
     out["loss"].backward()

@@ -98,6 +98,47 @@ def test_gradients(golden, name):
             assert np.abs(got - ref).max() <= 1e-4 * scale + 1e-9, k
 
 
+# ---- the AMP variant: the reference executed under torch.autocast("cpu", bfloat16) (its --bf16 run) -------------------
+# Tolerances are bf16 noise, measured between two implementations of the same arithmetic (this oracle with explicit
+# casts vs the reference's autocast): logits 4e-3 of their abs-max, per-tensor gradient norms 5e-3, single gradient
+# entries 3e-2 of the tensor's abs-max.  The SEMANTIC difference to the fp32 path - an "empty" query row gives 0 under
+# bf16 because the finfo.min mask becomes -inf - is 20x to 40x larger (7.6e-2 / 1.5e-1 on these fixtures) and is
+# asserted below, so a kernel that kept the fp32 rule cannot pass.
+@pytest.mark.parametrize("name", ["small_bf16", "full_bf16"])
+def test_amp_forward_and_gradients(golden, name):
+    z, meta, cfg, sd, batch = _setup(golden, name)
+    z32, _ = golden(name[:-5])
+    assert meta["autocast"] == "bfloat16" and str(z["logits_dtype"]) == "torch.bfloat16"
+    key = "logits_raw" if "logits_raw" in z.files else "logits_raw_sample"
+    with torch.no_grad():
+        out = forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["actions"], amp=True)
+        out32 = forward(sd, cfg, batch["input_ids"], batch["attention_mask"], batch["actions"])
+    assert out["logits"].dtype == torch.bfloat16
+    got, got32 = out["logits"].float(), out32["logits"]
+    if key.endswith("sample"):
+        got, got32 = got[:, ::37, ::53], got32[:, ::37, ::53]
+    ref = torch.from_numpy(z[key])
+    amax = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 1e-2 * amax
+    assert float((got32 - ref).abs().max()) > 5e-2 * amax          # the fp32 rule (uniform empty rows) is NOT the bf16 run
+    np.testing.assert_allclose(got32.numpy(), z32[key], atol=1e-5)   # ... it is the fp32 fixture
+    loss, grads, _ = loss_and_grads(sd, cfg, batch, temperature=meta["temperature"], amp=True)
+    assert abs(float(loss) - float(z["loss_train_mode"])) < 5e-4
+    gkeys = [str(k) for k in z["grad_keys"]]
+    norms = np.array([float(grads[k].double().norm()) for k in gkeys])
+    np.testing.assert_allclose(norms, z["grad_norms"], rtol=2e-2, atol=1e-9)
+    gn = float(np.sqrt((norms ** 2).sum()))
+    assert abs(gn - float(z["global_grad_norm"])) < 3e-3 * float(z["global_grad_norm"])
+    # MATH and default SDPA dispatch agree under bf16 (they do not in fp32: SURVEY section 0)
+    assert abs(float(z["global_grad_norm_default_sdpa"]) - float(z["global_grad_norm"])) < 2e-3 * float(z["global_grad_norm"])
+    for k in z.files:
+        if k.startswith("grad::") or k.startswith("gradsample::"):
+            g = grads[k.split("::")[1]]
+            got = g.numpy() if k.startswith("grad::") else g[::max(1, g.shape[0] // 8), ::max(1, g.shape[1] // 8)].numpy()
+            scale = max(np.abs(z[k]).max(), 1e-12)
+            assert np.abs(got - z[k]).max() <= 6e-2 * scale, k
+
+
 def test_empty_rows_exist_in_fixtures(golden):
     """The cross-attention fixtures must exercise the 'no allowed key -> uniform over all S keys' rule."""
     from oracle.qwen3multi_oracle import mask_predicates
