@@ -46,6 +46,29 @@ class GemmDesc(C.Structure):
     ]
 
 
+class GemmBf16Desc(C.Structure):
+    """Mirror of gamer_gemm_bf16_desc."""
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_int64),
+        ("B", c_void_p), ("ldb", c_int64),
+        ("C", c_void_p), ("ldc", c_int64),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("accumulate", c_int),
+        ("groups", c_int),
+        ("group_mode", c_int),
+        ("group_offsets", c_void_p),
+        ("strideB", c_int64), ("strideC", c_int64),
+        ("kchunk", c_int),
+        ("resid", c_void_p),
+        ("row_map", c_void_p),
+        ("p_drop", c_float),
+        ("seed", c_uint64),
+        ("rowdot_other", c_void_p),
+        ("rowdot_out", c_void_p),
+        ("rowdot_S", c_int),
+    ]
+
+
 P, I, F, L, U = c_void_p, c_int, c_float, c_int64, c_uint64
 
 # name -> argtypes (everything returns int except the two noted below)
@@ -60,6 +83,10 @@ _SIGNATURES = {
     "gamer_rowtable_fwd": [P, P, P, I, I, P, I, I, P],
     "gamer_rowtable_bwd": [P, I, I, P, P, I, I, I, P, P],
     "gamer_gemm_f32": [C.POINTER(GemmDesc), P],
+    "gamer_gemm_bf16": [C.POINTER(GemmBf16Desc), P],
+    "gamer_cast_params_bf16": [P, P, P, P, I, I, P],
+    "gamer_attn_fwd_bf16": [P, I, P, I, P, I, P, P, I, I, I, I, F, F, U, P, P, P, P],
+    "gamer_attn_bwd_bf16": [P, I, P, I, P, I, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, I, P],
     "gamer_session_spans": [P, P, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P],
     "gamer_qknorm_rope_fwd": [P, I, I, I, I, P, P, F, P, P, P, P, P, P, P, P, P, P],
     "gamer_qknorm_rope_bwd": [P, P, P, I, I, I, I, P, P, F, P, P, P, P, P, I, P, P, P, P, P, P, P, P, L, P],

@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgamer_hip.so")
-SOURCES = ["prep.hip", "elementwise.hip", "gemm.hip", "attention.hip", "optim.hip", "decode.hip", "modules.hip"]
+SOURCES = ["prep.hip", "elementwise.hip", "gemm.hip", "gemm_bf16.hip", "attention.hip", "attention_bf16.hip", "optim.hip", "decode.hip",
+           "modules.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++20", "-Wall", "-Wno-unused-function"]
 
 
@@ -52,7 +53,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -1,0 +1,562 @@
+// bf16 MFMA GEMM for gfx950 (v_mfma_f32_32x32x16_bf16, fp32 accumulate) - the AMP variant of the nn.Linear sites.
+//
+// Two kernels, both 128 x 128 workgroup tiles, 4 waves as 2 x 2, each wave a 64 x 64 patch = 2 x 2 MFMA tiles of
+// 32 x 32 (64 accumulator registers), operand tiles global -> registers -> LDS, double buffered, one barrier per
+// K-step of 64:
+//
+//   gemm_bf16_kernel   C[m][n] = sum_k A[m][k] * B[n][k]      both operands K-CONTIGUOUS (Linear forward; the dgrad
+//       GEMMs run in this form too, against a transposed bf16 copy of the weights that the optimizer refreshes once per
+//       step - 49 MB against GB-sized activations).  LDS image [row][64 + 8] bf16: the 8 k-values of one MFMA operand
+//       are one conflict-free ds_read_b128.  Epilogues: bf16 store (optionally +=), fp32 residual + dropout store
+//       (the decoder layer's three residual sites), bf16 store + row-dot (attention backward's delta).
+//   gemm_bf16_wgrad_kernel   C[m][n] += sum_t A[t][m] * B[t][n]   the contraction runs over TOKENS, so both operands
+//       are strided in k.  Tiles are staged as they lie in memory ([token][128 columns], 256-byte rows, 16-byte chunks
+//       XOR-swizzled by the token's low bits) and read with ds_read_b64_tr_b16: the hardware transposing read hands
+//       every lane 4 consecutive tokens of its column, two reads = the 8 k-values of a fragment, conflict-free.
+//       Split over token chunks, combined with fp32 atomics (one accumulator register = two 128-byte row segments,
+//       the shape the memory-side atomic units take at full rate).
+#include "common.h"
+#include <stdlib.h>
+
+namespace gamer {
+
+constexpr int HB_BM = 128, HB_BN = 128, HB_BK = 64;
+constexpr int HB_THREADS = 256;
+constexpr int HB_LD = HB_BK + 8;                       // bf16 elements per row of a K-contiguous tile image (144 B)
+constexpr int HB_TILE = HB_BM * HB_LD;                 // elements per operand image
+constexpr int HB_LDS_BYTES = 4 * HB_TILE * 2;          // 2 operands x 2 buffers = 73,728 B -> two workgroups per CU
+constexpr int HW_TILE = HB_BK * 128;                   // wgrad: [64 tokens][128 columns] elements per operand image
+constexpr int HW_LDS_BYTES = 4 * HW_TILE * 2;          // 65,536 B
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmBf16Params {
+    const bf16_t* A; int64_t lda;
+    const bf16_t* B; int64_t ldb;
+    void* C; int64_t ldc;
+    int M, N, K;
+    int accumulate;
+    int groups;
+    const int32_t* group_offsets;
+    int64_t strideB, strideC;
+    int kchunk;
+    int m_tiles, n_tiles;
+    const float* resid;
+    const int32_t* row_map;
+    float p_drop;
+    uint64_t seed;
+    const bf16_t* rowdot_other;
+    float* rowdot_out;
+    int rowdot_S;
+};
+
+__device__ __forceinline__ int xcd_remap_b(int id, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = id & 7, idx = id >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// =================================================================================================
+// K-contiguous x K-contiguous
+// =================================================================================================
+// EPI 0: C bf16 (= or +=); EPI 1: C fp32 = resid + dropout(acc), rows optionally scattered through row_map;
+// EPI 2: C bf16 + rowdot_out[b][head][i] = sum over the head's 64 columns of acc * other (full tiles only)
+template <int EPI, bool ACCUM>
+__global__ void __launch_bounds__(HB_THREADS, 2)
+gemm_bf16_kernel(const GemmBf16Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);           // buffer b: A image at 2*b*HB_TILE, B image behind it
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int L = xcd_remap_b(blockIdx.x, gridDim.x);
+
+    const int mt = L / p.n_tiles;
+    const int col0 = (L % p.n_tiles) * HB_BN;
+    int g = 0, seg_beg = 0, seg_end = p.M, tiles_before = 0;
+    bool found = false;
+    if (p.group_offsets) {
+        int prev = p.group_offsets[0];
+        for (int gi = 0; gi < p.groups; ++gi) {
+            const int nxt = p.group_offsets[gi + 1];
+            const int tiles = (nxt - prev + HB_BM - 1) / HB_BM;
+            if (!found && mt < tiles_before + tiles) { g = gi; seg_beg = prev; seg_end = nxt; found = true; }
+            if (!found) tiles_before += tiles;
+            prev = nxt;
+        }
+    } else {
+        found = mt < (p.M + HB_BM - 1) / HB_BM;
+    }
+    if (!found) return;
+    const int row0 = seg_beg + (mt - tiles_before) * HB_BM;
+    const int row_end = seg_end;
+    const int col_end = p.N;
+    const bf16_t* Bp = p.B + (int64_t)g * p.strideB;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nkt = p.K / HB_BK;                                  // K % 64 == 0 (checked on the host)
+    const bool a_in = row0 + HB_BM <= row_end, b_in = col0 + HB_BN <= col_end;   // workgroup-uniform
+    // chunk f = tid + 256 j of a tile: row f >> 3, 16-byte k-chunk f & 7.  Rows past the end are read from the last
+    // valid row (their results are never stored), so there is no predicate anywhere in the loads.
+    const bf16_t* pa[4];
+    const bf16_t* pb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = tid + HB_THREADS * j;
+        const int ra = min(row0 + (f >> 3), row_end - 1);
+        const int rb = min(col0 + (f >> 3), col_end - 1);
+        pa[j] = p.A + (int64_t)ra * p.lda + ((f & 7) << 3);
+        pb[j] = Bp + (int64_t)rb * p.ldb + ((f & 7) << 3);
+    }
+    uint4 ra[4], rb[4];
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ra[j] = *reinterpret_cast<const uint4*>(pa[j]); pa[j] += HB_BK; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { rb[j] = *reinterpret_cast<const uint4*>(pb[j]); pb[j] += HB_BK; }
+    };
+    auto store_tile = [&](bf16_t* dst) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + HB_THREADS * j;
+            *reinterpret_cast<uint4*>(dst + (f >> 3) * HB_LD + ((f & 7) << 3)) = ra[j];
+            *reinterpret_cast<uint4*>(dst + HB_TILE + (f >> 3) * HB_LD + ((f & 7) << 3)) = rb[j];
+        }
+    };
+    // a wave whose 64 x 64 patch lies entirely past the edge of C (N = 320 leaves half of the last column tile empty)
+    // issues no MFMAs
+    const bool wave_live = (row0 + wm * 64 < row_end) && (col0 + wn * 64 < col_end);
+    auto mfma_tile = [&](const bf16_t* as) {
+        if (!wave_live) return;
+        const bf16_t* bs = as + HB_TILE;
+#pragma unroll
+        for (int s = 0; s < HB_BK / 16; ++s) {
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(as + (wm * 64 + i * 32 + r32) * HB_LD + 16 * s + 8 * h);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bf[j] = *reinterpret_cast<const bf16x8*>(bs + (wn * 64 + j * 32 + r32) * HB_LD + 16 * s + 8 * h);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (nkt > 0) {
+        load_tile();
+        store_tile(smem);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) load_tile();
+        mfma_tile(smem + 2 * cur * HB_TILE);
+        if (more) store_tile(smem + 2 * (cur ^ 1) * HB_TILE);
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[i][j][r] is C[row = (r&3)+8*(r>>2)+4*h][col = lane&31] of its 32x32 tile --
+    const bool interior = a_in && b_in;
+    const bool c_f32 = EPI == 1;
+    if (interior && (p.ldc & 7) == 0) {
+        // Row-major rewrite through LDS (the K-loop images are dead after its last barrier): each wave parks its
+        // 64 x 64 patch as [64][68] floats and reads it back row-wise.
+        float* patch = reinterpret_cast<float*>(smem_raw) + wid * (64 * 68);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    patch[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + j * 32 + r32] = acc[i][j][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): own LDS writes landed (wave-private patch)
+        if (c_f32) {
+            // fp32 residual stream: 16 lanes x float4 per row, 4 rows per store instruction
+            float* Cp = reinterpret_cast<float*>(p.C);
+            const int c4 = (lane & 15) << 2;
+            const DropoutRng rng(p.p_drop, p.seed);
+            const int row_first = row0 + wm * 64 + (lane >> 4);
+            const int col = col0 + wn * 64 + c4;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int lr = (lane >> 4) + 4 * it;
+                const float4 v = *reinterpret_cast<const float4*>(patch + lr * 68 + c4);
+                const int64_t rc = p.row_map ? (int64_t)p.row_map[row_first + 4 * it] : (int64_t)(row_first + 4 * it);
+                const int64_t e = rc * p.ldc + col;
+                const float4 x = *reinterpret_cast<const float4*>(p.resid + e);
+                float m[4];
+                rng.mult4((uint32_t)(e >> 2), m);
+                float4 o;
+                o.x = x.x + m[0] * v.x; o.y = x.y + m[1] * v.y; o.z = x.z + m[2] * v.z; o.w = x.w + m[3] * v.w;
+                *reinterpret_cast<float4*>(Cp + e) = o;
+            }
+        } else {
+            // bf16 activations: 8 lanes x 8 elements (16 bytes) per row, 8 rows per store instruction
+            bf16_t* Cp = reinterpret_cast<bf16_t*>(p.C);
+            const int c8 = (lane & 7) << 3;
+            const int row_first = row0 + wm * 64 + (lane >> 3);
+            const int col = col0 + wn * 64 + c8;
+            bf16x8 oth[EPI == 2 ? 8 : 1];
+            if (EPI == 2) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it)
+                    oth[it] = *reinterpret_cast<const bf16x8*>(p.rowdot_other + (int64_t)(row_first + 8 * it) * p.ldc + col);
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int lr = (lane >> 3) + 8 * it;
+                const float4 v0 = *reinterpret_cast<const float4*>(patch + lr * 68 + c8);
+                const float4 v1 = *reinterpret_cast<const float4*>(patch + lr * 68 + c8 + 4);
+                f32x8v v = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                bf16_t* dst = Cp + (int64_t)(row_first + 8 * it) * p.ldc + col;
+                if (ACCUM) {
+                    const bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
+                }
+                const bf16x8 o = __builtin_convertvector(v, bf16x8);
+                *reinterpret_cast<bf16x8*>(dst) = o;
+                if (EPI == 2) {
+                    // the wave's 64-column patch is exactly one head: 8 lanes hold one row of it.  delta uses the
+                    // ROUNDED dO (what the attention backward reads), times O.
+                    float d = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d += (float)o[e] * (float)oth[EPI == 2 ? it : 0][e];
+                    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+                    if ((lane & 7) == 0) {
+                        const int row = row_first + 8 * it;
+                        const int heads = p.N >> 6, head = (col0 + wn * 64) >> 6;
+                        p.rowdot_out[((int64_t)(row / p.rowdot_S) * heads + head) * p.rowdot_S + row % p.rowdot_S] = d;
+                    }
+                }
+            }
+        }
+    } else {
+        // edge tiles: element-wise stores with bounds checks
+        const DropoutRng rng(EPI == 1 ? p.p_drop : 0.f, p.seed);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = col0 + wn * 64 + j * 32 + r32;
+                const int rbase = row0 + wm * 64 + i * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < row_end && col < col_end) {
+                        const float v = acc[i][j][r];
+                        if (c_f32) {
+                            const int64_t rc = p.row_map ? (int64_t)p.row_map[row] : (int64_t)row;
+                            const int64_t e = rc * p.ldc + col;
+                            float m[4];
+                            rng.mult4((uint32_t)(e >> 2), m);
+                            reinterpret_cast<float*>(p.C)[e] = p.resid[e] + m[e & 3] * v;
+                        } else {
+                            bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (int64_t)row * p.ldc + col;
+                            *dst = (bf16_t)(ACCUM ? v + (float)*dst : v);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// wgrad: contraction over tokens, both operands token-major
+// =================================================================================================
+// chunk c (16 bytes = 8 columns) of token row t lives at physical chunk c ^ ((t & 3) << 2) of its 256-byte LDS row
+__device__ __forceinline__ int hw_off(int t, int chunk) { return t * 128 + ((chunk ^ ((t & 3) << 2)) << 3); }
+
+__global__ void __launch_bounds__(HB_THREADS, 2)
+gemm_bf16_wgrad_kernel(const GemmBf16Params p, const bf16_t* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);           // buffer b: A image at 2*b*HW_TILE, B image behind it
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int L = xcd_remap_b(blockIdx.x, gridDim.x);
+
+    const int tiles_mn = p.m_tiles * p.n_tiles;
+    const int chunk = L / tiles_mn;
+    const int tile = L % tiles_mn;
+    const int row0 = (tile / p.n_tiles) * HB_BM;       // first column of A (= row of C)
+    const int col0 = (tile % p.n_tiles) * HB_BN;       // first column of B (= column of C)
+    int g = 0, seg_beg = 0, seg_end = p.K, chunks_before = 0;
+    bool found = false;
+    if (p.group_offsets) {
+        int prev = p.group_offsets[0];
+        for (int gi = 0; gi < p.groups; ++gi) {
+            const int nxt = p.group_offsets[gi + 1];
+            const int chunks = (nxt - prev + p.kchunk - 1) / p.kchunk;
+            if (!found && chunk < chunks_before + chunks) { g = gi; seg_beg = prev; seg_end = nxt; found = true; }
+            if (!found) chunks_before += chunks;
+            prev = nxt;
+        }
+    } else {
+        found = chunk < (p.K + p.kchunk - 1) / p.kchunk;
+    }
+    if (!found) return;
+    const int kbeg = seg_beg + (chunk - chunks_before) * p.kchunk;
+    const int kend = min(seg_end, kbeg + p.kchunk);
+    float* Cp = reinterpret_cast<float*>(p.C) + (int64_t)g * p.strideC;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // chunk f = tid + 256 j of a tile: token f >> 4, 16-byte column chunk f & 15.  Column chunks past the operand's
+    // width are read from its last chunk (those rows / columns of C are never stored); tokens past the end of the
+    // segment are read from a page of zeros (they must not contribute).
+    const int a_cmax = ((p.M + 7) >> 3) - 1, b_cmax = ((p.N + 7) >> 3) - 1;        // last readable chunk (ld >= round_up(., 8))
+    int ca[4], cb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = tid + HB_THREADS * j;
+        ca[j] = min((row0 >> 3) + (f & 15), a_cmax) << 3;
+        cb[j] = min((col0 >> 3) + (f & 15), b_cmax) << 3;
+    }
+    uint4 ra[4], rb[4];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + HB_THREADS * j;
+            const int t = k0 + (f >> 4);
+            const bool ok = t < kend;
+            const bf16_t* sa = ok ? p.A + (int64_t)t * p.lda + ca[j] : zeros;
+            const bf16_t* sb = ok ? p.B + (int64_t)t * p.ldb + cb[j] : zeros;
+            ra[j] = *reinterpret_cast<const uint4*>(sa);
+            rb[j] = *reinterpret_cast<const uint4*>(sb);
+        }
+    };
+    auto store_tile = [&](bf16_t* dst) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + HB_THREADS * j;
+            const int off = hw_off(f >> 4, f & 15);
+            *reinterpret_cast<uint4*>(dst + off) = ra[j];
+            *reinterpret_cast<uint4*>(dst + HW_TILE + off) = rb[j];
+        }
+    };
+    const bool wave_live = (row0 + wm * 64 < p.M) && (col0 + wn * 64 < p.N);
+    // transposing read: lane 16g + 4q + pp of a wave supplies the address of (token 4-block row q, columns 4pp..4pp+3)
+    // of its group's 4 x 16 block and receives column (lane & 15) of the four tokens
+    const int q = (lane >> 2) & 3, pp = lane & 3, gsel = (lane >> 4) & 1;
+    auto frag = [&](const bf16_t* img, int cbase, int sub) {
+        // 8 k-values (tokens 16*sub + 8*h + 0..7) of column cbase + r32
+        const int col = cbase + 16 * gsel + 4 * pp;
+        bf16x8 out;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int t = 16 * sub + 8 * h + 4 * c + q;
+            const bf16_t* src = img + hw_off(t, col >> 3) + (col & 7);
+            const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (bf16x4 __attribute__((address_space(3)))*)(src));
+            out[4 * c + 0] = v[0]; out[4 * c + 1] = v[1]; out[4 * c + 2] = v[2]; out[4 * c + 3] = v[3];
+        }
+        return out;
+    };
+    auto mfma_tile = [&](const bf16_t* as) {
+        if (!wave_live) return;
+        const bf16_t* bs = as + HW_TILE;
+#pragma unroll
+        for (int s = 0; s < HB_BK / 16; ++s) {
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = frag(as, wm * 64 + i * 32, s);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = frag(bs, wn * 64 + j * 32, s);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    const int nkt = (kend - kbeg + HB_BK - 1) / HB_BK;
+    if (nkt > 0) {
+        load_tile(kbeg);
+        store_tile(smem);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) load_tile(kbeg + (kt + 1) * HB_BK);
+        mfma_tile(smem + 2 * cur * HW_TILE);
+        if (more) store_tile(smem + 2 * (cur ^ 1) * HW_TILE);
+        __syncthreads();
+    }
+    if (!wave_live) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + wn * 64 + j * 32 + r32;
+            const int rbase = row0 + wm * 64 + i * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < p.M && col < p.N) atomicAdd(Cp + (int64_t)row * p.ldc + col, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+// [rows][cols] fp32 -> bf16 copy and/or transposed bf16 copy ([cols][ldt], columns >= rows left untouched): the
+// operand copies of the parameters that the bf16 GEMMs read.  One launch covers every matrix of a table.
+struct CastEntry { int64_t src, dst, dst_t; int rows, cols, ldt, tile0; };
+__global__ void __launch_bounds__(256)
+cast_params_kernel(const float* __restrict__ flat, bf16_t* __restrict__ out, bf16_t* __restrict__ out_t,
+                   const CastEntry* __restrict__ table, int n_entries) {
+    __shared__ float tile[32][33];
+    int e = 0;
+    for (int i = 1; i < n_entries; ++i) e = ((int)blockIdx.x >= table[i].tile0) ? i : e;
+    const CastEntry ce = table[e];
+    const int tiles_c = (ce.cols + 31) / 32;
+    const int tl = blockIdx.x - ce.tile0;
+    const int r0 = (tl / tiles_c) * 32, c0 = (tl % tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    const float* src = flat + ce.src;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        const float v = (r < ce.rows && c < ce.cols) ? src[(int64_t)r * ce.cols + c] : 0.f;
+        tile[ty + 8 * k][tx] = v;
+        if (out && r < ce.rows && c < ce.cols) out[ce.dst + (int64_t)r * ce.cols + c] = (bf16_t)v;
+    }
+    __syncthreads();
+    if (out_t && ce.dst_t >= 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + ty + 8 * k, r = r0 + tx;               // transposed: row index c, column index r
+            if (c < ce.cols && r < ce.rows) out_t[ce.dst_t + (int64_t)c * ce.ldt + r] = (bf16_t)tile[tx][ty + 8 * k];
+        }
+    }
+}
+
+}  // namespace gamer
+
+using namespace gamer;
+
+static const bf16_t* zero_page() {
+    static bf16_t* page = nullptr;
+    if (!page) {
+        if (hipMalloc(reinterpret_cast<void**>(&page), 4096) != hipSuccess) return nullptr;
+        if (hipMemset(page, 0, 4096) != hipSuccess) return nullptr;
+    }
+    return page;
+}
+
+template <int EPI, bool ACCUM>
+static int launch_hb(const GemmBf16Params& p, int blocks, hipStream_t st) {
+    static bool attr = false;
+    auto kfn = gemm_bf16_kernel<EPI, ACCUM>;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           HB_LDS_BYTES);
+        if (e != hipSuccess) { set_error("gamer_gemm_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        attr = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, st, p);
+    GAMER_CHECK_LAUNCH("gamer_gemm_bf16");
+    return 0;
+}
+
+extern "C" int gamer_gemm_bf16(const gamer_gemm_bf16_desc* d, void* stream) {
+    GAMER_CHECK_ARG(d, "gamer_gemm_bf16: null descriptor");
+    GAMER_CHECK_ARG(d->A && d->B && d->C, "gamer_gemm_bf16: null matrix pointer");
+    GAMER_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gamer_gemm_bf16: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+    GAMER_CHECK_ARG(d->lda % 8 == 0 && d->ldb % 8 == 0 && aligned16(d->A) && aligned16(d->B),
+                    "gamer_gemm_bf16: A and B must be 16-byte aligned with leading dims %% 8 == 0 (lda=%lld ldb=%lld)",
+                    (long long)d->lda, (long long)d->ldb);
+    GAMER_CHECK_ARG(d->groups >= 1 && (d->groups == 1 || d->group_offsets), "gamer_gemm_bf16: groups=%d needs group_offsets", d->groups);
+    GAMER_CHECK_ARG(d->group_mode == 0 || d->group_mode == 1, "gamer_gemm_bf16: group_mode=%d", d->group_mode);
+    GemmBf16Params p;
+    p.A = (const bf16_t*)d->A; p.lda = d->lda;
+    p.B = (const bf16_t*)d->B; p.ldb = d->ldb;
+    p.C = d->C; p.ldc = d->ldc;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.accumulate = d->accumulate;
+    p.groups = d->groups; p.group_offsets = d->group_offsets;
+    p.strideB = d->strideB; p.strideC = d->strideC;
+    p.kchunk = d->kchunk;
+    p.resid = d->resid; p.row_map = d->row_map; p.p_drop = d->p_drop; p.seed = d->seed;
+    p.rowdot_other = (const bf16_t*)d->rowdot_other; p.rowdot_out = d->rowdot_out; p.rowdot_S = d->rowdot_S;
+    p.n_tiles = (d->N + HB_BN - 1) / HB_BN;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->group_mode == 0) {
+        GAMER_CHECK_ARG(d->K % HB_BK == 0 && d->lda >= d->K && d->ldb >= d->K,
+                        "gamer_gemm_bf16: the K-contiguous form needs K %% 64 == 0 (K=%d) and lda, ldb >= K", d->K);
+        GAMER_CHECK_ARG(d->ldc >= d->N && d->strideB % 8 == 0, "gamer_gemm_bf16: ldc=%lld < N or strideB %% 8 != 0", (long long)d->ldc);
+        GAMER_CHECK_ARG(!d->resid || (!d->accumulate && !d->rowdot_out && d->ldc % 4 == 0 && aligned16(d->resid) &&
+                                      aligned16(d->C) && d->p_drop >= 0.f && d->p_drop < 1.f),
+                        "gamer_gemm_bf16: the residual epilogue writes fp32 C: ldc %% 4 == 0, no accumulate / row-dot");
+        GAMER_CHECK_ARG(!d->rowdot_out || (d->rowdot_other && d->rowdot_S > 0 && d->groups == 1 && !d->accumulate &&
+                                           d->M % HB_BM == 0 && d->N % HB_BN == 0 && d->M % d->rowdot_S == 0 &&
+                                           d->ldc % 8 == 0 && aligned16(d->rowdot_other) && aligned16(d->C)),
+                        "gamer_gemm_bf16: the row-dot epilogue needs full 128 x 128 tiles (M=%d N=%d), one group, ldc %% 8 == 0",
+                        d->M, d->N);
+        p.m_tiles = (d->M + HB_BM - 1) / HB_BM + (d->group_offsets ? d->groups : 0);
+        const int64_t blocks = (int64_t)p.m_tiles * p.n_tiles;
+        GAMER_CHECK_ARG(blocks < (1LL << 31), "gamer_gemm_bf16: grid too large");
+        if (d->resid) return launch_hb<1, false>(p, (int)blocks, st);
+        if (d->rowdot_out) return launch_hb<2, false>(p, (int)blocks, st);
+        if (d->accumulate) return launch_hb<0, true>(p, (int)blocks, st);
+        return launch_hb<0, false>(p, (int)blocks, st);
+    }
+    // wgrad
+    GAMER_CHECK_ARG(d->kchunk >= HB_BK && d->kchunk % HB_BK == 0, "gamer_gemm_bf16: kchunk=%d must be a positive multiple of 64", d->kchunk);
+    GAMER_CHECK_ARG(d->lda >= ((d->M + 7) / 8) * 8 && d->ldb >= ((d->N + 7) / 8) * 8,
+                    "gamer_gemm_bf16: wgrad operands need leading dims >= their width rounded up to 8 (lda=%lld M=%d ldb=%lld N=%d)",
+                    (long long)d->lda, d->M, (long long)d->ldb, d->N);
+    GAMER_CHECK_ARG(!d->resid && !d->rowdot_out, "gamer_gemm_bf16: no fused epilogue in the wgrad form");
+    const bf16_t* zp = zero_page();
+    GAMER_CHECK_ARG(zp, "gamer_gemm_bf16: could not allocate the zero page");
+    p.m_tiles = (d->M + HB_BM - 1) / HB_BM;
+    const int64_t chunks = (d->K + d->kchunk - 1) / d->kchunk + (d->group_offsets ? d->groups : 0);
+    const int64_t blocks = chunks * p.m_tiles * p.n_tiles;
+    GAMER_CHECK_ARG(blocks < (1LL << 31), "gamer_gemm_bf16: grid too large");
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_wgrad_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, HW_LDS_BYTES);
+        if (e != hipSuccess) { set_error("gamer_gemm_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        attr = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_wgrad_kernel, dim3((int)blocks), dim3(HB_THREADS), HW_LDS_BYTES, st, p, zp);
+    GAMER_CHECK_LAUNCH("gamer_gemm_bf16/wgrad");
+    return 0;
+}
+
+extern "C" int gamer_cast_params_bf16(const float* flat, gamer_bf16* out, gamer_bf16* out_t, const int64_t* table,
+                                      int n_entries, int n_tiles, void* stream) {
+    GAMER_CHECK_ARG(flat && table && (out || out_t) && n_entries > 0 && n_tiles > 0, "gamer_cast_params_bf16: bad arguments");
+    static_assert(sizeof(CastEntry) == 5 * sizeof(int64_t), "CastEntry layout");
+    hipLaunchKernelGGL(cast_params_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, flat, (bf16_t*)out,
+                       (bf16_t*)out_t, reinterpret_cast<const CastEntry*>(table), n_entries);
+    GAMER_CHECK_LAUNCH("gamer_cast_params_bf16");
+    return 0;
+}

@@ -132,6 +132,87 @@ class _LayerW:
         self.beh = v[lp + "mlp.behavior_embedding.weight"] if self.inject else None
 
 
+class Bf16Shadow:
+    """bf16 operand copies of the fp32 master parameters for the AMP variant (the reference's autocast casts the weight
+    of every F.linear to bf16 on the fly; here the cast happens once per optimizer step):
+
+      flat16   same offsets as the fp32 flat buffer (k-contiguous operands of the forward and weight-gradient GEMMs)
+      flatT    the TRANSPOSED matrices, so that the input-gradient GEMMs dX = dY W are k-contiguous on both sides as
+               well (gamer_gemm_bf16); the tied head's transpose is [H, round_up(V, 64)] with zero padding (its
+               contraction runs over the padded vocabulary).
+    One gamer_cast_params_bf16 launch refreshes both (98 MB read, 98 MB written)."""
+
+    def __init__(self, cfg: Qwen3MultiConfig, layout: ParamLayout, flat_p: torch.Tensor):
+        dev = flat_p.device
+        H, dh = cfg.hidden_size, cfg.head_dim
+        nq, nkv, I, E = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size, cfg.num_experts
+        QKV = (nq + 2 * nkv) * dh
+        self.layout, self.flat_p = layout, flat_p
+        self.flat16 = torch.zeros(layout.numel, dtype=torch.bfloat16, device=dev)
+        self.ldv = _round_up(cfg.vocab_size, 64)
+        entries = []          # (src offset, rows, cols, ldt, key of the transposed view)
+        toff = 0
+        self.t_views: Dict[str, Tuple[int, tuple]] = {}
+
+        def add(first: str, rows: int, cols: int, ldt: Optional[int] = None, tkey: Optional[str] = None):
+            nonlocal toff
+            src = layout.entries[first][0]
+            ldt = ldt or rows
+            entries.append((src, rows, cols, ldt, toff))
+            self.t_views[tkey or first] = (toff, (cols, ldt))
+            toff += _round_up(cols * ldt, 8)
+
+        add("model.embed_tokens.weight", cfg.vocab_size, H, ldt=self.ldv)
+        for l in range(cfg.num_hidden_layers):
+            lp = f"model.layers.{l}."
+            cross = l in cfg.cross_attention_decoder
+            din = H + (cfg.behavior_embedding_dim if l in cfg.behavior_injection_decoder else 0)
+            for a in (["self_attn", "cross_attn"] if cross else ["self_attn"]):
+                add(lp + a + ".q_proj.weight", QKV, H, tkey=lp + a + ".qkv")
+                add(lp + a + ".o_proj.weight", H, nq * dh)
+                if a == "cross_attn":
+                    add(lp + a + ".gating.weight", H, H)
+            for kind, rows, cols in (("gate_proj", I, din), ("up_proj", I, din), ("down_proj", H, I)):
+                for e in range(E):
+                    add(f"{lp}mlp.experts.expert_{e}.{kind}.weight", rows, cols)
+        self.flatT = torch.zeros(toff, dtype=torch.bfloat16, device=dev)
+        tab, tile0 = [], 0
+        for src, rows, cols, ldt, dst_t in entries:
+            tab += [src, src, dst_t, rows | (cols << 32), ldt | (tile0 << 32)]
+            tile0 += ((rows + 31) // 32) * ((cols + 31) // 32)
+        self.n_entries, self.n_tiles = len(entries), tile0
+        self.table = torch.tensor(tab, dtype=torch.int64, device=dev)
+        self.params16 = layout.views(self.flat16)
+
+    def refresh(self):
+        ops.cast_params_bf16(self.flat_p, self.flat16, self.flatT, self.table, self.n_entries, self.n_tiles)
+
+    def t(self, key: str) -> torch.Tensor:
+        """[cols, ldt] view of the transposed copy of matrix `key`."""
+        off, shp = self.t_views[key]
+        return self.flatT[off:off + shp[0] * shp[1]].view(shp)
+
+
+class _LayerWT:
+    """Transposed bf16 weight views of one decoder layer (dgrad operands of the AMP variant)."""
+
+    def __init__(self, cfg, sh: Bf16Shadow, l: int):
+        lp = f"model.layers.{l}."
+        cross = l in cfg.cross_attention_decoder
+
+        def attn(a):
+            d = dict(qkv=sh.t(lp + a + ".qkv"), o=sh.t(lp + a + ".o_proj.weight"))
+            if a == "cross_attn":
+                d["gate"] = sh.t(lp + a + ".gating.weight")
+            return d
+        self.self_attn = attn("self_attn")
+        self.cross_attn = attn("cross_attn") if cross else None
+        # expert e's transposed matrix sits e * (cols * rows) behind expert 0's (consecutive add() calls, sizes % 8 == 0)
+        self.gate = sh.t(f"{lp}mlp.experts.expert_0.gate_proj.weight")
+        self.up = sh.t(f"{lp}mlp.experts.expert_0.up_proj.weight")
+        self.down = sh.t(f"{lp}mlp.experts.expert_0.down_proj.weight")
+
+
 class _Workspace:
     """All activation / scratch buffers of the train step (``train=True``) or of a scoring forward.
 
@@ -193,8 +274,12 @@ class _Workspace:
         self.cross_order = (buf("co_perm", (B, S), i32), buf("co_kind", (B, n_t32), i32), buf("co_maxpos", (B, n_t32), i32))
         self.offsets = buf("offsets", (E + 1,), i32)
         self.work = buf("work", ((B + 1) * E,), i32)
-        self.ldl = _round_up(cfg.vocab_size, 32)
-        self.logits = buf("logits", (T, self.ldl), f32)
+        # logits [T, ldl]: fp32, or bf16 as the reference's autocast lm_head returns them; the bf16 row is padded to a
+        # multiple of 64 columns (the head's dgrad contracts over the padded vocabulary) and the padding stays zero
+        self.ldl = _round_up(cfg.vocab_size, 32 if act == f32 else 64)
+        self.logits = buf("logits", (T, self.ldl), act)
+        if act != f32:
+            self.logits[:, cfg.vocab_size:].zero_()
         self.lse_ce = buf("lse_ce", (T,), f32)
         self.row_loss = buf("row_loss", (T,), f32)
         self.xn = buf("xn", (T, H), act)
@@ -287,6 +372,13 @@ class Engine:
         L = cfg.num_hidden_layers
         self.W = [_LayerW(cfg, self.layout, self.flat_p, l) for l in range(L)]
         self.G = [_LayerW(cfg, self.layout, self.flat_g, l) for l in range(L)]
+        # matrices the GEMMs read: the fp32 masters themselves, or their bf16 copies (+ transposed copies for dgrad)
+        self.shadow: Optional[Bf16Shadow] = None
+        self.Wm, self.WT = self.W, None
+        if dtype == "bf16":
+            self.shadow = Bf16Shadow(cfg, self.layout, self.flat_p)
+            self.Wm = [_LayerW(cfg, self.layout, self.shadow.flat16, l) for l in range(L)]
+            self.WT = [_LayerWT(cfg, self.shadow, l) for l in range(L)]
         self.lut = cfg.behavior_lut().to(self.device)
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._ws: Dict[bool, _Workspace] = {}
@@ -378,6 +470,11 @@ class Engine:
             raise ValueError("act_zero_col / uniform_len are evaluation-only options")
         if last_row_logits and (train or labels is not None):
             raise ValueError("last_row_logits is an evaluation-only option")
+        bf16 = self.dtype == "bf16"
+        if bf16:
+            if last_row_logits or uniform_len not in (0, S):
+                raise NotImplementedError("generation (cached decode / re-run scoring) is built for dtype='f32' only")
+            self.shadow.refresh()                    # the masters may have been updated by any optimizer since the last call
         T, H = B * S, cfg.hidden_size
         nq, nkv, dh, I, E = (cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size,
                              cfg.num_experts)
@@ -427,45 +524,53 @@ class Engine:
             ops.session_spans(sid, ext, am, cfg.num_positions, S, r, ws.session)     # overwrites r["empty_*"]
             span_self, span_cross, pos_ids = (ws.session["span_self"], ws.session["span_cross"],
                                               ws.session["pos_ids"])
-        if cfg.cross_attention_decoder:
-            ops.attn_row_order(r["empty_cross"], *ws.cross_order)
+        if cfg.cross_attention_decoder and not bf16:
+            ops.attn_row_order(r["empty_cross"], *ws.cross_order)        # (bf16: empty rows attend nothing, no order)
         cos, sin = self.rope(S)
         scale = float(dh) ** -0.5
         x = ws.x[0][0]
         ops.embedding_fwd(ids, self.params["model.embed_tokens.weight"], x)
         t0, t1 = ws.tmpH[0], ws.tmpH[1]
+        emb_m = self.shadow.params16["model.embed_tokens.weight"] if bf16 else self.params["model.embed_tokens.weight"]
+
+        def attention(qb, kb, vb, kl_, ql_, empty_, tile_empty_, seed_, ob, lseb, order_, span_):
+            if bf16:
+                ops.attn_fwd_bf16(qb, NQ, kb, NKV, vb, QKV, kl_, ql_, B, S, nq, nkv, scale, p_att, seed_, ob, lseb,
+                                  q_span=span_)
+            else:
+                ops.attn_fwd(qb, NQ, kb, NKV, vb, QKV, kl_, ql_, empty_, tile_empty_, B, S, nq, nkv, scale, p_att, seed_,
+                             ob, lseb, order=order_, uniform_len=uniform_len, q_span=span_)
+
         for l in range(cfg.num_hidden_layers):
             W, A, xs = self.W[l], ws.layers[l], ws.x[l]
+            Wm = self.Wm[l]                          # GEMM operands (fp32 masters or bf16 copies); W: norms, tables
             # ---- self attention (model.py:204-217) ----
             ops.rmsnorm_fwd(xs[0], W.ln1, eps, A["h1"])
-            ops.linear_fwd(A["h1"], H, W.self_attn["qkv"], H, A["qkv"], QKV, T, QKV, H)
+            ops.linear_fwd(A["h1"], H, Wm.self_attn["qkv"], H, A["qkv"], QKV, T, QKV, H)
             ops.qknorm_rope_fwd(A["qkv"], S, nq, nkv, W.self_attn["qn"], W.self_attn["kn"], eps, cos, sin, A["q"], A["k"],
                                 pos_ids=pos_ids)
             if kv_sink is not None:
                 kv_sink(l, "self", A["k"], A["qkv"][:, NQ + NKV:])
-            ops.attn_fwd(A["q"], NQ, A["k"], NKV, A["qkv"][:, NQ + NKV:], QKV, r["kl_self"], None, r["empty_self"],
-                         r["tile_empty_self"], B, S, nq, nkv, scale, p_att, self._seed(l, 0), A["ao"], A["lse"],
-                         uniform_len=uniform_len, q_span=span_self)
+            attention(A["q"], A["k"], A["qkv"][:, NQ + NKV:], r["kl_self"], None, r["empty_self"], r["tile_empty_self"],
+                      self._seed(l, 0), A["ao"], A["lse"], None, span_self)
             # o_proj with the residual add + dropout fused into the GEMM epilogue (model.py:149,217)
-            ops.gemm(A["ao"], NQ, 1, W.self_attn["o"], NQ, 1, xs[1], H, T, H, NQ, resid=xs[0], p_drop=p_res,
+            ops.gemm(A["ao"], NQ, 1, Wm.self_attn["o"], NQ, 1, xs[1], H, T, H, NQ, resid=xs[0], p_drop=p_res,
                      seed=self._seed(l, 1))
             xcur = xs[1]
             # ---- behaviour-level "cross" attention (model.py:220-235) ----
             if W.cross:
-                C = W.cross_attn
+                C, Cm = W.cross_attn, Wm.cross_attn
                 ops.rmsnorm_fwd(xs[1], W.ln2, eps, A["h2"])
-                ops.linear_fwd(A["h2"], H, C["qkv"], H, A["qkv_c"], QKV, T, QKV, H)
+                ops.linear_fwd(A["h2"], H, Cm["qkv"], H, A["qkv_c"], QKV, T, QKV, H)
                 ops.qknorm_rope_fwd(A["qkv_c"], S, nq, nkv, C["qn"], C["kn"], eps, cos, sin, A["q_c"], A["k_c"],
                                     bias_q=C["bq"], bias_k=C["bk"], bias_v=C["bv"], act_idx=r["act_idx"],
                                     pos_ids=pos_ids)
                 if kv_sink is not None:
                     kv_sink(l, "cross", A["k_c"], A["qkv_c"][:, NQ + NKV:])
-                ops.attn_fwd(A["q_c"], NQ, A["k_c"], NKV, A["qkv_c"][:, NQ + NKV:], QKV, r["kl_cross"], r["ql_cross"],
-                             r["empty_cross"], r["tile_empty_cross"], B, S, nq, nkv, scale, p_att, self._seed(l, 2),
-                             A["ao_c"], A["lse_c"], order=ws.cross_order, uniform_len=uniform_len,
-                             q_span=span_cross)
-                ops.linear_fwd(A["ao_c"], NQ, C["o"], NQ, A["op_c"], H, T, H, NQ)
-                ops.linear_fwd(A["h2"], H, C["gate"], H, A["gate_c"], H, T, H, H)
+                attention(A["q_c"], A["k_c"], A["qkv_c"][:, NQ + NKV:], r["kl_cross"], r["ql_cross"], r["empty_cross"],
+                          r["tile_empty_cross"], self._seed(l, 2), A["ao_c"], A["lse_c"], ws.cross_order, span_cross)
+                ops.linear_fwd(A["ao_c"], NQ, Cm["o"], NQ, A["op_c"], H, T, H, NQ)
+                ops.linear_fwd(A["h2"], H, Cm["gate"], H, A["gate_c"], H, T, H, H)
                 # output gate + residual add + dropout in one pass (model.py:147, 235)
                 ops.silu_gate_fwd(A["op_c"], A["gate_c"], xs[2], resid=xs[1], p=p_res, seed=self._seed(l, 3))
                 xcur = xs[2]
@@ -494,13 +599,13 @@ class Engine:
             if W.inject:
                 ops.rowtable_fwd(W.beh, r["beh_idx"], A["hin"], din, H, ws.slot)
             grp = dict(groups=E, group_offsets=ws.offsets)
-            ops.linear_fwd(A["hin"], din, W.gate, din, A["g"], I, T, I, din, strideB=I * din, **grp)
-            ops.linear_fwd(A["hin"], din, W.up, din, A["u"], I, T, I, din, strideB=I * din, **grp)
+            ops.linear_fwd(A["hin"], din, Wm.gate, din, A["g"], I, T, I, din, strideB=I * din, **grp)
+            ops.linear_fwd(A["hin"], din, Wm.up, din, A["u"], I, T, I, din, strideB=I * din, **grp)
             ops.swiglu_fwd(A["g"], A["u"], T * I, p_res, self._seed(l, 4), A["hm"])
             xnext = ws.x[l + 1][0] if l + 1 < cfg.num_hidden_layers else ws.x_final
             # down projection: rows are in expert-sorted order, the epilogue scatters them back to token
             # order through perm while adding the residual and applying dropout (FFN.py:25-27, model.py:241)
-            ops.gemm(A["hm"], I, 1, W.down, I, 1, xnext, H, T, H, I, strideB=H * I, resid=xcur, row_map=ws.perm,
+            ops.gemm(A["hm"], I, 1, Wm.down, I, 1, xnext, H, T, H, I, strideB=H * I, resid=xcur, row_map=ws.perm,
                      p_drop=p_res, seed=self._seed(l, 5), **grp)
         # ---- final norm, tied head, temperature CE (model.py:869,1001,904-922) ----
         V = cfg.vocab_size
@@ -513,7 +618,7 @@ class Engine:
             self.last_logits_buf = small               # [B, ldl] (columns >= V are padding), what DecodeSession scores
             return None, small.view(B, 1, ws.ldl)[:, :, :V]
         ops.rmsnorm_fwd(ws.x_final, self.params["model.norm.weight"], eps, ws.xn)
-        ops.linear_fwd(ws.xn, H, self.params["model.embed_tokens.weight"], H, ws.logits, ws.ldl, T, V, H)
+        ops.linear_fwd(ws.xn, H, emb_m, H, ws.logits, ws.ldl, T, V, H)
         loss = None
         if lab is not None:
             ops.ce_fwd(ws.logits, ws.ldl, lab, V, self.temperature, IGNORE_INDEX, ws.lse_ce, ws.row_loss, ws.loss_sum,
@@ -580,7 +685,27 @@ class Engine:
         NP = ws.norm_partial
         # delta = dO . O of the attention backward comes out of the o_proj dgrad GEMM (row-dot epilogue) when the dS-spill
         # path is in use and every tile of that GEMM is full; otherwise gamer_attn_bwd computes it itself
-        fuse_delta = ws.ds_work is not None and T % 128 == 0 and NQ % 128 == 0
+        bf16 = self.dtype == "bf16"
+        fuse_delta = (ws.ds_work is not None or bf16) and T % 128 == 0 and NQ % 128 == 0
+
+        def dgrad(dy, lddy, Wf, Wt, ldw, dx, lddx, n_out, k_in, **kw):
+            """dx[T,k_in] (+)= dy[T,n_out] @ W[n_out,k_in]: fp32 reads W itself (row-contiguous B operand), bf16 the
+            transposed copy Wt [k_in, n_out] (k-contiguous on both sides); strideB is the same element count."""
+            if bf16:
+                ops.linear_dgrad_t(dy, lddy, Wt, Wt.shape[1], dx, lddx, T, n_out if Wt.shape[1] == n_out else Wt.shape[1],
+                                   k_in, **kw)
+            else:
+                ops.linear_dgrad(dy, lddy, Wf, ldw, dx, lddx, T, n_out, k_in, **kw)
+
+        def attention_bwd(qb, kb, vb, ob, lseb, kl_, ql_, empty_, tile_empty_, seed_, order_, span_):
+            if bf16:
+                ops.attn_bwd_bf16(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, B, S, nq, nkv, scale, p_att, seed_,
+                                  ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, q_span=span_,
+                                  delta_ready=fuse_delta)
+            else:
+                ops.attn_bwd(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, empty_, tile_empty_, B, S, nq, nkv, scale,
+                             p_att, seed_, ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, order=order_,
+                             ds_work=ws.ds_work, q_span=span_, delta_ready=fuse_delta)
 
         def norm_bwd(xin, w, dy, lddy, dw, accumulate_dx, dy_rows=None, branch=None):
             """``branch`` = (seed, rows): the residual branch that consumes the updated dx next; its input gradient
@@ -602,24 +727,25 @@ class Engine:
         ops.linear_wgrad(ws.logits, ws.ldl, ws.xn, H, demb, H, T, V, H)
         t0, t1, t2, t3 = ws.tmpH
         L = cfg.num_hidden_layers
-        ops.linear_dgrad(ws.logits, ws.ldl, emb, H, t3, H, T, V, H)
+        dgrad(ws.logits, ws.ldl, emb, self.shadow.t("model.embed_tokens.weight") if bf16 else None, H, t3, H, V, H)
         # every norm backward that completes dx also emits t0 = mask * dx for the branch that reads dx next
         norm_bwd(ws.x_final, self.params["model.norm.weight"], t3, H, self.grads["model.norm.weight"], False,
                  branch=(self._seed(L - 1, 5), ws.slot))
 
         for l in reversed(range(cfg.num_hidden_layers)):
             W, G, A, xs = self.W[l], self.G[l], ws.layers[l], ws.x[l]
+            WT = self.WT[l] if bf16 else None
             din = W.din
             grp = dict(groups=E, group_offsets=ws.offsets)
             xlast = xs[2] if W.cross else xs[1]
             # ---- experts ----   (t0 = d out_sorted, written by the norm backward that completed dx)
             ops.linear_wgrad(t0, H, A["hm"], I, G.down, I, T, H, I, strideC=H * I, **grp)
-            ops.linear_dgrad(t0, H, W.down, I, ws.dhm, I, T, H, I, strideB=H * I, **grp)
+            dgrad(t0, H, W.down, WT.down if bf16 else None, I, ws.dhm, I, H, I, strideB=H * I, **grp)
             ops.swiglu_bwd(A["g"], A["u"], ws.dhm, T * I, p_res, self._seed(l, 4))          # g <- dg, u <- du
             ops.linear_wgrad(A["g"], I, A["hin"], din, G.gate, din, T, I, din, strideC=I * din, **grp)
             ops.linear_wgrad(A["u"], I, A["hin"], din, G.up, din, T, I, din, strideC=I * din, **grp)
-            ops.linear_dgrad(A["g"], I, W.gate, din, ws.dhin, din, T, I, din, strideB=I * din, **grp)
-            ops.linear_dgrad(A["u"], I, W.up, din, ws.dhin, din, T, I, din, accumulate=True, strideB=I * din, **grp)
+            dgrad(A["g"], I, W.gate, WT.gate if bf16 else None, din, ws.dhin, din, I, din, strideB=I * din, **grp)
+            dgrad(A["u"], I, W.up, WT.up if bf16 else None, din, ws.dhin, din, I, din, accumulate=True, strideB=I * din, **grp)
             if W.inject:
                 ops.rowtable_bwd(ws.dhin, din, H, r["beh_idx"], G.beh, ws.slot)
             norm_bwd(xlast, W.ln3, ws.dhin, din, G.ln3, True, ws.slot,
@@ -627,38 +753,36 @@ class Engine:
             # ---- cross attention ----
             if W.cross:
                 C, GC = W.cross_attn, G.cross_attn
+                CT = WT.cross_attn if bf16 else dict(o=None, gate=None, qkv=None)
                 # dropout mask of the residual add + gate backward in one pass: t1 = d op, t2 = d gate
                 ops.silu_gate_bwd(A["op_c"], A["gate_c"], ws.dx, t1, t2, p=p_res, seed=self._seed(l, 3))
                 ops.linear_wgrad(t1, H, A["ao_c"], NQ, GC["o"], NQ, T, H, NQ)
                 ops.linear_wgrad(t2, H, A["h2"], H, GC["gate"], H, T, H, H)
-                ops.linear_dgrad(t1, H, C["o"], NQ, ws.dao, NQ, T, H, NQ,
-                                 rowdot=(A["ao_c"], ws.delta, S) if fuse_delta else None)
-                ops.attn_bwd(A["q_c"], NQ, A["k_c"], NKV, A["qkv_c"][:, NQ + NKV:], QKV, A["ao_c"], ws.dao, A["lse_c"],
-                             r["kl_cross"], r["ql_cross"], r["empty_cross"], r["tile_empty_cross"], B, S, nq, nkv,
-                             scale, p_att, self._seed(l, 2), ws.delta, ws.dq, NQ, ws.dk, NKV,
-                             ws.dqkv[:, NQ + NKV:], QKV, order=ws.cross_order, ds_work=ws.ds_work, q_span=span_cross,
-                             delta_ready=fuse_delta)
+                dgrad(t1, H, C["o"], CT["o"], NQ, ws.dao, NQ, H, NQ,
+                      rowdot=(A["ao_c"], ws.delta, S) if fuse_delta else None)
+                attention_bwd(A["q_c"], A["k_c"], A["qkv_c"][:, NQ + NKV:], A["ao_c"], A["lse_c"], r["kl_cross"],
+                              r["ql_cross"], r["empty_cross"], r["tile_empty_cross"], self._seed(l, 2), ws.cross_order,
+                              span_cross)
                 ops.qknorm_rope_bwd(A["qkv_c"], ws.dq, ws.dk, S, nq, nkv, C["qn"], C["kn"], eps, cos, sin, ws.dqkv,
                                     GC["qn"], GC["kn"], bias_q=C["bq"], bias_k=C["bk"], act_idx=r["act_idx"], nb1=NB1,
                                     dbias_q=GC["bq"], dbias_k=GC["bk"], dbias_v=GC["bv"], pos_ids=pos_ids,
                                     partial=ws.qk_partial)
                 ops.linear_wgrad(ws.dqkv, QKV, A["h2"], H, GC["qkv"], H, T, QKV, H)
-                ops.linear_dgrad(ws.dqkv, QKV, C["qkv"], H, t3, H, T, QKV, H)
-                ops.linear_dgrad(t2, H, C["gate"], H, t3, H, T, H, H, accumulate=True)
+                dgrad(ws.dqkv, QKV, C["qkv"], CT["qkv"], H, t3, H, QKV, H)
+                dgrad(t2, H, C["gate"], CT["gate"], H, t3, H, H, H, accumulate=True)
                 norm_bwd(xs[1], W.ln2, t3, H, G.ln2, True, branch=(self._seed(l, 1), None))
             # ---- self attention ----
             SA, GS = W.self_attn, G.self_attn
+            ST = WT.self_attn if bf16 else dict(o=None, qkv=None)
             # (t0 = mask * dx of this branch, written by the norm backward above)
             ops.linear_wgrad(t0, H, A["ao"], NQ, GS["o"], NQ, T, H, NQ)
-            ops.linear_dgrad(t0, H, SA["o"], NQ, ws.dao, NQ, T, H, NQ, rowdot=(A["ao"], ws.delta, S) if fuse_delta else None)
-            ops.attn_bwd(A["q"], NQ, A["k"], NKV, A["qkv"][:, NQ + NKV:], QKV, A["ao"], ws.dao, A["lse"], r["kl_self"],
-                         None, r["empty_self"], r["tile_empty_self"], B, S, nq, nkv, scale, p_att, self._seed(l, 0),
-                         ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, ds_work=ws.ds_work,
-                         q_span=span_self, delta_ready=fuse_delta)
+            dgrad(t0, H, SA["o"], ST["o"], NQ, ws.dao, NQ, H, NQ, rowdot=(A["ao"], ws.delta, S) if fuse_delta else None)
+            attention_bwd(A["q"], A["k"], A["qkv"][:, NQ + NKV:], A["ao"], A["lse"], r["kl_self"], None, r["empty_self"],
+                          r["tile_empty_self"], self._seed(l, 0), None, span_self)
             ops.qknorm_rope_bwd(A["qkv"], ws.dq, ws.dk, S, nq, nkv, SA["qn"], SA["kn"], eps, cos, sin, ws.dqkv, GS["qn"],
                                 GS["kn"], pos_ids=pos_ids, partial=ws.qk_partial)
             ops.linear_wgrad(ws.dqkv, QKV, A["h1"], H, GS["qkv"], H, T, QKV, H)
-            ops.linear_dgrad(ws.dqkv, QKV, SA["qkv"], H, t3, H, T, QKV, H)
+            dgrad(ws.dqkv, QKV, SA["qkv"], ST["qkv"], H, t3, H, QKV, H)
             norm_bwd(xs[0], W.ln1, t3, H, G.ln1, True, branch=(self._seed(l - 1, 5), ws.slot) if l > 0 else None)
             if layer_done is not None:
                 layer_done(l)

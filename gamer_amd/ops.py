@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, call, ptr, stream_ptr
+from ._lib import GemmBf16Desc, GemmDesc, call, ptr, stream_ptr
 
 
 def _sfx(t: torch.Tensor) -> str:
@@ -126,7 +126,11 @@ def rowtable_bwd(dy, lddy, col0, idx, dtable, dy_rows=None):
 def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=False, groups=1, group_mode=0,
          group_offsets=None, strideB=0, strideC=0, kchunk=0, resid=None, row_map=None, p_drop=0.0, seed=0,
          rowdot=None):
-    """C[m][n] (=|+=) alpha * sum_k A(m,k) B(n,k); see gamer_gemm_desc in include/gamer_hip.h."""
+    """C[m][n] (=|+=) alpha * sum_k A(m,k) B(n,k); see gamer_gemm_desc in include/gamer_hip.h.  bf16 operands go to
+    gamer_gemm_bf16 (k-contiguous x k-contiguous, or the token-major wgrad form; see gamer_gemm_bf16_desc)."""
+    if A.dtype == torch.bfloat16:
+        return _gemm_bf16(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha, accumulate, groups, group_mode,
+                          group_offsets, strideB, strideC, kchunk, resid, row_map, p_drop, seed, rowdot)
     d = GemmDesc()
     d.A = ptr(A); d.a_rs = a_rs; d.a_ks = a_ks
     d.B = ptr(Bm); d.b_rs = b_rs; d.b_ks = b_ks
@@ -148,6 +152,40 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
     call("gamer_gemm_f32", C.byref(d), stream_ptr())
 
 
+def _gemm_bf16(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha, accumulate, groups, group_mode, group_offsets,
+               strideB, strideC, kchunk, resid, row_map, p_drop, seed, rowdot):
+    if Bm.dtype != torch.bfloat16 or alpha != 1.0:
+        raise RuntimeError("gamer_gemm_bf16 takes two bf16 operands and alpha = 1")
+    d = GemmBf16Desc()
+    if group_mode == 0:
+        if a_ks != 1 or b_ks != 1:
+            raise RuntimeError("bf16 GEMM: both operands must be k-contiguous (dgrad runs on the transposed weight copy)")
+        d.lda, d.ldb = a_rs, b_rs
+        want = torch.float32 if resid is not None else torch.bfloat16
+    else:
+        if a_rs != 1 or b_rs != 1:
+            raise RuntimeError("bf16 wgrad: both operands must be token-major")
+        d.lda, d.ldb = a_ks, b_ks
+        want = torch.float32
+    if Cm.dtype != want:
+        raise RuntimeError(f"bf16 GEMM: C must be {want}, got {Cm.dtype}")
+    d.A, d.B, d.C, d.ldc = ptr(A), ptr(Bm), ptr(Cm), ldc
+    d.M, d.N, d.K = M, N, K
+    d.accumulate = 1 if accumulate else 0
+    d.groups, d.group_mode, d.group_offsets = groups, group_mode, ptr(group_offsets)
+    d.strideB, d.strideC, d.kchunk = strideB, strideC, kchunk
+    d.resid, d.row_map, d.p_drop, d.seed = ptr(resid), ptr(row_map), p_drop, seed
+    if rowdot is not None:
+        d.rowdot_other, d.rowdot_out, d.rowdot_S = ptr(rowdot[0]), ptr(rowdot[1]), int(rowdot[2])
+    call("gamer_gemm_bf16", C.byref(d), stream_ptr())
+
+
+def linear_dgrad_t(dy, lddy, WT, ldwt, dx, lddx, M, K_out, N_in, accumulate=False, **grp):
+    """dx[M,N_in] = dy[M,K_out] @ W[K_out,N_in] given WT = W^T [N_in, ldwt >= K_out] (k-contiguous on both sides: the
+    form the bf16 path uses, against the transposed weight copy; K_out may include zero padding)."""
+    gemm(dy, lddy, 1, WT, ldwt, 1, dx, lddx, M, N_in, K_out, accumulate=accumulate, **grp)
+
+
 def linear_fwd(x, ldx, W, ldw, y, ldy, M, N, K, accumulate=False, **grp):
     """y[M,N] = x[M,K] @ W[N,K]^T"""
     gemm(x, ldx, 1, W, ldw, 1, y, ldy, M, N, K, accumulate=accumulate, **grp)
@@ -158,11 +196,14 @@ def linear_dgrad(dy, lddy, W, ldw, dx, lddx, M, N_out, K_in, accumulate=False, *
     gemm(dy, lddy, 1, W, 1, ldw, dx, lddx, M, K_in, N_out, accumulate=accumulate, **grp)
 
 
-def pick_kchunk(rows: int, grouped: bool) -> int:
+def pick_kchunk(rows: int, grouped: bool, bf16: bool = False) -> int:
     """Token chunk per workgroup of the wgrad split.  Measured on MI355X at T = 517k (tools/wgrad_probe.py):
     1024 rows for the grouped (expert) form and 2048 for the plain one are within 3 % of the best for every
-    shape on this path; 4k+ chunks lose 15-25 % to the tail (too few, too long workgroups)."""
+    shape on this path; 4k+ chunks lose 15-25 % to the tail (too few, too long workgroups).  The bf16 kernel's tiles
+    take 16x less matrix time, so its chunks are 4x longer (the fp32 atomics of a chunk are the same bytes)."""
     chunk = 1024 if grouped else 2048
+    if bf16:
+        chunk *= 4
     while chunk > 256 and rows < 64 * chunk:          # small problems: keep >= ~64 chunks
         chunk //= 2
     return chunk
@@ -171,7 +212,7 @@ def pick_kchunk(rows: int, grouped: bool) -> int:
 def linear_wgrad(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups=1, group_offsets=None, strideC=0, kchunk=None):
     """dW[N_out,K_in] += dy[rows,N_out]^T @ x[rows,K_in]   (dW must be initialised; fp32 atomics)."""
     if kchunk is None:
-        kchunk = pick_kchunk(rows, groups > 1)
+        kchunk = pick_kchunk(rows, groups > 1, dy.dtype == torch.bfloat16)
     gemm(dy, 1, lddy, x, 1, ldx, dW, lddw, N_out, K_in, rows, groups=groups, group_mode=1,
          group_offsets=group_offsets, strideC=strideC, kchunk=kchunk)
 
@@ -225,6 +266,24 @@ def attn_bwd(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty,
          ptr(row_empty), ptr(tile_empty), B, S, nq, nkv, scale, p_drop, seed, ptr(delta), ptr(dq), lddq, ptr(dk),
          lddk, ptr(dv), lddv, ptr(pm), ptr(tk), ptr(tm), ptr(ds_work), ptr(q_span),
          1 if (delta_ready and ds_work is not None) else 0, stream_ptr())
+
+
+def attn_fwd_bf16(q, ldq, k, ldk, v, ldv, kl, ql, B, S, nq, nkv, scale, p_drop, seed, o, lse, q_span=None):
+    """bf16 attention (empty rows -> 0, see gamer_attn_fwd_bf16 in include/gamer_hip.h)."""
+    call("gamer_attn_fwd_bf16", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(kl), ptr(ql), B, S, nq, nkv, scale, p_drop,
+         seed, ptr(o), ptr(lse), ptr(q_span), stream_ptr())
+
+
+def attn_bwd_bf16(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, B, S, nq, nkv, scale, p_drop, seed, delta, dq, lddq, dk,
+                  lddk, dv, lddv, q_span=None, delta_ready=False):
+    call("gamer_attn_bwd_bf16", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), ptr(d_o), ptr(lse), ptr(kl), ptr(ql),
+         B, S, nq, nkv, scale, p_drop, seed, ptr(delta), ptr(dq), lddq, ptr(dk), lddk, ptr(dv), lddv, ptr(q_span),
+         1 if delta_ready else 0, stream_ptr())
+
+
+def cast_params_bf16(flat, out, out_t, table, n_entries, n_tiles):
+    """bf16 (and transposed bf16) operand copies of the fp32 master parameters; table from engine.Bf16Shadow."""
+    call("gamer_cast_params_bf16", ptr(flat), ptr(out), ptr(out_t), ptr(table), n_entries, n_tiles, stream_ptr())
 
 
 def attn_ds_work_numel(B, S, nq):

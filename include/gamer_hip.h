@@ -197,6 +197,51 @@ typedef struct {
 int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulation): the nn.Linear sites of the reference's --bf16 run
+ * (autocast casts both operands of every F.linear to bf16, model.py:93-99,145-149,1001, FFN.py:25-27).
+ *   group_mode 0  C[m][n] = sum_k A[m][k] * B[n][k]: BOTH operands k-contiguous (row-major [M,K] and [N,K], leading
+ *       dims lda / ldb, K % 64 == 0).  Linear forward: A = X, B = W.  dgrad dX = dY W: A = dY, B = the TRANSPOSED
+ *       bf16 copy of W (gamer_cast_params_bf16 keeps it), K = the layer's output width (pad columns must be finite
+ *       in A and zero in B).  C is bf16 [M, ldc] (accumulate: C += ), or - with `resid` - the fp32 residual stream:
+ *       C[map(m)][n] = resid[map(m)][n] + dropout(acc) exactly as gamer_gemm_f32's fused epilogue (same mask).
+ *       Row segments (experts) as in gamer_gemm_f32.  rowdot_*: as gamer_gemm_f32, `other` bf16, the dot product uses
+ *       the rounded C.
+ *   group_mode 1  (wgrad) C[m][n] += sum_t A[t][m] * B[t][n]: A [K rows, lda] and B [K rows, ldb] token-major bf16
+ *       (lda >= round_up(M, 8), ldb >= round_up(N, 8): whole 16-byte chunks are read), C fp32 [M, ldc] accumulated
+ *       with atomics over token chunks of `kchunk` (multiple of 64); the token range may be segmented (experts,
+ *       C + g * strideC).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const gamer_bf16* A; int64_t lda;
+    const gamer_bf16* B; int64_t ldb;
+    void* C; int64_t ldc;        /* gamer_bf16* (mode 0), float* (mode 0 with resid, mode 1) */
+    int M, N, K;
+    int accumulate;              /* mode 0, bf16 C only */
+    int groups;
+    int group_mode;
+    const int32_t* group_offsets;
+    int64_t strideB, strideC;
+    int kchunk;
+    const float* resid;
+    const int32_t* row_map;
+    float p_drop;
+    uint64_t seed;
+    const gamer_bf16* rowdot_other;
+    float* rowdot_out;
+    int rowdot_S;
+} gamer_gemm_bf16_desc;
+
+int gamer_gemm_bf16(const gamer_gemm_bf16_desc* d, void* stream);
+
+/* bf16 operand copies of the fp32 master parameters, refreshed after every optimizer step (one launch):
+ * table[5 * e + ...] describes matrix e of the flat fp32 buffer: { src offset, dst offset in `out`, dst offset in
+ * `out_t` or -1, rows | cols << 32, ldt | first_tile << 32 } with first_tile = sum over earlier entries of
+ * ceil(rows / 32) * ceil(cols / 32); n_tiles = that sum over all entries.  out[dst + r * cols + c] = bf16(W[r][c]);
+ * out_t[dst_t + c * ldt + r] = bf16(W[r][c]) (columns >= rows of a row of out_t are never written: keep them zero). */
+int gamer_cast_params_bf16(const float* flat, gamer_bf16* out, gamer_bf16* out_t, const int64_t* table,
+                           int n_entries, int n_tiles, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * q/k per-head RMSNorm + RoPE (+ per-behaviour q/k/v bias for the cross attention)
  * (model.py:88-101; Qwen3MoeRMSNorm; apply_rotary_pos_emb / rotate_half).
  *   qkv: [T, (nq+2*nkv)*64] output of the fused q|k|v projection; head_dim is 64.
@@ -290,6 +335,26 @@ int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float
                    float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                    const int32_t* row_perm, const int32_t* tile_kind, const int32_t* tile_maxpos,
                    float* ds_work, const int32_t* q_span, int delta_ready, void* stream);
+
+/* bf16 attention of the reference's --bf16 run (autocast casts q, k, v AND the additive mask of
+ * sdpa_attention_forward to bf16).  Same predicate, layouts and dropout mask function as gamer_attn_fwd / _bwd, with
+ * ONE semantic difference that the reference itself has under bf16 and that tests/golden/*_bf16.npz pin:
+ * finfo(float32).min is not representable in bf16, the mask becomes -inf, and SDPA returns 0 for a query row with
+ * no allowed key - so an "empty" row gives o = 0 (lse = 0) and no gradient instead of the fp32 run's uniform average
+ * over all S keys.  (No row_empty / tile_empty / row order / uniform_len arguments: nothing depends on them.)
+ *   q [T,nq*64] (ldq), k [T,nkv*64] (ldk), v rows at v + t*ldv, o / d_o [T,nq*64]: bf16, leading dims multiples of 8;
+ *   lse, delta [B,nq,S] fp32; dq / dk / dv bf16 (leading dims multiples of 4).
+ *   Scores and softmax statistics fp32, un-normalised probabilities rounded to bf16 for the second product, fp32
+ *   accumulation.  bwd = delta (unless delta_ready: gamer_gemm_bf16's row-dot epilogue wrote it; o may then be NULL),
+ *   dK/dV kernel, dQ kernel (probabilities recomputed in both; no atomics, no workspace).                          */
+int gamer_attn_fwd_bf16(const gamer_bf16* q, int ldq, const gamer_bf16* k, int ldk, const gamer_bf16* v, int ldv,
+                        const int32_t* kl, const int32_t* ql, int B, int S, int nq, int nkv, float scale,
+                        float p_drop, uint64_t seed, gamer_bf16* o, float* lse, const int32_t* q_span, void* stream);
+int gamer_attn_bwd_bf16(const gamer_bf16* q, int ldq, const gamer_bf16* k, int ldk, const gamer_bf16* v, int ldv,
+                        const gamer_bf16* o, const gamer_bf16* d_o, const float* lse, const int32_t* kl,
+                        const int32_t* ql, int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+                        float* delta, gamer_bf16* dq, int lddq, gamer_bf16* dk, int lddk, gamer_bf16* dv, int lddv,
+                        const int32_t* q_span, int delta_ready, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Post-LN BERT-style encoder of the discriminative baselines (SURVEY section 8(f) row 4;

@@ -72,3 +72,6 @@ def test_bad_arguments_are_reported_not_crashing(lib):
     d = _lib.GemmDesc()
     rc = lib.gamer_gemm_f32(C.byref(d), None)
     assert rc != 0 and b"gamer_gemm_f32" in lib.gamer_last_error()
+    d16 = _lib.GemmBf16Desc()
+    rc = lib.gamer_gemm_bf16(C.byref(d16), None)
+    assert rc != 0 and b"gamer_gemm_bf16" in lib.gamer_last_error()
