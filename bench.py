@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = 64 FLOP/clk/SIMD
+BF16_MATRIX_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (v_mfma_f32_32x32x16_bf16, 1024 FLOP/clk/SIMD)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -86,6 +87,8 @@ class KernelTimer:
         self.records = []
         self.enabled = False
         self._next = None
+        self._dgrad_t = False
+        self._bytes = 0.0
         self.pairs = {"self": 0, "cross": 0}     # allowed (query, key) pairs of the current batch
 
     def install(self):
@@ -98,21 +101,58 @@ class KernelTimer:
                 return orig_call(name, *args)
             s = torch.cuda.Event(enable_timing=True)
             e = torch.cuda.Event(enable_timing=True)
-            label, flops = timer._next if timer._next else (name.replace("gamer_", ""), 0.0)
+            label, flops = timer._next if timer._next else (name.replace("gamer_", "").replace("_bf16", ""), 0.0)
+            nbytes = timer._bytes if timer._next else 0.0
             timer._next = None
+            timer._bytes = 0.0
             s.record()
             orig_call(name, *args)
             e.record()
-            timer.records.append((label, s, e, flops))
+            timer.records.append((label, s, e, flops, nbytes))
+
+        orig_dgrad_t = ops.linear_dgrad_t
+
+        def timed_dgrad_t(*a, **kw):
+            timer._dgrad_t = True                       # bf16 dgrad runs in the forward layout on the transposed weights
+            try:
+                return orig_dgrad_t(*a, **kw)
+            finally:
+                timer._dgrad_t = False
 
         def timed_gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, **kw):
             kind = "gemm_fwd" if (a_ks == 1 and b_ks == 1) else ("gemm_dgrad" if a_ks == 1 else "gemm_wgrad")
+            if timer._dgrad_t:
+                kind = "gemm_dgrad"
+            esz = A.element_size()
+            timer._bytes = (M * K + N * K) * esz + M * N * Cm.element_size() * (2 if (kw.get("accumulate") or kw.get("resid") is not None) else 1)
             if kw.get("resid") is not None:
                 kind = "gemm_fwd_resid"                 # fused residual + dropout epilogue (a different instantiation)
             if kw.get("rowdot") is not None:
                 kind = "gemm_dgrad_delta"               # o_proj dgrad that also emits the attention backward's delta
             timer._next = (kind, 2.0 * M * N * K)
             return orig_gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, **kw)
+
+        orig_af16, orig_ab16 = ops.attn_fwd_bf16, ops.attn_bwd_bf16
+
+        def timed_attn_fwd16(q, ldq, k, ldk, v, ldv, kl, ql, B, S, nq, *rest, **kw):
+            pairs = timer.pairs["self" if ql is None else "cross"]
+            timer._next = ("attn_fwd_self" if ql is None else "attn_fwd_cross", 4.0 * 64 * nq * pairs)
+            return orig_af16(q, ldq, k, ldk, v, ldv, kl, ql, B, S, nq, *rest, **kw)
+
+        def timed_attn_bwd16(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, B, S, nq, *rest, **kw):
+            pairs = timer.pairs["self" if ql is None else "cross"]
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            was = timer.enabled
+            timer.enabled = False
+            s.record()
+            r = orig_ab16(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, B, S, nq, *rest, **kw)
+            e.record()
+            timer.enabled = was
+            if was:
+                # recompute form: S and dP twice, dV, dK, dQ = 7 products of 2 * 64 FLOP per pair and head
+                timer.records.append(("attn_bwd_self" if ql is None else "attn_bwd_cross", s, e, 14.0 * 64 * nq * pairs, 0.0))
+            return r
 
         orig_af, orig_ab = ops.attn_fwd, ops.attn_bwd
 
@@ -136,20 +176,24 @@ class KernelTimer:
             e.record()
             timer.enabled = was
             if was:
-                timer.records.append(("attn_bwd_self" if ql is None else "attn_bwd_cross", s, e, 10.0 * 64 * nq * pairs))
+                timer.records.append(("attn_bwd_self" if ql is None else "attn_bwd_cross", s, e, 10.0 * 64 * nq * pairs, 0.0))
             return r
 
         ops.call = timed_call
         ops.gemm = timed_gemm
+        ops.linear_dgrad_t = timed_dgrad_t
+        ops.attn_fwd_bf16 = timed_attn_fwd16
+        ops.attn_bwd_bf16 = timed_attn_bwd16
         ops.attn_fwd = timed_attn_fwd
         ops.attn_bwd = timed_attn_bwd
 
     def summary(self, steps: int):
         agg = {}
-        for label, s, e, flops in self.records:
-            d = agg.setdefault(label, dict(ms=0.0, flops=0.0, launches=0))
+        for label, s, e, flops, nbytes in self.records:
+            d = agg.setdefault(label, dict(ms=0.0, flops=0.0, launches=0, bytes=0.0))
             d["ms"] += s.elapsed_time(e)
             d["flops"] += flops
+            d["bytes"] += nbytes
             d["launches"] += 1
         out = []
         for label, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
@@ -157,6 +201,8 @@ class KernelTimer:
                        avg_launch_ms=d["ms"] / d["launches"])
             if d["flops"] > 0:
                 row["tflops"] = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            if d["bytes"] > 0:
+                row["algorithmic_GBps"] = d["bytes"] / (d["ms"] * 1e-3) / 1e9      # operands read once + result written
             out.append(row)
         return out
 
@@ -352,7 +398,7 @@ def main(argv=None):
     if args.no_dropout:
         cfg.dropout_rate = 0.0
         cfg.attention_dropout = 0.0
-    eng = Engine(cfg, device=f"cuda:{local_rank}", temperature=0.7, variant=args.variant)
+    eng = Engine(cfg, device=f"cuda:{local_rank}", temperature=0.7, variant=args.variant, dtype=args.dtype)
     smean = args.session_mean if args.variant == "session" else None
     eng.init_weights(seed=0)                     # identical replicas on every rank
     eng.base_seed = 0x5EED + rank                # independent dropout streams per rank
@@ -446,7 +492,8 @@ def main(argv=None):
         kname = {"gemm_fwd": "gemm_f32_kernel<true, true, 0, false, false, 2, 0>",
                  "gemm_dgrad": "gemm_f32_kernel<true, false, 0, false, false, 2, 0>",
                  "gemm_wgrad": "gemm_f32_kernel<false, false, 1, false, false, 2, 0>"}.get(dom["kernel"] if dom else "", None)
-        traffic = committed_traffic(kname) if (kname and args.batch == 1024 and args.items == 101) else None
+        traffic = committed_traffic(kname) if (kname and args.batch == 1024 and args.items == 101 and args.dtype == "f32") else None
+        peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS
         result = {
             "metric": ("train-step sequences/sec, Qwen3Multi SMB decoder, his_len=100" if args.variant == "multi" else
                        "train-step sequences/sec, Qwen3SessionMulti SMB decoder, his_len=100"),
@@ -474,11 +521,15 @@ def main(argv=None):
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": f"gemm_f32_kernel ({dom['kernel']})" if dom else None,
+                "kernel": (f"gemm_{'f32' if args.dtype == 'f32' else 'bf16'}_kernel ({dom['kernel']})") if dom else None,
                 "achieved": dom["tflops"] if dom else None,
-                "peak": FP32_MATRIX_PEAK_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": dom["tflops"] / FP32_MATRIX_PEAK_TFLOPS if dom else None,
+                "frac": dom["tflops"] / peak if dom else None,
+                # the same launches against the HBM roofline (operands once + result): at K = 256 the bf16 GEMMs sit
+                # below the MFMA/HBM ridge, so this is the bound that binds them
+                "algorithmic_GBps": dom.get("algorithmic_GBps") if dom else None,
+                "hbm_frac": (dom["algorithmic_GBps"] / HBM_PEAK_GBS) if (dom and dom.get("algorithmic_GBps")) else None,
                 "traffic": traffic["bytes_per_launch"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
                 "algorithmic_flop_per_launch": (dom["tflops"] * 1e12 * dom["avg_launch_ms"] * 1e-3) if dom else None,
@@ -486,7 +537,7 @@ def main(argv=None):
                 "all_gemm_tflops": gemm_tf,
                 "all_gemm_ms_per_step": gemm_ms,
                 "step_algorithmic_tflops": step_flops / (ms_per_step * 1e-3) / 1e12,
-                "step_frac_of_fp32_matrix_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+                "step_frac_of_matrix_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / peak,
             },
             "kernels": kernels[:12],
             "loss": final_loss,

@@ -29,6 +29,18 @@ constexpr int HW_TILE = HB_BK * 128;                   // wgrad: [64 tokens][128
 constexpr int HW_LDS_BYTES = 4 * HW_TILE * 2;          // 65,536 B
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Staging helpers as functions over array references (kept in registers; the same code written as lambdas over captured
+// uint4 arrays was placed in scratch memory by hipcc: 144 bytes per lane, every K-step through private memory).
+__device__ __forceinline__ void hb_load4(const bf16_t* __restrict__ base, const int64_t (&off)[4], int64_t k, u32x4 (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const u32x4*>(base + off[j] + k);
+}
+__device__ __forceinline__ void hb_store4(bf16_t* __restrict__ dst, const int (&loff)[4], const u32x4 (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(dst + loff[j]) = r[j];
+}
 
 struct GemmBf16Params {
     const bf16_t* A; int64_t lda;
@@ -109,31 +121,16 @@ gemm_bf16_kernel(const GemmBf16Params p) {
     const bool a_in = row0 + HB_BM <= row_end, b_in = col0 + HB_BN <= col_end;   // workgroup-uniform
     // chunk f = tid + 256 j of a tile: row f >> 3, 16-byte k-chunk f & 7.  Rows past the end are read from the last
     // valid row (their results are never stored), so there is no predicate anywhere in the loads.
-    const bf16_t* pa[4];
-    const bf16_t* pb[4];
+    int64_t oa[4], ob[4];
+    int lo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int f = tid + HB_THREADS * j;
-        const int ra = min(row0 + (f >> 3), row_end - 1);
-        const int rb = min(col0 + (f >> 3), col_end - 1);
-        pa[j] = p.A + (int64_t)ra * p.lda + ((f & 7) << 3);
-        pb[j] = Bp + (int64_t)rb * p.ldb + ((f & 7) << 3);
+        oa[j] = (int64_t)min(row0 + (f >> 3), row_end - 1) * p.lda + ((f & 7) << 3);
+        ob[j] = (int64_t)min(col0 + (f >> 3), col_end - 1) * p.ldb + ((f & 7) << 3);
+        lo[j] = (f >> 3) * HB_LD + ((f & 7) << 3);
     }
-    uint4 ra[4], rb[4];
-    auto load_tile = [&]() {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { ra[j] = *reinterpret_cast<const uint4*>(pa[j]); pa[j] += HB_BK; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { rb[j] = *reinterpret_cast<const uint4*>(pb[j]); pb[j] += HB_BK; }
-    };
-    auto store_tile = [&](bf16_t* dst) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = tid + HB_THREADS * j;
-            *reinterpret_cast<uint4*>(dst + (f >> 3) * HB_LD + ((f & 7) << 3)) = ra[j];
-            *reinterpret_cast<uint4*>(dst + HB_TILE + (f >> 3) * HB_LD + ((f & 7) << 3)) = rb[j];
-        }
-    };
+    u32x4 ra[4], rb[4];
     // a wave whose 64 x 64 patch lies entirely past the edge of C (N = 320 leaves half of the last column tile empty)
     // issues no MFMAs
     const bool wave_live = (row0 + wm * 64 < row_end) && (col0 + wn * 64 < col_end);
@@ -157,16 +154,24 @@ gemm_bf16_kernel(const GemmBf16Params p) {
         }
     };
     if (nkt > 0) {
-        load_tile();
-        store_tile(smem);
+        hb_load4(p.A, oa, 0, ra);
+        hb_load4(Bp, ob, 0, rb);
+        hb_store4(smem, lo, ra);
+        hb_store4(smem + HB_TILE, lo, rb);
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
-        if (more) load_tile();
+        if (more) {
+            hb_load4(p.A, oa, (int64_t)(kt + 1) * HB_BK, ra);
+            hb_load4(Bp, ob, (int64_t)(kt + 1) * HB_BK, rb);
+        }
         mfma_tile(smem + 2 * cur * HB_TILE);
-        if (more) store_tile(smem + 2 * (cur ^ 1) * HB_TILE);
+        if (more) {
+            hb_store4(smem + 2 * (cur ^ 1) * HB_TILE, lo, ra);
+            hb_store4(smem + 2 * (cur ^ 1) * HB_TILE + HB_TILE, lo, rb);
+        }
         __syncthreads();
     }
 
@@ -282,6 +287,15 @@ gemm_bf16_kernel(const GemmBf16Params p) {
 // =================================================================================================
 // chunk c (16 bytes = 8 columns) of token row t lives at physical chunk c ^ ((t & 3) << 2) of its 256-byte LDS row
 __device__ __forceinline__ int hw_off(int t, int chunk) { return t * 128 + ((chunk ^ ((t & 3) << 2)) << 3); }
+// chunk j of the thread: token k0 + tk[j] (zero page past kend), element offset off[j] relative to token row 0
+__device__ __forceinline__ void hw_load4(const bf16_t* __restrict__ base, int64_t ld, const int64_t (&off)[4], const int (&tk)[4],
+                                         int k0, int kend, const bf16_t* __restrict__ zeros, u32x4 (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bf16_t* s = (k0 + tk[j] < kend) ? base + (int64_t)k0 * ld + off[j] : zeros;
+        r[j] = *reinterpret_cast<const u32x4*>(s);
+    }
+}
 
 __global__ void __launch_bounds__(HB_THREADS, 2)
 gemm_bf16_wgrad_kernel(const GemmBf16Params p, const bf16_t* __restrict__ zeros) {
@@ -331,35 +345,18 @@ gemm_bf16_wgrad_kernel(const GemmBf16Params p, const bf16_t* __restrict__ zeros)
     // width are read from its last chunk (those rows / columns of C are never stored); tokens past the end of the
     // segment are read from a page of zeros (they must not contribute).
     const int a_cmax = ((p.M + 7) >> 3) - 1, b_cmax = ((p.N + 7) >> 3) - 1;        // last readable chunk (ld >= round_up(., 8))
-    int ca[4], cb[4];
+    int64_t oa[4], ob[4];
+    int lo[4], tk[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int f = tid + HB_THREADS * j;
-        ca[j] = min((row0 >> 3) + (f & 15), a_cmax) << 3;
-        cb[j] = min((col0 >> 3) + (f & 15), b_cmax) << 3;
+        tk[j] = f >> 4;
+        oa[j] = (int64_t)tk[j] * p.lda + (min((row0 >> 3) + (f & 15), a_cmax) << 3);
+        ob[j] = (int64_t)tk[j] * p.ldb + (min((col0 >> 3) + (f & 15), b_cmax) << 3);
+        lo[j] = hw_off(f >> 4, f & 15);
     }
-    uint4 ra[4], rb[4];
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = tid + HB_THREADS * j;
-            const int t = k0 + (f >> 4);
-            const bool ok = t < kend;
-            const bf16_t* sa = ok ? p.A + (int64_t)t * p.lda + ca[j] : zeros;
-            const bf16_t* sb = ok ? p.B + (int64_t)t * p.ldb + cb[j] : zeros;
-            ra[j] = *reinterpret_cast<const uint4*>(sa);
-            rb[j] = *reinterpret_cast<const uint4*>(sb);
-        }
-    };
-    auto store_tile = [&](bf16_t* dst) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = tid + HB_THREADS * j;
-            const int off = hw_off(f >> 4, f & 15);
-            *reinterpret_cast<uint4*>(dst + off) = ra[j];
-            *reinterpret_cast<uint4*>(dst + HW_TILE + off) = rb[j];
-        }
-    };
+    u32x4 ra[4], rb[4];
+    // token rows at or past kend come from a page of zeros (a select on the ADDRESS: the load itself has no predicate)
     const bool wave_live = (row0 + wm * 64 < p.M) && (col0 + wn * 64 < p.N);
     // transposing read: lane 16g + 4q + pp of a wave supplies the address of (token 4-block row q, columns 4pp..4pp+3)
     // of its group's 4 x 16 block and receives column (lane & 15) of the four tokens
@@ -397,16 +394,24 @@ gemm_bf16_wgrad_kernel(const GemmBf16Params p, const bf16_t* __restrict__ zeros)
     };
     const int nkt = (kend - kbeg + HB_BK - 1) / HB_BK;
     if (nkt > 0) {
-        load_tile(kbeg);
-        store_tile(smem);
+        hw_load4(p.A, p.lda, oa, tk, kbeg, kend, zeros, ra);
+        hw_load4(p.B, p.ldb, ob, tk, kbeg, kend, zeros, rb);
+        hb_store4(smem, lo, ra);
+        hb_store4(smem + HW_TILE, lo, rb);
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
-        if (more) load_tile(kbeg + (kt + 1) * HB_BK);
+        if (more) {
+            hw_load4(p.A, p.lda, oa, tk, kbeg + (kt + 1) * HB_BK, kend, zeros, ra);
+            hw_load4(p.B, p.ldb, ob, tk, kbeg + (kt + 1) * HB_BK, kend, zeros, rb);
+        }
         mfma_tile(smem + 2 * cur * HW_TILE);
-        if (more) store_tile(smem + 2 * (cur ^ 1) * HW_TILE);
+        if (more) {
+            hb_store4(smem + 2 * (cur ^ 1) * HW_TILE, lo, ra);
+            hb_store4(smem + 2 * (cur ^ 1) * HW_TILE + HW_TILE, lo, rb);
+        }
         __syncthreads();
     }
     if (!wave_live) return;

@@ -196,14 +196,11 @@ def linear_dgrad(dy, lddy, W, ldw, dx, lddx, M, N_out, K_in, accumulate=False, *
     gemm(dy, lddy, 1, W, 1, ldw, dx, lddx, M, K_in, N_out, accumulate=accumulate, **grp)
 
 
-def pick_kchunk(rows: int, grouped: bool, bf16: bool = False) -> int:
-    """Token chunk per workgroup of the wgrad split.  Measured on MI355X at T = 517k (tools/wgrad_probe.py):
+def pick_kchunk(rows: int, grouped: bool) -> int:
+    """Token chunk per workgroup of the fp32 wgrad split.  Measured on MI355X at T = 517k (tools/wgrad_probe.py):
     1024 rows for the grouped (expert) form and 2048 for the plain one are within 3 % of the best for every
-    shape on this path; 4k+ chunks lose 15-25 % to the tail (too few, too long workgroups).  The bf16 kernel's tiles
-    take 16x less matrix time, so its chunks are 4x longer (the fp32 atomics of a chunk are the same bytes)."""
+    shape on this path; 4k+ chunks lose 15-25 % to the tail (too few, too long workgroups)."""
     chunk = 1024 if grouped else 2048
-    if bf16:
-        chunk *= 4
     while chunk > 256 and rows < 64 * chunk:          # small problems: keep >= ~64 chunks
         chunk //= 2
     return chunk
@@ -211,8 +208,16 @@ def pick_kchunk(rows: int, grouped: bool, bf16: bool = False) -> int:
 
 def linear_wgrad(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups=1, group_offsets=None, strideC=0, kchunk=None):
     """dW[N_out,K_in] += dy[rows,N_out]^T @ x[rows,K_in]   (dW must be initialised; fp32 atomics)."""
+    if kchunk is None and dy.dtype == torch.bfloat16:
+        # bf16 tiles take 16x less matrix time than fp32 ones: chunks as long as possible (fewer fp32 atomics: every chunk
+        # adds the whole 128 x 128 tile) while the grid still fills the chip's 512 workgroup slots once
+        tiles = ((N_out + 127) // 128) * ((K_in + 127) // 128)
+        per_group = max(1, rows // max(groups, 1))
+        chunks = max(1, 512 // (tiles * max(groups, 1)))
+        kchunk = min(16384, max(256, -(-per_group // chunks)))
+        kchunk = (kchunk + 63) // 64 * 64
     if kchunk is None:
-        kchunk = pick_kchunk(rows, groups > 1, dy.dtype == torch.bfloat16)
+        kchunk = pick_kchunk(rows, groups > 1)
     gemm(dy, 1, lddy, x, 1, ldx, dW, lddw, N_out, K_in, rows, groups=groups, group_mode=1,
          group_offsets=group_offsets, strideC=strideC, kchunk=kchunk)
 

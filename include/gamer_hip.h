@@ -338,7 +338,7 @@ int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float
 
 /* bf16 attention of the reference's --bf16 run (autocast casts q, k, v AND the additive mask of
  * sdpa_attention_forward to bf16).  Same predicate, layouts and dropout mask function as gamer_attn_fwd / _bwd, with
- * ONE semantic difference that the reference itself has under bf16 and that tests/golden/*_bf16.npz pin:
+ * ONE semantic difference that the reference itself has under bf16 and that the fixtures tests/golden/{small,full}_bf16.npz pin:
  * finfo(float32).min is not representable in bf16, the mask becomes -inf, and SDPA returns 0 for a query row with
  * no allowed key - so an "empty" row gives o = 0 (lse = 0) and no gradient instead of the fp32 run's uniform average
  * over all S keys.  (No row_empty / tile_empty / row order / uniform_len arguments: nothing depends on them.)
