@@ -94,14 +94,21 @@ class DecodeSession:
     step sit at the same position, hence in the same position-routed expert - and ``gamer_attn_decode``."""
 
     def __init__(self, engine, input_ids, attention_mask, actions, num_beams: int, max_new_tokens: int,
-                 session_ids=None, extended_session_ids=None):
-        """``session_ids`` / ``extended_session_ids`` [B, L0] (the test collator's layout, collator.py:176-195) for a
+                 session_ids=None, extended_session_ids=None, reorder_cross_cache: bool = False):
+        """``reorder_cross_cache=False`` (default) is the reference as shipped: its cross-attention K/V cache lives on
+        the module (model.py:569, 785, 844-860) and HF's beam search only re-orders ``past_key_values``, so the
+        generated positions' cross K/V rows stay in the beam SLOT that wrote them.  They are masked for every query
+        except target rows with no lower-level key in the prompt, whose uniform average then reads V rows of other
+        beams.  ``True`` re-orders the cross cache with the beams like the self cache (the consistent variant; the
+        only one the cache-free re-run path can reproduce).
+        ``session_ids`` / ``extended_session_ids`` [B, L0] (the test collator's layout, collator.py:176-195) for a
         "session" engine: the prompt runs with the session masks; the generated tokens then see every kept key in
         the self attention and the prompt's last cross-mask row in the cross attention, exactly as for Qwen3Multi
         (Qwen3SessionMulti/model.py:598-613, 716-728), with RoPE positions last extended id + 1, + 2, ...
         (:969-982)."""
         cfg, dev = engine.cfg, engine.device
         self.eng, self.nb, self.tmax = engine, num_beams, max_new_tokens
+        self.reorder_cross_cache = bool(reorder_cross_cache)
         self.B, self.L0 = input_ids.shape
         B, L0, nb = self.B, self.L0, num_beams
         self.N = N = B * nb
@@ -161,8 +168,11 @@ class DecodeSession:
         self.t = 0
 
     def reorder(self, parent: torch.Tensor):
-        """Beams were re-ordered: the generated part of the cache follows its beam (the prompt part is shared)."""
+        """Beams were re-ordered: the generated part of the SELF cache follows its beam (the prompt part is shared);
+        the cross cache only with ``reorder_cross_cache`` (see __init__)."""
         for key, (kg, vg) in self.gen.items():
+            if key[1] == "cross" and not self.reorder_cross_cache:
+                continue
             self.gen[key] = (kg.index_select(0, parent), vg.index_select(0, parent))
 
     def step(self, tokens: torch.Tensor) -> torch.Tensor:
@@ -235,12 +245,16 @@ class DecodeSession:
 @torch.no_grad()
 def beam_search(engine, input_ids: torch.Tensor, attention_mask: torch.Tensor, actions: torch.Tensor, trie: ItemTrie,
                 num_beams: int, max_new_tokens: int = 4, use_cache: bool = True, session_ids=None,
-                extended_session_ids=None) -> Tuple[torch.Tensor, torch.Tensor]:
+                extended_session_ids=None, reorder_cross_cache: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """input_ids / attention_mask / actions: [B, L0] left-padded prompts ending with the target behaviour token.
     Returns (sequences [B*num_beams, L0+max_new_tokens] int64, sequences_scores [B*num_beams] fp32), the beams of
     sample b at rows b*num_beams .., best first - the layout of HF's GenerateBeamOutput.
-    ``use_cache=False`` re-runs the whole sequence every step (the cross-check of the cache path).
+    ``use_cache=False`` re-runs the whole sequence every step (the cross-check of the cache path; it has no slots, so
+    it needs ``reorder_cross_cache=True``).  ``reorder_cross_cache``: see ``DecodeSession`` (False = the reference).
     ``session_ids`` / ``extended_session_ids`` [B, L0]: required by a "session" engine (see DecodeSession)."""
+    if not use_cache and not reorder_cross_cache:
+        raise ValueError("use_cache=False re-computes every position for its own beam: it can only reproduce "
+                         "reorder_cross_cache=True (the shipped reference's un-reordered cross cache needs the cache)")
     dev = engine.device
     B, L0 = input_ids.shape
     V = engine.cfg.vocab_size
@@ -278,7 +292,8 @@ def beam_search(engine, input_ids: torch.Tensor, attention_mask: torch.Tensor, a
             sid, ext = sid.repeat_interleave(nb, 0), ext.repeat_interleave(nb, 0)
         return dict(session_ids=sid, extended_session_ids=ext)
     session = (DecodeSession(engine, ids0, am0, act0, nb, max_new_tokens, session_ids if sess_variant else None,
-                             extended_session_ids if sess_variant else None) if use_cache else None)
+                             extended_session_ids if sess_variant else None, reorder_cross_cache=reorder_cross_cache)
+               if use_cache else None)
     last_tok = None
     for step in range(max_new_tokens):
         cur = L0 + step

@@ -200,7 +200,8 @@ class Qwen3MultiWithTemperature(nn.Module):
             raise ValueError("generate() needs attention_mask and actions")
         seqs, scores = decode.beam_search(self.engine, input_ids, attention_mask, actions, trie, num_beams, max_new_tokens,
                                           session_ids=kwargs.get("session_ids"),
-                                          extended_session_ids=kwargs.get("extended_session_ids"))
+                                          extended_session_ids=kwargs.get("extended_session_ids"),
+                                          reorder_cross_cache=bool(kwargs.get("reorder_cross_cache", False)))
         return CausalLMOutput(sequences=seqs, sequences_scores=scores)
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,

@@ -12,11 +12,15 @@
   The model is re-run on the whole sequence every step (no cache), with the two things a cache freezes passed
   explicitly: the prompt's last token keeps action index 0 (``act_zero_col``) and an "empty" row stays uniform
   over the keys that existed when it was computed (``uniform_len``).  That is equivalent to the reference's cached
-  decode (model.py:573-630, 691-741; router.py:83-97) except for ONE reference defect that is deliberately not
-  reproduced: the reference keeps the cross-attention K/V cache on the module (model.py:569, 785, 844-860) and HF
-  only reorders ``past_key_values``, so after a beam re-ordering the cross cache rows of GENERATED positions belong
-  to other beams.  Those keys are masked for every query except "empty" rows (no lower-level key in the prompt),
-  whose uniform attention then averages V rows of the wrong beam.  Rows with a non-empty mask are unaffected.
+  decode (model.py:573-630, 691-741; router.py:83-97) up to ONE thing the reference's cache does that a re-run
+  cannot see by itself: the reference keeps the cross-attention K/V cache on the module (model.py:569, 785,
+  844-860) and HF only reorders ``past_key_values``, so after a beam re-ordering the cross cache rows of GENERATED
+  positions belong to whichever beam sat in that SLOT when they were written.  Those keys are masked for every query
+  except "empty" rows (no lower-level key in the prompt), whose uniform attention then averages V rows of other
+  beams.  ``reorder_cross_cache=False`` (the default: the reference as shipped) restates exactly that with a
+  per-slot, append-only store of the generated positions' cross V rows and the slot every beam occupied when each of
+  its positions was computed; ``True`` is the variant with the cross cache re-ordered like the self cache (what the
+  fixture calls ``_crossfix``).  Rows with a non-empty mask are identical in both.
 * Qwen3SessionMulti (``session_ids`` / ``extended_session_ids`` given): its cached steps use a plain causal self
   mask and the prompt's last cross-mask row (Qwen3SessionMulti/model.py:598-613, 716-728) and advance the RoPE
   position by one per generated token from the prompt's largest extended id (:969-982).  Re-running the whole
@@ -53,12 +57,51 @@ class ItemTrie:
         return list(d.keys())
 
 
+class _SlotCrossCache:
+    """The generated part of the reference's module-level cross-attention cache under beam search: row (slot n,
+    generated index g) is written once, by the beam that sits in slot n when position L0 + g is computed, and never
+    moves.  ``hist[n][g]`` = the slot the beam NOW in slot n occupied at that time."""
+
+    def __init__(self, N: int, L0: int):
+        self.N, self.L0 = N, L0
+        self.v: Dict[str, Dict[int, torch.Tensor]] = {}          # layer prefix -> generated index -> [N, nkv, dh]
+        self.hist: List[List[int]] = [[] for _ in range(N)]
+
+    def hook(self, step: int, nq: int):
+        """o_hook of orc.attention for the forward of generation step ``step`` (>= 1: positions L0 .. L0+step-1 exist)."""
+        L0 = self.L0
+
+        def fn(prefix, o, v, empty):
+            store = self.v.setdefault(prefix, {})
+            g_new = step - 1
+            store[g_new] = v[:, L0 + g_new].detach().clone()      # this forward's newest position, written at its slot
+            rep = nq // v.shape[2]
+            o = o.clone()
+            for n in range(self.N):
+                slots = self.hist[n] + [n]                        # slot at positions g = 0 .. g_new
+                for g in range(step):
+                    if not bool(empty[n, L0 + g]):
+                        continue
+                    acc = v[n, :L0].sum(0)
+                    for g2 in range(g + 1):
+                        acc = acc + store[g2][slots[g]]
+                    o[n, L0 + g] = (acc / float(L0 + g + 1)).repeat_interleave(rep, 0)
+            return o
+        return fn
+
+    def advance(self, parent: List[int]):
+        """after the beams were re-ordered: new slot n continues the beam that sat in slot parent[n]"""
+        self.hist = [self.hist[p] + [p] for p in parent]
+
+
 def beam_search(sd, cfg, input_ids, attention_mask, actions, trie: ItemTrie, num_beams: int, max_new_tokens: int = 4,
-                forward=None, session_ids=None, extended_session_ids=None):
-    """Returns (sequences [B*num_beams, L0+max_new_tokens], sequences_scores [B*num_beams]), best beam first."""
+                forward=None, session_ids=None, extended_session_ids=None, reorder_cross_cache: bool = False):
+    """Returns (sequences [B*num_beams, L0+max_new_tokens], sequences_scores [B*num_beams]), best beam first.
+    ``reorder_cross_cache``: see the module docstring (False = the reference as shipped)."""
     B, L0 = input_ids.shape
     V = sd["model.embed_tokens.weight"].shape[0]
     K = 2 * num_beams
+    slot_cache = _SlotCrossCache(B * num_beams, L0) if (not reorder_cross_cache and forward is None) else None
     seqs = input_ids[:, None, :].expand(B, num_beams, L0).clone()
     run_scores = torch.zeros(B, num_beams)
     run_scores[:, 1:] = -1e9
@@ -77,8 +120,9 @@ def beam_search(sd, cfg, input_ids, attention_mask, actions, trie: ItemTrie, num
             skw = dict(session_ids=sess.repeat_interleave(num_beams, 0),
                        extended_session_ids=ext.repeat_interleave(num_beams, 0))
         if forward is None:
+            hook = slot_cache.hook(step, cfg.num_attention_heads) if (slot_cache is not None and step >= 1) else None
             with torch.no_grad():
-                logits = orc.forward(sd, cfg, flat, am, act, act_zero_col=L0 - 1, uniform_len=L0,
+                logits = orc.forward(sd, cfg, flat, am, act, act_zero_col=L0 - 1, uniform_len=L0, cross_o_hook=hook,
                                      **skw)["logits"][:, -1].float()
         else:
             logits = forward(flat, am, act, L0 - 1, **skw)
@@ -95,6 +139,9 @@ def beam_search(sd, cfg, input_ids, attention_mask, actions, trie: ItemTrie, num
         if step == max_new_tokens - 1:
             fin_seq, fin_score = cand_seq[:, :num_beams], top_s[:, :num_beams] / max_new_tokens
         seqs, run_scores = cand_seq[:, :num_beams].clone(), top_s[:, :num_beams].clone()
+        if slot_cache is not None and step >= 1:
+            parent = (beam_i[:, :num_beams] + torch.arange(B)[:, None] * num_beams).reshape(-1).tolist()
+            slot_cache.advance(parent)
     return fin_seq.reshape(B * num_beams, -1), fin_score.reshape(-1)
 
 

@@ -186,7 +186,7 @@ def _linear(x, w, amp: bool):
 
 
 def attention(h, sd, prefix, ok, cfg: OracleConfig, cos, sin, act_idx=None, training=False, uniform_len=None,
-              amp: bool = False):
+              amp: bool = False, o_hook=None):
     """Qwen3MultiAttention.forward (model.py:75-150) with the additive finfo.min mask folded in.
 
     ``amp`` = the reference under ``torch.autocast(bfloat16)`` (its ``--bf16`` run, train_SMB_decoder.py:114-118,
@@ -250,7 +250,12 @@ def attention(h, sd, prefix, ok, cfg: OracleConfig, cos, sin, act_idx=None, trai
     s_eff = torch.where(empty[:, None, :, None], s_empty, s_norm)
     p = torch.softmax(s_eff, dim=-1)
     p = _dropout(p, cfg.attention_dropout, training)
-    o = torch.einsum("bnij,bjnd->bind", p, vq).reshape(B, S, nq * dh)
+    o = torch.einsum("bnij,bjnd->bind", p, vq)
+    if o_hook is not None:
+        # evaluation only (oracle/decode_oracle.py): lets the decode restatement replace attention outputs whose
+        # VALUE rows come from the reference's un-reordered cross-attention cache
+        o = o_hook(prefix, o, v, empty)
+    o = o.reshape(B, S, nq * dh)
     out = F.linear(o, sd[prefix + "o_proj.weight"])
     if cross:
         out = out * F.silu(F.linear(h, sd[prefix + "gating.weight"]))
@@ -280,7 +285,8 @@ def sparse_mlp(h, sd, prefix, pos_idx, beh_idx, cfg: OracleConfig, inject: bool,
 def forward(sd: Dict[str, torch.Tensor], cfg: OracleConfig, input_ids, attention_mask, actions,
             labels=None, temperature: float = 1.0, num_items_in_batch: Optional[float] = None,
             training: bool = False, return_hidden: bool = False, act_zero_col: Optional[int] = None,
-            uniform_len: Optional[int] = None, session_ids=None, extended_session_ids=None, amp: bool = False):
+            uniform_len: Optional[int] = None, session_ids=None, extended_session_ids=None, amp: bool = False,
+            cross_o_hook=None):
     """Qwen3MultiWithTemperature.forward (model.py:928-1013).
 
     ``session_ids`` given: the Qwen3SessionMulti variant (``session_mask_predicates``; with
@@ -329,7 +335,8 @@ def forward(sd: Dict[str, torch.Tensor], cfg: OracleConfig, input_ids, attention
         x = x + _dropout(a, cfg.dropout_rate, training)
         if l in cfg.cross_attention_decoder:
             h = rmsnorm(x, sd[lp + "post_self_attention_layernorm.weight"], eps)
-            a = attention(h, sd, lp + "cross_attn.", cross_ok, cfg, cos, sin, act_idx, training, uniform_len, amp)
+            a = attention(h, sd, lp + "cross_attn.", cross_ok, cfg, cos, sin, act_idx, training, uniform_len, amp,
+                          o_hook=cross_o_hook)
             x = x + _dropout(a, cfg.dropout_rate, training)
         h = rmsnorm(x, sd[lp + "post_cross_attention_layernorm.weight"], eps)
         m = sparse_mlp(h, sd, lp + "mlp.", pos_idx, beh_idx, cfg,

@@ -61,20 +61,22 @@ def test_oracle_beam_search_matches_reference_generate(tb):
     beams, cb = meta["beams"], meta["codebook"]
     ids, am, act = _case(fx, tb)
     trie = dec.ItemTrie(synthetic.item_tokens(torch.from_numpy(fx["catalogue"]), tb, cb).tolist())
-    seq, sc = dec.beam_search(sd, ocfg, ids, am, act, trie, beams, 4)
     empty = _empty_target_rows(am, act)
     every = torch.ones_like(empty)
-    # with the reference's cross-attention cache re-ordered like past_key_values: every sample
-    _check(seq, sc, fx, tb, "_crossfix", every, beams, 2e-5)
-    # the reference as shipped: every sample whose target row can see a lower-level key
-    if (~empty).any():
-        _check(seq, sc, fx, tb, "", ~empty, beams, 2e-5)
+    # the reference AS SHIPPED (cross-attention cache not re-ordered with the beams): every sample of every behaviour,
+    # including behaviour 0 whose target rows are all "empty"
+    seq, sc = dec.beam_search(sd, ocfg, ids, am, act, trie, beams, 4)
+    _check(seq, sc, fx, tb, "", every, beams, 2e-5)
+    # option: the cross cache re-ordered like past_key_values (the fixture's patched run): every sample
+    seq_f, sc_f = dec.beam_search(sd, ocfg, ids, am, act, trie, beams, 4, reorder_cross_cache=True)
+    _check(seq_f, sc_f, fx, tb, "_crossfix", every, beams, 2e-5)
     if empty.any():
         # ... and the defect is real: an empty target row moves the reference's own scores by ~1e-2
         rs = torch.from_numpy(fx[f"b{tb}_scores"]).view(-1, beams)
         rf = torch.from_numpy(fx[f"b{tb}_scores_crossfix"]).view(-1, beams)
         assert float((rs[empty] - rf[empty]).abs().max()) > 1e-4
-        assert float((rs[~empty] - rf[~empty]).abs().max() if (~empty).any() else 0.0) < 1e-6
+        others = torch.cat([(rs[~empty] - rf[~empty]).abs().flatten(), torch.zeros(1, dtype=rs.dtype)])
+        assert float(others.max()) < 1e-6
 
 
 @pytest.mark.parametrize("tb", [0, 1, 2])
@@ -88,10 +90,11 @@ def test_oracle_session_beam_search_matches_reference_generate(tb):
     assert bool((sess[:, :-1].max(1).values + 1 == sess[:, -1]).all())          # the test collator's layout
     trie = dec.ItemTrie(synthetic.item_tokens(torch.from_numpy(fx["catalogue"]), tb, cb).tolist())
     seq, sc = dec.beam_search(sd, ocfg, ids, am, act, trie, beams, 4, session_ids=sess, extended_session_ids=ext)
-    empty = _empty_target_rows(am, act)
-    _check(seq, sc, fx, tb, "_crossfix", torch.ones_like(empty), beams, 2e-5)
-    if (~empty).any():
-        _check(seq, sc, fx, tb, "", ~empty, beams, 2e-5)
+    every = torch.ones(ids.shape[0], dtype=torch.bool)
+    _check(seq, sc, fx, tb, "", every, beams, 2e-5)                     # the reference as shipped, every row
+    seq_f, sc_f = dec.beam_search(sd, ocfg, ids, am, act, trie, beams, 4, session_ids=sess, extended_session_ids=ext,
+                                  reorder_cross_cache=True)
+    _check(seq_f, sc_f, fx, tb, "_crossfix", every, beams, 2e-5)
     # and the session masks matter on this fixture: Qwen3Multi's masks give other scores
     _, sc_multi = dec.beam_search(sd, ocfg, ids, am, act, trie, beams, 4)
     assert float((sc_multi - sc).abs().max()) > 1e-3
@@ -190,19 +193,24 @@ def test_engine_beam_search_matches_reference_generate(tb):
     eng.load_state_dict(sd)
     ids, am, act = _case(fx, tb)
     trie = ItemTrie(synthetic.item_tokens(torch.from_numpy(fx["catalogue"]), tb, cb).tolist())
+    every = torch.ones(ids.shape[0], dtype=torch.bool)
+    otrie = dec.ItemTrie(synthetic.item_tokens(torch.from_numpy(fx["catalogue"]), tb, cb).tolist())
+    # default = the reference AS SHIPPED (cross-attention cache not re-ordered with the beams): every row, every
+    # behaviour - including behaviour 0, whose target rows are all "empty" - against the un-patched generate()
     seq, sc = beam_search(eng, ids, am, act, trie, beams, 4)
-    # the K/V-cache path and the re-run-everything path give the same beams
-    seq_nc, sc_nc = beam_search(eng, ids, am, act, trie, beams, 4, use_cache=False)
-    assert torch.equal(seq, seq_nc) and float((sc - sc_nc).abs().max()) < 2e-5
-    empty = _empty_target_rows(am, act)
-    _check(seq, sc, fx, tb, "_crossfix", torch.ones_like(empty), beams, 1e-4)
-    if (~empty).any():
-        _check(seq, sc, fx, tb, "", ~empty, beams, 1e-4)
-    # and the oracle on the same inputs, beam for beam
-    oseq, osc = dec.beam_search(sd, ocfg, ids, am, act, dec.ItemTrie(synthetic.item_tokens(
-        torch.from_numpy(fx["catalogue"]), tb, cb).tolist()), beams, 4)
-    assert torch.equal(seq.cpu(), oseq)
-    assert float((sc.cpu() - osc).abs().max()) < 1e-4
+    _check(seq, sc, fx, tb, "", every, beams, 1e-4)
+    oseq, osc = dec.beam_search(sd, ocfg, ids, am, act, otrie, beams, 4)
+    assert torch.equal(seq.cpu(), oseq) and float((sc.cpu() - osc).abs().max()) < 1e-4
+    # option: cross cache re-ordered like the self cache = the patched reference run of the fixture; the K/V-cache
+    # path and the re-run-everything path give the same beams
+    seq_f, sc_f = beam_search(eng, ids, am, act, trie, beams, 4, reorder_cross_cache=True)
+    seq_nc, sc_nc = beam_search(eng, ids, am, act, trie, beams, 4, use_cache=False, reorder_cross_cache=True)
+    assert torch.equal(seq_f, seq_nc) and float((sc_f - sc_nc).abs().max()) < 2e-5
+    _check(seq_f, sc_f, fx, tb, "_crossfix", every, beams, 1e-4)
+    oseq, osc = dec.beam_search(sd, ocfg, ids, am, act, otrie, beams, 4, reorder_cross_cache=True)
+    assert torch.equal(seq_f.cpu(), oseq) and float((sc_f.cpu() - osc).abs().max()) < 1e-4
+    with pytest.raises(ValueError):
+        beam_search(eng, ids, am, act, trie, beams, 4, use_cache=False)
 
 
 @pytest.mark.gpu
@@ -223,17 +231,21 @@ def test_engine_session_beam_search_matches_reference_generate(tb):
     sess, ext = torch.from_numpy(fx[f"b{tb}_session_ids"]), torch.from_numpy(fx[f"b{tb}_extended_session_ids"])
     items = synthetic.item_tokens(torch.from_numpy(fx["catalogue"]), tb, cb).tolist()
     trie = ItemTrie(items)
+    every = torch.ones(ids.shape[0], dtype=torch.bool)
     seq, sc = beam_search(eng, ids, am, act, trie, beams, 4, session_ids=sess, extended_session_ids=ext)
-    seq_nc, sc_nc = beam_search(eng, ids, am, act, trie, beams, 4, use_cache=False, session_ids=sess,
-                                extended_session_ids=ext)
-    assert torch.equal(seq, seq_nc) and float((sc - sc_nc).abs().max()) < 2e-5
-    empty = _empty_target_rows(am, act)
-    _check(seq, sc, fx, tb, "_crossfix", torch.ones_like(empty), beams, 1e-4)
-    if (~empty).any():
-        _check(seq, sc, fx, tb, "", ~empty, beams, 1e-4)
+    _check(seq, sc, fx, tb, "", every, beams, 1e-4)                     # the reference as shipped, every row
     oseq, osc = dec.beam_search(sd, ocfg, ids, am, act, dec.ItemTrie(items), beams, 4, session_ids=sess,
                                 extended_session_ids=ext)
     assert torch.equal(seq.cpu(), oseq) and float((sc.cpu() - osc).abs().max()) < 1e-4
+    seq_f, sc_f = beam_search(eng, ids, am, act, trie, beams, 4, session_ids=sess, extended_session_ids=ext,
+                              reorder_cross_cache=True)
+    seq_nc, sc_nc = beam_search(eng, ids, am, act, trie, beams, 4, use_cache=False, session_ids=sess,
+                                extended_session_ids=ext, reorder_cross_cache=True)
+    assert torch.equal(seq_f, seq_nc) and float((sc_f - sc_nc).abs().max()) < 2e-5
+    _check(seq_f, sc_f, fx, tb, "_crossfix", every, beams, 1e-4)
+    oseq, osc = dec.beam_search(sd, ocfg, ids, am, act, dec.ItemTrie(items), beams, 4, session_ids=sess,
+                                extended_session_ids=ext, reorder_cross_cache=True)
+    assert torch.equal(seq_f.cpu(), oseq) and float((sc_f.cpu() - osc).abs().max()) < 1e-4
     out = model.generate(input_ids=ids, attention_mask=am, actions=act, session_ids=sess, extended_session_ids=ext,
                          max_new_tokens=4, prefix_allowed_tokens_fn=prefix_allowed_tokens(trie), num_beams=beams,
                          num_return_sequences=beams)
