@@ -313,6 +313,10 @@ def parse_args(argv=None):
     ap.add_argument("--items", type=int, default=101, help="items per sequence (max_his_len + 1)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = BASELINE configs[1] (headline); bf16 = the AMP variant of configs[2]")
+    ap.add_argument("--path", choices=["engine", "module", "module-fused"], default="engine",
+                    help="engine = Engine.train_step (the fused fast path, headline); module = the nn.Module plug-in surface "
+                         "driven the way HF Trainer drives the reference (forward -> loss.backward() -> clip_grad_norm_ -> "
+                         "torch AdamW -> zero_grad); module-fused = the same with the module's FusedClipAdamW optimizer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (and the roofline object)")
@@ -441,10 +445,42 @@ def main(argv=None):
     lr = 5e-4
     grad_scale = 1.0                              # gradients are already global means (sum CE / global count)
 
+    module = opt = None
+    if args.path != "engine":
+        if world > 1:
+            raise SystemExit("--path module is a single-GPU measurement (HF Trainer would wrap the module in DDP)")
+        from gamer_amd.modeling import Qwen3MultiWithTemperature, Qwen3SessionMultiWithTemperature
+        cls = Qwen3MultiWithTemperature if args.variant == "multi" else Qwen3SessionMultiWithTemperature
+        del eng
+        torch.cuda.empty_cache()
+        module = cls(cfg, device=f"cuda:{local_rank}", dtype=args.dtype)
+        module.set_hyper(0.7)
+        module.train()
+        eng = module.engine
+        eng.base_seed = 0x5EED + rank
+        if args.path == "module-fused":
+            opt = module.fused_optimizer(lr=lr, weight_decay=0.01, max_grad_norm=1.0)
+        else:
+            # HF Trainer's parameter groups: no weight decay on the norm weights (get_decay_parameter_names)
+            decay = [p for n, p in module.named_parameters() if not n.endswith("norm.weight")]
+            nodecay = [p for n, p in module.named_parameters() if n.endswith("norm.weight")]
+            opt = torch.optim.AdamW([dict(params=decay, weight_decay=0.01), dict(params=nodecay, weight_decay=0.0)], lr=lr,
+                                    betas=(0.9, 0.999), eps=1e-8)
+
     def step(i):
         f = flops[i % n_batches]
         timer.pairs = {"self": f["p_self"], "cross": f["p_cross"]}
-        return eng.train_step(batches[i % n_batches], lr, reducer=reducer, grad_scale=grad_scale)
+        if module is None:
+            return eng.train_step(batches[i % n_batches], lr, reducer=reducer, grad_scale=grad_scale)
+        b = batches[i % n_batches]
+        out = module(input_ids=b["input_ids"], attention_mask=b["attention_mask"], actions=b["actions"], labels=b["labels"],
+                     session_ids=b.get("session_ids"), extended_session_ids=b.get("extended_session_ids"), split="train")
+        out.loss.backward()
+        if args.path == "module":
+            torch.nn.utils.clip_grad_norm_(module.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return out.loss.detach()
 
     def barrier():
         if world > 1 or force_dist:
@@ -547,6 +583,7 @@ def main(argv=None):
                 "global_batch": args.batch * world,
                 "seq_len": args.items * 5,
                 "parallelism": f"dp{world}",
+                "path": args.path,
             },
             "roofline": {
                 "bound": "mfma",

@@ -101,7 +101,7 @@ _SIGNATURES = {
     "gamer_silu_gate_bwd": [P, P, P, L, P, P, F, U, P],
     "gamer_check_labels": [P, L, I, I, P, P],
     "gamer_ce_fwd": [P, I, P, I, I, I, F, I, P, P, P, P, P],
-    "gamer_ce_bwd": [P, I, P, I, I, I, F, I, P, P, F, F, P],
+    "gamer_ce_bwd": [P, I, P, I, I, I, F, I, P, P, F, F, P, P],
     "gamer_sumsq": [P, L, P, I, P],
     "gamer_adamw": [P, P, P, P, L, L, F, F, F, F, F, I, F, F, P, I, P, P],
     "gamer_fill_f32": [P, L, F, P],

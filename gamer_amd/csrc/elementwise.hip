@@ -797,12 +797,12 @@ template <typename TL>
 __global__ void __launch_bounds__(EW_THREADS)
 ce_bwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labels, int T, int S, int V,
               int ignore_index, const float* __restrict__ lse, const float* __restrict__ count_dev,
-              float denom_host, float dloss_over_temp) {
+              float denom_host, float dloss_over_temp, const float* __restrict__ dloss_dev) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * EW_THREADS) >> 6;
     const float denom = count_dev ? count_dev[0] : denom_host;
-    const float gs = dloss_over_temp / denom;
+    const float gs = dloss_over_temp * (dloss_dev ? dloss_dev[0] : 1.f) / denom;
     for (int t = wave; t < T; t += nwaves) {
         TL* row = logits + (int64_t)t * ldl;
         const int s = t % S;
@@ -1178,27 +1178,27 @@ extern "C" int gamer_ce_fwd_bf16(gamer_bf16* logits, int ldl, const int64_t* lab
 template <typename TL>
 static int ce_bwd_impl(const char* name, TL* logits, int ldl, const int64_t* labels, int B, int S, int V,
                        float temperature, int ignore_index, const float* lse, const float* count_dev, float denom_host,
-                       float dloss, void* stream) {
+                       float dloss, const float* dloss_dev, void* stream) {
     GAMER_CHECK_ARG(logits && labels && lse, "%s: null pointer", name);
     GAMER_CHECK_ARG(B > 0 && S > 0 && V > 0 && ldl >= V && temperature > 0.f, "%s: bad shape", name);
     GAMER_CHECK_ARG(count_dev || denom_host > 0.f, "%s: need count_dev or a positive denom_host", name);
     const int T = B * S;
     hipLaunchKernelGGL(ce_bwd_kernel<TL>, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), logits, ldl, labels, T,
-                       S, V, ignore_index, lse, count_dev, denom_host, dloss / temperature);
+                       S, V, ignore_index, lse, count_dev, denom_host, dloss / temperature, dloss_dev);
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }
 extern "C" int gamer_ce_bwd(float* logits, int ldl, const int64_t* labels, int B, int S, int V, float temperature,
                             int ignore_index, const float* lse, const float* count_dev, float denom_host, float dloss,
-                            void* stream) {
+                            const float* dloss_dev, void* stream) {
     return ce_bwd_impl<float>("gamer_ce_bwd", logits, ldl, labels, B, S, V, temperature, ignore_index, lse, count_dev,
-                              denom_host, dloss, stream);
+                              denom_host, dloss, dloss_dev, stream);
 }
 extern "C" int gamer_ce_bwd_bf16(gamer_bf16* logits, int ldl, const int64_t* labels, int B, int S, int V,
                                  float temperature, int ignore_index, const float* lse, const float* count_dev,
-                                 float denom_host, float dloss, void* stream) {
+                                 float denom_host, float dloss, const float* dloss_dev, void* stream) {
     return ce_bwd_impl<bf16_t>("gamer_ce_bwd_bf16", (bf16_t*)logits, ldl, labels, B, S, V, temperature, ignore_index, lse,
-                               count_dev, denom_host, dloss, stream);
+                               count_dev, denom_host, dloss, dloss_dev, stream);
 }
 
 extern "C" int gamer_fill_f32(float* p, int64_t n, float value, void* stream) {

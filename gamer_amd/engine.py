@@ -653,9 +653,10 @@ class Engine:
     def zero_grad(self):
         ops.fill(self.flat_g, 0.0)
 
-    def backward(self, dloss: float = 1.0, layer_done=None):
+    def backward(self, dloss: float = 1.0, layer_done=None, dloss_dev: Optional[torch.Tensor] = None):
         """Accumulates d(loss)*dloss into the flat gradient buffer (call zero_grad() first for a fresh
-        window).  Needs a forward(..., labels=..., train=True) before it.  ``layer_done(l)`` is called as
+        window).  Needs a forward(..., labels=..., train=True) before it.  ``dloss_dev``: fp32 device scalar that
+        multiplies ``dloss`` (the module path hands autograd's incoming gradient over without reading it on the host).  ``layer_done(l)`` is called as
         soon as every kernel writing layer l's weight gradients has been enqueued (data-parallel
         all-reduce overlap, gamer_amd.dp)."""
         sv = self._saved
@@ -720,10 +721,10 @@ class Engine:
         # ---- loss -> logits -> final norm ----
         if sv["num_items"] is not None:
             ops.ce_bwd(ws.logits, ws.ldl, sv["labels"], V, self.temperature, IGNORE_INDEX, ws.lse_ce, None,
-                       float(sv["num_items"]), dloss)
+                       float(sv["num_items"]), dloss, dloss_dev)
         else:
             ops.ce_bwd(ws.logits, ws.ldl, sv["labels"], V, self.temperature, IGNORE_INDEX, ws.lse_ce, ws.count, 0.0,
-                       dloss)
+                       dloss, dloss_dev)
         ops.linear_wgrad(ws.logits, ws.ldl, ws.xn, H, demb, H, T, V, H)
         t0, t1, t2, t3 = ws.tmpH
         L = cfg.num_hidden_layers

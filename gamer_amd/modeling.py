@@ -11,6 +11,7 @@ fused fast path used by bench.py.  There is no CPU implementation here.
 from __future__ import annotations
 
 import json
+import math
 import os
 from collections import OrderedDict
 from typing import Optional
@@ -44,7 +45,9 @@ class _ModelFn(torch.autograd.Function):
         loss, logits = eng.forward(input_ids, attention_mask, actions, labels=labels, num_items_in_batch=num_items,
                                    train=True, dropout=model.training, session_ids=sess[0],
                                    extended_session_ids=sess[1])
-        logits = logits.clone()          # Engine.backward() reuses the logits buffer for d(logits)
+        # `logits` is a view of the engine's workspace: valid until this step's backward (which turns the buffer into
+        # d(logits)) or the next forward.  The training loop only reads `loss` (HF Trainer.training_step); a 2.2 GB
+        # copy per forward at batch 1024 would buy nothing.  The no-grad forward below hands out a copy.
         ctx.model = model
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(logits)
@@ -54,8 +57,15 @@ class _ModelFn(torch.autograd.Function):
     def backward(ctx, dloss, _dlogits):
         eng: Engine = ctx.model.engine
         eng.zero_grad()
-        eng.backward(float(dloss) if dloss is not None else 0.0)
-        grads = [eng.grads[k].clone() for k in ctx.model._param_keys]
+        if dloss is None:
+            eng.backward(0.0)
+        else:
+            # the incoming gradient stays on the device (no host read between forward and backward)
+            eng.backward(1.0, dloss_dev=dloss.detach().to(torch.float32).reshape(1).contiguous())
+        # one 98 MB device copy (~40 us): autograd accumulates into .grad tensors of its own, the engine's flat
+        # gradient buffer is rewritten by the next backward
+        flat = eng.flat_g.clone()
+        grads = [flat[o:o + math.prod(s)].view(s) for o, s in (eng.layout.entries[k] for k in ctx.model._param_keys)]
         return (None, None, None, None, None, None, None, *grads)
 
 
@@ -86,7 +96,9 @@ except Exception:                                             # noqa: BLE001
 class Qwen3MultiWithTemperature(nn.Module):
     VARIANT = "multi"
 
-    def __init__(self, config: Qwen3MultiConfig, device: str = "cuda"):
+    def __init__(self, config: Qwen3MultiConfig, device: str = "cuda", dtype: str = "f32"):
+        """``dtype="bf16"``: what the reference gets from ``--bf16`` (HF Trainer autocast) is a property of the engine
+        here - bf16 matrix operands and activations, fp32 parameters / gradients (the nn.Parameters stay fp32)."""
         super().__init__()
         assert "num_positions" in config and isinstance(config.num_positions, int), \
             "Config must have 'num_positions' attribute for Qwen3SessionModel."
@@ -95,10 +107,17 @@ class Qwen3MultiWithTemperature(nn.Module):
         self.config = config
         self.vocab_size = config.vocab_size
         self.temperature = 1.0
-        self.engine = Engine(config, device=device, temperature=1.0, variant=self.VARIANT)
+        self.engine = Engine(config, device=device, temperature=1.0, variant=self.VARIANT, dtype=dtype)
         self.engine.init_weights(seed=0)
         self._param_keys = list(self.engine.layout.entries.keys())
         self._register_views()
+
+    def fused_optimizer(self, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
+                        max_grad_norm: float = 1.0) -> "FusedClipAdamW":
+        """torch.optim.Optimizer over this module's parameters that runs clip_grad_norm_(max_grad_norm) + AdamW as
+        the engine's two fused sweeps over the flat buffers (HF Trainer: pass it as ``optimizers=(opt, scheduler)`` and
+        set ``max_grad_norm=0`` so that the Trainer does not clip a second time)."""
+        return FusedClipAdamW(self, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
 
     def _register_views(self):
         """nn.Parameters that alias the engine's flat buffer, hung on a tree of empty holder modules with the
@@ -132,7 +151,7 @@ class Qwen3MultiWithTemperature(nn.Module):
         self.config.vocab_size = int(new_num_tokens)
         self.vocab_size = int(new_num_tokens)
         self.engine = Engine(self.config, device=str(self.engine.device), temperature=self.temperature,
-                             variant=self.VARIANT)
+                             variant=self.VARIANT, dtype=self.engine.dtype)
         self.engine.init_weights(seed=0)
         for name in list(self._modules):                      # drop the old parameter tree
             del self._modules[name]
@@ -170,9 +189,9 @@ class Qwen3MultiWithTemperature(nn.Module):
             torch.save(sd, os.path.join(path, "pytorch_model.bin"))
 
     @classmethod
-    def from_pretrained(cls, path: str, device: str = "cuda"):
+    def from_pretrained(cls, path: str, device: str = "cuda", dtype: str = "f32"):
         cfg = Qwen3MultiConfig.from_pretrained(path)
-        model = cls(cfg, device=device)
+        model = cls(cfg, device=device, dtype=dtype)
         st = os.path.join(path, "model.safetensors")
         if os.path.exists(st):
             from safetensors.torch import load_file
@@ -236,6 +255,49 @@ class Qwen3MultiWithTemperature(nn.Module):
         if isinstance(logits_to_keep, int) and logits_to_keep > 0:
             logits = logits[:, -logits_to_keep:, :]
         return CausalLMOutput(loss=loss, logits=logits, past_key_values=None, hidden_states=None, attentions=None)
+
+
+class FusedClipAdamW(torch.optim.Optimizer):
+    """clip_grad_norm_ + AdamW of the HF Trainer defaults (ref:SeqRec/tasks/train_SMB_decoder.py:396-428) as the
+    engine's fused kernels (gamer_sumsq + gamer_adamw: 28 B per parameter in one sweep) behind the torch optimizer
+    interface: ``param_groups[0]["lr"]`` is what schedulers drive; norm weights get no weight decay (the engine's
+    layout keeps them behind ``n_decay``), as HF's ``get_decay_parameter_names`` arranges for the reference."""
+
+    def __init__(self, model: "Qwen3MultiWithTemperature", lr, betas, eps, weight_decay, max_grad_norm):
+        self.model = model
+        super().__init__([p for p in model.parameters()], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                                               max_grad_norm=max_grad_norm))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        eng, g = self.model.engine, self.param_groups[0]
+        # gather the autograd gradients into the flat buffer (one foreach copy; parameters without a gradient count 0)
+        views = eng.layout.views(eng.flat_g)
+        have = [(views[k], self.model._params_by_key[k].grad) for k in self.model._param_keys]
+        dst = [d for d, s in have if s is not None]
+        src = [s for d, s in have if s is not None]
+        for d, s in have:
+            if s is None:
+                d.zero_()
+        if dst:
+            torch._foreach_copy_(dst, src)
+        eng.optimizer_step(g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
+                           max_norm=float(g["max_grad_norm"] or 0.0))          # 0 = no clipping
+        return loss
+
+    def state_dict(self):
+        eng = self.model.engine
+        return {"state": {"m": eng.flat_m, "v": eng.flat_v, "step": eng.opt_step}, "param_groups": self.param_groups}
+
+    def load_state_dict(self, sd):
+        eng = self.model.engine
+        st = sd["state"]
+        if st.get("m") is not None:
+            eng.flat_m, eng.flat_v = st["m"].to(eng.device).clone(), st["v"].to(eng.device).clone()
+        eng.opt_step = int(st.get("step", 0))
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in saved.items() if k != "params"})
 
 
 class Qwen3SessionMultiWithTemperature(Qwen3MultiWithTemperature):

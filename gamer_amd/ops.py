@@ -336,10 +336,11 @@ def ce_fwd(logits, ldl, labels, V, temperature, ignore_index, lse, row_loss, los
          ptr(loss_sum), ptr(count), stream_ptr())
 
 
-def ce_bwd(logits, ldl, labels, V, temperature, ignore_index, lse, count_dev, denom_host, dloss):
+def ce_bwd(logits, ldl, labels, V, temperature, ignore_index, lse, count_dev, denom_host, dloss, dloss_dev=None):
+    """dloss_dev: optional fp32 device scalar multiplied into dloss (autograd's incoming gradient, no host read)."""
     B, S = labels.shape
     call("gamer_ce_bwd" + _sfx(logits), ptr(logits), ldl, ptr(labels), B, S, V, temperature, ignore_index, ptr(lse), ptr(count_dev),
-         float(denom_host), float(dloss), stream_ptr())
+         float(denom_host), float(dloss), ptr(dloss_dev), stream_ptr())
 
 
 def sumsq(g, partial):

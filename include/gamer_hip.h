@@ -432,7 +432,8 @@ int gamer_silu_gate_bwd_bf16(const gamer_bf16* a, const gamer_bf16* gate, const 
  *   row_loss [T] per-row CE (0 where ignored), lse_out [T]; loss_sum[0] = sum CE and
  *   count[0] = #targets != ignore, both reduced in a fixed order (deterministic).
  * bwd: logits <- (softmax - onehot) * dloss / (denom * temperature), denom = count_dev[0] when
- *   count_dev != NULL (mean reduction) else denom_host (num_items_in_batch from the trainer).
+ *   count_dev != NULL (mean reduction) else denom_host (num_items_in_batch from the trainer); dloss_dev (optional,
+ *   device scalar) multiplies dloss: the incoming gradient of the loss under autograd, read without a host sync.
  * ---------------------------------------------------------------------------------------- */
 /* bad_label[0] += number of labels that are neither ignore_index nor inside [0, V): the reference's
  * nn.CrossEntropyLoss raises on those (transformers/loss/loss_utils.py fixed_cross_entropy); gamer_ce_* skip them, so
@@ -444,7 +445,7 @@ int gamer_ce_fwd(float* logits, int ldl, const int64_t* labels, int B, int S, in
                  float* loss_sum, float* count, void* stream);
 int gamer_ce_bwd(float* logits, int ldl, const int64_t* labels, int B, int S, int V,
                  float temperature, int ignore_index, const float* lse, const float* count_dev,
-                 float denom_host, float dloss, void* stream);
+                 float denom_host, float dloss, const float* dloss_dev, void* stream);
 /* bf16 logits (what the reference's lm_head returns under autocast; the in-place /temperature rounds to bf16 again,
  * as upstream); lse / loss / count are fp32 (loss_utils.py upcasts the logits).  bwd writes d(logits) as bf16.     */
 int gamer_ce_fwd_bf16(gamer_bf16* logits, int ldl, const int64_t* labels, int B, int S, int V,
@@ -452,7 +453,7 @@ int gamer_ce_fwd_bf16(gamer_bf16* logits, int ldl, const int64_t* labels, int B,
                       float* loss_sum, float* count, void* stream);
 int gamer_ce_bwd_bf16(gamer_bf16* logits, int ldl, const int64_t* labels, int B, int S, int V,
                       float temperature, int ignore_index, const float* lse, const float* count_dev,
-                      float denom_host, float dloss, void* stream);
+                      float denom_host, float dloss, const float* dloss_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * HF Trainer update: clip_grad_norm_(max_norm) + AdamW (transformers/trainer.py;

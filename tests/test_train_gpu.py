@@ -28,6 +28,23 @@ def test_train_harness_learns_and_resumes(tmp_path):
     assert abs(state2["log_history"][-1]["loss"] - losses[-1]) < 0.15
 
 
+def test_train_harness_bf16_flag_and_fp16_refusal(tmp_path):
+    """--bf16 (the reference's AMP flag, train_SMB_decoder.py:114-118) trains through the bf16 kernels with fp32 master
+    weights: the loss falls like the fp32 run's on the same stream; --fp16 is refused, not ignored."""
+    from gamer_amd import train
+    base = ["--max_his_len", "20", "--per_device_batch_size", "16", "--gradient_accumulation_steps", "2", "--epochs", "1",
+            "--steps_per_epoch", "24", "--logging_step", "4", "--warmup_ratio", "0.1"]
+    s16 = train.main(base + ["--bf16"])
+    s32 = train.main(base)
+    l16 = [r["loss"] for r in s16["log_history"] if "loss" in r]
+    l32 = [r["loss"] for r in s32["log_history"] if "loss" in r]
+    assert l16[-1] < l16[0] - 0.3, l16
+    assert abs(l16[-1] - l32[-1]) < 0.15, (l16, l32)
+    assert all(r["train_samples_per_second"] > 0 for r in s16["log_history"] if "loss" in r)
+    with pytest.raises(SystemExit):
+        train.main(base + ["--fp16"])
+
+
 @pytest.mark.parametrize("backbone", ["Qwen3Multi", "Qwen3SessionMulti"])
 def test_train_harness_on_a_dataset_in_the_reference_format(tmp_path, backbone):
     """--data_path/--dataset/--tasks as upstream: dataset directory (written in the reference's on-disk format) ->
