@@ -282,8 +282,15 @@ class FusedClipAdamW(torch.optim.Optimizer):
                 d.zero_()
         if dst:
             torch._foreach_copy_(dst, src)
-        eng.optimizer_step(g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
-                           max_norm=float(g["max_grad_norm"] or 0.0))          # 0 = no clipping
+        if eng.flat_m is None:
+            eng.flat_m, eng.flat_v = torch.zeros_like(eng.flat_p), torch.zeros_like(eng.flat_p)
+        eng.opt_step += 1
+        from . import torch_ops
+        # the dispatcher-registered op (TORCH_LIBRARY(gamer), csrc/torch_ops.cpp): gamer_sumsq + gamer_adamw
+        norm = torch_ops.load().fused_adamw_clip(eng.flat_p, eng.flat_g, eng.flat_m, eng.flat_v, eng.layout.n_decay,
+                                                 float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
+                                                 eng.opt_step, float(g["max_grad_norm"] or 0.0), 1.0)   # 0 = no clipping
+        eng.grad_norm.copy_(norm)
         return loss
 
     def state_dict(self):
