@@ -90,9 +90,11 @@ embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // RMSNorm (hidden dim H <= 1024, H % 4 == 0); one wave per row, row cached in registers
 // ---------------------------------------------------------------------------------------------
-constexpr int RMS_MAXC = 4;   // float4 chunks per lane -> H <= 1024
+// float4 chunks per lane: 1 for H <= 256 (the shipped hidden size: one chunk per lane, 4x fewer registers - the
+// 4-chunk form sat at 134 VGPRs = 3 waves per SIMD after the dtype templating, 9.2 -> 12.3 ms per step), 4 for H <= 1024
+constexpr int RMS_MAXC_BIG = 4;
 
-template <typename TY>
+template <typename TY, int RMS_MAXC>
 __global__ void __launch_bounds__(EW_THREADS)
 rmsnorm_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, int T, int H4, float inv_h,
                    float eps, const int32_t* __restrict__ dst_rows, TY* __restrict__ y, int ldy) {
@@ -134,7 +136,7 @@ rmsnorm_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, i
 }
 
 // dx (+)= rstd*(w*dy - xhat*mean(w*dy*xhat)); per-workgroup dw partial sums (deterministic).
-template <typename TG>
+template <typename TG, int RMS_MAXC>
 __global__ void __launch_bounds__(EW_THREADS)
 rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, const TG* __restrict__ dy,
                    int lddy, const int32_t* __restrict__ dy_rows, int T, int H4, float inv_h, float eps,
@@ -513,6 +515,217 @@ qknorm_rope_bwd_kernel(const TA* __restrict__ qkv, const TA* __restrict__ dq_rot
     }
 }
 
+// ---- bf16 activations: 8 lanes x 8 elements (16 bytes) per (token, head) row, 8 rows per wave --------------------
+// Same arithmetic as the <bf16_t> instantiations of the kernels above (which move 8 bytes per lane and ran at
+// 2.4 TB/s); the RoPE partner (d +- 32) is lane +- 4 of the 8-lane group.
+__device__ __forceinline__ float group8_sum(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+}
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&f)[8]) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+}
+__device__ __forceinline__ void ld8(const float* p, float (&f)[8]) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&f)[8]) {
+    f32x8v v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = f[e];
+    *reinterpret_cast<bf16x8*>(p) = __builtin_convertvector(v, bf16x8);
+}
+
+__global__ void __launch_bounds__(EW_THREADS)
+qknorm_rope_fwd_b8_kernel(bf16_t* __restrict__ qkv, int T, int S, int nq, int nkv,
+                          const float* __restrict__ wq, const float* __restrict__ wk, float eps,
+                          const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                          const float* __restrict__ bias_q, const float* __restrict__ bias_k,
+                          const float* __restrict__ bias_v, const int32_t* __restrict__ act_idx,
+                          bf16_t* __restrict__ q_rot, bf16_t* __restrict__ k_rot, const int32_t* __restrict__ pos_ids) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane & 7, sub = lane >> 3;
+    const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * EW_THREADS) >> 6;
+    const bool cross = bias_q != nullptr;
+    const int NH = nq + nkv + (cross ? nkv : 0);
+    const int ldqkv = (nq + 2 * nkv) * 64;
+    float wqv[8], wkv[8];
+    ld8(wq + 8 * g, wqv);
+    ld8(wk + 8 * g, wkv);
+    const float sgn = g < 4 ? -1.f : 1.f;
+    const int64_t total = (int64_t)T * NH;
+    for (int64_t i0 = wave * 8; i0 < total; i0 += nwaves * 8) {
+        const int64_t i = i0 + sub;
+        const bool live = i < total;
+        const int64_t ic = live ? i : total - 1;
+        const int t = (int)(ic / NH);
+        const int hd = (int)(ic % NH);
+        const int a = cross ? act_idx[t] : 0;
+        bf16_t* row = qkv + (int64_t)t * ldqkv;
+        if (hd < nq + nkv) {
+            const bool isq = hd < nq;
+            float x[8];
+            ld8(row + hd * 64 + 8 * g, x);
+            if (cross) {
+                float b[8];
+                ld8(isq ? bias_q + (int64_t)a * nq * 64 + hd * 64 + 8 * g : bias_k + (int64_t)a * nkv * 64 + (hd - nq) * 64 + 8 * g, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] += b[e];
+            }
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+            ss = group8_sum(ss);
+            const float rstd = rsqrtf(ss * (1.f / 64.f) + eps);
+            float y[8], pr[8], c[8], sn[8], o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float xn = x[e] * rstd;
+                if (!cross) xn = round_as<bf16_t>(xn);        // Qwen3MoeRMSNorm on a bf16 tensor: .to(input_dtype) before * weight
+                y[e] = (isq ? wqv[e] : wkv[e]) * xn;
+                pr[e] = __shfl_xor(y[e], 4, 64);
+            }
+            const int pos = pos_ids ? pos_ids[t] : t % S;
+            ld8(cos_t + pos * 64 + 8 * g, c);
+            ld8(sin_t + pos * 64 + 8 * g, sn);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = y[e] * c[e] + sgn * pr[e] * sn[e];
+            if (live) {
+                if (isq) st8(q_rot + (int64_t)t * nq * 64 + hd * 64 + 8 * g, o);
+                else st8(k_rot + (int64_t)t * nkv * 64 + (hd - nq) * 64 + 8 * g, o);
+            }
+        } else {
+            const int hv = hd - nq - nkv;
+            bf16_t* dst = row + (nq + nkv + hv) * 64 + 8 * g;
+            float x[8], b[8];
+            ld8(dst, x);
+            ld8(bias_v + (int64_t)a * nkv * 64 + hv * 64 + 8 * g, b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += b[e];
+            if (live) st8(dst, x);
+        }
+    }
+}
+
+// NBR = compile-time bound of the bias-table rows (4 for the shipped three behaviours, 8 otherwise)
+template <int NBR>
+__global__ void __launch_bounds__(EW_THREADS)
+qknorm_rope_bwd_b8_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dq_rot,
+                          const bf16_t* __restrict__ dk_rot, int T, int S, int nq, int nkv,
+                          const float* __restrict__ wq, const float* __restrict__ wk, float eps,
+                          const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                          int cross, const float* __restrict__ bias_q, const float* __restrict__ bias_k,
+                          const int32_t* __restrict__ act_idx, int nb1,
+                          bf16_t* __restrict__ dqkv, float* __restrict__ partial,
+                          int waves_per_head, const int32_t* __restrict__ pos_ids) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane & 7, sub = lane >> 3;
+    const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
+    const int NH = nq + nkv + (cross ? nkv : 0);
+    if (wave >= (int64_t)NH * waves_per_head) return;
+    const int hd = (int)(wave % NH);
+    const int w0 = (int)(wave / NH);
+    const int ldqkv = (nq + 2 * nkv) * 64;
+    float dwacc[8], dbacc[NBR][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dwacc[e] = 0.f;
+#pragma unroll
+    for (int a = 0; a < NBR; ++a)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dbacc[a][e] = 0.f;
+    const float sgn = g < 4 ? 1.f : -1.f;             // transpose of the rotation
+    if (hd < nq + nkv) {
+        const bool isq = hd < nq;
+        float w8[8];
+        ld8((isq ? wq : wk) + 8 * g, w8);
+        for (int tb = w0 * 8; tb < T; tb += waves_per_head * 8) {
+            const int t = tb + sub;
+            const bool live = t < T;
+            const int tc = live ? t : T - 1;
+            float x[8], d[8], c[8], sn[8];
+            ld8(qkv + (int64_t)tc * ldqkv + hd * 64 + 8 * g, x);
+            const int a_t = cross ? act_idx[tc] : 0;
+            if (cross) {
+                float b[8];
+                ld8(isq ? bias_q + (int64_t)a_t * nq * 64 + hd * 64 + 8 * g : bias_k + (int64_t)a_t * nkv * 64 + (hd - nq) * 64 + 8 * g, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] += b[e];
+            }
+            ld8(isq ? dq_rot + (int64_t)tc * nq * 64 + hd * 64 + 8 * g : dk_rot + (int64_t)tc * nkv * 64 + (hd - nq) * 64 + 8 * g, d);
+            const int pos = pos_ids ? pos_ids[tc] : tc % S;
+            ld8(cos_t + pos * 64 + 8 * g, c);
+            ld8(sin_t + pos * 64 + 8 * g, sn);
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+            ss = group8_sum(ss);
+            const float rstd = rsqrtf(ss * (1.f / 64.f) + eps);
+            const float lv = live ? 1.f : 0.f;
+            float gg[8], xh[8], dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float dp = __shfl_xor(d[e], 4, 64);
+                const float dy = d[e] * c[e] + sgn * dp * sn[e];
+                xh[e] = x[e] * rstd;
+                dwacc[e] += lv * dy * (cross ? xh[e] : round_as<bf16_t>(xh[e]));
+                gg[e] = dy * w8[e];
+                dot += gg[e] * xh[e];
+            }
+            dot = group8_sum(dot) * (1.f / 64.f);
+            float dx[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dx[e] = rstd * (gg[e] - xh[e] * dot);
+            if (live) st8(dqkv + (int64_t)t * ldqkv + hd * 64 + 8 * g, dx);
+            if (cross) {
+                const int a_l = live ? a_t : -1;
+#pragma unroll
+                for (int a = 0; a < NBR; ++a) {
+                    const float m = (a_l == a) ? 1.f : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dbacc[a][e] += m * dx[e];
+                }
+            }
+        }
+    } else {
+        const int hv = hd - nq - nkv;
+        for (int tb = w0 * 8; tb < T; tb += waves_per_head * 8) {
+            const int t = tb + sub;
+            const bool live = t < T;
+            const int tc = live ? t : T - 1;
+            float dv[8];
+            ld8(dqkv + (int64_t)tc * ldqkv + (nq + nkv + hv) * 64 + 8 * g, dv);
+            const int a_t = live ? act_idx[t] : -1;
+#pragma unroll
+            for (int a = 0; a < NBR; ++a) {
+                const float m = (a_t == a) ? 1.f : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dbacc[a][e] += m * dv[e];
+            }
+        }
+    }
+    // fold the eight 8-lane groups, then group 0 writes this wave's row of partial sums (same layout as above)
+    auto fold = [&](float v) { v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
+    const int SL = 1 + (cross ? nb1 : 0);
+    float* prow = partial + ((int64_t)w0 * NH + hd) * SL * 64;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float s0 = fold(dwacc[e]);
+        if (sub == 0) prow[8 * g + e] = s0;
+    }
+    if (cross) {
+#pragma unroll
+        for (int a = 0; a < NBR; ++a)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float s0 = fold(dbacc[a][e]);
+                if (a < nb1 && sub == 0) prow[(1 + a) * 64 + 8 * g + e] = s0;
+            }
+    }
+}
+
 // dwq[c] += sum over (row, q head) of slot 0; dwk likewise over the k heads; dbias_x[a][head*64 + c] += sum over rows of
 // slot 1 + a.  One workgroup per 32 output columns, 32 row groups, fixed summation order (deterministic).
 __global__ void __launch_bounds__(32 * COLSUM_RG)
@@ -858,11 +1071,15 @@ template <typename TY>
 static int rmsnorm_fwd_impl(const char* name, const float* x, const float* w, int T, int H, float eps,
                             const int32_t* dst_rows, TY* y, int ldy, void* stream) {
     GAMER_CHECK_ARG(x && w && y, "%s: null pointer", name);
-    GAMER_CHECK_ARG(T > 0 && H > 0 && H % 4 == 0 && H <= 256 * RMS_MAXC && ldy >= H && ldy % 4 == 0,
+    GAMER_CHECK_ARG(T > 0 && H > 0 && H % 4 == 0 && H <= 256 * RMS_MAXC_BIG && ldy >= H && ldy % 4 == 0,
                     "%s: bad shape T=%d H=%d ldy=%d (H%%4==0, H<=1024, ldy%%4==0)", name, T, H, ldy);
     GAMER_CHECK_ARG(aligned16(x) && aligned16(w) && aligned_vec4<TY>(y), "%s: pointers must be 16-byte aligned", name);
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel<TY>, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream),
-                       (const float4*)x, (const float4*)w, T, H / 4, 1.f / (float)H, eps, dst_rows, y, ldy);
+    if (H <= 256)
+        hipLaunchKernelGGL((rmsnorm_fwd_kernel<TY, 1>), dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream),
+                           (const float4*)x, (const float4*)w, T, H / 4, 1.f / (float)H, eps, dst_rows, y, ldy);
+    else
+        hipLaunchKernelGGL((rmsnorm_fwd_kernel<TY, RMS_MAXC_BIG>), dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream),
+                           (const float4*)x, (const float4*)w, T, H / 4, 1.f / (float)H, eps, dst_rows, y, ldy);
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }
@@ -881,13 +1098,18 @@ static int rmsnorm_bwd_impl(const char* name, const float* x, const float* w, co
                             float* dw_partial, int n_partial, TG* mask_out, const int32_t* mask_rows, float p_drop,
                             uint64_t seed, void* stream) {
     GAMER_CHECK_ARG(x && w && dy && dx && dw_partial, "%s: null pointer", name);
-    GAMER_CHECK_ARG(T > 0 && H > 0 && H % 4 == 0 && H <= 256 * RMS_MAXC && lddy >= H && lddy % 4 == 0 && n_partial > 0,
+    GAMER_CHECK_ARG(T > 0 && H > 0 && H % 4 == 0 && H <= 256 * RMS_MAXC_BIG && lddy >= H && lddy % 4 == 0 && n_partial > 0,
                     "%s: bad shape T=%d H=%d lddy=%d n_partial=%d", name, T, H, lddy, n_partial);
     GAMER_CHECK_ARG(aligned16(x) && aligned16(w) && aligned_vec4<TG>(dy) && aligned16(dx) && aligned16(dw_partial) &&
                     aligned_vec4<TG>(mask_out), "%s: pointers must be 16-byte aligned", name);
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel<TG>, dim3(n_partial), dim3(EW_THREADS), 0, ST(stream),
-                       (const float4*)x, (const float4*)w, dy, lddy, dy_rows, T, H / 4, 1.f / (float)H, eps,
-                       accumulate_dx, (float4*)dx, dw_partial, mask_out, mask_rows, p_drop, seed);
+    if (H <= 256)
+        hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, 1>), dim3(n_partial), dim3(EW_THREADS), 0, ST(stream),
+                           (const float4*)x, (const float4*)w, dy, lddy, dy_rows, T, H / 4, 1.f / (float)H, eps,
+                           accumulate_dx, (float4*)dx, dw_partial, mask_out, mask_rows, p_drop, seed);
+    else
+        hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, RMS_MAXC_BIG>), dim3(n_partial), dim3(EW_THREADS), 0, ST(stream),
+                           (const float4*)x, (const float4*)w, dy, lddy, dy_rows, T, H / 4, 1.f / (float)H, eps,
+                           accumulate_dx, (float4*)dx, dw_partial, mask_out, mask_rows, p_drop, seed);
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }
@@ -971,9 +1193,15 @@ static int qknorm_rope_fwd_impl(const char* name, TA* qkv, int T, int S, int nq,
     const bool cross = bias_q != nullptr;
     GAMER_CHECK_ARG(!cross || (bias_k && bias_v && act_idx), "%s: cross needs bias_k, bias_v, act_idx", name);
     const int NH = nq + nkv + (cross ? nkv : 0);
-    hipLaunchKernelGGL(qknorm_rope_fwd_kernel<TA>, dim3(grid_for_waves(((int64_t)T * NH + 3) / 4)), dim3(EW_THREADS), 0,
-                       ST(stream), qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot,
-                       k_rot, pos_ids);
+    if constexpr (sizeof(TA) == 2) {
+        hipLaunchKernelGGL(qknorm_rope_fwd_b8_kernel, dim3(grid_for_waves(((int64_t)T * NH + 7) / 8)), dim3(EW_THREADS), 0,
+                           ST(stream), qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot,
+                           k_rot, pos_ids);
+    } else {
+        hipLaunchKernelGGL(qknorm_rope_fwd_kernel<TA>, dim3(grid_for_waves(((int64_t)T * NH + 3) / 4)), dim3(EW_THREADS), 0,
+                           ST(stream), qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot,
+                           k_rot, pos_ids);
+    }
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }
@@ -1009,8 +1237,9 @@ static int qknorm_rope_bwd_impl(const char* name, const TA* qkv, const TA* dq_ro
                     "%s: cross needs bias_k, act_idx, dbias_*, 0<nb1<=8 (nb1=%d)", name, nb1);
     const int NH = nq + nkv + (cross ? nkv : 0);
     const int SL = 1 + (cross ? nb1 : 0);
+    constexpr int RPW = sizeof(TA) == 2 ? 8 : 4;        // token rows per wave iteration
     int waves_per_head = 8192 / NH;
-    if (waves_per_head > (T + 3) / 4) waves_per_head = (T + 3) / 4;
+    if (waves_per_head > (T + RPW - 1) / RPW) waves_per_head = (T + RPW - 1) / RPW;
     const int64_t cap = partial_numel / ((int64_t)NH * SL * 64);
     if (waves_per_head > cap) waves_per_head = (int)cap;
     GAMER_CHECK_ARG(waves_per_head >= 1 && aligned16(partial),
@@ -1018,9 +1247,20 @@ static int qknorm_rope_bwd_impl(const char* name, const TA* qkv, const TA* dq_ro
                     (long long)partial_numel);
     const int64_t total_waves = (int64_t)NH * waves_per_head;
     const int blocks = (int)((total_waves + EW_WAVES - 1) / EW_WAVES);
-    hipLaunchKernelGGL(qknorm_rope_bwd_kernel<TA>, dim3(blocks), dim3(EW_THREADS), 0, ST(stream), qkv, dq_rot, dk_rot, T,
-                       S, nq, nkv, wq, wk, eps, cos_t, sin_t, cross, bias_q, bias_k, act_idx, nb1, dqkv, partial,
-                       waves_per_head, pos_ids);
+    if constexpr (sizeof(TA) == 2) {
+        if (!cross || nb1 <= 4)
+            hipLaunchKernelGGL(qknorm_rope_bwd_b8_kernel<4>, dim3(blocks), dim3(EW_THREADS), 0, ST(stream), qkv, dq_rot, dk_rot,
+                               T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, cross, bias_q, bias_k, act_idx, nb1, dqkv, partial,
+                               waves_per_head, pos_ids);
+        else
+            hipLaunchKernelGGL(qknorm_rope_bwd_b8_kernel<TBL_MAXROWS>, dim3(blocks), dim3(EW_THREADS), 0, ST(stream), qkv,
+                               dq_rot, dk_rot, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, cross, bias_q, bias_k, act_idx, nb1,
+                               dqkv, partial, waves_per_head, pos_ids);
+    } else {
+        hipLaunchKernelGGL(qknorm_rope_bwd_kernel<TA>, dim3(blocks), dim3(EW_THREADS), 0, ST(stream), qkv, dq_rot, dk_rot, T,
+                           S, nq, nkv, wq, wk, eps, cos_t, sin_t, cross, bias_q, bias_k, act_idx, nb1, dqkv, partial,
+                           waves_per_head, pos_ids);
+    }
     GAMER_CHECK_LAUNCH(name);
     const int cols = 128 + (cross ? NH * nb1 * 64 : 0);
     hipLaunchKernelGGL(qknorm_partial_reduce_kernel, dim3(cols / 32), dim3(32 * COLSUM_RG), 0, ST(stream), partial,

@@ -73,10 +73,45 @@ __device__ __forceinline__ int xcd_remap_b(int id, int n) {
 // K-contiguous x K-contiguous
 // =================================================================================================
 // EPI 0: C bf16 (= or +=); EPI 1: C fp32 = resid + dropout(acc), rows optionally scattered through row_map;
-// EPI 2: C bf16 + rowdot_out[b][head][i] = sum over the head's 64 columns of acc * other (full tiles only)
+// EPI 2: C bf16 + rowdot_out[b][head][i] = sum over the head's 64 columns of C * other (full tiles only)
+//
+// Persistent workgroups: at K = 256 a tile is four K-steps, so the first global load of a tile (nothing to hide it
+// behind) and the epilogue were most of its time (first version: 12 % of the matrix pipe).  Each workgroup now walks a
+// list of tiles and requests the first K-step of tile n+1 during the last K-step of tile n, so the load is in flight
+// while the epilogue of tile n runs - and that epilogue no longer touches LDS: the MFMA is issued with its operands
+// swapped (acc = C^T tile: the lane owns a ROW of C, its registers run over columns), v_permlane32_swap pairs the two
+// lane halves so that every lane holds 8 consecutive columns, and the tile leaves as 16-byte stores straight from
+// registers.  The residual epilogue reads and writes its float4 pieces the same way.
+struct HbTile { int row0, row_end, col0, g; bool valid; };
+
+__device__ __forceinline__ HbTile hb_locate(const GemmBf16Params& p, int L) {
+    HbTile t;
+    const int mt = L / p.n_tiles;
+    t.col0 = (L % p.n_tiles) * HB_BN;
+    t.g = 0;
+    int seg_beg = 0, seg_end = p.M, tiles_before = 0;
+    bool found = false;
+    if (p.group_offsets) {
+        int prev = p.group_offsets[0];
+        for (int gi = 0; gi < p.groups; ++gi) {
+            const int nxt = p.group_offsets[gi + 1];
+            const int tiles = (nxt - prev + HB_BM - 1) / HB_BM;
+            if (!found && mt < tiles_before + tiles) { t.g = gi; seg_beg = prev; seg_end = nxt; found = true; }
+            if (!found) tiles_before += tiles;
+            prev = nxt;
+        }
+    } else {
+        found = mt < (p.M + HB_BM - 1) / HB_BM;
+    }
+    t.valid = found;
+    t.row0 = seg_beg + (mt - tiles_before) * HB_BM;
+    t.row_end = seg_end;
+    return t;
+}
+
 template <int EPI, bool ACCUM>
 __global__ void __launch_bounds__(HB_THREADS, 2)
-gemm_bf16_kernel(const GemmBf16Params p) {
+gemm_bf16_kernel(const GemmBf16Params p, const int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);           // buffer b: A image at 2*b*HB_TILE, B image behind it
 
@@ -85,40 +120,26 @@ gemm_bf16_kernel(const GemmBf16Params p) {
     const int wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int r32 = lane & 31, h = lane >> 5;
-    const int L = xcd_remap_b(blockIdx.x, gridDim.x);
-
-    const int mt = L / p.n_tiles;
-    const int col0 = (L % p.n_tiles) * HB_BN;
-    int g = 0, seg_beg = 0, seg_end = p.M, tiles_before = 0;
-    bool found = false;
-    if (p.group_offsets) {
-        int prev = p.group_offsets[0];
-        for (int gi = 0; gi < p.groups; ++gi) {
-            const int nxt = p.group_offsets[gi + 1];
-            const int tiles = (nxt - prev + HB_BM - 1) / HB_BM;
-            if (!found && mt < tiles_before + tiles) { g = gi; seg_beg = prev; seg_end = nxt; found = true; }
-            if (!found) tiles_before += tiles;
-            prev = nxt;
-        }
-    } else {
-        found = mt < (p.M + HB_BM - 1) / HB_BM;
-    }
-    if (!found) return;
-    const int row0 = seg_beg + (mt - tiles_before) * HB_BM;
-    const int row_end = seg_end;
+    // tile list: the logical tile range is cut into 8 contiguous parts, one per XCD (workgroup ids are dealt
+    // round-robin over the XCDs), and the workgroups of an XCD walk their part side by side, so that the column tiles
+    // of one row panel of A run at the same time on one L2
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nlocal = (int)gridDim.x >> 3;
+    const int per_xcd = (total_tiles + 7) >> 3;
+    const int t_hi = min(total_tiles, (xcd + 1) * per_xcd);
     const int col_end = p.N;
-    const bf16_t* Bp = p.B + (int64_t)g * p.strideB;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const int nkt = p.K / HB_BK;                                  // K % 64 == 0 (checked on the host)
-    const bool a_in = row0 + HB_BM <= row_end, b_in = col0 + HB_BN <= col_end;   // workgroup-uniform
+
+    auto next_valid = [&](int& L) {
+        HbTile t;
+        t.valid = false;
+        while (L < t_hi) {
+            t = hb_locate(p, L);
+            if (t.valid) break;
+            L += nlocal;
+        }
+        if (L >= t_hi) t.valid = false;
+        return t;
+    };
     // chunk f = tid + 256 j of a tile: row f >> 3, 16-byte k-chunk f & 7.  Rows past the end are read from the last
     // valid row (their results are never stored), so there is no predicate anywhere in the loads.
     int64_t oa[4], ob[4];
@@ -126,159 +147,203 @@ gemm_bf16_kernel(const GemmBf16Params p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int f = tid + HB_THREADS * j;
-        oa[j] = (int64_t)min(row0 + (f >> 3), row_end - 1) * p.lda + ((f & 7) << 3);
-        ob[j] = (int64_t)min(col0 + (f >> 3), col_end - 1) * p.ldb + ((f & 7) << 3);
         lo[j] = (f >> 3) * HB_LD + ((f & 7) << 3);
     }
-    u32x4 ra[4], rb[4];
-    // a wave whose 64 x 64 patch lies entirely past the edge of C (N = 320 leaves half of the last column tile empty)
-    // issues no MFMAs
-    const bool wave_live = (row0 + wm * 64 < row_end) && (col0 + wn * 64 < col_end);
-    auto mfma_tile = [&](const bf16_t* as) {
-        if (!wave_live) return;
-        const bf16_t* bs = as + HB_TILE;
+    auto offsets = [&](const HbTile& t) {
 #pragma unroll
-        for (int s = 0; s < HB_BK / 16; ++s) {
-            bf16x8 af[2], bf[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(as + (wm * 64 + i * 32 + r32) * HB_LD + 16 * s + 8 * h);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                bf[j] = *reinterpret_cast<const bf16x8*>(bs + (wn * 64 + j * 32 + r32) * HB_LD + 16 * s + 8 * h);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + HB_THREADS * j;
+            oa[j] = (int64_t)min(t.row0 + (f >> 3), t.row_end - 1) * p.lda + ((f & 7) << 3);
+            ob[j] = (int64_t)t.g * p.strideB + (int64_t)min(t.col0 + (f >> 3), col_end - 1) * p.ldb + ((f & 7) << 3);
         }
     };
-    if (nkt > 0) {
-        hb_load4(p.A, oa, 0, ra);
-        hb_load4(Bp, ob, 0, rb);
-        hb_store4(smem, lo, ra);
-        hb_store4(smem + HB_TILE, lo, rb);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nkt;
-        if (more) {
-            hb_load4(p.A, oa, (int64_t)(kt + 1) * HB_BK, ra);
-            hb_load4(Bp, ob, (int64_t)(kt + 1) * HB_BK, rb);
-        }
-        mfma_tile(smem + 2 * cur * HB_TILE);
-        if (more) {
-            hb_store4(smem + 2 * (cur ^ 1) * HB_TILE, lo, ra);
-            hb_store4(smem + 2 * (cur ^ 1) * HB_TILE + HB_TILE, lo, rb);
-        }
-        __syncthreads();
-    }
+    u32x4 ra[4], rb[4];
 
-    // ---- epilogue: acc[i][j][r] is C[row = (r&3)+8*(r>>2)+4*h][col = lane&31] of its 32x32 tile --
-    const bool interior = a_in && b_in;
-    const bool c_f32 = EPI == 1;
-    if (interior && (p.ldc & 7) == 0) {
-        // Row-major rewrite through LDS (the K-loop images are dead after its last barrier): each wave parks its
-        // 64 x 64 patch as [64][68] floats and reads it back row-wise.
-        float* patch = reinterpret_cast<float*>(smem_raw) + wid * (64 * 68);
+    int L = xcd * per_xcd + local;
+    HbTile cur = next_valid(L);
+    if (!cur.valid || nkt == 0) return;
+    offsets(cur);
+    hb_load4(p.A, oa, 0, ra);
+    hb_load4(p.B, ob, 0, rb);
+    int buf = 0;
+    while (true) {
+        hb_store4(smem + 2 * buf * HB_TILE, lo, ra);
+        hb_store4(smem + 2 * buf * HB_TILE + HB_TILE, lo, rb);
+        __syncthreads();
+        int Ln = L + nlocal;
+        const HbTile nxt = next_valid(Ln);
+        const int row0 = cur.row0, row_end = cur.row_end, col0 = cur.col0;
+        // a wave whose 64 x 64 patch lies entirely past the edge of C (N = 320 leaves half of the last column tile
+        // empty) issues no MFMAs
+        const bool wave_live = (row0 + wm * 64 < row_end) && (col0 + wn * 64 < col_end);
+
+        f32x16 acc[2][2];               // acc[i][j] = C^T tile: lane -> row i*32 + r32, register -> column j*32 + rowmap
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    patch[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + j * 32 + r32] = acc[i][j][r];
-        __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): own LDS writes landed (wave-private patch)
-        if (c_f32) {
-            // fp32 residual stream: 16 lanes x float4 per row, 4 rows per store instruction
-            float* Cp = reinterpret_cast<float*>(p.C);
-            const int c4 = (lane & 15) << 2;
-            const DropoutRng rng(p.p_drop, p.seed);
-            const int row_first = row0 + wm * 64 + (lane >> 4);
-            const int col = col0 + wn * 64 + c4;
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int lr = (lane >> 4) + 4 * it;
-                const float4 v = *reinterpret_cast<const float4*>(patch + lr * 68 + c4);
-                const int64_t rc = p.row_map ? (int64_t)p.row_map[row_first + 4 * it] : (int64_t)(row_first + 4 * it);
-                const int64_t e = rc * p.ldc + col;
-                const float4 x = *reinterpret_cast<const float4*>(p.resid + e);
-                float m[4];
-                rng.mult4((uint32_t)(e >> 2), m);
-                float4 o;
-                o.x = x.x + m[0] * v.x; o.y = x.y + m[1] * v.y; o.z = x.z + m[2] * v.z; o.w = x.w + m[3] * v.w;
-                *reinterpret_cast<float4*>(Cp + e) = o;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nkt; ++kt) {
+            const bool more = kt + 1 < nkt;
+            if (more) {
+                hb_load4(p.A, oa, (int64_t)(kt + 1) * HB_BK, ra);
+                hb_load4(p.B, ob, (int64_t)(kt + 1) * HB_BK, rb);
+            } else if (nxt.valid) {
+                offsets(nxt);                                    // first K-step of the next tile: lands during the epilogue
+                hb_load4(p.A, oa, 0, ra);
+                hb_load4(p.B, ob, 0, rb);
             }
-        } else {
-            // bf16 activations: 8 lanes x 8 elements (16 bytes) per row, 8 rows per store instruction
-            bf16_t* Cp = reinterpret_cast<bf16_t*>(p.C);
-            const int c8 = (lane & 7) << 3;
-            const int row_first = row0 + wm * 64 + (lane >> 3);
-            const int col = col0 + wn * 64 + c8;
-            bf16x8 oth[EPI == 2 ? 8 : 1];
-            if (EPI == 2) {
+            if (wave_live) {
+                const bf16_t* as = smem + 2 * buf * HB_TILE;
+                const bf16_t* bs = as + HB_TILE;
 #pragma unroll
-                for (int it = 0; it < 8; ++it)
-                    oth[it] = *reinterpret_cast<const bf16x8*>(p.rowdot_other + (int64_t)(row_first + 8 * it) * p.ldc + col);
+                for (int s = 0; s < HB_BK / 16; ++s) {
+                    bf16x8 af[2], bf[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        af[i] = *reinterpret_cast<const bf16x8*>(as + (wm * 64 + i * 32 + r32) * HB_LD + 16 * s + 8 * h);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        bf[j] = *reinterpret_cast<const bf16x8*>(bs + (wn * 64 + j * 32 + r32) * HB_LD + 16 * s + 8 * h);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int lr = (lane >> 3) + 8 * it;
-                const float4 v0 = *reinterpret_cast<const float4*>(patch + lr * 68 + c8);
-                const float4 v1 = *reinterpret_cast<const float4*>(patch + lr * 68 + c8 + 4);
-                f32x8v v = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                bf16_t* dst = Cp + (int64_t)(row_first + 8 * it) * p.ldc + col;
-                if (ACCUM) {
-                    const bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
-                }
-                const bf16x8 o = __builtin_convertvector(v, bf16x8);
-                *reinterpret_cast<bf16x8*>(dst) = o;
-                if (EPI == 2) {
-                    // the wave's 64-column patch is exactly one head: 8 lanes hold one row of it.  delta uses the
-                    // ROUNDED dO (what the attention backward reads), times O.
-                    float d = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) d += (float)o[e] * (float)oth[EPI == 2 ? it : 0][e];
-                    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-                    if ((lane & 7) == 0) {
-                        const int row = row_first + 8 * it;
-                        const int heads = p.N >> 6, head = (col0 + wn * 64) >> 6;
-                        p.rowdot_out[((int64_t)(row / p.rowdot_S) * heads + head) * p.rowdot_S + row % p.rowdot_S] = d;
-                    }
-                }
+            if (more) {
+                hb_store4(smem + 2 * (buf ^ 1) * HB_TILE, lo, ra);
+                hb_store4(smem + 2 * (buf ^ 1) * HB_TILE + HB_TILE, lo, rb);
+                __syncthreads();
+                buf ^= 1;
             }
         }
-    } else {
-        // edge tiles: element-wise stores with bounds checks
-        const DropoutRng rng(EPI == 1 ? p.p_drop : 0.f, p.seed);
+
+        // ---- epilogue from registers: lane = row (i*32 + r32), acc[i][j][4*g4 + e] = column j*32 + 8*g4 + 4*h + e ----
+        const bool interior = (row0 + HB_BM <= row_end) && (col0 + HB_BN <= col_end);
+        if (wave_live) {
+            if (EPI == 1) {
+                float* Cp = reinterpret_cast<float*>(p.C);
+                const DropoutRng rng(p.p_drop, p.seed);
+                if (interior && (p.ldc & 3) == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = row0 + wm * 64 + i * 32 + r32;
+                        const int64_t rc = p.row_map ? (int64_t)p.row_map[row] : (int64_t)row;
+                        const int64_t e0 = rc * p.ldc + col0 + wn * 64 + 4 * h;
+                        float4 x[8];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = col0 + wn * 64 + j * 32 + r32;
-                const int rbase = row0 + wm * 64 + i * 32 + 4 * h;
+                        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (row < row_end && col < col_end) {
-                        const float v = acc[i][j][r];
-                        if (c_f32) {
-                            const int64_t rc = p.row_map ? (int64_t)p.row_map[row] : (int64_t)row;
-                            const int64_t e = rc * p.ldc + col;
-                            float m[4];
-                            rng.mult4((uint32_t)(e >> 2), m);
-                            reinterpret_cast<float*>(p.C)[e] = p.resid[e] + m[e & 3] * v;
-                        } else {
-                            bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (int64_t)row * p.ldc + col;
-                            *dst = (bf16_t)(ACCUM ? v + (float)*dst : v);
+                            for (int g4 = 0; g4 < 4; ++g4)
+                                x[4 * j + g4] = *reinterpret_cast<const float4*>(p.resid + e0 + j * 32 + 8 * g4);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) {
+                                const int64_t e = e0 + j * 32 + 8 * g4;
+                                float m[4];
+                                rng.mult4((uint32_t)(e >> 2), m);
+                                const float4 xx = x[4 * j + g4];
+                                float4 o;
+                                o.x = xx.x + m[0] * acc[i][j][4 * g4 + 0]; o.y = xx.y + m[1] * acc[i][j][4 * g4 + 1];
+                                o.z = xx.z + m[2] * acc[i][j][4 * g4 + 2]; o.w = xx.w + m[3] * acc[i][j][4 * g4 + 3];
+                                *reinterpret_cast<float4*>(Cp + e) = o;
+                            }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = row0 + wm * 64 + i * 32 + r32;
+                        if (row >= row_end) continue;
+                        const int64_t rc = p.row_map ? (int64_t)p.row_map[row] : (int64_t)row;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int col = col0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                if (col < col_end) {
+                                    const int64_t e = rc * p.ldc + col;
+                                    float m[4];
+                                    rng.mult4((uint32_t)(e >> 2), m);
+                                    Cp[e] = p.resid[e] + m[e & 3] * acc[i][j][r];
+                                }
+                            }
+                    }
+                }
+            } else {
+                bf16_t* Cp = reinterpret_cast<bf16_t*>(p.C);
+                if (interior && (p.ldc & 7) == 0) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = row0 + wm * 64 + i * 32 + r32;
+                        bf16_t* crow = Cp + (int64_t)row * p.ldc + col0 + wn * 64 + 8 * h;
+                        const bf16_t* orow = EPI == 2 ? p.rowdot_other + (int64_t)row * p.ldc + col0 + wn * 64 + 8 * h : nullptr;
+                        float dot = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int t2 = 0; t2 < 2; ++t2) {
+                                // groups g4 = 2*t2 (columns 16*t2 + 4h..) and 2*t2 + 1 (columns 16*t2 + 8 + 4h..): after the
+                                // swap the lower lane half holds columns 16*t2 + 0..7, the upper half 16*t2 + 8..15
+                                f32x8v v;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * t2 + e]),
+                                                                                     __float_as_uint(acc[i][j][8 * t2 + 4 + e]), false, false);
+                                    v[e] = __uint_as_float(sw[0]);
+                                    v[4 + e] = __uint_as_float(sw[1]);
+                                }
+                                bf16_t* dst = crow + j * 32 + 16 * t2;
+                                if (ACCUM) {
+                                    const bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
+                                }
+                                const bf16x8 o = __builtin_convertvector(v, bf16x8);
+                                *reinterpret_cast<bf16x8*>(dst) = o;
+                                if (EPI == 2) {
+                                    // delta uses the ROUNDED dO (what the attention backward reads), times O
+                                    const bf16x8 ot = *reinterpret_cast<const bf16x8*>(orow + j * 32 + 16 * t2);
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) dot += (float)o[e] * (float)ot[e];
+                                }
+                            }
+                        if (EPI == 2) {
+                            // the wave's 64-column patch is exactly one head; the two lane halves hold its two halves
+                            dot += __shfl_xor(dot, 32, 64);
+                            if (h == 0) {
+                                const int heads = p.N >> 6, head = (col0 + wn * 64) >> 6;
+                                p.rowdot_out[((int64_t)(row / p.rowdot_S) * heads + head) * p.rowdot_S + row % p.rowdot_S] = dot;
+                            }
                         }
                     }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = row0 + wm * 64 + i * 32 + r32;
+                        if (row >= row_end) continue;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int col = col0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                if (col < col_end) {
+                                    bf16_t* dst = Cp + (int64_t)row * p.ldc + col;
+                                    const float v = acc[i][j][r];
+                                    *dst = (bf16_t)(ACCUM ? v + (float)*dst : v);
+                                }
+                            }
+                    }
                 }
             }
         }
+        if (!nxt.valid) break;
+        cur = nxt;
+        L = Ln;
+        buf ^= 1;
     }
 }
 
@@ -476,7 +541,7 @@ static const bf16_t* zero_page() {
 }
 
 template <int EPI, bool ACCUM>
-static int launch_hb(const GemmBf16Params& p, int blocks, hipStream_t st) {
+static int launch_hb(const GemmBf16Params& p, int tiles, hipStream_t st) {
     static bool attr = false;
     auto kfn = gemm_bf16_kernel<EPI, ACCUM>;
     if (!attr) {
@@ -485,7 +550,10 @@ static int launch_hb(const GemmBf16Params& p, int blocks, hipStream_t st) {
         if (e != hipSuccess) { set_error("gamer_gemm_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         attr = true;
     }
-    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, st, p);
+    // two workgroups per CU x 256 CUs, in multiples of 8 (one share per XCD); small problems: one workgroup per tile
+    int blocks = 512;
+    if (tiles < blocks) blocks = ((tiles + 7) / 8) * 8;
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, st, p, tiles);
     GAMER_CHECK_LAUNCH("gamer_gemm_bf16");
     return 0;
 }

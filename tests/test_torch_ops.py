@@ -53,7 +53,8 @@ def test_ops_match_the_ctypes_path(dt):
     out_ref = torch.empty(T, N, dtype=dt, device=dev)
     ops.linear_fwd(a, K, wt, K, out_ref, N, T, N, K)
     assert torch.equal(out, out_ref)
-    assert float((out.float() - a.float() @ wt.float().T).abs().max()) < (0.1 if bf else 1e-4)
+    ref_lin = a.float() @ wt.float().T
+    assert float((out.float() - ref_lin).abs().max()) < (1e-2 if bf else 1e-5) * float(ref_lin.abs().max())
     # qkv norm + rope, attention fwd / bwd (self: ql undefined)
     from oracle import qwen3multi_oracle as orc
     cos, sin = (t.to(dev) for t in orc.rope_tables(S, 64, 1e6))
@@ -123,6 +124,7 @@ def test_fused_optimizer_runs_through_the_registered_op():
     eng = Engine(cfg, temperature=0.7)
     eng.load_state_dict({k: v.clone() for k, v in model.engine.params.items()})
     opt = model.fused_optimizer(lr=1e-3)
+    p0 = eng.flat_p.clone()
     for step in range(3):
         b = synthetic.make_batch(4, 6, 8, 3, seed=step)
         bd = {k: v.cuda() for k, v in b.items()}
@@ -131,7 +133,10 @@ def test_fused_optimizer_runs_through_the_registered_op():
         opt.step()
         opt.zero_grad(set_to_none=True)
         eng.train_step(b, 1e-3)
-    assert torch.allclose(model.engine.flat_p, eng.flat_p, rtol=1e-5, atol=1e-7)
+    # two runs of the same step differ by the summation order of the split-K fp32 atomics (and Adam turns a sign flip
+    # of a ~0 gradient into a full lr-sized difference on that element): compare the UPDATES in norm
+    upd = (eng.flat_p - p0).double()
+    assert float((model.engine.flat_p - eng.flat_p).double().norm() / upd.norm()) < 2e-2
     assert abs(float(model.engine.grad_norm) - float(eng.grad_norm)) < 1e-4 * float(eng.grad_norm)
     sd = opt.state_dict()
     assert sd["state"]["step"] == 3 and sd["state"]["m"] is not None
