@@ -22,6 +22,10 @@ namespace gamer {
 
 constexpr int HB_BM = 128, HB_BN = 128, HB_BK = 64;
 constexpr int HB_THREADS = 256;
+constexpr int HB_MAX_GROUPS = 64;
+#ifndef HB_ABLATE
+#define HB_ABLATE 0            // tools/ablate_gemm.sh: 1 no epilogue stores, 2 no global loads, 4 no MFMA / LDS reads, 8 no LDS stores
+#endif
 constexpr int HB_LD = HB_BK + 8;                       // bf16 elements per row of a K-contiguous tile image (144 B)
 constexpr int HB_TILE = HB_BM * HB_LD;                 // elements per operand image
 constexpr int HB_LDS_BYTES = 4 * HB_TILE * 2;          // 2 operands x 2 buffers = 73,728 B -> two workgroups per CU
@@ -84,7 +88,9 @@ __device__ __forceinline__ int xcd_remap_b(int id, int n) {
 // registers.  The residual epilogue reads and writes its float4 pieces the same way.
 struct HbTile { int row0, row_end, col0, g; bool valid; };
 
-__device__ __forceinline__ HbTile hb_locate(const GemmBf16Params& p, int L) {
+// `offs` = the segment offsets in LDS (read once at kernel start: a global load here would put an s_waitcnt vmcnt(0)
+// - a drain of the whole operand prefetch - at every tile boundary)
+__device__ __forceinline__ HbTile hb_locate(const GemmBf16Params& p, const int32_t* offs, int L) {
     HbTile t;
     const int mt = L / p.n_tiles;
     t.col0 = (L % p.n_tiles) * HB_BN;
@@ -92,9 +98,9 @@ __device__ __forceinline__ HbTile hb_locate(const GemmBf16Params& p, int L) {
     int seg_beg = 0, seg_end = p.M, tiles_before = 0;
     bool found = false;
     if (p.group_offsets) {
-        int prev = p.group_offsets[0];
+        int prev = offs[0];
         for (int gi = 0; gi < p.groups; ++gi) {
-            const int nxt = p.group_offsets[gi + 1];
+            const int nxt = offs[gi + 1];
             const int tiles = (nxt - prev + HB_BM - 1) / HB_BM;
             if (!found && mt < tiles_before + tiles) { t.g = gi; seg_beg = prev; seg_end = nxt; found = true; }
             if (!found) tiles_before += tiles;
@@ -107,6 +113,132 @@ __device__ __forceinline__ HbTile hb_locate(const GemmBf16Params& p, int L) {
     t.row0 = seg_beg + (mt - tiles_before) * HB_BM;
     t.row_end = seg_end;
     return t;
+}
+
+// epilogue of one tile from registers: lane = row (i*32 + r32), acc[i][j][4*g4 + e] = column j*32 + 8*g4 + 4*h + e
+template <int EPI, bool ACCUM>
+__device__ __forceinline__ void hb_epilogue(const GemmBf16Params& p, f32x16 (&acc)[2][2], const int row0, const int row_end,
+                                            const int col0, const int col_end, const int wm, const int wn, const int r32,
+                                            const int h, const bool wave_live) {
+    // ---- epilogue from registers: lane = row (i*32 + r32), acc[i][j][4*g4 + e] = column j*32 + 8*g4 + 4*h + e ----
+    const bool interior = (row0 + HB_BM <= row_end) && (col0 + HB_BN <= col_end);
+    if (wave_live) {
+        if (EPI == 1) {
+            float* Cp = reinterpret_cast<float*>(p.C);
+            const DropoutRng rng(p.p_drop, p.seed);
+            if (interior && (p.ldc & 3) == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = row0 + wm * 64 + i * 32 + r32;
+                    const int64_t rc = p.row_map ? (int64_t)p.row_map[row] : (int64_t)row;
+                    const int64_t e0 = rc * p.ldc + col0 + wn * 64 + 4 * h;
+                    float4 x[8];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4)
+                            x[4 * j + g4] = *reinterpret_cast<const float4*>(p.resid + e0 + j * 32 + 8 * g4);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int64_t e = e0 + j * 32 + 8 * g4;
+                            float m[4];
+                            rng.mult4((uint32_t)(e >> 2), m);
+                            const float4 xx = x[4 * j + g4];
+                            float4 o;
+                            o.x = xx.x + m[0] * acc[i][j][4 * g4 + 0]; o.y = xx.y + m[1] * acc[i][j][4 * g4 + 1];
+                            o.z = xx.z + m[2] * acc[i][j][4 * g4 + 2]; o.w = xx.w + m[3] * acc[i][j][4 * g4 + 3];
+                            *reinterpret_cast<float4*>(Cp + e) = o;
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = row0 + wm * 64 + i * 32 + r32;
+                    if (row >= row_end) continue;
+                    const int64_t rc = p.row_map ? (int64_t)p.row_map[row] : (int64_t)row;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int col = col0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            if (col < col_end) {
+                                const int64_t e = rc * p.ldc + col;
+                                float m[4];
+                                rng.mult4((uint32_t)(e >> 2), m);
+                                Cp[e] = p.resid[e] + m[e & 3] * acc[i][j][r];
+                            }
+                        }
+                }
+            }
+        } else {
+            bf16_t* Cp = reinterpret_cast<bf16_t*>(p.C);
+            if (interior && (p.ldc & 7) == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = row0 + wm * 64 + i * 32 + r32;
+                    bf16_t* crow = Cp + (int64_t)row * p.ldc + col0 + wn * 64 + 8 * h;
+                    const bf16_t* orow = EPI == 2 ? p.rowdot_other + (int64_t)row * p.ldc + col0 + wn * 64 + 8 * h : nullptr;
+                    float dot = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int t2 = 0; t2 < 2; ++t2) {
+                            // groups g4 = 2*t2 (columns 16*t2 + 4h..) and 2*t2 + 1 (columns 16*t2 + 8 + 4h..): after the
+                            // swap the lower lane half holds columns 16*t2 + 0..7, the upper half 16*t2 + 8..15
+                            f32x8v v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * t2 + e]),
+                                                                                 __float_as_uint(acc[i][j][8 * t2 + 4 + e]), false, false);
+                                v[e] = __uint_as_float(sw[0]);
+                                v[4 + e] = __uint_as_float(sw[1]);
+                            }
+                            bf16_t* dst = crow + j * 32 + 16 * t2;
+                            if (ACCUM) {
+                                const bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
+                            }
+                            const bf16x8 o = __builtin_convertvector(v, bf16x8);
+                            *reinterpret_cast<bf16x8*>(dst) = o;
+                            if (EPI == 2) {
+                                // delta uses the ROUNDED dO (what the attention backward reads), times O
+                                const bf16x8 ot = *reinterpret_cast<const bf16x8*>(orow + j * 32 + 16 * t2);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) dot += (float)o[e] * (float)ot[e];
+                            }
+                        }
+                    if (EPI == 2) {
+                        // the wave's 64-column patch is exactly one head; the two lane halves hold its two halves
+                        dot += __shfl_xor(dot, 32, 64);
+                        if (h == 0) {
+                            const int heads = p.N >> 6, head = (col0 + wn * 64) >> 6;
+                            p.rowdot_out[((int64_t)(row / p.rowdot_S) * heads + head) * p.rowdot_S + row % p.rowdot_S] = dot;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = row0 + wm * 64 + i * 32 + r32;
+                    if (row >= row_end) continue;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int col = col0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            if (col < col_end) {
+                                bf16_t* dst = Cp + (int64_t)row * p.ldc + col;
+                                const float v = acc[i][j][r];
+                                *dst = (bf16_t)(ACCUM ? v + (float)*dst : v);
+                            }
+                        }
+                }
+            }
+        }
+    }
 }
 
 template <int EPI, bool ACCUM>
@@ -128,12 +260,15 @@ gemm_bf16_kernel(const GemmBf16Params p, const int total_tiles) {
     const int t_hi = min(total_tiles, (xcd + 1) * per_xcd);
     const int col_end = p.N;
     const int nkt = p.K / HB_BK;                                  // K % 64 == 0 (checked on the host)
+    __shared__ int32_t s_offs[HB_MAX_GROUPS + 1];
+    if (p.group_offsets && tid <= p.groups) s_offs[tid] = p.group_offsets[tid];
+    __syncthreads();
 
     auto next_valid = [&](int& L) {
         HbTile t;
         t.valid = false;
         while (L < t_hi) {
-            t = hb_locate(p, L);
+            t = hb_locate(p, s_offs, L);
             if (t.valid) break;
             L += nlocal;
         }
@@ -157,194 +292,97 @@ gemm_bf16_kernel(const GemmBf16Params p, const int total_tiles) {
             ob[j] = (int64_t)t.g * p.strideB + (int64_t)min(t.col0 + (f >> 3), col_end - 1) * p.ldb + ((f & 7) << 3);
         }
     };
-    u32x4 ra[4], rb[4];
-
-    int L = xcd * per_xcd + local;
-    HbTile cur = next_valid(L);
-    if (!cur.valid || nkt == 0) return;
-    offsets(cur);
-    hb_load4(p.A, oa, 0, ra);
-    hb_load4(p.B, ob, 0, rb);
-    int buf = 0;
-    while (true) {
-        hb_store4(smem + 2 * buf * HB_TILE, lo, ra);
-        hb_store4(smem + 2 * buf * HB_TILE + HB_TILE, lo, rb);
-        __syncthreads();
-        int Ln = L + nlocal;
-        const HbTile nxt = next_valid(Ln);
-        const int row0 = cur.row0, row_end = cur.row_end, col0 = cur.col0;
-        // a wave whose 64 x 64 patch lies entirely past the edge of C (N = 320 leaves half of the last column tile
-        // empty) issues no MFMAs
-        const bool wave_live = (row0 + wm * 64 < row_end) && (col0 + wn * 64 < col_end);
-
-        f32x16 acc[2][2];               // acc[i][j] = C^T tile: lane -> row i*32 + r32, register -> column j*32 + rowmap
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int kt = 0; kt < nkt; ++kt) {
-            const bool more = kt + 1 < nkt;
-            if (more) {
-                hb_load4(p.A, oa, (int64_t)(kt + 1) * HB_BK, ra);
-                hb_load4(p.B, ob, (int64_t)(kt + 1) * HB_BK, rb);
-            } else if (nxt.valid) {
-                offsets(nxt);                                    // first K-step of the next tile: lands during the epilogue
-                hb_load4(p.A, oa, 0, ra);
-                hb_load4(p.B, ob, 0, rb);
-            }
-            if (wave_live) {
-                const bf16_t* as = smem + 2 * buf * HB_TILE;
-                const bf16_t* bs = as + HB_TILE;
-#pragma unroll
-                for (int s = 0; s < HB_BK / 16; ++s) {
-                    bf16x8 af[2], bf[2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        af[i] = *reinterpret_cast<const bf16x8*>(as + (wm * 64 + i * 32 + r32) * HB_LD + 16 * s + 8 * h);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        bf[j] = *reinterpret_cast<const bf16x8*>(bs + (wn * 64 + j * 32 + r32) * HB_LD + 16 * s + 8 * h);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-                }
-            }
-            if (more) {
-                hb_store4(smem + 2 * (buf ^ 1) * HB_TILE, lo, ra);
-                hb_store4(smem + 2 * (buf ^ 1) * HB_TILE + HB_TILE, lo, rb);
-                __syncthreads();
-                buf ^= 1;
-            }
-        }
-
-        // ---- epilogue from registers: lane = row (i*32 + r32), acc[i][j][4*g4 + e] = column j*32 + 8*g4 + 4*h + e ----
-        const bool interior = (row0 + HB_BM <= row_end) && (col0 + HB_BN <= col_end);
-        if (wave_live) {
-            if (EPI == 1) {
-                float* Cp = reinterpret_cast<float*>(p.C);
-                const DropoutRng rng(p.p_drop, p.seed);
-                if (interior && (p.ldc & 3) == 0) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int row = row0 + wm * 64 + i * 32 + r32;
-                        const int64_t rc = p.row_map ? (int64_t)p.row_map[row] : (int64_t)row;
-                        const int64_t e0 = rc * p.ldc + col0 + wn * 64 + 4 * h;
-                        float4 x[8];
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-#pragma unroll
-                            for (int g4 = 0; g4 < 4; ++g4)
-                                x[4 * j + g4] = *reinterpret_cast<const float4*>(p.resid + e0 + j * 32 + 8 * g4);
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-#pragma unroll
-                            for (int g4 = 0; g4 < 4; ++g4) {
-                                const int64_t e = e0 + j * 32 + 8 * g4;
-                                float m[4];
-                                rng.mult4((uint32_t)(e >> 2), m);
-                                const float4 xx = x[4 * j + g4];
-                                float4 o;
-                                o.x = xx.x + m[0] * acc[i][j][4 * g4 + 0]; o.y = xx.y + m[1] * acc[i][j][4 * g4 + 1];
-                                o.z = xx.z + m[2] * acc[i][j][4 * g4 + 2]; o.w = xx.w + m[3] * acc[i][j][4 * g4 + 3];
-                                *reinterpret_cast<float4*>(Cp + e) = o;
-                            }
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int row = row0 + wm * 64 + i * 32 + r32;
-                        if (row >= row_end) continue;
-                        const int64_t rc = p.row_map ? (int64_t)p.row_map[row] : (int64_t)row;
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int col = col0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                                if (col < col_end) {
-                                    const int64_t e = rc * p.ldc + col;
-                                    float m[4];
-                                    rng.mult4((uint32_t)(e >> 2), m);
-                                    Cp[e] = p.resid[e] + m[e & 3] * acc[i][j][r];
-                                }
-                            }
-                    }
-                }
-            } else {
-                bf16_t* Cp = reinterpret_cast<bf16_t*>(p.C);
-                if (interior && (p.ldc & 7) == 0) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int row = row0 + wm * 64 + i * 32 + r32;
-                        bf16_t* crow = Cp + (int64_t)row * p.ldc + col0 + wn * 64 + 8 * h;
-                        const bf16_t* orow = EPI == 2 ? p.rowdot_other + (int64_t)row * p.ldc + col0 + wn * 64 + 8 * h : nullptr;
-                        float dot = 0.f;
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-#pragma unroll
-                            for (int t2 = 0; t2 < 2; ++t2) {
-                                // groups g4 = 2*t2 (columns 16*t2 + 4h..) and 2*t2 + 1 (columns 16*t2 + 8 + 4h..): after the
-                                // swap the lower lane half holds columns 16*t2 + 0..7, the upper half 16*t2 + 8..15
-                                f32x8v v;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * t2 + e]),
-                                                                                     __float_as_uint(acc[i][j][8 * t2 + 4 + e]), false, false);
-                                    v[e] = __uint_as_float(sw[0]);
-                                    v[4 + e] = __uint_as_float(sw[1]);
-                                }
-                                bf16_t* dst = crow + j * 32 + 16 * t2;
-                                if (ACCUM) {
-                                    const bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
-#pragma unroll
-                                    for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
-                                }
-                                const bf16x8 o = __builtin_convertvector(v, bf16x8);
-                                *reinterpret_cast<bf16x8*>(dst) = o;
-                                if (EPI == 2) {
-                                    // delta uses the ROUNDED dO (what the attention backward reads), times O
-                                    const bf16x8 ot = *reinterpret_cast<const bf16x8*>(orow + j * 32 + 16 * t2);
-#pragma unroll
-                                    for (int e = 0; e < 8; ++e) dot += (float)o[e] * (float)ot[e];
-                                }
-                            }
-                        if (EPI == 2) {
-                            // the wave's 64-column patch is exactly one head; the two lane halves hold its two halves
-                            dot += __shfl_xor(dot, 32, 64);
-                            if (h == 0) {
-                                const int heads = p.N >> 6, head = (col0 + wn * 64) >> 6;
-                                p.rowdot_out[((int64_t)(row / p.rowdot_S) * heads + head) * p.rowdot_S + row % p.rowdot_S] = dot;
-                            }
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int row = row0 + wm * 64 + i * 32 + r32;
-                        if (row >= row_end) continue;
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int col = col0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                                if (col < col_end) {
-                                    bf16_t* dst = Cp + (int64_t)row * p.ldc + col;
-                                    const float v = acc[i][j][r];
-                                    *dst = (bf16_t)(ACCUM ? v + (float)*dst : v);
-                                }
-                            }
-                    }
-                }
-            }
-        }
-        if (!nxt.valid) break;
-        cur = nxt;
-        L = Ln;
-        buf ^= 1;
+    // The (tile, K-step) pairs of this workgroup form ONE stream of steps; the operands of step s+2 are requested while
+    // step s is multiplied and step s+1 waits in the other register set: the memory latency under load is several
+    // K-steps of bf16 MFMA time, and with one step of prefetch every K-step waited for its operands (0.32 ms for the
+    // q|k|v shape against 0.21 ms of HBM time).  Step s lives in LDS buffer s & 1; r0a / r0b carry even steps, r1a / r1b
+    // odd ones.  The load side (ld, ld_kt) runs two steps ahead of the compute side (cur, kt) over the same tile list.
+    u32x4 r0a[4], r0b[4], r1a[4], r1b[4];
+    int Lld = xcd * per_xcd + local;
+    HbTile ld = next_valid(Lld);
+    int ld_kt = 0;
+    if (!ld.valid || nkt == 0) return;
+    offsets(ld);
+    // The loads are issued UNCONDITIONALLY (past the end of the tile list the last step is simply read again): with a
+    // conditional issue the compiler has to assume "not issued" when it counts how many younger loads may stay in
+    // flight behind the ones a ds_write needs, and waits for all of them.
+#define HB_ISSUE(RA, RB)                                                                       \
+    {                                                                                          \
+        if (!(HB_ABLATE & 2)) {                                                                \
+        hb_load4(p.A, oa, (int64_t)ld_kt * HB_BK, RA);                                         \
+        hb_load4(p.B, ob, (int64_t)ld_kt * HB_BK, RB);                                         \
+        }                                                                                      \
+        if (ld.valid && ld_kt + 1 == nkt) {                                                    \
+            Lld += nlocal;                                                                     \
+            ld = next_valid(Lld);                                                              \
+            if (ld.valid) { offsets(ld); ld_kt = 0; }                                          \
+        } else if (ld.valid) {                                                                 \
+            ++ld_kt;                                                                           \
+        }                                                                                      \
     }
+    int Lc = Lld;
+    HbTile cur = ld;
+    HB_ISSUE(r0a, r0b)                                             // step 0
+    HB_ISSUE(r1a, r1b)                                             // step 1 (if there is one)
+    hb_store4(smem, lo, r0a);
+    hb_store4(smem + HB_TILE, lo, r0b);
+    __syncthreads();
+    int Ln = Lc + nlocal;
+    HbTile nxt = next_valid(Ln);
+    int kt = 0;
+    bool wave_live = (cur.row0 + wm * 64 < cur.row_end) && (cur.col0 + wn * 64 < col_end);
+    f32x16 acc[2][2];               // acc[i][j] = C^T tile: lane -> row i*32 + r32, register -> column j*32 + rowmap
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // one step: BUF = LDS buffer of this step, (NA, NB) = registers of the next step, (FA, FB) = registers free for step + 2
+#define HB_STEP(BUF, NA, NB, FA, FB)                                                                                   \
+    {                                                                                                                  \
+        HB_ISSUE(FA, FB)                                                                                               \
+        if (wave_live && !(HB_ABLATE & 4)) {                                                                           \
+            const bf16_t* as = smem + 2 * (BUF) * HB_TILE;                                                             \
+            const bf16_t* bs = as + HB_TILE;                                                                           \
+            _Pragma("unroll") for (int s = 0; s < HB_BK / 16; ++s) {                                                   \
+                bf16x8 af[2], bf[2];                                                                                   \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+                    af[i] = *reinterpret_cast<const bf16x8*>(as + (wm * 64 + i * 32 + r32) * HB_LD + 16 * s + 8 * h);  \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+                    bf[j] = *reinterpret_cast<const bf16x8*>(bs + (wn * 64 + j * 32 + r32) * HB_LD + 16 * s + 8 * h);  \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);         \
+            }                                                                                                          \
+        }                                                                                                              \
+        const bool tile_done = ++kt == nkt;                                                                            \
+        if (!(HB_ABLATE & 8)) {                                                                                        \
+        hb_store4(smem + 2 * ((BUF) ^ 1) * HB_TILE, lo, NA);       /* past the last step: a harmless re-store */       \
+        hb_store4(smem + 2 * ((BUF) ^ 1) * HB_TILE + HB_TILE, lo, NB);                                                 \
+        } else { asm volatile("" :: "v"(NA[0]), "v"(NA[1]), "v"(NA[2]), "v"(NA[3]), "v"(NB[0]), "v"(NB[1]), "v"(NB[2]), "v"(NB[3])); } \
+        if (tile_done) {                                                                                               \
+            if (!(HB_ABLATE & 1) || acc[0][0][0] == 1.2345e-30f)                                                       \
+            hb_epilogue<EPI, ACCUM>(p, acc, cur.row0, cur.row_end, cur.col0, col_end, wm, wn, r32, h, wave_live);      \
+            if (!nxt.valid) break;                                                                                     \
+            cur = nxt;                                                                                                 \
+            Ln += nlocal;                                                                                              \
+            nxt = next_valid(Ln);                                                                                      \
+            kt = 0;                                                                                                    \
+            wave_live = (cur.row0 + wm * 64 < cur.row_end) && (cur.col0 + wn * 64 < col_end);                          \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                              \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;                                 \
+        }                                                                                                              \
+        __syncthreads();                                                                                               \
+    }
+    while (true) {
+        HB_STEP(0, r1a, r1b, r0a, r0b)
+        HB_STEP(1, r0a, r0b, r1a, r1b)
+    }
+#undef HB_STEP
+#undef HB_ISSUE
 }
 
 // =================================================================================================
@@ -457,26 +495,38 @@ gemm_bf16_wgrad_kernel(const GemmBf16Params p, const bf16_t* __restrict__ zeros)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     };
+    // Two K-steps of loads in flight: step k+2 is requested while step k is multiplied and step k+1 sits in the other
+    // register set (the memory latency under load is several K-steps of bf16 MFMA time; one step of prefetch left every
+    // K-step waiting for its operands).  ra / rb hold odd steps, ra2 / rb2 even ones.
+    u32x4 ra2[4], rb2[4];
     const int nkt = (kend - kbeg + HB_BK - 1) / HB_BK;
-    if (nkt > 0) {
-        hw_load4(p.A, p.lda, oa, tk, kbeg, kend, zeros, ra);
-        hw_load4(p.B, p.ldb, ob, tk, kbeg, kend, zeros, rb);
-        hb_store4(smem, lo, ra);
-        hb_store4(smem + HW_TILE, lo, rb);
-    }
+    auto kof = [&](int kt) { return kbeg + kt * HB_BK; };
+    // Every load and LDS store below is UNCONDITIONAL (steps past the end read the page of zeros and are never
+    // multiplied): a conditional issue makes the compiler wait for the youngest loads too when an LDS store needs the
+    // older ones.
+    if (nkt <= 0) return;
+    hw_load4(p.A, p.lda, oa, tk, kof(0), kend, zeros, ra2);
+    hw_load4(p.B, p.ldb, ob, tk, kof(0), kend, zeros, rb2);
+    hw_load4(p.A, p.lda, oa, tk, kof(1), kend, zeros, ra);
+    hw_load4(p.B, p.ldb, ob, tk, kof(1), kend, zeros, rb);
+    hb_store4(smem, lo, ra2);
+    hb_store4(smem + HW_TILE, lo, rb2);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nkt;
-        if (more) {
-            hw_load4(p.A, p.lda, oa, tk, kbeg + (kt + 1) * HB_BK, kend, zeros, ra);
-            hw_load4(p.B, p.ldb, ob, tk, kbeg + (kt + 1) * HB_BK, kend, zeros, rb);
-        }
-        mfma_tile(smem + 2 * cur * HW_TILE);
-        if (more) {
-            hb_store4(smem + 2 * (cur ^ 1) * HW_TILE, lo, ra);
-            hb_store4(smem + 2 * (cur ^ 1) * HW_TILE + HW_TILE, lo, rb);
-        }
+    for (int kt = 0; kt < nkt; kt += 2) {
+        // even step kt: LDS buffer 0; step kt+1 is in ra / rb; request step kt+2 into ra2 / rb2
+        hw_load4(p.A, p.lda, oa, tk, kof(kt + 2), kend, zeros, ra2);
+        hw_load4(p.B, p.ldb, ob, tk, kof(kt + 2), kend, zeros, rb2);
+        mfma_tile(smem);
+        hb_store4(smem + 2 * HW_TILE, lo, ra);
+        hb_store4(smem + 2 * HW_TILE + HW_TILE, lo, rb);
+        __syncthreads();
+        if (kt + 1 >= nkt) break;
+        // odd step kt+1: LDS buffer 1; step kt+2 is in ra2 / rb2; request step kt+3 into ra / rb
+        hw_load4(p.A, p.lda, oa, tk, kof(kt + 3), kend, zeros, ra);
+        hw_load4(p.B, p.ldb, ob, tk, kof(kt + 3), kend, zeros, rb);
+        mfma_tile(smem + 2 * HW_TILE);
+        hb_store4(smem, lo, ra2);
+        hb_store4(smem + HW_TILE, lo, rb2);
         __syncthreads();
     }
     if (!wave_live) return;

@@ -8,13 +8,16 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gamer_amd import ops  # noqa: E402
-
 ap = argparse.ArgumentParser()
+ap.add_argument("--lib", type=str, default="", help="time another build of the library (tools/ablate_gemm.sh)")
 ap.add_argument("--tokens", type=int, default=1024 * 505)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--only", type=str, default="")
 args = ap.parse_args()
+from gamer_amd import _lib  # noqa: E402
+if args.lib:
+    _lib.LIB_PATH = os.path.abspath(args.lib)
+from gamer_amd import ops  # noqa: E402
 T, dev, BF = args.tokens, "cuda", torch.bfloat16
 
 
