@@ -319,6 +319,9 @@ def parse_args(argv=None):
                          "torch AdamW -> zero_grad); module-fused = the same with the module's FusedClipAdamW optimizer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--matmul", choices=["f32", "split6", "split9"], default="f32",
+                    help="fp32 GEMM form (--dtype f32 only): f32 = fp32 MFMA (the headline record); split6 / split9 = "
+                         "gamer_gemm_f32_split, exact three-way bf16 cut of both operands, 6 / 9 products on the bf16 pipe")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (and the roofline object)")
     ap.add_argument("--ragged", action="store_true", help="secondary workload: n_items ~ U{2..items}, right padded")
     ap.add_argument("--variant", choices=["multi", "session"], default="multi",
@@ -417,7 +420,10 @@ def main(argv=None):
     if args.no_dropout:
         cfg.dropout_rate = 0.0
         cfg.attention_dropout = 0.0
-    eng = Engine(cfg, device=f"cuda:{local_rank}", temperature=0.7, variant=args.variant, dtype=args.dtype)
+    if args.matmul != "f32" and (args.dtype != "f32" or args.path != "engine"):
+        raise SystemExit("--matmul split6/split9 is a form of the fp32 engine path (--dtype f32 --path engine)")
+    eng = Engine(cfg, device=f"cuda:{local_rank}", temperature=0.7, variant=args.variant, dtype=args.dtype,
+                 matmul=args.matmul)
     smean = args.session_mean if args.variant == "session" else None
     eng.init_weights(seed=0)                     # identical replicas on every rank
     eng.base_seed = 0x5EED + rank                # independent dropout streams per rank
@@ -559,6 +565,12 @@ def main(argv=None):
                  "gemm_wgrad": "gemm_f32_kernel<false, false, 1, false, false, 2, 0>"}.get(dom["kernel"] if dom else "", None)
         traffic = committed_traffic(kname) if (kname and args.batch == 1024 and args.items == 101 and args.dtype == "f32") else None
         peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS
+        split_terms = {"f32": 0, "split6": 6, "split9": 9}[args.matmul]
+        if split_terms:
+            # every fp32 product is `terms` bf16 MFMA products: the pipe that bounds the kernel is the bf16 one, and its
+            # peak in units of the ALGORITHMIC (fp32 problem) FLOPs is the bf16 peak / terms
+            peak = BF16_MATRIX_PEAK_TFLOPS / split_terms
+            traffic = None
         result = {
             "metric": ("train-step sequences/sec, Qwen3Multi SMB decoder, his_len=100" if args.variant == "multi" else
                        "train-step sequences/sec, Qwen3SessionMulti SMB decoder, his_len=100"),
@@ -579,15 +591,20 @@ def main(argv=None):
                              " SMB decoder train step (fwd+bwd+clip+AdamW, dropout 0.2), ShortVideoAD-shaped "
                              f"synthetic ids, per-GPU batch {args.batch} x {args.items * 5} tokens"
                              + (" ragged" if args.ragged else "") + ", V=1041, " +
-                             ("fp32" if args.dtype == "f32" else "bf16 AMP (fp32 master weights / gradients / moments)")),
+                             ("fp32" if args.dtype == "f32" else "bf16 AMP (fp32 master weights / gradients / moments)") +
+                             (f"; Linear products as {split_terms} exact bf16 piece products per fp32 product "
+                              "(gamer_gemm_f32_split), fp32 accumulate" if split_terms else "")),
                 "global_batch": args.batch * world,
                 "seq_len": args.items * 5,
                 "parallelism": f"dp{world}",
                 "path": args.path,
+                "matmul": args.matmul,
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": (f"gemm_{'f32' if args.dtype == 'f32' else 'bf16'}_kernel ({dom['kernel']})") if dom else None,
+                "kernel": (f"gemm_{'f32' if args.dtype == 'f32' else 'bf16'}_kernel ({dom['kernel']})"
+                           + (f" SPLIT={split_terms}: bf16 MFMA pipe, peak = {BF16_MATRIX_PEAK_TFLOPS:g} / {split_terms}"
+                              if split_terms else "")) if dom else None,
                 "achieved": dom["tflops"] if dom else None,
                 "peak": peak,
                 "unit": "TFLOP/s",

@@ -83,6 +83,7 @@ _SIGNATURES = {
     "gamer_rowtable_fwd": [P, P, P, I, I, P, I, I, P],
     "gamer_rowtable_bwd": [P, I, I, P, P, I, I, I, P, P],
     "gamer_gemm_f32": [C.POINTER(GemmDesc), P],
+    "gamer_gemm_f32_split": [C.POINTER(GemmDesc), c_int, P],
     "gamer_gemm_bf16": [C.POINTER(GemmBf16Desc), P],
     "gamer_cast_params_bf16": [P, P, P, P, I, I, P],
     "gamer_attn_fwd_bf16": [P, I, P, I, P, I, P, P, I, I, I, I, F, F, U, P, P, P, P],

@@ -14,6 +14,15 @@
 //       32 lanes of a half read 32 consecutive floats.
 // Grouped forms cover the position-routed experts without host synchronisation: segment offsets are
 // read from device memory and surplus workgroups exit.
+//
+// SPLIT = 6 | 9 (gamer_gemm_f32_split): the same kernel with the products formed on the bf16 matrix pipe, which is
+// 16 x wider than the fp32 one.  Every fp32 operand value is cut into three bf16 pieces x = x0 + x1 + x2 - EXACTLY:
+// x0 = the upper 16 bits of x (8 significant bits), x1 = the upper 16 bits of x - x0 (the subtraction is exact), x2 =
+// x - x0 - x1, which has at most 8 significant bits left - while the tile is written to LDS (three bf16 images per
+// operand), and a.b is accumulated as the bf16 products a_i.b_j (each exact in fp32: 8 x 8 significant bits) in the
+// fp32 accumulators of v_mfma_f32_32x32x16_bf16: all nine of them (SPLIT = 9: every bit of both mantissas takes part,
+// the only rounding left is the fp32 accumulation, as in the fp32 MFMA), or the six with i + j <= 2 (SPLIT = 6: the
+// three dropped products are below 2^-24 of |a.b| each - the size of one fp32 rounding).  Inf / NaN operands give NaN.
 #include "common.h"
 #include <stdlib.h>
 
@@ -26,6 +35,84 @@ constexpr int TILE_FLOATS = BM * KC_LD;        // 4608 >= BK*BM (RC image)
 constexpr int GEMM_LDS_BYTES = 4 * TILE_FLOATS * (int)sizeof(float);   // 2 operands x 2 buffers
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- SPLIT mode: LDS images and the exact three-way cut ------------------------------------------------------------
+constexpr int SP_KC_ROW = 80;                  // bytes per row of a K-contiguous bf16 image: 32 k + 16 bytes of padding
+constexpr int SP_KC_IMG = BM * SP_KC_ROW;      // 10,240
+constexpr int SP_RC_IMG = BK * 256;            // [k][128 rows] bf16, 256-byte rows, 16-byte chunks XOR-swizzled: 8,192
+constexpr int SP_OPERAND = 3 * SP_KC_IMG;      // one operand = three images (the larger layout)
+constexpr int SP_LDS_BYTES = 2 * SP_OPERAND;   // 61,440: ONE stage (two barriers per K-step), two workgroups per CU
+
+#ifndef SP_ABLATE
+#define SP_ABLATE 0     // timing-only builds (tools/ablate_gemm.sh): 1 no split arithmetic, 2 no LDS stores, 4 no MFMA, 8 no global loads
+#endif
+// upper halves of (w1, w0) -> one register {bf16(w0), bf16(w1)}
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t w0, uint32_t w1) { return __builtin_amdgcn_perm(w1, w0, 0x07060302u); }
+// x = p0 + p1 + p2 exactly, p_i = the value of the upper 16 bits of w[i]
+__device__ __forceinline__ void split3(float x, uint32_t (&w)[3]) {
+    if (SP_ABLATE & 1) { w[0] = w[1] = w[2] = __float_as_uint(x); return; }
+    w[0] = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(w[0] & 0xffff0000u);
+    w[1] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(w[1] & 0xffff0000u);
+    w[2] = __float_as_uint(r2);
+}
+// the three bf16 images of 4 consecutive values: img[s] = {lo dword, hi dword}
+__device__ __forceinline__ void split3_quad(const float4& v, uint2 (&img)[3]) {
+    uint32_t a[3], b[3], c[3], d[3];
+    split3(v.x, a); split3(v.y, b); split3(v.z, c); split3(v.w, d);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) img[s] = make_uint2(pack_hi16(a[s], b[s]), pack_hi16(c[s], d[s]));
+}
+// byte offset of (k, row) in an RC image: chunk (row >> 3) of the k row is XORed with (k & 3) << 2 so that both the
+// 8-byte stores of a float4's pieces and the transposing reads spread over the banks
+__device__ __forceinline__ int sp_rc_off(int k, int row) { return k * 256 + ((((row >> 3) ^ ((k & 3) << 2))) << 4) + ((row & 7) << 1); }
+__device__ __forceinline__ void store_kc_split(unsigned char* __restrict__ lds, int tid, const float4 (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = tid + GEMM_THREADS * j;
+        uint2 img[3];
+        split3_quad(r[j], img);
+        unsigned char* dst = lds + (f >> 3) * SP_KC_ROW + ((f & 7) << 3);
+        if (SP_ABLATE & 2) { asm volatile("" :: "v"(img[0].x), "v"(img[1].x), "v"(img[2].x), "v"(img[0].y), "v"(img[1].y), "v"(img[2].y)); continue; }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) *reinterpret_cast<uint2*>(dst + s * SP_KC_IMG) = img[s];
+    }
+}
+__device__ __forceinline__ void store_rc_split(unsigned char* __restrict__ lds, int tid, const float4 (&r)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = tid + GEMM_THREADS * j;
+        uint2 img[3];
+        split3_quad(r[j], img);
+        unsigned char* dst = lds + sp_rc_off(f >> 5, (f & 31) << 2);
+        if (SP_ABLATE & 2) { asm volatile("" :: "v"(img[0].x), "v"(img[1].x), "v"(img[2].x), "v"(img[0].y), "v"(img[1].y), "v"(img[2].y)); continue; }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) *reinterpret_cast<uint2*>(dst + s * SP_RC_IMG) = img[s];
+    }
+}
+// fragment of `v_mfma_f32_32x32x16_bf16`: lane (r32, h) holds k = 16 * sub + 8 * h + 0..7 of operand row `rbase + r32`
+template <bool KC>
+__device__ __forceinline__ bf16x8 read_frag_split(const unsigned char* __restrict__ img, int rbase, int sub, int lane) {
+    const int r32 = lane & 31, h = lane >> 5;
+    if (KC) {
+        return *reinterpret_cast<const bf16x8*>(img + (rbase + r32) * SP_KC_ROW + ((2 * sub + h) << 4));
+    } else {
+        // transposing read: lane 16g + 4q + pp supplies the address of (k 4-block row q, rows 4pp..4pp+3) of its group's
+        // 4 x 16 block and receives row (lane & 15) of the four k
+        const int q = (lane >> 2) & 3, pp = lane & 3, gsel = (lane >> 4) & 1;
+        const int row = rbase + 16 * gsel + 4 * pp;
+        bf16x8 out;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int k = 16 * sub + 8 * h + 4 * c + q;
+            const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (bf16x4 __attribute__((address_space(3)))*)(img + sp_rc_off(k, row)));
+            out[4 * c + 0] = v[0]; out[4 * c + 1] = v[1]; out[4 * c + 2] = v[2]; out[4 * c + 3] = v[3];
+        }
+        return out;
+    }
+}
 
 // Diagnostic build only (STAMP = true, selected by gamer_debug_gemm_stamp): wave 0 of every workgroup
 // accumulates shader-clock cycles per phase of the K loop into g_gemm_stamp[8 * blockIdx.x + phase].
@@ -151,8 +238,8 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row
 
 // EPI: 0 plain, 1 residual + dropout (Linear-forward sites of the decoder layer), 2 row-dot ("delta = dO . O" of the
 // attention backward, taken while the o_proj dgrad tile is still in LDS: one pass over dO and one over O less)
-template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, int EPI>
-__global__ void __launch_bounds__(GEMM_THREADS, NBUF == 1 ? 3 : 2)
+template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, int EPI, int SPLIT = 0>
+__global__ void __launch_bounds__(GEMM_THREADS, (NBUF == 1 && SPLIT == 0) ? 3 : 2)
 gemm_f32_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // buffer b: A image at smem + 2*b*TILE_FLOATS, B image right behind it
@@ -255,6 +342,12 @@ gemm_f32_kernel(const GemmParams p) {
         }
     };
     auto store_tile = [&](float* dst) {
+        if (SPLIT) {
+            unsigned char* d8 = reinterpret_cast<unsigned char*>(dst);
+            if (A_KC) store_kc_split(d8, tid, ra); else store_rc_split(d8, tid, ra);
+            if (B_KC) store_kc_split(d8 + SP_OPERAND, tid, rb); else store_rc_split(d8 + SP_OPERAND, tid, rb);
+            return;
+        }
         if (A_KC) store_kc(dst, tid, ra); else store_rc(dst, tid, ra);
         if (B_KC) store_kc(dst + TILE_FLOATS, tid, rb); else store_rc(dst + TILE_FLOATS, tid, rb);
     };
@@ -266,6 +359,37 @@ gemm_f32_kernel(const GemmParams p) {
     const bool wave_live = (row0 + wm * 64 < row_end) && (col0 + wn * 64 < col_end);
     auto mfma_tile = [&](const float* as) {
         if (!wave_live) return;
+        if (SPLIT && (SP_ABLATE & 4)) return;
+        if (SPLIT) {
+            const unsigned char* a8 = reinterpret_cast<const unsigned char*>(as);
+            const unsigned char* b8 = a8 + SP_OPERAND;
+            constexpr int A_IMG = A_KC ? SP_KC_IMG : SP_RC_IMG, B_IMG = B_KC ? SP_KC_IMG : SP_RC_IMG;
+#pragma unroll
+            for (int sub = 0; sub < BK / 16; ++sub) {
+                bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) af[i][s] = read_frag_split<A_KC>(a8 + s * A_IMG, wm * 64 + i * 32, sub, lane);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bf[j][s] = read_frag_split<B_KC>(b8 + s * B_IMG, wn * 64 + j * 32, sub, lane);
+                }
+                // smallest products first; sa + sb <= 2 for SPLIT == 6, all nine for SPLIT == 9
+#pragma unroll
+                for (int order = (SPLIT == 9 ? 4 : 2); order >= 0; --order)
+#pragma unroll
+                    for (int sa = 0; sa < 3; ++sa) {
+                        const int sb = order - sa;
+                        if (sb < 0 || sb > 2) continue;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][sa], bf[j][sb], acc[i][j], 0, 0, 0);
+                    }
+            }
+            return;
+        }
         // measured (tools/ab_libs.sh): +0.5-1 % on the forward / dgrad layouts, -2 % on the split-K wgrad
         if (MODE == 0) __builtin_amdgcn_s_setprio(1);
         const float* bs = as + TILE_FLOATS;
@@ -299,6 +423,7 @@ gemm_f32_kernel(const GemmParams p) {
         const int64_t sa = A_KC ? BK : BK * p.a_ks;               // one K-step
         const int64_t sb = B_KC ? BK : BK * p.b_ks;
         auto fast_load = [&]() {
+            if (SPLIT && (SP_ABLATE & 8)) return;
 #pragma unroll
             for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(pa + j * ja);
 #pragma unroll
@@ -306,7 +431,17 @@ gemm_f32_kernel(const GemmParams p) {
             pa += sa;
             pb += sb;
         };
-        if (NBUF == 1) {
+        if (SPLIT) {
+            // one stage of three-image tiles (60 KB): split + store, barrier, request the next step, multiply, barrier
+            fast_load();
+            for (int kt = 0; kt < nkt; ++kt) {
+                store_tile(smem);
+                __syncthreads();
+                if (kt + 1 < nkt) fast_load();
+                mfma_tile(smem);
+                __syncthreads();
+            }
+        } else if (NBUF == 1) {
             // one LDS image (36 KB): three workgroups per CU; two barriers per K-step, covered by the other
             // two waves of the SIMD
             fast_load();
@@ -336,7 +471,16 @@ gemm_f32_kernel(const GemmParams p) {
             }
         }
     } else {
-        if (NBUF == 1) {
+        if (SPLIT) {
+            if (nkt > 0) load_tile(kbeg);
+            for (int kt = 0; kt < nkt; ++kt) {
+                store_tile(smem);
+                __syncthreads();
+                if (kt + 1 < nkt) load_tile(kbeg + (kt + 1) * BK);
+                mfma_tile(smem);
+                __syncthreads();
+            }
+        } else if (NBUF == 1) {
             if (nkt > 0) load_tile(kbeg);
             for (int kt = 0; kt < nkt; ++kt) {
                 if (kt > 0) __syncthreads();
@@ -365,7 +509,7 @@ gemm_f32_kernel(const GemmParams p) {
 
     // ---- epilogue: acc[i][j][r] is C[row = (r&3)+8*(r>>2)+4*h][col = lane&31] of its 32x32 tile --
     const bool interior = a_in && b_in;
-    if (MODE == 0 && NBUF == 2 && interior && (p.ldc & 3) == 0) {
+    if (MODE == 0 && (NBUF == 2 || SPLIT) && interior && (p.ldc & 3) == 0) {
         // Row-major rewrite through LDS (the K-loop images are dead after its last barrier): each wave
         // parks its 64x64 patch as [64][68] floats and reads it back one 16-byte row chunk per lane, so the
         // patch leaves in 16 x 1-KiB store instructions (4 rows x 256 B each) instead of 64 dword stores.
@@ -497,10 +641,10 @@ gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, int EPI = 0>
+template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, int EPI = 0, int SPLIT = 0>
 static int launch_gemm_t(const GemmParams& p, int blocks, hipStream_t st, int lds) {
     static int attr_lds = 0;
-    auto kfn = gemm_f32_kernel<A_KC, B_KC, MODE, ACCUM, STAMP, NBUF, EPI>;
+    auto kfn = gemm_f32_kernel<A_KC, B_KC, MODE, ACCUM, STAMP, NBUF, EPI, SPLIT>;
     if (attr_lds != lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -515,8 +659,22 @@ static int launch_gemm_t(const GemmParams& p, int blocks, hipStream_t st, int ld
     return 0;
 }
 
+// the bf16-split forms: one LDS stage; the epilogue's row-major rewrite needs the full 72 KB
+template <bool A_KC, bool B_KC, int MODE, int SPLIT>
+static int launch_gemm_split(const GemmParams& p, int blocks, hipStream_t st) {
+    const int lds = GEMM_LDS_BYTES;
+    static_assert(SP_LDS_BYTES <= GEMM_LDS_BYTES, "split images must fit the fp32 kernel's LDS allocation");
+    const bool acc = MODE == 0 && p.accumulate;
+    if (MODE == 0 && p.resid) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 1, SPLIT>(p, blocks, st, lds);
+    if (MODE == 0 && p.rowdot_out) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 2, SPLIT>(p, blocks, st, lds);
+    if (acc) return launch_gemm_t<A_KC, B_KC, MODE, true, false, 2, 0, SPLIT>(p, blocks, st, lds);
+    return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 0, SPLIT>(p, blocks, st, lds);
+}
+
 template <bool A_KC, bool B_KC, int MODE>
-static int launch_gemm(const GemmParams& p, int blocks, hipStream_t st) {
+static int launch_gemm(const GemmParams& p, int blocks, hipStream_t st, int split = 0) {
+    if (split == 6) return launch_gemm_split<A_KC, B_KC, MODE, 6>(p, blocks, st);
+    if (split == 9) return launch_gemm_split<A_KC, B_KC, MODE, 9>(p, blocks, st);
     static int stamp = -1, solo = 0, nbuf = 2;
     if (stamp < 0) {
         const char* e = getenv("GAMER_GEMM_STAMP");
@@ -549,7 +707,7 @@ extern "C" int gamer_debug_gemm_stamp(void* p) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamp), &v, sizeof(v));
 }
 
-extern "C" int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream) {
+static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     GAMER_CHECK_ARG(d, "gamer_gemm_f32: null descriptor");
     GAMER_CHECK_ARG(d->A && d->B && d->C, "gamer_gemm_f32: null matrix pointer");
     GAMER_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gamer_gemm_f32: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -594,9 +752,9 @@ extern "C" int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream) {
         p.m_tiles = (d->M + BM - 1) / BM + (d->group_offsets ? d->groups : 0);
         const int64_t blocks = (int64_t)p.m_tiles * p.n_tiles;
         GAMER_CHECK_ARG(blocks < (1LL << 31), "gamer_gemm_f32: grid too large");
-        if (a_kc && b_kc) return launch_gemm<true, true, 0>(p, (int)blocks, st);
-        if (a_kc && !b_kc) return launch_gemm<true, false, 0>(p, (int)blocks, st);
-        if (!a_kc && !b_kc) return launch_gemm<false, false, 0>(p, (int)blocks, st);
+        if (a_kc && b_kc) return launch_gemm<true, true, 0>(p, (int)blocks, st, split);
+        if (a_kc && !b_kc) return launch_gemm<true, false, 0>(p, (int)blocks, st, split);
+        if (!a_kc && !b_kc) return launch_gemm<false, false, 0>(p, (int)blocks, st, split);
         GAMER_CHECK_ARG(false, "gamer_gemm_f32: layout (A row-contiguous, B k-contiguous) is not built");
     } else {
         GAMER_CHECK_ARG(!a_kc && !b_kc, "gamer_gemm_f32: group_mode 1 (wgrad) needs row-contiguous A and B");
@@ -605,7 +763,14 @@ extern "C" int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream) {
         const int64_t chunks = (d->K + d->kchunk - 1) / d->kchunk + (d->group_offsets ? d->groups : 0);
         const int64_t blocks = chunks * p.m_tiles * p.n_tiles;
         GAMER_CHECK_ARG(blocks < (1LL << 31), "gamer_gemm_f32: grid too large");
-        return launch_gemm<false, false, 1>(p, (int)blocks, st);
+        return launch_gemm<false, false, 1>(p, (int)blocks, st, split);
     }
     return 0;
+}
+
+extern "C" int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream) { return gemm_entry(d, stream, 0); }
+
+extern "C" int gamer_gemm_f32_split(const gamer_gemm_desc* d, int terms, void* stream) {
+    GAMER_CHECK_ARG(terms == 6 || terms == 9, "gamer_gemm_f32_split: terms=%d (6 or 9)", terms);
+    return gemm_entry(d, stream, terms);
 }

@@ -339,14 +339,23 @@ class Engine:
     N_SUMSQ_PARTIAL = 1024
 
     def __init__(self, cfg: Qwen3MultiConfig, device="cuda", temperature: float = 1.0, variant: str = "multi",
-                 dtype: str = "f32"):
+                 dtype: str = "f32", matmul: str = "f32"):
         """``variant``: "multi" = Qwen3Multi (train_SMB_decoder.py:362-364), "session" = Qwen3SessionMulti
         (train_SMB_decoder.py:365-367): the same parameters and layers with session-wise attention masks and
         RoPE positions taken from ``extended_session_ids``.
         ``dtype``: "f32" (default) or "bf16" = the reference's ``--bf16`` run (train_SMB_decoder.py:114-118, 407-408:
         HF Trainer autocast): bf16 matrix operands and activations, fp32 accumulation, fp32 residual stream,
-        normalisation statistics, loss, master weights, gradients and optimizer state."""
+        normalisation statistics, loss, master weights, gradients and optimizer state.
+        ``matmul`` (dtype "f32" only): how the nn.Linear sites multiply fp32 operands - "f32" = v_mfma_f32_32x32x2_f32,
+        "split6" / "split9" = gamer_gemm_f32_split: both operands cut exactly into three bf16 pieces, 6 or 9 piece
+        products on the 16x wider bf16 pipe, fp32 accumulation (include/gamer_hip.h; error vs fp64 measured equal to
+        the fp32 MFMA's, tools/split_error.py).  Attention stays on the fp32 MFMA either way."""
         cfg.validate()
+        if matmul not in ops.MATMUL_MODES:
+            raise ValueError(f"unknown matmul {matmul!r} ({sorted(ops.MATMUL_MODES)})")
+        if dtype != "f32" and matmul != "f32":
+            raise ValueError("matmul='split6'/'split9' is a form of the fp32 path; dtype='bf16' has its own GEMM")
+        self.matmul = matmul
         if variant not in ("multi", "session"):
             raise ValueError(f"unknown variant {variant!r}")
         if dtype not in ("f32", "bf16"):
@@ -462,6 +471,7 @@ class Engine:
         last position only (HF's ``logits_to_keep``): final norm and head run on B rows instead of B*S and the
         returned logits are [B, 1, V]."""
         cfg = self.cfg
+        ops.set_f32_matmul(self.matmul)
         B, S = input_ids.shape
         if train and S % cfg.num_positions != 0:
             raise ValueError(f"sequence length {S} is not a multiple of num_positions={cfg.num_positions} "
@@ -662,6 +672,7 @@ class Engine:
         sv = self._saved
         if sv is None or not sv["train"] or sv["labels"] is None:
             raise RuntimeError("backward() needs forward(train=True, labels=...) first")
+        ops.set_f32_matmul(self.matmul)
         cfg, ws = self.cfg, self.ws
         B, S = sv["B"], sv["S"]
         span_self = span_cross = pos_ids = None

@@ -123,6 +123,23 @@ def rowtable_bwd(dy, lddy, col0, idx, dtable, dy_rows=None):
     call("gamer_rowtable_bwd" + _sfx(dy), ptr(dy), lddy, col0, ptr(idx), ptr(dy_rows), T, E, rows, ptr(dtable), stream_ptr())
 
 
+# fp32 matmul form of the calling thread's engine: 0 = v_mfma_f32_32x32x2_f32, 6 / 9 = gamer_gemm_f32_split (exact
+# three-way bf16 cut of both operands, 6 or 9 piece products on the bf16 pipe).  Engine.forward / backward set it.
+F32_MATMUL_TERMS = 0
+MATMUL_MODES = {"f32": 0, "split6": 6, "split9": 9}
+
+
+def set_f32_matmul(mode) -> int:
+    """mode: "f32" | "split6" | "split9" (or 0 / 6 / 9); returns the previous setting."""
+    global F32_MATMUL_TERMS
+    prev = F32_MATMUL_TERMS
+    terms = MATMUL_MODES[mode] if isinstance(mode, str) else int(mode)
+    if terms not in (0, 6, 9):
+        raise ValueError(f"fp32 matmul mode {mode!r}: one of {sorted(MATMUL_MODES)}")
+    F32_MATMUL_TERMS = terms
+    return prev
+
+
 def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=False, groups=1, group_mode=0,
          group_offsets=None, strideB=0, strideC=0, kchunk=0, resid=None, row_map=None, p_drop=0.0, seed=0,
          rowdot=None):
@@ -149,7 +166,10 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
     d.seed = seed
     if rowdot is not None:                 # (other [M, ldc], out [M / S, N / 64, S], S): see gamer_gemm_desc
         d.rowdot_other, d.rowdot_out, d.rowdot_S = ptr(rowdot[0]), ptr(rowdot[1]), int(rowdot[2])
-    call("gamer_gemm_f32", C.byref(d), stream_ptr())
+    if F32_MATMUL_TERMS:
+        call("gamer_gemm_f32_split", C.byref(d), F32_MATMUL_TERMS, stream_ptr())
+    else:
+        call("gamer_gemm_f32", C.byref(d), stream_ptr())
 
 
 def _gemm_bf16(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha, accumulate, groups, group_mode, group_offsets,

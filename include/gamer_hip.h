@@ -196,6 +196,15 @@ typedef struct {
 
 int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);
 
+/* The same GEMM (same descriptor, same layouts, epilogues and fp32 inputs / outputs) with the products formed on the
+ * bf16 matrix pipe: every operand value is cut EXACTLY into three bf16 pieces (x = x0 + x1 + x2, 8 + 8 + 8 significant
+ * bits) on its way into LDS and a.b is accumulated in fp32 from the piece products a_i.b_j, each of which is exact:
+ * terms = 9 -> all nine (no bit of either operand is dropped; the only rounding is the fp32 accumulation of
+ * v_mfma_f32_32x32x16_bf16), terms = 6 -> those with i + j <= 2 (the three omitted products are each below 2^-24 |a.b|).
+ * Same F.linear sites as gamer_gemm_f32 (model.py:93-99,145-149,1001, FFN.py:25-27); selected per Engine
+ * (`matmul="split6" | "split9"`), never implicitly.  Inf / NaN operands produce NaN. */
+int gamer_gemm_f32_split(const gamer_gemm_desc* d, int terms, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulation): the nn.Linear sites of the reference's --bf16 run
  * (autocast casts both operands of every F.linear to bf16, model.py:93-99,145-149,1001, FFN.py:25-27).

@@ -30,13 +30,16 @@ def _record(name, value):
         json.dump(REPORT, f, indent=1)
 
 
-def _engine_from_golden(golden, name):
+MATMULS = ["f32", "split6", "split9"]     # fp32 MFMA / exact bf16-piece products (gamer_gemm_f32_split): same bars
+
+
+def _engine_from_golden(golden, name, matmul="f32"):
     z, meta = golden(name)
     cfg = Qwen3MultiConfig(**meta["config"])
     cfg.dropout_rate = 0.2          # kernels get p=0 through train=False / dropout=False anyway
     ocfg = orc.OracleConfig.from_dict(meta["config"])
     sd = orc.init_state_dict(ocfg, seed=meta["weight_seed"])
-    eng = Engine(cfg, temperature=meta["temperature"])
+    eng = Engine(cfg, temperature=meta["temperature"], matmul=matmul)
     eng.load_state_dict(sd)
     batch = {k: torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "actions", "labels")}
     return z, meta, eng, batch, ocfg, sd
@@ -48,9 +51,10 @@ def _relmax(got, ref):
     return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
 
 
+@pytest.mark.parametrize("matmul", MATMULS)
 @pytest.mark.parametrize("name", ["small", "full"])
-def test_logits_and_loss_match_reference_fixture(golden, name):
-    z, meta, eng, batch, _, _ = _engine_from_golden(golden, name)
+def test_logits_and_loss_match_reference_fixture(golden, name, matmul):
+    z, meta, eng, batch, _, _ = _engine_from_golden(golden, name, matmul)
     _, logits = eng.forward(batch["input_ids"], batch["attention_mask"], batch["actions"], train=False)
     lg = logits.cpu().numpy()
     if name == "small":
@@ -66,15 +70,17 @@ def test_logits_and_loss_match_reference_fixture(golden, name):
                             num_items_in_batch=float(z["num_items"]), train=False)
     e_loss_n = abs(float(loss_n) - float(z["loss_sum"])) / float(z["loss_sum"])
     eng.check_inputs()
-    _record(f"{name}_forward", dict(logits_raw=e_raw, logits_scaled=e_scaled, loss=e_loss, loss_num_items=e_loss_n))
+    _record(f"{name}_forward" + ("" if matmul == "f32" else "_" + matmul),
+            dict(logits_raw=e_raw, logits_scaled=e_scaled, loss=e_loss, loss_num_items=e_loss_n))
     assert e_raw < 1e-3 and e_scaled < 1e-3          # north-star tolerance (fp32, relative)
-    assert e_raw < 2e-5, "fp32 MFMA path is expected to be far inside the tolerance"
+    assert e_raw < 2e-5, "every fp32 matmul form is expected to be far inside the tolerance"
     assert e_loss < 1e-5 and e_loss_n < 1e-5
 
 
+@pytest.mark.parametrize("matmul", MATMULS)
 @pytest.mark.parametrize("name", ["small", "full"])
-def test_gradients_match_reference_fixture(golden, name):
-    z, meta, eng, batch, _, _ = _engine_from_golden(golden, name)
+def test_gradients_match_reference_fixture(golden, name, matmul):
+    z, meta, eng, batch, _, _ = _engine_from_golden(golden, name, matmul)
     loss, _ = eng.forward(batch["input_ids"], batch["attention_mask"], batch["actions"], labels=batch["labels"],
                           train=True, dropout=False)
     assert abs(float(loss) - float(z["loss_train_mode"])) < 1e-5 * float(z["loss_train_mode"])
@@ -98,7 +104,7 @@ def test_gradients_match_reference_fixture(golden, name):
             sample_err[k[12:]] = _relmax(got, z[k])
     wk = max(sample_err, key=sample_err.get)
     rec.update(worst_sample_rel=sample_err[wk], worst_sample_key=wk)
-    _record(f"{name}_gradients", rec)
+    _record(f"{name}_gradients" + ("" if matmul == "f32" else "_" + matmul), rec)
     assert abs(gn - float(z["global_grad_norm"])) < 1e-4 * float(z["global_grad_norm"])
     assert float(rel.max()) < 1e-3, gkeys[worst]
     assert sample_err[wk] < 1e-3, wk

@@ -181,8 +181,16 @@ def test_rowtable_fwd_bwd():
 
 
 # ----------------------------------------------------------------------------------------------
+@pytest.fixture(params=["f32", "split6", "split9"])
+def gemm_mode(request):
+    """Every fp32 GEMM test runs on the fp32 MFMA and on both bf16-piece forms (gamer_gemm_f32_split) with the SAME bars."""
+    prev = ops.set_f32_matmul(request.param)
+    yield request.param
+    ops.set_f32_matmul(prev)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 384, 256), (1000, 1041, 256), (257, 256, 1041), (128, 128, 32), (64, 40, 96)])
-def test_gemm_linear_fwd_and_dgrad(M, N, K):
+def test_gemm_linear_fwd_and_dgrad(M, N, K, gemm_mode):
     ldx, ldw, ldy = (K + 3) // 4 * 4 + 8, (K + 3) // 4 * 4, (N + 3) // 4 * 4 + 4
     x = torch.zeros(M, ldx); x[:, :K] = torch.randn(M, K)
     w = torch.zeros(N, ldw); w[:, :K] = torch.randn(N, K)
@@ -191,7 +199,7 @@ def test_gemm_linear_fwd_and_dgrad(M, N, K):
     ops.linear_fwd(dev(x), ldx, dev(w), ldw, y, ldy, M, N, K)
     ref = x[:, :K].double() @ w[:, :K].double().T
     e = _rel(y.cpu()[:, :N], ref)
-    _record(f"gemm_fwd_{M}x{N}x{K}", e)
+    _record(f"gemm_fwd_{M}x{N}x{K}_{gemm_mode}", e)
     assert e < 2e-6
     assert bool((y.cpu()[:, N:] == -3.0).all())
     # dgrad: dx[M,K] = dy[M,N] @ w[N,K]
@@ -200,14 +208,14 @@ def test_gemm_linear_fwd_and_dgrad(M, N, K):
     ops.linear_dgrad(dev(dy), ldy, dev(w), ldw, dx, ldx, M, N, K)
     refd = dy[:, :N].double() @ w[:, :K].double()
     e = _rel(dx.cpu()[:, :K], refd)
-    _record(f"gemm_dgrad_{M}x{N}x{K}", e)
+    _record(f"gemm_dgrad_{M}x{N}x{K}_{gemm_mode}", e)
     assert e < 2e-6
     # accumulate
     ops.linear_dgrad(dev(dy), ldy, dev(w), ldw, dx, ldx, M, N, K, accumulate=True)
     assert _rel(dx.cpu()[:, :K], 2 * refd) < 2e-6
 
 
-def test_gemm_rowdot_epilogue():
+def test_gemm_rowdot_epilogue(gemm_mode):
     """dgrad layout with the row-dot epilogue: C as without it, and out[b][head][i] = C[m, head] . other[m, head]
     (flash attention's delta from the o_proj dgrad)."""
     S, B, heads, K = 64, 6, 4, 96
@@ -225,7 +233,7 @@ def test_gemm_rowdot_epilogue():
 
 
 @pytest.mark.parametrize("rows,N,K", [(5000, 384, 256), (777, 1041, 256), (4100, 512, 320)])
-def test_gemm_wgrad_splitk(rows, N, K):
+def test_gemm_wgrad_splitk(rows, N, K, gemm_mode):
     ldy, ldx = (N + 3) // 4 * 4, K
     dy = torch.zeros(rows, ldy); dy[:, :N] = torch.randn(rows, N)
     x = torch.randn(rows, ldx)
@@ -233,12 +241,12 @@ def test_gemm_wgrad_splitk(rows, N, K):
     ops.linear_wgrad(dev(dy), ldy, dev(x), ldx, dW, K, rows, N, K)
     ref = 1.0 + dy[:, :N].double().T @ x.double()
     e = _rel(dW, ref)
-    _record(f"gemm_wgrad_{rows}x{N}x{K}", e)
+    _record(f"gemm_wgrad_{rows}x{N}x{K}_{gemm_mode}", e)
     assert e < 5e-6
 
 
 @pytest.mark.parametrize("p_drop", [0.0, 0.2])
-def test_gemm_fused_residual_epilogue(p_drop):
+def test_gemm_fused_residual_epilogue(p_drop, gemm_mode):
     """C[map(m)] = resid[map(m)] + dropout(x W^T): same values and the same mask as GEMM followed by the
     stand-alone residual kernel (plain and expert-grouped with the sorted-slot -> token map)."""
     T, N, K, seed = 1000, 256, 384, 4242
@@ -267,7 +275,7 @@ def test_gemm_fused_residual_epilogue(p_drop):
     assert float((out2 - ref2).abs().max()) < 1e-5
 
 
-def test_gemm_grouped_experts():
+def test_gemm_grouped_experts(gemm_mode):
     E, Din, I = 6, 320, 512
     sizes = [0, 700, 129, 1, 300, 128]              # an empty expert, ragged and exact tiles
     T = sum(sizes)
@@ -299,9 +307,77 @@ def test_gemm_grouped_experts():
         a, b = int(offs[e]), int(offs[e + 1])
         refw[e] = dy[a:b].double().T @ x[a:b].double()
     e3 = _rel(dW, refw)
-    _record("gemm_grouped", [e1, e2, e3])
+    _record("gemm_grouped_" + gemm_mode, [e1, e2, e3])
     assert e1 < 2e-6 and e2 < 2e-6 and e3 < 5e-6
     assert float(dW[0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("terms", [6, 9])
+def test_gemm_split_is_exact_where_fp32_is(terms):
+    """The three bf16 pieces carry all 24 bits of an operand: (a) small integers - every product and partial sum is exact
+    in fp32 - give bit-identical results to the fp32 MFMA on all three layouts; (b) values that need the last mantissa
+    bit (1 + 2^-23, 1 - 2^-24, 2^-120 * odd) times powers of two come back exactly; (c) with BOTH operands using their
+    low bits the nine-product form is exact where the sum is representable, and the six-product form is off by at
+    most the three omitted piece products (< 3 * 2^-24 per term)."""
+    torch.manual_seed(5)
+    M, N, K = 384, 256, 96
+    x = torch.randint(-8, 9, (M, K)).float()
+    w = torch.randint(-8, 9, (N, K)).float()
+    dy = torch.randint(-8, 9, (M, N)).float()
+    outs = {}
+    for mode in (0, terms):
+        ops.set_f32_matmul(mode)
+        y, dx, dW = torch.empty(M, N, device=DEV), torch.empty(M, K, device=DEV), torch.zeros(N, K, device=DEV)
+        ops.linear_fwd(dev(x), K, dev(w), K, y, N, M, N, K)
+        ops.linear_dgrad(dev(dy), N, dev(w), K, dx, K, M, N, K)
+        ops.linear_wgrad(dev(dy), N, dev(x), K, dW, K, M, N, K)
+        outs[mode] = (y.cpu(), dx.cpu(), dW.cpu())
+    ops.set_f32_matmul(0)
+    for a, b in zip(outs[0], outs[terms]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[terms][0].double(), x.double() @ w.double().T)
+    # (b) one non-zero product per output element: nothing to round
+    vals = torch.tensor([1 + 2.0 ** -23, 1 - 2.0 ** -24, 3 * 2.0 ** -120, -(2.0 ** 20 + 1), 1.9999998807907104, 7 * 2.0 ** 100])
+    xb = torch.zeros(128, 32); xb[torch.arange(128), torch.arange(128) % 32] = vals[torch.arange(128) % 6]
+    wb = torch.zeros(128, 32); wb[torch.arange(128), torch.arange(128) % 32] = 2.0 ** (torch.arange(128) % 5 - 2).float()
+    ops.set_f32_matmul(terms)
+    yb = torch.empty(128, 128, device=DEV)
+    ops.linear_fwd(dev(xb), 32, dev(wb), 32, yb, 128, 128, 128, 32)
+    ops.set_f32_matmul(0)
+    assert torch.equal(yb.cpu().double(), xb.double() @ wb.double().T)
+    # (c) both operands with low bits: a = 1 + 2^-12 + 2^-23 (all three pieces non-zero), b likewise
+    a, b = 1 + 2.0 ** -12 + 2.0 ** -23, 1 - 2.0 ** -11 + 2.0 ** -22
+    xc = torch.zeros(128, 32); xc[:, 0] = a
+    wc = torch.zeros(128, 32); wc[:, 0] = b
+    ops.set_f32_matmul(terms)
+    yc = torch.empty(128, 128, device=DEV)
+    ops.linear_fwd(dev(xc), 32, dev(wc), 32, yc, 128, 128, 128, 32)
+    ops.set_f32_matmul(0)
+    exact = float(torch.tensor(a, dtype=torch.float64) * torch.tensor(b, dtype=torch.float64))
+    err = float((yc.cpu().double() - exact).abs().max())
+    assert err <= (2.0 ** -24 if terms == 9 else 4 * 2.0 ** -24) * abs(exact)
+
+
+def test_gemm_split_error_is_not_larger_than_the_fp32_mfma():
+    """Wide dynamic range inputs at a train-step shape: error against the fp64 product of the same fp32 inputs, relative
+    to sum_k |a_k b_k|, for the fp32 MFMA and both bf16-piece forms."""
+    torch.manual_seed(11)
+    T, N, K = 4096, 768, 256
+    x = torch.randn(T, K) * torch.exp(torch.randn(T, K))
+    W = torch.randn(N, K) * 0.05
+    ref, sc = x.double() @ W.double().T, x.double().abs() @ W.double().abs().T
+    errs = {}
+    for mode in ("f32", "split6", "split9"):
+        ops.set_f32_matmul(mode)
+        y = torch.empty(T, N, device=DEV)
+        ops.linear_fwd(dev(x), K, dev(W), K, y, N, T, N, K)
+        e = (y.cpu().double() - ref).abs() / sc
+        errs[mode] = (float(e.max()), float(e.pow(2).mean().sqrt()))
+    ops.set_f32_matmul("f32")
+    _record("gemm_split_error", errs)
+    for mode in ("split6", "split9"):
+        assert errs[mode][0] < 1.5 * errs["f32"][0] + 1e-8 and errs[mode][1] < 1.25 * errs["f32"][1]
+        assert errs[mode][0] < 2e-6
 
 
 # ----------------------------------------------------------------------------------------------

@@ -14,6 +14,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from gamer_amd import _lib  # noqa: E402
+if "--lib" in sys.argv:                                  # another build of the library (tools/ablate_gemm.sh)
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from gamer_amd import ops, synthetic  # noqa: E402
 from gamer_amd.config import synthetic_config  # noqa: E402
 
@@ -170,5 +173,8 @@ if __name__ == "__main__":
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--only", default=None)
     ap.add_argument("--no-order", dest="no_order", action="store_true", help="cross attention without the row order")
+    ap.add_argument("--lib", default="")
+    ap.add_argument("--matmul", default="f32", choices=sorted(ops.MATMUL_MODES), help="fp32 GEMM form (gamer_gemm_f32_split)")
     args = ap.parse_args()
+    ops.set_f32_matmul(args.matmul)
     {"attn": bench_attn, "gemm": bench_gemm, "gemmk": bench_gemm_k, "elem": bench_elem}[args.what](args)
