@@ -8,6 +8,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib
@@ -226,18 +228,64 @@ def pick_kchunk(rows: int, grouped: bool) -> int:
     return chunk
 
 
-def linear_wgrad(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups=1, group_offsets=None, strideC=0, kchunk=None):
-    """dW[N_out,K_in] += dy[rows,N_out]^T @ x[rows,K_in]   (dW must be initialised; fp32 atomics)."""
-    if kchunk is None and dy.dtype == torch.bfloat16:
+# Token chunk of the split-K wgrad, measured once per (shape, dtype, matmul form) on first use: the best chunk depends on
+# how tiles x chunks lands on the chip's 512 workgroup slots (tools/wgrad_probe.py: at 64,640 tokens the fixed rule loses
+# 10-17 % on the o_proj, expert and head shapes; at 517k tokens 0-3 %).  GAMER_WGRAD_TUNE=0 keeps the fixed rules.
+_WGRAD_TUNED = {}
+_WGRAD_TUNE = os.environ.get("GAMER_WGRAD_TUNE", "1") != "0"
+
+
+def _rule_kchunk(dy, rows, N_out, K_in, groups):
+    if dy.dtype == torch.bfloat16:
         # bf16 tiles take 16x less matrix time than fp32 ones: chunks as long as possible (fewer fp32 atomics: every chunk
         # adds the whole 128 x 128 tile) while the grid still fills the chip's 512 workgroup slots once
         tiles = ((N_out + 127) // 128) * ((K_in + 127) // 128)
         per_group = max(1, rows // max(groups, 1))
         chunks = max(1, 512 // (tiles * max(groups, 1)))
         kchunk = min(16384, max(256, -(-per_group // chunks)))
-        kchunk = (kchunk + 63) // 64 * 64
+        return (kchunk + 63) // 64 * 64
+    return pick_kchunk(rows, groups > 1)
+
+
+def _tune_kchunk(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups, group_offsets, strideC):
+    rule = _rule_kchunk(dy, rows, N_out, K_in, groups)
+    if dy.dtype == torch.bfloat16:
+        cands = {rule, 512, 1024, 2048, 4096, 8192, 16384}
+    else:
+        cands = {rule, 384, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096}
+    cands = sorted(c for c in cands if c <= max(256, rows))
+    scratch = torch.zeros_like(dW)                 # the sweep must not touch the real gradient
+    best, best_t = rule, float("inf")
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for c in cands:
+        ts = []
+        for it in range(4):
+            s.record()
+            gemm(dy, 1, lddy, x, 1, ldx, scratch, lddw, N_out, K_in, rows, groups=groups, group_mode=1,
+                 group_offsets=group_offsets, strideC=strideC, kchunk=c)
+            e.record()
+            e.synchronize()
+            if it:
+                ts.append(s.elapsed_time(e))
+        t = min(ts)
+        if t < best_t * (0.98 if c != rule else 1.0):      # ties go to the smaller chunk / the rule
+            best, best_t = c, t
+    return best
+
+
+def linear_wgrad(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups=1, group_offsets=None, strideC=0, kchunk=None):
+    """dW[N_out,K_in] += dy[rows,N_out]^T @ x[rows,K_in]   (dW must be initialised; fp32 atomics)."""
     if kchunk is None:
-        kchunk = pick_kchunk(rows, groups > 1)
+        key = (rows, N_out, K_in, groups, dy.dtype, F32_MATMUL_TERMS)
+        kchunk = _WGRAD_TUNED.get(key)
+        if kchunk is None:
+            capturing = torch.cuda.is_current_stream_capturing()
+            if _WGRAD_TUNE and rows >= 4096 and not capturing:
+                kchunk = _tune_kchunk(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups, group_offsets, strideC)
+            else:
+                kchunk = _rule_kchunk(dy, rows, N_out, K_in, groups)
+            if not capturing:
+                _WGRAD_TUNED[key] = kchunk
     gemm(dy, 1, lddy, x, 1, ldx, dW, lddw, N_out, K_in, rows, groups=groups, group_mode=1,
          group_offsets=group_offsets, strideC=strideC, kchunk=kchunk)
 
