@@ -26,9 +26,21 @@ constexpr int HB_MAX_GROUPS = 64;
 #ifndef HB_ABLATE
 #define HB_ABLATE 0            // tools/ablate_gemm.sh: 1 no epilogue stores, 2 no global loads, 4 no MFMA / LDS reads, 8 no LDS stores
 #endif
-constexpr int HB_LD = HB_BK + 8;                       // bf16 elements per row of a K-contiguous tile image (144 B)
+// K-contiguous kernel: K-step and workgroups per CU (tools/ablate_gemm.sh builds other combinations)
+// (measured: K-step 32 with three workgroups per CU - 41 KB of LDS, 164 VGPRs - is 2-8 % SLOWER on every shape)
+#ifndef HF_BK
+#define HF_BK 64
+#endif
+#ifndef HF_WGS
+#define HF_WGS 2
+#endif
+constexpr int HB_LD = HF_BK + 8;                       // bf16 elements per row of a K-contiguous tile image (80 / 144 B)
 constexpr int HB_TILE = HB_BM * HB_LD;                 // elements per operand image
-constexpr int HB_LDS_BYTES = 4 * HB_TILE * 2;          // 2 operands x 2 buffers = 73,728 B -> two workgroups per CU
+constexpr int HB_LDS_BYTES = 4 * HB_TILE * 2;          // 2 operands x 2 buffers: 40,960 B (K-step 32) / 73,728 B (64)
+constexpr int HF_NJ = HF_BK / 16;                      // 16-byte chunks per thread, operand and K-step
+constexpr int HF_CH = HF_BK / 8;                       // chunks per tile row
+constexpr int HF_CS = HF_BK == 64 ? 3 : 2;
+static_assert(HF_BK == 32 || HF_BK == 64, "K-step of the K-contiguous bf16 GEMM");
 constexpr int HW_TILE = HB_BK * 128;                   // wgrad: [64 tokens][128 columns] elements per operand image
 constexpr int HW_LDS_BYTES = 4 * HW_TILE * 2;          // 65,536 B
 
@@ -37,13 +49,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // Staging helpers as functions over array references (kept in registers; the same code written as lambdas over captured
 // uint4 arrays was placed in scratch memory by hipcc: 144 bytes per lane, every K-step through private memory).
-__device__ __forceinline__ void hb_load4(const bf16_t* __restrict__ base, const int64_t (&off)[4], int64_t k, u32x4 (&r)[4]) {
+template <int NJ>
+__device__ __forceinline__ void hb_load4(const bf16_t* __restrict__ base, const int64_t (&off)[NJ], int64_t k, u32x4 (&r)[NJ]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const u32x4*>(base + off[j] + k);
+    for (int j = 0; j < NJ; ++j) r[j] = *reinterpret_cast<const u32x4*>(base + off[j] + k);
 }
-__device__ __forceinline__ void hb_store4(bf16_t* __restrict__ dst, const int (&loff)[4], const u32x4 (&r)[4]) {
+template <int NJ>
+__device__ __forceinline__ void hb_store4(bf16_t* __restrict__ dst, const int (&loff)[NJ], const u32x4 (&r)[NJ]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(dst + loff[j]) = r[j];
+    for (int j = 0; j < NJ; ++j) *reinterpret_cast<u32x4*>(dst + loff[j]) = r[j];
 }
 
 struct GemmBf16Params {
@@ -116,12 +130,12 @@ __device__ __forceinline__ HbTile hb_locate(const GemmBf16Params& p, const int32
 }
 
 // epilogue of one tile from registers: lane = row (i*32 + r32), acc[i][j][4*g4 + e] = column j*32 + 8*g4 + 4*h + e
+// (wm, wn) = position of the 64 x 64 patch inside the workgroup tile, `interior` = the whole workgroup tile is in range
 template <int EPI, bool ACCUM>
 __device__ __forceinline__ void hb_epilogue(const GemmBf16Params& p, f32x16 (&acc)[2][2], const int row0, const int row_end,
                                             const int col0, const int col_end, const int wm, const int wn, const int r32,
-                                            const int h, const bool wave_live) {
+                                            const int h, const bool wave_live, const bool interior) {
     // ---- epilogue from registers: lane = row (i*32 + r32), acc[i][j][4*g4 + e] = column j*32 + 8*g4 + 4*h + e ----
-    const bool interior = (row0 + HB_BM <= row_end) && (col0 + HB_BN <= col_end);
     if (wave_live) {
         if (EPI == 1) {
             float* Cp = reinterpret_cast<float*>(p.C);
@@ -132,25 +146,28 @@ __device__ __forceinline__ void hb_epilogue(const GemmBf16Params& p, f32x16 (&ac
                     const int row = row0 + wm * 64 + i * 32 + r32;
                     const int64_t rc = p.row_map ? (int64_t)p.row_map[row] : (int64_t)row;
                     const int64_t e0 = rc * p.ldc + col0 + wn * 64 + 4 * h;
-                    float4 x[8];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < 2; ++j) {
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4)
-                            x[4 * j + g4] = *reinterpret_cast<const float4*>(p.resid + e0 + j * 32 + 8 * g4);
+                        for (int gp = 0; gp < 2; ++gp) {
+                            float4 x[2];                 // (two at a time: the 256 x 256 form has no registers for more)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                            for (int g2 = 0; g2 < 2; ++g2)
+                                x[g2] = *reinterpret_cast<const float4*>(p.resid + e0 + j * 32 + 8 * (2 * gp + g2));
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const int64_t e = e0 + j * 32 + 8 * g4;
-                            float m[4];
-                            rng.mult4((uint32_t)(e >> 2), m);
-                            const float4 xx = x[4 * j + g4];
-                            float4 o;
-                            o.x = xx.x + m[0] * acc[i][j][4 * g4 + 0]; o.y = xx.y + m[1] * acc[i][j][4 * g4 + 1];
-                            o.z = xx.z + m[2] * acc[i][j][4 * g4 + 2]; o.w = xx.w + m[3] * acc[i][j][4 * g4 + 3];
-                            *reinterpret_cast<float4*>(Cp + e) = o;
+                            for (int g2 = 0; g2 < 2; ++g2) {
+                                const int g4 = 2 * gp + g2;
+                                const int64_t e = e0 + j * 32 + 8 * g4;
+                                float m[4];
+                                rng.mult4((uint32_t)(e >> 2), m);
+                                const float4 xx = x[g2];
+                                float4 o;
+                                o.x = xx.x + m[0] * acc[i][j][4 * g4 + 0]; o.y = xx.y + m[1] * acc[i][j][4 * g4 + 1];
+                                o.z = xx.z + m[2] * acc[i][j][4 * g4 + 2]; o.w = xx.w + m[3] * acc[i][j][4 * g4 + 3];
+                                *reinterpret_cast<float4*>(Cp + e) = o;
+                            }
                         }
+                    }
                 }
             } else {
 #pragma unroll
@@ -242,7 +259,7 @@ __device__ __forceinline__ void hb_epilogue(const GemmBf16Params& p, f32x16 (&ac
 }
 
 template <int EPI, bool ACCUM>
-__global__ void __launch_bounds__(HB_THREADS, 2)
+__global__ void __launch_bounds__(HB_THREADS, HF_WGS)
 gemm_bf16_kernel(const GemmBf16Params p, const int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);           // buffer b: A image at 2*b*HB_TILE, B image behind it
@@ -259,7 +276,7 @@ gemm_bf16_kernel(const GemmBf16Params p, const int total_tiles) {
     const int per_xcd = (total_tiles + 7) >> 3;
     const int t_hi = min(total_tiles, (xcd + 1) * per_xcd);
     const int col_end = p.N;
-    const int nkt = p.K / HB_BK;                                  // K % 64 == 0 (checked on the host)
+    const int nkt = p.K / HF_BK;                                  // K % HF_BK == 0 (checked on the host)
     __shared__ int32_t s_offs[HB_MAX_GROUPS + 1];
     if (p.group_offsets && tid <= p.groups) s_offs[tid] = p.group_offsets[tid];
     __syncthreads();
@@ -277,19 +294,19 @@ gemm_bf16_kernel(const GemmBf16Params p, const int total_tiles) {
     };
     // chunk f = tid + 256 j of a tile: row f >> 3, 16-byte k-chunk f & 7.  Rows past the end are read from the last
     // valid row (their results are never stored), so there is no predicate anywhere in the loads.
-    int64_t oa[4], ob[4];
-    int lo[4];
+    int64_t oa[HF_NJ], ob[HF_NJ];
+    int lo[HF_NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < HF_NJ; ++j) {
         const int f = tid + HB_THREADS * j;
-        lo[j] = (f >> 3) * HB_LD + ((f & 7) << 3);
+        lo[j] = (f >> HF_CS) * HB_LD + ((f & (HF_CH - 1)) << 3);
     }
     auto offsets = [&](const HbTile& t) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < HF_NJ; ++j) {
             const int f = tid + HB_THREADS * j;
-            oa[j] = (int64_t)min(t.row0 + (f >> 3), t.row_end - 1) * p.lda + ((f & 7) << 3);
-            ob[j] = (int64_t)t.g * p.strideB + (int64_t)min(t.col0 + (f >> 3), col_end - 1) * p.ldb + ((f & 7) << 3);
+            oa[j] = (int64_t)min(t.row0 + (f >> HF_CS), t.row_end - 1) * p.lda + ((f & (HF_CH - 1)) << 3);
+            ob[j] = (int64_t)t.g * p.strideB + (int64_t)min(t.col0 + (f >> HF_CS), col_end - 1) * p.ldb + ((f & (HF_CH - 1)) << 3);
         }
     };
     // The (tile, K-step) pairs of this workgroup form ONE stream of steps; the operands of step s+2 are requested while
@@ -297,7 +314,7 @@ gemm_bf16_kernel(const GemmBf16Params p, const int total_tiles) {
     // K-steps of bf16 MFMA time, and with one step of prefetch every K-step waited for its operands (0.32 ms for the
     // q|k|v shape against 0.21 ms of HBM time).  Step s lives in LDS buffer s & 1; r0a / r0b carry even steps, r1a / r1b
     // odd ones.  The load side (ld, ld_kt) runs two steps ahead of the compute side (cur, kt) over the same tile list.
-    u32x4 r0a[4], r0b[4], r1a[4], r1b[4];
+    u32x4 r0a[HF_NJ], r0b[HF_NJ], r1a[HF_NJ], r1b[HF_NJ];
     int Lld = xcd * per_xcd + local;
     HbTile ld = next_valid(Lld);
     int ld_kt = 0;
@@ -309,8 +326,8 @@ gemm_bf16_kernel(const GemmBf16Params p, const int total_tiles) {
 #define HB_ISSUE(RA, RB)                                                                       \
     {                                                                                          \
         if (!(HB_ABLATE & 2)) {                                                                \
-        hb_load4(p.A, oa, (int64_t)ld_kt * HB_BK, RA);                                         \
-        hb_load4(p.B, ob, (int64_t)ld_kt * HB_BK, RB);                                         \
+        hb_load4(p.A, oa, (int64_t)ld_kt * HF_BK, RA);                                         \
+        hb_load4(p.B, ob, (int64_t)ld_kt * HF_BK, RB);                                         \
         }                                                                                      \
         if (ld.valid && ld_kt + 1 == nkt) {                                                    \
             Lld += nlocal;                                                                     \
@@ -346,7 +363,7 @@ gemm_bf16_kernel(const GemmBf16Params p, const int total_tiles) {
         if (wave_live && !(HB_ABLATE & 4)) {                                                                           \
             const bf16_t* as = smem + 2 * (BUF) * HB_TILE;                                                             \
             const bf16_t* bs = as + HB_TILE;                                                                           \
-            _Pragma("unroll") for (int s = 0; s < HB_BK / 16; ++s) {                                                   \
+            _Pragma("unroll") for (int s = 0; s < HF_BK / 16; ++s) {                                                   \
                 bf16x8 af[2], bf[2];                                                                                   \
                 _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
                     af[i] = *reinterpret_cast<const bf16x8*>(as + (wm * 64 + i * 32 + r32) * HB_LD + 16 * s + 8 * h);  \
@@ -361,10 +378,11 @@ gemm_bf16_kernel(const GemmBf16Params p, const int total_tiles) {
         if (!(HB_ABLATE & 8)) {                                                                                        \
         hb_store4(smem + 2 * ((BUF) ^ 1) * HB_TILE, lo, NA);       /* past the last step: a harmless re-store */       \
         hb_store4(smem + 2 * ((BUF) ^ 1) * HB_TILE + HB_TILE, lo, NB);                                                 \
-        } else { asm volatile("" :: "v"(NA[0]), "v"(NA[1]), "v"(NA[2]), "v"(NA[3]), "v"(NB[0]), "v"(NB[1]), "v"(NB[2]), "v"(NB[3])); } \
+        } else { asm volatile("" :: "v"(NA[0]), "v"(NA[1]), "v"(NB[0]), "v"(NB[1])); }                                 \
         if (tile_done) {                                                                                               \
             if (!(HB_ABLATE & 1) || acc[0][0][0] == 1.2345e-30f)                                                       \
-            hb_epilogue<EPI, ACCUM>(p, acc, cur.row0, cur.row_end, cur.col0, col_end, wm, wn, r32, h, wave_live);      \
+            hb_epilogue<EPI, ACCUM>(p, acc, cur.row0, cur.row_end, cur.col0, col_end, wm, wn, r32, h, wave_live,       \
+                                    (cur.row0 + HB_BM <= cur.row_end) && (cur.col0 + HB_BN <= col_end));               \
             if (!nxt.valid) break;                                                                                     \
             cur = nxt;                                                                                                 \
             Ln += nlocal;                                                                                              \
@@ -383,6 +401,164 @@ gemm_bf16_kernel(const GemmBf16Params p, const int total_tiles) {
     }
 #undef HB_STEP
 #undef HB_ISSUE
+}
+
+// =================================================================================================
+// 256 x 256 tile form of the same GEMM (plain bf16 store): 8 waves as 2 x 4, each a 128 x 64 patch (4 x 2 MFMA tiles,
+// 128 accumulator registers), one workgroup per CU, persistent.  Against the 128 x 128 form a K-step moves half the
+// operand bytes from L2 to LDS per MFMA and needs 0.75 LDS fragment reads per MFMA instead of 1.
+// =================================================================================================
+constexpr int HG_BM = 256, HG_BN = 256, HG_THREADS = 512;
+constexpr int HG_TILE = HG_BM * (HB_BK + 8);                   // elements per operand image (144-byte rows)
+constexpr int HG_LDS_BYTES = 4 * HG_TILE * 2;                  // 147,456 B
+
+template <int EPI, bool ACCUM>
+__global__ void __launch_bounds__(HG_THREADS, 1)
+gemm_bf16_big_kernel(const GemmBf16Params p, const int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    constexpr int LD = HB_BK + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nlocal = (int)gridDim.x >> 3;
+    const int per_xcd = (total_tiles + 7) >> 3;
+    const int t_hi = min(total_tiles, (xcd + 1) * per_xcd);
+    const int nkt = p.K / HB_BK;
+    __shared__ int32_t s_offs[HB_MAX_GROUPS + 1];
+    if (p.group_offsets && tid <= p.groups) s_offs[tid] = p.group_offsets[tid];
+    __syncthreads();
+    auto locate = [&](int L) {
+        HbTile t;
+        const int mt = L / p.n_tiles;
+        t.col0 = (L % p.n_tiles) * HG_BN;
+        t.g = 0;
+        int seg_beg = 0, seg_end = p.M, tiles_before = 0;
+        bool found = false;
+        if (p.group_offsets) {
+            int prev = s_offs[0];
+            for (int gi = 0; gi < p.groups; ++gi) {
+                const int nxt = s_offs[gi + 1];
+                const int tiles = (nxt - prev + HG_BM - 1) / HG_BM;
+                if (!found && mt < tiles_before + tiles) { t.g = gi; seg_beg = prev; seg_end = nxt; found = true; }
+                if (!found) tiles_before += tiles;
+                prev = nxt;
+            }
+        } else {
+            found = mt < (p.M + HG_BM - 1) / HG_BM;
+        }
+        t.valid = found;
+        t.row0 = seg_beg + (mt - tiles_before) * HG_BM;
+        t.row_end = seg_end;
+        return t;
+    };
+    auto next_valid = [&](int& L) {
+        HbTile t;
+        t.valid = false;
+        while (L < t_hi) {
+            t = locate(L);
+            if (t.valid) break;
+            L += nlocal;
+        }
+        if (L >= t_hi) t.valid = false;
+        return t;
+    };
+    int64_t oa[4], ob[4];
+    int lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = tid + HG_THREADS * j;
+        lo[j] = (f >> 3) * LD + ((f & 7) << 3);
+    }
+    auto offsets = [&](const HbTile& t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + HG_THREADS * j;
+            oa[j] = (int64_t)min(t.row0 + (f >> 3), t.row_end - 1) * p.lda + ((f & 7) << 3);
+            ob[j] = (int64_t)t.g * p.strideB + (int64_t)min(t.col0 + (f >> 3), p.N - 1) * p.ldb + ((f & 7) << 3);
+        }
+    };
+    u32x4 ra[4], rb[4];
+    int Lld = xcd * per_xcd + local;
+    HbTile ld = next_valid(Lld);
+    int ld_kt = 0;
+    if (!ld.valid || nkt == 0) return;
+    offsets(ld);
+    auto issue = [&]() {
+        hb_load4(p.A, oa, (int64_t)ld_kt * HB_BK, ra);
+        hb_load4(p.B, ob, (int64_t)ld_kt * HB_BK, rb);
+        if (ld.valid && ld_kt + 1 == nkt) {
+            Lld += nlocal;
+            ld = next_valid(Lld);
+            if (ld.valid) { offsets(ld); ld_kt = 0; }
+        } else if (ld.valid) {
+            ++ld_kt;
+        }
+    };
+    int Lc = Lld;
+    HbTile cur = ld;
+    issue();
+    hb_store4(smem, lo, ra);
+    hb_store4(smem + HG_TILE, lo, rb);
+    __syncthreads();
+    int Ln = Lc + nlocal;
+    HbTile nxt = next_valid(Ln);
+    int kt = 0, buf = 0;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    while (true) {
+        issue();
+        {
+            const bf16_t* as = smem + 2 * buf * HG_TILE;
+            const bf16_t* bs = as + HG_TILE;
+#pragma unroll
+            for (int s = 0; s < HB_BK / 16; ++s) {
+                bf16x8 af[4], bf[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8*>(as + (wm * 128 + i * 32 + r32) * LD + 16 * s + 8 * h);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    bf[j] = *reinterpret_cast<const bf16x8*>(bs + (wn * 64 + j * 32 + r32) * LD + 16 * s + 8 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        const bool tile_done = ++kt == nkt;
+        hb_store4(smem + 2 * (buf ^ 1) * HG_TILE, lo, ra);
+        hb_store4(smem + 2 * (buf ^ 1) * HG_TILE + HG_TILE, lo, rb);
+        if (tile_done) {
+            // the 128 x 64 patch of the wave = two 64 x 64 patches of the common epilogue
+            const bool interior = (cur.row0 + HG_BM <= cur.row_end) && (cur.col0 + HG_BN <= p.N);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const bool live = (cur.row0 + wm * 128 + half * 64 < cur.row_end) && (cur.col0 + wn * 64 < p.N);
+                hb_epilogue<EPI, ACCUM>(p, reinterpret_cast<f32x16(&)[2][2]>(acc[2 * half]), cur.row0, cur.row_end, cur.col0, p.N,
+                                        2 * wm + half, wn, r32, h, live, interior);
+            }
+            if (!nxt.valid) break;
+            cur = nxt;
+            Ln += nlocal;
+            nxt = next_valid(Ln);
+            kt = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        buf ^= 1;
+        __syncthreads();
+    }
 }
 
 // =================================================================================================
@@ -600,11 +776,28 @@ static int launch_hb(const GemmBf16Params& p, int tiles, hipStream_t st) {
         if (e != hipSuccess) { set_error("gamer_gemm_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         attr = true;
     }
-    // two workgroups per CU x 256 CUs, in multiples of 8 (one share per XCD); small problems: one workgroup per tile
-    int blocks = 512;
+    // HF_WGS workgroups per CU x 256 CUs, in multiples of 8 (one share per XCD); small problems: one workgroup per tile
+    int blocks = 256 * HF_WGS;
     if (tiles < blocks) blocks = ((tiles + 7) / 8) * 8;
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(HB_THREADS), HB_LDS_BYTES, st, p, tiles);
     GAMER_CHECK_LAUNCH("gamer_gemm_bf16");
+    return 0;
+}
+
+template <int EPI, bool ACCUM>
+static int launch_big(const GemmBf16Params& p, int tiles, hipStream_t st) {
+    static bool attr = false;
+    auto kfn = gemm_bf16_big_kernel<EPI, ACCUM>;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           HG_LDS_BYTES);
+        if (e != hipSuccess) { set_error("gamer_gemm_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        attr = true;
+    }
+    int blocks = 256;                                   // one workgroup per CU, in multiples of 8 (one share per XCD)
+    if (tiles < blocks) blocks = ((tiles + 7) / 8) * 8;
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(HG_THREADS), HG_LDS_BYTES, st, p, tiles);
+    GAMER_CHECK_LAUNCH("gamer_gemm_bf16/256");
     return 0;
 }
 
@@ -631,7 +824,7 @@ extern "C" int gamer_gemm_bf16(const gamer_gemm_bf16_desc* d, void* stream) {
     p.n_tiles = (d->N + HB_BN - 1) / HB_BN;
     hipStream_t st = (hipStream_t)stream;
     if (d->group_mode == 0) {
-        GAMER_CHECK_ARG(d->K % HB_BK == 0 && d->lda >= d->K && d->ldb >= d->K,
+        GAMER_CHECK_ARG(d->K % 64 == 0 && d->lda >= d->K && d->ldb >= d->K,
                         "gamer_gemm_bf16: the K-contiguous form needs K %% 64 == 0 (K=%d) and lda, ldb >= K", d->K);
         GAMER_CHECK_ARG(d->ldc >= d->N && d->strideB % 8 == 0, "gamer_gemm_bf16: ldc=%lld < N or strideB %% 8 != 0", (long long)d->ldc);
         GAMER_CHECK_ARG(!d->resid || (!d->accumulate && !d->rowdot_out && d->ldc % 4 == 0 && aligned16(d->resid) &&
@@ -645,6 +838,21 @@ extern "C" int gamer_gemm_bf16(const gamer_gemm_bf16_desc* d, void* stream) {
         p.m_tiles = (d->M + HB_BM - 1) / HB_BM + (d->group_offsets ? d->groups : 0);
         const int64_t blocks = (int64_t)p.m_tiles * p.n_tiles;
         GAMER_CHECK_ARG(blocks < (1LL << 31), "gamer_gemm_bf16: grid too large");
+        static int big = -1;
+        if (big < 0) { const char* e = getenv("GAMER_GEMM_BF16_BIG"); big = (e && e[0] == '0') ? 0 : 1; }
+        // 256 x 256 tiles when they are well filled: at least 3/4 of the last column tile in use (N = 320 stays with
+        // 128 x 128: 3 tiles of 128 waste less than 2 of 256) and enough row tiles to give every CU work
+        const int rem = d->N % HG_BN;
+        // (the fp32 residual and the row-dot epilogues measured 3-15 % slower in this form - their epilogues need the
+        // registers the 128 accumulators take - and stay with 128 x 128)
+        if (big && (rem == 0 || rem >= 3 * HG_BN / 4 || d->N >= 4 * HG_BN) && d->M >= 16 * HG_BM && !d->resid && !d->rowdot_out) {
+            GemmBf16Params q = p;
+            q.n_tiles = (d->N + HG_BN - 1) / HG_BN;
+            q.m_tiles = (d->M + HG_BM - 1) / HG_BM + (d->group_offsets ? d->groups : 0);
+            const int tiles = q.m_tiles * q.n_tiles;
+            if (d->accumulate) return launch_big<0, true>(q, tiles, st);
+            return launch_big<0, false>(q, tiles, st);
+        }
         if (d->resid) return launch_hb<1, false>(p, (int)blocks, st);
         if (d->rowdot_out) return launch_hb<2, false>(p, (int)blocks, st);
         if (d->accumulate) return launch_hb<0, true>(p, (int)blocks, st);

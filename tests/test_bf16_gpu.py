@@ -51,6 +51,30 @@ def test_gemm_bf16_forward_exact(M, N, K, ldc, accumulate):
     assert torch.equal(c.cpu()[:, N:].float(), C0[:, N:].to(BF).float()), "columns past N must stay untouched"
 
 
+@pytest.mark.parametrize("M,N,K,ldc", [(4096, 256, 64, 256), (4196, 512, 256, 520), (8192 + 77, 768, 128, 768)])
+def test_gemm_bf16_forward_exact_256_tile_form(M, N, K, ldc):
+    """M >= 4096 and N % 256 == 0 take the 256 x 256 tile kernel (ragged last row tile, ldc > N, several tiles per
+    workgroup); plus the row-segmented (expert) form with an empty and ragged segments."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B = ints((M, K), g), ints((N, K), g)
+    B = B + torch.arange(N)[:, None] % 3
+    C0 = ints((M, ldc), g, -2, 3)
+    c = dev(C0.to(BF))
+    ops.gemm(dev(A.to(BF)), K, 1, dev(B.to(BF)), K, 1, c, ldc, M, N, K)
+    ref = A.double() @ B.double().T
+    assert torch.equal(c.cpu()[:, :N].float(), ref.to(BF).float())
+    assert torch.equal(c.cpu()[:, N:].float(), C0[:, N:].to(BF).float()), "columns past N must stay untouched"
+    if N == 512:
+        E = 6
+        seg = [0, 700, 700, 1725, 2000, 3300, M]
+        W = ints((E * N, K), g)
+        cg = torch.full((M, N), 7.0, dtype=BF, device=DEV)
+        ops.gemm(dev(A.to(BF)), K, 1, dev(W.to(BF)), K, 1, cg, N, M, N, K, groups=E,
+                 group_offsets=dev(torch.tensor(seg, dtype=torch.int32)), strideB=N * K)
+        refg = torch.cat([A[seg[e]:seg[e + 1]].double() @ W[e * N:(e + 1) * N].double().T for e in range(E)])
+        assert torch.equal(cg.cpu().float(), refg.to(BF).float())
+
+
 def test_gemm_bf16_grouped_rows():
     g = torch.Generator().manual_seed(3)
     K, N, E = 256, 256, 6
