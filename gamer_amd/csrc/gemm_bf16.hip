@@ -562,6 +562,208 @@ gemm_bf16_big_kernel(const GemmBf16Params p, const int total_tiles) {
 }
 
 // =================================================================================================
+// Wave-specialised form (plain bf16 store / +=): 256 x 128 tiles, EIGHT waves per workgroup, one workgroup per CU.
+//   waves 4-7 (loaders): fetch the operand tiles with LDS-DMA (global_load_lds_dwordx4: no destination registers, no
+//       ds_write pass) into a ring of three 48-KB stages, two K-steps ahead of the multiply, and never store;
+//   waves 0-3 (compute): 64 x 128 patch each (2 x 4 MFMA tiles, 128 accumulator registers), fragments by ds_read_b128,
+//       and the epilogue's global stores - and never load an operand from global memory.
+// Why: a wave's memory operations retire in order, so a wave that stores a C tile and then loads the next operands waits
+// for the store acknowledgements (~6 us per 256 x 256 tile at one workgroup per CU) before its loads count as done; in
+// the one-role kernels the load, multiply and store phases of a workgroup therefore ADD (tools/ablate_gemm.sh).  Here the
+// stores of the compute waves are fire-and-forget and the loader's only wait is a counted vmcnt for its own loads.
+// LDS image: rows of 128 bytes (64 bf16) as they lie in memory, 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7)
+// - the permutation is applied on the SOURCE address of the LDS-DMA (its destination is lane-linear) and again in the
+// fragment reads, which are conflict-free.  One raw s_barrier per K-step for all eight waves.
+// =================================================================================================
+constexpr int WS_BM = 256, WS_BN = 128, WS_LOADERS = 4, WS_THREADS = 256 + 64 * WS_LOADERS, WS_STAGES = 3;
+constexpr int WS_A_BYTES = WS_BM * 128, WS_B_BYTES = WS_BN * 128, WS_STAGE = WS_A_BYTES + WS_B_BYTES;     // 49,152
+constexpr int WS_GLDS = WS_STAGE / 1024 / WS_LOADERS;                 // LDS-DMA instructions per stage and loader wave (12)
+static_assert(2 * WS_GLDS < 64, "a wave cannot have more than 63 memory operations in flight (6-bit vmcnt)");
+constexpr int WS_LDS_BYTES = WS_STAGES * WS_STAGE + 512;              // + the segment offsets
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <bool ACCUM>
+__global__ void __launch_bounds__(WS_THREADS, 1)
+gemm_bf16_ws_kernel(const GemmBf16Params p, const int total_tiles) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    unsigned char* smem = smem_raw;
+    int32_t* s_offs = reinterpret_cast<int32_t*>(smem + WS_STAGES * WS_STAGE);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, nlocal = (int)gridDim.x >> 3;
+    const int per_xcd = (total_tiles + 7) >> 3;
+    const int t_hi = min(total_tiles, (xcd + 1) * per_xcd);
+    const int nkt = p.K / HB_BK;
+    if (p.group_offsets && tid <= p.groups) s_offs[tid] = p.group_offsets[tid];
+    __syncthreads();
+    auto locate = [&](int L) {
+        HbTile t;
+        const int mt = L / p.n_tiles;
+        t.col0 = (L % p.n_tiles) * WS_BN;
+        t.g = 0;
+        int seg_beg = 0, seg_end = p.M, tiles_before = 0;
+        bool found = false;
+        if (p.group_offsets) {
+            int prev = s_offs[0];
+            for (int gi = 0; gi < p.groups; ++gi) {
+                const int nxt = s_offs[gi + 1];
+                const int tiles = (nxt - prev + WS_BM - 1) / WS_BM;
+                if (!found && mt < tiles_before + tiles) { t.g = gi; seg_beg = prev; seg_end = nxt; found = true; }
+                if (!found) tiles_before += tiles;
+                prev = nxt;
+            }
+        } else {
+            found = mt < (p.M + WS_BM - 1) / WS_BM;
+        }
+        t.valid = found;
+        t.row0 = seg_beg + (mt - tiles_before) * WS_BM;
+        t.row_end = seg_end;
+        return t;
+    };
+    auto next_valid = [&](int& L) {
+        HbTile t;
+        t.valid = false;
+        while (L < t_hi) {
+            t = locate(L);
+            if (t.valid) break;
+            L += nlocal;
+        }
+        if (L >= t_hi) t.valid = false;
+        return t;
+    };
+    // both roles walk the same list of tiles; the number of K-steps of this workgroup fixes the barrier count
+    int n_steps = 0;
+    {
+        int L = xcd * per_xcd + local;
+        for (HbTile t = next_valid(L); t.valid; L += nlocal, t = next_valid(L)) n_steps += nkt;
+    }
+    if (n_steps == 0) return;
+
+    if (wid >= 4) {
+        // ------------------------------------------------ loaders ------------------------------------------------
+        // piece g of the A image = rows 8g .. 8g+7 (1 KiB), lane -> row 8g + (lane >> 3), stored chunk lane & 7, which
+        // holds the memory chunk (lane & 7) ^ ((row >> 1) & 7); B likewise.  Loader q takes the pieces g = q (mod 4): with
+        // one loader the 6-bit vmcnt (63 operations in flight per wave) would cap the ring at 63 KB in flight per CU.
+        constexpr int NA = WS_A_BYTES / 1024 / WS_LOADERS, NB = WS_B_BYTES / 1024 / WS_LOADERS;
+        const int lq = wid - 4;
+        const bf16_t* pa[NA];
+        const bf16_t* pb[NB];
+        int Lld = xcd * per_xcd + local;
+        HbTile ld = next_valid(Lld);
+        int ld_kt = 0;
+        auto set_tile = [&](const HbTile& t) {
+#pragma unroll
+            for (int g = 0; g < NA; ++g) {
+                const int row = 8 * (WS_LOADERS * g + lq) + (lane >> 3);
+                const int c = (lane & 7) ^ ((row >> 1) & 7);
+                pa[g] = p.A + (int64_t)min(t.row0 + row, t.row_end - 1) * p.lda + 8 * c;
+            }
+#pragma unroll
+            for (int g = 0; g < NB; ++g) {
+                const int col = 8 * (WS_LOADERS * g + lq) + (lane >> 3);
+                const int c = (lane & 7) ^ ((col >> 1) & 7);
+                pb[g] = p.B + (int64_t)t.g * p.strideB + (int64_t)min(t.col0 + col, p.N - 1) * p.ldb + 8 * c;
+            }
+        };
+        set_tile(ld);
+        auto issue_stage = [&](int buf) -> bool {
+            if (!ld.valid) return false;
+            unsigned char* dst = smem + buf * WS_STAGE + lq * 1024;
+            const int64_t kof = (int64_t)ld_kt * HB_BK;
+            if (!(HB_ABLATE & 2))
+#pragma unroll
+            for (int g = 0; g < NA; ++g)
+                __builtin_amdgcn_global_load_lds((gptr_t)(pa[g] + kof), (lptr_t)(dst + g * WS_LOADERS * 1024), 16, 0, 0);
+            if (!(HB_ABLATE & 2))
+#pragma unroll
+            for (int g = 0; g < NB; ++g)
+                __builtin_amdgcn_global_load_lds((gptr_t)(pb[g] + kof), (lptr_t)(dst + WS_A_BYTES + g * WS_LOADERS * 1024), 16, 0, 0);
+            if (++ld_kt == nkt) {
+                ld_kt = 0;
+                Lld += nlocal;
+                ld = next_valid(Lld);
+                if (ld.valid) set_tile(ld);
+            }
+            return true;
+        };
+        issue_stage(0);
+        const bool two = issue_stage(1);
+        // stage 0 has landed when at most this wave's 12 pieces of stage 1 are still in flight
+        static_assert(WS_GLDS == 12, "the counted waits below are written for 12 pieces per stage and loader");
+        if (two) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int s = 0; s < n_steps; ++s) {
+            // the compute waves multiply stage s; the buffer of stage s+2 was read in step s-1, which the last barrier ended
+            const bool have = issue_stage((s + 2) % WS_STAGES);
+            if (have) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");      // stage s+1 has landed
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        return;
+    }
+    // ---------------------------------------------------- compute ----------------------------------------------------
+    const int r32 = lane & 31, h = lane >> 5;
+    int Lc = xcd * per_xcd + local;
+    HbTile cur = next_valid(Lc);
+    int kt = 0;
+    f32x16 acc[2][2][2];                       // [column half][i][jj]: two 64 x 64 patches of the common epilogue
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
+    const int swz = (r32 >> 1) & 7;
+    int coff[HB_BK / 16];
+#pragma unroll
+    for (int s = 0; s < HB_BK / 16; ++s) coff[s] = ((2 * s + h) ^ swz) << 4;
+    const int a_row = (wid * 64 + r32) * 128;
+    const int b_row = WS_A_BYTES + r32 * 128;
+    asm volatile("s_barrier" ::: "memory");
+    for (int s = 0; s < n_steps; ++s) {
+        const unsigned char* st = smem + (s % WS_STAGES) * WS_STAGE;
+#pragma unroll
+        for (int kb = 0; kb < ((HB_ABLATE & 4) ? 0 : HB_BK / 16); ++kb) {
+            bf16x8 af[2], bf[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_row + i * 32 * 128 + coff[kb]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(st + b_row + j * 32 * 128 + coff[kb]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j >> 1][i][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[j >> 1][i][j & 1], 0, 0, 0);
+        }
+        if (++kt == nkt) {
+            // (holding the rounded tile in 64 registers and storing a quarter of it with every K-step of the next tile
+            // was measured too: 0.451 against 0.407 ms on the q|k|v shape - the burst is not what costs)
+            const bool interior = (cur.row0 + WS_BM <= cur.row_end) && (cur.col0 + WS_BN <= p.N);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if ((HB_ABLATE & 1) && acc[a][0][0][0] != 1.2345e-30f) continue;
+                const bool live = (cur.row0 + wid * 64 < cur.row_end) && (cur.col0 + a * 64 < p.N);
+                hb_epilogue<0, ACCUM>(p, acc[a], cur.row0, cur.row_end, cur.col0, p.N, wid, a, r32, h, live, interior);
+            }
+            Lc += nlocal;
+            cur = next_valid(Lc);
+            kt = 0;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[a][i][j][r] = 0.f;
+        }
+        asm volatile("s_barrier" ::: "memory");
+    }
+}
+
+// =================================================================================================
 // wgrad: contraction over tokens, both operands token-major
 // =================================================================================================
 // chunk c (16 bytes = 8 columns) of token row t lives at physical chunk c ^ ((t & 3) << 2) of its 256-byte LDS row
@@ -784,6 +986,23 @@ static int launch_hb(const GemmBf16Params& p, int tiles, hipStream_t st) {
     return 0;
 }
 
+template <bool ACCUM>
+static int launch_ws(const GemmBf16Params& p, int tiles, hipStream_t st) {
+    static bool attr = false;
+    auto kfn = gemm_bf16_ws_kernel<ACCUM>;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           WS_LDS_BYTES);
+        if (e != hipSuccess) { set_error("gamer_gemm_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        attr = true;
+    }
+    int blocks = 256;                                   // one workgroup per CU, in multiples of 8 (one share per XCD)
+    if (tiles < blocks) blocks = ((tiles + 7) / 8) * 8;
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(WS_THREADS), WS_LDS_BYTES, st, p, tiles);
+    GAMER_CHECK_LAUNCH("gamer_gemm_bf16/ws");
+    return 0;
+}
+
 template <int EPI, bool ACCUM>
 static int launch_big(const GemmBf16Params& p, int tiles, hipStream_t st) {
     static bool attr = false;
@@ -839,13 +1058,25 @@ extern "C" int gamer_gemm_bf16(const gamer_gemm_bf16_desc* d, void* stream) {
         const int64_t blocks = (int64_t)p.m_tiles * p.n_tiles;
         GAMER_CHECK_ARG(blocks < (1LL << 31), "gamer_gemm_bf16: grid too large");
         static int big = -1;
-        if (big < 0) { const char* e = getenv("GAMER_GEMM_BF16_BIG"); big = (e && e[0] == '0') ? 0 : 1; }
-        // 256 x 256 tiles when they are well filled: at least 3/4 of the last column tile in use (N = 320 stays with
-        // 128 x 128: 3 tiles of 128 waste less than 2 of 256) and enough row tiles to give every CU work
+        // 0: 128^2 only; 1 (default): 256^2 where its last column tile is well filled, else the wave-specialised 256 x 128
+        // form (N = 320: 0.321 against 0.345 ms), else 128^2; 2: wave-specialised wherever it applies.  Measured per shape
+        // with tools/kbench_bf16.py; the vendor library (torch.mm, tools/vendor_gemm.py) is within +-8 % of the best of
+        // these on every shape except the head forward (0.755 ms there, 0.55 here).
+        if (big < 0) { const char* e = getenv("GAMER_GEMM_BF16_BIG"); big = e ? atoi(e) : 1; }
         const int rem = d->N % HG_BN;
-        // (the fp32 residual and the row-dot epilogues measured 3-15 % slower in this form - their epilogues need the
-        // registers the 128 accumulators take - and stay with 128 x 128)
-        if (big && (rem == 0 || rem >= 3 * HG_BN / 4 || d->N >= 4 * HG_BN) && d->M >= 16 * HG_BM && !d->resid && !d->rowdot_out) {
+        const bool big_ok = (rem == 0 || rem >= 3 * HG_BN / 4 || d->N >= 4 * HG_BN) && d->M >= 16 * HG_BM && !d->resid && !d->rowdot_out;
+        if ((big == 2 || (big == 1 && !big_ok)) && d->M >= 16 * WS_BM && !d->resid && !d->rowdot_out) {
+            GemmBf16Params q = p;
+            q.n_tiles = (d->N + WS_BN - 1) / WS_BN;
+            q.m_tiles = (d->M + WS_BM - 1) / WS_BM + (d->group_offsets ? d->groups : 0);
+            const int tiles = q.m_tiles * q.n_tiles;
+            if (d->accumulate) return launch_ws<true>(q, tiles, st);
+            return launch_ws<false>(q, tiles, st);
+        }
+        // 256 x 256 tiles when they are well filled: at least 3/4 of the last column tile in use and enough row tiles to give
+        // every CU work (the fp32 residual and the row-dot epilogues measured 3-15 % slower in this form - their epilogues
+        // need the registers the 128 accumulators take - and stay with 128 x 128)
+        if (big == 1 && big_ok) {
             GemmBf16Params q = p;
             q.n_tiles = (d->N + HG_BN - 1) / HG_BN;
             q.m_tiles = (d->M + HG_BM - 1) / HG_BM + (d->group_offsets ? d->groups : 0);
