@@ -189,7 +189,9 @@ def gemm_mode(request):
     ops.set_f32_matmul(prev)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 384, 256), (1000, 1041, 256), (257, 256, 1041), (128, 128, 32), (64, 40, 96)])
+# (M >= 4096 with well-filled 256-column tiles: the bf16-piece forms take their 256 x 256 tile kernel there)
+@pytest.mark.parametrize("M,N,K", [(300, 384, 256), (1000, 1041, 256), (257, 256, 1041), (128, 128, 32), (64, 40, 96),
+                                   (4173, 256, 512), (4096, 1041, 256)])
 def test_gemm_linear_fwd_and_dgrad(M, N, K, gemm_mode):
     ldx, ldw, ldy = (K + 3) // 4 * 4 + 8, (K + 3) // 4 * 4, (N + 3) // 4 * 4 + 4
     x = torch.zeros(M, ldx); x[:, :K] = torch.randn(M, K)
@@ -215,10 +217,11 @@ def test_gemm_linear_fwd_and_dgrad(M, N, K, gemm_mode):
     assert _rel(dx.cpu()[:, :K], 2 * refd) < 2e-6
 
 
-def test_gemm_rowdot_epilogue(gemm_mode):
+@pytest.mark.parametrize("B", [6, 64])
+def test_gemm_rowdot_epilogue(gemm_mode, B):
     """dgrad layout with the row-dot epilogue: C as without it, and out[b][head][i] = C[m, head] . other[m, head]
     (flash attention's delta from the o_proj dgrad)."""
-    S, B, heads, K = 64, 6, 4, 96
+    S, heads, K = 64, 4, 96
     M, N = B * S, heads * 64
     dy, W, other = torch.randn(M, K), torch.randn(K, N), torch.randn(M, N)
     ref = dy.double() @ W.double()
@@ -232,7 +235,7 @@ def test_gemm_rowdot_epilogue(gemm_mode):
         ops.linear_dgrad(dev(dy[:100]), K, dev(W), N, dx[:100], N, 100, K, N, rowdot=(dev(other[:100]), out, 50))
 
 
-@pytest.mark.parametrize("rows,N,K", [(5000, 384, 256), (777, 1041, 256), (4100, 512, 320)])
+@pytest.mark.parametrize("rows,N,K", [(5000, 384, 256), (777, 1041, 256), (4100, 512, 320), (4500, 256, 512), (4200, 1041, 256)])
 def test_gemm_wgrad_splitk(rows, N, K, gemm_mode):
     ldy, ldx = (N + 3) // 4 * 4, K
     dy = torch.zeros(rows, ldy); dy[:, :N] = torch.randn(rows, N)
@@ -245,11 +248,12 @@ def test_gemm_wgrad_splitk(rows, N, K, gemm_mode):
     assert e < 5e-6
 
 
+@pytest.mark.parametrize("T", [1000, 4224])
 @pytest.mark.parametrize("p_drop", [0.0, 0.2])
-def test_gemm_fused_residual_epilogue(p_drop, gemm_mode):
+def test_gemm_fused_residual_epilogue(p_drop, gemm_mode, T):
     """C[map(m)] = resid[map(m)] + dropout(x W^T): same values and the same mask as GEMM followed by the
     stand-alone residual kernel (plain and expert-grouped with the sorted-slot -> token map)."""
-    T, N, K, seed = 1000, 256, 384, 4242
+    N, K, seed = 256, 384, 4242
     x, W, resid = torch.randn(T, K), torch.randn(N, K) * 0.1, torch.randn(T, N)
     y = torch.empty(T, N, device=DEV)
     ops.linear_fwd(dev(x), K, dev(W), K, y, N, T, N, K)
@@ -260,7 +264,7 @@ def test_gemm_fused_residual_epilogue(p_drop, gemm_mode):
     assert float((out - ref).abs().max()) < 1e-5
     # grouped + row map (the expert down projection): rows in sorted order, output scattered to tokens
     E, I = 6, 512
-    sizes = [0, 300, 129, 1, 300, 270]
+    sizes = [0, 300, 129, 1, 300, 270] if T == 1000 else [0, 1300, 129, 1, 1524, 1270]
     offs = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32)
     perm = torch.randperm(T).int()                   # sorted slot -> token
     slot = torch.empty(T, dtype=torch.int32); slot[perm.long()] = torch.arange(T, dtype=torch.int32)
@@ -275,9 +279,10 @@ def test_gemm_fused_residual_epilogue(p_drop, gemm_mode):
     assert float((out2 - ref2).abs().max()) < 1e-5
 
 
-def test_gemm_grouped_experts(gemm_mode):
+@pytest.mark.parametrize("scale", [1, 5])
+def test_gemm_grouped_experts(gemm_mode, scale):
     E, Din, I = 6, 320, 512
-    sizes = [0, 700, 129, 1, 300, 128]              # an empty expert, ragged and exact tiles
+    sizes = [scale * n for n in [0, 700, 129, 1, 300, 128]]     # an empty expert, ragged and exact tiles
     T = sum(sizes)
     offs = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32)
     x = torch.randn(T, Din)
