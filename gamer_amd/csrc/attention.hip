@@ -476,7 +476,13 @@ attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ 
     for (int it = 0;; ++it) {
         const int pair = wl.pair_at(it);
         if (pair >= wl.n_pairs) break;
-        const int heavy = n_tiles - 1 - wl.u, light = wl.u;       // later query tiles see more keys
+        // With the row order the tiles of a sequence are NOT a causal ramp (normal rows first: short key ranges, then the
+        // empty rows: all S keys, one product), so "tile u + tile n-1-u" is not equal work for every u: u = 0 pairs a
+        // short tile with a long one, the middle u two long ones.  The workgroups that share a pair still cover every u in
+        // every round, but each takes a different u from round to round: over its ~24 pairs every workgroup sees the mix.
+        const int halves = (n_tiles + 1) >> 1;
+        const int uu = ORD ? (wl.u + it) % halves : wl.u;
+        const int heavy = n_tiles - 1 - uu, light = uu;           // later query tiles see more keys
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {                    // one inlined body (register pressure)
             if (pass == 1 && light == heavy) break;
