@@ -86,8 +86,8 @@ _SIGNATURES = {
     "gamer_gemm_f32_split": [C.POINTER(GemmDesc), c_int, P],
     "gamer_gemm_bf16": [C.POINTER(GemmBf16Desc), P],
     "gamer_cast_params_bf16": [P, P, P, P, I, I, P],
-    "gamer_attn_fwd_bf16": [P, I, P, I, P, I, P, P, I, I, I, I, F, F, U, P, P, P, P],
-    "gamer_attn_bwd_bf16": [P, I, P, I, P, I, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, I, P],
+    "gamer_attn_fwd_bf16": [P, I, P, I, P, I, P, P, I, I, I, I, F, F, U, P, P, P, P, P, P, P],
+    "gamer_attn_bwd_bf16": [P, I, P, I, P, I, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, I, P, P, P, P],
     "gamer_session_spans": [P, P, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P],
     "gamer_qknorm_rope_fwd": [P, I, I, I, I, P, P, F, P, P, P, P, P, P, P, P, P, P],
     "gamer_qknorm_rope_bwd": [P, P, P, I, I, I, I, P, P, F, P, P, P, P, P, I, P, P, P, P, P, P, P, P, L, P],

@@ -58,6 +58,17 @@ struct QuerySpanB {
     }
 };
 
+// Optional query-row order (behaviour-level "cross" attention; the fp32 kernels' RowOrder): the rows of every sequence
+// are visited through `perm` (sorted slot -> position: rows with an allowed key first, ascending; rows without one -
+// "empty" rows, whose bf16 output and gradient are 0 - behind them), so that the tiles behind the last normal row of a
+// sequence cost nothing and no tile mixes a short key range with dead rows.  `tile_maxpos[b][t]` = largest position of
+// a normal row in the 32-slot tile t, -1 if it has none; `row_empty[b][position]` != 0 marks the empty rows.
+struct QOrdB {
+    const int32_t* perm;
+    const int32_t* tile_maxpos;
+    const int32_t* row_empty;
+};
+
 // persistent workgroups walking equal-work (heavy tile + light tile) items; see attention.hip for the measurements
 struct WorkListB {
     int xcd, pair_slot, u, pairs_per_round, n_pairs, n_tiles;
@@ -183,12 +194,12 @@ __device__ __forceinline__ void read_key_quads_b(const int32_t* __restrict__ bas
 // =============================================================================================
 // forward
 // =============================================================================================
-template <int G, bool DROP, bool SPAN>
+template <int G, bool DROP, bool SPAN, bool ORD>
 __device__ __forceinline__ void
 attn_fwd_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                 const bf16_t* __restrict__ v, int ldv, const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                 int S, int nq, int nkv, float scale, float p_drop, uint64_t seed, bf16_t* __restrict__ o,
-                float* __restrict__ lse, const int32_t* __restrict__ span, const int pair, const int qtile) {
+                float* __restrict__ lse, const int32_t* __restrict__ span, const QOrdB ord, const int pair, const int qtile) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
     __shared__ __attribute__((aligned(16))) bf16_t Ks[2][64 * 64];
@@ -201,9 +212,9 @@ attn_fwd_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict_
     const int head = kvh * G + hg;
     const int r = lane & 31, h = lane >> 5;
     const LdsOffsets lo(lane);
-    const int iq = q0 + sub * 32 + r;
+    const int iq = q0 + sub * 32 + r;                 // sorted slot (= position without a row order)
     const bool valid_q = iq < S;
-    const int iqc = valid_q ? iq : S - 1;
+    const int iqc = ORD ? ord.perm[(int64_t)b * S + (valid_q ? iq : S - 1)] : (valid_q ? iq : S - 1);
     const int64_t tok = (int64_t)b * S + iqc;
 
     bf16x8 qf[4];
@@ -213,13 +224,22 @@ attn_fwd_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict_
         for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + 16 * s);
     }
     const int my_ql = ql ? ql[tok] : 1;
-    const QuerySpanB sp = QuerySpanB::load<SPAN>(span, tok, iqc, valid_q);
+    QuerySpanB sp = QuerySpanB::load<SPAN>(span, tok, iqc, valid_q);
+    if (ORD && valid_q && ord.row_empty[tok] != 0) sp.hi = -1;
     const int wave_q_hi = wave_max_i32(sp.hi);
     const int wave_q_lo = wave_min_i32(valid_q ? sp.hi : INT_BIG_B);
     const int wave_ql_min = wave_min_i32(valid_q ? my_ql : INT_BIG_B);
     const int wave_hole_lo = SPAN ? wave_min_i32(valid_q ? sp.hole_lo : INT_BIG_B) : INT_BIG_B;
     const int wave_hole_hi = SPAN ? wave_max_i32(valid_q ? sp.hole_hi : 0) : 0;
-    const int n_iter = (min(S, q0 + R) + 63) / 64;              // allowed keys are <= the query position
+    int n_iter = (min(S, q0 + R) + 63) / 64;                    // allowed keys are <= the query position
+    if (ORD) {                                                  // ... = the largest position of a normal row of the tile
+        const int n32 = (S + 31) >> 5;
+        int mp = -1;
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t)
+            if (qtile * NSUB + t < n32) mp = max(mp, ord.tile_maxpos[(int64_t)b * n32 + qtile * NSUB + t]);
+        n_iter = mp < 0 ? 0 : (min(S, mp + 1) + 63) / 64;
+    }
     const float c2 = scale * 1.4426950408889634f;               // scores in the log2 domain
     const AttnDropout rng(p_drop, seed);
     const uint32_t aw = DROP ? rng.row_word((uint32_t)(((int64_t)b * nq + head) * S + iqc)) : 0u;
@@ -234,14 +254,16 @@ attn_fwd_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict_
     for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
 
     uint4 rk[2], rv[2];
-    int rmeta;
+    int rmeta = 0;
     __syncthreads();                                             // the previous item of this workgroup is done with LDS
-    load_rows<64>(kbase, ldk, 0, S, tid, rk);
-    load_rows<64>(vbase, ldv, 0, S, tid, rv);
-    rmeta = key_meta_load_b<DROP>(klb, 0, S, w, lane, rng);
-    store_rows<64>(Ks[0], tid, rk, S);
-    store_rows<64>(Vs[0], tid, rv, S);
-    key_meta_store_b(kms[0], w, lane, rmeta);
+    if (n_iter > 0) {
+        load_rows<64>(kbase, ldk, 0, S, tid, rk);
+        load_rows<64>(vbase, ldv, 0, S, tid, rv);
+        rmeta = key_meta_load_b<DROP>(klb, 0, S, w, lane, rng);
+        store_rows<64>(Ks[0], tid, rk, S);
+        store_rows<64>(Vs[0], tid, rv, S);
+        key_meta_store_b(kms[0], w, lane, rmeta);
+    }
     __syncthreads();
 
     for (int jt = 0; jt < n_iter; ++jt) {
@@ -343,12 +365,12 @@ attn_fwd_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict_
     }
 }
 
-template <int G, bool DROP, bool SPAN>
+template <int G, bool DROP, bool SPAN, bool ORD>
 __global__ void __launch_bounds__(AB_THREADS, 2)
 attn_fwd_b_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                   const bf16_t* __restrict__ v, int ldv, const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                   int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-                  bf16_t* __restrict__ o, float* __restrict__ lse, const int32_t* __restrict__ span) {
+                  bf16_t* __restrict__ o, float* __restrict__ lse, const int32_t* __restrict__ span, const QOrdB ord) {
     constexpr int R = (4 / G) * 32;
     const int n_tiles = (S + R - 1) / R;
     const WorkListB wl(nbatch * nkv, n_tiles);
@@ -356,12 +378,14 @@ attn_fwd_b_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restric
     for (int it = 0;; ++it) {
         const int pair = wl.pair_at(it);
         if (pair >= wl.n_pairs) break;
-        const int heavy = n_tiles - 1 - wl.u, light = wl.u;       // later query tiles see more keys
+        // (with a row order the tiles are not a causal ramp: every workgroup takes another slot u from pair to pair)
+        const int uu = ORD ? (wl.u + it) % ((n_tiles + 1) >> 1) : wl.u;
+        const int heavy = n_tiles - 1 - uu, light = uu;           // later query tiles see more keys
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
-            attn_fwd_b_tile<G, DROP, SPAN>(q, ldq, k, ldk, v, ldv, kl, ql, S, nq, nkv, scale, p_drop, seed, o, lse, span,
-                                           pair, pass == 0 ? heavy : light);
+            attn_fwd_b_tile<G, DROP, SPAN, ORD>(q, ldq, k, ldk, v, ldv, kl, ql, S, nq, nkv, scale, p_drop, seed, o, lse, span,
+                                                ord, pair, pass == 0 ? heavy : light);
         }
     }
 }
@@ -399,13 +423,13 @@ attn_delta_b_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o
 // =============================================================================================
 // backward: dQ
 // =============================================================================================
-template <int G, bool DROP, bool SPAN>
+template <int G, bool DROP, bool SPAN, bool ORD>
 __device__ __forceinline__ void
 attn_bwd_dq_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                    const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                    const float* __restrict__ delta, const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                    int S, int nq, int nkv, float scale, float p_drop, uint64_t seed, bf16_t* __restrict__ dq, int lddq,
-                   const int32_t* __restrict__ span, const int pair, const int qtile) {
+                   const int32_t* __restrict__ span, const QOrdB ord, const int pair, const int qtile) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
     __shared__ __attribute__((aligned(16))) bf16_t Ks[2][64 * 64];
@@ -418,9 +442,9 @@ attn_bwd_dq_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restri
     const int head = kvh * G + hg;
     const int r = lane & 31, h = lane >> 5;
     const LdsOffsets lo(lane);
-    const int iq = q0 + sub * 32 + r;
+    const int iq = q0 + sub * 32 + r;                 // sorted slot (= position without a row order)
     const bool valid_q = iq < S;
-    const int iqc = valid_q ? iq : S - 1;
+    const int iqc = ORD ? ord.perm[(int64_t)b * S + (valid_q ? iq : S - 1)] : (valid_q ? iq : S - 1);
     const int64_t tok = (int64_t)b * S + iqc;
 
     bf16x8 qf[4], dof[4];
@@ -434,7 +458,8 @@ attn_bwd_dq_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restri
         }
     }
     const int my_ql = ql ? ql[tok] : 1;
-    const QuerySpanB sp = QuerySpanB::load<SPAN>(span, tok, iqc, valid_q);
+    QuerySpanB sp = QuerySpanB::load<SPAN>(span, tok, iqc, valid_q);
+    if (ORD && valid_q && ord.row_empty[tok] != 0) sp.hi = -1;
     const float neg_lse2 = -lse[((int64_t)b * nq + head) * S + iqc] * 1.4426950408889634f;
     const float neg_delta = -delta[((int64_t)b * nq + head) * S + iqc];
     const int wave_q_hi = wave_max_i32(sp.hi);
@@ -442,7 +467,15 @@ attn_bwd_dq_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restri
     const int wave_ql_min = wave_min_i32(valid_q ? my_ql : INT_BIG_B);
     const int wave_hole_lo = SPAN ? wave_min_i32(valid_q ? sp.hole_lo : INT_BIG_B) : INT_BIG_B;
     const int wave_hole_hi = SPAN ? wave_max_i32(valid_q ? sp.hole_hi : 0) : 0;
-    const int n_iter = (min(S, q0 + R) + 63) / 64;
+    int n_iter = (min(S, q0 + R) + 63) / 64;
+    if (ORD) {                                                  // ... = the largest position of a normal row of the tile
+        const int n32 = (S + 31) >> 5;
+        int mp = -1;
+#pragma unroll
+        for (int t = 0; t < NSUB; ++t)
+            if (qtile * NSUB + t < n32) mp = max(mp, ord.tile_maxpos[(int64_t)b * n32 + qtile * NSUB + t]);
+        n_iter = mp < 0 ? 0 : (min(S, mp + 1) + 63) / 64;
+    }
     const float c2 = scale * 1.4426950408889634f;
     const AttnDropout rng(p_drop, seed);
     const uint32_t aw = DROP ? rng.row_word((uint32_t)(((int64_t)b * nq + head) * S + iqc)) : 0u;
@@ -457,14 +490,16 @@ attn_bwd_dq_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restri
     for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
 
     uint4 rk[2], rv[2];
-    int rmeta;
+    int rmeta = 0;
     __syncthreads();
-    load_rows<64>(kbase, ldk, 0, S, tid, rk);
-    load_rows<64>(vbase, ldv, 0, S, tid, rv);
-    rmeta = key_meta_load_b<DROP>(klb, 0, S, w, lane, rng);
-    store_rows<64>(Ks[0], tid, rk, S);
-    store_rows<64>(Vs[0], tid, rv, S);
-    key_meta_store_b(kms[0], w, lane, rmeta);
+    if (n_iter > 0) {
+        load_rows<64>(kbase, ldk, 0, S, tid, rk);
+        load_rows<64>(vbase, ldv, 0, S, tid, rv);
+        rmeta = key_meta_load_b<DROP>(klb, 0, S, w, lane, rng);
+        store_rows<64>(Ks[0], tid, rk, S);
+        store_rows<64>(Vs[0], tid, rv, S);
+        key_meta_store_b(kms[0], w, lane, rmeta);
+    }
     __syncthreads();
 
     for (int jt = 0; jt < n_iter; ++jt) {
@@ -552,13 +587,13 @@ attn_bwd_dq_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restri
     }
 }
 
-template <int G, bool DROP, bool SPAN>
+template <int G, bool DROP, bool SPAN, bool ORD>
 __global__ void __launch_bounds__(AB_THREADS, 2)
 attn_bwd_dq_b_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                      const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                      const float* __restrict__ delta, const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                      int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-                     bf16_t* __restrict__ dq, int lddq, const int32_t* __restrict__ span) {
+                     bf16_t* __restrict__ dq, int lddq, const int32_t* __restrict__ span, const QOrdB ord) {
     constexpr int R = (4 / G) * 32;
     const int n_tiles = (S + R - 1) / R;
     const WorkListB wl(nbatch * nkv, n_tiles);
@@ -566,12 +601,13 @@ attn_bwd_dq_b_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __rest
     for (int it = 0;; ++it) {
         const int pair = wl.pair_at(it);
         if (pair >= wl.n_pairs) break;
-        const int heavy = n_tiles - 1 - wl.u, light = wl.u;
+        const int uu = ORD ? (wl.u + it) % ((n_tiles + 1) >> 1) : wl.u;
+        const int heavy = n_tiles - 1 - uu, light = uu;
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
-            attn_bwd_dq_b_tile<G, DROP, SPAN>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, S, nq, nkv, scale, p_drop, seed,
-                                              dq, lddq, span, pair, pass == 0 ? heavy : light);
+            attn_bwd_dq_b_tile<G, DROP, SPAN, ORD>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, S, nq, nkv, scale, p_drop, seed,
+                                                   dq, lddq, span, ord, pair, pass == 0 ? heavy : light);
         }
     }
 }
@@ -599,13 +635,14 @@ struct DkvSmemB {
     int32_t hole_hi_max[2];
 };
 
-template <int G, bool DROP, bool SPAN>
+template <int G, bool DROP, bool SPAN, bool ORD>
 __device__ __forceinline__ void
 attn_bwd_dkv_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                     const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                     const float* __restrict__ delta, const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                     int S, int nq, int nkv, float scale, float p_drop, uint64_t seed, bf16_t* __restrict__ dk, int lddk,
-                    bf16_t* __restrict__ dv, int lddv, const int32_t* __restrict__ span, const int pair, const int ktile) {
+                    bf16_t* __restrict__ dv, int lddv, const int32_t* __restrict__ span, const QOrdB ord, const int pair,
+                    const int ktile) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char dkvb_raw[];
@@ -642,8 +679,18 @@ attn_bwd_dkv_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restr
     const uint32_t bw = DROP ? rng.key_word((uint32_t)jk) : 0u;
     const float sd = rng.scale;
     const uint32_t drop_head0 = (uint32_t)(((int64_t)b * nq + kvh * G) * S);
-    const int n_qt = (S + 31) / 32;
-    const int qt_first = k0 >> 5;                      // earlier query tiles only hold queries before every key here
+    int n_qt = (S + 31) / 32;
+    int qt_first = k0 >> 5;                            // earlier query tiles only hold queries before every key here
+    if (ORD) {
+        // sorted tiles: the normal rows come first in ascending position, so tile_maxpos is non-decreasing over them and
+        // -1 behind them: visit [first tile that reaches this workgroup's first key, last tile with a normal row]
+        const int32_t* mp = ord.tile_maxpos + (int64_t)b * n_qt;
+        int first = 0, end = 0;
+        while (end < n_qt && mp[end] >= 0) ++end;
+        while (first < end && mp[first] < k0) ++first;
+        qt_first = first;
+        n_qt = end;
+    }
 
     f32x16 dkacc[2], dvacc[2];
 #pragma unroll
@@ -661,7 +708,8 @@ attn_bwd_dkv_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restr
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int hd = kvh * G + g;
-            const int row = min(i0 + (tid >> 3), S - 1);
+            int row = min(i0 + (tid >> 3), S - 1);
+            if (ORD) row = ord.perm[(int64_t)b * S + row];
             rq[g] = *reinterpret_cast<const uint4*>(q + ((int64_t)b * S + row) * ldq + hd * 64 + ((tid & 7) << 3));
             rdo[g] = *reinterpret_cast<const uint4*>(d_o + ((int64_t)b * S + row) * (int64_t)nq * 64 + hd * 64 + ((tid & 7) << 3));
         }
@@ -670,7 +718,8 @@ attn_bwd_dkv_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restr
             const int g = w, row = lane & 31;
             const int i = i0 + row;
             const bool in = i < S;
-            const int ic = in ? i : S - 1;
+            int ic = in ? i : S - 1;
+            if (ORD) ic = ord.perm[(int64_t)b * S + ic];
             const int hd = kvh * G + g;
             rl = in ? -lse[((int64_t)b * nq + hd) * S + ic] * 1.4426950408889634f : 0.f;
             rd = in ? -delta[((int64_t)b * nq + hd) * S + ic] : 0.f;
@@ -679,6 +728,7 @@ attn_bwd_dkv_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restr
                 rql = in ? (ql ? ql[(int64_t)b * S + ic] : 1) : 0;
                 const QuerySpanB qs = QuerySpanB::load<SPAN>(span, (int64_t)b * S + ic, ic, in);
                 rpos = qs.hi;
+                if (ORD && in && ord.row_empty[(int64_t)b * S + ic] != 0) rpos = -1;
                 rqlmin = wave_min_i32(in ? rql : INT_BIG_B);
                 rposmin = wave_min_i32(in ? rpos : INT_BIG_B);
                 rposmax = wave_max_i32(rpos);
@@ -859,14 +909,14 @@ attn_bwd_dkv_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restr
     }
 }
 
-template <int G, bool DROP, bool SPAN>
+template <int G, bool DROP, bool SPAN, bool ORD>
 __global__ void __launch_bounds__(AB_THREADS, 2)
 attn_bwd_dkv_b_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                       const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                       const float* __restrict__ delta, const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                       int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                       bf16_t* __restrict__ dk, int lddk, bf16_t* __restrict__ dv, int lddv,
-                      const int32_t* __restrict__ span) {
+                      const int32_t* __restrict__ span, const QOrdB ord) {
     constexpr int R = (4 / G) * 32;
     const int n_tiles = (S + R - 1) / R;
     const WorkListB wl(nbatch * nkv, n_tiles);
@@ -878,8 +928,8 @@ attn_bwd_dkv_b_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __res
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
-            attn_bwd_dkv_b_tile<G, DROP, SPAN>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, S, nq, nkv, scale, p_drop,
-                                               seed, dk, lddk, dv, lddv, span, pair, pass == 0 ? heavy : light);
+            attn_bwd_dkv_b_tile<G, DROP, SPAN, ORD>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, S, nq, nkv, scale, p_drop,
+                                                    seed, dk, lddk, dv, lddv, span, ord, pair, pass == 0 ? heavy : light);
         }
     }
 }
@@ -888,25 +938,26 @@ attn_bwd_dkv_b_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __res
 template <int G>
 static int launch_fwd_b(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv, const int32_t* kl,
                         const int32_t* ql, int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-                        bf16_t* o, float* lse, const int32_t* span, hipStream_t st) {
+                        bf16_t* o, float* lse, const int32_t* span, const QOrdB ord, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     dim3 grid(worklist_grid_b(B * nkv, (S + R - 1) / R, 2));
-#define GAMER_LAUNCH_FWD_B(DROPV, SPANV)                                                                                    \
-    hipLaunchKernelGGL((attn_fwd_b_kernel<G, DROPV, SPANV>), grid, dim3(AB_THREADS), 0, st, q, ldq, k, ldk, v, ldv, kl, ql, \
-                       B, S, nq, nkv, scale, p_drop, seed, o, lse, span)
-    if (p_drop > 0.f) { if (span) GAMER_LAUNCH_FWD_B(true, true); else GAMER_LAUNCH_FWD_B(true, false); }
-    else { if (span) GAMER_LAUNCH_FWD_B(false, true); else GAMER_LAUNCH_FWD_B(false, false); }
+#define GAMER_LAUNCH_FWD_B(DROPV, SPANV, ORDV)                                                                              \
+    hipLaunchKernelGGL((attn_fwd_b_kernel<G, DROPV, SPANV, ORDV>), grid, dim3(AB_THREADS), 0, st, q, ldq, k, ldk, v, ldv,   \
+                       kl, ql, B, S, nq, nkv, scale, p_drop, seed, o, lse, span, ord)
+    if (ord.perm) { if (p_drop > 0.f) GAMER_LAUNCH_FWD_B(true, false, true); else GAMER_LAUNCH_FWD_B(false, false, true); }
+    else if (p_drop > 0.f) { if (span) GAMER_LAUNCH_FWD_B(true, true, false); else GAMER_LAUNCH_FWD_B(true, false, false); }
+    else { if (span) GAMER_LAUNCH_FWD_B(false, true, false); else GAMER_LAUNCH_FWD_B(false, false, false); }
 #undef GAMER_LAUNCH_FWD_B
     GAMER_CHECK_LAUNCH("gamer_attn_fwd_bf16");
     return 0;
 }
 
-template <int G, bool DROP, bool SPAN>
+template <int G, bool DROP, bool SPAN, bool ORD>
 static int launch_bwd_b_variant(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv,
                                 const bf16_t* d_o, const float* lse, const float* delta, const int32_t* kl,
                                 const int32_t* ql, int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                                 bf16_t* dq, int lddq, bf16_t* dk, int lddk, bf16_t* dv, int lddv, const int32_t* span,
-                                hipStream_t st) {
+                                const QOrdB ord, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     dim3 grid(worklist_grid_b(B * nkv, (S + R - 1) / R, 2));
     size_t shmem = sizeof(DkvSmemB<G>);
@@ -914,7 +965,7 @@ static int launch_bwd_b_variant(const bf16_t* q, int ldq, const bf16_t* k, int l
     if (shmem < red_bytes) shmem = red_bytes;
     static bool attr_set = false;             // one flag per template instantiation
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_b_kernel<G, DROP, SPAN>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_b_kernel<G, DROP, SPAN, ORD>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) {
             set_error("gamer_attn_bwd_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -922,11 +973,11 @@ static int launch_bwd_b_variant(const bf16_t* q, int ldq, const bf16_t* k, int l
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_bwd_dkv_b_kernel<G, DROP, SPAN>), grid, dim3(AB_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o,
-                       lse, delta, kl, ql, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, span);
+    hipLaunchKernelGGL((attn_bwd_dkv_b_kernel<G, DROP, SPAN, ORD>), grid, dim3(AB_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o,
+                       lse, delta, kl, ql, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, span, ord);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd_bf16/dkv");
-    hipLaunchKernelGGL((attn_bwd_dq_b_kernel<G, DROP, SPAN>), grid, dim3(AB_THREADS), 0, st, q, ldq, k, ldk, v, ldv, d_o, lse,
-                       delta, kl, ql, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, span);
+    hipLaunchKernelGGL((attn_bwd_dq_b_kernel<G, DROP, SPAN, ORD>), grid, dim3(AB_THREADS), 0, st, q, ldq, k, ldk, v, ldv, d_o, lse,
+                       delta, kl, ql, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, span, ord);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd_bf16/dq");
     return 0;
 }
@@ -935,12 +986,13 @@ template <int G>
 static int launch_bwd_b(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv, const bf16_t* d_o,
                         const float* lse, const float* delta, const int32_t* kl, const int32_t* ql, int B, int S, int nq,
                         int nkv, float scale, float p_drop, uint64_t seed, bf16_t* dq, int lddq, bf16_t* dk, int lddk,
-                        bf16_t* dv, int lddv, const int32_t* span, hipStream_t st) {
-#define GAMER_LAUNCH_BWD_B(DROPV, SPANV)                                                                                    \
-    return launch_bwd_b_variant<G, DROPV, SPANV>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, B, S, nq, nkv, scale,      \
-                                                 p_drop, seed, dq, lddq, dk, lddk, dv, lddv, span, st)
-    if (p_drop > 0.f) { if (span) GAMER_LAUNCH_BWD_B(true, true); else GAMER_LAUNCH_BWD_B(true, false); }
-    else { if (span) GAMER_LAUNCH_BWD_B(false, true); else GAMER_LAUNCH_BWD_B(false, false); }
+                        bf16_t* dv, int lddv, const int32_t* span, const QOrdB ord, hipStream_t st) {
+#define GAMER_LAUNCH_BWD_B(DROPV, SPANV, ORDV)                                                                              \
+    return launch_bwd_b_variant<G, DROPV, SPANV, ORDV>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, B, S, nq, nkv, scale, \
+                                                       p_drop, seed, dq, lddq, dk, lddk, dv, lddv, span, ord, st)
+    if (ord.perm) { if (p_drop > 0.f) GAMER_LAUNCH_BWD_B(true, false, true); else GAMER_LAUNCH_BWD_B(false, false, true); }
+    else if (p_drop > 0.f) { if (span) GAMER_LAUNCH_BWD_B(true, true, false); else GAMER_LAUNCH_BWD_B(true, false, false); }
+    else { if (span) GAMER_LAUNCH_BWD_B(false, true, false); else GAMER_LAUNCH_BWD_B(false, false, false); }
 #undef GAMER_LAUNCH_BWD_B
     return -1;      // not reached
 }
@@ -965,30 +1017,37 @@ static int check_attn_b(const char* name, const void* q, const void* k, const vo
 extern "C" int gamer_attn_fwd_bf16(const gamer_bf16* q, int ldq, const gamer_bf16* k, int ldk, const gamer_bf16* v, int ldv,
                                    const int32_t* kl, const int32_t* ql, int B, int S, int nq, int nkv, float scale,
                                    float p_drop, uint64_t seed, gamer_bf16* o, float* lse, const int32_t* q_span,
-                                   void* stream) {
+                                   const int32_t* perm, const int32_t* tile_maxpos, const int32_t* row_empty, void* stream) {
     int rc = check_attn_b("gamer_attn_fwd_bf16", q, k, v, kl, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
     if (rc) return rc;
     GAMER_CHECK_ARG(o && lse && aligned16(o), "gamer_attn_fwd_bf16: null/unaligned output");
     GAMER_CHECK_ARG(!q_span || aligned16(q_span), "gamer_attn_fwd_bf16: q_span must be 16-byte aligned");
+    GAMER_CHECK_ARG(!perm || (tile_maxpos && row_empty && !q_span),
+                    "gamer_attn_fwd_bf16: a row order needs perm, tile_maxpos and row_empty, and excludes q_span");
+    const QOrdB ord{perm, tile_maxpos, row_empty};
     hipStream_t st = (hipStream_t)stream;
     if (nq / nkv == 1)
         return launch_fwd_b<1>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, kl, ql, B, S, nq, nkv,
-                               scale, p_drop, seed, (bf16_t*)o, lse, q_span, st);
+                               scale, p_drop, seed, (bf16_t*)o, lse, q_span, ord, st);
     return launch_fwd_b<2>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, kl, ql, B, S, nq, nkv, scale,
-                           p_drop, seed, (bf16_t*)o, lse, q_span, st);
+                           p_drop, seed, (bf16_t*)o, lse, q_span, ord, st);
 }
 
 extern "C" int gamer_attn_bwd_bf16(const gamer_bf16* q, int ldq, const gamer_bf16* k, int ldk, const gamer_bf16* v, int ldv,
                                    const gamer_bf16* o, const gamer_bf16* d_o, const float* lse, const int32_t* kl,
                                    const int32_t* ql, int B, int S, int nq, int nkv, float scale, float p_drop,
                                    uint64_t seed, float* delta, gamer_bf16* dq, int lddq, gamer_bf16* dk, int lddk,
-                                   gamer_bf16* dv, int lddv, const int32_t* q_span, int delta_ready, void* stream) {
+                                   gamer_bf16* dv, int lddv, const int32_t* q_span, int delta_ready, const int32_t* perm,
+                                   const int32_t* tile_maxpos, const int32_t* row_empty, void* stream) {
     int rc = check_attn_b("gamer_attn_bwd_bf16", q, k, v, kl, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
     if (rc) return rc;
     GAMER_CHECK_ARG(d_o && lse && delta && dq && dk && dv && (o || delta_ready), "gamer_attn_bwd_bf16: null pointer");
     GAMER_CHECK_ARG(lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 && aligned16(d_o),
                     "gamer_attn_bwd_bf16: gradient leading dims must be multiples of 4, dO 16-byte aligned");
     GAMER_CHECK_ARG(!q_span || aligned16(q_span), "gamer_attn_bwd_bf16: q_span must be 16-byte aligned");
+    GAMER_CHECK_ARG(!perm || (tile_maxpos && row_empty && !q_span),
+                    "gamer_attn_bwd_bf16: a row order needs perm, tile_maxpos and row_empty, and excludes q_span");
+    const QOrdB ord{perm, tile_maxpos, row_empty};
     hipStream_t st = (hipStream_t)stream;
     if (!delta_ready) {
         hipLaunchKernelGGL(attn_delta_b_kernel, dim3(2048), dim3(AB_THREADS), 0, st, (const bf16_t*)o, (const bf16_t*)d_o, B,
@@ -998,8 +1057,8 @@ extern "C" int gamer_attn_bwd_bf16(const gamer_bf16* q, int ldq, const gamer_bf1
     if (nq / nkv == 1)
         return launch_bwd_b<1>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lse,
                                delta, kl, ql, B, S, nq, nkv, scale, p_drop, seed, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk,
-                               (bf16_t*)dv, lddv, q_span, st);
+                               (bf16_t*)dv, lddv, q_span, ord, st);
     return launch_bwd_b<2>((const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)d_o, lse, delta,
                            kl, ql, B, S, nq, nkv, scale, p_drop, seed, (bf16_t*)dq, lddq, (bf16_t*)dk, lddk, (bf16_t*)dv,
-                           lddv, q_span, st);
+                           lddv, q_span, ord, st);
 }

@@ -112,7 +112,7 @@ std::tuple<Tensor, Tensor> mb_attention_fwd(const Tensor& q, const Tensor& k, co
     TORCH_CHECK(q.size(0) == T && k.size(0) == T && v.size(0) == T, "mb_attention_fwd: q/k/v need B*S rows");
     Tensor o = at::empty({T, nq * 64}, q.options()), lse = at::empty({B, nq, S}, q.options().dtype(at::kFloat));
     if (is_bf16(q))
-        check(gamer_attn_fwd_bf16(ptr<gamer_bf16>(q), (int)q.stride(0), ptr<gamer_bf16>(k), (int)k.stride(0), ptr<gamer_bf16>(v), (int)v.stride(0), ptr<int32_t>(kl), optr<int32_t>(ql), (int)B, (int)S, (int)nq, (int)nkv, (float)scale, (float)p_drop, (uint64_t)seed, ptr<gamer_bf16>(o), ptr<float>(lse), nullptr, cur_stream()), "gamer_attn_fwd_bf16");
+        check(gamer_attn_fwd_bf16(ptr<gamer_bf16>(q), (int)q.stride(0), ptr<gamer_bf16>(k), (int)k.stride(0), ptr<gamer_bf16>(v), (int)v.stride(0), ptr<int32_t>(kl), optr<int32_t>(ql), (int)B, (int)S, (int)nq, (int)nkv, (float)scale, (float)p_drop, (uint64_t)seed, ptr<gamer_bf16>(o), ptr<float>(lse), nullptr, nullptr, nullptr, nullptr, cur_stream()), "gamer_attn_fwd_bf16");
     else
         check(gamer_attn_fwd(ptr<float>(q), (int)q.stride(0), ptr<float>(k), (int)k.stride(0), ptr<float>(v), (int)v.stride(0), ptr<int32_t>(kl), optr<int32_t>(ql), ptr<int32_t>(row_empty), ptr<int32_t>(tile_empty), (int)B, (int)S, (int)nq, (int)nkv, (float)scale, (float)p_drop, (uint64_t)seed, ptr<float>(o), ptr<float>(lse), nullptr, nullptr, nullptr, 0, nullptr, cur_stream()), "gamer_attn_fwd");
     return {o, lse};
@@ -128,7 +128,7 @@ std::tuple<Tensor, Tensor, Tensor> mb_attention_bwd(const Tensor& q, const Tenso
     Tensor dq = at::empty({T, nq * 64}, q.options()), dk = at::empty({T, nkv * 64}, q.options()), dv = at::empty({T, nkv * 64}, q.options());
     Tensor delta = at::empty({B, nq, S}, lse.options());
     if (is_bf16(q))
-        check(gamer_attn_bwd_bf16(ptr<gamer_bf16>(q), (int)q.stride(0), ptr<gamer_bf16>(k), (int)k.stride(0), ptr<gamer_bf16>(v), (int)v.stride(0), ptr<gamer_bf16>(o), ptr<gamer_bf16>(d_o), ptr<float>(lse), ptr<int32_t>(kl), optr<int32_t>(ql), (int)B, (int)S, (int)nq, (int)nkv, (float)scale, (float)p_drop, (uint64_t)seed, ptr<float>(delta), ptr<gamer_bf16>(dq), (int)nq * 64, ptr<gamer_bf16>(dk), (int)nkv * 64, ptr<gamer_bf16>(dv), (int)nkv * 64, nullptr, 0, cur_stream()), "gamer_attn_bwd_bf16");
+        check(gamer_attn_bwd_bf16(ptr<gamer_bf16>(q), (int)q.stride(0), ptr<gamer_bf16>(k), (int)k.stride(0), ptr<gamer_bf16>(v), (int)v.stride(0), ptr<gamer_bf16>(o), ptr<gamer_bf16>(d_o), ptr<float>(lse), ptr<int32_t>(kl), optr<int32_t>(ql), (int)B, (int)S, (int)nq, (int)nkv, (float)scale, (float)p_drop, (uint64_t)seed, ptr<float>(delta), ptr<gamer_bf16>(dq), (int)nq * 64, ptr<gamer_bf16>(dk), (int)nkv * 64, ptr<gamer_bf16>(dv), (int)nkv * 64, nullptr, 0, nullptr, nullptr, nullptr, cur_stream()), "gamer_attn_bwd_bf16");
     else
         check(gamer_attn_bwd(ptr<float>(q), (int)q.stride(0), ptr<float>(k), (int)k.stride(0), ptr<float>(v), (int)v.stride(0), ptr<float>(o), ptr<float>(d_o), ptr<float>(lse), ptr<int32_t>(kl), optr<int32_t>(ql), ptr<int32_t>(row_empty), ptr<int32_t>(tile_empty), (int)B, (int)S, (int)nq, (int)nkv, (float)scale, (float)p_drop, (uint64_t)seed, ptr<float>(delta), ptr<float>(dq), (int)nq * 64, ptr<float>(dk), (int)nkv * 64, ptr<float>(dv), (int)nkv * 64, nullptr, nullptr, nullptr, nullptr, nullptr, 0, cur_stream()), "gamer_attn_bwd");
     return {dq, dk, dv};

@@ -534,8 +534,10 @@ class Engine:
             ops.session_spans(sid, ext, am, cfg.num_positions, S, r, ws.session)     # overwrites r["empty_*"]
             span_self, span_cross, pos_ids = (ws.session["span_self"], ws.session["span_cross"],
                                               ws.session["pos_ids"])
-        if cfg.cross_attention_decoder and not bf16:
-            ops.attn_row_order(r["empty_cross"], *ws.cross_order)        # (bf16: empty rows attend nothing, no order)
+        if cfg.cross_attention_decoder:
+            # (bf16: the rows without an allowed key - 70 % of them in the cross attention - output 0; sorted behind the
+            # others they cost nothing)
+            ops.attn_row_order(r["empty_cross"], *ws.cross_order)
         cos, sin = self.rope(S)
         scale = float(dh) ** -0.5
         x = ws.x[0][0]
@@ -545,8 +547,9 @@ class Engine:
 
         def attention(qb, kb, vb, kl_, ql_, empty_, tile_empty_, seed_, ob, lseb, order_, span_):
             if bf16:
+                ord16 = (order_[0], order_[2], empty_) if (order_ is not None and span_ is None) else None
                 ops.attn_fwd_bf16(qb, NQ, kb, NKV, vb, QKV, kl_, ql_, B, S, nq, nkv, scale, p_att, seed_, ob, lseb,
-                                  q_span=span_)
+                                  q_span=span_, order=ord16)
             else:
                 ops.attn_fwd(qb, NQ, kb, NKV, vb, QKV, kl_, ql_, empty_, tile_empty_, B, S, nq, nkv, scale, p_att, seed_,
                              ob, lseb, order=order_, uniform_len=uniform_len, q_span=span_)
@@ -711,9 +714,10 @@ class Engine:
 
         def attention_bwd(qb, kb, vb, ob, lseb, kl_, ql_, empty_, tile_empty_, seed_, order_, span_):
             if bf16:
+                ord16 = (order_[0], order_[2], empty_) if (order_ is not None and span_ is None) else None
                 ops.attn_bwd_bf16(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, B, S, nq, nkv, scale, p_att, seed_,
                                   ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, q_span=span_,
-                                  delta_ready=fuse_delta)
+                                  delta_ready=fuse_delta, order=ord16)
             else:
                 ops.attn_bwd(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, empty_, tile_empty_, B, S, nq, nkv, scale,
                              p_att, seed_, ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, order=order_,

@@ -341,17 +341,20 @@ def attn_bwd(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty,
          1 if (delta_ready and ds_work is not None) else 0, stream_ptr())
 
 
-def attn_fwd_bf16(q, ldq, k, ldk, v, ldv, kl, ql, B, S, nq, nkv, scale, p_drop, seed, o, lse, q_span=None):
-    """bf16 attention (empty rows -> 0, see gamer_attn_fwd_bf16 in include/gamer_hip.h)."""
+def attn_fwd_bf16(q, ldq, k, ldk, v, ldv, kl, ql, B, S, nq, nkv, scale, p_drop, seed, o, lse, q_span=None, order=None):
+    """bf16 attention (empty rows -> 0, see gamer_attn_fwd_bf16 in include/gamer_hip.h).
+    order = (perm, tile_maxpos, row_empty): visit the query rows through the row order of attn_row_order."""
+    perm, tmax, rempty = order if order is not None else (None, None, None)
     call("gamer_attn_fwd_bf16", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(kl), ptr(ql), B, S, nq, nkv, scale, p_drop,
-         seed, ptr(o), ptr(lse), ptr(q_span), stream_ptr())
+         seed, ptr(o), ptr(lse), ptr(q_span), ptr(perm), ptr(tmax), ptr(rempty), stream_ptr())
 
 
 def attn_bwd_bf16(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, B, S, nq, nkv, scale, p_drop, seed, delta, dq, lddq, dk,
-                  lddk, dv, lddv, q_span=None, delta_ready=False):
+                  lddk, dv, lddv, q_span=None, delta_ready=False, order=None):
+    perm, tmax, rempty = order if order is not None else (None, None, None)
     call("gamer_attn_bwd_bf16", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), ptr(d_o), ptr(lse), ptr(kl), ptr(ql),
          B, S, nq, nkv, scale, p_drop, seed, ptr(delta), ptr(dq), lddq, ptr(dk), lddk, ptr(dv), lddv, ptr(q_span),
-         1 if delta_ready else 0, stream_ptr())
+         1 if delta_ready else 0, ptr(perm), ptr(tmax), ptr(rempty), stream_ptr())
 
 
 def cast_params_bf16(flat, out, out_t, table, n_entries, n_tiles):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GAMER_ABI_VERSION 2
+#define GAMER_ABI_VERSION 3
 
 /* bf16 activations of the AMP variant (the reference's --bf16 run, ref:SeqRec/tasks/train_SMB_decoder.py:114-118,
  * 407-408: HF Trainer autocast): raw bfloat16 bits.  Entry points with the suffix _bf16 are the same operation with
@@ -350,7 +350,11 @@ int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float
  * ONE semantic difference that the reference itself has under bf16 and that the fixtures tests/golden/{small,full}_bf16.npz pin:
  * finfo(float32).min is not representable in bf16, the mask becomes -inf, and SDPA returns 0 for a query row with
  * no allowed key - so an "empty" row gives o = 0 (lse = 0) and no gradient instead of the fp32 run's uniform average
- * over all S keys.  (No row_empty / tile_empty / row order / uniform_len arguments: nothing depends on them.)
+ * over all S keys.  (No tile_empty / uniform_len arguments: nothing depends on them.)
+ *   Optional row order (row_perm, tile_maxpos from gamer_attn_row_order, row_empty [B,S]; all three or none, not together
+ *   with q_span): the query rows are visited through row_perm - rows with an allowed key first - so the tiles behind the
+ *   last such row of a sequence cost nothing (in the cross attention 70 % of the rows have none); results are identical
+ *   to the call without it, element for element.
  *   q [T,nq*64] (ldq), k [T,nkv*64] (ldk), v rows at v + t*ldv, o / d_o [T,nq*64]: bf16, leading dims multiples of 8;
  *   lse, delta [B,nq,S] fp32; dq / dk / dv bf16 (leading dims multiples of 4).
  *   Scores and softmax statistics fp32, un-normalised probabilities rounded to bf16 for the second product, fp32
@@ -358,12 +362,14 @@ int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float
  *   dK/dV kernel, dQ kernel (probabilities recomputed in both; no atomics, no workspace).                          */
 int gamer_attn_fwd_bf16(const gamer_bf16* q, int ldq, const gamer_bf16* k, int ldk, const gamer_bf16* v, int ldv,
                         const int32_t* kl, const int32_t* ql, int B, int S, int nq, int nkv, float scale,
-                        float p_drop, uint64_t seed, gamer_bf16* o, float* lse, const int32_t* q_span, void* stream);
+                        float p_drop, uint64_t seed, gamer_bf16* o, float* lse, const int32_t* q_span,
+                        const int32_t* row_perm, const int32_t* tile_maxpos, const int32_t* row_empty, void* stream);
 int gamer_attn_bwd_bf16(const gamer_bf16* q, int ldq, const gamer_bf16* k, int ldk, const gamer_bf16* v, int ldv,
                         const gamer_bf16* o, const gamer_bf16* d_o, const float* lse, const int32_t* kl,
                         const int32_t* ql, int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                         float* delta, gamer_bf16* dq, int lddq, gamer_bf16* dk, int lddk, gamer_bf16* dv, int lddv,
-                        const int32_t* q_span, int delta_ready, void* stream);
+                        const int32_t* q_span, int delta_ready, const int32_t* row_perm, const int32_t* tile_maxpos,
+                        const int32_t* row_empty, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Post-LN BERT-style encoder of the discriminative baselines (SURVEY section 8(f) row 4;

@@ -326,7 +326,7 @@ def _attn_ref_zero(q, k, v, ok, nq, nkv, scale, mult=None):
     return torch.einsum("bnij,bjnd->bind", pd, vq), lse, empty
 
 
-def _run_attn16(batch, cross, B, S, nq, nkv, q, k, v, d_o=None, p_drop=0.0, seed=1234):
+def _run_attn16(batch, cross, B, S, nq, nkv, q, k, v, d_o=None, p_drop=0.0, seed=1234, ordered=False):
     T = B * S
     router = ops.alloc_router_outputs(B, S, DEV)
     lut = torch.full((64,), -1, dtype=torch.int32)
@@ -340,7 +340,15 @@ def _run_attn16(batch, cross, B, S, nq, nkv, q, k, v, d_o=None, p_drop=0.0, seed
     o = torch.full((T, nq * 64), float("nan"), dtype=BF, device=DEV)
     lse = torch.empty(B, nq, S, device=DEV)
     dq_, dk_ = dev(q.reshape(T, -1).to(BF)), dev(k.reshape(T, -1).to(BF))
-    ops.attn_fwd_bf16(dq_, nq * 64, dk_, nkv * 64, vview, ldv, kl, ql, B, S, nq, nkv, 0.125, p_drop, seed, o, lse)
+    order = None
+    if ordered:             # rows with an allowed key first (gamer_attn_row_order); results must not depend on it
+        rempty = router["empty_cross"] if cross else router["empty_self"]
+        n_t = (S + 31) // 32
+        perm, kind, maxpos = (torch.empty(B, S, dtype=torch.int32, device=DEV), torch.empty(B, n_t, dtype=torch.int32, device=DEV),
+                              torch.empty(B, n_t, dtype=torch.int32, device=DEV))
+        ops.attn_row_order(rempty, perm, kind, maxpos)
+        order = (perm, maxpos, rempty)
+    ops.attn_fwd_bf16(dq_, nq * 64, dk_, nkv * 64, vview, ldv, kl, ql, B, S, nq, nkv, 0.125, p_drop, seed, o, lse, order=order)
     res = dict(o=o, lse=lse)
     if d_o is not None:
         delta = torch.empty(B, nq, S, device=DEV)
@@ -349,7 +357,7 @@ def _run_attn16(batch, cross, B, S, nq, nkv, q, k, v, d_o=None, p_drop=0.0, seed
         dqkv = torch.zeros(T, ldv, dtype=BF, device=DEV)
         dvv = dqkv[:, (nq + nkv) * 64:]
         ops.attn_bwd_bf16(dq_, nq * 64, dk_, nkv * 64, vview, ldv, o, dev(d_o.reshape(T, -1).to(BF)), lse, kl, ql, B, S, nq,
-                          nkv, 0.125, p_drop, seed, delta, dq, nq * 64, dk, nkv * 64, dvv, ldv)
+                          nkv, 0.125, p_drop, seed, delta, dq, nq * 64, dk, nkv * 64, dvv, ldv, order=order)
         res.update(dq=dq, dk=dk, dv=dvv, delta=delta)
     return res
 
@@ -381,6 +389,14 @@ def test_attention_bf16_fwd_bwd(cross, n_items, B, nq, nkv):
          _rel(res["dv"], leaves[2].grad.reshape(T, -1))]
     # probabilities and dS are rounded to bf16 (2^-9 relative) before the second products, outputs once more
     assert max(e) < 2e-2, e
+    # the row order (cross attention: rows without an allowed key sorted behind the others and skipped) changes which
+    # workgroup computes a row, never the row: forward outputs and dQ bit for bit; dK / dV sum the same query tiles in
+    # another tile partition (bf16 rounding of the result only)
+    for p_drop in (0.0, 0.2):
+        base = res if p_drop == 0.0 else _run_attn16(batch, cross, B, S, nq, nkv, q, k, v, d_o, p_drop=p_drop)
+        ordd = _run_attn16(batch, cross, B, S, nq, nkv, q, k, v, d_o, p_drop=p_drop, ordered=True)
+        assert torch.equal(ordd["o"], base["o"]) and torch.equal(ordd["lse"], base["lse"]) and torch.equal(ordd["dq"], base["dq"])
+        assert _rel(ordd["dk"], base["dk"].double()) < 1e-2 and _rel(ordd["dv"], base["dv"].double()) < 1e-2
 
 
 @pytest.mark.parametrize("cross", [False, True])
