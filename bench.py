@@ -560,9 +560,10 @@ def main(argv=None):
         gemm_ms = sum(k["ms_per_step"] for k in gemm_rows)
         gemm_tf = sum(k["tflops"] * k["ms_per_step"] for k in gemm_rows) / max(gemm_ms, 1e-9)
         ms_per_step = elapsed / args.steps * 1e3
-        kname = {"gemm_fwd": "gemm_f32_kernel<true, true, 0, false, false, 2, 0>",
-                 "gemm_dgrad": "gemm_f32_kernel<true, false, 0, false, false, 2, 0>",
-                 "gemm_wgrad": "gemm_f32_kernel<false, false, 1, false, false, 2, 0>"}.get(dom["kernel"] if dom else "", None)
+        # (prefixes: the kernel's template list ends with the matmul form, ", 0>" = fp32 MFMA)
+        kname = {"gemm_fwd": "gemm_f32_kernel<true, true, 0, false, false, 2, 0, 0>",
+                 "gemm_dgrad": "gemm_f32_kernel<true, false, 0, false, false, 2, 0, 0>",
+                 "gemm_wgrad": "gemm_f32_kernel<false, false, 1, false, false, 2, 0, 0>"}.get(dom["kernel"] if dom else "", None)
         traffic = committed_traffic(kname) if (kname and args.batch == 1024 and args.items == 101 and args.dtype == "f32") else None
         peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS
         split_terms = {"f32": 0, "split6": 6, "split9": 9}[args.matmul]

@@ -233,6 +233,27 @@ def pick_kchunk(rows: int, grouped: bool) -> int:
 # 10-17 % on the o_proj, expert and head shapes; at 517k tokens 0-3 %).  GAMER_WGRAD_TUNE=0 keeps the fixed rules.
 _WGRAD_TUNED = {}
 _WGRAD_TUNE = os.environ.get("GAMER_WGRAD_TUNE", "1") != "0"
+# GAMER_WGRAD_TUNE_FILE=<json>: chunks measured by an earlier process are read from / added to this file (profiling runs:
+# the sweep's launches would otherwise sit in the kernel statistics of the profiled step)
+_WGRAD_TUNE_FILE = os.environ.get("GAMER_WGRAD_TUNE_FILE", "")
+
+
+def _tune_key_str(key) -> str:
+    return "|".join(str(k) for k in key)
+
+
+def _load_tune_file():
+    if _WGRAD_TUNE_FILE and os.path.exists(_WGRAD_TUNE_FILE):
+        import json
+        try:
+            with open(_WGRAD_TUNE_FILE) as f:
+                return {k: int(v) for k, v in json.load(f).items()}
+        except (OSError, ValueError):
+            return {}
+    return {}
+
+
+_WGRAD_FILE_CACHE = _load_tune_file()
 
 
 def _rule_kchunk(dy, rows, N_out, K_in, groups):
@@ -278,10 +299,20 @@ def linear_wgrad(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups=1, group_
     if kchunk is None:
         key = (rows, N_out, K_in, groups, dy.dtype, F32_MATMUL_TERMS)
         kchunk = _WGRAD_TUNED.get(key)
+        if kchunk is None and _tune_key_str(key) in _WGRAD_FILE_CACHE:
+            kchunk = _WGRAD_TUNED[key] = _WGRAD_FILE_CACHE[_tune_key_str(key)]
         if kchunk is None:
             capturing = torch.cuda.is_current_stream_capturing()
             if _WGRAD_TUNE and rows >= 4096 and not capturing:
                 kchunk = _tune_kchunk(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups, group_offsets, strideC)
+                if _WGRAD_TUNE_FILE:
+                    import json
+                    _WGRAD_FILE_CACHE[_tune_key_str(key)] = int(kchunk)
+                    try:
+                        with open(_WGRAD_TUNE_FILE, "w") as f:
+                            json.dump(_WGRAD_FILE_CACHE, f, indent=0)
+                    except OSError:
+                        pass
             else:
                 kchunk = _rule_kchunk(dy, rows, N_out, K_in, groups)
             if not capturing:
