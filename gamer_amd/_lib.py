@@ -43,6 +43,14 @@ class GemmDesc(C.Structure):
         ("rowdot_other", c_void_p),
         ("rowdot_out", c_void_p),
         ("rowdot_S", c_int),
+        ("qk_wq", c_void_p), ("qk_wk", c_void_p),
+        ("qk_eps", c_float),
+        ("qk_cos", c_void_p), ("qk_sin", c_void_p),
+        ("qk_bias_q", c_void_p), ("qk_bias_k", c_void_p), ("qk_bias_v", c_void_p),
+        ("qk_act_idx", c_void_p),
+        ("qk_pos_ids", c_void_p),
+        ("qk_q_rot", c_void_p), ("qk_k_rot", c_void_p),
+        ("qk_S", c_int), ("qk_nq", c_int), ("qk_nkv", c_int),
     ]
 
 

@@ -144,6 +144,15 @@ struct GemmParams {
     const float* rowdot_other;
     float* rowdot_out;
     int rowdot_S;
+    // q|k|v epilogue (EPI == 3): per-head RMSNorm + RoPE of the q and k heads while the tile is in LDS (see gamer_gemm_desc)
+    const float* qk_wq; const float* qk_wk;
+    float qk_eps;
+    const float* qk_cos; const float* qk_sin;
+    const float* qk_bias_q; const float* qk_bias_k; const float* qk_bias_v;
+    const int32_t* qk_act_idx;
+    const int32_t* qk_pos_ids;
+    float* qk_q_rot; float* qk_k_rot;
+    int qk_S, qk_nq, qk_nkv;
 };
 
 // blockIdx -> logical tile id such that consecutive logical ids run on one XCD (ids are dealt
@@ -237,7 +246,9 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row
 }
 
 // EPI: 0 plain, 1 residual + dropout (Linear-forward sites of the decoder layer), 2 row-dot ("delta = dO . O" of the
-// attention backward, taken while the o_proj dgrad tile is still in LDS: one pass over dO and one over O less)
+// attention backward, taken while the o_proj dgrad tile is still in LDS: one pass over dO and one over O less),
+// 3 q|k|v projection: (+ behaviour bias,) per-head RMSNorm * weight and RoPE of the q / k heads written to q_rot / k_rot
+// next to the raw q|k|v - the row-major rewrite hands 16 lanes x float4 = one head row, the layout of qknorm_rope_fwd
 template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, int EPI, int SPLIT = 0>
 __global__ void __launch_bounds__(GEMM_THREADS, (NBUF == 1 && SPLIT == 0) ? 3 : 2)
 gemm_f32_kernel(const GemmParams p) {
@@ -550,11 +561,56 @@ gemm_f32_kernel(const GemmParams p) {
         float* dst0 = Cp + (int64_t)row_first * p.ldc + col;
         const float* res0 = EPI == 1 ? p.resid + (int64_t)row_first * p.ldc + col : nullptr;
         const int64_t step = 4 * p.ldc;
+        const int qk_pos0 = EPI == 3 ? row_first % max(p.qk_S, 1) : 0;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int lr = (lane >> 4) + 4 * it;             // row inside the patch
             const float4 v = *reinterpret_cast<const float4*>(patch + lr * 68 + c4);
-            if (EPI == 1) {
+            if (EPI == 3) {
+                const int row = row_first + 4 * it;
+                const int hd = (col0 + wn * 64) >> 6;                 // the wave's patch is one head
+                const int g = lane & 15;
+                float4 x = v;
+                const bool cross = p.qk_bias_q != nullptr;
+                const int a = cross ? p.qk_act_idx[row] : 0;
+                if (hd < p.qk_nq + p.qk_nkv) {
+                    const bool isq = hd < p.qk_nq;
+                    if (cross) {
+                        const float4 b4 = isq ? reinterpret_cast<const float4*>(p.qk_bias_q + (int64_t)a * p.qk_nq * 64 + hd * 64)[g]
+                                              : reinterpret_cast<const float4*>(p.qk_bias_k + (int64_t)a * p.qk_nkv * 64 + (hd - p.qk_nq) * 64)[g];
+                        x.x += b4.x; x.y += b4.y; x.z += b4.z; x.w += b4.w;
+                    }
+                    *reinterpret_cast<float4*>(dst0 + it * step) = x;         // raw (biased) q / k: what the backward reads
+                    float ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+                    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+                    const float rstd = rsqrtf(ss * (1.f / 64.f) + p.qk_eps);
+                    const float4 w4 = reinterpret_cast<const float4*>(isq ? p.qk_wq : p.qk_wk)[g];
+                    float4 y;
+                    y.x = w4.x * (x.x * rstd); y.y = w4.y * (x.y * rstd); y.z = w4.z * (x.z * rstd); y.w = w4.w * (x.w * rstd);
+                    float4 pr;
+                    pr.x = __shfl_xor(y.x, 8, 64); pr.y = __shfl_xor(y.y, 8, 64); pr.z = __shfl_xor(y.z, 8, 64); pr.w = __shfl_xor(y.w, 8, 64);
+                    // (the rows of a tile are consecutive: one division per wave, then an add and a conditional subtract)
+                    int pos = qk_pos0 + 4 * it;
+                    pos = pos >= p.qk_S ? pos - p.qk_S : pos;
+                    if (p.qk_pos_ids) pos = p.qk_pos_ids[row];
+                    const float4 cc = reinterpret_cast<const float4*>(p.qk_cos + pos * 64)[g];
+                    const float4 sn = reinterpret_cast<const float4*>(p.qk_sin + pos * 64)[g];
+                    const float sgn = g < 8 ? -1.f : 1.f;
+                    float4 o;
+                    o.x = y.x * cc.x + sgn * pr.x * sn.x; o.y = y.y * cc.y + sgn * pr.y * sn.y;
+                    o.z = y.z * cc.z + sgn * pr.z * sn.z; o.w = y.w * cc.w + sgn * pr.w * sn.w;
+                    float* rot = isq ? p.qk_q_rot + (int64_t)row * p.qk_nq * 64 + hd * 64
+                                     : p.qk_k_rot + (int64_t)row * p.qk_nkv * 64 + (hd - p.qk_nq) * 64;
+                    *reinterpret_cast<float4*>(rot + 4 * g) = o;
+                } else {
+                    if (cross) {
+                        const float4 b4 = reinterpret_cast<const float4*>(p.qk_bias_v + (int64_t)a * p.qk_nkv * 64 +
+                                                                          (hd - p.qk_nq - p.qk_nkv) * 64)[g];
+                        x.x += b4.x; x.y += b4.y; x.z += b4.z; x.w += b4.w;
+                    }
+                    *reinterpret_cast<float4*>(dst0 + it * step) = x;
+                }
+            } else if (EPI == 1) {
                 float* dst = dst0 + it * step;
                 const float* rsrc = res0 + it * step;
                 int64_t e = (int64_t)(row_first + 4 * it) * p.ldc + col;
@@ -667,6 +723,7 @@ static int launch_gemm_split(const GemmParams& p, int blocks, hipStream_t st) {
     const bool acc = MODE == 0 && p.accumulate;
     if (MODE == 0 && p.resid) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 1, SPLIT>(p, blocks, st, lds);
     if (MODE == 0 && p.rowdot_out) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 2, SPLIT>(p, blocks, st, lds);
+    if (MODE == 0 && A_KC && B_KC && p.qk_q_rot) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 3, SPLIT>(p, blocks, st, lds);
     if (acc) return launch_gemm_t<A_KC, B_KC, MODE, true, false, 2, 0, SPLIT>(p, blocks, st, lds);
     return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 0, SPLIT>(p, blocks, st, lds);
 }
@@ -689,6 +746,7 @@ static int launch_gemm(const GemmParams& p, int blocks, hipStream_t st, int spli
     if (stamp) return launch_gemm_t<A_KC, B_KC, MODE, false, true, 2>(p, blocks, st, lds);
     if (MODE == 0 && p.resid) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 1>(p, blocks, st, lds);
     if (MODE == 0 && p.rowdot_out) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 2>(p, blocks, st, lds);
+    if (MODE == 0 && A_KC && B_KC && p.qk_q_rot) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 3>(p, blocks, st, lds);
     if (nbuf == 1) {
         const int lds1 = 2 * TILE_FLOATS * (int)sizeof(float);
         if (acc) return launch_gemm_t<A_KC, B_KC, MODE, true, false, 1>(p, blocks, st, lds1);
@@ -736,6 +794,19 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     p.kchunk = d->kchunk;
     p.resid = d->resid; p.row_map = d->row_map; p.p_drop = d->p_drop; p.seed = d->seed;
     p.rowdot_other = d->rowdot_other; p.rowdot_out = d->rowdot_out; p.rowdot_S = d->rowdot_S;
+    p.qk_wq = d->qk_wq; p.qk_wk = d->qk_wk; p.qk_eps = d->qk_eps; p.qk_cos = d->qk_cos; p.qk_sin = d->qk_sin;
+    p.qk_bias_q = d->qk_bias_q; p.qk_bias_k = d->qk_bias_k; p.qk_bias_v = d->qk_bias_v;
+    p.qk_act_idx = d->qk_act_idx; p.qk_pos_ids = d->qk_pos_ids; p.qk_q_rot = d->qk_q_rot; p.qk_k_rot = d->qk_k_rot;
+    p.qk_S = d->qk_S; p.qk_nq = d->qk_nq; p.qk_nkv = d->qk_nkv;
+    GAMER_CHECK_ARG(!d->qk_q_rot || (d->qk_k_rot && d->qk_wq && d->qk_wk && d->qk_cos && d->qk_sin && d->group_mode == 0 &&
+                                     d->groups == 1 && a_kc && b_kc && !d->resid && !d->rowdot_out && !d->accumulate &&
+                                     d->alpha == 1.f && d->M % BM == 0 && d->qk_nq > 0 && d->qk_nkv > 0 && d->qk_S > 0 &&
+                                     d->N == (d->qk_nq + 2 * d->qk_nkv) * 64 && d->N % BN == 0 && d->ldc % 4 == 0 &&
+                                     aligned16(d->C) && aligned16(d->qk_q_rot) && aligned16(d->qk_k_rot) &&
+                                     (!d->qk_bias_q || (d->qk_bias_k && d->qk_bias_v && d->qk_act_idx)) &&
+                                     !getenv("GAMER_GEMM_STAMP") && !getenv("GAMER_GEMM_NBUF")),
+                    "gamer_gemm_f32: the q|k|v epilogue needs a Linear-forward layout, one group, M %% 128 == 0 (M=%d), "
+                    "N = (nq + 2 nkv) * 64 a multiple of 128 (N=%d), alpha = 1 and no other epilogue", d->M, d->N);
     GAMER_CHECK_ARG(!d->rowdot_out || (d->rowdot_other && d->rowdot_S > 0 && d->group_mode == 0 && d->groups == 1 &&
                                        !d->resid && !d->accumulate && d->M % BM == 0 && d->N % BN == 0 &&
                                        d->M % d->rowdot_S == 0 && d->ldc % 4 == 0 && aligned16(d->rowdot_other) &&

@@ -356,6 +356,11 @@ class Engine:
         if dtype != "f32" and matmul != "f32":
             raise ValueError("matmul='split6'/'split9' is a form of the fp32 path; dtype='bf16' has its own GEMM")
         self.matmul = matmul
+        # q / k RMSNorm + RoPE in the q|k|v projection's epilogue (gamer_gemm_desc.qk_*): built, parity-tested and measured
+        # at batch 1024 - the 12 projections got 6.8 ms slower per step (their tiles now also store q_rot / k_rot, and
+        # on gfx950 epilogue work is matrix-pipe time), the removed kernel had cost 8.1 ms: 373.9-375.4 against 373.4-377 ms
+        # per step, inside the box-to-box noise.  Off by default; Engine.fuse_qkv = True turns it on.
+        self.fuse_qkv = False
         if variant not in ("multi", "session"):
             raise ValueError(f"unknown variant {variant!r}")
         if dtype not in ("f32", "bf16"):
@@ -545,6 +550,9 @@ class Engine:
         t0, t1 = ws.tmpH[0], ws.tmpH[1]
         emb_m = self.shadow.params16["model.embed_tokens.weight"] if bf16 else self.params["model.embed_tokens.weight"]
 
+        # fp32: the q|k|v projection carries per-head RMSNorm + RoPE in its epilogue when its tiles are whole
+        fuse_qkv = (not bf16) and self.fuse_qkv and ops.qkv_fused_ok(ws.x[0][0], T, QKV) and cfg.head_dim == 64
+
         def attention(qb, kb, vb, kl_, ql_, empty_, tile_empty_, seed_, ob, lseb, order_, span_):
             if bf16:
                 ord16 = (order_[0], order_[2], empty_) if (order_ is not None and span_ is None) else None
@@ -559,9 +567,15 @@ class Engine:
             Wm = self.Wm[l]                          # GEMM operands (fp32 masters or bf16 copies); W: norms, tables
             # ---- self attention (model.py:204-217) ----
             ops.rmsnorm_fwd(xs[0], W.ln1, eps, A["h1"])
-            ops.linear_fwd(A["h1"], H, Wm.self_attn["qkv"], H, A["qkv"], QKV, T, QKV, H)
-            ops.qknorm_rope_fwd(A["qkv"], S, nq, nkv, W.self_attn["qn"], W.self_attn["kn"], eps, cos, sin, A["q"], A["k"],
-                                pos_ids=pos_ids)
+            if fuse_qkv:
+                # per-head RMSNorm + RoPE of q / k in the projection's epilogue (model.py:88-101 in one kernel)
+                ops.gemm(A["h1"], H, 1, Wm.self_attn["qkv"], H, 1, A["qkv"], QKV, T, QKV, H,
+                         qknorm=dict(wq=W.self_attn["qn"], wk=W.self_attn["kn"], eps=eps, cos=cos, sin=sin, q_rot=A["q"],
+                                     k_rot=A["k"], pos_ids=pos_ids, S=S, nq=nq, nkv=nkv))
+            else:
+                ops.linear_fwd(A["h1"], H, Wm.self_attn["qkv"], H, A["qkv"], QKV, T, QKV, H)
+                ops.qknorm_rope_fwd(A["qkv"], S, nq, nkv, W.self_attn["qn"], W.self_attn["kn"], eps, cos, sin, A["q"], A["k"],
+                                    pos_ids=pos_ids)
             if kv_sink is not None:
                 kv_sink(l, "self", A["k"], A["qkv"][:, NQ + NKV:])
             attention(A["q"], A["k"], A["qkv"][:, NQ + NKV:], r["kl_self"], None, r["empty_self"], r["tile_empty_self"],
@@ -574,10 +588,16 @@ class Engine:
             if W.cross:
                 C, Cm = W.cross_attn, Wm.cross_attn
                 ops.rmsnorm_fwd(xs[1], W.ln2, eps, A["h2"])
-                ops.linear_fwd(A["h2"], H, Cm["qkv"], H, A["qkv_c"], QKV, T, QKV, H)
-                ops.qknorm_rope_fwd(A["qkv_c"], S, nq, nkv, C["qn"], C["kn"], eps, cos, sin, A["q_c"], A["k_c"],
-                                    bias_q=C["bq"], bias_k=C["bk"], bias_v=C["bv"], act_idx=r["act_idx"],
-                                    pos_ids=pos_ids)
+                if fuse_qkv:
+                    ops.gemm(A["h2"], H, 1, Cm["qkv"], H, 1, A["qkv_c"], QKV, T, QKV, H,
+                             qknorm=dict(wq=C["qn"], wk=C["kn"], eps=eps, cos=cos, sin=sin, q_rot=A["q_c"], k_rot=A["k_c"],
+                                         bias_q=C["bq"], bias_k=C["bk"], bias_v=C["bv"], act_idx=r["act_idx"],
+                                         pos_ids=pos_ids, S=S, nq=nq, nkv=nkv))
+                else:
+                    ops.linear_fwd(A["h2"], H, Cm["qkv"], H, A["qkv_c"], QKV, T, QKV, H)
+                    ops.qknorm_rope_fwd(A["qkv_c"], S, nq, nkv, C["qn"], C["kn"], eps, cos, sin, A["q_c"], A["k_c"],
+                                        bias_q=C["bq"], bias_k=C["bk"], bias_v=C["bv"], act_idx=r["act_idx"],
+                                        pos_ids=pos_ids)
                 if kv_sink is not None:
                     kv_sink(l, "cross", A["k_c"], A["qkv_c"][:, NQ + NKV:])
                 attention(A["q_c"], A["k_c"], A["qkv_c"][:, NQ + NKV:], r["kl_cross"], r["ql_cross"], r["empty_cross"],

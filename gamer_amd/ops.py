@@ -144,7 +144,7 @@ def set_f32_matmul(mode) -> int:
 
 def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=False, groups=1, group_mode=0,
          group_offsets=None, strideB=0, strideC=0, kchunk=0, resid=None, row_map=None, p_drop=0.0, seed=0,
-         rowdot=None):
+         rowdot=None, qknorm=None):
     """C[m][n] (=|+=) alpha * sum_k A(m,k) B(n,k); see gamer_gemm_desc in include/gamer_hip.h.  bf16 operands go to
     gamer_gemm_bf16 (k-contiguous x k-contiguous, or the token-major wgrad form; see gamer_gemm_bf16_desc)."""
     if A.dtype == torch.bfloat16:
@@ -168,6 +168,14 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
     d.seed = seed
     if rowdot is not None:                 # (other [M, ldc], out [M / S, N / 64, S], S): see gamer_gemm_desc
         d.rowdot_other, d.rowdot_out, d.rowdot_S = ptr(rowdot[0]), ptr(rowdot[1]), int(rowdot[2])
+    if qknorm is not None:                 # the q|k|v epilogue: dict with the arguments of qknorm_rope_fwd
+        q = qknorm
+        d.qk_wq, d.qk_wk, d.qk_eps = ptr(q["wq"]), ptr(q["wk"]), float(q["eps"])
+        d.qk_cos, d.qk_sin = ptr(q["cos"]), ptr(q["sin"])
+        d.qk_bias_q, d.qk_bias_k, d.qk_bias_v = ptr(q.get("bias_q")), ptr(q.get("bias_k")), ptr(q.get("bias_v"))
+        d.qk_act_idx, d.qk_pos_ids = ptr(q.get("act_idx")), ptr(q.get("pos_ids"))
+        d.qk_q_rot, d.qk_k_rot = ptr(q["q_rot"]), ptr(q["k_rot"])
+        d.qk_S, d.qk_nq, d.qk_nkv = int(q["S"]), int(q["nq"]), int(q["nkv"])
     if F32_MATMUL_TERMS:
         call("gamer_gemm_f32_split", C.byref(d), F32_MATMUL_TERMS, stream_ptr())
     else:
@@ -206,6 +214,11 @@ def linear_dgrad_t(dy, lddy, WT, ldwt, dx, lddx, M, K_out, N_in, accumulate=Fals
     """dx[M,N_in] = dy[M,K_out] @ W[K_out,N_in] given WT = W^T [N_in, ldwt >= K_out] (k-contiguous on both sides: the
     form the bf16 path uses, against the transposed weight copy; K_out may include zero padding)."""
     gemm(dy, lddy, 1, WT, ldwt, 1, dx, lddx, M, N_in, K_out, accumulate=accumulate, **grp)
+
+
+def qkv_fused_ok(x, M: int, N: int) -> bool:
+    """The q|k|v GEMM can carry the per-head RMSNorm + RoPE epilogue: fp32 operands, whole 128-row / 128-column tiles."""
+    return x.dtype == torch.float32 and M % 128 == 0 and N % 128 == 0
 
 
 def linear_fwd(x, ldx, W, ldw, y, ldy, M, N, K, accumulate=False, **grp):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GAMER_ABI_VERSION 3
+#define GAMER_ABI_VERSION 4
 
 /* bf16 activations of the AMP variant (the reference's --bf16 run, ref:SeqRec/tasks/train_SMB_decoder.py:114-118,
  * 407-408: HF Trainer autocast): raw bfloat16 bits.  Entry points with the suffix _bf16 are the same operation with
@@ -192,6 +192,20 @@ typedef struct {
     const float* rowdot_other;
     float* rowdot_out;
     int rowdot_S;
+    /* Optional q|k|v epilogue (Linear-forward layout, one group, M % 128 == 0, N == (qk_nq + 2 * qk_nkv) * 64, no other
+     * epilogue): the projection of Qwen3MultiAttention (model.py:88-101) leaves the GEMM as
+     *   C (= q|k|v, the values the backward needs: with the behaviour-level biases added when qk_bias_q != NULL),
+     *   qk_q_rot [M, qk_nq*64] / qk_k_rot [M, qk_nkv*64] = RoPE(RMSNorm_head(q or k) * weight)
+     * exactly as gamer_qknorm_rope_fwd computes them from C - while the tile is still in LDS (a wave's 64-column patch is
+     * one head), saving that kernel's pass over q|k|v.  Arguments as gamer_qknorm_rope_fwd.  qk_q_rot == NULL: off. */
+    const float* qk_wq; const float* qk_wk;
+    float qk_eps;
+    const float* qk_cos; const float* qk_sin;
+    const float* qk_bias_q; const float* qk_bias_k; const float* qk_bias_v;
+    const int32_t* qk_act_idx;
+    const int32_t* qk_pos_ids;
+    float* qk_q_rot; float* qk_k_rot;
+    int qk_S, qk_nq, qk_nkv;
 } gamer_gemm_desc;
 
 int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);

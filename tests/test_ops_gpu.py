@@ -317,6 +317,39 @@ def test_gemm_grouped_experts(gemm_mode, scale):
     assert float(dW[0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cross", [False, True])
+def test_gemm_qkv_epilogue_equals_gemm_then_qknorm_rope(cross, gemm_mode):
+    """The q|k|v projection with the per-head RMSNorm + RoPE epilogue (gamer_gemm_desc.qk_*) against the two-kernel form:
+    the same raw q|k|v (with the behaviour biases in the cross attention) and the same rotated q / k."""
+    B, S, nq, nkv, H, nb1 = 2, 128, 6, 3, 256, 4
+    T, QKV = B * S, (6 + 2 * 3) * 64
+    g = torch.Generator().manual_seed(17)
+    x, W = torch.randn(T, H, generator=g), torch.randn(QKV, H, generator=g) * 0.1
+    wq, wk = 1 + 0.1 * torch.randn(64, generator=g), 1 + 0.1 * torch.randn(64, generator=g)
+    cos, sin = orc.rope_tables(S, 64, 1e6)
+    pos_ids = dev(torch.randint(0, S, (T,), generator=g).int()) if cross else None          # session-style positions
+    bias = dict(bias_q=dev(torch.randn(nb1, nq * 64, generator=g)), bias_k=dev(torch.randn(nb1, nkv * 64, generator=g)),
+                bias_v=dev(torch.randn(nb1, nkv * 64, generator=g)),
+                act_idx=dev(torch.randint(0, nb1, (T,), generator=g).int())) if cross else {}
+    ref = torch.empty(T, QKV, device=DEV)
+    q_ref, k_ref = torch.empty(T, nq * 64, device=DEV), torch.empty(T, nkv * 64, device=DEV)
+    ops.linear_fwd(dev(x), H, dev(W), H, ref, QKV, T, QKV, H)
+    ops.qknorm_rope_fwd(ref, S, nq, nkv, dev(wq), dev(wk), 1e-6, dev(cos), dev(sin), q_ref, k_ref, pos_ids=pos_ids, **bias)
+    out = torch.full((T, QKV), float("nan"), device=DEV)
+    q_rot, k_rot = torch.full_like(q_ref, float("nan")), torch.full_like(k_ref, float("nan"))
+    assert ops.qkv_fused_ok(dev(x), T, QKV)
+    ops.gemm(dev(x), H, 1, dev(W), H, 1, out, QKV, T, QKV, H,
+             qknorm=dict(wq=dev(wq), wk=dev(wk), eps=1e-6, cos=dev(cos), sin=dev(sin), q_rot=q_rot, k_rot=k_rot, pos_ids=pos_ids,
+                         S=S, nq=nq, nkv=nkv, **bias))
+    assert torch.equal(out, ref)
+    assert float((q_rot - q_ref).abs().max()) < 2e-6 * float(q_ref.abs().max())
+    assert float((k_rot - k_ref).abs().max()) < 2e-6 * float(k_ref.abs().max())
+    with pytest.raises(RuntimeError):          # partial row tiles keep the two-kernel form
+        ops.gemm(dev(x[:100]), H, 1, dev(W), H, 1, out[:100], QKV, 100, QKV, H,
+                 qknorm=dict(wq=dev(wq), wk=dev(wk), eps=1e-6, cos=dev(cos), sin=dev(sin), q_rot=q_rot, k_rot=k_rot, S=S, nq=nq,
+                             nkv=nkv))
+
+
 @pytest.mark.parametrize("terms", [6, 9])
 def test_gemm_split_is_exact_where_fp32_is(terms):
     """The three bf16 pieces carry all 24 bits of an operand: (a) small integers - every product and partial sum is exact
