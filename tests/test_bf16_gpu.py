@@ -51,10 +51,12 @@ def test_gemm_bf16_forward_exact(M, N, K, ldc, accumulate):
     assert torch.equal(c.cpu()[:, N:].float(), C0[:, N:].to(BF).float()), "columns past N must stay untouched"
 
 
-@pytest.mark.parametrize("M,N,K,ldc", [(4096, 256, 64, 256), (4196, 512, 256, 520), (8192 + 77, 768, 128, 768)])
+@pytest.mark.parametrize("M,N,K,ldc", [(4096, 256, 64, 256), (4196, 512, 256, 520), (8192 + 77, 768, 128, 768),
+                                       (4224 + 50, 320, 512, 320), (4100, 1041, 256, 1088)])
 def test_gemm_bf16_forward_exact_256_tile_form(M, N, K, ldc):
     """M >= 4096 and N % 256 == 0 take the 256 x 256 tile kernel (ragged last row tile, ldc > N, several tiles per
-    workgroup); plus the row-segmented (expert) form with an empty and ragged segments."""
+    workgroup); N = 320 (a badly filled 256-column tile) takes the wave-specialised LDS-DMA kernel, N = 1041 the 256 x 256
+    one with a ragged last column tile; plus the row-segmented (expert) form with an empty and ragged segments, and +=."""
     g = torch.Generator().manual_seed(M + N + K)
     A, B = ints((M, K), g), ints((N, K), g)
     B = B + torch.arange(N)[:, None] % 3
@@ -64,6 +66,9 @@ def test_gemm_bf16_forward_exact_256_tile_form(M, N, K, ldc):
     ref = A.double() @ B.double().T
     assert torch.equal(c.cpu()[:, :N].float(), ref.to(BF).float())
     assert torch.equal(c.cpu()[:, N:].float(), C0[:, N:].to(BF).float()), "columns past N must stay untouched"
+    c2 = dev(C0.to(BF))
+    ops.gemm(dev(A.to(BF)), K, 1, dev(B.to(BF)), K, 1, c2, ldc, M, N, K, accumulate=True)
+    assert torch.equal(c2.cpu()[:, :N].float(), (ref + C0[:, :N].double()).to(BF).float())
     if N == 512:
         E = 6
         seg = [0, 700, 700, 1725, 2000, 3300, M]
