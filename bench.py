@@ -461,6 +461,7 @@ def main(argv=None):
         torch.cuda.empty_cache()
         module = cls(cfg, device=f"cuda:{local_rank}", dtype=args.dtype)
         module.set_hyper(0.7)
+        module.zero_copy_logits = True      # the loop below reads only the loss (HF Trainer.training_step does the same)
         module.train()
         eng = module.engine
         eng.base_seed = 0x5EED + rank

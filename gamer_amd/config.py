@@ -67,6 +67,10 @@ class Qwen3MultiConfig:
     def __init__(self, **kwargs):
         d = copy.deepcopy(_DEFAULTS)
         d.update(kwargs)
+        # transformers 5.x stores rope_theta inside `rope_parameters` (config.json written by its save_pretrained)
+        rp = kwargs.get("rope_parameters")
+        if "rope_theta" not in kwargs and isinstance(rp, dict) and "rope_theta" in rp:
+            d["rope_theta"] = rp["rope_theta"]
         if "sparse_layers_decoder" not in kwargs:
             d["sparse_layers_decoder"] = list(range(int(d["num_hidden_layers"])))
         self.__dict__.update(d)
@@ -82,6 +86,30 @@ class Qwen3MultiConfig:
 
     @classmethod
     def from_dict(cls, d: Dict[str, Any]) -> "Qwen3MultiConfig":
+        return cls(**d)
+
+    @classmethod
+    def coerce(cls, config) -> "Qwen3MultiConfig":
+        """Accepts what the reference hands its model (ref:SeqRec/tasks/train_SMB_decoder.py:231, 335-368): a
+        ``transformers`` ``Qwen3MoeConfig`` read from config.json and mutated at run time - or an instance of this
+        class, or a plain dict.  Every field of the schema is read by ATTRIBUTE (the run-time fields the task sets are
+        attributes, not constructor arguments); ``rope_theta`` also from transformers 5.x's ``rope_parameters``."""
+        if isinstance(config, cls):
+            return config
+        if isinstance(config, dict):
+            return cls(**config)
+        d = {}
+        for key in _DEFAULTS:
+            if hasattr(config, key):
+                d[key] = copy.deepcopy(getattr(config, key))
+        if "rope_theta" not in d:
+            rp = getattr(config, "rope_parameters", None)
+            if isinstance(rp, dict) and "rope_theta" in rp:
+                d["rope_theta"] = rp["rope_theta"]
+        missing = [k for k in ("num_positions", "model_max_length", "num_behavior", "behavior_maps") if k not in d]
+        if missing:
+            raise ValueError(f"config object lacks the run-time fields {missing} (train_SMB_decoder.py:335-360 sets them "
+                             "before the model is constructed)")
         return cls(**d)
 
     @classmethod

@@ -1493,7 +1493,8 @@ static int launch_bwd_variant(const float* q, int ldq, const float* k, int ldk, 
     size_t shmem = sizeof(DkvSmem<G>);
     const size_t red_bytes = (size_t)R * 132 * sizeof(float);
     if (shmem < red_bytes) shmem = red_bytes;
-    static bool attr_set = false;             // one flag per template instantiation
+    static bool attr_dev[MAX_DEVICES] = {};   // one set of flags per template instantiation, one flag per device
+    bool& attr_set = attr_dev[current_device()];
     if (!attr_set) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<G, DROP, ORD, SPAN>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -1510,7 +1511,8 @@ static int launch_bwd_variant(const float* q, int ldq, const float* k, int ldk, 
     if (ds_work != nullptr) {
         const size_t kall = (size_t)((S + 31) / 32) * 32 * KLD * sizeof(float);
         if (kall <= 156 * 1024) {
-            static bool attr3 = false;
+            static bool attr3_dev[MAX_DEVICES] = {};
+            bool& attr3 = attr3_dev[current_device()];
             if (!attr3) {
                 const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq3_kernel<G, ORD>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);

@@ -963,7 +963,8 @@ static int launch_bwd_b_variant(const bf16_t* q, int ldq, const bf16_t* k, int l
     size_t shmem = sizeof(DkvSmemB<G>);
     const size_t red_bytes = (size_t)R * 132 * sizeof(float);
     if (shmem < red_bytes) shmem = red_bytes;
-    static bool attr_set = false;             // one flag per template instantiation
+    static bool attr_dev[MAX_DEVICES] = {};   // one set of flags per template instantiation, one flag per device
+    bool& attr_set = attr_dev[current_device()];
     if (!attr_set) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_b_kernel<G, DROP, SPAN, ORD>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);

@@ -30,6 +30,14 @@ void set_error(const char* fmt, ...);
         }                                                                               \
     } while (0)
 
+// Per-device "done once" flags (hipFuncSetAttribute and friends are per device; a process may drive several GPUs).
+constexpr int MAX_DEVICES = 16;
+static inline int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) d = 0;
+    return d;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- device helpers -----------------------------------------------------------------------

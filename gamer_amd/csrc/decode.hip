@@ -297,7 +297,8 @@ extern "C" int gamer_attn_decode(const float* q, int ldq, const float* kp, int l
                     "gamer_attn_decode: q / prompt K / V need 16-byte alignment and leading dims %% 4 == 0");
     dim3 grid(B * nkv);
     const size_t shmem = (size_t)DEC_LDS_FLOATS * sizeof(float);
-    static bool attr = false;
+    static bool attr_dev[MAX_DEVICES] = {};
+    bool& attr = attr_dev[current_device()];
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_kernel<1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);

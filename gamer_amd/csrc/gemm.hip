@@ -591,7 +591,8 @@ gemm_f32_kernel(const GemmParams p) {
                     pr.x = __shfl_xor(y.x, 8, 64); pr.y = __shfl_xor(y.y, 8, 64); pr.z = __shfl_xor(y.z, 8, 64); pr.w = __shfl_xor(y.w, 8, 64);
                     // (the rows of a tile are consecutive: one division per wave, then an add and a conditional subtract)
                     int pos = qk_pos0 + 4 * it;
-                    pos = pos >= p.qk_S ? pos - p.qk_S : pos;
+                    if (p.qk_S >= 64) pos = pos >= p.qk_S ? pos - p.qk_S : pos;   // a 64-row patch crosses at most one sequence end
+                    else pos %= p.qk_S;                                           // short sequences: several ends per patch
                     if (p.qk_pos_ids) pos = p.qk_pos_ids[row];
                     const float4 cc = reinterpret_cast<const float4*>(p.qk_cos + pos * 64)[g];
                     const float4 sn = reinterpret_cast<const float4*>(p.qk_sin + pos * 64)[g];
@@ -699,7 +700,8 @@ gemm_f32_kernel(const GemmParams p) {
 
 template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, int EPI = 0, int SPLIT = 0>
 static int launch_gemm_t(const GemmParams& p, int blocks, hipStream_t st, int lds) {
-    static int attr_lds = 0;
+    static int attr_lds_dev[MAX_DEVICES] = {};
+    int& attr_lds = attr_lds_dev[current_device()];
     auto kfn = gemm_f32_kernel<A_KC, B_KC, MODE, ACCUM, STAMP, NBUF, EPI, SPLIT>;
     if (attr_lds != lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),

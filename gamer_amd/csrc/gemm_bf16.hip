@@ -959,18 +959,25 @@ cast_params_kernel(const float* __restrict__ flat, bf16_t* __restrict__ out, bf1
 
 using namespace gamer;
 
+// 4 KB of zeros the wgrad kernel points out-of-range loads at.  A device symbol: present (zero-initialised by the loader)
+// on every device the library runs on, no allocation or memset at first use (a first use inside a stream capture is fine).
+__device__ __attribute__((aligned(4096))) uint16_t g_zero_page[2048];
+
 static const bf16_t* zero_page() {
-    static bf16_t* page = nullptr;
-    if (!page) {
-        if (hipMalloc(reinterpret_cast<void**>(&page), 4096) != hipSuccess) return nullptr;
-        if (hipMemset(page, 0, 4096) != hipSuccess) return nullptr;
+    static const bf16_t* page[MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (!page[dev]) {
+        void* ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_zero_page)) != hipSuccess) return nullptr;
+        page[dev] = static_cast<const bf16_t*>(ptr);
     }
-    return page;
+    return page[dev];
 }
 
 template <int EPI, bool ACCUM>
 static int launch_hb(const GemmBf16Params& p, int tiles, hipStream_t st) {
-    static bool attr = false;
+    static bool attr_dev[MAX_DEVICES] = {};
+    bool& attr = attr_dev[current_device()];
     auto kfn = gemm_bf16_kernel<EPI, ACCUM>;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -988,7 +995,8 @@ static int launch_hb(const GemmBf16Params& p, int tiles, hipStream_t st) {
 
 template <bool ACCUM>
 static int launch_ws(const GemmBf16Params& p, int tiles, hipStream_t st) {
-    static bool attr = false;
+    static bool attr_dev[MAX_DEVICES] = {};
+    bool& attr = attr_dev[current_device()];
     auto kfn = gemm_bf16_ws_kernel<ACCUM>;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1005,7 +1013,8 @@ static int launch_ws(const GemmBf16Params& p, int tiles, hipStream_t st) {
 
 template <int EPI, bool ACCUM>
 static int launch_big(const GemmBf16Params& p, int tiles, hipStream_t st) {
-    static bool attr = false;
+    static bool attr_dev[MAX_DEVICES] = {};
+    bool& attr = attr_dev[current_device()];
     auto kfn = gemm_bf16_big_kernel<EPI, ACCUM>;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1101,7 +1110,8 @@ extern "C" int gamer_gemm_bf16(const gamer_gemm_bf16_desc* d, void* stream) {
     const int64_t chunks = (d->K + d->kchunk - 1) / d->kchunk + (d->group_offsets ? d->groups : 0);
     const int64_t blocks = chunks * p.m_tiles * p.n_tiles;
     GAMER_CHECK_ARG(blocks < (1LL << 31), "gamer_gemm_bf16: grid too large");
-    static bool attr = false;
+    static bool attr_dev[MAX_DEVICES] = {};
+    bool& attr = attr_dev[current_device()];
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_wgrad_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, HW_LDS_BYTES);

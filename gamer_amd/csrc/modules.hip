@@ -395,7 +395,8 @@ extern "C" int gamer_attn_dense_fwd(const float* q, int ldq, const float* k, int
     const size_t staged = shmem + (size_t)3 * S * (head_dim + 1) * sizeof(float);
     a.stage = staged <= DENSE_LDS_MAX ? 1 : 0;
     if (a.stage) shmem = staged;
-    static bool attr = false;
+    static bool attr_dev[MAX_DEVICES] = {};
+    bool& attr = attr_dev[current_device()];
     if (!attr) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dense_fwd_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)DENSE_LDS_MAX);
@@ -421,7 +422,8 @@ extern "C" int gamer_attn_dense_bwd(const float* q, int ldq, const float* k, int
     const size_t staged = shmem + (size_t)4 * S * (head_dim + 1) * sizeof(float);
     a.stage = staged <= DENSE_LDS_MAX ? 1 : 0;
     if (a.stage) shmem = staged;
-    static bool attr = false;
+    static bool attr_dev[MAX_DEVICES] = {};
+    bool& attr = attr_dev[current_device()];
     if (!attr) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dense_bwd_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)DENSE_LDS_MAX);

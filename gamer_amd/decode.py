@@ -175,10 +175,10 @@ class DecodeSession:
                 continue
             self.gen[key] = (kg.index_select(0, parent), vg.index_select(0, parent))
 
+    @ops.scoped_f32_matmul(lambda self, *a: self.eng.matmul)
     def step(self, tokens: torch.Tensor) -> torch.Tensor:
         """tokens [N] int64: the token just appended to every beam.  Returns the next-token logits [N, ld]."""
         eng, cfg, b = self.eng, self.eng.cfg, self.buf
-        ops.set_f32_matmul(eng.matmul)
         N, B, nb, L0 = self.N, self.B, self.nb, self.L0
         H, I, E = cfg.hidden_size, cfg.intermediate_size, cfg.num_experts
         nq, nkv, NQ, NKV = cfg.num_attention_heads, cfg.num_key_value_heads, self.NQ, self.NKV

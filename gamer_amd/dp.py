@@ -39,26 +39,45 @@ class GradAllReducer:
         self.layers, self.tail = layer_buckets(layout, num_layers)
         self.pending = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # gloo cannot be relied on to take device tensors (it is the CPU backend of the tests; tests/test_dp_gpu.py runs
+        # two ranks on ONE GPU with it): device buckets go through a host copy for that backend only.  RCCL ("nccl")
+        # reduces the device slices in place.
+        self.stage = bool(dist.is_initialized() and dist.get_backend(group) == "gloo" and flat_grad.is_cuda)
+        self.staged = []
+
+    def _reduce(self, a: int, b: int):
+        if self.stage:
+            host = self.flat[a:b].cpu()              # synchronises with the stream that wrote the bucket
+            self.staged.append((a, b, host))
+            self.pending.append(dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.pending.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def layer_done(self, l: int):
         if self.world == 1:
             return
-        a, b = self.layers[l]
-        self.pending.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._reduce(*self.layers[l])
 
     def finish(self):
         if self.world == 1:
             return
         for a, b in self.tail:
-            self.pending.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._reduce(a, b)
         for w in self.pending:
             w.wait()
-        self.pending = []
+        for a, b, host in self.staged:
+            self.flat[a:b].copy_(host)
+        self.pending, self.staged = [], []
 
 
 def all_reduce_scalar_(t: torch.Tensor, group=None):
     """In-place SUM of a tiny device tensor (the global label count for the loss normalisation,
     HF average_tokens_across_devices semantics)."""
     if dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("GAMER_BENCH_FORCE_DIST") == "1"):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if t.is_cuda and dist.get_backend(group) == "gloo":
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t

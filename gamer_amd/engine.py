@@ -455,6 +455,7 @@ class Engine:
         return ((self.base_seed & 0xFFFF) << 48) | ((self.dropout_step & 0xFFFFFFFF) << 16) | (layer << 4) | site
 
     # ------------------------------------------------------------------------------------------
+    @ops.scoped_f32_matmul(lambda self, *a: self.matmul)
     def forward(self, input_ids, attention_mask=None, actions=None, labels=None, num_items_in_batch=None,
                 train: bool = False, dropout: Optional[bool] = None, act_zero_col: Optional[int] = None,
                 uniform_len: int = 0, kv_sink=None, session_ids=None, extended_session_ids=None,
@@ -476,7 +477,6 @@ class Engine:
         last position only (HF's ``logits_to_keep``): final norm and head run on B rows instead of B*S and the
         returned logits are [B, 1, V]."""
         cfg = self.cfg
-        ops.set_f32_matmul(self.matmul)
         B, S = input_ids.shape
         if train and S % cfg.num_positions != 0:
             raise ValueError(f"sequence length {S} is not a multiple of num_positions={cfg.num_positions} "
@@ -656,7 +656,11 @@ class Engine:
         if lab is not None:
             ops.ce_fwd(ws.logits, ws.ldl, lab, V, self.temperature, IGNORE_INDEX, ws.lse_ce, ws.row_loss, ws.loss_sum,
                        ws.count)
-            if num_items_in_batch is not None:
+            if torch.is_tensor(num_items_in_batch):
+                # a device scalar (the label count of the window summed over ranks): never read on the host
+                num_items_in_batch = num_items_in_batch.to(self.device, torch.float32).reshape(1)
+                loss = ws.loss_sum[0] / num_items_in_batch[0]
+            elif num_items_in_batch is not None:
                 loss = ws.loss_sum[0] / float(num_items_in_batch)
             else:
                 loss = ws.loss_sum[0] / ws.count[0]
@@ -686,6 +690,7 @@ class Engine:
     def zero_grad(self):
         ops.fill(self.flat_g, 0.0)
 
+    @ops.scoped_f32_matmul(lambda self, *a: self.matmul)
     def backward(self, dloss: float = 1.0, layer_done=None, dloss_dev: Optional[torch.Tensor] = None):
         """Accumulates d(loss)*dloss into the flat gradient buffer (call zero_grad() first for a fresh
         window).  Needs a forward(..., labels=..., train=True) before it.  ``dloss_dev``: fp32 device scalar that
@@ -695,7 +700,6 @@ class Engine:
         sv = self._saved
         if sv is None or not sv["train"] or sv["labels"] is None:
             raise RuntimeError("backward() needs forward(train=True, labels=...) first")
-        ops.set_f32_matmul(self.matmul)
         cfg, ws = self.cfg, self.ws
         B, S = sv["B"], sv["S"]
         span_self = span_cross = pos_ids = None
@@ -754,7 +758,10 @@ class Engine:
             ops.colsum_reduce(NP, dw, accumulate=True)
 
         # ---- loss -> logits -> final norm ----
-        if sv["num_items"] is not None:
+        if torch.is_tensor(sv["num_items"]):
+            ops.ce_bwd(ws.logits, ws.ldl, sv["labels"], V, self.temperature, IGNORE_INDEX, ws.lse_ce, sv["num_items"], 0.0,
+                       dloss, dloss_dev)
+        elif sv["num_items"] is not None:
             ops.ce_bwd(ws.logits, ws.ldl, sv["labels"], V, self.temperature, IGNORE_INDEX, ws.lse_ce, None,
                        float(sv["num_items"]), dloss, dloss_dev)
         else:
@@ -858,3 +865,33 @@ class Engine:
             reducer.finish()
         self.optimizer_step(lr, **opt)
         return loss
+
+    def train_window(self, micro_batches, lr: float, n_items=None, reducer=None, **opt):
+        """One optimizer step over a gradient-accumulation window (HF Trainer with gradient_accumulation_steps =
+        len(micro_batches), ref:SeqRec/tasks/train_SMB_decoder.py:405, README recipe 4): the loss of every micro-batch is
+        sum CE / ``n_items`` with ``n_items`` the label count of the WHOLE window (HF ``num_items_in_batch``; counted
+        here when None), summed over ranks on the device when a ``GradAllReducer`` is given
+        (``average_tokens_across_devices``); gradients accumulate in the flat buffer and the per-layer buckets are
+        all-reduced during the LAST micro-batch's backward only.  Returns the list of micro-batch losses (device)."""
+        if n_items is None:
+            n_items = sum(int((b["labels"][:, 1:] != IGNORE_INDEX).sum()) for b in micro_batches)
+        if not torch.is_tensor(n_items):
+            n_items = torch.tensor([float(n_items)], dtype=torch.float32, device=self.device)
+        else:
+            n_items = n_items.to(self.device, torch.float32).reshape(1)
+        if reducer is not None:
+            from .dp import all_reduce_scalar_
+            all_reduce_scalar_(n_items)
+        self.zero_grad()
+        losses = []
+        for a, b in enumerate(micro_batches):
+            loss, _ = self.forward(b["input_ids"], b.get("attention_mask"), b.get("actions"), labels=b["labels"],
+                                   num_items_in_batch=n_items, train=True, session_ids=b.get("session_ids"),
+                                   extended_session_ids=b.get("extended_session_ids"))
+            last = a == len(micro_batches) - 1
+            self.backward(1.0, layer_done=reducer.layer_done if (reducer is not None and last) else None)
+            losses.append(loss)
+        if reducer is not None:
+            reducer.finish()
+        self.optimizer_step(lr, **opt)
+        return losses

@@ -45,9 +45,13 @@ class _ModelFn(torch.autograd.Function):
         loss, logits = eng.forward(input_ids, attention_mask, actions, labels=labels, num_items_in_batch=num_items,
                                    train=True, dropout=model.training, session_ids=sess[0],
                                    extended_session_ids=sess[1])
-        # `logits` is a view of the engine's workspace: valid until this step's backward (which turns the buffer into
-        # d(logits)) or the next forward.  The training loop only reads `loss` (HF Trainer.training_step); a 2.2 GB
-        # copy per forward at batch 1024 would buy nothing.  The no-grad forward below hands out a copy.
+        # The engine's logits live in a workspace buffer that this step's backward turns into d(logits) and the next
+        # forward overwrites, so the module hands out a COPY by default (custom compute_loss, training-time metrics and
+        # label smoothing read outputs.logits after backward).  A training loop that only reads `loss` (HF
+        # Trainer.training_step, bench.py --path module) sets `model.zero_copy_logits = True` and gets the view
+        # instead of a 2.2 GB copy per forward at batch 1024.
+        if not model.zero_copy_logits:
+            logits = logits.clone()
         ctx.model = model
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(logits)
@@ -96,18 +100,24 @@ except Exception:                                             # noqa: BLE001
 class Qwen3MultiWithTemperature(nn.Module):
     VARIANT = "multi"
 
-    def __init__(self, config: Qwen3MultiConfig, device: str = "cuda", dtype: str = "f32"):
-        """``dtype="bf16"``: what the reference gets from ``--bf16`` (HF Trainer autocast) is a property of the engine
+    def __init__(self, config, device: str = "cuda", dtype: str = "f32"):
+        """``config``: the object the reference constructs its model from - a transformers ``Qwen3MoeConfig`` loaded from
+        config.json and mutated by the task (ref:SeqRec/tasks/train_SMB_decoder.py:231, 335-368) - or a
+        ``gamer_amd.config.Qwen3MultiConfig`` / dict with the same fields.  ``self.config`` stays the caller's object
+        (the task keeps writing to it: ``model.config.use_cache = False``, :442); the engine gets a plain copy.
+        ``dtype="bf16"``: what the reference gets from ``--bf16`` (HF Trainer autocast) is a property of the engine
         here - bf16 matrix operands and activations, fp32 parameters / gradients (the nn.Parameters stay fp32)."""
         super().__init__()
-        assert "num_positions" in config and isinstance(config.num_positions, int), \
+        assert hasattr(config, "num_positions") and isinstance(config.num_positions, int), \
             "Config must have 'num_positions' attribute for Qwen3SessionModel."
-        assert "model_max_length" in config and isinstance(config.model_max_length, int), \
+        assert hasattr(config, "model_max_length") and isinstance(config.model_max_length, int), \
             "Config must have 'model_max_length' attribute for Qwen3SessionModel."
         self.config = config
+        self._cfg = Qwen3MultiConfig.coerce(config)
         self.vocab_size = config.vocab_size
         self.temperature = 1.0
-        self.engine = Engine(config, device=device, temperature=1.0, variant=self.VARIANT, dtype=dtype)
+        self.zero_copy_logits = False       # True: the training forward returns a view of the engine's logits buffer
+        self.engine = Engine(self._cfg, device=device, temperature=1.0, variant=self.VARIANT, dtype=dtype)
         self.engine.init_weights(seed=0)
         self._param_keys = list(self.engine.layout.entries.keys())
         self._register_views()
@@ -149,8 +159,9 @@ class Qwen3MultiWithTemperature(nn.Module):
             return
         old = {k: v.detach().clone() for k, v in self.state_dict().items()}
         self.config.vocab_size = int(new_num_tokens)
+        self._cfg.vocab_size = int(new_num_tokens)
         self.vocab_size = int(new_num_tokens)
-        self.engine = Engine(self.config, device=str(self.engine.device), temperature=self.temperature,
+        self.engine = Engine(self._cfg, device=str(self.engine.device), temperature=self.temperature,
                              variant=self.VARIANT, dtype=self.engine.dtype)
         self.engine.init_weights(seed=0)
         for name in list(self._modules):                      # drop the old parameter tree
@@ -180,7 +191,7 @@ class Qwen3MultiWithTemperature(nn.Module):
 
     def save_pretrained(self, path: str):
         os.makedirs(path, exist_ok=True)
-        self.config.save_pretrained(path)
+        self._cfg.save_pretrained(path)        # the reference's config.json schema (readable by both sides)
         sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items() if k != "lm_head.weight"}
         try:
             from safetensors.torch import save_file

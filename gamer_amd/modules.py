@@ -53,8 +53,8 @@ class _EncoderLayerFn(torch.autograd.Function):
     """One TransformerEncoderLayer: forward keeps the activations the hand-written backward needs."""
 
     @staticmethod
+    @ops.scoped_f32_matmul(lambda *a: "f32")
     def forward(ctx, x, mask, meta, wq, bq, wk, bk, wv, bv, wd, bd, ln1w, ln1b, w1, b1, w2, b2):
-        ops.set_f32_matmul("f32")
         if not x.is_cuda:
             raise RuntimeError("gamer_amd.modules runs on the HIP device only (no CPU fallback)")
         B, S, D = x.shape
@@ -99,8 +99,8 @@ class _EncoderLayerFn(torch.autograd.Function):
         return f2.view(B, S, D)
 
     @staticmethod
+    @ops.scoped_f32_matmul(lambda *a: "f32")
     def backward(ctx, dout):
-        ops.set_f32_matmul("f32")
         xf, wqkv, qkv, ctxv, lse, wd, v1, mean1, rstd1, ln1w, y1, w1, pre1, a1, w2 = ctx.saved_tensors
         mt = ctx.meta
         B, S, D = mt["shape"]

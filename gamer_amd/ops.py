@@ -125,10 +125,40 @@ def rowtable_bwd(dy, lddy, col0, idx, dtable, dy_rows=None):
     call("gamer_rowtable_bwd" + _sfx(dy), ptr(dy), lddy, col0, ptr(idx), ptr(dy_rows), T, E, rows, ptr(dtable), stream_ptr())
 
 
-# fp32 matmul form of the calling thread's engine: 0 = v_mfma_f32_32x32x2_f32, 6 / 9 = gamer_gemm_f32_split (exact
-# three-way bf16 cut of both operands, 6 or 9 piece products on the bf16 pipe).  Engine.forward / backward set it.
+# fp32 matmul form in effect: 0 = v_mfma_f32_32x32x2_f32, 6 / 9 = gamer_gemm_f32_split (exact three-way bf16 cut of both
+# operands, 6 or 9 piece products on the bf16 pipe).  Default 0; an Engine / DecodeSession with another form scopes its
+# own calls with `with ops.f32_matmul(form):`, which restores the previous value on exit - two engines with different
+# forms, tools and tests in one process do not leak their setting into each other.
 F32_MATMUL_TERMS = 0
 MATMUL_MODES = {"f32": 0, "split6": 6, "split9": 9}
+
+
+class f32_matmul:
+    """Context manager: fp32 GEMMs issued inside the block use `mode` ("f32" | "split6" | "split9" or 0 / 6 / 9)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = set_f32_matmul(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_f32_matmul(self.prev)
+        return False
+
+
+def scoped_f32_matmul(get_mode):
+    """Decorator form of f32_matmul: `get_mode(*args)` names the form for the duration of the call."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            with f32_matmul(get_mode(*args)):
+                return fn(*args, **kwargs)
+        return wrapper
+    return deco
 
 
 def set_f32_matmul(mode) -> int:
@@ -246,6 +276,22 @@ def pick_kchunk(rows: int, grouped: bool) -> int:
 # 10-17 % on the o_proj, expert and head shapes; at 517k tokens 0-3 %).  GAMER_WGRAD_TUNE=0 keeps the fixed rules.
 _WGRAD_TUNED = {}
 _WGRAD_TUNE = os.environ.get("GAMER_WGRAD_TUNE", "1") != "0"
+
+
+def _tune_allowed() -> bool:
+    """On-line measurement only in single-process runs: under data parallelism every rank must pick the SAME chunk for
+    a shape (the chunking is the fp32 summation partition of the weight gradient, and a sweep on one rank would skew
+    step 0), so ranks use the shipped / file table (gamer_amd/wgrad_chunks.json, GAMER_WGRAD_TUNE_FILE) and the fixed
+    rule - all deterministic functions of the shape."""
+    if not _WGRAD_TUNE:
+        return False
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return False
+    except Exception:                               # noqa: BLE001
+        pass
+    return int(os.environ.get("WORLD_SIZE", "1")) <= 1
 # GAMER_WGRAD_TUNE_FILE=<json>: chunks measured by an earlier process are read from / added to this file (profiling runs:
 # the sweep's launches would otherwise sit in the kernel statistics of the profiled step)
 _WGRAD_TUNE_FILE = os.environ.get("GAMER_WGRAD_TUNE_FILE", "")
@@ -255,15 +301,35 @@ def _tune_key_str(key) -> str:
     return "|".join(str(k) for k in key)
 
 
+_WGRAD_SHIPPED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "wgrad_chunks.json")
+
+
 def _load_tune_file():
-    if _WGRAD_TUNE_FILE and os.path.exists(_WGRAD_TUNE_FILE):
-        import json
-        try:
-            with open(_WGRAD_TUNE_FILE) as f:
-                return {k: int(v) for k, v in json.load(f).items()}
-        except (OSError, ValueError):
-            return {}
-    return {}
+    """Shipped table (chunks measured on MI355X for the bench shapes, tools/wgrad_table.py) overlaid by the user's file."""
+    import json
+    out = {}
+    for path in (_WGRAD_SHIPPED, _WGRAD_TUNE_FILE):
+        if path and os.path.exists(path):
+            try:
+                with open(path) as f:
+                    out.update({k: int(v) for k, v in json.load(f).items()})
+            except (OSError, ValueError):
+                pass
+    return out
+
+
+def _save_tune_file():
+    """Atomic (temp file + rename): concurrent writers cannot leave a torn JSON behind."""
+    import json
+    import tempfile
+    try:
+        d = os.path.dirname(os.path.abspath(_WGRAD_TUNE_FILE))
+        fd, tmp = tempfile.mkstemp(prefix=".wgrad_tune.", dir=d)
+        with os.fdopen(fd, "w") as f:
+            json.dump(_WGRAD_FILE_CACHE, f, indent=0)
+        os.replace(tmp, _WGRAD_TUNE_FILE)
+    except OSError:
+        pass
 
 
 _WGRAD_FILE_CACHE = _load_tune_file()
@@ -316,16 +382,11 @@ def linear_wgrad(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups=1, group_
             kchunk = _WGRAD_TUNED[key] = _WGRAD_FILE_CACHE[_tune_key_str(key)]
         if kchunk is None:
             capturing = torch.cuda.is_current_stream_capturing()
-            if _WGRAD_TUNE and rows >= 4096 and not capturing:
+            if rows >= 4096 and not capturing and _tune_allowed():
                 kchunk = _tune_kchunk(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups, group_offsets, strideC)
                 if _WGRAD_TUNE_FILE:
-                    import json
                     _WGRAD_FILE_CACHE[_tune_key_str(key)] = int(kchunk)
-                    try:
-                        with open(_WGRAD_TUNE_FILE, "w") as f:
-                            json.dump(_WGRAD_FILE_CACHE, f, indent=0)
-                    except OSError:
-                        pass
+                    _save_tune_file()
             else:
                 kchunk = _rule_kchunk(dy, rows, N_out, K_in, groups)
             if not capturing:

@@ -221,26 +221,14 @@ def main(argv=None):
     while state["global_step"] < total_steps:
         step, micro, n_local = feed.next(eng.device)
         assert step == state["global_step"]
-        # label tokens of the whole accumulation window, over all ranks (HF num_items_in_batch)
-        if world > 1:
-            n_items = torch.tensor([n_local], device=eng.device)
-            all_reduce_scalar_(n_items)
-            n_items = float(n_items.item())
-        else:
-            n_items = n_local
-        eng.zero_grad()
-        loss_sum = 0.0
-        for a, b in enumerate(micro):
-            loss, _ = eng.forward(b["input_ids"], b["attention_mask"], b["actions"], labels=b["labels"],
-                                  num_items_in_batch=n_items, train=True, session_ids=b.get("session_ids"),
-                                  extended_session_ids=b.get("extended_session_ids"))
-            last = a == accum - 1
-            eng.backward(1.0, layer_done=reducer.layer_done if (reducer and last) else None)
-            loss_sum += float(loss) if (step + 1) % args.logging_step == 0 else 0.0
-        if reducer:
-            reducer.finish()
+        # label tokens of the whole accumulation window, summed over all ranks ON THE DEVICE (HF num_items_in_batch with
+        # average_tokens_across_devices; no host read in the steady state), gradients accumulated over the window and
+        # reduced during the last micro-batch's backward: Engine.train_window
         lr = cosine_with_warmup(step, args.learning_rate, warmup, total_steps)
-        eng.optimizer_step(lr, weight_decay=args.weight_decay, max_norm=args.max_grad_norm)
+        losses = eng.train_window(micro, lr, n_items=n_local, reducer=reducer, weight_decay=args.weight_decay,
+                                  max_norm=args.max_grad_norm)
+        loss = losses[-1]
+        loss_sum = float(sum(float(x) for x in losses)) if (step + 1) % args.logging_step == 0 else 0.0
         state["global_step"] = step + 1
         seq_since += args.per_device_batch_size * accum * world
         if (step + 1) % args.logging_step == 0 or step + 1 == total_steps:

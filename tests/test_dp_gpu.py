@@ -1,0 +1,64 @@
+"""SURVEY section 8(a) row D1 / 8(e) on the GPU: the REAL HIP engine under data parallelism.
+
+Two fresh child processes (started with subprocess, nothing is re-exec'ed) share cuda:0 and form a gloo group; each
+runs Engine.train_window - forward, backward with the per-layer GradAllReducer buckets launched from `layer_done`, the
+device-side all-reduce of the window's label count, clip + AdamW - on its shard of one ragged global batch.  The
+reduced flat gradient and the post-step parameters must equal a single-rank run on the concatenated batch (fp32: the
+two differ by summation order only), for accumulation windows of 1 and 2 micro-batches; two consecutive optimizer
+steps, so that zero_grad / moment / step-count handling across windows is covered as well.  The collective itself
+(RCCL vs gloo) is torch.distributed's; what is under test is everything around it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("accum,dtype", [(1, "f32"), (2, "f32"), (2, "bf16")])
+def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path, accum, dtype):
+    world, port = 2, _free_port()
+    env = dict(os.environ, GAMER_WGRAD_TUNE="0")
+    env.pop("WORLD_SIZE", None)
+    outs = [str(tmp_path / f"rank{r}.json") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_gpu_worker.py"), str(r), str(world), str(port),
+                               str(accum), dtype, outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(out)
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    res = [json.load(open(o)) for o in outs]
+    r0 = res[0]
+    # Window 1 starts from identical weights: the two runs differ by summation order only (fp32 atomics of the split-K
+    # weight gradients, bucket sums) in BOTH dtypes - rows are independent, so the bf16 roundings are the same per row.
+    # Window 2 starts from masters that differ in the last bits; fp32 stays at that level, while in bf16 a last-bit
+    # difference of a master flips the rounding of its bf16 operand copy now and then (2^-8 relative), so the second
+    # window is compared at bf16 resolution.
+    assert r0["grad_rel"][0] < 1e-5, r0
+    assert r0["param_rel"][0] < 1e-5, r0
+    tol2 = 1e-5 if dtype == "f32" else 5e-3
+    assert r0["grad_rel"][1] < tol2 and r0["param_rel"][1] < tol2, r0
+    for a, b in zip(r0["grad_norm"], r0["grad_norm_ref"]):
+        assert abs(a - b) < 10 * tol2 * b, r0
+    for r in res:
+        assert max(r["param_max_diff_vs_rank0"]) == 0.0, r          # replicas stay bit-identical
+    for i, (got, want) in enumerate(zip(r0["loss_sum_over_ranks"], r0["ref_loss"])):
+        assert abs(got - want) < (1e-5 if (dtype == "f32" or i < accum) else 2e-3) * abs(want), (got, want)

@@ -37,6 +37,41 @@ def test_reference_config_json_loads_when_present():
     assert cfg.hidden_size == 256 and cfg.cross_attention_decoder == [4, 5, 6, 7] and cfg.vocab_size == 14
 
 
+def test_hf_config_object_is_accepted_as_the_reference_passes_it(tmp_path):
+    """ref:SeqRec/tasks/train_SMB_decoder.py:231, 335-368: the task loads a transformers Qwen3MoeConfig from config.json,
+    sets the run-time fields as ATTRIBUTES and hands the object to the model.  Qwen3MultiConfig.coerce (what
+    Qwen3MultiWithTemperature.__init__ runs) must read it field by field - rope_theta sits in `rope_parameters` under
+    transformers 5.x."""
+    transformers = pytest.importorskip("transformers")
+    from transformers.models.qwen3_moe import Qwen3MoeConfig
+    syn = synthetic_config()
+    syn.save_pretrained(str(tmp_path))                      # the reference's config.json schema
+    base = {k: v for k, v in syn.to_dict().items()
+            if k not in ("num_behavior", "behavior_maps", "use_behavior_token", "num_positions", "num_experts",
+                         "n_positions", "use_user_token", "model_max_length", "vocab_size")}
+    import json
+    json.dump(base, open(tmp_path / "config.json", "w"))
+    hf = Qwen3MoeConfig.from_pretrained(str(tmp_path))
+    with pytest.raises(ValueError, match="run-time fields"):
+        Qwen3MultiConfig.coerce(hf)
+    hf.num_behavior, hf.behavior_maps = 3, {"1038": 0, "1039": 1, "1040": 2}
+    hf.use_behavior_token, hf.num_positions, hf.num_experts, hf.n_positions = True, 5, 6, 101
+    hf.use_user_token, hf.model_max_length, hf.vocab_size = False, 1024, 1041
+    cfg = Qwen3MultiConfig.coerce(hf)
+    cfg.validate()
+    want = syn.to_dict()
+    got = cfg.to_dict()
+    for k in want:
+        if k in ("torch_dtype", "architectures", "rope_scaling", "model_type"):      # bookkeeping fields HF rewrites
+            continue
+        assert got[k] == want[k], k
+    assert float(cfg.rope_theta) == 1e6
+    assert Qwen3MultiConfig.coerce(cfg) is cfg and Qwen3MultiConfig.coerce(want).to_dict() == want
+    # a config.json written by transformers 5.x (rope_parameters instead of rope_theta) loads too
+    hf.save_pretrained(str(tmp_path / "hf"))
+    assert float(Qwen3MultiConfig.from_pretrained(str(tmp_path / "hf")).rope_theta) == 1e6
+
+
 def test_param_layout_matches_reference_state_dict():
     cfg = synthetic_config()
     layout = ParamLayout(cfg)

@@ -201,6 +201,8 @@ def test_module_surface_autograd_and_state_dict(golden, tmp_path):
     out = model(**batch, session_ids=None, extended_session_ids=None, split="train")
     assert abs(float(out["loss"]) - float(z["loss_train_mode"])) < 1e-5 * float(z["loss_train_mode"])
     out.loss.backward()
+    # outputs.logits must survive backward (the engine's buffer becomes d(logits)): the module hands out a copy by default
+    assert _relmax(out.logits.cpu().numpy(), z["logits_scaled"]) < 2e-5
     named = dict(model.named_parameters())
     gkeys = [str(k) for k in z["grad_keys"]]
     norms = np.array([float(named[k].grad.double().norm()) for k in gkeys])

@@ -317,11 +317,13 @@ def test_gemm_grouped_experts(gemm_mode, scale):
     assert float(dW[0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,S", [(2, 128), (16, 40), (128, 5)])
 @pytest.mark.parametrize("cross", [False, True])
-def test_gemm_qkv_epilogue_equals_gemm_then_qknorm_rope(cross, gemm_mode):
+def test_gemm_qkv_epilogue_equals_gemm_then_qknorm_rope(cross, gemm_mode, B, S):
     """The q|k|v projection with the per-head RMSNorm + RoPE epilogue (gamer_gemm_desc.qk_*) against the two-kernel form:
-    the same raw q|k|v (with the behaviour biases in the cross attention) and the same rotated q / k."""
-    B, S, nq, nkv, H, nb1 = 2, 128, 6, 3, 256, 4
+    the same raw q|k|v (with the behaviour biases in the cross attention) and the same rotated q / k.  S = 40 and S = 5:
+    a wave's 64-row patch spans several sequences (the RoPE position wraps more than once per patch)."""
+    nq, nkv, H, nb1 = 6, 3, 256, 4
     T, QKV = B * S, (6 + 2 * 3) * 64
     g = torch.Generator().manual_seed(17)
     x, W = torch.randn(T, H, generator=g), torch.randn(QKV, H, generator=g) * 0.1
