@@ -92,6 +92,10 @@ class KernelTimer:
         self._bytes = 0.0
         self.pairs = {"self": 0, "cross": 0}     # allowed (query, key) pairs of the current batch
 
+    def reset(self):
+        self.records, self.enabled, self._next, self.only = [], False, None, None
+        self._dgrad_t, self._bytes = False, 0.0
+
     def install(self):
         from gamer_amd import ops
         orig_call, orig_gemm = ops.call, ops.gemm
@@ -241,30 +245,43 @@ def log(msg: str):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def committed_traffic(kernel_substr: str):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summaries of this same command
-    (profiles/*_pmc_{FETCH,WRITE}_SIZE.csv; separate --pmc passes).  gfx950 correction from
-    MI355X_MICROARCH.md: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> doubled;
-    WRITE_SIZE is exact; both are in KiB.  Returns None when no profile is committed."""
+def committed_traffic(kernel_substr: str, want: dict):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summaries (profiles/<tag>_pmc_{FETCH,WRITE}_SIZE.csv;
+    separate --pmc passes).  Only a profile set whose sidecar ``profiles/<tag>_pmc_meta.json`` (written by the profiling
+    script next to the CSVs: the bench arguments of the profiled command) matches the CURRENT run's workload in every
+    key of ``want`` (batch, items, dtype, matmul, variant, ragged) is used; the newest matching set wins.  No match ->
+    None (``traffic: null``) rather than a figure from another shape.  gfx950 correction from MI355X_MICROARCH.md:
+    FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> doubled; WRITE_SIZE is exact; both in KiB."""
     import csv
     import glob
     prof = os.path.join(ROOT, "profiles")
-    fetch = sorted(glob.glob(os.path.join(prof, "*_pmc_FETCH_SIZE.csv")))
-    write = sorted(glob.glob(os.path.join(prof, "*_pmc_WRITE_SIZE.csv")))
-    if not fetch or not write:
-        return None
 
     def avg(path, col):
         for r in csv.DictReader(open(path)):
             if kernel_substr in r["kernel"]:
                 return float(r[col])
         return None
-    f = avg(fetch[-1], "avg_FETCH_SIZE_KB_per_dispatch")
-    w = avg(write[-1], "avg_WRITE_SIZE_KB_per_dispatch")
-    if f is None or w is None:
-        return None
-    return {"bytes_per_launch": (2.0 * f + w) * 1024.0, "source": os.path.basename(fetch[-1]) + " + " + os.path.basename(write[-1]),
-            "fetch_kib_raw": f, "write_kib": w}
+
+    # newest first: profile sets are tagged per round (r02z_..., r03a_...), so the name order is the age order (file
+    # times are meaningless in a fresh checkout)
+    for meta_path in sorted(glob.glob(os.path.join(prof, "*_pmc_meta.json")), reverse=True):
+        try:
+            meta = json.load(open(meta_path))
+        except (OSError, ValueError):
+            continue
+        if any(meta.get(k) != v for k, v in want.items()):
+            continue
+        tag = meta_path[:-len("_pmc_meta.json")]
+        fetch, write = tag + "_pmc_FETCH_SIZE.csv", tag + "_pmc_WRITE_SIZE.csv"
+        if not (os.path.exists(fetch) and os.path.exists(write)):
+            continue
+        f = avg(fetch, "avg_FETCH_SIZE_KB_per_dispatch")
+        w = avg(write, "avg_WRITE_SIZE_KB_per_dispatch")
+        if f is None or w is None:
+            continue
+        return {"bytes_per_launch": (2.0 * f + w) * 1024.0, "source": os.path.basename(fetch) + " + " + os.path.basename(write),
+                "fetch_kib_raw": f, "write_kib": w, "profiled_command": meta.get("cmd")}
+    return None
 
 
 def cpu_baseline(cfg_dict, seq_items: int, micro_batch: int = 32, timed_steps: int = 3, session_mean=None):
@@ -318,6 +335,8 @@ def parse_args(argv=None):
                          "driven the way HF Trainer drives the reference (forward -> loss.backward() -> clip_grad_norm_ -> "
                          "torch AdamW -> zero_grad); module-fused = the same with the module's FusedClipAdamW optimizer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary legs (bf16, split6, per-GPU batch 128) the default single-GPU run adds")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--matmul", choices=["f32", "split6", "split9"], default="f32",
                     help="fp32 GEMM form (--dtype f32 only): f32 = fp32 MFMA (the headline record); split6 / split9 = "
@@ -389,28 +408,18 @@ def spawn_ranks(args, argv) -> int:
     return 0
 
 
-def main(argv=None):
-    argv = list(sys.argv[1:] if argv is None else argv)
-    args = parse_args(argv)
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        raise SystemExit(spawn_ranks(args, argv))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    force_dist = os.environ.get("GAMER_BENCH_FORCE_DIST") == "1"     # exercise the RCCL path on one GPU
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        if force_dist and "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
-        if dist.get_world_size() != world:
-            raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {world}")
+SECONDARY_LEGS = (
+    # (name, dtype, matmul, per-GPU batch): what DESIGN.md / README.md quote beside the headline, timed by the SAME driver run
+    ("bf16_b1024", "bf16", "f32", 1024),
+    ("f32_split6_b1024", "f32", "split6", 1024),
+    ("f32_b128", "f32", "f32", 128),
+    ("bf16_b128", "bf16", "f32", 128),
+)
 
+
+def run_leg(args, rank, world, local_rank, force_dist, timer):
+    """One measurement: W untimed steps, K timed steps between barrier + synchronize (MAX over ranks).  Returns the result
+    dict on rank 0 (None elsewhere).  Frees its engine before returning."""
     from gamer_amd import synthetic
     from gamer_amd.config import synthetic_config
     from gamer_amd.dp import GradAllReducer
@@ -445,9 +454,7 @@ def main(argv=None):
                                         session_mean=smean)
                    for s in range(n_batches)]
     flops = [algorithmic_flops(cfg, b, session=args.variant == "session") for b in cpu_batches]
-    timer = KernelTimer()
-    if not args.no_kernel_timing:
-        timer.install()
+    timer.reset()
     lr = 5e-4
     grad_scale = 1.0                              # gradients are already global means (sum CE / global count)
 
@@ -499,7 +506,7 @@ def main(argv=None):
     # per-GPU batch 128, 54.1 vs 51.6 ms fp32, 20.6 vs 18.3 ms bf16), so every launch is timed only in the WARM-UP steps
     # after the first (-> the "kernels" table) and the timed region carries events on the dominant kernel family alone
     # (-> "roofline", measured live in the timed region as the contract asks, ~100 events per step).
-    log(f"engine ready, {n_batches} batches resident; warm-up")
+    log(f"engine ready ({args.dtype}/{args.matmul}, per-GPU batch {args.batch}), {n_batches} batches resident; warm-up")
     warm_kernels, warm_steps = [], 0
     for i in range(args.warmup):
         if i == 1 and not args.no_kernel_timing:
@@ -551,6 +558,7 @@ def main(argv=None):
         allreduce = {"ranks": dist.get_world_size(), "backend": "nccl (RCCL)", "bytes": nbytes, "buckets": cfg.num_hidden_layers + 2,
                      "ms": ms, "bus_GBps": 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9}
 
+    result = None
     if rank == 0:
         seqs = args.batch * world * args.steps
         step_flops = sum(flops[i % n_batches]["step"] for i in range(args.warmup, args.warmup + args.steps)) / args.steps
@@ -565,7 +573,10 @@ def main(argv=None):
         kname = {"gemm_fwd": "gemm_f32_kernel<true, true, 0, false, false, 2, 0, 0>",
                  "gemm_dgrad": "gemm_f32_kernel<true, false, 0, false, false, 2, 0, 0>",
                  "gemm_wgrad": "gemm_f32_kernel<false, false, 1, false, false, 2, 0, 0>"}.get(dom["kernel"] if dom else "", None)
-        traffic = committed_traffic(kname) if (kname and args.batch == 1024 and args.items == 101 and args.dtype == "f32") else None
+        # HBM bytes per launch from a committed PMC profile of THIS workload (shape / dtype / matmul form checked)
+        want = dict(batch=args.batch, items=args.items, dtype=args.dtype, matmul=args.matmul, variant=args.variant,
+                    ragged=bool(args.ragged))
+        traffic = committed_traffic(kname, want) if kname else None
         peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS
         split_terms = {"f32": 0, "split6": 6, "split9": 9}[args.matmul]
         if split_terms:
@@ -617,6 +628,7 @@ def main(argv=None):
                 "hbm_frac": (dom["algorithmic_GBps"] / HBM_PEAK_GBS) if (dom and dom.get("algorithmic_GBps")) else None,
                 "traffic": traffic["bytes_per_launch"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
+                "traffic_profiled_command": traffic["profiled_command"] if traffic else None,
                 "algorithmic_flop_per_launch": (dom["tflops"] * 1e12 * dom["avg_launch_ms"] * 1e-3) if dom else None,
                 "avg_launch_ms": dom["avg_launch_ms"] if dom else None,
                 "all_gemm_tflops": gemm_tf,
@@ -633,8 +645,75 @@ def main(argv=None):
             result["allreduce"] = allreduce
         if args.no_kernel_timing:
             result["roofline"] = None
+    # release this leg's engine (86 GB of activations at batch 1024 fp32) before the next leg allocates its own
+    del eng, module, opt, batches, reducer
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return result
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args, argv))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    force_dist = os.environ.get("GAMER_BENCH_FORCE_DIST") == "1"     # exercise the RCCL path on one GPU
+    if world > 1 or force_dist:
+        import torch.distributed as dist
+        if force_dist and "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != world:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {world}")
+
+    timer = KernelTimer()
+    if not args.no_kernel_timing:
+        timer.install()
+    result = run_leg(args, rank, world, local_rank, force_dist, timer)
+
+    # Secondary legs (N = 1, default workload only): the other step forms DESIGN.md quotes - bf16 AMP, fp32 Linear
+    # products on the bf16 pipe (split6), and both dtypes at the per-GPU batch of the 8-GPU north-star point (128) -
+    # timed by the same run, 2 warm-up + 5 timed steps each, reported under "secondary" on the ONE JSON line.
+    default_workload = (world == 1 and not force_dist and args.path == "engine" and args.dtype == "f32" and args.matmul == "f32"
+                        and args.batch == 1024 and args.items == 101 and args.variant == "multi" and not args.ragged
+                        and not args.no_dropout)
+    if default_workload and not args.no_secondary and result is not None:
+        import copy
+        secondary = []
+        for name, dtype, matmul, batch in SECONDARY_LEGS:
+            a = copy.copy(args)
+            a.dtype, a.matmul, a.batch, a.steps, a.warmup = dtype, matmul, batch, 5, 2
+            try:
+                r = run_leg(a, rank, world, local_rank, force_dist, timer)
+            except Exception as e:                                  # a failing extra leg must not cost the headline line
+                log(f"secondary leg {name} failed: {e!r}")
+                secondary.append({"name": name, "error": repr(e)})
+                continue
+            rf = r.get("roofline") or {}
+            secondary.append({"name": name, "dtype": dtype, "matmul": matmul, "per_gpu_batch": batch, "steps": a.steps,
+                              "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "value": r["value"], "unit": r["unit"],
+                              "loss": r["loss"], "dominant_kernel": rf.get("kernel"), "achieved": rf.get("achieved"),
+                              "peak": rf.get("peak"), "frac": rf.get("frac"), "hbm_frac": rf.get("hbm_frac"),
+                              "step_algorithmic_tflops": rf.get("step_algorithmic_tflops"),
+                              "all_gemm_ms_per_step": rf.get("all_gemm_ms_per_step"),
+                              "kernels": [{k: row[k] for k in ("kernel", "ms_per_step", "avg_launch_ms", "tflops") if k in row}
+                                          for row in r["kernels"][:8]]})
+        result["secondary"] = secondary
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg.to_dict(), args.items, session_mean=smean)
+            from gamer_amd.config import synthetic_config
+            smean = args.session_mean if args.variant == "session" else None
+            result["cpu_baseline"] = cpu_baseline(synthetic_config().to_dict(), args.items, session_mean=smean)
         # RCCL prints a version banner through C stdio; push it out first so that the JSON line is last
         try:
             import ctypes
