@@ -150,11 +150,43 @@ __device__ __forceinline__ bf16x8 read_tr8(const bf16_t* __restrict__ img, const
     }
     return out;
 }
+// Two fp32 -> one register of two bf16 (round to nearest even).  Spelled as the instruction: left to the compiler, the
+// conversion of a vector that has just gone through a select came out as one v_cvt_pk_bf16_f32 PER ELEMENT (upper half
+// unused), the select on the 16-bit result and a v_perm_b32 per pair - 40 vector instructions per 16 probabilities where
+// 8 do the work, in kernels whose time is vector-ALU time.
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+typedef uint32_t u32x4b __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s2) {
-    f32x8v f;
+    u32x4b u;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = a[8 * s2 + j];
-    return __builtin_convertvector(f, bf16x8);
+    for (int j = 0; j < 4; ++j) u[j] = cvt_pk_bf16(a[8 * s2 + 2 * j], a[8 * s2 + 2 * j + 1]);
+    return __builtin_bit_cast(bf16x8, u);
+}
+// x[i] = exp2(x[i] * c + d) for the 16 registers of a tile, the multiply-adds as 8 packed v_pk_fma_f32
+__device__ __forceinline__ void exp2_affine16(f32x16& x, const float c, const float d) {
+    const f32x2 cv = {c, c}, dv = {d, d};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        f32x2 t = {x[2 * j], x[2 * j + 1]};
+        t = __builtin_elementwise_fma(t, cv, dv);
+        x[2 * j] = __builtin_amdgcn_exp2f(t[0]);
+        x[2 * j + 1] = __builtin_amdgcn_exp2f(t[1]);
+    }
+}
+__device__ __forceinline__ float sum16(const f32x16& x) {
+    f32x2 a = {x[0], x[1]}, b = {x[2], x[3]};
+#pragma unroll
+    for (int j = 2; j < 8; j += 2) {
+        a += (f32x2){x[2 * j], x[2 * j + 1]};
+        b += (f32x2){x[2 * j + 2], x[2 * j + 3]};
+    }
+    a += b;
+    return a[0] + a[1];
 }
 
 // per staged 64-key tile: key levels, dropout key words, the largest level of each 32-key half
@@ -313,14 +345,8 @@ attn_fwd_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict_
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
             }
-            float rowsum = 0.f;
-            const float nm = -m_ref;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float pe = __builtin_amdgcn_exp2f(fmaf(st[reg], c2, nm));       // masked: exp2(-inf) = 0
-                rowsum += pe;
-                st[reg] = pe;
-            }
+            exp2_affine16(st, c2, -m_ref);                          // masked: exp2(-inf) = 0
+            float rowsum = sum16(st);
             rowsum += __shfl_xor(rowsum, 32, 64);
             l_run += rowsum;
             if (DROP) {
@@ -545,17 +571,19 @@ attn_bwd_dq_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restri
                 int kwv[16];
                 read_key_quads_b(reinterpret_cast<const int32_t*>(km.kw) + 32 * kb, h, kwv);
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const float t = rng.keep(aw, (uint32_t)kwv[reg]) ? dp[reg] : 0.f;
-                    dp[reg] = fmaf(t, sd, neg_delta);
-                }
-            } else {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) dp[reg] += neg_delta;
+                for (int reg = 0; reg < 16; ++reg) dp[reg] = rng.keep(aw, (uint32_t)kwv[reg]) ? dp[reg] : 0.f;
             }
+            exp2_affine16(st, c2, neg_lse2);
+            {
+                const f32x2 sdv = {DROP ? sd : 1.f, DROP ? sd : 1.f}, ndv = {neg_delta, neg_delta};
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg)
-                st[reg] = __builtin_amdgcn_exp2f(fmaf(st[reg], c2, neg_lse2)) * dp[reg];
+                for (int j = 0; j < 8; ++j) {
+                    f32x2 t = {dp[2 * j], dp[2 * j + 1]};
+                    t = __builtin_elementwise_fma(t, sdv, ndv);
+                    st[2 * j] *= t[0];
+                    st[2 * j + 1] *= t[1];
+                }
+            }
             // dQ^T[d][query] += sum_key K[key][d] dS^T[key][query]
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {

@@ -1,0 +1,1215 @@
+// Multi-behaviour flash attention for gfx950 with fp32 inputs / outputs and every matrix product formed on the bf16 matrix
+// pipe from an EXACT three-way cut of both operands (the attention counterpart of gamer_gemm_f32_split, csrc/gemm.hip):
+// an fp32 value x is the sum of three bf16 values x0 = upper 16 bits of x, x1 = upper 16 bits of (x - x0), x2 = x - x0 - x1
+// (both subtractions are exact), every piece product a_i b_j (8 x 8 significant bits) is exact in fp32, and the six
+// products with i + j <= 2 are accumulated by v_mfma_f32_32x32x16_bf16 in fp32 - what is dropped is below 2^-24 |a b|,
+// the size of one fp32 rounding.  The bf16 pipe is 16 x wider than the fp32 one, so six products cost 3/8 of the fp32
+// MFMA's time, and on gfx950 fp32 MFMA and fp32 VALU work share a pipe (tools/ubench_pipes.hip).
+//
+// Same algorithm, semantics, work partition and entry-point signatures as attention.hip (Qwen3Multi masks as predicates,
+// "empty" rows uniform over all S keys, lazily rescaled online softmax, row order of the cross attention, dropout mask
+// function): replaces ref:SeqRec/models/generative/Qwen3Multi/model.py:133-143 + HF sdpa_attention_forward in the
+// Engine(matmul="split6") step.  What differs from attention.hip:
+//   * K / V (Q / dO in the dK/dV kernel) tiles are cut on their way into LDS: three bf16 images [rows][64] per tile,
+//     16-byte chunks XOR-swizzled (the layout of attention_bf16.hip: conflict-free row reads and transposing reads);
+//   * q (pre-scaled), dO rows are cut once per tile into register fragments; P and dS are cut in registers;
+//   * the backward is the recompute form (dQ kernel + dK/dV kernel, 7 products per tile pair): the dS spill of the fp32
+//     design would need the whole K of a sequence as three images in LDS (194 KB) for its streaming dQ kernel.
+// Not built here (the Engine keeps those calls on the fp32-MFMA kernels): per-query key spans (Qwen3SessionMulti) and
+// uniform_len of the evaluation re-run path.
+#include "attention_common.h"
+
+namespace gamer {
+
+constexpr int SIMG = 32 * 64;              // bf16 elements of one piece image of a 32-row tile
+
+// element offset of (row, column) in a [rows][64] bf16 image with swizzled 16-byte chunks (attention_bf16.hip: lds_off)
+__device__ __forceinline__ int sl_f(int row) { return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1); }
+__device__ __forceinline__ int sl_off(int row, int col) { return row * 64 + ((((col >> 3) ^ sl_f(row))) << 3) + (col & 7); }
+struct SlOffsets {
+    int row[4];        // row read:  row (lane & 31), columns 16 s + 8 h .. + 7        (s = 0..3)
+    int tr[2][2];      // transposing read [c][db]: row 8 c + 4 h + q4, column 32 db + 16 gsel + 4 pp
+    __device__ __forceinline__ SlOffsets(int lane) {
+        const int r = lane & 31, h = lane >> 5, gsel = (lane >> 4) & 1, q4 = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) row[s] = sl_off(r, 16 * s + 8 * h);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) tr[c][db] = sl_off(8 * c + 4 * h + q4, 32 * db + 16 * gsel + 4 * pp);
+    }
+};
+// row read: the 8 k-values (columns 16 s + 8 h ..) of row rblk + (lane & 31); rblk a multiple of 32
+__device__ __forceinline__ bf16x8 read_row8(const bf16_t* __restrict__ img, const SlOffsets& lo, int rblk, int s) {
+    return *reinterpret_cast<const bf16x8*>(img + rblk * 64 + lo.row[s]);
+}
+// transposing read (the MFMA's k index runs over ROWS of the image): for column 32 db + (lane & 31), the 8 rows
+// rbase + 8 * (j >> 2) + 4 * h + (j & 3), j = 0..7 (rbase a multiple of 16) - the k order of an accumulator tile
+__device__ __forceinline__ bf16x8 read_tr8(const bf16_t* __restrict__ img, const SlOffsets& lo, int rbase, int db) {
+    bf16x8 out;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (bf16x4 __attribute__((address_space(3)))*)(img + rbase * 64 + lo.tr[c][db]));
+        out[4 * c + 0] = v[0]; out[4 * c + 1] = v[1]; out[4 * c + 2] = v[2]; out[4 * c + 3] = v[3];
+    }
+    return out;
+}
+
+// ---- the exact three-way cut (csrc/gemm.hip: split3) ---------------------------------------------------------------
+// upper halves of (w1, w0) -> one register {bf16(w0), bf16(w1)}
+__device__ __forceinline__ uint32_t hi16_pair(uint32_t w0, uint32_t w1) { return __builtin_amdgcn_perm(w1, w0, 0x07060302u); }
+// x = p0 + p1 + p2 exactly, p_i = the value of the upper 16 bits of w[i]
+__device__ __forceinline__ void cut3(float x, uint32_t (&w)[3]) {
+    w[0] = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(w[0] & 0xffff0000u);
+    w[1] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(w[1] & 0xffff0000u);
+    w[2] = __float_as_uint(r2);
+}
+typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+// eight consecutive values (two float4) -> the three bf16x8 fragments
+__device__ __forceinline__ void cut8(const float4& a, const float4& b, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t w[8][3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cut3(x[e], w[e]);
+    u32x4s u[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[s][j] = hi16_pair(w[2 * j][s], w[2 * j + 1][s]);
+    p0 = __builtin_bit_cast(bf16x8, u[0]); p1 = __builtin_bit_cast(bf16x8, u[1]); p2 = __builtin_bit_cast(bf16x8, u[2]);
+}
+// registers first .. first + 7 of an accumulator tile -> the three bf16x8 fragments (operand of the second product)
+__device__ __forceinline__ void cut8_regs(const f32x16& t, const int first, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    uint32_t w[8][3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cut3(t[first + e], w[e]);
+    u32x4s u[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[s][j] = hi16_pair(w[2 * j][s], w[2 * j + 1][s]);
+    p0 = __builtin_bit_cast(bf16x8, u[0]); p1 = __builtin_bit_cast(bf16x8, u[1]); p2 = __builtin_bit_cast(bf16x8, u[2]);
+}
+// a staged 32 x 64 fp32 tile (load_tile32's registers: thread -> row f >> 4, columns 4 (f & 15) .. + 3) -> three images
+__device__ __forceinline__ void store_tile32_split(bf16_t* __restrict__ img, int tid, const float4 (&rg)[2], int n_valid) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int f = tid + AT_THREADS * jj;
+        const int row = f >> 4;
+        const bool ok = row < n_valid;
+        const float x[4] = {ok ? rg[jj].x : 0.f, ok ? rg[jj].y : 0.f, ok ? rg[jj].z : 0.f, ok ? rg[jj].w : 0.f};
+        uint32_t w[4][3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cut3(x[e], w[e]);
+        bf16_t* dst = img + sl_off(row, (f & 15) << 2);
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            *reinterpret_cast<uint2*>(dst + s * SIMG) = make_uint2(hi16_pair(w[0][s], w[1][s]), hi16_pair(w[2][s], w[3][s]));
+    }
+}
+// ACC += (three K images of one slot)(rows = this tile's 32 keys) . q^T, six piece products, smallest first
+#define SPLIT_QK_TILE(ACC, KIMG)                                                                                          \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                         \
+        const bf16x8 k0 = read_row8(KIMG, lo, 0, s), k1 = read_row8(KIMG + SIMG, lo, 0, s), k2 = read_row8(KIMG + 2 * SIMG, lo, 0, s); \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[0][s], ACC, 0, 0, 0);                                          \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1][s], ACC, 0, 0, 0);                                          \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[2][s], ACC, 0, 0, 0);                                          \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[0][s], ACC, 0, 0, 0);                                          \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[1][s], ACC, 0, 0, 0);                                          \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0][s], ACC, 0, 0, 0);                                          \
+    }
+
+// =============================================================================================
+// forward (attention.hip: attn_fwd_tile, with the split fragments)
+// =============================================================================================
+template <int G, bool DROP, bool ORD, bool SPAN>
+__device__ __forceinline__ void
+attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+              const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
+              const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
+              int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+              float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int pair, const int qtile,
+              const int uspan) {
+    constexpr int NSUB = 4 / G;
+    constexpr int R = NSUB * 32;
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[2][3 * SIMG];      // slot x (three bf16 piece images of 32 keys x 64)
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[2][3 * SIMG];
+    __shared__ __attribute__((aligned(16))) KeyMeta kms[3];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int hg = w / NSUB, sub = w % NSUB;
+    const int b = pair / nkv, kvh = pair % nkv, q0 = qtile * R;
+    const int head = kvh * G + hg;
+    const int r = lane & 31, h = lane >> 5;
+    const SlOffsets lo(lane);
+    const int slot = q0 + sub * 32 + r;                 // sorted slot of this lane's query row
+    const bool valid_q = slot < S;
+    const int slotc = valid_q ? slot : S - 1;
+    const int iq_raw = ORD ? ro.perm[(int64_t)b * S + slotc] : slotc;
+    const int iq = valid_q ? iq_raw : S;                // position in the sequence (S: beyond every key)
+    const int iqc = iq_raw;
+    const int64_t tok = (int64_t)b * S + iqc;
+
+    // scores are kept in the log2 domain: q is pre-scaled by scale*log2(e), p = exp2(s - m_ref)
+    const float qs = scale * 1.4426950408889634f;
+    bf16x8 qf[3][4];                   // piece x k-step: lane (r, h) holds d = 16 s + 8 h .. + 7 of its query row
+    {
+        const float* qrow = q + tok * ldq + head * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float4 a4 = *reinterpret_cast<const float4*>(qrow + 16 * s);
+            float4 b4 = *reinterpret_cast<const float4*>(qrow + 16 * s + 4);
+            a4.x *= qs; a4.y *= qs; a4.z *= qs; a4.w *= qs; b4.x *= qs; b4.y *= qs; b4.z *= qs; b4.w *= qs;
+            cut8(a4, b4, qf[0][s], qf[1][s], qf[2][s]);
+        }
+    }
+    const int my_ql = ql ? ql[tok] : 1;
+    const bool my_empty = valid_q && row_empty[tok] != 0;
+    const bool normal = valid_q && !my_empty;
+    const QuerySpan sp = QuerySpan::load<SPAN>(ro.span, tok, iq_raw, valid_q, S);
+    const int wave_ql_min = wave_min_i32(normal ? my_ql : INT_BIG_A);
+    const int wave_q_lo = wave_min_i32(normal ? sp.hi : INT_BIG_A);   // every key up to here passes every row's limit
+    const bool wave_all_empty = wave_q_lo == INT_BIG_A;          // no normal row: no scores needed at all
+    const int wave_hole_lo = SPAN ? wave_min_i32(normal ? sp.hole_lo : INT_BIG_A) : INT_BIG_A;
+    const int wave_hole_hi = SPAN ? wave_max_i32(normal ? sp.hole_hi : 0) : 0;
+    const int n_all = (S + 31) / 32;
+    int wave_q_hi, n_causal;
+    bool wave_has_empty;
+    if (ORD) {
+        const int64_t tb = (int64_t)b * n_all + (q0 >> 5);
+        const int wt = min(sub, n_all - 1 - (q0 >> 5));          // tiles past the end: reuse the last one
+        wave_q_hi = (q0 + sub * 32 < S) ? ro.tile_maxpos[tb + wt] : -1;
+        wave_has_empty = (q0 + sub * 32 < S) && (ro.tile_kind[tb + wt] & 2) != 0;
+        int hi = -1;
+#pragma unroll
+        for (int ss = 0; ss < NSUB; ++ss)
+            if (q0 + ss * 32 < S) hi = max(hi, ro.tile_maxpos[tb + ss]);
+        n_causal = hi < 0 ? 0 : (hi >> 5) + 1;
+    } else {
+        wave_q_hi = wave_all_empty ? -1 : min(S - 1, q0 + sub * 32 + 31);
+        wave_has_empty = __any(my_empty ? 1 : 0) != 0;
+        n_causal = (min(S, q0 + R) + 31) / 32;
+    }
+    const bool block_has_empty = __syncthreads_or(my_empty ? 1 : 0) != 0;
+    const int n_iter = block_has_empty ? n_all : n_causal;
+    // An empty row is uniform over my_span keys: all S in training (uspan = S); when an evaluation loop re-runs
+    // the whole sequence, over the keys that existed when the reference's cached decode computed the row
+    // (uspan = prompt length for prompt rows, i + 1 for generated rows; model.py:603-617)
+    const int my_span = min(S, max(uspan, iq + 1));
+    const float invS = 1.f / (float)my_span;
+    const AttnDropout rng(p_drop, seed);
+    const uint32_t aw = DROP ? rng.row_word((uint32_t)(((int64_t)b * nq + head) * S + iqc)) : 0u;
+
+    const float* kbase = k + (int64_t)b * S * ldk + kvh * 64;
+    const float* vbase = v + (int64_t)b * S * ldv + kvh * 64;
+    const int32_t* klb = kl + (int64_t)b * S;
+
+    float m_ref = 0.f, l_run = 0.f;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+
+    // K tiles are staged one iteration earlier than V tiles (the scores of tile t+1 are taken at the end of
+    // iteration t): K slot t&1 is loaded two iterations ahead, V slot t&1 one ahead, key metadata ring of 3.
+    float4 rk[2], rv[2];
+    int rmeta;
+    load_tile32(kbase, ldk, 0, S, tid, rk);
+    load_tile32(vbase, ldv, 0, S, tid, rv);
+    rmeta = key_meta_load<DROP>(klb, 0, S, w, lane, rng);
+    store_tile32_split(Ks[0], tid, rk, S);
+    store_tile32_split(Vs[0], tid, rv, S);
+    key_meta_store(kms[0], w, lane, rmeta);
+    if (n_iter > 1) {
+        load_tile32(kbase, ldk, 32, S, tid, rk);
+        rmeta = key_meta_load<DROP>(klb, 32, S, w, lane, rng);
+        store_tile32_split(Ks[1], tid, rk, S - 32);
+        key_meta_store(kms[1], w, lane, rmeta);
+    }
+    __syncthreads();
+
+    f32x16 st_cur;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st_cur[i] = 0.f;
+    if (!(0 > wave_q_hi)) { SPLIT_QK_TILE(st_cur, Ks[0]) }
+    // K(0) must stay intact until every wave has taken its first scores: a wave without work in this tile
+    // (rows past the end of the sequence, or empty rows only) reaches the K(2) store of iteration 0 at once
+    __syncthreads();
+
+    for (int jt = 0; jt < n_iter; ++jt) {
+        const int j0 = jt * 32;
+        const bool have_next = jt + 1 < n_iter;
+        const bool have_next2 = jt + 2 < n_iter;
+        if (have_next2) {
+            load_tile32(kbase, ldk, j0 + 64, S, tid, rk);
+            rmeta = key_meta_load<DROP>(klb, j0 + 64, S, w, lane, rng);
+        }
+        if (have_next) load_tile32(vbase, ldv, j0 + 32, S, tid, rv);
+
+        const bool beyond = j0 > wave_q_hi;                // every key of the tile is in every row's future
+        const bool beyond_next = (j0 + 32) > wave_q_hi;
+        if (!(beyond && !wave_has_empty)) {
+            const KeyMeta& km = kms[jt % 3];
+            const bf16_t* Vc = Vs[jt & 1];
+            const bool full_span = (j0 + 32 <= uspan) || uspan >= S;   // every key of the tile is inside every span
+            // O^T[d][query] += sum_key V[key][d] * P[query][key]   (rows of V past the sequence end are zero).
+            // Called at the end of every variant below so that each one is a straight-line path (a join in
+            // front of the MFMAs costs 16 register copies per tile, and VALU time is not hidden here).
+            auto pv_tile = [&]<bool ONE_PIECE>() {
+                // P (fp32, in registers) cut into three bf16 pieces; ONE_PIECE: every P is 0 or 1 (exact in bf16)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 pf[3];
+                    cut8_regs(st_cur, 8 * s2, pf[0], pf[1], pf[2]);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const bf16x8 v0 = read_tr8(Vc, lo, 16 * s2, db);
+                        const bf16x8 v1 = read_tr8(Vc + SIMG, lo, 16 * s2, db);
+                        const bf16x8 v2 = read_tr8(Vc + 2 * SIMG, lo, 16 * s2, db);
+                        // smallest piece products first: (v0 p2), (v1 p1), (v2 p0), (v0 p1), (v1 p0), (v0 p0)
+                        if (!ONE_PIECE) {
+                            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[2], oacc[db], 0, 0, 0);
+                            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf[1], oacc[db], 0, 0, 0);
+                        }
+                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2, pf[0], oacc[db], 0, 0, 0);
+                        if (!ONE_PIECE) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[1], oacc[db], 0, 0, 0);
+                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf[0], oacc[db], 0, 0, 0);
+                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[0], oacc[db], 0, 0, 0);
+                    }
+                }
+            };
+            // MASK: evaluate the causal + level predicate per element (tiles on the diagonal, tiles holding a
+            // blocked key); EMPTYSEL: some rows of the wave are "empty" rows (p = 1, normalised by 1/S at the end)
+            auto softmax_tile = [&]<bool MASK, bool EMPTYSEL>() {
+                if (MASK) {
+                    int klv[16];
+                    read_key_quads(km.kl, h, klv);
+                    const int t_pos = sp.hi - j0 - 4 * h;        // key (reg&3)+8*(reg>>2) of the tile is <= hi (= iq)
+                    const int t_lo = sp.hole_lo - j0 - 4 * h, t_hi = sp.hole_hi - j0 - 4 * h;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int ko = (reg & 3) + 8 * (reg >> 2);
+                        bool allowed = (ko <= t_pos) & (klv[reg] < my_ql);
+                        if (SPAN) allowed = allowed & !((ko >= t_lo) & (ko < t_hi));
+                        st_cur[reg] = allowed ? st_cur[reg] : -INFINITY;
+                    }
+                }
+                float mloc = st_cur[0];
+#pragma unroll
+                for (int reg = 1; reg < 16; ++reg) mloc = fmaxf(mloc, st_cur[reg]);
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                bool need = (l_run == 0.f) ? (mloc > -INFINITY) : (mloc > RESCALE_TAU);
+                if (EMPTYSEL) need = need && !my_empty;
+                if (__any(need ? 1 : 0)) {
+                    const float d = need ? mloc : 0.f;
+                    const float alpha = (l_run == 0.f) ? 1.f : __builtin_amdgcn_exp2f(-d);
+                    m_ref += d;
+                    l_run *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; st_cur[i] -= d; }
+                }
+                float rowsum = 0.f;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    float pe = __builtin_amdgcn_exp2f(st_cur[reg]);            // masked -> exp2(-inf) = 0
+                    if (EMPTYSEL) {
+                        const float one = (full_span || (j0 + rowmap(reg, h) < my_span)) ? 1.f : 0.f;
+                        pe = my_empty ? one : pe;
+                    }
+                    rowsum += pe;
+                    st_cur[reg] = pe;
+                }
+                rowsum += __shfl_xor(rowsum, 32, 64);
+                l_run += rowsum;
+                if (DROP) {
+                    int kwv[16];
+                    read_key_quads(reinterpret_cast<const int32_t*>(km.kw), h, kwv);
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        st_cur[reg] = rng.keep(aw, (uint32_t)kwv[reg]) ? st_cur[reg] : 0.f;
+                }
+                pv_tile.template operator()<false>();
+            };
+            if (wave_all_empty) {
+                // every row of the wave is an empty row: P = keep / span, no scores, no softmax state
+                if (DROP) {
+                    int kwv[16];
+                    read_key_quads(reinterpret_cast<const int32_t*>(km.kw), h, kwv);
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) st_cur[reg] = rng.keep(aw, (uint32_t)kwv[reg]) ? 1.f : 0.f;
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) st_cur[reg] = 1.f;
+                }
+                if (!full_span) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) st_cur[reg] = (j0 + rowmap(reg, h) < my_span) ? st_cur[reg] : 0.f;
+                }
+                pv_tile.template operator()<true>();
+            } else if (wave_has_empty) {
+                softmax_tile.template operator()<true, true>();
+            } else {
+                const int klmax = __builtin_amdgcn_readfirstlane(km.klmax);
+                const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min) &&
+                                       (!SPAN || j0 + 31 < wave_hole_lo || j0 >= wave_hole_hi);
+                if (free_tile) softmax_tile.template operator()<false, false>();
+                else softmax_tile.template operator()<true, false>();
+            }
+        }
+        if (have_next && !beyond_next) {
+            // scores of the next tile (minus the reference), taken BEFORE the barrier: after it other waves may
+            // already overwrite this K slot with K(jt+3)
+            const float init = -m_ref;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st_cur[i] = init;
+            if ((jt + 1) & 1) { SPLIT_QK_TILE(st_cur, Ks[1]) } else { SPLIT_QK_TILE(st_cur, Ks[0]) }
+        }
+        if (have_next2) {
+            store_tile32_split(Ks[jt & 1], tid, rk, S - (j0 + 64));   // K(jt) is dead: its scores were taken last iteration
+            key_meta_store(kms[(jt + 2) % 3], w, lane, rmeta);
+        }
+        if (have_next) store_tile32_split(Vs[(jt + 1) & 1], tid, rv, S - (j0 + 32));
+        __syncthreads();
+    }
+
+    if (valid_q) {
+        float linv = my_empty ? invS : (l_run > 0.f ? 1.f / l_run : 0.f);
+        if (DROP) linv *= rng.scale;
+        float* orow = o + tok * (int64_t)nq * 64 + head * 64;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 t4;
+                t4.x = oacc[dh][4 * g4 + 0] * linv; t4.y = oacc[dh][4 * g4 + 1] * linv;
+                t4.z = oacc[dh][4 * g4 + 2] * linv; t4.w = oacc[dh][4 * g4 + 3] * linv;
+                *reinterpret_cast<float4*>(orow + 32 * dh + 8 * g4 + 4 * h) = t4;
+            }
+        }
+        // natural-log LSE of the scaled scores (what the backward kernels consume)
+        if (h == 0) lse[((int64_t)b * nq + head) * S + iqc] =
+            my_empty ? 0.f : (m_ref + __log2f(l_run)) * 0.6931471805599453f;
+    }
+}
+
+template <int G, bool DROP, bool ORD, bool SPAN>
+__global__ void __launch_bounds__(AT_THREADS, 2)
+attn_fwd_s_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
+                const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
+                int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+                float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int uspan) {
+    constexpr int R = (4 / G) * 32;
+    const int n_tiles = (S + R - 1) / R;
+    const WorkList wl(nbatch * nkv, n_tiles);
+    if (!wl.valid) return;
+    for (int it = 0;; ++it) {
+        const int pair = wl.pair_at(it);
+        if (pair >= wl.n_pairs) break;
+        // With the row order the tiles of a sequence are NOT a causal ramp (normal rows first: short key ranges, then the
+        // empty rows: all S keys, one product), so "tile u + tile n-1-u" is not equal work for every u: u = 0 pairs a
+        // short tile with a long one, the middle u two long ones.  The workgroups that share a pair still cover every u in
+        // every round, but each takes a different u from round to round: over its ~24 pairs every workgroup sees the mix.
+        const int halves = (n_tiles + 1) >> 1;
+        const int uu = ORD ? (wl.u + it) % halves : wl.u;
+        const int heavy = n_tiles - 1 - uu, light = uu;           // later query tiles see more keys
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {                    // one inlined body (register pressure)
+            if (pass == 1 && light == heavy) break;
+            attn_fwd_s_tile<G, DROP, ORD, SPAN>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed, o, lse,
+                                        ro, pair, pass == 0 ? heavy : light, uspan);
+        }
+    }
+}
+
+
+// =============================================================================================
+// backward: dQ (attention.hip: attn_bwd_dq_tile, with the split fragments; K / V single-buffered, dO pieces in LDS)
+// =============================================================================================
+template <int G, bool DROP, bool ORD, bool SPAN>
+__device__ __forceinline__ void
+attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                   const float* __restrict__ v, int ldv, const float* __restrict__ o, const float* __restrict__ d_o,
+                   const float* __restrict__ lse, float* __restrict__ delta,
+                   const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
+                   const int32_t* __restrict__ row_empty, int S, int nq, int nkv, float scale,
+                   float p_drop, uint64_t seed, float* __restrict__ dq, int lddq, const RowOrder ro, const int pair,
+                   const int qtile, const int delta_ready) {
+    constexpr int NSUB = 4 / G;
+    constexpr int R = NSUB * 32;
+    // K / V: ONE slot of three piece images each (the next tile waits in registers while this one is multiplied); dO: three
+    // piece images of every wave's 32 query rows (the B operand of dP = V dO^T: in registers they would be 48 more VGPRs
+    // next to the 48 of q's pieces).  24 + 24 + 48 KB: two workgroups per CU.
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[3 * SIMG];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[3 * SIMG];
+    __shared__ __attribute__((aligned(16))) bf16_t dOs[4][3 * SIMG];
+    __shared__ __attribute__((aligned(16))) KeyMeta kms[2];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int hg = w / NSUB, sub = w % NSUB;
+    const int b = pair / nkv, kvh = pair % nkv, q0 = qtile * R;
+    const int head = kvh * G + hg;
+    const int r = lane & 31, h = lane >> 5;
+    const SlOffsets lo(lane);
+    const int slot = q0 + sub * 32 + r;                 // sorted slot of this lane's query row
+    const bool valid_q = slot < S;
+    const int slotc = valid_q ? slot : S - 1;
+    const int iq_raw = ORD ? ro.perm[(int64_t)b * S + slotc] : slotc;
+    const int iqc = iq_raw;
+    const int64_t tok = (int64_t)b * S + iqc;
+
+    // log2 domain: q is pre-scaled by scale*log2(e) and the score accumulators start at -lse*log2(e), so
+    // p = exp2(accumulator)
+    const float qs = scale * 1.4426950408889634f;
+    bf16x8 qf[3][4];                      // piece x k-step of the pre-scaled q row (lane = query)
+    float my_delta = 0.f;                 // delta_i = dO_i . O_i: computed here and published for the dK/dV kernel unless ready
+    {
+        const float* qrow = q + tok * ldq + head * 64 + 8 * h;
+        const float* drow = d_o + tok * (int64_t)nq * 64 + head * 64 + 8 * h;
+        const float* orow = o + tok * (int64_t)nq * 64 + head * 64 + 8 * h;
+        bf16_t* dimg = dOs[w];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float4 a4 = *reinterpret_cast<const float4*>(qrow + 16 * s);
+            float4 b4 = *reinterpret_cast<const float4*>(qrow + 16 * s + 4);
+            a4.x *= qs; a4.y *= qs; a4.z *= qs; a4.w *= qs; b4.x *= qs; b4.y *= qs; b4.z *= qs; b4.w *= qs;
+            cut8(a4, b4, qf[0][s], qf[1][s], qf[2][s]);
+            float4 u4 = *reinterpret_cast<const float4*>(drow + 16 * s);
+            float4 w4 = *reinterpret_cast<const float4*>(drow + 16 * s + 4);
+            if (!delta_ready) {
+                const float4 o4 = *reinterpret_cast<const float4*>(orow + 16 * s);
+                const float4 p4 = *reinterpret_cast<const float4*>(orow + 16 * s + 4);
+                my_delta += u4.x * o4.x + u4.y * o4.y + u4.z * o4.z + u4.w * o4.w + w4.x * p4.x + w4.y * p4.y + w4.z * p4.z + w4.w * p4.w;
+            }
+            if (!valid_q) { u4 = make_float4(0.f, 0.f, 0.f, 0.f); w4 = u4; }
+            bf16x8 d0, d1, d2;
+            cut8(u4, w4, d0, d1, d2);
+            // this lane's 8 values are columns 16 s + 8 h .. + 7 of row r: exactly what read_row8 hands back to it
+            *reinterpret_cast<bf16x8*>(dimg + lo.row[s]) = d0;
+            *reinterpret_cast<bf16x8*>(dimg + SIMG + lo.row[s]) = d1;
+            *reinterpret_cast<bf16x8*>(dimg + 2 * SIMG + lo.row[s]) = d2;
+        }
+        if (!delta_ready) {
+            my_delta += __shfl_xor(my_delta, 32, 64);
+            if (valid_q && h == 0) delta[((int64_t)b * nq + head) * S + iqc] = my_delta;
+        } else {
+            my_delta = delta[((int64_t)b * nq + head) * S + iqc];
+        }
+    }
+    const int my_ql = ql ? ql[tok] : 1;
+    const bool my_empty = valid_q && row_empty[tok] != 0;
+    const bool normal = valid_q && !my_empty;
+    const QuerySpan sp = QuerySpan::load<SPAN>(ro.span, tok, iq_raw, valid_q, S);
+    const float neg_lse2 = -lse[((int64_t)b * nq + head) * S + iqc] * 1.4426950408889634f;
+    const int wave_ql_min = wave_min_i32(normal ? my_ql : INT_BIG_A);
+    const int wave_q_lo = wave_min_i32(normal ? sp.hi : INT_BIG_A);
+    const bool wave_all_empty = wave_q_lo == INT_BIG_A;
+    const int wave_hole_lo = SPAN ? wave_min_i32(normal ? sp.hole_lo : INT_BIG_A) : INT_BIG_A;
+    const int wave_hole_hi = SPAN ? wave_max_i32(normal ? sp.hole_hi : 0) : 0;
+    const int n_all = (S + 31) / 32;
+    int wave_q_hi, n_causal;
+    bool wave_has_empty;
+    if (ORD) {
+        const int64_t tb = (int64_t)b * n_all + (q0 >> 5);
+        const int wt = min(sub, n_all - 1 - (q0 >> 5));          // tiles past the end: reuse the last one
+        wave_q_hi = (q0 + sub * 32 < S) ? ro.tile_maxpos[tb + wt] : -1;
+        wave_has_empty = (q0 + sub * 32 < S) && (ro.tile_kind[tb + wt] & 2) != 0;
+        int hi = -1;
+#pragma unroll
+        for (int ss = 0; ss < NSUB; ++ss)
+            if (q0 + ss * 32 < S) hi = max(hi, ro.tile_maxpos[tb + ss]);
+        n_causal = hi < 0 ? 0 : (hi >> 5) + 1;
+    } else {
+        wave_q_hi = wave_all_empty ? -1 : min(S - 1, q0 + sub * 32 + 31);
+        wave_has_empty = __any(my_empty ? 1 : 0) != 0;
+        n_causal = (min(S, q0 + R) + 31) / 32;
+    }
+    const bool block_has_empty = __syncthreads_or(my_empty ? 1 : 0) != 0;
+    const int n_iter = block_has_empty ? n_all : n_causal;
+    const float invS = 1.f / (float)S;
+    const AttnDropout rng(p_drop, seed);
+    const uint32_t aw = DROP ? rng.row_word((uint32_t)(((int64_t)b * nq + head) * S + iqc)) : 0u;
+    const float sd = rng.scale;
+    const float neg_delta = -my_delta;
+
+    const float* kbase = k + (int64_t)b * S * ldk + kvh * 64;
+    const float* vbase = v + (int64_t)b * S * ldv + kvh * 64;
+    const int32_t* klb = kl + (int64_t)b * S;
+
+    f32x16 dqacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
+
+    float4 rk[2], rv[2];
+    int rmeta;
+    load_tile32(kbase, ldk, 0, S, tid, rk);
+    load_tile32(vbase, ldv, 0, S, tid, rv);
+    rmeta = key_meta_load<DROP>(klb, 0, S, w, lane, rng);
+
+    for (int jt = 0; jt < n_iter; ++jt) {
+        const int cur = jt & 1;
+        const bool more = jt + 1 < n_iter;
+        const int j0 = jt * 32;
+        __syncthreads();                              // the previous tile has been consumed by every wave
+        store_tile32_split(Ks, tid, rk, S - j0);
+        store_tile32_split(Vs, tid, rv, S - j0);
+        key_meta_store(kms[cur], w, lane, rmeta);
+        __syncthreads();
+        if (more) {                                   // in flight while this tile is multiplied
+            load_tile32(kbase, ldk, j0 + 32, S, tid, rk);
+            load_tile32(vbase, ldv, j0 + 32, S, tid, rv);
+            rmeta = key_meta_load<DROP>(klb, j0 + 32, S, w, lane, rng);
+        }
+        const bool beyond = j0 > wave_q_hi;
+        if (!(beyond && !wave_has_empty)) {
+            const KeyMeta& km = kms[cur];
+            f32x16 st, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { st[i] = neg_lse2; dp[i] = 0.f; }
+            // S^T = K Q^T and dP^T[key][query] = sum_d V[key][d] dO[query][d]: two independent accumulation chains,
+            // issued alternately (a single dependent chain of this MFMA runs 5-13 % below the pipe rate)
+            const bf16_t* dimg = dOs[w];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 v0 = read_row8(Vs, lo, 0, s), v1 = read_row8(Vs + SIMG, lo, 0, s), v2 = read_row8(Vs + 2 * SIMG, lo, 0, s);
+                const bf16x8 d0 = read_row8(dimg, lo, 0, s), d1 = read_row8(dimg + SIMG, lo, 0, s), d2 = read_row8(dimg + 2 * SIMG, lo, 0, s);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2, d0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, d1, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, d2, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, d0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, d1, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, d0, dp, 0, 0, 0);
+            }
+            if (!beyond) { SPLIT_QK_TILE(st, Ks) }
+            __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of the later phases below this point
+            // u = mult * dP - delta  (mult = keep / (1 - p))
+            if (DROP) {
+                int kwv[16];
+                read_key_quads(reinterpret_cast<const int32_t*>(km.kw), h, kwv);
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float t = rng.keep(aw, (uint32_t)kwv[reg]) ? dp[reg] : 0.f;
+                    dp[reg] = fmaf(t, sd, neg_delta);
+                }
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) dp[reg] += neg_delta;
+            }
+            // dQ^T[d][query] += sum_key K[key][d] dS^T[key][query]   (rows of K past the sequence end are zero)
+            auto dq_tile = [&](const f32x16& ds) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 df[3];
+                    cut8_regs(ds, 8 * s2, df[0], df[1], df[2]);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const bf16x8 k0 = read_tr8(Ks, lo, 16 * s2, db);
+                        const bf16x8 k1 = read_tr8(Ks + SIMG, lo, 16 * s2, db);
+                        const bf16x8 k2 = read_tr8(Ks + 2 * SIMG, lo, 16 * s2, db);
+                        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, df[2], dqacc[db], 0, 0, 0);
+                        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, df[1], dqacc[db], 0, 0, 0);
+                        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, df[0], dqacc[db], 0, 0, 0);
+                        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, df[1], dqacc[db], 0, 0, 0);
+                        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, df[0], dqacc[db], 0, 0, 0);
+                        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, df[0], dqacc[db], 0, 0, 0);
+                    }
+                }
+            };
+            // dS^T = p * u ; an empty row has p = 1 here and 1/S in the final scale
+            auto ds_tile = [&]<bool MASK, bool EMPTYSEL>() {
+                if (MASK) {
+                    int klv[16];
+                    read_key_quads(km.kl, h, klv);
+                    const int t_pos = sp.hi - j0 - 4 * h;
+                    const int t_lo = sp.hole_lo - j0 - 4 * h, t_hi = sp.hole_hi - j0 - 4 * h;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int ko = (reg & 3) + 8 * (reg >> 2);
+                        bool allowed = (ko <= t_pos) & (klv[reg] < my_ql);
+                        if (SPAN) allowed = allowed & !((ko >= t_lo) & (ko < t_hi));
+                        st[reg] = allowed ? st[reg] : -INFINITY;
+                    }
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    float pe = __builtin_amdgcn_exp2f(st[reg]);
+                    if (EMPTYSEL) pe = my_empty ? 1.f : pe;
+                    st[reg] = pe * dp[reg];
+                }
+            };
+            if (wave_all_empty) {
+                st = dp;
+            } else if (wave_has_empty) {
+                ds_tile.template operator()<true, true>();
+            } else {
+                const int klmax = __builtin_amdgcn_readfirstlane(km.klmax);
+                const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min) &&
+                                       (!SPAN || j0 + 31 < wave_hole_lo || j0 >= wave_hole_hi);
+                if (free_tile) ds_tile.template operator()<false, false>();
+                else ds_tile.template operator()<true, false>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            dq_tile(st);
+        }
+    }
+
+    if (valid_q) {
+        const float fs = my_empty ? scale * invS : scale;
+        float* drow = dq + tok * lddq + head * 64;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 t4;
+                t4.x = dqacc[dh][4 * g4 + 0] * fs; t4.y = dqacc[dh][4 * g4 + 1] * fs;
+                t4.z = dqacc[dh][4 * g4 + 2] * fs; t4.w = dqacc[dh][4 * g4 + 3] * fs;
+                *reinterpret_cast<float4*>(drow + 32 * dh + 8 * g4 + 4 * h) = t4;
+            }
+        }
+    }
+}
+
+template <int G, bool DROP, bool ORD, bool SPAN>
+__global__ void __launch_bounds__(AT_THREADS, 2)
+attn_bwd_dq_s_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                   const float* __restrict__ v, int ldv, const float* __restrict__ o, const float* __restrict__ d_o,
+                   const float* __restrict__ lse, float* __restrict__ delta,
+                   const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
+                   const int32_t* __restrict__ row_empty, int nbatch, int S, int nq, int nkv, float scale,
+                   float p_drop, uint64_t seed, float* __restrict__ dq, int lddq, const RowOrder ro, const int delta_ready) {
+    constexpr int R = (4 / G) * 32;
+    const int n_tiles = (S + R - 1) / R;
+    const WorkList wl(nbatch * nkv, n_tiles);
+    if (!wl.valid) return;
+    for (int it = 0;; ++it) {
+        const int pair = wl.pair_at(it);
+        if (pair >= wl.n_pairs) break;
+        const int heavy = n_tiles - 1 - wl.u, light = wl.u;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1 && light == heavy) break;
+            attn_bwd_dq_s_tile<G, DROP, ORD, SPAN>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, S, nq, nkv, scale,
+                                           p_drop, seed, dq, lddq, ro, pair, pass == 0 ? heavy : light, delta_ready);
+        }
+    }
+}
+
+
+// =============================================================================================
+// backward: dK, dV (attention.hip: attn_bwd_dkv_tile without the dS spill, with the split fragments)
+// =============================================================================================
+// Workgroup = 4 G waves (G = 2: 512 threads), 128 keys of one (sequence, kv head): wave = (query head hg, 32 keys).
+// LDS: the workgroup's K and V rows as three piece images each (96 KB: they are the B operands of S = Q K^T and
+// dP = dO V^T for every query tile), the staged query tile's Q and dO images per head (12 KB each), per-query scalars.
+// 144 KB at G = 2: ONE workgroup per CU, eight waves = two per SIMD, as the two four-wave workgroups of the fp32 form.
+constexpr int DKV_S_KEYS = 128;
+template <int G>
+struct DkvSmemS {
+    bf16_t Kt[3][DKV_S_KEYS * 64];
+    bf16_t Vt[3][DKV_S_KEYS * 64];
+    bf16_t Qs[G][3 * SIMG];
+    bf16_t dOs[G][3 * SIMG];
+    float nlse2_s[G][32];       // -lse * log2(e) of the staged query rows
+    float ndelta_s[G][32];      // -delta
+    uint32_t aw_s[G][32];       // dropout row words
+    int32_t ql_s[32];
+    int32_t empty_s[32];
+    int32_t pos_s[32];          // key limit of the staged query rows: their position, S past the end
+    int32_t qlmin;              // smallest query level / key limit over the normal rows of the tile (INT_MAX: none)
+    int32_t posmin;
+};
+
+template <int G, bool DROP, bool ORD>
+__device__ __forceinline__ void
+attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                    const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
+                    const float* __restrict__ lse, const float* __restrict__ delta,
+                    const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
+                    const int32_t* __restrict__ row_empty, const int32_t* __restrict__ tile_empty,
+                    int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+                    float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const RowOrder ro, const int pair,
+                    const int ktile) {
+    constexpr int THREADS = 256 * G;
+    constexpr int R = DKV_S_KEYS;
+    constexpr int NLD = 512 / THREADS;               // float4 per thread, tensor and head of a staged 32 x 64 tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char dkvs_raw[];
+    DkvSmemS<G>& sm = *reinterpret_cast<DkvSmemS<G>*>(dkvs_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int hg = w >> 2, sub = w & 3;
+    __syncthreads();                 // the previous item's head reduction may still be reading the LDS region
+    const int b = pair / nkv, kvh = pair % nkv, k0 = ktile * R;
+    const int r = lane & 31, h = lane >> 5;
+    const SlOffsets lo(lane);
+    const int jk = k0 + sub * 32 + r;                 // this lane's key
+    const bool valid_k = jk < S;
+    const int jkc = valid_k ? jk : S - 1;
+    const int64_t ktok = (int64_t)b * S + jkc;
+
+    // stage this workgroup's K and V rows once: cut into the three piece images (zero rows past the end of the sequence)
+    for (int f = tid; f < R * 16; f += THREADS) {
+        const int row = f >> 4, c4 = (f & 15) << 2;
+        const int j = k0 + row;
+        float4 kv4 = make_float4(0.f, 0.f, 0.f, 0.f), vv4 = kv4;
+        if (j < S) {
+            kv4 = *reinterpret_cast<const float4*>(k + ((int64_t)b * S + j) * ldk + kvh * 64 + c4);
+            vv4 = *reinterpret_cast<const float4*>(v + ((int64_t)b * S + j) * ldv + kvh * 64 + c4);
+        }
+        const float xk[4] = {kv4.x, kv4.y, kv4.z, kv4.w}, xv[4] = {vv4.x, vv4.y, vv4.z, vv4.w};
+        uint32_t wk[4][3], wv[4][3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cut3(xk[e], wk[e]); cut3(xv[e], wv[e]); }
+        const int off = sl_off(row, c4);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            *reinterpret_cast<uint2*>(sm.Kt[s] + off) = make_uint2(hi16_pair(wk[0][s], wk[1][s]), hi16_pair(wk[2][s], wk[3][s]));
+            *reinterpret_cast<uint2*>(sm.Vt[s] + off) = make_uint2(hi16_pair(wv[0][s], wv[1][s]), hi16_pair(wv[2][s], wv[3][s]));
+        }
+    }
+    const int my_kl = valid_k ? kl[ktok] : INT_BIG_A;
+    const int wave_kl_max = wave_max_i32(my_kl);
+    const int wave_k_lo = k0 + sub * 32, wave_k_hi = wave_k_lo + 31;
+    const float invS = 1.f / (float)S;
+    const float c2 = scale * 1.4426950408889634f;
+    const AttnDropout rng(p_drop, seed);
+    const uint32_t bw = DROP ? rng.key_word((uint32_t)jk) : 0u;
+    const float sd = rng.scale;
+    const uint32_t drop_head0 = (uint32_t)(((int64_t)b * nq + kvh * G) * S);
+
+    const int n_qt = (S + 31) / 32;
+    const int32_t* te = tile_empty + (int64_t)b * n_qt;
+    const int32_t* tkind = ORD ? ro.tile_kind + (int64_t)b * n_qt : nullptr;
+    const int32_t* tmax = ORD ? ro.tile_maxpos + (int64_t)b * n_qt : nullptr;
+    const int32_t* pmap = ORD ? ro.perm + (int64_t)b * S : nullptr;
+    // a query tile matters to this key tile if it has an empty row (attends every key) or a normal row at
+    // or after the first key
+    auto tile_empty_rows = [&](int qt) { return ORD ? (tkind[qt] & 2) != 0 : te[qt] != 0; };
+    auto tile_last_pos = [&](int qt) { return ORD ? tmax[qt] : min(S - 1, qt * 32 + 31); };
+
+    f32x16 dkacc[2], dvacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dkacc[0][i] = 0.f; dkacc[1][i] = 0.f; dvacc[0][i] = 0.f; dvacc[1][i] = 0.f; }
+
+    // staged registers: per head one Q tile and one dO tile (NLD float4 each per thread); the NEXT tile's loads are in
+    // flight while the current one is multiplied
+    float4 rq[G][NLD], rdo[G][NLD];
+    float rl = 0.f, rd = 0.f;
+    uint32_t raw = 0;
+    int rql = 1, rem = 0, rpos = 0;
+
+    auto next_tile = [&](int qt) {
+        while (qt < n_qt && !tile_empty_rows(qt) && tile_last_pos(qt) < k0) ++qt;
+        return qt;
+    };
+    auto load_q_tile = [&](int qt) {
+        const int i0 = qt * 32;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int hd = kvh * G + g;
+#pragma unroll
+            for (int jj = 0; jj < NLD; ++jj) {
+                const int f = tid + THREADS * jj;
+                const int sl = min(i0 + (f >> 4), S - 1);
+                const int pos = ORD ? pmap[sl] : sl;
+                rq[g][jj] = *reinterpret_cast<const float4*>(q + ((int64_t)b * S + pos) * ldq + hd * 64 + ((f & 15) << 2));
+                rdo[g][jj] = *reinterpret_cast<const float4*>(d_o + ((int64_t)b * S + pos) * (int64_t)nq * 64 + hd * 64 + ((f & 15) << 2));
+            }
+        }
+        // per-query scalars: waves 0 .. G-1 take (g = wave, row = lane & 31); both lane halves compute the same values
+        if (w < G) {
+            const int g = w, row = lane & 31;
+            const int sl = i0 + row;
+            const bool in = sl < S;
+            const int i = in ? (ORD ? pmap[sl] : sl) : 0;          // position of the row
+            const int hd = kvh * G + g;
+            rl = in ? -lse[((int64_t)b * nq + hd) * S + i] * 1.4426950408889634f : 0.f;
+            rd = in ? -delta[((int64_t)b * nq + hd) * S + i] : 0.f;
+            if (DROP) raw = rng.row_word(drop_head0 + (uint32_t)(g * S + i));
+            if (g == 0) {
+                rql = in ? (ql ? ql[(int64_t)b * S + i] : 1) : 0;
+                rem = in ? row_empty[(int64_t)b * S + i] : 0;
+                rpos = in ? i : S;
+            }
+        }
+    };
+    auto store_q_tile = [&](int qt) {
+        const int n_valid = S - qt * 32;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int jj = 0; jj < NLD; ++jj) {
+                const int f = tid + THREADS * jj;
+                const int row = f >> 4;
+                const bool ok = row < n_valid;
+                const float4 a = rq[g][jj], c = rdo[g][jj];
+                const float xa[4] = {ok ? a.x : 0.f, ok ? a.y : 0.f, ok ? a.z : 0.f, ok ? a.w : 0.f};
+                const float xc[4] = {ok ? c.x : 0.f, ok ? c.y : 0.f, ok ? c.z : 0.f, ok ? c.w : 0.f};
+                uint32_t wa[4][3], wc[4][3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { cut3(xa[e], wa[e]); cut3(xc[e], wc[e]); }
+                const int off = sl_off(row, (f & 15) << 2);
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    *reinterpret_cast<uint2*>(sm.Qs[g] + s * SIMG + off) = make_uint2(hi16_pair(wa[0][s], wa[1][s]), hi16_pair(wa[2][s], wa[3][s]));
+                    *reinterpret_cast<uint2*>(sm.dOs[g] + s * SIMG + off) = make_uint2(hi16_pair(wc[0][s], wc[1][s]), hi16_pair(wc[2][s], wc[3][s]));
+                }
+            }
+        if (w < G) {
+            const int g = w, row = lane & 31;
+            int qlmin = 0, posmin = 0;
+            if (g == 0) {
+                const bool in = qt * 32 + row < S;
+                const bool normal = in && rem == 0;
+                qlmin = wave_min_i32(normal ? rql : INT_BIG_A);
+                posmin = wave_min_i32(normal ? rpos : INT_BIG_A);
+            }
+            if (lane < 32) {
+                sm.nlse2_s[g][row] = rl;
+                sm.ndelta_s[g][row] = rd;
+                if (DROP) sm.aw_s[g][row] = raw;
+                if (g == 0) {
+                    sm.ql_s[row] = rql; sm.empty_s[row] = rem; sm.pos_s[row] = rpos;
+                    if (row == 0) { sm.qlmin = qlmin; sm.posmin = posmin; }
+                }
+            }
+        }
+    };
+
+    int qt = next_tile(0);
+    if (qt < n_qt) load_q_tile(qt);
+    while (qt < n_qt) {
+        __syncthreads();                 // previous tile fully consumed (and K/V staging visible)
+        store_q_tile(qt);
+        __syncthreads();
+        const bool tile_has_empty = tile_empty_rows(qt);
+        const int qt_next = next_tile(qt + 1);
+        if (qt_next < n_qt) load_q_tile(qt_next);
+        const int posmin = __builtin_amdgcn_readfirstlane(sm.posmin);
+        const int qlmin = __builtin_amdgcn_readfirstlane(sm.qlmin);
+        const bool tile_all_empty = tile_has_empty && posmin == INT_BIG_A;
+
+        const bool before = tile_last_pos(qt) < wave_k_lo;   // every normal query of the tile precedes this wave's keys
+        if (!(before && !tile_has_empty)) {
+            f32x16 st, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+            const bf16_t* Qh = sm.Qs[hg];
+            const bf16_t* dOh = sm.dOs[hg];
+            // S[query][key] = sum_d Q[query][d] K[key][d] and dP[query][key] = sum_d dO[query][d] V[key][d]; six piece
+            // products each, smallest first
+            const bool need_s = !before && !tile_all_empty;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 c0 = read_row8(dOh, lo, 0, s), c1 = read_row8(dOh + SIMG, lo, 0, s), c2p = read_row8(dOh + 2 * SIMG, lo, 0, s);
+                const bf16x8 v0 = read_row8(sm.Vt[0], lo, 32 * sub, s), v1 = read_row8(sm.Vt[1], lo, 32 * sub, s), v2 = read_row8(sm.Vt[2], lo, 32 * sub, s);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2p, v0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, v1, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, v2, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, v0, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, v1, dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, v0, dp, 0, 0, 0);
+                if (need_s) {
+                    const bf16x8 a0 = read_row8(Qh, lo, 0, s), a1 = read_row8(Qh + SIMG, lo, 0, s), a2 = read_row8(Qh + 2 * SIMG, lo, 0, s);
+                    const bf16x8 b0 = read_row8(sm.Kt[0], lo, 32 * sub, s), b1 = read_row8(sm.Kt[1], lo, 32 * sub, s), b2 = read_row8(sm.Kt[2], lo, 32 * sub, s);
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, st, 0, 0, 0);
+                }
+            }
+            // per element (query = register, key = lane):  P -> st (for dV, 1/(1-p) applied at the end),
+            //                                               dS -> dp (for dK)
+            // Rows past the end of the sequence have Q = dO = 0, lse = delta = 0: p = 1 but dS = 0 and dO = 0.
+            auto elem_tile = [&]<bool MASK, bool EMPTYSEL, bool ALL_EMPTY>() {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int qb = 8 * g4 + 4 * h;
+                    const float4 d4 = *reinterpret_cast<const float4*>(&sm.ndelta_s[hg][qb]);
+                    const float ndl[4] = {d4.x, d4.y, d4.z, d4.w};
+                    float nl[4] = {0.f, 0.f, 0.f, 0.f};
+                    int qlv[4] = {0, 0, 0, 0}, posv[4] = {0, 0, 0, 0}, emv[4] = {0, 0, 0, 0};
+                    uint32_t awv[4] = {0, 0, 0, 0};
+                    if (!ALL_EMPTY) {
+                        const float4 l4 = *reinterpret_cast<const float4*>(&sm.nlse2_s[hg][qb]);
+                        nl[0] = l4.x; nl[1] = l4.y; nl[2] = l4.z; nl[3] = l4.w;
+                    }
+                    if (MASK) {
+                        const int4 q4 = *reinterpret_cast<const int4*>(&sm.ql_s[qb]);
+                        const int4 p4 = *reinterpret_cast<const int4*>(&sm.pos_s[qb]);
+                        qlv[0] = q4.x; qlv[1] = q4.y; qlv[2] = q4.z; qlv[3] = q4.w;
+                        posv[0] = p4.x; posv[1] = p4.y; posv[2] = p4.z; posv[3] = p4.w;
+                    }
+                    if (EMPTYSEL) {
+                        const int4 e4 = *reinterpret_cast<const int4*>(&sm.empty_s[qb]);
+                        emv[0] = e4.x; emv[1] = e4.y; emv[2] = e4.z; emv[3] = e4.w;
+                    }
+                    if (DROP) {
+                        const uint4 a4 = *reinterpret_cast<const uint4*>(&sm.aw_s[hg][qb]);
+                        awv[0] = a4.x; awv[1] = a4.y; awv[2] = a4.z; awv[3] = a4.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int reg = 4 * g4 + e;
+                        float pe;
+                        if (ALL_EMPTY) {
+                            pe = invS;
+                        } else {
+                            pe = __builtin_amdgcn_exp2f(fmaf(st[reg], c2, nl[e]));
+                            if (MASK) {
+                                const bool allowed = (jk <= posv[e]) & (my_kl < qlv[e]);
+                                pe = allowed ? pe : 0.f;
+                            }
+                            if (EMPTYSEL) pe = (emv[e] != 0) ? invS : pe;
+                        }
+                        if (DROP) {
+                            const bool keep = rng.keep(awv[e], bw);
+                            const float t = keep ? dp[reg] : 0.f;
+                            dp[reg] = pe * fmaf(t, sd, ndl[e]);          // dS[query][key]
+                            st[reg] = keep ? pe : 0.f;                   // dropped P[query][key] * (1 - p)
+                        } else {
+                            dp[reg] = pe * (dp[reg] + ndl[e]);
+                            st[reg] = pe;
+                        }
+                    }
+                }
+            };
+            if (tile_all_empty) {
+                elem_tile.template operator()<false, false, true>();
+            } else if (tile_has_empty) {
+                elem_tile.template operator()<true, true, false>();
+            } else {
+                const bool free_tile = (posmin >= wave_k_hi) && (wave_kl_max < qlmin);
+                if (free_tile) elem_tile.template operator()<false, false, false>();
+                else elem_tile.template operator()<true, false, false>();
+            }
+            // dV^T[d][key] += sum_query dO[query][d] Pd[query][key] ; dK^T[d][key] += sum_query Q[query][d] dS[query][key]
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf[3], df[3];
+                cut8_regs(st, 8 * s2, pf[0], pf[1], pf[2]);
+                cut8_regs(dp, 8 * s2, df[0], df[1], df[2]);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8 o0 = read_tr8(dOh, lo, 16 * s2, db), o1 = read_tr8(dOh + SIMG, lo, 16 * s2, db), o2 = read_tr8(dOh + 2 * SIMG, lo, 16 * s2, db);
+                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o0, pf[2], dvacc[db], 0, 0, 0);
+                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1, pf[1], dvacc[db], 0, 0, 0);
+                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o2, pf[0], dvacc[db], 0, 0, 0);
+                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o0, pf[1], dvacc[db], 0, 0, 0);
+                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1, pf[0], dvacc[db], 0, 0, 0);
+                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o0, pf[0], dvacc[db], 0, 0, 0);
+                    const bf16x8 q0 = read_tr8(Qh, lo, 16 * s2, db), q1 = read_tr8(Qh + SIMG, lo, 16 * s2, db), q2 = read_tr8(Qh + 2 * SIMG, lo, 16 * s2, db);
+                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0, df[2], dkacc[db], 0, 0, 0);
+                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1, df[1], dkacc[db], 0, 0, 0);
+                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q2, df[0], dkacc[db], 0, 0, 0);
+                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0, df[1], dkacc[db], 0, 0, 0);
+                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1, df[0], dkacc[db], 0, 0, 0);
+                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0, df[0], dkacc[db], 0, 0, 0);
+                }
+            }
+        }
+        qt = qt_next;
+    }
+
+    // ---- sum the G query heads of this kv head through LDS, then store ---------------------------
+    // LDS image [sub][key 32][132] floats (dK 64 | dV 64) reuses the tile region.
+    float* red = reinterpret_cast<float*>(dkvs_raw);
+#pragma unroll
+    for (int gsrc = G - 1; gsrc >= 1; --gsrc) {
+        __syncthreads();
+        if (hg == gsrc) {
+            float* dst = red + (sub * 32 + r) * 132;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d = 32 * dh + 8 * g4 + 4 * h;
+                    *reinterpret_cast<float4*>(dst + d) = make_float4(dkacc[dh][4 * g4], dkacc[dh][4 * g4 + 1],
+                                                                      dkacc[dh][4 * g4 + 2], dkacc[dh][4 * g4 + 3]);
+                    *reinterpret_cast<float4*>(dst + 64 + d) = make_float4(dvacc[dh][4 * g4], dvacc[dh][4 * g4 + 1],
+                                                                           dvacc[dh][4 * g4 + 2], dvacc[dh][4 * g4 + 3]);
+                }
+        }
+        __syncthreads();
+        if (hg == 0) {
+            const float* src = red + (sub * 32 + r) * 132;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d = 32 * dh + 8 * g4 + 4 * h;
+                    const float4 a = *reinterpret_cast<const float4*>(src + d);
+                    const float4 c = *reinterpret_cast<const float4*>(src + 64 + d);
+                    dkacc[dh][4 * g4] += a.x; dkacc[dh][4 * g4 + 1] += a.y; dkacc[dh][4 * g4 + 2] += a.z; dkacc[dh][4 * g4 + 3] += a.w;
+                    dvacc[dh][4 * g4] += c.x; dvacc[dh][4 * g4 + 1] += c.y; dvacc[dh][4 * g4 + 2] += c.z; dvacc[dh][4 * g4 + 3] += c.w;
+                }
+        }
+    }
+    if (hg == 0 && valid_k) {
+        float* dkrow = dk + ktok * lddk + kvh * 64;
+        float* dvrow = dv + ktok * lddv + kvh * 64;
+        const float vs = DROP ? sd : 1.f;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * dh + 8 * g4 + 4 * h;
+                *reinterpret_cast<float4*>(dkrow + d) = make_float4(dkacc[dh][4 * g4] * scale, dkacc[dh][4 * g4 + 1] * scale,
+                                                                    dkacc[dh][4 * g4 + 2] * scale, dkacc[dh][4 * g4 + 3] * scale);
+                *reinterpret_cast<float4*>(dvrow + d) = make_float4(dvacc[dh][4 * g4] * vs, dvacc[dh][4 * g4 + 1] * vs,
+                                                                    dvacc[dh][4 * g4 + 2] * vs, dvacc[dh][4 * g4 + 3] * vs);
+            }
+    }
+}
+
+// one workgroup per CU: the work list hands out (heavy key tile + light key tile) items, 32 slots per XCD
+static inline int worklist_grid_1(int n_pairs, int n_tiles) {
+    const int halves = (n_tiles + 1) / 2;
+    int per_xcd = (n_pairs + 7) / 8;
+    int rounds_cap = 32 / halves;
+    if (rounds_cap < 1) rounds_cap = 1;
+    const int ppr = per_xcd < rounds_cap ? per_xcd : rounds_cap;
+    return 8 * ppr * halves;
+}
+
+template <int G, bool DROP, bool ORD>
+__global__ void __launch_bounds__(256 * G, 1)
+attn_bwd_dkv_s_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                      const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
+                      const float* __restrict__ lse, const float* __restrict__ delta,
+                      const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
+                      const int32_t* __restrict__ row_empty, const int32_t* __restrict__ tile_empty,
+                      int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+                      float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const RowOrder ro) {
+    const int n_tiles = (S + DKV_S_KEYS - 1) / DKV_S_KEYS;
+    const WorkList wl(nbatch * nkv, n_tiles);
+    if (!wl.valid) return;
+    for (int it = 0;; ++it) {
+        const int pair = wl.pair_at(it);
+        if (pair >= wl.n_pairs) break;
+        const int heavy = wl.u, light = n_tiles - 1 - wl.u;       // earlier key tiles are seen by more queries
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1 && light == heavy) break;
+            attn_bwd_dkv_s_tile<G, DROP, ORD>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv,
+                                              scale, p_drop, seed, dk, lddk, dv, lddv, ro, pair, pass == 0 ? heavy : light);
+        }
+    }
+}
+
+template <int G>
+static int launch_fwd_s(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl,
+                        const int32_t* ql, const int32_t* row_empty, int B, int S, int nq, int nkv, float scale,
+                        float p_drop, uint64_t seed, float* o, float* lse, RowOrder ro, hipStream_t st) {
+    constexpr int R = (4 / G) * 32;
+    dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
+#define GAMER_LAUNCH_FWD_S(DROPV, ORDV)                                                                                    \
+    hipLaunchKernelGGL((attn_fwd_s_kernel<G, DROPV, ORDV, false>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv,    \
+                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, S)
+    if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD_S(true, true); else GAMER_LAUNCH_FWD_S(true, false); }
+    else { if (ro.perm) GAMER_LAUNCH_FWD_S(false, true); else GAMER_LAUNCH_FWD_S(false, false); }
+#undef GAMER_LAUNCH_FWD_S
+    GAMER_CHECK_LAUNCH("gamer_attn_fwd_split");
+    return 0;
+}
+
+template <int G, bool DROP, bool ORD>
+static int launch_bwd_s_variant(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                                const float* d_o, const float* lse, float* delta, const int32_t* kl, const int32_t* ql,
+                                const int32_t* row_empty, const int32_t* tile_empty, int B, int S, int nq, int nkv,
+                                float scale, float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk,
+                                float* dv, int lddv, RowOrder ro, int delta_ready, hipStream_t st) {
+    constexpr int R = (4 / G) * 32;
+    hipLaunchKernelGGL((attn_bwd_dq_s_kernel<G, DROP, ORD, false>), dim3(worklist_grid(B * nkv, (S + R - 1) / R)), dim3(AT_THREADS),
+                       0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed,
+                       dq, lddq, ro, delta_ready);
+    GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dq");
+    const size_t shmem = sizeof(DkvSmemS<G>);
+    static bool attr_dev[MAX_DEVICES] = {};   // one set of flags per template instantiation, one flag per device
+    bool& attr_set = attr_dev[current_device()];
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_s_kernel<G, DROP, ORD>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) {
+            set_error("gamer_attn_bwd_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    const int n_kt = (S + DKV_S_KEYS - 1) / DKV_S_KEYS;
+    hipLaunchKernelGGL((attn_bwd_dkv_s_kernel<G, DROP, ORD>), dim3(worklist_grid_1(B * nkv, n_kt)), dim3(256 * G), shmem, st, q, ldq,
+                       k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk,
+                       lddk, dv, lddv, ro);
+    GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dkv");
+    return 0;
+}
+
+template <int G>
+static int launch_bwd_s(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                        const float* d_o, const float* lse, float* delta, const int32_t* kl, const int32_t* ql,
+                        const int32_t* row_empty, const int32_t* tile_empty, int B, int S, int nq, int nkv, float scale,
+                        float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                        RowOrder ro, int delta_ready, hipStream_t st) {
+#define GAMER_LAUNCH_BWD_S(DROPV, ORDV)                                                                                       \
+    return launch_bwd_s_variant<G, DROPV, ORDV>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, \
+                                                nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, st)
+    if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_BWD_S(true, true); else GAMER_LAUNCH_BWD_S(true, false); }
+    else { if (ro.perm) GAMER_LAUNCH_BWD_S(false, true); else GAMER_LAUNCH_BWD_S(false, false); }
+#undef GAMER_LAUNCH_BWD_S
+    return -1;      // not reached
+}
+
+}  // namespace gamer
+
+using namespace gamer;
+
+static int check_attn_split(const char* name, const void* q, const void* k, const void* v, const void* kl,
+                            const void* row_empty, int ldq, int ldk, int ldv, int B, int S, int nq, int nkv, float p_drop) {
+    GAMER_CHECK_ARG(q && k && v && kl && row_empty, "%s: null pointer", name);
+    GAMER_CHECK_ARG(B > 0 && S > 0 && nq > 0 && nkv > 0 && nq % nkv == 0, "%s: bad shape B=%d S=%d nq=%d nkv=%d", name, B, S, nq, nkv);
+    const int G = nq / nkv;
+    GAMER_CHECK_ARG(G == 1 || G == 2, "%s: GQA group %d not built (1 or 2)", name, G);
+    GAMER_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldq >= nq * 64 && ldk >= nkv * 64 && ldv >= nkv * 64,
+                    "%s: bad leading dims ldq=%d ldk=%d ldv=%d", name, ldq, ldk, ldv);
+    GAMER_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v), "%s: q/k/v must be 16-byte aligned", name);
+    GAMER_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "%s: p_drop=%f", name, p_drop);
+    return 0;
+}
+
+extern "C" int gamer_attn_fwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                    const int32_t* kl, const int32_t* ql, const int32_t* row_empty, int B, int S, int nq,
+                                    int nkv, float scale, float p_drop, uint64_t seed, float* o, float* lse,
+                                    const int32_t* row_perm, const int32_t* tile_kind, const int32_t* tile_maxpos,
+                                    void* stream) {
+    GAMER_CHECK_ARG(!row_perm || (tile_kind && tile_maxpos), "gamer_attn_fwd_split: row_perm needs tile_kind and tile_maxpos");
+    const RowOrder ro{row_perm, tile_kind, tile_maxpos, nullptr};
+    int rc = check_attn_split("gamer_attn_fwd_split", q, k, v, kl, row_empty, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
+    if (rc) return rc;
+    GAMER_CHECK_ARG(o && lse && aligned16(o), "gamer_attn_fwd_split: null/unaligned output");
+    hipStream_t st = (hipStream_t)stream;
+    if (nq / nkv == 1) return launch_fwd_s<1>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st);
+    return launch_fwd_s<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st);
+}
+
+extern "C" int gamer_attn_bwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                    const float* o, const float* d_o, const float* lse, const int32_t* kl,
+                                    const int32_t* ql, const int32_t* row_empty, const int32_t* tile_empty, int B, int S,
+                                    int nq, int nkv, float scale, float p_drop, uint64_t seed, float* delta, float* dq,
+                                    int lddq, float* dk, int lddk, float* dv, int lddv, const int32_t* row_perm,
+                                    const int32_t* tile_kind, const int32_t* tile_maxpos, int delta_ready, void* stream) {
+    int rc = check_attn_split("gamer_attn_bwd_split", q, k, v, kl, row_empty, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
+    if (rc) return rc;
+    GAMER_CHECK_ARG(o && d_o && lse && tile_empty && delta && dq && dk && dv, "gamer_attn_bwd_split: null pointer");
+    GAMER_CHECK_ARG(!row_perm || (tile_kind && tile_maxpos), "gamer_attn_bwd_split: row_perm needs tile_kind and tile_maxpos");
+    const RowOrder ro{row_perm, tile_kind, tile_maxpos, nullptr};
+    GAMER_CHECK_ARG(lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 && aligned16(dq) && aligned16(dk) && aligned16(dv) &&
+                    aligned16(d_o) && aligned16(o),
+                    "gamer_attn_bwd_split: gradient buffers must be 16-byte aligned with leading dims %% 4 == 0");
+    hipStream_t st = (hipStream_t)stream;
+    if (nq / nkv == 1)
+        return launch_bwd_s<1>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, st);
+    return launch_bwd_s<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, st);
+}

@@ -46,14 +46,14 @@ embedding_fwd_kernel(const int64_t* __restrict__ ids, const float4* __restrict__
 // EMB_CACHE distinct ids of its chunk in LDS (the hot ids are among them: a chunk starts with a behaviour token),
 // accumulates those rows with LDS atomics and flushes them once; every other row goes straight to global atomics.
 constexpr int EMB_CACHE = 8;
-constexpr int EMB_CHUNK = 1024;
+constexpr int EMB_CHUNK = 1024;          // tokens per workgroup at large T; smaller chunks keep >= ~512 workgroups at small T
 __global__ void __launch_bounds__(EW_THREADS)
 embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx, int V, int T, int H,
-                     int pad_id, float* __restrict__ dW) {
+                     int pad_id, float* __restrict__ dW, const int chunk) {
     extern __shared__ __attribute__((aligned(16))) float emb_cache[];       // [EMB_CACHE][H]
     __shared__ int64_t cache_id[EMB_CACHE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int t0 = blockIdx.x * EMB_CHUNK, t1 = min(T, t0 + EMB_CHUNK);
+    const int t0 = blockIdx.x * chunk, t1 = min(T, t0 + chunk);
     for (int e = threadIdx.x; e < EMB_CACHE * H; e += EW_THREADS) emb_cache[e] = 0.f;
     if (threadIdx.x == 0) {
         int n = 0;
@@ -728,16 +728,22 @@ qknorm_rope_bwd_b8_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restri
 
 // dwq[c] += sum over (row, q head) of slot 0; dwk likewise over the k heads; dbias_x[a][head*64 + c] += sum over rows of
 // slot 1 + a.  One workgroup per 32 output columns, 32 row groups, fixed summation order (deterministic).
-__global__ void __launch_bounds__(32 * COLSUM_RG)
+// QKR_CW output columns per workgroup, 1024 / QKR_CW row groups: with 32 columns per workgroup the self-attention call
+// (128 output columns) ran on FOUR workgroups, every thread walking ~170 dependent-latency loads: 54 us per call at every
+// batch size, 0.65 ms per step.  8 columns per workgroup = 16 (self) / 400 (cross) workgroups, ~43 / 7 loads per thread;
+// 32-byte row segments out of a 2-MB, L2-resident buffer.  Fixed summation order (deterministic).
+constexpr int QKR_CW = 8;
+constexpr int QKR_RG = 1024 / QKR_CW;
+__global__ void __launch_bounds__(1024)
 qknorm_partial_reduce_kernel(const float* __restrict__ partial, int n_rows, int nq, int nkv, int cross, int nb1,
                              float* __restrict__ dwq, float* __restrict__ dwk, float* __restrict__ dbias_q,
                              float* __restrict__ dbias_k, float* __restrict__ dbias_v) {
-    __shared__ float sh[COLSUM_RG][32];
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    __shared__ float sh[16][QKR_CW];
+    const int cl = threadIdx.x & (QKR_CW - 1), rg = threadIdx.x / QKR_CW;
     const int NH = nq + nkv + (cross ? nkv : 0);
     const int SL = 1 + (cross ? nb1 : 0);
     const int64_t row_stride = (int64_t)NH * SL * 64;
-    const int col = blockIdx.x * 32 + cl;            // [0,64): dwq, [64,128): dwk, then bias columns (head, a, c)
+    const int col = blockIdx.x * QKR_CW + cl;        // [0,64): dwq, [64,128): dwk, then bias columns (head, a, c)
     int h0, h1, slot, c;
     float* dst;
     if (col < 64) { h0 = 0; h1 = nq; slot = 0; c = col; dst = dwq + c; }
@@ -755,17 +761,21 @@ qknorm_partial_reduce_kernel(const float* __restrict__ partial, int n_rows, int 
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     auto at = [&](int64_t it) { return partial[(it / nh) * row_stride + ((int64_t)(h0 + it % nh) * SL + slot) * 64 + c]; };
     int64_t it = rg;
-    for (; it + 3 * COLSUM_RG < n_items; it += 4 * COLSUM_RG) {
-        s0 += at(it); s1 += at(it + COLSUM_RG); s2 += at(it + 2 * COLSUM_RG); s3 += at(it + 3 * COLSUM_RG);
+    for (; it + 3 * QKR_RG < n_items; it += 4 * QKR_RG) {
+        s0 += at(it); s1 += at(it + QKR_RG); s2 += at(it + 2 * QKR_RG); s3 += at(it + 3 * QKR_RG);
     }
-    for (; it < n_items; it += COLSUM_RG) s0 += at(it);
-    sh[rg][cl] = (s0 + s1) + (s2 + s3);
+    for (; it < n_items; it += QKR_RG) s0 += at(it);
+    // a wave holds 8 row groups of the same 8 columns: fold them with three shuffles, then the 16 waves through LDS
+    float t = (s0 + s1) + (s2 + s3);
+    t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < QKR_CW) sh[w][lane] = t;
     __syncthreads();
-    if (rg == 0) {
-        float t = 0.f;
+    if (threadIdx.x < QKR_CW) {
+        float tot = 0.f;
 #pragma unroll
-        for (int gi = 0; gi < COLSUM_RG; ++gi) t += sh[gi][cl];
-        *dst += t;
+        for (int gi = 0; gi < 16; ++gi) tot += sh[gi][threadIdx.x];
+        *dst += tot;
     }
 }
 
@@ -1061,8 +1071,12 @@ extern "C" int gamer_embedding_bwd(const int64_t* ids, const float* dx, int V, i
     GAMER_CHECK_ARG(ids && dx && dW, "gamer_embedding_bwd: null pointer");
     GAMER_CHECK_ARG(T > 0 && H > 0 && V > 0, "gamer_embedding_bwd: bad shape T=%d H=%d V=%d", T, H, V);
     GAMER_CHECK_ARG(H <= 1024, "gamer_embedding_bwd: H=%d > 1024 unsupported", H);
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((T + EMB_CHUNK - 1) / EMB_CHUNK), dim3(EW_THREADS),
-                       (size_t)EMB_CACHE * H * sizeof(float), ST(stream), ids, dx, V, T, H, pad_id, dW);
+    // 1024-token chunks at T = 517k (505 workgroups); at the 8-GPU per-rank shape (T = 64,640) that would be 64 workgroups
+    // walking 256 dependent iterations each (0.44 ms): chunks of >= 128 tokens sized for ~512 workgroups instead
+    int chunk = EMB_CHUNK;
+    while (chunk > 128 && (T + chunk - 1) / chunk < 512) chunk >>= 1;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((T + chunk - 1) / chunk), dim3(EW_THREADS),
+                       (size_t)EMB_CACHE * H * sizeof(float), ST(stream), ids, dx, V, T, H, pad_id, dW, chunk);
     GAMER_CHECK_LAUNCH("gamer_embedding_bwd");
     return 0;
 }
@@ -1263,7 +1277,7 @@ static int qknorm_rope_bwd_impl(const char* name, const TA* qkv, const TA* dq_ro
     }
     GAMER_CHECK_LAUNCH(name);
     const int cols = 128 + (cross ? NH * nb1 * 64 : 0);
-    hipLaunchKernelGGL(qknorm_partial_reduce_kernel, dim3(cols / 32), dim3(32 * COLSUM_RG), 0, ST(stream), partial,
+    hipLaunchKernelGGL(qknorm_partial_reduce_kernel, dim3(cols / QKR_CW), dim3(1024), 0, ST(stream), partial,
                        waves_per_head, nq, nkv, cross, nb1, dwq, dwk, dbias_q, dbias_k, dbias_v);
     GAMER_CHECK_LAUNCH(name);
     return 0;

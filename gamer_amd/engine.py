@@ -349,7 +349,8 @@ class Engine:
         ``matmul`` (dtype "f32" only): how the nn.Linear sites multiply fp32 operands - "f32" = v_mfma_f32_32x32x2_f32,
         "split6" / "split9" = gamer_gemm_f32_split: both operands cut exactly into three bf16 pieces, 6 or 9 piece
         products on the 16x wider bf16 pipe, fp32 accumulation (include/gamer_hip.h; error vs fp64 measured equal to
-        the fp32 MFMA's, tools/split_error.py).  Attention stays on the fp32 MFMA either way."""
+        the fp32 MFMA's, tools/split_error.py).  The attention products take the same form (gamer_attn_fwd_split /
+        gamer_attn_bwd_split, csrc/attention_split.hip; ``self.split_attention = False`` keeps them on the fp32 MFMA)."""
         cfg.validate()
         if matmul not in ops.MATMUL_MODES:
             raise ValueError(f"unknown matmul {matmul!r} ({sorted(ops.MATMUL_MODES)})")
@@ -361,6 +362,8 @@ class Engine:
         # on gfx950 epilogue work is matrix-pipe time), the removed kernel had cost 8.1 ms: 373.9-375.4 against 373.4-377 ms
         # per step, inside the box-to-box noise.  Off by default; Engine.fuse_qkv = True turns it on.
         self.fuse_qkv = False
+        # attention products of the split forms on the bf16 pipe too (csrc/attention_split.hip); False keeps fp32-MFMA attention
+        self.split_attention = True
         if variant not in ("multi", "session"):
             raise ValueError(f"unknown variant {variant!r}")
         if dtype not in ("f32", "bf16"):
@@ -553,8 +556,16 @@ class Engine:
         # fp32: the q|k|v projection carries per-head RMSNorm + RoPE in its epilogue when its tiles are whole
         fuse_qkv = (not bf16) and self.fuse_qkv and ops.qkv_fused_ok(ws.x[0][0], T, QKV) and cfg.head_dim == 64
 
+        # matmul="split6" / "split9": the attention products run on the bf16 pipe as well (gamer_attn_fwd_split: exact
+        # three-way cuts, six piece products); the session variant's key spans and the evaluation re-run path stay on the
+        # fp32-MFMA kernels
+        split_attn = self.split_attention and self.matmul != "f32" and not bf16 and uniform_len in (0, S)
+
         def attention(qb, kb, vb, kl_, ql_, empty_, tile_empty_, seed_, ob, lseb, order_, span_):
-            if bf16:
+            if split_attn and span_ is None:
+                ops.attn_fwd_split(qb, NQ, kb, NKV, vb, QKV, kl_, ql_, empty_, B, S, nq, nkv, scale, p_att, seed_, ob, lseb,
+                                   order=order_)
+            elif bf16:
                 ord16 = (order_[0], order_[2], empty_) if (order_ is not None and span_ is None) else None
                 ops.attn_fwd_bf16(qb, NQ, kb, NKV, vb, QKV, kl_, ql_, B, S, nq, nkv, scale, p_att, seed_, ob, lseb,
                                   q_span=span_, order=ord16)
@@ -725,7 +736,8 @@ class Engine:
         # delta = dO . O of the attention backward comes out of the o_proj dgrad GEMM (row-dot epilogue) when the dS-spill
         # path is in use and every tile of that GEMM is full; otherwise gamer_attn_bwd computes it itself
         bf16 = self.dtype == "bf16"
-        fuse_delta = (ws.ds_work is not None or bf16) and T % 128 == 0 and NQ % 128 == 0
+        split_attn = self.split_attention and self.matmul != "f32" and not bf16
+        fuse_delta = (ws.ds_work is not None or bf16 or split_attn) and T % 128 == 0 and NQ % 128 == 0
 
         def dgrad(dy, lddy, Wf, Wt, ldw, dx, lddx, n_out, k_in, **kw):
             """dx[T,k_in] (+)= dy[T,n_out] @ W[n_out,k_in]: fp32 reads W itself (row-contiguous B operand), bf16 the
@@ -737,7 +749,11 @@ class Engine:
                 ops.linear_dgrad(dy, lddy, Wf, ldw, dx, lddx, T, n_out, k_in, **kw)
 
         def attention_bwd(qb, kb, vb, ob, lseb, kl_, ql_, empty_, tile_empty_, seed_, order_, span_):
-            if bf16:
+            if split_attn and span_ is None:
+                ops.attn_bwd_split(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, empty_, tile_empty_, B, S, nq, nkv, scale,
+                                   p_att, seed_, ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, order=order_,
+                                   delta_ready=fuse_delta)
+            elif bf16:
                 ord16 = (order_[0], order_[2], empty_) if (order_ is not None and span_ is None) else None
                 ops.attn_bwd_bf16(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, B, S, nq, nkv, scale, p_att, seed_,
                                   ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, q_span=span_,
@@ -745,7 +761,7 @@ class Engine:
             else:
                 ops.attn_bwd(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, empty_, tile_empty_, B, S, nq, nkv, scale,
                              p_att, seed_, ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, order=order_,
-                             ds_work=ws.ds_work, q_span=span_, delta_ready=fuse_delta)
+                             ds_work=ws.ds_work, q_span=span_, delta_ready=fuse_delta and ws.ds_work is not None)
 
         def norm_bwd(xin, w, dy, lddy, dw, accumulate_dx, dy_rows=None, branch=None):
             """``branch`` = (seed, rows): the residual branch that consumes the updated dx next; its input gradient

@@ -446,6 +446,22 @@ def attn_bwd(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty,
          1 if (delta_ready and ds_work is not None) else 0, stream_ptr())
 
 
+def attn_fwd_split(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, order=None):
+    """gamer_attn_fwd with its products on the bf16 pipe (exact three-way cuts, six piece products); training semantics."""
+    pm, tk, tm = order if order is not None else (None, None, None)
+    call("gamer_attn_fwd_split", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(kl), ptr(ql), ptr(row_empty), B, S, nq, nkv,
+         scale, p_drop, seed, ptr(o), ptr(lse), ptr(pm), ptr(tk), ptr(tm), stream_ptr())
+
+
+def attn_bwd_split(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed,
+                   delta, dq, lddq, dk, lddk, dv, lddv, order=None, delta_ready=False):
+    """gamer_attn_bwd (recompute form) with its products on the bf16 pipe; delta_ready: `delta` already holds dO.O."""
+    pm, tk, tm = order if order is not None else (None, None, None)
+    call("gamer_attn_bwd_split", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), ptr(d_o), ptr(lse), ptr(kl), ptr(ql),
+         ptr(row_empty), ptr(tile_empty), B, S, nq, nkv, scale, p_drop, seed, ptr(delta), ptr(dq), lddq, ptr(dk), lddk, ptr(dv),
+         lddv, ptr(pm), ptr(tk), ptr(tm), 1 if delta_ready else 0, stream_ptr())
+
+
 def attn_fwd_bf16(q, ldq, k, ldk, v, ldv, kl, ql, B, S, nq, nkv, scale, p_drop, seed, o, lse, q_span=None, order=None):
     """bf16 attention (empty rows -> 0, see gamer_attn_fwd_bf16 in include/gamer_hip.h).
     order = (perm, tile_maxpos, row_empty): visit the query rows through the row order of attn_row_order."""

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GAMER_ABI_VERSION 4
+#define GAMER_ABI_VERSION 5
 
 /* bf16 activations of the AMP variant (the reference's --bf16 run, ref:SeqRec/tasks/train_SMB_decoder.py:114-118,
  * 407-408: HF Trainer autocast): raw bfloat16 bits.  Entry points with the suffix _bf16 are the same operation with
@@ -358,6 +358,26 @@ int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float
                    float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                    const int32_t* row_perm, const int32_t* tile_kind, const int32_t* tile_maxpos,
                    float* ds_work, const int32_t* q_span, int delta_ready, void* stream);
+
+/* The same attention (training semantics: uniform_len = S, no q_span) with fp32 inputs / outputs and every matrix product
+ * formed on the bf16 matrix pipe from an exact three-way bf16 cut of both operands, six piece products per fp32 product,
+ * fp32 accumulation - the attention counterpart of gamer_gemm_f32_split (csrc/attention_split.hip; same predicate,
+ * empty-row rule, row order and dropout mask function as gamer_attn_fwd / _bwd, so the three kernels of either form
+ * regenerate the same masks).  Replaces ref:SeqRec/models/generative/Qwen3Multi/model.py:133-143 in the
+ * Engine(matmul="split6") step.  bwd = recompute form (dQ kernel + dK/dV kernel, no workspace); delta_ready != 0: delta
+ * already holds dO.O (row-dot epilogue of the o_proj dgrad GEMM), otherwise the dQ kernel computes and publishes it. */
+int gamer_attn_fwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                         const int32_t* kl, const int32_t* ql, const int32_t* row_empty,
+                         int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+                         float* o, float* lse,
+                         const int32_t* row_perm, const int32_t* tile_kind, const int32_t* tile_maxpos, void* stream);
+int gamer_attn_bwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                         const float* o, const float* d_o, const float* lse,
+                         const int32_t* kl, const int32_t* ql, const int32_t* row_empty, const int32_t* tile_empty,
+                         int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+                         float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                         const int32_t* row_perm, const int32_t* tile_kind, const int32_t* tile_maxpos,
+                         int delta_ready, void* stream);
 
 /* bf16 attention of the reference's --bf16 run (autocast casts q, k, v AND the additive mask of
  * sdpa_attention_forward to bf16).  Same predicate, layouts and dropout mask function as gamer_attn_fwd / _bwd, with

@@ -519,8 +519,13 @@ def _run_attn(batch, cross, B, S, nq, nkv, p_drop=0.0, seed=1234, q=None, k=None
     o = torch.empty(T, nq * 64, device=DEV)
     lse = torch.empty(B, nq, S, device=DEV)
     dq_, dk_ = dev(q.reshape(T, -1)), dev(k.reshape(T, -1))
-    ops.attn_fwd(dq_, nq * 64, dk_, nkv * 64, vview, ldv, kl, ql, re_, te, B, S, nq, nkv, 0.125, p_drop, seed, o, lse,
-                 order=order)
+    split = spill == "split"            # the same attention with its products on the bf16 pipe (gamer_attn_*_split)
+    if split:
+        ops.attn_fwd_split(dq_, nq * 64, dk_, nkv * 64, vview, ldv, kl, ql, re_, B, S, nq, nkv, 0.125, p_drop, seed, o, lse,
+                           order=order)
+    else:
+        ops.attn_fwd(dq_, nq * 64, dk_, nkv * 64, vview, ldv, kl, ql, re_, te, B, S, nq, nkv, 0.125, p_drop, seed, o, lse,
+                     order=order)
     res = dict(o=o, lse=lse, router=router, order=order)
     if d_o is not None:
         delta = torch.empty(B, nq, S, device=DEV)
@@ -528,18 +533,22 @@ def _run_attn(batch, cross, B, S, nq, nkv, p_drop=0.0, seed=1234, q=None, k=None
         dk = torch.empty(T, nkv * 64, device=DEV)
         dqkv = torch.zeros(T, ldv, device=DEV)
         dvv = dqkv[:, (nq + nkv) * 64:]
-        ds_work = torch.full((ops.attn_ds_work_numel(B, S, nq),), float("nan"), device=DEV) if spill else None
-        ops.attn_bwd(dq_, nq * 64, dk_, nkv * 64, vview, ldv, o, dev(d_o.reshape(T, -1)), lse, kl, ql, re_, te, B, S, nq,
-                     nkv, 0.125, p_drop, seed, delta, dq, nq * 64, dk, nkv * 64, dvv, ldv, order=order, ds_work=ds_work)
+        if split:
+            ops.attn_bwd_split(dq_, nq * 64, dk_, nkv * 64, vview, ldv, o, dev(d_o.reshape(T, -1)), lse, kl, ql, re_, te, B, S,
+                               nq, nkv, 0.125, p_drop, seed, delta, dq, nq * 64, dk, nkv * 64, dvv, ldv, order=order)
+        else:
+            ds_work = torch.full((ops.attn_ds_work_numel(B, S, nq),), float("nan"), device=DEV) if spill else None
+            ops.attn_bwd(dq_, nq * 64, dk_, nkv * 64, vview, ldv, o, dev(d_o.reshape(T, -1)), lse, kl, ql, re_, te, B, S, nq,
+                         nkv, 0.125, p_drop, seed, delta, dq, nq * 64, dk, nkv * 64, dvv, ldv, order=order, ds_work=ds_work)
         res.update(dq=dq, dk=dk, dv=dvv)
     return res
 
 
-@pytest.mark.parametrize("spill", [False, True])
+@pytest.mark.parametrize("spill", [False, True, "split"])
 @pytest.mark.parametrize("use_order", [False, True])
 @pytest.mark.parametrize("cross", [False, True])
 @pytest.mark.parametrize("n_items,B,nq,nkv", [(7, 3, 2, 1), (14, 2, 2, 1), (20, 2, 2, 1), (101, 2, 2, 1), (101, 11, 6, 3),
-                                              (33, 40, 6, 3)])
+                                              (33, 40, 6, 3), (40, 3, 3, 3)])
 def test_attention_fwd_bwd(cross, n_items, B, nq, nkv, use_order, spill):
     """The last two shapes give every persistent workgroup several (pair, tile) items, the regime the
     train step runs in (LDS reuse across items and tiles).  S = 70 leaves a 32-row wave tile entirely past the
@@ -572,7 +581,7 @@ def test_attention_fwd_bwd(cross, n_items, B, nq, nkv, use_order, spill):
     e_dq = _rel(res["dq"], leaves[0].grad.reshape(T, -1))
     e_dk = _rel(res["dk"], leaves[1].grad.reshape(T, -1))
     e_dv = _rel(res["dv"], leaves[2].grad.reshape(T, -1))
-    _record(f"attn_cross{int(cross)}_S{S}_B{B}_h{nq}_ord{int(use_order)}_spill{int(spill)}", dict(o=e_o, lse=e_l, dq=e_dq, dk=e_dk, dv=e_dv,
+    _record(f"attn_cross{int(cross)}_S{S}_B{B}_h{nq}_ord{int(use_order)}_spill{spill}", dict(o=e_o, lse=e_l, dq=e_dq, dk=e_dk, dv=e_dv,
                                                    empty_rows=int(empty.sum())))
     if cross:
         assert int((empty & batch["attention_mask"].bool()).sum()) > 0, "fixture must contain empty rows"
@@ -596,17 +605,18 @@ def test_attention_left_padding_empty_self_rows():
     o_ref, _, empty = _attn_ref(*leaves, self_ok, nq, nkv, 0.125)
     assert int(empty.sum()) == 15
     (o_ref * d_o.double()).sum().backward()
-    for use_order in (False, True):
-        res = _run_attn(batch, False, B, S, nq, nkv, q=q, k=k, v=v, d_o=d_o, use_order=use_order)
-        assert _rel(res["o"], o_ref.reshape(B * S, -1)) < 2e-5
     T = B * S
-    assert _rel(res["o"], o_ref.reshape(T, -1)) < 2e-5
-    assert _rel(res["dq"], leaves[0].grad.reshape(T, -1)) < 5e-5
-    assert _rel(res["dk"], leaves[1].grad.reshape(T, -1)) < 5e-5
-    assert _rel(res["dv"], leaves[2].grad.reshape(T, -1)) < 5e-5
+    for form in (False, "split"):
+        for use_order in (False, True):
+            res = _run_attn(batch, False, B, S, nq, nkv, q=q, k=k, v=v, d_o=d_o, use_order=use_order, spill=form)
+            assert _rel(res["o"], o_ref.reshape(B * S, -1)) < 2e-5
+        assert _rel(res["o"], o_ref.reshape(T, -1)) < 2e-5
+        assert _rel(res["dq"], leaves[0].grad.reshape(T, -1)) < 5e-5
+        assert _rel(res["dk"], leaves[1].grad.reshape(T, -1)) < 5e-5
+        assert _rel(res["dv"], leaves[2].grad.reshape(T, -1)) < 5e-5
 
 
-@pytest.mark.parametrize("spill", [False, True])
+@pytest.mark.parametrize("spill", [False, True, "split"])
 @pytest.mark.parametrize("use_order", [False, True])
 @pytest.mark.parametrize("cross", [False, True])
 def test_attention_dropout_mask_consistent_fwd_bwd(cross, use_order, spill):

@@ -84,6 +84,20 @@ def bench_attn(args):
         tf, tb = timeit(f, args.iters), timeit(b, args.iters)
         tb2 = timeit(b2, args.iters)
         print(f"attn_{name}: bwd with dS spill {tb2:.3f} ms (recompute {tb:.3f} ms)")
+        if args.bf16:
+            BF = torch.bfloat16
+            q16, k16, qkv16, do16 = q.to(BF), k.to(BF), qkv.to(BF), do.to(BF)
+            v16 = qkv16[:, (nq + nkv) * 64:]
+            o16, dq16, dk16, dqkv16 = torch.empty_like(q16), torch.empty_like(q16), torch.empty_like(k16), torch.empty_like(qkv16)
+            ord16 = (od[0], od[2], re_) if od is not None else None
+            f16 = lambda: ops.attn_fwd_bf16(q16, nq * 64, k16, nkv * 64, v16, qkv16.shape[1], kl, ql, B, S, nq, nkv, 0.125, p, 7,
+                                            o16, lse, order=ord16)
+            b16 = lambda: ops.attn_bwd_bf16(q16, nq * 64, k16, nkv * 64, v16, qkv16.shape[1], o16, do16, lse, kl, ql, B, S, nq, nkv,
+                                            0.125, p, 7, delta, dq16, nq * 64, dk16, nkv * 64, dqkv16[:, (nq + nkv) * 64:],
+                                            qkv16.shape[1], order=ord16)
+            tf16, tb16 = timeit(f16, args.iters), timeit(b16, args.iters)
+            print(f"attn_{name} bf16: fwd {tf16:.3f} ms  bwd {tb16:.3f} ms")
+            f()                                    # restore the fp32 lse for the lines below
         causal_pairs = B * S * (S + 1) // 2
         print(f"attn_{name}: fwd {tf:.3f} ms ({4 * 64 * nq * npairs / tf / 1e9:.1f} TF alg, "
               f"{4 * 64 * nq * causal_pairs / tf / 1e9:.1f} TF causal-dense)  bwd {tb:.3f} ms "
@@ -172,6 +186,7 @@ if __name__ == "__main__":
     ap.add_argument("--p", type=float, default=0.2)
     ap.add_argument("--ragged", action="store_true")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--bf16", action="store_true", help="attn: also time the bf16 kernels on the same inputs")
     ap.add_argument("--no-order", dest="no_order", action="store_true", help="cross attention without the row order")
     ap.add_argument("--lib", default="")
     ap.add_argument("--matmul", default="f32", choices=sorted(ops.MATMUL_MODES), help="fp32 GEMM form (gamer_gemm_f32_split)")
