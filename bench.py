@@ -338,15 +338,19 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs (bf16, split6, per-GPU batch 128) the default single-GPU run adds")
     ap.add_argument("--no-dropout", action="store_true")
-    ap.add_argument("--matmul", choices=["f32", "split6", "split9"], default="f32",
-                    help="fp32 GEMM form (--dtype f32 only): f32 = fp32 MFMA (the headline record); split6 / split9 = "
-                         "gamer_gemm_f32_split, exact three-way bf16 cut of both operands, 6 / 9 products on the bf16 pipe")
+    ap.add_argument("--matmul", choices=["f32", "split6", "split9"], default=None,
+                    help="how fp32 matrix products are formed (--dtype f32 only; default split6, the engine's default): "
+                         "split6 / split9 = every fp32 product from an exact three-way bf16 cut of both operands, 6 / 9 piece "
+                         "products on the bf16 pipe, fp32 accumulation (gamer_gemm_f32_split, gamer_attn_*_split; error against "
+                         "fp64 at the fp32 MFMA's level, DESIGN.md section 13); f32 = v_mfma_f32_32x32x2_f32 throughout")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (and the roofline object)")
     ap.add_argument("--ragged", action="store_true", help="secondary workload: n_items ~ U{2..items}, right padded")
     ap.add_argument("--variant", choices=["multi", "session"], default="multi",
                     help="secondary workload: 'session' = Qwen3SessionMulti (session-wise masks, same weights)")
     ap.add_argument("--session-mean", type=float, default=4.0, help="items per session for --variant session")
     args = ap.parse_args(argv)
+    if args.matmul is None:
+        args.matmul = "split6" if args.dtype == "f32" else "f32"
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     if args.batch is not None:
@@ -410,9 +414,10 @@ def spawn_ranks(args, argv) -> int:
 
 SECONDARY_LEGS = (
     # (name, dtype, matmul, per-GPU batch): what DESIGN.md / README.md quote beside the headline, timed by the SAME driver run
-    ("bf16_b1024", "bf16", "f32", 1024),
-    ("f32_split6_b1024", "f32", "split6", 1024),
-    ("f32_b128", "f32", "f32", 128),
+    ("f32_mfma_b1024", "f32", "f32", 1024),        # the same fp32 step with every product on v_mfma_f32_32x32x2_f32
+    ("bf16_b1024", "bf16", "f32", 1024),           # BASELINE configs[2]'s per-GPU shape (bf16 AMP)
+    ("f32_split6_b128", "f32", "split6", 128),     # the headline form at the per-GPU batch of the 8-GPU north-star point
+    ("f32_mfma_b128", "f32", "f32", 128),
     ("bf16_b128", "bf16", "f32", 128),
 )
 
@@ -429,8 +434,8 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
     if args.no_dropout:
         cfg.dropout_rate = 0.0
         cfg.attention_dropout = 0.0
-    if args.matmul != "f32" and (args.dtype != "f32" or args.path != "engine"):
-        raise SystemExit("--matmul split6/split9 is a form of the fp32 engine path (--dtype f32 --path engine)")
+    if args.matmul != "f32" and args.dtype != "f32":
+        raise SystemExit("--matmul split6/split9 is a form of the fp32 path (--dtype f32)")
     eng = Engine(cfg, device=f"cuda:{local_rank}", temperature=0.7, variant=args.variant, dtype=args.dtype,
                  matmul=args.matmul)
     smean = args.session_mean if args.variant == "session" else None
@@ -466,7 +471,7 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
         cls = Qwen3MultiWithTemperature if args.variant == "multi" else Qwen3SessionMultiWithTemperature
         del eng
         torch.cuda.empty_cache()
-        module = cls(cfg, device=f"cuda:{local_rank}", dtype=args.dtype)
+        module = cls(cfg, device=f"cuda:{local_rank}", dtype=args.dtype, matmul=args.matmul)
         module.set_hyper(0.7)
         module.zero_copy_logits = True      # the loop below reads only the loss (HF Trainer.training_step does the same)
         module.train()
@@ -570,20 +575,21 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
         gemm_tf = sum(k["tflops"] * k["ms_per_step"] for k in gemm_rows) / max(gemm_ms, 1e-9)
         ms_per_step = elapsed / args.steps * 1e3
         # (prefixes: the kernel's template list ends with the matmul form, ", 0>" = fp32 MFMA)
-        kname = {"gemm_fwd": "gemm_f32_kernel<true, true, 0, false, false, 2, 0, 0>",
-                 "gemm_dgrad": "gemm_f32_kernel<true, false, 0, false, false, 2, 0, 0>",
-                 "gemm_wgrad": "gemm_f32_kernel<false, false, 1, false, false, 2, 0, 0>"}.get(dom["kernel"] if dom else "", None)
+        split_terms = {"f32": 0, "split6": 6, "split9": 9}[args.matmul]
+        kname = {"gemm_fwd": f"gemm_f32_kernel<true, true, 0, false, false, 2, 0, {split_terms}>",
+                 "gemm_dgrad": f"gemm_f32_kernel<true, false, 0, false, false, 2, 0, {split_terms}>",
+                 "gemm_wgrad": f"gemm_f32_kernel<false, false, 1, false, false, 2, 0, {split_terms}>"}.get(dom["kernel"] if dom else "", None)
+        if args.dtype != "f32":
+            kname = None
         # HBM bytes per launch from a committed PMC profile of THIS workload (shape / dtype / matmul form checked)
         want = dict(batch=args.batch, items=args.items, dtype=args.dtype, matmul=args.matmul, variant=args.variant,
                     ragged=bool(args.ragged))
         traffic = committed_traffic(kname, want) if kname else None
         peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS
-        split_terms = {"f32": 0, "split6": 6, "split9": 9}[args.matmul]
         if split_terms:
             # every fp32 product is `terms` bf16 MFMA products: the pipe that bounds the kernel is the bf16 one, and its
             # peak in units of the ALGORITHMIC (fp32 problem) FLOPs is the bf16 peak / terms
             peak = BF16_MATRIX_PEAK_TFLOPS / split_terms
-            traffic = None
         result = {
             "metric": ("train-step sequences/sec, Qwen3Multi SMB decoder, his_len=100" if args.variant == "multi" else
                        "train-step sequences/sec, Qwen3SessionMulti SMB decoder, his_len=100"),
@@ -605,8 +611,9 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
                              f"synthetic ids, per-GPU batch {args.batch} x {args.items * 5} tokens"
                              + (" ragged" if args.ragged else "") + ", V=1041, " +
                              ("fp32" if args.dtype == "f32" else "bf16 AMP (fp32 master weights / gradients / moments)") +
-                             (f"; Linear products as {split_terms} exact bf16 piece products per fp32 product "
-                              "(gamer_gemm_f32_split), fp32 accumulate" if split_terms else "")),
+                             (f" tensors and accumulation; every fp32 matrix product (Linear and attention) formed as {split_terms} "
+                              "exact bf16 piece products of a three-way cut of both operands (error vs fp64 at the fp32 MFMA's "
+                              "level)" if split_terms else (" on the fp32 MFMA" if args.dtype == "f32" else ""))),
                 "global_batch": args.batch * world,
                 "seq_len": args.items * 5,
                 "parallelism": f"dp{world}",
@@ -683,7 +690,7 @@ def main(argv=None):
     # Secondary legs (N = 1, default workload only): the other step forms DESIGN.md quotes - bf16 AMP, fp32 Linear
     # products on the bf16 pipe (split6), and both dtypes at the per-GPU batch of the 8-GPU north-star point (128) -
     # timed by the same run, 2 warm-up + 5 timed steps each, reported under "secondary" on the ONE JSON line.
-    default_workload = (world == 1 and not force_dist and args.path == "engine" and args.dtype == "f32" and args.matmul == "f32"
+    default_workload = (world == 1 and not force_dist and args.path == "engine" and args.dtype == "f32" and args.matmul == "split6"
                         and args.batch == 1024 and args.items == 101 and args.variant == "multi" and not args.ragged
                         and not args.no_dropout)
     if default_workload and not args.no_secondary and result is not None:

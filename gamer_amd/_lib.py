@@ -74,6 +74,12 @@ class GemmBf16Desc(C.Structure):
         ("rowdot_other", c_void_p),
         ("rowdot_out", c_void_p),
         ("rowdot_S", c_int),
+        ("qk_wq", c_void_p), ("qk_wk", c_void_p), ("qk_eps", c_float),
+        ("qk_cos", c_void_p), ("qk_sin", c_void_p),
+        ("qk_bias_q", c_void_p), ("qk_bias_k", c_void_p), ("qk_bias_v", c_void_p),
+        ("qk_act_idx", c_void_p), ("qk_pos_ids", c_void_p),
+        ("qk_q_rot", c_void_p), ("qk_k_rot", c_void_p),
+        ("qk_S", c_int), ("qk_nq", c_int), ("qk_nkv", c_int),
     ]
 
 
@@ -103,7 +109,7 @@ _SIGNATURES = {
     "gamer_attn_fwd": [P, I, P, I, P, I, P, P, P, P, I, I, I, I, F, F, U, P, P, P, P, P, I, P, P],
     "gamer_attn_bwd": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, P, P, P, P, I, P],
     "gamer_attn_fwd_split": [P, I, P, I, P, I, P, P, P, I, I, I, I, F, F, U, P, P, P, P, P, P],
-    "gamer_attn_bwd_split": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, P, P, I, P],
+    "gamer_attn_bwd_split": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, P, P, I, P, P],
     "gamer_residual_dropout_fwd": [P, P, P, I, I, F, U, P, P],
     "gamer_residual_dropout_bwd": [P, P, I, I, F, U, P, P],
     "gamer_swiglu_fwd": [P, P, L, F, U, P, P],

@@ -13,14 +13,19 @@
 //   * K / V (Q / dO in the dK/dV kernel) tiles are cut on their way into LDS: three bf16 images [rows][64] per tile,
 //     16-byte chunks XOR-swizzled (the layout of attention_bf16.hip: conflict-free row reads and transposing reads);
 //   * q (pre-scaled), dO rows are cut once per tile into register fragments; P and dS are cut in registers;
-//   * the backward is the recompute form (dQ kernel + dK/dV kernel, 7 products per tile pair): the dS spill of the fp32
-//     design would need the whole K of a sequence as three images in LDS (194 KB) for its streaming dQ kernel.
+//   * the backward comes in the two forms of attention.hip: recompute (dQ kernel + dK/dV kernel, 7 products per tile pair)
+//     and, with a workspace, the dS spill (the dK/dV kernel writes its fp32 dS tiles, dQ = dS K is one product per tile
+//     pair in the tiled kernel - the fp32 design's streaming dQ kernel would need the whole K of a sequence as three
+//     images in LDS, 194 KB).
 // Not built here (the Engine keeps those calls on the fp32-MFMA kernels): per-query key spans (Qwen3SessionMulti) and
 // uniform_len of the evaluation re-run path.
 #include "attention_common.h"
 
 namespace gamer {
 
+#ifndef SPA_ABLATE
+#define SPA_ABLATE 0      // timing-only builds (tools/ablate_attn_split.sh): 1 no S = K Q^T MFMAs, 2 no second-product MFMAs, 4 no cut of P / dS,
+#endif                    // 8 no cut arithmetic anywhere (pieces = the raw word), 16 no LDS tile stores
 constexpr int SIMG = 32 * 64;              // bf16 elements of one piece image of a 32-row tile
 
 // element offset of (row, column) in a [rows][64] bf16 image with swizzled 16-byte chunks (attention_bf16.hip: lds_off)
@@ -59,8 +64,11 @@ __device__ __forceinline__ bf16x8 read_tr8(const bf16_t* __restrict__ img, const
 // ---- the exact three-way cut (csrc/gemm.hip: split3) ---------------------------------------------------------------
 // upper halves of (w1, w0) -> one register {bf16(w0), bf16(w1)}
 __device__ __forceinline__ uint32_t hi16_pair(uint32_t w0, uint32_t w1) { return __builtin_amdgcn_perm(w1, w0, 0x07060302u); }
-// x = p0 + p1 + p2 exactly, p_i = the value of the upper 16 bits of w[i]
+// x = p0 + p1 + p2 exactly, p_i = the value of the upper 16 bits of w[i].  (Measured and not kept: the two subtractions on
+// PAIRS of values as v_pk_add_f32 - fewer instructions, but the 64-bit register pairs it forces cost the forward kernel a
+// spill cascade: 0.58 -> 0.91 ms at batch 256; the GEMM's cut got 2-7 % slower the same way.)
 __device__ __forceinline__ void cut3(float x, uint32_t (&w)[3]) {
+    if (SPA_ABLATE & 8) { w[0] = w[1] = w[2] = __float_as_uint(x); return; }
     w[0] = __float_as_uint(x);
     const float r1 = x - __uint_as_float(w[0] & 0xffff0000u);
     w[1] = __float_as_uint(r1);
@@ -83,6 +91,13 @@ __device__ __forceinline__ void cut8(const float4& a, const float4& b, bf16x8& p
 }
 // registers first .. first + 7 of an accumulator tile -> the three bf16x8 fragments (operand of the second product)
 __device__ __forceinline__ void cut8_regs(const f32x16& t, const int first, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    if (SPA_ABLATE & 4) {
+        u32x4s z;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[j] = __float_as_uint(t[first + 2 * j]);
+        p0 = p1 = p2 = __builtin_bit_cast(bf16x8, z);
+        return;
+    }
     uint32_t w[8][3];
 #pragma unroll
     for (int e = 0; e < 8; ++e) cut3(t[first + e], w[e]);
@@ -105,21 +120,36 @@ __device__ __forceinline__ void store_tile32_split(bf16_t* __restrict__ img, int
 #pragma unroll
         for (int e = 0; e < 4; ++e) cut3(x[e], w[e]);
         bf16_t* dst = img + sl_off(row, (f & 15) << 2);
+        if (SPA_ABLATE & 16) { asm volatile("" :: "v"(w[0][0]), "v"(w[1][1]), "v"(w[2][2]), "v"(w[3][0])); continue; }
 #pragma unroll
         for (int s = 0; s < 3; ++s)
             *reinterpret_cast<uint2*>(dst + s * SIMG) = make_uint2(hi16_pair(w[0][s], w[1][s]), hi16_pair(w[2][s], w[3][s]));
     }
 }
-// ACC += (three K images of one slot)(rows = this tile's 32 keys) . q^T, six piece products, smallest first
+// ACC += (three K images of one slot)(rows = this tile's 32 keys) . q^T, six piece products, smallest first.
+// (Measured and not kept: two interleaved accumulation chains here and in the second products - the extra 16 accumulator
+// registers cost more in spills than the independent chains gained: forward 0.63 -> 0.76 ms at batch 256.)
 #define SPLIT_QK_TILE(ACC, KIMG)                                                                                          \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                         \
-        const bf16x8 k0 = read_row8(KIMG, lo, 0, s), k1 = read_row8(KIMG + SIMG, lo, 0, s), k2 = read_row8(KIMG + 2 * SIMG, lo, 0, s); \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[0][s], ACC, 0, 0, 0);                                          \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1][s], ACC, 0, 0, 0);                                          \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[2][s], ACC, 0, 0, 0);                                          \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[0][s], ACC, 0, 0, 0);                                          \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[1][s], ACC, 0, 0, 0);                                          \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0][s], ACC, 0, 0, 0);                                          \
+    if (!(SPA_ABLATE & 1)) {                                                                                                \
+        /* the fragments of k-step s + 1 are requested BEFORE the six products of k-step s (left alone the compiler issues  \
+           every ds_read right in front of the MFMA that needs it and waits for it: the 24 MFMAs of a tile cost 3.3 x their \
+           pipe time, tools/ablate_attn_split.sh) */                                                                        \
+        bf16x8 kf_[2][3];                                                                                                   \
+        _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_) kf_[0][pc_] = read_row8(KIMG + pc_ * SIMG, lo, 0, 0);           \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                     \
+            if (s + 1 < 4) {                                                                                                \
+                _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_) kf_[(s + 1) & 1][pc_] = read_row8(KIMG + pc_ * SIMG, lo, 0, s + 1); \
+            }                                                                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                                              \
+            const bf16x8 k0 = kf_[s & 1][0], k1 = kf_[s & 1][1], k2 = kf_[s & 1][2];                                        \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[0][s], ACC, 0, 0, 0);                                      \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1][s], ACC, 0, 0, 0);                                      \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[2][s], ACC, 0, 0, 0);                                      \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[0][s], ACC, 0, 0, 0);                                      \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[1][s], ACC, 0, 0, 0);                                      \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0][s], ACC, 0, 0, 0);                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                              \
+        }                                                                                                                   \
     }
 
 // =============================================================================================
@@ -263,6 +293,7 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
                 for (int s2 = 0; s2 < 2; ++s2) {
                     bf16x8 pf[3];
                     cut8_regs(st_cur, 8 * s2, pf[0], pf[1], pf[2]);
+                    if (SPA_ABLATE & 2) { asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2])); continue; }
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
                         const bf16x8 v0 = read_tr8(Vc, lo, 16 * s2, db);
@@ -730,7 +761,7 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                     const int32_t* __restrict__ row_empty, const int32_t* __restrict__ tile_empty,
                     int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                     float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const RowOrder ro, const int pair,
-                    const int ktile) {
+                    const int ktile, float* __restrict__ ds_out) {
     constexpr int THREADS = 256 * G;
     constexpr int R = DKV_S_KEYS;
     constexpr int NLD = 512 / THREADS;               // float4 per thread, tensor and head of a staged 32 x 64 tile
@@ -885,7 +916,11 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
         __syncthreads();
         const bool tile_has_empty = tile_empty_rows(qt);
         const int qt_next = next_tile(qt + 1);
-        if (qt_next < n_qt) load_q_tile(qt_next);
+        // the next tile's global loads are in flight while this one is multiplied.  With the dS spill they are issued BEHIND
+        // the spill stores (the wait for them in front of the next LDS store is s_waitcnt vmcnt(0): issued ahead of the
+        // stores, every tile would wait for its own spill to be acknowledged)
+        bool prefetched = ds_out == nullptr;
+        if (prefetched && qt_next < n_qt) load_q_tile(qt_next);
         const int posmin = __builtin_amdgcn_readfirstlane(sm.posmin);
         const int qlmin = __builtin_amdgcn_readfirstlane(sm.qlmin);
         const bool tile_all_empty = tile_has_empty && posmin == INT_BIG_A;
@@ -986,6 +1021,17 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                 if (free_tile) elem_tile.template operator()<false, false, false>();
                 else elem_tile.template operator()<true, false, false>();
             }
+            if (ds_out != nullptr && (k0 >> 5) + sub < n_qt) {
+                // spill dS (fp32) for the dQ kernel: tile (head, query tile qt, this wave's 32-key tile) as [query][key]
+                const int head = kvh * G + hg;
+                float* tile = ds_out + ((((int64_t)b * nq + head) * n_qt + qt) * n_qt + (k0 >> 5) + sub) * 1024;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) tile[rowmap(reg, h) * 32 + r] = dp[reg];
+            }
+            if (!prefetched) {
+                prefetched = true;
+                if (qt_next < n_qt) load_q_tile(qt_next);
+            }
             // dV^T[d][key] += sum_query dO[query][d] Pd[query][key] ; dK^T[d][key] += sum_query Q[query][d] dS[query][key]
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -1011,6 +1057,7 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                 }
             }
         }
+        if (!prefetched && qt_next < n_qt) load_q_tile(qt_next);
         qt = qt_next;
     }
 
@@ -1083,7 +1130,8 @@ attn_bwd_dkv_s_kernel(const float* __restrict__ q, int ldq, const float* __restr
                       const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                       const int32_t* __restrict__ row_empty, const int32_t* __restrict__ tile_empty,
                       int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-                      float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const RowOrder ro) {
+                      float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const RowOrder ro,
+                      float* __restrict__ ds_out) {
     const int n_tiles = (S + DKV_S_KEYS - 1) / DKV_S_KEYS;
     const WorkList wl(nbatch * nkv, n_tiles);
     if (!wl.valid) return;
@@ -1095,10 +1143,183 @@ attn_bwd_dkv_s_kernel(const float* __restrict__ q, int ldq, const float* __restr
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
             attn_bwd_dkv_s_tile<G, DROP, ORD>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv,
-                                              scale, p_drop, seed, dk, lddk, dv, lddv, ro, pair, pass == 0 ? heavy : light);
+                                              scale, p_drop, seed, dk, lddk, dv, lddv, ro, pair, pass == 0 ? heavy : light, ds_out);
         }
     }
 }
+
+// =============================================================================================
+// backward: dQ = dS K from the dS tiles the dK/dV kernel spilled (attention.hip: attn_bwd_dq2_tile, split fragments):
+// one product per tile pair instead of the three of the recompute form, for 2 x 4 KB of HBM traffic per tile pair
+// =============================================================================================
+// delta[b,h,i] = sum_d dO * O
+__global__ void __launch_bounds__(AT_THREADS)
+attn_delta_s_kernel(const float* __restrict__ o, const float* __restrict__ d_o, int B, int S, int nq, float* __restrict__ delta) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane & 15, sub = lane >> 4;                  // 16 lanes x float4 = one head row, 4 rows per wave
+    const int64_t wave = ((int64_t)blockIdx.x * AT_THREADS + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * AT_THREADS) >> 6;
+    const int64_t total = (int64_t)B * S * nq;
+    for (int64_t i0 = wave * 4; i0 < total; i0 += nwaves * 4) {
+        const int64_t i = i0 + sub;
+        const bool live = i < total;
+        const int64_t ic = live ? i : total - 1;
+        const float4 a = reinterpret_cast<const float4*>(o + ic * 64)[g];
+        const float4 c = reinterpret_cast<const float4*>(d_o + ic * 64)[g];
+        float sum = a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        if (live && g == 0) {
+            const int64_t t = i / nq;
+            delta[((t / S) * nq + (int)(i % nq)) * S + t % S] = sum;
+        }
+    }
+}
+
+template <int G, bool ORD>
+__device__ __forceinline__ void
+attn_bwd_dq2_s_tile(const float* __restrict__ k, int ldk, const float* __restrict__ ds_in,
+                  const int32_t* __restrict__ row_empty, int S, int nq, int nkv, float scale,
+                  float* __restrict__ dq, int lddq, const RowOrder ro, const int pair, const int qtile) {
+    constexpr int NSUB = 4 / G;
+    constexpr int R = NSUB * 32;
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[2][3 * SIMG];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int hg = w / NSUB, sub = w % NSUB;
+    const int b = pair / nkv, kvh = pair % nkv, q0 = qtile * R;
+    const int head = kvh * G + hg;
+    const int r = lane & 31, h = lane >> 5;
+    const SlOffsets lo(lane);
+    const int slot = q0 + sub * 32 + r;
+    const bool valid_q = slot < S;
+    const int slotc = valid_q ? slot : S - 1;
+    const int iqc = ORD ? ro.perm[(int64_t)b * S + slotc] : slotc;
+    const int64_t tok = (int64_t)b * S + iqc;
+    const bool my_empty = valid_q && row_empty[tok] != 0;
+    const int n_all = (S + 31) / 32;
+    const int qt32 = (q0 >> 5) + sub;                            // this wave's 32-row query tile
+    int wave_q_hi, n_causal;
+    bool wave_has_empty;
+    if (ORD) {
+        const int64_t tb = (int64_t)b * n_all + (q0 >> 5);
+        const int wt = min(sub, n_all - 1 - (q0 >> 5));
+        wave_q_hi = (q0 + sub * 32 < S) ? ro.tile_maxpos[tb + wt] : -1;
+        wave_has_empty = (q0 + sub * 32 < S) && (ro.tile_kind[tb + wt] & 2) != 0;
+        int hi = -1;
+#pragma unroll
+        for (int ss = 0; ss < NSUB; ++ss)
+            if (q0 + ss * 32 < S) hi = max(hi, ro.tile_maxpos[tb + ss]);
+        n_causal = hi < 0 ? 0 : (hi >> 5) + 1;
+    } else {
+        wave_q_hi = (q0 + sub * 32 < S) ? min(S - 1, q0 + sub * 32 + 31) : -1;
+        wave_has_empty = __any(my_empty ? 1 : 0) != 0;
+        n_causal = (min(S, q0 + R) + 31) / 32;
+    }
+    const bool block_has_empty = __syncthreads_or(my_empty ? 1 : 0) != 0;
+    const int n_iter = block_has_empty ? n_all : n_causal;
+    const float* kbase = k + (int64_t)b * S * ldk + kvh * 64;
+    // dS tiles of this wave: (head, qt32, key tile jt) -> 1024 floats [query][key]; the lane takes query r and the
+    // keys rowmap(reg, h), i.e. four 16-byte pieces of its row
+    const float* ds_row = ds_in + ((((int64_t)b * nq + head) * n_all + min(qt32, n_all - 1)) * n_all) * 1024 + r * 32 + 4 * h;
+
+    f32x16 dqacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
+    auto live = [&](int jt) { return !((jt * 32 > wave_q_hi) && !wave_has_empty); };   // mirrors the dK/dV kernel
+    auto load_ds = [&](int jt, float4 (&t4)[4]) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) t4[g4] = *reinterpret_cast<const float4*>(ds_row + (int64_t)jt * 1024 + 8 * g4);
+    };
+    // the dS tiles come straight from HBM and one tile of MFMA work (~1 us) is shorter than the load latency:
+    // three tiles are kept in flight per wave
+    float4 rk[2], t0[4], t1[4], t2[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) { t0[g4] = make_float4(0.f, 0.f, 0.f, 0.f); t1[g4] = t0[g4]; t2[g4] = t0[g4]; }
+    load_tile32(kbase, ldk, 0, S, tid, rk);
+    store_tile32_split(Ks[0], tid, rk, S);
+    if (n_iter > 0 && live(0)) load_ds(0, t0);
+    if (n_iter > 1 && live(1)) load_ds(1, t1);
+    if (n_iter > 2 && live(2)) load_ds(2, t2);
+    __syncthreads();
+    // iteration jt consumes ring slot jt % 3 and refills it with tile jt + 3 (no register rotation: a copy of a
+    // register with a load in flight would wait for the load)
+    auto step = [&](int jt, float4 (&tu)[4]) {
+        const int cur = jt & 1;
+        const bool more = jt + 1 < n_iter;
+        if (more) load_tile32(kbase, ldk, jt * 32 + 32, S, tid, rk);
+        if (live(jt)) {
+            f32x16 st;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) { st[4 * g4] = tu[g4].x; st[4 * g4 + 1] = tu[g4].y; st[4 * g4 + 2] = tu[g4].z; st[4 * g4 + 3] = tu[g4].w; }
+            // dQ^T[d][query] += sum_key K[key][d] dS^T[key][query]   (rows of K past the sequence end are zero)
+            const bf16_t* Kc = Ks[cur];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 df[3];
+                cut8_regs(st, 8 * s2, df[0], df[1], df[2]);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8 k0 = read_tr8(Kc, lo, 16 * s2, db), k1 = read_tr8(Kc + SIMG, lo, 16 * s2, db), k2 = read_tr8(Kc + 2 * SIMG, lo, 16 * s2, db);
+                    dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, df[2], dqacc[db], 0, 0, 0);
+                    dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, df[1], dqacc[db], 0, 0, 0);
+                    dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, df[0], dqacc[db], 0, 0, 0);
+                    dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, df[1], dqacc[db], 0, 0, 0);
+                    dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, df[0], dqacc[db], 0, 0, 0);
+                    dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, df[0], dqacc[db], 0, 0, 0);
+                }
+            }
+        }
+        if (jt + 3 < n_iter && live(jt + 3)) load_ds(jt + 3, tu);
+        if (more) store_tile32_split(Ks[cur ^ 1], tid, rk, S - (jt * 32 + 32));
+        __syncthreads();
+    };
+    for (int jt = 0; jt < n_iter; jt += 3) {
+        step(jt, t0);
+        if (jt + 1 < n_iter) step(jt + 1, t1);
+        if (jt + 2 < n_iter) step(jt + 2, t2);
+    }
+    if (valid_q) {
+        float* drow = dq + tok * lddq + head * 64;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 t4;
+                t4.x = dqacc[dh][4 * g4 + 0] * scale; t4.y = dqacc[dh][4 * g4 + 1] * scale;
+                t4.z = dqacc[dh][4 * g4 + 2] * scale; t4.w = dqacc[dh][4 * g4 + 3] * scale;
+                *reinterpret_cast<float4*>(drow + 32 * dh + 8 * g4 + 4 * h) = t4;
+            }
+        }
+    }
+}
+
+template <int G, bool ORD>
+__global__ void __launch_bounds__(AT_THREADS, 2)
+attn_bwd_dq2_s_kernel(const float* __restrict__ k, int ldk, const float* __restrict__ ds_in,
+                    const int32_t* __restrict__ row_empty, int nbatch, int S, int nq, int nkv, float scale,
+                    float* __restrict__ dq, int lddq, const RowOrder ro) {
+    constexpr int R = (4 / G) * 32;
+    const int n_tiles = (S + R - 1) / R;
+    const WorkList wl(nbatch * nkv, n_tiles);
+    if (!wl.valid) return;
+    for (int it = 0;; ++it) {
+        const int pair = wl.pair_at(it);
+        if (pair >= wl.n_pairs) break;
+        const int heavy = n_tiles - 1 - wl.u, light = wl.u;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1 && light == heavy) break;
+            attn_bwd_dq2_s_tile<G, ORD>(k, ldk, ds_in, row_empty, S, nq, nkv, scale, dq, lddq, ro, pair,
+                                      pass == 0 ? heavy : light);
+        }
+    }
+}
+
+// Streaming form of the dQ kernel for sequences whose K fits in LDS (S <= 573 at head_dim 64): one workgroup per
+// (sample, kv head) keeps ALL its keys in LDS (137 KB at S = 505), so the loop has no staging, no barrier and no
+// branch - four dS loads for tile t+5, 32 LDS fragment reads and 32 MFMAs per step - and each wave keeps five dS
+// tiles (20 KB) in flight: the kernel runs at the rate the spilled dS comes back from HBM.
+constexpr int DQ3_THREADS = 512;          // two waves per SIMD: twice the dS tiles in flight per CU
 
 template <int G>
 static int launch_fwd_s(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl,
@@ -1121,12 +1342,17 @@ static int launch_bwd_s_variant(const float* q, int ldq, const float* k, int ldk
                                 const float* d_o, const float* lse, float* delta, const int32_t* kl, const int32_t* ql,
                                 const int32_t* row_empty, const int32_t* tile_empty, int B, int S, int nq, int nkv,
                                 float scale, float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk,
-                                float* dv, int lddv, RowOrder ro, int delta_ready, hipStream_t st) {
+                                float* dv, int lddv, RowOrder ro, int delta_ready, float* ds_work, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
-    hipLaunchKernelGGL((attn_bwd_dq_s_kernel<G, DROP, ORD, false>), dim3(worklist_grid(B * nkv, (S + R - 1) / R)), dim3(AT_THREADS),
-                       0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed,
-                       dq, lddq, ro, delta_ready);
-    GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dq");
+    if (ds_work == nullptr) {
+        hipLaunchKernelGGL((attn_bwd_dq_s_kernel<G, DROP, ORD, false>), dim3(worklist_grid(B * nkv, (S + R - 1) / R)),
+                           dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv,
+                           scale, p_drop, seed, dq, lddq, ro, delta_ready);
+        GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dq");
+    } else if (!delta_ready) {
+        hipLaunchKernelGGL(attn_delta_s_kernel, dim3(2048), dim3(AT_THREADS), 0, st, o, d_o, B, S, nq, delta);
+        GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/delta");
+    }
     const size_t shmem = sizeof(DkvSmemS<G>);
     static bool attr_dev[MAX_DEVICES] = {};   // one set of flags per template instantiation, one flag per device
     bool& attr_set = attr_dev[current_device()];
@@ -1142,8 +1368,13 @@ static int launch_bwd_s_variant(const float* q, int ldq, const float* k, int ldk
     const int n_kt = (S + DKV_S_KEYS - 1) / DKV_S_KEYS;
     hipLaunchKernelGGL((attn_bwd_dkv_s_kernel<G, DROP, ORD>), dim3(worklist_grid_1(B * nkv, n_kt)), dim3(256 * G), shmem, st, q, ldq,
                        k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk,
-                       lddk, dv, lddv, ro);
+                       lddk, dv, lddv, ro, ds_work);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dkv");
+    if (ds_work != nullptr) {
+        hipLaunchKernelGGL((attn_bwd_dq2_s_kernel<G, ORD>), dim3(worklist_grid(B * nkv, (S + R - 1) / R)), dim3(AT_THREADS), 0, st,
+                           k, ldk, ds_work, row_empty, B, S, nq, nkv, scale, dq, lddq, ro);
+        GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dq2");
+    }
     return 0;
 }
 
@@ -1152,10 +1383,10 @@ static int launch_bwd_s(const float* q, int ldq, const float* k, int ldk, const 
                         const float* d_o, const float* lse, float* delta, const int32_t* kl, const int32_t* ql,
                         const int32_t* row_empty, const int32_t* tile_empty, int B, int S, int nq, int nkv, float scale,
                         float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
-                        RowOrder ro, int delta_ready, hipStream_t st) {
+                        RowOrder ro, int delta_ready, float* ds_work, hipStream_t st) {
 #define GAMER_LAUNCH_BWD_S(DROPV, ORDV)                                                                                       \
     return launch_bwd_s_variant<G, DROPV, ORDV>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, \
-                                                nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, st)
+                                                nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, ds_work, st)
     if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_BWD_S(true, true); else GAMER_LAUNCH_BWD_S(true, false); }
     else { if (ro.perm) GAMER_LAUNCH_BWD_S(false, true); else GAMER_LAUNCH_BWD_S(false, false); }
 #undef GAMER_LAUNCH_BWD_S
@@ -1199,7 +1430,8 @@ extern "C" int gamer_attn_bwd_split(const float* q, int ldq, const float* k, int
                                     const int32_t* ql, const int32_t* row_empty, const int32_t* tile_empty, int B, int S,
                                     int nq, int nkv, float scale, float p_drop, uint64_t seed, float* delta, float* dq,
                                     int lddq, float* dk, int lddk, float* dv, int lddv, const int32_t* row_perm,
-                                    const int32_t* tile_kind, const int32_t* tile_maxpos, int delta_ready, void* stream) {
+                                    const int32_t* tile_kind, const int32_t* tile_maxpos, int delta_ready, float* ds_work,
+                                    void* stream) {
     int rc = check_attn_split("gamer_attn_bwd_split", q, k, v, kl, row_empty, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
     if (rc) return rc;
     GAMER_CHECK_ARG(o && d_o && lse && tile_empty && delta && dq && dk && dv, "gamer_attn_bwd_split: null pointer");
@@ -1210,6 +1442,6 @@ extern "C" int gamer_attn_bwd_split(const float* q, int ldq, const float* k, int
                     "gamer_attn_bwd_split: gradient buffers must be 16-byte aligned with leading dims %% 4 == 0");
     hipStream_t st = (hipStream_t)stream;
     if (nq / nkv == 1)
-        return launch_bwd_s<1>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, st);
-    return launch_bwd_s<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, st);
+        return launch_bwd_s<1>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, ds_work, st);
+    return launch_bwd_s<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, ds_work, st);
 }

@@ -78,6 +78,13 @@ struct GemmBf16Params {
     const bf16_t* rowdot_other;
     float* rowdot_out;
     int rowdot_S;
+    // EPI 3 (q|k|v projection): per-head RMSNorm x weight + RoPE of the q / k heads (+ behaviour biases), see hb_epilogue
+    const float* qk_wq; const float* qk_wk; float qk_eps;
+    const float* qk_cos; const float* qk_sin;
+    const float* qk_bias_q; const float* qk_bias_k; const float* qk_bias_v;
+    const int32_t* qk_act_idx; const int32_t* qk_pos_ids;
+    bf16_t* qk_q_rot; bf16_t* qk_k_rot;
+    int qk_S, qk_nq, qk_nkv;
 };
 
 __device__ __forceinline__ int xcd_remap_b(int id, int n) {
@@ -187,6 +194,91 @@ __device__ __forceinline__ void hb_epilogue(const GemmBf16Params& p, f32x16 (&ac
                                 Cp[e] = p.resid[e] + m[e & 3] * acc[i][j][r];
                             }
                         }
+                }
+            }
+        } else if (EPI == 3) {
+            // q|k|v projection of the AMP step with qknorm_rope_fwd_b8's arithmetic in the epilogue (full tiles only, checked
+            // on the host): the wave's 64-column patch is ONE head, the lane owns a row and - after the lane-half swap - the 32
+            // columns 32 j + 16 t2 + 8 h + e of it, so the 64-wide sum of squares is a local sum + one cross-half add, and the
+            // RoPE partner d +- 32 is the same (t2, e) of the other j in the SAME lane.  As under autocast
+            // (ref:SeqRec/models/generative/Qwen3Multi/model.py:88-101): the projection output is rounded to bf16 (stored: the
+            // backward reads it), self attention normalises that bf16 value and rounds the normalised value before the fp32
+            // weight, the cross attention adds the fp32 behaviour bias first and stays fp32; RoPE in fp32; q_rot / k_rot bf16.
+            bf16_t* Cp = reinterpret_cast<bf16_t*>(p.C);
+            const int hd = (col0 + wn * 64) >> 6;
+            const bool cross = p.qk_bias_q != nullptr;
+            const bool isq = hd < p.qk_nq, isk = !isq && hd < p.qk_nq + p.qk_nkv;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = row0 + wm * 64 + i * 32 + r32;
+                bf16_t* crow = Cp + (int64_t)row * p.ldc + col0 + wn * 64 + 8 * h;
+                const int a = cross ? p.qk_act_idx[row] : 0;
+                float x[2][2][8];
+                float ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        f32x8v v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * t2 + e]),
+                                                                             __float_as_uint(acc[i][j][8 * t2 + 4 + e]), false, false);
+                            v[e] = __uint_as_float(sw[0]);
+                            v[4 + e] = __uint_as_float(sw[1]);
+                        }
+                        bf16x8 o = __builtin_convertvector(v, bf16x8);
+                        const int c = j * 32 + 16 * t2 + 8 * h;                 // first of this lane's 8 columns of the head
+                        if (isq || isk) {
+                            *reinterpret_cast<bf16x8*>(crow + j * 32 + 16 * t2) = o;          // raw projection output
+                            const float* bias = !cross ? nullptr
+                                : (isq ? p.qk_bias_q + (int64_t)a * p.qk_nq * 64 + hd * 64 + c
+                                       : p.qk_bias_k + (int64_t)a * p.qk_nkv * 64 + (hd - p.qk_nq) * 64 + c);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                float xe = (float)o[e];
+                                if (cross) xe += bias[e];
+                                x[j][t2][e] = xe;
+                                ss += xe * xe;
+                            }
+                        } else {
+                            if (cross) {                                                      // v += bias_v, rounded once more
+                                const float* bias = p.qk_bias_v + (int64_t)a * p.qk_nkv * 64 + (hd - p.qk_nq - p.qk_nkv) * 64 + c;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = (float)o[e] + bias[e];
+                                o = __builtin_convertvector(v, bf16x8);
+                            }
+                            *reinterpret_cast<bf16x8*>(crow + j * 32 + 16 * t2) = o;
+                        }
+                    }
+                if (isq || isk) {
+                    ss += __shfl_xor(ss, 32, 64);
+                    const float rstd = rsqrtf(ss * (1.f / 64.f) + p.qk_eps);
+                    const float* wn_ = isq ? p.qk_wq : p.qk_wk;
+                    const int pos = p.qk_pos_ids ? p.qk_pos_ids[row] : row % p.qk_S;
+                    bf16_t* rot = isq ? p.qk_q_rot + (int64_t)row * p.qk_nq * 64 + hd * 64
+                                      : p.qk_k_rot + (int64_t)row * p.qk_nkv * 64 + (hd - p.qk_nq) * 64;
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        const int c = 16 * t2 + 8 * h;                               // columns c + e (j = 0) and 32 + c + e (j = 1)
+                        float y0[8], y1[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float n0 = x[0][t2][e] * rstd, n1 = x[1][t2][e] * rstd;
+                            if (!cross) { n0 = round_as<bf16_t>(n0); n1 = round_as<bf16_t>(n1); }
+                            y0[e] = wn_[c + e] * n0;
+                            y1[e] = wn_[32 + c + e] * n1;
+                        }
+                        f32x8v o0, o1;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float cs = p.qk_cos[pos * 64 + c + e], sn = p.qk_sin[pos * 64 + c + e];   // cos[d] = cos[d + 32]
+                            o0[e] = y0[e] * cs - y1[e] * sn;                          // rotate_half: d < 32 pairs with -x[d + 32]
+                            o1[e] = y1[e] * cs + y0[e] * sn;
+                        }
+                        *reinterpret_cast<bf16x8*>(rot + c) = __builtin_convertvector(o0, bf16x8);
+                        *reinterpret_cast<bf16x8*>(rot + 32 + c) = __builtin_convertvector(o1, bf16x8);
+                    }
                 }
             }
         } else {
@@ -1049,6 +1141,10 @@ extern "C" int gamer_gemm_bf16(const gamer_gemm_bf16_desc* d, void* stream) {
     p.kchunk = d->kchunk;
     p.resid = d->resid; p.row_map = d->row_map; p.p_drop = d->p_drop; p.seed = d->seed;
     p.rowdot_other = (const bf16_t*)d->rowdot_other; p.rowdot_out = d->rowdot_out; p.rowdot_S = d->rowdot_S;
+    p.qk_wq = d->qk_wq; p.qk_wk = d->qk_wk; p.qk_eps = d->qk_eps; p.qk_cos = d->qk_cos; p.qk_sin = d->qk_sin;
+    p.qk_bias_q = d->qk_bias_q; p.qk_bias_k = d->qk_bias_k; p.qk_bias_v = d->qk_bias_v; p.qk_act_idx = d->qk_act_idx;
+    p.qk_pos_ids = d->qk_pos_ids; p.qk_q_rot = (bf16_t*)d->qk_q_rot; p.qk_k_rot = (bf16_t*)d->qk_k_rot;
+    p.qk_S = d->qk_S; p.qk_nq = d->qk_nq; p.qk_nkv = d->qk_nkv;
     p.n_tiles = (d->N + HB_BN - 1) / HB_BN;
     hipStream_t st = (hipStream_t)stream;
     if (d->group_mode == 0) {
@@ -1066,6 +1162,25 @@ extern "C" int gamer_gemm_bf16(const gamer_gemm_bf16_desc* d, void* stream) {
         p.m_tiles = (d->M + HB_BM - 1) / HB_BM + (d->group_offsets ? d->groups : 0);
         const int64_t blocks = (int64_t)p.m_tiles * p.n_tiles;
         GAMER_CHECK_ARG(blocks < (1LL << 31), "gamer_gemm_bf16: grid too large");
+        if (d->qk_q_rot) {
+            // q|k|v projection with the per-head RMSNorm + RoPE epilogue: full tiles, one group, plain bf16 store
+            GAMER_CHECK_ARG(d->qk_k_rot && d->qk_wq && d->qk_wk && d->qk_cos && d->qk_sin && d->qk_S > 0 && d->qk_nq > 0 && d->qk_nkv > 0 &&
+                            d->N == (d->qk_nq + 2 * d->qk_nkv) * 64 && d->M % HB_BM == 0 && d->N % HB_BN == 0 && d->groups == 1 &&
+                            !d->accumulate && !d->resid && !d->rowdot_out && d->ldc % 8 == 0 && aligned16(d->C) &&
+                            aligned16(d->qk_q_rot) && aligned16(d->qk_k_rot) &&
+                            (!d->qk_bias_q || (d->qk_bias_k && d->qk_bias_v && d->qk_act_idx)),
+                            "gamer_gemm_bf16: the q|k|v epilogue needs N = (nq + 2 nkv) * 64, full 128 x 128 tiles (M=%d N=%d), one "
+                            "group, a plain bf16 C with ldc %% 8 == 0, and bias_k / bias_v / act_idx with bias_q", d->M, d->N);
+            static int big3 = -1;
+            if (big3 < 0) { const char* e = getenv("GAMER_GEMM_BF16_QK_BIG"); big3 = e ? atoi(e) : 1; }
+            if (big3 && d->M % HG_BM == 0 && d->N % HG_BN == 0 && d->M >= 16 * HG_BM) {
+                GemmBf16Params q = p;
+                q.n_tiles = d->N / HG_BN;
+                q.m_tiles = d->M / HG_BM;
+                return launch_big<3, false>(q, q.m_tiles * q.n_tiles, st);
+            }
+            return launch_hb<3, false>(p, (int)blocks, st);
+        }
         static int big = -1;
         // 0: 128^2 only; 1 (default): 256^2 where its last column tile is well filled, else the wave-specialised 256 x 128
         // form (N = 320: 0.321 against 0.345 ms), else 128^2; 2: wave-specialised wherever it applies.  Measured per shape

@@ -152,6 +152,50 @@ std::tuple<Tensor, Tensor> swiglu_bwd(const Tensor& g, const Tensor& u, const Te
     return {dg, du};
 }
 
+// ---- position-routed SwiGLU experts as one op (FFN.py:53-72 in expert-sorted order) ---------------------------------------
+// hin [T, din] fp32 rows sorted by expert (gamer_expert_lists), w_gate / w_up [E*I, din] stacked per expert, offsets int32 [E+1]:
+// g = hin W_gate_e^T, u = hin W_up_e^T as grouped GEMMs over the expert segments, hm = dropout(silu(g) * u).
+void grouped_gemm_f32(const float* A, int64_t a_rs, int64_t a_ks, const float* B, int64_t b_rs, int64_t b_ks, float* C, int64_t ldc,
+                      int M, int N, int K, int groups, int mode, const int32_t* offs, int64_t strideB, int64_t strideC, int kchunk,
+                      int accumulate, const char* what) {
+    gamer_gemm_desc d{};
+    d.A = A; d.a_rs = a_rs; d.a_ks = a_ks; d.B = B; d.b_rs = b_rs; d.b_ks = b_ks; d.C = C; d.ldc = ldc;
+    d.M = M; d.N = N; d.K = K; d.alpha = 1.f; d.accumulate = accumulate; d.groups = groups; d.group_mode = mode;
+    d.group_offsets = offs; d.strideB = strideB; d.strideC = strideC; d.kchunk = kchunk;
+    check(gamer_gemm_f32(&d, cur_stream()), what);
+}
+std::tuple<Tensor, Tensor, Tensor> routed_swiglu_fwd(const Tensor& hin, const Tensor& w_gate, const Tensor& w_up, const Tensor& offsets,
+                                                     double p_drop, int64_t seed) {
+    need(hin, "hin", at::kFloat); need(w_gate, "w_gate", at::kFloat); need(w_up, "w_up", at::kFloat); need(offsets, "offsets", at::kInt);
+    TORCH_CHECK(hin.dim() == 2 && w_gate.dim() == 2 && w_gate.sizes() == w_up.sizes() && w_gate.size(1) == hin.size(1) && offsets.dim() == 1 &&
+                offsets.numel() >= 2 && w_gate.size(0) % (offsets.numel() - 1) == 0,
+                "routed_swiglu_fwd: hin [T,din], w_gate / w_up [E*I,din], offsets [E+1]; got ", hin.sizes(), " ", w_gate.sizes(), " ", offsets.sizes());
+    const int T = (int)hin.size(0), din = (int)hin.size(1), E = (int)offsets.numel() - 1, I = (int)(w_gate.size(0) / E);
+    Tensor g = at::empty({T, I}, hin.options()), u = at::empty({T, I}, hin.options()), hm = at::empty({T, I}, hin.options());
+    grouped_gemm_f32(ptr<float>(hin), din, 1, ptr<float>(w_gate), din, 1, ptr<float>(g), I, T, I, din, E, 0, ptr<int32_t>(offsets), (int64_t)I * din, 0, 0, 0, "gamer_gemm_f32 (gate)");
+    grouped_gemm_f32(ptr<float>(hin), din, 1, ptr<float>(w_up), din, 1, ptr<float>(u), I, T, I, din, E, 0, ptr<int32_t>(offsets), (int64_t)I * din, 0, 0, 0, "gamer_gemm_f32 (up)");
+    check(gamer_swiglu_fwd(ptr<float>(g), ptr<float>(u), g.numel(), (float)p_drop, (uint64_t)seed, ptr<float>(hm), cur_stream()), "gamer_swiglu_fwd");
+    return {g, u, hm};
+}
+// (dhin, dw_gate, dw_up) from d(hm); g, u, hin as returned / passed by routed_swiglu_fwd
+std::tuple<Tensor, Tensor, Tensor> routed_swiglu_bwd(const Tensor& g, const Tensor& u, const Tensor& dhm, const Tensor& hin,
+                                                     const Tensor& w_gate, const Tensor& w_up, const Tensor& offsets, double p_drop,
+                                                     int64_t seed) {
+    need(g, "g", at::kFloat); need(u, "u", at::kFloat); need(dhm, "dhm", at::kFloat); need(hin, "hin", at::kFloat);
+    need(w_gate, "w_gate", at::kFloat); need(w_up, "w_up", at::kFloat); need(offsets, "offsets", at::kInt);
+    TORCH_CHECK(g.sizes() == u.sizes() && g.sizes() == dhm.sizes() && hin.size(0) == g.size(0) && w_gate.sizes() == w_up.sizes(),
+                "routed_swiglu_bwd: shapes");
+    const int T = (int)hin.size(0), din = (int)hin.size(1), E = (int)offsets.numel() - 1, I = (int)g.size(1);
+    Tensor dg = g.clone(), du = u.clone();                       // gamer_swiglu_bwd works in place
+    check(gamer_swiglu_bwd(ptr<float>(dg), ptr<float>(du), ptr<float>(dhm), g.numel(), (float)p_drop, (uint64_t)seed, cur_stream()), "gamer_swiglu_bwd");
+    Tensor dwg = at::zeros_like(w_gate), dwu = at::zeros_like(w_up), dhin = at::empty_like(hin);
+    const int kchunk = 1024;                                     // token chunk of the split-K weight gradient (gamer_amd/ops.py: pick_kchunk)
+    grouped_gemm_f32(ptr<float>(dg), 1, I, ptr<float>(hin), 1, din, ptr<float>(dwg), din, I, din, T, E, 1, ptr<int32_t>(offsets), 0, (int64_t)I * din, kchunk, 1, "gamer_gemm_f32 (gate wgrad)");
+    grouped_gemm_f32(ptr<float>(du), 1, I, ptr<float>(hin), 1, din, ptr<float>(dwu), din, I, din, T, E, 1, ptr<int32_t>(offsets), 0, (int64_t)I * din, kchunk, 1, "gamer_gemm_f32 (up wgrad)");
+    grouped_gemm_f32(ptr<float>(dg), I, 1, ptr<float>(w_gate), 1, din, ptr<float>(dhin), din, T, din, I, E, 0, ptr<int32_t>(offsets), (int64_t)I * din, 0, 0, 0, "gamer_gemm_f32 (gate dgrad)");
+    grouped_gemm_f32(ptr<float>(du), I, 1, ptr<float>(w_up), 1, din, ptr<float>(dhin), din, T, din, I, E, 0, ptr<int32_t>(offsets), (int64_t)I * din, 0, 0, 1, "gamer_gemm_f32 (up dgrad)");
+    return {dhin, dwg, dwu};
+}
 // ---- tied head loss: temperature + shifted cross entropy (model.py:904-922) -----------------------------------------
 // logits [B*S, ld] are divided by the temperature IN PLACE (as upstream); returns (sum CE, #targets, per-row lse)
 std::tuple<Tensor, Tensor, Tensor> lmhead_ce_fwd(Tensor logits, const Tensor& labels, int64_t V, double temperature) {
@@ -200,6 +244,9 @@ TORCH_LIBRARY(gamer, m) {
           "Tensor tile_empty, int B, int S, int nq, int nkv, float scale, float p_drop=0.0, int seed=0) -> (Tensor, Tensor, Tensor)");
     m.def("swiglu_fwd(Tensor g, Tensor u, float p_drop=0.0, int seed=0) -> Tensor");
     m.def("swiglu_bwd(Tensor g, Tensor u, Tensor dhm, float p_drop=0.0, int seed=0) -> (Tensor, Tensor)");
+    m.def("routed_swiglu_fwd(Tensor hin, Tensor w_gate, Tensor w_up, Tensor offsets, float p_drop=0.0, int seed=0) -> (Tensor, Tensor, Tensor)");
+    m.def("routed_swiglu_bwd(Tensor g, Tensor u, Tensor dhm, Tensor hin, Tensor w_gate, Tensor w_up, Tensor offsets, float p_drop=0.0, "
+          "int seed=0) -> (Tensor, Tensor, Tensor)");
     m.def("lmhead_ce_fwd(Tensor(a!) logits, Tensor labels, int V, float temperature) -> (Tensor, Tensor, Tensor)");
     m.def("lmhead_ce_bwd(Tensor(a!) logits, Tensor labels, Tensor lse, int V, float temperature, Tensor denom, Tensor dloss) -> ()");
     m.def("fused_adamw_clip(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, int n_decay, float lr, float beta1, float beta2, "
@@ -215,6 +262,8 @@ TORCH_LIBRARY_IMPL(gamer, CUDA, m) {
     m.impl("mb_attention_bwd", mb_attention_bwd);
     m.impl("swiglu_fwd", swiglu_fwd);
     m.impl("swiglu_bwd", swiglu_bwd);
+    m.impl("routed_swiglu_fwd", routed_swiglu_fwd);
+    m.impl("routed_swiglu_bwd", routed_swiglu_bwd);
     m.impl("lmhead_ce_fwd", lmhead_ce_fwd);
     m.impl("lmhead_ce_bwd", lmhead_ce_bwd);
     m.impl("fused_adamw_clip", fused_adamw_clip);

@@ -23,6 +23,7 @@ Data layout in HBM (T = B*S tokens, row t = b*S + s, everything fp32):
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -223,8 +224,8 @@ class _Workspace:
     ``act`` is the dtype of the activations the GEMMs read and write: fp32, or bf16 for the AMP variant (the
     residual stream, the normalisation statistics and everything the optimizer touches stay fp32)."""
 
-    def __init__(self, cfg: Qwen3MultiConfig, device, train: bool, act: torch.dtype = torch.float32):
-        self.cfg, self.device, self.train, self.act = cfg, device, train, act
+    def __init__(self, cfg: Qwen3MultiConfig, device, train: bool, act: torch.dtype = torch.float32, spill: bool = True):
+        self.cfg, self.device, self.train, self.act, self.spill = cfg, device, train, act, spill
         self._store: Dict[str, torch.Tensor] = {}
         self.B = self.S = self.T = 0
         self.loss_sum = torch.zeros(1, dtype=torch.float32, device=device)
@@ -328,7 +329,8 @@ class _Workspace:
             # 6.4 GB at B = 1024, shared by all layers.  GAMER_ATTN_SPILL=0 keeps the two recompute kernels.
             import os
             self.ds_work = (buf("ds_work", (ops.attn_ds_work_numel(B, S, nq),), f32)
-                            if (os.environ.get("GAMER_ATTN_SPILL", "1") != "0" and act == torch.float32) else None)
+                            if (os.environ.get("GAMER_ATTN_SPILL", "1") != "0" and act == torch.float32 and self.spill)
+                            else None)
         return self
 
 
@@ -339,7 +341,7 @@ class Engine:
     N_SUMSQ_PARTIAL = 1024
 
     def __init__(self, cfg: Qwen3MultiConfig, device="cuda", temperature: float = 1.0, variant: str = "multi",
-                 dtype: str = "f32", matmul: str = "f32"):
+                 dtype: str = "f32", matmul: Optional[str] = None):
         """``variant``: "multi" = Qwen3Multi (train_SMB_decoder.py:362-364), "session" = Qwen3SessionMulti
         (train_SMB_decoder.py:365-367): the same parameters and layers with session-wise attention masks and
         RoPE positions taken from ``extended_session_ids``.
@@ -352,6 +354,9 @@ class Engine:
         the fp32 MFMA's, tools/split_error.py).  The attention products take the same form (gamer_attn_fwd_split /
         gamer_attn_bwd_split, csrc/attention_split.hip; ``self.split_attention = False`` keeps them on the fp32 MFMA)."""
         cfg.validate()
+        if matmul is None:
+            # default of the fp32 path: products on the bf16 pipe from exact cuts (DESIGN.md section 13); "f32" = fp32 MFMA
+            matmul = "split6" if dtype == "f32" else "f32"
         if matmul not in ops.MATMUL_MODES:
             raise ValueError(f"unknown matmul {matmul!r} ({sorted(ops.MATMUL_MODES)})")
         if dtype != "f32" and matmul != "f32":
@@ -362,6 +367,10 @@ class Engine:
         # on gfx950 epilogue work is matrix-pipe time), the removed kernel had cost 8.1 ms: 373.9-375.4 against 373.4-377 ms
         # per step, inside the box-to-box noise.  Off by default; Engine.fuse_qkv = True turns it on.
         self.fuse_qkv = False
+        # the same epilogue in the bf16 GEMM (gamer_gemm_bf16_desc.qk_*; round 3): the twelve projections got 4.5 ms slower per
+        # step at batch 1024 (9.4 -> 13.9 ms), the removed kernel had cost 4.2 ms: 108.4 vs 108.7 ms, 16.7 vs 16.6 ms at batch 128
+        # - neutral again.  Off by default; GAMER_FUSE_QKV_BF16=1 or Engine.fuse_qkv_bf16 = True turns it on.
+        self.fuse_qkv_bf16 = os.environ.get("GAMER_FUSE_QKV_BF16", "0") == "1"
         # attention products of the split forms on the bf16 pipe too (csrc/attention_split.hip); False keeps fp32-MFMA attention
         self.split_attention = True
         if variant not in ("multi", "session"):
@@ -446,7 +455,10 @@ class Engine:
         """The train and the scoring workspace live side by side (an epoch's evaluation does not evict the training
         buffers); each is bound to the shape of the current batch without reallocating (grow-only storage)."""
         if train not in self._ws:
-            self._ws[train] = _Workspace(self.cfg, self.device, train, self.act_dtype)
+            # the 6.4 GB dS-spill scratch is the fp32-MFMA attention backward's; the split form (recompute) does not use
+            # it - unless the session variant sends its span calls to the fp32-MFMA kernels
+            spill = not (self.split_attention and self.matmul != "f32" and self.variant == "multi")
+            self._ws[train] = _Workspace(self.cfg, self.device, train, self.act_dtype, spill=spill)
         return self._ws[train].bind(B, S)
 
     def reserve(self, B: int, S: int, train: bool = True):
@@ -554,7 +566,8 @@ class Engine:
         emb_m = self.shadow.params16["model.embed_tokens.weight"] if bf16 else self.params["model.embed_tokens.weight"]
 
         # fp32: the q|k|v projection carries per-head RMSNorm + RoPE in its epilogue when its tiles are whole
-        fuse_qkv = (not bf16) and self.fuse_qkv and ops.qkv_fused_ok(ws.x[0][0], T, QKV) and cfg.head_dim == 64
+        fuse_qkv = ((self.fuse_qkv_bf16 if bf16 else self.fuse_qkv) and ops.qkv_fused_ok(ws.layers[0]["h1"], T, QKV)
+                    and cfg.head_dim == 64)
 
         # matmul="split6" / "split9": the attention products run on the bf16 pipe as well (gamer_attn_fwd_split: exact
         # three-way cuts, six piece products); the session variant's key spans and the evaluation re-run path stay on the
@@ -752,7 +765,7 @@ class Engine:
             if split_attn and span_ is None:
                 ops.attn_bwd_split(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, empty_, tile_empty_, B, S, nq, nkv, scale,
                                    p_att, seed_, ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, order=order_,
-                                   delta_ready=fuse_delta)
+                                   delta_ready=fuse_delta)       # recompute form: measured faster than its dS spill
             elif bf16:
                 ord16 = (order_[0], order_[2], empty_) if (order_ is not None and span_ is None) else None
                 ops.attn_bwd_bf16(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, B, S, nq, nkv, scale, p_att, seed_,

@@ -100,13 +100,14 @@ except Exception:                                             # noqa: BLE001
 class Qwen3MultiWithTemperature(nn.Module):
     VARIANT = "multi"
 
-    def __init__(self, config, device: str = "cuda", dtype: str = "f32"):
+    def __init__(self, config, device: str = "cuda", dtype: str = "f32", matmul: Optional[str] = None):
         """``config``: the object the reference constructs its model from - a transformers ``Qwen3MoeConfig`` loaded from
         config.json and mutated by the task (ref:SeqRec/tasks/train_SMB_decoder.py:231, 335-368) - or a
         ``gamer_amd.config.Qwen3MultiConfig`` / dict with the same fields.  ``self.config`` stays the caller's object
         (the task keeps writing to it: ``model.config.use_cache = False``, :442); the engine gets a plain copy.
         ``dtype="bf16"``: what the reference gets from ``--bf16`` (HF Trainer autocast) is a property of the engine
-        here - bf16 matrix operands and activations, fp32 parameters / gradients (the nn.Parameters stay fp32)."""
+        here - bf16 matrix operands and activations, fp32 parameters / gradients (the nn.Parameters stay fp32).
+        ``matmul``: the engine's form of the fp32 matrix products (None = its default "split6"; "f32" = fp32 MFMA)."""
         super().__init__()
         assert hasattr(config, "num_positions") and isinstance(config.num_positions, int), \
             "Config must have 'num_positions' attribute for Qwen3SessionModel."
@@ -117,7 +118,7 @@ class Qwen3MultiWithTemperature(nn.Module):
         self.vocab_size = config.vocab_size
         self.temperature = 1.0
         self.zero_copy_logits = False       # True: the training forward returns a view of the engine's logits buffer
-        self.engine = Engine(self._cfg, device=device, temperature=1.0, variant=self.VARIANT, dtype=dtype)
+        self.engine = Engine(self._cfg, device=device, temperature=1.0, variant=self.VARIANT, dtype=dtype, matmul=matmul)
         self.engine.init_weights(seed=0)
         self._param_keys = list(self.engine.layout.entries.keys())
         self._register_views()
@@ -162,7 +163,7 @@ class Qwen3MultiWithTemperature(nn.Module):
         self._cfg.vocab_size = int(new_num_tokens)
         self.vocab_size = int(new_num_tokens)
         self.engine = Engine(self._cfg, device=str(self.engine.device), temperature=self.temperature,
-                             variant=self.VARIANT, dtype=self.engine.dtype)
+                             variant=self.VARIANT, dtype=self.engine.dtype, matmul=self.engine.matmul)
         self.engine.init_weights(seed=0)
         for name in list(self._modules):                      # drop the old parameter tree
             del self._modules[name]
@@ -200,9 +201,9 @@ class Qwen3MultiWithTemperature(nn.Module):
             torch.save(sd, os.path.join(path, "pytorch_model.bin"))
 
     @classmethod
-    def from_pretrained(cls, path: str, device: str = "cuda", dtype: str = "f32"):
+    def from_pretrained(cls, path: str, device: str = "cuda", dtype: str = "f32", matmul: Optional[str] = None):
         cfg = Qwen3MultiConfig.from_pretrained(path)
-        model = cls(cfg, device=device, dtype=dtype)
+        model = cls(cfg, device=device, dtype=dtype, matmul=matmul)
         st = os.path.join(path, "model.safetensors")
         if os.path.exists(st):
             from safetensors.torch import load_file

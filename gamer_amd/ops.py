@@ -179,7 +179,7 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
     gamer_gemm_bf16 (k-contiguous x k-contiguous, or the token-major wgrad form; see gamer_gemm_bf16_desc)."""
     if A.dtype == torch.bfloat16:
         return _gemm_bf16(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha, accumulate, groups, group_mode,
-                          group_offsets, strideB, strideC, kchunk, resid, row_map, p_drop, seed, rowdot)
+                          group_offsets, strideB, strideC, kchunk, resid, row_map, p_drop, seed, rowdot, qknorm)
     d = GemmDesc()
     d.A = ptr(A); d.a_rs = a_rs; d.a_ks = a_ks
     d.B = ptr(Bm); d.b_rs = b_rs; d.b_ks = b_ks
@@ -213,7 +213,7 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
 
 
 def _gemm_bf16(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha, accumulate, groups, group_mode, group_offsets,
-               strideB, strideC, kchunk, resid, row_map, p_drop, seed, rowdot):
+               strideB, strideC, kchunk, resid, row_map, p_drop, seed, rowdot, qknorm=None):
     if Bm.dtype != torch.bfloat16 or alpha != 1.0:
         raise RuntimeError("gamer_gemm_bf16 takes two bf16 operands and alpha = 1")
     d = GemmBf16Desc()
@@ -237,6 +237,14 @@ def _gemm_bf16(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha, accumulat
     d.resid, d.row_map, d.p_drop, d.seed = ptr(resid), ptr(row_map), p_drop, seed
     if rowdot is not None:
         d.rowdot_other, d.rowdot_out, d.rowdot_S = ptr(rowdot[0]), ptr(rowdot[1]), int(rowdot[2])
+    if qknorm is not None:                 # the q|k|v epilogue (AMP arithmetic of qknorm_rope_fwd on bf16 activations)
+        q = qknorm
+        d.qk_wq, d.qk_wk, d.qk_eps = ptr(q["wq"]), ptr(q["wk"]), float(q["eps"])
+        d.qk_cos, d.qk_sin = ptr(q["cos"]), ptr(q["sin"])
+        d.qk_bias_q, d.qk_bias_k, d.qk_bias_v = ptr(q.get("bias_q")), ptr(q.get("bias_k")), ptr(q.get("bias_v"))
+        d.qk_act_idx, d.qk_pos_ids = ptr(q.get("act_idx")), ptr(q.get("pos_ids"))
+        d.qk_q_rot, d.qk_k_rot = ptr(q["q_rot"]), ptr(q["k_rot"])
+        d.qk_S, d.qk_nq, d.qk_nkv = int(q["S"]), int(q["nq"]), int(q["nkv"])
     call("gamer_gemm_bf16", C.byref(d), stream_ptr())
 
 
@@ -247,8 +255,8 @@ def linear_dgrad_t(dy, lddy, WT, ldwt, dx, lddx, M, K_out, N_in, accumulate=Fals
 
 
 def qkv_fused_ok(x, M: int, N: int) -> bool:
-    """The q|k|v GEMM can carry the per-head RMSNorm + RoPE epilogue: fp32 operands, whole 128-row / 128-column tiles."""
-    return x.dtype == torch.float32 and M % 128 == 0 and N % 128 == 0
+    """The q|k|v GEMM can carry the per-head RMSNorm + RoPE epilogue: whole 128-row / 128-column tiles (fp32 or bf16)."""
+    return x.dtype in (torch.float32, torch.bfloat16) and M % 128 == 0 and N % 128 == 0
 
 
 def linear_fwd(x, ldx, W, ldw, y, ldy, M, N, K, accumulate=False, **grp):
@@ -454,12 +462,13 @@ def attn_fwd_split(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, sca
 
 
 def attn_bwd_split(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed,
-                   delta, dq, lddq, dk, lddk, dv, lddv, order=None, delta_ready=False):
-    """gamer_attn_bwd (recompute form) with its products on the bf16 pipe; delta_ready: `delta` already holds dO.O."""
+                   delta, dq, lddq, dk, lddk, dv, lddv, order=None, delta_ready=False, ds_work=None):
+    """gamer_attn_bwd with its products on the bf16 pipe; delta_ready: `delta` already holds dO.O; ds_work: the dS spill
+    scratch of attn_bwd (None = recompute form)."""
     pm, tk, tm = order if order is not None else (None, None, None)
     call("gamer_attn_bwd_split", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), ptr(d_o), ptr(lse), ptr(kl), ptr(ql),
          ptr(row_empty), ptr(tile_empty), B, S, nq, nkv, scale, p_drop, seed, ptr(delta), ptr(dq), lddq, ptr(dk), lddk, ptr(dv),
-         lddv, ptr(pm), ptr(tk), ptr(tm), 1 if delta_ready else 0, stream_ptr())
+         lddv, ptr(pm), ptr(tk), ptr(tm), 1 if delta_ready else 0, ptr(ds_work), stream_ptr())
 
 
 def attn_fwd_bf16(q, ldq, k, ldk, v, ldv, kl, ql, B, S, nq, nkv, scale, p_drop, seed, o, lse, q_span=None, order=None):

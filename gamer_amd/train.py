@@ -58,6 +58,9 @@ def parse_args(argv=None):
                     help="the reference's --bf16 (train_SMB_decoder.py:114-118): bf16 matrix operands / activations, "
                          "fp32 master weights, gradients and optimizer state")
     ap.add_argument("--fp16", action="store_true", help="accepted for flag compatibility and refused: not built")
+    ap.add_argument("--matmul", choices=["f32", "split6", "split9"], default=None,
+                    help="fp32 runs: how matrix products are formed (default: the engine's, split6 = exact bf16 piece products "
+                         "with fp32 accumulation; f32 = the fp32 MFMA)")
     ap.add_argument("--prefetch", type=int, default=2, help="optimizer steps collated ahead on a background thread")
     ap.add_argument("--output_dir", type=str, default="")
     ap.add_argument("--resume_from_checkpoint", type=str, default="")
@@ -180,7 +183,7 @@ def main(argv=None):
     else:
         cfg = synthetic_config(n_positions=args.max_his_len + 1)
     eng = Engine(cfg, device=f"cuda:{local_rank}", temperature=args.temperature, variant=variant,
-                 dtype="bf16" if args.bf16 else "f32")
+                 dtype="bf16" if args.bf16 else "f32", matmul=None if args.bf16 else args.matmul)
     eng.init_weights(seed=args.seed)
     # one workspace for the longest batch the collator can produce: shorter batches bind views of it, nothing is
     # allocated inside the loop

@@ -252,6 +252,16 @@ typedef struct {
     const gamer_bf16* rowdot_other;
     float* rowdot_out;
     int rowdot_S;
+    /* optional (ABI 5): the q|k|v projection of an attention with qknorm_rope_fwd's work in the epilogue, as qk_* of
+     * gamer_gemm_desc but with the AMP arithmetic of gamer_qknorm_rope_fwd_bf16: C = raw q|k|v (bf16; v + bias_v in the cross
+     * attention), q_rot / k_rot = RoPE(w * rmsnorm(q | k (+ bias))) as bf16 [M, nq*64] / [M, nkv*64].  qk_q_rot != NULL
+     * selects it; needs N = (nq + 2 nkv) * 64, M %% 128 == 0, one group, no accumulate / resid / rowdot. */
+    const float* qk_wq; const float* qk_wk; float qk_eps;
+    const float* qk_cos; const float* qk_sin;
+    const float* qk_bias_q; const float* qk_bias_k; const float* qk_bias_v;
+    const int32_t* qk_act_idx; const int32_t* qk_pos_ids;
+    gamer_bf16* qk_q_rot; gamer_bf16* qk_k_rot;
+    int qk_S, qk_nq, qk_nkv;
 } gamer_gemm_bf16_desc;
 
 int gamer_gemm_bf16(const gamer_gemm_bf16_desc* d, void* stream);
@@ -364,8 +374,10 @@ int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float
  * fp32 accumulation - the attention counterpart of gamer_gemm_f32_split (csrc/attention_split.hip; same predicate,
  * empty-row rule, row order and dropout mask function as gamer_attn_fwd / _bwd, so the three kernels of either form
  * regenerate the same masks).  Replaces ref:SeqRec/models/generative/Qwen3Multi/model.py:133-143 in the
- * Engine(matmul="split6") step.  bwd = recompute form (dQ kernel + dK/dV kernel, no workspace); delta_ready != 0: delta
- * already holds dO.O (row-dot epilogue of the o_proj dgrad GEMM), otherwise the dQ kernel computes and publishes it. */
+ * Engine(matmul="split6") step.  bwd: ds_work == NULL = recompute form (dQ kernel + dK/dV kernel, 7 products per tile
+ * pair); ds_work = the scratch of gamer_attn_bwd (B*nq*ceil(S/32)^2*1024 floats) = the dK/dV kernel spills its fp32 dS
+ * tiles and dQ = dS K is one product per tile pair (5 products).  delta_ready != 0: delta already holds dO.O (row-dot
+ * epilogue of the o_proj dgrad GEMM), otherwise it is computed here. */
 int gamer_attn_fwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                          const int32_t* kl, const int32_t* ql, const int32_t* row_empty,
                          int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
@@ -377,7 +389,7 @@ int gamer_attn_bwd_split(const float* q, int ldq, const float* k, int ldk, const
                          int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                          float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                          const int32_t* row_perm, const int32_t* tile_kind, const int32_t* tile_maxpos,
-                         int delta_ready, void* stream);
+                         int delta_ready, float* ds_work, void* stream);
 
 /* bf16 attention of the reference's --bf16 run (autocast casts q, k, v AND the additive mask of
  * sdpa_attention_forward to bf16).  Same predicate, layouts and dropout mask function as gamer_attn_fwd / _bwd, with

@@ -262,6 +262,50 @@ def test_ce_bf16_matches_reference_arithmetic():
     assert bool((lg.cpu()[:, V:] == 0).all())
 
 
+@pytest.mark.parametrize("B_,S", [(2, 128), (16, 40), (128, 505), (256, 505)])
+@pytest.mark.parametrize("cross", [False, True])
+def test_gemm_bf16_qkv_epilogue_equals_gemm_then_qknorm_rope(cross, B_, S):
+    """The bf16 q|k|v projection with the per-head RMSNorm + RoPE epilogue (gamer_gemm_bf16_desc.qk_*; both tile forms: the
+    last shape takes the 256 x 256 kernel) against the two-kernel form: bit-identical raw q|k|v (v + bias_v in the cross
+    attention), rotated q / k within one bf16 ulp (the 64-wide sum of squares is grouped differently).  256 x 505 tokens take
+    the 256 x 256 tile form, 128 x 505 the 128 x 128 one."""
+    nq, nkv, H, nb1 = 6, 3, 256, 4
+    T, QKV = B_ * S, (nq + 2 * nkv) * 64
+    assert T % 128 == 0
+    g = torch.Generator().manual_seed(23)
+    x, W = _bfr(torch.randn(T, H, generator=g)).to(BF), (_bfr(torch.randn(QKV, H, generator=g) * 0.1)).to(BF)
+    wq, wk = 1 + 0.1 * torch.randn(64, generator=g), 1 + 0.1 * torch.randn(64, generator=g)
+    cos, sin = orc.rope_tables(S, 64, 1e6)
+    pos_ids = dev(torch.randint(0, S, (T,), generator=g).int()) if (cross and S == 40) else None
+    bias = dict(bias_q=dev(torch.randn(nb1, nq * 64, generator=g)), bias_k=dev(torch.randn(nb1, nkv * 64, generator=g)),
+                bias_v=dev(torch.randn(nb1, nkv * 64, generator=g)),
+                act_idx=dev(torch.randint(0, nb1, (T,), generator=g).int())) if cross else {}
+    ref = torch.empty(T, QKV, dtype=BF, device=DEV)
+    q_ref, k_ref = torch.empty(T, nq * 64, dtype=BF, device=DEV), torch.empty(T, nkv * 64, dtype=BF, device=DEV)
+    ops.linear_fwd(dev(x), H, dev(W), H, ref, QKV, T, QKV, H)
+    ops.qknorm_rope_fwd(ref, S, nq, nkv, dev(wq), dev(wk), 1e-6, dev(cos), dev(sin), q_ref, k_ref, pos_ids=pos_ids, **bias)
+    out = torch.full((T, QKV), float("nan"), dtype=BF, device=DEV)
+    q_rot, k_rot = torch.full_like(q_ref, float("nan")), torch.full_like(k_ref, float("nan"))
+    assert ops.qkv_fused_ok(dev(x), T, QKV)
+    ops.gemm(dev(x), H, 1, dev(W), H, 1, out, QKV, T, QKV, H,
+             qknorm=dict(wq=dev(wq), wk=dev(wk), eps=1e-6, cos=dev(cos), sin=dev(sin), q_rot=q_rot, k_rot=k_rot, pos_ids=pos_ids,
+                         S=S, nq=nq, nkv=nkv, **bias))
+    assert torch.equal(out, ref)                      # (the two-kernel form's v + bias_v is written back in place as well)
+
+    def ulps(a, b, heads):
+        """largest difference in units of the bf16 spacing at the magnitude of the rotated PAIR (d, d + 32): RoPE keeps the
+        pair's norm, and a component can cancel to far below it"""
+        a, b = a.float().view(T, heads, 2, 32), b.float().view(T, heads, 2, 32)
+        mag = b.pow(2).sum(2, keepdim=True).sqrt().clamp_min(2.0 ** -6)
+        spacing = torch.exp2(torch.floor(torch.log2(mag)) - 7)
+        return float(((a - b).abs() / spacing).max())
+    # one rounding may flip; in the self attention the normalised value is rounded before the weight as well: two
+    assert ulps(q_rot, q_ref, nq) <= (1 if cross else 2) and ulps(k_rot, k_ref, nkv) <= (1 if cross else 2)
+    assert float((q_rot.float() - q_ref.float()).abs().max()) < 2e-2 * float(q_ref.float().abs().max())
+    mism = float((q_rot != q_ref).float().mean())
+    assert mism < 0.02, mism                           # a different summation grouping flips a rounding now and then, no more
+
+
 @pytest.mark.parametrize("cross", [False, True])
 def test_qknorm_rope_bf16(cross):
     """Against a torch restatement with the casts autocast makes (see the kernel's header comment), fwd and bwd."""

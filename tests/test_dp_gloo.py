@@ -54,6 +54,11 @@ def _worker(rank, world, port, numel_scale, out):
         cnt = torch.tensor([3.0 + rank])
         all_reduce_scalar_(cnt)
         ok = ok and float(cnt) == 7.0
+        # the same bucket sum as a dispatcher op (torch.ops.gamer.allreduce_bucket)
+        from gamer_amd import torch_ops
+        t = torch.arange(6.0) + 10 * rank
+        torch_ops.load().allreduce_bucket(t, 1, 4)
+        ok = ok and torch.equal(t, torch.tensor([0.0, 12.0, 14.0, 16.0, 4.0, 5.0]) + torch.tensor([10.0 * rank, 0, 0, 0, 10.0 * rank, 10.0 * rank]))
         out[rank] = bool(ok)
     finally:
         dist.destroy_process_group()

@@ -140,3 +140,42 @@ def test_fused_optimizer_runs_through_the_registered_op():
     assert abs(float(model.engine.grad_norm) - float(eng.grad_norm)) < 1e-4 * float(eng.grad_norm)
     sd = opt.state_dict()
     assert sd["state"]["step"] == 3 and sd["state"]["m"] is not None
+
+
+@pytest.mark.gpu
+def test_routed_swiglu_ops_against_dense_reference():
+    """gamer::routed_swiglu_fwd / _bwd (FFN.py:53-72 in expert-sorted order) against a per-expert fp64 loop."""
+    ns = torch_ops.load()
+    dev = "cuda"
+    g = torch.Generator().manual_seed(3)
+    E, I, din = 6, 128, 96
+    sizes = [0, 130, 257, 1, 64, 200]                       # expert 0 empty (the pad / eos expert), ragged segments
+    offs = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32)
+    T = int(offs[-1])
+    hin = torch.randn(T, din, generator=g)
+    wg, wu = torch.randn(E * I, din, generator=g) * 0.1, torch.randn(E * I, din, generator=g) * 0.1
+    dhm = torch.randn(T, I, generator=g)
+    gt, ut, hm = ns.routed_swiglu_fwd(hin.to(dev), wg.to(dev), wu.to(dev), offs.to(dev))
+    leaves = [t.double().requires_grad_(True) for t in (hin, wg, wu)]
+    outs = []
+    for e in range(E):
+        a, b = int(offs[e]), int(offs[e + 1])
+        x = leaves[0][a:b]
+        ge, ue = x @ leaves[1][e * I:(e + 1) * I].T, x @ leaves[2][e * I:(e + 1) * I].T
+        outs.append(torch.nn.functional.silu(ge) * ue)
+    ref = torch.cat(outs)
+    (ref * dhm.double()).sum().backward()
+    rel = lambda got, want: float((got.cpu().double() - want).abs().max() / want.abs().max())
+    assert rel(hm, ref.detach()) < 2e-6
+    dhin, dwg, dwu = ns.routed_swiglu_bwd(gt, ut, dhm.to(dev), hin.to(dev), wg.to(dev), wu.to(dev), offs.to(dev))
+    assert rel(dhin, leaves[0].grad) < 5e-6 and rel(dwg, leaves[1].grad) < 5e-6 and rel(dwu, leaves[2].grad) < 5e-6
+    assert float(dwg[:I].abs().max()) == 0.0                 # the empty expert gets a zero gradient
+
+
+def test_allreduce_bucket_is_the_identity_without_a_group():
+    ns = torch_ops.load()
+    f = torch.arange(8.0)
+    ns.allreduce_bucket(f, 2, 5)
+    assert torch.equal(f, torch.arange(8.0))
+    with pytest.raises(RuntimeError):
+        ns.allreduce_bucket(f, 5, 2)

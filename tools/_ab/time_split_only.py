@@ -1,9 +1,12 @@
-import sys, torch
+import sys, os, torch
 sys.path.insert(0, "/root/repo")
+lib = sys.argv[1] if len(sys.argv) > 1 else ""
+from gamer_amd import _lib
+if lib: _lib.LIB_PATH = os.path.abspath(lib)
 from gamer_amd import ops, synthetic
 from gamer_amd.config import synthetic_config
 cfg = synthetic_config(); dev = "cuda"
-B, items, nq, nkv, p = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 101, 6, 3, 0.2
+B, items, nq, nkv, p = 256, 101, 6, 3, 0.2
 S = items * 5; T = B * S
 batch = synthetic.make_batch(B, items, 256, 3, seed=3, behavior_probs=[0.7, 0.25, 0.05])
 r = ops.alloc_router_outputs(B, S, dev)
@@ -15,12 +18,19 @@ order = (torch.empty(B, S, dtype=torch.int32, device=dev), torch.empty(B, n_t, d
 ops.attn_row_order(r["empty_cross"], *order)
 o = torch.empty(T, nq * 64, device=dev); lse = torch.empty(B, nq, S, device=dev); delta = torch.zeros(B, nq, S, device=dev)
 dq = torch.empty(T, nq * 64, device=dev); dk = torch.empty(T, nkv * 64, device=dev); dqkv = torch.empty_like(qkv); dv = dqkv[:, (nq + nkv) * 64:]
-dsw = torch.empty(ops.attn_ds_work_numel(B, S, nq), device=dev)
+def timeit(fn, iters=8):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+out = []
 for name, kl, ql, re_, te, od in (("self", r["kl_self"], None, r["empty_self"], r["tile_empty_self"], None), ("cross", r["kl_cross"], r["ql_cross"], r["empty_cross"], r["tile_empty_cross"], order)):
-    for it in range(6):
-        ops.attn_fwd(q, nq * 64, k, nkv * 64, v, qkv.shape[1], kl, ql, re_, te, B, S, nq, nkv, 0.125, p, 7, o, lse, order=od)
-        ops.attn_bwd(q, nq * 64, k, nkv * 64, v, qkv.shape[1], o, do, lse, kl, ql, re_, te, B, S, nq, nkv, 0.125, p, 7, delta, dq, nq * 64, dk, nkv * 64, dv, qkv.shape[1], order=od, ds_work=dsw)
-        ops.attn_fwd_split(q, nq * 64, k, nkv * 64, v, qkv.shape[1], kl, ql, re_, B, S, nq, nkv, 0.125, p, 7, o, lse, order=od)
-        ops.attn_bwd_split(q, nq * 64, k, nkv * 64, v, qkv.shape[1], o, do, lse, kl, ql, re_, te, B, S, nq, nkv, 0.125, p, 7, delta, dq, nq * 64, dk, nkv * 64, dv, qkv.shape[1], order=od)
-        ops.attn_bwd_split(q, nq * 64, k, nkv * 64, v, qkv.shape[1], o, do, lse, kl, ql, re_, te, B, S, nq, nkv, 0.125, p, 7, delta, dq, nq * 64, dk, nkv * 64, dv, qkv.shape[1], order=od, ds_work=dsw)
-torch.cuda.synchronize()
+    ops.attn_fwd(q, nq * 64, k, nkv * 64, v, qkv.shape[1], kl, ql, re_, te, B, S, nq, nkv, 0.125, p, 7, o, lse, order=od)
+    tf = timeit(lambda: ops.attn_fwd_split(q, nq * 64, k, nkv * 64, v, qkv.shape[1], kl, ql, re_, B, S, nq, nkv, 0.125, p, 7, o, lse, order=od))
+    ops.attn_fwd(q, nq * 64, k, nkv * 64, v, qkv.shape[1], kl, ql, re_, te, B, S, nq, nkv, 0.125, p, 7, o, lse, order=od)
+    tb = timeit(lambda: ops.attn_bwd_split(q, nq * 64, k, nkv * 64, v, qkv.shape[1], o, do, lse, kl, ql, re_, te, B, S, nq, nkv, 0.125, p, 7, delta, dq, nq * 64, dk, nkv * 64, dv, qkv.shape[1], order=od))
+    out.append(f"{name}: fwd {tf:.3f} bwd {tb:.3f}")
+print(os.path.basename(lib) or "current", " | ".join(out))

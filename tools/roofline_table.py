@@ -40,13 +40,17 @@ def main():
     tf = {k["kernel"]: k.get("tflops") for k in (tfsrc.get("kernels") or [])}
     bf16 = tfsrc.get("dtype") == "bf16"
     mfma_peak, mfma_name = (2500.0, "bf16 MFMA") if bf16 else (FP32_MFMA_PEAK, "fp32 MFMA")
+    terms = {"split6": 6, "split9": 9}.get((tfsrc.get("config") or {}).get("matmul"), 0)
+    if terms and not bf16:          # fp32 products as `terms` bf16 piece products: the bf16 pipe's peak in fp32-problem FLOPs
+        mfma_peak, mfma_name = 2500.0 / terms, f"bf16 MFMA / {terms}"
     group = {"gemm_f32_kernel<true, true, 0, false, false, 2, 0": "gemm_fwd",
              "gemm_f32_kernel<true, true, 0, false, false, 2, 1": "gemm_fwd_resid",
              "gemm_f32_kernel<true, false, 0, false, false, 2, 2": "gemm_dgrad_delta",
              "gemm_f32_kernel<true, false, 0": "gemm_dgrad", "gemm_f32_kernel<false, false, 1": "gemm_wgrad",
              "gemm_bf16_wgrad_kernel": "gemm_wgrad", "gemm_bf16_kernel<1": "gemm_fwd_resid", "gemm_bf16_kernel<2": "gemm_dgrad_delta",
              "attn_fwd_kernel<2, true, false": "attn_fwd_self", "attn_fwd_kernel<2, true, true": "attn_fwd_cross",
-             "attn_fwd_b_kernel<2, true, false, false": "attn_fwd_self"}
+             "attn_fwd_b_kernel<2, true, false, false": "attn_fwd_self",
+             "attn_fwd_s_kernel<2, true, false": "attn_fwd_split_self", "attn_fwd_s_kernel<2, true, true": "attn_fwd_split_cross"}
     total = sum(float(r["total_ms"]) for r in stats)
     lines = [f"# Per-kernel roofline, profile set {tag}", "",
              f"`python3 bench.py --steps {bench['steps']} --warmup {bench['warmup']} --no-cpu-baseline` under rocprofv3 "
