@@ -5,6 +5,9 @@ import sys
 import numpy as np
 import pytest
 
+# parity tests run with the deterministic weight-gradient chunk rule / shipped table (no on-line timing sweep in the first step)
+os.environ.setdefault("GAMER_WGRAD_TUNE", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

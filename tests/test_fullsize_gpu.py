@@ -1,8 +1,9 @@
 """Parity at BASELINE.json's full size (per-GPU batch 1024 x 505 tokens, shipped dims), where the CPU oracle cannot run the
 whole batch: size-independent properties of the train step, tied to the oracle on rows sampled from the full batch.
 
-  (a) sequences do not interact: the logits of rows taken out of the 1024-row batch equal the logits of the same rows
-      run as a small batch, and the CPU oracle's logits for those rows (north-star bar: 1e-3 of the abs-max);
+  (a) sequences do not interact: the logits of EVERY row of the 1024-row batch equal the logits of the same row run inside
+      a 128-row batch (all 1024 rows, eight chunks), and for twelve rows spread over the batch also the logits of those
+      rows run alone and the CPU oracle's logits for them (north-star bar: 1e-3 of the abs-max);
   (b) the loss is a normalised sum: with num_items_in_batch fixed, loss(full) = loss(first half) + loss(second half);
   (c) the gradient is linear in the batch: the gradient of the full batch equals the accumulated gradient of its two halves
       (fp32 atomics in the split-K weight gradients: summation order differs, tolerance 2e-4 of each tensor's abs-max),
@@ -23,7 +24,7 @@ from gamer_amd.engine import Engine  # noqa: E402
 from oracle import qwen3multi_oracle as orc  # noqa: E402
 
 B, ITEMS = 1024, 101
-ROWS = [0, 1, 517, 1023]                     # rows compared against the CPU oracle
+ROWS = [0, 1, 2, 127, 128, 255, 511, 512, 517, 768, 1022, 1023]     # rows compared against the CPU oracle
 
 
 def _sub(batch, idx):
@@ -53,6 +54,7 @@ def test_full_batch_properties_and_oracle_rows(dtype, matmul):
                                     num_items_in_batch=n_items, train=False)
     loss_full = float(loss_full)
     rows_full = logits[idx.to(logits.device)].float().cpu().numpy()
+    full = logits.clone()                    # (the returned logits are a view of the engine's workspace)
     small = _sub(batch, idx)
     _, lg_small = eng.forward(small["input_ids"], small["attention_mask"], small["actions"], labels=small["labels"],
                               num_items_in_batch=n_items, train=False)
@@ -62,6 +64,16 @@ def test_full_batch_properties_and_oracle_rows(dtype, matmul):
     e_oracle = _relmax(rows_full, out["logits"].float().detach().numpy())
     assert e_small < (5e-3 if amp else 1e-5), e_small
     assert e_oracle < tol_logits, e_oracle
+    # ... and every row of the batch against the same row inside a 128-row batch (different tile / work-list positions)
+    scale = float(full.float().abs().max())
+    worst_chunk = 0.0
+    for c0 in range(0, B, 128):
+        cb = _sub(batch, torch.arange(c0, c0 + 128))
+        _, lg_c = eng.forward(cb["input_ids"], cb["attention_mask"], cb["actions"], labels=cb["labels"],
+                              num_items_in_batch=n_items, train=False)
+        worst_chunk = max(worst_chunk, float((lg_c.float() - full[c0:c0 + 128].float()).abs().max()) / scale)
+    del full
+    assert worst_chunk < (5e-3 if amp else 1e-5), worst_chunk
 
     # (b) the loss is a normalised sum over the rows
     halves = [_sub(batch, torch.arange(0, B // 2)), _sub(batch, torch.arange(B // 2, B))]
