@@ -51,6 +51,7 @@ class GemmDesc(C.Structure):
         ("qk_pos_ids", c_void_p),
         ("qk_q_rot", c_void_p), ("qk_k_rot", c_void_p),
         ("qk_S", c_int), ("qk_nq", c_int), ("qk_nkv", c_int),
+        ("b_planes", c_void_p), ("b_plane_stride", c_int64),
     ]
 
 
@@ -108,6 +109,7 @@ _SIGNATURES = {
     "gamer_attn_row_order": [P, I, I, P, P, P, P],
     "gamer_attn_fwd": [P, I, P, I, P, I, P, P, P, P, I, I, I, I, F, F, U, P, P, P, P, P, I, P, P],
     "gamer_attn_bwd": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, P, P, P, P, I, P],
+    "gamer_split3_planes": [P, P, L, L, P],
     "gamer_attn_fwd_split": [P, I, P, I, P, I, P, P, P, I, I, I, I, F, F, U, P, P, P, P, P, P],
     "gamer_attn_bwd_split": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, P, P, I, P, P],
     "gamer_residual_dropout_fwd": [P, P, P, I, I, F, U, P, P],

@@ -153,6 +153,8 @@ struct GemmParams {
     const int32_t* qk_pos_ids;
     float* qk_q_rot; float* qk_k_rot;
     int qk_S, qk_nq, qk_nkv;
+    const uint16_t* b_planes;      // SPLIT, MODE 0: B pre-cut into three bf16 planes indexed like B (nullptr: cut in the kernel)
+    int64_t b_plane_stride;
 };
 
 // blockIdx -> logical tile id such that consecutive logical ids run on one XCD (ids are dealt
@@ -442,7 +444,46 @@ gemm_f32_kernel(const GemmParams p) {
             pa += sa;
             pb += sb;
         };
-        if (SPLIT) {
+        if (SPLIT && MODE == 0 && p.b_planes != nullptr) {
+            // B = weights pre-cut into their three bf16 planes (gamer_split3_planes, once per step): the planes are staged as
+            // they are - 8-byte loads, 8-byte LDS stores, no cut (a weight element is otherwise re-cut by every row tile of the
+            // activations: half of the 176 vector instructions of a K-step)
+            const uint16_t* pq = p.b_planes + (pb - p.B);
+            const int64_t plane = p.b_plane_stride;
+            uint2 rq[3][4];
+            auto load_a = [&]() {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(pa + j * ja);
+                pa += sa;
+            };
+            auto load_bq = [&]() {
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rq[s][j] = *reinterpret_cast<const uint2*>(pq + s * plane + j * jb);
+                pq += sb;
+            };
+            auto store_bq = [&](unsigned char* d8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = tid + GEMM_THREADS * j;
+                    unsigned char* dst = B_KC ? d8 + (f >> 3) * SP_KC_ROW + ((f & 7) << 3) : d8 + sp_rc_off(f >> 5, (f & 31) << 2);
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) *reinterpret_cast<uint2*>(dst + s * (B_KC ? SP_KC_IMG : SP_RC_IMG)) = rq[s][j];
+                }
+            };
+            load_a();
+            load_bq();
+            for (int kt = 0; kt < nkt; ++kt) {
+                unsigned char* d8 = reinterpret_cast<unsigned char*>(smem);
+                if (A_KC) store_kc_split(d8, tid, ra); else store_rc_split(d8, tid, ra);
+                store_bq(d8 + SP_OPERAND);
+                __syncthreads();
+                if (kt + 1 < nkt) { load_a(); load_bq(); }
+                mfma_tile(smem);
+                __syncthreads();
+            }
+        } else if (SPLIT) {
             // one stage of three-image tiles (60 KB): split + store, barrier, request the next step, multiply, barrier
             fast_load();
             for (int kt = 0; kt < nkt; ++kt) {
@@ -758,9 +799,34 @@ static int launch_gemm(const GemmParams& p, int blocks, hipStream_t st, int spli
     return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2>(p, blocks, st, lds);
 }
 
+// x[i] -> its three bf16 pieces, planes[s * stride + i]  (the cut of split3, four values per thread)
+__global__ void __launch_bounds__(256)
+split3_planes_kernel(const float4* __restrict__ x, uint16_t* __restrict__ planes, int64_t n4, int64_t stride) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        uint2 img[3];
+        split3_quad(x[i], img);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) *reinterpret_cast<uint2*>(planes + s * stride + 4 * i) = img[s];
+    }
+}
+
 }  // namespace gamer
 
 using namespace gamer;
+
+extern "C" int gamer_split3_planes(const float* x, gamer_bf16* planes, int64_t n, int64_t plane_stride, void* stream) {
+    GAMER_CHECK_ARG(x && planes && n > 0 && n % 4 == 0 && plane_stride >= n && plane_stride % 4 == 0 && aligned16(x) &&
+                    (reinterpret_cast<uintptr_t>(planes) & 7u) == 0,
+                    "gamer_split3_planes: n=%lld and plane_stride=%lld must be multiples of 4 (stride >= n), x 16-byte and planes 8-byte aligned",
+                    (long long)n, (long long)plane_stride);
+    const int64_t n4 = n / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split3_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x),
+                       reinterpret_cast<uint16_t*>(planes), n4, plane_stride);
+    GAMER_CHECK_LAUNCH("gamer_split3_planes");
+    return 0;
+}
 
 extern "C" int gamer_debug_gemm_stamp(void* p) {
     unsigned long long* v = (unsigned long long*)p;
@@ -800,6 +866,10 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     p.qk_bias_q = d->qk_bias_q; p.qk_bias_k = d->qk_bias_k; p.qk_bias_v = d->qk_bias_v;
     p.qk_act_idx = d->qk_act_idx; p.qk_pos_ids = d->qk_pos_ids; p.qk_q_rot = d->qk_q_rot; p.qk_k_rot = d->qk_k_rot;
     p.qk_S = d->qk_S; p.qk_nq = d->qk_nq; p.qk_nkv = d->qk_nkv;
+    p.b_planes = (split && d->group_mode == 0) ? (const uint16_t*)d->b_planes : nullptr;
+    p.b_plane_stride = d->b_plane_stride;
+    GAMER_CHECK_ARG(!p.b_planes || ((reinterpret_cast<uintptr_t>(p.b_planes) & 7u) == 0 && d->b_plane_stride % 4 == 0 && d->b_plane_stride > 0),
+                    "gamer_gemm_f32_split: b_planes must be 8-byte aligned with b_plane_stride %% 4 == 0");
     GAMER_CHECK_ARG(!d->qk_q_rot || (d->qk_k_rot && d->qk_wq && d->qk_wk && d->qk_cos && d->qk_sin && d->group_mode == 0 &&
                                      d->groups == 1 && a_kc && b_kc && !d->resid && !d->rowdot_out && !d->accumulate &&
                                      d->alpha == 1.f && d->M % BM == 0 && d->qk_nq > 0 && d->qk_nkv > 0 && d->qk_S > 0 &&

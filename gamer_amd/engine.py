@@ -405,6 +405,14 @@ class Engine:
             self.shadow = Bf16Shadow(cfg, self.layout, self.flat_p)
             self.Wm = [_LayerW(cfg, self.layout, self.shadow.flat16, l) for l in range(L)]
             self.WT = [_LayerWT(cfg, self.shadow, l) for l in range(L)]
+        # split forms, opt-in (GAMER_SPLIT_PLANES=1): the fp32 masters cut once per step into three bf16 planes - the B operand
+        # of every forward / input-gradient GEMM is a weight, and without this every row tile of the activations cuts its weight
+        # tile again (half of a K-step's cut instructions).  Bit-identical results (tests/test_ops_gpu.py); measured at batch
+        # 1024: 320.98 vs 320.55 ms per step, forward GEMMs 36.2 vs 35.1 ms, input-gradient GEMMs 43.6 vs 44.0 - the cut
+        # arithmetic is not what bounds the kernel, so it stays off.
+        self.weight_planes: Optional[torch.Tensor] = None
+        if dtype == "f32" and matmul != "f32" and os.environ.get("GAMER_SPLIT_PLANES", "0") == "1":
+            self.weight_planes = torch.zeros(3, _round_up(n, 4), dtype=torch.bfloat16, device=self.device)
         self.lut = cfg.behavior_lut().to(self.device)
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._ws: Dict[bool, _Workspace] = {}
@@ -470,7 +478,11 @@ class Engine:
         return ((self.base_seed & 0xFFFF) << 48) | ((self.dropout_step & 0xFFFFFFFF) << 16) | (layer << 4) | site
 
     # ------------------------------------------------------------------------------------------
-    @ops.scoped_f32_matmul(lambda self, *a: self.matmul)
+    def _planes(self):
+        wp = self.weight_planes
+        return None if wp is None else (self.flat_p.data_ptr(), self.flat_p.numel() * 4, wp.data_ptr(), wp.stride(0))
+
+    @ops.scoped_f32_matmul(lambda self, *a: self.matmul, lambda self, *a: self._planes())
     def forward(self, input_ids, attention_mask=None, actions=None, labels=None, num_items_in_batch=None,
                 train: bool = False, dropout: Optional[bool] = None, act_zero_col: Optional[int] = None,
                 uniform_len: int = 0, kv_sink=None, session_ids=None, extended_session_ids=None,
@@ -505,6 +517,8 @@ class Engine:
             if last_row_logits or uniform_len not in (0, S):
                 raise NotImplementedError("generation (cached decode / re-run scoring) is built for dtype='f32' only")
             self.shadow.refresh()                    # the masters may have been updated by any optimizer since the last call
+        if self.weight_planes is not None:
+            ops.split3_planes(self.flat_p, self.weight_planes)     # likewise: 98 MB read, 147 MB written, once per forward
         T, H = B * S, cfg.hidden_size
         nq, nkv, dh, I, E = (cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size,
                              cfg.num_experts)
@@ -714,7 +728,7 @@ class Engine:
     def zero_grad(self):
         ops.fill(self.flat_g, 0.0)
 
-    @ops.scoped_f32_matmul(lambda self, *a: self.matmul)
+    @ops.scoped_f32_matmul(lambda self, *a: self.matmul, lambda self, *a: self._planes())
     def backward(self, dloss: float = 1.0, layer_done=None, dloss_dev: Optional[torch.Tensor] = None):
         """Accumulates d(loss)*dloss into the flat gradient buffer (call zero_grad() first for a fresh
         window).  Needs a forward(..., labels=..., train=True) before it.  ``dloss_dev``: fp32 device scalar that

@@ -131,34 +131,49 @@ def rowtable_bwd(dy, lddy, col0, idx, dtable, dy_rows=None):
 # forms, tools and tests in one process do not leak their setting into each other.
 F32_MATMUL_TERMS = 0
 MATMUL_MODES = {"f32": 0, "split6": 6, "split9": 9}
+# Pre-cut weights of the split forms: (address of the fp32 flat parameter buffer, its bytes, address of the three bf16 planes,
+# plane stride in elements) or None.  Set - scoped, like the matmul form - by the engine that owns the buffers; gemm() hands a
+# B operand that lies inside the flat buffer to gamer_gemm_f32_split together with its planes.
+WEIGHT_PLANES = None
 
 
 class f32_matmul:
     """Context manager: fp32 GEMMs issued inside the block use `mode` ("f32" | "split6" | "split9" or 0 / 6 / 9)."""
 
-    def __init__(self, mode):
-        self.mode = mode
+    def __init__(self, mode, planes=None):
+        self.mode, self.planes = mode, planes
 
     def __enter__(self):
+        global WEIGHT_PLANES
         self.prev = set_f32_matmul(self.mode)
+        self.prev_planes = WEIGHT_PLANES
+        WEIGHT_PLANES = self.planes
         return self
 
     def __exit__(self, *exc):
+        global WEIGHT_PLANES
         set_f32_matmul(self.prev)
+        WEIGHT_PLANES = self.prev_planes
         return False
 
 
-def scoped_f32_matmul(get_mode):
-    """Decorator form of f32_matmul: `get_mode(*args)` names the form for the duration of the call."""
+def scoped_f32_matmul(get_mode, get_planes=None):
+    """Decorator form of f32_matmul: `get_mode(*args)` names the form for the duration of the call, `get_planes(*args)`
+    (optional) the pre-cut weight planes (WEIGHT_PLANES)."""
     import functools
 
     def deco(fn):
         @functools.wraps(fn)
         def wrapper(*args, **kwargs):
-            with f32_matmul(get_mode(*args)):
+            with f32_matmul(get_mode(*args), get_planes(*args) if get_planes is not None else None):
                 return fn(*args, **kwargs)
         return wrapper
     return deco
+
+
+def split3_planes(x, planes):
+    """planes [3, n] bf16 <- the three exact bf16 pieces of x [n] fp32 (gamer_split3_planes)."""
+    call("gamer_split3_planes", ptr(x), ptr(planes), x.numel(), planes.stride(0), stream_ptr())
 
 
 def set_f32_matmul(mode) -> int:
@@ -207,6 +222,11 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
         d.qk_q_rot, d.qk_k_rot = ptr(q["q_rot"]), ptr(q["k_rot"])
         d.qk_S, d.qk_nq, d.qk_nkv = int(q["S"]), int(q["nq"]), int(q["nkv"])
     if F32_MATMUL_TERMS:
+        if WEIGHT_PLANES is not None and group_mode == 0:
+            base, nbytes, pl, stride = WEIGHT_PLANES
+            off = Bm.data_ptr() - base
+            if 0 <= off < nbytes:                       # B is a view of the engine's flat parameter buffer: hand over its planes
+                d.b_planes, d.b_plane_stride = pl + off // 2, stride
         call("gamer_gemm_f32_split", C.byref(d), F32_MATMUL_TERMS, stream_ptr())
     else:
         call("gamer_gemm_f32", C.byref(d), stream_ptr())

@@ -206,6 +206,12 @@ typedef struct {
     const int32_t* qk_pos_ids;
     float* qk_q_rot; float* qk_k_rot;
     int qk_S, qk_nq, qk_nkv;
+    /* optional (ABI 5), gamer_gemm_f32_split with group_mode 0 only: B pre-cut into its three bf16 pieces by
+     * gamer_split3_planes - three bf16 arrays indexed exactly like B (piece s of B's element e at b_planes + s *
+     * b_plane_stride + e; 8-byte aligned).  Full tiles then stage B without the cut (weights are re-cut by every row tile
+     * otherwise: 4040 times per step at batch 1024); edge tiles and gamer_gemm_f32 ignore it.  Results are bit-identical. */
+    const gamer_bf16* b_planes;
+    int64_t b_plane_stride;
 } gamer_gemm_desc;
 
 int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);
@@ -218,6 +224,10 @@ int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);
  * Same F.linear sites as gamer_gemm_f32 (model.py:93-99,145-149,1001, FFN.py:25-27); selected per Engine
  * (`matmul="split6" | "split9"`), never implicitly.  Inf / NaN operands produce NaN. */
 int gamer_gemm_f32_split(const gamer_gemm_desc* d, int terms, void* stream);
+/* planes[s * plane_stride + i] = piece s (s = 0, 1, 2) of x[i] under the exact three-way cut above (n % 4 == 0,
+ * plane_stride % 4 == 0, 16-byte aligned x, 8-byte aligned planes): the `b_planes` operand of gamer_gemm_f32_split.  The
+ * engine cuts its fp32 master parameters once per step with it (98 MB read, 147 MB written). */
+int gamer_split3_planes(const float* x, gamer_bf16* planes, int64_t n, int64_t plane_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16, fp32 accumulation): the nn.Linear sites of the reference's --bf16 run

@@ -353,6 +353,42 @@ def test_gemm_qkv_epilogue_equals_gemm_then_qknorm_rope(cross, gemm_mode, B, S):
 
 
 @pytest.mark.parametrize("terms", [6, 9])
+def test_gemm_split_with_precut_weight_planes_is_bit_identical(terms):
+    """gamer_split3_planes + gamer_gemm_desc.b_planes: the B operand (weights) cut once into three bf16 planes instead of
+    in every row tile.  Forward (k-contiguous B), input gradient (row-contiguous B), grouped experts (strideB), residual
+    epilogue; an edge shape (partial tiles ignore the planes).  Same bits as the in-kernel cut, and the planes ARE the cut:
+    p0 + p1 + p2 == x exactly."""
+    g = torch.Generator().manual_seed(9)
+    E, I, din, T = 3, 256, 128, 640
+    flat = (torch.randn(E * I * din + 384 * din, generator=g) * torch.exp2(torch.randint(-12, 8, (E * I * din + 384 * din,), generator=g).float())).to(DEV)
+    planes = torch.empty(3, flat.numel(), dtype=torch.bfloat16, device=DEV)
+    ops.split3_planes(flat, planes)
+    assert torch.equal(planes[0].float() + planes[1].float() + planes[2].float(), flat)       # exact in fp32: 24 bits in three pieces
+    Wexp = flat[:E * I * din].view(E * I, din)
+    W2 = flat[E * I * din:].view(384, din)
+    x = dev(torch.randn(T, din, generator=g))
+    dy = dev(torch.randn(T, 384, generator=g))
+    offs = dev(torch.tensor([0, 256, 384, 640], dtype=torch.int32))
+    res = dev(torch.randn(T, 384, generator=g))
+
+    def run():
+        y = torch.empty(T, 384, device=DEV); ops.linear_fwd(x, din, W2, din, y, 384, T, 384, din)
+        yg = torch.empty(T, I, device=DEV); ops.linear_fwd(x, din, Wexp, din, yg, I, T, I, din, groups=E, group_offsets=offs, strideB=I * din)
+        dx = torch.empty(T, din, device=DEV); ops.linear_dgrad(dy, 384, W2, din, dx, din, T, 384, din)
+        yr = torch.empty(T, 384, device=DEV); ops.gemm(x, din, 1, W2, din, 1, yr, 384, T, 384, din, resid=res, p_drop=0.2, seed=5)
+        ye = torch.empty(100, 384, device=DEV); ops.linear_fwd(x[:100], din, W2, din, ye, 384, 100, 384, din)     # partial row tile
+        return [t.clone() for t in (y, yg, dx, yr, ye)]
+    with ops.f32_matmul(terms):
+        plain = run()
+    with ops.f32_matmul(terms, (flat.data_ptr(), flat.numel() * 4, planes.data_ptr(), planes.stride(0))):
+        pre = run()
+    for a, b in zip(plain, pre):
+        assert torch.equal(a, b)
+    ref = x.double() @ W2.double().T
+    assert float((pre[0].double() - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("terms", [6, 9])
 def test_gemm_split_is_exact_where_fp32_is(terms):
     """The three bf16 pieces carry all 24 bits of an operand: (a) small integers - every product and partial sum is exact
     in fp32 - give bit-identical results to the fp32 MFMA on all three layouts; (b) values that need the last mantissa
