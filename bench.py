@@ -198,6 +198,35 @@ class KernelTimer:
             timer.records.append(("attn_bwd_self" if ql is None else "attn_bwd_cross", s, e, 10.0 * 64 * nq * pairs, 0.0))
             return r
 
+        orig_afs, orig_abs = ops.attn_fwd_split, ops.attn_bwd_split
+
+        def timed_attn_fwd_split(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, *rest, **kw):
+            pairs = timer.pairs["self" if ql is None else "cross"]
+            timer._next = ("attn_fwd_self" if ql is None else "attn_fwd_cross", 4.0 * 64 * nq * pairs)
+            return orig_afs(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, *rest, **kw)
+
+        def timed_attn_bwd_split(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty, B, S, nq, *rest, **kw):
+            label = "attn_bwd_self" if ql is None else "attn_bwd_cross"
+            pairs = timer.pairs["self" if ql is None else "cross"]
+            if not (timer.enabled and (timer.only is None or label in timer.only)):
+                en = timer.enabled
+                timer.enabled = False
+                try:
+                    return orig_abs(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty, B, S, nq, *rest, **kw)
+                finally:
+                    timer.enabled = en
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            timer.enabled = False
+            s_.record()
+            r = orig_abs(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty, B, S, nq, *rest, **kw)
+            e_.record()
+            timer.enabled = True
+            # algorithmic = the five products of the backward (the recompute form executes seven)
+            timer.records.append((label, s_, e_, 10.0 * 64 * nq * pairs, 0.0))
+            return r
+
+        ops.attn_fwd_split = timed_attn_fwd_split
+        ops.attn_bwd_split = timed_attn_bwd_split
         ops.call = timed_call
         ops.gemm = timed_gemm
         ops.linear_dgrad_t = timed_dgrad_t

@@ -28,6 +28,18 @@
 namespace gamer {
 
 constexpr int AB_THREADS = 256;
+#ifndef AB_ABLATE
+#define AB_ABLATE 0       // timing-only: 1 = the forward re-stages its first K/V tile instead of loading the next ones
+#endif
+#ifndef AB_OCC_FWD
+#define AB_OCC_FWD 2      // workgroups per CU the forward / dQ / dK-dV kernels are compiled for (register budget 512 / (2 x this))
+#endif
+#ifndef AB_OCC_DQ
+#define AB_OCC_DQ 2
+#endif
+#ifndef AB_OCC_DKV
+#define AB_OCC_DKV 2
+#endif
 constexpr int INT_BIG_B = 0x7fffffff;
 constexpr float RESCALE_TAU_B = 16.f;      // log2 domain: p <= 2^16 relative to the running reference
 
@@ -301,7 +313,7 @@ attn_fwd_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict_
     for (int jt = 0; jt < n_iter; ++jt) {
         const int cur = jt & 1;
         const bool more = jt + 1 < n_iter;
-        if (more) {
+        if (more && !(AB_ABLATE & 1)) {
             load_rows<64>(kbase, ldk, jt * 64 + 64, S, tid, rk);
             load_rows<64>(vbase, ldv, jt * 64 + 64, S, tid, rv);
             rmeta = key_meta_load_b<DROP>(klb, jt * 64 + 64, S, w, lane, rng);
@@ -336,7 +348,7 @@ attn_fwd_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict_
             float mloc = st[0];
 #pragma unroll
             for (int reg = 1; reg < 16; ++reg) mloc = fmaxf(mloc, st[reg]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * c2;
+            mloc = xor32_max(mloc) * c2;
             const bool need = (l_run == 0.f) ? (mloc > -INFINITY) : (mloc > m_ref + RESCALE_TAU_B);
             if (__any(need ? 1 : 0)) {
                 const float alpha = (need && l_run != 0.f) ? __builtin_amdgcn_exp2f(m_ref - mloc) : 1.f;
@@ -347,7 +359,7 @@ attn_fwd_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict_
             }
             exp2_affine16(st, c2, -m_ref);                          // masked: exp2(-inf) = 0
             float rowsum = sum16(st);
-            rowsum += __shfl_xor(rowsum, 32, 64);
+            rowsum = xor32_sum(rowsum);
             l_run += rowsum;
             if (DROP) {
                 int kwv[16];
@@ -392,7 +404,7 @@ attn_fwd_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict_
 }
 
 template <int G, bool DROP, bool SPAN, bool ORD>
-__global__ void __launch_bounds__(AB_THREADS, 2)
+__global__ void __launch_bounds__(AB_THREADS, AB_OCC_FWD)
 attn_fwd_b_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                   const bf16_t* __restrict__ v, int ldv, const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                   int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
@@ -616,7 +628,7 @@ attn_bwd_dq_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restri
 }
 
 template <int G, bool DROP, bool SPAN, bool ORD>
-__global__ void __launch_bounds__(AB_THREADS, 2)
+__global__ void __launch_bounds__(AB_THREADS, AB_OCC_DQ)
 attn_bwd_dq_b_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                      const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                      const float* __restrict__ delta, const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
@@ -938,7 +950,7 @@ attn_bwd_dkv_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restr
 }
 
 template <int G, bool DROP, bool SPAN, bool ORD>
-__global__ void __launch_bounds__(AB_THREADS, 2)
+__global__ void __launch_bounds__(AB_THREADS, AB_OCC_DKV)
 attn_bwd_dkv_b_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                       const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                       const float* __restrict__ delta, const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
@@ -968,7 +980,7 @@ static int launch_fwd_b(const bf16_t* q, int ldq, const bf16_t* k, int ldk, cons
                         const int32_t* ql, int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                         bf16_t* o, float* lse, const int32_t* span, const QOrdB ord, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
-    dim3 grid(worklist_grid_b(B * nkv, (S + R - 1) / R, 2));
+    dim3 grid(worklist_grid_b(B * nkv, (S + R - 1) / R, AB_OCC_FWD));
 #define GAMER_LAUNCH_FWD_B(DROPV, SPANV, ORDV)                                                                              \
     hipLaunchKernelGGL((attn_fwd_b_kernel<G, DROPV, SPANV, ORDV>), grid, dim3(AB_THREADS), 0, st, q, ldq, k, ldk, v, ldv,   \
                        kl, ql, B, S, nq, nkv, scale, p_drop, seed, o, lse, span, ord)

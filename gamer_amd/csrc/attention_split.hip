@@ -330,7 +330,7 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
                 float mloc = st_cur[0];
 #pragma unroll
                 for (int reg = 1; reg < 16; ++reg) mloc = fmaxf(mloc, st_cur[reg]);
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                mloc = xor32_max(mloc);
                 bool need = (l_run == 0.f) ? (mloc > -INFINITY) : (mloc > RESCALE_TAU);
                 if (EMPTYSEL) need = need && !my_empty;
                 if (__any(need ? 1 : 0)) {
@@ -352,7 +352,7 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
                     rowsum += pe;
                     st_cur[reg] = pe;
                 }
-                rowsum += __shfl_xor(rowsum, 32, 64);
+                rowsum = xor32_sum(rowsum);
                 l_run += rowsum;
                 if (DROP) {
                     int kwv[16];

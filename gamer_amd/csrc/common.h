@@ -149,6 +149,18 @@ struct AttnDropout {
     __device__ __forceinline__ bool keep(uint32_t a, uint32_t b) const { return __umul24(a, b) >= thr; }
 };
 
+// value of the lane 32 positions away (lane ^ 32) without the LDS crossbar: v_permlane32_swap exchanges the upper half of one
+// register with the lower half of another; with both = v the pair becomes (v[l & 31], v[32 + (l & 31)]) in every lane.  A
+// ds_bpermute round trip (~100+ cycles) sat twice in the dependent chain of every attention tile (row maximum, row sum).
+__device__ __forceinline__ float xor32_max(float v) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

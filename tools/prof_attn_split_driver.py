@@ -1,3 +1,5 @@
+"""Driver of tools/prof_attn_split.sh: six rounds of fp32-MFMA and split attention (forward, backward recompute, backward
+with the dS spill) on one problem, self and cross."""
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from gamer_amd import ops, synthetic

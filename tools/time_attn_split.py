@@ -1,3 +1,6 @@
+"""Forward / backward times of the split attention (gamer_attn_*_split) at batch 256 x 505, self and cross (row order),
+for the current build or another build of the library: python tools/time_attn_split.py [path/to/libgamer_hip.so]
+(tools/ablate_attn_split.sh builds timing-only variants)."""
 import sys, os, torch
 sys.path.insert(0, "/root/repo")
 lib = sys.argv[1] if len(sys.argv) > 1 else ""
