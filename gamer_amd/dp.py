@@ -81,3 +81,13 @@ def all_reduce_scalar_(t: torch.Tensor, group=None):
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def already_reduced_hook(state, bucket):
+    """DDP communication hook for a module whose backward has ALREADY reduced its gradients (the nn.Module path after
+    ``model.enable_dp_overlap()``: the engine launches its per-layer buckets while the remaining layers' backward kernels
+    run, which torch DDP cannot do for a model that is one autograd node).  Returns the bucket untouched:
+    ``ddp_model.register_comm_hook(None, gamer_amd.dp.already_reduced_hook)``."""
+    fut = torch.futures.Future()
+    fut.set_result(bucket.buffer())
+    return fut

@@ -61,14 +61,18 @@ class _ModelFn(torch.autograd.Function):
     def backward(ctx, dloss, _dlogits):
         eng: Engine = ctx.model.engine
         eng.zero_grad()
+        red = ctx.model._reducer
+        done = red.layer_done if red is not None else None
         if dloss is None:
-            eng.backward(0.0)
+            eng.backward(0.0, layer_done=done)
         else:
             # the incoming gradient stays on the device (no host read between forward and backward)
-            eng.backward(1.0, dloss_dev=dloss.detach().to(torch.float32).reshape(1).contiguous())
+            eng.backward(1.0, dloss_dev=dloss.detach().to(torch.float32).reshape(1).contiguous(), layer_done=done)
+        if red is not None:
+            red.finish()
         # one 98 MB device copy (~40 us): autograd accumulates into .grad tensors of its own, the engine's flat
-        # gradient buffer is rewritten by the next backward
-        flat = eng.flat_g.clone()
+        # gradient buffer is rewritten by the next backward.  After enable_dp_overlap() the sum over ranks becomes DDP's mean.
+        flat = eng.flat_g.clone() if red is None or red.world == 1 else eng.flat_g / float(red.world)
         grads = [flat[o:o + math.prod(s)].view(s) for o, s in (eng.layout.entries[k] for k in ctx.model._param_keys)]
         return (None, None, None, None, None, None, None, *grads)
 
@@ -118,10 +122,23 @@ class Qwen3MultiWithTemperature(nn.Module):
         self.vocab_size = config.vocab_size
         self.temperature = 1.0
         self.zero_copy_logits = False       # True: the training forward returns a view of the engine's logits buffer
+        self._reducer = None                # enable_dp_overlap(): the engine's own per-layer gradient all-reduce
         self.engine = Engine(self._cfg, device=device, temperature=1.0, variant=self.VARIANT, dtype=dtype, matmul=matmul)
         self.engine.init_weights(seed=0)
         self._param_keys = list(self.engine.layout.entries.keys())
         self._register_views()
+
+    def enable_dp_overlap(self, group=None):
+        """Under DistributedDataParallel (HF Trainer wraps the module, ref:SeqRec/tasks/train_SMB_decoder.py:420) the whole
+        model is ONE autograd node, so torch's reducer sees every gradient at the same moment and cannot overlap anything.
+        After this call the module's backward reduces the engine's flat gradient itself - per-layer buckets launched while
+        the remaining layers' backward runs (gamer_amd.dp.GradAllReducer over RCCL), summed and divided by the world size,
+        DDP's mean - and DDP must be told not to reduce again:
+            ddp_model.register_comm_hook(None, gamer_amd.dp.already_reduced_hook)
+        (with HF Trainer: in ``TrainerCallback.on_train_begin``, ``kwargs["model"]`` is the wrapped model)."""
+        from .dp import GradAllReducer
+        self._reducer = GradAllReducer(self.engine.flat_g, self.engine.layout, self._cfg.num_hidden_layers, group)
+        return self
 
     def fused_optimizer(self, lr: float = 5e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
                         max_grad_norm: float = 1.0) -> "FusedClipAdamW":
@@ -165,6 +182,8 @@ class Qwen3MultiWithTemperature(nn.Module):
         self.engine = Engine(self._cfg, device=str(self.engine.device), temperature=self.temperature,
                              variant=self.VARIANT, dtype=self.engine.dtype, matmul=self.engine.matmul)
         self.engine.init_weights(seed=0)
+        if self._reducer is not None:                         # the flat gradient buffer is a new one
+            self.enable_dp_overlap(self._reducer.group)
         for name in list(self._modules):                      # drop the old parameter tree
             del self._modules[name]
         self._param_keys = list(self.engine.layout.entries.keys())

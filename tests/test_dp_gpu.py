@@ -62,3 +62,30 @@ def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path, accum, dtype):
         assert max(r["param_max_diff_vs_rank0"]) == 0.0, r          # replicas stay bit-identical
     for i, (got, want) in enumerate(zip(r0["loss_sum_over_ranks"], r0["ref_loss"])):
         assert abs(got - want) < (1e-5 if (dtype == "f32" or i < accum) else 2e-3) * abs(want), (got, want)
+
+
+def test_module_under_ddp_with_the_engines_own_overlap(tmp_path):
+    """The nn.Module path under torch DistributedDataParallel (how HF Trainer runs the reference,
+    ref:SeqRec/tasks/train_SMB_decoder.py:420): after model.enable_dp_overlap() the module's backward launches the engine's
+    per-layer gradient buckets itself, DDP's own reduction is replaced by gamer_amd.dp.already_reduced_hook, and every
+    parameter's .grad must be DDP's result: the mean over ranks of the per-rank gradients."""
+    world, port = 2, _free_port()
+    env = dict(os.environ, GAMER_WGRAD_TUNE="0")
+    env.pop("WORLD_SIZE", None)
+    outs = [str(tmp_path / f"ddp{r}.json") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_overlap_worker.py"), str(r), str(world), str(port),
+                               outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(out)
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    for o in outs:
+        r = json.load(open(o))
+        assert r["n_params"] > 40 and r["worst_rel"] < 1e-5, r
