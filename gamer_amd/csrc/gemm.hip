@@ -91,6 +91,71 @@ __device__ __forceinline__ void store_rc_split(unsigned char* __restrict__ lds, 
         for (int s = 0; s < 3; ++s) *reinterpret_cast<uint2*>(dst + s * SP_RC_IMG) = img[s];
     }
 }
+// ---- two-stage form (SP_TWO_STAGE): K-steps of 16, each stage = both operands' three images of a 128 x 16 slice.  A KC image
+// row is 32 B of k + 16 B of padding (48-byte rows: the 16-byte fragment reads of 16 consecutive rows fall on distinct banks),
+// an RC image is [16 k][128 rows] with the chunk swizzle of sp_rc_off.  2 x 2 x 3 x 6144 B = 73,728 B = the fp32 kernel's
+// allocation, two workgroups per CU.
+#ifndef SP_TWO_STAGE
+#define SP_TWO_STAGE 0
+#endif
+#ifndef SP_PREFETCH2
+#define SP_PREFETCH2 0  // one-stage form with the global loads two K-steps ahead (two register sets, ~230 VGPRs)
+#endif
+#ifndef SP_PINGPONG
+#define SP_PINGPONG 0   // instantiate the eight-wave ping-pong form (PP below); GAMER_GEMM_PP=1 then selects it
+#endif
+// The three forms above are bit-identical to the default one-stage form and were each measured within +-3 % of it on every
+// GEMM shape of the step: the split kernels run against the matrix pipe's POWER limit, not against
+// their loop structure (tools/ubench_memtime.hip: random operand bits sustain 58-67 % of the nominal bf16 rate).
+constexpr int SPH_KC_ROW = 48;
+constexpr int SPH_KC_IMG = BM * SPH_KC_ROW;    // 6,144
+constexpr int SPH_RC_IMG = 16 * 256;           // 4,096
+constexpr int SPH_OPERAND = 3 * SPH_KC_IMG;    // (the larger layout)
+constexpr int SPH_STAGE = 2 * SPH_OPERAND;     // 36,864
+// KC slice: 128 rows x 16 k = 512 float4; f = tid + 256 j: row f >> 2, k-quad f & 3
+__device__ __forceinline__ void store_kc_half(unsigned char* __restrict__ lds, int tid, const float4 (&r)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int f = tid + GEMM_THREADS * j;
+        uint2 img[3];
+        split3_quad(r[j], img);
+        unsigned char* dst = lds + (f >> 2) * SPH_KC_ROW + ((f & 3) << 3);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) *reinterpret_cast<uint2*>(dst + s * SPH_KC_IMG) = img[s];
+    }
+}
+// RC slice: 16 k x 128 rows = 512 float4; f: k f >> 5, row-quad f & 31
+__device__ __forceinline__ void store_rc_half(unsigned char* __restrict__ lds, int tid, const float4 (&r)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int f = tid + GEMM_THREADS * j;
+        uint2 img[3];
+        split3_quad(r[j], img);
+        unsigned char* dst = lds + sp_rc_off(f >> 5, (f & 31) << 2);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) *reinterpret_cast<uint2*>(dst + s * SPH_RC_IMG) = img[s];
+    }
+}
+template <bool KC>
+__device__ __forceinline__ bf16x8 read_frag_half(const unsigned char* __restrict__ img, int rbase, int lane) {
+    const int r32 = lane & 31, h = lane >> 5;
+    if (KC) {
+        return *reinterpret_cast<const bf16x8*>(img + (rbase + r32) * SPH_KC_ROW + (h << 4));
+    } else {
+        const int q = (lane >> 2) & 3, pp = lane & 3, gsel = (lane >> 4) & 1;
+        const int row = rbase + 16 * gsel + 4 * pp;
+        bf16x8 out;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int k = 8 * h + 4 * c + q;
+            const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (bf16x4 __attribute__((address_space(3)))*)(img + sp_rc_off(k, row)));
+            out[4 * c + 0] = v[0]; out[4 * c + 1] = v[1]; out[4 * c + 2] = v[2]; out[4 * c + 3] = v[3];
+        }
+        return out;
+    }
+}
+
 // fragment of `v_mfma_f32_32x32x16_bf16`: lane (r32, h) holds k = 16 * sub + 8 * h + 0..7 of operand row `rbase + r32`
 template <bool KC>
 __device__ __forceinline__ bf16x8 read_frag_split(const unsigned char* __restrict__ img, int rbase, int sub, int lane) {
@@ -251,19 +316,27 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row
 // attention backward, taken while the o_proj dgrad tile is still in LDS: one pass over dO and one over O less),
 // 3 q|k|v projection: (+ behaviour bias,) per-head RMSNorm * weight and RoPE of the q / k heads written to q_rot / k_rot
 // next to the raw q|k|v - the row-major rewrite hands 16 lanes x float4 = one head row, the layout of qknorm_rope_fwd
-template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, int EPI, int SPLIT = 0>
-__global__ void __launch_bounds__(GEMM_THREADS, (NBUF == 1 && SPLIT == 0) ? 3 : 2)
+// PP ("ping-pong", SPLIT forms): ONE workgroup of eight waves per CU = two groups of four waves, each group computing its
+// own 128 x 128 tile from its own LDS region with the K loop of the four-wave kernel - but group 1 runs half a K-step behind
+// group 0, and every barrier is a barrier of all eight waves: while one group's waves cut and store their tile, the other
+// group's issue MFMAs, by construction.  (Two independent four-wave workgroups on a CU fall INTO phase instead - both in
+// their MFMA phase at half rate each, then both in their store phase with the matrix pipe idle: tools/stamp_gemm_split.py.)
+template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, int EPI, int SPLIT = 0, bool PP = false>
+__global__ void __launch_bounds__(PP ? 2 * GEMM_THREADS : GEMM_THREADS, (NBUF == 1 && SPLIT == 0) ? 3 : 2)
 gemm_f32_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
     // buffer b: A image at smem + 2*b*TILE_FLOATS, B image right behind it
 
-    const int tid = threadIdx.x;
+    const int grp = PP ? (int)(threadIdx.x >> 8) : 0;             // wave-uniform
+    const int tid = threadIdx.x & (GEMM_THREADS - 1);
+    float* const smem = smem_all + (PP ? grp * (GEMM_LDS_BYTES / 4) : 0);
     const int lane = tid & 63;
     const int wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int r32 = lane & 31, h = lane >> 5;
 
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int Lx = xcd_remap(blockIdx.x, gridDim.x);
+    const int L = (PP && MODE == 0) ? 2 * Lx + grp : Lx;           // mode 0: the two groups take neighbouring tiles
 
     // ---- which tile / which group -------------------------------------------------------------
     int row0, row_end;          // A/C row range of this tile (mode 0) or C row tile (mode 1)
@@ -298,8 +371,10 @@ gemm_f32_kernel(const GemmParams p) {
         Bp += (int64_t)g * p.strideB;
     } else {
         const int tiles_mn = p.m_tiles * p.n_tiles;
-        const int chunk = L / tiles_mn;
-        const int tile = L % tiles_mn;
+        const int per_chunk = PP ? (tiles_mn + 1) / 2 : tiles_mn;  // PP: the two groups take two C tiles of the SAME k chunk
+        const int chunk = L / per_chunk;
+        const int tile = PP ? 2 * (L % per_chunk) + grp : L % per_chunk;
+        if (PP && tile >= tiles_mn) return;                        // (terminated waves do not take part in barriers)
         row0 = (tile / p.n_tiles) * BM;
         row_end = p.M;
         col0 = (tile % p.n_tiles) * BN;
@@ -358,6 +433,7 @@ gemm_f32_kernel(const GemmParams p) {
         if (SPLIT) {
             unsigned char* d8 = reinterpret_cast<unsigned char*>(dst);
             if (A_KC) store_kc_split(d8, tid, ra); else store_rc_split(d8, tid, ra);
+            if (SP_ABLATE & 16) { asm volatile("" :: "v"(rb[0].x), "v"(rb[1].y), "v"(rb[2].z), "v"(rb[3].w)); return; }   // timing-only: B never enters LDS
             if (B_KC) store_kc_split(d8 + SP_OPERAND, tid, rb); else store_rc_split(d8 + SP_OPERAND, tid, rb);
             return;
         }
@@ -372,7 +448,7 @@ gemm_f32_kernel(const GemmParams p) {
     const bool wave_live = (row0 + wm * 64 < row_end) && (col0 + wn * 64 < col_end);
     auto mfma_tile = [&](const float* as) {
         if (!wave_live) return;
-        if (SPLIT && (SP_ABLATE & 4)) return;
+        if (SPLIT != 0 && (SP_ABLATE & 4) != 0) return;
         if (SPLIT) {
             const unsigned char* a8 = reinterpret_cast<const unsigned char*>(as);
             const unsigned char* b8 = a8 + SP_OPERAND;
@@ -385,7 +461,8 @@ gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) af[i][s] = read_frag_split<A_KC>(a8 + s * A_IMG, wm * 64 + i * 32, sub, lane);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bf[j][s] = read_frag_split<B_KC>(b8 + s * B_IMG, wn * 64 + j * 32, sub, lane);
+                    for (int j = 0; j < 2; ++j)
+                        bf[j][s] = (SP_ABLATE & 16) ? af[j][s] : read_frag_split<B_KC>(b8 + s * B_IMG, wn * 64 + j * 32, sub, lane);
                 }
                 // smallest products first; sa + sb <= 2 for SPLIT == 6, all nine for SPLIT == 9
 #pragma unroll
@@ -436,7 +513,7 @@ gemm_f32_kernel(const GemmParams p) {
         const int64_t sa = A_KC ? BK : BK * p.a_ks;               // one K-step
         const int64_t sb = B_KC ? BK : BK * p.b_ks;
         auto fast_load = [&]() {
-            if (SPLIT && (SP_ABLATE & 8)) return;
+            if (SPLIT != 0 && (SP_ABLATE & 8) != 0) return;
 #pragma unroll
             for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(pa + j * ja);
 #pragma unroll
@@ -444,7 +521,76 @@ gemm_f32_kernel(const GemmParams p) {
             pa += sa;
             pb += sb;
         };
-        if (SPLIT && MODE == 0 && p.b_planes != nullptr) {
+        if (SPLIT && SP_TWO_STAGE && !PP && !(MODE == 0 && p.b_planes != nullptr)) {
+            // Two LDS stages of 16-k slices: while the MFMAs of slice j run from one stage, slice j + 1 is cut and stored into
+            // the other and slice j + 2 is in flight from global memory - ONE barrier per slice and no phase in which a whole
+            // workgroup only stores (the one-stage form below: store | barrier | multiply | barrier).
+            const float* pa2 = A_KC ? p.A + (int64_t)(row0 + (tid >> 2)) * p.a_rs + kbeg + ((tid & 3) << 2)
+                                    : p.A + (int64_t)(kbeg + (tid >> 5)) * p.a_ks + row0 + ((tid & 31) << 2);
+            const float* pb2 = B_KC ? Bp + (int64_t)(col0 + (tid >> 2)) * p.b_rs + kbeg + ((tid & 3) << 2)
+                                    : Bp + (int64_t)(kbeg + (tid >> 5)) * p.b_ks + col0 + ((tid & 31) << 2);
+            const int64_t ja2 = A_KC ? 64 * p.a_rs : 8 * p.a_ks;      // float4 #j sits 64 rows (KC) / 8 k (RC) further
+            const int64_t jb2 = B_KC ? 64 * p.b_rs : 8 * p.b_ks;
+            const int64_t sa2 = A_KC ? 16 : 16 * p.a_ks;              // one 16-k slice
+            const int64_t sb2 = B_KC ? 16 : 16 * p.b_ks;
+            const int n16 = (kend - kbeg) / 16;
+            float4 a0[2], b0[2], a1[2], b1[2];
+            auto load16 = [&](float4 (&ra_)[2], float4 (&rb_)[2]) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) ra_[j] = *reinterpret_cast<const float4*>(pa2 + j * ja2);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) rb_[j] = *reinterpret_cast<const float4*>(pb2 + j * jb2);
+                pa2 += sa2;
+                pb2 += sb2;
+            };
+            auto store16 = [&](unsigned char* st8, const float4 (&ra_)[2], const float4 (&rb_)[2]) {
+                if (A_KC) store_kc_half(st8, tid, ra_); else store_rc_half(st8, tid, ra_);
+                if (B_KC) store_kc_half(st8 + SPH_OPERAND, tid, rb_); else store_rc_half(st8 + SPH_OPERAND, tid, rb_);
+            };
+            auto mfma16 = [&](const unsigned char* st8) {
+                if (!wave_live) return;
+                const unsigned char* a8 = st8;
+                const unsigned char* b8 = st8 + SPH_OPERAND;
+                constexpr int A_IMG = A_KC ? SPH_KC_IMG : SPH_RC_IMG, B_IMG = B_KC ? SPH_KC_IMG : SPH_RC_IMG;
+                bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) af[i][s3] = read_frag_half<A_KC>(a8 + s3 * A_IMG, wm * 64 + i * 32, lane);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bf[j][s3] = read_frag_half<B_KC>(b8 + s3 * B_IMG, wn * 64 + j * 32, lane);
+                }
+#pragma unroll
+                for (int order = (SPLIT == 9 ? 4 : 2); order >= 0; --order)
+#pragma unroll
+                    for (int sa3 = 0; sa3 < 3; ++sa3) {
+                        const int sb3 = order - sa3;
+                        if (sb3 < 0 || sb3 > 2) continue;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][sa3], bf[j][sb3], acc[i][j], 0, 0, 0);
+                    }
+            };
+            unsigned char* st0 = reinterpret_cast<unsigned char*>(smem);
+            unsigned char* st1 = st0 + SPH_STAGE;
+            load16(a0, b0);
+            if (n16 > 1) load16(a1, b1);
+            store16(st0, a0, b0);
+            __syncthreads();
+            for (int j16 = 0; j16 < n16; j16 += 2) {
+                if (j16 + 2 < n16) load16(a0, b0);                 // slice j + 2 (its registers were stored one slice ago)
+                mfma16(st0);
+                if (j16 + 1 < n16) store16(st1, a1, b1);           // slice j + 1 -> the other stage
+                __syncthreads();
+                if (j16 + 1 >= n16) break;
+                if (j16 + 3 < n16) load16(a1, b1);
+                mfma16(st1);
+                if (j16 + 2 < n16) store16(st0, a0, b0);
+                __syncthreads();
+            }
+        } else if (SPLIT && MODE == 0 && p.b_planes != nullptr) {
             // B = weights pre-cut into their three bf16 planes (gamer_split3_planes, once per step): the planes are staged as
             // they are - 8-byte loads, 8-byte LDS stores, no cut (a weight element is otherwise re-cut by every row tile of the
             // activations: half of the 176 vector instructions of a K-step)
@@ -483,15 +629,55 @@ gemm_f32_kernel(const GemmParams p) {
                 mfma_tile(smem);
                 __syncthreads();
             }
+        } else if (SPLIT && SP_PREFETCH2) {
+            // one stage of three-image tiles (60 KB), global loads TWO K-steps ahead in two register sets: a split K-step
+            // is ~0.4x as long as the fp32 kernel's, and one step of distance no longer covers the load latency under load
+            float4 ra2[4], rb2[4];
+            auto load_into = [&](float4 (&qa)[4], float4 (&qb)[4]) {
+                if (SP_ABLATE & 8) return;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qa[j] = *reinterpret_cast<const float4*>(pa + j * ja);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qb[j] = *reinterpret_cast<const float4*>(pb + j * jb);
+                pa += sa;
+                pb += sb;
+            };
+            auto store_from = [&](const float4 (&qa)[4], const float4 (&qb)[4]) {
+                unsigned char* d8 = reinterpret_cast<unsigned char*>(smem);
+                if (A_KC) store_kc_split(d8, tid, qa); else store_rc_split(d8, tid, qa);
+                if (B_KC) store_kc_split(d8 + SP_OPERAND, tid, qb); else store_rc_split(d8 + SP_OPERAND, tid, qb);
+            };
+            load_into(ra, rb);
+            if (nkt > 1) load_into(ra2, rb2);
+            if (PP && grp == 1) __syncthreads();                   // half a K-step behind group 0
+            for (int kt = 0; kt < nkt; kt += 2) {
+                store_from(ra, rb);
+                __syncthreads();
+                if (kt + 2 < nkt) load_into(ra, rb);
+                mfma_tile(smem);
+                __syncthreads();
+                if (kt + 1 >= nkt) break;
+                store_from(ra2, rb2);
+                __syncthreads();
+                if (kt + 3 < nkt) load_into(ra2, rb2);
+                mfma_tile(smem);
+                __syncthreads();
+            }
         } else if (SPLIT) {
             // one stage of three-image tiles (60 KB): split + store, barrier, request the next step, multiply, barrier
             fast_load();
+            if (PP && grp == 1) __syncthreads();
             for (int kt = 0; kt < nkt; ++kt) {
+                if (STAMP) { __builtin_amdgcn_sched_barrier(0); t0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
                 store_tile(smem);
+                if (STAMP) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); t1 = stamp_now(); t_ph[0] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
                 __syncthreads();
+                if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[1] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
                 if (kt + 1 < nkt) fast_load();
                 mfma_tile(smem);
+                if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[2] += t1 - t0; t0 = t1; __builtin_amdgcn_sched_barrier(0); }
                 __syncthreads();
+                if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1 = stamp_now(); t_ph[3] += t1 - t0; __builtin_amdgcn_sched_barrier(0); }
             }
         } else if (NBUF == 1) {
             // one LDS image (36 KB): three workgroups per CU; two barriers per K-step, covered by the other
@@ -525,6 +711,7 @@ gemm_f32_kernel(const GemmParams p) {
     } else {
         if (SPLIT) {
             if (nkt > 0) load_tile(kbeg);
+            if (PP && grp == 1) __syncthreads();
             for (int kt = 0; kt < nkt; ++kt) {
                 store_tile(smem);
                 __syncthreads();
@@ -557,6 +744,7 @@ gemm_f32_kernel(const GemmParams p) {
             }
         }
     }
+    if (PP && grp == 0) __syncthreads();                           // pairs with group 1's last barrier
     const unsigned long long t_loop_end = STAMP ? stamp_now() : 0;
 
     // ---- epilogue: acc[i][j][r] is C[row = (r&3)+8*(r>>2)+4*h][col = lane&31] of its 32x32 tile --
@@ -727,7 +915,7 @@ gemm_f32_kernel(const GemmParams p) {
     }
     if (STAMP) {
         unsigned long long* st = g_gemm_stamp;
-        if (st && tid == 0) {
+        if (st && threadIdx.x == 0) {
             const unsigned long long t_end = stamp_now();
             unsigned long long* rec = st + 8ull * blockIdx.x;
             rec[0] = t_ph[0]; rec[1] = t_ph[1]; rec[2] = t_ph[2]; rec[3] = t_ph[3];
@@ -739,11 +927,11 @@ gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, int EPI = 0, int SPLIT = 0>
+template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, int EPI = 0, int SPLIT = 0, bool PP = false>
 static int launch_gemm_t(const GemmParams& p, int blocks, hipStream_t st, int lds) {
     static int attr_lds_dev[MAX_DEVICES] = {};
     int& attr_lds = attr_lds_dev[current_device()];
-    auto kfn = gemm_f32_kernel<A_KC, B_KC, MODE, ACCUM, STAMP, NBUF, EPI, SPLIT>;
+    auto kfn = gemm_f32_kernel<A_KC, B_KC, MODE, ACCUM, STAMP, NBUF, EPI, SPLIT, PP>;
     if (attr_lds != lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -753,7 +941,7 @@ static int launch_gemm_t(const GemmParams& p, int blocks, hipStream_t st, int ld
         }
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(GEMM_THREADS), lds, st, p);
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(PP ? 2 * GEMM_THREADS : GEMM_THREADS), lds, st, p);
     GAMER_CHECK_LAUNCH("gamer_gemm_f32");
     return 0;
 }
@@ -764,6 +952,32 @@ static int launch_gemm_split(const GemmParams& p, int blocks, hipStream_t st) {
     const int lds = GEMM_LDS_BYTES;
     static_assert(SP_LDS_BYTES <= GEMM_LDS_BYTES, "split images must fit the fp32 kernel's LDS allocation");
     const bool acc = MODE == 0 && p.accumulate;
+    static int stamp = -1, pp = 0;
+    if (stamp < 0) {
+        const char* e = getenv("GAMER_GEMM_STAMP");
+        stamp = (e && e[0] == '1') ? 1 : 0;
+        const char* e2 = getenv("GAMER_GEMM_PP");
+        pp = (SP_PINGPONG && e2 && e2[0] == '1') ? 1 : 0;
+    }
+#if SP_PINGPONG
+    if (SPLIT == 6 && pp && !(MODE == 0 && p.b_planes)) {
+        // eight-wave ping-pong form: one workgroup per two tiles, both groups' LDS regions
+        int pblocks;
+        if (MODE == 0) pblocks = (blocks + 1) / 2;
+        else {
+            const int tiles_mn = p.m_tiles * p.n_tiles;
+            pblocks = blocks / tiles_mn * ((tiles_mn + 1) / 2);
+        }
+        const int plds = 2 * GEMM_LDS_BYTES;
+        if (stamp) return launch_gemm_t<A_KC, B_KC, MODE, false, true, 2, 0, SPLIT, true>(p, pblocks, st, plds);
+        if (MODE == 0 && p.resid) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 1, SPLIT, true>(p, pblocks, st, plds);
+        if (MODE == 0 && p.rowdot_out) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 2, SPLIT, true>(p, pblocks, st, plds);
+        if (MODE == 0 && A_KC && B_KC && p.qk_q_rot) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 3, SPLIT, true>(p, pblocks, st, plds);
+        if (acc) return launch_gemm_t<A_KC, B_KC, MODE, true, false, 2, 0, SPLIT, true>(p, pblocks, st, plds);
+        return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 0, SPLIT, true>(p, pblocks, st, plds);
+    }
+#endif
+    if (stamp && SPLIT == 6) return launch_gemm_t<A_KC, B_KC, MODE, false, true, 2, 0, SPLIT>(p, blocks, st, lds);
     if (MODE == 0 && p.resid) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 1, SPLIT>(p, blocks, st, lds);
     if (MODE == 0 && p.rowdot_out) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 2, SPLIT>(p, blocks, st, lds);
     if (MODE == 0 && A_KC && B_KC && p.qk_q_rot) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 3, SPLIT>(p, blocks, st, lds);
