@@ -15,6 +15,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgamer_hip.so")
+if os.environ.get("GAMER_LIB_PATH"):            # A/B runs of another build of the same library (tools/)
+    LIB_PATH = os.path.abspath(os.environ["GAMER_LIB_PATH"])
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gamer_hip.h")
 
 _lib: Optional[C.CDLL] = None

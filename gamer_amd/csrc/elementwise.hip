@@ -8,13 +8,19 @@ namespace gamer {
 constexpr int EW_THREADS = 256;
 constexpr int EW_WAVES = EW_THREADS / WAVE;
 
-static inline int grid_for_waves(int64_t n_waves, int max_blocks = 8192) {
+#ifndef EW_MAX_BLOCKS_W
+#define EW_MAX_BLOCKS_W 8192
+#endif
+#ifndef EW_MAX_BLOCKS_T
+#define EW_MAX_BLOCKS_T 16384
+#endif
+static inline int grid_for_waves(int64_t n_waves, int max_blocks = EW_MAX_BLOCKS_W) {
     int64_t blocks = (n_waves + EW_WAVES - 1) / EW_WAVES;
     if (blocks < 1) blocks = 1;
     if (blocks > max_blocks) blocks = max_blocks;
     return (int)blocks;
 }
-static inline int grid_for_threads(int64_t n, int max_blocks = 16384) {
+static inline int grid_for_threads(int64_t n, int max_blocks = EW_MAX_BLOCKS_T) {
     int64_t blocks = (n + EW_THREADS - 1) / EW_THREADS;
     if (blocks < 1) blocks = 1;
     if (blocks > max_blocks) blocks = max_blocks;
