@@ -104,10 +104,13 @@ class KernelTimer:
         def timed_call(name, *args):
             if not timer.enabled:
                 return orig_call(name, *args)
-            label, flops = timer._next if timer._next else (name.replace("gamer_", "").replace("_bf16", ""), 0.0)
-            nbytes = timer._bytes if timer._next else 0.0
-            timer._next = None
-            timer._bytes = 0.0
+            if name == "gamer_absmax_f32":              # split3: the operand maxima in front of a GEMM keep their own row
+                label, flops, nbytes = "absmax", 0.0, 0.0
+            else:
+                label, flops = timer._next if timer._next else (name.replace("gamer_", "").replace("_bf16", ""), 0.0)
+                nbytes = timer._bytes if timer._next else 0.0
+                timer._next = None
+                timer._bytes = 0.0
             if timer.only is not None and label not in timer.only:
                 return orig_call(name, *args)
             s = torch.cuda.Event(enable_timing=True)
@@ -367,7 +370,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs (bf16, split6, per-GPU batch 128) the default single-GPU run adds")
     ap.add_argument("--no-dropout", action="store_true")
-    ap.add_argument("--matmul", choices=["f32", "split6", "split9"], default=None,
+    ap.add_argument("--matmul", choices=["f32", "split3", "split6", "split9"], default=None,
                     help="how fp32 matrix products are formed (--dtype f32 only; default split6, the engine's default): "
                          "split6 / split9 = every fp32 product from an exact three-way bf16 cut of both operands, 6 / 9 piece "
                          "products on the bf16 pipe, fp32 accumulation (gamer_gemm_f32_split, gamer_attn_*_split; error against "
@@ -604,7 +607,7 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
         gemm_tf = sum(k["tflops"] * k["ms_per_step"] for k in gemm_rows) / max(gemm_ms, 1e-9)
         ms_per_step = elapsed / args.steps * 1e3
         # (prefixes: the kernel's template list ends with the matmul form, ", 0>" = fp32 MFMA)
-        split_terms = {"f32": 0, "split6": 6, "split9": 9}[args.matmul]
+        split_terms = {"f32": 0, "split3": 3, "split6": 6, "split9": 9}[args.matmul]
         kname = {"gemm_fwd": f"gemm_f32_kernel<true, true, 0, false, false, 2, 0, {split_terms}>",
                  "gemm_dgrad": f"gemm_f32_kernel<true, false, 0, false, false, 2, 0, {split_terms}>",
                  "gemm_wgrad": f"gemm_f32_kernel<false, false, 1, false, false, 2, 0, {split_terms}>"}.get(dom["kernel"] if dom else "", None)

@@ -54,6 +54,7 @@ class GemmDesc(C.Structure):
         ("qk_q_rot", c_void_p), ("qk_k_rot", c_void_p),
         ("qk_S", c_int), ("qk_nq", c_int), ("qk_nkv", c_int),
         ("b_planes", c_void_p), ("b_plane_stride", c_int64),
+        ("amax_a", c_void_p), ("amax_b", c_void_p),
     ]
 
 
@@ -112,6 +113,7 @@ _SIGNATURES = {
     "gamer_attn_fwd": [P, I, P, I, P, I, P, P, P, P, I, I, I, I, F, F, U, P, P, P, P, P, I, P, P],
     "gamer_attn_bwd": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, P, P, P, P, I, P],
     "gamer_split3_planes": [P, P, L, L, P],
+    "gamer_absmax_f32": [P, I, L, I, I, L, P, P],
     "gamer_attn_fwd_split": [P, I, P, I, P, I, P, P, P, I, I, I, I, F, F, U, P, P, P, P, P, P],
     "gamer_attn_bwd_split": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, P, P, I, P, P],
     "gamer_residual_dropout_fwd": [P, P, P, I, I, F, U, P, P],

@@ -23,6 +23,15 @@
 // fp32 accumulators of v_mfma_f32_32x32x16_bf16: all nine of them (SPLIT = 9: every bit of both mantissas takes part,
 // the only rounding left is the fp32 accumulation, as in the fp32 MFMA), or the six with i + j <= 2 (SPLIT = 6: the
 // three dropped products are below 2^-24 of |a.b| each - the size of one fp32 rounding).  Inf / NaN operands give NaN.
+//
+// SPLIT = 3 (gamer_gemm_f32_split, terms = 3): a TWO-way fp16 cut and three products.  Each operand TENSOR has a power-of-two
+// scale s = 2^e from its largest magnitude (gamer_absmax_f32 -> `amax_a` / `amax_b`, read here from device memory: max |x| s
+// in [2^13, 2^14)); x s = h0 + h1 + r with h0 = fp16(x s), h1 = fp16(x s - h0) (the subtraction is exact), |r| <= 2^-22 |x s|
+// for every element within 2^17 of the tensor's largest (smaller ones keep an ABSOLUTE error of 2^-25 of the scaled
+// unit, i.e. < 2^-38 of the largest); a.b = (a0.b0 + a0.b1 + a1.b0) / (s_a s_b) in the fp32 accumulators of
+// v_mfma_f32_32x32x16_f16 (11 x 11-bit products are exact in fp32; the dropped a1.b1 and the residuals are ~2^-22 |a.b| per term,
+// measured against fp64: rms error 1.2e-8 of sum |a_k b_k|, the six-product form's 0.9e-8, the fp32 MFMA's 4.4e-8).  Half the
+// MFMAs, two thirds of the LDS bytes and ~60 % of the cut's vector instructions of SPLIT = 6.
 #include "common.h"
 #include <stdlib.h>
 
@@ -90,6 +99,49 @@ __device__ __forceinline__ void store_rc_split(unsigned char* __restrict__ lds, 
 #pragma unroll
         for (int s = 0; s < 3; ++s) *reinterpret_cast<uint2*>(dst + s * SP_RC_IMG) = img[s];
     }
+}
+// ---- SPLIT == 3: two fp16 pieces of x * s (s = the tensor's power-of-two scale); images 0 and 1 of the three-image layouts
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2h_quad(const float4& v, float s, uint2 (&img)[2]) {
+    const float tx = v.x * s, ty = v.y * s, tz = v.z * s, tw = v.w * s;
+    const f16x2 a0 = {(_Float16)tx, (_Float16)ty}, a1 = {(_Float16)tz, (_Float16)tw};          // v_cvt_pk_f16_f32 (nearest even)
+    const f16x2 b0 = {(_Float16)(tx - (float)a0[0]), (_Float16)(ty - (float)a0[1])};
+    const f16x2 b1 = {(_Float16)(tz - (float)a1[0]), (_Float16)(tw - (float)a1[1])};
+    img[0] = make_uint2(__builtin_bit_cast(uint32_t, a0), __builtin_bit_cast(uint32_t, a1));
+    img[1] = make_uint2(__builtin_bit_cast(uint32_t, b0), __builtin_bit_cast(uint32_t, b1));
+}
+__device__ __forceinline__ void store_kc_h2(unsigned char* __restrict__ lds, int tid, const float4 (&r)[4], float s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = tid + GEMM_THREADS * j;
+        uint2 img[2];
+        split2h_quad(r[j], s, img);
+        unsigned char* dst = lds + (f >> 3) * SP_KC_ROW + ((f & 7) << 3);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<uint2*>(dst + q * SP_KC_IMG) = img[q];
+    }
+}
+__device__ __forceinline__ void store_rc_h2(unsigned char* __restrict__ lds, int tid, const float4 (&r)[4], float s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = tid + GEMM_THREADS * j;
+        uint2 img[2];
+        split2h_quad(r[j], s, img);
+        unsigned char* dst = lds + sp_rc_off(f >> 5, (f & 31) << 2);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<uint2*>(dst + q * SP_RC_IMG) = img[q];
+    }
+}
+// the scale of a tensor from the bits of its largest magnitude (a non-negative float): max * s in [2^13, 2^14); 1 for a
+// zero, denormal, infinite or NaN maximum (Inf / NaN then reach the MFMA as they are).  inv = 1 / s, exact.
+__device__ __forceinline__ void scale_from_amax(uint32_t bits, float& s, float& inv) {
+    const int e = (int)((bits >> 23) & 0xffu);
+    int se = 127 + 13 - (e - 127);
+    if (e == 0 || e == 255) se = 127;
+    se = se < 1 ? 1 : (se > 253 ? 253 : se);
+    s = __uint_as_float((uint32_t)se << 23);
+    inv = __uint_as_float((uint32_t)(254 - se) << 23);
 }
 // ---- two-stage form (SP_TWO_STAGE): K-steps of 16, each stage = both operands' three images of a 128 x 16 slice.  A KC image
 // row is 32 B of k + 16 B of padding (48-byte rows: the 16-byte fragment reads of 16 consecutive rows fall on distinct banks),
@@ -218,6 +270,7 @@ struct GemmParams {
     const int32_t* qk_pos_ids;
     float* qk_q_rot; float* qk_k_rot;
     int qk_S, qk_nq, qk_nkv;
+    const uint32_t* amax_a; const uint32_t* amax_b;   // SPLIT == 3: bits of max |A|, max |B| (gamer_absmax_f32)
     const uint16_t* b_planes;      // SPLIT, MODE 0: B pre-cut into three bf16 planes indexed like B (nullptr: cut in the kernel)
     int64_t b_plane_stride;
 };
@@ -412,6 +465,13 @@ gemm_f32_kernel(const GemmParams p) {
     const int nkt = (kend - kbeg + BK - 1) / BK;
     const bool a_in = row0 + BM <= row_end, b_in = col0 + BN <= col_end;     // workgroup-uniform
     float4 ra[4], rb[4];
+    float scale_a = 1.f, scale_b = 1.f, unscale = 1.f;
+    if (SPLIT == 3) {
+        float ia, ib;
+        scale_from_amax(p.amax_a[0], scale_a, ia);
+        scale_from_amax(p.amax_b[0], scale_b, ib);
+        unscale = ia * ib;
+    }
     auto load_tile = [&](int k0) {
         const bool k_in = k0 + BK <= kend;
         if (a_in && k_in) {
@@ -430,6 +490,12 @@ gemm_f32_kernel(const GemmParams p) {
         }
     };
     auto store_tile = [&](float* dst) {
+        if (SPLIT == 3) {
+            unsigned char* d8 = reinterpret_cast<unsigned char*>(dst);
+            if (A_KC) store_kc_h2(d8, tid, ra, scale_a); else store_rc_h2(d8, tid, ra, scale_a);
+            if (B_KC) store_kc_h2(d8 + SP_OPERAND, tid, rb, scale_b); else store_rc_h2(d8 + SP_OPERAND, tid, rb, scale_b);
+            return;
+        }
         if (SPLIT) {
             unsigned char* d8 = reinterpret_cast<unsigned char*>(dst);
             if (A_KC) store_kc_split(d8, tid, ra); else store_rc_split(d8, tid, ra);
@@ -449,6 +515,33 @@ gemm_f32_kernel(const GemmParams p) {
     auto mfma_tile = [&](const float* as) {
         if (!wave_live) return;
         if (SPLIT != 0 && (SP_ABLATE & 4) != 0) return;
+        if (SPLIT == 3) {
+            const unsigned char* a8 = reinterpret_cast<const unsigned char*>(as);
+            const unsigned char* b8 = a8 + SP_OPERAND;
+            constexpr int A_IMG = A_KC ? SP_KC_IMG : SP_RC_IMG, B_IMG = B_KC ? SP_KC_IMG : SP_RC_IMG;
+#pragma unroll
+            for (int sub = 0; sub < BK / 16; ++sub) {
+                f16x8 af[2][2], bf[2][2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) af[i][q] = __builtin_bit_cast(f16x8, read_frag_split<A_KC>(a8 + q * A_IMG, wm * 64 + i * 32, sub, lane));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bf[j][q] = __builtin_bit_cast(f16x8, read_frag_split<B_KC>(b8 + q * B_IMG, wn * 64 + j * 32, sub, lane));
+                }
+                // a0.b1, a1.b0 (small) first, then a0.b0
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int qa = t == 1 ? 1 : 0, qb = t == 0 ? 1 : 0;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][qa], bf[j][qb], acc[i][j], 0, 0, 0);
+                }
+            }
+            return;
+        }
         if (SPLIT) {
             const unsigned char* a8 = reinterpret_cast<const unsigned char*>(as);
             const unsigned char* b8 = a8 + SP_OPERAND;
@@ -521,7 +614,7 @@ gemm_f32_kernel(const GemmParams p) {
             pa += sa;
             pb += sb;
         };
-        if (SPLIT && SP_TWO_STAGE && !PP && !(MODE == 0 && p.b_planes != nullptr)) {
+        if (SPLIT && SPLIT != 3 && SP_TWO_STAGE && !PP && !(MODE == 0 && p.b_planes != nullptr)) {
             // Two LDS stages of 16-k slices: while the MFMAs of slice j run from one stage, slice j + 1 is cut and stored into
             // the other and slice j + 2 is in flight from global memory - ONE barrier per slice and no phase in which a whole
             // workgroup only stores (the one-stage form below: store | barrier | multiply | barrier).
@@ -590,7 +683,7 @@ gemm_f32_kernel(const GemmParams p) {
                 if (j16 + 2 < n16) store16(st0, a0, b0);
                 __syncthreads();
             }
-        } else if (SPLIT && MODE == 0 && p.b_planes != nullptr) {
+        } else if (SPLIT && SPLIT != 3 && MODE == 0 && p.b_planes != nullptr) {
             // B = weights pre-cut into their three bf16 planes (gamer_split3_planes, once per step): the planes are staged as
             // they are - 8-byte loads, 8-byte LDS stores, no cut (a weight element is otherwise re-cut by every row tile of the
             // activations: half of the 176 vector instructions of a K-step)
@@ -629,7 +722,7 @@ gemm_f32_kernel(const GemmParams p) {
                 mfma_tile(smem);
                 __syncthreads();
             }
-        } else if (SPLIT && SP_PREFETCH2) {
+        } else if (SPLIT && SPLIT != 3 && SP_PREFETCH2) {
             // one stage of three-image tiles (60 KB), global loads TWO K-steps ahead in two register sets: a split K-step
             // is ~0.4x as long as the fp32 kernel's, and one step of distance no longer covers the load latency under load
             float4 ra2[4], rb2[4];
@@ -749,6 +842,7 @@ gemm_f32_kernel(const GemmParams p) {
 
     // ---- epilogue: acc[i][j][r] is C[row = (r&3)+8*(r>>2)+4*h][col = lane&31] of its 32x32 tile --
     const bool interior = a_in && b_in;
+    const float alpha_eff = SPLIT == 3 ? p.alpha * unscale : p.alpha;      // (alpha and 1 / (s_a s_b) are powers of two or 1 in the step)
     if (MODE == 0 && (NBUF == 2 || SPLIT) && interior && (p.ldc & 3) == 0) {
         // Row-major rewrite through LDS (the K-loop images are dead after its last barrier): each wave
         // parks its 64x64 patch as [64][68] floats and reads it back one 16-byte row chunk per lane, so the
@@ -763,7 +857,7 @@ gemm_f32_kernel(const GemmParams p) {
             for (int it = 0; it < 16; ++it) oth[it] = *reinterpret_cast<const float4*>(ob + (int64_t)it * 4 * p.ldc);
         }
         // (alpha == 1 for every GEMM of the train step: no multiply; every VALU instruction here is matrix time)
-        if (p.alpha == 1.f) {
+        if (SPLIT != 3 && p.alpha == 1.f) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -778,7 +872,7 @@ gemm_f32_kernel(const GemmParams p) {
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        patch[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + j * 32 + r32] = p.alpha * acc[i][j][r];
+                        patch[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + j * 32 + r32] = alpha_eff * acc[i][j][r];
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): own LDS writes landed (wave-private patch)
         const int c4 = (lane & 15) << 2;
@@ -902,12 +996,12 @@ gemm_f32_kernel(const GemmParams p) {
                 const int rbase = row0 + wm * 64 + i * 32 + 4 * h;
                 if (interior) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) emit(rbase + (r & 3) + 8 * (r >> 2), col, p.alpha * acc[i][j][r]);
+                    for (int r = 0; r < 16; ++r) emit(rbase + (r & 3) + 8 * (r >> 2), col, alpha_eff * acc[i][j][r]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int rr = (r & 3) + 8 * (r >> 2);
-                        if (rbase + rr < row_end && col < col_end) emit(rbase + rr, col, p.alpha * acc[i][j][r]);
+                        if (rbase + rr < row_end && col < col_end) emit(rbase + rr, col, alpha_eff * acc[i][j][r]);
                     }
                 }
             }
@@ -989,6 +1083,7 @@ template <bool A_KC, bool B_KC, int MODE>
 static int launch_gemm(const GemmParams& p, int blocks, hipStream_t st, int split = 0) {
     if (split == 6) return launch_gemm_split<A_KC, B_KC, MODE, 6>(p, blocks, st);
     if (split == 9) return launch_gemm_split<A_KC, B_KC, MODE, 9>(p, blocks, st);
+    if (split == 3) return launch_gemm_split<A_KC, B_KC, MODE, 3>(p, blocks, st);
     static int stamp = -1, solo = 0, nbuf = 2;
     if (stamp < 0) {
         const char* e = getenv("GAMER_GEMM_STAMP");
@@ -1080,7 +1175,9 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     p.qk_bias_q = d->qk_bias_q; p.qk_bias_k = d->qk_bias_k; p.qk_bias_v = d->qk_bias_v;
     p.qk_act_idx = d->qk_act_idx; p.qk_pos_ids = d->qk_pos_ids; p.qk_q_rot = d->qk_q_rot; p.qk_k_rot = d->qk_k_rot;
     p.qk_S = d->qk_S; p.qk_nq = d->qk_nq; p.qk_nkv = d->qk_nkv;
-    p.b_planes = (split && d->group_mode == 0) ? (const uint16_t*)d->b_planes : nullptr;
+    p.amax_a = d->amax_a; p.amax_b = d->amax_b;
+    GAMER_CHECK_ARG(split != 3 || (d->amax_a && d->amax_b), "gamer_gemm_f32_split: terms = 3 needs amax_a and amax_b (gamer_absmax_f32)");
+    p.b_planes = (split && split != 3 && d->group_mode == 0) ? (const uint16_t*)d->b_planes : nullptr;
     p.b_plane_stride = d->b_plane_stride;
     GAMER_CHECK_ARG(!p.b_planes || ((reinterpret_cast<uintptr_t>(p.b_planes) & 7u) == 0 && d->b_plane_stride % 4 == 0 && d->b_plane_stride > 0),
                     "gamer_gemm_f32_split: b_planes must be 8-byte aligned with b_plane_stride %% 4 == 0");
@@ -1125,9 +1222,75 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     return 0;
 }
 
+// bits of max |x| over `batch` matrices [rows, cols] (leading dimension ld, `stride` elements apart) -> atomicMax(out):
+// non-negative floats order like their bit patterns, a NaN's pattern is above every number's (it wins, on purpose)
+__device__ __forceinline__ uint32_t amax4(uint32_t m, const uint4 v) {
+    return max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+}
+// one atomic per workgroup (and few workgroups: every atomic of the launch goes to the same word)
+__device__ __forceinline__ void amax_commit(uint32_t m, uint32_t* __restrict__ out) {
+    __shared__ uint32_t part[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(part[0], part[1]), max(part[2], part[3]));
+        if (m) atomicMax(out, m);
+    }
+}
+// dense storage (ld == cols, matrices back to back): one 16-byte load per thread and iteration, two in flight
+__global__ void __launch_bounds__(256)
+absmax_flat_kernel(const uint4* __restrict__ x, int64_t n4, uint32_t* __restrict__ out) {
+    uint32_t m = 0;
+    const int64_t step = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + step < n4; i += 2 * step) {
+        const uint4 a = x[i], b = x[i + step];
+        m = amax4(amax4(m, a), b);
+    }
+    if (i < n4) m = amax4(m, x[i]);
+    amax_commit(m, out);
+}
+// padded rows: one wave per row at a time, lanes across the row's 16-byte chunks
+__global__ void __launch_bounds__(256)
+absmax_rows_kernel(const float* __restrict__ x, int batch, int64_t stride, int rows, int cols, int64_t ld, uint32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t waves = (int64_t)gridDim.x * 4, nrows = (int64_t)batch * rows;
+    uint32_t m = 0;
+    for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nrows; w += waves) {
+        const int64_t b = w / rows, r = w - b * rows;
+        const float* src = x + b * stride + r * ld;
+        for (int c = lane << 2; c < cols; c += 256) {
+            if (c + 3 < cols) m = amax4(m, *reinterpret_cast<const uint4*>(src + c));
+            else for (int q = 0; c + q < cols; ++q) m = max(m, __float_as_uint(src[c + q]) & 0x7fffffffu);
+        }
+    }
+    amax_commit(m, out);
+}
+extern "C" int gamer_absmax_f32(const float* x, int batch, int64_t stride, int rows, int cols, int64_t ld, uint32_t* out, void* stream) {
+    GAMER_CHECK_ARG(x && out && batch >= 1 && rows >= 1 && cols >= 1 && ld >= cols && ld % 4 == 0 && stride % 4 == 0 &&
+                    (reinterpret_cast<uintptr_t>(x) & 15u) == 0, "gamer_absmax_f32: bad arguments (rows=%d cols=%d ld=%lld)",
+                    rows, cols, (long long)ld);
+    if (ld == cols && (batch == 1 || stride == (int64_t)rows * ld)) {
+        const int64_t n4 = (int64_t)batch * rows * cols / 4;
+        int64_t blocks = (n4 + 511) / 512;
+        if (blocks < 1) blocks = 1;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(absmax_flat_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const uint4*>(x), n4, out);
+    } else {
+        int64_t blocks = ((int64_t)batch * rows + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(absmax_rows_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, batch, stride, rows, cols, ld, out);
+    }
+    GAMER_CHECK_LAUNCH("gamer_absmax_f32");
+    return 0;
+}
+
 extern "C" int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream) { return gemm_entry(d, stream, 0); }
 
 extern "C" int gamer_gemm_f32_split(const gamer_gemm_desc* d, int terms, void* stream) {
-    GAMER_CHECK_ARG(terms == 6 || terms == 9, "gamer_gemm_f32_split: terms=%d (6 or 9)", terms);
+    GAMER_CHECK_ARG(terms == 3 || terms == 6 || terms == 9, "gamer_gemm_f32_split: terms=%d (3, 6 or 9)", terms);
     return gemm_entry(d, stream, terms);
 }

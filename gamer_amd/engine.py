@@ -413,6 +413,11 @@ class Engine:
         self.weight_planes: Optional[torch.Tensor] = None
         if dtype == "f32" and matmul != "f32" and os.environ.get("GAMER_SPLIT_PLANES", "0") == "1":
             self.weight_planes = torch.zeros(3, _round_up(n, 4), dtype=torch.bfloat16, device=self.device)
+        # matmul="split3": the per-tensor maxima its GEMMs scale their operands by; the parameters keep theirs for a whole pass
+        self._amax = None
+        if dtype == "f32" and matmul == "split3":
+            self._amax = ops.amax_reuse()
+            self._amax.stable_range(self.flat_p.data_ptr(), self.flat_p.numel() * 4)
         self.lut = cfg.behavior_lut().to(self.device)
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._ws: Dict[bool, _Workspace] = {}
@@ -483,6 +488,7 @@ class Engine:
         return None if wp is None else (self.flat_p.data_ptr(), self.flat_p.numel() * 4, wp.data_ptr(), wp.stride(0))
 
     @ops.scoped_f32_matmul(lambda self, *a: self.matmul, lambda self, *a: self._planes())
+    @ops.scoped_amax(lambda self, *a: self._amax)
     def forward(self, input_ids, attention_mask=None, actions=None, labels=None, num_items_in_batch=None,
                 train: bool = False, dropout: Optional[bool] = None, act_zero_col: Optional[int] = None,
                 uniform_len: int = 0, kv_sink=None, session_ids=None, extended_session_ids=None,
@@ -532,6 +538,12 @@ class Engine:
             self.dropout_step += 1
         ws = self.workspace(B, S, train)
         self.ws = ws
+        if self._amax is not None:
+            # matmul="split3": maxima of the tensors that do not change between their first GEMM of this pass and the backward
+            # (saved GEMM inputs, the parameters) are measured once; everything else per GEMM (ops.amax_reuse)
+            self._amax.reset()
+            if train:       # (the evaluation workspace shares one set of buffers between the layers: nothing is stable there)
+                self._amax.stable(ws.xn, *[A[k] for A in ws.layers for k in ("h1", "h2", "ao", "ao_c", "hin", "hm") if k in A])
         ids = input_ids.to(self.device, torch.int64).contiguous()
         am = attention_mask.to(self.device, torch.int64).contiguous() if attention_mask is not None else None
         act = actions.to(self.device, torch.int64).contiguous() if actions is not None else None
@@ -729,6 +741,7 @@ class Engine:
         ops.fill(self.flat_g, 0.0)
 
     @ops.scoped_f32_matmul(lambda self, *a: self.matmul, lambda self, *a: self._planes())
+    @ops.scoped_amax(lambda self, *a: self._amax)
     def backward(self, dloss: float = 1.0, layer_done=None, dloss_dev: Optional[torch.Tensor] = None):
         """Accumulates d(loss)*dloss into the flat gradient buffer (call zero_grad() first for a fresh
         window).  Needs a forward(..., labels=..., train=True) before it.  ``dloss_dev``: fp32 device scalar that
@@ -810,10 +823,14 @@ class Engine:
         else:
             ops.ce_bwd(ws.logits, ws.ldl, sv["labels"], V, self.temperature, IGNORE_INDEX, ws.lse_ce, ws.count, 0.0,
                        dloss, dloss_dev)
-        ops.linear_wgrad(ws.logits, ws.ldl, ws.xn, H, demb, H, T, V, H)
+        import contextlib
+        # (matmul="split3") a gradient read by the weight- and the input-gradient GEMM of a site is measured once
+        hold = self._amax.hold if self._amax is not None else (lambda *t: contextlib.nullcontext())
         t0, t1, t2, t3 = ws.tmpH
         L = cfg.num_hidden_layers
-        dgrad(ws.logits, ws.ldl, emb, self.shadow.t("model.embed_tokens.weight") if bf16 else None, H, t3, H, V, H)
+        with hold(ws.logits):
+            ops.linear_wgrad(ws.logits, ws.ldl, ws.xn, H, demb, H, T, V, H)
+            dgrad(ws.logits, ws.ldl, emb, self.shadow.t("model.embed_tokens.weight") if bf16 else None, H, t3, H, V, H)
         # every norm backward that completes dx also emits t0 = mask * dx for the branch that reads dx next
         norm_bwd(ws.x_final, self.params["model.norm.weight"], t3, H, self.grads["model.norm.weight"], False,
                  branch=(self._seed(L - 1, 5), ws.slot))
@@ -825,13 +842,15 @@ class Engine:
             grp = dict(groups=E, group_offsets=ws.offsets)
             xlast = xs[2] if W.cross else xs[1]
             # ---- experts ----   (t0 = d out_sorted, written by the norm backward that completed dx)
-            ops.linear_wgrad(t0, H, A["hm"], I, G.down, I, T, H, I, strideC=H * I, **grp)
-            dgrad(t0, H, W.down, WT.down if bf16 else None, I, ws.dhm, I, H, I, strideB=H * I, **grp)
+            with hold(t0):
+                ops.linear_wgrad(t0, H, A["hm"], I, G.down, I, T, H, I, strideC=H * I, **grp)
+                dgrad(t0, H, W.down, WT.down if bf16 else None, I, ws.dhm, I, H, I, strideB=H * I, **grp)
             ops.swiglu_bwd(A["g"], A["u"], ws.dhm, T * I, p_res, self._seed(l, 4))          # g <- dg, u <- du
-            ops.linear_wgrad(A["g"], I, A["hin"], din, G.gate, din, T, I, din, strideC=I * din, **grp)
-            ops.linear_wgrad(A["u"], I, A["hin"], din, G.up, din, T, I, din, strideC=I * din, **grp)
-            dgrad(A["g"], I, W.gate, WT.gate if bf16 else None, din, ws.dhin, din, I, din, strideB=I * din, **grp)
-            dgrad(A["u"], I, W.up, WT.up if bf16 else None, din, ws.dhin, din, I, din, accumulate=True, strideB=I * din, **grp)
+            with hold(A["g"], A["u"]):
+                ops.linear_wgrad(A["g"], I, A["hin"], din, G.gate, din, T, I, din, strideC=I * din, **grp)
+                ops.linear_wgrad(A["u"], I, A["hin"], din, G.up, din, T, I, din, strideC=I * din, **grp)
+                dgrad(A["g"], I, W.gate, WT.gate if bf16 else None, din, ws.dhin, din, I, din, strideB=I * din, **grp)
+                dgrad(A["u"], I, W.up, WT.up if bf16 else None, din, ws.dhin, din, I, din, accumulate=True, strideB=I * din, **grp)
             if W.inject:
                 ops.rowtable_bwd(ws.dhin, din, H, r["beh_idx"], G.beh, ws.slot)
             norm_bwd(xlast, W.ln3, ws.dhin, din, G.ln3, True, ws.slot,
@@ -842,10 +861,13 @@ class Engine:
                 CT = WT.cross_attn if bf16 else dict(o=None, gate=None, qkv=None)
                 # dropout mask of the residual add + gate backward in one pass: t1 = d op, t2 = d gate
                 ops.silu_gate_bwd(A["op_c"], A["gate_c"], ws.dx, t1, t2, p=p_res, seed=self._seed(l, 3))
-                ops.linear_wgrad(t1, H, A["ao_c"], NQ, GC["o"], NQ, T, H, NQ)
-                ops.linear_wgrad(t2, H, A["h2"], H, GC["gate"], H, T, H, H)
-                dgrad(t1, H, C["o"], CT["o"], NQ, ws.dao, NQ, H, NQ,
-                      rowdot=(A["ao_c"], ws.delta, S) if fuse_delta else None)
+                hold_t2 = hold(t2)                       # (t2 is read again by its input-gradient GEMM below)
+                hold_t2.__enter__()
+                with hold(t1):
+                    ops.linear_wgrad(t1, H, A["ao_c"], NQ, GC["o"], NQ, T, H, NQ)
+                    ops.linear_wgrad(t2, H, A["h2"], H, GC["gate"], H, T, H, H)
+                    dgrad(t1, H, C["o"], CT["o"], NQ, ws.dao, NQ, H, NQ,
+                          rowdot=(A["ao_c"], ws.delta, S) if fuse_delta else None)
                 attention_bwd(A["q_c"], A["k_c"], A["qkv_c"][:, NQ + NKV:], A["ao_c"], A["lse_c"], r["kl_cross"],
                               r["ql_cross"], r["empty_cross"], r["tile_empty_cross"], self._seed(l, 2), ws.cross_order,
                               span_cross)
@@ -853,22 +875,26 @@ class Engine:
                                     GC["qn"], GC["kn"], bias_q=C["bq"], bias_k=C["bk"], act_idx=r["act_idx"], nb1=NB1,
                                     dbias_q=GC["bq"], dbias_k=GC["bk"], dbias_v=GC["bv"], pos_ids=pos_ids,
                                     partial=ws.qk_partial)
-                ops.linear_wgrad(ws.dqkv, QKV, A["h2"], H, GC["qkv"], H, T, QKV, H)
-                dgrad(ws.dqkv, QKV, C["qkv"], CT["qkv"], H, t3, H, QKV, H)
+                with hold(ws.dqkv):
+                    ops.linear_wgrad(ws.dqkv, QKV, A["h2"], H, GC["qkv"], H, T, QKV, H)
+                    dgrad(ws.dqkv, QKV, C["qkv"], CT["qkv"], H, t3, H, QKV, H)
                 dgrad(t2, H, C["gate"], CT["gate"], H, t3, H, H, H, accumulate=True)
+                hold_t2.__exit__(None, None, None)
                 norm_bwd(xs[1], W.ln2, t3, H, G.ln2, True, branch=(self._seed(l, 1), None))
             # ---- self attention ----
             SA, GS = W.self_attn, G.self_attn
             ST = WT.self_attn if bf16 else dict(o=None, qkv=None)
             # (t0 = mask * dx of this branch, written by the norm backward above)
-            ops.linear_wgrad(t0, H, A["ao"], NQ, GS["o"], NQ, T, H, NQ)
-            dgrad(t0, H, SA["o"], ST["o"], NQ, ws.dao, NQ, H, NQ, rowdot=(A["ao"], ws.delta, S) if fuse_delta else None)
+            with hold(t0):
+                ops.linear_wgrad(t0, H, A["ao"], NQ, GS["o"], NQ, T, H, NQ)
+                dgrad(t0, H, SA["o"], ST["o"], NQ, ws.dao, NQ, H, NQ, rowdot=(A["ao"], ws.delta, S) if fuse_delta else None)
             attention_bwd(A["q"], A["k"], A["qkv"][:, NQ + NKV:], A["ao"], A["lse"], r["kl_self"], None, r["empty_self"],
                           r["tile_empty_self"], self._seed(l, 0), None, span_self)
             ops.qknorm_rope_bwd(A["qkv"], ws.dq, ws.dk, S, nq, nkv, SA["qn"], SA["kn"], eps, cos, sin, ws.dqkv, GS["qn"],
                                 GS["kn"], pos_ids=pos_ids, partial=ws.qk_partial)
-            ops.linear_wgrad(ws.dqkv, QKV, A["h1"], H, GS["qkv"], H, T, QKV, H)
-            dgrad(ws.dqkv, QKV, SA["qkv"], ST["qkv"], H, t3, H, QKV, H)
+            with hold(ws.dqkv):
+                ops.linear_wgrad(ws.dqkv, QKV, A["h1"], H, GS["qkv"], H, T, QKV, H)
+                dgrad(ws.dqkv, QKV, SA["qkv"], ST["qkv"], H, t3, H, QKV, H)
             norm_bwd(xs[0], W.ln1, t3, H, G.ln1, True, branch=(self._seed(l - 1, 5), ws.slot) if l > 0 else None)
             if layer_done is not None:
                 layer_done(l)

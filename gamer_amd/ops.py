@@ -126,11 +126,12 @@ def rowtable_bwd(dy, lddy, col0, idx, dtable, dy_rows=None):
 
 
 # fp32 matmul form in effect: 0 = v_mfma_f32_32x32x2_f32, 6 / 9 = gamer_gemm_f32_split (exact three-way bf16 cut of both
-# operands, 6 or 9 piece products on the bf16 pipe).  Default 0; an Engine / DecodeSession with another form scopes its
+# operands, 6 or 9 piece products on the bf16 pipe), 3 = its two-way fp16 form (per-tensor power-of-two scales from
+# gamer_absmax_f32, 3 piece products).  Default 0; an Engine / DecodeSession with another form scopes its
 # own calls with `with ops.f32_matmul(form):`, which restores the previous value on exit - two engines with different
 # forms, tools and tests in one process do not leak their setting into each other.
 F32_MATMUL_TERMS = 0
-MATMUL_MODES = {"f32": 0, "split6": 6, "split9": 9}
+MATMUL_MODES = {"f32": 0, "split3": 3, "split6": 6, "split9": 9}
 # Pre-cut weights of the split forms: (address of the fp32 flat parameter buffer, its bytes, address of the three bf16 planes,
 # plane stride in elements) or None.  Set - scoped, like the matmul form - by the engine that owns the buffers; gemm() hands a
 # B operand that lies inside the flat buffer to gamer_gemm_f32_split together with its planes.
@@ -171,6 +172,121 @@ def scoped_f32_matmul(get_mode, get_planes=None):
     return deco
 
 
+# split3: one device word per operand tensor for the bits of its largest magnitude.  Slots come from a ring that is zeroed as a
+# whole when it wraps (stream-ordered: every GEMM that read an old slot was enqueued before the memset).
+_AMAX_RING = {}
+_AMAX_SLOTS = 4096
+# Optional reuse of a maximum for a tensor that is read by several GEMMs while it does not change (x by forward and weight
+# gradient, dy by weight and input gradient, a weight by every GEMM of a step): inside `with cache:` (an amax_reuse) a slot is
+# keyed by (address, extent) and measured once for tensors the OWNER declared unchanging - `stable(...)` tensors / address
+# ranges until the next `reset()`, `hold(...)` tensors for the duration of a with-block.  Everything else is measured per GEMM.
+_AMAX_REUSE = None
+
+
+class amax_reuse:
+    def __init__(self, everything=False):
+        self.slots, self.pools, self.used = {}, [], 0
+        self.stable_ptrs, self.stable_ranges, self.held = set(), [], {}
+        self.everything = everything          # tools: every tensor counts as unchanging (kernel timing)
+
+    def __enter__(self):
+        global _AMAX_REUSE
+        self.prev, _AMAX_REUSE = _AMAX_REUSE, self
+        return self
+
+    def __exit__(self, *exc):
+        global _AMAX_REUSE
+        _AMAX_REUSE = self.prev
+        return False
+
+    def stable(self, *tensors):
+        self.stable_ptrs.update(t.data_ptr() for t in tensors if t is not None)
+
+    def stable_range(self, base, nbytes):
+        self.stable_ranges.append((int(base), int(nbytes)))
+
+    def reset(self):
+        """Start of a forward pass: every cached maximum is dropped, the slot words are zeroed (one memset per pool)."""
+        self.slots.clear()
+        self.held.clear()
+        for pool in self.pools:
+            pool.zero_()
+        self.used = 0
+
+    def hold(self, *tensors):
+        cache = self
+
+        class _Hold:
+            def __enter__(self_h):
+                for t in tensors:
+                    cache.held[t.data_ptr()] = cache.held.get(t.data_ptr(), 0) + 1
+
+            def __exit__(self_h, *exc):
+                for t in tensors:
+                    p = t.data_ptr()
+                    cache.held[p] -= 1
+                    if cache.held[p] == 0:
+                        del cache.held[p]
+                        for k in [k for k in cache.slots if k[0] == p]:
+                            del cache.slots[k]
+                return False
+        return _Hold()
+
+    def _cached(self, p):
+        if self.everything or p in self.stable_ptrs or p in self.held:
+            return True
+        return any(b <= p < b + n for b, n in self.stable_ranges)
+
+    def slot(self, x, geom):
+        p = x.data_ptr()
+        key = (p,) + geom
+        keep = self._cached(p)
+        if keep and key in self.slots:
+            return self.slots[key]
+        i, j = divmod(self.used, 1024)
+        if i == len(self.pools):
+            self.pools.append(torch.zeros(1024, dtype=torch.int32, device=x.device))
+        ptr_ = self.pools[i].data_ptr() + 4 * j
+        self.used += 1
+        call("gamer_absmax_f32", ptr(x), *geom, ptr_, stream_ptr())
+        if keep:
+            self.slots[key] = ptr_
+        return ptr_
+
+
+def scoped_amax(get_cache):
+    """Decorator: `get_cache(*args)` (an amax_reuse or None) is the maxima cache in effect for the duration of the call."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            cache = get_cache(*args)
+            if cache is None:
+                return fn(*args, **kwargs)
+            with cache:
+                return fn(*args, **kwargs)
+        return wrapper
+    return deco
+
+
+def absmax_slot(x, batch, stride, rows, cols, ld):
+    """Device pointer of a word holding the bits of max |x| over `batch` matrices [rows, cols] (leading dimension ld)."""
+    if _AMAX_REUSE is not None:
+        return _AMAX_REUSE.slot(x, (batch, stride, rows, cols, ld))
+    key = (x.device.index, stream_ptr())
+    ring = _AMAX_RING.get(key)
+    if ring is None:
+        ring = _AMAX_RING[key] = [torch.zeros(_AMAX_SLOTS, dtype=torch.int32, device=x.device), 0]
+    if ring[1] == _AMAX_SLOTS:
+        ring[0].zero_()
+        ring[1] = 0
+    slot = ring[0].data_ptr() + 4 * ring[1]
+    ring[1] += 1
+    call("gamer_absmax_f32", ptr(x), batch, stride, rows, cols, ld, slot, stream_ptr())
+    return slot
+
+
 def split3_planes(x, planes):
     """planes [3, n] bf16 <- the three exact bf16 pieces of x [n] fp32 (gamer_split3_planes)."""
     call("gamer_split3_planes", ptr(x), ptr(planes), x.numel(), planes.stride(0), stream_ptr())
@@ -181,7 +297,7 @@ def set_f32_matmul(mode) -> int:
     global F32_MATMUL_TERMS
     prev = F32_MATMUL_TERMS
     terms = MATMUL_MODES[mode] if isinstance(mode, str) else int(mode)
-    if terms not in (0, 6, 9):
+    if terms not in (0, 3, 6, 9):
         raise ValueError(f"fp32 matmul mode {mode!r}: one of {sorted(MATMUL_MODES)}")
     F32_MATMUL_TERMS = terms
     return prev
@@ -221,6 +337,15 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
         d.qk_act_idx, d.qk_pos_ids = ptr(q.get("act_idx")), ptr(q.get("pos_ids"))
         d.qk_q_rot, d.qk_k_rot = ptr(q["q_rot"]), ptr(q["k_rot"])
         d.qk_S, d.qk_nq, d.qk_nkv = int(q["S"]), int(q["nq"]), int(q["nkv"])
+    if F32_MATMUL_TERMS == 3:
+        # operand extents: A(m, k) at A + m a_rs + k a_ks, B(n, k) at B + n b_rs + k b_ks (one of each stride pair is 1)
+        ga = (M, K, a_rs) if a_ks == 1 else (K, M, a_ks)
+        gb = (N, K, b_rs) if b_ks == 1 else (K, N, b_ks)
+        nb = groups if (group_mode == 0 and groups > 1) else 1
+        d.amax_a = absmax_slot(A, 1, 0, *ga)
+        d.amax_b = absmax_slot(Bm, nb, strideB if nb > 1 else 0, *gb)
+        call("gamer_gemm_f32_split", C.byref(d), 3, stream_ptr())
+        return
     if F32_MATMUL_TERMS:
         if WEIGHT_PLANES is not None and group_mode == 0:
             base, nbytes, pl, stride = WEIGHT_PLANES

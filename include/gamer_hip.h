@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GAMER_ABI_VERSION 5
+#define GAMER_ABI_VERSION 6
 
 /* bf16 activations of the AMP variant (the reference's --bf16 run, ref:SeqRec/tasks/train_SMB_decoder.py:114-118,
  * 407-408: HF Trainer autocast): raw bfloat16 bits.  Entry points with the suffix _bf16 are the same operation with
@@ -212,6 +212,10 @@ typedef struct {
      * otherwise: 4040 times per step at batch 1024); edge tiles and gamer_gemm_f32 ignore it.  Results are bit-identical. */
     const gamer_bf16* b_planes;
     int64_t b_plane_stride;
+    /* (ABI 6) gamer_gemm_f32_split with terms = 3 only: device words holding the bits of max |A| and max |B| over the operand
+     * tensors (gamer_absmax_f32; for grouped B: over all groups) - the kernel derives each tensor's power-of-two scale from them. */
+    const uint32_t* amax_a;
+    const uint32_t* amax_b;
 } gamer_gemm_desc;
 
 int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);
@@ -224,6 +228,16 @@ int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);
  * Same F.linear sites as gamer_gemm_f32 (model.py:93-99,145-149,1001, FFN.py:25-27); selected per Engine
  * (`matmul="split6" | "split9"`), never implicitly.  Inf / NaN operands produce NaN. */
 int gamer_gemm_f32_split(const gamer_gemm_desc* d, int terms, void* stream);
+/* terms = 3 (ABI 6): the two-way fp16 form - every operand value times its tensor's power-of-two scale s (largest magnitude
+ * brought into [2^13, 2^14)) is cut into h0 = fp16(x s), h1 = fp16(x s - h0) and a.b = (a0.b0 + a0.b1 + a1.b0) / (s_a s_b) is
+ * accumulated in fp32 by v_mfma_f32_32x32x16_f16: |x s - h0 - h1| <= 2^-22 |x s| for elements within 2^17 of the tensor's
+ * largest (smaller ones: absolute 2^-25 of the scaled unit).  Against fp64 the result is at the six-product form's error
+ * (rms 1.2e-8 of sum |a_k b_k|; fp32 MFMA 4.4e-8) at half its matrix instructions.  Needs d->amax_a / d->amax_b.
+ *
+ * gamer_absmax_f32: *out = max(*out, bits of max |x|) over `batch` matrices [rows, cols] with leading dimension ld
+ * (ld % 4 == 0, 16-byte aligned), `stride` elements apart; *out must hold 0 (or an earlier maximum) on entry.  One pass over
+ * x; a NaN anywhere leaves a NaN pattern (the GEMM then scales by 1 and the NaN propagates). */
+int gamer_absmax_f32(const float* x, int batch, int64_t stride, int rows, int cols, int64_t ld, uint32_t* out, void* stream);
 /* planes[s * plane_stride + i] = piece s (s = 0, 1, 2) of x[i] under the exact three-way cut above (n % 4 == 0,
  * plane_stride % 4 == 0, 16-byte aligned x, 8-byte aligned planes): the `b_planes` operand of gamer_gemm_f32_split.  The
  * engine cuts its fp32 master parameters once per step with it (98 MB read, 147 MB written). */

@@ -30,7 +30,7 @@ def _record(name, value):
         json.dump(REPORT, f, indent=1)
 
 
-MATMULS = ["f32", "split6", "split9"]     # fp32 MFMA / exact bf16-piece products (gamer_gemm_f32_split): same bars
+MATMULS = ["f32", "split3", "split6", "split9"]     # fp32 MFMA / exact bf16-piece products (gamer_gemm_f32_split): same bars
 
 
 def _engine_from_golden(golden, name, matmul="f32"):

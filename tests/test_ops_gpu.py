@@ -181,9 +181,10 @@ def test_rowtable_fwd_bwd():
 
 
 # ----------------------------------------------------------------------------------------------
-@pytest.fixture(params=["f32", "split6", "split9"])
+@pytest.fixture(params=["f32", "split3", "split6", "split9"])
 def gemm_mode(request):
-    """Every fp32 GEMM test runs on the fp32 MFMA and on both bf16-piece forms (gamer_gemm_f32_split) with the SAME bars."""
+    """Every fp32 GEMM test runs on the fp32 MFMA, on both bf16-piece forms and on the two-way fp16 form (gamer_gemm_f32_split)
+    with the SAME bars."""
     prev = ops.set_f32_matmul(request.param)
     yield request.param
     ops.set_f32_matmul(prev)
@@ -443,7 +444,7 @@ def test_gemm_split_error_is_not_larger_than_the_fp32_mfma():
     W = torch.randn(N, K) * 0.05
     ref, sc = x.double() @ W.double().T, x.double().abs() @ W.double().abs().T
     errs = {}
-    for mode in ("f32", "split6", "split9"):
+    for mode in ("f32", "split3", "split6", "split9"):
         ops.set_f32_matmul(mode)
         y = torch.empty(T, N, device=DEV)
         ops.linear_fwd(dev(x), K, dev(W), K, y, N, T, N, K)
@@ -451,9 +452,52 @@ def test_gemm_split_error_is_not_larger_than_the_fp32_mfma():
         errs[mode] = (float(e.max()), float(e.pow(2).mean().sqrt()))
     ops.set_f32_matmul("f32")
     _record("gemm_split_error", errs)
-    for mode in ("split6", "split9"):
+    for mode in ("split3", "split6", "split9"):
         assert errs[mode][0] < 1.5 * errs["f32"][0] + 1e-8 and errs[mode][1] < 1.25 * errs["f32"][1]
         assert errs[mode][0] < 2e-6
+
+
+@pytest.mark.parametrize("mag", [1e-30, 1e-9, 1e-4, 1.0, 1e6, 1e25])
+def test_gemm_split3_error_does_not_depend_on_the_magnitude(mag):
+    """The two-way fp16 form scales every operand tensor by a power of two from its own largest magnitude: gradients of
+    1e-9 and activations of 1e6 come out at the same relative error (forward, dgrad and split-K wgrad layouts), small
+    integers exactly, an all-zero operand gives zeros, and an Inf operand does not turn finite outputs of OTHER rows into
+    garbage silently (it gives NaN / Inf in its row)."""
+    torch.manual_seed(3)
+    M, N, K = 640, 384, 160
+    x = torch.randn(M, K) * torch.exp(torch.randn(M, K)) * mag
+    w = torch.randn(N, K) * 0.05
+    dy = torch.randn(M, N) * (1.0 / max(mag, 1e-30) if mag > 1 else 1.0) * 1e-3
+    with ops.f32_matmul("split3"):
+        y, dx, dW = torch.empty(M, N, device=DEV), torch.empty(M, K, device=DEV), torch.zeros(N, K, device=DEV)
+        ops.linear_fwd(dev(x), K, dev(w), K, y, N, M, N, K)
+        ops.linear_dgrad(dev(dy), N, dev(w), K, dx, K, M, N, K)
+        ops.linear_wgrad(dev(dy), N, dev(x), K, dW, K, M, N, K)
+    xd, wd, dyd = x.double(), w.double(), dy.double()
+    for got, ref, sc in ((y, xd @ wd.T, xd.abs() @ wd.abs().T), (dx, dyd @ wd, dyd.abs() @ wd.abs()),
+                         (dW, dyd.T @ xd, dyd.abs().T @ xd.abs())):
+        e = ((got.cpu().double() - ref).abs() / sc.clamp_min(1e-300))
+        assert float(e.max()) < 1e-6 and float(e.pow(2).mean().sqrt()) < 6e-8, (mag, float(e.max()))
+
+
+def test_gemm_split3_integers_zeros_and_inf():
+    torch.manual_seed(4)
+    M, N, K = 256, 128, 64
+    x = torch.randint(-30, 31, (M, K)).float()
+    w = torch.randint(-30, 31, (N, K)).float()
+    with ops.f32_matmul("split3"):
+        y = torch.empty(M, N, device=DEV)
+        ops.linear_fwd(dev(x), K, dev(w), K, y, N, M, N, K)
+        assert torch.equal(y.cpu().double(), x.double() @ w.double().T)
+        z = torch.full((M, N), 5.0, device=DEV)
+        ops.linear_fwd(dev(torch.zeros(M, K)), K, dev(w), K, z, N, M, N, K)
+        assert torch.equal(z.cpu(), torch.zeros(M, N))
+        xi = x.clone(); xi[7, 3] = float("inf")
+        yi = torch.empty(M, N, device=DEV)
+        ops.linear_fwd(dev(xi), K, dev(w), K, yi, N, M, N, K)
+        assert not torch.isfinite(yi[7].cpu()).all()
+        ok = torch.ones(M, dtype=torch.bool); ok[7] = False
+        assert torch.equal(yi.cpu()[ok].double(), (x.double() @ w.double().T)[ok])
 
 
 # ----------------------------------------------------------------------------------------------

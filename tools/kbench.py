@@ -125,7 +125,13 @@ def bench_gemm(args):
         d = lambda: ops.linear_dgrad(y, ldn, W, K, dx, K, T, N, K, strideB=N * K if grouped else 0, **grp)
         w = lambda: ops.linear_wgrad(y, ldn, x, K, dW, K, T, N, K, strideC=N * K if grouped else 0, **grp)
         fl = 2.0 * T * N * K
-        tf, td, tw = timeit(f, args.iters), timeit(d, args.iters), timeit(w, args.iters)
+        if args.matmul == "split3":          # the GEMM kernels alone (operand maxima measured once), then the maxima
+            with ops.amax_reuse(everything=True):
+                tf, td, tw = timeit(f, args.iters), timeit(d, args.iters), timeit(w, args.iters)
+            ta = timeit(lambda: (ops.absmax_slot(x, 1, 0, T, K, K), ops.absmax_slot(y, 1, 0, T, N, ldn)), args.iters)
+            print(f"     absmax of x [T,{K}] + y [T,{N}] (ld {ldn}): {ta:.3f} ms  {T * (K + N) * 4 / ta / 1e6:.0f} GB/s")
+        else:
+            tf, td, tw = timeit(f, args.iters), timeit(d, args.iters), timeit(w, args.iters)
         print(f"gemm {name:8s} N={N:4d} K={K:3d}: fwd {tf:.3f} ms {fl / tf / 1e9:6.1f} TF | dgrad {td:.3f} ms "
               f"{fl / td / 1e9:6.1f} TF | wgrad {tw:.3f} ms {fl / tw / 1e9:6.1f} TF")
 
