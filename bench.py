@@ -371,8 +371,9 @@ def parse_args(argv=None):
                     help="skip the secondary legs (bf16, split6, per-GPU batch 128) the default single-GPU run adds")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--matmul", choices=["f32", "split3", "split6", "split9"], default=None,
-                    help="how fp32 matrix products are formed (--dtype f32 only; default split6, the engine's default): "
-                         "split6 / split9 = every fp32 product from an exact three-way bf16 cut of both operands, 6 / 9 piece "
+                    help="how fp32 matrix products are formed (--dtype f32 only; default split3, the engine's default): "
+                         "split3 = Linear products from a two-way fp16 cut of both operands scaled per tensor, 3 piece products "
+                         "(attention as split6); split6 / split9 = every fp32 product from an exact three-way bf16 cut of both operands, 6 / 9 piece "
                          "products on the bf16 pipe, fp32 accumulation (gamer_gemm_f32_split, gamer_attn_*_split; error against "
                          "fp64 at the fp32 MFMA's level, DESIGN.md section 13); f32 = v_mfma_f32_32x32x2_f32 throughout")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (and the roofline object)")
@@ -382,7 +383,7 @@ def parse_args(argv=None):
     ap.add_argument("--session-mean", type=float, default=4.0, help="items per session for --variant session")
     args = ap.parse_args(argv)
     if args.matmul is None:
-        args.matmul = "split6" if args.dtype == "f32" else "f32"
+        args.matmul = "split3" if args.dtype == "f32" else "f32"
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     if args.batch is not None:
@@ -446,9 +447,10 @@ def spawn_ranks(args, argv) -> int:
 
 SECONDARY_LEGS = (
     # (name, dtype, matmul, per-GPU batch): what DESIGN.md / README.md quote beside the headline, timed by the SAME driver run
+    ("f32_split6_b1024", "f32", "split6", 1024),   # Linear products as six bf16 piece products (the exact three-way cut)
     ("f32_mfma_b1024", "f32", "f32", 1024),        # the same fp32 step with every product on v_mfma_f32_32x32x2_f32
     ("bf16_b1024", "bf16", "f32", 1024),           # BASELINE configs[2]'s per-GPU shape (bf16 AMP)
-    ("f32_split6_b128", "f32", "split6", 128),     # the headline form at the per-GPU batch of the 8-GPU north-star point
+    ("f32_split3_b128", "f32", "split3", 128),     # the headline form at the per-GPU batch of the 8-GPU north-star point
     ("f32_mfma_b128", "f32", "f32", 128),
     ("bf16_b128", "bf16", "f32", 128),
 )
@@ -467,7 +469,7 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
         cfg.dropout_rate = 0.0
         cfg.attention_dropout = 0.0
     if args.matmul != "f32" and args.dtype != "f32":
-        raise SystemExit("--matmul split6/split9 is a form of the fp32 path (--dtype f32)")
+        raise SystemExit("--matmul split3/split6/split9 is a form of the fp32 path (--dtype f32)")
     eng = Engine(cfg, device=f"cuda:{local_rank}", temperature=0.7, variant=args.variant, dtype=args.dtype,
                  matmul=args.matmul)
     smean = args.session_mean if args.variant == "session" else None
@@ -643,7 +645,10 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
                              f"synthetic ids, per-GPU batch {args.batch} x {args.items * 5} tokens"
                              + (" ragged" if args.ragged else "") + ", V=1041, " +
                              ("fp32" if args.dtype == "f32" else "bf16 AMP (fp32 master weights / gradients / moments)") +
-                             (f" tensors and accumulation; every fp32 matrix product (Linear and attention) formed as {split_terms} "
+                             (" tensors and accumulation; Linear products formed as 3 fp16 piece products of a two-way cut of both "
+                              "operands scaled per tensor by a power of two, attention products as 6 exact bf16 piece products of a "
+                              "three-way cut (error vs fp64 at or below the fp32 MFMA's)" if split_terms == 3 else
+                              f" tensors and accumulation; every fp32 matrix product (Linear and attention) formed as {split_terms} "
                               "exact bf16 piece products of a three-way cut of both operands (error vs fp64 at the fp32 MFMA's "
                               "level)" if split_terms else (" on the fp32 MFMA" if args.dtype == "f32" else ""))),
                 "global_batch": args.batch * world,
@@ -655,8 +660,8 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
             "roofline": {
                 "bound": "mfma",
                 "kernel": (f"gemm_{'f32' if args.dtype == 'f32' else 'bf16'}_kernel ({dom['kernel']})"
-                           + (f" SPLIT={split_terms}: bf16 MFMA pipe, peak = {BF16_MATRIX_PEAK_TFLOPS:g} / {split_terms}"
-                              if split_terms else "")) if dom else None,
+                           + (f" SPLIT={split_terms}: {'fp16' if split_terms == 3 else 'bf16'} MFMA pipe, peak = "
+                              f"{BF16_MATRIX_PEAK_TFLOPS:g} / {split_terms}" if split_terms else "")) if dom else None,
                 "achieved": dom["tflops"] if dom else None,
                 "peak": peak,
                 "unit": "TFLOP/s",
@@ -674,6 +679,10 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
                 "all_gemm_ms_per_step": gemm_ms,
                 "step_algorithmic_tflops": step_flops / (ms_per_step * 1e-3) / 1e12,
                 "step_frac_of_matrix_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / peak,
+                # what the 16-bit matrix pipe SUSTAINS with the whole chip busy depends on the operand data (power): measured
+                # 1.43-1.68 PFLOP/s on random bits against the nominal 2.5 (tools/ubench_memtime.hip); `peak` above is nominal
+                "pipe_sustained_random_operands_TFLOPs": ([1430.0 / split_terms, 1680.0 / split_terms] if split_terms else None),
+                "pipe_sustained_source": "profiles/r03_mfma_sustained.txt" if split_terms else None,
             },
             "kernels": kernels[:12],
             "kernels_measured_in": (f"warm-up steps 2..{args.warmup} (every launch between HIP events)" if warm_kernels
@@ -722,7 +731,7 @@ def main(argv=None):
     # Secondary legs (N = 1, default workload only): the other step forms DESIGN.md quotes - bf16 AMP, fp32 Linear
     # products on the bf16 pipe (split6), and both dtypes at the per-GPU batch of the 8-GPU north-star point (128) -
     # timed by the same run, 2 warm-up + 5 timed steps each, reported under "secondary" on the ONE JSON line.
-    default_workload = (world == 1 and not force_dist and args.path == "engine" and args.dtype == "f32" and args.matmul == "split6"
+    default_workload = (world == 1 and not force_dist and args.path == "engine" and args.dtype == "f32" and args.matmul == "split3"
                         and args.batch == 1024 and args.items == 101 and args.variant == "multi" and not args.ragged
                         and not args.no_dropout)
     if default_workload and not args.no_secondary and result is not None:

@@ -352,15 +352,19 @@ class Engine:
         "split6" / "split9" = gamer_gemm_f32_split: both operands cut exactly into three bf16 pieces, 6 or 9 piece
         products on the 16x wider bf16 pipe, fp32 accumulation (include/gamer_hip.h; error vs fp64 measured equal to
         the fp32 MFMA's, tools/split_error.py).  The attention products take the same form (gamer_attn_fwd_split /
-        gamer_attn_bwd_split, csrc/attention_split.hip; ``self.split_attention = False`` keeps them on the fp32 MFMA)."""
+        gamer_attn_bwd_split, csrc/attention_split.hip; ``self.split_attention = False`` keeps them on the fp32 MFMA).
+        "split3" (the default) = the Linear sites as THREE fp16 piece products of a two-way cut of both operands, each
+        operand tensor scaled by a power of two from its largest magnitude (gamer_absmax_f32) - the
+        same error against fp64 at half the matrix instructions; the attention products as in "split6"."""
         cfg.validate()
         if matmul is None:
-            # default of the fp32 path: products on the bf16 pipe from exact cuts (DESIGN.md section 13); "f32" = fp32 MFMA
-            matmul = "split6" if dtype == "f32" else "f32"
+            # default of the fp32 path: products on the 16-bit matrix pipe from piece cuts (DESIGN.md sections 13, 15, 17);
+            # "f32" = fp32 MFMA
+            matmul = "split3" if dtype == "f32" else "f32"
         if matmul not in ops.MATMUL_MODES:
             raise ValueError(f"unknown matmul {matmul!r} ({sorted(ops.MATMUL_MODES)})")
         if dtype != "f32" and matmul != "f32":
-            raise ValueError("matmul='split6'/'split9' is a form of the fp32 path; dtype='bf16' has its own GEMM")
+            raise ValueError("matmul='split3'/'split6'/'split9' is a form of the fp32 path; dtype='bf16' has its own GEMM")
         self.matmul = matmul
         # q / k RMSNorm + RoPE in the q|k|v projection's epilogue (gamer_gemm_desc.qk_*): built, parity-tested and measured
         # at batch 1024 - the 12 projections got 6.8 ms slower per step (their tiles now also store q_rot / k_rot, and

@@ -111,7 +111,7 @@ class Qwen3MultiWithTemperature(nn.Module):
         (the task keeps writing to it: ``model.config.use_cache = False``, :442); the engine gets a plain copy.
         ``dtype="bf16"``: what the reference gets from ``--bf16`` (HF Trainer autocast) is a property of the engine
         here - bf16 matrix operands and activations, fp32 parameters / gradients (the nn.Parameters stay fp32).
-        ``matmul``: the engine's form of the fp32 matrix products (None = its default "split6"; "f32" = fp32 MFMA)."""
+        ``matmul``: the engine's form of the fp32 matrix products (None = its default "split3"; "split6" = exact bf16 pieces; "f32" = fp32 MFMA)."""
         super().__init__()
         assert hasattr(config, "num_positions") and isinstance(config.num_positions, int), \
             "Config must have 'num_positions' attribute for Qwen3SessionModel."

@@ -59,8 +59,8 @@ def parse_args(argv=None):
                          "fp32 master weights, gradients and optimizer state")
     ap.add_argument("--fp16", action="store_true", help="accepted for flag compatibility and refused: not built")
     ap.add_argument("--matmul", choices=["f32", "split3", "split6", "split9"], default=None,
-                    help="fp32 runs: how matrix products are formed (default: the engine's, split6 = exact bf16 piece products "
-                         "with fp32 accumulation; f32 = the fp32 MFMA)")
+                    help="fp32 runs: how matrix products are formed (default: the engine's, split3 = Linear sites as three fp16 piece "
+                         "products scaled per tensor; split6 = exact bf16 piece products with fp32 accumulation; f32 = the fp32 MFMA)")
     ap.add_argument("--prefetch", type=int, default=2, help="optimizer steps collated ahead on a background thread")
     ap.add_argument("--output_dir", type=str, default="")
     ap.add_argument("--resume_from_checkpoint", type=str, default="")

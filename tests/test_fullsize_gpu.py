@@ -36,7 +36,7 @@ def _relmax(got, ref):
     return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
 
 
-@pytest.mark.parametrize("dtype,matmul", [("f32", "f32"), ("f32", "split6"), ("bf16", "f32")])
+@pytest.mark.parametrize("dtype,matmul", [("f32", "f32"), ("f32", "split3"), ("f32", "split6"), ("bf16", "f32")])
 def test_full_batch_properties_and_oracle_rows(dtype, matmul):
     cfg = synthetic_config()
     ocfg = orc.OracleConfig.from_dict(cfg.to_dict())
