@@ -102,7 +102,7 @@ class KernelTimer:
         timer = self
 
         def timed_call(name, *args):
-            if not timer.enabled:
+            if not timer.enabled or name == "gamer_amax_sink":       # (not a launch)
                 return orig_call(name, *args)
             if name == "gamer_absmax_f32":              # split3: the operand maxima in front of a GEMM keep their own row
                 label, flops, nbytes = "absmax", 0.0, 0.0
@@ -376,6 +376,7 @@ def parse_args(argv=None):
                          "(attention as split6); split6 / split9 = every fp32 product from an exact three-way bf16 cut of both operands, 6 / 9 piece "
                          "products on the bf16 pipe, fp32 accumulation (gamer_gemm_f32_split, gamer_attn_*_split; error against "
                          "fp64 at the fp32 MFMA's level, DESIGN.md section 13); f32 = v_mfma_f32_32x32x2_f32 throughout")
+    ap.add_argument("--kernel-rows", type=int, default=12, help="rows of the per-family kernel table in the JSON line")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (and the roofline object)")
     ap.add_argument("--ragged", action="store_true", help="secondary workload: n_items ~ U{2..items}, right padded")
     ap.add_argument("--variant", choices=["multi", "session"], default="multi",
@@ -684,7 +685,7 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
                 "pipe_sustained_random_operands_TFLOPs": ([1430.0 / split_terms, 1680.0 / split_terms] if split_terms else None),
                 "pipe_sustained_source": "profiles/r03_mfma_sustained.txt" if split_terms else None,
             },
-            "kernels": kernels[:12],
+            "kernels": kernels[:args.kernel_rows],
             "kernels_measured_in": (f"warm-up steps 2..{args.warmup} (every launch between HIP events)" if warm_kernels
                                     else "timed region"),
             "loss": final_loss,

@@ -82,6 +82,35 @@ template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = 
 template <typename T> __device__ __forceinline__ float round_as(float v) { return (float)(T)v; }
 template <typename T> static inline bool aligned_vec4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(T) - 1)) == 0; }
 
+// ---- maxima of what a kernel stores (matmul = "split3": the consumer GEMM scales its operand by a power of two from it) ----
+// gamer_amax_sink(out0, out1) arms the NEXT launch (on the calling host thread) of a kernel that supports it: that kernel folds
+// the bits of max |value stored| of its first / second output into *out0 / *out1 (atomicMax; the words hold 0 or an earlier
+// maximum).  The pointers travel as kernel arguments - stream-ordered like everything else - and are disarmed by the launch.
+struct AmaxSink { uint32_t* out[2]; };
+AmaxSink take_amax_sink();
+// (float maxima: |x| is a free source modifier and max3 takes two values per instruction; a NaN is ignored here - it reaches the
+// GEMM as a NaN piece whatever the scale is)
+__device__ __forceinline__ uint32_t amax_f4(uint32_t m, const float4 v) {
+    float f = __uint_as_float(m);
+    f = fmaxf(fmaxf(f, fabsf(v.x)), fabsf(v.y));
+    f = fmaxf(fmaxf(f, fabsf(v.z)), fabsf(v.w));
+    return __float_as_uint(f);
+}
+// every thread of a 256-thread workgroup calls this once, at the end of the kernel (out is workgroup-uniform); one atomic per
+// workgroup, and none when the word already holds a larger value (read at agent scope: the atomics execute at the memory side,
+// an XCD's L2 may hold an older copy)
+__device__ __forceinline__ void amax_block_commit(uint32_t m, uint32_t* __restrict__ out, uint32_t* __restrict__ lds4) {
+    if (!out) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(lds4[0], lds4[1]), max(lds4[2], lds4[3]));
+        if (m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

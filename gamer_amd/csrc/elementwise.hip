@@ -103,7 +103,9 @@ constexpr int RMS_MAXC_BIG = 4;
 template <typename TY, int RMS_MAXC>
 __global__ void __launch_bounds__(EW_THREADS)
 rmsnorm_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, int T, int H4, float inv_h,
-                   float eps, const int32_t* __restrict__ dst_rows, TY* __restrict__ y, int ldy) {
+                   float eps, const int32_t* __restrict__ dst_rows, TY* __restrict__ y, int ldy, uint32_t* __restrict__ amax_out) {
+    __shared__ uint32_t amax_lds[4];
+    uint32_t am = 0;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * EW_THREADS) >> 6;
@@ -136,9 +138,11 @@ rmsnorm_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, i
                 o.z = wv[i].z * (v[i].z * rstd);
                 o.w = wv[i].w * (v[i].w * rstd);
                 st4(yrow + 4 * c, o);
+                am = amax_f4(am, o);
             }
         }
     }
+    amax_block_commit(am, amax_out, amax_lds);
 }
 
 // dx (+)= rstd*(w*dy - xhat*mean(w*dy*xhat)); per-workgroup dw partial sums (deterministic).
@@ -147,11 +151,15 @@ __global__ void __launch_bounds__(EW_THREADS)
 rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, const TG* __restrict__ dy,
                    int lddy, const int32_t* __restrict__ dy_rows, int T, int H4, float inv_h, float eps,
                    int accumulate_dx, float4* __restrict__ dx, float* __restrict__ dw_partial,
-                   TG* __restrict__ mask_out, const int32_t* __restrict__ mask_rows, float p_drop, uint64_t seed) {
+                   TG* __restrict__ mask_out, const int32_t* __restrict__ mask_rows, float p_drop, uint64_t seed,
+                   uint32_t* __restrict__ amax_out) {
     // mask_out != nullptr: the next consumer of dx is a residual branch with dropout; its input gradient
     // mask(seed) * dx is written here (what gamer_residual_dropout_bwd would compute in a second pass over dx)
+    // amax_out: max |mask_out| (the GEMM operand of that branch)
     const DropoutRng rng(mask_out ? p_drop : 0.f, seed);
     __shared__ float4 red[EW_WAVES][64 * RMS_MAXC];
+    __shared__ uint32_t amax_lds[4];
+    uint32_t am = 0;
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
@@ -206,7 +214,9 @@ rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, c
                     float m[4];
                     rng.mult4((uint32_t)((int64_t)t * H4 + c), m);
                     const int64_t mr = mask_rows ? mask_rows[t] : t;
-                    st4(mask_out + (mr * H4 + c) * 4, make_float4(m[0] * o.x, m[1] * o.y, m[2] * o.z, m[3] * o.w));
+                    const float4 mo = make_float4(m[0] * o.x, m[1] * o.y, m[2] * o.z, m[3] * o.w);
+                    st4(mask_out + (mr * H4 + c) * 4, mo);
+                    am = amax_f4(am, mo);
                 }
             }
         }
@@ -228,6 +238,7 @@ rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, c
             }
         }
     }
+    amax_block_commit(am, mask_out ? amax_out : nullptr, amax_lds);
 }
 
 // out[c] (+)= sum_r partial[r][c]; one workgroup per 32 columns, 32 row groups per workgroup, four independent
@@ -267,14 +278,20 @@ colsum_reduce_kernel(const float* __restrict__ partial, int rows, int cols, int 
 template <typename TY>
 __global__ void __launch_bounds__(EW_THREADS)
 rowtable_fwd_kernel(const float4* __restrict__ table, const int32_t* __restrict__ idx,
-                    const int32_t* __restrict__ dst_rows, int T, int E4, TY* __restrict__ y, int ldy, int col0) {
+                    const int32_t* __restrict__ dst_rows, int T, int E4, TY* __restrict__ y, int ldy, int col0,
+                    uint32_t* __restrict__ amax_out) {
+    __shared__ uint32_t amax_lds[4];
+    uint32_t am = 0;
     const int64_t total = (int64_t)T * E4;
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
         const int t = (int)(i / E4);
         const int c = (int)(i % E4);
         const int64_t r = dst_rows ? dst_rows[t] : t;
-        st4(y + r * ldy + col0 + 4 * c, table[(int64_t)idx[t] * E4 + c]);
+        const float4 v = table[(int64_t)idx[t] * E4 + c];
+        st4(y + r * ldy + col0 + 4 * c, v);
+        am = amax_f4(am, v);
     }
+    amax_block_commit(am, amax_out, amax_lds);
 }
 
 constexpr int TBL_MAXROWS = 8;   // num_behavior + 1 <= 8
@@ -828,7 +845,9 @@ residual_dropout_bwd_kernel(const float4* __restrict__ dx, const int32_t* __rest
 template <typename TA>
 __global__ void __launch_bounds__(EW_THREADS)
 swiglu_fwd_kernel(const TA* __restrict__ g, const TA* __restrict__ u, int64_t n4, float p, uint64_t seed,
-                  TA* __restrict__ hm) {
+                  TA* __restrict__ hm, uint32_t* __restrict__ amax_out) {
+    __shared__ uint32_t amax_lds[4];
+    uint32_t am = 0;
     const DropoutRng rng(p, seed);
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
         const float4 a = ld4(g + 4 * i), b = ld4(u + 4 * i);
@@ -840,13 +859,17 @@ swiglu_fwd_kernel(const TA* __restrict__ g, const TA* __restrict__ u, int64_t n4
         o.z = m[2] * (silu_f(a.z) * b.z);
         o.w = m[3] * (silu_f(a.w) * b.w);
         st4(hm + 4 * i, o);
+        am = amax_f4(am, o);
     }
+    amax_block_commit(am, amax_out, amax_lds);
 }
 
 template <typename TA>
 __global__ void __launch_bounds__(EW_THREADS)
 swiglu_bwd_kernel(TA* __restrict__ g, TA* __restrict__ u, const TA* __restrict__ dhm, int64_t n4,
-                  float p, uint64_t seed) {
+                  float p, uint64_t seed, uint32_t* __restrict__ amax_g, uint32_t* __restrict__ amax_u) {
+    __shared__ uint32_t amax_lds[2][4];
+    uint32_t amg = 0, amu = 0;
     const DropoutRng rng(p, seed);
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
         const float4 a = ld4(g + 4 * i), b = ld4(u + 4 * i), d = ld4(dhm + 4 * i);
@@ -860,7 +883,11 @@ swiglu_bwd_kernel(TA* __restrict__ g, TA* __restrict__ u, const TA* __restrict__
         dg.w = d3 * b.w * dsilu_f(a.w); du.w = d3 * silu_f(a.w);
         st4(g + 4 * i, dg);
         st4(u + 4 * i, du);
+        amg = amax_f4(amg, dg);
+        amu = amax_f4(amu, du);
     }
+    amax_block_commit(amg, amax_g, amax_lds[0]);
+    amax_block_commit(amu, amax_u, amax_lds[1]);
 }
 
 // TO = type of `out`: the residual stream (fp32) when resid is given, otherwise the activation type
@@ -888,8 +915,11 @@ silu_gate_fwd_kernel(const TA* __restrict__ a, const TA* __restrict__ gate, int6
 template <typename TA>
 __global__ void __launch_bounds__(EW_THREADS)
 silu_gate_bwd_kernel(const TA* __restrict__ a, const TA* __restrict__ gate, const float4* __restrict__ dout,
-                     int64_t n4, TA* __restrict__ da, TA* __restrict__ dgate, float p, uint64_t seed) {
+                     int64_t n4, TA* __restrict__ da, TA* __restrict__ dgate, float p, uint64_t seed,
+                     uint32_t* __restrict__ amax_a, uint32_t* __restrict__ amax_gate) {
     // p > 0: dout is the gradient of the residual stream; the dropout mask of the fused forward is applied first
+    __shared__ uint32_t amax_lds[2][4];
+    uint32_t ama = 0, amg = 0;
     const DropoutRng rng(p, seed);
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
         const float4 x = ld4(a + 4 * i), g = ld4(gate + 4 * i);
@@ -904,7 +934,11 @@ silu_gate_bwd_kernel(const TA* __restrict__ a, const TA* __restrict__ gate, cons
         oa.w = d.w * silu_f(g.w); og.w = d.w * x.w * dsilu_f(g.w);
         st4(da + 4 * i, oa);
         st4(dgate + 4 * i, og);
+        ama = amax_f4(ama, oa);
+        amg = amax_f4(amg, og);
     }
+    amax_block_commit(ama, amax_a, amax_lds[0]);
+    amax_block_commit(amg, amax_gate, amax_lds[1]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1026,7 +1060,9 @@ template <typename TL>
 __global__ void __launch_bounds__(EW_THREADS)
 ce_bwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labels, int T, int S, int V,
               int ignore_index, const float* __restrict__ lse, const float* __restrict__ count_dev,
-              float denom_host, float dloss_over_temp, const float* __restrict__ dloss_dev) {
+              float denom_host, float dloss_over_temp, const float* __restrict__ dloss_dev, uint32_t* __restrict__ amax_out) {
+    __shared__ uint32_t amax_lds[4];
+    uint32_t am = 0;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * EW_THREADS) >> 6;
@@ -1046,8 +1082,10 @@ ce_bwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labe
                 g *= gs;
             }
             st1(row + c, g);
+            am = __float_as_uint(fmaxf(__uint_as_float(am), fabsf(g)));
         }
     }
+    amax_block_commit(am, amax_out, amax_lds);
 }
 
 __global__ void __launch_bounds__(EW_THREADS)
@@ -1058,9 +1096,24 @@ fill_kernel(float* __restrict__ p, int64_t n, float value) {
 
 }  // namespace gamer
 
+namespace gamer {
+static thread_local AmaxSink g_amax_sink = {{nullptr, nullptr}};
+AmaxSink take_amax_sink() {
+    const AmaxSink s = g_amax_sink;
+    g_amax_sink.out[0] = g_amax_sink.out[1] = nullptr;
+    return s;
+}
+}  // namespace gamer
+
 using namespace gamer;
 
 #define ST(s) ((hipStream_t)(s))
+
+extern "C" int gamer_amax_sink(uint32_t* out0, uint32_t* out1) {
+    g_amax_sink.out[0] = out0;
+    g_amax_sink.out[1] = out1;
+    return 0;
+}
 
 extern "C" int gamer_embedding_fwd(const int64_t* ids, const float* W, int V, int T, int H, float* x, void* stream) {
     GAMER_CHECK_ARG(ids && W && x, "gamer_embedding_fwd: null pointer");
@@ -1094,12 +1147,13 @@ static int rmsnorm_fwd_impl(const char* name, const float* x, const float* w, in
     GAMER_CHECK_ARG(T > 0 && H > 0 && H % 4 == 0 && H <= 256 * RMS_MAXC_BIG && ldy >= H && ldy % 4 == 0,
                     "%s: bad shape T=%d H=%d ldy=%d (H%%4==0, H<=1024, ldy%%4==0)", name, T, H, ldy);
     GAMER_CHECK_ARG(aligned16(x) && aligned16(w) && aligned_vec4<TY>(y), "%s: pointers must be 16-byte aligned", name);
+    const AmaxSink sink = take_amax_sink();
     if (H <= 256)
         hipLaunchKernelGGL((rmsnorm_fwd_kernel<TY, 1>), dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream),
-                           (const float4*)x, (const float4*)w, T, H / 4, 1.f / (float)H, eps, dst_rows, y, ldy);
+                           (const float4*)x, (const float4*)w, T, H / 4, 1.f / (float)H, eps, dst_rows, y, ldy, sink.out[0]);
     else
         hipLaunchKernelGGL((rmsnorm_fwd_kernel<TY, RMS_MAXC_BIG>), dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream),
-                           (const float4*)x, (const float4*)w, T, H / 4, 1.f / (float)H, eps, dst_rows, y, ldy);
+                           (const float4*)x, (const float4*)w, T, H / 4, 1.f / (float)H, eps, dst_rows, y, ldy, sink.out[0]);
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }
@@ -1122,14 +1176,15 @@ static int rmsnorm_bwd_impl(const char* name, const float* x, const float* w, co
                     "%s: bad shape T=%d H=%d lddy=%d n_partial=%d", name, T, H, lddy, n_partial);
     GAMER_CHECK_ARG(aligned16(x) && aligned16(w) && aligned_vec4<TG>(dy) && aligned16(dx) && aligned16(dw_partial) &&
                     aligned_vec4<TG>(mask_out), "%s: pointers must be 16-byte aligned", name);
+    const AmaxSink sink = take_amax_sink();
     if (H <= 256)
         hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, 1>), dim3(n_partial), dim3(EW_THREADS), 0, ST(stream),
                            (const float4*)x, (const float4*)w, dy, lddy, dy_rows, T, H / 4, 1.f / (float)H, eps,
-                           accumulate_dx, (float4*)dx, dw_partial, mask_out, mask_rows, p_drop, seed);
+                           accumulate_dx, (float4*)dx, dw_partial, mask_out, mask_rows, p_drop, seed, sink.out[0]);
     else
         hipLaunchKernelGGL((rmsnorm_bwd_kernel<TG, RMS_MAXC_BIG>), dim3(n_partial), dim3(EW_THREADS), 0, ST(stream),
                            (const float4*)x, (const float4*)w, dy, lddy, dy_rows, T, H / 4, 1.f / (float)H, eps,
-                           accumulate_dx, (float4*)dx, dw_partial, mask_out, mask_rows, p_drop, seed);
+                           accumulate_dx, (float4*)dx, dw_partial, mask_out, mask_rows, p_drop, seed, sink.out[0]);
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }
@@ -1164,7 +1219,7 @@ static int rowtable_fwd_impl(const char* name, const float* table, const int32_t
     GAMER_CHECK_ARG(T > 0 && E > 0 && E % 4 == 0 && ldy % 4 == 0 && col0 % 4 == 0 && col0 + E <= ldy,
                     "%s: bad shape T=%d E=%d ldy=%d col0=%d", name, T, E, ldy, col0);
     hipLaunchKernelGGL(rowtable_fwd_kernel<TY>, dim3(grid_for_threads((int64_t)T * E / 4)), dim3(EW_THREADS), 0,
-                       ST(stream), (const float4*)table, idx, dst_rows, T, E / 4, y, ldy, col0);
+                       ST(stream), (const float4*)table, idx, dst_rows, T, E / 4, y, ldy, col0, take_amax_sink().out[0]);
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }
@@ -1336,7 +1391,7 @@ static int swiglu_fwd_impl(const char* name, const TA* g, const TA* u, int64_t n
                            void* stream) {
     GAMER_CHECK_ARG(g && u && hm && n > 0 && n % 4 == 0 && p_drop >= 0.f && p_drop < 1.f, "%s: bad arguments", name);
     hipLaunchKernelGGL(swiglu_fwd_kernel<TA>, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream), g, u, n / 4,
-                       p_drop, seed, hm);
+                       p_drop, seed, hm, take_amax_sink().out[0]);
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }
@@ -1354,8 +1409,9 @@ template <typename TA>
 static int swiglu_bwd_impl(const char* name, TA* g, TA* u, const TA* dhm, int64_t n, float p_drop, uint64_t seed,
                            void* stream) {
     GAMER_CHECK_ARG(g && u && dhm && n > 0 && n % 4 == 0 && p_drop >= 0.f && p_drop < 1.f, "%s: bad arguments", name);
+    const AmaxSink sink = take_amax_sink();
     hipLaunchKernelGGL(swiglu_bwd_kernel<TA>, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream), g, u, dhm,
-                       n / 4, p_drop, seed);
+                       n / 4, p_drop, seed, sink.out[0], sink.out[1]);
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }
@@ -1392,8 +1448,9 @@ static int silu_gate_bwd_impl(const char* name, const TA* a, const TA* gate, con
                               TA* dgate, float p_drop, uint64_t seed, void* stream) {
     GAMER_CHECK_ARG(a && gate && dout && da && dgate && n > 0 && n % 4 == 0 && p_drop >= 0.f && p_drop < 1.f,
                     "%s: bad arguments", name);
+    const AmaxSink sink = take_amax_sink();
     hipLaunchKernelGGL(silu_gate_bwd_kernel<TA>, dim3(grid_for_threads(n / 4)), dim3(EW_THREADS), 0, ST(stream), a, gate,
-                       (const float4*)dout, n / 4, da, dgate, p_drop, seed);
+                       (const float4*)dout, n / 4, da, dgate, p_drop, seed, sink.out[0], sink.out[1]);
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }
@@ -1444,7 +1501,7 @@ static int ce_bwd_impl(const char* name, TL* logits, int ldl, const int64_t* lab
     GAMER_CHECK_ARG(count_dev || denom_host > 0.f, "%s: need count_dev or a positive denom_host", name);
     const int T = B * S;
     hipLaunchKernelGGL(ce_bwd_kernel<TL>, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), logits, ldl, labels, T,
-                       S, V, ignore_index, lse, count_dev, denom_host, dloss / temperature, dloss_dev);
+                       S, V, ignore_index, lse, count_dev, denom_host, dloss / temperature, dloss_dev, take_amax_sink().out[0]);
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }

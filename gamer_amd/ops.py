@@ -95,8 +95,9 @@ def embedding_bwd(ids, dx, pad_id, dW):
 
 def rmsnorm_fwd(x, w, eps, y, ldy=None, dst_rows=None):
     T, H = x.shape
-    call("gamer_rmsnorm_fwd" + _sfx(y), ptr(x), ptr(w), T, H, eps, ptr(dst_rows), ptr(y), ldy if ldy else y.stride(0),
-         stream_ptr())
+    ld = ldy if ldy else y.stride(0)
+    _arm_sink((y, (1, 0, T, ld, ld), False))       # (the consumer GEMM reads rows of ld columns: rowtable_fwd adds the rest)
+    call("gamer_rmsnorm_fwd" + _sfx(y), ptr(x), ptr(w), T, H, eps, ptr(dst_rows), ptr(y), ld, stream_ptr())
 
 
 def rmsnorm_bwd(x, w, dy, lddy, eps, dx, dw_partial, accumulate_dx=True, dy_rows=None, mask_out=None, mask_rows=None,
@@ -104,6 +105,8 @@ def rmsnorm_bwd(x, w, dy, lddy, eps, dx, dw_partial, accumulate_dx=True, dy_rows
     """mask_out: also write dropout_mask(seed) * dx (the input gradient of the next residual branch), rows scattered
     through mask_rows when given - the second pass gamer_residual_dropout_bwd would make over dx."""
     T, H = x.shape
+    if mask_out is not None:
+        _arm_sink((mask_out, (1, 0, T, H, H), False))
     call("gamer_rmsnorm_bwd" + _sfx(dy), ptr(x), ptr(w), ptr(dy), lddy, ptr(dy_rows), T, H, eps, 1 if accumulate_dx else 0,
          ptr(dx), ptr(dw_partial), dw_partial.shape[0], ptr(mask_out), ptr(mask_rows), p, seed, stream_ptr())
 
@@ -116,6 +119,7 @@ def colsum_reduce(partial, out, accumulate=False):
 def rowtable_fwd(table, idx, y, ldy, col0, dst_rows=None):
     T = idx.numel()
     E = table.shape[1]
+    _arm_sink((y, (1, 0, T, ldy, ldy), True))
     call("gamer_rowtable_fwd" + _sfx(y), ptr(table), ptr(idx), ptr(dst_rows), T, E, ptr(y), ldy, col0, stream_ptr())
 
 
@@ -185,7 +189,7 @@ _AMAX_REUSE = None
 
 class amax_reuse:
     def __init__(self, everything=False):
-        self.slots, self.pools, self.used = {}, [], 0
+        self.slots, self.pending, self.pools, self.used = {}, {}, [], 0
         self.stable_ptrs, self.stable_ranges, self.held = set(), [], {}
         self.everything = everything          # tools: every tensor counts as unchanging (kernel timing)
 
@@ -208,6 +212,7 @@ class amax_reuse:
     def reset(self):
         """Start of a forward pass: every cached maximum is dropped, the slot words are zeroed (one memset per pool)."""
         self.slots.clear()
+        self.pending.clear()
         self.held.clear()
         for pool in self.pools:
             pool.zero_()
@@ -237,21 +242,55 @@ class amax_reuse:
             return True
         return any(b <= p < b + n for b, n in self.stable_ranges)
 
-    def slot(self, x, geom):
-        p = x.data_ptr()
-        key = (p,) + geom
-        keep = self._cached(p)
-        if keep and key in self.slots:
-            return self.slots[key]
+    @staticmethod
+    def _key(p, geom):
+        batch, stride, rows, cols, ld = geom
+        if ld == cols and (batch == 1 or stride == rows * ld):
+            return (p, "dense", batch * rows * cols)
+        return (p,) + tuple(geom)
+
+    def _new_slot(self, device):
         i, j = divmod(self.used, 1024)
         if i == len(self.pools):
-            self.pools.append(torch.zeros(1024, dtype=torch.int32, device=x.device))
-        ptr_ = self.pools[i].data_ptr() + 4 * j
+            self.pools.append(torch.zeros(1024, dtype=torch.int32, device=device))
         self.used += 1
+        return self.pools[i].data_ptr() + 4 * j
+
+    def preset(self, x, geom, accumulate=False):
+        """A slot the PRODUCER of x is about to fill (gamer_amax_sink): the next GEMM that reads x with this extent takes
+        it instead of measuring x.  accumulate: a second producer writing other columns of the same tensor."""
+        key = self._key(x.data_ptr(), geom)
+        if accumulate and key in self.pending:
+            return self.pending[key]
+        self.slots.pop(key, None)
+        ptr_ = self.pending[key] = self._new_slot(x.device)
+        return ptr_
+
+    def slot(self, x, geom):
+        p = x.data_ptr()
+        key = self._key(p, geom)
+        keep = self._cached(p)
+        if key in self.pending:                     # written by its producer together with the tensor
+            ptr_ = self.pending.pop(key)
+            if keep:
+                self.slots[key] = ptr_
+            return ptr_
+        if keep and key in self.slots:
+            return self.slots[key]
+        ptr_ = self._new_slot(x.device)
         call("gamer_absmax_f32", ptr(x), *geom, ptr_, stream_ptr())
         if keep:
             self.slots[key] = ptr_
         return ptr_
+
+
+def _arm_sink(*outs):
+    """outs: (tensor, (batch, stride, rows, cols, ld), accumulate) for the first / second output of the kernel launched next.
+    With a maxima cache in effect and the split3 form selected, its slots are handed to that kernel (gamer_amax_sink)."""
+    if _AMAX_REUSE is None or F32_MATMUL_TERMS != 3 or outs[0][0].dtype != torch.float32:
+        return
+    slots = [_AMAX_REUSE.preset(t, g, acc) for t, g, acc in outs]
+    call("gamer_amax_sink", slots[0], slots[1] if len(slots) > 1 else None)
 
 
 def scoped_amax(get_cache):
@@ -655,10 +694,12 @@ def residual_dropout_bwd(dx, p, seed, ddelta, src_rows=None):
 
 
 def swiglu_fwd(g, u, n, p, seed, hm):
+    _arm_sink((hm, (1, 0, 1, n, n), False))
     call("gamer_swiglu_fwd" + _sfx(g), ptr(g), ptr(u), n, p, seed, ptr(hm), stream_ptr())
 
 
 def swiglu_bwd(g, u, dhm, n, p, seed):
+    _arm_sink((g, (1, 0, 1, n, n), False), (u, (1, 0, 1, n, n), False))
     call("gamer_swiglu_bwd" + _sfx(g), ptr(g), ptr(u), ptr(dhm), n, p, seed, stream_ptr())
 
 
@@ -669,6 +710,7 @@ def silu_gate_fwd(a, gate, out, resid=None, p=0.0, seed=0):
 
 def silu_gate_bwd(a, gate, dout, da, dgate, p=0.0, seed=0):
     """p > 0: dout is the residual-stream gradient and the forward's dropout mask (seed) is applied to it first."""
+    _arm_sink((da, (1, 0, 1, a.numel(), a.numel()), False), (dgate, (1, 0, 1, a.numel(), a.numel()), False))
     call("gamer_silu_gate_bwd" + _sfx(a), ptr(a), ptr(gate), ptr(dout), a.numel(), ptr(da), ptr(dgate), p, seed, stream_ptr())
 
 
@@ -685,6 +727,7 @@ def ce_fwd(logits, ldl, labels, V, temperature, ignore_index, lse, row_loss, los
 def ce_bwd(logits, ldl, labels, V, temperature, ignore_index, lse, count_dev, denom_host, dloss, dloss_dev=None):
     """dloss_dev: optional fp32 device scalar multiplied into dloss (autograd's incoming gradient, no host read)."""
     B, S = labels.shape
+    _arm_sink((logits, (1, 0, B * S, V, ldl), False))
     call("gamer_ce_bwd" + _sfx(logits), ptr(logits), ldl, ptr(labels), B, S, V, temperature, ignore_index, ptr(lse), ptr(count_dev),
          float(denom_host), float(dloss), ptr(dloss_dev), stream_ptr())
 

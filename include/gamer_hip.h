@@ -238,6 +238,13 @@ int gamer_gemm_f32_split(const gamer_gemm_desc* d, int terms, void* stream);
  * (ld % 4 == 0, 16-byte aligned), `stride` elements apart; *out must hold 0 (or an earlier maximum) on entry.  One pass over
  * x; a NaN anywhere leaves a NaN pattern (the GEMM then scales by 1 and the NaN propagates). */
 int gamer_absmax_f32(const float* x, int batch, int64_t stride, int rows, int cols, int64_t ld, uint32_t* out, void* stream);
+/* The same maximum as a by-product of the kernel that WRITES the tensor: gamer_amax_sink(out0, out1) arms the next launch - on
+ * the calling host thread - of one of gamer_rmsnorm_fwd (y), gamer_rowtable_fwd (the columns it writes), gamer_swiglu_fwd (hm),
+ * gamer_swiglu_bwd (out0: d gate, out1: d up), gamer_silu_gate_bwd (out0: da, out1: dgate), gamer_rmsnorm_bwd (mask_out),
+ * gamer_ce_bwd (d logits) [fp32 and bf16 entry points]: the kernel folds the bits of max |value it stores| into *out0 / *out1
+ * (atomicMax; words hold 0 or an earlier maximum; NULL = none) and the launch disarms the sink.  Any other launch in between
+ * leaves it armed.  Saves the separate pass of gamer_absmax_f32 over the tensor. */
+int gamer_amax_sink(uint32_t* out0, uint32_t* out1);
 /* planes[s * plane_stride + i] = piece s (s = 0, 1, 2) of x[i] under the exact three-way cut above (n % 4 == 0,
  * plane_stride % 4 == 0, 16-byte aligned x, 8-byte aligned planes): the `b_planes` operand of gamer_gemm_f32_split.  The
  * engine cuts its fp32 master parameters once per step with it (98 MB read, 147 MB written). */
