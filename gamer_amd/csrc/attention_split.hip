@@ -162,7 +162,7 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
               const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
               int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
               float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int pair, const int qtile,
-              const int uspan) {
+              const int uspan, uint32_t* __restrict__ amax_lds) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
     __shared__ __attribute__((aligned(16))) bf16_t Ks[2][3 * SIMG];      // slot x (three bf16 piece images of 32 keys x 64)
@@ -409,6 +409,7 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
         float linv = my_empty ? invS : (l_run > 0.f ? 1.f / l_run : 0.f);
         if (DROP) linv *= rng.scale;
         float* orow = o + tok * (int64_t)nq * 64 + head * 64;
+        float omax = 0.f;
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh) {
 #pragma unroll
@@ -417,8 +418,10 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
                 t4.x = oacc[dh][4 * g4 + 0] * linv; t4.y = oacc[dh][4 * g4 + 1] * linv;
                 t4.z = oacc[dh][4 * g4 + 2] * linv; t4.w = oacc[dh][4 * g4 + 3] * linv;
                 *reinterpret_cast<float4*>(orow + 32 * dh + 8 * g4 + 4 * h) = t4;
+                omax = fmaxf(fmaxf(fmaxf(omax, fabsf(t4.x)), fabsf(t4.y)), fmaxf(fabsf(t4.z), fabsf(t4.w)));
             }
         }
+        if (amax_lds) atomicMax(amax_lds, __float_as_uint(omax));      // (gamer_amax_sink: max |o| for the o_proj GEMM's scale)
         // natural-log LSE of the scaled scores (what the backward kernels consume)
         if (h == 0) lse[((int64_t)b * nq + head) * S + iqc] =
             my_empty ? 0.f : (m_ref + __log2f(l_run)) * 0.6931471805599453f;
@@ -431,11 +434,17 @@ attn_fwd_s_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
                 const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
                 const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
                 int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
-                float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int uspan) {
+                float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int uspan,
+                uint32_t* __restrict__ amax_out) {
     constexpr int R = (4 / G) * 32;
     const int n_tiles = (S + R - 1) / R;
     const WorkList wl(nbatch * nkv, n_tiles);
     if (!wl.valid) return;
+    __shared__ uint32_t amax_word;
+    if (amax_out) {
+        if (threadIdx.x == 0) amax_word = 0;
+        __syncthreads();
+    }
     for (int it = 0;; ++it) {
         const int pair = wl.pair_at(it);
         if (pair >= wl.n_pairs) break;
@@ -450,8 +459,13 @@ attn_fwd_s_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
         for (int pass = 0; pass < 2; ++pass) {                    // one inlined body (register pressure)
             if (pass == 1 && light == heavy) break;
             attn_fwd_s_tile<G, DROP, ORD, SPAN>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed, o, lse,
-                                        ro, pair, pass == 0 ? heavy : light, uspan);
+                                        ro, pair, pass == 0 ? heavy : light, uspan, amax_out ? &amax_word : nullptr);
         }
+    }
+    if (amax_out) {
+        __syncthreads();
+        if (threadIdx.x == 0 && amax_word > __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(amax_out, amax_word);
     }
 }
 
@@ -761,7 +775,7 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                     const int32_t* __restrict__ row_empty, const int32_t* __restrict__ tile_empty,
                     int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                     float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const RowOrder ro, const int pair,
-                    const int ktile, float* __restrict__ ds_out) {
+                    const int ktile, float* __restrict__ ds_out, uint32_t* __restrict__ amax_lds) {
     constexpr int THREADS = 256 * G;
     constexpr int R = DKV_S_KEYS;
     constexpr int NLD = 512 / THREADS;               // float4 per thread, tensor and head of a staged 32 x 64 tile
@@ -1099,6 +1113,7 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
         float* dkrow = dk + ktok * lddk + kvh * 64;
         float* dvrow = dv + ktok * lddv + kvh * 64;
         const float vs = DROP ? sd : 1.f;
+        float vmax = 0.f;
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
@@ -1106,9 +1121,12 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                 const int d = 32 * dh + 8 * g4 + 4 * h;
                 *reinterpret_cast<float4*>(dkrow + d) = make_float4(dkacc[dh][4 * g4] * scale, dkacc[dh][4 * g4 + 1] * scale,
                                                                     dkacc[dh][4 * g4 + 2] * scale, dkacc[dh][4 * g4 + 3] * scale);
-                *reinterpret_cast<float4*>(dvrow + d) = make_float4(dvacc[dh][4 * g4] * vs, dvacc[dh][4 * g4 + 1] * vs,
-                                                                    dvacc[dh][4 * g4 + 2] * vs, dvacc[dh][4 * g4 + 3] * vs);
+                const float4 dv4 = make_float4(dvacc[dh][4 * g4] * vs, dvacc[dh][4 * g4 + 1] * vs,
+                                               dvacc[dh][4 * g4 + 2] * vs, dvacc[dh][4 * g4 + 3] * vs);
+                *reinterpret_cast<float4*>(dvrow + d) = dv4;
+                vmax = fmaxf(fmaxf(fmaxf(vmax, fabsf(dv4.x)), fabsf(dv4.y)), fmaxf(fabsf(dv4.z), fabsf(dv4.w)));
             }
+        if (amax_lds) atomicMax(amax_lds, __float_as_uint(vmax));      // (gamer_amax_sink: max |dv|, the v columns of d(q|k|v))
     }
 }
 
@@ -1131,10 +1149,15 @@ attn_bwd_dkv_s_kernel(const float* __restrict__ q, int ldq, const float* __restr
                       const int32_t* __restrict__ row_empty, const int32_t* __restrict__ tile_empty,
                       int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                       float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const RowOrder ro,
-                      float* __restrict__ ds_out) {
+                      float* __restrict__ ds_out, uint32_t* __restrict__ amax_out) {
     const int n_tiles = (S + DKV_S_KEYS - 1) / DKV_S_KEYS;
     const WorkList wl(nbatch * nkv, n_tiles);
     if (!wl.valid) return;
+    __shared__ uint32_t amax_word;
+    if (amax_out) {
+        if (threadIdx.x == 0) amax_word = 0;
+        __syncthreads();
+    }
     for (int it = 0;; ++it) {
         const int pair = wl.pair_at(it);
         if (pair >= wl.n_pairs) break;
@@ -1143,8 +1166,14 @@ attn_bwd_dkv_s_kernel(const float* __restrict__ q, int ldq, const float* __restr
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
             attn_bwd_dkv_s_tile<G, DROP, ORD>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv,
-                                              scale, p_drop, seed, dk, lddk, dv, lddv, ro, pair, pass == 0 ? heavy : light, ds_out);
+                                              scale, p_drop, seed, dk, lddk, dv, lddv, ro, pair, pass == 0 ? heavy : light, ds_out,
+                                              amax_out ? &amax_word : nullptr);
         }
+    }
+    if (amax_out) {
+        __syncthreads();
+        if (threadIdx.x == 0 && amax_word > __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(amax_out, amax_word);
     }
 }
 
@@ -1321,6 +1350,9 @@ attn_bwd_dq2_s_kernel(const float* __restrict__ k, int ldk, const float* __restr
 // tiles (20 KB) in flight: the kernel runs at the rate the spilled dS comes back from HBM.
 constexpr int DQ3_THREADS = 512;          // two waves per SIMD: twice the dS tiles in flight per CU
 
+// the sink armed for the entry point in progress (gamer_amax_sink): max |o| of the forward, max |dv| of the backward
+static thread_local uint32_t* t_amax_out = nullptr;
+
 template <int G>
 static int launch_fwd_s(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl,
                         const int32_t* ql, const int32_t* row_empty, int B, int S, int nq, int nkv, float scale,
@@ -1329,7 +1361,7 @@ static int launch_fwd_s(const float* q, int ldq, const float* k, int ldk, const 
     dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
 #define GAMER_LAUNCH_FWD_S(DROPV, ORDV)                                                                                    \
     hipLaunchKernelGGL((attn_fwd_s_kernel<G, DROPV, ORDV, false>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv,    \
-                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, S)
+                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, S, t_amax_out)
     if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD_S(true, true); else GAMER_LAUNCH_FWD_S(true, false); }
     else { if (ro.perm) GAMER_LAUNCH_FWD_S(false, true); else GAMER_LAUNCH_FWD_S(false, false); }
 #undef GAMER_LAUNCH_FWD_S
@@ -1368,7 +1400,7 @@ static int launch_bwd_s_variant(const float* q, int ldq, const float* k, int ldk
     const int n_kt = (S + DKV_S_KEYS - 1) / DKV_S_KEYS;
     hipLaunchKernelGGL((attn_bwd_dkv_s_kernel<G, DROP, ORD>), dim3(worklist_grid_1(B * nkv, n_kt)), dim3(256 * G), shmem, st, q, ldq,
                        k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk,
-                       lddk, dv, lddv, ro, ds_work);
+                       lddk, dv, lddv, ro, ds_work, t_amax_out);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dkv");
     if (ds_work != nullptr) {
         hipLaunchKernelGGL((attn_bwd_dq2_s_kernel<G, ORD>), dim3(worklist_grid(B * nkv, (S + R - 1) / R)), dim3(AT_THREADS), 0, st,
@@ -1421,8 +1453,11 @@ extern "C" int gamer_attn_fwd_split(const float* q, int ldq, const float* k, int
     if (rc) return rc;
     GAMER_CHECK_ARG(o && lse && aligned16(o), "gamer_attn_fwd_split: null/unaligned output");
     hipStream_t st = (hipStream_t)stream;
-    if (nq / nkv == 1) return launch_fwd_s<1>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st);
-    return launch_fwd_s<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st);
+    t_amax_out = take_amax_sink().out[0];               // gamer_amax_sink: max |o|
+    rc = (nq / nkv == 1) ? launch_fwd_s<1>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st)
+                         : launch_fwd_s<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st);
+    t_amax_out = nullptr;
+    return rc;
 }
 
 extern "C" int gamer_attn_bwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
@@ -1441,7 +1476,10 @@ extern "C" int gamer_attn_bwd_split(const float* q, int ldq, const float* k, int
                     aligned16(d_o) && aligned16(o),
                     "gamer_attn_bwd_split: gradient buffers must be 16-byte aligned with leading dims %% 4 == 0");
     hipStream_t st = (hipStream_t)stream;
-    if (nq / nkv == 1)
-        return launch_bwd_s<1>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, ds_work, st);
-    return launch_bwd_s<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, ds_work, st);
+    t_amax_out = take_amax_sink().out[0];               // gamer_amax_sink: max |dv|
+    rc = (nq / nkv == 1)
+        ? launch_bwd_s<1>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, ds_work, st)
+        : launch_bwd_s<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, ds_work, st);
+    t_amax_out = nullptr;
+    return rc;
 }

@@ -438,13 +438,14 @@ qknorm_rope_bwd_kernel(const TA* __restrict__ qkv, const TA* __restrict__ dq_rot
                        int cross, const float* __restrict__ bias_q, const float* __restrict__ bias_k,
                        const int32_t* __restrict__ act_idx, int nb1,
                        TA* __restrict__ dqkv, float* __restrict__ partial,
-                       int waves_per_head, const int32_t* __restrict__ pos_ids) {
+                       int waves_per_head, const int32_t* __restrict__ pos_ids, uint32_t* __restrict__ amax_out) {
     constexpr bool F32 = sizeof(TA) == 4;
     const int lane = threadIdx.x & 63;
     const int g = lane & 15, sub = lane >> 4;
     const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
     const int NH = nq + nkv + (cross ? nkv : 0);
     if (wave >= (int64_t)NH * waves_per_head) return;
+    float am = 0.f;                                    // gamer_amax_sink: max |dq|, |dk| written here (one atomic per wave)
     const int hd = (int)(wave % NH);
     const int w0 = (int)(wave / NH);
     const int ldqkv = (nq + 2 * nkv) * 64;
@@ -496,7 +497,10 @@ qknorm_rope_bwd_kernel(const TA* __restrict__ qkv, const TA* __restrict__ dq_rot
             float4 dx;
             dx.x = rstd * (gg.x - xh.x * dot); dx.y = rstd * (gg.y - xh.y * dot);
             dx.z = rstd * (gg.z - xh.z * dot); dx.w = rstd * (gg.w - xh.w * dot);
-            if (live) st4(dqkv + (int64_t)t * ldqkv + hd * 64 + 4 * g, dx);
+            if (live) {
+                st4(dqkv + (int64_t)t * ldqkv + hd * 64 + 4 * g, dx);
+                am = fmaxf(fmaxf(fmaxf(am, fabsf(dx.x)), fabsf(dx.y)), fmaxf(fabsf(dx.z), fabsf(dx.w)));
+            }
             if (cross) {
                 const int a_l = live ? a_t : -1;
 #pragma unroll
@@ -520,6 +524,12 @@ qknorm_rope_bwd_kernel(const TA* __restrict__ qkv, const TA* __restrict__ dq_rot
                 dbacc[a].x += m * dv.x; dbacc[a].y += m * dv.y; dbacc[a].z += m * dv.z; dbacc[a].w += m * dv.w;
             }
         }
+    }
+    if (amax_out) {
+        uint32_t m = __float_as_uint(am);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        if (lane == 0 && m > __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_out, m);
     }
     // fold the four 16-lane groups, then group 0 writes this wave's row of partial sums
     auto fold = [&](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
@@ -1334,7 +1344,7 @@ static int qknorm_rope_bwd_impl(const char* name, const TA* qkv, const TA* dq_ro
     } else {
         hipLaunchKernelGGL(qknorm_rope_bwd_kernel<TA>, dim3(blocks), dim3(EW_THREADS), 0, ST(stream), qkv, dq_rot, dk_rot, T,
                            S, nq, nkv, wq, wk, eps, cos_t, sin_t, cross, bias_q, bias_k, act_idx, nb1, dqkv, partial,
-                           waves_per_head, pos_ids);
+                           waves_per_head, pos_ids, take_amax_sink().out[0]);
     }
     GAMER_CHECK_LAUNCH(name);
     const int cols = 128 + (cross ? NH * nb1 * 64 : 0);

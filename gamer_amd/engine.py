@@ -796,7 +796,7 @@ class Engine:
             if split_attn and span_ is None:
                 ops.attn_bwd_split(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, empty_, tile_empty_, B, S, nq, nkv, scale,
                                    p_att, seed_, ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, order=order_,
-                                   delta_ready=fuse_delta)       # recompute form: measured faster than its dS spill
+                                   delta_ready=fuse_delta, dv_of=ws.dqkv)   # recompute form: measured faster than its dS spill
             elif bf16:
                 ord16 = (order_[0], order_[2], empty_) if (order_ is not None and span_ is None) else None
                 ops.attn_bwd_bf16(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, B, S, nq, nkv, scale, p_att, seed_,

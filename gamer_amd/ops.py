@@ -262,6 +262,8 @@ class amax_reuse:
         key = self._key(x.data_ptr(), geom)
         if accumulate and key in self.pending:
             return self.pending[key]
+        if accumulate == "only":                    # a later producer of a tensor whose first producer did not open a slot
+            return None
         self.slots.pop(key, None)
         ptr_ = self.pending[key] = self._new_slot(x.device)
         return ptr_
@@ -284,12 +286,17 @@ class amax_reuse:
         return ptr_
 
 
+_AMAX_ATTN = os.environ.get("GAMER_AMAX_ATTN", "1") != "0"      # the attention kernels as producers (o, dv) - A/B switch
+
+
 def _arm_sink(*outs):
     """outs: (tensor, (batch, stride, rows, cols, ld), accumulate) for the first / second output of the kernel launched next.
     With a maxima cache in effect and the split3 form selected, its slots are handed to that kernel (gamer_amax_sink)."""
     if _AMAX_REUSE is None or F32_MATMUL_TERMS != 3 or outs[0][0].dtype != torch.float32:
         return
     slots = [_AMAX_REUSE.preset(t, g, acc) for t, g, acc in outs]
+    if slots[0] is None:
+        return
     call("gamer_amax_sink", slots[0], slots[1] if len(slots) > 1 else None)
 
 
@@ -607,6 +614,8 @@ def qknorm_rope_bwd(qkv, dq_rot, dk_rot, S, nq, nkv, wq, wk, eps, cos_t, sin_t, 
     T = qkv.shape[0]
     if partial is None:
         partial = torch.empty(qknorm_partial_numel(nb1), dtype=torch.float32, device=qkv.device)
+    # the q and k columns of d(q|k|v) are written here, the v columns by the attention backward before: its slot, if it opened one
+    _arm_sink((dqkv, (1, 0, T, dqkv.shape[1], dqkv.stride(0)), "only"))
     call("gamer_qknorm_rope_bwd" + _sfx(qkv), ptr(qkv), ptr(dq_rot), ptr(dk_rot), T, S, nq, nkv, ptr(wq), ptr(wk), eps,
          ptr(cos_t), ptr(sin_t), ptr(bias_q), ptr(bias_k), ptr(act_idx), nb1, ptr(dqkv), ptr(dwq), ptr(dwk),
          ptr(dbias_q), ptr(dbias_k), ptr(dbias_v), ptr(pos_ids), ptr(partial), partial.numel(), stream_ptr())
@@ -641,15 +650,20 @@ def attn_bwd(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty,
 def attn_fwd_split(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, order=None):
     """gamer_attn_fwd with its products on the bf16 pipe (exact three-way cuts, six piece products); training semantics."""
     pm, tk, tm = order if order is not None else (None, None, None)
+    if _AMAX_ATTN:
+        _arm_sink((o, (1, 0, 1, B * S * nq * 64, B * S * nq * 64), False))
     call("gamer_attn_fwd_split", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(kl), ptr(ql), ptr(row_empty), B, S, nq, nkv,
          scale, p_drop, seed, ptr(o), ptr(lse), ptr(pm), ptr(tk), ptr(tm), stream_ptr())
 
 
 def attn_bwd_split(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed,
-                   delta, dq, lddq, dk, lddk, dv, lddv, order=None, delta_ready=False, ds_work=None):
+                   delta, dq, lddq, dk, lddk, dv, lddv, order=None, delta_ready=False, ds_work=None, dv_of=None):
     """gamer_attn_bwd with its products on the bf16 pipe; delta_ready: `delta` already holds dO.O; ds_work: the dS spill
-    scratch of attn_bwd (None = recompute form)."""
+    scratch of attn_bwd (None = recompute form); dv_of: the d(q|k|v) tensor whose v columns `dv` is (its maximum is then
+    collected by the kernels that write it: this one and qknorm_rope_bwd)."""
     pm, tk, tm = order if order is not None else (None, None, None)
+    if dv_of is not None and _AMAX_ATTN:
+        _arm_sink((dv_of, (1, 0, dv_of.shape[0], dv_of.shape[1], dv_of.stride(0)), False))
     call("gamer_attn_bwd_split", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), ptr(d_o), ptr(lse), ptr(kl), ptr(ql),
          ptr(row_empty), ptr(tile_empty), B, S, nq, nkv, scale, p_drop, seed, ptr(delta), ptr(dq), lddq, ptr(dk), lddk, ptr(dv),
          lddv, ptr(pm), ptr(tk), ptr(tm), 1 if delta_ready else 0, ptr(ds_work), stream_ptr())
