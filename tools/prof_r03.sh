@@ -1,16 +1,19 @@
 # Round-3 measurement pass (run on the GPU box through gpurun): the driver's default bench line, then rocprofv3 kernel-trace
-# summaries and HBM byte counters (separate --pmc passes: FETCH_SIZE, WRITE_SIZE; SQ set) of the default (fp32 / split6) step
+# summaries and HBM byte counters (separate --pmc passes: FETCH_SIZE, WRITE_SIZE; SQ set) of the default (fp32 / split3) step
 # and of the fp32-MFMA and bf16 steps.  Every PMC set gets a <tag>_pmc_meta.json naming the profiled command and workload.
-# usage: bash tools/prof_r03.sh <tag>      (outputs under gpurun_out/<tag>_*)
+# usage: bash tools/prof_r03.sh <tag> ["f32 split3" "f32 f32" ...]     (outputs under gpurun_out/<tag>_*; default: the three sets)
 set -x
 TAG=${1:-r03z}
+shift
+if [ $# -eq 0 ]; then set -- "f32 split3" "f32 f32" "bf16 f32"; fi
+CFGS=("$@")
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out
 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err; tail -2 $O/${TAG}_bench_default.err
 export TMPDIR=/tmp; cd /tmp
 export GAMER_WGRAD_TUNE_FILE=$O/${TAG}_wgrad_tune.json
-for cfg in "f32 split6" "f32 f32" "bf16 f32"; do set -- $cfg; python3 $GRAFT_REPO_ROOT/bench.py --dtype $1 --matmul $2 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-secondary > /dev/null 2>&1; done
-for cfg in "f32 split6" "f32 f32" "bf16 f32"; do
+for cfg in "${CFGS[@]}"; do set -- $cfg; python3 $GRAFT_REPO_ROOT/bench.py --dtype $1 --matmul $2 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-secondary > /dev/null 2>&1; done
+for cfg in "${CFGS[@]}"; do
   set -- $cfg; dt=$1; mm=$2; tag=${dt}_${mm}
   B="python3 $GRAFT_REPO_ROOT/bench.py --dtype $dt --matmul $mm --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-secondary"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_${tag}_stats -o p -- $B > $O/${TAG}_${tag}_bench_under_rocprof.json 2>/dev/null

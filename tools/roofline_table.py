@@ -40,9 +40,9 @@ def main():
     tf = {k["kernel"]: k.get("tflops") for k in (tfsrc.get("kernels") or [])}
     bf16 = tfsrc.get("dtype") == "bf16"
     mfma_peak, mfma_name = (2500.0, "bf16 MFMA") if bf16 else (FP32_MFMA_PEAK, "fp32 MFMA")
-    terms = {"split6": 6, "split9": 9}.get((tfsrc.get("config") or {}).get("matmul"), 0)
-    if terms and not bf16:          # fp32 products as `terms` bf16 piece products: the bf16 pipe's peak in fp32-problem FLOPs
-        mfma_peak, mfma_name = 2500.0 / terms, f"bf16 MFMA / {terms}"
+    terms = {"split3": 3, "split6": 6, "split9": 9}.get((tfsrc.get("config") or {}).get("matmul"), 0)
+    if terms and not bf16:          # fp32 products as `terms` 16-bit piece products: that pipe's peak in fp32-problem FLOPs
+        mfma_peak, mfma_name = 2500.0 / terms, f"{'fp16' if terms == 3 else 'bf16'} MFMA / {terms}"
     group = {"gemm_f32_kernel<true, true, 0, false, false, 2, 0": "gemm_fwd",
              "gemm_f32_kernel<true, true, 0, false, false, 2, 1": "gemm_fwd_resid",
              "gemm_f32_kernel<true, false, 0, false, false, 2, 2": "gemm_dgrad_delta",
