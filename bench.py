@@ -102,7 +102,7 @@ class KernelTimer:
         timer = self
 
         def timed_call(name, *args):
-            if not timer.enabled or name == "gamer_amax_sink":       # (not a launch)
+            if not timer.enabled or name in ("gamer_amax_sink", "gamer_attn_split_amax"):       # (not launches)
                 return orig_call(name, *args)
             if name == "gamer_absmax_f32":              # split3: the operand maxima in front of a GEMM keep their own row
                 label, flops, nbytes = "absmax", 0.0, 0.0

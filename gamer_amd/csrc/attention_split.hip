@@ -126,6 +126,103 @@ __device__ __forceinline__ void store_tile32_split(bf16_t* __restrict__ img, int
             *reinterpret_cast<uint2*>(dst + s * SIMG) = make_uint2(hi16_pair(w[0][s], w[1][s]), hi16_pair(w[2][s], w[3][s]));
     }
 }
+// ---- H2: the two-way fp16 cut of csrc/gemm.hip's SPLIT == 3 form (x s = h0 + h1 + r, |r| <= 2^-22 |x s|; s = a power of two that
+// brings the tensor's largest magnitude into [2^13, 2^14)), three piece products h0 h0' + h0 h1' + h1 h0'.  Fragments travel in
+// the same bf16x8 containers (bits), images 0 and 1 of the three-image layouts.
+__device__ __forceinline__ void cut2h_pair(float x0, float x1, uint32_t& p0, uint32_t& p1) {
+    const f16x2 a = {(_Float16)x0, (_Float16)x1};                                   // v_cvt_pk_f16_f32 (nearest even)
+    const f16x2 b = {(_Float16)(x0 - (float)a[0]), (_Float16)(x1 - (float)a[1])};
+    p0 = __builtin_bit_cast(uint32_t, a);
+    p1 = __builtin_bit_cast(uint32_t, b);
+}
+// piece fragments of eight consecutive values; H2: the values are multiplied by s first, p[2] is not written
+template <bool H2>
+__device__ __forceinline__ void cut8_t(const float4& a, const float4& b, float s, bf16x8 (&p)[3]) {
+    if (!H2) { cut8(a, b, p[0], p[1], p[2]); return; }
+    const float x[8] = {a.x * s, a.y * s, a.z * s, a.w * s, b.x * s, b.y * s, b.z * s, b.w * s};
+    u32x4s u0, u1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t a, c;
+        cut2h_pair(x[2 * j], x[2 * j + 1], a, c);
+        u0[j] = a; u1[j] = c;
+    }
+    p[0] = __builtin_bit_cast(bf16x8, u0); p[1] = __builtin_bit_cast(bf16x8, u1);
+}
+template <bool H2>
+__device__ __forceinline__ void cut8_regs_t(const f32x16& t, const int first, float s, bf16x8 (&p)[3]) {
+    if (!H2) { cut8_regs(t, first, p[0], p[1], p[2]); return; }
+    u32x4s u0, u1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t a, c;
+        cut2h_pair(t[first + 2 * j] * s, t[first + 2 * j + 1] * s, a, c);
+        u0[j] = a; u1[j] = c;
+    }
+    p[0] = __builtin_bit_cast(bf16x8, u0); p[1] = __builtin_bit_cast(bf16x8, u1);
+}
+template <bool H2>
+__device__ __forceinline__ void store_tile32_t(bf16_t* __restrict__ img, int tid, const float4 (&rg)[2], int n_valid, float s) {
+    if (!H2) { store_tile32_split(img, tid, rg, n_valid); return; }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int f = tid + AT_THREADS * jj;
+        const int row = f >> 4;
+        const bool ok = row < n_valid;
+        uint32_t a0, a1, b0, b1;
+        cut2h_pair(ok ? rg[jj].x * s : 0.f, ok ? rg[jj].y * s : 0.f, a0, a1);
+        cut2h_pair(ok ? rg[jj].z * s : 0.f, ok ? rg[jj].w * s : 0.f, b0, b1);
+        bf16_t* dst = img + sl_off(row, (f & 15) << 2);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(a0, b0);
+        *reinterpret_cast<uint2*>(dst + SIMG) = make_uint2(a1, b1);
+    }
+}
+template <bool H2>
+__device__ __forceinline__ f32x16 mfma_piece(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+    if (H2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// acc += sum over piece pairs i + j < NP of A_i . B_j, smallest products first (NP = 3: the six products of the exact cut in
+// the order (2,0) (1,1) (0,2) (1,0) (0,1) (0,0); NP = 2: (1,0) (0,1) (0,0)); ONE_B: B has one non-zero piece (0 / 1 values)
+template <bool H2, bool ONE_B = false>
+__device__ __forceinline__ f32x16 mfma_pieces(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 acc) {
+    constexpr int NP = H2 ? 2 : 3;
+#pragma unroll
+    for (int sum = NP - 1; sum >= 0; --sum)
+#pragma unroll
+        for (int i = sum; i >= 0; --i) {
+            const int j = sum - i;
+            if (ONE_B && j != 0) continue;
+            acc = mfma_piece<H2>(a[i], b[j], acc);
+        }
+    return acc;
+}
+// the scales of one attention call in the H2 form (powers of two; kernel-uniform)
+struct H2Scales {
+    float q, k, v, d_o, ds;          // operand tensors (from their maxima); dS: from the bound |dS| <= 128 / (1 - p) max|dO| max|V|
+    float inv_qk, inv_v, inv_q, inv_k, inv_do, inv_ds;
+    static constexpr float P = 8192.f, INV_P = 1.f / 8192.f;       // probabilities (<= 1 / (1 - p_drop) < 4)
+    __device__ __forceinline__ H2Scales(const uint32_t* __restrict__ aq, const uint32_t* __restrict__ ak,
+                                        const uint32_t* __restrict__ av, const uint32_t* __restrict__ ado, float q_prescale,
+                                        float drop_scale = 1.f) {
+        q = k = v = d_o = ds = inv_q = inv_k = inv_v = inv_do = inv_ds = inv_qk = 1.f;
+        if (aq) {
+            // q enters its products multiplied by q_prescale (the softmax scale, log2 domain): scale that product's maximum
+            const uint32_t qb = __float_as_uint(__uint_as_float(aq[0]) * q_prescale);
+            scale_from_amax(qb, q, inv_q);
+            scale_from_amax(ak[0], k, inv_k);
+            scale_from_amax(av[0], v, inv_v);
+            if (ado) {
+                scale_from_amax(ado[0], d_o, inv_do);
+                // dS = p (mult dP - delta), p <= 1, |dP| <= 64 max|dO| max|V|, |delta| <= 64 max|dO| max|O|, |O| <= mult max|V|
+                const float bound = 128.f * drop_scale * __uint_as_float(ado[0]) * __uint_as_float(av[0]);
+                scale_from_amax(__float_as_uint(bound), ds, inv_ds);
+            }
+            inv_qk = inv_q * inv_k;
+        }
+    }
+};
+
 // ACC += (three K images of one slot)(rows = this tile's 32 keys) . q^T, six piece products, smallest first.
 // (Measured and not kept: two interleaved accumulation chains here and in the second products - the extra 16 accumulator
 // registers cost more in spills than the independent chains gained: forward 0.63 -> 0.76 ms at batch 256.)
@@ -134,20 +231,16 @@ __device__ __forceinline__ void store_tile32_split(bf16_t* __restrict__ img, int
         /* the fragments of k-step s + 1 are requested BEFORE the six products of k-step s (left alone the compiler issues  \
            every ds_read right in front of the MFMA that needs it and waits for it: the 24 MFMAs of a tile cost 3.3 x their \
            pipe time, tools/ablate_attn_split.sh) */                                                                        \
+        constexpr int NP_ = H2 ? 2 : 3;                                                                                     \
         bf16x8 kf_[2][3];                                                                                                   \
-        _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_) kf_[0][pc_] = read_row8(KIMG + pc_ * SIMG, lo, 0, 0);           \
+        _Pragma("unroll") for (int pc_ = 0; pc_ < NP_; ++pc_) kf_[0][pc_] = read_row8(KIMG + pc_ * SIMG, lo, 0, 0);         \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                     \
             if (s + 1 < 4) {                                                                                                \
-                _Pragma("unroll") for (int pc_ = 0; pc_ < 3; ++pc_) kf_[(s + 1) & 1][pc_] = read_row8(KIMG + pc_ * SIMG, lo, 0, s + 1); \
+                _Pragma("unroll") for (int pc_ = 0; pc_ < NP_; ++pc_) kf_[(s + 1) & 1][pc_] = read_row8(KIMG + pc_ * SIMG, lo, 0, s + 1); \
             }                                                                                                               \
             __builtin_amdgcn_sched_barrier(0);                                                                              \
-            const bf16x8 k0 = kf_[s & 1][0], k1 = kf_[s & 1][1], k2 = kf_[s & 1][2];                                        \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, qf[0][s], ACC, 0, 0, 0);                                      \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1][s], ACC, 0, 0, 0);                                      \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[2][s], ACC, 0, 0, 0);                                      \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[0][s], ACC, 0, 0, 0);                                      \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[1][s], ACC, 0, 0, 0);                                      \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0][s], ACC, 0, 0, 0);                                      \
+            const bf16x8 qs_[3] = {qf[0][s], qf[1][s], qf[NP_ - 1][s]};                                                     \
+            ACC = mfma_pieces<H2>(kf_[s & 1], qs_, ACC);                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                                              \
         }                                                                                                                   \
     }
@@ -155,18 +248,19 @@ __device__ __forceinline__ void store_tile32_split(bf16_t* __restrict__ img, int
 // =============================================================================================
 // forward (attention.hip: attn_fwd_tile, with the split fragments)
 // =============================================================================================
-template <int G, bool DROP, bool ORD, bool SPAN>
+template <int G, bool DROP, bool ORD, bool SPAN, bool H2>
 __device__ __forceinline__ void
 attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
               const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
               const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
               int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
               float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int pair, const int qtile,
-              const int uspan, uint32_t* __restrict__ amax_lds) {
+              const int uspan, uint32_t* __restrict__ amax_lds, const H2Scales& sc) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[2][3 * SIMG];      // slot x (three bf16 piece images of 32 keys x 64)
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[2][3 * SIMG];
+    constexpr int NP = H2 ? 2 : 3;
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[2][NP * SIMG];     // slot x (NP piece images of 32 keys x 64)
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[2][NP * SIMG];
     __shared__ __attribute__((aligned(16))) KeyMeta kms[3];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -193,7 +287,10 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
             float4 a4 = *reinterpret_cast<const float4*>(qrow + 16 * s);
             float4 b4 = *reinterpret_cast<const float4*>(qrow + 16 * s + 4);
             a4.x *= qs; a4.y *= qs; a4.z *= qs; a4.w *= qs; b4.x *= qs; b4.y *= qs; b4.z *= qs; b4.w *= qs;
-            cut8(a4, b4, qf[0][s], qf[1][s], qf[2][s]);
+            bf16x8 pq[3];
+            cut8_t<H2>(a4, b4, sc.q, pq);
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) qf[pc][s] = pq[pc];
         }
     }
     const int my_ql = ql ? ql[tok] : 1;
@@ -249,13 +346,13 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
     load_tile32(kbase, ldk, 0, S, tid, rk);
     load_tile32(vbase, ldv, 0, S, tid, rv);
     rmeta = key_meta_load<DROP>(klb, 0, S, w, lane, rng);
-    store_tile32_split(Ks[0], tid, rk, S);
-    store_tile32_split(Vs[0], tid, rv, S);
+    store_tile32_t<H2>(Ks[0], tid, rk, S, sc.k);
+    store_tile32_t<H2>(Vs[0], tid, rv, S, sc.v);
     key_meta_store(kms[0], w, lane, rmeta);
     if (n_iter > 1) {
         load_tile32(kbase, ldk, 32, S, tid, rk);
         rmeta = key_meta_load<DROP>(klb, 32, S, w, lane, rng);
-        store_tile32_split(Ks[1], tid, rk, S - 32);
+        store_tile32_t<H2>(Ks[1], tid, rk, S - 32, sc.k);
         key_meta_store(kms[1], w, lane, rmeta);
     }
     __syncthreads();
@@ -263,7 +360,13 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
     f32x16 st_cur;
 #pragma unroll
     for (int i = 0; i < 16; ++i) st_cur[i] = 0.f;
-    if (!(0 > wave_q_hi)) { SPLIT_QK_TILE(st_cur, Ks[0]) }
+    if (!(0 > wave_q_hi)) {
+        SPLIT_QK_TILE(st_cur, Ks[0])
+        if (H2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st_cur[i] *= sc.inv_qk;
+        }
+    }
     // K(0) must stay intact until every wave has taken its first scores: a wave without work in this tile
     // (rows past the end of the sequence, or empty rows only) reaches the K(2) store of iteration 0 at once
     __syncthreads();
@@ -292,22 +395,15 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     bf16x8 pf[3];
-                    cut8_regs(st_cur, 8 * s2, pf[0], pf[1], pf[2]);
-                    if (SPA_ABLATE & 2) { asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2])); continue; }
+                    cut8_regs_t<H2>(st_cur, 8 * s2, H2Scales::P, pf);
+                    if (SPA_ABLATE & 2) { asm volatile("" :: "v"(pf[0]), "v"(pf[1])); continue; }
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
-                        const bf16x8 v0 = read_tr8(Vc, lo, 16 * s2, db);
-                        const bf16x8 v1 = read_tr8(Vc + SIMG, lo, 16 * s2, db);
-                        const bf16x8 v2 = read_tr8(Vc + 2 * SIMG, lo, 16 * s2, db);
-                        // smallest piece products first: (v0 p2), (v1 p1), (v2 p0), (v0 p1), (v1 p0), (v0 p0)
-                        if (!ONE_PIECE) {
-                            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[2], oacc[db], 0, 0, 0);
-                            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf[1], oacc[db], 0, 0, 0);
-                        }
-                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2, pf[0], oacc[db], 0, 0, 0);
-                        if (!ONE_PIECE) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[1], oacc[db], 0, 0, 0);
-                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf[0], oacc[db], 0, 0, 0);
-                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf[0], oacc[db], 0, 0, 0);
+                        bf16x8 vf[3];
+#pragma unroll
+                        for (int pc = 0; pc < NP; ++pc) vf[pc] = read_tr8(Vc + pc * SIMG, lo, 16 * s2, db);
+                        // smallest piece products first: (v2 p0), (v1 p1), (v0 p2), (v1 p0), (v0 p1), (v0 p0); a 0 / 1 P has one piece
+                        oacc[db] = mfma_pieces<H2, ONE_PIECE>(vf, pf, oacc[db]);
                     }
                 }
             };
@@ -331,7 +427,8 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
 #pragma unroll
                 for (int reg = 1; reg < 16; ++reg) mloc = fmaxf(mloc, st_cur[reg]);
                 mloc = xor32_max(mloc);
-                bool need = (l_run == 0.f) ? (mloc > -INFINITY) : (mloc > RESCALE_TAU);
+                // (H2: P is cut into fp16 pieces of P * 2^13 - it must stay below 2^3, so the reference follows the maximum closely)
+                bool need = (l_run == 0.f) ? (mloc > -INFINITY) : (mloc > (H2 ? 2.f : RESCALE_TAU));
                 if (EMPTYSEL) need = need && !my_empty;
                 if (__any(need ? 1 : 0)) {
                     const float d = need ? mloc : 0.f;
@@ -392,22 +489,27 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
         if (have_next && !beyond_next) {
             // scores of the next tile (minus the reference), taken BEFORE the barrier: after it other waves may
             // already overwrite this K slot with K(jt+3)
-            const float init = -m_ref;
+            const float init = H2 ? -m_ref * (sc.q * sc.k) : -m_ref;        // (H2: the products carry the operands' scales)
 #pragma unroll
             for (int i = 0; i < 16; ++i) st_cur[i] = init;
             if ((jt + 1) & 1) { SPLIT_QK_TILE(st_cur, Ks[1]) } else { SPLIT_QK_TILE(st_cur, Ks[0]) }
+            if (H2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) st_cur[i] *= sc.inv_qk;
+            }
         }
         if (have_next2) {
-            store_tile32_split(Ks[jt & 1], tid, rk, S - (j0 + 64));   // K(jt) is dead: its scores were taken last iteration
+            store_tile32_t<H2>(Ks[jt & 1], tid, rk, S - (j0 + 64), sc.k);   // K(jt) is dead: its scores were taken last iteration
             key_meta_store(kms[(jt + 2) % 3], w, lane, rmeta);
         }
-        if (have_next) store_tile32_split(Vs[(jt + 1) & 1], tid, rv, S - (j0 + 32));
+        if (have_next) store_tile32_t<H2>(Vs[(jt + 1) & 1], tid, rv, S - (j0 + 32), sc.v);
         __syncthreads();
     }
 
     if (valid_q) {
         float linv = my_empty ? invS : (l_run > 0.f ? 1.f / l_run : 0.f);
         if (DROP) linv *= rng.scale;
+        if (H2) linv *= H2Scales::INV_P * sc.inv_v;
         float* orow = o + tok * (int64_t)nq * 64 + head * 64;
         float omax = 0.f;
 #pragma unroll
@@ -428,15 +530,19 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
     }
 }
 
-template <int G, bool DROP, bool ORD, bool SPAN>
+// the maxima of q, k, v (and dO in the backward) of the H2 form: device words (gamer_absmax_f32 / gamer_amax_sink)
+struct AttnAmax { const uint32_t* q; const uint32_t* k; const uint32_t* v; const uint32_t* d_o; };
+
+template <int G, bool DROP, bool ORD, bool SPAN, bool H2>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_fwd_s_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                 const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
                 const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
                 int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                 float* __restrict__ o, float* __restrict__ lse, const RowOrder ro, const int uspan,
-                uint32_t* __restrict__ amax_out) {
+                uint32_t* __restrict__ amax_out, const AttnAmax am) {
     constexpr int R = (4 / G) * 32;
+    const H2Scales sc(H2 ? am.q : nullptr, am.k, am.v, nullptr, scale * 1.4426950408889634f);
     const int n_tiles = (S + R - 1) / R;
     const WorkList wl(nbatch * nkv, n_tiles);
     if (!wl.valid) return;
@@ -458,8 +564,8 @@ attn_fwd_s_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {                    // one inlined body (register pressure)
             if (pass == 1 && light == heavy) break;
-            attn_fwd_s_tile<G, DROP, ORD, SPAN>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed, o, lse,
-                                        ro, pair, pass == 0 ? heavy : light, uspan, amax_out ? &amax_word : nullptr);
+            attn_fwd_s_tile<G, DROP, ORD, SPAN, H2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, S, nq, nkv, scale, p_drop, seed, o, lse,
+                                        ro, pair, pass == 0 ? heavy : light, uspan, amax_out ? &amax_word : nullptr, sc);
         }
     }
     if (amax_out) {
@@ -473,7 +579,7 @@ attn_fwd_s_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
 // =============================================================================================
 // backward: dQ (attention.hip: attn_bwd_dq_tile, with the split fragments; K / V single-buffered, dO pieces in LDS)
 // =============================================================================================
-template <int G, bool DROP, bool ORD, bool SPAN>
+template <int G, bool DROP, bool ORD, bool SPAN, bool H2>
 __device__ __forceinline__ void
 attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                    const float* __restrict__ v, int ldv, const float* __restrict__ o, const float* __restrict__ d_o,
@@ -481,15 +587,16 @@ attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict
                    const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                    const int32_t* __restrict__ row_empty, int S, int nq, int nkv, float scale,
                    float p_drop, uint64_t seed, float* __restrict__ dq, int lddq, const RowOrder ro, const int pair,
-                   const int qtile, const int delta_ready) {
+                   const int qtile, const int delta_ready, const H2Scales& sc) {
     constexpr int NSUB = 4 / G;
     constexpr int R = NSUB * 32;
+    constexpr int NP = H2 ? 2 : 3;
     // K / V: ONE slot of three piece images each (the next tile waits in registers while this one is multiplied); dO: three
     // piece images of every wave's 32 query rows (the B operand of dP = V dO^T: in registers they would be 48 more VGPRs
     // next to the 48 of q's pieces).  24 + 24 + 48 KB: two workgroups per CU.
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[3 * SIMG];
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[3 * SIMG];
-    __shared__ __attribute__((aligned(16))) bf16_t dOs[4][3 * SIMG];
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[NP * SIMG];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[NP * SIMG];
+    __shared__ __attribute__((aligned(16))) bf16_t dOs[4][NP * SIMG];
     __shared__ __attribute__((aligned(16))) KeyMeta kms[2];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -520,7 +627,10 @@ attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict
             float4 a4 = *reinterpret_cast<const float4*>(qrow + 16 * s);
             float4 b4 = *reinterpret_cast<const float4*>(qrow + 16 * s + 4);
             a4.x *= qs; a4.y *= qs; a4.z *= qs; a4.w *= qs; b4.x *= qs; b4.y *= qs; b4.z *= qs; b4.w *= qs;
-            cut8(a4, b4, qf[0][s], qf[1][s], qf[2][s]);
+            bf16x8 pq[3];
+            cut8_t<H2>(a4, b4, sc.q, pq);
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) qf[pc][s] = pq[pc];
             float4 u4 = *reinterpret_cast<const float4*>(drow + 16 * s);
             float4 w4 = *reinterpret_cast<const float4*>(drow + 16 * s + 4);
             if (!delta_ready) {
@@ -529,12 +639,11 @@ attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict
                 my_delta += u4.x * o4.x + u4.y * o4.y + u4.z * o4.z + u4.w * o4.w + w4.x * p4.x + w4.y * p4.y + w4.z * p4.z + w4.w * p4.w;
             }
             if (!valid_q) { u4 = make_float4(0.f, 0.f, 0.f, 0.f); w4 = u4; }
-            bf16x8 d0, d1, d2;
-            cut8(u4, w4, d0, d1, d2);
+            bf16x8 dpc[3];
+            cut8_t<H2>(u4, w4, sc.d_o, dpc);
             // this lane's 8 values are columns 16 s + 8 h .. + 7 of row r: exactly what read_row8 hands back to it
-            *reinterpret_cast<bf16x8*>(dimg + lo.row[s]) = d0;
-            *reinterpret_cast<bf16x8*>(dimg + SIMG + lo.row[s]) = d1;
-            *reinterpret_cast<bf16x8*>(dimg + 2 * SIMG + lo.row[s]) = d2;
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<bf16x8*>(dimg + pc * SIMG + lo.row[s]) = dpc[pc];
         }
         if (!delta_ready) {
             my_delta += __shfl_xor(my_delta, 32, 64);
@@ -598,8 +707,8 @@ attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict
         const bool more = jt + 1 < n_iter;
         const int j0 = jt * 32;
         __syncthreads();                              // the previous tile has been consumed by every wave
-        store_tile32_split(Ks, tid, rk, S - j0);
-        store_tile32_split(Vs, tid, rv, S - j0);
+        store_tile32_t<H2>(Ks, tid, rk, S - j0, sc.k);
+        store_tile32_t<H2>(Vs, tid, rv, S - j0, sc.v);
         key_meta_store(kms[cur], w, lane, rmeta);
         __syncthreads();
         if (more) {                                   // in flight while this tile is multiplied
@@ -611,23 +720,29 @@ attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict
         if (!(beyond && !wave_has_empty)) {
             const KeyMeta& km = kms[cur];
             f32x16 st, dp;
+            const float st0 = (H2 && !beyond) ? neg_lse2 * (sc.q * sc.k) : neg_lse2;   // (H2: the products carry the operands' scales)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { st[i] = neg_lse2; dp[i] = 0.f; }
+            for (int i = 0; i < 16; ++i) { st[i] = st0; dp[i] = 0.f; }
             // S^T = K Q^T and dP^T[key][query] = sum_d V[key][d] dO[query][d]: two independent accumulation chains,
             // issued alternately (a single dependent chain of this MFMA runs 5-13 % below the pipe rate)
             const bf16_t* dimg = dOs[w];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const bf16x8 v0 = read_row8(Vs, lo, 0, s), v1 = read_row8(Vs + SIMG, lo, 0, s), v2 = read_row8(Vs + 2 * SIMG, lo, 0, s);
-                const bf16x8 d0 = read_row8(dimg, lo, 0, s), d1 = read_row8(dimg + SIMG, lo, 0, s), d2 = read_row8(dimg + 2 * SIMG, lo, 0, s);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v2, d0, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, d1, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, d2, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, d0, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, d1, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, d0, dp, 0, 0, 0);
+                bf16x8 vf[3], df0[3];
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) { vf[pc] = read_row8(Vs + pc * SIMG, lo, 0, s); df0[pc] = read_row8(dimg + pc * SIMG, lo, 0, s); }
+                dp = mfma_pieces<H2>(vf, df0, dp);
             }
             if (!beyond) { SPLIT_QK_TILE(st, Ks) }
+            if (H2) {
+                const float cdp = sc.inv_v * sc.inv_do;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dp[i] *= cdp;
+                if (!beyond) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) st[i] *= sc.inv_qk;
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);      // keep the LDS reads of the later phases below this point
             // u = mult * dP - delta  (mult = keep / (1 - p))
             if (DROP) {
@@ -647,18 +762,13 @@ attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     bf16x8 df[3];
-                    cut8_regs(ds, 8 * s2, df[0], df[1], df[2]);
+                    cut8_regs_t<H2>(ds, 8 * s2, sc.ds, df);
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
-                        const bf16x8 k0 = read_tr8(Ks, lo, 16 * s2, db);
-                        const bf16x8 k1 = read_tr8(Ks + SIMG, lo, 16 * s2, db);
-                        const bf16x8 k2 = read_tr8(Ks + 2 * SIMG, lo, 16 * s2, db);
-                        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, df[2], dqacc[db], 0, 0, 0);
-                        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, df[1], dqacc[db], 0, 0, 0);
-                        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k2, df[0], dqacc[db], 0, 0, 0);
-                        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, df[1], dqacc[db], 0, 0, 0);
-                        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, df[0], dqacc[db], 0, 0, 0);
-                        dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, df[0], dqacc[db], 0, 0, 0);
+                        bf16x8 kf[3];
+#pragma unroll
+                        for (int pc = 0; pc < NP; ++pc) kf[pc] = read_tr8(Ks + pc * SIMG, lo, 16 * s2, db);
+                        dqacc[db] = mfma_pieces<H2>(kf, df, dqacc[db]);
                     }
                 }
             };
@@ -701,7 +811,8 @@ attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict
     }
 
     if (valid_q) {
-        const float fs = my_empty ? scale * invS : scale;
+        float fs = my_empty ? scale * invS : scale;
+        if (H2) fs *= sc.inv_ds * sc.inv_k;
         float* drow = dq + tok * lddq + head * 64;
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh) {
@@ -716,15 +827,17 @@ attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict
     }
 }
 
-template <int G, bool DROP, bool ORD, bool SPAN>
+template <int G, bool DROP, bool ORD, bool SPAN, bool H2>
 __global__ void __launch_bounds__(AT_THREADS, 2)
 attn_bwd_dq_s_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                    const float* __restrict__ v, int ldv, const float* __restrict__ o, const float* __restrict__ d_o,
                    const float* __restrict__ lse, float* __restrict__ delta,
                    const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
                    const int32_t* __restrict__ row_empty, int nbatch, int S, int nq, int nkv, float scale,
-                   float p_drop, uint64_t seed, float* __restrict__ dq, int lddq, const RowOrder ro, const int delta_ready) {
+                   float p_drop, uint64_t seed, float* __restrict__ dq, int lddq, const RowOrder ro, const int delta_ready,
+                   const AttnAmax am) {
     constexpr int R = (4 / G) * 32;
+    const H2Scales sc(H2 ? am.q : nullptr, am.k, am.v, am.d_o, scale * 1.4426950408889634f, 1.f / (1.f - p_drop));
     const int n_tiles = (S + R - 1) / R;
     const WorkList wl(nbatch * nkv, n_tiles);
     if (!wl.valid) return;
@@ -735,8 +848,8 @@ attn_bwd_dq_s_kernel(const float* __restrict__ q, int ldq, const float* __restri
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
-            attn_bwd_dq_s_tile<G, DROP, ORD, SPAN>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, S, nq, nkv, scale,
-                                           p_drop, seed, dq, lddq, ro, pair, pass == 0 ? heavy : light, delta_ready);
+            attn_bwd_dq_s_tile<G, DROP, ORD, SPAN, H2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, S, nq, nkv, scale,
+                                           p_drop, seed, dq, lddq, ro, pair, pass == 0 ? heavy : light, delta_ready, sc);
         }
     }
 }
@@ -750,12 +863,12 @@ attn_bwd_dq_s_kernel(const float* __restrict__ q, int ldq, const float* __restri
 // dP = dO V^T for every query tile), the staged query tile's Q and dO images per head (12 KB each), per-query scalars.
 // 144 KB at G = 2: ONE workgroup per CU, eight waves = two per SIMD, as the two four-wave workgroups of the fp32 form.
 constexpr int DKV_S_KEYS = 128;
-template <int G>
+template <int G, int NP = 3>
 struct DkvSmemS {
-    bf16_t Kt[3][DKV_S_KEYS * 64];
-    bf16_t Vt[3][DKV_S_KEYS * 64];
-    bf16_t Qs[G][3 * SIMG];
-    bf16_t dOs[G][3 * SIMG];
+    bf16_t Kt[NP][DKV_S_KEYS * 64];
+    bf16_t Vt[NP][DKV_S_KEYS * 64];
+    bf16_t Qs[G][NP * SIMG];
+    bf16_t dOs[G][NP * SIMG];
     float nlse2_s[G][32];       // -lse * log2(e) of the staged query rows
     float ndelta_s[G][32];      // -delta
     uint32_t aw_s[G][32];       // dropout row words
@@ -766,7 +879,7 @@ struct DkvSmemS {
     int32_t posmin;
 };
 
-template <int G, bool DROP, bool ORD>
+template <int G, bool DROP, bool ORD, bool H2>
 __device__ __forceinline__ void
 attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                     const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
@@ -775,12 +888,13 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                     const int32_t* __restrict__ row_empty, const int32_t* __restrict__ tile_empty,
                     int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                     float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const RowOrder ro, const int pair,
-                    const int ktile, float* __restrict__ ds_out, uint32_t* __restrict__ amax_lds) {
+                    const int ktile, float* __restrict__ ds_out, uint32_t* __restrict__ amax_lds, const H2Scales& sc) {
+    constexpr int NP = H2 ? 2 : 3;
     constexpr int THREADS = 256 * G;
     constexpr int R = DKV_S_KEYS;
     constexpr int NLD = 512 / THREADS;               // float4 per thread, tensor and head of a staged 32 x 64 tile
     extern __shared__ __attribute__((aligned(16))) unsigned char dkvs_raw[];
-    DkvSmemS<G>& sm = *reinterpret_cast<DkvSmemS<G>*>(dkvs_raw);
+    DkvSmemS<G, NP>& sm = *reinterpret_cast<DkvSmemS<G, NP>*>(dkvs_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int hg = w >> 2, sub = w & 3;
@@ -802,25 +916,37 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
             kv4 = *reinterpret_cast<const float4*>(k + ((int64_t)b * S + j) * ldk + kvh * 64 + c4);
             vv4 = *reinterpret_cast<const float4*>(v + ((int64_t)b * S + j) * ldv + kvh * 64 + c4);
         }
-        const float xk[4] = {kv4.x, kv4.y, kv4.z, kv4.w}, xv[4] = {vv4.x, vv4.y, vv4.z, vv4.w};
-        uint32_t wk[4][3], wv[4][3];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { cut3(xk[e], wk[e]); cut3(xv[e], wv[e]); }
         const int off = sl_off(row, c4);
+        if (H2) {
+            uint32_t a0, a1, b0, b1;
+            cut2h_pair(kv4.x * sc.k, kv4.y * sc.k, a0, a1); cut2h_pair(kv4.z * sc.k, kv4.w * sc.k, b0, b1);
+            *reinterpret_cast<uint2*>(sm.Kt[0] + off) = make_uint2(a0, b0);
+            *reinterpret_cast<uint2*>(sm.Kt[1] + off) = make_uint2(a1, b1);
+            cut2h_pair(vv4.x * sc.v, vv4.y * sc.v, a0, a1); cut2h_pair(vv4.z * sc.v, vv4.w * sc.v, b0, b1);
+            *reinterpret_cast<uint2*>(sm.Vt[0] + off) = make_uint2(a0, b0);
+            *reinterpret_cast<uint2*>(sm.Vt[1] + off) = make_uint2(a1, b1);
+        } else {
+            const float xk[4] = {kv4.x, kv4.y, kv4.z, kv4.w}, xv[4] = {vv4.x, vv4.y, vv4.z, vv4.w};
+            uint32_t wk[4][3], wv[4][3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            *reinterpret_cast<uint2*>(sm.Kt[s] + off) = make_uint2(hi16_pair(wk[0][s], wk[1][s]), hi16_pair(wk[2][s], wk[3][s]));
-            *reinterpret_cast<uint2*>(sm.Vt[s] + off) = make_uint2(hi16_pair(wv[0][s], wv[1][s]), hi16_pair(wv[2][s], wv[3][s]));
+            for (int e = 0; e < 4; ++e) { cut3(xk[e], wk[e]); cut3(xv[e], wv[e]); }
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                *reinterpret_cast<uint2*>(sm.Kt[s] + off) = make_uint2(hi16_pair(wk[0][s], wk[1][s]), hi16_pair(wk[2][s], wk[3][s]));
+                *reinterpret_cast<uint2*>(sm.Vt[s] + off) = make_uint2(hi16_pair(wv[0][s], wv[1][s]), hi16_pair(wv[2][s], wv[3][s]));
+            }
         }
     }
     const int my_kl = valid_k ? kl[ktok] : INT_BIG_A;
     const int wave_kl_max = wave_max_i32(my_kl);
     const int wave_k_lo = k0 + sub * 32, wave_k_hi = wave_k_lo + 31;
     const float invS = 1.f / (float)S;
-    const float c2 = scale * 1.4426950408889634f;
+    // (H2: the products carry their operands' scales - folded into the constants that multiply them anyway)
+    const float c2 = scale * 1.4426950408889634f * (H2 ? sc.inv_qk : 1.f);
     const AttnDropout rng(p_drop, seed);
     const uint32_t bw = DROP ? rng.key_word((uint32_t)jk) : 0u;
-    const float sd = rng.scale;
+    const float cdp = H2 ? sc.inv_v * sc.inv_do : 1.f;     // dP = (dO' V'^T) cdp
+    const float sd = rng.scale * cdp;
     const uint32_t drop_head0 = (uint32_t)(((int64_t)b * nq + kvh * G) * S);
 
     const int n_qt = (S + 31) / 32;
@@ -891,14 +1017,24 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                 const float4 a = rq[g][jj], c = rdo[g][jj];
                 const float xa[4] = {ok ? a.x : 0.f, ok ? a.y : 0.f, ok ? a.z : 0.f, ok ? a.w : 0.f};
                 const float xc[4] = {ok ? c.x : 0.f, ok ? c.y : 0.f, ok ? c.z : 0.f, ok ? c.w : 0.f};
-                uint32_t wa[4][3], wc[4][3];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { cut3(xa[e], wa[e]); cut3(xc[e], wc[e]); }
                 const int off = sl_off(row, (f & 15) << 2);
+                if (H2) {
+                    uint32_t a0, a1, b0, b1;
+                    cut2h_pair(xa[0] * sc.q, xa[1] * sc.q, a0, a1); cut2h_pair(xa[2] * sc.q, xa[3] * sc.q, b0, b1);
+                    *reinterpret_cast<uint2*>(sm.Qs[g] + off) = make_uint2(a0, b0);
+                    *reinterpret_cast<uint2*>(sm.Qs[g] + SIMG + off) = make_uint2(a1, b1);
+                    cut2h_pair(xc[0] * sc.d_o, xc[1] * sc.d_o, a0, a1); cut2h_pair(xc[2] * sc.d_o, xc[3] * sc.d_o, b0, b1);
+                    *reinterpret_cast<uint2*>(sm.dOs[g] + off) = make_uint2(a0, b0);
+                    *reinterpret_cast<uint2*>(sm.dOs[g] + SIMG + off) = make_uint2(a1, b1);
+                } else {
+                    uint32_t wa[4][3], wc[4][3];
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    *reinterpret_cast<uint2*>(sm.Qs[g] + s * SIMG + off) = make_uint2(hi16_pair(wa[0][s], wa[1][s]), hi16_pair(wa[2][s], wa[3][s]));
-                    *reinterpret_cast<uint2*>(sm.dOs[g] + s * SIMG + off) = make_uint2(hi16_pair(wc[0][s], wc[1][s]), hi16_pair(wc[2][s], wc[3][s]));
+                    for (int e = 0; e < 4; ++e) { cut3(xa[e], wa[e]); cut3(xc[e], wc[e]); }
+#pragma unroll
+                    for (int s = 0; s < NP; ++s) {
+                        *reinterpret_cast<uint2*>(sm.Qs[g] + s * SIMG + off) = make_uint2(hi16_pair(wa[0][s], wa[1][s]), hi16_pair(wa[2][s], wa[3][s]));
+                        *reinterpret_cast<uint2*>(sm.dOs[g] + s * SIMG + off) = make_uint2(hi16_pair(wc[0][s], wc[1][s]), hi16_pair(wc[2][s], wc[3][s]));
+                    }
                 }
             }
         if (w < G) {
@@ -951,23 +1087,15 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
             const bool need_s = !before && !tile_all_empty;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const bf16x8 c0 = read_row8(dOh, lo, 0, s), c1 = read_row8(dOh + SIMG, lo, 0, s), c2p = read_row8(dOh + 2 * SIMG, lo, 0, s);
-                const bf16x8 v0 = read_row8(sm.Vt[0], lo, 32 * sub, s), v1 = read_row8(sm.Vt[1], lo, 32 * sub, s), v2 = read_row8(sm.Vt[2], lo, 32 * sub, s);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2p, v0, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, v1, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, v2, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, v0, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, v1, dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, v0, dp, 0, 0, 0);
+                bf16x8 cf[3], vf[3];
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) { cf[pc] = read_row8(dOh + pc * SIMG, lo, 0, s); vf[pc] = read_row8(sm.Vt[pc], lo, 32 * sub, s); }
+                dp = mfma_pieces<H2>(cf, vf, dp);
                 if (need_s) {
-                    const bf16x8 a0 = read_row8(Qh, lo, 0, s), a1 = read_row8(Qh + SIMG, lo, 0, s), a2 = read_row8(Qh + 2 * SIMG, lo, 0, s);
-                    const bf16x8 b0 = read_row8(sm.Kt[0], lo, 32 * sub, s), b1 = read_row8(sm.Kt[1], lo, 32 * sub, s), b2 = read_row8(sm.Kt[2], lo, 32 * sub, s);
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, st, 0, 0, 0);
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, st, 0, 0, 0);
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, st, 0, 0, 0);
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, st, 0, 0, 0);
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, st, 0, 0, 0);
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, st, 0, 0, 0);
+                    bf16x8 af[3], bfr[3];
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc) { af[pc] = read_row8(Qh + pc * SIMG, lo, 0, s); bfr[pc] = read_row8(sm.Kt[pc], lo, 32 * sub, s); }
+                    st = mfma_pieces<H2>(af, bfr, st);
                 }
             }
             // per element (query = register, key = lane):  P -> st (for dV, 1/(1-p) applied at the end),
@@ -1020,7 +1148,7 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                             dp[reg] = pe * fmaf(t, sd, ndl[e]);          // dS[query][key]
                             st[reg] = keep ? pe : 0.f;                   // dropped P[query][key] * (1 - p)
                         } else {
-                            dp[reg] = pe * (dp[reg] + ndl[e]);
+                            dp[reg] = pe * (H2 ? fmaf(dp[reg], cdp, ndl[e]) : dp[reg] + ndl[e]);
                             st[reg] = pe;
                         }
                     }
@@ -1050,24 +1178,17 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 bf16x8 pf[3], df[3];
-                cut8_regs(st, 8 * s2, pf[0], pf[1], pf[2]);
-                cut8_regs(dp, 8 * s2, df[0], df[1], df[2]);
+                cut8_regs_t<H2>(st, 8 * s2, H2Scales::P, pf);
+                cut8_regs_t<H2>(dp, 8 * s2, sc.ds, df);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const bf16x8 o0 = read_tr8(dOh, lo, 16 * s2, db), o1 = read_tr8(dOh + SIMG, lo, 16 * s2, db), o2 = read_tr8(dOh + 2 * SIMG, lo, 16 * s2, db);
-                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o0, pf[2], dvacc[db], 0, 0, 0);
-                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1, pf[1], dvacc[db], 0, 0, 0);
-                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o2, pf[0], dvacc[db], 0, 0, 0);
-                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o0, pf[1], dvacc[db], 0, 0, 0);
-                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o1, pf[0], dvacc[db], 0, 0, 0);
-                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o0, pf[0], dvacc[db], 0, 0, 0);
-                    const bf16x8 q0 = read_tr8(Qh, lo, 16 * s2, db), q1 = read_tr8(Qh + SIMG, lo, 16 * s2, db), q2 = read_tr8(Qh + 2 * SIMG, lo, 16 * s2, db);
-                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0, df[2], dkacc[db], 0, 0, 0);
-                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1, df[1], dkacc[db], 0, 0, 0);
-                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q2, df[0], dkacc[db], 0, 0, 0);
-                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0, df[1], dkacc[db], 0, 0, 0);
-                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1, df[0], dkacc[db], 0, 0, 0);
-                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0, df[0], dkacc[db], 0, 0, 0);
+                    bf16x8 of[3], qfr[3];
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc) of[pc] = read_tr8(dOh + pc * SIMG, lo, 16 * s2, db);
+                    dvacc[db] = mfma_pieces<H2>(of, pf, dvacc[db]);
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc) qfr[pc] = read_tr8(Qh + pc * SIMG, lo, 16 * s2, db);
+                    dkacc[db] = mfma_pieces<H2>(qfr, df, dkacc[db]);
                 }
             }
         }
@@ -1112,15 +1233,16 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
     if (hg == 0 && valid_k) {
         float* dkrow = dk + ktok * lddk + kvh * 64;
         float* dvrow = dv + ktok * lddv + kvh * 64;
-        const float vs = DROP ? sd : 1.f;
+        const float vs = (DROP ? rng.scale : 1.f) * (H2 ? sc.inv_do * H2Scales::INV_P : 1.f);
+        const float ks = scale * (H2 ? sc.inv_q * sc.inv_ds : 1.f);
         float vmax = 0.f;
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d = 32 * dh + 8 * g4 + 4 * h;
-                *reinterpret_cast<float4*>(dkrow + d) = make_float4(dkacc[dh][4 * g4] * scale, dkacc[dh][4 * g4 + 1] * scale,
-                                                                    dkacc[dh][4 * g4 + 2] * scale, dkacc[dh][4 * g4 + 3] * scale);
+                *reinterpret_cast<float4*>(dkrow + d) = make_float4(dkacc[dh][4 * g4] * ks, dkacc[dh][4 * g4 + 1] * ks,
+                                                                    dkacc[dh][4 * g4 + 2] * ks, dkacc[dh][4 * g4 + 3] * ks);
                 const float4 dv4 = make_float4(dvacc[dh][4 * g4] * vs, dvacc[dh][4 * g4 + 1] * vs,
                                                dvacc[dh][4 * g4 + 2] * vs, dvacc[dh][4 * g4 + 3] * vs);
                 *reinterpret_cast<float4*>(dvrow + d) = dv4;
@@ -1140,7 +1262,7 @@ static inline int worklist_grid_1(int n_pairs, int n_tiles) {
     return 8 * ppr * halves;
 }
 
-template <int G, bool DROP, bool ORD>
+template <int G, bool DROP, bool ORD, bool H2>
 __global__ void __launch_bounds__(256 * G, 1)
 attn_bwd_dkv_s_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                       const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
@@ -1149,7 +1271,8 @@ attn_bwd_dkv_s_kernel(const float* __restrict__ q, int ldq, const float* __restr
                       const int32_t* __restrict__ row_empty, const int32_t* __restrict__ tile_empty,
                       int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                       float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, const RowOrder ro,
-                      float* __restrict__ ds_out, uint32_t* __restrict__ amax_out) {
+                      float* __restrict__ ds_out, uint32_t* __restrict__ amax_out, const AttnAmax am) {
+    const H2Scales sc(H2 ? am.q : nullptr, am.k, am.v, am.d_o, 1.f, 1.f / (1.f - p_drop));
     const int n_tiles = (S + DKV_S_KEYS - 1) / DKV_S_KEYS;
     const WorkList wl(nbatch * nkv, n_tiles);
     if (!wl.valid) return;
@@ -1165,9 +1288,9 @@ attn_bwd_dkv_s_kernel(const float* __restrict__ q, int ldq, const float* __restr
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
-            attn_bwd_dkv_s_tile<G, DROP, ORD>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv,
+            attn_bwd_dkv_s_tile<G, DROP, ORD, H2>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv,
                                               scale, p_drop, seed, dk, lddk, dv, lddv, ro, pair, pass == 0 ? heavy : light, ds_out,
-                                              amax_out ? &amax_word : nullptr);
+                                              amax_out ? &amax_word : nullptr, sc);
         }
     }
     if (amax_out) {
@@ -1352,6 +1475,9 @@ constexpr int DQ3_THREADS = 512;          // two waves per SIMD: twice the dS ti
 
 // the sink armed for the entry point in progress (gamer_amax_sink): max |o| of the forward, max |dv| of the backward
 static thread_local uint32_t* t_amax_out = nullptr;
+// the operand maxima armed for the entry point in progress (gamer_attn_split_amax): non-null q selects the H2 form
+static thread_local AttnAmax t_attn_amax = {nullptr, nullptr, nullptr, nullptr};
+static thread_local AttnAmax g_attn_amax_armed = {nullptr, nullptr, nullptr, nullptr};
 
 template <int G>
 static int launch_fwd_s(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl,
@@ -1359,11 +1485,16 @@ static int launch_fwd_s(const float* q, int ldq, const float* k, int ldk, const 
                         float p_drop, uint64_t seed, float* o, float* lse, RowOrder ro, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
-#define GAMER_LAUNCH_FWD_S(DROPV, ORDV)                                                                                    \
-    hipLaunchKernelGGL((attn_fwd_s_kernel<G, DROPV, ORDV, false>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv,    \
-                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, S, t_amax_out)
-    if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD_S(true, true); else GAMER_LAUNCH_FWD_S(true, false); }
-    else { if (ro.perm) GAMER_LAUNCH_FWD_S(false, true); else GAMER_LAUNCH_FWD_S(false, false); }
+#define GAMER_LAUNCH_FWD_S(DROPV, ORDV, H2V)                                                                               \
+    hipLaunchKernelGGL((attn_fwd_s_kernel<G, DROPV, ORDV, false, H2V>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, \
+                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, S, t_amax_out, t_attn_amax)
+    if (t_attn_amax.q) {
+        if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD_S(true, true, true); else GAMER_LAUNCH_FWD_S(true, false, true); }
+        else { if (ro.perm) GAMER_LAUNCH_FWD_S(false, true, true); else GAMER_LAUNCH_FWD_S(false, false, true); }
+    } else {
+        if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD_S(true, true, false); else GAMER_LAUNCH_FWD_S(true, false, false); }
+        else { if (ro.perm) GAMER_LAUNCH_FWD_S(false, true, false); else GAMER_LAUNCH_FWD_S(false, false, false); }
+    }
 #undef GAMER_LAUNCH_FWD_S
     GAMER_CHECK_LAUNCH("gamer_attn_fwd_split");
     return 0;
@@ -1376,31 +1507,42 @@ static int launch_bwd_s_variant(const float* q, int ldq, const float* k, int ldk
                                 float scale, float p_drop, uint64_t seed, float* dq, int lddq, float* dk, int lddk,
                                 float* dv, int lddv, RowOrder ro, int delta_ready, float* ds_work, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
+    const bool h2 = t_attn_amax.q != nullptr;       // gamer_attn_split_amax: the three-product fp16 form (recompute form only)
     if (ds_work == nullptr) {
-        hipLaunchKernelGGL((attn_bwd_dq_s_kernel<G, DROP, ORD, false>), dim3(worklist_grid(B * nkv, (S + R - 1) / R)),
-                           dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv,
-                           scale, p_drop, seed, dq, lddq, ro, delta_ready);
+        if (h2)
+            hipLaunchKernelGGL((attn_bwd_dq_s_kernel<G, DROP, ORD, false, true>), dim3(worklist_grid(B * nkv, (S + R - 1) / R)),
+                               dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv,
+                               scale, p_drop, seed, dq, lddq, ro, delta_ready, t_attn_amax);
+        else
+            hipLaunchKernelGGL((attn_bwd_dq_s_kernel<G, DROP, ORD, false, false>), dim3(worklist_grid(B * nkv, (S + R - 1) / R)),
+                               dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv,
+                               scale, p_drop, seed, dq, lddq, ro, delta_ready, t_attn_amax);
         GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dq");
     } else if (!delta_ready) {
         hipLaunchKernelGGL(attn_delta_s_kernel, dim3(2048), dim3(AT_THREADS), 0, st, o, d_o, B, S, nq, delta);
         GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/delta");
     }
-    const size_t shmem = sizeof(DkvSmemS<G>);
-    static bool attr_dev[MAX_DEVICES] = {};   // one set of flags per template instantiation, one flag per device
-    bool& attr_set = attr_dev[current_device()];
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_s_kernel<G, DROP, ORD>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) {
-            set_error("gamer_attn_bwd_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return (int)e;
-        }
-        attr_set = true;
-    }
     const int n_kt = (S + DKV_S_KEYS - 1) / DKV_S_KEYS;
-    hipLaunchKernelGGL((attn_bwd_dkv_s_kernel<G, DROP, ORD>), dim3(worklist_grid_1(B * nkv, n_kt)), dim3(256 * G), shmem, st, q, ldq,
-                       k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk,
-                       lddk, dv, lddv, ro, ds_work, t_amax_out);
+    auto launch_dkv = [&]<bool H2V>() -> int {
+        const size_t shmem = sizeof(DkvSmemS<G, H2V ? 2 : 3>);
+        static bool attr_dev[MAX_DEVICES] = {};   // one set of flags per template instantiation, one flag per device
+        bool& attr_set = attr_dev[current_device()];
+        if (!attr_set) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_s_kernel<G, DROP, ORD, H2V>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            if (e != hipSuccess) {
+                set_error("gamer_attn_bwd_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                return (int)e;
+            }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_dkv_s_kernel<G, DROP, ORD, H2V>), dim3(worklist_grid_1(B * nkv, n_kt)), dim3(256 * G), shmem, st, q, ldq,
+                           k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dk,
+                           lddk, dv, lddv, ro, ds_work, t_amax_out, t_attn_amax);
+        return 0;
+    };
+    const int rc_dkv = h2 ? launch_dkv.template operator()<true>() : launch_dkv.template operator()<false>();
+    if (rc_dkv) return rc_dkv;
     GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dkv");
     if (ds_work != nullptr) {
         hipLaunchKernelGGL((attn_bwd_dq2_s_kernel<G, ORD>), dim3(worklist_grid(B * nkv, (S + R - 1) / R)), dim3(AT_THREADS), 0, st,
@@ -1454,10 +1596,19 @@ extern "C" int gamer_attn_fwd_split(const float* q, int ldq, const float* k, int
     GAMER_CHECK_ARG(o && lse && aligned16(o), "gamer_attn_fwd_split: null/unaligned output");
     hipStream_t st = (hipStream_t)stream;
     t_amax_out = take_amax_sink().out[0];               // gamer_amax_sink: max |o|
+    t_attn_amax = g_attn_amax_armed;                    // gamer_attn_split_amax: the three-product fp16 form
+    g_attn_amax_armed = AttnAmax{nullptr, nullptr, nullptr, nullptr};
+    GAMER_CHECK_ARG(!t_attn_amax.q || (t_attn_amax.k && t_attn_amax.v), "gamer_attn_fwd_split: gamer_attn_split_amax needs q, k and v");
     rc = (nq / nkv == 1) ? launch_fwd_s<1>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st)
                          : launch_fwd_s<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st);
     t_amax_out = nullptr;
+    t_attn_amax = AttnAmax{nullptr, nullptr, nullptr, nullptr};
     return rc;
+}
+
+extern "C" int gamer_attn_split_amax(const uint32_t* q, const uint32_t* k, const uint32_t* v, const uint32_t* d_o) {
+    g_attn_amax_armed = AttnAmax{q, k, v, d_o};
+    return 0;
 }
 
 extern "C" int gamer_attn_bwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
@@ -1477,9 +1628,14 @@ extern "C" int gamer_attn_bwd_split(const float* q, int ldq, const float* k, int
                     "gamer_attn_bwd_split: gradient buffers must be 16-byte aligned with leading dims %% 4 == 0");
     hipStream_t st = (hipStream_t)stream;
     t_amax_out = take_amax_sink().out[0];               // gamer_amax_sink: max |dv|
+    t_attn_amax = g_attn_amax_armed;
+    g_attn_amax_armed = AttnAmax{nullptr, nullptr, nullptr, nullptr};
+    GAMER_CHECK_ARG(!t_attn_amax.q || (t_attn_amax.k && t_attn_amax.v && t_attn_amax.d_o && !ds_work),
+                    "gamer_attn_bwd_split: gamer_attn_split_amax needs q, k, v and d_o, and the recompute form (ds_work = NULL)");
     rc = (nq / nkv == 1)
         ? launch_bwd_s<1>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, ds_work, st)
         : launch_bwd_s<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, ds_work, st);
     t_amax_out = nullptr;
+    t_attn_amax = AttnAmax{nullptr, nullptr, nullptr, nullptr};
     return rc;
 }

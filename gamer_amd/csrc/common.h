@@ -48,6 +48,8 @@ constexpr int WAVE = 64;
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef float f32x8v __attribute__((ext_vector_type(8)));
 
@@ -82,6 +84,16 @@ template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = 
 template <typename T> __device__ __forceinline__ float round_as(float v) { return (float)(T)v; }
 template <typename T> static inline bool aligned_vec4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(T) - 1)) == 0; }
 
+// the scale of a tensor from the bits of its largest magnitude (a non-negative float): max * s in [2^13, 2^14); 1 for a
+// zero, denormal, infinite or NaN maximum (Inf / NaN then reach the MFMA as they are).  inv = 1 / s, exact.
+__device__ __forceinline__ void scale_from_amax(uint32_t bits, float& s, float& inv) {
+    const int e = (int)((bits >> 23) & 0xffu);
+    int se = 127 + 13 - (e - 127);
+    if (e == 0 || e == 255) se = 127;
+    se = se < 1 ? 1 : (se > 253 ? 253 : se);
+    s = __uint_as_float((uint32_t)se << 23);
+    inv = __uint_as_float((uint32_t)(254 - se) << 23);
+}
 // ---- maxima of what a kernel stores (matmul = "split3": the consumer GEMM scales its operand by a power of two from it) ----
 // gamer_amax_sink(out0, out1) arms the NEXT launch (on the calling host thread) of a kernel that supports it: that kernel folds
 // the bits of max |value stored| of its first / second output into *out0 / *out1 (atomicMax; the words hold 0 or an earlier

@@ -101,8 +101,6 @@ __device__ __forceinline__ void store_rc_split(unsigned char* __restrict__ lds, 
     }
 }
 // ---- SPLIT == 3: two fp16 pieces of x * s (s = the tensor's power-of-two scale); images 0 and 1 of the three-image layouts
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split2h_quad(const float4& v, float s, uint2 (&img)[2]) {
     const float tx = v.x * s, ty = v.y * s, tz = v.z * s, tw = v.w * s;
     const f16x2 a0 = {(_Float16)tx, (_Float16)ty}, a1 = {(_Float16)tz, (_Float16)tw};          // v_cvt_pk_f16_f32 (nearest even)
@@ -132,16 +130,6 @@ __device__ __forceinline__ void store_rc_h2(unsigned char* __restrict__ lds, int
 #pragma unroll
         for (int q = 0; q < 2; ++q) *reinterpret_cast<uint2*>(dst + q * SP_RC_IMG) = img[q];
     }
-}
-// the scale of a tensor from the bits of its largest magnitude (a non-negative float): max * s in [2^13, 2^14); 1 for a
-// zero, denormal, infinite or NaN maximum (Inf / NaN then reach the MFMA as they are).  inv = 1 / s, exact.
-__device__ __forceinline__ void scale_from_amax(uint32_t bits, float& s, float& inv) {
-    const int e = (int)((bits >> 23) & 0xffu);
-    int se = 127 + 13 - (e - 127);
-    if (e == 0 || e == 255) se = 127;
-    se = se < 1 ? 1 : (se > 253 ? 253 : se);
-    s = __uint_as_float((uint32_t)se << 23);
-    inv = __uint_as_float((uint32_t)(254 - se) << 23);
 }
 // ---- two-stage form (SP_TWO_STAGE): K-steps of 16, each stage = both operands' three images of a 128 x 16 slice.  A KC image
 // row is 32 B of k + 16 B of padding (48-byte rows: the 16-byte fragment reads of 16 consecutive rows fall on distinct banks),

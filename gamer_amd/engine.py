@@ -418,6 +418,9 @@ class Engine:
         if dtype == "f32" and matmul != "f32" and os.environ.get("GAMER_SPLIT_PLANES", "0") == "1":
             self.weight_planes = torch.zeros(3, _round_up(n, 4), dtype=torch.bfloat16, device=self.device)
         # matmul="split3": the per-tensor maxima its GEMMs scale their operands by; the parameters keep theirs for a whole pass
+        # matmul="split3": the attention products in the three-product fp16 form as well (gamer_attn_split_amax); False keeps
+        # them in the six-product bf16 form
+        self.h2_attention = os.environ.get("GAMER_H2_ATTENTION", "1") != "0"
         self._amax = None
         if dtype == "f32" and matmul == "split3":
             self._amax = ops.amax_reuse()
@@ -607,7 +610,7 @@ class Engine:
         def attention(qb, kb, vb, kl_, ql_, empty_, tile_empty_, seed_, ob, lseb, order_, span_):
             if split_attn and span_ is None:
                 ops.attn_fwd_split(qb, NQ, kb, NKV, vb, QKV, kl_, ql_, empty_, B, S, nq, nkv, scale, p_att, seed_, ob, lseb,
-                                   order=order_)
+                                   order=order_, h2=self.h2_attention and self.matmul == "split3")
             elif bf16:
                 ord16 = (order_[0], order_[2], empty_) if (order_ is not None and span_ is None) else None
                 ops.attn_fwd_bf16(qb, NQ, kb, NKV, vb, QKV, kl_, ql_, B, S, nq, nkv, scale, p_att, seed_, ob, lseb,
@@ -796,7 +799,8 @@ class Engine:
             if split_attn and span_ is None:
                 ops.attn_bwd_split(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, empty_, tile_empty_, B, S, nq, nkv, scale,
                                    p_att, seed_, ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, order=order_,
-                                   delta_ready=fuse_delta, dv_of=ws.dqkv)   # recompute form: measured faster than its dS spill
+                                   delta_ready=fuse_delta, dv_of=ws.dqkv,   # recompute form: measured faster than its dS spill
+                                   h2=self.h2_attention and self.matmul == "split3")
             elif bf16:
                 ord16 = (order_[0], order_[2], empty_) if (order_ is not None and span_ is None) else None
                 ops.attn_bwd_bf16(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, B, S, nq, nkv, scale, p_att, seed_,

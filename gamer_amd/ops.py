@@ -647,9 +647,21 @@ def attn_bwd(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty,
          1 if (delta_ready and ds_work is not None) else 0, stream_ptr())
 
 
-def attn_fwd_split(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, order=None):
-    """gamer_attn_fwd with its products on the bf16 pipe (exact three-way cuts, six piece products); training semantics."""
+def attn_operand_maxima(q, ldq, k, ldk, v, ldv, T, nq, nkv, d_o=None):
+    """Slots with the maxima of the attention operands (the three-product fp16 form): measured here unless their producers
+    left them in the cache in effect (ops.amax_reuse)."""
+    sl = [absmax_slot(q, 1, 0, T, nq * 64, ldq), absmax_slot(k, 1, 0, T, nkv * 64, ldk), absmax_slot(v, 1, 0, T, nkv * 64, ldv)]
+    sl.append(absmax_slot(d_o, 1, 0, T, nq * 64, nq * 64) if d_o is not None else None)
+    return sl
+
+
+def attn_fwd_split(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, order=None,
+                   h2=False):
+    """gamer_attn_fwd with its products on the 16-bit matrix pipe; training semantics.  h2 = False: exact three-way bf16
+    cuts, six piece products; h2 = True: two-way fp16 cuts scaled per tensor, three piece products (gamer_attn_split_amax)."""
     pm, tk, tm = order if order is not None else (None, None, None)
+    if h2:
+        call("gamer_attn_split_amax", *attn_operand_maxima(q, ldq, k, ldk, v, ldv, B * S, nq, nkv))
     if _AMAX_ATTN:
         _arm_sink((o, (1, 0, 1, B * S * nq * 64, B * S * nq * 64), False))
     call("gamer_attn_fwd_split", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(kl), ptr(ql), ptr(row_empty), B, S, nq, nkv,
@@ -657,11 +669,13 @@ def attn_fwd_split(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, sca
 
 
 def attn_bwd_split(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed,
-                   delta, dq, lddq, dk, lddk, dv, lddv, order=None, delta_ready=False, ds_work=None, dv_of=None):
+                   delta, dq, lddq, dk, lddk, dv, lddv, order=None, delta_ready=False, ds_work=None, dv_of=None, h2=False):
     """gamer_attn_bwd with its products on the bf16 pipe; delta_ready: `delta` already holds dO.O; ds_work: the dS spill
     scratch of attn_bwd (None = recompute form); dv_of: the d(q|k|v) tensor whose v columns `dv` is (its maximum is then
     collected by the kernels that write it: this one and qknorm_rope_bwd)."""
     pm, tk, tm = order if order is not None else (None, None, None)
+    if h2:           # the three-product fp16 form (see attn_fwd_split)
+        call("gamer_attn_split_amax", *attn_operand_maxima(q, ldq, k, ldk, v, ldv, B * S, nq, nkv, d_o=d_o))
     if dv_of is not None and _AMAX_ATTN:
         _arm_sink((dv_of, (1, 0, dv_of.shape[0], dv_of.shape[1], dv_of.stride(0)), False))
     call("gamer_attn_bwd_split", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), ptr(d_o), ptr(lse), ptr(kl), ptr(ql),

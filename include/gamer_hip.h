@@ -245,6 +245,12 @@ int gamer_absmax_f32(const float* x, int batch, int64_t stride, int rows, int co
  * (atomicMax; words hold 0 or an earlier maximum; NULL = none) and the launch disarms the sink.  Any other launch in between
  * leaves it armed.  Saves the separate pass of gamer_absmax_f32 over the tensor. */
 int gamer_amax_sink(uint32_t* out0, uint32_t* out1);
+/* gamer_attn_split_amax(q, k, v, d_o) arms the next gamer_attn_fwd_split / gamer_attn_bwd_split on the calling host thread to form
+ * its products in the three-product fp16 form of gamer_gemm_f32_split(terms = 3): q, k, v (d_o: backward; NULL in the forward)
+ * are device words holding the bits of max |.| of those operand tensors; P is scaled by 2^13, dS by a bound derived from the
+ * maxima.  Same results within the forms' tolerances (tests/test_ops_gpu.py runs the attention grid in this form at the same
+ * bars); not armed = the six-product bf16 form. */
+int gamer_attn_split_amax(const uint32_t* q, const uint32_t* k, const uint32_t* v, const uint32_t* d_o);
 /* planes[s * plane_stride + i] = piece s (s = 0, 1, 2) of x[i] under the exact three-way cut above (n % 4 == 0,
  * plane_stride % 4 == 0, 16-byte aligned x, 8-byte aligned planes): the `b_planes` operand of gamer_gemm_f32_split.  The
  * engine cuts its fp32 master parameters once per step with it (98 MB read, 147 MB written). */

@@ -599,10 +599,11 @@ def _run_attn(batch, cross, B, S, nq, nkv, p_drop=0.0, seed=1234, q=None, k=None
     o = torch.empty(T, nq * 64, device=DEV)
     lse = torch.empty(B, nq, S, device=DEV)
     dq_, dk_ = dev(q.reshape(T, -1)), dev(k.reshape(T, -1))
-    split = spill in ("split", "split_spill")        # the same attention with its products on the bf16 pipe (gamer_attn_*_split)
+    split = spill in ("split", "split_spill", "split_h2")   # the same attention with its products on the 16-bit pipe (gamer_attn_*_split)
+    h2 = spill == "split_h2"                          # ... in the three-product fp16 form
     if split:
         ops.attn_fwd_split(dq_, nq * 64, dk_, nkv * 64, vview, ldv, kl, ql, re_, B, S, nq, nkv, 0.125, p_drop, seed, o, lse,
-                           order=order)
+                           order=order, h2=h2)
     else:
         ops.attn_fwd(dq_, nq * 64, dk_, nkv * 64, vview, ldv, kl, ql, re_, te, B, S, nq, nkv, 0.125, p_drop, seed, o, lse,
                      order=order)
@@ -618,7 +619,7 @@ def _run_attn(batch, cross, B, S, nq, nkv, p_drop=0.0, seed=1234, q=None, k=None
                        if spill == "split_spill" else None)
             ops.attn_bwd_split(dq_, nq * 64, dk_, nkv * 64, vview, ldv, o, dev(d_o.reshape(T, -1)), lse, kl, ql, re_, te, B, S,
                                nq, nkv, 0.125, p_drop, seed, delta, dq, nq * 64, dk, nkv * 64, dvv, ldv, order=order,
-                               ds_work=ds_work)
+                               ds_work=ds_work, h2=h2)
         else:
             ds_work = torch.full((ops.attn_ds_work_numel(B, S, nq),), float("nan"), device=DEV) if spill else None
             ops.attn_bwd(dq_, nq * 64, dk_, nkv * 64, vview, ldv, o, dev(d_o.reshape(T, -1)), lse, kl, ql, re_, te, B, S, nq,
@@ -627,7 +628,7 @@ def _run_attn(batch, cross, B, S, nq, nkv, p_drop=0.0, seed=1234, q=None, k=None
     return res
 
 
-@pytest.mark.parametrize("spill", [False, True, "split", "split_spill"])
+@pytest.mark.parametrize("spill", [False, True, "split", "split_spill", "split_h2"])
 @pytest.mark.parametrize("use_order", [False, True])
 @pytest.mark.parametrize("cross", [False, True])
 @pytest.mark.parametrize("n_items,B,nq,nkv", [(7, 3, 2, 1), (14, 2, 2, 1), (20, 2, 2, 1), (101, 2, 2, 1), (101, 11, 6, 3),
@@ -689,7 +690,7 @@ def test_attention_left_padding_empty_self_rows():
     assert int(empty.sum()) == 15
     (o_ref * d_o.double()).sum().backward()
     T = B * S
-    for form in (False, "split", "split_spill"):
+    for form in (False, "split", "split_spill", "split_h2"):
         for use_order in (False, True):
             res = _run_attn(batch, False, B, S, nq, nkv, q=q, k=k, v=v, d_o=d_o, use_order=use_order, spill=form)
             assert _rel(res["o"], o_ref.reshape(B * S, -1)) < 2e-5
@@ -699,7 +700,7 @@ def test_attention_left_padding_empty_self_rows():
         assert _rel(res["dv"], leaves[2].grad.reshape(T, -1)) < 5e-5
 
 
-@pytest.mark.parametrize("spill", [False, True, "split", "split_spill"])
+@pytest.mark.parametrize("spill", [False, True, "split", "split_spill", "split_h2"])
 @pytest.mark.parametrize("use_order", [False, True])
 @pytest.mark.parametrize("cross", [False, True])
 def test_attention_dropout_mask_consistent_fwd_bwd(cross, use_order, spill):
