@@ -360,8 +360,11 @@ qknorm_rope_fwd_kernel(TA* __restrict__ qkv, int T, int S, int nq, int nkv,
                        const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                        const float* __restrict__ bias_q, const float* __restrict__ bias_k,
                        const float* __restrict__ bias_v, const int32_t* __restrict__ act_idx,
-                       TA* __restrict__ q_rot, TA* __restrict__ k_rot, const int32_t* __restrict__ pos_ids) {
+                       TA* __restrict__ q_rot, TA* __restrict__ k_rot, const int32_t* __restrict__ pos_ids,
+                       uint32_t* __restrict__ amax_q, uint32_t* __restrict__ amax_k) {
     constexpr bool F32 = sizeof(TA) == 4;
+    __shared__ uint32_t amax_lds[2][4];
+    uint32_t amq = 0, amk = 0;                          // gamer_amax_sink: max |q_rot|, max |k_rot|
     const int lane = threadIdx.x & 63;
     const int g = lane & 15, sub = lane >> 4;
     const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
@@ -409,8 +412,8 @@ qknorm_rope_fwd_kernel(TA* __restrict__ qkv, int T, int S, int nq, int nkv,
             o.x = y.x * c4.x + sgn * pr.x * s4.x; o.y = y.y * c4.y + sgn * pr.y * s4.y;
             o.z = y.z * c4.z + sgn * pr.z * s4.z; o.w = y.w * c4.w + sgn * pr.w * s4.w;
             if (live) {
-                if (isq) st4(q_rot + (int64_t)t * nq * 64 + hd * 64 + 4 * g, o);
-                else st4(k_rot + (int64_t)t * nkv * 64 + (hd - nq) * 64 + 4 * g, o);
+                if (isq) { st4(q_rot + (int64_t)t * nq * 64 + hd * 64 + 4 * g, o); amq = amax_f4(amq, o); }
+                else { st4(k_rot + (int64_t)t * nkv * 64 + (hd - nq) * 64 + 4 * g, o); amk = amax_f4(amk, o); }
             }
         } else {
             // (only reached when cross) v += bias_v; the shuffles above are skipped by the whole 16-lane group
@@ -422,6 +425,8 @@ qknorm_rope_fwd_kernel(TA* __restrict__ qkv, int T, int S, int nq, int nkv,
             if (live) st4(dst, x);
         }
     }
+    amax_block_commit(amq, amax_q, amax_lds[0]);
+    amax_block_commit(amk, amax_k, amax_lds[1]);
 }
 
 // Each wave keeps one head for its whole life so that the norm-weight and bias gradients accumulate in
@@ -1283,9 +1288,10 @@ static int qknorm_rope_fwd_impl(const char* name, TA* qkv, int T, int S, int nq,
                            ST(stream), qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot,
                            k_rot, pos_ids);
     } else {
+        const AmaxSink sink = take_amax_sink();
         hipLaunchKernelGGL(qknorm_rope_fwd_kernel<TA>, dim3(grid_for_waves(((int64_t)T * NH + 3) / 4)), dim3(EW_THREADS), 0,
                            ST(stream), qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot,
-                           k_rot, pos_ids);
+                           k_rot, pos_ids, sink.out[0], sink.out[1]);
     }
     GAMER_CHECK_LAUNCH(name);
     return 0;

@@ -551,6 +551,9 @@ class Engine:
             self._amax.reset()
             if train:       # (the evaluation workspace shares one set of buffers between the layers: nothing is stable there)
                 self._amax.stable(ws.xn, *[A[k] for A in ws.layers for k in ("h1", "h2", "ao", "ao_c", "hin", "hm") if k in A])
+                if self.h2_attention:       # the attention operands saved for the backward: q, k (after norm + RoPE) and the v columns
+                    self._amax.stable(*[A[k] for A in ws.layers for k in ("q", "k", "q_c", "k_c") if k in A],
+                                      *[A[k][:, NQ + NKV:] for A in ws.layers for k in ("qkv", "qkv_c") if k in A])
         ids = input_ids.to(self.device, torch.int64).contiguous()
         am = attention_mask.to(self.device, torch.int64).contiguous() if attention_mask is not None else None
         act = actions.to(self.device, torch.int64).contiguous() if actions is not None else None

@@ -598,6 +598,7 @@ def qknorm_rope_fwd(qkv, S, nq, nkv, wq, wk, eps, cos_t, sin_t, q_rot, k_rot, bi
                     act_idx=None, pos_ids=None):
     """pos_ids: int32 [T] RoPE table row per token (session model); None = position in the sequence."""
     T = qkv.shape[0]
+    _arm_sink((q_rot, (1, 0, T, nq * 64, nq * 64), False), (k_rot, (1, 0, T, nkv * 64, nkv * 64), False))
     call("gamer_qknorm_rope_fwd" + _sfx(qkv), ptr(qkv), T, S, nq, nkv, ptr(wq), ptr(wk), eps, ptr(cos_t), ptr(sin_t),
          ptr(bias_q), ptr(bias_k), ptr(bias_v), ptr(act_idx), ptr(q_rot), ptr(k_rot), ptr(pos_ids), stream_ptr())
 

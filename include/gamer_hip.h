@@ -241,7 +241,8 @@ int gamer_absmax_f32(const float* x, int batch, int64_t stride, int rows, int co
 /* The same maximum as a by-product of the kernel that WRITES the tensor: gamer_amax_sink(out0, out1) arms the next launch - on
  * the calling host thread - of one of gamer_rmsnorm_fwd (y), gamer_rowtable_fwd (the columns it writes), gamer_swiglu_fwd (hm),
  * gamer_swiglu_bwd (out0: d gate, out1: d up), gamer_silu_gate_bwd (out0: da, out1: dgate), gamer_rmsnorm_bwd (mask_out),
- * gamer_ce_bwd (d logits) [fp32 and bf16 entry points]: the kernel folds the bits of max |value it stores| into *out0 / *out1
+ * gamer_ce_bwd (d logits), gamer_qknorm_rope_fwd (out0: q_rot, out1: k_rot; fp32), gamer_attn_fwd_split (o), gamer_attn_bwd_split
+ * (dv), gamer_qknorm_rope_bwd (dq, dk; fp32): the kernel folds the bits of max |value it stores| into *out0 / *out1
  * (atomicMax; words hold 0 or an earlier maximum; NULL = none) and the launch disarms the sink.  Any other launch in between
  * leaves it armed.  Saves the separate pass of gamer_absmax_f32 over the tensor. */
 int gamer_amax_sink(uint32_t* out0, uint32_t* out1);
