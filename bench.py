@@ -372,8 +372,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--matmul", choices=["f32", "split3", "split6", "split9"], default=None,
                     help="how fp32 matrix products are formed (--dtype f32 only; default split3, the engine's default): "
-                         "split3 = Linear products from a two-way fp16 cut of both operands scaled per tensor, 3 piece products "
-                         "(attention as split6); split6 / split9 = every fp32 product from an exact three-way bf16 cut of both operands, 6 / 9 piece "
+                         "split3 = every fp32 product from a two-way fp16 cut of both operands scaled per tensor, 3 piece products; "
+                         "split6 / split9 = every fp32 product from an exact three-way bf16 cut of both operands, 6 / 9 piece "
                          "products on the bf16 pipe, fp32 accumulation (gamer_gemm_f32_split, gamer_attn_*_split; error against "
                          "fp64 at the fp32 MFMA's level, DESIGN.md section 13); f32 = v_mfma_f32_32x32x2_f32 throughout")
     ap.add_argument("--kernel-rows", type=int, default=12, help="rows of the per-family kernel table in the JSON line")
@@ -611,9 +611,10 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
         ms_per_step = elapsed / args.steps * 1e3
         # (prefixes: the kernel's template list ends with the matmul form, ", 0>" = fp32 MFMA)
         split_terms = {"f32": 0, "split3": 3, "split6": 6, "split9": 9}[args.matmul]
-        kname = {"gemm_fwd": f"gemm_f32_kernel<true, true, 0, false, false, 2, 0, {split_terms}>",
-                 "gemm_dgrad": f"gemm_f32_kernel<true, false, 0, false, false, 2, 0, {split_terms}>",
-                 "gemm_wgrad": f"gemm_f32_kernel<false, false, 1, false, false, 2, 0, {split_terms}>"}.get(dom["kernel"] if dom else "", None)
+        # (substring match: the template list continues with the ping-pong flag)
+        kname = {"gemm_fwd": f"gemm_f32_kernel<true, true, 0, false, false, 2, 0, {split_terms},",
+                 "gemm_dgrad": f"gemm_f32_kernel<true, false, 0, false, false, 2, 0, {split_terms},",
+                 "gemm_wgrad": f"gemm_f32_kernel<false, false, 1, false, false, 2, 0, {split_terms},"}.get(dom["kernel"] if dom else "", None)
         if args.dtype != "f32":
             kname = None
         # HBM bytes per launch from a committed PMC profile of THIS workload (shape / dtype / matmul form checked)
@@ -646,9 +647,9 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
                              f"synthetic ids, per-GPU batch {args.batch} x {args.items * 5} tokens"
                              + (" ragged" if args.ragged else "") + ", V=1041, " +
                              ("fp32" if args.dtype == "f32" else "bf16 AMP (fp32 master weights / gradients / moments)") +
-                             (" tensors and accumulation; Linear products formed as 3 fp16 piece products of a two-way cut of both "
-                              "operands scaled per tensor by a power of two, attention products as 6 exact bf16 piece products of a "
-                              "three-way cut (error vs fp64 at or below the fp32 MFMA's)" if split_terms == 3 else
+                             (" tensors and accumulation; every fp32 matrix product (Linear and attention) formed as 3 fp16 piece "
+                              "products of a two-way cut of both operands, each operand tensor scaled by a power of two from its "
+                              "largest magnitude (error vs fp64 at or below the fp32 MFMA's)" if split_terms == 3 else
                               f" tensors and accumulation; every fp32 matrix product (Linear and attention) formed as {split_terms} "
                               "exact bf16 piece products of a three-way cut of both operands (error vs fp64 at the fp32 MFMA's "
                               "level)" if split_terms else (" on the fp32 MFMA" if args.dtype == "f32" else ""))),

@@ -355,7 +355,8 @@ class Engine:
         gamer_attn_bwd_split, csrc/attention_split.hip; ``self.split_attention = False`` keeps them on the fp32 MFMA).
         "split3" (the default) = the Linear sites as THREE fp16 piece products of a two-way cut of both operands, each
         operand tensor scaled by a power of two from its largest magnitude (gamer_absmax_f32) - the
-        same error against fp64 at half the matrix instructions; the attention products as in "split6"."""
+        same error against fp64 at half the matrix instructions; the attention products take the same three-product form
+        (``self.h2_attention = False`` keeps them in the six-product bf16 form)."""
         cfg.validate()
         if matmul is None:
             # default of the fp32 path: products on the 16-bit matrix pipe from piece cuts (DESIGN.md sections 13, 15, 17);
