@@ -208,14 +208,16 @@ struct H2Scales {
         q = k = v = d_o = ds = inv_q = inv_k = inv_v = inv_do = inv_ds = inv_qk = 1.f;
         if (aq) {
             // q enters its products multiplied by q_prescale (the softmax scale, log2 domain): scale that product's maximum
-            const uint32_t qb = __float_as_uint(__uint_as_float(aq[0]) * q_prescale);
+            const uint32_t mv = amax_read(av);
+            const uint32_t qb = __float_as_uint(__uint_as_float(amax_read(aq)) * q_prescale);
             scale_from_amax(qb, q, inv_q);
-            scale_from_amax(ak[0], k, inv_k);
-            scale_from_amax(av[0], v, inv_v);
+            scale_from_amax(amax_read(ak), k, inv_k);
+            scale_from_amax(mv, v, inv_v);
             if (ado) {
-                scale_from_amax(ado[0], d_o, inv_do);
+                const uint32_t mdo = amax_read(ado);
+                scale_from_amax(mdo, d_o, inv_do);
                 // dS = p (mult dP - delta), p <= 1, |dP| <= 64 max|dO| max|V|, |delta| <= 64 max|dO| max|O|, |O| <= mult max|V|
-                const float bound = 128.f * drop_scale * __uint_as_float(ado[0]) * __uint_as_float(av[0]);
+                const float bound = 128.f * drop_scale * __uint_as_float(mdo) * __uint_as_float(mv);
                 scale_from_amax(__float_as_uint(bound), ds, inv_ds);
             }
             inv_qk = inv_q * inv_k;
@@ -570,8 +572,7 @@ attn_fwd_s_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
     }
     if (amax_out) {
         __syncthreads();
-        if (threadIdx.x == 0 && amax_word > __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(amax_out, amax_word);
+        if (threadIdx.x == 0 && amax_word) amax_publish(amax_word, amax_out, blockIdx.x);
     }
 }
 
@@ -1295,8 +1296,7 @@ attn_bwd_dkv_s_kernel(const float* __restrict__ q, int ldq, const float* __restr
     }
     if (amax_out) {
         __syncthreads();
-        if (threadIdx.x == 0 && amax_word > __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(amax_out, amax_word);
+        if (threadIdx.x == 0 && amax_word) amax_publish(amax_word, amax_out, blockIdx.x);
     }
 }
 

@@ -108,9 +108,24 @@ __device__ __forceinline__ uint32_t amax_f4(uint32_t m, const float4 v) {
     f = fmaxf(fmaxf(f, fabsf(v.z)), fabsf(v.w));
     return __float_as_uint(f);
 }
-// every thread of a 256-thread workgroup calls this once, at the end of the kernel (out is workgroup-uniform); one atomic per
-// workgroup, and none when the word already holds a larger value (read at agent scope: the atomics execute at the memory side,
-// an XCD's L2 may hold an older copy)
+// A maximum lives in AMAX_WAYS words, AMAX_STRIDE words apart (one 64-byte line each): a launch's workgroups publish into the
+// word of their index modulo AMAX_WAYS - thousands of same-address atomics serialise at the memory side (20 us for the first
+// resident wave of workgroups of a 25-us kernel at per-GPU batch 128) -, a consumer takes the maximum of the words.
+constexpr int AMAX_WAYS = 16, AMAX_STRIDE = 16;
+__device__ __forceinline__ uint32_t amax_read(const uint32_t* __restrict__ p) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < AMAX_WAYS; ++i) m = max(m, p[AMAX_STRIDE * i]);
+    return m;
+}
+// (no atomic when the word already holds more; read at agent scope: the atomics execute at the memory side, an XCD's L2 may
+// hold an older copy)
+__device__ __forceinline__ void amax_publish(uint32_t m, uint32_t* __restrict__ out, uint32_t way) {
+    uint32_t* w = out + AMAX_STRIDE * (way & (AMAX_WAYS - 1));
+    if (m > __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(w, m);
+}
+// every thread of a 256-thread workgroup calls this once, at the end of the kernel (out is workgroup-uniform); at most one
+// atomic per workgroup
 __device__ __forceinline__ void amax_block_commit(uint32_t m, uint32_t* __restrict__ out, uint32_t* __restrict__ lds4) {
     if (!out) return;
 #pragma unroll
@@ -119,7 +134,7 @@ __device__ __forceinline__ void amax_block_commit(uint32_t m, uint32_t* __restri
     __syncthreads();
     if (threadIdx.x == 0) {
         m = max(max(lds4[0], lds4[1]), max(lds4[2], lds4[3]));
-        if (m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+        if (m) amax_publish(m, out, blockIdx.x);
     }
 }
 

@@ -534,7 +534,7 @@ qknorm_rope_bwd_kernel(const TA* __restrict__ qkv, const TA* __restrict__ dq_rot
         uint32_t m = __float_as_uint(am);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-        if (lane == 0 && m > __hip_atomic_load(amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_out, m);
+        if (lane == 0 && m) amax_publish(m, amax_out, (uint32_t)wave);
     }
     // fold the four 16-lane groups, then group 0 writes this wave's row of partial sums
     auto fold = [&](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };

@@ -456,8 +456,8 @@ gemm_f32_kernel(const GemmParams p) {
     float scale_a = 1.f, scale_b = 1.f, unscale = 1.f;
     if (SPLIT == 3) {
         float ia, ib;
-        scale_from_amax(p.amax_a[0], scale_a, ia);
-        scale_from_amax(p.amax_b[0], scale_b, ib);
+        scale_from_amax(amax_read(p.amax_a), scale_a, ia);
+        scale_from_amax(amax_read(p.amax_b), scale_b, ib);
         unscale = ia * ib;
     }
     auto load_tile = [&](int k0) {
@@ -1042,7 +1042,7 @@ static int launch_gemm_split(const GemmParams& p, int blocks, hipStream_t st) {
         pp = (SP_PINGPONG && e2 && e2[0] == '1') ? 1 : 0;
     }
 #if SP_PINGPONG
-    if (SPLIT == 6 && pp && !(MODE == 0 && p.b_planes)) {
+    if ((SPLIT == 6 || SPLIT == 3) && pp && !(MODE == 0 && p.b_planes)) {
         // eight-wave ping-pong form: one workgroup per two tiles, both groups' LDS regions
         int pblocks;
         if (MODE == 0) pblocks = (blocks + 1) / 2;
@@ -1215,7 +1215,7 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
 __device__ __forceinline__ uint32_t amax4(uint32_t m, const uint4 v) {
     return max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
 }
-// one atomic per workgroup (and few workgroups: every atomic of the launch goes to the same word)
+// one atomic per workgroup
 __device__ __forceinline__ void amax_commit(uint32_t m, uint32_t* __restrict__ out) {
     __shared__ uint32_t part[4];
 #pragma unroll
@@ -1224,7 +1224,7 @@ __device__ __forceinline__ void amax_commit(uint32_t m, uint32_t* __restrict__ o
     __syncthreads();
     if (threadIdx.x == 0) {
         m = max(max(part[0], part[1]), max(part[2], part[3]));
-        if (m) atomicMax(out, m);
+        if (m) amax_publish(m, out, blockIdx.x);
     }
 }
 // dense storage (ld == cols, matrices back to back): one 16-byte load per thread and iteration, two in flight
@@ -1273,6 +1273,33 @@ extern "C" int gamer_absmax_f32(const float* x, int batch, int64_t stride, int r
         hipLaunchKernelGGL(absmax_rows_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, batch, stride, rows, cols, ld, out);
     }
     GAMER_CHECK_LAUNCH("gamer_absmax_f32");
+    return 0;
+}
+
+// several dense tensors inside one buffer in ONE launch (the weights of a pass): table[e] = {offset, numel} in elements (both
+// multiples of 4), `bpe` workgroups per entry, out + e * GAMER_AMAX_WORDS = the slot of entry e
+__global__ void __launch_bounds__(256)
+absmax_multi_kernel(const float* __restrict__ base, const int64_t* __restrict__ table, int bpe, uint32_t* __restrict__ out) {
+    const int e = blockIdx.x / bpe, part = blockIdx.x % bpe;
+    const uint4* x = reinterpret_cast<const uint4*>(base + table[2 * e]);
+    const int64_t n4 = table[2 * e + 1] >> 2;
+    uint32_t m = 0;
+    for (int64_t i = (int64_t)part * 256 + threadIdx.x; i < n4; i += (int64_t)bpe * 256) m = amax4(m, x[i]);
+    __shared__ uint32_t part4[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) part4[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(part4[0], part4[1]), max(part4[2], part4[3]));
+        if (m) amax_publish(m, out + (int64_t)e * 256, (uint32_t)part);
+    }
+}
+extern "C" int gamer_absmax_multi_f32(const float* base, const int64_t* table, int n, uint32_t* out, void* stream) {
+    GAMER_CHECK_ARG(base && table && out && n >= 1 && (reinterpret_cast<uintptr_t>(base) & 15u) == 0, "gamer_absmax_multi_f32: bad arguments");
+    const int bpe = 16;
+    hipLaunchKernelGGL(absmax_multi_kernel, dim3(n * bpe), dim3(256), 0, (hipStream_t)stream, base, table, bpe, out);
+    GAMER_CHECK_LAUNCH("gamer_absmax_multi_f32");
     return 0;
 }
 

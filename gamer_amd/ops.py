@@ -179,7 +179,8 @@ def scoped_f32_matmul(get_mode, get_planes=None):
 # split3: one device word per operand tensor for the bits of its largest magnitude.  Slots come from a ring that is zeroed as a
 # whole when it wraps (stream-ordered: every GEMM that read an old slot was enqueued before the memset).
 _AMAX_RING = {}
-_AMAX_SLOTS = 4096
+_AMAX_SLOTS = 1024
+AMAX_WORDS = 256            # GAMER_AMAX_WORDS: one maximum = 16 words 64 bytes apart (producers spread their atomics over them)
 # Optional reuse of a maximum for a tensor that is read by several GEMMs while it does not change (x by forward and weight
 # gradient, dy by weight and input gradient, a weight by every GEMM of a step): inside `with cache:` (an amax_reuse) a slot is
 # keyed by (address, extent) and measured once for tensors the OWNER declared unchanging - `stable(...)` tensors / address
@@ -191,6 +192,9 @@ class amax_reuse:
     def __init__(self, everything=False):
         self.slots, self.pending, self.pools, self.used = {}, {}, [], 0
         self.stable_ptrs, self.stable_ranges, self.held = set(), [], {}
+        # dense tensors inside the FIRST stable range (the parameter buffer) that GEMMs asked for: measured together by one
+        # launch at the start of the next pass (gamer_absmax_multi_f32) instead of one launch each
+        self._wkeys, self._wtable, self._wtable_n = [], None, 0
         self.everything = everything          # tools: every tensor counts as unchanging (kernel timing)
 
     def __enter__(self):
@@ -217,6 +221,19 @@ class amax_reuse:
         for pool in self.pools:
             pool.zero_()
         self.used = 0
+        if self._wkeys and self.stable_ranges and len(self._wkeys) <= 1024:
+            base = self.stable_ranges[0][0]
+            dev = self._wdev
+            if self._wtable is None or self._wtable_n != len(self._wkeys):
+                tab = [v for (p_, n_) in self._wkeys for v in ((p_ - base) // 4, n_)]
+                self._wtable = torch.tensor(tab, dtype=torch.int64, device=dev)
+                self._wtable_n = len(self._wkeys)
+            first = self._new_slot(dev)
+            for _ in range(len(self._wkeys) - 1):
+                self._new_slot(dev)                 # (consecutive: a fresh pool holds 1024 slots)
+            call("gamer_absmax_multi_f32", base, self._wtable.data_ptr(), len(self._wkeys), first, stream_ptr())
+            for e, (p_, n_) in enumerate(self._wkeys):
+                self.slots[(p_, "dense", n_)] = first + 4 * AMAX_WORDS * e
 
     def hold(self, *tensors):
         cache = self
@@ -252,9 +269,9 @@ class amax_reuse:
     def _new_slot(self, device):
         i, j = divmod(self.used, 1024)
         if i == len(self.pools):
-            self.pools.append(torch.zeros(1024, dtype=torch.int32, device=device))
+            self.pools.append(torch.zeros(1024 * AMAX_WORDS, dtype=torch.int32, device=device))
         self.used += 1
-        return self.pools[i].data_ptr() + 4 * j
+        return self.pools[i].data_ptr() + 4 * AMAX_WORDS * j
 
     def preset(self, x, geom, accumulate=False):
         """A slot the PRODUCER of x is about to fill (gamer_amax_sink): the next GEMM that reads x with this extent takes
@@ -283,6 +300,11 @@ class amax_reuse:
         call("gamer_absmax_f32", ptr(x), *geom, ptr_, stream_ptr())
         if keep:
             self.slots[key] = ptr_
+            if (len(key) == 3 and self.stable_ranges and key[2] % 4 == 0 and
+                    self.stable_ranges[0][0] <= p < self.stable_ranges[0][0] + self.stable_ranges[0][1] and
+                    (p, key[2]) not in self._wkeys):
+                self._wkeys.append((p, key[2]))     # a parameter tensor: part of the one-launch measurement from the next pass on
+                self._wdev = x.device
         return ptr_
 
 
@@ -323,11 +345,11 @@ def absmax_slot(x, batch, stride, rows, cols, ld):
     key = (x.device.index, stream_ptr())
     ring = _AMAX_RING.get(key)
     if ring is None:
-        ring = _AMAX_RING[key] = [torch.zeros(_AMAX_SLOTS, dtype=torch.int32, device=x.device), 0]
+        ring = _AMAX_RING[key] = [torch.zeros(_AMAX_SLOTS * AMAX_WORDS, dtype=torch.int32, device=x.device), 0]
     if ring[1] == _AMAX_SLOTS:
         ring[0].zero_()
         ring[1] = 0
-    slot = ring[0].data_ptr() + 4 * ring[1]
+    slot = ring[0].data_ptr() + 4 * AMAX_WORDS * ring[1]
     ring[1] += 1
     call("gamer_absmax_f32", ptr(x), batch, stride, rows, cols, ld, slot, stream_ptr())
     return slot

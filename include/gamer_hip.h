@@ -29,6 +29,7 @@ extern "C" {
 #endif
 
 #define GAMER_ABI_VERSION 6
+#define GAMER_AMAX_WORDS 256      /* words of one maximum slot (1 KB): see gamer_absmax_f32 */
 
 /* bf16 activations of the AMP variant (the reference's --bf16 run, ref:SeqRec/tasks/train_SMB_decoder.py:114-118,
  * 407-408: HF Trainer autocast): raw bfloat16 bits.  Entry points with the suffix _bf16 are the same operation with
@@ -228,7 +229,10 @@ int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);
  * Same F.linear sites as gamer_gemm_f32 (model.py:93-99,145-149,1001, FFN.py:25-27); selected per Engine
  * (`matmul="split6" | "split9"`), never implicitly.  Inf / NaN operands produce NaN. */
 int gamer_gemm_f32_split(const gamer_gemm_desc* d, int terms, void* stream);
-/* terms = 3 (ABI 6): the two-way fp16 form - every operand value times its tensor's power-of-two scale s (largest magnitude
+/* A tensor's maximum ("amax slot") is GAMER_AMAX_WORDS consecutive 32-bit words of device memory, zero before the first kernel
+ * that writes it: producers publish the bits of max |x| into words 16 i (i = workgroup index modulo 16; same-address atomics of
+ * thousands of workgroups would serialise), consumers take the maximum over them.
+ * terms = 3 (ABI 6): the two-way fp16 form - every operand value times its tensor's power-of-two scale s (largest magnitude
  * brought into [2^13, 2^14)) is cut into h0 = fp16(x s), h1 = fp16(x s - h0) and a.b = (a0.b0 + a0.b1 + a1.b0) / (s_a s_b) is
  * accumulated in fp32 by v_mfma_f32_32x32x16_f16: |x s - h0 - h1| <= 2^-22 |x s| for elements within 2^17 of the tensor's
  * largest (smaller ones: absolute 2^-25 of the scaled unit).  Against fp64 the result is at the six-product form's error
@@ -238,6 +242,9 @@ int gamer_gemm_f32_split(const gamer_gemm_desc* d, int terms, void* stream);
  * (ld % 4 == 0, 16-byte aligned), `stride` elements apart; *out must hold 0 (or an earlier maximum) on entry.  One pass over
  * x; a NaN anywhere leaves a NaN pattern (the GEMM then scales by 1 and the NaN propagates). */
 int gamer_absmax_f32(const float* x, int batch, int64_t stride, int rows, int cols, int64_t ld, uint32_t* out, void* stream);
+/* n dense tensors inside one buffer in one launch (the parameters a pass multiplies by): table[2 e] = offset, table[2 e + 1] =
+ * numel of tensor e in elements (multiples of 4; int64, device memory), out + e * GAMER_AMAX_WORDS = its slot. */
+int gamer_absmax_multi_f32(const float* base, const int64_t* table, int n, uint32_t* out, void* stream);
 /* The same maximum as a by-product of the kernel that WRITES the tensor: gamer_amax_sink(out0, out1) arms the next launch - on
  * the calling host thread - of one of gamer_rmsnorm_fwd (y), gamer_rowtable_fwd (the columns it writes), gamer_swiglu_fwd (hm),
  * gamer_swiglu_bwd (out0: d gate, out1: d up), gamer_silu_gate_bwd (out0: da, out1: dgate), gamer_rmsnorm_bwd (mask_out),
