@@ -119,7 +119,7 @@ def colsum_reduce(partial, out, accumulate=False):
 def rowtable_fwd(table, idx, y, ldy, col0, dst_rows=None):
     T = idx.numel()
     E = table.shape[1]
-    _arm_sink((y, (1, 0, T, ldy, ldy), True))
+    _arm_sink((y, (1, 0, T, ldy, ldy), "only"))    # joins the slot the RMSNorm that wrote the other columns opened, if any
     call("gamer_rowtable_fwd" + _sfx(y), ptr(table), ptr(idx), ptr(dst_rows), T, E, ptr(y), ldy, col0, stream_ptr())
 
 
@@ -218,6 +218,7 @@ class amax_reuse:
         self.slots.clear()
         self.pending.clear()
         self.held.clear()
+        self.stable_ptrs.clear()        # (the owner declares its unchanging tensors again: addresses of a freed workspace may be reused)
         for pool in self.pools:
             pool.zero_()
         self.used = 0

@@ -619,7 +619,8 @@ def _run_attn(batch, cross, B, S, nq, nkv, p_drop=0.0, seed=1234, q=None, k=None
                        if spill == "split_spill" else None)
             ops.attn_bwd_split(dq_, nq * 64, dk_, nkv * 64, vview, ldv, o, dev(d_o.reshape(T, -1)), lse, kl, ql, re_, te, B, S,
                                nq, nkv, 0.125, p_drop, seed, delta, dq, nq * 64, dk, nkv * 64, dvv, ldv, order=order,
-                               ds_work=ds_work, h2=h2)
+                               ds_work=ds_work, h2=h2, dv_of=dqkv if h2 else None)
+            res["dqkv"] = dqkv
         else:
             ds_work = torch.full((ops.attn_ds_work_numel(B, S, nq),), float("nan"), device=DEV) if spill else None
             ops.attn_bwd(dq_, nq * 64, dk_, nkv * 64, vview, ldv, o, dev(d_o.reshape(T, -1)), lse, kl, ql, re_, te, B, S, nq,
@@ -822,6 +823,102 @@ def test_swiglu_and_gate():
     da1, dg1 = torch.empty_like(out), torch.empty_like(out)
     ops.silu_gate_bwd(dev(a), dev(gate), dev(dout), da1, dg1, p=0.2, seed=77)
     assert torch.equal(da1, da2) and torch.equal(dg1, dg2)
+
+
+def _slot_value(ptr_):
+    """max over the 16 words of a maximum slot (ops.AMAX_WORDS apart by 16), as a float"""
+    import ctypes
+    words = torch.empty(ops.AMAX_WORDS, dtype=torch.int32, device=DEV)
+    assert torch.cuda.current_stream().cuda_stream is not None
+    # device-to-device copy of the slot through a tensor view of the pool that owns it
+    for pool in ops._AMAX_REUSE.pools:
+        base = pool.data_ptr()
+        if base <= ptr_ < base + pool.numel() * 4:
+            off = (ptr_ - base) // 4
+            words.copy_(pool[off:off + ops.AMAX_WORDS])
+            break
+    else:
+        raise AssertionError("slot not inside a pool")
+    return float(words.cpu().view(torch.float32).max())
+
+
+def test_amax_sinks_equal_the_maximum_of_what_the_kernel_wrote():
+    """matmul="split3": every kernel that writes a GEMM / attention operand leaves max |value| in the slot the consumer will
+    read (gamer_amax_sink) - bit-equal to the maximum of the tensor it wrote; gamer_absmax_f32 (dense and strided) and
+    gamer_absmax_multi_f32 give the same."""
+    torch.manual_seed(9)
+    T, H, I, S, nq, nkv = 640, 256, 512, 64, 2, 1
+    with ops.f32_matmul("split3"), ops.amax_reuse(everything=True) as cache:
+        def pending(t, geom):
+            key = cache._key(t.data_ptr(), geom)
+            assert key in cache.pending, "the producer did not open a slot"
+            return _slot_value(cache.pending[key])
+
+        # RMSNorm forward (+ the behaviour-table columns of an injecting layer)
+        x, w = dev(torch.randn(T, H) * 3), dev(1 + 0.1 * torch.randn(H))
+        din = H + 64
+        hin = torch.zeros(T, din, device=DEV)
+        ops.rmsnorm_fwd(x, w, 1e-6, hin, din)
+        tab, idx = dev(torch.randn(4, 64) * 9), dev(torch.randint(0, 4, (T,)).int())
+        ops.rowtable_fwd(tab, idx, hin, din, H)
+        assert pending(hin, (1, 0, T, din, din)) == float(hin.abs().max())
+        # SwiGLU forward / backward, output gate backward
+        g, u, hm = dev(torch.randn(T, I)), dev(torch.randn(T, I)), torch.empty(T, I, device=DEV)
+        ops.swiglu_fwd(g, u, T * I, 0.2, 5, hm)
+        assert pending(hm, (1, 0, 1, T * I, T * I)) == float(hm.abs().max())
+        ops.swiglu_bwd(g, u, dev(torch.randn(T, I) * 1e-4), T * I, 0.2, 5)
+        assert pending(g, (1, 0, 1, T * I, T * I)) == float(g.abs().max())
+        assert pending(u, (1, 0, 1, T * I, T * I)) == float(u.abs().max())
+        a, gate, dout = dev(torch.randn(T, H)), dev(torch.randn(T, H)), dev(torch.randn(T, H) * 1e-3)
+        da, dgate = torch.empty(T, H, device=DEV), torch.empty(T, H, device=DEV)
+        ops.silu_gate_bwd(a, gate, dout, da, dgate, p=0.2, seed=3)
+        assert pending(da, (1, 0, 1, T * H, T * H)) == float(da.abs().max())
+        assert pending(dgate, (1, 0, 1, T * H, T * H)) == float(dgate.abs().max())
+        # RMSNorm backward: the masked copy for the next branch
+        dx, part, mo = torch.zeros(T, H, device=DEV), torch.empty(512, H, device=DEV), torch.empty(T, H, device=DEV)
+        ops.rmsnorm_bwd(x, w, dev(torch.randn(T, H) * 1e-5), H, 1e-6, dx, part, False, mask_out=mo, p=0.2, seed=11)
+        assert pending(mo, (1, 0, T, H, H)) == float(mo.abs().max())
+        # CE backward (the pad columns of the logits buffer do not count)
+        B, V, ldl = T // S, 1041, 1056
+        logits = dev(torch.randn(T, ldl) * 2)
+        labels = dev(torch.randint(0, V, (B, S)))
+        lse, rl, ls, cnt = (torch.zeros(n, device=DEV) for n in (T, T, 1, 1))
+        ops.ce_fwd(logits, ldl, labels, V, 0.7, -100, lse, rl, ls, cnt)
+        logits[:, V:] = 1e9
+        ops.ce_bwd(logits, ldl, labels, V, 0.7, -100, lse, cnt, 0.0, 1.0)
+        assert pending(logits, (1, 0, T, V, ldl)) == float(logits[:, :V].abs().max())
+        # q/k norm + RoPE forward: q_rot, k_rot
+        QKV = (nq + 2 * nkv) * 64
+        qkv = dev(torch.randn(T, QKV) * 5)
+        cos, sin = orc.rope_tables(S, 64, 1e6)
+        q_rot, k_rot = torch.empty(T, nq * 64, device=DEV), torch.empty(T, nkv * 64, device=DEV)
+        w64 = dev(1 + 0.1 * torch.randn(64))
+        ops.qknorm_rope_fwd(qkv, S, nq, nkv, w64, w64, 1e-6, dev(cos), dev(sin), q_rot, k_rot)
+        assert pending(q_rot, (1, 0, T, nq * 64, nq * 64)) == float(q_rot.abs().max())
+        assert pending(k_rot, (1, 0, T, nkv * 64, nkv * 64)) == float(k_rot.abs().max())
+        # gamer_absmax_f32: dense, strided columns; gamer_absmax_multi_f32
+        v = qkv[:, (nq + nkv) * 64:]
+        assert _slot_value(ops.absmax_slot(v, 1, 0, T, nkv * 64, QKV)) == float(v.abs().max())
+        assert _slot_value(ops.absmax_slot(qkv, 1, 0, T, QKV, QKV)) == float(qkv.abs().max())
+        flat = dev(torch.randn(4096 + 8192 + 256))
+        flat[5000] = -77.0
+        table = torch.tensor([0, 4096, 4096, 8192, 12288, 256], dtype=torch.int64, device=DEV)
+        first = cache._new_slot(flat.device)
+        cache._new_slot(flat.device); cache._new_slot(flat.device)
+        ops.call("gamer_absmax_multi_f32", flat.data_ptr(), table.data_ptr(), 3, first, ops.stream_ptr())
+        for e, (o, n) in enumerate(((0, 4096), (4096, 8192), (12288, 256))):
+            assert _slot_value(first + 4 * ops.AMAX_WORDS * e) == float(flat[o:o + n].abs().max())
+        # the split attention as a producer: o (forward) and the v columns of d(q|k|v) (dK/dV kernel), self and row-ordered cross
+        for cross in (False, True):
+            cache.slots.clear()         # (everything=True keeps maxima by ADDRESS: new tensors may land where freed ones were)
+            batch = synthetic.make_batch(3, 20, 8, 3, seed=13, pad_rows={0: 5})
+            S2 = batch["input_ids"].shape[1]
+            gq = torch.Generator().manual_seed(2)
+            q4, k4, v4, do4 = (torch.randn(3, S2, n, 64, generator=gq) for n in (2, 1, 1, 2))
+            res = _run_attn(batch, cross, 3, S2, 2, 1, p_drop=0.2, q=q4, k=k4, v=v4, d_o=do4 * 1e-4, use_order=cross, spill="split_h2")
+            T2 = 3 * S2
+            assert pending(res["o"], (1, 0, 1, T2 * 128, T2 * 128)) == float(res["o"].abs().max())
+            assert pending(res["dqkv"], (1, 0, T2, 256, 256)) == float(res["dqkv"].abs().max())
 
 
 @pytest.mark.parametrize("use_count", [True, False])
