@@ -363,9 +363,9 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ lds, int row
 // group's issue MFMAs, by construction.  (Two independent four-wave workgroups on a CU fall INTO phase instead - both in
 // their MFMA phase at half rate each, then both in their store phase with the matrix pipe idle: tools/stamp_gemm_split.py.)
 template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, int EPI, int SPLIT = 0, bool PP = false>
-__global__ void __launch_bounds__(PP ? 2 * GEMM_THREADS : GEMM_THREADS, (NBUF == 1 && SPLIT == 0) ? 3 : 2)
-gemm_f32_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+__device__ __forceinline__ void
+gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vblock, const int vgrid) {
+    // one tile (PP: two) of the launch: `vblock` of `vgrid` is what blockIdx.x of gridDim.x is in a one-tile-per-workgroup launch
     // buffer b: A image at smem + 2*b*TILE_FLOATS, B image right behind it
 
     const int grp = PP ? (int)(threadIdx.x >> 8) : 0;             // wave-uniform
@@ -376,7 +376,7 @@ gemm_f32_kernel(const GemmParams p) {
     const int wm = wid >> 1, wn = wid & 1;
     const int r32 = lane & 31, h = lane >> 5;
 
-    const int Lx = xcd_remap(blockIdx.x, gridDim.x);
+    const int Lx = xcd_remap(vblock, vgrid);
     const int L = (PP && MODE == 0) ? 2 * Lx + grp : Lx;           // mode 0: the two groups take neighbouring tiles
 
     // ---- which tile / which group -------------------------------------------------------------
@@ -710,7 +710,7 @@ gemm_f32_kernel(const GemmParams p) {
                 mfma_tile(smem);
                 __syncthreads();
             }
-        } else if (SPLIT && SPLIT != 3 && SP_PREFETCH2) {
+        } else if (SPLIT && SP_PREFETCH2) {
             // one stage of three-image tiles (60 KB), global loads TWO K-steps ahead in two register sets: a split K-step
             // is ~0.4x as long as the fp32 kernel's, and one step of distance no longer covers the load latency under load
             float4 ra2[4], rb2[4];
@@ -725,6 +725,11 @@ gemm_f32_kernel(const GemmParams p) {
             };
             auto store_from = [&](const float4 (&qa)[4], const float4 (&qb)[4]) {
                 unsigned char* d8 = reinterpret_cast<unsigned char*>(smem);
+                if (SPLIT == 3) {
+                    if (A_KC) store_kc_h2(d8, tid, qa, scale_a); else store_rc_h2(d8, tid, qa, scale_a);
+                    if (B_KC) store_kc_h2(d8 + SP_OPERAND, tid, qb, scale_b); else store_rc_h2(d8 + SP_OPERAND, tid, qb, scale_b);
+                    return;
+                }
                 if (A_KC) store_kc_split(d8, tid, qa); else store_rc_split(d8, tid, qa);
                 if (B_KC) store_kc_split(d8 + SP_OPERAND, tid, qb); else store_rc_split(d8 + SP_OPERAND, tid, qb);
             };
@@ -999,13 +1004,26 @@ gemm_f32_kernel(const GemmParams p) {
         unsigned long long* st = g_gemm_stamp;
         if (st && threadIdx.x == 0) {
             const unsigned long long t_end = stamp_now();
-            unsigned long long* rec = st + 8ull * blockIdx.x;
+            unsigned long long* rec = st + 8ull * vblock;
             rec[0] = t_ph[0]; rec[1] = t_ph[1]; rec[2] = t_ph[2]; rec[3] = t_ph[3];
             rec[4] = t_loop_end - t_begin;        // whole K loop
             rec[5] = t_end - t_loop_end;          // epilogue
             rec[6] = t_begin;                     // absolute start (for gaps between workgroups)
             rec[7] = t_end;
         }
+    }
+}
+
+// grid = `vgrid` workgroups: one tile each; a smaller grid (GAMER_GEMM_PERSIST): every workgroup walks tiles blockIdx.x,
+// blockIdx.x + gridDim.x, ... - the stores of one tile's epilogue drain while the next tile's first loads are on their way,
+// and no workgroup start-up sits between them (gridDim.x a multiple of 8: a workgroup's tiles stay on its XCD's share)
+template <bool A_KC, bool B_KC, int MODE, bool ACCUM, bool STAMP, int NBUF, int EPI, int SPLIT = 0, bool PP = false>
+__global__ void __launch_bounds__(PP ? 2 * GEMM_THREADS : GEMM_THREADS, (NBUF == 1 && SPLIT == 0) ? 3 : 2)
+gemm_f32_kernel(const GemmParams p, const int vgrid) {
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    for (int v = blockIdx.x; v < vgrid; v += gridDim.x) {
+        gemm_f32_tile<A_KC, B_KC, MODE, ACCUM, STAMP, NBUF, EPI, SPLIT, PP>(p, smem_all, v, vgrid);
+        if (v + (int)gridDim.x < vgrid) __syncthreads();       // the next tile's staging overwrites this tile's epilogue patches
     }
 }
 
@@ -1023,7 +1041,11 @@ static int launch_gemm_t(const GemmParams& p, int blocks, hipStream_t st, int ld
         }
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(PP ? 2 * GEMM_THREADS : GEMM_THREADS), lds, st, p);
+    static int persist = -1;
+    if (persist < 0) { const char* e = getenv("GAMER_GEMM_PERSIST"); persist = e ? atoi(e) : 0; }
+    // GAMER_GEMM_PERSIST=n (n a multiple of 8): at most n workgroups, each walking several tiles (plain split forms only)
+    const int grid = (persist > 0 && SPLIT != 0 && !PP && !STAMP && blocks > persist) ? persist : blocks;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(PP ? 2 * GEMM_THREADS : GEMM_THREADS), lds, st, p, blocks);
     GAMER_CHECK_LAUNCH("gamer_gemm_f32");
     return 0;
 }
