@@ -864,10 +864,9 @@ attn_bwd_dq_s_kernel(const float* __restrict__ q, int ldq, const float* __restri
 // dP = dO V^T for every query tile), the staged query tile's Q and dO images per head (12 KB each), per-query scalars.
 // 144 KB at G = 2: ONE workgroup per CU, eight waves = two per SIMD, as the two four-wave workgroups of the fp32 form.
 constexpr int DKV_S_KEYS = 128;
-template <int G, int NP = 3>
-struct DkvSmemS {
-    bf16_t Kt[NP][DKV_S_KEYS * 64];
-    bf16_t Vt[NP][DKV_S_KEYS * 64];
+// one staged query tile: the Q and dO piece images of the G heads and the per-query scalars
+template <int G, int NP>
+struct DkvQTile {
     bf16_t Qs[G][NP * SIMG];
     bf16_t dOs[G][NP * SIMG];
     float nlse2_s[G][32];       // -lse * log2(e) of the staged query rows
@@ -878,6 +877,16 @@ struct DkvSmemS {
     int32_t pos_s[32];          // key limit of the staged query rows: their position, S past the end
     int32_t qlmin;              // smallest query level / key limit over the normal rows of the tile (INT_MAX: none)
     int32_t posmin;
+    int32_t pad_[2];
+};
+// NP = 3 (six-product bf16 form): 96 KB of K / V images + one 48-KB query tile = 144 KB.  NP = 2 (three-product fp16 form):
+// 64 KB + TWO 32-KB query tiles = 130 KB - tile t + 1 is cut and stored while tile t is multiplied, one barrier per tile.
+template <int G, int NP = 3>
+struct DkvSmemS {
+    static constexpr int NBUF = NP == 2 ? 2 : 1;
+    bf16_t Kt[NP][DKV_S_KEYS * 64];
+    bf16_t Vt[NP][DKV_S_KEYS * 64];
+    DkvQTile<G, NP> qt[NBUF];
 };
 
 template <int G, bool DROP, bool ORD, bool H2>
@@ -1006,7 +1015,7 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
             }
         }
     };
-    auto store_q_tile = [&](int qt) {
+    auto store_q_tile = [&](int qt, DkvQTile<G, NP>& dst) {
         const int n_valid = S - qt * 32;
 #pragma unroll
         for (int g = 0; g < G; ++g)
@@ -1022,19 +1031,19 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                 if (H2) {
                     uint32_t a0, a1, b0, b1;
                     cut2h_pair(xa[0] * sc.q, xa[1] * sc.q, a0, a1); cut2h_pair(xa[2] * sc.q, xa[3] * sc.q, b0, b1);
-                    *reinterpret_cast<uint2*>(sm.Qs[g] + off) = make_uint2(a0, b0);
-                    *reinterpret_cast<uint2*>(sm.Qs[g] + SIMG + off) = make_uint2(a1, b1);
+                    *reinterpret_cast<uint2*>(dst.Qs[g] + off) = make_uint2(a0, b0);
+                    *reinterpret_cast<uint2*>(dst.Qs[g] + SIMG + off) = make_uint2(a1, b1);
                     cut2h_pair(xc[0] * sc.d_o, xc[1] * sc.d_o, a0, a1); cut2h_pair(xc[2] * sc.d_o, xc[3] * sc.d_o, b0, b1);
-                    *reinterpret_cast<uint2*>(sm.dOs[g] + off) = make_uint2(a0, b0);
-                    *reinterpret_cast<uint2*>(sm.dOs[g] + SIMG + off) = make_uint2(a1, b1);
+                    *reinterpret_cast<uint2*>(dst.dOs[g] + off) = make_uint2(a0, b0);
+                    *reinterpret_cast<uint2*>(dst.dOs[g] + SIMG + off) = make_uint2(a1, b1);
                 } else {
                     uint32_t wa[4][3], wc[4][3];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { cut3(xa[e], wa[e]); cut3(xc[e], wc[e]); }
 #pragma unroll
                     for (int s = 0; s < NP; ++s) {
-                        *reinterpret_cast<uint2*>(sm.Qs[g] + s * SIMG + off) = make_uint2(hi16_pair(wa[0][s], wa[1][s]), hi16_pair(wa[2][s], wa[3][s]));
-                        *reinterpret_cast<uint2*>(sm.dOs[g] + s * SIMG + off) = make_uint2(hi16_pair(wc[0][s], wc[1][s]), hi16_pair(wc[2][s], wc[3][s]));
+                        *reinterpret_cast<uint2*>(dst.Qs[g] + s * SIMG + off) = make_uint2(hi16_pair(wa[0][s], wa[1][s]), hi16_pair(wa[2][s], wa[3][s]));
+                        *reinterpret_cast<uint2*>(dst.dOs[g] + s * SIMG + off) = make_uint2(hi16_pair(wc[0][s], wc[1][s]), hi16_pair(wc[2][s], wc[3][s]));
                     }
                 }
             }
@@ -1048,32 +1057,22 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                 posmin = wave_min_i32(normal ? rpos : INT_BIG_A);
             }
             if (lane < 32) {
-                sm.nlse2_s[g][row] = rl;
-                sm.ndelta_s[g][row] = rd;
-                if (DROP) sm.aw_s[g][row] = raw;
+                dst.nlse2_s[g][row] = rl;
+                dst.ndelta_s[g][row] = rd;
+                if (DROP) dst.aw_s[g][row] = raw;
                 if (g == 0) {
-                    sm.ql_s[row] = rql; sm.empty_s[row] = rem; sm.pos_s[row] = rpos;
-                    if (row == 0) { sm.qlmin = qlmin; sm.posmin = posmin; }
+                    dst.ql_s[row] = rql; dst.empty_s[row] = rem; dst.pos_s[row] = rpos;
+                    if (row == 0) { dst.qlmin = qlmin; dst.posmin = posmin; }
                 }
             }
         }
     };
 
-    int qt = next_tile(0);
-    if (qt < n_qt) load_q_tile(qt);
-    while (qt < n_qt) {
-        __syncthreads();                 // previous tile fully consumed (and K/V staging visible)
-        store_q_tile(qt);
-        __syncthreads();
+    // the products of one staged query tile `tq` (qt) against this wave's 32 keys
+    auto compute_tile = [&](const int qt, const DkvQTile<G, NP>& tq, bool& prefetched, const int qt_next) {
         const bool tile_has_empty = tile_empty_rows(qt);
-        const int qt_next = next_tile(qt + 1);
-        // the next tile's global loads are in flight while this one is multiplied.  With the dS spill they are issued BEHIND
-        // the spill stores (the wait for them in front of the next LDS store is s_waitcnt vmcnt(0): issued ahead of the
-        // stores, every tile would wait for its own spill to be acknowledged)
-        bool prefetched = ds_out == nullptr;
-        if (prefetched && qt_next < n_qt) load_q_tile(qt_next);
-        const int posmin = __builtin_amdgcn_readfirstlane(sm.posmin);
-        const int qlmin = __builtin_amdgcn_readfirstlane(sm.qlmin);
+        const int posmin = __builtin_amdgcn_readfirstlane(tq.posmin);
+        const int qlmin = __builtin_amdgcn_readfirstlane(tq.qlmin);
         const bool tile_all_empty = tile_has_empty && posmin == INT_BIG_A;
 
         const bool before = tile_last_pos(qt) < wave_k_lo;   // every normal query of the tile precedes this wave's keys
@@ -1081,8 +1080,8 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
             f32x16 st, dp;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
-            const bf16_t* Qh = sm.Qs[hg];
-            const bf16_t* dOh = sm.dOs[hg];
+            const bf16_t* Qh = tq.Qs[hg];
+            const bf16_t* dOh = tq.dOs[hg];
             // S[query][key] = sum_d Q[query][d] K[key][d] and dP[query][key] = sum_d dO[query][d] V[key][d]; six piece
             // products each, smallest first
             const bool need_s = !before && !tile_all_empty;
@@ -1106,27 +1105,27 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int qb = 8 * g4 + 4 * h;
-                    const float4 d4 = *reinterpret_cast<const float4*>(&sm.ndelta_s[hg][qb]);
+                    const float4 d4 = *reinterpret_cast<const float4*>(&tq.ndelta_s[hg][qb]);
                     const float ndl[4] = {d4.x, d4.y, d4.z, d4.w};
                     float nl[4] = {0.f, 0.f, 0.f, 0.f};
                     int qlv[4] = {0, 0, 0, 0}, posv[4] = {0, 0, 0, 0}, emv[4] = {0, 0, 0, 0};
                     uint32_t awv[4] = {0, 0, 0, 0};
                     if (!ALL_EMPTY) {
-                        const float4 l4 = *reinterpret_cast<const float4*>(&sm.nlse2_s[hg][qb]);
+                        const float4 l4 = *reinterpret_cast<const float4*>(&tq.nlse2_s[hg][qb]);
                         nl[0] = l4.x; nl[1] = l4.y; nl[2] = l4.z; nl[3] = l4.w;
                     }
                     if (MASK) {
-                        const int4 q4 = *reinterpret_cast<const int4*>(&sm.ql_s[qb]);
-                        const int4 p4 = *reinterpret_cast<const int4*>(&sm.pos_s[qb]);
+                        const int4 q4 = *reinterpret_cast<const int4*>(&tq.ql_s[qb]);
+                        const int4 p4 = *reinterpret_cast<const int4*>(&tq.pos_s[qb]);
                         qlv[0] = q4.x; qlv[1] = q4.y; qlv[2] = q4.z; qlv[3] = q4.w;
                         posv[0] = p4.x; posv[1] = p4.y; posv[2] = p4.z; posv[3] = p4.w;
                     }
                     if (EMPTYSEL) {
-                        const int4 e4 = *reinterpret_cast<const int4*>(&sm.empty_s[qb]);
+                        const int4 e4 = *reinterpret_cast<const int4*>(&tq.empty_s[qb]);
                         emv[0] = e4.x; emv[1] = e4.y; emv[2] = e4.z; emv[3] = e4.w;
                     }
                     if (DROP) {
-                        const uint4 a4 = *reinterpret_cast<const uint4*>(&sm.aw_s[hg][qb]);
+                        const uint4 a4 = *reinterpret_cast<const uint4*>(&tq.aw_s[hg][qb]);
                         awv[0] = a4.x; awv[1] = a4.y; awv[2] = a4.z; awv[3] = a4.w;
                     }
 #pragma unroll
@@ -1193,8 +1192,47 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                 }
             }
         }
-        if (!prefetched && qt_next < n_qt) load_q_tile(qt_next);
-        qt = qt_next;
+    };
+
+    int qt = next_tile(0);
+    if (H2) {
+        // two query-tile buffers: tile t + 1 (loaded from global memory during tile t - 1's products ... ) is cut and stored into the
+        // other buffer right after this wave's products of tile t - ONE barrier per tile, and no phase in which the whole
+        // workgroup only stores
+        int buf = 0;
+        if (qt < n_qt) {
+            load_q_tile(qt);
+            store_q_tile(qt, sm.qt[0]);
+        }
+        __syncthreads();                 // K / V staging and the first query tile visible
+        int qt_next = qt < n_qt ? next_tile(qt + 1) : n_qt;
+        if (qt_next < n_qt) load_q_tile(qt_next);
+        while (qt < n_qt) {
+            bool prefetched = true;
+            compute_tile(qt, sm.qt[buf], prefetched, qt_next);
+            if (qt_next < n_qt) store_q_tile(qt_next, sm.qt[DkvSmemS<G, NP>::NBUF - 1 - buf]);
+            __syncthreads();             // tile qt consumed by every wave, tile qt_next visible
+            qt = qt_next;
+            buf = DkvSmemS<G, NP>::NBUF - 1 - buf;
+            qt_next = qt < n_qt ? next_tile(qt + 1) : n_qt;
+            if (qt_next < n_qt) load_q_tile(qt_next);
+        }
+    } else {
+        if (qt < n_qt) load_q_tile(qt);
+        while (qt < n_qt) {
+            __syncthreads();                 // previous tile fully consumed (and K/V staging visible)
+            store_q_tile(qt, sm.qt[0]);
+            __syncthreads();
+            const int qt_next = next_tile(qt + 1);
+            // the next tile's global loads are in flight while this one is multiplied.  With the dS spill they are issued BEHIND
+            // the spill stores (the wait for them in front of the next LDS store is s_waitcnt vmcnt(0): issued ahead of the
+            // stores, every tile would wait for its own spill to be acknowledged)
+            bool prefetched = ds_out == nullptr;
+            if (prefetched && qt_next < n_qt) load_q_tile(qt_next);
+            compute_tile(qt, sm.qt[0], prefetched, qt_next);
+            if (!prefetched && qt_next < n_qt) load_q_tile(qt_next);
+            qt = qt_next;
+        }
     }
 
     // ---- sum the G query heads of this kv head through LDS, then store ---------------------------
