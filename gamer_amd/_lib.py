@@ -115,6 +115,7 @@ _SIGNATURES = {
     "gamer_split3_planes": [P, P, L, L, P],
     "gamer_absmax_f32": [P, I, L, I, I, L, P, P],
     "gamer_absmax_multi_f32": [P, P, I, P, P],
+    "gamer_split2h_planes_multi": [P, P, I, P, P, P],
     "gamer_amax_sink": [P, P],
     "gamer_attn_split_amax": [P, P, P, P],
     "gamer_attn_fwd_split": [P, I, P, I, P, I, P, P, P, I, I, I, I, F, F, U, P, P, P, P, P, P],

@@ -410,6 +410,10 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
         kbeg = 0;
         kend = p.K;
         Bp += (int64_t)g * p.strideB;
+        // SPLIT == 3 with pre-cut parameters: `b_planes` holds, at the SAME offsets as B, 16 bytes per four elements = their four
+        // h0 pieces and their four h1 pieces (gamer_split2h_planes_multi) - the loads below stay what they are, the B half of the
+        // cut becomes two 8-byte LDS stores
+        if (SPLIT == 3 && p.b_planes) Bp = reinterpret_cast<const float*>(p.b_planes) + (Bp - p.B);
     } else {
         const int tiles_mn = p.m_tiles * p.n_tiles;
         const int per_chunk = PP ? (tiles_mn + 1) / 2 : tiles_mn;  // PP: the two groups take two C tiles of the SAME k chunk
@@ -481,6 +485,17 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
         if (SPLIT == 3) {
             unsigned char* d8 = reinterpret_cast<unsigned char*>(dst);
             if (A_KC) store_kc_h2(d8, tid, ra, scale_a); else store_rc_h2(d8, tid, ra, scale_a);
+            if (MODE == 0 && p.b_planes) {          // packed pieces: {h0 x 4 | h1 x 4} per float4 slot
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = tid + GEMM_THREADS * j;
+                    unsigned char* dstb = B_KC ? d8 + SP_OPERAND + (f >> 3) * SP_KC_ROW + ((f & 7) << 3)
+                                               : d8 + SP_OPERAND + sp_rc_off(f >> 5, (f & 31) << 2);
+                    *reinterpret_cast<uint2*>(dstb) = make_uint2(__float_as_uint(rb[j].x), __float_as_uint(rb[j].y));
+                    *reinterpret_cast<uint2*>(dstb + (B_KC ? SP_KC_IMG : SP_RC_IMG)) = make_uint2(__float_as_uint(rb[j].z), __float_as_uint(rb[j].w));
+                }
+                return;
+            }
             if (B_KC) store_kc_h2(d8 + SP_OPERAND, tid, rb, scale_b); else store_rc_h2(d8 + SP_OPERAND, tid, rb, scale_b);
             return;
         }
@@ -673,11 +688,11 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
             }
         } else if (SPLIT && SPLIT != 3 && MODE == 0 && p.b_planes != nullptr) {
             // B = weights pre-cut into their three bf16 planes (gamer_split3_planes, once per step): the planes are staged as
-            // they are - 8-byte loads, 8-byte LDS stores, no cut (a weight element is otherwise re-cut by every row tile of the
-            // activations: half of the 176 vector instructions of a K-step)
+            // they are - 8-byte loads, 8-byte LDS stores, no cut.  (The SPLIT == 3 form reads PACKED pieces instead: below.)
+            constexpr int NPL = 3;
             const uint16_t* pq = p.b_planes + (pb - p.B);
             const int64_t plane = p.b_plane_stride;
-            uint2 rq[3][4];
+            uint2 rq[NPL][4];
             auto load_a = [&]() {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4*>(pa + j * ja);
@@ -685,7 +700,7 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
             };
             auto load_bq = [&]() {
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
+                for (int s = 0; s < NPL; ++s)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) rq[s][j] = *reinterpret_cast<const uint2*>(pq + s * plane + j * jb);
                 pq += sb;
@@ -696,7 +711,7 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
                     const int f = tid + GEMM_THREADS * j;
                     unsigned char* dst = B_KC ? d8 + (f >> 3) * SP_KC_ROW + ((f & 7) << 3) : d8 + sp_rc_off(f >> 5, (f & 31) << 2);
 #pragma unroll
-                    for (int s = 0; s < 3; ++s) *reinterpret_cast<uint2*>(dst + s * (B_KC ? SP_KC_IMG : SP_RC_IMG)) = rq[s][j];
+                    for (int s = 0; s < NPL; ++s) *reinterpret_cast<uint2*>(dst + s * (B_KC ? SP_KC_IMG : SP_RC_IMG)) = rq[s][j];
                 }
             };
             load_a();
@@ -1187,10 +1202,12 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     p.qk_S = d->qk_S; p.qk_nq = d->qk_nq; p.qk_nkv = d->qk_nkv;
     p.amax_a = d->amax_a; p.amax_b = d->amax_b;
     GAMER_CHECK_ARG(split != 3 || (d->amax_a && d->amax_b), "gamer_gemm_f32_split: terms = 3 needs amax_a and amax_b (gamer_absmax_f32)");
-    p.b_planes = (split && split != 3 && d->group_mode == 0) ? (const uint16_t*)d->b_planes : nullptr;
+    p.b_planes = (split && d->group_mode == 0) ? (const uint16_t*)d->b_planes : nullptr;
     p.b_plane_stride = d->b_plane_stride;
-    GAMER_CHECK_ARG(!p.b_planes || ((reinterpret_cast<uintptr_t>(p.b_planes) & 7u) == 0 && d->b_plane_stride % 4 == 0 && d->b_plane_stride > 0),
+    GAMER_CHECK_ARG(!p.b_planes || split == 3 || ((reinterpret_cast<uintptr_t>(p.b_planes) & 7u) == 0 && d->b_plane_stride % 4 == 0 && d->b_plane_stride > 0),
                     "gamer_gemm_f32_split: b_planes must be 8-byte aligned with b_plane_stride %% 4 == 0");
+    GAMER_CHECK_ARG(!p.b_planes || split != 3 || (reinterpret_cast<uintptr_t>(p.b_planes) & 15u) == 0,
+                    "gamer_gemm_f32_split: terms = 3 takes b_planes as packed pieces at B's offsets (16-byte aligned)");
     GAMER_CHECK_ARG(!d->qk_q_rot || (d->qk_k_rot && d->qk_wq && d->qk_wk && d->qk_cos && d->qk_sin && d->group_mode == 0 &&
                                      d->groups == 1 && a_kc && b_kc && !d->resid && !d->rowdot_out && !d->accumulate &&
                                      d->alpha == 1.f && d->M % BM == 0 && d->qk_nq > 0 && d->qk_nkv > 0 && d->qk_S > 0 &&
@@ -1322,6 +1339,34 @@ extern "C" int gamer_absmax_multi_f32(const float* base, const int64_t* table, i
     const int bpe = 16;
     hipLaunchKernelGGL(absmax_multi_kernel, dim3(n * bpe), dim3(256), 0, (hipStream_t)stream, base, table, bpe, out);
     GAMER_CHECK_LAUNCH("gamer_absmax_multi_f32");
+    return 0;
+}
+
+// the fp16 pieces of several dense tensors of one buffer (the parameters), each scaled by ITS power of two, PACKED at the
+// offsets of the values they replace: the 16 bytes of elements 4 i .. 4 i + 3 hold their four h0 pieces, then their four h1
+// pieces (table as gamer_absmax_multi_f32, slots = its output)
+__global__ void __launch_bounds__(256)
+split2h_planes_multi_kernel(const float* __restrict__ base, const int64_t* __restrict__ table, int bpe,
+                            const uint32_t* __restrict__ slots, uint16_t* __restrict__ planes) {
+    const int e = blockIdx.x / bpe, part = blockIdx.x % bpe;
+    const int64_t off = table[2 * e], n4 = table[2 * e + 1] >> 2;
+    float s, inv;
+    scale_from_amax(amax_read(slots + (int64_t)e * 256), s, inv);
+    const float4* x = reinterpret_cast<const float4*>(base + off);
+    for (int64_t i = (int64_t)part * 256 + threadIdx.x; i < n4; i += (int64_t)bpe * 256) {
+        uint2 img[2];
+        split2h_quad(x[i], s, img);
+        reinterpret_cast<uint4*>(planes)[(off >> 2) + i] = make_uint4(img[0].x, img[0].y, img[1].x, img[1].y);
+    }
+}
+extern "C" int gamer_split2h_planes_multi(const float* base, const int64_t* table, int n, const uint32_t* slots, gamer_bf16* planes,
+                                          void* stream) {
+    GAMER_CHECK_ARG(base && table && slots && planes && n >= 1 && (reinterpret_cast<uintptr_t>(base) & 15u) == 0 &&
+                    (reinterpret_cast<uintptr_t>(planes) & 15u) == 0, "gamer_split2h_planes_multi: bad arguments");
+    const int bpe = 16;
+    hipLaunchKernelGGL(split2h_planes_multi_kernel, dim3(n * bpe), dim3(256), 0, (hipStream_t)stream, base, table, bpe, slots,
+                       reinterpret_cast<uint16_t*>(planes));
+    GAMER_CHECK_LAUNCH("gamer_split2h_planes_multi");
     return 0;
 }
 

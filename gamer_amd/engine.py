@@ -426,6 +426,10 @@ class Engine:
         if dtype == "f32" and matmul == "split3":
             self._amax = ops.amax_reuse()
             self._amax.stable_range(self.flat_p.data_ptr(), self.flat_p.numel() * 4)
+            if os.environ.get("GAMER_SPLIT3_PLANES", "1") != "0":
+                # the parameters' fp16 pieces, packed at their values' offsets and rebuilt at the start of every pass (98 MB read,
+                # 98 MB written): the B operand of the forward and input-gradient GEMMs is then staged without its cut
+                self._amax.planes = torch.zeros(_round_up(n, 4), dtype=torch.float32, device=self.device)
         self.lut = cfg.behavior_lut().to(self.device)
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._ws: Dict[bool, _Workspace] = {}

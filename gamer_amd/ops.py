@@ -195,6 +195,9 @@ class amax_reuse:
         # dense tensors inside the FIRST stable range (the parameter buffer) that GEMMs asked for: measured together by one
         # launch at the start of the next pass (gamer_absmax_multi_f32) instead of one launch each
         self._wkeys, self._wtable, self._wtable_n = [], None, 0
+        # (a buffer of the parameter buffer's size, or None): the fp16 pieces of those tensors packed at their values' offsets,
+        # rebuilt by the same pass-start launch pair; a GEMM whose B operand is exactly one of them reads them instead of cutting
+        self.planes, self._plane_keys = None, set()
         self.everything = everything          # tools: every tensor counts as unchanging (kernel timing)
 
     def __enter__(self):
@@ -235,6 +238,11 @@ class amax_reuse:
             call("gamer_absmax_multi_f32", base, self._wtable.data_ptr(), len(self._wkeys), first, stream_ptr())
             for e, (p_, n_) in enumerate(self._wkeys):
                 self.slots[(p_, "dense", n_)] = first + 4 * AMAX_WORDS * e
+            self._plane_keys = set()
+            if self.planes is not None:
+                call("gamer_split2h_planes_multi", base, self._wtable.data_ptr(), len(self._wkeys), first, self.planes.data_ptr(),
+                     stream_ptr())
+                self._plane_keys = {(p_, "dense", n_) for (p_, n_) in self._wkeys}
 
     def hold(self, *tensors):
         cache = self
@@ -412,7 +420,12 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
         gb = (N, K, b_rs) if b_ks == 1 else (K, N, b_ks)
         nb = groups if (group_mode == 0 and groups > 1) else 1
         d.amax_a = absmax_slot(A, 1, 0, *ga)
-        d.amax_b = absmax_slot(Bm, nb, strideB if nb > 1 else 0, *gb)
+        geom_b = (nb, strideB if nb > 1 else 0) + gb
+        d.amax_b = absmax_slot(Bm, *geom_b)
+        c = _AMAX_REUSE
+        if c is not None and c.planes is not None and group_mode == 0 and c._key(Bm.data_ptr(), geom_b) in c._plane_keys:
+            # B is a parameter tensor whose fp16 piece planes were built at the start of this pass (same scale as amax_b gives)
+            d.b_planes = c.planes.data_ptr() + (Bm.data_ptr() - c.stable_ranges[0][0])      # packed pieces at B's offsets
         call("gamer_gemm_f32_split", C.byref(d), 3, stream_ptr())
         return
     if F32_MATMUL_TERMS:

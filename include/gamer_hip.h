@@ -245,6 +245,13 @@ int gamer_absmax_f32(const float* x, int batch, int64_t stride, int rows, int co
 /* n dense tensors inside one buffer in one launch (the parameters a pass multiplies by): table[2 e] = offset, table[2 e + 1] =
  * numel of tensor e in elements (multiples of 4; int64, device memory), out + e * GAMER_AMAX_WORDS = its slot. */
 int gamer_absmax_multi_f32(const float* base, const int64_t* table, int n, uint32_t* out, void* stream);
+/* The `b_planes` operand of gamer_gemm_f32_split(terms = 3): PACKED pieces at the offsets of the values they replace - the 16
+ * bytes of elements 4 i .. 4 i + 3 of entry e of `table` (as gamer_absmax_multi_f32; slots = that call's output, which fixes the
+ * scale s(e) exactly as the GEMM derives it from amax_b) hold the four fp16 pieces h0 of base[.] * s(e), then the four pieces h1.
+ * The GEMM then loads B as before (from `b_planes` + B's offset; b_plane_stride is not used) and stages it without the cut:
+ * parameters are cut once per pass instead of once per row tile of the activations; results are bit-identical. */
+int gamer_split2h_planes_multi(const float* base, const int64_t* table, int n, const uint32_t* slots, gamer_bf16* planes,
+                               void* stream);
 /* The same maximum as a by-product of the kernel that WRITES the tensor: gamer_amax_sink(out0, out1) arms the next launch - on
  * the calling host thread - of one of gamer_rmsnorm_fwd (y), gamer_rowtable_fwd (the columns it writes), gamer_swiglu_fwd (hm),
  * gamer_swiglu_bwd (out0: d gate, out1: d up), gamer_silu_gate_bwd (out0: da, out1: dgate), gamer_rmsnorm_bwd (mask_out),

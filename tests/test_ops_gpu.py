@@ -457,6 +457,35 @@ def test_gemm_split_error_is_not_larger_than_the_fp32_mfma():
         assert errs[mode][0] < 2e-6
 
 
+def test_gemm_split3_weight_planes_are_bit_identical():
+    """matmul="split3": from the second pass on the parameters' maxima come from one launch and their fp16 piece planes are
+    built once per pass (gamer_absmax_multi_f32 + gamer_split2h_planes_multi); forward, input-gradient and grouped (expert)
+    GEMMs that read the planes give the bits of the in-kernel cut."""
+    torch.manual_seed(6)
+    T, N, K, E = 1024, 384, 256, 3
+    flat = dev(torch.randn(N * K + E * N * K + 8) * 0.05)
+    W = flat[:N * K].view(N, K)
+    WE = flat[N * K:N * K + E * N * K].view(E * N, K)
+    x, dy = dev(torch.randn(T, K) * 3), dev(torch.randn(T, N) * 1e-3)
+    offs = dev(torch.tensor([0, 256, 640, T], dtype=torch.int32))
+    cache = ops.amax_reuse()
+    cache.stable_range(flat.data_ptr(), flat.numel() * 4)
+    cache.planes = torch.zeros(flat.numel(), dtype=torch.float32, device=DEV)
+    outs = []
+    with ops.f32_matmul("split3"), cache:
+        for it in range(2):
+            cache.reset()
+            y, dx, ye = torch.empty(T, N, device=DEV), torch.empty(T, K, device=DEV), torch.empty(T, N, device=DEV)
+            ops.linear_fwd(x, K, W, K, y, N, T, N, K)
+            ops.linear_dgrad(dy, N, W, K, dx, K, T, N, K)
+            ops.linear_fwd(x, K, WE, K, ye, N, T, N, K, strideB=N * K, groups=E, group_offsets=offs)
+            outs.append((y.clone(), dx.clone(), ye.clone()))
+            assert (len(cache._plane_keys) > 0) == (it == 1)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert _rel(outs[1][0], x.double().cpu() @ W.double().cpu().T) < 1e-6
+
+
 @pytest.mark.parametrize("mag", [1e-30, 1e-9, 1e-4, 1.0, 1e6, 1e25])
 def test_gemm_split3_error_does_not_depend_on_the_magnitude(mag):
     """The two-way fp16 form scales every operand tensor by a power of two from its own largest magnitude: gradients of
