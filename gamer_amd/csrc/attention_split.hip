@@ -129,23 +129,17 @@ __device__ __forceinline__ void store_tile32_split(bf16_t* __restrict__ img, int
 // ---- H2: the two-way fp16 cut of csrc/gemm.hip's SPLIT == 3 form (x s = h0 + h1 + r, |r| <= 2^-22 |x s|; s = a power of two that
 // brings the tensor's largest magnitude into [2^13, 2^14)), three piece products h0 h0' + h0 h1' + h1 h0'.  Fragments travel in
 // the same bf16x8 containers (bits), images 0 and 1 of the three-image layouts.
-__device__ __forceinline__ void cut2h_pair(float x0, float x1, uint32_t& p0, uint32_t& p1) {
-    const f16x2 a = {(_Float16)x0, (_Float16)x1};                                   // v_cvt_pk_f16_f32 (nearest even)
-    const f16x2 b = {(_Float16)(x0 - (float)a[0]), (_Float16)(x1 - (float)a[1])};
-    p0 = __builtin_bit_cast(uint32_t, a);
-    p1 = __builtin_bit_cast(uint32_t, b);
-}
 // piece fragments of eight consecutive values; H2: the values are multiplied by s first, p[2] is not written
 template <bool H2>
 __device__ __forceinline__ void cut8_t(const float4& a, const float4& b, float s, bf16x8 (&p)[3]) {
     if (!H2) { cut8(a, b, p[0], p[1], p[2]); return; }
-    const float x[8] = {a.x * s, a.y * s, a.z * s, a.w * s, b.x * s, b.y * s, b.z * s, b.w * s};
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     u32x4s u0, u1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t a, c;
-        cut2h_pair(x[2 * j], x[2 * j + 1], a, c);
-        u0[j] = a; u1[j] = c;
+    for (int j = 0; j < 2; ++j) {
+        uint32_t a0, a1, b0, b1;
+        cut2h_quad(x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3], s, a0, a1, b0, b1);
+        u0[2 * j] = a0; u0[2 * j + 1] = b0; u1[2 * j] = a1; u1[2 * j + 1] = b1;
     }
     p[0] = __builtin_bit_cast(bf16x8, u0); p[1] = __builtin_bit_cast(bf16x8, u1);
 }
@@ -154,10 +148,10 @@ __device__ __forceinline__ void cut8_regs_t(const f32x16& t, const int first, fl
     if (!H2) { cut8_regs(t, first, p[0], p[1], p[2]); return; }
     u32x4s u0, u1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t a, c;
-        cut2h_pair(t[first + 2 * j] * s, t[first + 2 * j + 1] * s, a, c);
-        u0[j] = a; u1[j] = c;
+    for (int j = 0; j < 2; ++j) {
+        uint32_t a0, a1, b0, b1;
+        cut2h_quad(t[first + 4 * j], t[first + 4 * j + 1], t[first + 4 * j + 2], t[first + 4 * j + 3], s, a0, a1, b0, b1);
+        u0[2 * j] = a0; u0[2 * j + 1] = b0; u1[2 * j] = a1; u1[2 * j + 1] = b1;
     }
     p[0] = __builtin_bit_cast(bf16x8, u0); p[1] = __builtin_bit_cast(bf16x8, u1);
 }
@@ -170,8 +164,7 @@ __device__ __forceinline__ void store_tile32_t(bf16_t* __restrict__ img, int tid
         const int row = f >> 4;
         const bool ok = row < n_valid;
         uint32_t a0, a1, b0, b1;
-        cut2h_pair(ok ? rg[jj].x * s : 0.f, ok ? rg[jj].y * s : 0.f, a0, a1);
-        cut2h_pair(ok ? rg[jj].z * s : 0.f, ok ? rg[jj].w * s : 0.f, b0, b1);
+        cut2h_quad(ok ? rg[jj].x : 0.f, ok ? rg[jj].y : 0.f, ok ? rg[jj].z : 0.f, ok ? rg[jj].w : 0.f, s, a0, a1, b0, b1);
         bf16_t* dst = img + sl_off(row, (f & 15) << 2);
         *reinterpret_cast<uint2*>(dst) = make_uint2(a0, b0);
         *reinterpret_cast<uint2*>(dst + SIMG) = make_uint2(a1, b1);
@@ -929,10 +922,10 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
         const int off = sl_off(row, c4);
         if (H2) {
             uint32_t a0, a1, b0, b1;
-            cut2h_pair(kv4.x * sc.k, kv4.y * sc.k, a0, a1); cut2h_pair(kv4.z * sc.k, kv4.w * sc.k, b0, b1);
+            cut2h_quad(kv4.x, kv4.y, kv4.z, kv4.w, sc.k, a0, a1, b0, b1);
             *reinterpret_cast<uint2*>(sm.Kt[0] + off) = make_uint2(a0, b0);
             *reinterpret_cast<uint2*>(sm.Kt[1] + off) = make_uint2(a1, b1);
-            cut2h_pair(vv4.x * sc.v, vv4.y * sc.v, a0, a1); cut2h_pair(vv4.z * sc.v, vv4.w * sc.v, b0, b1);
+            cut2h_quad(vv4.x, vv4.y, vv4.z, vv4.w, sc.v, a0, a1, b0, b1);
             *reinterpret_cast<uint2*>(sm.Vt[0] + off) = make_uint2(a0, b0);
             *reinterpret_cast<uint2*>(sm.Vt[1] + off) = make_uint2(a1, b1);
         } else {
@@ -1030,10 +1023,10 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                 const int off = sl_off(row, (f & 15) << 2);
                 if (H2) {
                     uint32_t a0, a1, b0, b1;
-                    cut2h_pair(xa[0] * sc.q, xa[1] * sc.q, a0, a1); cut2h_pair(xa[2] * sc.q, xa[3] * sc.q, b0, b1);
+                    cut2h_quad(xa[0], xa[1], xa[2], xa[3], sc.q, a0, a1, b0, b1);
                     *reinterpret_cast<uint2*>(dst.Qs[g] + off) = make_uint2(a0, b0);
                     *reinterpret_cast<uint2*>(dst.Qs[g] + SIMG + off) = make_uint2(a1, b1);
-                    cut2h_pair(xc[0] * sc.d_o, xc[1] * sc.d_o, a0, a1); cut2h_pair(xc[2] * sc.d_o, xc[3] * sc.d_o, b0, b1);
+                    cut2h_quad(xc[0], xc[1], xc[2], xc[3], sc.d_o, a0, a1, b0, b1);
                     *reinterpret_cast<uint2*>(dst.dOs[g] + off) = make_uint2(a0, b0);
                     *reinterpret_cast<uint2*>(dst.dOs[g] + SIMG + off) = make_uint2(a1, b1);
                 } else {

@@ -84,6 +84,30 @@ template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = 
 template <typename T> __device__ __forceinline__ float round_as(float v) { return (float)(T)v; }
 template <typename T> static inline bool aligned_vec4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(T) - 1)) == 0; }
 
+// The two fp16 pieces of four values times s (s a power of two): h0 = fp16(x s), h1 = fp16(x s - h0), both round-to-nearest-even,
+// as packed pairs a0 = {x0's, x1's h0}, b0 = {x2's, x3's h0}, a1 / b1 = the h1 pairs.  Eight v_fma_mix instructions = two per
+// value - the multiply, the exact residual in fp32 and the conversion in one instruction per piece (the C form: multiply,
+// convert, convert back, subtract, convert = 3-3.5 per value).  ONE asm block, ordered so that no instruction reads a register
+// the instruction before it wrote in part: on gfx940+ a VALU that reads a VGPR right after an op_sel (half-register) write of
+// it needs a wait state, which the compiler inserts for its own instructions but not inside or around inline asm - a first
+// form with mixlo / mixhi of one register back to back was right in the GEMM (where the scheduler happened to interleave
+// pairs) and lost the h1 pieces in the dropout variants of the attention kernels.  Bit-equal to the C form except that x = -0
+// gives (+0, -0) instead of (-0, +0) (tools/mix_cut_test.hip on MI355X: random pairs at five scales, Inf, NaN, the fp16
+// overflow boundary, denormals).
+__device__ __forceinline__ void cut2h_quad(float x0, float x1, float x2, float x3, float s,
+                                           uint32_t& a0, uint32_t& a1, uint32_t& b0, uint32_t& b1) {
+    asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+        "v_fma_mixlo_f16 %2, %6, %8, 0\n\t"
+        "v_fma_mixhi_f16 %0, %5, %8, 0\n\t"
+        "v_fma_mixhi_f16 %2, %7, %8, 0\n\t"
+        "v_fma_mixlo_f16 %1, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %6, %8, -%2 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %7, %8, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 0"
+        : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(s));
+}
 // the scale of a tensor from the bits of its largest magnitude (a non-negative float): max * s in [2^13, 2^14); 1 for a
 // zero, denormal, infinite or NaN maximum (Inf / NaN then reach the MFMA as they are).  inv = 1 / s, exact.
 __device__ __forceinline__ void scale_from_amax(uint32_t bits, float& s, float& inv) {

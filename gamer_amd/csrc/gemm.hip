@@ -102,12 +102,10 @@ __device__ __forceinline__ void store_rc_split(unsigned char* __restrict__ lds, 
 }
 // ---- SPLIT == 3: two fp16 pieces of x * s (s = the tensor's power-of-two scale); images 0 and 1 of the three-image layouts
 __device__ __forceinline__ void split2h_quad(const float4& v, float s, uint2 (&img)[2]) {
-    const float tx = v.x * s, ty = v.y * s, tz = v.z * s, tw = v.w * s;
-    const f16x2 a0 = {(_Float16)tx, (_Float16)ty}, a1 = {(_Float16)tz, (_Float16)tw};          // v_cvt_pk_f16_f32 (nearest even)
-    const f16x2 b0 = {(_Float16)(tx - (float)a0[0]), (_Float16)(ty - (float)a0[1])};
-    const f16x2 b1 = {(_Float16)(tz - (float)a1[0]), (_Float16)(tw - (float)a1[1])};
-    img[0] = make_uint2(__builtin_bit_cast(uint32_t, a0), __builtin_bit_cast(uint32_t, a1));
-    img[1] = make_uint2(__builtin_bit_cast(uint32_t, b0), __builtin_bit_cast(uint32_t, b1));
+    uint32_t a0, a1, b0, b1;
+    cut2h_quad(v.x, v.y, v.z, v.w, s, a0, a1, b0, b1);
+    img[0] = make_uint2(a0, b0);
+    img[1] = make_uint2(a1, b1);
 }
 __device__ __forceinline__ void store_kc_h2(unsigned char* __restrict__ lds, int tid, const float4 (&r)[4], float s) {
 #pragma unroll
