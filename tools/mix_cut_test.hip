@@ -1,9 +1,11 @@
-#include <hip/hip_runtime.h>
+// The v_fma_mix form of the two-piece fp16 cut (gamer_amd/csrc/common.h: cut2h_quad) against its C form, bit for bit:
+//   hipcc -O3 --offload-arch=gfx950 -Iinclude tools/mix_cut_test.hip -o tools/_ab/mix_cut_test && tools/_ab/mix_cut_test
+#include "../gamer_amd/csrc/common.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
 #include <math.h>
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+using gamer::f16x2;
 __device__ void ref_pair(float x0, float x1, float s, unsigned& p0, unsigned& p1) {
     x0 *= s; x1 *= s;
     const f16x2 a = {(_Float16)x0, (_Float16)x1};
@@ -11,10 +13,9 @@ __device__ void ref_pair(float x0, float x1, float s, unsigned& p0, unsigned& p1
     p0 = __builtin_bit_cast(unsigned, a); p1 = __builtin_bit_cast(unsigned, b);
 }
 __device__ void mix_pair(float x0, float x1, float s, unsigned& h0, unsigned& h1) {
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(x0), "v"(s));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(x1), "v"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(h1) : "v"(x0), "v"(s), "v"(h0));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(h1) : "v"(x1), "v"(s), "v"(h0));
+    unsigned b0, b1;
+    gamer::cut2h_quad(x0, x1, x1, x0, s, h0, h1, b0, b1);
+    if (b0 != ((h0 >> 16) | (h0 << 16)) || b1 != ((h1 >> 16) | (h1 << 16))) h0 = 0xdeadbeefu;      // the second pair = the first, swapped
 }
 __global__ void k(const float* x, float s, int n, unsigned* out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
