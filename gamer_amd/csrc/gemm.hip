@@ -139,6 +139,9 @@ __device__ __forceinline__ void store_rc_h2(unsigned char* __restrict__ lds, int
 #ifndef SP_PREFETCH2
 #define SP_PREFETCH2 0  // one-stage form with the global loads two K-steps ahead (two register sets, ~230 VGPRs)
 #endif
+#ifndef SP_WIDE3
+#define SP_WIDE3 1      // SPLIT == 3, forward layout: two 32-deep slices (two LDS stages) per barrier pair (the other layouts: measured slower)
+#endif
 #ifndef SP_PINGPONG
 #define SP_PINGPONG 0   // instantiate the eight-wave ping-pong form (PP below); GAMER_GEMM_PP=1 then selects it
 #endif
@@ -479,34 +482,39 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
             else load_rc<false>(Bp, p.b_ks, col0, col_end, k0, kend, tid, rb);
         }
     };
-    auto store_tile = [&](float* dst) {
+    // SPLIT == 3: two images per operand, B right behind A's two (a stage is 2 (A_IMG + B_IMG) bytes: 40,960 / 36,864 / 32,768 for
+    // the forward / input-gradient / weight-gradient layouts)
+    constexpr int H2_B_OFF = 2 * (A_KC ? SP_KC_IMG : SP_RC_IMG);
+    constexpr int H2_STAGE = H2_B_OFF + 2 * (B_KC ? SP_KC_IMG : SP_RC_IMG);
+    auto store_tile_from = [&](float* dst, const float4 (&qa)[4], const float4 (&qb)[4]) {
         if (SPLIT == 3) {
             unsigned char* d8 = reinterpret_cast<unsigned char*>(dst);
-            if (A_KC) store_kc_h2(d8, tid, ra, scale_a); else store_rc_h2(d8, tid, ra, scale_a);
+            if (A_KC) store_kc_h2(d8, tid, qa, scale_a); else store_rc_h2(d8, tid, qa, scale_a);
             if (MODE == 0 && p.b_planes) {          // packed pieces: {h0 x 4 | h1 x 4} per float4 slot
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int f = tid + GEMM_THREADS * j;
-                    unsigned char* dstb = B_KC ? d8 + SP_OPERAND + (f >> 3) * SP_KC_ROW + ((f & 7) << 3)
-                                               : d8 + SP_OPERAND + sp_rc_off(f >> 5, (f & 31) << 2);
-                    *reinterpret_cast<uint2*>(dstb) = make_uint2(__float_as_uint(rb[j].x), __float_as_uint(rb[j].y));
-                    *reinterpret_cast<uint2*>(dstb + (B_KC ? SP_KC_IMG : SP_RC_IMG)) = make_uint2(__float_as_uint(rb[j].z), __float_as_uint(rb[j].w));
+                    unsigned char* dstb = B_KC ? d8 + H2_B_OFF + (f >> 3) * SP_KC_ROW + ((f & 7) << 3)
+                                               : d8 + H2_B_OFF + sp_rc_off(f >> 5, (f & 31) << 2);
+                    *reinterpret_cast<uint2*>(dstb) = make_uint2(__float_as_uint(qb[j].x), __float_as_uint(qb[j].y));
+                    *reinterpret_cast<uint2*>(dstb + (B_KC ? SP_KC_IMG : SP_RC_IMG)) = make_uint2(__float_as_uint(qb[j].z), __float_as_uint(qb[j].w));
                 }
                 return;
             }
-            if (B_KC) store_kc_h2(d8 + SP_OPERAND, tid, rb, scale_b); else store_rc_h2(d8 + SP_OPERAND, tid, rb, scale_b);
+            if (B_KC) store_kc_h2(d8 + H2_B_OFF, tid, qb, scale_b); else store_rc_h2(d8 + H2_B_OFF, tid, qb, scale_b);
             return;
         }
         if (SPLIT) {
             unsigned char* d8 = reinterpret_cast<unsigned char*>(dst);
-            if (A_KC) store_kc_split(d8, tid, ra); else store_rc_split(d8, tid, ra);
-            if (SP_ABLATE & 16) { asm volatile("" :: "v"(rb[0].x), "v"(rb[1].y), "v"(rb[2].z), "v"(rb[3].w)); return; }   // timing-only: B never enters LDS
-            if (B_KC) store_kc_split(d8 + SP_OPERAND, tid, rb); else store_rc_split(d8 + SP_OPERAND, tid, rb);
+            if (A_KC) store_kc_split(d8, tid, qa); else store_rc_split(d8, tid, qa);
+            if (SP_ABLATE & 16) { asm volatile("" :: "v"(qb[0].x), "v"(qb[1].y), "v"(qb[2].z), "v"(qb[3].w)); return; }   // timing-only: B never enters LDS
+            if (B_KC) store_kc_split(d8 + SP_OPERAND, tid, qb); else store_rc_split(d8 + SP_OPERAND, tid, qb);
             return;
         }
-        if (A_KC) store_kc(dst, tid, ra); else store_rc(dst, tid, ra);
-        if (B_KC) store_kc(dst + TILE_FLOATS, tid, rb); else store_rc(dst + TILE_FLOATS, tid, rb);
+        if (A_KC) store_kc(dst, tid, qa); else store_rc(dst, tid, qa);
+        if (B_KC) store_kc(dst + TILE_FLOATS, tid, qb); else store_rc(dst + TILE_FLOATS, tid, qb);
     };
+    auto store_tile = [&](float* dst) { store_tile_from(dst, ra, rb); };
     unsigned long long t_ph[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t0 = 0, t1 = 0;
     const unsigned long long t_begin = STAMP ? stamp_now() : 0;
@@ -518,7 +526,7 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
         if (SPLIT != 0 && (SP_ABLATE & 4) != 0) return;
         if (SPLIT == 3) {
             const unsigned char* a8 = reinterpret_cast<const unsigned char*>(as);
-            const unsigned char* b8 = a8 + SP_OPERAND;
+            const unsigned char* b8 = a8 + H2_B_OFF;
             constexpr int A_IMG = A_KC ? SP_KC_IMG : SP_RC_IMG, B_IMG = B_KC ? SP_KC_IMG : SP_RC_IMG;
 #pragma unroll
             for (int sub = 0; sub < BK / 16; ++sub) {
@@ -723,6 +731,32 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
                 mfma_tile(smem);
                 __syncthreads();
             }
+        } else if (SPLIT == 3 && SP_WIDE3 && A_KC && B_KC) {
+            // TWO 32-deep slices per barrier pair, each in its own stage: 48 MFMAs between barriers as in the six-product form (with
+            // 24 the fixed cost of a K-step - two barriers, the wait for the loads - is half of the step)
+            float4 ra2[4], rb2[4];
+            float* const stage1 = smem + H2_STAGE / 4;
+            auto load_into = [&](float4 (&qa)[4], float4 (&qb)[4]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qa[j] = *reinterpret_cast<const float4*>(pa + j * ja);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qb[j] = *reinterpret_cast<const float4*>(pb + j * jb);
+                pa += sa;
+                pb += sb;
+            };
+            load_into(ra, rb);
+            if (nkt > 1) load_into(ra2, rb2);
+            for (int kt = 0; kt < nkt; kt += 2) {
+                const bool two = kt + 1 < nkt;
+                store_tile(smem);
+                if (two) store_tile_from(stage1, ra2, rb2);
+                __syncthreads();
+                if (kt + 2 < nkt) load_into(ra, rb);
+                if (kt + 3 < nkt) load_into(ra2, rb2);
+                mfma_tile(smem);
+                if (two) mfma_tile(stage1);
+                __syncthreads();
+            }
         } else if (SPLIT && SP_PREFETCH2) {
             // one stage of three-image tiles (60 KB), global loads TWO K-steps ahead in two register sets: a split K-step
             // is ~0.4x as long as the fp32 kernel's, and one step of distance no longer covers the load latency under load
@@ -740,7 +774,7 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
                 unsigned char* d8 = reinterpret_cast<unsigned char*>(smem);
                 if (SPLIT == 3) {
                     if (A_KC) store_kc_h2(d8, tid, qa, scale_a); else store_rc_h2(d8, tid, qa, scale_a);
-                    if (B_KC) store_kc_h2(d8 + SP_OPERAND, tid, qb, scale_b); else store_rc_h2(d8 + SP_OPERAND, tid, qb, scale_b);
+                    if (B_KC) store_kc_h2(d8 + H2_B_OFF, tid, qb, scale_b); else store_rc_h2(d8 + H2_B_OFF, tid, qb, scale_b);
                     return;
                 }
                 if (A_KC) store_kc_split(d8, tid, qa); else store_rc_split(d8, tid, qa);
@@ -1066,7 +1100,10 @@ static int launch_gemm_t(const GemmParams& p, int blocks, hipStream_t st, int ld
 // the bf16-split forms: one LDS stage; the epilogue's row-major rewrite needs the full 72 KB
 template <bool A_KC, bool B_KC, int MODE, int SPLIT>
 static int launch_gemm_split(const GemmParams& p, int blocks, hipStream_t st) {
-    const int lds = GEMM_LDS_BYTES;
+    // (SPLIT == 3 with two stages: 81,920 / 73,728 / 65,536 bytes for the forward / input-gradient / weight-gradient layouts; the
+    // epilogue's row-major rewrite needs 69,632)
+    constexpr int h2_stage = 2 * ((A_KC ? SP_KC_IMG : SP_RC_IMG) + (B_KC ? SP_KC_IMG : SP_RC_IMG));
+    const int lds = (SPLIT == 3 && SP_WIDE3 && A_KC && B_KC && 2 * h2_stage > GEMM_LDS_BYTES) ? 2 * h2_stage : GEMM_LDS_BYTES;
     static_assert(SP_LDS_BYTES <= GEMM_LDS_BYTES, "split images must fit the fp32 kernel's LDS allocation");
     const bool acc = MODE == 0 && p.accumulate;
     static int stamp = -1, pp = 0;
