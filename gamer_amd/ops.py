@@ -588,6 +588,15 @@ def _tune_kchunk(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups, group_of
         cands = {rule, 512, 1024, 2048, 4096, 8192, 16384}
     else:
         cands = {rule, 384, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096}
+        # ... and the chunks that make the grid a whole number of rounds of the chip's 512 workgroup slots (at per-GPU batch 128 a
+        # power-of-two chunk leaves a quarter of the slots empty or starts a second, mostly empty round)
+        tiles = ((N_out + 127) // 128) * ((K_in + 127) // 128)
+        per_group = max(1, rows // max(groups, 1))
+        for rounds in (1, 2, 3, 4):
+            n_chunks = max(1, (512 * rounds) // (tiles * max(groups, 1)))
+            c = (-(-per_group // n_chunks) + 31) // 32 * 32
+            if 256 <= c <= 8192:
+                cands.add(c)
     cands = sorted(c for c in cands if c <= max(256, rows))
     scratch = torch.zeros_like(dW)                 # the sweep must not touch the real gradient
     best, best_t = rule, float("inf")
