@@ -2,7 +2,7 @@
 """Training trajectories of the matmul / dtype forms side by side: the same weights, the same synthetic stream, the same
 dropout seeds, N optimizer steps (fwd + bwd + clip + AdamW, cosine schedule off, lr 5e-4), loss logged every step.
 python tools/trajectory.py [--steps 200] [--batch 64] > profiles/<tag>_trajectory.txt
-Prints the losses of the fp32-MFMA run and, for split6 / split9 / bf16, the largest and the final |loss - loss_f32|."""
+Prints the losses of the fp32-MFMA run and, for split3 / split6 / split9 / bf16, the largest and the final |loss - loss_f32|."""
 import argparse
 import os
 import sys
@@ -28,8 +28,8 @@ batches = [synthetic.make_batch(args.batch, args.items, 256, 3, seed=1000 + s, b
 curves = {}
 # "f32 again": the same fp32-MFMA configuration a second time - the split-K weight gradients add with fp32 atomics in
 # whatever order the workgroups finish, so two identical runs drift apart too; that drift is the yardstick
-for name, kw in (("f32", dict()), ("f32 again", dict()), ("split6", dict(matmul="split6")), ("split9", dict(matmul="split9")),
-                 ("bf16", dict(dtype="bf16"))):
+for name, kw in (("f32", dict(matmul="f32")), ("f32 again", dict(matmul="f32")), ("split3", dict(matmul="split3")),
+                 ("split6", dict(matmul="split6")), ("split9", dict(matmul="split9")), ("bf16", dict(dtype="bf16"))):
     eng = Engine(cfg, temperature=0.7, **kw)
     eng.load_state_dict(sd)
     losses = []
@@ -40,10 +40,10 @@ for name, kw in (("f32", dict()), ("f32 again", dict()), ("split6", dict(matmul=
     torch.cuda.empty_cache()
 ref = curves["f32"]
 print(f"batch {args.batch} x {args.items * 5} tokens, {args.steps} steps, dropout 0.2 (same masks in every run)")
-print("step   f32        f32 again  split6     split9     bf16")
+print("step   f32        f32 again  split3     split6     split9     bf16")
 for s in list(range(0, args.steps, max(1, args.steps // 20))) + [args.steps - 1]:
-    print(f"{s:4d}  " + "  ".join(f"{curves[k][s]:9.6f}" for k in ("f32", "f32 again", "split6", "split9", "bf16")))
-for k in ("f32 again", "split6", "split9", "bf16"):
+    print(f"{s:4d}  " + "  ".join(f"{curves[k][s]:9.6f}" for k in ("f32", "f32 again", "split3", "split6", "split9", "bf16")))
+for k in ("f32 again", "split3", "split6", "split9", "bf16"):
     d = [abs(a - b) for a, b in zip(curves[k], ref)]
     print(f"{k:9s} max |loss - loss_f32| over the run {max(d):.3e} (step {d.index(max(d))}), at the last step {d[-1]:.3e}, "
           f"first step {d[0]:.3e}")
