@@ -501,12 +501,12 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
         __syncthreads();
     }
 
+    float omax = 0.f;
     if (valid_q) {
         float linv = my_empty ? invS : (l_run > 0.f ? 1.f / l_run : 0.f);
         if (DROP) linv *= rng.scale;
         if (H2) linv *= H2Scales::INV_P * sc.inv_v;
         float* orow = o + tok * (int64_t)nq * 64 + head * 64;
-        float omax = 0.f;
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh) {
 #pragma unroll
@@ -518,10 +518,16 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
                 omax = fmaxf(fmaxf(fmaxf(omax, fabsf(t4.x)), fabsf(t4.y)), fmaxf(fabsf(t4.z), fabsf(t4.w)));
             }
         }
-        if (amax_lds) atomicMax(amax_lds, __float_as_uint(omax));      // (gamer_amax_sink: max |o| for the o_proj GEMM's scale)
+
         // natural-log LSE of the scaled scores (what the backward kernels consume)
         if (h == 0) lse[((int64_t)b * nq + head) * S + iqc] =
             my_empty ? 0.f : (m_ref + __log2f(l_run)) * 0.6931471805599453f;
+    }
+    if (amax_lds) {                                                     // (gamer_amax_sink: max |o| for the o_proj GEMM's scale)
+        uint32_t mw = __float_as_uint(omax);                            // one LDS atomic per wave, not 64 to one address
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) mw = max(mw, (uint32_t)__shfl_xor((int)mw, o2, 64));
+        if (lane == 0 && mw) atomicMax(amax_lds, mw);
     }
 }
 
@@ -1280,7 +1286,7 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                 *reinterpret_cast<float4*>(dvrow + d) = dv4;
                 vmax = fmaxf(fmaxf(fmaxf(vmax, fabsf(dv4.x)), fabsf(dv4.y)), fmaxf(fabsf(dv4.z), fabsf(dv4.w)));
             }
-        if (amax_lds) atomicMax(amax_lds, __float_as_uint(vmax));      // (gamer_amax_sink: max |dv|, the v columns of d(q|k|v))
+        if (amax_lds) atomicMax(amax_lds, __float_as_uint(vmax));      // (gamer_amax_sink: max |dv|, the v columns of d(q|k|v); once per key tile)
     }
 }
 
