@@ -342,7 +342,20 @@ def cpu_baseline(cfg_dict, seq_items: int, micro_batch: int = 32, timed_steps: i
             break
     timed_steps = len(times) - 1
     mean = sum(times[1:]) / len(times[1:])
+    quota = None
+    try:
+        q_, p_ = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q_ == "max" else float(q_) / float(p_)
+    except (OSError, ValueError):
+        pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = None
     return dict(value=micro_batch / mean, unit="sequences/s", cores=cores, kind="port",
+                # BASELINE.md section 3 asks for N = os.cpu_count(); this box reports more logical CPUs than the process may use:
+                # threads = min(affinity mask, cgroup CPU quota), all three stated here
+                os_cpu_count=os.cpu_count(), affinity_cpus=affinity, cgroup_quota_cpus=quota,
                 sample=f"oracle/qwen3multi_oracle.py train step (fwd+bwd+clip+AdamW, dropout 0.2), micro-batch "
                        f"{micro_batch} x {seq_items * 5} tokens, 1 warm-up + {timed_steps} timed steps, "
                        f"torch.set_num_threads({cores})")
@@ -379,6 +392,12 @@ def parse_args(argv=None):
     ap.add_argument("--kernel-rows", type=int, default=12, help="rows of the per-family kernel table in the JSON line")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (and the roofline object)")
     ap.add_argument("--ragged", action="store_true", help="secondary workload: n_items ~ U{2..items}, right padded")
+    ap.add_argument("--accum", type=int, default=1,
+                    help="gradient accumulation: one step = ACCUM micro-batches of --batch through Engine.train_window (one clip + "
+                         "AdamW per window); BASELINE configs[3] is --batch 128 --accum 4 --augment 4")
+    ap.add_argument("--augment", type=int, default=0,
+                    help="secondary workload: rows shaped like tasks=smb_explicit_decoder_<AUGMENT> (thinned copies, cropped to "
+                         "--items, right padded per micro-batch; synthetic.make_augmented_batch)")
     ap.add_argument("--variant", choices=["multi", "session"], default="multi",
                     help="secondary workload: 'session' = Qwen3SessionMulti (session-wise masks, same weights)")
     ap.add_argument("--session-mean", type=float, default=4.0, help="items per session for --variant session")
@@ -454,6 +473,10 @@ SECONDARY_LEGS = (
     ("f32_split3_b128", "f32", "split3", 128),     # the headline form at the per-GPU batch of the 8-GPU north-star point
     ("f32_mfma_b128", "f32", "f32", 128),
     ("bf16_b128", "bf16", "f32", 128),
+    # BASELINE configs[3]: per-GPU micro-batch 128 x gradient accumulation 4 on 4x-augmentation-shaped ragged rows (one step = one
+    # optimizer step over 512 sequences)
+    ("f32_split3_b128_accum4_ragged", "f32", "split3", 128, dict(accum=4, augment=4)),
+    ("bf16_b128_accum4_ragged", "bf16", "f32", 128, dict(accum=4, augment=4)),
 )
 
 
@@ -480,20 +503,27 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
     if reducer is not None and force_dist:
         reducer.world = 2                        # take the collective code path even with one rank
 
-    def make(step):
-        b = synthetic.make_batch(args.batch, args.items, 256, 3, ragged=args.ragged,
-                                 seed=20251114 + 1000 * rank + step, behavior_probs=[0.7, 0.25, 0.05],
-                                 session_mean=smean)
-        return {k: v.cuda(non_blocking=True) for k, v in b.items()}
+    accum = max(1, int(args.accum))
 
-    # inputs are resident in HBM before the timed region starts
+    def make_cpu(seed):
+        if args.augment:
+            return synthetic.make_augmented_batch(args.batch, args.items, 256, 3, augment=args.augment, seed=seed,
+                                                  behavior_probs=[0.7, 0.25, 0.05])
+        return synthetic.make_batch(args.batch, args.items, 256, 3, ragged=args.ragged, seed=seed,
+                                    behavior_probs=[0.7, 0.25, 0.05], session_mean=smean)
+
+    # inputs are resident in HBM before the timed region starts; with --accum a "batch" is a window of ACCUM micro-batches
     n_batches = min(args.steps + args.warmup, 4)
-    batches = [make(s) for s in range(n_batches)]
-    cpu_batches = [synthetic.make_batch(args.batch, args.items, 256, 3, ragged=args.ragged,
-                                        seed=20251114 + 1000 * rank + s, behavior_probs=[0.7, 0.25, 0.05],
-                                        session_mean=smean)
-                   for s in range(n_batches)]
-    flops = [algorithmic_flops(cfg, b, session=args.variant == "session") for b in cpu_batches]
+    cpu_windows = [[make_cpu(20251114 + 1000 * rank + 16 * s + a) for a in range(accum)] for s in range(n_batches)]
+    windows = [[{k: v.cuda(non_blocking=True) for k, v in b.items()} for b in w] for w in cpu_windows]
+    batches = [w[0] for w in windows]
+    flops = []
+    for w in cpu_windows:
+        fs = [algorithmic_flops(cfg, b, session=args.variant == "session") for b in w]
+        flops.append({k: sum(f[k] for f in fs) for k in ("fwd", "step", "tokens", "p_self", "p_cross")})
+    window_labels = [float(sum(int((b["labels"][:, 1:] != -100).sum()) for b in w)) for w in cpu_windows]   # HF's num_items_in_batch
+    if accum > 1 and (args.path != "engine" or args.variant != "multi"):
+        raise SystemExit("--accum is measured on the engine path (Engine.train_window) of the Qwen3Multi variant")
     timer.reset()
     lr = 5e-4
     grad_scale = 1.0                              # gradients are already global means (sum CE / global count)
@@ -524,6 +554,10 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
     def step(i):
         f = flops[i % n_batches]
         timer.pairs = {"self": f["p_self"], "cross": f["p_cross"]}
+        if module is None and accum > 1:
+            # (the per-family kernel table's attention TFLOP/s use the window's pair count / ACCUM per launch)
+            timer.pairs = {"self": f["p_self"] / accum, "cross": f["p_cross"] / accum}
+            return eng.train_window(windows[i % n_batches], lr, n_items=window_labels[i % n_batches], reducer=reducer)[-1]
         if module is None:
             return eng.train_step(batches[i % n_batches], lr, reducer=reducer, grad_scale=grad_scale)
         b = batches[i % n_batches]
@@ -600,7 +634,7 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
 
     result = None
     if rank == 0:
-        seqs = args.batch * world * args.steps
+        seqs = args.batch * accum * world * args.steps
         step_flops = sum(flops[i % n_batches]["step"] for i in range(args.warmup, args.warmup + args.steps)) / args.steps
         timed = timer.summary(args.steps)                      # the dominant family, measured in the timed region
         kernels = warm_kernels if warm_kernels else timed      # every launch, measured in the warm-up steps
@@ -638,10 +672,18 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
             "higher_is_better": True,
             "scaling": "weak" if args.weak else "strong",
             "vs_baseline": None,
-            "dtype": args.dtype,
+            # the arithmetic the path computes in: fp32 tensors and accumulators throughout; for the split forms the PRODUCTS are
+            # formed on the 16-bit matrix pipe from piece cuts of the fp32 operands - named here, not hidden behind "f32"
+            "dtype": ({"f32": "f32", "split3": "f32 tensors/accumulators, products = 3 x fp16 pieces (split3)",
+                       "split6": "f32 tensors/accumulators, products = 6 x bf16 pieces (split6, exact cut)",
+                       "split9": "f32 tensors/accumulators, products = 9 x bf16 pieces (split9, exact cut)"}[args.matmul]
+                      if args.dtype == "f32" else "bf16"),
             "data": "synthetic",
             "config": {
-                "workload": (("Qwen3Multi" if args.variant == "multi" else
+                "workload": ((f"[{args.matmul if args.dtype == 'f32' else 'bf16'}] ") +
+                             (f"[accum {accum} x micro-batch {args.batch}] " if accum > 1 else "") +
+                             (f"[{args.augment}x-augmentation-shaped ragged rows] " if args.augment else "") +
+                             ("Qwen3Multi" if args.variant == "multi" else
                               f"Qwen3SessionMulti (sessions of {args.session_mean:g} items on average)") +
                              " SMB decoder train step (fwd+bwd+clip+AdamW, dropout 0.2), ShortVideoAD-shaped "
                              f"synthetic ids, per-GPU batch {args.batch} x {args.items * 5} tokens"
@@ -653,7 +695,9 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
                               f" tensors and accumulation; every fp32 matrix product (Linear and attention) formed as {split_terms} "
                               "exact bf16 piece products of a three-way cut of both operands (error vs fp64 at the fp32 MFMA's "
                               "level)" if split_terms else (" on the fp32 MFMA" if args.dtype == "f32" else ""))),
-                "global_batch": args.batch * world,
+                "global_batch": args.batch * accum * world,
+                "micro_batch": args.batch,
+                "grad_accum": accum,
                 "seq_len": args.items * 5,
                 "parallelism": f"dp{world}",
                 "path": args.path,
@@ -735,13 +779,16 @@ def main(argv=None):
     # timed by the same run, 2 warm-up + 5 timed steps each, reported under "secondary" on the ONE JSON line.
     default_workload = (world == 1 and not force_dist and args.path == "engine" and args.dtype == "f32" and args.matmul == "split3"
                         and args.batch == 1024 and args.items == 101 and args.variant == "multi" and not args.ragged
-                        and not args.no_dropout)
+                        and not args.no_dropout and args.accum == 1 and not args.augment)
     if default_workload and not args.no_secondary and result is not None:
         import copy
         secondary = []
-        for name, dtype, matmul, batch in SECONDARY_LEGS:
+        for leg in SECONDARY_LEGS:
+            name, dtype, matmul, batch = leg[:4]
             a = copy.copy(args)
             a.dtype, a.matmul, a.batch, a.steps, a.warmup = dtype, matmul, batch, 5, 2
+            for k_, v_ in (leg[4] if len(leg) > 4 else {}).items():
+                setattr(a, k_, v_)
             try:
                 r = run_leg(a, rank, world, local_rank, force_dist, timer)
             except Exception as e:                                  # a failing extra leg must not cost the headline line
@@ -749,7 +796,8 @@ def main(argv=None):
                 secondary.append({"name": name, "error": repr(e)})
                 continue
             rf = r.get("roofline") or {}
-            secondary.append({"name": name, "dtype": dtype, "matmul": matmul, "per_gpu_batch": batch, "steps": a.steps,
+            secondary.append({"name": name, "dtype": dtype, "matmul": matmul, "per_gpu_batch": batch, "grad_accum": a.accum,
+                              "sequences_per_step": batch * a.accum, "steps": a.steps,
                               "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "value": r["value"], "unit": r["unit"],
                               "loss": r["loss"], "dominant_kernel": rf.get("kernel"), "achieved": rf.get("achieved"),
                               "peak": rf.get("peak"), "frac": rf.get("frac"), "hbm_frac": rf.get("hbm_frac"),

@@ -102,6 +102,7 @@ _SIGNATURES = {
     "gamer_rowtable_bwd": [P, I, I, P, P, I, I, I, P, P],
     "gamer_gemm_f32": [C.POINTER(GemmDesc), P],
     "gamer_gemm_f32_split": [C.POINTER(GemmDesc), c_int, P],
+    "gamer_split3_guard": [I],
     "gamer_gemm_bf16": [C.POINTER(GemmBf16Desc), P],
     "gamer_cast_params_bf16": [P, P, P, P, I, I, P],
     "gamer_attn_fwd_bf16": [P, I, P, I, P, I, P, P, I, I, I, I, F, F, U, P, P, P, P, P, P, P],
@@ -199,7 +200,15 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# Called (with the entry point's name) when an entry point returns non-zero, before the RuntimeError is raised: host-side state
+# that was prepared for "the next launch" (ops: maxima slots handed to a producer that never ran) is dropped here.
+FAILURE_HOOKS = []
+
+
 def call(name: str, *args):
     lib = load()
     rc = getattr(lib, name)(*args)
+    if rc != 0:
+        for hook in FAILURE_HOOKS:
+            hook(name)
     check(rc, name)

@@ -194,11 +194,13 @@ __device__ __forceinline__ f32x16 mfma_pieces(const bf16x8 (&a)[3], const bf16x8
 struct H2Scales {
     float q, k, v, d_o, ds;          // operand tensors (from their maxima); dS: from the bound |dS| <= 128 / (1 - p) max|dO| max|V|
     float inv_qk, inv_v, inv_q, inv_k, inv_do, inv_ds;
+    float ds_coef;                   // 128 / (1 - p) max|V|: times a ROW's max|dO| = that row's dS bound (the dQ kernel scales per row)
     static constexpr float P = 8192.f, INV_P = 1.f / 8192.f;       // probabilities (<= 1 / (1 - p_drop) < 4)
     __device__ __forceinline__ H2Scales(const uint32_t* __restrict__ aq, const uint32_t* __restrict__ ak,
                                         const uint32_t* __restrict__ av, const uint32_t* __restrict__ ado, float q_prescale,
                                         float drop_scale = 1.f) {
         q = k = v = d_o = ds = inv_q = inv_k = inv_v = inv_do = inv_ds = inv_qk = 1.f;
+        ds_coef = 0.f;
         if (aq) {
             // q enters its products multiplied by q_prescale (the softmax scale, log2 domain): scale that product's maximum
             const uint32_t mv = amax_read(av);
@@ -210,7 +212,8 @@ struct H2Scales {
                 const uint32_t mdo = amax_read(ado);
                 scale_from_amax(mdo, d_o, inv_do);
                 // dS = p (mult dP - delta), p <= 1, |dP| <= 64 max|dO| max|V|, |delta| <= 64 max|dO| max|O|, |O| <= mult max|V|
-                const float bound = 128.f * drop_scale * __uint_as_float(mdo) * __uint_as_float(mv);
+                ds_coef = 128.f * drop_scale * __uint_as_float(mv);
+                const float bound = ds_coef * __uint_as_float(mdo);
                 scale_from_amax(__float_as_uint(bound), ds, inv_ds);
             }
             inv_qk = inv_q * inv_k;
@@ -617,11 +620,18 @@ attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict
     const float qs = scale * 1.4426950408889634f;
     bf16x8 qf[3][4];                      // piece x k-step of the pre-scaled q row (lane = query)
     float my_delta = 0.f;                 // delta_i = dO_i . O_i: computed here and published for the dK/dV kernel unless ready
+    // H2: dO and dS are scaled PER QUERY ROW here - the query is on the lane in both products that consume them (dP^T = V dO^T,
+    // dQ^T = K^T dS^T: the row index is never contracted), so the scale is a per-lane factor of the accumulators.  A row of dO
+    // far below the tensor's maximum (a low-gradient token, or every other row once one row holds an outlier) then keeps its
+    // full relative precision; the dK/dV kernel contracts OVER the rows and keeps the tensor's scale (a small row is a small term).
+    float my_sdo = sc.d_o, my_inv_do = sc.inv_do, my_sds = sc.ds, my_inv_ds = sc.inv_ds;
     {
         const float* qrow = q + tok * ldq + head * 64 + 8 * h;
         const float* drow = d_o + tok * (int64_t)nq * 64 + head * 64 + 8 * h;
         const float* orow = o + tok * (int64_t)nq * 64 + head * 64 + 8 * h;
         bf16_t* dimg = dOs[w];
+        float4 du[4], dw[4];
+        float rowmax = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             float4 a4 = *reinterpret_cast<const float4*>(qrow + 16 * s);
@@ -639,8 +649,23 @@ attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict
                 my_delta += u4.x * o4.x + u4.y * o4.y + u4.z * o4.z + u4.w * o4.w + w4.x * p4.x + w4.y * p4.y + w4.z * p4.z + w4.w * p4.w;
             }
             if (!valid_q) { u4 = make_float4(0.f, 0.f, 0.f, 0.f); w4 = u4; }
+            du[s] = u4; dw[s] = w4;
+            if (H2) {
+                rowmax = fmaxf(fmaxf(fmaxf(rowmax, fabsf(u4.x)), fabsf(u4.y)), fmaxf(fabsf(u4.z), fabsf(u4.w)));
+                rowmax = fmaxf(fmaxf(fmaxf(rowmax, fabsf(w4.x)), fabsf(w4.y)), fmaxf(fabsf(w4.z), fabsf(w4.w)));
+            }
+        }
+        if (H2) {
+            rowmax = fmaxf(rowmax, __shfl_xor(rowmax, 32, 64));          // the row's other 32 columns
+            if (rowmax > 0.f) {                                          // (an all-zero row keeps the tensor's scales: its pieces are 0)
+                scale_from_amax(__float_as_uint(rowmax), my_sdo, my_inv_do);
+                scale_from_amax(__float_as_uint(sc.ds_coef * rowmax), my_sds, my_inv_ds);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
             bf16x8 dpc[3];
-            cut8_t<H2>(u4, w4, sc.d_o, dpc);
+            cut8_t<H2>(du[s], dw[s], my_sdo, dpc);
             // this lane's 8 values are columns 16 s + 8 h .. + 7 of row r: exactly what read_row8 hands back to it
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<bf16x8*>(dimg + pc * SIMG + lo.row[s]) = dpc[pc];
@@ -735,7 +760,7 @@ attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict
             }
             if (!beyond) { SPLIT_QK_TILE(st, Ks) }
             if (H2) {
-                const float cdp = sc.inv_v * sc.inv_do;
+                const float cdp = sc.inv_v * my_inv_do;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) dp[i] *= cdp;
                 if (!beyond) {
@@ -762,7 +787,7 @@ attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     bf16x8 df[3];
-                    cut8_regs_t<H2>(ds, 8 * s2, sc.ds, df);
+                    cut8_regs_t<H2>(ds, 8 * s2, my_sds, df);
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
                         bf16x8 kf[3];
@@ -812,7 +837,7 @@ attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict
 
     if (valid_q) {
         float fs = my_empty ? scale * invS : scale;
-        if (H2) fs *= sc.inv_ds * sc.inv_k;
+        if (H2) fs *= my_inv_ds * sc.inv_k;
         float* drow = dq + tok * lddq + head * 64;
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh) {
@@ -1515,6 +1540,7 @@ static thread_local uint32_t* t_amax_out = nullptr;
 // the operand maxima armed for the entry point in progress (gamer_attn_split_amax): non-null q selects the H2 form
 static thread_local AttnAmax t_attn_amax = {nullptr, nullptr, nullptr, nullptr};
 static thread_local AttnAmax g_attn_amax_armed = {nullptr, nullptr, nullptr, nullptr};
+void disarm_attn_amax() { g_attn_amax_armed = AttnAmax{nullptr, nullptr, nullptr, nullptr}; }
 
 template <int G>
 static int launch_fwd_s(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl,
@@ -1636,6 +1662,8 @@ extern "C" int gamer_attn_fwd_split(const float* q, int ldq, const float* k, int
     t_attn_amax = g_attn_amax_armed;                    // gamer_attn_split_amax: the three-product fp16 form
     g_attn_amax_armed = AttnAmax{nullptr, nullptr, nullptr, nullptr};
     GAMER_CHECK_ARG(!t_attn_amax.q || (t_attn_amax.k && t_attn_amax.v), "gamer_attn_fwd_split: gamer_attn_split_amax needs q, k and v");
+    GAMER_CHECK_ARG(!t_attn_amax.q || p_drop < 0.75f, "gamer_attn_fwd_split: the three-product fp16 form needs p_drop < 0.75 (p_drop=%f): "
+                    "its probabilities are cut at a fixed 2^13 scale; do not arm gamer_attn_split_amax for this call", p_drop);
     rc = (nq / nkv == 1) ? launch_fwd_s<1>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st)
                          : launch_fwd_s<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st);
     t_amax_out = nullptr;
@@ -1669,6 +1697,7 @@ extern "C" int gamer_attn_bwd_split(const float* q, int ldq, const float* k, int
     g_attn_amax_armed = AttnAmax{nullptr, nullptr, nullptr, nullptr};
     GAMER_CHECK_ARG(!t_attn_amax.q || (t_attn_amax.k && t_attn_amax.v && t_attn_amax.d_o && !ds_work),
                     "gamer_attn_bwd_split: gamer_attn_split_amax needs q, k, v and d_o, and the recompute form (ds_work = NULL)");
+    GAMER_CHECK_ARG(!t_attn_amax.q || p_drop < 0.75f, "gamer_attn_bwd_split: the three-product fp16 form needs p_drop < 0.75 (p_drop=%f)", p_drop);
     rc = (nq / nkv == 1)
         ? launch_bwd_s<1>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, ds_work, st)
         : launch_bwd_s<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, ds_work, st);

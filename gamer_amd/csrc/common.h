@@ -124,6 +124,7 @@ __device__ __forceinline__ void scale_from_amax(uint32_t bits, float& s, float& 
 // maximum).  The pointers travel as kernel arguments - stream-ordered like everything else - and are disarmed by the launch.
 struct AmaxSink { uint32_t* out[2]; };
 AmaxSink take_amax_sink();
+void disarm_attn_amax();            // (attention_split.hip) drops what gamer_attn_split_amax armed; set_error calls both
 // (float maxima: |x| is a free source modifier and max3 takes two values per instruction; a NaN is ignored here - it reaches the
 // GEMM as a NaN piece whatever the scale is)
 __device__ __forceinline__ uint32_t amax_f4(uint32_t m, const float4 v) {

@@ -262,7 +262,24 @@ struct GemmParams {
     const uint32_t* amax_a; const uint32_t* amax_b;   // SPLIT == 3: bits of max |A|, max |B| (gamer_absmax_f32)
     const uint16_t* b_planes;      // SPLIT, MODE 0: B pre-cut into three bf16 planes indexed like B (nullptr: cut in the kernel)
     int64_t b_plane_stride;
+    int guard;                     // SPLIT == 3, MODE 0: row-range guard of the A operand (gamer_split3_guard; default on)
 };
+
+// SPLIT == 3 scales a whole operand TENSOR by one power of two, so a row of A whose largest magnitude lies more than 2^16 below
+// the tensor's keeps only an absolute precision (2^-38 of the tensor's maximum): relative to that row's own result the error
+// grows as 2^(r - 38) for a row 2^r below the maximum - an outlier element or a loss spike anywhere in the tensor does that to
+// every other row, and the input-gradient GEMMs see it on low-gradient rows.  Guard (Linear-forward and input-gradient
+// layouts, where a row of A is a row of C): every thread tracks max |a| of the rows it stages (one v_max3 per two values), and
+// a tile that holds a non-zero row below 2^-16 of the tensor's maximum is computed AGAIN from the fp32 operands in global
+// memory with v_mfma_f32_32x32x2_f32 (exact fp32 products; slow, rare) before the epilogue - decided on the device, no host
+// synchronisation, results of unaffected tiles bit-identical to the unguarded kernel.  Not guarded: the B operand (parameters;
+// their rows and columns stay within a few powers of two of each other) and the weight-gradient layout (its contraction runs
+// over the tokens: a small row contributes a small term, the error stays relative to sum |a_k b_k|).
+constexpr float SPLIT3_GUARD_RATIO = 1.f / 65536.f;
+#ifndef GAMER_SPLIT3_GUARD_BUILD
+#define GAMER_SPLIT3_GUARD_BUILD 1      // 0: timing-only builds without the row-maximum tracking (tools: what the guard costs)
+#endif
+static int g_split3_guard = 1;
 
 // blockIdx -> logical tile id such that consecutive logical ids run on one XCD (ids are dealt
 // round-robin over the 8 XCDs); bijective for any grid size.
@@ -385,6 +402,7 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
     int col0;                   // C column tile start
     int kbeg, kend;             // contraction range
     const float* Bp = p.B;
+    const float* Bsrc = p.B;    // the fp32 values of this tile's B (Bp may point at their packed pieces)
     float* Cp = p.C;
     if (MODE == 0) {
         const int mt = L / p.n_tiles;
@@ -414,6 +432,7 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
         // SPLIT == 3 with pre-cut parameters: `b_planes` holds, at the SAME offsets as B, 16 bytes per four elements = their four
         // h0 pieces and their four h1 pieces (gamer_split2h_planes_multi) - the loads below stay what they are, the B half of the
         // cut becomes two 8-byte LDS stores
+        Bsrc = Bp;
         if (SPLIT == 3 && p.b_planes) Bp = reinterpret_cast<const float*>(p.b_planes) + (Bp - p.B);
     } else {
         const int tiles_mn = p.m_tiles * p.n_tiles;
@@ -459,9 +478,13 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
     const bool a_in = row0 + BM <= row_end, b_in = col0 + BN <= col_end;     // workgroup-uniform
     float4 ra[4], rb[4];
     float scale_a = 1.f, scale_b = 1.f, unscale = 1.f;
+    constexpr bool GUARD = GAMER_SPLIT3_GUARD_BUILD && SPLIT == 3 && MODE == 0 && A_KC && !PP && !STAMP;
+    float rmax[4] = {0.f, 0.f, 0.f, 0.f};          // GUARD: max |a| of this thread's part of rows (tid >> 3) + 32 j
+    uint32_t amax_a_bits = 0;
     if (SPLIT == 3) {
         float ia, ib;
-        scale_from_amax(amax_read(p.amax_a), scale_a, ia);
+        amax_a_bits = amax_read(p.amax_a);
+        scale_from_amax(amax_a_bits, scale_a, ia);
         scale_from_amax(amax_read(p.amax_b), scale_b, ib);
         unscale = ia * ib;
     }
@@ -490,6 +513,13 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
         if (SPLIT == 3) {
             unsigned char* d8 = reinterpret_cast<unsigned char*>(dst);
             if (A_KC) store_kc_h2(d8, tid, qa, scale_a); else store_rc_h2(d8, tid, qa, scale_a);
+            if (GUARD) {
+                // two v_max3_f32 per float4 (|x| is a source modifier; the C form costs a canonicalising v_max per operand: 7 per float4)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    asm("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|"
+                        : "+v"(rmax[j]) : "v"(qa[j].x), "v"(qa[j].y), "v"(qa[j].z), "v"(qa[j].w));
+            }
             if (MODE == 0 && p.b_planes) {          // packed pieces: {h0 x 4 | h1 x 4} per float4 slot
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -880,9 +910,63 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
     if (PP && grp == 0) __syncthreads();                           // pairs with group 1's last barrier
     const unsigned long long t_loop_end = STAMP ? stamp_now() : 0;
 
+    // ---- SPLIT == 3 row-range guard (see SPLIT3_GUARD_RATIO): a tile with a row too far below the tensor's maximum is redone in fp32
+    bool redo = false;
+    if (GUARD && p.guard) {
+        const float thr = __uint_as_float(amax_a_bits) * SPLIT3_GUARD_RATIO;      // (Inf / NaN maximum: every tile takes the fp32 path)
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float m = rmax[j];                                                    // the row's 8 threads are 8 consecutive lanes
+            m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
+            bad |= (m > 0.f) & !(m >= thr);
+        }
+        // workgroup OR through the tail of the DYNAMIC allocation (behind the epilogue's four 64 x 68 patches; the K loop's last
+        // barrier has retired every read of the images): a static __shared__ word - what __syncthreads_or takes - would push the
+        // forward layout's 2 x 40,960-byte stages past half of the CU's 160 KB and leave ONE workgroup per CU (+47 % measured)
+        int* flags = reinterpret_cast<int*>(smem + 4 * 64 * 68);
+        const bool wave_bad = __any(bad ? 1 : 0) != 0;
+        if (lane == 0) flags[wid] = wave_bad ? 1 : 0;
+        __syncthreads();
+        redo = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+        if (redo) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            if (wave_live) {
+                // lane (r32, h) supplies A(row, k + h) and B(col, k + h) of v_mfma_f32_32x32x2_f32, straight from global memory
+                const int ar0 = row0 + wm * 64 + r32, bc0 = col0 + wn * 64 + r32;
+#pragma unroll 1
+                for (int k = kbeg; k < kend; k += 2) {
+                    const int kk = k + h;
+                    const bool kin = kk < kend;
+                    float av[2], bv[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = ar0 + i * 32;
+                        av[i] = (kin && row < row_end) ? p.A[(int64_t)row * p.a_rs + kk] : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int col = bc0 + j * 32;
+                        bv[j] = (kin && col < col_end) ? (B_KC ? Bsrc[(int64_t)col * p.b_rs + kk] : Bsrc[(int64_t)kk * p.b_ks + col]) : 0.f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
     // ---- epilogue: acc[i][j][r] is C[row = (r&3)+8*(r>>2)+4*h][col = lane&31] of its 32x32 tile --
     const bool interior = a_in && b_in;
-    const float alpha_eff = SPLIT == 3 ? p.alpha * unscale : p.alpha;      // (alpha and 1 / (s_a s_b) are powers of two or 1 in the step)
+    const float alpha_eff = (SPLIT == 3 && !redo) ? p.alpha * unscale : p.alpha;      // (alpha and 1 / (s_a s_b) are powers of two or 1 in the step)
     if (MODE == 0 && (NBUF == 2 || SPLIT) && interior && (p.ldc & 3) == 0) {
         // Row-major rewrite through LDS (the K-loop images are dead after its last barrier): each wave
         // parks its 64x64 patch as [64][68] floats and reads it back one 16-byte row chunk per lane, so the
@@ -1236,6 +1320,7 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     p.qk_act_idx = d->qk_act_idx; p.qk_pos_ids = d->qk_pos_ids; p.qk_q_rot = d->qk_q_rot; p.qk_k_rot = d->qk_k_rot;
     p.qk_S = d->qk_S; p.qk_nq = d->qk_nq; p.qk_nkv = d->qk_nkv;
     p.amax_a = d->amax_a; p.amax_b = d->amax_b;
+    p.guard = g_split3_guard;
     GAMER_CHECK_ARG(split != 3 || (d->amax_a && d->amax_b), "gamer_gemm_f32_split: terms = 3 needs amax_a and amax_b (gamer_absmax_f32)");
     p.b_planes = (split && d->group_mode == 0) ? (const uint16_t*)d->b_planes : nullptr;
     p.b_plane_stride = d->b_plane_stride;
@@ -1243,6 +1328,9 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
                     "gamer_gemm_f32_split: b_planes must be 8-byte aligned with b_plane_stride %% 4 == 0");
     GAMER_CHECK_ARG(!p.b_planes || split != 3 || (reinterpret_cast<uintptr_t>(p.b_planes) & 15u) == 0,
                     "gamer_gemm_f32_split: terms = 3 takes b_planes as packed pieces at B's offsets (16-byte aligned)");
+    // packed pieces hold FOUR elements per 16 bytes ({h0 x 4 | h1 x 4}): the ragged-quad masking of the edge tiles works on
+    // plain fp32 lanes, so a B whose contiguous extent is not a multiple of 4 is cut in the kernel instead (same bits)
+    if (split == 3 && p.b_planes && ((b_kc ? d->K : d->N) % 4) != 0) p.b_planes = nullptr;
     GAMER_CHECK_ARG(!d->qk_q_rot || (d->qk_k_rot && d->qk_wq && d->qk_wk && d->qk_cos && d->qk_sin && d->group_mode == 0 &&
                                      d->groups == 1 && a_kc && b_kc && !d->resid && !d->rowdot_out && !d->accumulate &&
                                      d->alpha == 1.f && d->M % BM == 0 && d->qk_nq > 0 && d->qk_nkv > 0 && d->qk_S > 0 &&
@@ -1406,6 +1494,12 @@ extern "C" int gamer_split2h_planes_multi(const float* base, const int64_t* tabl
 }
 
 extern "C" int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream) { return gemm_entry(d, stream, 0); }
+
+extern "C" int gamer_split3_guard(int on) {
+    const int prev = g_split3_guard;
+    if (on >= 0) g_split3_guard = on ? 1 : 0;
+    return prev;
+}
 
 extern "C" int gamer_gemm_f32_split(const gamer_gemm_desc* d, int terms, void* stream) {
     GAMER_CHECK_ARG(terms == 3 || terms == 6 || terms == 9, "gamer_gemm_f32_split: terms=%d (3, 6 or 9)", terms);

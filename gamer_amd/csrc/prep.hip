@@ -12,6 +12,10 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+    // every failing entry point comes through here: whatever the caller armed for "the next launch" (gamer_amax_sink,
+    // gamer_attn_split_amax) must not survive a rejected call and attach itself to a later launch of another tensor
+    take_amax_sink();
+    disarm_attn_amax();
 }
 
 constexpr int ROUTER_THREADS = 256;

@@ -85,6 +85,45 @@ def prefix_allowed_tokens(trie: ItemTrie):
     return fn
 
 
+def trie_from_callable(fn, input_ids, max_new_tokens: int, device="cuda", pad_token_id: int = 4) -> ItemTrie:
+    """Device trie equivalent to an arbitrary ``prefix_allowed_tokens_fn(batch_id, sentence) -> allowed token ids`` for
+    prompts that end with a target behaviour token - the closure the evaluation task builds per behaviour
+    (ref:SeqRec/tasks/test_SMB_decoder.py:470-500, ref:SeqRec/generation/trie.py:90-104) passed to ``generate`` unchanged.
+    The callable is walked depth first from one prompt per distinct final token (its answers only depend on the tokens
+    since the last item-ending token, i.e. on [behaviour token] + generated), ``max_new_tokens`` levels deep: one host
+    call per trie node, once - the result is cached on the callable (``fn._gamer_tries``)."""
+    ids = input_ids.detach().cpu()
+    cache = getattr(fn, "_gamer_tries", None)
+    if cache is None:
+        cache = {}
+        try:
+            fn._gamer_tries = cache
+        except AttributeError:                      # a callable without a __dict__: walk it every time
+            pass
+    last = ids[:, -1]
+    key = (tuple(sorted(set(int(t) for t in last.tolist()))), int(max_new_tokens), str(device))
+    if key in cache:
+        return cache[key]
+    sequences = []
+    for tok in key[0]:
+        b = int((last == tok).nonzero()[0])
+        prompt = ids[b].tolist()
+
+        def walk(prefix):
+            if len(prefix) == max_new_tokens:
+                sequences.append([tok] + prefix)
+                return
+            allowed = [int(t) for t in fn(b, torch.tensor(prompt + prefix))]
+            if not allowed and prefix:                          # an item shorter than max_new_tokens
+                sequences.append([tok] + prefix)
+            for t in allowed:
+                walk(prefix + [t])
+        walk([])
+    trie = ItemTrie(sequences, device=device, pad_token_id=pad_token_id)
+    cache[key] = trie
+    return trie
+
+
 class DecodeSession:
     """K/V cache of one generation run + the single-token forward over it (model.py:118-121, 784-785).
 
@@ -176,8 +215,12 @@ class DecodeSession:
             self.gen[key] = (kg.index_select(0, parent), vg.index_select(0, parent))
 
     @ops.scoped_f32_matmul(lambda self, *a: self.eng.matmul)
+    @ops.scoped_amax(lambda self, *a: self.eng._amax)
     def step(self, tokens: torch.Tensor) -> torch.Tensor:
-        """tokens [N] int64: the token just appended to every beam.  Returns the next-token logits [N, ld]."""
+        """tokens [N] int64: the token just appended to every beam.  Returns the next-token logits [N, ld].
+        (matmul="split3": runs inside the engine's maxima cache - the parameters keep the slots of the prompt pass, which
+        measured them once (they cannot change during a generation), the producers of the step's activations hand their
+        maxima to the GEMMs (gamer_amax_sink) - instead of two gamer_absmax_f32 launches per GEMM and token.)"""
         eng, cfg, b = self.eng, self.eng.cfg, self.buf
         N, B, nb, L0 = self.N, self.B, self.nb, self.L0
         H, I, E = cfg.hidden_size, cfg.intermediate_size, cfg.num_experts

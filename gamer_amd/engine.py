@@ -341,7 +341,7 @@ class Engine:
     N_SUMSQ_PARTIAL = 1024
 
     def __init__(self, cfg: Qwen3MultiConfig, device="cuda", temperature: float = 1.0, variant: str = "multi",
-                 dtype: str = "f32", matmul: Optional[str] = None):
+                 dtype: str = "f32", matmul: Optional[str] = None, share_buffers_of: Optional["Engine"] = None):
         """``variant``: "multi" = Qwen3Multi (train_SMB_decoder.py:362-364), "session" = Qwen3SessionMulti
         (train_SMB_decoder.py:365-367): the same parameters and layers with session-wise attention masks and
         RoPE positions taken from ``extended_session_ids``.
@@ -356,7 +356,10 @@ class Engine:
         "split3" (the default) = the Linear sites as THREE fp16 piece products of a two-way cut of both operands, each
         operand tensor scaled by a power of two from its largest magnitude (gamer_absmax_f32) - the
         same error against fp64 at half the matrix instructions; the attention products take the same three-product form
-        (``self.h2_attention = False`` keeps them in the six-product bf16 form)."""
+        (``self.h2_attention = False`` keeps them in the six-product bf16 form).
+        ``share_buffers_of``: another engine of the same configuration whose flat parameter and gradient buffers this one
+        uses instead of allocating its own - the nn.Module keeps one set of fp32 masters and runs them through the fp32 or the
+        bf16 step depending on the caller's autocast state (gamer_amd/modeling.py)."""
         cfg.validate()
         if matmul is None:
             # default of the fp32 path: products on the 16-bit matrix pipe from piece cuts (DESIGN.md sections 13, 15, 17);
@@ -394,8 +397,13 @@ class Engine:
         self.temperature = float(temperature)
         self.layout = ParamLayout(cfg)
         n = self.layout.numel
-        self.flat_p = torch.zeros(n, dtype=torch.float32, device=self.device)
-        self.flat_g = torch.zeros(n, dtype=torch.float32, device=self.device)
+        if share_buffers_of is not None:
+            if share_buffers_of.layout.numel != n or share_buffers_of.device != self.device:
+                raise ValueError("share_buffers_of: the other engine has another parameter layout or device")
+            self.flat_p, self.flat_g = share_buffers_of.flat_p, share_buffers_of.flat_g
+        else:
+            self.flat_p = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.flat_g = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.flat_m: Optional[torch.Tensor] = None
         self.flat_v: Optional[torch.Tensor] = None
         self.params = self.layout.views(self.flat_p)
@@ -618,7 +626,7 @@ class Engine:
         def attention(qb, kb, vb, kl_, ql_, empty_, tile_empty_, seed_, ob, lseb, order_, span_):
             if split_attn and span_ is None:
                 ops.attn_fwd_split(qb, NQ, kb, NKV, vb, QKV, kl_, ql_, empty_, B, S, nq, nkv, scale, p_att, seed_, ob, lseb,
-                                   order=order_, h2=self.h2_attention and self.matmul == "split3")
+                                   order=order_, h2=self.h2_attention and self.matmul == "split3" and p_att < 0.75)
             elif bf16:
                 ord16 = (order_[0], order_[2], empty_) if (order_ is not None and span_ is None) else None
                 ops.attn_fwd_bf16(qb, NQ, kb, NKV, vb, QKV, kl_, ql_, B, S, nq, nkv, scale, p_att, seed_, ob, lseb,
@@ -808,7 +816,7 @@ class Engine:
                 ops.attn_bwd_split(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, empty_, tile_empty_, B, S, nq, nkv, scale,
                                    p_att, seed_, ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, order=order_,
                                    delta_ready=fuse_delta, dv_of=ws.dqkv,   # recompute form: measured faster than its dS spill
-                                   h2=self.h2_attention and self.matmul == "split3")
+                                   h2=self.h2_attention and self.matmul == "split3" and p_att < 0.75)
             elif bf16:
                 ord16 = (order_[0], order_[2], empty_) if (order_ is not None and span_ is None) else None
                 ops.attn_bwd_bf16(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, B, S, nq, nkv, scale, p_att, seed_,

@@ -38,10 +38,29 @@ class CausalLMOutput(OrderedDict):
         return super().__getitem__(k)
 
 
+def _autocast_dtype():
+    """dtype of the autocast region the caller runs in, or None.  HF Trainer / accelerate wrap ``forward`` in
+    ``torch.autocast(device_type, dtype=torch.bfloat16)`` when the task passes ``TrainingArguments(bf16=True)``
+    (ref:SeqRec/tasks/train_SMB_decoder.py:114-118, 407-408) - that region IS the reference's bf16 switch."""
+    try:
+        if torch.is_autocast_enabled("cuda"):
+            return torch.get_autocast_dtype("cuda")
+    except TypeError:                                         # older torch: no device argument
+        if torch.is_autocast_enabled():
+            return torch.get_autocast_gpu_dtype()
+    return None
+
+
+try:                                                          # isinstance(model, GenerationMixin) is how the evaluation task decides
+    from transformers.generation.utils import GenerationMixin as _GenerationMixin    # whether to call model.generate or
+except Exception:                                             # noqa: BLE001          model.module.generate (test_SMB_decoder.py:141-145)
+    class _GenerationMixin:                                   # transformers absent: nothing checks the type
+        pass
+
+
 class _ModelFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, input_ids, attention_mask, actions, labels, num_items, sess, *params):
-        eng: Engine = model.engine
+    def forward(ctx, model, eng, input_ids, attention_mask, actions, labels, num_items, sess, *params):
         loss, logits = eng.forward(input_ids, attention_mask, actions, labels=labels, num_items_in_batch=num_items,
                                    train=True, dropout=model.training, session_ids=sess[0],
                                    extended_session_ids=sess[1])
@@ -52,14 +71,14 @@ class _ModelFn(torch.autograd.Function):
         # instead of a 2.2 GB copy per forward at batch 1024.
         if not model.zero_copy_logits:
             logits = logits.clone()
-        ctx.model = model
+        ctx.model, ctx.eng = model, eng
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(logits)
         return loss, logits
 
     @staticmethod
     def backward(ctx, dloss, _dlogits):
-        eng: Engine = ctx.model.engine
+        eng: Engine = ctx.eng          # the engine the forward ran on (fp32, or the bf16 one under autocast): same flat gradient buffer
         eng.zero_grad()
         red = ctx.model._reducer
         done = red.layer_done if red is not None else None
@@ -74,7 +93,7 @@ class _ModelFn(torch.autograd.Function):
         # gradient buffer is rewritten by the next backward.  After enable_dp_overlap() the sum over ranks becomes DDP's mean.
         flat = eng.flat_g.clone() if red is None or red.world == 1 else eng.flat_g / float(red.world)
         grads = [flat[o:o + math.prod(s)].view(s) for o, s in (eng.layout.entries[k] for k in ctx.model._param_keys)]
-        return (None, None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, None, *grads)
 
 
 class _Holder(nn.Module):
@@ -101,7 +120,7 @@ except Exception:                                             # noqa: BLE001
     pass
 
 
-class Qwen3MultiWithTemperature(nn.Module):
+class Qwen3MultiWithTemperature(nn.Module, _GenerationMixin):
     VARIANT = "multi"
 
     def __init__(self, config, device: str = "cuda", dtype: str = "f32", matmul: Optional[str] = None):
@@ -112,7 +131,7 @@ class Qwen3MultiWithTemperature(nn.Module):
         ``dtype="bf16"``: what the reference gets from ``--bf16`` (HF Trainer autocast) is a property of the engine
         here - bf16 matrix operands and activations, fp32 parameters / gradients (the nn.Parameters stay fp32).
         ``matmul``: the engine's form of the fp32 matrix products (None = its default "split3"; "split6" = exact bf16 pieces; "f32" = fp32 MFMA)."""
-        super().__init__()
+        nn.Module.__init__(self)
         assert hasattr(config, "num_positions") and isinstance(config.num_positions, int), \
             "Config must have 'num_positions' attribute for Qwen3SessionModel."
         assert hasattr(config, "model_max_length") and isinstance(config.model_max_length, int), \
@@ -125,8 +144,27 @@ class Qwen3MultiWithTemperature(nn.Module):
         self._reducer = None                # enable_dp_overlap(): the engine's own per-layer gradient all-reduce
         self.engine = Engine(self._cfg, device=device, temperature=1.0, variant=self.VARIANT, dtype=dtype, matmul=matmul)
         self.engine.init_weights(seed=0)
+        self._amp_engine: Optional[Engine] = None     # the bf16 step over the SAME masters / gradients, built on first use under autocast
         self._param_keys = list(self.engine.layout.entries.keys())
         self._register_views()
+
+    def _engine_for_call(self) -> Engine:
+        """The reference's precision switch is the caller's autocast region (HF Trainer, ``TrainingArguments(bf16=True)``:
+        ref:SeqRec/tasks/train_SMB_decoder.py:114-118, 407-408).  Honour it: under ``torch.autocast(dtype=bfloat16)`` the
+        call runs the bf16 step (``Engine(dtype="bf16")``: bf16 matrix operands and activations, fp32 masters, gradients,
+        residual stream and loss - what autocast does to the reference) on an engine that shares this module's flat
+        parameter and gradient buffers; fp16 autocast is refused (the reference's --fp16 run is not built); no autocast =
+        the engine the module was constructed with.  Never a silent fp32 run inside a bf16 region."""
+        ac = _autocast_dtype()
+        if ac is None or self.engine.dtype == "bf16":
+            return self.engine
+        if ac != torch.bfloat16:
+            raise NotImplementedError(f"autocast dtype {ac}: the bf16 (--bf16) and fp32 steps are built, --fp16 is not")
+        if self._amp_engine is None:
+            self._amp_engine = Engine(self._cfg, device=str(self.engine.device), temperature=self.temperature,
+                                      variant=self.VARIANT, dtype="bf16", share_buffers_of=self.engine)
+        self._amp_engine.temperature = float(self.temperature)
+        return self._amp_engine
 
     def enable_dp_overlap(self, group=None):
         """Under DistributedDataParallel (HF Trainer wraps the module, ref:SeqRec/tasks/train_SMB_decoder.py:420) the whole
@@ -182,6 +220,7 @@ class Qwen3MultiWithTemperature(nn.Module):
         self.engine = Engine(self._cfg, device=str(self.engine.device), temperature=self.temperature,
                              variant=self.VARIANT, dtype=self.engine.dtype, matmul=self.engine.matmul)
         self.engine.init_weights(seed=0)
+        self._amp_engine = None                               # (rebuilt over the new buffers on the next autocast call)
         if self._reducer is not None:                         # the flat gradient buffer is a new one
             self.enable_dp_overlap(self._reducer.group)
         for name in list(self._modules):                      # drop the old parameter tree
@@ -242,8 +281,14 @@ class Qwen3MultiWithTemperature(nn.Module):
         from . import decode
         if trie is None:
             trie = getattr(prefix_allowed_tokens_fn, "trie", None)
+        if trie is None and callable(prefix_allowed_tokens_fn):
+            # the reference's own closure (prefix_allowed_tokens_fn_by_last_token, ref:SeqRec/generation/trie.py:90-104): walked
+            # once per target behaviour token into a device trie and cached on the callable
+            trie = decode.trie_from_callable(prefix_allowed_tokens_fn, input_ids, max_new_tokens,
+                                             device=self.engine.device, pad_token_id=self._cfg.pad_token_id)
         if trie is None:
-            raise NotImplementedError("generate() needs trie=ItemTrie(...) (constrained beam search of the SMB evaluation)")
+            raise NotImplementedError("generate() needs trie=ItemTrie(...) or prefix_allowed_tokens_fn (constrained beam search "
+                                      "of the SMB evaluation)")
         if num_return_sequences not in (None, num_beams):
             raise NotImplementedError("num_return_sequences must equal num_beams (what the evaluation task uses)")
         if attention_mask is None or actions is None:
@@ -267,12 +312,12 @@ class Qwen3MultiWithTemperature(nn.Module):
         num_items = kwargs.get("num_items_in_batch", None)
         if torch.is_tensor(num_items):
             num_items = float(num_items)
-        eng = self.engine
+        eng = self._engine_for_call()
         sess = (session_ids, extended_session_ids) if self.VARIANT == "session" else (None, None)
         needs_grad = torch.is_grad_enabled() and labels is not None
         if needs_grad:
             params = [self._params_by_key[k] for k in self._param_keys]
-            loss, logits = _ModelFn.apply(self, input_ids, attention_mask, actions, labels, num_items, sess, *params)
+            loss, logits = _ModelFn.apply(self, eng, input_ids, attention_mask, actions, labels, num_items, sess, *params)
         else:
             with torch.no_grad():
                 loss, logits = eng.forward(input_ids, attention_mask, actions, labels=labels,

@@ -311,11 +311,23 @@ class amax_reuse:
             self.slots[key] = ptr_
             if (len(key) == 3 and self.stable_ranges and key[2] % 4 == 0 and
                     self.stable_ranges[0][0] <= p < self.stable_ranges[0][0] + self.stable_ranges[0][1] and
-                    (p, key[2]) not in self._wkeys):
-                self._wkeys.append((p, key[2]))     # a parameter tensor: part of the one-launch measurement from the next pass on
+                    not any(p_ < p + 4 * key[2] and p < p_ + 4 * n_ for (p_, n_) in self._wkeys)):
+                # a parameter tensor: part of the one-launch measurement from the next pass on.  Tensors that OVERLAP a registered
+                # one (one expert's slice of a stacked weight in the decode step) stay per-pass measurements: their packed pieces
+                # would land on the registered tensor's, cut with another scale
+                self._wkeys.append((p, key[2]))
                 self._wdev = x.device
         return ptr_
 
+
+def _drop_pending_on_failure(name):
+    """A rejected entry point never wrote the maxima slots its producers were armed with (the C side disarms the sink itself,
+    set_error): forget them, or a later GEMM keyed by the same (address, extent) would scale by a slot that still holds 0."""
+    if _AMAX_REUSE is not None:
+        _AMAX_REUSE.pending.clear()
+
+
+_lib.FAILURE_HOOKS.append(_drop_pending_on_failure)
 
 _AMAX_ATTN = os.environ.get("GAMER_AMAX_ATTN", "1") != "0"      # the attention kernels as producers (o, dv) - A/B switch
 
@@ -367,6 +379,22 @@ def absmax_slot(x, batch, stride, rows, cols, ld):
 def split3_planes(x, planes):
     """planes [3, n] bf16 <- the three exact bf16 pieces of x [n] fp32 (gamer_split3_planes)."""
     call("gamer_split3_planes", ptr(x), ptr(planes), x.numel(), planes.stride(0), stream_ptr())
+
+
+class split3_guard:
+    """Context manager: the row-range guard of the split3 GEMMs on / off for the block (gamer_split3_guard in include/gamer_hip.h;
+    on by default).  Tests turn it off to show what it guards against."""
+
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _lib.load().gamer_split3_guard(1 if self.on else 0)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().gamer_split3_guard(self.prev)
+        return False
 
 
 def set_f32_matmul(mode) -> int:

@@ -107,6 +107,59 @@ def make_batch(batch_size: int, n_items: int = 101, codebook: int = 256, num_beh
     }
 
 
+def make_augmented_batch(batch_size: int, n_items: int = 101, codebook: int = 256, num_behavior: int = 3, augment: int = 4,
+                         seed: int = 20251114, behavior_probs: Optional[Sequence[float]] = None, min_full: int = 20,
+                         max_full: int = 250) -> Dict[str, torch.Tensor]:
+    """One collated training batch shaped like ``tasks=smb_explicit_decoder_<augment>`` (BASELINE configs[3]): every row is a
+    user's interaction list or one of its ``augment`` thinned copies - copy r drops floor(count_b * (r / augment) / (level_b + 1))
+    random interactions of every behaviour below the target level (ref:SeqRec/datasets/SMB_dataset.py:540-584) -, cropped
+    to the LAST ``n_items`` interactions (max_his_len + 1) and right padded to the batch's longest row, as the collator does.
+    Full lengths are U{min_full..max_full} (the real ShortVideoAD statistics are LFS pointers here: a documented guess);
+    behaviours i.i.d. ``behavior_probs`` with level == behaviour index."""
+    g = torch.Generator().manual_seed(seed)
+    if behavior_probs is None:
+        behavior_probs = [1.0 / num_behavior] * num_behavior
+    probs = torch.tensor(behavior_probs, dtype=torch.float64)
+    rows = []
+    for _ in range(batch_size):
+        n_full = int(torch.randint(min_full, max_full + 1, (1,), generator=g))
+        beh = torch.multinomial(probs, n_full, replacement=True, generator=g)
+        codes = torch.randint(0, codebook, (n_full, 4), generator=g)
+        r = int(torch.randint(0, augment + 1, (1,), generator=g))          # 0 = the unthinned sequence
+        keep = torch.ones(n_full, dtype=torch.bool)
+        if r:
+            for b in range(num_behavior - 1):                              # the highest level is the target behaviour: kept
+                idx = torch.nonzero(beh == b).flatten()
+                n_drop = int(len(idx) * ((r / augment) / (b + 1)))
+                if n_drop > 0:
+                    keep[idx[torch.randperm(len(idx), generator=g)[:n_drop]]] = False
+            if int(keep.sum()) < 2:
+                keep[:] = True
+        beh, codes = beh[keep][-n_items:], codes[keep][-n_items:]
+        rows.append((beh, codes))
+    max_items = max(len(b) for b, _ in rows)
+    S = max_items * TOKENS_PER_ITEM
+    ids = torch.full((batch_size, S), PAD_ID, dtype=torch.int64)
+    actions = torch.full((batch_size, S), 100, dtype=torch.int64)
+    valid = torch.zeros(batch_size, S, dtype=torch.bool)
+    for i, (beh, codes) in enumerate(rows):
+        n = len(beh)
+        tok = torch.empty(n, TOKENS_PER_ITEM, dtype=torch.int64)
+        tok[:, 0] = N_SPECIAL + 4 * codebook + beh
+        for l in range(4):
+            tok[:, 1 + l] = N_SPECIAL + codebook * l + codes[:, l]
+        ids[i, :n * TOKENS_PER_ITEM] = tok.reshape(-1)
+        actions[i, :n * TOKENS_PER_ITEM] = beh.repeat_interleave(TOKENS_PER_ITEM)
+        valid[i, :n * TOKENS_PER_ITEM] = True
+    labels = ids.clone()
+    labels[~valid] = -100
+    labels[:, ::TOKENS_PER_ITEM] = -100
+    pos = torch.arange(S)[None, :].expand(batch_size, S)
+    return {"input_ids": ids, "attention_mask": valid.to(torch.int64), "actions": actions, "labels": labels,
+            "session_ids": torch.where(valid, pos // TOKENS_PER_ITEM, torch.zeros_like(ids)),
+            "extended_session_ids": torch.where(valid, pos, torch.zeros_like(ids))}
+
+
 def make_catalogue(n_items: int, codebook: int = 256, seed: int = 7) -> torch.Tensor:
     """``n_items`` distinct semantic-ID tuples [n_items, 4] (the item universe of an evaluation run)."""
     g = torch.Generator().manual_seed(seed)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GAMER_ABI_VERSION 6
+#define GAMER_ABI_VERSION 7
 #define GAMER_AMAX_WORDS 256      /* words of one maximum slot (1 KB): see gamer_absmax_f32 */
 
 /* bf16 activations of the AMP variant (the reference's --bf16 run, ref:SeqRec/tasks/train_SMB_decoder.py:114-118,
@@ -229,6 +229,15 @@ int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);
  * Same F.linear sites as gamer_gemm_f32 (model.py:93-99,145-149,1001, FFN.py:25-27); selected per Engine
  * (`matmul="split6" | "split9"`), never implicitly.  Inf / NaN operands produce NaN. */
 int gamer_gemm_f32_split(const gamer_gemm_desc* d, int terms, void* stream);
+/* (ABI 7) Row-range guard of terms = 3, Linear-forward and input-gradient layouts (group_mode 0, A k-contiguous): one scale per
+ * operand TENSOR means a row of A whose largest magnitude is 2^r below the tensor's is only computed to 2^(r - 38) of ITS OWN
+ * result - an outlier element anywhere in A does that to every other row.  With the guard ON (the default) the kernel tracks
+ * the row maxima of the A tile it stages and a tile holding a non-zero row more than 2^16 below the tensor's maximum is
+ * recomputed from the fp32 operands with v_mfma_f32_32x32x2_f32 (exact fp32 products) before its epilogue - decided on the
+ * device, no host synchronisation; other tiles are bit-identical to the unguarded kernel.  Not covered: the B operand and the
+ * weight-gradient layout (error there stays relative to sum |a_k b_k|).  gamer_split3_guard(1 / 0) turns it on / off for the
+ * process, a negative argument only queries; returns the PREVIOUS setting (not an error code). */
+int gamer_split3_guard(int on);
 /* A tensor's maximum ("amax slot") is GAMER_AMAX_WORDS consecutive 32-bit words of device memory, zero before the first kernel
  * that writes it: producers publish the bits of max |x| into words 16 i (i = workgroup index modulo 16; same-address atomics of
  * thousands of workgroups would serialise), consumers take the maximum over them.
@@ -249,7 +258,9 @@ int gamer_absmax_multi_f32(const float* base, const int64_t* table, int n, uint3
  * bytes of elements 4 i .. 4 i + 3 of entry e of `table` (as gamer_absmax_multi_f32; slots = that call's output, which fixes the
  * scale s(e) exactly as the GEMM derives it from amax_b) hold the four fp16 pieces h0 of base[.] * s(e), then the four pieces h1.
  * The GEMM then loads B as before (from `b_planes` + B's offset; b_plane_stride is not used) and stages it without the cut:
- * parameters are cut once per pass instead of once per row tile of the activations; results are bit-identical. */
+ * parameters are cut once per pass instead of once per row tile of the activations; results are bit-identical.  A B whose
+ * contiguous extent (K when k-contiguous, N when row-contiguous) is not a multiple of 4 is cut in the kernel as if b_planes were
+ * NULL (a packed quad cannot be masked element-wise at a ragged edge). */
 int gamer_split2h_planes_multi(const float* base, const int64_t* table, int n, const uint32_t* slots, gamer_bf16* planes,
                                void* stream);
 /* The same maximum as a by-product of the kernel that WRITES the tensor: gamer_amax_sink(out0, out1) arms the next launch - on
@@ -264,7 +275,8 @@ int gamer_amax_sink(uint32_t* out0, uint32_t* out1);
  * its products in the three-product fp16 form of gamer_gemm_f32_split(terms = 3): q, k, v (d_o: backward; NULL in the forward)
  * are device words holding the bits of max |.| of those operand tensors; P is scaled by 2^13, dS by a bound derived from the
  * maxima.  Same results within the forms' tolerances (tests/test_ops_gpu.py runs the attention grid in this form at the same
- * bars); not armed = the six-product bf16 form. */
+ * bars); not armed = the six-product bf16 form.  The armed form needs p_drop < 0.75 (P / (1 - p_drop) must stay below 2^3 for its
+ * fixed 2^13 scale; the entry points reject larger values - use the six-product form there). */
 int gamer_attn_split_amax(const uint32_t* q, const uint32_t* k, const uint32_t* v, const uint32_t* d_o);
 /* planes[s * plane_stride + i] = piece s (s = 0, 1, 2) of x[i] under the exact three-way cut above (n % 4 == 0,
  * plane_stride % 4 == 0, 16-byte aligned x, 8-byte aligned planes): the `b_planes` operand of gamer_gemm_f32_split.  The

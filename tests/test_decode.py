@@ -316,3 +316,116 @@ def test_attn_decode_kernel_against_dense(nq, nkv, nb, L0, t):
                 ref[n, hd] = torch.softmax(s, 0) @ vals
         err = float((o.cpu().double().view(N, nq, 64) - ref).abs().max() / ref.abs().max())
         assert err < 2e-6, (kind, err)
+
+
+# ---- BASELINE configs[4] at the shipped architecture ------------------------------------------------------------------
+def _shipped_case(B, tb, seed, n_catalogue=400):
+    from gamer_amd.config import synthetic_config
+    cfg = synthetic_config()                                  # hidden 256, 8 layers, 6 / 3 heads, V = 1041 (codebook 256)
+    ocfg = orc.OracleConfig.from_dict(cfg.to_dict())
+    sd = orc.init_state_dict(ocfg, seed=17)
+    for k, v in sd.items():
+        if v.dim() == 2:
+            sd[k] = v * 4.0                                   # (as the decode fixtures: scores far from uniform, no near-ties)
+    sd["model.embed_tokens.weight"][synthetic.PAD_ID] = 0
+    cat = synthetic.make_catalogue(n_catalogue, 256, seed=3)
+    batch = synthetic.make_eval_batch(B, 100, cat, tb, codebook=256, min_his=70, seed=seed)
+    items = synthetic.item_tokens(cat, tb, 256).tolist()
+    return cfg, ocfg, sd, batch, items
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tb", [0, 2])
+def test_beam_search_at_the_shipped_architecture(tb):
+    """What test_SMB_decoder.py:158-177 asks of the model at the shipped dims: hidden 256, 8 layers (4 with behaviour
+    injection, 4 with the behaviour-level attention), 6 query / 3 kv heads, V = 1041, max_his_len 100 (prompts of 501 tokens,
+    left padded), 20 beams, 4 new tokens - the cached generation of gamer_amd.decode against the oracle's beam search run on
+    the host (every step re-runs all 20 beams of every sample through oracle.forward).  Behaviour 0: every target row is an
+    "empty" row (uniform attention over all keys, the reference's un-reordered cross cache); behaviour 2: none is."""
+    from gamer_amd.decode import beam_search
+    from gamer_amd.engine import Engine
+    B, beams = 2, 20
+    cfg, ocfg, sd, batch, items = _shipped_case(B, tb, seed=11 + tb)
+    ids, am, act = batch["input_ids"], batch["attention_mask"], batch["actions"]
+    assert ids.shape[1] == 501 and int(am[1].sum()) < 501                     # sample 1 is left padded
+    eng = Engine(cfg, temperature=0.7)
+    eng.load_state_dict(sd)
+    seq, sc = beam_search(eng, ids, am, act, ItemTrie(items), beams, 4)
+    oseq, osc = dec.beam_search(sd, ocfg, ids, am, act, dec.ItemTrie(items), beams, 4)
+    assert torch.equal(seq.cpu(), oseq), "beams differ from the oracle's"
+    err = float((sc.cpu() - osc).abs().max())
+    assert err < 1e-4, err
+    assert len({tuple(r) for r in seq[:beams, -4:].tolist()}) == beams      # 20 distinct items per sample
+    # the fp32-MFMA form and the default (three fp16 piece products) find the same beams
+    eng32 = Engine(cfg, temperature=0.7, matmul="f32")
+    eng32.load_state_dict(sd)
+    seq32, sc32 = beam_search(eng32, ids, am, act, ItemTrie(items), beams, 4)
+    assert torch.equal(seq32, seq) and float((sc32 - sc).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_beam_search_batch_256_rows_equal_rows_alone():
+    """configs[4]'s batch: 256 users x 20 beams at the shipped dims.  Size-independent property: the beams of a user inside
+    the 256-row batch are the beams of that user decoded alone (same sequences, scores to 2e-5), for rows with the longest,
+    a padded and the shortest history; every returned item is a catalogue item of the target behaviour."""
+    from gamer_amd.decode import beam_search
+    from gamer_amd.engine import Engine
+    B, beams, tb = 256, 20, 1
+    cfg, ocfg, sd, batch, items = _shipped_case(B, tb, seed=5, n_catalogue=2000)
+    ids, am, act = batch["input_ids"], batch["attention_mask"], batch["actions"]
+    eng = Engine(cfg, temperature=0.7)
+    eng.load_state_dict(sd)
+    trie = ItemTrie(items)
+    seq, sc = beam_search(eng, ids, am, act, trie, beams, 4)
+    assert seq.shape == (B * beams, 505) and bool(torch.isfinite(sc).all())
+    lens = am.sum(1)
+    rows = sorted({0, int(lens.argmin()), 100, 255})
+    sub = torch.tensor(rows)
+    seq_s, sc_s = beam_search(eng, ids[sub], am[sub], act[sub], trie, beams, 4)
+    for j, r in enumerate(rows):
+        assert torch.equal(seq_s[j * beams:(j + 1) * beams], seq[r * beams:(r + 1) * beams]), r
+        assert float((sc_s[j * beams:(j + 1) * beams] - sc[r * beams:(r + 1) * beams]).abs().max()) < 2e-5
+    valid = {tuple(it[1:]) for it in items}
+    assert all(tuple(t) in valid for t in seq[:, -4:].tolist())
+    best = sc.view(B, beams)
+    assert bool((best[:, :-1] >= best[:, 1:]).all())                          # best first
+
+
+@pytest.mark.gpu
+def test_generate_takes_the_reference_callable_and_is_a_generation_mixin():
+    """The evaluation task calls ``(model if isinstance(model, GenerationMixin) else model.module).generate(...,
+    prefix_allowed_tokens_fn=<closure over the reference's Trie>, output_scores=True, return_dict_in_generate=True,
+    early_stopping=True)`` (ref:SeqRec/tasks/test_SMB_decoder.py:158-177): the module is a GenerationMixin, and an
+    arbitrary callable with the reference's semantics (trie.py:90-104) gives the beams of the device trie."""
+    transformers = pytest.importorskip("transformers")
+    from gamer_amd.config import Qwen3MultiConfig
+    from gamer_amd.decode import beam_search
+    from gamer_amd.modeling import Qwen3MultiWithTemperature
+    fx, meta, ocfg, sd = _load()
+    tb, beams, cb = 1, meta["beams"], meta["codebook"]
+    model = Qwen3MultiWithTemperature(Qwen3MultiConfig(**meta["config"]))
+    model.set_hyper(0.7)
+    model.load_state_dict(sd)
+    assert isinstance(model, transformers.generation.utils.GenerationMixin)
+    ids, am, act = _case(fx, tb)
+    items = synthetic.item_tokens(torch.from_numpy(fx["catalogue"]), tb, cb).tolist()
+    otrie = dec.ItemTrie(items)
+    last_tokens = {it[-1] for it in items} | {synthetic.PAD_ID}
+    calls = []
+
+    def by_last_token(batch_id, sentence):                   # the reference's closure, restated over the oracle's trie
+        s = sentence.tolist()
+        calls.append(len(s))
+        i = len(s) - 1
+        while i >= 0 and s[i] not in last_tokens:
+            i -= 1
+        return otrie.get(s[i + 1:])
+    out = model.generate(input_ids=ids, attention_mask=am, actions=act, max_new_tokens=4, prefix_allowed_tokens_fn=by_last_token,
+                         num_beams=beams, num_return_sequences=beams, output_scores=True, return_dict_in_generate=True,
+                         early_stopping=True)
+    seq, sc = beam_search(model.engine, ids, am, act, ItemTrie(items), beams, 4)
+    assert torch.equal(out.sequences, seq) and torch.equal(out.sequences_scores, sc)
+    n_calls = len(calls)
+    model.generate(input_ids=ids, attention_mask=am, actions=act, max_new_tokens=4, prefix_allowed_tokens_fn=by_last_token,
+                   num_beams=beams, num_return_sequences=beams)
+    assert len(calls) == n_calls                             # the walk is cached on the callable

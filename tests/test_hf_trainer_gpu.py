@@ -9,7 +9,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_hf_trainer_drives_the_module(golden, tmp_path):
+@pytest.mark.parametrize("bf16", [False, True])
+def test_hf_trainer_drives_the_module(golden, tmp_path, bf16):
+    """bf16=True: ``TrainingArguments(bf16=True)`` is the reference's --bf16 switch (train_SMB_decoder.py:114-118, 407-408): the
+    Trainer runs the forward under ``torch.autocast(dtype=bfloat16)`` and the module must then run the bf16 step - compared
+    with ``Engine(dtype="bf16")`` on the same batches, and shown NOT to be the fp32 step."""
     transformers = pytest.importorskip("transformers")
     from torch.utils.data import SequentialSampler
     from gamer_amd import synthetic
@@ -27,11 +31,12 @@ def test_hf_trainer_drives_the_module(golden, tmp_path):
     keys = ("input_ids", "attention_mask", "actions", "labels", "session_ids", "extended_session_ids")
 
     # ---- reference run of this repo: the fused engine step
-    eng = Engine(Qwen3MultiConfig(**cfgd), temperature=0.7)
-    eng.load_state_dict(sd)
-    for s in range(2):
-        eng.train_step({k: data[k][s * bs:(s + 1) * bs] for k in keys}, lr)
-    want = {k: v.detach().cpu().clone() for k, v in eng.params.items()}
+    def engine_run(dtype):
+        eng = Engine(Qwen3MultiConfig(**cfgd), temperature=0.7, dtype=dtype)
+        eng.load_state_dict(sd)
+        losses = [float(eng.train_step({k: data[k][s * bs:(s + 1) * bs] for k in keys}, lr)) for s in range(2)]
+        return {k: v.detach().cpu().clone() for k, v in eng.params.items()}, losses
+    want, want_losses = engine_run("bf16" if bf16 else "f32")
 
     # ---- the same two steps through transformers.Trainer
     model = Qwen3MultiWithTemperature(Qwen3MultiConfig(**cfgd))
@@ -55,7 +60,7 @@ def test_hf_trainer_drives_the_module(golden, tmp_path):
         output_dir=str(tmp_path), per_device_train_batch_size=bs, max_steps=2, learning_rate=lr,
         lr_scheduler_type="constant", warmup_steps=0, optim="adamw_torch", weight_decay=0.01, max_grad_norm=1.0,
         adam_beta1=0.9, adam_beta2=0.999, adam_epsilon=1e-8, report_to=[], save_strategy="no", logging_steps=1,
-        remove_unused_columns=False, dataloader_num_workers=0, seed=0, disable_tqdm=True)
+        remove_unused_columns=False, dataloader_num_workers=0, seed=0, disable_tqdm=True, bf16=bf16)
     trainer = OrderedTrainer(model=model, args=args, train_dataset=Rows(),
                              data_collator=lambda rows: {k: torch.stack([r[k] for r in rows]) for k in keys})
     # the decay / no-decay split the optimizer will be built from
@@ -63,12 +68,33 @@ def test_hf_trainer_drives_the_module(golden, tmp_path):
     assert all(("norm" in n) != (n in decay) for n in names), "norm weights (and only they) are excluded from weight decay"
     trainer.train()
     got = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    worst = 0.0
+    if bf16:
+        assert model._amp_engine is not None, "TrainingArguments(bf16=True) did not put the forward under bf16 autocast"
+    worst, d_sum, moved_sum = 0.0, 0.0, 0.0
     for k, w in want.items():
         d = (got[k] - w).abs()
         moved = (w - sd[k]).abs()
         # same update: compare where the step is well conditioned (|dw| ~ lr), bound the rest by 2*lr
         assert float(d.max()) <= 2 * 2 * lr + 1e-7, k
         worst = max(worst, float(d.max() / (moved.max() + 1e-12)))
-    assert worst < 5e-3, worst
+        d_sum, moved_sum = d_sum + float(d.sum()), moved_sum + float(moved.sum())
+    logged = [h["loss"] for h in trainer.state.log_history if "loss" in h]          # (rounded to 4 decimals by the Trainer)
+    if bf16:
+        # the autocast region selected the bf16 engine over the module's own masters - not a silent fp32 run: the first step's
+        # loss is the bf16 step's (1e-6 in the unrounded numbers), 4e-3 away from the fp32 step's on this batch
+        assert model._amp_engine is not None and model._amp_engine.dtype == "bf16"
+        assert model._amp_engine.flat_p.data_ptr() == model.engine.flat_p.data_ptr()
+        _, losses32 = engine_run("f32")
+        assert abs(logged[0] - want_losses[0]) < 2e-4 and abs(logged[0] - losses32[0]) > 1e-3, (logged, want_losses, losses32)
+        assert abs(logged[1] - want_losses[1]) < 2e-3
+        # the second step starts from masters that differ in their last bits (torch AdamW vs the fused kernel), which re-rounds
+        # some bf16 operand copies: elements whose two gradients nearly cancel land up to 2 lr apart, the bulk does not move
+        assert d_sum / moved_sum < 3e-2, d_sum / moved_sum
+        with torch.autocast("cuda", dtype=torch.float16):
+            with pytest.raises(NotImplementedError):
+                model(**{k: data[k][:bs].cuda() for k in keys})
+    else:
+        assert worst < 5e-3, worst
+        assert model._amp_engine is None
+        assert abs(logged[0] - want_losses[0]) < 2e-4
     assert float(np.mean([float((got[k] - sd[k]).abs().max()) for k in want])) > 1e-5      # it did train
