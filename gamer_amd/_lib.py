@@ -55,6 +55,7 @@ class GemmDesc(C.Structure):
         ("qk_S", c_int), ("qk_nq", c_int), ("qk_nkv", c_int),
         ("b_planes", c_void_p), ("b_plane_stride", c_int64),
         ("amax_a", c_void_p), ("amax_b", c_void_p),
+        ("amax_c", c_void_p), ("amax_c_col0", c_int),
     ]
 
 
@@ -119,8 +120,8 @@ _SIGNATURES = {
     "gamer_split2h_planes_multi": [P, P, I, P, P, P],
     "gamer_amax_sink": [P, P],
     "gamer_attn_split_amax": [P, P, P, P],
-    "gamer_attn_fwd_split": [P, I, P, I, P, I, P, P, P, I, I, I, I, F, F, U, P, P, P, P, P, P],
-    "gamer_attn_bwd_split": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, P, P, I, P, P],
+    "gamer_attn_fwd_split": [P, I, P, I, P, I, P, P, P, I, I, I, I, F, F, U, P, P, P, P, P, I, P, P],
+    "gamer_attn_bwd_split": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, P, P, I, P, P, P],
     "gamer_residual_dropout_fwd": [P, P, P, I, I, F, U, P, P],
     "gamer_residual_dropout_bwd": [P, P, I, I, F, U, P, P],
     "gamer_swiglu_fwd": [P, P, L, F, U, P, P],

@@ -25,7 +25,8 @@ namespace gamer {
 
 #ifndef SPA_ABLATE
 #define SPA_ABLATE 0      // timing-only builds (tools/ablate_attn_split.sh): 1 no S = K Q^T MFMAs, 2 no second-product MFMAs, 4 no cut of P / dS,
-#endif                    // 8 no cut arithmetic anywhere (pieces = the raw word), 16 no LDS tile stores
+#endif                    // 8 no cut arithmetic anywhere (pieces = the raw word), 16 no LDS tile stores, 32 (H2) no staging of K / V / Q / dO tiles at all,
+                          // forward only: 64 no exp2, 128 no barrier in the key loop, 256 no softmax / dropout at all
 constexpr int SIMG = 32 * 64;              // bf16 elements of one piece image of a 32-row tile
 
 // element offset of (row, column) in a [rows][64] bf16 image with swizzled 16-byte chunks (attention_bf16.hip: lds_off)
@@ -146,6 +147,13 @@ __device__ __forceinline__ void cut8_t(const float4& a, const float4& b, float s
 template <bool H2>
 __device__ __forceinline__ void cut8_regs_t(const f32x16& t, const int first, float s, bf16x8 (&p)[3]) {
     if (!H2) { cut8_regs(t, first, p[0], p[1], p[2]); return; }
+    if (SPA_ABLATE & 4) {
+        u32x4s z;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[j] = __float_as_uint(t[first + 2 * j]);
+        p[0] = p[1] = __builtin_bit_cast(bf16x8, z);
+        return;
+    }
     u32x4s u0, u1;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -158,6 +166,7 @@ __device__ __forceinline__ void cut8_regs_t(const f32x16& t, const int first, fl
 template <bool H2>
 __device__ __forceinline__ void store_tile32_t(bf16_t* __restrict__ img, int tid, const float4 (&rg)[2], int n_valid, float s) {
     if (!H2) { store_tile32_split(img, tid, rg, n_valid); return; }
+    if (SPA_ABLATE & 32) { asm volatile("" :: "v"(rg[0].x), "v"(rg[0].w), "v"(rg[1].y), "v"(rg[1].z)); return; }   // timing-only: no cut, no store
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const int f = tid + AT_THREADS * jj;
@@ -408,6 +417,7 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
             // MASK: evaluate the causal + level predicate per element (tiles on the diagonal, tiles holding a
             // blocked key); EMPTYSEL: some rows of the wave are "empty" rows (p = 1, normalised by 1/S at the end)
             auto softmax_tile = [&]<bool MASK, bool EMPTYSEL>() {
+                if (SPA_ABLATE & 256) { pv_tile.template operator()<false>(); return; }     // timing-only: no softmax, no dropout
                 if (MASK) {
                     int klv[16];
                     read_key_quads(km.kl, h, klv);
@@ -439,7 +449,7 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
                 float rowsum = 0.f;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    float pe = __builtin_amdgcn_exp2f(st_cur[reg]);            // masked -> exp2(-inf) = 0
+                    float pe = (SPA_ABLATE & 64) ? st_cur[reg] : __builtin_amdgcn_exp2f(st_cur[reg]);            // masked -> exp2(-inf) = 0
                     if (EMPTYSEL) {
                         const float one = (full_span || (j0 + rowmap(reg, h) < my_span)) ? 1.f : 0.f;
                         pe = my_empty ? one : pe;
@@ -501,7 +511,7 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
             key_meta_store(kms[(jt + 2) % 3], w, lane, rmeta);
         }
         if (have_next) store_tile32_t<H2>(Vs[(jt + 1) & 1], tid, rv, S - (j0 + 32), sc.v);
-        __syncthreads();
+        if (!(SPA_ABLATE & 128)) __syncthreads();
     }
 
     float omax = 0.f;
@@ -898,10 +908,13 @@ struct DkvQTile {
     uint32_t aw_s[G][32];       // dropout row words
     int32_t ql_s[32];
     int32_t empty_s[32];
-    int32_t pos_s[32];          // key limit of the staged query rows: their position, S past the end
+    int32_t pos_s[32];          // key limit of the staged query rows: their position (session masks: QuerySpan.hi), S past the end
+    int32_t hole_lo_s[32];      // QuerySpan hole of the staged query rows (SPAN kernels only)
+    int32_t hole_hi_s[32];
     int32_t qlmin;              // smallest query level / key limit over the normal rows of the tile (INT_MAX: none)
     int32_t posmin;
-    int32_t pad_[2];
+    int32_t hole_lo_min;        // smallest hole start / largest hole end over the normal rows (SPAN kernels only)
+    int32_t hole_hi_max;
 };
 // NP = 3 (six-product bf16 form): 96 KB of K / V images + one 48-KB query tile = 144 KB.  NP = 2 (three-product fp16 form):
 // 64 KB + TWO 32-KB query tiles = 130 KB - tile t + 1 is cut and stored while tile t is multiplied, one barrier per tile.
@@ -913,7 +926,7 @@ struct DkvSmemS {
     DkvQTile<G, NP> qt[NBUF];
 };
 
-template <int G, bool DROP, bool ORD, bool H2>
+template <int G, bool DROP, bool ORD, bool H2, bool SPAN = false>
 __device__ __forceinline__ void
 attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                     const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
@@ -1002,7 +1015,7 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
     float4 rq[G][NLD], rdo[G][NLD];
     float rl = 0.f, rd = 0.f;
     uint32_t raw = 0;
-    int rql = 1, rem = 0, rpos = 0;
+    int rql = 1, rem = 0, rpos = 0, rhlo = INT_BIG_A, rhhi = 0;
 
     auto next_tile = [&](int qt) {
         while (qt < n_qt && !tile_empty_rows(qt) && tile_last_pos(qt) < k0) ++qt;
@@ -1035,7 +1048,9 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
             if (g == 0) {
                 rql = in ? (ql ? ql[(int64_t)b * S + i] : 1) : 0;
                 rem = in ? row_empty[(int64_t)b * S + i] : 0;
-                rpos = in ? i : S;
+                const QuerySpan qsp = QuerySpan::load<SPAN>(ro.span, (int64_t)b * S + i, i, in, S);
+                rpos = qsp.hi;
+                if (SPAN) { rhlo = qsp.hole_lo; rhhi = qsp.hole_hi; }
             }
         }
     };
@@ -1052,6 +1067,7 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                 const float xa[4] = {ok ? a.x : 0.f, ok ? a.y : 0.f, ok ? a.z : 0.f, ok ? a.w : 0.f};
                 const float xc[4] = {ok ? c.x : 0.f, ok ? c.y : 0.f, ok ? c.z : 0.f, ok ? c.w : 0.f};
                 const int off = sl_off(row, (f & 15) << 2);
+                if (H2 && (SPA_ABLATE & 32)) { asm volatile("" :: "v"(xa[0]), "v"(xa[3]), "v"(xc[1]), "v"(xc[2])); continue; }
                 if (H2) {
                     uint32_t a0, a1, b0, b1;
                     cut2h_quad(xa[0], xa[1], xa[2], xa[3], sc.q, a0, a1, b0, b1);
@@ -1073,12 +1089,16 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
             }
         if (w < G) {
             const int g = w, row = lane & 31;
-            int qlmin = 0, posmin = 0;
+            int qlmin = 0, posmin = 0, hlomin = INT_BIG_A, hhimax = 0;
             if (g == 0) {
                 const bool in = qt * 32 + row < S;
                 const bool normal = in && rem == 0;
                 qlmin = wave_min_i32(normal ? rql : INT_BIG_A);
                 posmin = wave_min_i32(normal ? rpos : INT_BIG_A);
+                if (SPAN) {
+                    hlomin = wave_min_i32(normal ? rhlo : INT_BIG_A);
+                    hhimax = wave_max_i32(normal ? rhhi : 0);
+                }
             }
             if (lane < 32) {
                 dst.nlse2_s[g][row] = rl;
@@ -1086,7 +1106,11 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                 if (DROP) dst.aw_s[g][row] = raw;
                 if (g == 0) {
                     dst.ql_s[row] = rql; dst.empty_s[row] = rem; dst.pos_s[row] = rpos;
-                    if (row == 0) { dst.qlmin = qlmin; dst.posmin = posmin; }
+                    if (SPAN) { dst.hole_lo_s[row] = rhlo; dst.hole_hi_s[row] = rhhi; }
+                    if (row == 0) {
+                        dst.qlmin = qlmin; dst.posmin = posmin;
+                        if (SPAN) { dst.hole_lo_min = hlomin; dst.hole_hi_max = hhimax; }
+                    }
                 }
             }
         }
@@ -1133,6 +1157,7 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                     const float ndl[4] = {d4.x, d4.y, d4.z, d4.w};
                     float nl[4] = {0.f, 0.f, 0.f, 0.f};
                     int qlv[4] = {0, 0, 0, 0}, posv[4] = {0, 0, 0, 0}, emv[4] = {0, 0, 0, 0};
+                    int hlo[4] = {0, 0, 0, 0}, hhi[4] = {0, 0, 0, 0};
                     uint32_t awv[4] = {0, 0, 0, 0};
                     if (!ALL_EMPTY) {
                         const float4 l4 = *reinterpret_cast<const float4*>(&tq.nlse2_s[hg][qb]);
@@ -1143,6 +1168,12 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                         const int4 p4 = *reinterpret_cast<const int4*>(&tq.pos_s[qb]);
                         qlv[0] = q4.x; qlv[1] = q4.y; qlv[2] = q4.z; qlv[3] = q4.w;
                         posv[0] = p4.x; posv[1] = p4.y; posv[2] = p4.z; posv[3] = p4.w;
+                        if (SPAN) {
+                            const int4 a4 = *reinterpret_cast<const int4*>(&tq.hole_lo_s[qb]);
+                            const int4 b4 = *reinterpret_cast<const int4*>(&tq.hole_hi_s[qb]);
+                            hlo[0] = a4.x; hlo[1] = a4.y; hlo[2] = a4.z; hlo[3] = a4.w;
+                            hhi[0] = b4.x; hhi[1] = b4.y; hhi[2] = b4.z; hhi[3] = b4.w;
+                        }
                     }
                     if (EMPTYSEL) {
                         const int4 e4 = *reinterpret_cast<const int4*>(&tq.empty_s[qb]);
@@ -1161,7 +1192,8 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
                         } else {
                             pe = __builtin_amdgcn_exp2f(fmaf(st[reg], c2, nl[e]));
                             if (MASK) {
-                                const bool allowed = (jk <= posv[e]) & (my_kl < qlv[e]);
+                                bool allowed = (jk <= posv[e]) & (my_kl < qlv[e]);
+                                if (SPAN) allowed = allowed & !((jk >= hlo[e]) & (jk < hhi[e]));
                                 pe = allowed ? pe : 0.f;
                             }
                             if (EMPTYSEL) pe = (emv[e] != 0) ? invS : pe;
@@ -1183,7 +1215,12 @@ attn_bwd_dkv_s_tile(const float* __restrict__ q, int ldq, const float* __restric
             } else if (tile_has_empty) {
                 elem_tile.template operator()<true, true, false>();
             } else {
-                const bool free_tile = (posmin >= wave_k_hi) && (wave_kl_max < qlmin);
+                bool free_tile = (posmin >= wave_k_hi) && (wave_kl_max < qlmin);
+                if (SPAN) {
+                    const int hl = __builtin_amdgcn_readfirstlane(tq.hole_lo_min);
+                    const int hh = __builtin_amdgcn_readfirstlane(tq.hole_hi_max);
+                    free_tile = free_tile && (wave_k_hi < hl || wave_k_lo >= hh);
+                }
                 if (free_tile) elem_tile.template operator()<false, false, false>();
                 else elem_tile.template operator()<true, false, false>();
             }
@@ -1325,7 +1362,7 @@ static inline int worklist_grid_1(int n_pairs, int n_tiles) {
     return 8 * ppr * halves;
 }
 
-template <int G, bool DROP, bool ORD, bool H2>
+template <int G, bool DROP, bool ORD, bool H2, bool SPAN = false>
 __global__ void __launch_bounds__(256 * G, 1)
 attn_bwd_dkv_s_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                       const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
@@ -1351,7 +1388,7 @@ attn_bwd_dkv_s_kernel(const float* __restrict__ q, int ldq, const float* __restr
 #pragma unroll 1
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1 && light == heavy) break;
-            attn_bwd_dkv_s_tile<G, DROP, ORD, H2>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv,
+            attn_bwd_dkv_s_tile<G, DROP, ORD, H2, SPAN>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, S, nq, nkv,
                                               scale, p_drop, seed, dk, lddk, dv, lddv, ro, pair, pass == 0 ? heavy : light, ds_out,
                                               amax_out ? &amax_word : nullptr, sc);
         }
@@ -1545,13 +1582,18 @@ void disarm_attn_amax() { g_attn_amax_armed = AttnAmax{nullptr, nullptr, nullptr
 template <int G>
 static int launch_fwd_s(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl,
                         const int32_t* ql, const int32_t* row_empty, int B, int S, int nq, int nkv, float scale,
-                        float p_drop, uint64_t seed, float* o, float* lse, RowOrder ro, hipStream_t st) {
+                        float p_drop, uint64_t seed, float* o, float* lse, RowOrder ro, int uspan, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     dim3 grid(worklist_grid(B * nkv, (S + R - 1) / R));
-#define GAMER_LAUNCH_FWD_S(DROPV, ORDV, H2V)                                                                               \
-    hipLaunchKernelGGL((attn_fwd_s_kernel<G, DROPV, ORDV, false, H2V>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, \
-                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, S, t_amax_out, t_attn_amax)
-    if (t_attn_amax.q) {
+#define GAMER_LAUNCH_FWD_SP(DROPV, ORDV, SPANV, H2V)                                                                         \
+    hipLaunchKernelGGL((attn_fwd_s_kernel<G, DROPV, ORDV, SPANV, H2V>), grid, dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, \
+                       kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, uspan, t_amax_out, t_attn_amax)
+#define GAMER_LAUNCH_FWD_S(DROPV, ORDV, H2V) GAMER_LAUNCH_FWD_SP(DROPV, ORDV, false, H2V)
+    if (ro.span) {
+        // per-query key spans (Qwen3SessionMulti): built for the three-product form (the entry point has checked that it is armed)
+        if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD_SP(true, true, true, true); else GAMER_LAUNCH_FWD_SP(true, false, true, true); }
+        else { if (ro.perm) GAMER_LAUNCH_FWD_SP(false, true, true, true); else GAMER_LAUNCH_FWD_SP(false, false, true, true); }
+    } else if (t_attn_amax.q) {
         if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD_S(true, true, true); else GAMER_LAUNCH_FWD_S(true, false, true); }
         else { if (ro.perm) GAMER_LAUNCH_FWD_S(false, true, true); else GAMER_LAUNCH_FWD_S(false, false, true); }
     } else {
@@ -1559,6 +1601,7 @@ static int launch_fwd_s(const float* q, int ldq, const float* k, int ldk, const 
         else { if (ro.perm) GAMER_LAUNCH_FWD_S(false, true, false); else GAMER_LAUNCH_FWD_S(false, false, false); }
     }
 #undef GAMER_LAUNCH_FWD_S
+#undef GAMER_LAUNCH_FWD_SP
     GAMER_CHECK_LAUNCH("gamer_attn_fwd_split");
     return 0;
 }
@@ -1571,6 +1614,30 @@ static int launch_bwd_s_variant(const float* q, int ldq, const float* k, int ldk
                                 float* dv, int lddv, RowOrder ro, int delta_ready, float* ds_work, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     const bool h2 = t_attn_amax.q != nullptr;       // gamer_attn_split_amax: the three-product fp16 form (recompute form only)
+    if (ro.span) {
+        // per-query key spans (Qwen3SessionMulti): the three-product recompute form (checked by the entry point)
+        hipLaunchKernelGGL((attn_bwd_dq_s_kernel<G, DROP, ORD, true, true>), dim3(worklist_grid(B * nkv, (S + R - 1) / R)),
+                           dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv,
+                           scale, p_drop, seed, dq, lddq, ro, delta_ready, t_attn_amax);
+        GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dq");
+        const size_t shmem = sizeof(DkvSmemS<G, 2>);
+        static bool attr_dev[MAX_DEVICES] = {};
+        bool& attr_set = attr_dev[current_device()];
+        if (!attr_set) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_s_kernel<G, DROP, ORD, true, true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            if (e != hipSuccess) {
+                set_error("gamer_attn_bwd_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                return (int)e;
+            }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_dkv_s_kernel<G, DROP, ORD, true, true>), dim3(worklist_grid_1(B * nkv, (S + DKV_S_KEYS - 1) / DKV_S_KEYS)),
+                           dim3(256 * G), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv,
+                           scale, p_drop, seed, dk, lddk, dv, lddv, ro, (float*)nullptr, t_amax_out, t_attn_amax);
+        GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dkv");
+        return 0;
+    }
     if (ds_work == nullptr) {
         if (h2)
             hipLaunchKernelGGL((attn_bwd_dq_s_kernel<G, DROP, ORD, false, true>), dim3(worklist_grid(B * nkv, (S + R - 1) / R)),
@@ -1651,9 +1718,12 @@ extern "C" int gamer_attn_fwd_split(const float* q, int ldq, const float* k, int
                                     const int32_t* kl, const int32_t* ql, const int32_t* row_empty, int B, int S, int nq,
                                     int nkv, float scale, float p_drop, uint64_t seed, float* o, float* lse,
                                     const int32_t* row_perm, const int32_t* tile_kind, const int32_t* tile_maxpos,
-                                    void* stream) {
+                                    int uniform_len, const int32_t* q_span, void* stream) {
     GAMER_CHECK_ARG(!row_perm || (tile_kind && tile_maxpos), "gamer_attn_fwd_split: row_perm needs tile_kind and tile_maxpos");
-    const RowOrder ro{row_perm, tile_kind, tile_maxpos, nullptr};
+    GAMER_CHECK_ARG(uniform_len >= 0 && uniform_len <= S, "gamer_attn_fwd_split: uniform_len=%d outside [0, S=%d]", uniform_len, S);
+    GAMER_CHECK_ARG(!q_span || aligned16(q_span), "gamer_attn_fwd_split: q_span must be 16-byte aligned");
+    const int uspan = uniform_len == 0 ? S : uniform_len;
+    const RowOrder ro{row_perm, tile_kind, tile_maxpos, q_span};
     int rc = check_attn_split("gamer_attn_fwd_split", q, k, v, kl, row_empty, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
     if (rc) return rc;
     GAMER_CHECK_ARG(o && lse && aligned16(o), "gamer_attn_fwd_split: null/unaligned output");
@@ -1664,8 +1734,9 @@ extern "C" int gamer_attn_fwd_split(const float* q, int ldq, const float* k, int
     GAMER_CHECK_ARG(!t_attn_amax.q || (t_attn_amax.k && t_attn_amax.v), "gamer_attn_fwd_split: gamer_attn_split_amax needs q, k and v");
     GAMER_CHECK_ARG(!t_attn_amax.q || p_drop < 0.75f, "gamer_attn_fwd_split: the three-product fp16 form needs p_drop < 0.75 (p_drop=%f): "
                     "its probabilities are cut at a fixed 2^13 scale; do not arm gamer_attn_split_amax for this call", p_drop);
-    rc = (nq / nkv == 1) ? launch_fwd_s<1>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st)
-                         : launch_fwd_s<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, st);
+    GAMER_CHECK_ARG(!q_span || t_attn_amax.q, "gamer_attn_fwd_split: q_span is built for the three-product form (arm gamer_attn_split_amax)");
+    rc = (nq / nkv == 1) ? launch_fwd_s<1>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, uspan, st)
+                         : launch_fwd_s<2>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, uspan, st);
     t_amax_out = nullptr;
     t_attn_amax = AttnAmax{nullptr, nullptr, nullptr, nullptr};
     return rc;
@@ -1682,12 +1753,13 @@ extern "C" int gamer_attn_bwd_split(const float* q, int ldq, const float* k, int
                                     int nq, int nkv, float scale, float p_drop, uint64_t seed, float* delta, float* dq,
                                     int lddq, float* dk, int lddk, float* dv, int lddv, const int32_t* row_perm,
                                     const int32_t* tile_kind, const int32_t* tile_maxpos, int delta_ready, float* ds_work,
-                                    void* stream) {
+                                    const int32_t* q_span, void* stream) {
     int rc = check_attn_split("gamer_attn_bwd_split", q, k, v, kl, row_empty, ldq, ldk, ldv, B, S, nq, nkv, p_drop);
     if (rc) return rc;
     GAMER_CHECK_ARG(o && d_o && lse && tile_empty && delta && dq && dk && dv, "gamer_attn_bwd_split: null pointer");
     GAMER_CHECK_ARG(!row_perm || (tile_kind && tile_maxpos), "gamer_attn_bwd_split: row_perm needs tile_kind and tile_maxpos");
-    const RowOrder ro{row_perm, tile_kind, tile_maxpos, nullptr};
+    GAMER_CHECK_ARG(!q_span || aligned16(q_span), "gamer_attn_bwd_split: q_span must be 16-byte aligned");
+    const RowOrder ro{row_perm, tile_kind, tile_maxpos, q_span};
     GAMER_CHECK_ARG(lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0 && aligned16(dq) && aligned16(dk) && aligned16(dv) &&
                     aligned16(d_o) && aligned16(o),
                     "gamer_attn_bwd_split: gradient buffers must be 16-byte aligned with leading dims %% 4 == 0");
@@ -1698,6 +1770,8 @@ extern "C" int gamer_attn_bwd_split(const float* q, int ldq, const float* k, int
     GAMER_CHECK_ARG(!t_attn_amax.q || (t_attn_amax.k && t_attn_amax.v && t_attn_amax.d_o && !ds_work),
                     "gamer_attn_bwd_split: gamer_attn_split_amax needs q, k, v and d_o, and the recompute form (ds_work = NULL)");
     GAMER_CHECK_ARG(!t_attn_amax.q || p_drop < 0.75f, "gamer_attn_bwd_split: the three-product fp16 form needs p_drop < 0.75 (p_drop=%f)", p_drop);
+    GAMER_CHECK_ARG(!q_span || (t_attn_amax.q && !ds_work), "gamer_attn_bwd_split: q_span is built for the three-product recompute form "
+                    "(arm gamer_attn_split_amax, ds_work = NULL)");
     rc = (nq / nkv == 1)
         ? launch_bwd_s<1>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, ds_work, st)
         : launch_bwd_s<2>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, dk, lddk, dv, lddv, ro, delta_ready, ds_work, st);

@@ -263,6 +263,8 @@ struct GemmParams {
     const uint16_t* b_planes;      // SPLIT, MODE 0: B pre-cut into three bf16 planes indexed like B (nullptr: cut in the kernel)
     int64_t b_plane_stride;
     int guard;                     // SPLIT == 3, MODE 0: row-range guard of the A operand (gamer_split3_guard; default on)
+    uint32_t* amax_c;              // MODE 0, plain / row-dot epilogues: fold the bits of max |C stored| over columns >= amax_c_col0 into this slot
+    int amax_c_col0;
 };
 
 // SPLIT == 3 scales a whole operand TENSOR by one power of two, so a row of A whose largest magnitude lies more than 2^16 below
@@ -276,6 +278,9 @@ struct GemmParams {
 // their rows and columns stay within a few powers of two of each other) and the weight-gradient layout (its contraction runs
 // over the tokens: a small row contributes a small term, the error stays relative to sum |a_k b_k|).
 constexpr float SPLIT3_GUARD_RATIO = 1.f / 65536.f;
+#ifndef GAMER_GEMM_CAMAX_BUILD
+#define GAMER_GEMM_CAMAX_BUILD 1        // 0: timing-only builds without the amax_c epilogue code (tools: what it costs the kernels)
+#endif
 #ifndef GAMER_SPLIT3_GUARD_BUILD
 #define GAMER_SPLIT3_GUARD_BUILD 1      // 0: timing-only builds without the row-maximum tracking (tools: what the guard costs)
 #endif
@@ -1009,6 +1014,9 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
         const float* res0 = EPI == 1 ? p.resid + (int64_t)row_first * p.ldc + col : nullptr;
         const int64_t step = 4 * p.ldc;
         const int qk_pos0 = EPI == 3 ? row_first % max(p.qk_S, 1) : 0;
+        // (a wave's 64-column patch lies on one side of amax_c_col0 when that is a multiple of 64 - the q|k / v boundary is)
+        const bool amax_on = GAMER_GEMM_CAMAX_BUILD && p.amax_c != nullptr && !ACCUM && col0 + wn * 64 >= p.amax_c_col0;
+        float cmax = 0.f;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int lr = (lane >> 4) + 4 * it;             // row inside the patch
@@ -1076,6 +1084,8 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
                 *reinterpret_cast<float4*>(dst) = o;
             } else {
                 float* dst = dst0 + it * step;
+                if (EPI != 1 && EPI != 3 && amax_on)
+                    asm("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|" : "+v"(cmax) : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
                 if (EPI == 2) {
                     // the wave's 64-column patch is exactly one head: 16 lanes hold one row of it
                     const float4 o4 = oth[EPI == 2 ? it : 0];
@@ -1096,8 +1106,16 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
                 }
             }
         }
+        if (EPI != 1 && EPI != 3 && amax_on) {
+            uint32_t mw = __float_as_uint(cmax);
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) mw = max(mw, (uint32_t)__shfl_xor((int)mw, o2, 64));
+            if (lane == 0 && mw) amax_publish(mw, p.amax_c, (uint32_t)(vblock * 4 + wid));
+        }
     } else {
+        float emax = 0.f;
         auto emit = [&](int row, int col, float v) {
+            if (GAMER_GEMM_CAMAX_BUILD && EPI != 1 && MODE == 0 && !ACCUM && p.amax_c != nullptr && col >= p.amax_c_col0) emax = fmaxf(emax, fabsf(v));
             if (EPI == 1) {
                 const int64_t rc = p.row_map ? p.row_map[row] : row;
                 const int64_t e = rc * p.ldc + col;
@@ -1129,6 +1147,12 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
                     }
                 }
             }
+        }
+        if (GAMER_GEMM_CAMAX_BUILD && MODE == 0 && !ACCUM && p.amax_c != nullptr) {
+            uint32_t mw = __float_as_uint(emax);
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) mw = max(mw, (uint32_t)__shfl_xor((int)mw, o2, 64));
+            if (lane == 0 && mw) amax_publish(mw, p.amax_c, (uint32_t)(vblock * 4 + wid));
         }
     }
     if (STAMP) {
@@ -1321,6 +1345,11 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     p.qk_S = d->qk_S; p.qk_nq = d->qk_nq; p.qk_nkv = d->qk_nkv;
     p.amax_a = d->amax_a; p.amax_b = d->amax_b;
     p.guard = g_split3_guard;
+    p.amax_c = d->amax_c; p.amax_c_col0 = d->amax_c_col0;
+    GAMER_CHECK_ARG(!d->amax_c || (d->group_mode == 0 && !d->accumulate && !d->resid && !d->qk_q_rot && d->amax_c_col0 >= 0 &&
+                                   d->amax_c_col0 % 64 == 0),
+                    "gamer_gemm_f32: amax_c needs a plain or row-dot Linear-forward / input-gradient GEMM (no accumulate, residual or "
+                    "q|k|v epilogue) and amax_c_col0 a multiple of 64 (amax_c_col0=%d)", d->amax_c_col0);
     GAMER_CHECK_ARG(split != 3 || (d->amax_a && d->amax_b), "gamer_gemm_f32_split: terms = 3 needs amax_a and amax_b (gamer_absmax_f32)");
     p.b_planes = (split && d->group_mode == 0) ? (const uint16_t*)d->b_planes : nullptr;
     p.b_plane_stride = d->b_plane_stride;

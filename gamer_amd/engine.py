@@ -430,6 +430,9 @@ class Engine:
         # matmul="split3": the attention products in the three-product fp16 form as well (gamer_attn_split_amax); False keeps
         # them in the six-product bf16 form
         self.h2_attention = os.environ.get("GAMER_H2_ATTENTION", "1") != "0"
+        # max |v| / max |dO| of the three-product attention out of the producing GEMMs' epilogues (gamer_gemm_desc.amax_c) instead of
+        # gamer_absmax_f32 passes; GAMER_GEMM_CAMAX=0 keeps the passes (A/B)
+        self.gemm_c_amax = os.environ.get("GAMER_GEMM_CAMAX", "1") != "0"
         self._amax = None
         if dtype == "f32" and matmul == "split3":
             self._amax = ops.amax_reuse()
@@ -490,7 +493,9 @@ class Engine:
         if train not in self._ws:
             # the 6.4 GB dS-spill scratch is the fp32-MFMA attention backward's; the split form (recompute) does not use
             # it - unless the session variant sends its span calls to the fp32-MFMA kernels
-            spill = not (self.split_attention and self.matmul != "f32" and self.variant == "multi")
+            # (the three-product form takes the session variant's key spans itself)
+            spill = not (self.split_attention and self.matmul != "f32" and
+                         (self.variant == "multi" or (self.matmul == "split3" and self.h2_attention)))
             self._ws[train] = _Workspace(self.cfg, self.device, train, self.act_dtype, spill=spill)
         return self._ws[train].bind(B, S)
 
@@ -621,12 +626,21 @@ class Engine:
         # matmul="split6" / "split9": the attention products run on the bf16 pipe as well (gamer_attn_fwd_split: exact
         # three-way cuts, six piece products); the session variant's key spans and the evaluation re-run path stay on the
         # fp32-MFMA kernels
-        split_attn = self.split_attention and self.matmul != "f32" and not bf16 and uniform_len in (0, S)
+        split_attn = self.split_attention and self.matmul != "f32" and not bf16
+
+        # (three-product attention) max |v| out of the q|k|v projection's epilogue instead of a pass over the v columns; the cross
+        # attention adds its behaviour bias to v afterwards (qknorm_rope_fwd), so only the self attention's v can take it
+        h2_now = split_attn and self.h2_attention and self.matmul == "split3" and p_att < 0.75
+
+        def v_amax(qkv_buf):
+            return dict(c_amax=(qkv_buf[:, NQ + NKV:], NQ + NKV)) if (h2_now and not bf16 and self.gemm_c_amax) else {}
 
         def attention(qb, kb, vb, kl_, ql_, empty_, tile_empty_, seed_, ob, lseb, order_, span_):
-            if split_attn and span_ is None:
+            if split_attn and (span_ is None or h2_now):
+                # (per-query key spans - the session variant - are built for the three-product form; the six-product form sends
+                # those calls to the fp32-MFMA kernels below)
                 ops.attn_fwd_split(qb, NQ, kb, NKV, vb, QKV, kl_, ql_, empty_, B, S, nq, nkv, scale, p_att, seed_, ob, lseb,
-                                   order=order_, h2=self.h2_attention and self.matmul == "split3" and p_att < 0.75)
+                                   order=order_, h2=h2_now, uniform_len=uniform_len, q_span=span_)
             elif bf16:
                 ord16 = (order_[0], order_[2], empty_) if (order_ is not None and span_ is None) else None
                 ops.attn_fwd_bf16(qb, NQ, kb, NKV, vb, QKV, kl_, ql_, B, S, nq, nkv, scale, p_att, seed_, ob, lseb,
@@ -646,7 +660,7 @@ class Engine:
                          qknorm=dict(wq=W.self_attn["qn"], wk=W.self_attn["kn"], eps=eps, cos=cos, sin=sin, q_rot=A["q"],
                                      k_rot=A["k"], pos_ids=pos_ids, S=S, nq=nq, nkv=nkv))
             else:
-                ops.linear_fwd(A["h1"], H, Wm.self_attn["qkv"], H, A["qkv"], QKV, T, QKV, H)
+                ops.linear_fwd(A["h1"], H, Wm.self_attn["qkv"], H, A["qkv"], QKV, T, QKV, H, **v_amax(A["qkv"]))
                 ops.qknorm_rope_fwd(A["qkv"], S, nq, nkv, W.self_attn["qn"], W.self_attn["kn"], eps, cos, sin, A["q"], A["k"],
                                     pos_ids=pos_ids)
             if kv_sink is not None:
@@ -801,6 +815,9 @@ class Engine:
         bf16 = self.dtype == "bf16"
         split_attn = self.split_attention and self.matmul != "f32" and not bf16
         fuse_delta = (ws.ds_work is not None or bf16 or split_attn) and T % 128 == 0 and NQ % 128 == 0
+        # (three-product attention) max |dO| out of the o_proj input-gradient GEMM's epilogue instead of a pass over dO
+        do_amax = (dict(c_amax=(ws.dao, 0)) if (split_attn and self.h2_attention and self.matmul == "split3" and p_att < 0.75 and
+                                                   self.gemm_c_amax) else {})
 
         def dgrad(dy, lddy, Wf, Wt, ldw, dx, lddx, n_out, k_in, **kw):
             """dx[T,k_in] (+)= dy[T,n_out] @ W[n_out,k_in]: fp32 reads W itself (row-contiguous B operand), bf16 the
@@ -812,11 +829,12 @@ class Engine:
                 ops.linear_dgrad(dy, lddy, Wf, ldw, dx, lddx, T, n_out, k_in, **kw)
 
         def attention_bwd(qb, kb, vb, ob, lseb, kl_, ql_, empty_, tile_empty_, seed_, order_, span_):
-            if split_attn and span_ is None:
+            h2_bwd = self.h2_attention and self.matmul == "split3" and p_att < 0.75
+            if split_attn and (span_ is None or h2_bwd):
                 ops.attn_bwd_split(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, empty_, tile_empty_, B, S, nq, nkv, scale,
                                    p_att, seed_, ws.delta, ws.dq, NQ, ws.dk, NKV, ws.dqkv[:, NQ + NKV:], QKV, order=order_,
                                    delta_ready=fuse_delta, dv_of=ws.dqkv,   # recompute form: measured faster than its dS spill
-                                   h2=self.h2_attention and self.matmul == "split3" and p_att < 0.75)
+                                   h2=h2_bwd, q_span=span_)
             elif bf16:
                 ord16 = (order_[0], order_[2], empty_) if (order_ is not None and span_ is None) else None
                 ops.attn_bwd_bf16(qb, NQ, kb, NKV, vb, QKV, ob, ws.dao, lseb, kl_, ql_, B, S, nq, nkv, scale, p_att, seed_,
@@ -891,7 +909,7 @@ class Engine:
                     ops.linear_wgrad(t1, H, A["ao_c"], NQ, GC["o"], NQ, T, H, NQ)
                     ops.linear_wgrad(t2, H, A["h2"], H, GC["gate"], H, T, H, H)
                     dgrad(t1, H, C["o"], CT["o"], NQ, ws.dao, NQ, H, NQ,
-                          rowdot=(A["ao_c"], ws.delta, S) if fuse_delta else None)
+                          rowdot=(A["ao_c"], ws.delta, S) if fuse_delta else None, **do_amax)
                 attention_bwd(A["q_c"], A["k_c"], A["qkv_c"][:, NQ + NKV:], A["ao_c"], A["lse_c"], r["kl_cross"],
                               r["ql_cross"], r["empty_cross"], r["tile_empty_cross"], self._seed(l, 2), ws.cross_order,
                               span_cross)
@@ -911,7 +929,8 @@ class Engine:
             # (t0 = mask * dx of this branch, written by the norm backward above)
             with hold(t0):
                 ops.linear_wgrad(t0, H, A["ao"], NQ, GS["o"], NQ, T, H, NQ)
-                dgrad(t0, H, SA["o"], ST["o"], NQ, ws.dao, NQ, H, NQ, rowdot=(A["ao"], ws.delta, S) if fuse_delta else None)
+                dgrad(t0, H, SA["o"], ST["o"], NQ, ws.dao, NQ, H, NQ, rowdot=(A["ao"], ws.delta, S) if fuse_delta else None,
+                      **do_amax)
             attention_bwd(A["q"], A["k"], A["qkv"][:, NQ + NKV:], A["ao"], A["lse"], r["kl_self"], None, r["empty_self"],
                           r["tile_empty_self"], self._seed(l, 0), None, span_self)
             ops.qknorm_rope_bwd(A["qkv"], ws.dq, ws.dk, S, nq, nkv, SA["qn"], SA["kn"], eps, cos, sin, ws.dqkv, GS["qn"],

@@ -410,7 +410,7 @@ def set_f32_matmul(mode) -> int:
 
 def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=False, groups=1, group_mode=0,
          group_offsets=None, strideB=0, strideC=0, kchunk=0, resid=None, row_map=None, p_drop=0.0, seed=0,
-         rowdot=None, qknorm=None):
+         rowdot=None, qknorm=None, c_amax=None):
     """C[m][n] (=|+=) alpha * sum_k A(m,k) B(n,k); see gamer_gemm_desc in include/gamer_hip.h.  bf16 operands go to
     gamer_gemm_bf16 (k-contiguous x k-contiguous, or the token-major wgrad form; see gamer_gemm_bf16_desc)."""
     if A.dtype == torch.bfloat16:
@@ -442,6 +442,13 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
         d.qk_act_idx, d.qk_pos_ids = ptr(q.get("act_idx")), ptr(q.get("pos_ids"))
         d.qk_q_rot, d.qk_k_rot = ptr(q["q_rot"]), ptr(q["k_rot"])
         d.qk_S, d.qk_nq, d.qk_nkv = int(q["S"]), int(q["nq"]), int(q["nkv"])
+    if (c_amax is not None and _AMAX_REUSE is not None and F32_MATMUL_TERMS == 3 and group_mode == 0 and not accumulate
+            and resid is None and qknorm is None and c_amax[1] % 64 == 0):
+        # c_amax = (view of C from column col0 on, col0): the maximum of those columns comes out of this GEMM's epilogue into the
+        # slot the next matrix product that reads the view (with this extent) will take - no gamer_absmax_f32 pass over it
+        view, col0 = c_amax
+        slot_c = _AMAX_REUSE.preset(view, (1, 0, M, N - col0, ldc))
+        d.amax_c, d.amax_c_col0 = slot_c, int(col0)
     if F32_MATMUL_TERMS == 3:
         # operand extents: A(m, k) at A + m a_rs + k a_ks, B(n, k) at B + n b_rs + k b_ks (one of each stride pair is 1)
         ga = (M, K, a_rs) if a_ks == 1 else (K, M, a_ks)
@@ -730,7 +737,7 @@ def attn_operand_maxima(q, ldq, k, ldk, v, ldv, T, nq, nkv, d_o=None):
 
 
 def attn_fwd_split(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, order=None,
-                   h2=False):
+                   h2=False, uniform_len=0, q_span=None):
     """gamer_attn_fwd with its products on the 16-bit matrix pipe; training semantics.  h2 = False: exact three-way bf16
     cuts, six piece products; h2 = True: two-way fp16 cuts scaled per tensor, three piece products (gamer_attn_split_amax)."""
     pm, tk, tm = order if order is not None else (None, None, None)
@@ -739,11 +746,12 @@ def attn_fwd_split(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, sca
     if _AMAX_ATTN:
         _arm_sink((o, (1, 0, 1, B * S * nq * 64, B * S * nq * 64), False))
     call("gamer_attn_fwd_split", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(kl), ptr(ql), ptr(row_empty), B, S, nq, nkv,
-         scale, p_drop, seed, ptr(o), ptr(lse), ptr(pm), ptr(tk), ptr(tm), stream_ptr())
+         scale, p_drop, seed, ptr(o), ptr(lse), ptr(pm), ptr(tk), ptr(tm), int(uniform_len), ptr(q_span), stream_ptr())
 
 
 def attn_bwd_split(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty, B, S, nq, nkv, scale, p_drop, seed,
-                   delta, dq, lddq, dk, lddk, dv, lddv, order=None, delta_ready=False, ds_work=None, dv_of=None, h2=False):
+                   delta, dq, lddq, dk, lddk, dv, lddv, order=None, delta_ready=False, ds_work=None, dv_of=None, h2=False,
+                   q_span=None):
     """gamer_attn_bwd with its products on the bf16 pipe; delta_ready: `delta` already holds dO.O; ds_work: the dS spill
     scratch of attn_bwd (None = recompute form); dv_of: the d(q|k|v) tensor whose v columns `dv` is (its maximum is then
     collected by the kernels that write it: this one and qknorm_rope_bwd)."""
@@ -754,7 +762,7 @@ def attn_bwd_split(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_
         _arm_sink((dv_of, (1, 0, dv_of.shape[0], dv_of.shape[1], dv_of.stride(0)), False))
     call("gamer_attn_bwd_split", ptr(q), ldq, ptr(k), ldk, ptr(v), ldv, ptr(o), ptr(d_o), ptr(lse), ptr(kl), ptr(ql),
          ptr(row_empty), ptr(tile_empty), B, S, nq, nkv, scale, p_drop, seed, ptr(delta), ptr(dq), lddq, ptr(dk), lddk, ptr(dv),
-         lddv, ptr(pm), ptr(tk), ptr(tm), 1 if delta_ready else 0, ptr(ds_work), stream_ptr())
+         lddv, ptr(pm), ptr(tk), ptr(tm), 1 if delta_ready else 0, ptr(ds_work), ptr(q_span), stream_ptr())
 
 
 def attn_fwd_bf16(q, ldq, k, ldk, v, ldv, kl, ql, B, S, nq, nkv, scale, p_drop, seed, o, lse, q_span=None, order=None):

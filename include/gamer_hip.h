@@ -217,6 +217,12 @@ typedef struct {
      * tensors (gamer_absmax_f32; for grouped B: over all groups) - the kernel derives each tensor's power-of-two scale from them. */
     const uint32_t* amax_a;
     const uint32_t* amax_b;
+    /* (ABI 7) optional, group_mode 0 with the plain or row-dot epilogue (no accumulate / resid / q|k|v epilogue): the kernel folds
+     * the bits of max |C[m][n] stored| over the columns n >= amax_c_col0 (a multiple of 64) into the amax slot `amax_c` (as
+     * gamer_amax_sink does for the element-wise producers): the maximum of an operand of the NEXT matrix product - the v columns
+     * of the q|k|v projection, dO out of the o_proj input gradient - without a pass of gamer_absmax_f32 over it.  NULL = off. */
+    uint32_t* amax_c;
+    int amax_c_col0;
 } gamer_gemm_desc;
 
 int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);
@@ -433,7 +439,7 @@ int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float
                    const int32_t* row_perm, const int32_t* tile_kind, const int32_t* tile_maxpos,
                    float* ds_work, const int32_t* q_span, int delta_ready, void* stream);
 
-/* The same attention (training semantics: uniform_len = S, no q_span) with fp32 inputs / outputs and every matrix product
+/* The same attention with fp32 inputs / outputs and every matrix product
  * formed on the bf16 matrix pipe from an exact three-way bf16 cut of both operands, six piece products per fp32 product,
  * fp32 accumulation - the attention counterpart of gamer_gemm_f32_split (csrc/attention_split.hip; same predicate,
  * empty-row rule, row order and dropout mask function as gamer_attn_fwd / _bwd, so the three kernels of either form
@@ -441,19 +447,23 @@ int gamer_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float
  * Engine(matmul="split6") step.  bwd: ds_work == NULL = recompute form (dQ kernel + dK/dV kernel, 7 products per tile
  * pair); ds_work = the scratch of gamer_attn_bwd (B*nq*ceil(S/32)^2*1024 floats) = the dK/dV kernel spills its fp32 dS
  * tiles and dQ = dS K is one product per tile pair (5 products).  delta_ready != 0: delta already holds dO.O (row-dot
- * epilogue of the o_proj dgrad GEMM), otherwise it is computed here. */
+ * epilogue of the o_proj dgrad GEMM), otherwise it is computed here.
+ * (ABI 7) uniform_len / q_span as in gamer_attn_fwd / _bwd: the evaluation re-run's span of an "empty" row (forward, both
+ * forms) and the per-query key spans of Qwen3SessionMulti (gamer_session_spans) - the latter in the three-product form only
+ * (armed by gamer_attn_split_amax; backward: recompute form). */
 int gamer_attn_fwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                          const int32_t* kl, const int32_t* ql, const int32_t* row_empty,
                          int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                          float* o, float* lse,
-                         const int32_t* row_perm, const int32_t* tile_kind, const int32_t* tile_maxpos, void* stream);
+                         const int32_t* row_perm, const int32_t* tile_kind, const int32_t* tile_maxpos,
+                         int uniform_len, const int32_t* q_span, void* stream);
 int gamer_attn_bwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                          const float* o, const float* d_o, const float* lse,
                          const int32_t* kl, const int32_t* ql, const int32_t* row_empty, const int32_t* tile_empty,
                          int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                          float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
                          const int32_t* row_perm, const int32_t* tile_kind, const int32_t* tile_maxpos,
-                         int delta_ready, float* ds_work, void* stream);
+                         int delta_ready, float* ds_work, const int32_t* q_span, void* stream);
 
 /* bf16 attention of the reference's --bf16 run (autocast casts q, k, v AND the additive mask of
  * sdpa_attention_forward to bf16).  Same predicate, layouts and dropout mask function as gamer_attn_fwd / _bwd, with

@@ -937,6 +937,20 @@ def test_amax_sinks_equal_the_maximum_of_what_the_kernel_wrote():
         ops.call("gamer_absmax_multi_f32", flat.data_ptr(), table.data_ptr(), 3, first, ops.stream_ptr())
         for e, (o, n) in enumerate(((0, 4096), (4096, 8192), (12288, 256))):
             assert _slot_value(first + 4 * ops.AMAX_WORDS * e) == float(flat[o:o + n].abs().max())
+        # a GEMM as a producer (gamer_gemm_desc.amax_c): the v columns of a q|k|v projection, full and ragged row counts, and dO with
+        # the row-dot epilogue; a row-range-guarded tile (recomputed in fp32) reports the maximum of what it finally stored
+        for Tg in (640, 300):
+            xg, wg = dev(torch.randn(Tg, H)), dev(torch.randn(QKV, H) * 0.3)
+            if Tg == 640:
+                xg[128:256] *= 2.0 ** -20
+            yg = torch.zeros(Tg, QKV, device=DEV)
+            vg = yg[:, (nq + nkv) * 64:]
+            ops.linear_fwd(xg, H, wg, H, yg, QKV, Tg, QKV, H, c_amax=(vg, (nq + nkv) * 64))
+            assert pending(vg, (1, 0, Tg, nkv * 64, QKV)) == float(vg.abs().max())
+        dyg, wo, other = dev(torch.randn(T, H) * 1e-3), dev(torch.randn(H, 128) * 0.1), dev(torch.randn(T, 128))
+        dao, dl = torch.empty(T, 128, device=DEV), torch.empty(T // S, 2, S, device=DEV)
+        ops.linear_dgrad(dyg, H, wo, 128, dao, 128, T, H, 128, rowdot=(other, dl, S), c_amax=(dao, 0))
+        assert pending(dao, (1, 0, T, 128, 128)) == float(dao.abs().max())
         # the split attention as a producer: o (forward) and the v columns of d(q|k|v) (dK/dV kernel), self and row-ordered cross
         for cross in (False, True):
             cache.slots.clear()         # (everything=True keeps maxima by ADDRESS: new tensors may land where freed ones were)

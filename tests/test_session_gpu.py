@@ -136,14 +136,16 @@ def _attn_ref(q, k, v, ok, nq, nkv, scale):
     return torch.einsum("bnij,bjnd->bind", p, vq), torch.logsumexp(s_eff, -1), empty
 
 
-@pytest.mark.parametrize("spill", [False, True])
+@pytest.mark.parametrize("spill", [False, True, "split_h2"])
 @pytest.mark.parametrize("use_order", [False, True])
 @pytest.mark.parametrize("cross", [False, True])
 @pytest.mark.parametrize("n_items,B,nq,nkv,mean", [(7, 3, 2, 1, 2.0), (14, 2, 2, 1, 3.0), (41, 3, 2, 1, 1.0),
-                                                   (101, 2, 2, 1, 4.0), (101, 9, 6, 3, 6.0), (33, 40, 6, 3, 2.5)])
+                                                   (101, 2, 2, 1, 4.0), (101, 9, 6, 3, 6.0), (33, 40, 6, 3, 2.5),
+                                                   (40, 3, 3, 3, 2.0)])
 def test_session_attention_fwd_bwd(cross, n_items, B, nq, nkv, mean, use_order, spill):
     """Attention kernels with per-query key spans (SPAN instantiations) against the dense reference with the
-    reference's session masks; same shapes as test_ops_gpu.test_attention_fwd_bwd plus one-item sessions."""
+    reference's session masks; same shapes as test_ops_gpu.test_attention_fwd_bwd plus one-item sessions.
+    "split_h2": the three-product fp16 form of csrc/attention_split.hip (what the default engine runs for Qwen3SessionMulti)."""
     batch = _session_batch(B, n_items, 7 + n_items, mean, pad_rows={0: max(1, n_items // 3)})
     S = batch["input_ids"].shape[1]
     T = B * S
@@ -177,23 +179,29 @@ def test_session_attention_fwd_bwd(cross, n_items, B, nq, nkv, mean, use_order, 
     o = torch.empty(T, nq * 64, device=DEV)
     lse = torch.empty(B, nq, S, device=DEV)
     dq_, dk_ = dev(q.reshape(T, -1)), dev(k.reshape(T, -1))
-    ops.attn_fwd(dq_, nq * 64, dk_, nkv * 64, vview, ldv, kl, ql, re_, te, B, S, nq, nkv, 0.125, 0.0, 1, o, lse,
-                 order=order, q_span=span)
     delta = torch.empty(B, nq, S, device=DEV)
     dq = torch.empty(T, nq * 64, device=DEV)
     dk = torch.empty(T, nkv * 64, device=DEV)
     dqkv = torch.zeros(T, ldv, device=DEV)
     dvv = dqkv[:, (nq + nkv) * 64:]
-    ds_work = torch.full((ops.attn_ds_work_numel(B, S, nq),), float("nan"), device=DEV) if spill else None
-    ops.attn_bwd(dq_, nq * 64, dk_, nkv * 64, vview, ldv, o, dev(d_o.reshape(T, -1)), lse, kl, ql, re_, te, B, S, nq,
-                 nkv, 0.125, 0.0, 1, delta, dq, nq * 64, dk, nkv * 64, dvv, ldv, order=order, ds_work=ds_work,
-                 q_span=span)
+    if spill == "split_h2":
+        ops.attn_fwd_split(dq_, nq * 64, dk_, nkv * 64, vview, ldv, kl, ql, re_, B, S, nq, nkv, 0.125, 0.0, 1, o, lse,
+                           order=order, h2=True, q_span=span)
+        ops.attn_bwd_split(dq_, nq * 64, dk_, nkv * 64, vview, ldv, o, dev(d_o.reshape(T, -1)), lse, kl, ql, re_, te, B, S, nq,
+                           nkv, 0.125, 0.0, 1, delta, dq, nq * 64, dk, nkv * 64, dvv, ldv, order=order, h2=True, q_span=span)
+    else:
+        ops.attn_fwd(dq_, nq * 64, dk_, nkv * 64, vview, ldv, kl, ql, re_, te, B, S, nq, nkv, 0.125, 0.0, 1, o, lse,
+                     order=order, q_span=span)
+        ds_work = torch.full((ops.attn_ds_work_numel(B, S, nq),), float("nan"), device=DEV) if spill else None
+        ops.attn_bwd(dq_, nq * 64, dk_, nkv * 64, vview, ldv, o, dev(d_o.reshape(T, -1)), lse, kl, ql, re_, te, B, S, nq,
+                     nkv, 0.125, 0.0, 1, delta, dq, nq * 64, dk, nkv * 64, dvv, ldv, order=order, ds_work=ds_work,
+                     q_span=span)
     ne = ~empty
     e = dict(o=_rel(o, o_ref.reshape(T, -1)),
              lse=float((lse.cpu().permute(0, 2, 1)[ne].double() - lse_ref.detach().permute(0, 2, 1)[ne]).abs().max()),
              dq=_rel(dq, leaves[0].grad.reshape(T, -1)), dk=_rel(dk, leaves[1].grad.reshape(T, -1)),
              dv=_rel(dvv, leaves[2].grad.reshape(T, -1)), empty_rows=int(empty.sum()))
-    _record(f"session_attn_cross{int(cross)}_S{S}_B{B}_h{nq}_ord{int(use_order)}_spill{int(spill)}", e)
+    _record(f"session_attn_cross{int(cross)}_S{S}_B{B}_h{nq}_ord{int(use_order)}_spill{spill}", e)
     assert int((empty & batch["attention_mask"].bool()).sum()) > 0 or not cross, "fixture must contain empty rows"
     assert e["o"] < 2e-5 and e["lse"] < 2e-5
     assert e["dq"] < 5e-5 and e["dk"] < 5e-5 and e["dv"] < 5e-5
@@ -237,6 +245,17 @@ def test_session_attention_dropout_uses_the_same_mask_fwd_bwd():
             outs.append((dq, dk, dv))
         for a, b_ in zip(*outs):
             assert _rel(a, b_) < 2e-5
+        # the three-product split form (csrc/attention_split.hip, SPAN instantiations) regenerates the same masks
+        o_s, lse_s = torch.empty_like(o), torch.empty_like(lse)
+        ops.attn_fwd_split(q, nq * 64, k, nkv * 64, v, nkv * 64, kl, ql, re_, B, S, nq, nkv, 0.125, 0.2, 77, o_s, lse_s, h2=True,
+                           q_span=span)
+        assert _rel(o_s, o) < 2e-5
+        delta = torch.empty(B, nq, S, device=DEV)
+        dq_s, dk_s, dv_s = torch.empty(T, nq * 64, device=DEV), torch.empty(T, nkv * 64, device=DEV), torch.empty(T, nkv * 64, device=DEV)
+        ops.attn_bwd_split(q, nq * 64, k, nkv * 64, v, nkv * 64, o, d_o, lse, kl, ql, re_, te, B, S, nq, nkv, 0.125, 0.2, 77, delta,
+                           dq_s, nq * 64, dk_s, nkv * 64, dv_s, nkv * 64, h2=True, q_span=span)
+        for a, b_ in zip((dq_s, dk_s, dv_s), outs[0]):
+            assert _rel(a, b_) < 5e-5
         # O is linear in V for a fixed mask: <dO, O(V + e W) - O(V)> / e = <dV, W>
         w = dev(torch.randn(T, nkv * 64, generator=g))
         o2, _ = fwd(v + 0.5 * w)
