@@ -395,6 +395,9 @@ def parse_args(argv=None):
     ap.add_argument("--accum", type=int, default=1,
                     help="gradient accumulation: one step = ACCUM micro-batches of --batch through Engine.train_window (one clip + "
                          "AdamW per window); BASELINE configs[3] is --batch 128 --accum 4 --augment 4")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="fp32 forms: every reduction of the step in a fixed order (Engine(deterministic=True): the embedding gradient as "
+                         "an ordered GEMM on top of the default two-pass weight gradients): what bit-reproducible runs cost")
     ap.add_argument("--augment", type=int, default=0,
                     help="secondary workload: rows shaped like tasks=smb_explicit_decoder_<AUGMENT> (thinned copies, cropped to "
                          "--items, right padded per micro-batch; synthetic.make_augmented_batch)")
@@ -495,7 +498,7 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
     if args.matmul != "f32" and args.dtype != "f32":
         raise SystemExit("--matmul split3/split6/split9 is a form of the fp32 path (--dtype f32)")
     eng = Engine(cfg, device=f"cuda:{local_rank}", temperature=0.7, variant=args.variant, dtype=args.dtype,
-                 matmul=args.matmul)
+                 matmul=args.matmul, deterministic=bool(getattr(args, "deterministic", False)) or None)
     smean = args.session_mean if args.variant == "session" else None
     eng.init_weights(seed=0)                     # identical replicas on every rank
     eng.base_seed = 0x5EED + rank                # independent dropout streams per rank
@@ -632,6 +635,31 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
         allreduce = {"ranks": dist.get_world_size(), "backend": "nccl (RCCL)", "bytes": nbytes, "buckets": cfg.num_hidden_layers + 2,
                      "ms": ms, "bus_GBps": 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9}
 
+    # N > 1 (or the forced single-rank collective path): what the reducer costs and hides.  (a) every bucket alone; (b) the same
+    # step WITHOUT any collective (local gradients only - not a valid training step, a timing reference): with - without = the
+    # communication the backward did not hide.
+    comm_diag = None
+    if reducer is not None and (world > 1 or force_dist) and accum == 1 and module is None:
+        import torch.distributed as dist
+        from gamer_amd.dp import bucket_timings
+        buckets = bucket_timings(reducer)
+        n_ref = max(2, min(args.steps, 4))
+
+        def timed_steps(red):
+            barrier()
+            ta = time.perf_counter()
+            for i in range(n_ref):
+                eng.train_step(batches[i % n_batches], lr, reducer=red, grad_scale=grad_scale)
+            barrier()
+            t = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item()) / n_ref * 1e3
+        with_ms = timed_steps(reducer)
+        without_ms = timed_steps(None)
+        comm_diag = {"per_bucket": buckets, "sum_of_buckets_ms": sum(b["ms"] for b in buckets),
+                     "step_ms_with_reducer": with_ms, "step_ms_without_collectives": without_ms,
+                     "exposed_communication_ms": max(0.0, with_ms - without_ms), "steps_each": n_ref}
+
     result = None
     if rank == 0:
         seqs = args.batch * accum * world * args.steps
@@ -702,6 +730,7 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
                 "parallelism": f"dp{world}",
                 "path": args.path,
                 "matmul": args.matmul,
+                "deterministic_wgrad": bool(getattr(args, "deterministic", False)),
             },
             "roofline": {
                 "bound": "mfma",
@@ -737,6 +766,8 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
         }
         if allreduce is not None:
             result["allreduce"] = allreduce
+        if comm_diag is not None:
+            result["communication"] = comm_diag
         if args.no_kernel_timing:
             result["roofline"] = None
     # release this leg's engine (86 GB of activations at batch 1024 fp32) before the next leg allocates its own
@@ -761,13 +792,29 @@ def main(argv=None):
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     force_dist = os.environ.get("GAMER_BENCH_FORCE_DIST") == "1"     # exercise the RCCL path on one GPU
+    rccl_log = None
     if world > 1 or force_dist:
         import torch.distributed as dist
+        if "NCCL_DEBUG_FILE" not in os.environ and os.environ.get("NCCL_DEBUG", "").upper() not in ("TRACE",):
+            # what RCCL decides (rings / channels / transports, algorithm and protocol per collective) goes into the JSON line:
+            # every rank writes its INFO log to a file of its own, rank 0's is parsed after the run (gamer_amd.dp.parse_rccl_log).
+            # (An inherited NCCL_DEBUG=WARN / VERSION is raised to INFO for this process; a user's own log file is left alone.)
+            import tempfile
+            log_dir = tempfile.mkdtemp(prefix="gamer_rccl_")
+            rccl_log = os.path.join(log_dir, f"rank{rank}.log")
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,TUNING,ENV", NCCL_DEBUG_FILE=rccl_log)
         if force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
         dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
         if dist.get_world_size() != world:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {world}")
+        # every rank really joined RCCL on a device of its own: one tiny all-reduce counts them, one all-gather lists the devices
+        probe = torch.ones(1, device="cuda")
+        dist.all_reduce(probe)
+        devs = [None] * world
+        dist.all_gather_object(devs, (rank, torch.cuda.current_device(), torch.cuda.get_device_properties(local_rank).name))
+        if int(probe.item()) != world or len({d[1] for d in devs}) != (world if torch.cuda.device_count() >= world else 1):
+            raise SystemExit(f"RCCL group check failed: sum of ones = {int(probe.item())}, ranks/devices = {devs}")
 
     timer = KernelTimer()
     if not args.no_kernel_timing:
@@ -779,7 +826,7 @@ def main(argv=None):
     # timed by the same run, 2 warm-up + 5 timed steps each, reported under "secondary" on the ONE JSON line.
     default_workload = (world == 1 and not force_dist and args.path == "engine" and args.dtype == "f32" and args.matmul == "split3"
                         and args.batch == 1024 and args.items == 101 and args.variant == "multi" and not args.ragged
-                        and not args.no_dropout and args.accum == 1 and not args.augment)
+                        and not args.no_dropout and args.accum == 1 and not args.augment and not args.deterministic)
     if default_workload and not args.no_secondary and result is not None:
         import copy
         secondary = []
@@ -812,6 +859,14 @@ def main(argv=None):
             from gamer_amd.config import synthetic_config
             smean = args.session_mean if args.variant == "session" else None
             result["cpu_baseline"] = cpu_baseline(synthetic_config().to_dict(), args.items, session_mean=smean)
+        if rccl_log is not None:
+            from gamer_amd.dp import parse_rccl_log
+            try:
+                result["rccl"] = parse_rccl_log(open(rccl_log, errors="replace").read())
+            except OSError as e:
+                result["rccl"] = {"error": repr(e)}
+        elif world > 1 or force_dist:
+            result["rccl"] = {"note": "NCCL_DEBUG_FILE / NCCL_DEBUG=TRACE set by the caller: log left where the caller put it"}
         # RCCL prints a version banner through C stdio; push it out first so that the JSON line is last
         try:
             import ctypes

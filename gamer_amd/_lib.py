@@ -56,6 +56,7 @@ class GemmDesc(C.Structure):
         ("b_planes", c_void_p), ("b_plane_stride", c_int64),
         ("amax_a", c_void_p), ("amax_b", c_void_p),
         ("amax_c", c_void_p), ("amax_c_col0", c_int),
+        ("wgrad_ws", c_void_p), ("wgrad_ws_floats", c_int64),
     ]
 
 
@@ -100,7 +101,7 @@ _SIGNATURES = {
     "gamer_rmsnorm_bwd": [P, P, P, I, P, I, I, F, I, P, P, I, P, P, F, U, P],
     "gamer_colsum_reduce": [P, I, I, I, P, P],
     "gamer_rowtable_fwd": [P, P, P, I, I, P, I, I, P],
-    "gamer_rowtable_bwd": [P, I, I, P, P, I, I, I, P, P],
+    "gamer_rowtable_bwd": [P, I, I, P, P, I, I, I, P, P, L, P],
     "gamer_gemm_f32": [C.POINTER(GemmDesc), P],
     "gamer_gemm_f32_split": [C.POINTER(GemmDesc), c_int, P],
     "gamer_split3_guard": [I],

@@ -26,7 +26,7 @@ namespace gamer {
 #ifndef SPA_ABLATE
 #define SPA_ABLATE 0      // timing-only builds (tools/ablate_attn_split.sh): 1 no S = K Q^T MFMAs, 2 no second-product MFMAs, 4 no cut of P / dS,
 #endif                    // 8 no cut arithmetic anywhere (pieces = the raw word), 16 no LDS tile stores, 32 (H2) no staging of K / V / Q / dO tiles at all,
-                          // forward only: 64 no exp2, 128 no barrier in the key loop, 256 no softmax / dropout at all
+                          // forward only: 64 no exp2, 128 no barrier in the key loop, 256 no softmax / dropout at all, 512 no global loads in the key loop
 constexpr int SIMG = 32 * 64;              // bf16 elements of one piece image of a 32-row tile
 
 // element offset of (row, column) in a [rows][64] bf16 image with swizzled 16-byte chunks (attention_bf16.hip: lds_off)
@@ -382,11 +382,11 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
         const int j0 = jt * 32;
         const bool have_next = jt + 1 < n_iter;
         const bool have_next2 = jt + 2 < n_iter;
-        if (have_next2) {
+        if (have_next2 && !(SPA_ABLATE & 512)) {
             load_tile32(kbase, ldk, j0 + 64, S, tid, rk);
             rmeta = key_meta_load<DROP>(klb, j0 + 64, S, w, lane, rng);
         }
-        if (have_next) load_tile32(vbase, ldv, j0 + 32, S, tid, rv);
+        if (have_next && !(SPA_ABLATE & 512)) load_tile32(vbase, ldv, j0 + 32, S, tid, rv);
 
         const bool beyond = j0 > wave_q_hi;                // every key of the tile is in every row's future
         const bool beyond_next = (j0 + 32) > wave_q_hi;

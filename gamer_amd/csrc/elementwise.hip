@@ -298,14 +298,19 @@ constexpr int TBL_MAXROWS = 8;   // num_behavior + 1 <= 8
 
 // dtable[idx[t]][c] += dy[src(t)][col0+c]; per-thread predicated accumulators, LDS combine, one
 // atomic per workgroup per table element.
-template <typename TG>
+// DET (a `partial` workspace was given): no atomics at all - the row groups of a workgroup are added in row-group order through
+// LDS, the workgroup's table goes to partial[block] and gamer_colsum_reduce's kernel folds the blocks in block order.
+template <typename TG, bool DET>
 __global__ void __launch_bounds__(EW_THREADS)
 rowtable_bwd_kernel(const TG* __restrict__ dy, int lddy, int col0, const int32_t* __restrict__ idx,
-                    const int32_t* __restrict__ dy_rows, int T, int E4, int nrows, float* __restrict__ dtable) {
-    extern __shared__ __attribute__((aligned(16))) float lds_tbl[];   // [nrows][E4*4]
+                    const int32_t* __restrict__ dy_rows, int T, int E4, int nrows, float* __restrict__ dtable,
+                    float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds_tbl[];   // [nrows][E4*4]; DET: [row groups][nrows][E4*4]
     const int E = E4 * 4;
-    for (int i = threadIdx.x; i < nrows * E; i += EW_THREADS) lds_tbl[i] = 0.f;
-    __syncthreads();
+    if (!DET) {
+        for (int i = threadIdx.x; i < nrows * E; i += EW_THREADS) lds_tbl[i] = 0.f;
+        __syncthreads();
+    }
     const int c = threadIdx.x % E4;
     const int rl = threadIdx.x / E4;
     const int rows_per_block = EW_THREADS / E4;
@@ -326,15 +331,27 @@ rowtable_bwd_kernel(const TG* __restrict__ dy, int lddy, int col0, const int32_t
 #pragma unroll
         for (int a = 0; a < TBL_MAXROWS; ++a) {
             if (a < nrows) {
-                atomicAdd(&lds_tbl[a * E + c * 4 + 0], acc[a].x);
-                atomicAdd(&lds_tbl[a * E + c * 4 + 1], acc[a].y);
-                atomicAdd(&lds_tbl[a * E + c * 4 + 2], acc[a].z);
-                atomicAdd(&lds_tbl[a * E + c * 4 + 3], acc[a].w);
+                if (DET) {
+                    *reinterpret_cast<float4*>(&lds_tbl[(rl * nrows + a) * E + c * 4]) = acc[a];
+                } else {
+                    atomicAdd(&lds_tbl[a * E + c * 4 + 0], acc[a].x);
+                    atomicAdd(&lds_tbl[a * E + c * 4 + 1], acc[a].y);
+                    atomicAdd(&lds_tbl[a * E + c * 4 + 2], acc[a].z);
+                    atomicAdd(&lds_tbl[a * E + c * 4 + 3], acc[a].w);
+                }
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nrows * E; i += EW_THREADS) atomicAdd(&dtable[i], lds_tbl[i]);
+    if (DET) {
+        for (int i = threadIdx.x; i < nrows * E; i += EW_THREADS) {
+            float t = 0.f;
+            for (int g = 0; g < rows_per_block; ++g) t += lds_tbl[g * nrows * E + i];
+            partial[(int64_t)blockIdx.x * nrows * E + i] = t;
+        }
+    } else {
+        for (int i = threadIdx.x; i < nrows * E; i += EW_THREADS) atomicAdd(&dtable[i], lds_tbl[i]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1249,7 +1266,8 @@ extern "C" int gamer_rowtable_fwd_bf16(const float* table, const int32_t* idx, c
 
 template <typename TG>
 static int rowtable_bwd_impl(const char* name, const TG* dy, int lddy, int col0, const int32_t* idx,
-                             const int32_t* dy_rows, int T, int E, int n_rows_table, float* dtable, void* stream) {
+                             const int32_t* dy_rows, int T, int E, int n_rows_table, float* dtable, float* partial,
+                             int64_t partial_numel, void* stream) {
     GAMER_CHECK_ARG(dy && idx && dtable, "%s: null pointer", name);
     GAMER_CHECK_ARG(T > 0 && E > 0 && E % 4 == 0 && E / 4 <= EW_THREADS && lddy % 4 == 0 && col0 % 4 == 0 &&
                     n_rows_table > 0 && n_rows_table <= TBL_MAXROWS,
@@ -1257,20 +1275,37 @@ static int rowtable_bwd_impl(const char* name, const TG* dy, int lddy, int col0,
     const int rows_per_block = EW_THREADS / (E / 4);
     int blocks = (T + rows_per_block - 1) / rows_per_block;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(rowtable_bwd_kernel<TG>, dim3(blocks), dim3(EW_THREADS), (size_t)n_rows_table * E * sizeof(float),
-                       ST(stream), dy, lddy, col0, idx, dy_rows, T, E / 4, n_rows_table, dtable);
+    if (partial) {
+        const int64_t per_block = (int64_t)n_rows_table * E;
+        if (blocks * per_block > partial_numel) blocks = (int)(partial_numel / per_block);
+        GAMER_CHECK_ARG(blocks >= 1, "%s: partial holds %lld floats, one workgroup's table needs %lld", name, (long long)partial_numel,
+                        (long long)per_block);
+        const size_t lds = (size_t)rows_per_block * per_block * sizeof(float);
+        GAMER_CHECK_ARG(lds <= 64 * 1024, "%s: the ordered form needs %zu bytes of LDS (E=%d, rows=%d)", name, lds, E, n_rows_table);
+        hipLaunchKernelGGL((rowtable_bwd_kernel<TG, true>), dim3(blocks), dim3(EW_THREADS), lds, ST(stream), dy, lddy, col0, idx,
+                           dy_rows, T, E / 4, n_rows_table, dtable, partial);
+        GAMER_CHECK_LAUNCH(name);
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3(((int)per_block + 31) / 32), dim3(32 * COLSUM_RG), 0, ST(stream), partial, blocks,
+                           (int)per_block, 1, dtable);
+        GAMER_CHECK_LAUNCH(name);
+        return 0;
+    }
+    hipLaunchKernelGGL((rowtable_bwd_kernel<TG, false>), dim3(blocks), dim3(EW_THREADS), (size_t)n_rows_table * E * sizeof(float),
+                       ST(stream), dy, lddy, col0, idx, dy_rows, T, E / 4, n_rows_table, dtable, (float*)nullptr);
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }
 extern "C" int gamer_rowtable_bwd(const float* dy, int lddy, int col0, const int32_t* idx, const int32_t* dy_rows,
-                                  int T, int E, int n_rows_table, float* dtable, void* stream) {
-    return rowtable_bwd_impl<float>("gamer_rowtable_bwd", dy, lddy, col0, idx, dy_rows, T, E, n_rows_table, dtable, stream);
+                                  int T, int E, int n_rows_table, float* dtable, float* partial, int64_t partial_numel,
+                                  void* stream) {
+    return rowtable_bwd_impl<float>("gamer_rowtable_bwd", dy, lddy, col0, idx, dy_rows, T, E, n_rows_table, dtable, partial,
+                                    partial_numel, stream);
 }
 extern "C" int gamer_rowtable_bwd_bf16(const gamer_bf16* dy, int lddy, int col0, const int32_t* idx,
                                        const int32_t* dy_rows, int T, int E, int n_rows_table, float* dtable,
-                                       void* stream) {
+                                       float* partial, int64_t partial_numel, void* stream) {
     return rowtable_bwd_impl<bf16_t>("gamer_rowtable_bwd_bf16", (const bf16_t*)dy, lddy, col0, idx, dy_rows, T, E,
-                                     n_rows_table, dtable, stream);
+                                     n_rows_table, dtable, partial, partial_numel, stream);
 }
 
 template <typename TA>

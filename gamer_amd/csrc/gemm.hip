@@ -265,6 +265,7 @@ struct GemmParams {
     int guard;                     // SPLIT == 3, MODE 0: row-range guard of the A operand (gamer_split3_guard; default on)
     uint32_t* amax_c;              // MODE 0, plain / row-dot epilogues: fold the bits of max |C stored| over columns >= amax_c_col0 into this slot
     int amax_c_col0;
+    float* wgrad_ws;               // MODE 1, deterministic form: chunk partial tiles [chunk][tile][128][128] instead of fp32 atomics
 };
 
 // SPLIT == 3 scales a whole operand TENSOR by one power of two, so a row of A whose largest magnitude lies more than 2^16 below
@@ -409,6 +410,7 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
     const float* Bp = p.B;
     const float* Bsrc = p.B;    // the fp32 values of this tile's B (Bp may point at their packed pieces)
     float* Cp = p.C;
+    int64_t ws_block = 0;       // MODE 1: index of this workgroup's partial tile in p.wgrad_ws
     if (MODE == 0) {
         const int mt = L / p.n_tiles;
         col0 = (L % p.n_tiles) * BN;
@@ -445,6 +447,7 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
         const int chunk = L / per_chunk;
         const int tile = PP ? 2 * (L % per_chunk) + grp : L % per_chunk;
         if (PP && tile >= tiles_mn) return;                        // (terminated waves do not take part in barriers)
+        ws_block = (int64_t)chunk * tiles_mn + tile;
         row0 = (tile / p.n_tiles) * BM;
         row_end = p.M;
         col0 = (tile % p.n_tiles) * BN;
@@ -1112,6 +1115,20 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
             for (int o2 = 32; o2 > 0; o2 >>= 1) mw = max(mw, (uint32_t)__shfl_xor((int)mw, o2, 64));
             if (lane == 0 && mw) amax_publish(mw, p.amax_c, (uint32_t)(vblock * 4 + wid));
         }
+    } else if (MODE == 1 && p.wgrad_ws != nullptr) {
+        // deterministic weight gradient: the chunk's 128 x 128 partial tile goes to the workspace with plain stores (out-of-range
+        // rows / columns hold exact zeros: their operand rows were staged as zeros), wgrad_reduce_kernel adds the chunks of a
+        // tile in chunk order - no fp32 atomics, the same bits on every run
+        float* blk = p.wgrad_ws + ws_block * (int64_t)(BM * BN);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int lc = wn * 64 + j * 32 + r32;
+                const int lr0 = wm * 64 + i * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) blk[(lr0 + (r & 3) + 8 * (r >> 2)) * BN + lc] = alpha_eff * acc[i][j][r];
+            }
     } else {
         float emax = 0.f;
         auto emit = [&](int row, int col, float v) {
@@ -1276,6 +1293,53 @@ static int launch_gemm(const GemmParams& p, int blocks, hipStream_t st, int spli
     return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2>(p, blocks, st, lds);
 }
 
+// Second pass of the deterministic weight gradient: C tile (+)= sum over the chunks of its group, in chunk order.  One workgroup
+// per (group, C tile, strip of 8 rows): thread -> (row tid >> 5, float4 column tid & 31); four chunk loads in flight.
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t ldc, int M, int N, int m_tiles, int n_tiles,
+                    int groups, const int32_t* __restrict__ group_offsets, int K, int kchunk, int64_t strideC) {
+    const int tiles_mn = m_tiles * n_tiles;
+    int id = blockIdx.x;
+    const int strip = id & 15; id >>= 4;
+    const int tile = id % tiles_mn, g = id / tiles_mn;
+    int c_beg = 0, c_n;
+    if (group_offsets) {
+        int prev = group_offsets[0];
+        c_n = 0;
+        for (int gi = 0; gi <= g; ++gi) {
+            const int nxt = group_offsets[gi + 1];
+            const int chunks = (nxt - prev + kchunk - 1) / kchunk;
+            if (gi < g) c_beg += chunks; else c_n = chunks;
+            prev = nxt;
+        }
+    } else {
+        c_n = (K + kchunk - 1) / kchunk;
+    }
+    const int lr = strip * 8 + (threadIdx.x >> 5), lc = (threadIdx.x & 31) << 2;
+    const float4* src = reinterpret_cast<const float4*>(ws + ((int64_t)c_beg * tiles_mn + tile) * (int64_t)(BM * BN) + lr * BN + lc);
+    const int64_t step4 = (int64_t)tiles_mn * (BM * BN) / 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int c = 0;
+    for (; c + 4 <= c_n; c += 4) {
+        const float4 a0 = src[(int64_t)c * step4], a1 = src[(int64_t)(c + 1) * step4], a2 = src[(int64_t)(c + 2) * step4],
+                     a3 = src[(int64_t)(c + 3) * step4];
+        s.x = (((s.x + a0.x) + a1.x) + a2.x) + a3.x; s.y = (((s.y + a0.y) + a1.y) + a2.y) + a3.y;
+        s.z = (((s.z + a0.z) + a1.z) + a2.z) + a3.z; s.w = (((s.w + a0.w) + a1.w) + a2.w) + a3.w;
+    }
+    for (; c < c_n; ++c) {
+        const float4 a0 = src[(int64_t)c * step4];
+        s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w;
+    }
+    const int row = (tile / n_tiles) * BM + lr, col = (tile % n_tiles) * BN + lc;
+    if (row < M && c_n > 0) {
+        float* dst = C + (int64_t)g * strideC + (int64_t)row * ldc + col;
+        const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (col + e < N) dst[e] += v[e];
+    }
+}
+
 // x[i] -> its three bf16 pieces, planes[s * stride + i]  (the cut of split3, four values per thread)
 __global__ void __launch_bounds__(256)
 split3_planes_kernel(const float4* __restrict__ x, uint16_t* __restrict__ planes, int64_t n4, int64_t stride) {
@@ -1346,6 +1410,7 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     p.amax_a = d->amax_a; p.amax_b = d->amax_b;
     p.guard = g_split3_guard;
     p.amax_c = d->amax_c; p.amax_c_col0 = d->amax_c_col0;
+    p.wgrad_ws = nullptr;
     GAMER_CHECK_ARG(!d->amax_c || (d->group_mode == 0 && !d->accumulate && !d->resid && !d->qk_q_rot && d->amax_c_col0 >= 0 &&
                                    d->amax_c_col0 % 64 == 0),
                     "gamer_gemm_f32: amax_c needs a plain or row-dot Linear-forward / input-gradient GEMM (no accumulate, residual or "
@@ -1396,7 +1461,21 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
         const int64_t chunks = (d->K + d->kchunk - 1) / d->kchunk + (d->group_offsets ? d->groups : 0);
         const int64_t blocks = chunks * p.m_tiles * p.n_tiles;
         GAMER_CHECK_ARG(blocks < (1LL << 31), "gamer_gemm_f32: grid too large");
-        return launch_gemm<false, false, 1>(p, (int)blocks, st, split);
+        p.wgrad_ws = d->wgrad_ws;
+        if (p.wgrad_ws) {
+            const int64_t need = chunks * p.m_tiles * p.n_tiles * (int64_t)(BM * BN);
+            GAMER_CHECK_ARG(d->wgrad_ws_floats >= need && aligned16(d->wgrad_ws),
+                            "gamer_gemm_f32: wgrad_ws holds %lld floats, this weight gradient needs %lld (chunks x tiles x 16384)",
+                            (long long)d->wgrad_ws_floats, (long long)need);
+            GAMER_CHECK_ARG(!getenv("GAMER_GEMM_PP"), "gamer_gemm_f32: the deterministic weight gradient is not built for the ping-pong form");
+        }
+        const int rc = launch_gemm<false, false, 1>(p, (int)blocks, st, split);
+        if (rc || !p.wgrad_ws) return rc;
+        const int64_t rblocks = (int64_t)d->groups * p.m_tiles * p.n_tiles * 16;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)rblocks), dim3(256), 0, st, p.wgrad_ws, d->C, d->ldc, d->M, d->N, p.m_tiles,
+                           p.n_tiles, d->groups, d->group_offsets, d->K, d->kchunk, d->strideC);
+        GAMER_CHECK_LAUNCH("gamer_gemm_f32/wgrad_reduce");
+        return 0;
     }
     return 0;
 }

@@ -91,3 +91,67 @@ def already_reduced_hook(state, bucket):
     fut = torch.futures.Future()
     fut.set_result(bucket.buffer())
     return fut
+
+
+# ---- diagnostics for the multi-GPU runs (bench.py --gpus N): what the collective actually did -----------------------------------
+_ALGO = {"0": "Tree", "1": "Ring", "2": "CollNetDirect", "3": "CollNetChain", "4": "NVLS", "5": "NVLSTree", "6": "PAT"}
+_PROTO = {"0": "LL", "1": "LL128", "2": "Simple"}
+
+
+def parse_rccl_log(text: str) -> dict:
+    """Summary of an ``NCCL_DEBUG=INFO`` log (RCCL prints the same lines): library version, ranks of the communicator, channel
+    count, transports of the peer connections ("via P2P/IPC", "via P2P/direct pointer", "via NET/..."), and - with
+    ``NCCL_DEBUG_SUBSYS`` including TUNING - which algorithm / protocol the tuner chose for how many collectives and bytes
+    ("<bytes> Bytes -> Algo <a> proto <p> time <t>").  Unknown lines are ignored; an empty log gives empty fields."""
+    import re
+    from collections import Counter
+    out = {"version": None, "nranks": None, "channels": None, "transports": {}, "algo_proto": {}, "lines": 0}
+    if not text:
+        return out
+    out["lines"] = text.count("\n") + 1
+    m = re.search(r"(?:RCCL|NCCL) version[ :]+([0-9][0-9A-Za-z.+_-]*)", text)
+    if m:
+        out["version"] = m.group(1)
+    m = re.findall(r"nranks\s+(\d+)", text)
+    if m:
+        out["nranks"] = int(m[-1])
+    ch = [int(b) for _, b in re.findall(r"Channel\s+(\d+)/(\d+)\s*:", text)]
+    if ch:
+        out["channels"] = max(ch)
+    out["transports"] = dict(Counter(re.findall(r"\bvia\s+([A-Za-z0-9/_ -]+?)(?:\s*$|\s+comm|\s*\n)", text, flags=re.M)))
+    ap = {}
+    for nbytes, algo, proto in re.findall(r"(\d+)\s+Bytes\s*->\s*Algo\s+(\S+)\s+proto\s+(\S+)", text):
+        key = f"{_ALGO.get(algo, algo)}/{_PROTO.get(proto, proto)}"
+        d = ap.setdefault(key, {"collectives": 0, "bytes": 0})
+        d["collectives"] += 1
+        d["bytes"] += int(nbytes)
+    out["algo_proto"] = ap
+    return out
+
+
+def bucket_timings(reducer: "GradAllReducer", reps: int = 5) -> list:
+    """Every gradient bucket of the train step all-reduced ALONE (nothing to overlap with), ``reps`` times: per bucket its
+    bytes, mean ms and bus GB/s (2 (N - 1) / N x bytes / time, the ring-equivalent convention).  Run outside the timed region."""
+    out = []
+    world = max(reducer.world, 1)
+    for name, (a, b) in ([(f"layer{l}", ab) for l, ab in enumerate(reducer.layers)] +
+                         [("embedding", reducer.tail[0]), ("norms", reducer.tail[1])]):
+        if b <= a:
+            continue
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            reducer._reduce(a, b)
+            for w in reducer.pending:
+                w.wait()                         # (the current stream waits for the collective: the end event sees it)
+            for aa, bb, host in reducer.staged:
+                reducer.flat[aa:bb].copy_(host)
+            reducer.pending, reducer.staged = [], []
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / reps
+        nbytes = (b - a) * 4
+        out.append({"bucket": name, "bytes": nbytes, "ms": ms,
+                    "bus_GBps": 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None})
+    return out

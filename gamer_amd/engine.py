@@ -341,7 +341,8 @@ class Engine:
     N_SUMSQ_PARTIAL = 1024
 
     def __init__(self, cfg: Qwen3MultiConfig, device="cuda", temperature: float = 1.0, variant: str = "multi",
-                 dtype: str = "f32", matmul: Optional[str] = None, share_buffers_of: Optional["Engine"] = None):
+                 dtype: str = "f32", matmul: Optional[str] = None, share_buffers_of: Optional["Engine"] = None,
+                 deterministic: Optional[bool] = None):
         """``variant``: "multi" = Qwen3Multi (train_SMB_decoder.py:362-364), "session" = Qwen3SessionMulti
         (train_SMB_decoder.py:365-367): the same parameters and layers with session-wise attention masks and
         RoPE positions taken from ``extended_session_ids``.
@@ -357,6 +358,10 @@ class Engine:
         operand tensor scaled by a power of two from its largest magnitude (gamer_absmax_f32) - the
         same error against fp64 at half the matrix instructions; the attention products take the same three-product form
         (``self.h2_attention = False`` keeps them in the six-product bf16 form).
+        ``deterministic`` (fp32 forms; None = GAMER_DETERMINISTIC=1): EVERY reduction of the step in a fixed order, so that two
+        runs from the same state give the same bits.  The weight gradients (two-pass chunk reduce) and the behaviour-table
+        gradients are ordered by default; what this flag adds is the embedding gradient as an ordered weight-gradient GEMM over
+        a one-hot matrix instead of a scatter with float atomics (+~1.3 ms per step at per-GPU batch 1024).
         ``share_buffers_of``: another engine of the same configuration whose flat parameter and gradient buffers this one
         uses instead of allocating its own - the nn.Module keeps one set of fp32 masters and runs them through the fp32 or the
         bf16 step depending on the caller's autocast state (gamer_amd/modeling.py)."""
@@ -370,6 +375,9 @@ class Engine:
         if dtype != "f32" and matmul != "f32":
             raise ValueError("matmul='split3'/'split6'/'split9' is a form of the fp32 path; dtype='bf16' has its own GEMM")
         self.matmul = matmul
+        self.deterministic = (os.environ.get("GAMER_DETERMINISTIC", "0") == "1") if deterministic is None else bool(deterministic)
+        if self.deterministic and dtype != "f32":
+            raise ValueError("deterministic=True is built for the fp32 forms (the bf16 weight-gradient kernel combines with atomics)")
         # q / k RMSNorm + RoPE in the q|k|v projection's epilogue (gamer_gemm_desc.qk_*): built, parity-tested and measured
         # at batch 1024 - the 12 projections got 6.8 ms slower per step (their tiles now also store q_rot / k_rot, and
         # on gfx950 epilogue work is matrix-pipe time), the removed kernel had cost 8.1 ms: 373.9-375.4 against 373.4-377 ms
@@ -777,9 +785,13 @@ class Engine:
     def zero_grad(self):
         ops.fill(self.flat_g, 0.0)
 
+    def backward(self, dloss: float = 1.0, layer_done=None, dloss_dev: Optional[torch.Tensor] = None):
+        with ops.deterministic(True if self.deterministic else ops.DETERMINISTIC_WGRAD):
+            return self._backward(dloss, layer_done, dloss_dev)
+
     @ops.scoped_f32_matmul(lambda self, *a: self.matmul, lambda self, *a: self._planes())
     @ops.scoped_amax(lambda self, *a: self._amax)
-    def backward(self, dloss: float = 1.0, layer_done=None, dloss_dev: Optional[torch.Tensor] = None):
+    def _backward(self, dloss: float = 1.0, layer_done=None, dloss_dev: Optional[torch.Tensor] = None):
         """Accumulates d(loss)*dloss into the flat gradient buffer (call zero_grad() first for a fresh
         window).  Needs a forward(..., labels=..., train=True) before it.  ``dloss_dev``: fp32 device scalar that
         multiplies ``dloss`` (the module path hands autograd's incoming gradient over without reading it on the host).  ``layer_done(l)`` is called as
@@ -894,7 +906,7 @@ class Engine:
                 dgrad(A["g"], I, W.gate, WT.gate if bf16 else None, din, ws.dhin, din, I, din, strideB=I * din, **grp)
                 dgrad(A["u"], I, W.up, WT.up if bf16 else None, din, ws.dhin, din, I, din, accumulate=True, strideB=I * din, **grp)
             if W.inject:
-                ops.rowtable_bwd(ws.dhin, din, H, r["beh_idx"], G.beh, ws.slot)
+                ops.rowtable_bwd(ws.dhin, din, H, r["beh_idx"], G.beh, ws.slot, partial=NP)
             norm_bwd(xlast, W.ln3, ws.dhin, din, G.ln3, True, ws.slot,
                      branch=None if W.cross else (self._seed(l, 1), None))
             # ---- cross attention ----
@@ -941,7 +953,16 @@ class Engine:
             norm_bwd(xs[0], W.ln1, t3, H, G.ln1, True, branch=(self._seed(l - 1, 5), ws.slot) if l > 0 else None)
             if layer_done is not None:
                 layer_done(l)
-        ops.embedding_bwd(sv["ids"], ws.dx, cfg.pad_token_id, demb)
+        if self.deterministic and not bf16:
+            # the scatter-add of the embedding gradient as an ordered weight-gradient GEMM: one-hot(ids)^T dx, the one-hot matrix
+            # in the logits buffer (d(logits) is dead by now); pad and out-of-range ids get a zero row (padding_idx, model.py:263)
+            oh, ids = ws.logits, sv["ids"].view(-1)
+            ok = (ids != cfg.pad_token_id) & (ids >= 0) & (ids < V)
+            oh.zero_()
+            oh.scatter_(1, ids.clamp(0, V - 1).unsqueeze(1), ok.to(oh.dtype).unsqueeze(1))
+            ops.linear_wgrad(oh, ws.ldl, ws.dx, H, demb, H, T, V, H)
+        else:
+            ops.embedding_bwd(sv["ids"], ws.dx, cfg.pad_token_id, demb)
         self.dropout_step = saved_step
 
     # ------------------------------------------------------------------------------------------

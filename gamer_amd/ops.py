@@ -123,10 +123,12 @@ def rowtable_fwd(table, idx, y, ldy, col0, dst_rows=None):
     call("gamer_rowtable_fwd" + _sfx(y), ptr(table), ptr(idx), ptr(dst_rows), T, E, ptr(y), ldy, col0, stream_ptr())
 
 
-def rowtable_bwd(dy, lddy, col0, idx, dtable, dy_rows=None):
+def rowtable_bwd(dy, lddy, col0, idx, dtable, dy_rows=None, partial=None):
+    """partial: fp32 scratch (>= rows * E floats): the ordered form (no float atomics, same bits on every run)."""
     T = idx.numel()
     rows, E = dtable.shape
-    call("gamer_rowtable_bwd" + _sfx(dy), ptr(dy), lddy, col0, ptr(idx), ptr(dy_rows), T, E, rows, ptr(dtable), stream_ptr())
+    call("gamer_rowtable_bwd" + _sfx(dy), ptr(dy), lddy, col0, ptr(idx), ptr(dy_rows), T, E, rows, ptr(dtable), ptr(partial),
+         partial.numel() if partial is not None else 0, stream_ptr())
 
 
 # fp32 matmul form in effect: 0 = v_mfma_f32_32x32x2_f32, 6 / 9 = gamer_gemm_f32_split (exact three-way bf16 cut of both
@@ -381,6 +383,39 @@ def split3_planes(x, planes):
     call("gamer_split3_planes", ptr(x), ptr(planes), x.numel(), planes.stride(0), stream_ptr())
 
 
+# Ordered weight gradients (fp32 forms): the split-K chunks of gamer_gemm_f32 / _split store their partial tiles in a workspace
+# and a second kernel adds them in chunk order (gamer_gemm_desc.wgrad_ws) instead of combining them with fp32 atomics, whose
+# order varies from run to run.  ON by default since round 4: measured equal or faster than the atomics (247.4 vs 247.0 ms per
+# step at per-GPU batch 1024, 33.10 vs 33.20 at 128 - 25 GB of float atomics per step become plain stores).
+# GAMER_WGRAD_TWO_PASS=0 or `with ops.deterministic(False):` give the atomics form.
+DETERMINISTIC_WGRAD = os.environ.get("GAMER_WGRAD_TWO_PASS", "1") != "0"
+_WGRAD_WS = {}
+
+
+class deterministic:
+    def __init__(self, on: bool = True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global DETERMINISTIC_WGRAD
+        self.prev, DETERMINISTIC_WGRAD = DETERMINISTIC_WGRAD, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global DETERMINISTIC_WGRAD
+        DETERMINISTIC_WGRAD = self.prev
+        return False
+
+
+def _wgrad_workspace(device, floats: int) -> torch.Tensor:
+    """grow-only scratch per device for the chunk partial tiles of the deterministic weight gradient"""
+    t = _WGRAD_WS.get(device)
+    if t is None or t.numel() < floats:
+        _WGRAD_WS[device] = None
+        t = _WGRAD_WS[device] = torch.empty(int(floats), dtype=torch.float32, device=device)
+    return t
+
+
 class split3_guard:
     """Context manager: the row-range guard of the split3 GEMMs on / off for the block (gamer_split3_guard in include/gamer_hip.h;
     on by default).  Tests turn it off to show what it guards against."""
@@ -449,6 +484,11 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
         view, col0 = c_amax
         slot_c = _AMAX_REUSE.preset(view, (1, 0, M, N - col0, ldc))
         d.amax_c, d.amax_c_col0 = slot_c, int(col0)
+    if group_mode == 1 and DETERMINISTIC_WGRAD:
+        n_chunks = (K + kchunk - 1) // kchunk + (groups if group_offsets is not None else 0)
+        need = n_chunks * ((M + 127) // 128) * ((N + 127) // 128) * 16384
+        ws = _wgrad_workspace(A.device, need)
+        d.wgrad_ws, d.wgrad_ws_floats = ws.data_ptr(), ws.numel()
     if F32_MATMUL_TERMS == 3:
         # operand extents: A(m, k) at A + m a_rs + k a_ks, B(n, k) at B + n b_rs + k b_ks (one of each stride pair is 1)
         ga = (M, K, a_rs) if a_ks == 1 else (K, M, a_ks)

@@ -138,17 +138,20 @@ int gamer_colsum_reduce(const float* partial, int rows, int cols, int accumulate
                         void* stream);
 
 /* Behaviour-embedding concat for the injected FFN layers (FFN.py:60-62):
- * y[dst(t)][col0 .. col0+E) = table[idx[t]];   bwd: dtable[idx[t]] += dy[dst(t)][col0..]        */
+ * y[dst(t)][col0 .. col0+E) = table[idx[t]];   bwd: dtable[idx[t]] += dy[dst(t)][col0..]
+ * bwd, (ABI 7) `partial` (scratch of partial_numel floats, at least n_rows_table * E; NULL = the round-1 form with float atomics):
+ * every workgroup writes its table to a row of it and a second kernel folds the rows in a fixed order - the same bits on
+ * every run.                                                                                                    */
 int gamer_rowtable_fwd(const float* table, const int32_t* idx, const int32_t* dst_rows, int T, int E,
                        float* y, int ldy, int col0, void* stream);
 int gamer_rowtable_bwd(const float* dy, int lddy, int col0, const int32_t* idx,
                        const int32_t* dy_rows, int T, int E, int n_rows_table, float* dtable,
-                       void* stream);
+                       float* partial, int64_t partial_numel, void* stream);
 int gamer_rowtable_fwd_bf16(const float* table, const int32_t* idx, const int32_t* dst_rows, int T, int E,
                             gamer_bf16* y, int ldy, int col0, void* stream);
 int gamer_rowtable_bwd_bf16(const gamer_bf16* dy, int lddy, int col0, const int32_t* idx,
                             const int32_t* dy_rows, int T, int E, int n_rows_table, float* dtable,
-                            void* stream);
+                            float* partial, int64_t partial_numel, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * fp32 MFMA GEMM  (v_mfma_f32_32x32x2_f32; exact fp32, replaces every nn.Linear on the path:
@@ -223,6 +226,12 @@ typedef struct {
      * of the q|k|v projection, dO out of the o_proj input gradient - without a pass of gamer_absmax_f32 over it.  NULL = off. */
     uint32_t* amax_c;
     int amax_c_col0;
+    /* (ABI 7) optional, group_mode 1 (weight gradient): a workspace of at least (number of k chunks, with one extra per group when
+     * group_offsets is given) x ceil(M / 128) x ceil(N / 128) x 16384 floats.  The chunks then store their partial tiles there
+     * with plain stores and a second kernel adds them to C in chunk order: a DETERMINISTIC weight gradient (same bits on every
+     * run; the default combines the chunks with fp32 atomics, whose order varies).  NULL = atomics. */
+    float* wgrad_ws;
+    int64_t wgrad_ws_floats;
 } gamer_gemm_desc;
 
 int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);

@@ -43,6 +43,7 @@ def main():
             return e
 
         eng = engine()
+        sd0 = {k: v.detach().cpu().clone() for k, v in eng.params.items()}      # (for the oracle: the weights of window 1)
         red = GradAllReducer(eng.flat_g, eng.layout, cfg.num_hidden_layers)
         assert red.world == world and red.stage          # gloo + device gradients: the host-staged bucket path
         ref = engine() if rank == 0 else None
@@ -69,6 +70,24 @@ def main():
                 pr = ref.flat_p.cpu()
                 res["param_rel"].append(float((p.double() - pr.double()).abs().max() / pr.double().abs().max()))
                 res["ref_loss"] += [float(x) for x in ref_losses]
+                if step == 0:
+                    # ... and tied DIRECTLY to the CPU oracle: the gradient two HIP ranks reduced over the process group against
+                    # oracle.loss_and_grads on the whole (unsharded) window with the window's label count as the normaliser
+                    from oracle import qwen3multi_oracle as orc
+                    ocfg = orc.OracleConfig.from_dict(cfg.to_dict())
+                    n_items = float(sum(int((b["labels"][:, 1:] != -100).sum()) for b in window))
+                    tot = None
+                    for b in window:
+                        _, grads, _ = orc.loss_and_grads(sd0, ocfg, b, temperature=0.7, num_items_in_batch=n_items,
+                                                         amp=(dtype == "bf16"))
+                        tot = grads if tot is None else {k: tot[k] + g for k, g in grads.items()}
+                    views = eng.layout.views(eng.flat_g)
+                    worst, worst_norm = 0.0, 0.0
+                    for k, g in tot.items():
+                        got = views[k].cpu().double()
+                        worst = max(worst, float((got - g.double()).abs().max() / g.double().abs().max().clamp_min(1e-30)))
+                        worst_norm = max(worst_norm, abs(float(got.norm()) - float(g.double().norm())) / max(float(g.double().norm()), 1e-30))
+                    res["grad_rel_oracle"], res["grad_norm_rel_oracle"] = worst, worst_norm
         # the sum over ranks of the per-rank losses (each = its CE sum / GLOBAL count) is the single-rank loss
         ls = torch.tensor(res["loss"], dtype=torch.float64)
         dist.all_reduce(ls)

@@ -58,6 +58,12 @@ def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path, accum, dtype):
     assert r0["grad_rel"][1] < tol2 and r0["param_rel"][1] < tol2, r0
     for a, b in zip(r0["grad_norm"], r0["grad_norm_ref"]):
         assert abs(a - b) < 10 * tol2 * b, r0
+    # the reduced two-rank HIP gradient against the CPU oracle on the unsharded window (north-star bar 1e-3 in fp32, measured
+    # ~1e-5; bf16: the per-tensor norm bar of tests/test_bf16_gpu.py)
+    if dtype == "f32":
+        assert r0["grad_rel_oracle"] < 1e-3, r0["grad_rel_oracle"]
+    else:
+        assert r0["grad_norm_rel_oracle"] < 3e-2, r0["grad_norm_rel_oracle"]
     for r in res:
         assert max(r["param_max_diff_vs_rank0"]) == 0.0, r          # replicas stay bit-identical
     for i, (got, want) in enumerate(zip(r0["loss_sum_over_ranks"], r0["ref_loss"])):

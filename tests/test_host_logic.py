@@ -209,3 +209,27 @@ def test_product_package_never_touches_the_oracle():
             "assert not bad, bad\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_rccl_log_parser():
+    """bench.py --gpus N puts what RCCL decided into its JSON line (gamer_amd.dp.parse_rccl_log): checked here on the line
+    shapes NCCL / RCCL print with NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,GRAPH,TUNING."""
+    from gamer_amd.dp import parse_rccl_log
+    log = """\\
+host:101:101 [0] NCCL INFO RCCL version 2.22.3+hip7.2 HEAD:abc
+host:101:140 [0] NCCL INFO Channel 00/16 :    0   1   2   3   4   5   6   7
+host:101:140 [0] NCCL INFO Channel 15/16 :    0   7   6   5   4   3   2   1
+host:101:140 [0] NCCL INFO Channel 00 : 0[0] -> 1[1] via P2P/IPC
+host:101:140 [0] NCCL INFO Channel 01 : 0[0] -> 1[1] via P2P/IPC
+host:101:140 [0] NCCL INFO Channel 00 : 0[0] -> 7[7] via P2P/direct pointer
+host:101:140 [0] NCCL INFO comm 0x55 rank 0 nranks 8 cudaDev 0 nvmlDev 0 busId 5000 commId 0x1 - Init COMPLETE
+host:101:101 [0] NCCL INFO 12582912 Bytes -> Algo 1 proto 2 time 210.5
+host:101:101 [0] NCCL INFO 12582912 Bytes -> Algo 1 proto 2 time 210.5
+host:101:101 [0] NCCL INFO 4 Bytes -> Algo 0 proto 0 time 9.1
+"""
+    r = parse_rccl_log(log)
+    assert r["version"].startswith("2.22.3") and r["nranks"] == 8 and r["channels"] == 16
+    assert r["transports"] == {"P2P/IPC": 2, "P2P/direct pointer": 1}
+    assert r["algo_proto"]["Ring/Simple"] == {"collectives": 2, "bytes": 2 * 12582912}
+    assert r["algo_proto"]["Tree/LL"] == {"collectives": 1, "bytes": 4}
+    assert parse_rccl_log("")["algo_proto"] == {} and parse_rccl_log("garbage\\nlines")["nranks"] is None

@@ -178,6 +178,17 @@ def test_rowtable_fwd_bwd():
     ref = torch.zeros(rows, E, dtype=torch.float64)
     ref.index_put_((idx.long(),), dy[dst.long(), col0:col0 + E].double(), accumulate=True)
     assert _rel(dt, ref) < 1e-5
+    # the ordered form (a `partial` scratch: no float atomics): += semantics, the same bits on every launch, many and few workgroups
+    for T2, scratch in ((T, 64 * 1024), (40000, 2048 * 256), (40000, 3 * rows * E)):
+        idx2, dy2 = torch.randint(0, rows, (T2,)).int(), torch.randn(T2, ld)
+        ref2 = torch.ones(rows, E, dtype=torch.float64)
+        ref2.index_put_((idx2.long(),), dy2[:, col0:col0 + E].double(), accumulate=True)
+        outs = []
+        for rep in range(3):
+            dt2 = torch.ones(rows, E, device=DEV)
+            ops.rowtable_bwd(dev(dy2), ld, col0, dev(idx2), dt2, partial=torch.empty(scratch, device=DEV))
+            outs.append(dt2)
+        assert _rel(outs[0], ref2) < 1e-5 and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 # ----------------------------------------------------------------------------------------------
@@ -247,6 +258,40 @@ def test_gemm_wgrad_splitk(rows, N, K, gemm_mode):
     e = _rel(dW, ref)
     _record(f"gemm_wgrad_{rows}x{N}x{K}_{gemm_mode}", e)
     assert e < 5e-6
+
+
+def test_gemm_wgrad_deterministic_form(gemm_mode):
+    """gamer_gemm_desc.wgrad_ws: the chunk partial tiles go to a workspace and are added in chunk order - the fp64 product at
+    the atomics form's tolerance, accumulate semantics (C += ...), ragged tiles, expert segments with an empty expert, and
+    the SAME BITS from repeated launches (which the atomics form does not promise)."""
+    torch.manual_seed(12)
+    with ops.deterministic(True):
+        for rows, N, K in ((5000, 384, 256), (777, 1041, 256), (4100, 512, 320)):
+            dy, x = torch.randn(rows, N + (-N) % 4), torch.randn(rows, K)
+            dy[:, N:] = 0
+            outs = []
+            for rep in range(3):
+                dW = torch.ones(N, K, device=DEV)
+                ops.linear_wgrad(dev(dy), dy.shape[1], dev(x), K, dW, K, rows, N, K, kchunk=256 if rows < 1000 else 512)
+                outs.append(dW)
+            assert _rel(outs[0], 1.0 + dy[:, :N].double().T @ x.double()) < 5e-6
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        E, Din, I = 6, 320, 512
+        sizes = [0, 700, 129, 1, 300, 128]
+        T = sum(sizes)
+        offs = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32)
+        x, dy = torch.randn(T, Din), torch.randn(T, I)
+        outs = []
+        for rep in range(2):
+            dW = torch.zeros(E, I, Din, device=DEV)
+            ops.linear_wgrad(dev(dy), I, dev(x), Din, dW, Din, T, I, Din, groups=E, group_offsets=dev(offs), strideC=I * Din,
+                             kchunk=256)
+            outs.append(dW)
+        refw = torch.zeros(E, I, Din, dtype=torch.float64)
+        for e in range(E):
+            a, b = int(offs[e]), int(offs[e + 1])
+            refw[e] = dy[a:b].double().T @ x[a:b].double()
+        assert _rel(outs[0], refw) < 5e-6 and torch.equal(outs[0], outs[1]) and float(outs[0][0].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("T", [1000, 4224])

@@ -81,6 +81,7 @@ def test_train_harness_on_a_dataset_in_the_reference_format(tmp_path, backbone):
 
 def test_bench_rccl_path_single_rank():
     env = dict(os.environ, GAMER_BENCH_FORCE_DIST="1")
+    env.pop("NCCL_DEBUG_FILE", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--items", "21", "--steps", "2",
                         "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -89,3 +90,9 @@ def test_bench_rccl_path_single_rank():
     assert r.stdout.strip().splitlines()[-1] == lines[0], "the JSON line must be the last line on stdout"
     line = json.loads(lines[0])
     assert line["unit"] == "sequences/s" and line["value"] > 0 and "roofline" in line
+    # the multi-GPU diagnostics ride on the same path: per-bucket all-reduce times, exposed communication, RCCL's log summary
+    comm = line["communication"]
+    assert len(comm["per_bucket"]) == 8 + 2 and all(b["ms"] > 0 and b["bytes"] > 0 for b in comm["per_bucket"])
+    assert comm["step_ms_with_reducer"] > 0 and comm["step_ms_without_collectives"] > 0 and comm["exposed_communication_ms"] >= 0
+    assert sum(b["bytes"] for b in comm["per_bucket"]) == 4 * 24535040 or line["config"]["seq_len"] != 505
+    assert "rccl" in line and line["rccl"].get("lines", 0) > 0, line.get("rccl")
