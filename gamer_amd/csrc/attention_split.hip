@@ -27,6 +27,16 @@ namespace gamer {
 #define SPA_ABLATE 0      // timing-only builds (tools/ablate_attn_split.sh): 1 no S = K Q^T MFMAs, 2 no second-product MFMAs, 4 no cut of P / dS,
 #endif                    // 8 no cut arithmetic anywhere (pieces = the raw word), 16 no LDS tile stores, 32 (H2) no staging of K / V / Q / dO tiles at all,
                           // forward only: 64 no exp2, 128 no barrier in the key loop, 256 no softmax / dropout at all, 512 no global loads in the key loop
+#ifndef SPA_STAMP
+#define SPA_STAMP 0       // diagnostic builds (tools/stamp_attn_fwd.py): every wave of the forward kernel accumulates shader-clock cycles per
+#endif                    // phase of its key loop into g_attn_stamp[(4 * blockIdx.x + wave) * 8 + phase] (set by gamer_debug_attn_stamp)
+#if SPA_STAMP
+__device__ unsigned long long* g_attn_stamp = nullptr;
+#define SPA_MARK(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                         ph_[i] += (unsigned)(t_ - tprev_); tprev_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SPA_MARK(i) do { } while (0)
+#endif
 constexpr int SIMG = 32 * 64;              // bf16 elements of one piece image of a 32-row tile
 
 // element offset of (row, column) in a [rows][64] bf16 image with swizzled 16-byte chunks (attention_bf16.hip: lds_off)
@@ -271,6 +281,10 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
     __shared__ __attribute__((aligned(16))) KeyMeta kms[3];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#if SPA_STAMP
+    unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
     const int hg = w / NSUB, sub = w % NSUB;
     const int b = pair / nkv, kvh = pair % nkv, q0 = qtile * R;
     const int head = kvh * G + hg;
@@ -378,6 +392,7 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
     // (rows past the end of the sequence, or empty rows only) reaches the K(2) store of iteration 0 at once
     __syncthreads();
 
+    SPA_MARK(0);                                         // 0: the tile's prologue (q, row data, first K / V tiles, first scores)
     for (int jt = 0; jt < n_iter; ++jt) {
         const int j0 = jt * 32;
         const bool have_next = jt + 1 < n_iter;
@@ -388,6 +403,7 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
         }
         if (have_next && !(SPA_ABLATE & 512)) load_tile32(vbase, ldv, j0 + 32, S, tid, rv);
 
+        SPA_MARK(1);                                       // 1: issue of the K / V / metadata loads
         const bool beyond = j0 > wave_q_hi;                // every key of the tile is in every row's future
         const bool beyond_next = (j0 + 32) > wave_q_hi;
         if (!(beyond && !wave_has_empty)) {
@@ -494,6 +510,7 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
                 else softmax_tile.template operator()<true, false>();
             }
         }
+        SPA_MARK(2);                                       // 2: softmax + dropout + cut of P + second products (issue)
         if (have_next && !beyond_next) {
             // scores of the next tile (minus the reference), taken BEFORE the barrier: after it other waves may
             // already overwrite this K slot with K(jt+3)
@@ -506,12 +523,15 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
                 for (int i = 0; i < 16; ++i) st_cur[i] *= sc.inv_qk;
             }
         }
+        SPA_MARK(3);                                       // 3: scores of the next tile (K fragment reads + products + scale)
         if (have_next2) {
             store_tile32_t<H2>(Ks[jt & 1], tid, rk, S - (j0 + 64), sc.k);   // K(jt) is dead: its scores were taken last iteration
             key_meta_store(kms[(jt + 2) % 3], w, lane, rmeta);
         }
         if (have_next) store_tile32_t<H2>(Vs[(jt + 1) & 1], tid, rv, S - (j0 + 32), sc.v);
+        SPA_MARK(4);                                       // 4: wait for the loads, cut, LDS stores
         if (!(SPA_ABLATE & 128)) __syncthreads();
+        SPA_MARK(5);                                       // 5: barrier
     }
 
     float omax = 0.f;
@@ -542,6 +562,15 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
         for (int o2 = 32; o2 > 0; o2 >>= 1) mw = max(mw, (uint32_t)__shfl_xor((int)mw, o2, 64));
         if (lane == 0 && mw) atomicMax(amax_lds, mw);
     }
+#if SPA_STAMP
+    SPA_MARK(6);                                           // 6: the tile's epilogue (normalise, store o and lse)
+    ph_[7] = (unsigned long long)n_iter;                   // 7: key-loop iterations of this tile
+    if (g_attn_stamp && lane == 0) {
+        unsigned long long* rec = g_attn_stamp + ((size_t)blockIdx.x * 4 + w) * 8;
+#pragma unroll
+        for (int i_ = 0; i_ < 8; ++i_) rec[i_] += ph_[i_];
+    }
+#endif
 }
 
 // the maxima of q, k, v (and dO in the backward) of the H2 form: device words (gamer_absmax_f32 / gamer_amax_sink)
@@ -1741,6 +1770,13 @@ extern "C" int gamer_attn_fwd_split(const float* q, int ldq, const float* k, int
     t_attn_amax = AttnAmax{nullptr, nullptr, nullptr, nullptr};
     return rc;
 }
+
+#if SPA_STAMP
+extern "C" int gamer_debug_attn_stamp(void* p) {
+    unsigned long long* v = (unsigned long long*)p;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(gamer::g_attn_stamp), &v, sizeof(v));
+}
+#endif
 
 extern "C" int gamer_attn_split_amax(const uint32_t* q, const uint32_t* k, const uint32_t* v, const uint32_t* d_o) {
     g_attn_amax_armed = AttnAmax{q, k, v, d_o};
