@@ -485,19 +485,16 @@ attn_fwd_s_tile(const float* __restrict__ q, int ldq, const float* __restrict__ 
                 pv_tile.template operator()<false>();
             };
             if (wave_all_empty) {
-                // every row of the wave is an empty row: P = keep / span, no scores, no softmax state
-                if (DROP) {
-                    int kwv[16];
-                    read_key_quads(reinterpret_cast<const int32_t*>(km.kw), h, kwv);
+                // every row of the wave is an empty row: P = keep / span, no scores, no softmax state.  (One pass over the 16
+                // values: with a second select pass over st_cur for the span the compiler kept sixteen 16-register copies of
+                // it in scratch in the self-attention variants.)
+                int kwv[16];
+                if (DROP) read_key_quads(reinterpret_cast<const int32_t*>(km.kw), h, kwv);
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) st_cur[reg] = rng.keep(aw, (uint32_t)kwv[reg]) ? 1.f : 0.f;
-                } else {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) st_cur[reg] = 1.f;
-                }
-                if (!full_span) {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) st_cur[reg] = (j0 + rowmap(reg, h) < my_span) ? st_cur[reg] : 0.f;
+                for (int reg = 0; reg < 16; ++reg) {
+                    bool on = DROP ? rng.keep(aw, (uint32_t)kwv[reg]) : true;
+                    on = on && (full_span || (j0 + rowmap(reg, h) < my_span));
+                    st_cur[reg] = on ? 1.f : 0.f;
                 }
                 pv_tile.template operator()<true>();
             } else if (wave_has_empty) {

@@ -171,18 +171,25 @@ rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, c
         wv[i] = (c < H4) ? w[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         dwacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int t = wave; t < T; t += nwaves) {
-        float4 v[RMS_MAXC], g[RMS_MAXC];
-        float ss = 0.f;
+    // Two rows per iteration, all their loads (x, dy and - when accumulating - dx) issued before the first reduction: with one
+    // row per wave in flight and the dx read behind both wave reductions the kernel ran at 3.7 TB/s (2 waves per SIMD: the grid
+    // is the number of dw partials).  The rows of a wave are still finished in ascending order: dw partials bit-identical.
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_row = [&](const int t, float4 (&v)[RMS_MAXC], float4 (&g)[RMS_MAXC], float4 (&pv)[RMS_MAXC]) {
         const int64_t r = dy_rows ? dy_rows[t] : t;
         const TG* dyrow = dy + r * lddy;
 #pragma unroll
         for (int i = 0; i < RMS_MAXC; ++i) {
             const int c = lane + 64 * i;
-            v[i] = (c < H4) ? x[(int64_t)t * H4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-            g[i] = (c < H4) ? ld4(dyrow + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+            v[i] = (c < H4) ? x[(int64_t)t * H4 + c] : z4;
+            g[i] = (c < H4) ? ld4(dyrow + 4 * c) : z4;
+            pv[i] = (accumulate_dx && c < H4) ? dx[(int64_t)t * H4 + c] : z4;
         }
+    };
+    auto finish_row = [&](const int t, float4 (&v)[RMS_MAXC], float4 (&g)[RMS_MAXC], const float4 (&pv)[RMS_MAXC]) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < RMS_MAXC; ++i) ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
         ss = wave_sum(ss);
         const float rstd = rsqrtf(ss * inv_h + eps);
         float dot = 0.f;
@@ -205,10 +212,7 @@ rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, c
                 o.y = rstd * (g[i].y - v[i].y * dot);
                 o.z = rstd * (g[i].z - v[i].z * dot);
                 o.w = rstd * (g[i].w - v[i].w * dot);
-                if (accumulate_dx) {
-                    float4 p = dx[(int64_t)t * H4 + c];
-                    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
-                }
+                if (accumulate_dx) { o.x += pv[i].x; o.y += pv[i].y; o.z += pv[i].z; o.w += pv[i].w; }
                 dx[(int64_t)t * H4 + c] = o;
                 if (mask_out) {
                     float m[4];
@@ -220,6 +224,15 @@ rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, c
                 }
             }
         }
+    };
+    for (int t = wave; t < T; t += 2 * nwaves) {
+        float4 v0[RMS_MAXC], g0[RMS_MAXC], p0[RMS_MAXC], v1[RMS_MAXC], g1[RMS_MAXC], p1[RMS_MAXC];
+        const int tb = t + nwaves;
+        const bool second = tb < T;                       // (uniform over the wave)
+        load_row(t, v0, g0, p0);
+        if (second) load_row(tb, v1, g1, p1);
+        finish_row(t, v0, g0, p0);
+        if (second) finish_row(tb, v1, g1, p1);
     }
 #pragma unroll
     for (int i = 0; i < RMS_MAXC; ++i) red[wib][lane + 64 * i] = dwacc[i];
@@ -440,6 +453,87 @@ qknorm_rope_fwd_kernel(TA* __restrict__ qkv, int T, int S, int nq, int nkv,
             float4 x = ld4(dst);
             x.x += b4.x; x.y += b4.y; x.z += b4.z; x.w += b4.w;
             if (live) st4(dst, x);
+        }
+    }
+    amax_block_commit(amq, amax_q, amax_lds[0]);
+    amax_block_commit(amk, amax_k, amax_lds[1]);
+}
+
+// fp32, token-major: one 16-lane group per TOKEN, walking its q and k heads three at a time (three 16-byte loads in flight
+// per lane, the token's cos / sin rows and behaviour index loaded once instead of once per head, no 64-bit division per row).
+// Same arithmetic per element as the kernel above (bit-identical outputs).  The row-major form above reached 3.5 TB/s of
+// 5.6 achievable: one dependent load -> reduce -> store chain per lane and per iteration, behind ~100 integer instructions.
+__global__ void __launch_bounds__(EW_THREADS)
+qknorm_rope_fwd_tok_kernel(float* __restrict__ qkv, int T, int S, int nq, int nkv,
+                           const float* __restrict__ wq, const float* __restrict__ wk, float eps,
+                           const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                           const float* __restrict__ bias_q, const float* __restrict__ bias_k,
+                           const float* __restrict__ bias_v, const int32_t* __restrict__ act_idx,
+                           float* __restrict__ q_rot, float* __restrict__ k_rot, const int32_t* __restrict__ pos_ids,
+                           uint32_t* __restrict__ amax_q, uint32_t* __restrict__ amax_k) {
+    __shared__ uint32_t amax_lds[2][4];
+    uint32_t amq = 0, amk = 0;
+    const int lane = threadIdx.x & 63;
+    const int g = lane & 15, sub = lane >> 4;
+    const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * EW_THREADS) >> 6;
+    const bool cross = bias_q != nullptr;
+    const int nqk = nq + nkv;
+    const int ldqkv = (nq + 2 * nkv) * 64;
+    const float4 wq4 = reinterpret_cast<const float4*>(wq)[g], wk4 = reinterpret_cast<const float4*>(wk)[g];
+    const float sgn = g < 8 ? -1.f : 1.f;
+    for (int64_t t0 = wave * 4; t0 < T; t0 += nwaves * 4) {
+        const int64_t tt = t0 + sub;
+        const bool live = tt < T;
+        const int t = (int)(live ? tt : T - 1);
+        const int a = cross ? act_idx[t] : 0;
+        const int pos = pos_ids ? pos_ids[t] : t % S;
+        const float4 c4 = reinterpret_cast<const float4*>(cos_t + pos * 64)[g];
+        const float4 s4 = reinterpret_cast<const float4*>(sin_t + pos * 64)[g];
+        float* row = qkv + (int64_t)t * ldqkv + 4 * g;
+        const float* bq = cross ? bias_q + (int64_t)a * nq * 64 + 4 * g : nullptr;
+        const float* bk = cross ? bias_k + (int64_t)a * nkv * 64 + 4 * g : nullptr;
+        for (int h0 = 0; h0 < nqk; h0 += 3) {
+            float4 x[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) x[u] = ld4(row + min(h0 + u, nqk - 1) * 64);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int hd = h0 + u;
+                if (hd >= nqk) break;                       // (uniform over the wave)
+                const bool isq = hd < nq;
+                float4 xx = x[u];
+                if (cross) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(isq ? bq + hd * 64 : bk + (hd - nq) * 64);
+                    xx.x += b4.x; xx.y += b4.y; xx.z += b4.z; xx.w += b4.w;
+                    if (live) st4(row + hd * 64, xx);       // keep the pre-norm (biased) value for the backward
+                }
+                const float ss = group16_sum(xx.x * xx.x + xx.y * xx.y + xx.z * xx.z + xx.w * xx.w);
+                const float rstd = rsqrtf(ss * (1.f / 64.f) + eps);
+                const float4 w4 = isq ? wq4 : wk4;
+                float4 xn;
+                xn.x = xx.x * rstd; xn.y = xx.y * rstd; xn.z = xx.z * rstd; xn.w = xx.w * rstd;
+                float4 y;
+                y.x = w4.x * xn.x; y.y = w4.y * xn.y; y.z = w4.z * xn.z; y.w = w4.w * xn.w;
+                float4 pr;
+                pr.x = __shfl_xor(y.x, 8, 64); pr.y = __shfl_xor(y.y, 8, 64); pr.z = __shfl_xor(y.z, 8, 64); pr.w = __shfl_xor(y.w, 8, 64);
+                float4 o;
+                o.x = y.x * c4.x + sgn * pr.x * s4.x; o.y = y.y * c4.y + sgn * pr.y * s4.y;
+                o.z = y.z * c4.z + sgn * pr.z * s4.z; o.w = y.w * c4.w + sgn * pr.w * s4.w;
+                if (live) {
+                    if (isq) { st4(q_rot + (int64_t)t * nq * 64 + hd * 64 + 4 * g, o); amq = amax_f4(amq, o); }
+                    else { st4(k_rot + (int64_t)t * nkv * 64 + (hd - nq) * 64 + 4 * g, o); amk = amax_f4(amk, o); }
+                }
+            }
+        }
+        if (cross) {                                        // v += bias_v
+            for (int hv = 0; hv < nkv; ++hv) {
+                float* dst = row + (nqk + hv) * 64;
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_v + (int64_t)a * nkv * 64 + hv * 64 + 4 * g);
+                float4 xv = ld4(dst);
+                xv.x += b4.x; xv.y += b4.y; xv.z += b4.z; xv.w += b4.w;
+                if (live) st4(dst, xv);
+            }
         }
     }
     amax_block_commit(amq, amax_q, amax_lds[0]);
@@ -1324,9 +1418,15 @@ static int qknorm_rope_fwd_impl(const char* name, TA* qkv, int T, int S, int nq,
                            k_rot, pos_ids);
     } else {
         const AmaxSink sink = take_amax_sink();
-        hipLaunchKernelGGL(qknorm_rope_fwd_kernel<TA>, dim3(grid_for_waves(((int64_t)T * NH + 3) / 4)), dim3(EW_THREADS), 0,
-                           ST(stream), qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot,
-                           k_rot, pos_ids, sink.out[0], sink.out[1]);
+        static const bool row_major = getenv("GAMER_QKNORM_ROW_MAJOR") != nullptr;       // (the round-1 form, kept for A/B runs)
+        if (row_major)
+            hipLaunchKernelGGL(qknorm_rope_fwd_kernel<TA>, dim3(grid_for_waves(((int64_t)T * NH + 3) / 4)), dim3(EW_THREADS), 0,
+                               ST(stream), qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot,
+                               k_rot, pos_ids, sink.out[0], sink.out[1]);
+        else
+            hipLaunchKernelGGL(qknorm_rope_fwd_tok_kernel, dim3(grid_for_waves(((int64_t)T + 3) / 4)), dim3(EW_THREADS), 0,
+                               ST(stream), qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot,
+                               k_rot, pos_ids, sink.out[0], sink.out[1]);
     }
     GAMER_CHECK_LAUNCH(name);
     return 0;
