@@ -171,25 +171,21 @@ rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, c
         wv[i] = (c < H4) ? w[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         dwacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // Two rows per iteration, all their loads (x, dy and - when accumulating - dx) issued before the first reduction: with one
-    // row per wave in flight and the dx read behind both wave reductions the kernel ran at 3.7 TB/s (2 waves per SIMD: the grid
-    // is the number of dw partials).  The rows of a wave are still finished in ascending order: dw partials bit-identical.
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_row = [&](const int t, float4 (&v)[RMS_MAXC], float4 (&g)[RMS_MAXC], float4 (&pv)[RMS_MAXC]) {
+    // (Measured and not kept: two rows per iteration with the dx read hoisted in front of the reductions - 0.58 -> 0.39 ms on a
+    // 512-workgroup grid, but the engine launches 2048 workgroups (8 waves per SIMD, 5.9 TB/s with the mask output) and there the
+    // extra registers cost occupancy: 0.45 -> 0.51 ms per call.)
+    for (int t = wave; t < T; t += nwaves) {
+        float4 v[RMS_MAXC], g[RMS_MAXC];
+        float ss = 0.f;
         const int64_t r = dy_rows ? dy_rows[t] : t;
         const TG* dyrow = dy + r * lddy;
 #pragma unroll
         for (int i = 0; i < RMS_MAXC; ++i) {
             const int c = lane + 64 * i;
-            v[i] = (c < H4) ? x[(int64_t)t * H4 + c] : z4;
-            g[i] = (c < H4) ? ld4(dyrow + 4 * c) : z4;
-            pv[i] = (accumulate_dx && c < H4) ? dx[(int64_t)t * H4 + c] : z4;
+            v[i] = (c < H4) ? x[(int64_t)t * H4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            g[i] = (c < H4) ? ld4(dyrow + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
         }
-    };
-    auto finish_row = [&](const int t, float4 (&v)[RMS_MAXC], float4 (&g)[RMS_MAXC], const float4 (&pv)[RMS_MAXC]) {
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < RMS_MAXC; ++i) ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
         ss = wave_sum(ss);
         const float rstd = rsqrtf(ss * inv_h + eps);
         float dot = 0.f;
@@ -212,7 +208,10 @@ rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, c
                 o.y = rstd * (g[i].y - v[i].y * dot);
                 o.z = rstd * (g[i].z - v[i].z * dot);
                 o.w = rstd * (g[i].w - v[i].w * dot);
-                if (accumulate_dx) { o.x += pv[i].x; o.y += pv[i].y; o.z += pv[i].z; o.w += pv[i].w; }
+                if (accumulate_dx) {
+                    float4 p = dx[(int64_t)t * H4 + c];
+                    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+                }
                 dx[(int64_t)t * H4 + c] = o;
                 if (mask_out) {
                     float m[4];
@@ -224,15 +223,6 @@ rmsnorm_bwd_kernel(const float4* __restrict__ x, const float4* __restrict__ w, c
                 }
             }
         }
-    };
-    for (int t = wave; t < T; t += 2 * nwaves) {
-        float4 v0[RMS_MAXC], g0[RMS_MAXC], p0[RMS_MAXC], v1[RMS_MAXC], g1[RMS_MAXC], p1[RMS_MAXC];
-        const int tb = t + nwaves;
-        const bool second = tb < T;                       // (uniform over the wave)
-        load_row(t, v0, g0, p0);
-        if (second) load_row(tb, v1, g1, p1);
-        finish_row(t, v0, g0, p0);
-        if (second) finish_row(tb, v1, g1, p1);
     }
 #pragma unroll
     for (int i = 0; i < RMS_MAXC; ++i) red[wib][lane + 64 * i] = dwacc[i];
@@ -755,6 +745,86 @@ qknorm_rope_fwd_b8_kernel(bf16_t* __restrict__ qkv, int T, int S, int nq, int nk
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] += b[e];
             if (live) st8(dst, x);
+        }
+    }
+}
+
+// token-major form of the kernel above (see qknorm_rope_fwd_tok_kernel): one 8-lane group per token, its heads three at a
+// time, cos / sin / behaviour index once per token; same arithmetic per element
+__global__ void __launch_bounds__(EW_THREADS)
+qknorm_rope_fwd_b8_tok_kernel(bf16_t* __restrict__ qkv, int T, int S, int nq, int nkv,
+                              const float* __restrict__ wq, const float* __restrict__ wk, float eps,
+                              const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                              const float* __restrict__ bias_q, const float* __restrict__ bias_k,
+                              const float* __restrict__ bias_v, const int32_t* __restrict__ act_idx,
+                              bf16_t* __restrict__ q_rot, bf16_t* __restrict__ k_rot, const int32_t* __restrict__ pos_ids) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane & 7, sub = lane >> 3;
+    const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * EW_THREADS) >> 6;
+    const bool cross = bias_q != nullptr;
+    const int nqk = nq + nkv;
+    const int ldqkv = (nq + 2 * nkv) * 64;
+    float wqv[8], wkv[8];
+    ld8(wq + 8 * g, wqv);
+    ld8(wk + 8 * g, wkv);
+    const float sgn = g < 4 ? -1.f : 1.f;
+    for (int64_t t0 = wave * 8; t0 < T; t0 += nwaves * 8) {
+        const int64_t tt = t0 + sub;
+        const bool live = tt < T;
+        const int t = (int)(live ? tt : T - 1);
+        const int a = cross ? act_idx[t] : 0;
+        const int pos = pos_ids ? pos_ids[t] : t % S;
+        float c[8], sn[8];
+        ld8(cos_t + pos * 64 + 8 * g, c);
+        ld8(sin_t + pos * 64 + 8 * g, sn);
+        bf16_t* row = qkv + (int64_t)t * ldqkv + 8 * g;
+        for (int h0 = 0; h0 < nqk; h0 += 3) {
+            float x[3][8];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) ld8(row + min(h0 + u, nqk - 1) * 64, x[u]);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int hd = h0 + u;
+                if (hd >= nqk) break;                       // (uniform over the wave)
+                const bool isq = hd < nq;
+                if (cross) {
+                    float b[8];
+                    ld8(isq ? bias_q + (int64_t)a * nq * 64 + hd * 64 + 8 * g : bias_k + (int64_t)a * nkv * 64 + (hd - nq) * 64 + 8 * g, b);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[u][e] += b[e];
+                }
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += x[u][e] * x[u][e];
+                ss = group8_sum(ss);
+                const float rstd = rsqrtf(ss * (1.f / 64.f) + eps);
+                float y[8], pr[8], o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float xn = x[u][e] * rstd;
+                    if (!cross) xn = round_as<bf16_t>(xn);    // Qwen3MoeRMSNorm on a bf16 tensor: .to(input_dtype) before * weight
+                    y[e] = (isq ? wqv[e] : wkv[e]) * xn;
+                    pr[e] = __shfl_xor(y[e], 4, 64);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = y[e] * c[e] + sgn * pr[e] * sn[e];
+                if (live) {
+                    if (isq) st8(q_rot + (int64_t)t * nq * 64 + hd * 64 + 8 * g, o);
+                    else st8(k_rot + (int64_t)t * nkv * 64 + (hd - nq) * 64 + 8 * g, o);
+                }
+            }
+        }
+        if (cross) {
+            for (int hv = 0; hv < nkv; ++hv) {
+                bf16_t* dst = row + (nqk + hv) * 64;
+                float xv[8], b[8];
+                ld8(dst, xv);
+                ld8(bias_v + (int64_t)a * nkv * 64 + hv * 64 + 8 * g, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] += b[e];
+                if (live) st8(dst, xv);
+            }
         }
     }
 }
@@ -1412,13 +1482,18 @@ static int qknorm_rope_fwd_impl(const char* name, TA* qkv, int T, int S, int nq,
     const bool cross = bias_q != nullptr;
     GAMER_CHECK_ARG(!cross || (bias_k && bias_v && act_idx), "%s: cross needs bias_k, bias_v, act_idx", name);
     const int NH = nq + nkv + (cross ? nkv : 0);
+    static const bool row_major = getenv("GAMER_QKNORM_ROW_MAJOR") != nullptr;           // (the round-1 forms, kept for A/B runs)
     if constexpr (sizeof(TA) == 2) {
-        hipLaunchKernelGGL(qknorm_rope_fwd_b8_kernel, dim3(grid_for_waves(((int64_t)T * NH + 7) / 8)), dim3(EW_THREADS), 0,
-                           ST(stream), qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot,
-                           k_rot, pos_ids);
+        if (row_major)
+            hipLaunchKernelGGL(qknorm_rope_fwd_b8_kernel, dim3(grid_for_waves(((int64_t)T * NH + 7) / 8)), dim3(EW_THREADS), 0,
+                               ST(stream), qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot,
+                               k_rot, pos_ids);
+        else
+            hipLaunchKernelGGL(qknorm_rope_fwd_b8_tok_kernel, dim3(grid_for_waves(((int64_t)T + 7) / 8)), dim3(EW_THREADS), 0,
+                               ST(stream), qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot,
+                               k_rot, pos_ids);
     } else {
         const AmaxSink sink = take_amax_sink();
-        static const bool row_major = getenv("GAMER_QKNORM_ROW_MAJOR") != nullptr;       // (the round-1 form, kept for A/B runs)
         if (row_major)
             hipLaunchKernelGGL(qknorm_rope_fwd_kernel<TA>, dim3(grid_for_waves(((int64_t)T * NH + 3) / 4)), dim3(EW_THREADS), 0,
                                ST(stream), qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot,

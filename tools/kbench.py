@@ -159,7 +159,7 @@ def bench_elem(args):
     w = torch.ones(H, device=dev)
     t = timeit(lambda: ops.rmsnorm_fwd(x, w, 1e-6, y), args.iters)
     print(f"rmsnorm_fwd {t:.3f} ms  {2 * T * H * 4 / t / 1e6:.0f} GB/s")
-    part = torch.empty(512, H, device=dev)
+    part = torch.empty(2048, H, device=dev)          # (the engine's grid: ws.norm_partial)
     dx = torch.zeros(T, H, device=dev)
     t = timeit(lambda: ops.rmsnorm_bwd(x, w, y, H, 1e-6, dx, part, True), args.iters)
     print(f"rmsnorm_bwd {t:.3f} ms  {4 * T * H * 4 / t / 1e6:.0f} GB/s")
