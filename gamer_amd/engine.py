@@ -525,7 +525,7 @@ class Engine:
     def forward(self, input_ids, attention_mask=None, actions=None, labels=None, num_items_in_batch=None,
                 train: bool = False, dropout: Optional[bool] = None, act_zero_col: Optional[int] = None,
                 uniform_len: int = 0, kv_sink=None, session_ids=None, extended_session_ids=None,
-                last_row_logits: bool = False):
+                last_row_logits: bool = False, hidden_sink: Optional[list] = None):
         """Returns (loss or None, logits view [B,S,V]).  With labels the logits are divided by the
         temperature in place, as the reference does (model.py:913).  The view aliases a workspace
         buffer: backward() overwrites it with d(logits), the next forward() with new logits.  ``train`` keeps every activation
@@ -541,7 +541,11 @@ class Engine:
         receives the keys (after k-norm + RoPE) and values of every attention ("self" / "cross") - the K/V cache of
         gamer_amd.decode.DecodeSession; ``last_row_logits``: the prompt pass of a generation needs the logits of the
         last position only (HF's ``logits_to_keep``): final norm and head run on B rows instead of B*S and the
-        returned logits are [B, 1, V]."""
+        returned logits are [B, 1, V].
+
+        ``hidden_sink``: a list that receives copies [B, S, H] of the residual stream at the entry of every decoder layer and of
+        the final norm's output - HF's ``output_hidden_states`` tuple (model.py:822-873).  fp32 in both dtypes (the residual
+        stream is kept in fp32), except the last entry, which has the activation dtype."""
         cfg = self.cfg
         B, S = input_ids.shape
         if train and S % cfg.num_positions != 0:
@@ -551,6 +555,8 @@ class Engine:
             raise ValueError("act_zero_col / uniform_len are evaluation-only options")
         if last_row_logits and (train or labels is not None):
             raise ValueError("last_row_logits is an evaluation-only option")
+        if hidden_sink is not None and last_row_logits:
+            raise ValueError("hidden_sink needs the full-sequence forward")
         bf16 = self.dtype == "bf16"
         if bf16:
             if last_row_logits or uniform_len not in (0, S):
@@ -660,6 +666,8 @@ class Engine:
         for l in range(cfg.num_hidden_layers):
             W, A, xs = self.W[l], ws.layers[l], ws.x[l]
             Wm = self.Wm[l]                          # GEMM operands (fp32 masters or bf16 copies); W: norms, tables
+            if hidden_sink is not None:
+                hidden_sink.append(xs[0].view(B, S, H).clone())
             # ---- self attention (model.py:204-217) ----
             ops.rmsnorm_fwd(xs[0], W.ln1, eps, A["h1"])
             if fuse_qkv:
@@ -746,6 +754,8 @@ class Engine:
             self.last_logits_buf = small               # [B, ldl] (columns >= V are padding), what DecodeSession scores
             return None, small.view(B, 1, ws.ldl)[:, :, :V]
         ops.rmsnorm_fwd(ws.x_final, self.params["model.norm.weight"], eps, ws.xn)
+        if hidden_sink is not None:
+            hidden_sink.append(ws.xn.view(B, S, H).clone())
         ops.linear_fwd(ws.xn, H, emb_m, H, ws.logits, ws.ldl, T, V, H)
         loss = None
         if lab is not None:

@@ -315,6 +315,11 @@ class Qwen3MultiWithTemperature(nn.Module, _GenerationMixin):
         eng = self._engine_for_call()
         sess = (session_ids, extended_session_ids) if self.VARIANT == "session" else (None, None)
         needs_grad = torch.is_grad_enabled() and labels is not None
+        want_hidden = output_hidden_states if output_hidden_states is not None else bool(getattr(self.config, "output_hidden_states", False))
+        hidden = [] if want_hidden else None
+        if want_hidden and needs_grad:
+            raise NotImplementedError("output_hidden_states is served by the scoring forward (torch.no_grad() or no labels): the "
+                                      "training step is one autograd node and hands out no differentiable intermediates")
         if needs_grad:
             params = [self._params_by_key[k] for k in self._param_keys]
             loss, logits = _ModelFn.apply(self, eng, input_ids, attention_mask, actions, labels, num_items, sess, *params)
@@ -322,7 +327,7 @@ class Qwen3MultiWithTemperature(nn.Module, _GenerationMixin):
             with torch.no_grad():
                 loss, logits = eng.forward(input_ids, attention_mask, actions, labels=labels,
                                            num_items_in_batch=num_items, train=False, dropout=False,
-                                           session_ids=sess[0], extended_session_ids=sess[1])
+                                           session_ids=sess[0], extended_session_ids=sess[1], hidden_sink=hidden)
                 # the engine's logits live in a workspace buffer that the next forward overwrites; callers keep
                 # module outputs across batches (HF Trainer.predict / evaluate with compute_metrics), so hand out a copy
                 logits = logits.clone()
@@ -330,7 +335,8 @@ class Qwen3MultiWithTemperature(nn.Module, _GenerationMixin):
             eng.check_inputs()          # session ids out of order cannot be expressed as key spans: raise, do not guess
         if isinstance(logits_to_keep, int) and logits_to_keep > 0:
             logits = logits[:, -logits_to_keep:, :]
-        return CausalLMOutput(loss=loss, logits=logits, past_key_values=None, hidden_states=None, attentions=None)
+        return CausalLMOutput(loss=loss, logits=logits, past_key_values=None,
+                              hidden_states=tuple(hidden) if hidden is not None else None, attentions=None)
 
 
 class FusedClipAdamW(torch.optim.Optimizer):
