@@ -1592,12 +1592,6 @@ attn_bwd_dq2_s_kernel(const float* __restrict__ k, int ldk, const float* __restr
     }
 }
 
-// Streaming form of the dQ kernel for sequences whose K fits in LDS (S <= 573 at head_dim 64): one workgroup per
-// (sample, kv head) keeps ALL its keys in LDS (137 KB at S = 505), so the loop has no staging, no barrier and no
-// branch - four dS loads for tile t+5, 32 LDS fragment reads and 32 MFMAs per step - and each wave keeps five dS
-// tiles (20 KB) in flight: the kernel runs at the rate the spilled dS comes back from HBM.
-constexpr int DQ3_THREADS = 512;          // two waves per SIMD: twice the dS tiles in flight per CU
-
 // the sink armed for the entry point in progress (gamer_amax_sink): max |o| of the forward, max |dv| of the backward
 static thread_local uint32_t* t_amax_out = nullptr;
 // the operand maxima armed for the entry point in progress (gamer_attn_split_amax): non-null q selects the H2 form

@@ -1238,6 +1238,7 @@ static int launch_gemm_split(const GemmParams& p, int blocks, hipStream_t st) {
         const char* e2 = getenv("GAMER_GEMM_PP");
         pp = (SP_PINGPONG && e2 && e2[0] == '1') ? 1 : 0;
     }
+    (void)pp;
 #if SP_PINGPONG
     if ((SPLIT == 6 || SPLIT == 3) && pp && !(MODE == 0 && p.b_planes)) {
         // eight-wave ping-pong form: one workgroup per two tiles, both groups' LDS regions

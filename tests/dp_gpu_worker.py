@@ -68,7 +68,10 @@ def main():
                 res["grad_rel"].append(float((g - gr).abs().max() / gr.abs().max()))
                 res["grad_norm_ref"].append(float(ref.grad_norm))
                 pr = ref.flat_p.cpu()
-                res["param_rel"].append(float((p.double() - pr.double()).abs().max() / pr.double().abs().max()))
+                dp_ = (p.double() - pr.double()).abs()
+                res["param_rel"].append(float(dp_.max() / pr.double().abs().max()))
+                # share of the parameters that moved apart by more than rounding (2e-6 of the largest parameter)
+                res.setdefault("param_frac_off", []).append(float((dp_ > 2e-6 * pr.double().abs().max()).double().mean()))
                 res["ref_loss"] += [float(x) for x in ref_losses]
                 if step == 0:
                     # ... and tied DIRECTLY to the CPU oracle: the gradient two HIP ranks reduced over the process group against
