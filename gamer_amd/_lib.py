@@ -127,6 +127,8 @@ _SIGNATURES = {
     "gamer_residual_dropout_bwd": [P, P, I, I, F, U, P, P],
     "gamer_swiglu_fwd": [P, P, L, F, U, P, P],
     "gamer_swiglu_bwd": [P, P, P, L, F, U, P],
+    "gamer_swiglu_fwd_ld": [P, L, I, I, F, U, P, P],
+    "gamer_swiglu_bwd_ld": [P, L, I, I, P, F, U, P],
     "gamer_silu_gate_fwd": [P, P, L, P, P, F, U, P],
     "gamer_silu_gate_bwd": [P, P, P, L, P, P, F, U, P],
     "gamer_check_labels": [P, L, I, I, P, P],
@@ -149,7 +151,7 @@ _SIGNATURES = {
 
 # bf16 twins: same argument kinds as the fp32 entry point (activation pointers are gamer_bf16* instead of float*)
 for _n in ("rmsnorm_fwd", "rmsnorm_bwd", "rowtable_fwd", "rowtable_bwd", "qknorm_rope_fwd", "qknorm_rope_bwd", "swiglu_fwd",
-           "swiglu_bwd", "silu_gate_fwd", "silu_gate_bwd", "ce_fwd", "ce_bwd"):
+           "swiglu_bwd", "swiglu_fwd_ld", "swiglu_bwd_ld", "silu_gate_fwd", "silu_gate_bwd", "ce_fwd", "ce_bwd"):
     _SIGNATURES[f"gamer_{_n}_bf16"] = _SIGNATURES[f"gamer_{_n}"]
 
 

@@ -1086,6 +1086,69 @@ swiglu_bwd_kernel(TA* __restrict__ g, TA* __restrict__ u, const TA* __restrict__
     amax_block_commit(amu, amax_u, amax_lds[1]);
 }
 
+// The same two kernels on the output of a FUSED gate|up projection: gu is [T][ld] with the gate in columns 0 .. I - 1 and the up
+// projection in columns I .. 2 I - 1 of every row (ld >= 2 I); hm / dhm are [T][I] contiguous.  One wave per row; the dropout
+// word of element (t, c) is that of the flat index t * I + c, as in the contiguous form (same masks).
+template <typename TA>
+__global__ void __launch_bounds__(EW_THREADS)
+swiglu_fwd_ld_kernel(const TA* __restrict__ gu, int64_t ld, int T, int I4, float p, uint64_t seed, TA* __restrict__ hm,
+                     uint32_t* __restrict__ amax_out) {
+    __shared__ uint32_t amax_lds[4];
+    uint32_t am = 0;
+    const DropoutRng rng(p, seed);
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6, nwaves = (gridDim.x * EW_THREADS) >> 6;
+    for (int t = wave; t < T; t += nwaves) {
+        const TA* row = gu + (int64_t)t * ld;
+        for (int c = lane; c < I4; c += 64) {
+            const float4 a = ld4(row + 4 * c), b = ld4(row + 4 * (I4 + c));
+            const int64_t i = (int64_t)t * I4 + c;
+            float m[4];
+            rng.mult4((uint32_t)i, m);
+            float4 o;
+            o.x = m[0] * (silu_f(a.x) * b.x);
+            o.y = m[1] * (silu_f(a.y) * b.y);
+            o.z = m[2] * (silu_f(a.z) * b.z);
+            o.w = m[3] * (silu_f(a.w) * b.w);
+            st4(hm + 4 * i, o);
+            am = amax_f4(am, o);
+        }
+    }
+    amax_block_commit(am, amax_out, amax_lds);
+}
+
+template <typename TA>
+__global__ void __launch_bounds__(EW_THREADS)
+swiglu_bwd_ld_kernel(TA* __restrict__ gu, int64_t ld, int T, int I4, const TA* __restrict__ dhm, float p, uint64_t seed,
+                     uint32_t* __restrict__ amax_g, uint32_t* __restrict__ amax_u) {
+    __shared__ uint32_t amax_lds[2][4];
+    uint32_t amg = 0, amu = 0;
+    const DropoutRng rng(p, seed);
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6, nwaves = (gridDim.x * EW_THREADS) >> 6;
+    for (int t = wave; t < T; t += nwaves) {
+        TA* row = gu + (int64_t)t * ld;
+        for (int c = lane; c < I4; c += 64) {
+            const int64_t i = (int64_t)t * I4 + c;
+            const float4 a = ld4(row + 4 * c), b = ld4(row + 4 * (I4 + c)), d = ld4(dhm + 4 * i);
+            float m[4];
+            rng.mult4((uint32_t)i, m);
+            const float d0 = m[0] * d.x, d1 = m[1] * d.y, d2 = m[2] * d.z, d3 = m[3] * d.w;
+            float4 dg, du;
+            dg.x = d0 * b.x * dsilu_f(a.x); du.x = d0 * silu_f(a.x);
+            dg.y = d1 * b.y * dsilu_f(a.y); du.y = d1 * silu_f(a.y);
+            dg.z = d2 * b.z * dsilu_f(a.z); du.z = d2 * silu_f(a.z);
+            dg.w = d3 * b.w * dsilu_f(a.w); du.w = d3 * silu_f(a.w);
+            st4(row + 4 * c, dg);
+            st4(row + 4 * (I4 + c), du);
+            amg = amax_f4(amg, dg);
+            amu = amax_f4(amu, du);
+        }
+    }
+    amax_block_commit(amg, amax_g, amax_lds[0]);
+    amax_block_commit(amu, amax_u, amax_lds[1]);
+}
+
 // TO = type of `out`: the residual stream (fp32) when resid is given, otherwise the activation type
 template <typename TA, typename TO>
 __global__ void __launch_bounds__(EW_THREADS)
@@ -1649,6 +1712,44 @@ extern "C" int gamer_swiglu_bwd_bf16(gamer_bf16* g, gamer_bf16* u, const gamer_b
                                      uint64_t seed, void* stream) {
     return swiglu_bwd_impl<bf16_t>("gamer_swiglu_bwd_bf16", (bf16_t*)g, (bf16_t*)u, (const bf16_t*)dhm, n, p_drop, seed,
                                    stream);
+}
+
+template <typename TA>
+static int swiglu_fwd_ld_impl(const char* name, const TA* gu, int64_t ld, int T, int I, float p_drop, uint64_t seed, TA* hm,
+                              void* stream) {
+    GAMER_CHECK_ARG(gu && hm && T > 0 && I > 0 && I % 4 == 0 && ld >= 2 * (int64_t)I && ld % 4 == 0 && p_drop >= 0.f && p_drop < 1.f,
+                    "%s: bad arguments (T=%d I=%d ld=%lld)", name, T, I, (long long)ld);
+    GAMER_CHECK_ARG(aligned_vec4<TA>(gu) && aligned_vec4<TA>(hm), "%s: pointers must be aligned to four elements", name);
+    hipLaunchKernelGGL(swiglu_fwd_ld_kernel<TA>, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), gu, ld, T, I / 4,
+                       p_drop, seed, hm, take_amax_sink().out[0]);
+    GAMER_CHECK_LAUNCH(name);
+    return 0;
+}
+extern "C" int gamer_swiglu_fwd_ld(const float* gu, int64_t ld, int T, int I, float p_drop, uint64_t seed, float* hm, void* stream) {
+    return swiglu_fwd_ld_impl<float>("gamer_swiglu_fwd_ld", gu, ld, T, I, p_drop, seed, hm, stream);
+}
+extern "C" int gamer_swiglu_fwd_ld_bf16(const gamer_bf16* gu, int64_t ld, int T, int I, float p_drop, uint64_t seed, gamer_bf16* hm,
+                                        void* stream) {
+    return swiglu_fwd_ld_impl<bf16_t>("gamer_swiglu_fwd_ld_bf16", (const bf16_t*)gu, ld, T, I, p_drop, seed, (bf16_t*)hm, stream);
+}
+template <typename TA>
+static int swiglu_bwd_ld_impl(const char* name, TA* gu, int64_t ld, int T, int I, const TA* dhm, float p_drop, uint64_t seed,
+                              void* stream) {
+    GAMER_CHECK_ARG(gu && dhm && T > 0 && I > 0 && I % 4 == 0 && ld >= 2 * (int64_t)I && ld % 4 == 0 && p_drop >= 0.f && p_drop < 1.f,
+                    "%s: bad arguments (T=%d I=%d ld=%lld)", name, T, I, (long long)ld);
+    GAMER_CHECK_ARG(aligned_vec4<TA>(gu) && aligned_vec4<TA>(dhm), "%s: pointers must be aligned to four elements", name);
+    const AmaxSink sink = take_amax_sink();
+    hipLaunchKernelGGL(swiglu_bwd_ld_kernel<TA>, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), gu, ld, T, I / 4, dhm,
+                       p_drop, seed, sink.out[0], sink.out[1]);
+    GAMER_CHECK_LAUNCH(name);
+    return 0;
+}
+extern "C" int gamer_swiglu_bwd_ld(float* gu, int64_t ld, int T, int I, const float* dhm, float p_drop, uint64_t seed, void* stream) {
+    return swiglu_bwd_ld_impl<float>("gamer_swiglu_bwd_ld", gu, ld, T, I, dhm, p_drop, seed, stream);
+}
+extern "C" int gamer_swiglu_bwd_ld_bf16(gamer_bf16* gu, int64_t ld, int T, int I, const gamer_bf16* dhm, float p_drop, uint64_t seed,
+                                        void* stream) {
+    return swiglu_bwd_ld_impl<bf16_t>("gamer_swiglu_bwd_ld_bf16", (bf16_t*)gu, ld, T, I, (const bf16_t*)dhm, p_drop, seed, stream);
 }
 
 extern "C" int gamer_silu_gate_fwd(const float* a, const float* gate, int64_t n, float* out, const float* resid,

@@ -201,8 +201,8 @@ class DecodeSession:
         self.buf = dict(x=[torch.empty(N, H, **f32) for _ in range(3)], h=torch.empty(N, H, **f32),
                         qkv=torch.empty(N, QKV, **f32), q=torch.empty(N, self.NQ, **f32), k=torch.empty(N, self.NKV, **f32),
                         ao=torch.empty(N, self.NQ, **f32), op=torch.empty(N, H, **f32), gate=torch.empty(N, H, **f32),
-                        t0=torch.empty(N, H, **f32), hin=torch.empty(N, din_max, **f32), g=torch.empty(N, I, **f32),
-                        u=torch.empty(N, I, **f32), hm=torch.empty(N, I, **f32), xn=torch.empty(N, H, **f32),
+                        t0=torch.empty(N, H, **f32), hin=torch.empty(N, din_max, **f32), gu=torch.empty(N, 2 * I, **f32),
+                        hm=torch.empty(N, I, **f32), xn=torch.empty(N, H, **f32),
                         logits=torch.empty(N, engine.ws.ldl, **f32))
         self.t = 0
 
@@ -275,9 +275,8 @@ class DecodeSession:
             ops.rmsnorm_fwd(xc, W.ln3, eps, b["hin"], din)
             if W.inject:
                 ops.rowtable_fwd(W.beh, self.beh, b["hin"], din, H)
-            ops.linear_fwd(b["hin"], din, W.gate[e * I:(e + 1) * I], din, b["g"], I, N, I, din)
-            ops.linear_fwd(b["hin"], din, W.up[e * I:(e + 1) * I], din, b["u"], I, N, I, din)
-            ops.swiglu_fwd(b["g"], b["u"], N * I, 0.0, 0, b["hm"])
+            ops.linear_fwd(b["hin"], din, W.gu[e * 2 * I:(e + 1) * 2 * I], din, b["gu"], 2 * I, N, 2 * I, din)      # gate | up of expert e
+            ops.swiglu_fwd_ld(b["gu"], 2 * I, N, I, 0.0, 0, b["hm"])
             ops.gemm(b["hm"], I, 1, W.down[e * H:(e + 1) * H], I, 1, x, H, N, H, I, resid=xc)
         cur = x
         ops.rmsnorm_fwd(cur, eng.params["model.norm.weight"], eps, b["xn"])

@@ -43,8 +43,9 @@ class ParamLayout:
 
     Decayed parameters first, RMSNorm weights (no weight decay under HF Trainer) last, so the
     fused AdamW kernel needs a single boundary.  q/k/v projection weights of one attention are
-    adjacent (one fused [768,256] GEMM operand) and the experts' gate / up / down weights of a layer
-    are stacked per kind (grouped GEMM with a constant stride).
+    adjacent (one fused [768,256] GEMM operand); the experts' gate and up weights of a layer are stored expert by expert as
+    gate_e | up_e (one [2 I, din] operand per expert: the FUSED gate|up projection, input gradient and weight gradient of the
+    grouped GEMMs, constant stride 2 I din), their down weights stacked behind them (stride H I).
     """
 
     def __init__(self, cfg: Qwen3MultiConfig):
@@ -68,9 +69,11 @@ class ParamLayout:
                               (ap + "k_behavior_embedding.weight", (NB1, nkv * Eb)),
                               (ap + "v_behavior_embedding.weight", (NB1, nkv * Eb))]
             din = H + (Eb if inject else 0)
-            for kind, shp in (("gate_proj", (I, din)), ("up_proj", (I, din)), ("down_proj", (H, I))):
-                for e in range(E):
-                    decay.append((f"{lp}mlp.experts.expert_{e}.{kind}.weight", shp))
+            for e in range(E):
+                decay.append((f"{lp}mlp.experts.expert_{e}.gate_proj.weight", (I, din)))
+                decay.append((f"{lp}mlp.experts.expert_{e}.up_proj.weight", (I, din)))
+            for e in range(E):
+                decay.append((f"{lp}mlp.experts.expert_{e}.down_proj.weight", (H, I)))
             if inject:
                 decay.append((lp + "mlp.behavior_embedding.weight", (NB1, Eb)))
             nodecay.append((lp + "input_layernorm.weight", (H,)))
@@ -127,10 +130,17 @@ class _LayerW:
         self.ln1 = v[lp + "input_layernorm.weight"]
         self.ln2 = v[lp + "post_self_attention_layernorm.weight"] if self.cross else None
         self.ln3 = v[lp + "post_cross_attention_layernorm.weight"]
-        self.gate = layout.span(flat, f"{lp}mlp.experts.expert_0.gate_proj.weight", E * I, self.din)
-        self.up = layout.span(flat, f"{lp}mlp.experts.expert_0.up_proj.weight", E * I, self.din)
+        # rows [e 2I, e 2I + I) = gate_proj of expert e, [e 2I + I, (e + 1) 2I) = its up_proj
+        self.gu = layout.span(flat, f"{lp}mlp.experts.expert_0.gate_proj.weight", E * 2 * I, self.din)
+        self.I = I
         self.down = layout.span(flat, f"{lp}mlp.experts.expert_0.down_proj.weight", E * H, I)
         self.beh = v[lp + "mlp.behavior_embedding.weight"] if self.inject else None
+
+    def gate_e(self, e: int) -> torch.Tensor:
+        return self.gu[e * 2 * self.I:e * 2 * self.I + self.I]
+
+    def up_e(self, e: int) -> torch.Tensor:
+        return self.gu[e * 2 * self.I + self.I:(e + 1) * 2 * self.I]
 
 
 class Bf16Shadow:
@@ -173,9 +183,10 @@ class Bf16Shadow:
                 add(lp + a + ".o_proj.weight", H, nq * dh)
                 if a == "cross_attn":
                     add(lp + a + ".gating.weight", H, H)
-            for kind, rows, cols in (("gate_proj", I, din), ("up_proj", I, din), ("down_proj", H, I)):
-                for e in range(E):
-                    add(f"{lp}mlp.experts.expert_{e}.{kind}.weight", rows, cols)
+            for e in range(E):              # gate_e | up_e are adjacent: one [2 I, din] matrix per expert, transposed [din, 2 I]
+                add(f"{lp}mlp.experts.expert_{e}.gate_proj.weight", 2 * I, din, tkey=f"{lp}mlp.experts.expert_{e}.gu")
+            for e in range(E):
+                add(f"{lp}mlp.experts.expert_{e}.down_proj.weight", H, I)
         self.flatT = torch.zeros(toff, dtype=torch.bfloat16, device=dev)
         tab, tile0 = [], 0
         for src, rows, cols, ldt, dst_t in entries:
@@ -209,8 +220,7 @@ class _LayerWT:
         self.self_attn = attn("self_attn")
         self.cross_attn = attn("cross_attn") if cross else None
         # expert e's transposed matrix sits e * (cols * rows) behind expert 0's (consecutive add() calls, sizes % 8 == 0)
-        self.gate = sh.t(f"{lp}mlp.experts.expert_0.gate_proj.weight")
-        self.up = sh.t(f"{lp}mlp.experts.expert_0.up_proj.weight")
+        self.gu = sh.t(f"{lp}mlp.experts.expert_0.gu")
         self.down = sh.t(f"{lp}mlp.experts.expert_0.down_proj.weight")
 
 
@@ -296,7 +306,7 @@ class _Workspace:
                 d = dict(
                     h1=buf(tag + "h1", (T, H), act), qkv=buf(tag + "qkv", (T, QKV), act), q=buf(tag + "q", (T, NQ), act),
                     k=buf(tag + "k", (T, NKV), act), ao=buf(tag + "ao", (T, NQ), act), lse=buf(tag + "lse", (B, nq, S), f32),
-                    hin=buf(tag + "hin", (T, din_max), act), g=buf(tag + "g", (T, I), act), u=buf(tag + "u", (T, I), act),
+                    hin=buf(tag + "hin", (T, din_max), act), gu=buf(tag + "gu", (T, 2 * I), act),
                     hm=buf(tag + "hm", (T, I), act))
                 if cross or not keep:
                     d.update(h2=buf(tag + "h2", (T, H), act), qkv_c=buf(tag + "qkv_c", (T, QKV), act),
@@ -724,10 +734,9 @@ class Engine:
                 ops.rmsnorm_fwd(xl, W.ln3, eps, hin, din)
                 if W.inject:
                     ops.rowtable_fwd(W.beh, r["beh_idx"].view(-1).index_select(0, rows).contiguous(), hin, din, H)
-                g, u, hm = torch.empty(B, I, **f32), torch.empty(B, I, **f32), torch.empty(B, I, **f32)
-                ops.linear_fwd(hin, din, W.gate[e * I:(e + 1) * I], din, g, I, B, I, din)
-                ops.linear_fwd(hin, din, W.up[e * I:(e + 1) * I], din, u, I, B, I, din)
-                ops.swiglu_fwd(g, u, B * I, 0.0, 0, hm)
+                gu, hm = torch.empty(B, 2 * I, **f32), torch.empty(B, I, **f32)
+                ops.linear_fwd(hin, din, W.gu[e * 2 * I:(e + 1) * 2 * I], din, gu, 2 * I, B, 2 * I, din)
+                ops.swiglu_fwd_ld(gu, 2 * I, B, I, 0.0, 0, hm)
                 x_last = torch.empty(B, H, **f32)
                 ops.gemm(hm, I, 1, W.down[e * H:(e + 1) * H], I, 1, x_last, H, B, H, I, resid=xl)
                 break
@@ -735,9 +744,10 @@ class Engine:
             if W.inject:
                 ops.rowtable_fwd(W.beh, r["beh_idx"], A["hin"], din, H, ws.slot)
             grp = dict(groups=E, group_offsets=ws.offsets)
-            ops.linear_fwd(A["hin"], din, Wm.gate, din, A["g"], I, T, I, din, strideB=I * din, **grp)
-            ops.linear_fwd(A["hin"], din, Wm.up, din, A["u"], I, T, I, din, strideB=I * din, **grp)
-            ops.swiglu_fwd(A["g"], A["u"], T * I, p_res, self._seed(l, 4), A["hm"])
+            # gate_proj and up_proj of the position's expert in ONE grouped GEMM against the stacked [2 I, din] weight (FFN.py:25-27:
+            # both read the same input): A["gu"][:, :I] = gate, [:, I:] = up
+            ops.linear_fwd(A["hin"], din, Wm.gu, din, A["gu"], 2 * I, T, 2 * I, din, strideB=2 * I * din, **grp)
+            ops.swiglu_fwd_ld(A["gu"], 2 * I, T, I, p_res, self._seed(l, 4), A["hm"])
             xnext = ws.x[l + 1][0] if l + 1 < cfg.num_hidden_layers else ws.x_final
             # down projection: rows are in expert-sorted order, the epilogue scatters them back to token
             # order through perm while adding the residual and applying dropout (FFN.py:25-27, model.py:241)
@@ -909,12 +919,10 @@ class Engine:
             with hold(t0):
                 ops.linear_wgrad(t0, H, A["hm"], I, G.down, I, T, H, I, strideC=H * I, **grp)
                 dgrad(t0, H, W.down, WT.down if bf16 else None, I, ws.dhm, I, H, I, strideB=H * I, **grp)
-            ops.swiglu_bwd(A["g"], A["u"], ws.dhm, T * I, p_res, self._seed(l, 4))          # g <- dg, u <- du
-            with hold(A["g"], A["u"]):
-                ops.linear_wgrad(A["g"], I, A["hin"], din, G.gate, din, T, I, din, strideC=I * din, **grp)
-                ops.linear_wgrad(A["u"], I, A["hin"], din, G.up, din, T, I, din, strideC=I * din, **grp)
-                dgrad(A["g"], I, W.gate, WT.gate if bf16 else None, din, ws.dhin, din, I, din, strideB=I * din, **grp)
-                dgrad(A["u"], I, W.up, WT.up if bf16 else None, din, ws.dhin, din, I, din, accumulate=True, strideB=I * din, **grp)
+            ops.swiglu_bwd_ld(A["gu"], 2 * I, T, I, ws.dhm, p_res, self._seed(l, 4))        # gu <- d gate | d up
+            with hold(A["gu"]):
+                ops.linear_wgrad(A["gu"], 2 * I, A["hin"], din, G.gu, din, T, 2 * I, din, strideC=2 * I * din, **grp)
+                dgrad(A["gu"], 2 * I, W.gu, WT.gu if bf16 else None, din, ws.dhin, din, 2 * I, din, strideB=2 * I * din, **grp)
             if W.inject:
                 ops.rowtable_bwd(ws.dhin, din, H, r["beh_idx"], G.beh, ws.slot, partial=NP)
             norm_bwd(xlast, W.ln3, ws.dhin, din, G.ln3, True, ws.slot,

@@ -853,6 +853,21 @@ def swiglu_bwd(g, u, dhm, n, p, seed):
     call("gamer_swiglu_bwd" + _sfx(g), ptr(g), ptr(u), ptr(dhm), n, p, seed, stream_ptr())
 
 
+def swiglu_fwd_ld(gu, ld, T, I, p, seed, hm):
+    """hm[T, I] = drop(silu(gu[:, :I]) * gu[:, I:2I]) on the output of the fused gate|up projection (row stride ld)."""
+    _arm_sink((hm, (1, 0, 1, T * I, T * I), False))
+    call("gamer_swiglu_fwd_ld" + _sfx(gu), ptr(gu), ld, T, I, p, seed, ptr(hm), stream_ptr())
+
+
+def swiglu_bwd_ld(gu, ld, T, I, dhm, p, seed):
+    """In place: gu[:, :I] <- d gate, gu[:, I:2I] <- d up.  The maximum of the whole [T, 2I] gradient goes to ONE slot (it is
+    one GEMM operand from here on) when the buffer is contiguous (ld == 2 I)."""
+    if ld == 2 * I:
+        geom = (1, 0, 1, T * ld, T * ld)
+        _arm_sink((gu, geom, False), (gu, geom, True))
+    call("gamer_swiglu_bwd_ld" + _sfx(gu), ptr(gu), ld, T, I, ptr(dhm), p, seed, stream_ptr())
+
+
 def silu_gate_fwd(a, gate, out, resid=None, p=0.0, seed=0):
     """out = a * silu(gate), or resid + dropout(a * silu(gate)) when resid is given (fused residual add)."""
     call("gamer_silu_gate_fwd" + _sfx(a), ptr(a), ptr(gate), a.numel(), ptr(out), ptr(resid), p, seed, stream_ptr())

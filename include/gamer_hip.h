@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GAMER_ABI_VERSION 7
+#define GAMER_ABI_VERSION 8
 #define GAMER_AMAX_WORDS 256      /* words of one maximum slot (1 KB): see gamer_absmax_f32 */
 
 /* bf16 activations of the AMP variant (the reference's --bf16 run, ref:SeqRec/tasks/train_SMB_decoder.py:114-118,
@@ -550,6 +550,17 @@ int gamer_swiglu_fwd(const float* g, const float* u, int64_t n, float p_drop, ui
 /* in place: g <- dg, u <- du given dhm                                                          */
 int gamer_swiglu_bwd(float* g, float* u, const float* dhm, int64_t n, float p_drop, uint64_t seed,
                      void* stream);
+/* The same two on the output of a FUSED gate|up projection (ref:SeqRec/models/generative/Qwen3Moe/FFN.py:25-27: gate_proj and
+ * up_proj read the same input - here one GEMM against the stacked [2 I, din] weight): gu is [T][ld], gate in columns 0 .. I - 1,
+ * up in columns I .. 2 I - 1 (ld >= 2 I, a multiple of 4); hm / dhm are [T][I] contiguous.  Same dropout masks as the contiguous
+ * form (element (t, c) <-> flat index t I + c).  gamer_amax_sink: out0 = max |hm|; backward out0 = max |d gate|, out1 = max |d up|
+ * (pass the same word twice for the maximum of the whole [T][2 I] gradient).                                                    */
+int gamer_swiglu_fwd_ld(const float* gu, int64_t ld, int T, int I, float p_drop, uint64_t seed, float* hm, void* stream);
+int gamer_swiglu_bwd_ld(float* gu, int64_t ld, int T, int I, const float* dhm, float p_drop, uint64_t seed, void* stream);
+int gamer_swiglu_fwd_ld_bf16(const gamer_bf16* gu, int64_t ld, int T, int I, float p_drop, uint64_t seed, gamer_bf16* hm,
+                             void* stream);
+int gamer_swiglu_bwd_ld_bf16(gamer_bf16* gu, int64_t ld, int T, int I, const gamer_bf16* dhm, float p_drop, uint64_t seed,
+                             void* stream);
 /* out = a * silu(gate)  (cross-attention output gate, model.py:147); with resid != NULL the block's residual add
  * is fused in: out = resid + drop(a * silu(gate)) (model.py:235), same mask as gamer_residual_dropout_fwd(seed)  */
 int gamer_silu_gate_fwd(const float* a, const float* gate, int64_t n, float* out, const float* resid,

@@ -163,17 +163,22 @@ def test_cast_params_and_transposes():
     sh.refresh()
     views = layout.views(flat)
     for key in ("model.embed_tokens.weight", "model.layers.1.cross_attn.gating.weight", "model.layers.0.self_attn.o_proj.weight",
-                "model.layers.0.mlp.experts.expert_3.up_proj.weight", "model.layers.1.mlp.experts.expert_5.down_proj.weight"):
+                "model.layers.1.mlp.experts.expert_5.down_proj.weight"):
         w = views[key]
         assert torch.equal(sh.params16[key], w.to(BF))
         t = sh.t(key)
         assert torch.equal(t[:, :w.shape[0]], w.to(BF).T)
         assert bool((t[:, w.shape[0]:] == 0).all())
+    assert torch.equal(sh.params16["model.layers.0.mlp.experts.expert_3.up_proj.weight"],
+                       views["model.layers.0.mlp.experts.expert_3.up_proj.weight"].to(BF))
     qkv = torch.cat([views[f"model.layers.1.cross_attn.{n}_proj.weight"] for n in "qkv"])
     assert torch.equal(sh.t("model.layers.1.cross_attn.qkv"), qkv.to(BF).T)
+    # gate_e | up_e of an expert are one [2 I, din] matrix (the fused projection): its transpose is [din, 2 I]
+    gu3 = torch.cat([views[f"model.layers.0.mlp.experts.expert_3.{n}_proj.weight"] for n in ("gate", "up")])
+    assert torch.equal(sh.t("model.layers.0.mlp.experts.expert_3.gu"), gu3.to(BF).T)
     # expert e sits e * rows * cols behind expert 0 in the transposed buffer (grouped dgrad stride)
-    t0 = sh.t("model.layers.0.mlp.experts.expert_0.gate_proj.weight")
-    t2 = sh.t("model.layers.0.mlp.experts.expert_2.gate_proj.weight")
+    t0 = sh.t("model.layers.0.mlp.experts.expert_0.gu")
+    t2 = sh.t("model.layers.0.mlp.experts.expert_2.gu")
     assert t2.data_ptr() - t0.data_ptr() == 2 * t0.numel() * 2
 
 

@@ -82,13 +82,18 @@ def test_param_layout_matches_reference_state_dict():
         assert tuple(shp) == tuple(shapes[k]), k
         assert off % 4 == 0
         assert (off >= layout.n_decay) == orc.is_no_decay(k), k
-    # fused operands are contiguous: q|k|v rows and the stacked experts
+    # fused operands are contiguous: q|k|v rows; gate_e | up_e per expert (one [2 I, din] operand, stride 2 I din between
+    # experts), the down weights stacked behind them
     e = layout.entries
     q, k_, v = (e[f"model.layers.5.cross_attn.{n}_proj.weight"][0] for n in "qkv")
     assert k_ - q == 384 * 256 and v - k_ == 192 * 256
     g0 = e["model.layers.0.mlp.experts.expert_0.gate_proj.weight"][0]
+    u0 = e["model.layers.0.mlp.experts.expert_0.up_proj.weight"][0]
     g1 = e["model.layers.0.mlp.experts.expert_1.gate_proj.weight"][0]
-    assert g1 - g0 == 512 * 320
+    assert u0 - g0 == 512 * 320 and g1 - g0 == 2 * 512 * 320
+    d0 = e["model.layers.0.mlp.experts.expert_0.down_proj.weight"][0]
+    d1 = e["model.layers.0.mlp.experts.expert_1.down_proj.weight"][0]
+    assert d0 - g0 == 6 * 2 * 512 * 320 and d1 - d0 == 256 * 512
     flat = torch.arange(layout.numel, dtype=torch.float32)
     views = layout.views(flat)
     assert views["model.norm.weight"].shape == (256,) and float(views["model.embed_tokens.weight"][0, 0]) == 0.0
