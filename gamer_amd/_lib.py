@@ -100,6 +100,7 @@ _SIGNATURES = {
     "gamer_rmsnorm_fwd": [P, P, I, I, F, P, P, I, P],
     "gamer_rmsnorm_bwd": [P, P, P, I, P, I, I, F, I, P, P, I, P, P, F, U, P],
     "gamer_colsum_reduce": [P, I, I, I, P, P],
+    "gamer_colsum_reduce_batched": [P, L, I, I, I, P, I, P],
     "gamer_rowtable_fwd": [P, P, P, I, I, P, I, I, P],
     "gamer_rowtable_bwd": [P, I, I, P, P, I, I, I, P, P, L, P],
     "gamer_gemm_f32": [C.POINTER(GemmDesc), P],

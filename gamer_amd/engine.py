@@ -333,7 +333,9 @@ class _Workspace:
             self.dk = buf("dk", (T, NKV), act)
             self.dao = buf("dao", (T, NQ), act)
             self.delta = buf("delta", (B, nq, S), f32)
-            self.norm_partial = buf("norm_partial", (2048, H), f32)
+            # one [2048, H] table of weight-gradient partial sums per RMSNorm backward of a pass (reduced together at its end),
+            # plus one scratch table for the ordered behaviour-table gradient
+            self.norm_partial = buf("norm_partial", (3 * L + 2, 2048, H), f32)
             self.qk_partial = buf("qk_partial", (ops.qknorm_partial_numel(cfg.num_behavior + 1),), f32)
             # dS spill of the attention backward (5 matmuls per tile pair instead of 7; gamer_attn_bwd):
             # 6.4 GB at B = 1024, shared by all layers.  GAMER_ATTN_SPILL=0 keeps the two recompute kernels.
@@ -468,6 +470,7 @@ class Engine:
         self.base_seed = 0x5EED
         self.sumsq_partial = torch.empty(self.N_SUMSQ_PARTIAL, dtype=torch.float32, device=self.device)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._norm_out_table = None                 # (addresses, device array) of the RMSNorm weight gradients in backward order
         self._saved = None
 
     # ------------------------------------------------------------------------------------------
@@ -841,7 +844,8 @@ class Engine:
         V = cfg.vocab_size
         emb = self.params["model.embed_tokens.weight"]
         demb = self.grads["model.embed_tokens.weight"]
-        NP = ws.norm_partial
+        NP = ws.norm_partial[-1]                    # scratch table (rowtable_bwd); the norm backward takes the others in turn
+        norm_dws: List[torch.Tensor] = []
         # delta = dO . O of the attention backward comes out of the o_proj dgrad GEMM (row-dot epilogue) when the dS-spill
         # path is in use and every tile of that GEMM is full; otherwise gamer_attn_bwd computes it itself
         bf16 = self.dtype == "bf16"
@@ -880,12 +884,13 @@ class Engine:
         def norm_bwd(xin, w, dy, lddy, dw, accumulate_dx, dy_rows=None, branch=None):
             """``branch`` = (seed, rows): the residual branch that consumes the updated dx next; its input gradient
             dropout_mask(seed) * dx goes to t0 in the same pass (t0 must not be ``dy``)."""
+            part = ws.norm_partial[len(norm_dws)]       # dw itself is summed at the end of the pass (one launch for all norms:
+            norm_dws.append(dw)                         # they sit in the tail bucket of the gradient all-reduce)
             if branch is None:
-                ops.rmsnorm_bwd(xin, w, dy, lddy, eps, ws.dx, NP, accumulate_dx, dy_rows)
+                ops.rmsnorm_bwd(xin, w, dy, lddy, eps, ws.dx, part, accumulate_dx, dy_rows)
             else:
-                ops.rmsnorm_bwd(xin, w, dy, lddy, eps, ws.dx, NP, accumulate_dx, dy_rows, mask_out=ws.tmpH[0],
+                ops.rmsnorm_bwd(xin, w, dy, lddy, eps, ws.dx, part, accumulate_dx, dy_rows, mask_out=ws.tmpH[0],
                                 mask_rows=branch[1], p=p_res, seed=branch[0])
-            ops.colsum_reduce(NP, dw, accumulate=True)
 
         # ---- loss -> logits -> final norm ----
         if torch.is_tensor(sv["num_items"]):
@@ -981,6 +986,10 @@ class Engine:
             ops.linear_wgrad(oh, ws.ldl, ws.dx, H, demb, H, T, V, H)
         else:
             ops.embedding_bwd(sv["ids"], ws.dx, cfg.pad_token_id, demb)
+        key = tuple(d.data_ptr() for d in norm_dws)
+        if self._norm_out_table is None or self._norm_out_table[0] != key:
+            self._norm_out_table = (key, torch.tensor(key, dtype=torch.int64, device=self.device))
+        ops.colsum_reduce_batched(ws.norm_partial, len(norm_dws), self._norm_out_table[1], accumulate=True)
         self.dropout_step = saved_step
 
     # ------------------------------------------------------------------------------------------

@@ -116,6 +116,13 @@ def colsum_reduce(partial, out, accumulate=False):
     call("gamer_colsum_reduce", ptr(partial), rows, cols, 1 if accumulate else 0, ptr(out), stream_ptr())
 
 
+def colsum_reduce_batched(partials, n, outs_table, accumulate=False):
+    """partials [>= n, rows, cols] (contiguous); outs_table: int64 device tensor of n output addresses."""
+    _, rows, cols = partials.shape
+    call("gamer_colsum_reduce_batched", ptr(partials), rows * cols, rows, cols, n, ptr(outs_table), 1 if accumulate else 0,
+         stream_ptr())
+
+
 def rowtable_fwd(table, idx, y, ldy, col0, dst_rows=None):
     T = idx.numel()
     E = table.shape[1]

@@ -136,6 +136,10 @@ int gamer_rmsnorm_bwd_bf16(const float* x, const float* w, const gamer_bf16* dy,
 /* out[c] (+)= sum_r partial[r][c] */
 int gamer_colsum_reduce(const float* partial, int rows, int cols, int accumulate, float* out,
                         void* stream);
+/* the same for n tables `stride` floats apart in one launch: outs[i][c] (+)= sum_r partial[i * stride + r * cols + c]; outs is a
+ * DEVICE array of n device pointers (the RMSNorm weight gradients of a whole backward pass at its end)                        */
+int gamer_colsum_reduce_batched(const float* partial, int64_t stride, int rows, int cols, int n, float* const* outs,
+                                int accumulate, void* stream);
 
 /* Behaviour-embedding concat for the injected FFN layers (FFN.py:60-62):
  * y[dst(t)][col0 .. col0+E) = table[idx[t]];   bwd: dtable[idx[t]] += dy[dst(t)][col0..]
