@@ -48,10 +48,13 @@ class ParamLayout:
     grouped GEMMs, constant stride 2 I din), their down weights stacked behind them (stride H I).
     """
 
-    def __init__(self, cfg: Qwen3MultiConfig):
+    VERSION = 2          # 1 (rounds 1-3): the experts' gate / up / down weights of a layer stacked per kind
+
+    def __init__(self, cfg: Qwen3MultiConfig, version: int = 2):
         H, dh = cfg.hidden_size, cfg.head_dim
         nq, nkv, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size
         Eb, NB1, E = cfg.behavior_embedding_dim, cfg.num_behavior + 1, cfg.num_experts
+        self.version = version
         decay: List[Tuple[str, tuple]] = [("model.embed_tokens.weight", (cfg.vocab_size, H))]
         nodecay: List[Tuple[str, tuple]] = []
         for l in range(cfg.num_hidden_layers):
@@ -69,11 +72,16 @@ class ParamLayout:
                               (ap + "k_behavior_embedding.weight", (NB1, nkv * Eb)),
                               (ap + "v_behavior_embedding.weight", (NB1, nkv * Eb))]
             din = H + (Eb if inject else 0)
-            for e in range(E):
-                decay.append((f"{lp}mlp.experts.expert_{e}.gate_proj.weight", (I, din)))
-                decay.append((f"{lp}mlp.experts.expert_{e}.up_proj.weight", (I, din)))
-            for e in range(E):
-                decay.append((f"{lp}mlp.experts.expert_{e}.down_proj.weight", (H, I)))
+            if version == 1:
+                for kind, shp in (("gate_proj", (I, din)), ("up_proj", (I, din)), ("down_proj", (H, I))):
+                    for e in range(E):
+                        decay.append((f"{lp}mlp.experts.expert_{e}.{kind}.weight", shp))
+            else:
+                for e in range(E):
+                    decay.append((f"{lp}mlp.experts.expert_{e}.gate_proj.weight", (I, din)))
+                    decay.append((f"{lp}mlp.experts.expert_{e}.up_proj.weight", (I, din)))
+                for e in range(E):
+                    decay.append((f"{lp}mlp.experts.expert_{e}.down_proj.weight", (H, I)))
             if inject:
                 decay.append((lp + "mlp.behavior_embedding.weight", (NB1, Eb)))
             nodecay.append((lp + "input_layernorm.weight", (H,)))
@@ -98,6 +106,20 @@ class ParamLayout:
 
     def views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
         return {k: flat[o:o + math.prod(s)].view(s) for k, (o, s) in self.entries.items()}
+
+    def adopt(self, flat: torch.Tensor, cfg: Qwen3MultiConfig, version) -> torch.Tensor:
+        """A flat buffer (optimizer moments of a checkpoint) written under layout `version` (None: a file from before the
+        layouts were numbered = 1) re-ordered to this layout, parameter by parameter; the same tensor if nothing moved."""
+        version = 1 if version is None else int(version)
+        if version == self.version:
+            return flat
+        if flat.numel() != self.numel:
+            raise ValueError(f"flat optimizer state has {flat.numel()} elements, this model {self.numel}")
+        old = ParamLayout(cfg, version=version).views(flat)
+        out = torch.empty_like(flat)
+        for k, v in self.views(out).items():
+            v.copy_(old[k])
+        return out
 
     def span(self, flat: torch.Tensor, first: str, rows: int, cols: int) -> torch.Tensor:
         """[rows, cols] view that starts at parameter `first` and runs over its successors."""

@@ -377,13 +377,16 @@ class FusedClipAdamW(torch.optim.Optimizer):
 
     def state_dict(self):
         eng = self.model.engine
-        return {"state": {"m": eng.flat_m, "v": eng.flat_v, "step": eng.opt_step}, "param_groups": self.param_groups}
+        return {"state": {"m": eng.flat_m, "v": eng.flat_v, "step": eng.opt_step, "layout_version": eng.layout.version},
+                "param_groups": self.param_groups}
 
     def load_state_dict(self, sd):
         eng = self.model.engine
         st = sd["state"]
         if st.get("m") is not None:
-            eng.flat_m, eng.flat_v = st["m"].to(eng.device).clone(), st["v"].to(eng.device).clone()
+            ver = st.get("layout_version")                # (flat moments: re-ordered by name if written under another parameter order)
+            eng.flat_m = eng.layout.adopt(st["m"], eng.cfg, ver).to(eng.device).clone()
+            eng.flat_v = eng.layout.adopt(st["v"], eng.cfg, ver).to(eng.device).clone()
         eng.opt_step = int(st.get("step", 0))
         for g, saved in zip(self.param_groups, sd["param_groups"]):
             g.update({k: v for k, v in saved.items() if k != "params"})

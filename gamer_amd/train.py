@@ -74,7 +74,7 @@ def save_checkpoint(eng: Engine, path: str, state: dict):
     save_file({k: v.detach().cpu().contiguous() for k, v in eng.params.items()}, os.path.join(path, "model.safetensors"))
     torch.save({"m": eng.flat_m.cpu() if eng.flat_m is not None else None,
                 "v": eng.flat_v.cpu() if eng.flat_v is not None else None,
-                "opt_step": eng.opt_step}, os.path.join(path, "optimizer.pt"))
+                "opt_step": eng.opt_step, "layout_version": eng.layout.version}, os.path.join(path, "optimizer.pt"))
     with open(os.path.join(path, "trainer_state.json"), "w") as f:
         json.dump(state, f)
 
@@ -84,8 +84,9 @@ def load_checkpoint(eng: Engine, path: str) -> dict:
     eng.load_state_dict(load_file(os.path.join(path, "model.safetensors")))
     opt = torch.load(os.path.join(path, "optimizer.pt"), map_location="cpu")
     if opt["m"] is not None:
-        eng.flat_m = opt["m"].to(eng.device)
-        eng.flat_v = opt["v"].to(eng.device)
+        # (the moments are stored flat: a file written under another parameter order is re-ordered by name)
+        eng.flat_m = eng.layout.adopt(opt["m"], eng.cfg, opt.get("layout_version")).to(eng.device)
+        eng.flat_v = eng.layout.adopt(opt["v"], eng.cfg, opt.get("layout_version")).to(eng.device)
     eng.opt_step = int(opt["opt_step"])
     with open(os.path.join(path, "trainer_state.json")) as f:
         return json.load(f)

@@ -99,6 +99,24 @@ def test_param_layout_matches_reference_state_dict():
     assert views["model.norm.weight"].shape == (256,) and float(views["model.embed_tokens.weight"][0, 0]) == 0.0
 
 
+def test_flat_optimizer_state_of_an_older_parameter_order_is_adopted_by_name():
+    """Checkpoints store the Adam moments flat.  Round 4 moved the experts' gate / up weights (gate_e | up_e adjacent for the fused
+    projection): a file written before must land on the right parameters, element for element."""
+    cfg = synthetic_config(num_hidden_layers=2, behavior_injection_decoder=[0], cross_attention_decoder=[1], codebook=8)
+    new, old = ParamLayout(cfg), ParamLayout(cfg, version=1)
+    assert new.numel == old.numel and set(new.entries) == set(old.entries) and new.version == ParamLayout.VERSION
+    assert new.entries != old.entries                       # the order did change
+    g = torch.Generator().manual_seed(0)
+    flat_old = torch.randn(old.numel, generator=g)
+    named = {k: v.clone() for k, v in old.views(flat_old).items()}
+    flat_new = new.adopt(flat_old, cfg, None)               # None: a file from before the layouts were numbered
+    for k, v in new.views(flat_new).items():
+        assert torch.equal(v, named[k]), k
+    assert new.adopt(flat_new, cfg, ParamLayout.VERSION) is flat_new
+    with pytest.raises(ValueError):
+        new.adopt(flat_old[:-4], cfg, 1)
+
+
 def test_no_decay_rule_matches_hf_trainer_when_reference_present():
     """oracle.is_no_decay restates HF Trainer.get_decay_parameter_names for this model."""
     if not os.path.isdir("/root/reference/SeqRec"):
