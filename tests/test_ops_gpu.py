@@ -850,6 +850,56 @@ def test_elementwise_dropout_family():
     assert float((z2.cpu() != mask).float().mean()) > 0.2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,I,ld", [(300, 512, 1024), (37, 96, 200), (1, 4, 8)])
+def test_swiglu_on_the_fused_gate_up_buffer_equals_the_contiguous_kernels(rows, I, ld, dtype):
+    """gamer_swiglu_fwd_ld / _bwd_ld read gate and up from the column halves of one [T, ld] buffer (the output of the fused
+    gate|up projection): bit-identical values and dropout masks to gamer_swiglu_fwd / _bwd on two contiguous arrays, padding
+    columns (ld > 2 I) untouched; with the maxima sink armed, the whole-gradient maximum of the backward lands in one slot."""
+    p, seed = 0.2, 11
+    gen = torch.Generator().manual_seed(rows)
+    g = torch.randn(rows, I, generator=gen).to(dtype)
+    u = torch.randn(rows, I, generator=gen).to(dtype)
+    dhm = torch.randn(rows, I, generator=gen).to(dtype)
+    gu = torch.full((rows, ld), 7.0, dtype=dtype)
+    gu[:, :I], gu[:, I:2 * I] = g, u
+    gu_d = dev(gu)
+    hm_a, hm_b = torch.empty(rows, I, dtype=dtype, device=DEV), torch.empty(rows, I, dtype=dtype, device=DEV)
+    ops.swiglu_fwd(dev(g), dev(u), rows * I, p, seed, hm_a)
+    ops.swiglu_fwd_ld(gu_d, ld, rows, I, p, seed, hm_b)
+    assert torch.equal(hm_a, hm_b)
+    assert torch.equal(gu_d.cpu(), gu)                       # the forward writes nothing into its input
+    dg, du = dev(g.clone()), dev(u.clone())
+    ops.swiglu_bwd(dg, du, dev(dhm), rows * I, p, seed)
+    ops.swiglu_bwd_ld(gu_d, ld, rows, I, dev(dhm), p, seed)
+    assert torch.equal(gu_d[:, :I], dg) and torch.equal(gu_d[:, I:2 * I], du)
+    assert bool((gu_d[:, 2 * I:] == 7.0).all())
+    if dtype == torch.float32 and ld == 2 * I:
+        with ops.f32_matmul("split3"), ops.amax_reuse(everything=True) as cache:
+            gu2 = dev(gu)
+            ops.swiglu_bwd_ld(gu2, ld, rows, I, dev(dhm), p, seed)
+            key = cache._key(gu2.data_ptr(), (1, 0, 1, rows * ld, rows * ld))
+            assert key in cache.pending, "the producer did not open a slot"
+            assert _slot_value(cache.pending[key]) == float(gu2.abs().max())
+
+
+def test_colsum_reduce_batched_equals_the_single_table_kernel():
+    rows, cols, n = 2048, 256, 5
+    gen = torch.Generator().manual_seed(0)
+    part = dev(torch.randn(n + 1, rows, cols, generator=gen))
+    outs_a = [dev(torch.randn(cols, generator=gen)) for _ in range(n)]
+    outs_b = [o.clone() for o in outs_a]
+    for i in range(n):
+        ops.colsum_reduce(part[i], outs_a[i], accumulate=True)
+    table = torch.tensor([o.data_ptr() for o in outs_b], dtype=torch.int64, device=DEV)
+    ops.colsum_reduce_batched(part, n, table, accumulate=True)
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
+    ops.colsum_reduce_batched(part, 2, table, accumulate=False)
+    assert torch.equal(outs_b[1], part[1].sum(0, dtype=torch.float32)) or _rel(outs_b[1], part[1].double().sum(0)) < 1e-5
+    assert torch.equal(outs_b[2], outs_a[2])                  # tables past n are not touched
+
+
 def test_swiglu_and_gate():
     n_rows, I, p, seed = 300, 512, 0.2, 5
     g, u = torch.randn(n_rows, I), torch.randn(n_rows, I)
