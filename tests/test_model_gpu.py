@@ -185,6 +185,17 @@ def test_gradient_accumulation_and_update_match_oracle():
     assert worst_p < 2e-7 and worst_any <= 2 * 5e-4
 
 
+def test_hidden_states_at_the_shipped_architecture_match_the_reference_sums(golden):
+    """The full-config fixture stores the sum of every entry of the reference's ``output_hidden_states`` tuple (8 layer inputs +
+    the final norm's output): the engine's ``hidden_sink`` must reproduce all nine."""
+    z, meta, eng, batch, _, _ = _engine_from_golden(golden, "full", None)
+    sink = []
+    eng.forward(batch["input_ids"], batch["attention_mask"], batch["actions"], train=False, hidden_sink=sink)
+    assert len(sink) == eng.cfg.num_hidden_layers + 1 == len(z["hidden_sum"])
+    got = np.array([float(h.double().sum()) for h in sink])
+    np.testing.assert_allclose(got, z["hidden_sum"], rtol=1e-4, atol=1e-2)
+
+
 @pytest.mark.parametrize("name", ["small", "session_small"])
 def test_module_output_hidden_states_match_the_reference(golden, name):
     """``output_hidden_states=True`` (model.py:822-873): the input of every decoder layer and the final norm's output, against
