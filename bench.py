@@ -862,6 +862,11 @@ def main(argv=None):
         if rccl_log is not None:
             from gamer_amd.dp import parse_rccl_log
             try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)           # RCCL writes its log through buffered C stdio: push it to the file first
+            except Exception:
+                pass
+            try:
                 result["rccl"] = parse_rccl_log(open(rccl_log, errors="replace").read())
             except OSError as e:
                 result["rccl"] = {"error": repr(e)}

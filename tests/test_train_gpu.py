@@ -89,10 +89,10 @@ def test_bench_rccl_path_single_rank():
     assert len(lines) == 1, r.stdout[-2000:]
     assert r.stdout.strip().splitlines()[-1] == lines[0], "the JSON line must be the last line on stdout"
     line = json.loads(lines[0])
-    assert line["unit"] == "sequences/s" and line["value"] > 0 and "roofline" in line
+    assert line["unit"] == "sequences/s" and line["value"] > 0 and "roofline" in line, lines[0][:600]
     # the multi-GPU diagnostics ride on the same path: per-bucket all-reduce times, exposed communication, RCCL's log summary
     comm = line["communication"]
-    assert len(comm["per_bucket"]) == 8 + 2 and all(b["ms"] > 0 and b["bytes"] > 0 for b in comm["per_bucket"])
-    assert comm["step_ms_with_reducer"] > 0 and comm["step_ms_without_collectives"] > 0 and comm["exposed_communication_ms"] >= 0
+    assert len(comm["per_bucket"]) == 8 + 2 and all(b["ms"] > 0 and b["bytes"] > 0 for b in comm["per_bucket"]), comm
+    assert comm["step_ms_with_reducer"] > 0 and comm["step_ms_without_collectives"] > 0 and comm["exposed_communication_ms"] >= 0, comm
     assert sum(b["bytes"] for b in comm["per_bucket"]) == 4 * 24535040 or line["config"]["seq_len"] != 505
     assert "rccl" in line and line["rccl"].get("lines", 0) > 0, line.get("rccl")
