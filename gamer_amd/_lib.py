@@ -57,6 +57,7 @@ class GemmDesc(C.Structure):
         ("amax_a", c_void_p), ("amax_b", c_void_p),
         ("amax_c", c_void_p), ("amax_c_col0", c_int),
         ("wgrad_ws", c_void_p), ("wgrad_ws_floats", c_int64),
+        ("sw_gu", c_void_p), ("sw_ld", c_int64),
     ]
 
 

@@ -266,6 +266,9 @@ struct GemmParams {
     uint32_t* amax_c;              // MODE 0, plain / row-dot epilogues: fold the bits of max |C stored| over columns >= amax_c_col0 into this slot
     int amax_c_col0;
     float* wgrad_ws;               // MODE 1, deterministic form: chunk partial tiles [chunk][tile][128][128] instead of fp32 atomics
+    // SwiGLU-backward epilogue (EPI == 4): C = d(hm) is NOT stored; with m = the dropout multiplier of flat element row N + col,
+    // sw_gu[row][col] <- m C b silu'(a), sw_gu[row][N + col] <- m C silu(a) for a, b = the gate / up values stored there
+    float* sw_gu; int64_t sw_ld;
 };
 
 // SPLIT == 3 scales a whole operand TENSOR by one power of two, so a row of A whose largest magnitude lies more than 2^16 below
@@ -1008,7 +1011,7 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): own LDS writes landed (wave-private patch)
         const int c4 = (lane & 15) << 2;
-        const DropoutRng rng(EPI == 1 ? p.p_drop : 0.f, p.seed);
+        const DropoutRng rng((EPI == 1 || EPI == 4) ? p.p_drop : 0.f, p.seed);
         // one 64-bit address per wave patch, then a constant stride per store (a per-store row * ldc product costs
         // two quarter-rate integer multiplies each)
         const int row_first = row0 + wm * 64 + (lane >> 4);
@@ -1068,6 +1071,26 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
                         x.x += b4.x; x.y += b4.y; x.z += b4.z; x.w += b4.w;
                     }
                     *reinterpret_cast<float4*>(dst0 + it * step) = x;
+                }
+            } else if (EPI == 4) {
+                // v = d(hm) of four consecutive columns of one row: the SwiGLU backward right here (gamer_swiglu_bwd_ld's arithmetic)
+                const int row = row_first + 4 * it;
+                float* ga = p.sw_gu + (int64_t)row * p.sw_ld + col;
+                float* ua = ga + p.N;
+                const float4 a = *reinterpret_cast<const float4*>(ga), b = *reinterpret_cast<const float4*>(ua);
+                float m[4];
+                rng.mult4((uint32_t)(((int64_t)row * p.N + col) >> 2), m);
+                const float d0 = m[0] * v.x, d1 = m[1] * v.y, d2 = m[2] * v.z, d3 = m[3] * v.w;
+                float4 dg, du;
+                dg.x = d0 * b.x * dsilu_f(a.x); du.x = d0 * silu_f(a.x);
+                dg.y = d1 * b.y * dsilu_f(a.y); du.y = d1 * silu_f(a.y);
+                dg.z = d2 * b.z * dsilu_f(a.z); du.z = d2 * silu_f(a.z);
+                dg.w = d3 * b.w * dsilu_f(a.w); du.w = d3 * silu_f(a.w);
+                *reinterpret_cast<float4*>(ga) = dg;
+                *reinterpret_cast<float4*>(ua) = du;
+                if (amax_on) {
+                    asm("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|" : "+v"(cmax) : "v"(dg.x), "v"(dg.y), "v"(dg.z), "v"(dg.w));
+                    asm("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|" : "+v"(cmax) : "v"(du.x), "v"(du.y), "v"(du.z), "v"(du.w));
                 }
             } else if (EPI == 1) {
                 float* dst = dst0 + it * step;
@@ -1132,6 +1155,19 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
     } else {
         float emax = 0.f;
         auto emit = [&](int row, int col, float v) {
+            if (EPI == 4) {
+                float* ga = p.sw_gu + (int64_t)row * p.sw_ld + col;
+                const float a = ga[0], b = ga[p.N];
+                const int64_t e = (int64_t)row * p.N + col;
+                const DropoutRng rng(p.p_drop, p.seed);
+                float m[4];
+                rng.mult4((uint32_t)(e >> 2), m);
+                const float d = m[e & 3] * v;
+                const float dg = d * b * dsilu_f(a), du = d * silu_f(a);
+                ga[0] = dg; ga[p.N] = du;
+                if (GAMER_GEMM_CAMAX_BUILD && p.amax_c != nullptr) emax = fmaxf(emax, fmaxf(fabsf(dg), fabsf(du)));
+                return;
+            }
             if (GAMER_GEMM_CAMAX_BUILD && EPI != 1 && MODE == 0 && !ACCUM && p.amax_c != nullptr && col >= p.amax_c_col0) emax = fmaxf(emax, fabsf(v));
             if (EPI == 1) {
                 const int64_t rc = p.row_map ? p.row_map[row] : row;
@@ -1258,6 +1294,9 @@ static int launch_gemm_split(const GemmParams& p, int blocks, hipStream_t st) {
     }
 #endif
     if (stamp && SPLIT == 6) return launch_gemm_t<A_KC, B_KC, MODE, false, true, 2, 0, SPLIT>(p, blocks, st, lds);
+    if constexpr (SPLIT == 3 && MODE == 0 && A_KC) {
+        if (p.sw_gu) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 4, SPLIT>(p, blocks, st, lds);
+    }
     if (MODE == 0 && p.resid) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 1, SPLIT>(p, blocks, st, lds);
     if (MODE == 0 && p.rowdot_out) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 2, SPLIT>(p, blocks, st, lds);
     if (MODE == 0 && A_KC && B_KC && p.qk_q_rot) return launch_gemm_t<A_KC, B_KC, MODE, false, false, 2, 3, SPLIT>(p, blocks, st, lds);
@@ -1412,6 +1451,12 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     p.guard = g_split3_guard;
     p.amax_c = d->amax_c; p.amax_c_col0 = d->amax_c_col0;
     p.wgrad_ws = nullptr;
+    p.sw_gu = d->sw_gu; p.sw_ld = d->sw_ld;
+    GAMER_CHECK_ARG(!d->sw_gu || (split == 3 && d->group_mode == 0 && !d->accumulate && !d->resid && !d->rowdot_out && !d->qk_q_rot &&
+                                  d->alpha == 1.f && d->N % 4 == 0 && d->sw_ld >= 2 * (int64_t)d->N && d->sw_ld % 4 == 0 &&
+                                  aligned16(d->sw_gu) && d->p_drop >= 0.f && d->p_drop < 1.f),
+                    "gamer_gemm_f32: the SwiGLU-backward epilogue (sw_gu) is built for gamer_gemm_f32_split(terms = 3), a plain input-"
+                    "gradient GEMM with alpha = 1, N %% 4 == 0, sw_ld >= 2 N (N=%d sw_ld=%lld)", d->N, (long long)d->sw_ld);
     GAMER_CHECK_ARG(!d->amax_c || (d->group_mode == 0 && !d->accumulate && !d->resid && !d->qk_q_rot && d->amax_c_col0 >= 0 &&
                                    d->amax_c_col0 % 64 == 0),
                     "gamer_gemm_f32: amax_c needs a plain or row-dot Linear-forward / input-gradient GEMM (no accumulate, residual or "

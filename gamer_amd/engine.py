@@ -493,6 +493,7 @@ class Engine:
         self.sumsq_partial = torch.empty(self.N_SUMSQ_PARTIAL, dtype=torch.float32, device=self.device)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._norm_out_table = None                 # (addresses, device array) of the RMSNorm weight gradients in backward order
+        self.fuse_swiglu_bwd = os.environ.get("GAMER_FUSE_SWIGLU_BWD", "1") != "0"     # (A/B switch; split3 only)
         self._saved = None
 
     # ------------------------------------------------------------------------------------------
@@ -877,6 +878,8 @@ class Engine:
         do_amax = (dict(c_amax=(ws.dao, 0)) if (split_attn and self.h2_attention and self.matmul == "split3" and p_att < 0.75 and
                                                    self.gemm_c_amax) else {})
 
+        fuse_swiglu_bwd = (not bf16) and self.matmul == "split3" and self.fuse_swiglu_bwd
+
         def dgrad(dy, lddy, Wf, Wt, ldw, dx, lddx, n_out, k_in, **kw):
             """dx[T,k_in] (+)= dy[T,n_out] @ W[n_out,k_in]: fp32 reads W itself (row-contiguous B operand), bf16 the
             transposed copy Wt [k_in, n_out] (k-contiguous on both sides); strideB is the same element count."""
@@ -945,8 +948,15 @@ class Engine:
             # ---- experts ----   (t0 = d out_sorted, written by the norm backward that completed dx)
             with hold(t0):
                 ops.linear_wgrad(t0, H, A["hm"], I, G.down, I, T, H, I, strideC=H * I, **grp)
-                dgrad(t0, H, W.down, WT.down if bf16 else None, I, ws.dhm, I, H, I, strideB=H * I, **grp)
-            ops.swiglu_bwd_ld(A["gu"], 2 * I, T, I, ws.dhm, p_res, self._seed(l, 4))        # gu <- d gate | d up
+                if fuse_swiglu_bwd:
+                    # the down projection's input gradient with the SwiGLU backward in its epilogue: d(hm) = t0 W_down never goes
+                    # to memory, A["gu"] <- d gate | d up (gamer_gemm_desc.sw_gu; ws.dhm is only the descriptor's C)
+                    ops.gemm(t0, H, 1, W.down, 1, I, ws.dhm, I, T, I, H, strideB=H * I, p_drop=p_res, seed=self._seed(l, 4),
+                             swiglu_bwd=(A["gu"], 2 * I), **grp)
+                else:
+                    dgrad(t0, H, W.down, WT.down if bf16 else None, I, ws.dhm, I, H, I, strideB=H * I, **grp)
+            if not fuse_swiglu_bwd:
+                ops.swiglu_bwd_ld(A["gu"], 2 * I, T, I, ws.dhm, p_res, self._seed(l, 4))    # gu <- d gate | d up
             with hold(A["gu"]):
                 ops.linear_wgrad(A["gu"], 2 * I, A["hin"], din, G.gu, din, T, 2 * I, din, strideC=2 * I * din, **grp)
                 dgrad(A["gu"], 2 * I, W.gu, WT.gu if bf16 else None, din, ws.dhin, din, 2 * I, din, strideB=2 * I * din, **grp)

@@ -452,7 +452,7 @@ def set_f32_matmul(mode) -> int:
 
 def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=False, groups=1, group_mode=0,
          group_offsets=None, strideB=0, strideC=0, kchunk=0, resid=None, row_map=None, p_drop=0.0, seed=0,
-         rowdot=None, qknorm=None, c_amax=None):
+         rowdot=None, qknorm=None, c_amax=None, swiglu_bwd=None):
     """C[m][n] (=|+=) alpha * sum_k A(m,k) B(n,k); see gamer_gemm_desc in include/gamer_hip.h.  bf16 operands go to
     gamer_gemm_bf16 (k-contiguous x k-contiguous, or the token-major wgrad form; see gamer_gemm_bf16_desc)."""
     if A.dtype == torch.bfloat16:
@@ -491,6 +491,12 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
         view, col0 = c_amax
         slot_c = _AMAX_REUSE.preset(view, (1, 0, M, N - col0, ldc))
         d.amax_c, d.amax_c_col0 = slot_c, int(col0)
+    if swiglu_bwd is not None:
+        # (gu, ld): C = d(hm) is consumed by the SwiGLU backward in the epilogue - gu <- d gate | d up - and never stored
+        gu, ld_gu = swiglu_bwd
+        d.sw_gu, d.sw_ld = ptr(gu), int(ld_gu)
+        if _AMAX_REUSE is not None and F32_MATMUL_TERMS == 3 and ld_gu == 2 * N:
+            d.amax_c, d.amax_c_col0 = _AMAX_REUSE.preset(gu, (1, 0, 1, M * ld_gu, M * ld_gu)), 0
     if group_mode == 1 and DETERMINISTIC_WGRAD:
         n_chunks = (K + kchunk - 1) // kchunk + (groups if group_offsets is not None else 0)
         need = n_chunks * ((M + 127) // 128) * ((N + 127) // 128) * 16384

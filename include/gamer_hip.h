@@ -236,6 +236,13 @@ typedef struct {
      * run; the default combines the chunks with fp32 atomics, whose order varies).  NULL = atomics. */
     float* wgrad_ws;
     int64_t wgrad_ws_floats;
+    /* SwiGLU-backward epilogue (gamer_gemm_f32_split, terms = 3; group_mode 0, alpha = 1, no other epilogue): this GEMM is the
+     * input gradient of the experts' down projection, C[m][n] = d(hm)[m][n] with N = the intermediate size.  C is NOT stored;
+     * instead sw_gu - the [M][sw_ld] buffer of the fused gate|up projection, gate in columns 0 .. N - 1, up in N .. 2 N - 1 - is
+     * overwritten with d gate | d up exactly as gamer_swiglu_bwd_ld(sw_gu, sw_ld, M, N, C, p_drop, seed) would do (p_drop / seed of
+     * this descriptor): d(hm) never goes to memory.  amax_c (amax_c_col0 = 0) then receives max |d gate|, |d up|.  NULL = off. */
+    float* sw_gu;
+    int64_t sw_ld;
 } gamer_gemm_desc;
 
 int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);

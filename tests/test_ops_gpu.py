@@ -883,6 +883,40 @@ def test_swiglu_on_the_fused_gate_up_buffer_equals_the_contiguous_kernels(rows, 
             assert _slot_value(cache.pending[key]) == float(gu2.abs().max())
 
 
+@pytest.mark.parametrize("T,offsets", [(1024, None), (700, [0, 0, 130, 131, 389, 389, 700]), (37, None)])
+def test_gemm_swiglu_backward_epilogue_equals_dgrad_then_swiglu_bwd(T, offsets):
+    """gamer_gemm_desc.sw_gu: the input gradient of the experts' down projection with the SwiGLU backward in its epilogue
+    (d(hm) never stored) against the two-kernel path - plain and grouped (ragged expert segments, empty experts: edge tiles),
+    dropout on, and the maxima slot of the fused gradient."""
+    H, I, p, seed = 256, 512, 0.2, 13
+    E = 6 if offsets is not None else 1
+    gen = torch.Generator().manual_seed(T)
+    t0 = dev(torch.randn(T, H, generator=gen) * 0.1)
+    Wd = dev(torch.randn(E * H, I, generator=gen) * 0.05)
+    gu0 = torch.randn(T, 2 * I, generator=gen)
+    grp = {}
+    if offsets is not None:
+        grp = dict(groups=E, group_offsets=dev(torch.tensor(offsets, dtype=torch.int32)), strideB=H * I)
+    with ops.f32_matmul("split3"), ops.amax_reuse(everything=True) as cache:
+        dhm = torch.empty(T, I, device=DEV)
+        ops.linear_dgrad(t0, H, Wd, I, dhm, I, T, H, I, **grp)
+        want = dev(gu0)
+        ops.swiglu_bwd_ld(want, 2 * I, T, I, dhm, p, seed)
+        got = dev(gu0)
+        dummy = torch.full((T, I), 5.0, device=DEV)
+        ops.gemm(t0, H, 1, Wd, 1, I, dummy, I, T, I, H, p_drop=p, seed=seed, swiglu_bwd=(got, 2 * I), **grp)
+        key = cache._key(got.data_ptr(), (1, 0, 1, T * 2 * I, T * 2 * I))
+        assert key in cache.pending
+        slot = _slot_value(cache.pending[key])
+    assert bool((dummy == 5.0).all()), "C must not be written"
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-6 * scale, float((got - want).abs().max()) / scale
+    assert slot == float(got.abs().max())
+    # rows outside every expert segment (grouped form with gaps) keep their gate | up values
+    if offsets is not None and offsets[0] > 0:
+        assert torch.equal(got[:offsets[0]].cpu(), gu0[:offsets[0]])
+
+
 def test_colsum_reduce_batched_equals_the_single_table_kernel():
     rows, cols, n = 2048, 256, 5
     gen = torch.Generator().manual_seed(0)
