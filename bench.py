@@ -139,6 +139,9 @@ class KernelTimer:
                 kind = "gemm_fwd_resid"                 # fused residual + dropout epilogue (a different instantiation)
             if kw.get("rowdot") is not None:
                 kind = "gemm_dgrad_delta"               # o_proj dgrad that also emits the attention backward's delta
+            if kw.get("swiglu_bwd") is not None:
+                kind = "gemm_dgrad_swiglu"              # down-projection dgrad with the SwiGLU backward in its epilogue: C is not
+                timer._bytes = (M * K + N * K) * esz + 4 * M * N * esz     # stored; gate | up are read and overwritten (4 M N)
             timer._next = (kind, 2.0 * M * N * K)
             return orig_gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, **kw)
 
