@@ -87,6 +87,7 @@ class GemmBf16Desc(C.Structure):
         ("qk_act_idx", c_void_p), ("qk_pos_ids", c_void_p),
         ("qk_q_rot", c_void_p), ("qk_k_rot", c_void_p),
         ("qk_S", c_int), ("qk_nq", c_int), ("qk_nkv", c_int),
+        ("sw_gu", c_void_p), ("sw_ld", c_int64),
     ]
 
 

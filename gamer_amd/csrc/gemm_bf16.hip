@@ -85,6 +85,9 @@ struct GemmBf16Params {
     const int32_t* qk_act_idx; const int32_t* qk_pos_ids;
     bf16_t* qk_q_rot; bf16_t* qk_k_rot;
     int qk_S, qk_nq, qk_nkv;
+    // EPI 4 (input gradient of the experts' down projection): C = d(hm) is rounded to bf16 and consumed by the SwiGLU backward in
+    // the epilogue - sw_gu[row][col] <- d gate, sw_gu[row][N + col] <- d up (gamer_swiglu_bwd_ld_bf16's arithmetic) - not stored
+    bf16_t* sw_gu; int64_t sw_ld;
 };
 
 __device__ __forceinline__ int xcd_remap_b(int id, int n) {
@@ -279,6 +282,70 @@ __device__ __forceinline__ void hb_epilogue(const GemmBf16Params& p, f32x16 (&ac
                         *reinterpret_cast<bf16x8*>(rot + c) = __builtin_convertvector(o0, bf16x8);
                         *reinterpret_cast<bf16x8*>(rot + 32 + c) = __builtin_convertvector(o1, bf16x8);
                     }
+                }
+            }
+        } else if (EPI == 4) {
+            const DropoutRng rng(p.p_drop, p.seed);
+            if (interior) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = row0 + wm * 64 + i * 32 + r32;
+                    const int cbase = col0 + wn * 64 + 8 * h;
+                    bf16_t* grow = p.sw_gu + (int64_t)row * p.sw_ld + cbase;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int t2 = 0; t2 < 2; ++t2) {
+                            // (the lane-half swap of the plain store: 8 consecutive columns 16 t2 + 8 h .. per lane)
+                            float v[8];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * t2 + e]),
+                                                                                 __float_as_uint(acc[i][j][8 * t2 + 4 + e]), false, false);
+                                v[e] = __uint_as_float(sw[0]);
+                                v[4 + e] = __uint_as_float(sw[1]);
+                            }
+                            bf16_t* ga = grow + j * 32 + 16 * t2;
+                            const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(ga);
+                            const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(ga + p.N);
+                            const int64_t e0 = (int64_t)row * p.N + cbase + j * 32 + 16 * t2;      // flat index of d(hm): the dropout word
+                            float m0[4], m1[4];
+                            rng.mult4((uint32_t)(e0 >> 2), m0);
+                            rng.mult4((uint32_t)(e0 >> 2) + 1u, m1);
+                            const float m[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+                            f32x8v dg, du;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float d = m[e] * round_as<bf16_t>(v[e]);       // (d(hm) is a bf16 tensor in the unfused path)
+                                const float a = (float)a8[e], b = (float)b8[e];
+                                dg[e] = d * b * dsilu_f(a);
+                                du[e] = d * silu_f(a);
+                            }
+                            *reinterpret_cast<bf16x8*>(ga) = __builtin_convertvector(dg, bf16x8);
+                            *reinterpret_cast<bf16x8*>(ga + p.N) = __builtin_convertvector(du, bf16x8);
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = row0 + wm * 64 + i * 32 + r32;
+                    if (row >= row_end) continue;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int col = col0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            if (col < col_end) {
+                                bf16_t* ga = p.sw_gu + (int64_t)row * p.sw_ld + col;
+                                const float a = (float)ga[0], b = (float)ga[p.N];
+                                const int64_t e = (int64_t)row * p.N + col;
+                                float m[4];
+                                rng.mult4((uint32_t)(e >> 2), m);
+                                const float d = m[e & 3] * round_as<bf16_t>(acc[i][j][r]);
+                                ga[0] = (bf16_t)(d * b * dsilu_f(a));
+                                ga[p.N] = (bf16_t)(d * silu_f(a));
+                            }
+                        }
                 }
             }
         } else {
@@ -1145,6 +1212,7 @@ extern "C" int gamer_gemm_bf16(const gamer_gemm_bf16_desc* d, void* stream) {
     p.qk_bias_q = d->qk_bias_q; p.qk_bias_k = d->qk_bias_k; p.qk_bias_v = d->qk_bias_v; p.qk_act_idx = d->qk_act_idx;
     p.qk_pos_ids = d->qk_pos_ids; p.qk_q_rot = (bf16_t*)d->qk_q_rot; p.qk_k_rot = (bf16_t*)d->qk_k_rot;
     p.qk_S = d->qk_S; p.qk_nq = d->qk_nq; p.qk_nkv = d->qk_nkv;
+    p.sw_gu = (bf16_t*)d->sw_gu; p.sw_ld = d->sw_ld;
     p.n_tiles = (d->N + HB_BN - 1) / HB_BN;
     hipStream_t st = (hipStream_t)stream;
     if (d->group_mode == 0) {
@@ -1180,6 +1248,15 @@ extern "C" int gamer_gemm_bf16(const gamer_gemm_bf16_desc* d, void* stream) {
                 return launch_big<3, false>(q, q.m_tiles * q.n_tiles, st);
             }
             return launch_hb<3, false>(p, (int)blocks, st);
+        }
+        if (d->sw_gu) {
+            // input gradient of the down projection with the SwiGLU backward in the epilogue (128 x 128 form: the epilogue's
+            // temporaries do not fit beside the 256 x 256 form's accumulators)
+            GAMER_CHECK_ARG(!d->accumulate && !d->resid && !d->rowdot_out && d->N % 8 == 0 && d->sw_ld % 8 == 0 &&
+                            d->sw_ld >= 2 * (int64_t)d->N && aligned16(d->sw_gu) && d->p_drop >= 0.f && d->p_drop < 1.f,
+                            "gamer_gemm_bf16: the SwiGLU-backward epilogue needs a plain input-gradient GEMM, N %% 8 == 0 and "
+                            "sw_ld >= 2 N, sw_ld %% 8 == 0 (N=%d sw_ld=%lld)", d->N, (long long)d->sw_ld);
+            return launch_hb<4, false>(p, (int)blocks, st);
         }
         static int big = -1;
         // 0: 128^2 only; 1 (default): 256^2 where its last column tile is well filled, else the wave-specialised 256 x 128

@@ -878,7 +878,7 @@ class Engine:
         do_amax = (dict(c_amax=(ws.dao, 0)) if (split_attn and self.h2_attention and self.matmul == "split3" and p_att < 0.75 and
                                                    self.gemm_c_amax) else {})
 
-        fuse_swiglu_bwd = (not bf16) and self.matmul == "split3" and self.fuse_swiglu_bwd
+        fuse_swiglu_bwd = (bf16 or self.matmul == "split3") and self.fuse_swiglu_bwd
 
         def dgrad(dy, lddy, Wf, Wt, ldw, dx, lddx, n_out, k_in, **kw):
             """dx[T,k_in] (+)= dy[T,n_out] @ W[n_out,k_in]: fp32 reads W itself (row-contiguous B operand), bf16 the
@@ -951,8 +951,12 @@ class Engine:
                 if fuse_swiglu_bwd:
                     # the down projection's input gradient with the SwiGLU backward in its epilogue: d(hm) = t0 W_down never goes
                     # to memory, A["gu"] <- d gate | d up (gamer_gemm_desc.sw_gu; ws.dhm is only the descriptor's C)
-                    ops.gemm(t0, H, 1, W.down, 1, I, ws.dhm, I, T, I, H, strideB=H * I, p_drop=p_res, seed=self._seed(l, 4),
-                             swiglu_bwd=(A["gu"], 2 * I), **grp)
+                    if bf16:
+                        ops.linear_dgrad_t(t0, H, WT.down, WT.down.shape[1], ws.dhm, I, T, H, I, strideB=H * I, p_drop=p_res,
+                                           seed=self._seed(l, 4), swiglu_bwd=(A["gu"], 2 * I), **grp)
+                    else:
+                        ops.gemm(t0, H, 1, W.down, 1, I, ws.dhm, I, T, I, H, strideB=H * I, p_drop=p_res, seed=self._seed(l, 4),
+                                 swiglu_bwd=(A["gu"], 2 * I), **grp)
                 else:
                     dgrad(t0, H, W.down, WT.down if bf16 else None, I, ws.dhm, I, H, I, strideB=H * I, **grp)
             if not fuse_swiglu_bwd:

@@ -457,7 +457,7 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
     gamer_gemm_bf16 (k-contiguous x k-contiguous, or the token-major wgrad form; see gamer_gemm_bf16_desc)."""
     if A.dtype == torch.bfloat16:
         return _gemm_bf16(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha, accumulate, groups, group_mode,
-                          group_offsets, strideB, strideC, kchunk, resid, row_map, p_drop, seed, rowdot, qknorm)
+                          group_offsets, strideB, strideC, kchunk, resid, row_map, p_drop, seed, rowdot, qknorm, swiglu_bwd)
     d = GemmDesc()
     d.A = ptr(A); d.a_rs = a_rs; d.a_ks = a_ks
     d.B = ptr(Bm); d.b_rs = b_rs; d.b_ks = b_ks
@@ -528,7 +528,7 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
 
 
 def _gemm_bf16(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha, accumulate, groups, group_mode, group_offsets,
-               strideB, strideC, kchunk, resid, row_map, p_drop, seed, rowdot, qknorm=None):
+               strideB, strideC, kchunk, resid, row_map, p_drop, seed, rowdot, qknorm=None, swiglu_bwd=None):
     if Bm.dtype != torch.bfloat16 or alpha != 1.0:
         raise RuntimeError("gamer_gemm_bf16 takes two bf16 operands and alpha = 1")
     d = GemmBf16Desc()
@@ -560,6 +560,8 @@ def _gemm_bf16(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha, accumulat
         d.qk_act_idx, d.qk_pos_ids = ptr(q.get("act_idx")), ptr(q.get("pos_ids"))
         d.qk_q_rot, d.qk_k_rot = ptr(q["q_rot"]), ptr(q["k_rot"])
         d.qk_S, d.qk_nq, d.qk_nkv = int(q["S"]), int(q["nq"]), int(q["nkv"])
+    if swiglu_bwd is not None:             # (gu, ld): see gamer_gemm_bf16_desc.sw_gu
+        d.sw_gu, d.sw_ld = ptr(swiglu_bwd[0]), int(swiglu_bwd[1])
     call("gamer_gemm_bf16", C.byref(d), stream_ptr())
 
 

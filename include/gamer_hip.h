@@ -352,6 +352,12 @@ typedef struct {
     const int32_t* qk_act_idx; const int32_t* qk_pos_ids;
     gamer_bf16* qk_q_rot; gamer_bf16* qk_k_rot;
     int qk_S, qk_nq, qk_nkv;
+    /* SwiGLU-backward epilogue (group_mode 0, no other epilogue, no accumulate): as gamer_gemm_desc.sw_gu - this GEMM is the input
+     * gradient of the experts' down projection; C = d(hm), rounded to bf16, is consumed in the tile and NOT stored, sw_gu (the
+     * [M][sw_ld] bf16 buffer of the fused gate|up projection, N = the intermediate size) becomes d gate | d up exactly as
+     * gamer_swiglu_bwd_ld_bf16 would make it (p_drop / seed of this descriptor).  NULL = off. */
+    gamer_bf16* sw_gu;
+    int64_t sw_ld;
 } gamer_gemm_bf16_desc;
 
 int gamer_gemm_bf16(const gamer_gemm_bf16_desc* d, void* stream);

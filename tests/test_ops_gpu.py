@@ -917,6 +917,31 @@ def test_gemm_swiglu_backward_epilogue_equals_dgrad_then_swiglu_bwd(T, offsets):
         assert torch.equal(got[:offsets[0]].cpu(), gu0[:offsets[0]])
 
 
+@pytest.mark.parametrize("T,offsets", [(1024, None), (700, [0, 0, 130, 131, 389, 389, 700]), (37, None)])
+def test_gemm_bf16_swiglu_backward_epilogue_is_bit_identical_to_the_two_kernels(T, offsets):
+    """gamer_gemm_bf16_desc.sw_gu: d(hm) is rounded to bf16 in the tile exactly as the unfused GEMM stores it, so the fused
+    epilogue must reproduce gamer_gemm_bf16 + gamer_swiglu_bwd_ld_bf16 bit for bit (plain, ragged expert segments)."""
+    H, I, p, seed = 256, 512, 0.2, 13
+    BF = torch.bfloat16
+    E = 6 if offsets is not None else 1
+    gen = torch.Generator().manual_seed(T + 1)
+    t0 = dev((torch.randn(T, H, generator=gen) * 0.1).to(BF))
+    WT = dev((torch.randn(E * I, H, generator=gen) * 0.05).to(BF))          # per expert: W_down^T [I, H]
+    gu0 = torch.randn(T, 2 * I, generator=gen).to(BF)
+    grp = {}
+    if offsets is not None:
+        grp = dict(groups=E, group_offsets=dev(torch.tensor(offsets, dtype=torch.int32)), strideB=H * I)
+    dhm = torch.empty(T, I, dtype=BF, device=DEV)
+    ops.linear_dgrad_t(t0, H, WT, H, dhm, I, T, H, I, **grp)
+    want = dev(gu0)
+    ops.swiglu_bwd_ld(want, 2 * I, T, I, dhm, p, seed)
+    got = dev(gu0)
+    dummy = torch.full((T, I), 5.0, dtype=BF, device=DEV)
+    ops.linear_dgrad_t(t0, H, WT, H, dummy, I, T, H, I, p_drop=p, seed=seed, swiglu_bwd=(got, 2 * I), **grp)
+    assert bool((dummy == 5.0).all()), "C must not be written"
+    assert torch.equal(got, want)
+
+
 def test_colsum_reduce_batched_equals_the_single_table_kernel():
     rows, cols, n = 2048, 256, 5
     gen = torch.Generator().manual_seed(0)
