@@ -686,6 +686,92 @@ qknorm_rope_bwd_kernel(const TA* __restrict__ qkv, const TA* __restrict__ dq_rot
     }
 }
 
+// fp32, self attention (no behaviour biases): token-major like qknorm_rope_fwd_tok_kernel - one 16-lane group per token walks its
+// q and k heads three at a time (six 16-byte loads in flight per lane), cos / sin once per token; the two norm-weight gradients
+// accumulate in registers over all the heads of all the tokens of the wave and leave as ONE partial row [dwq | dwk] per wave
+// (qknorm_partial_reduce_kernel with nq = nkv = 1 folds them).  Same arithmetic per element as qknorm_rope_bwd_kernel.
+__global__ void __launch_bounds__(EW_THREADS)
+qknorm_rope_bwd_tok_kernel(const float* __restrict__ qkv, const float* __restrict__ dq_rot, const float* __restrict__ dk_rot,
+                           int T, int S, int nq, int nkv, const float* __restrict__ wq, const float* __restrict__ wk, float eps,
+                           const float* __restrict__ cos_t, const float* __restrict__ sin_t, float* __restrict__ dqkv,
+                           float* __restrict__ partial, int n_waves, const int32_t* __restrict__ pos_ids,
+                           uint32_t* __restrict__ amax_out) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane & 15, sub = lane >> 4;
+    const int wave = (int)(((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6);
+    if (wave >= n_waves) return;
+    float am = 0.f;
+    const int nqk = nq + nkv;
+    const int ldqkv = (nq + 2 * nkv) * 64;
+    const float4 wq4 = reinterpret_cast<const float4*>(wq)[g], wk4 = reinterpret_cast<const float4*>(wk)[g];
+    float4 dwq = make_float4(0.f, 0.f, 0.f, 0.f), dwk = dwq;
+    const float sgn = g < 8 ? 1.f : -1.f;             // transpose of the rotation
+    for (int tb = wave * 4; tb < T; tb += n_waves * 4) {
+        const int t = tb + sub;
+        const bool live = t < T;
+        const int tc = live ? t : T - 1;
+        const int pos = pos_ids ? pos_ids[tc] : tc % S;
+        const float4 c4 = reinterpret_cast<const float4*>(cos_t + pos * 64)[g];
+        const float4 s4 = reinterpret_cast<const float4*>(sin_t + pos * 64)[g];
+        const float* xrow = qkv + (int64_t)tc * ldqkv + 4 * g;
+        const float* dqrow = dq_rot + (int64_t)tc * nq * 64 + 4 * g;
+        const float* dkrow = dk_rot + (int64_t)tc * nkv * 64 + 4 * g;
+        const float lv = live ? 1.f : 0.f;
+        for (int h0 = 0; h0 < nqk; h0 += 3) {
+            float4 xs[3], ds[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int hd = min(h0 + u, nqk - 1);
+                xs[u] = ld4(xrow + hd * 64);
+                ds[u] = hd < nq ? ld4(dqrow + hd * 64) : ld4(dkrow + (hd - nq) * 64);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int hd = h0 + u;
+                if (hd >= nqk) break;                       // (uniform over the wave)
+                const bool isq = hd < nq;
+                const float4 x = xs[u], d = ds[u];
+                const float4 w4 = isq ? wq4 : wk4;
+                float4 dp;
+                dp.x = __shfl_xor(d.x, 8, 64); dp.y = __shfl_xor(d.y, 8, 64); dp.z = __shfl_xor(d.z, 8, 64); dp.w = __shfl_xor(d.w, 8, 64);
+                float4 dy;
+                dy.x = d.x * c4.x + sgn * dp.x * s4.x; dy.y = d.y * c4.y + sgn * dp.y * s4.y;
+                dy.z = d.z * c4.z + sgn * dp.z * s4.z; dy.w = d.w * c4.w + sgn * dp.w * s4.w;
+                const float ss = group16_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
+                const float rstd = rsqrtf(ss * (1.f / 64.f) + eps);
+                float4 xh;
+                xh.x = x.x * rstd; xh.y = x.y * rstd; xh.z = x.z * rstd; xh.w = x.w * rstd;
+                if (isq) { dwq.x += lv * dy.x * xh.x; dwq.y += lv * dy.y * xh.y; dwq.z += lv * dy.z * xh.z; dwq.w += lv * dy.w * xh.w; }
+                else { dwk.x += lv * dy.x * xh.x; dwk.y += lv * dy.y * xh.y; dwk.z += lv * dy.z * xh.z; dwk.w += lv * dy.w * xh.w; }
+                float4 gg;
+                gg.x = dy.x * w4.x; gg.y = dy.y * w4.y; gg.z = dy.z * w4.z; gg.w = dy.w * w4.w;
+                const float dot = group16_sum(gg.x * xh.x + gg.y * xh.y + gg.z * xh.z + gg.w * xh.w) * (1.f / 64.f);
+                float4 dx;
+                dx.x = rstd * (gg.x - xh.x * dot); dx.y = rstd * (gg.y - xh.y * dot);
+                dx.z = rstd * (gg.z - xh.z * dot); dx.w = rstd * (gg.w - xh.w * dot);
+                if (live) {
+                    st4(dqkv + (int64_t)t * ldqkv + hd * 64 + 4 * g, dx);
+                    am = fmaxf(fmaxf(fmaxf(am, fabsf(dx.x)), fabsf(dx.y)), fmaxf(fabsf(dx.z), fabsf(dx.w)));
+                }
+            }
+        }
+    }
+    if (amax_out) {
+        uint32_t m = __float_as_uint(am);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        if (lane == 0 && m) amax_publish(m, amax_out, (uint32_t)wave);
+    }
+    auto fold = [&](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
+    float* prow = partial + (int64_t)wave * 128;
+    const float a0 = fold(dwq.x), a1 = fold(dwq.y), a2 = fold(dwq.z), a3 = fold(dwq.w);
+    const float b0 = fold(dwk.x), b1 = fold(dwk.y), b2 = fold(dwk.z), b3 = fold(dwk.w);
+    if (sub == 0) {
+        reinterpret_cast<float4*>(prow)[g] = make_float4(a0, a1, a2, a3);
+        reinterpret_cast<float4*>(prow + 64)[g] = make_float4(b0, b1, b2, b3);
+    }
+}
+
 // ---- bf16 activations: 8 lanes x 8 elements (16 bytes) per (token, head) row, 8 rows per wave --------------------
 // Same arithmetic as the <bf16_t> instantiations of the kernels above (which move 8 bytes per lane and ran at
 // 2.4 TB/s); the RoPE partner (d +- 32) is lane +- 4 of the 8-lane group.
@@ -1663,6 +1749,21 @@ static int qknorm_rope_bwd_impl(const char* name, const TA* qkv, const TA* dq_ro
                                dq_rot, dk_rot, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, cross, bias_q, bias_k, act_idx, nb1,
                                dqkv, partial, waves_per_head, pos_ids);
     } else {
+        static const bool row_major = getenv("GAMER_QKNORM_ROW_MAJOR") != nullptr;       // (the round-1 form, kept for A/B runs)
+        int n_waves = (T + 3) / 4;
+        if (n_waves > 8192) n_waves = 8192;
+        if ((int64_t)n_waves * 128 > partial_numel) n_waves = (int)(partial_numel / 128);
+        if (!cross && !row_major && n_waves >= 1) {
+            // self attention: token-major (one partial row [dwq | dwk] per wave; the reduce sees one q and one k "head")
+            hipLaunchKernelGGL(qknorm_rope_bwd_tok_kernel, dim3((n_waves + EW_WAVES - 1) / EW_WAVES), dim3(EW_THREADS), 0, ST(stream),
+                               qkv, dq_rot, dk_rot, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, dqkv, partial, n_waves, pos_ids,
+                               take_amax_sink().out[0]);
+            GAMER_CHECK_LAUNCH(name);
+            hipLaunchKernelGGL(qknorm_partial_reduce_kernel, dim3(128 / QKR_CW), dim3(1024), 0, ST(stream), partial, n_waves, 1, 1, 0,
+                               0, dwq, dwk, dbias_q, dbias_k, dbias_v);
+            GAMER_CHECK_LAUNCH(name);
+            return 0;
+        }
         hipLaunchKernelGGL(qknorm_rope_bwd_kernel<TA>, dim3(blocks), dim3(EW_THREADS), 0, ST(stream), qkv, dq_rot, dk_rot, T,
                            S, nq, nkv, wq, wk, eps, cos_t, sin_t, cross, bias_q, bias_k, act_idx, nb1, dqkv, partial,
                            waves_per_head, pos_ids, take_amax_sink().out[0]);
