@@ -99,6 +99,8 @@ _SIGNATURES = {
     "gamer_expert_lists": [P, I, I, I, P, P, P, P, P],
     "gamer_embedding_fwd": [P, P, I, I, I, P, P],
     "gamer_embedding_bwd": [P, P, I, I, I, I, P, P],
+    "gamer_embedding_bwd_ordered": [P, P, I, I, I, I, P, P, L, P],
+    "gamer_embedding_bwd_ordered_ws_bytes": [I, I, I],
     "gamer_rmsnorm_fwd": [P, P, I, I, F, P, P, I, P],
     "gamer_rmsnorm_bwd": [P, P, P, I, P, I, I, F, I, P, P, I, P, P, F, U, P],
     "gamer_colsum_reduce": [P, I, I, I, P, P],
@@ -185,6 +187,7 @@ def load(build_if_missing: bool = False) -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = c_int
         fn.argtypes = args
+    lib.gamer_embedding_bwd_ordered_ws_bytes.restype = c_int64      # (a size, not an error code: call it on the library object)
     _lib = lib
     return lib
 

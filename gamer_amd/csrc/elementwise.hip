@@ -93,6 +93,168 @@ embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ 
     }
 }
 
+// ---- the same gradient without float atomics: a stable counting sort of the tokens by id, then sums in sorted order ----
+// (1) per-chunk histograms of the ids (integer LDS atomics: the counts do not depend on their order), (2) one workgroup turns
+// them into every chunk's write cursors (rows ascending, chunks ascending inside a row: a STABLE order) and cuts every row's
+// token list into pieces of EMB_PIECE tokens, (3) every chunk writes its token indices to their sorted positions in token
+// order, (4) one workgroup per piece adds its <= EMB_PIECE rows of dx in sorted order, (5) one workgroup per table row adds its
+// pieces in order into dW.  Same bits on every run; 517k tokens x 256: five launches, ~0.3 ms (the atomic form: 0.75 ms).
+constexpr int EMB_SORT_CHUNK = 1024;
+constexpr int EMB_PIECE = 256;
+constexpr int EMB_MAX_V = 8191;          // (V + 1 counters in LDS)
+struct EmbSortWs { int* hist; int* row_start; int* row_count; int* piece_start; int* perm; float* partial; };
+
+__global__ void __launch_bounds__(EW_THREADS)
+emb_hist_kernel(const int64_t* __restrict__ ids, int V, int T, int pad_id, int* __restrict__ hist) {
+    extern __shared__ int emb_cnt[];                             // [V + 1]: bucket V = padding / out-of-range ids
+    for (int v = threadIdx.x; v <= V; v += EW_THREADS) emb_cnt[v] = 0;
+    __syncthreads();
+    const int t0 = blockIdx.x * EMB_SORT_CHUNK, t1 = min(T, t0 + EMB_SORT_CHUNK);
+    for (int t = t0 + threadIdx.x; t < t1; t += EW_THREADS) {
+        const int64_t id = ids[t];
+        atomicAdd(&emb_cnt[(id == pad_id || id < 0 || id >= V) ? V : (int)id], 1);
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v <= V; v += EW_THREADS) hist[(int64_t)blockIdx.x * (V + 1) + v] = emb_cnt[v];
+}
+
+// one wave per table row v: hist[c][v] -> exclusive prefix over the chunks c, row_count[v] = the row's total
+__global__ void __launch_bounds__(64)
+emb_chunk_scan_kernel(int V, int n_chunks, int* __restrict__ hist, int* __restrict__ row_count) {
+    const int v = blockIdx.x, lane = threadIdx.x;
+    int carry = 0;
+    for (int c0 = 0; c0 < n_chunks; c0 += 64) {
+        const int c = c0 + lane;
+        const int h = c < n_chunks ? hist[(int64_t)c * (V + 1) + v] : 0;
+        int incl = h;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (c < n_chunks) hist[(int64_t)c * (V + 1) + v] = carry + incl - h;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) row_count[v] = carry;
+}
+// one workgroup: row_start[v] = tokens in front of row v, piece_start[v] = pieces in front of it (v = 0 .. V; [V + 1] = the end)
+__global__ void __launch_bounds__(1024)
+emb_row_scan_kernel(int V, const int* __restrict__ row_count, int* __restrict__ row_start, int* __restrict__ piece_start) {
+    __shared__ int s_tok[1024], s_pc[1024];
+    const int tid = threadIdx.x;
+    const int per = (V + 1 + 1023) / 1024;                        // rows per thread (<= 8)
+    int tok = 0, pc = 0;
+    for (int i = 0; i < per; ++i) {
+        const int v = tid * per + i;
+        if (v <= V) {
+            const int n = row_count[v];
+            tok += n;
+            if (v < V) pc += (n + EMB_PIECE - 1) / EMB_PIECE;
+        }
+    }
+    s_tok[tid] = tok; s_pc[tid] = pc;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                          // inclusive scans of the per-thread sums
+        const int a = tid >= o ? s_tok[tid - o] : 0, b = tid >= o ? s_pc[tid - o] : 0;
+        __syncthreads();
+        s_tok[tid] += a; s_pc[tid] += b;
+        __syncthreads();
+    }
+    int t_run = s_tok[tid] - tok, p_run = s_pc[tid] - pc;
+    for (int i = 0; i < per; ++i) {
+        const int v = tid * per + i;
+        if (v <= V) {
+            row_start[v] = t_run;
+            piece_start[v] = p_run;
+            const int n = row_count[v];
+            t_run += n;
+            if (v < V) p_run += (n + EMB_PIECE - 1) / EMB_PIECE;
+        }
+    }
+    if (tid == 1023) piece_start[V + 1] = s_pc[1023];
+}
+
+__global__ void __launch_bounds__(EW_THREADS)
+emb_scatter_kernel(const int64_t* __restrict__ ids, int V, int T, int pad_id, const int* __restrict__ hist,
+                   const int* __restrict__ row_start, int* __restrict__ perm) {
+    extern __shared__ int emb_cur[];                             // [V + 1] write cursors of this chunk, then its [1024] buckets
+    int* bucket = emb_cur + V + 1;
+    const int t0 = blockIdx.x * EMB_SORT_CHUNK, t1 = min(T, t0 + EMB_SORT_CHUNK);
+    for (int v = threadIdx.x; v <= V; v += EW_THREADS) emb_cur[v] = row_start[v] + hist[(int64_t)blockIdx.x * (V + 1) + v];
+    for (int t = t0 + threadIdx.x; t < t1; t += EW_THREADS) {
+        const int64_t id = ids[t];
+        bucket[t - t0] = (id == pad_id || id < 0 || id >= V) ? -1 : (int)id;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                      // token order inside the chunk: one thread walks it (LDS only)
+        for (int t = t0; t < t1; ++t) {
+            const int b = bucket[t - t0];
+            if (b >= 0) perm[emb_cur[b]++] = t;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(EW_THREADS)
+emb_piece_sum_kernel(const float4* __restrict__ dx, int V, int H4, const int* __restrict__ row_start, const int* __restrict__ row_count,
+                     const int* __restrict__ piece_start, const int* __restrict__ perm, float4* __restrict__ partial) {
+    __shared__ float4 red[3][256];
+    const int p = blockIdx.x;
+    if (p >= piece_start[V]) return;
+    int lo = 0, hi = V;                                          // the row of piece p: last v with piece_start[v] <= p
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (piece_start[mid] <= p) lo = mid; else hi = mid; }
+    const int v = lo, k = p - piece_start[v];
+    const int begin = row_start[v] + k * EMB_PIECE;
+    const int count = min(EMB_PIECE, row_count[v] - k * EMB_PIECE);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // wave w adds tokens [w * 64, w * 64 + 64) of the piece in order; the four sums are then combined in a fixed order
+    for (int c0 = 0; c0 < H4; c0 += 64) {
+        const int c = c0 + lane;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < H4) {
+            const int j1 = min(count, (w + 1) * (EMB_PIECE / 4));
+            int j = w * (EMB_PIECE / 4);
+            for (; j + 4 <= j1; j += 4) {
+                const int r0 = perm[begin + j], r1 = perm[begin + j + 1], r2 = perm[begin + j + 2], r3 = perm[begin + j + 3];
+                const float4 a0 = dx[(int64_t)r0 * H4 + c], a1 = dx[(int64_t)r1 * H4 + c], a2 = dx[(int64_t)r2 * H4 + c],
+                             a3 = dx[(int64_t)r3 * H4 + c];
+                acc.x = (((acc.x + a0.x) + a1.x) + a2.x) + a3.x; acc.y = (((acc.y + a0.y) + a1.y) + a2.y) + a3.y;
+                acc.z = (((acc.z + a0.z) + a1.z) + a2.z) + a3.z; acc.w = (((acc.w + a0.w) + a1.w) + a2.w) + a3.w;
+            }
+            for (; j < j1; ++j) {
+                const float4 a0 = dx[(int64_t)perm[begin + j] * H4 + c];
+                acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+            }
+        }
+        if (w > 0 && c < H4) red[w - 1][lane] = acc;
+        __syncthreads();
+        if (w == 0 && c < H4) {
+            const float4 b = red[0][lane], d = red[1][lane], e = red[2][lane];
+            float4 o;
+            o.x = (acc.x + b.x) + (d.x + e.x); o.y = (acc.y + b.y) + (d.y + e.y);
+            o.z = (acc.z + b.z) + (d.z + e.z); o.w = (acc.w + b.w) + (d.w + e.w);
+            partial[(int64_t)p * H4 + c] = o;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(64)
+emb_row_sum_kernel(int H4, const int* __restrict__ piece_start, const float4* __restrict__ partial, float4* __restrict__ dW) {
+    const int v = blockIdx.x;
+    const int p0 = piece_start[v], p1 = piece_start[v + 1];
+    if (p0 == p1) return;
+    for (int c = threadIdx.x; c < H4; c += 64) {
+        float4 s = partial[(int64_t)p0 * H4 + c];
+        for (int p = p0 + 1; p < p1; ++p) {
+            const float4 a = partial[(int64_t)p * H4 + c];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        float4 o = dW[(int64_t)v * H4 + c];
+        o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+        dW[(int64_t)v * H4 + c] = o;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // RMSNorm (hidden dim H <= 1024, H % 4 == 0); one wave per row, row cached in registers
 // ---------------------------------------------------------------------------------------------
@@ -1514,6 +1676,52 @@ extern "C" int gamer_embedding_bwd(const int64_t* ids, const float* dx, int V, i
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3((T + chunk - 1) / chunk), dim3(EW_THREADS),
                        (size_t)EMB_CACHE * H * sizeof(float), ST(stream), ids, dx, V, T, H, pad_id, dW, chunk);
     GAMER_CHECK_LAUNCH("gamer_embedding_bwd");
+    return 0;
+}
+
+// bytes of the workspace gamer_embedding_bwd_ordered needs
+extern "C" int64_t gamer_embedding_bwd_ordered_ws_bytes(int V, int T, int H) {
+    if (V <= 0 || T <= 0 || H <= 0) return -1;
+    const int64_t chunks = (T + EMB_SORT_CHUNK - 1) / EMB_SORT_CHUNK;
+    const int64_t pieces = (int64_t)T / EMB_PIECE + V + 1;
+    const int64_t ints = chunks * (V + 1) + 2 * (int64_t)(V + 1) + (V + 2) + T;
+    return ((ints * 4 + 15) / 16) * 16 + pieces * H * 4;
+}
+extern "C" int gamer_embedding_bwd_ordered(const int64_t* ids, const float* dx, int V, int T, int H, int pad_id, float* dW,
+                                           void* ws, int64_t ws_bytes, void* stream) {
+    GAMER_CHECK_ARG(ids && dx && dW && ws, "gamer_embedding_bwd_ordered: null pointer");
+    GAMER_CHECK_ARG(T > 0 && H > 0 && H % 4 == 0 && V > 0 && V <= EMB_MAX_V,
+                    "gamer_embedding_bwd_ordered: bad shape T=%d H=%d V=%d (H %% 4 == 0, V <= %d)", T, H, V, EMB_MAX_V);
+    GAMER_CHECK_ARG(aligned16(dx) && aligned16(dW) && aligned16(ws) && ws_bytes >= gamer_embedding_bwd_ordered_ws_bytes(V, T, H),
+                    "gamer_embedding_bwd_ordered: dx / dW / ws must be 16-byte aligned and ws hold %lld bytes (got %lld)",
+                    (long long)gamer_embedding_bwd_ordered_ws_bytes(V, T, H), (long long)ws_bytes);
+    const int chunks = (T + EMB_SORT_CHUNK - 1) / EMB_SORT_CHUNK;
+    const int pieces_max = T / EMB_PIECE + V + 1;
+    int* ip = (int*)ws;
+    EmbSortWs w;
+    w.hist = ip; ip += (int64_t)chunks * (V + 1);
+    w.row_start = ip; ip += V + 1;
+    w.row_count = ip; ip += V + 1;
+    w.piece_start = ip; ip += V + 2;
+    w.perm = ip; ip += T;
+    const int64_t ints = (int64_t)chunks * (V + 1) + 2 * (int64_t)(V + 1) + (V + 2) + T;
+    w.partial = (float*)((char*)ws + ((ints * 4 + 15) / 16) * 16);
+    hipStream_t st = ST(stream);
+    const size_t lds = (size_t)(V + 1) * sizeof(int);
+    hipLaunchKernelGGL(emb_hist_kernel, dim3(chunks), dim3(EW_THREADS), lds, st, ids, V, T, pad_id, w.hist);
+    GAMER_CHECK_LAUNCH("gamer_embedding_bwd_ordered/hist");
+    hipLaunchKernelGGL(emb_chunk_scan_kernel, dim3(V + 1), dim3(64), 0, st, V, chunks, w.hist, w.row_count);
+    GAMER_CHECK_LAUNCH("gamer_embedding_bwd_ordered/chunk_scan");
+    hipLaunchKernelGGL(emb_row_scan_kernel, dim3(1), dim3(1024), 0, st, V, w.row_count, w.row_start, w.piece_start);
+    GAMER_CHECK_LAUNCH("gamer_embedding_bwd_ordered/row_scan");
+    hipLaunchKernelGGL(emb_scatter_kernel, dim3(chunks), dim3(EW_THREADS), lds + EMB_SORT_CHUNK * sizeof(int), st, ids, V, T, pad_id,
+                       w.hist, w.row_start, w.perm);
+    GAMER_CHECK_LAUNCH("gamer_embedding_bwd_ordered/scatter");
+    hipLaunchKernelGGL(emb_piece_sum_kernel, dim3(pieces_max), dim3(EW_THREADS), 0, st, (const float4*)dx, V, H / 4, w.row_start,
+                       w.row_count, w.piece_start, w.perm, (float4*)w.partial);
+    GAMER_CHECK_LAUNCH("gamer_embedding_bwd_ordered/pieces");
+    hipLaunchKernelGGL(emb_row_sum_kernel, dim3(V), dim3(64), 0, st, H / 4, w.piece_start, (const float4*)w.partial, (float4*)dW);
+    GAMER_CHECK_LAUNCH("gamer_embedding_bwd_ordered/rows");
     return 0;
 }
 

@@ -494,6 +494,7 @@ class Engine:
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._norm_out_table = None                 # (addresses, device array) of the RMSNorm weight gradients in backward order
         self.fuse_swiglu_bwd = os.environ.get("GAMER_FUSE_SWIGLU_BWD", "1") != "0"     # (A/B switch; split3 only)
+        self.ordered_embedding_grad = os.environ.get("GAMER_EMBEDDING_ATOMICS", "0") == "0"   # (1: the float-atomics scatter)
         self._saved = None
 
     # ------------------------------------------------------------------------------------------
@@ -1012,14 +1013,11 @@ class Engine:
             norm_bwd(xs[0], W.ln1, t3, H, G.ln1, True, branch=(self._seed(l - 1, 5), ws.slot) if l > 0 else None)
             if layer_done is not None:
                 layer_done(l)
-        if self.deterministic and not bf16:
-            # the scatter-add of the embedding gradient as an ordered weight-gradient GEMM: one-hot(ids)^T dx, the one-hot matrix
-            # in the logits buffer (d(logits) is dead by now); pad and out-of-range ids get a zero row (padding_idx, model.py:263)
-            oh, ids = ws.logits, sv["ids"].view(-1)
-            ok = (ids != cfg.pad_token_id) & (ids >= 0) & (ids < V)
-            oh.zero_()
-            oh.scatter_(1, ids.clamp(0, V - 1).unsqueeze(1), ok.to(oh.dtype).unsqueeze(1))
-            ops.linear_wgrad(oh, ws.ldl, ws.dx, H, demb, H, T, V, H)
+        if self.ordered_embedding_grad and V <= 8191:
+            # the scatter-add of the embedding gradient in a fixed order: a stable counting sort of the tokens by id, then sums in
+            # token order (no float atomics: with the ordered weight gradients and table gradients every gradient of the step
+            # has the same bits on every run); pad and out-of-range ids are skipped (padding_idx, model.py:263)
+            ops.embedding_bwd_ordered(sv["ids"], ws.dx, cfg.pad_token_id, demb)
         else:
             ops.embedding_bwd(sv["ids"], ws.dx, cfg.pad_token_id, demb)
         key = tuple(d.data_ptr() for d in norm_dws)

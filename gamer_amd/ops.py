@@ -93,6 +93,21 @@ def embedding_bwd(ids, dx, pad_id, dW):
     call("gamer_embedding_bwd", ptr(ids), ptr(dx), V, T, H, pad_id, ptr(dW), stream_ptr())
 
 
+_EMB_WS = {}
+
+
+def embedding_bwd_ordered(ids, dx, pad_id, dW):
+    """dW[id] += dx rows, without float atomics: the same bits on every run (gamer_embedding_bwd_ordered)."""
+    T = ids.numel()
+    V, H = dW.shape
+    need = int(_lib.load().gamer_embedding_bwd_ordered_ws_bytes(V, T, H))
+    ws = _EMB_WS.get(dx.device)
+    if ws is None or ws.numel() < need:
+        _EMB_WS[dx.device] = None
+        ws = _EMB_WS[dx.device] = torch.empty(need, dtype=torch.uint8, device=dx.device)
+    call("gamer_embedding_bwd_ordered", ptr(ids), ptr(dx), V, T, H, pad_id, ptr(dW), ptr(ws), ws.numel(), stream_ptr())
+
+
 def rmsnorm_fwd(x, w, eps, y, ldy=None, dst_rows=None):
     T, H = x.shape
     ld = ldy if ldy else y.stride(0)

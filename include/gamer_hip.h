@@ -109,6 +109,12 @@ int gamer_expert_lists(const int32_t* expert, int B, int S, int num_experts,
 int gamer_embedding_fwd(const int64_t* ids, const float* W, int V, int T, int H, float* x, void* stream);
 int gamer_embedding_bwd(const int64_t* ids, const float* dx, int V, int T, int H, int pad_id, float* dW,
                         void* stream);
+/* The same gradient WITHOUT float atomics (same bits on every run): a stable counting sort of the tokens by id (integer
+ * counters only), then every table row adds its tokens' rows of dx in token order - pieces of 256 tokens, the pieces in order.
+ * dW += as above.  ws: scratch of gamer_embedding_bwd_ordered_ws_bytes(V, T, H) bytes, 16-byte aligned; V <= 8191, H % 4 == 0. */
+int64_t gamer_embedding_bwd_ordered_ws_bytes(int V, int T, int H);
+int gamer_embedding_bwd_ordered(const int64_t* ids, const float* dx, int V, int T, int H, int pad_id, float* dW,
+                                void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * RMSNorm over the hidden dim (Qwen3RMSNorm, transformers/models/qwen3/modeling_qwen3.py;

@@ -13,7 +13,7 @@ def _parse_header():
     txt = open(_lib.HEADER_PATH).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(gamer_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+    for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(gamer_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
         name, args = m.group(2), m.group(3).strip()
         if args == "void":
             protos[name] = []

@@ -340,3 +340,33 @@ def test_deterministic_engine_repeats_its_gradient_bit_for_bit():
         grads.append(runs[0])
     d = float((grads[0] - grads[1]).abs().max() / grads[1].abs().max())
     assert d < 1e-5, d
+
+
+def test_default_engine_gradient_is_bit_reproducible(monkeypatch):
+    """Round 4: the last float-atomics reduction of the default fp32 step (the embedding gradient's scatter-add) became a stable
+    sort + ordered sums, so the DEFAULT engine repeats its flat gradient bit for bit (the bf16 step's weight gradients still
+    combine their chunks with fp32 atomics); with GAMER_EMBEDDING_ATOMICS=1 the atomics form is back and agrees to rounding."""
+    dtype = "f32"
+    from gamer_amd.config import synthetic_config
+    cfg = synthetic_config()
+    sd = orc.init_state_dict(orc.OracleConfig.from_dict(cfg.to_dict()), seed=2)
+    batch = synthetic.make_batch(24, 101, 256, 3, ragged=True, seed=5, behavior_probs=[0.7, 0.25, 0.05])
+
+    def grads(reps):
+        eng = Engine(cfg, temperature=0.7, dtype=dtype)
+        eng.load_state_dict(sd)
+        eng.base_seed = 99
+        out = []
+        for _ in range(reps):
+            eng.dropout_step = 0
+            eng.forward(batch["input_ids"], batch["attention_mask"], batch["actions"], labels=batch["labels"], train=True)
+            eng.zero_grad()
+            eng.backward(1.0)
+            out.append(eng.flat_g.clone())
+        return out
+    runs = grads(4)
+    assert all(torch.equal(runs[0], r) for r in runs[1:])
+    monkeypatch.setenv("GAMER_EMBEDDING_ATOMICS", "1")
+    atom = grads(1)[0]
+    d = float((runs[0] - atom).abs().max() / atom.abs().max())
+    assert d < 1e-5, d

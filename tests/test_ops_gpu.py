@@ -124,6 +124,54 @@ def test_embedding_fwd_bwd():
     assert _rel(dW, ref) < 1e-5
 
 
+@pytest.mark.parametrize("V,H,T", [(49, 128, 300), (1041, 256, 5000), (7, 64, 1), (300, 1024, 2049)])
+def test_embedding_bwd_ordered_is_exact_in_order_and_repeatable(V, H, T):
+    """gamer_embedding_bwd_ordered: stable sort by id + sums in token order (pieces of 256 tokens).  Against an fp64 scatter-add,
+    against the same sums formed in the kernel's order on the host (bit for bit on a small case), twice the same bits; padding
+    and out-of-range ids are skipped; rows without tokens keep their value; a hot row (a fifth of the tokens) crosses pieces."""
+    gen = torch.Generator().manual_seed(V + T)
+    ids = torch.randint(0, V, (T,), generator=gen)
+    ids[::5] = min(3, V - 1)                          # a hot row
+    pad = 4 if V > 4 else 0
+    if T > 10:
+        ids[7], ids[8] = -1, V + 3                    # out of range: skipped
+    dx = torch.randn(T, H, generator=gen)
+    base = torch.randn(V, H, generator=gen)
+    outs = []
+    for _ in range(2):
+        dW = dev(base.clone())
+        ops.embedding_bwd_ordered(dev(ids), dev(dx), pad, dW)
+        outs.append(dW.cpu())
+    assert torch.equal(outs[0], outs[1])
+    ok = (ids != pad) & (ids >= 0) & (ids < V)
+    ref = base.double().clone()
+    ref.index_put_((ids[ok],), dx[ok].double(), accumulate=True)
+    assert _rel(outs[0], ref) < 1e-6
+    untouched = torch.ones(V, dtype=torch.bool)
+    untouched[ids[ok]] = False
+    assert torch.equal(outs[0][untouched], base[untouched])
+    if T <= 300:
+        # the kernel's order on the host: per row, token order; quarters of a piece summed left to right, then (q0 + q1) + (q2 + q3)
+        want = base.clone()
+        for v in range(V):
+            tok = torch.nonzero(ok & (ids == v)).flatten()
+            if len(tok) == 0:
+                continue
+            tot = None
+            for p0 in range(0, len(tok), 256):
+                piece = tok[p0:p0 + 256]
+                qs = []
+                for q in range(4):
+                    acc = torch.zeros(H)
+                    for t in piece[64 * q:64 * q + 64]:
+                        acc = acc + dx[t]
+                    qs.append(acc)
+                ps = (qs[0] + qs[1]) + (qs[2] + qs[3])
+                tot = ps if tot is None else tot + ps
+            want[v] = want[v] + tot
+        assert torch.equal(outs[0], want)
+
+
 @pytest.mark.parametrize("H", [128, 256])
 def test_rmsnorm_fwd_bwd(H):
     T, ldy = 333, H + 64
