@@ -399,8 +399,8 @@ def parse_args(argv=None):
                     help="gradient accumulation: one step = ACCUM micro-batches of --batch through Engine.train_window (one clip + "
                          "AdamW per window); BASELINE configs[3] is --batch 128 --accum 4 --augment 4")
     ap.add_argument("--deterministic", action="store_true",
-                    help="fp32 forms: every reduction of the step in a fixed order (Engine(deterministic=True): the embedding gradient as "
-                         "an ordered GEMM on top of the default two-pass weight gradients): what bit-reproducible runs cost")
+                    help="Engine(deterministic=True): every reduction of the step in a fixed order whatever the environment says - the "
+                         "default of the fp32 forms anyway; with --dtype bf16 the weight-gradient GEMMs take the two-pass form too")
     ap.add_argument("--augment", type=int, default=0,
                     help="secondary workload: rows shaped like tasks=smb_explicit_decoder_<AUGMENT> (thinned copies, cropped to "
                          "--items, right padded per micro-batch; synthetic.make_augmented_batch)")

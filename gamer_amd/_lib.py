@@ -88,6 +88,7 @@ class GemmBf16Desc(C.Structure):
         ("qk_q_rot", c_void_p), ("qk_k_rot", c_void_p),
         ("qk_S", c_int), ("qk_nq", c_int), ("qk_nkv", c_int),
         ("sw_gu", c_void_p), ("sw_ld", c_int64),
+        ("wgrad_ws", c_void_p), ("wgrad_ws_floats", c_int64),
     ]
 
 

@@ -277,4 +277,8 @@ __device__ __forceinline__ float dsilu_f(float x) {
     return s * (1.f + x * (1.f - s));
 }
 
+// (gemm.hip) C (+)= the chunk partial tiles of an ordered weight gradient, in chunk order; returns hipGetLastError()
+int launch_wgrad_reduce(const float* ws, float* C, int64_t ldc, int M, int N, int groups, const int32_t* group_offsets, int K,
+                        int kchunk, int64_t strideC, hipStream_t st);
+
 }  // namespace gamer

@@ -1380,6 +1380,16 @@ wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int64_t
     }
 }
 
+// host side of the second pass, shared with the bf16 weight-gradient GEMM (gemm_bf16.hip: same tiles, same chunk order)
+int launch_wgrad_reduce(const float* ws, float* C, int64_t ldc, int M, int N, int groups, const int32_t* group_offsets, int K,
+                        int kchunk, int64_t strideC, hipStream_t st) {
+    const int m_tiles = (M + BM - 1) / BM, n_tiles = (N + BN - 1) / BN;
+    const int64_t rblocks = (int64_t)groups * m_tiles * n_tiles * 16;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)rblocks), dim3(256), 0, st, ws, C, ldc, M, N, m_tiles, n_tiles, groups,
+                       group_offsets, K, kchunk, strideC);
+    return (int)hipGetLastError();
+}
+
 // x[i] -> its three bf16 pieces, planes[s * stride + i]  (the cut of split3, four values per thread)
 __global__ void __launch_bounds__(256)
 split3_planes_kernel(const float4* __restrict__ x, uint16_t* __restrict__ planes, int64_t n4, int64_t stride) {

@@ -88,6 +88,9 @@ struct GemmBf16Params {
     // EPI 4 (input gradient of the experts' down projection): C = d(hm) is rounded to bf16 and consumed by the SwiGLU backward in
     // the epilogue - sw_gu[row][col] <- d gate, sw_gu[row][N + col] <- d up (gamer_swiglu_bwd_ld_bf16's arithmetic) - not stored
     bf16_t* sw_gu; int64_t sw_ld;
+    // weight gradient, ordered form: chunk partial tiles [chunk][tile][128][128] (plain stores) instead of fp32 atomics into C;
+    // gemm.hip's wgrad_reduce_kernel adds them in chunk order afterwards
+    float* wgrad_ws;
 };
 
 __device__ __forceinline__ int xcd_remap_b(int id, int n) {
@@ -1067,6 +1070,20 @@ gemm_bf16_wgrad_kernel(const GemmBf16Params p, const bf16_t* __restrict__ zeros)
         __syncthreads();
     }
     if (!wave_live) return;
+    if (p.wgrad_ws) {
+        // (elements past M / N hold sums of re-read columns: the second pass never adds them to C)
+        float* blk = p.wgrad_ws + ((int64_t)chunk * tiles_mn + tile) * (int64_t)(HB_BM * HB_BN);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int lc = wn * 64 + j * 32 + r32;
+                const int lr0 = wm * 64 + i * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) blk[(lr0 + (r & 3) + 8 * (r >> 2)) * HB_BN + lc] = acc[i][j][r];
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -1213,6 +1230,7 @@ extern "C" int gamer_gemm_bf16(const gamer_gemm_bf16_desc* d, void* stream) {
     p.qk_pos_ids = d->qk_pos_ids; p.qk_q_rot = (bf16_t*)d->qk_q_rot; p.qk_k_rot = (bf16_t*)d->qk_k_rot;
     p.qk_S = d->qk_S; p.qk_nq = d->qk_nq; p.qk_nkv = d->qk_nkv;
     p.sw_gu = (bf16_t*)d->sw_gu; p.sw_ld = d->sw_ld;
+    p.wgrad_ws = nullptr;
     p.n_tiles = (d->N + HB_BN - 1) / HB_BN;
     hipStream_t st = (hipStream_t)stream;
     if (d->group_mode == 0) {
@@ -1310,8 +1328,20 @@ extern "C" int gamer_gemm_bf16(const gamer_gemm_bf16_desc* d, void* stream) {
         if (e != hipSuccess) { set_error("gamer_gemm_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         attr = true;
     }
+    if (d->wgrad_ws) {
+        const int64_t need = blocks * (int64_t)(HB_BM * HB_BN);
+        GAMER_CHECK_ARG(d->wgrad_ws_floats >= need && aligned16(d->wgrad_ws),
+                        "gamer_gemm_bf16: wgrad_ws holds %lld floats, this weight gradient needs %lld (chunks x tiles x 16384)",
+                        (long long)d->wgrad_ws_floats, (long long)need);
+        p.wgrad_ws = d->wgrad_ws;
+    }
     hipLaunchKernelGGL(gemm_bf16_wgrad_kernel, dim3((int)blocks), dim3(HB_THREADS), HW_LDS_BYTES, st, p, zp);
     GAMER_CHECK_LAUNCH("gamer_gemm_bf16/wgrad");
+    if (p.wgrad_ws) {
+        const int e = launch_wgrad_reduce(p.wgrad_ws, reinterpret_cast<float*>(d->C), d->ldc, d->M, d->N, d->groups, d->group_offsets,
+                                          d->K, d->kchunk, d->strideC, st);
+        if (e) { set_error("gamer_gemm_bf16/wgrad_reduce: %s", hipGetErrorString((hipError_t)e)); return e; }
+    }
     return 0;
 }
 

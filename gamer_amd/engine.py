@@ -410,8 +410,6 @@ class Engine:
             raise ValueError("matmul='split3'/'split6'/'split9' is a form of the fp32 path; dtype='bf16' has its own GEMM")
         self.matmul = matmul
         self.deterministic = (os.environ.get("GAMER_DETERMINISTIC", "0") == "1") if deterministic is None else bool(deterministic)
-        if self.deterministic and dtype != "f32":
-            raise ValueError("deterministic=True is built for the fp32 forms (the bf16 weight-gradient kernel combines with atomics)")
         # q / k RMSNorm + RoPE in the q|k|v projection's epilogue (gamer_gemm_desc.qk_*): built, parity-tested and measured
         # at batch 1024 - the 12 projections got 6.8 ms slower per step (their tiles now also store q_rot / k_rot, and
         # on gfx950 epilogue work is matrix-pipe time), the removed kernel had cost 8.1 ms: 373.9-375.4 against 373.4-377 ms
@@ -833,7 +831,7 @@ class Engine:
         ops.fill(self.flat_g, 0.0)
 
     def backward(self, dloss: float = 1.0, layer_done=None, dloss_dev: Optional[torch.Tensor] = None):
-        with ops.deterministic(True if self.deterministic else ops.DETERMINISTIC_WGRAD):
+        with ops.deterministic(True if self.deterministic else ops.DETERMINISTIC_WGRAD, bf16=True if self.deterministic else None):
             return self._backward(dloss, layer_done, dloss_dev)
 
     @ops.scoped_f32_matmul(lambda self, *a: self.matmul, lambda self, *a: self._planes())

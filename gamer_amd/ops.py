@@ -411,21 +411,31 @@ def split3_planes(x, planes):
 # step at per-GPU batch 1024, 33.10 vs 33.20 at 128 - 25 GB of float atomics per step become plain stores).
 # GAMER_WGRAD_TWO_PASS=0 or `with ops.deterministic(False):` give the atomics form.
 DETERMINISTIC_WGRAD = os.environ.get("GAMER_WGRAD_TWO_PASS", "1") != "0"
+# The bf16 weight-gradient GEMM has the same ordered form (gamer_gemm_bf16_desc.wgrad_ws, same second pass).  There it measured
+# 0.6 ms per step SLOWER than the atomics (104.2 against 103.6 ms at per-GPU batch 1024, equal at 128; the bf16 chunks are long and
+# few, so there are few atomics to save), so it is opt-in: Engine(dtype="bf16", deterministic=True), GAMER_WGRAD_TWO_PASS_BF16=1.
+DETERMINISTIC_WGRAD_BF16 = os.environ.get("GAMER_WGRAD_TWO_PASS_BF16", "0") == "1"
 _WGRAD_WS = {}
 
 
 class deterministic:
-    def __init__(self, on: bool = True):
-        self.on = bool(on)
+    """Scope: ordered (two-pass) weight gradients on / off for the fp32 forms; ``bf16`` (None = leave alone) likewise for the
+    bf16 weight-gradient GEMM."""
+
+    def __init__(self, on: bool = True, bf16=None):
+        self.on, self.bf16 = bool(on), bf16
 
     def __enter__(self):
-        global DETERMINISTIC_WGRAD
+        global DETERMINISTIC_WGRAD, DETERMINISTIC_WGRAD_BF16
         self.prev, DETERMINISTIC_WGRAD = DETERMINISTIC_WGRAD, self.on
+        self.prev16 = DETERMINISTIC_WGRAD_BF16
+        if self.bf16 is not None:
+            DETERMINISTIC_WGRAD_BF16 = bool(self.bf16)
         return self
 
     def __exit__(self, *exc):
-        global DETERMINISTIC_WGRAD
-        DETERMINISTIC_WGRAD = self.prev
+        global DETERMINISTIC_WGRAD, DETERMINISTIC_WGRAD_BF16
+        DETERMINISTIC_WGRAD, DETERMINISTIC_WGRAD_BF16 = self.prev, self.prev16
         return False
 
 
@@ -577,6 +587,11 @@ def _gemm_bf16(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha, accumulat
         d.qk_S, d.qk_nq, d.qk_nkv = int(q["S"]), int(q["nq"]), int(q["nkv"])
     if swiglu_bwd is not None:             # (gu, ld): see gamer_gemm_bf16_desc.sw_gu
         d.sw_gu, d.sw_ld = ptr(swiglu_bwd[0]), int(swiglu_bwd[1])
+    if group_mode == 1 and DETERMINISTIC_WGRAD_BF16:
+        n_chunks = (K + kchunk - 1) // kchunk + (groups if group_offsets is not None else 0)
+        need = n_chunks * ((M + 127) // 128) * ((N + 127) // 128) * 16384
+        ws = _wgrad_workspace(A.device, need)
+        d.wgrad_ws, d.wgrad_ws_floats = ws.data_ptr(), ws.numel()
     call("gamer_gemm_bf16", C.byref(d), stream_ptr())
 
 

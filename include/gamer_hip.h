@@ -364,6 +364,10 @@ typedef struct {
      * gamer_swiglu_bwd_ld_bf16 would make it (p_drop / seed of this descriptor).  NULL = off. */
     gamer_bf16* sw_gu;
     int64_t sw_ld;
+    /* group_mode 1: the ordered form of the weight gradient, as gamer_gemm_desc.wgrad_ws (chunk partial tiles to this scratch of
+     * (chunks + groups if grouped) x tiles x 16384 floats, then added to C in chunk order: no fp32 atomics).  NULL = atomics. */
+    float* wgrad_ws;
+    int64_t wgrad_ws_floats;
 } gamer_gemm_bf16_desc;
 
 int gamer_gemm_bf16(const gamer_gemm_bf16_desc* d, void* stream);

@@ -342,18 +342,19 @@ def test_deterministic_engine_repeats_its_gradient_bit_for_bit():
     assert d < 1e-5, d
 
 
-def test_default_engine_gradient_is_bit_reproducible(monkeypatch):
-    """Round 4: the last float-atomics reduction of the default fp32 step (the embedding gradient's scatter-add) became a stable
-    sort + ordered sums, so the DEFAULT engine repeats its flat gradient bit for bit (the bf16 step's weight gradients still
-    combine their chunks with fp32 atomics); with GAMER_EMBEDDING_ATOMICS=1 the atomics form is back and agrees to rounding."""
-    dtype = "f32"
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_default_engine_gradient_is_bit_reproducible(dtype, monkeypatch):
+    """Round 4: the last float-atomics reduction of the default fp32 step, the embedding gradient's scatter-add, became a stable
+    sort + ordered sums: the DEFAULT fp32 engine repeats its flat gradient bit for bit.  The bf16 engine does so with
+    deterministic=True (its weight-gradient GEMM then takes the two-pass form as well; 0.6 ms per step, so opt-in there).  With
+    GAMER_EMBEDDING_ATOMICS=1 the atomics form of the embedding gradient is back and agrees to rounding."""
     from gamer_amd.config import synthetic_config
     cfg = synthetic_config()
     sd = orc.init_state_dict(orc.OracleConfig.from_dict(cfg.to_dict()), seed=2)
     batch = synthetic.make_batch(24, 101, 256, 3, ragged=True, seed=5, behavior_probs=[0.7, 0.25, 0.05])
 
     def grads(reps):
-        eng = Engine(cfg, temperature=0.7, dtype=dtype)
+        eng = Engine(cfg, temperature=0.7, dtype=dtype, deterministic=True if dtype == "bf16" else None)
         eng.load_state_dict(sd)
         eng.base_seed = 99
         out = []
