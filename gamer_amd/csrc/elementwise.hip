@@ -186,10 +186,28 @@ emb_scatter_kernel(const int64_t* __restrict__ ids, int V, int T, int pad_id, co
         bucket[t - t0] = (id == pad_id || id < 0 || id >= V) ? -1 : (int)id;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {                                      // token order inside the chunk: one thread walks it (LDS only)
-        for (int t = t0; t < t1; ++t) {
-            const int b = bucket[t - t0];
-            if (b >= 0) perm[emb_cur[b]++] = t;
+    if (threadIdx.x < 64) {
+        // token order inside the chunk: ONE wave walks it 64 tokens at a time.  A lane's position = its row's cursor + the number of
+        // earlier lanes of the batch with the same id; the last lane of every id moves the cursor on.  (A single thread walking
+        // the 1024 tokens took 120-150 us per launch - every step a dependent LDS round trip.)
+        const int lane = threadIdx.x;
+        for (int tb = t0; tb < t1; tb += 64) {
+            const int t = tb + lane;
+            const int b = t < t1 ? bucket[t - t0] : -1;
+            int rank = 0, cnt = 0;
+            for (int j = 0; j < 64; ++j) {
+                const int bj = __shfl(b, j, 64);
+                const bool same = bj == b;
+                rank += (same && j < lane) ? 1 : 0;
+                cnt += same ? 1 : 0;
+            }
+            if (b >= 0) {
+                const int pos = emb_cur[b] + rank;               // (every lane reads before any lane of this batch writes)
+                perm[pos] = t;
+                __builtin_amdgcn_wave_barrier();
+                if (rank == cnt - 1) emb_cur[b] = pos + 1;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
