@@ -1127,6 +1127,84 @@ qknorm_rope_fwd_b8_tok_kernel(bf16_t* __restrict__ qkv, int T, int S, int nq, in
     }
 }
 
+// token-major form for the self-attention calls (see qknorm_rope_bwd_tok_kernel): one 8-lane group per token walks its heads three
+// at a time, cos / sin once per token, the two norm-weight gradients accumulate over all heads and leave as one partial row
+// [dwq | dwk] per wave; same arithmetic per element as the kernel below with cross = 0
+__global__ void __launch_bounds__(EW_THREADS)
+qknorm_rope_bwd_b8_tok_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dq_rot, const bf16_t* __restrict__ dk_rot,
+                              int T, int S, int nq, int nkv, const float* __restrict__ wq, const float* __restrict__ wk, float eps,
+                              const float* __restrict__ cos_t, const float* __restrict__ sin_t, bf16_t* __restrict__ dqkv,
+                              float* __restrict__ partial, int n_waves, const int32_t* __restrict__ pos_ids) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane & 7, sub = lane >> 3;
+    const int wave = (int)(((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6);
+    if (wave >= n_waves) return;
+    const int nqk = nq + nkv;
+    const int ldqkv = (nq + 2 * nkv) * 64;
+    float wq8[8], wk8[8], dwq[8], dwk[8];
+    ld8(wq + 8 * g, wq8);
+    ld8(wk + 8 * g, wk8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dwq[e] = 0.f; dwk[e] = 0.f; }
+    const float sgn = g < 4 ? 1.f : -1.f;             // transpose of the rotation
+    for (int tb = wave * 8; tb < T; tb += n_waves * 8) {
+        const int t = tb + sub;
+        const bool live = t < T;
+        const int tc = live ? t : T - 1;
+        const int pos = pos_ids ? pos_ids[tc] : tc % S;
+        float c[8], sn[8];
+        ld8(cos_t + pos * 64 + 8 * g, c);
+        ld8(sin_t + pos * 64 + 8 * g, sn);
+        const bf16_t* xrow = qkv + (int64_t)tc * ldqkv + 8 * g;
+        const bf16_t* dqrow = dq_rot + (int64_t)tc * nq * 64 + 8 * g;
+        const bf16_t* dkrow = dk_rot + (int64_t)tc * nkv * 64 + 8 * g;
+        const float lv = live ? 1.f : 0.f;
+        for (int h0 = 0; h0 < nqk; h0 += 3) {
+            float xs[3][8], ds[3][8];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int hd = min(h0 + u, nqk - 1);
+                ld8(xrow + hd * 64, xs[u]);
+                ld8(hd < nq ? dqrow + hd * 64 : dkrow + (hd - nq) * 64, ds[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int hd = h0 + u;
+                if (hd >= nqk) break;                       // (uniform over the wave)
+                const bool isq = hd < nq;
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += xs[u][e] * xs[u][e];
+                ss = group8_sum(ss);
+                const float rstd = rsqrtf(ss * (1.f / 64.f) + eps);
+                float gg[8], xh[8], dot = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float dp = __shfl_xor(ds[u][e], 4, 64);
+                    const float dy = ds[u][e] * c[e] + sgn * dp * sn[e];
+                    xh[e] = xs[u][e] * rstd;
+                    const float contrib = lv * dy * round_as<bf16_t>(xh[e]);
+                    if (isq) dwq[e] += contrib; else dwk[e] += contrib;
+                    gg[e] = dy * (isq ? wq8[e] : wk8[e]);
+                    dot += gg[e] * xh[e];
+                }
+                dot = group8_sum(dot) * (1.f / 64.f);
+                float dx[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dx[e] = rstd * (gg[e] - xh[e] * dot);
+                if (live) st8(dqkv + (int64_t)t * ldqkv + hd * 64 + 8 * g, dx);
+            }
+        }
+    }
+    auto fold = [&](float v) { v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
+    float* prow = partial + (int64_t)wave * 128;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float a = fold(dwq[e]), b = fold(dwk[e]);
+        if (sub == 0) { prow[8 * g + e] = a; prow[64 + 8 * g + e] = b; }
+    }
+}
+
 // NBR = compile-time bound of the bias-table rows (4 for the shipped three behaviours, 8 otherwise)
 template <int NBR>
 __global__ void __launch_bounds__(EW_THREADS)
@@ -1966,6 +2044,20 @@ static int qknorm_rope_bwd_impl(const char* name, const TA* qkv, const TA* dq_ro
     const int64_t total_waves = (int64_t)NH * waves_per_head;
     const int blocks = (int)((total_waves + EW_WAVES - 1) / EW_WAVES);
     if constexpr (sizeof(TA) == 2) {
+        static const bool row_major16 = getenv("GAMER_QKNORM_ROW_MAJOR") != nullptr;     // (the round-1 form, kept for A/B runs)
+        int n_waves16 = (T + 7) / 8;
+        if (n_waves16 > 8192) n_waves16 = 8192;
+        if ((int64_t)n_waves16 * 128 > partial_numel) n_waves16 = (int)(partial_numel / 128);
+        if (!cross && !row_major16 && n_waves16 >= 1) {
+            hipLaunchKernelGGL(qknorm_rope_bwd_b8_tok_kernel, dim3((n_waves16 + EW_WAVES - 1) / EW_WAVES), dim3(EW_THREADS), 0,
+                               ST(stream), qkv, dq_rot, dk_rot, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, dqkv, partial, n_waves16,
+                               pos_ids);
+            GAMER_CHECK_LAUNCH(name);
+            hipLaunchKernelGGL(qknorm_partial_reduce_kernel, dim3(128 / QKR_CW), dim3(1024), 0, ST(stream), partial, n_waves16, 1, 1, 0,
+                               0, dwq, dwk, dbias_q, dbias_k, dbias_v);
+            GAMER_CHECK_LAUNCH(name);
+            return 0;
+        }
         if (!cross || nb1 <= 4)
             hipLaunchKernelGGL(qknorm_rope_bwd_b8_kernel<4>, dim3(blocks), dim3(EW_THREADS), 0, ST(stream), qkv, dq_rot, dk_rot,
                                T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, cross, bias_q, bias_k, act_idx, nb1, dqkv, partial,
