@@ -126,6 +126,7 @@ _SIGNATURES = {
     "gamer_absmax_multi_f32": [P, P, I, P, P],
     "gamer_split2h_planes_multi": [P, P, I, P, P, P],
     "gamer_amax_sink": [P, P],
+    "gamer_amax_sink3": [P, P, P],
     "gamer_attn_split_amax": [P, P, P, P],
     "gamer_attn_fwd_split": [P, I, P, I, P, I, P, P, P, I, I, I, I, F, F, U, P, P, P, P, P, I, P, P],
     "gamer_attn_bwd_split": [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, I, I, F, F, U, P, P, I, P, I, P, I, P, P, P, I, P, P, P],

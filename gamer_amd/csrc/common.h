@@ -122,7 +122,7 @@ __device__ __forceinline__ void scale_from_amax(uint32_t bits, float& s, float& 
 // gamer_amax_sink(out0, out1) arms the NEXT launch (on the calling host thread) of a kernel that supports it: that kernel folds
 // the bits of max |value stored| of its first / second output into *out0 / *out1 (atomicMax; the words hold 0 or an earlier
 // maximum).  The pointers travel as kernel arguments - stream-ordered like everything else - and are disarmed by the launch.
-struct AmaxSink { uint32_t* out[2]; };
+struct AmaxSink { uint32_t* out[3]; };          // (out[2]: gamer_amax_sink3 - the q/k-norm forward's third output, v + bias)
 AmaxSink take_amax_sink();
 void disarm_attn_amax();            // (attention_split.hip) drops what gamer_attn_split_amax armed; set_error calls both
 // (float maxima: |x| is a free source modifier and max3 takes two values per instruction; a NaN is ignored here - it reaches the

@@ -593,10 +593,10 @@ qknorm_rope_fwd_kernel(TA* __restrict__ qkv, int T, int S, int nq, int nkv,
                        const float* __restrict__ bias_q, const float* __restrict__ bias_k,
                        const float* __restrict__ bias_v, const int32_t* __restrict__ act_idx,
                        TA* __restrict__ q_rot, TA* __restrict__ k_rot, const int32_t* __restrict__ pos_ids,
-                       uint32_t* __restrict__ amax_q, uint32_t* __restrict__ amax_k) {
+                       uint32_t* __restrict__ amax_q, uint32_t* __restrict__ amax_k, uint32_t* __restrict__ amax_v) {
     constexpr bool F32 = sizeof(TA) == 4;
-    __shared__ uint32_t amax_lds[2][4];
-    uint32_t amq = 0, amk = 0;                          // gamer_amax_sink: max |q_rot|, max |k_rot|
+    __shared__ uint32_t amax_lds[3][4];
+    uint32_t amq = 0, amk = 0, amv = 0;                 // gamer_amax_sink(3): max |q_rot|, max |k_rot|, max |v + bias_v|
     const int lane = threadIdx.x & 63;
     const int g = lane & 15, sub = lane >> 4;
     const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
@@ -654,11 +654,12 @@ qknorm_rope_fwd_kernel(TA* __restrict__ qkv, int T, int S, int nq, int nkv,
             const float4 b4 = reinterpret_cast<const float4*>(bias_v + (int64_t)a * nkv * 64 + hv * 64)[g];
             float4 x = ld4(dst);
             x.x += b4.x; x.y += b4.y; x.z += b4.z; x.w += b4.w;
-            if (live) st4(dst, x);
+            if (live) { st4(dst, x); amv = amax_f4(amv, x); }
         }
     }
     amax_block_commit(amq, amax_q, amax_lds[0]);
     amax_block_commit(amk, amax_k, amax_lds[1]);
+    amax_block_commit(amv, amax_v, amax_lds[2]);
 }
 
 // fp32, token-major: one 16-lane group per TOKEN, walking its q and k heads three at a time (three 16-byte loads in flight
@@ -672,9 +673,9 @@ qknorm_rope_fwd_tok_kernel(float* __restrict__ qkv, int T, int S, int nq, int nk
                            const float* __restrict__ bias_q, const float* __restrict__ bias_k,
                            const float* __restrict__ bias_v, const int32_t* __restrict__ act_idx,
                            float* __restrict__ q_rot, float* __restrict__ k_rot, const int32_t* __restrict__ pos_ids,
-                           uint32_t* __restrict__ amax_q, uint32_t* __restrict__ amax_k) {
-    __shared__ uint32_t amax_lds[2][4];
-    uint32_t amq = 0, amk = 0;
+                           uint32_t* __restrict__ amax_q, uint32_t* __restrict__ amax_k, uint32_t* __restrict__ amax_v) {
+    __shared__ uint32_t amax_lds[3][4];
+    uint32_t amq = 0, amk = 0, amv = 0;
     const int lane = threadIdx.x & 63;
     const int g = lane & 15, sub = lane >> 4;
     const int64_t wave = ((int64_t)blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
@@ -734,12 +735,13 @@ qknorm_rope_fwd_tok_kernel(float* __restrict__ qkv, int T, int S, int nq, int nk
                 const float4 b4 = *reinterpret_cast<const float4*>(bias_v + (int64_t)a * nkv * 64 + hv * 64 + 4 * g);
                 float4 xv = ld4(dst);
                 xv.x += b4.x; xv.y += b4.y; xv.z += b4.z; xv.w += b4.w;
-                if (live) st4(dst, xv);
+                if (live) { st4(dst, xv); amv = amax_f4(amv, xv); }
             }
         }
     }
     amax_block_commit(amq, amax_q, amax_lds[0]);
     amax_block_commit(amk, amax_k, amax_lds[1]);
+    amax_block_commit(amv, amax_v, amax_lds[2]);
 }
 
 // Each wave keeps one head for its whole life so that the norm-weight and bias gradients accumulate in
@@ -1732,10 +1734,10 @@ fill_kernel(float* __restrict__ p, int64_t n, float value) {
 }  // namespace gamer
 
 namespace gamer {
-static thread_local AmaxSink g_amax_sink = {{nullptr, nullptr}};
+static thread_local AmaxSink g_amax_sink = {{nullptr, nullptr, nullptr}};
 AmaxSink take_amax_sink() {
     const AmaxSink s = g_amax_sink;
-    g_amax_sink.out[0] = g_amax_sink.out[1] = nullptr;
+    g_amax_sink.out[0] = g_amax_sink.out[1] = g_amax_sink.out[2] = nullptr;
     return s;
 }
 }  // namespace gamer
@@ -1747,6 +1749,13 @@ using namespace gamer;
 extern "C" int gamer_amax_sink(uint32_t* out0, uint32_t* out1) {
     g_amax_sink.out[0] = out0;
     g_amax_sink.out[1] = out1;
+    g_amax_sink.out[2] = nullptr;
+    return 0;
+}
+extern "C" int gamer_amax_sink3(uint32_t* out0, uint32_t* out1, uint32_t* out2) {
+    g_amax_sink.out[0] = out0;
+    g_amax_sink.out[1] = out1;
+    g_amax_sink.out[2] = out2;
     return 0;
 }
 
@@ -1992,11 +2001,11 @@ static int qknorm_rope_fwd_impl(const char* name, TA* qkv, int T, int S, int nq,
         if (row_major)
             hipLaunchKernelGGL(qknorm_rope_fwd_kernel<TA>, dim3(grid_for_waves(((int64_t)T * NH + 3) / 4)), dim3(EW_THREADS), 0,
                                ST(stream), qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot,
-                               k_rot, pos_ids, sink.out[0], sink.out[1]);
+                               k_rot, pos_ids, sink.out[0], sink.out[1], sink.out[2]);
         else
             hipLaunchKernelGGL(qknorm_rope_fwd_tok_kernel, dim3(grid_for_waves(((int64_t)T + 3) / 4)), dim3(EW_THREADS), 0,
                                ST(stream), qkv, T, S, nq, nkv, wq, wk, eps, cos_t, sin_t, bias_q, bias_k, bias_v, act_idx, q_rot,
-                               k_rot, pos_ids, sink.out[0], sink.out[1]);
+                               k_rot, pos_ids, sink.out[0], sink.out[1], sink.out[2]);
     }
     GAMER_CHECK_LAUNCH(name);
     return 0;

@@ -364,7 +364,10 @@ def _arm_sink(*outs):
     slots = [_AMAX_REUSE.preset(t, g, acc) for t, g, acc in outs]
     if slots[0] is None:
         return
-    call("gamer_amax_sink", slots[0], slots[1] if len(slots) > 1 else None)
+    if len(slots) > 2:
+        call("gamer_amax_sink3", slots[0], slots[1], slots[2])
+    else:
+        call("gamer_amax_sink", slots[0], slots[1] if len(slots) > 1 else None)
 
 
 def scoped_amax(get_cache):
@@ -763,7 +766,11 @@ def qknorm_rope_fwd(qkv, S, nq, nkv, wq, wk, eps, cos_t, sin_t, q_rot, k_rot, bi
                     act_idx=None, pos_ids=None):
     """pos_ids: int32 [T] RoPE table row per token (session model); None = position in the sequence."""
     T = qkv.shape[0]
-    _arm_sink((q_rot, (1, 0, T, nq * 64, nq * 64), False), (k_rot, (1, 0, T, nkv * 64, nkv * 64), False))
+    outs = [(q_rot, (1, 0, T, nq * 64, nq * 64), False), (k_rot, (1, 0, T, nkv * 64, nkv * 64), False)]
+    if bias_v is not None:
+        # the cross block: v + bias_v is written back into the v columns of q|k|v - their maximum is the attention's third operand
+        outs.append((qkv[:, (nq + nkv) * 64:], (1, 0, T, nkv * 64, qkv.stride(0)), False))
+    _arm_sink(*outs)
     call("gamer_qknorm_rope_fwd" + _sfx(qkv), ptr(qkv), T, S, nq, nkv, ptr(wq), ptr(wk), eps, ptr(cos_t), ptr(sin_t),
          ptr(bias_q), ptr(bias_k), ptr(bias_v), ptr(act_idx), ptr(q_rot), ptr(k_rot), ptr(pos_ids), stream_ptr())
 

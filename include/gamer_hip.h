@@ -303,6 +303,9 @@ int gamer_split2h_planes_multi(const float* base, const int64_t* table, int n, c
  * (atomicMax; words hold 0 or an earlier maximum; NULL = none) and the launch disarms the sink.  Any other launch in between
  * leaves it armed.  Saves the separate pass of gamer_absmax_f32 over the tensor. */
 int gamer_amax_sink(uint32_t* out0, uint32_t* out1);
+/* the same with a third word: gamer_qknorm_rope_fwd with behaviour biases (the cross block) folds max |v + bias_v| - the v columns
+ * of q|k|v as the attention reads them - into *out2 (out0 / out1: q_rot / k_rot as above) */
+int gamer_amax_sink3(uint32_t* out0, uint32_t* out1, uint32_t* out2);
 /* gamer_attn_split_amax(q, k, v, d_o) arms the next gamer_attn_fwd_split / gamer_attn_bwd_split on the calling host thread to form
  * its products in the three-product fp16 form of gamer_gemm_f32_split(terms = 3): q, k, v (d_o: backward; NULL in the forward)
  * are device words holding the bits of max |.| of those operand tensors; P is scaled by 2^13, dS by a bound derived from the

@@ -1127,6 +1127,15 @@ def test_amax_sinks_equal_the_maximum_of_what_the_kernel_wrote():
         ops.qknorm_rope_fwd(qkv, S, nq, nkv, w64, w64, 1e-6, dev(cos), dev(sin), q_rot, k_rot)
         assert pending(q_rot, (1, 0, T, nq * 64, nq * 64)) == float(q_rot.abs().max())
         assert pending(k_rot, (1, 0, T, nkv * 64, nkv * 64)) == float(k_rot.abs().max())
+        # ... with behaviour biases (the cross block) also the v columns it rewrites as v + bias_v (gamer_amax_sink3)
+        qkv_c = dev(torch.randn(T, QKV) * 5)
+        act = dev(torch.randint(0, 4, (T,)).int())
+        bq, bk, bv = (dev(torch.randn(4, n * 64) * 3) for n in (nq, nkv, nkv))
+        ops.qknorm_rope_fwd(qkv_c, S, nq, nkv, w64, w64, 1e-6, dev(cos), dev(sin), q_rot, k_rot, bias_q=bq, bias_k=bk, bias_v=bv,
+                            act_idx=act)
+        vc = qkv_c[:, (nq + nkv) * 64:]
+        assert pending(vc, (1, 0, T, nkv * 64, QKV)) == float(vc.abs().max())
+        assert pending(q_rot, (1, 0, T, nq * 64, nq * 64)) == float(q_rot.abs().max())
         # gamer_absmax_f32: dense, strided columns; gamer_absmax_multi_f32
         v = qkv[:, (nq + nkv) * 64:]
         assert _slot_value(ops.absmax_slot(v, 1, 0, T, nkv * 64, QKV)) == float(v.abs().max())
