@@ -1,0 +1,782 @@
+// Multi-behaviour flash attention, three-product fp16 form (H2, csrc/attention_split.hip), with the K and V rows of a
+// (sequence, kv head) RESIDENT in LDS: replaces ref:SeqRec/models/generative/Qwen3Multi/model.py:75-150 (+ masks :573-630,
+// :691-741, HF sdpa_attention_forward) in the Engine(matmul="split3") train step, same semantics and entry points as
+// attention_split.hip (predicate masks, "empty" rows uniform over all S keys, lazily rescaled online softmax, row order of the
+// cross attention, dropout mask function, operand maxima / sinks).
+//
+// Why (round 4 measurements): the tiled kernels re-stage the causal prefix of K / V for every 64-query
+// tile (4.5 x per sequence at S = 505); per 32 x 32 tile and wave that is ~215 of ~350 vector instructions (address arithmetic of
+// the loads, the cut, the LDS stores) next to 24 MFMAs, plus one workgroup barrier per key tile - 49 % of the wave cycles parked
+// at waits / barriers, 17 % MFMA-busy.  Here one workgroup of eight waves owns a (sequence, kv head) pair:
+//   * keys are processed in BLOCKS of 256: the block's K and V rows are cut ONCE into their two fp16 piece images
+//     (4 x 32 KB of LDS, one workgroup per CU) and every query row tile of both query heads runs against them;
+//   * inside a block a wave walks its own 32-query row tiles with NO barrier and no global load in the key loop: K fragments by
+//     row reads, V^T fragments by transposing reads of the resident images, key levels / dropout words from LDS;
+//   * a row tile that needs keys of more than one block (S = 505: the upper half of the queries) carries its softmax state
+//     through the output buffers: the block-0 pass stores O / l and m + log2 l (the state of an attention over the keys seen so
+//     far, in final form up to constants), the next pass reloads it as (m_ref = that LSE, l = 1) - the same wave, the same
+//     lanes, so program order makes it visible; the last pass writes the final o and lse;
+//   * row tiles are dealt to the waves of a query head boustrophedon (causal ramp: equal work per wave in every block).
+// Sessions' key spans (SPAN), uniform_len of the evaluation re-run and the six-product bf16 form stay on attention_split.hip.
+#include "attention_split_common.h"
+
+namespace gamer {
+
+#ifndef RES_STAMP
+#define RES_STAMP 0       // diagnostic builds (tools/stamp_attn_res.py): every wave of the forward kernel accumulates shader-clock cycles per phase
+#endif                    // into g_res_stamp[(8 * blockIdx.x + wave) * 8 + phase] (set by gamer_debug_res_stamp); never in the shipped library
+#if RES_STAMP
+__device__ unsigned long long* g_res_stamp = nullptr;
+#define RES_MARK(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                         ph_[i] += (t_ - tprev_); tprev_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RES_STAMP_ARGS , unsigned long long (&ph_)[8], unsigned long long& tprev_
+#define RES_STAMP_PASS , ph_, tprev_
+#else
+#define RES_MARK(i) do { } while (0)
+#define RES_STAMP_ARGS
+#define RES_STAMP_PASS
+#endif
+
+constexpr int RB_KEYS = 256;                 // keys of one resident block
+constexpr int RB_TILES = RB_KEYS / 32;
+constexpr int RES_THREADS = 512;
+constexpr int RIMG = RB_KEYS * 64;           // 16-bit elements of one piece image of a block ([256][64], swizzled like a tile image)
+
+struct ResSmem {
+    bf16_t K[2][RIMG];
+    bf16_t V[2][RIMG];
+    int32_t kl[RB_KEYS];                     // key levels (INT_MAX past the end of the sequence)
+    uint32_t kw[RB_KEYS];                    // dropout key words
+    int32_t klmax[RB_TILES];                 // largest key level per 32-key tile
+    uint32_t amax_word;
+    int32_t pad_[7];
+};
+
+// Cut and store the K / V rows j0 .. j0 + 255 of one (sequence, kv head) and their metadata.  Every thread: 8 (row, quad) items per
+// tensor, four loads of each tensor in flight.
+template <bool DROP>
+__device__ __forceinline__ void res_stage_block(ResSmem& sm, const float* __restrict__ kbase, int ldk, const float* __restrict__ vbase,
+                                                int ldv, const int32_t* __restrict__ klb, int j0, int S, int tid, const H2Scales& sc,
+                                                const AttnDropout& rng) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float4 rk[4], rv[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int f = tid + RES_THREADS * (4 * half + p);
+            const int j = min(j0 + (f >> 4), S - 1);
+            rk[p] = *reinterpret_cast<const float4*>(kbase + (int64_t)j * ldk + ((f & 15) << 2));
+            rv[p] = *reinterpret_cast<const float4*>(vbase + (int64_t)j * ldv + ((f & 15) << 2));
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int f = tid + RES_THREADS * (4 * half + p);
+            const int row = f >> 4;
+            const bool ok = j0 + row < S;
+            const int off = sl_off(row, (f & 15) << 2);
+            uint32_t a0, a1, b0, b1;
+            cut2h_quad(ok ? rk[p].x : 0.f, ok ? rk[p].y : 0.f, ok ? rk[p].z : 0.f, ok ? rk[p].w : 0.f, sc.k, a0, a1, b0, b1);
+            *reinterpret_cast<uint2*>(sm.K[0] + off) = make_uint2(a0, b0);
+            *reinterpret_cast<uint2*>(sm.K[1] + off) = make_uint2(a1, b1);
+            cut2h_quad(ok ? rv[p].x : 0.f, ok ? rv[p].y : 0.f, ok ? rv[p].z : 0.f, ok ? rv[p].w : 0.f, sc.v, a0, a1, b0, b1);
+            *reinterpret_cast<uint2*>(sm.V[0] + off) = make_uint2(a0, b0);
+            *reinterpret_cast<uint2*>(sm.V[1] + off) = make_uint2(a1, b1);
+        }
+    }
+    if (tid < RB_KEYS) {
+        const int j = j0 + tid;
+        const int v = j < S ? klb[j] : INT_BIG_A;
+        sm.kl[tid] = v;
+        int m = v;
+#pragma unroll
+        for (int o2 = 16; o2 > 0; o2 >>= 1) m = max(m, __shfl_xor(m, o2, 64));
+        if ((tid & 31) == 0) sm.klmax[tid >> 5] = m;
+    } else if (DROP) {
+        sm.kw[tid - RB_KEYS] = rng.key_word((uint32_t)(j0 + tid - RB_KEYS));
+    }
+}
+
+// st += K(tile) q^T: 4 k-steps x 3 piece products; the fragments of k-step s + 1 are requested before the products of k-step s
+__device__ __forceinline__ f32x16 res_qk_tile(const ResSmem& sm, int tl, const SlOffsets& lo, const bf16x8 (&qf)[2][4], f32x16 st) {
+    const bf16_t* k0 = sm.K[0] + tl * SIMG;
+    const bf16_t* k1 = sm.K[1] + tl * SIMG;
+    bf16x8 kf[2][2];
+    kf[0][0] = *reinterpret_cast<const bf16x8*>(k0 + lo.row[0]);
+    kf[0][1] = *reinterpret_cast<const bf16x8*>(k1 + lo.row[0]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s + 1 < 4) {
+            kf[(s + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(k0 + lo.row[s + 1]);
+            kf[(s + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(k1 + lo.row[s + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // smallest piece products first: (k1 q0), (k0 q1), (k0 q0)
+        st = mfma_piece<true>(kf[s & 1][1], qf[0][s], st);
+        st = mfma_piece<true>(kf[s & 1][0], qf[1][s], st);
+        st = mfma_piece<true>(kf[s & 1][0], qf[0][s], st);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return st;
+}
+
+// One 32-query row tile of one query head against the resident key block kb.
+template <int G, bool DROP, bool ORD>
+__device__ __forceinline__ void
+res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
+                int S, int nq, float scale, const AttnDropout& rng, float* o, float* lse, const RowOrder& ro, const int b,
+                const int head, const int t, const int kb, const bool want_amax, const H2Scales& sc RES_STAMP_ARGS) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const SlOffsets lo(lane);
+    const int n_all = (S + 31) >> 5;
+    const int slot = t * 32 + r;                        // sorted slot of this lane's query row
+    const bool valid_q = slot < S;
+    const int slotc = valid_q ? slot : S - 1;
+    const int iqc = ORD ? ro.perm[(int64_t)b * S + slotc] : slotc;
+    const int iq = valid_q ? iqc : S;                   // position in the sequence (S: beyond every key)
+    const int64_t tok = (int64_t)b * S + iqc;
+
+    const int my_ql = ql ? ql[tok] : 1;
+    const bool my_empty = valid_q && row_empty[tok] != 0;
+    const bool normal = valid_q && !my_empty;
+    const int wave_ql_min = wave_min_i32(normal ? my_ql : INT_BIG_A);
+    const int wave_q_lo = wave_min_i32(normal ? iq : INT_BIG_A);      // every key up to here passes every row's causal limit
+    const bool wave_all_empty = wave_q_lo == INT_BIG_A;               // no normal row: no scores needed at all
+    int wave_q_hi;
+    bool wave_has_empty;
+    if (ORD) {
+        wave_q_hi = ro.tile_maxpos[(int64_t)b * n_all + t];
+        wave_has_empty = (ro.tile_kind[(int64_t)b * n_all + t] & 2) != 0;
+    } else {
+        wave_q_hi = wave_all_empty ? -1 : min(S - 1, t * 32 + 31);
+        wave_has_empty = __any(my_empty ? 1 : 0) != 0;
+    }
+    // key tiles this row tile needs: all of them with an empty row (uniform over all S keys), else the causal prefix
+    const int n_total = wave_has_empty ? n_all : (wave_q_hi < 0 ? 0 : (wave_q_hi >> 5) + 1);
+    const int jt_lo = kb * RB_TILES;
+    if (kb > 0 && jt_lo >= n_total) { RES_MARK(5); return; }   // finished in an earlier block
+    const int jt_hi = min(n_total, jt_lo + RB_TILES);
+    const bool first = kb == 0, last = jt_lo + RB_TILES >= n_total;
+
+    // scores are kept in the log2 domain: q is pre-scaled by scale*log2(e), p = exp2(s - m_ref)
+    const float qs = scale * 1.4426950408889634f;
+    bf16x8 qf[2][4];                   // piece x k-step: lane (r, h) holds d = 16 s + 8 h .. + 7 of its query row
+    {
+        const float* qrow = q + tok * ldq + head * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float4 a4 = *reinterpret_cast<const float4*>(qrow + 16 * s);
+            float4 b4 = *reinterpret_cast<const float4*>(qrow + 16 * s + 4);
+            a4.x *= qs; a4.y *= qs; a4.z *= qs; a4.w *= qs; b4.x *= qs; b4.y *= qs; b4.z *= qs; b4.w *= qs;
+            bf16x8 pq[3];
+            cut8_t<true>(a4, b4, sc.q, pq);
+            qf[0][s] = pq[0]; qf[1][s] = pq[1];
+        }
+    }
+    const float invS = 1.f / (float)S;
+    const uint32_t aw = DROP ? rng.row_word((uint32_t)(((int64_t)b * nq + head) * S + iqc)) : 0u;
+    float* orow = o + tok * (int64_t)nq * 64 + head * 64;
+    float* lse_p = lse + ((int64_t)b * nq + head) * S + iqc;
+
+    float m_ref = 0.f, l_run = 0.f;
+    f32x16 oacc[2];
+    if (first) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+    } else {
+        // the state the previous block's pass left in o / lse: O / l (times the powers of two of the final form) and m + log2 l
+        const float up = H2Scales::P * sc.v;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid_q) t4 = *reinterpret_cast<const float4*>(orow + 32 * dh + 8 * g4 + 4 * h);
+                oacc[dh][4 * g4 + 0] = t4.x * up; oacc[dh][4 * g4 + 1] = t4.y * up;
+                oacc[dh][4 * g4 + 2] = t4.z * up; oacc[dh][4 * g4 + 3] = t4.w * up;
+            }
+        const float L = normal ? *lse_p : -INFINITY;
+        const bool had = L > -INFINITY;                 // (a row whose keys so far were all blocked: nothing accumulated)
+        m_ref = had ? L : 0.f;
+        l_run = had ? 1.f : 0.f;
+    }
+    RES_MARK(1);                                           // 1: row-tile prologue (row data, q load + cut, carried state)
+
+#pragma unroll 1
+    for (int jt = jt_lo; jt < jt_hi; ++jt) {
+        const int j0 = jt * 32, tl = jt - jt_lo;
+        const bool beyond = j0 > wave_q_hi;                // every key of the tile is in every normal row's future
+        if (beyond && !wave_has_empty) continue;
+        f32x16 st;
+        if (!wave_all_empty && !beyond) {
+            const float init = -m_ref * (sc.q * sc.k);     // (the products carry the operands' scales)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st[i] = init;
+            st = res_qk_tile(sm, tl, lo, qf, st);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st[i] *= sc.inv_qk;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st[i] = 0.f;      // (beyond: the mask below blocks every normal row)
+        }
+        const bf16_t* v0 = sm.V[0] + tl * SIMG;
+        const bf16_t* v1 = sm.V[1] + tl * SIMG;
+        const int32_t* klt = sm.kl + tl * 32;
+        const int32_t* kwt = reinterpret_cast<const int32_t*>(sm.kw) + tl * 32;
+        // O^T[d][query] += sum_key V[key][d] * P[query][key]   (rows of V past the sequence end are zero)
+        auto pv_tile = [&]<bool ONE_PIECE>() {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf[3];
+                cut8_regs_t<true>(st, 8 * s2, H2Scales::P, pf);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    bf16x8 vf[3];
+                    vf[0] = read_tr8(v0, lo, 16 * s2, db);
+                    vf[1] = read_tr8(v1, lo, 16 * s2, db);
+                    vf[2] = vf[1];
+                    oacc[db] = mfma_pieces<true, ONE_PIECE>(vf, pf, oacc[db]);
+                }
+            }
+        };
+        auto softmax_tile = [&]<bool MASK, bool EMPTYSEL>() {
+            if (MASK) {
+                int klv[16];
+                read_key_quads(klt, h, klv);
+                const int t_pos = iq - j0 - 4 * h;           // key (reg&3)+8*(reg>>2) of the tile is <= iq
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int ko = (reg & 3) + 8 * (reg >> 2);
+                    const bool allowed = (ko <= t_pos) & (klv[reg] < my_ql);
+                    st[reg] = allowed ? st[reg] : -INFINITY;
+                }
+            }
+            float mloc = st[0];
+#pragma unroll
+            for (int reg = 1; reg < 16; ++reg) mloc = fmaxf(mloc, st[reg]);
+            mloc = xor32_max(mloc);
+            // (P is cut into fp16 pieces of P * 2^13 - it must stay below 2^3, so the reference follows the maximum closely)
+            bool need = (l_run == 0.f) ? (mloc > -INFINITY) : (mloc > 2.f);
+            if (EMPTYSEL) need = need && !my_empty;
+            if (__any(need ? 1 : 0)) {
+                const float d = need ? mloc : 0.f;
+                const float alpha = (l_run == 0.f) ? 1.f : __builtin_amdgcn_exp2f(-d);
+                m_ref += d;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; st[i] -= d; }
+            }
+            float rowsum = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                float pe = __builtin_amdgcn_exp2f(st[reg]);            // masked -> exp2(-inf) = 0
+                if (EMPTYSEL) pe = my_empty ? 1.f : pe;
+                rowsum += pe;
+                st[reg] = pe;
+            }
+            rowsum = xor32_sum(rowsum);
+            l_run += rowsum;
+            if (DROP) {
+                int kwv[16];
+                read_key_quads(kwt, h, kwv);
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) st[reg] = rng.keep(aw, (uint32_t)kwv[reg]) ? st[reg] : 0.f;
+            }
+            pv_tile.template operator()<false>();
+        };
+        if (wave_all_empty) {
+            // every row of the wave is an empty row: P = keep, no scores, no softmax state
+            int kwv[16];
+            if (DROP) read_key_quads(kwt, h, kwv);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const bool on = DROP ? rng.keep(aw, (uint32_t)kwv[reg]) : true;
+                st[reg] = on ? 1.f : 0.f;
+            }
+            pv_tile.template operator()<true>();
+        } else if (wave_has_empty) {
+            softmax_tile.template operator()<true, true>();
+        } else {
+            const int klmax = __builtin_amdgcn_readfirstlane(sm.klmax[tl]);
+            const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min);
+            if (free_tile) softmax_tile.template operator()<false, false>();
+            else softmax_tile.template operator()<true, false>();
+        }
+#if RES_STAMP
+        ph_[6] += 1;                                       // 6: key tiles
+#endif
+    }
+    RES_MARK(2);                                           // 2: key loop
+
+    if (last) {
+        float omax = 0.f;
+        if (valid_q) {
+            float linv = my_empty ? invS : (l_run > 0.f ? 1.f / l_run : 0.f);
+            if (DROP) linv *= rng.scale;
+            linv *= H2Scales::INV_P * sc.inv_v;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float4 t4;
+                    t4.x = oacc[dh][4 * g4 + 0] * linv; t4.y = oacc[dh][4 * g4 + 1] * linv;
+                    t4.z = oacc[dh][4 * g4 + 2] * linv; t4.w = oacc[dh][4 * g4 + 3] * linv;
+                    *reinterpret_cast<float4*>(orow + 32 * dh + 8 * g4 + 4 * h) = t4;
+                    omax = fmaxf(fmaxf(fmaxf(omax, fabsf(t4.x)), fabsf(t4.y)), fmaxf(fabsf(t4.z), fabsf(t4.w)));
+                }
+            // natural-log LSE of the scaled scores (what the backward kernels consume)
+            if (h == 0) *lse_p = my_empty ? 0.f : (m_ref + __log2f(l_run)) * 0.6931471805599453f;
+        }
+        if (want_amax) {                                                    // (gamer_amax_sink: max |o| for the o_proj GEMM's scale)
+            uint32_t mw = __float_as_uint(omax);
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) mw = max(mw, (uint32_t)__shfl_xor((int)mw, o2, 64));
+            if (lane == 0 && mw) atomicMax(&sm.amax_word, mw);
+        }
+    } else if (valid_q) {
+        // carry: the attention over the keys seen so far, normalised (an empty row: its plain sum)
+        float f = my_empty ? 1.f : (l_run > 0.f ? 1.f / l_run : 0.f);
+        f *= H2Scales::INV_P * sc.inv_v;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 t4;
+                t4.x = oacc[dh][4 * g4 + 0] * f; t4.y = oacc[dh][4 * g4 + 1] * f;
+                t4.z = oacc[dh][4 * g4 + 2] * f; t4.w = oacc[dh][4 * g4 + 3] * f;
+                *reinterpret_cast<float4*>(orow + 32 * dh + 8 * g4 + 4 * h) = t4;
+            }
+        if (h == 0) *lse_p = my_empty ? 0.f : m_ref + __log2f(l_run);       // (log2 domain; -inf: nothing accumulated yet)
+    }
+    RES_MARK(3);                                           // 3: epilogue (final or carried state)
+}
+
+template <int G, bool DROP, bool ORD>
+__global__ void __launch_bounds__(RES_THREADS, 1)
+attn_fwd_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv,
+                  const int32_t* __restrict__ kl, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
+                  int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed, float* o, float* lse,
+                  const RowOrder ro, uint32_t* __restrict__ amax_out, const AttnAmax am) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char res_raw[];
+    ResSmem& sm = *reinterpret_cast<ResSmem*>(res_raw);
+    constexpr int NWH = 8 / G;                              // waves per query head
+    const H2Scales sc(am.q, am.k, am.v, nullptr, scale * 1.4426950408889634f);
+    const AttnDropout rng(p_drop, seed);
+    const int tid = threadIdx.x, w = tid >> 6;
+    const int hg = w / NWH, sub = w % NWH;
+    const int n_all = (S + 31) >> 5;
+    const int nblk = (S + RB_KEYS - 1) / RB_KEYS;
+    const int n_chunks = (n_all + NWH - 1) / NWH;
+    const int n_pairs = nbatch * nkv;
+    if (tid == 0) sm.amax_word = 0;
+#if RES_STAMP
+    unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll 1
+    for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+        const int b = pair / nkv, kvh = pair % nkv;
+        const float* kbase = k + (int64_t)b * S * ldk + kvh * 64;
+        const float* vbase = v + (int64_t)b * S * ldv + kvh * 64;
+        const int32_t* klb = kl + (int64_t)b * S;
+#pragma unroll 1
+        for (int kb = 0; kb < nblk; ++kb) {
+            RES_MARK(5);                                    // 5: loop control between row tiles
+            __syncthreads();                                // every wave is done with the previous block's images
+            RES_MARK(4);                                    // 4: waiting for the slowest wave of the block
+            res_stage_block<DROP>(sm, kbase, ldk, vbase, ldv, klb, kb * RB_KEYS, S, tid, sc, rng);
+            __syncthreads();
+            RES_MARK(0);                                    // 0: staging of the block (loads, cut, LDS stores, barrier)
+            // row tiles of this wave's head, dealt boustrophedon over its NWH waves, late (long) tiles first
+#pragma unroll 1
+            for (int c = n_chunks - 1; c >= 0; --c) {
+                const int t = (c & 1) ? c * NWH + NWH - 1 - sub : c * NWH + sub;
+                if (t < n_all)
+                    res_fwd_rowtile<G, DROP, ORD>(sm, q, ldq, ql, row_empty, S, nq, scale, rng, o, lse, ro, b, kvh * G + hg, t, kb,
+                                                  amax_out != nullptr, sc RES_STAMP_PASS);
+            }
+        }
+    }
+    if (amax_out) {
+        __syncthreads();
+        if (tid == 0 && sm.amax_word) amax_publish(sm.amax_word, amax_out, blockIdx.x);
+    }
+#if RES_STAMP
+    RES_MARK(5);
+    if (g_res_stamp && (tid & 63) == 0) {
+        unsigned long long* rec = g_res_stamp + ((size_t)blockIdx.x * 8 + w) * 8;
+#pragma unroll
+        for (int i_ = 0; i_ < 8; ++i_) rec[i_] += ph_[i_];
+    }
+#endif
+}
+
+
+// =============================================================================================
+// backward: dQ (attention_split.hip: attn_bwd_dq_s_tile) against the resident K / V block.  Per key tile: dP^T = V dO^T and
+// S^T = K q^T (query on the lane, the dO pieces in registers like q's), dS = P (mult dP - delta), dQ^T += K^T dS^T with the K^T
+// fragments by transposing reads of the resident image; dO and dS are scaled per query row.  A row tile that needs more than one
+// key block carries its raw accumulators through dq (fp32, exact: the sum continues as if the key loop had not been cut).
+// =============================================================================================
+template <int G, bool DROP, bool ORD>
+__device__ __forceinline__ void
+res_dq_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const float* __restrict__ o, const float* __restrict__ d_o,
+               const float* __restrict__ lse, float* delta, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
+               int S, int nq, float scale, const AttnDropout& rng, float* dq, int lddq, const RowOrder& ro, const int b,
+               const int head, const int t, const int kb, const int delta_ready, const H2Scales& sc) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const SlOffsets lo(lane);
+    const int n_all = (S + 31) >> 5;
+    const int slot = t * 32 + r;
+    const bool valid_q = slot < S;
+    const int slotc = valid_q ? slot : S - 1;
+    const int iqc = ORD ? ro.perm[(int64_t)b * S + slotc] : slotc;
+    const int iq = valid_q ? iqc : S;
+    const int64_t tok = (int64_t)b * S + iqc;
+
+    const int my_ql = ql ? ql[tok] : 1;
+    const bool my_empty = valid_q && row_empty[tok] != 0;
+    const bool normal = valid_q && !my_empty;
+    const int wave_ql_min = wave_min_i32(normal ? my_ql : INT_BIG_A);
+    const int wave_q_lo = wave_min_i32(normal ? iq : INT_BIG_A);
+    const bool wave_all_empty = wave_q_lo == INT_BIG_A;
+    int wave_q_hi;
+    bool wave_has_empty;
+    if (ORD) {
+        wave_q_hi = ro.tile_maxpos[(int64_t)b * n_all + t];
+        wave_has_empty = (ro.tile_kind[(int64_t)b * n_all + t] & 2) != 0;
+    } else {
+        wave_q_hi = wave_all_empty ? -1 : min(S - 1, t * 32 + 31);
+        wave_has_empty = __any(my_empty ? 1 : 0) != 0;
+    }
+    const int n_total = wave_has_empty ? n_all : (wave_q_hi < 0 ? 0 : (wave_q_hi >> 5) + 1);
+    const int jt_lo = kb * RB_TILES;
+    if (kb > 0 && jt_lo >= n_total) return;
+    const int jt_hi = min(n_total, jt_lo + RB_TILES);
+    const bool first = kb == 0, last = jt_lo + RB_TILES >= n_total;
+
+    // log2 domain: q is pre-scaled by scale*log2(e) and the score accumulators start at -lse*log2(e), so p = exp2(accumulator)
+    const float qs = scale * 1.4426950408889634f;
+    bf16x8 qf[2][4], dof[2][4];           // piece x k-step of the pre-scaled q row and of the dO row (lane = query)
+    float my_delta = 0.f;
+    float my_sdo = sc.d_o, my_inv_do = sc.inv_do, my_sds = sc.ds, my_inv_ds = sc.inv_ds;
+    float* delta_p = delta + ((int64_t)b * nq + head) * S + iqc;
+    {
+        const float* qrow = q + tok * ldq + head * 64 + 8 * h;
+        const float* drow = d_o + tok * (int64_t)nq * 64 + head * 64 + 8 * h;
+        const float* orow = o + tok * (int64_t)nq * 64 + head * 64 + 8 * h;
+        float4 du[4], dw[4];
+        float rowmax = 0.f;
+        const bool need_delta = !delta_ready && first;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float4 a4 = *reinterpret_cast<const float4*>(qrow + 16 * s);
+            float4 b4 = *reinterpret_cast<const float4*>(qrow + 16 * s + 4);
+            a4.x *= qs; a4.y *= qs; a4.z *= qs; a4.w *= qs; b4.x *= qs; b4.y *= qs; b4.z *= qs; b4.w *= qs;
+            bf16x8 pq[3];
+            cut8_t<true>(a4, b4, sc.q, pq);
+            qf[0][s] = pq[0]; qf[1][s] = pq[1];
+            float4 u4 = *reinterpret_cast<const float4*>(drow + 16 * s);
+            float4 w4 = *reinterpret_cast<const float4*>(drow + 16 * s + 4);
+            if (need_delta) {
+                const float4 o4 = *reinterpret_cast<const float4*>(orow + 16 * s);
+                const float4 p4 = *reinterpret_cast<const float4*>(orow + 16 * s + 4);
+                my_delta += u4.x * o4.x + u4.y * o4.y + u4.z * o4.z + u4.w * o4.w + w4.x * p4.x + w4.y * p4.y + w4.z * p4.z + w4.w * p4.w;
+            }
+            if (!valid_q) { u4 = make_float4(0.f, 0.f, 0.f, 0.f); w4 = u4; }
+            du[s] = u4; dw[s] = w4;
+            rowmax = fmaxf(fmaxf(fmaxf(rowmax, fabsf(u4.x)), fabsf(u4.y)), fmaxf(fabsf(u4.z), fabsf(u4.w)));
+            rowmax = fmaxf(fmaxf(fmaxf(rowmax, fabsf(w4.x)), fabsf(w4.y)), fmaxf(fabsf(w4.z), fabsf(w4.w)));
+        }
+        rowmax = fmaxf(rowmax, __shfl_xor(rowmax, 32, 64));          // the row's other 32 columns
+        if (rowmax > 0.f) {                                          // (an all-zero row keeps the tensor's scales: its pieces are 0)
+            scale_from_amax(__float_as_uint(rowmax), my_sdo, my_inv_do);
+            scale_from_amax(__float_as_uint(sc.ds_coef * rowmax), my_sds, my_inv_ds);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 dpc[3];
+            cut8_t<true>(du[s], dw[s], my_sdo, dpc);
+            dof[0][s] = dpc[0]; dof[1][s] = dpc[1];
+        }
+        if (need_delta) {
+            my_delta += __shfl_xor(my_delta, 32, 64);
+            if (valid_q) *delta_p = my_delta;        // (both lane halves store the same value: each reads back its own store in later passes)
+        } else {
+            my_delta = *delta_p;
+        }
+    }
+    const float neg_lse2 = -lse[((int64_t)b * nq + head) * S + iqc] * 1.4426950408889634f;
+    const float invS = 1.f / (float)S;
+    const uint32_t aw = DROP ? rng.row_word((uint32_t)(((int64_t)b * nq + head) * S + iqc)) : 0u;
+    const float sd = rng.scale;
+    const float neg_delta = -my_delta;
+    float* dqrow = dq + tok * lddq + head * 64;
+
+    f32x16 dqacc[2];
+    if (first) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
+    } else {
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid_q) t4 = *reinterpret_cast<const float4*>(dqrow + 32 * dh + 8 * g4 + 4 * h);
+                dqacc[dh][4 * g4 + 0] = t4.x; dqacc[dh][4 * g4 + 1] = t4.y; dqacc[dh][4 * g4 + 2] = t4.z; dqacc[dh][4 * g4 + 3] = t4.w;
+            }
+    }
+
+#pragma unroll 1
+    for (int jt = jt_lo; jt < jt_hi; ++jt) {
+        const int j0 = jt * 32, tl = jt - jt_lo;
+        const bool beyond = j0 > wave_q_hi;
+        if (beyond && !wave_has_empty) continue;
+        const bf16_t* k0 = sm.K[0] + tl * SIMG;
+        const bf16_t* k1 = sm.K[1] + tl * SIMG;
+        const bf16_t* v0 = sm.V[0] + tl * SIMG;
+        const bf16_t* v1 = sm.V[1] + tl * SIMG;
+        const int32_t* klt = sm.kl + tl * 32;
+        const int32_t* kwt = reinterpret_cast<const int32_t*>(sm.kw) + tl * 32;
+        f32x16 st, dp;
+        const float st0 = !beyond ? neg_lse2 * (sc.q * sc.k) : neg_lse2;   // (the products carry the operands' scales)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st[i] = st0; dp[i] = 0.f; }
+        // dP^T[key][query] = sum_d V[key][d] dO[query][d]
+        {
+            bf16x8 vf[2][2];
+            vf[0][0] = *reinterpret_cast<const bf16x8*>(v0 + lo.row[0]);
+            vf[0][1] = *reinterpret_cast<const bf16x8*>(v1 + lo.row[0]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s + 1 < 4) {
+                    vf[(s + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(v0 + lo.row[s + 1]);
+                    vf[(s + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(v1 + lo.row[s + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                dp = mfma_piece<true>(vf[s & 1][1], dof[0][s], dp);
+                dp = mfma_piece<true>(vf[s & 1][0], dof[1][s], dp);
+                dp = mfma_piece<true>(vf[s & 1][0], dof[0][s], dp);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!beyond && !wave_all_empty) st = res_qk_tile(sm, tl, lo, qf, st);
+        {
+            const float cdp = sc.inv_v * my_inv_do;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dp[i] *= cdp;
+            if (!beyond) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) st[i] *= sc.inv_qk;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // u = mult * dP - delta  (mult = keep / (1 - p))
+        if (DROP) {
+            int kwv[16];
+            read_key_quads(kwt, h, kwv);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float tt = rng.keep(aw, (uint32_t)kwv[reg]) ? dp[reg] : 0.f;
+                dp[reg] = fmaf(tt, sd, neg_delta);
+            }
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) dp[reg] += neg_delta;
+        }
+        // dS^T = p * u ; an empty row has p = 1 here and 1/S in the final scale
+        auto ds_tile = [&]<bool MASK, bool EMPTYSEL>() {
+            if (MASK) {
+                int klv[16];
+                read_key_quads(klt, h, klv);
+                const int t_pos = iq - j0 - 4 * h;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int ko = (reg & 3) + 8 * (reg >> 2);
+                    const bool allowed = (ko <= t_pos) & (klv[reg] < my_ql);
+                    st[reg] = allowed ? st[reg] : -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                float pe = __builtin_amdgcn_exp2f(st[reg]);
+                if (EMPTYSEL) pe = my_empty ? 1.f : pe;
+                st[reg] = pe * dp[reg];
+            }
+        };
+        if (wave_all_empty) {
+            st = dp;
+        } else if (wave_has_empty) {
+            ds_tile.template operator()<true, true>();
+        } else {
+            const int klmax = __builtin_amdgcn_readfirstlane(sm.klmax[tl]);
+            const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min);
+            if (free_tile) ds_tile.template operator()<false, false>();
+            else ds_tile.template operator()<true, false>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // dQ^T[d][query] += sum_key K[key][d] dS^T[key][query]   (rows of K past the sequence end are zero)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 df[3];
+            cut8_regs_t<true>(st, 8 * s2, my_sds, df);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                bf16x8 kf[3];
+                kf[0] = read_tr8(k0, lo, 16 * s2, db);
+                kf[1] = read_tr8(k1, lo, 16 * s2, db);
+                kf[2] = kf[1];
+                dqacc[db] = mfma_pieces<true>(kf, df, dqacc[db]);
+            }
+        }
+    }
+
+    if (valid_q) {
+        float fs = 1.f;
+        if (last) fs = (my_empty ? scale * invS : scale) * (my_inv_ds * sc.inv_k);
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 t4;
+                t4.x = dqacc[dh][4 * g4 + 0] * fs; t4.y = dqacc[dh][4 * g4 + 1] * fs;
+                t4.z = dqacc[dh][4 * g4 + 2] * fs; t4.w = dqacc[dh][4 * g4 + 3] * fs;
+                *reinterpret_cast<float4*>(dqrow + 32 * dh + 8 * g4 + 4 * h) = t4;
+            }
+    }
+}
+
+template <int G, bool DROP, bool ORD>
+__global__ void __launch_bounds__(RES_THREADS, 1)
+attn_bwd_dq_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv,
+                     const float* __restrict__ o, const float* __restrict__ d_o, const float* __restrict__ lse, float* delta,
+                     const int32_t* __restrict__ kl, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
+                     int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed, float* dq, int lddq,
+                     const RowOrder ro, const int delta_ready, const AttnAmax am) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char res_raw[];
+    ResSmem& sm = *reinterpret_cast<ResSmem*>(res_raw);
+    constexpr int NWH = 8 / G;
+    const H2Scales sc(am.q, am.k, am.v, am.d_o, scale * 1.4426950408889634f, 1.f / (1.f - p_drop));
+    const AttnDropout rng(p_drop, seed);
+    const int tid = threadIdx.x, w = tid >> 6;
+    const int hg = w / NWH, sub = w % NWH;
+    const int n_all = (S + 31) >> 5;
+    const int nblk = (S + RB_KEYS - 1) / RB_KEYS;
+    const int n_chunks = (n_all + NWH - 1) / NWH;
+    const int n_pairs = nbatch * nkv;
+#pragma unroll 1
+    for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+        const int b = pair / nkv, kvh = pair % nkv;
+        const float* kbase = k + (int64_t)b * S * ldk + kvh * 64;
+        const float* vbase = v + (int64_t)b * S * ldv + kvh * 64;
+        const int32_t* klb = kl + (int64_t)b * S;
+#pragma unroll 1
+        for (int kb = 0; kb < nblk; ++kb) {
+            __syncthreads();
+            res_stage_block<DROP>(sm, kbase, ldk, vbase, ldv, klb, kb * RB_KEYS, S, tid, sc, rng);
+            __syncthreads();
+#pragma unroll 1
+            for (int c = n_chunks - 1; c >= 0; --c) {
+                const int t = (c & 1) ? c * NWH + NWH - 1 - sub : c * NWH + sub;
+                if (t < n_all)
+                    res_dq_rowtile<G, DROP, ORD>(sm, q, ldq, o, d_o, lse, delta, ql, row_empty, S, nq, scale, rng, dq, lddq, ro, b,
+                                                 kvh * G + hg, t, kb, delta_ready, sc);
+            }
+        }
+    }
+}
+
+template <int G, bool DROP, bool ORD>
+static int launch_fwd_r_variant(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl,
+                                const int32_t* ql, const int32_t* row_empty, int B, int S, int nq, int nkv, float scale, float p_drop,
+                                uint64_t seed, float* o, float* lse, RowOrder ro, uint32_t* amax_out, AttnAmax am, hipStream_t st) {
+    const size_t shmem = sizeof(ResSmem);
+    static bool attr_dev[MAX_DEVICES] = {};
+    bool& attr_set = attr_dev[current_device()];
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_r_kernel<G, DROP, ORD>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) {
+            set_error("gamer_attn_fwd_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    const int n_pairs = B * nkv;
+    const int grid = n_pairs < res_grid_cap() ? n_pairs : res_grid_cap();
+    hipLaunchKernelGGL((attn_fwd_r_kernel<G, DROP, ORD>), dim3(grid), dim3(RES_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, kl, ql,
+                       row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, amax_out, am);
+    GAMER_CHECK_LAUNCH("gamer_attn_fwd_split/resident");
+    return 0;
+}
+
+int launch_fwd_res(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl, const int32_t* ql,
+                   const int32_t* row_empty, int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed, float* o,
+                   float* lse, RowOrder ro, uint32_t* amax_out, AttnAmax am, hipStream_t st) {
+#define GAMER_LAUNCH_FWD_R(GV, DROPV, ORDV)                                                                                   \
+    return launch_fwd_r_variant<GV, DROPV, ORDV>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, \
+                                                 ro, amax_out, am, st)
+    if (nq / nkv == 1) {
+        if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD_R(1, true, true); else GAMER_LAUNCH_FWD_R(1, true, false); }
+        else { if (ro.perm) GAMER_LAUNCH_FWD_R(1, false, true); else GAMER_LAUNCH_FWD_R(1, false, false); }
+    } else {
+        if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD_R(2, true, true); else GAMER_LAUNCH_FWD_R(2, true, false); }
+        else { if (ro.perm) GAMER_LAUNCH_FWD_R(2, false, true); else GAMER_LAUNCH_FWD_R(2, false, false); }
+    }
+#undef GAMER_LAUNCH_FWD_R
+    return -1;      // not reached
+}
+
+template <int G, bool DROP, bool ORD>
+static int launch_dq_r_variant(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                               const float* d_o, const float* lse, float* delta, const int32_t* kl, const int32_t* ql,
+                               const int32_t* row_empty, int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+                               float* dq, int lddq, RowOrder ro, int delta_ready, AttnAmax am, hipStream_t st) {
+    const size_t shmem = sizeof(ResSmem);
+    static bool attr_dev[MAX_DEVICES] = {};
+    bool& attr_set = attr_dev[current_device()];
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_r_kernel<G, DROP, ORD>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) {
+            set_error("gamer_attn_bwd_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    const int n_pairs = B * nkv;
+    const int grid = n_pairs < res_grid_cap() ? n_pairs : res_grid_cap();
+    hipLaunchKernelGGL((attn_bwd_dq_r_kernel<G, DROP, ORD>), dim3(grid), dim3(RES_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, o, d_o,
+                       lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, ro, delta_ready, am);
+    GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dq resident");
+    return 0;
+}
+
+int launch_dq_res(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, const float* d_o,
+                  const float* lse, float* delta, const int32_t* kl, const int32_t* ql, const int32_t* row_empty, int B, int S,
+                  int nq, int nkv, float scale, float p_drop, uint64_t seed, float* dq, int lddq, RowOrder ro, int delta_ready,
+                  AttnAmax am, hipStream_t st) {
+#define GAMER_LAUNCH_DQ_R(GV, DROPV, ORDV)                                                                                    \
+    return launch_dq_r_variant<GV, DROPV, ORDV>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, \
+                                                p_drop, seed, dq, lddq, ro, delta_ready, am, st)
+    if (nq / nkv == 1) {
+        if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_DQ_R(1, true, true); else GAMER_LAUNCH_DQ_R(1, true, false); }
+        else { if (ro.perm) GAMER_LAUNCH_DQ_R(1, false, true); else GAMER_LAUNCH_DQ_R(1, false, false); }
+    } else {
+        if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_DQ_R(2, true, true); else GAMER_LAUNCH_DQ_R(2, true, false); }
+        else { if (ro.perm) GAMER_LAUNCH_DQ_R(2, false, true); else GAMER_LAUNCH_DQ_R(2, false, false); }
+    }
+#undef GAMER_LAUNCH_DQ_R
+    return -1;      // not reached
+}
+
+}  // namespace gamer
+
+#if RES_STAMP
+extern "C" int gamer_debug_res_stamp(void* p) {
+    unsigned long long* v = (unsigned long long*)p;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(gamer::g_res_stamp), &v, sizeof(v));
+}
+#endif
