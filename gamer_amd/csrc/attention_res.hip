@@ -41,6 +41,7 @@ constexpr int RB_KEYS = 256;                 // keys of one resident block
 constexpr int RB_TILES = RB_KEYS / 32;
 constexpr int RES_THREADS = 512;
 constexpr int RIMG = RB_KEYS * 64;           // 16-bit elements of one piece image of a block ([256][64], swizzled like a tile image)
+constexpr int RES_MAX_TILES = 64;            // 32-query row tiles per head the kernels are built for (S <= 2048)
 
 struct ResSmem {
     bf16_t K[2][RIMG];
@@ -49,8 +50,19 @@ struct ResSmem {
     uint32_t kw[RB_KEYS];                    // dropout key words
     int32_t klmax[RB_TILES];                 // largest key level per 32-key tile
     uint32_t amax_word;
-    int32_t pad_[7];
+    int32_t ctr;                             // the block's row-tile queue: next item (waves take items with an LDS atomic)
+    int32_t pad_[6];
+    int32_t ntot[2 * RES_MAX_TILES];         // key tiles every (head of the pair, row tile) needs, written by the block-0 pass
 };
+// the row tile a wave will process after the current one: its q rows (and row data) are requested into the L2 while the current
+// tile is multiplied - a row tile's prologue is otherwise two dependent HBM round trips with nothing to overlap them
+struct ResNext { bool valid; int head, t, perm; };
+__device__ __forceinline__ int res_grab_ctr(int32_t* ctr, int lane) {
+    int v = 0;
+    if (lane == 0) v = atomicAdd(ctr, 1);
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int res_grab(ResSmem& sm, int lane) { return res_grab_ctr(&sm.ctr, lane); }
 
 // Cut and store the K / V rows j0 .. j0 + 255 of one (sequence, kv head) and their metadata.  Every thread: 8 (row, quad) items per
 // tensor, four loads of each tensor in flight.
@@ -124,7 +136,8 @@ template <int G, bool DROP, bool ORD>
 __device__ __forceinline__ void
 res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
                 int S, int nq, float scale, const AttnDropout& rng, float* o, float* lse, const RowOrder& ro, const int b,
-                const int head, const int t, const int kb, const bool want_amax, const H2Scales& sc RES_STAMP_ARGS) {
+                const int head, const int t, const int kb, const bool want_amax, const H2Scales& sc, const int perm_cur,
+                const ResNext& nx RES_STAMP_ARGS) {
     const int lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
     const SlOffsets lo(lane);
@@ -132,7 +145,7 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
     const int slot = t * 32 + r;                        // sorted slot of this lane's query row
     const bool valid_q = slot < S;
     const int slotc = valid_q ? slot : S - 1;
-    const int iqc = ORD ? ro.perm[(int64_t)b * S + slotc] : slotc;
+    const int iqc = ORD ? perm_cur : slotc;
     const int iq = valid_q ? iqc : S;                   // position in the sequence (S: beyond every key)
     const int64_t tok = (int64_t)b * S + iqc;
 
@@ -154,9 +167,9 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
     // key tiles this row tile needs: all of them with an empty row (uniform over all S keys), else the causal prefix
     const int n_total = wave_has_empty ? n_all : (wave_q_hi < 0 ? 0 : (wave_q_hi >> 5) + 1);
     const int jt_lo = kb * RB_TILES;
-    if (kb > 0 && jt_lo >= n_total) { RES_MARK(5); return; }   // finished in an earlier block
     const int jt_hi = min(n_total, jt_lo + RB_TILES);
     const bool first = kb == 0, last = jt_lo + RB_TILES >= n_total;
+    if (first && lane == 0) sm.ntot[(head % G) * RES_MAX_TILES + t] = n_total;     // (later blocks skip finished tiles without loading anything)
 
     // scores are kept in the log2 domain: q is pre-scaled by scale*log2(e), p = exp2(s - m_ref)
     const float qs = scale * 1.4426950408889634f;
@@ -202,9 +215,16 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
     }
     RES_MARK(1);                                           // 1: row-tile prologue (row data, q load + cut, carried state)
 
+    uint32_t tq = 0, tm = 0;                               // (destinations of the next tile's L2 warm-up loads: never read)
 #pragma unroll 1
     for (int jt = jt_lo; jt < jt_hi; ++jt) {
         const int j0 = jt * 32, tl = jt - jt_lo;
+        if (jt == jt_lo && nx.valid) {
+            // one 128-byte line per lane: lane (r, h) takes half h of row r of the next tile's q rows; its row data by lane half
+            const int64_t ntok = (int64_t)b * S + (ORD ? nx.perm : min(nx.t * 32 + r, S - 1));
+            tq = *reinterpret_cast<const uint32_t*>(q + ntok * ldq + nx.head * 64 + 32 * h);
+            tm = *reinterpret_cast<const uint32_t*>(((h == 1 && ql) ? ql : row_empty) + ntok);
+        }
         const bool beyond = j0 > wave_q_hi;                // every key of the tile is in every normal row's future
         if (beyond && !wave_has_empty) continue;
         f32x16 st;
@@ -348,6 +368,7 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
             }
         if (h == 0) *lse_p = my_empty ? 0.f : m_ref + __log2f(l_run);       // (log2 domain; -inf: nothing accumulated yet)
     }
+    asm volatile("" :: "v"(tq), "v"(tm));
     RES_MARK(3);                                           // 3: epilogue (final or carried state)
 }
 
@@ -359,15 +380,14 @@ attn_fwd_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
                   const RowOrder ro, uint32_t* __restrict__ amax_out, const AttnAmax am) {
     extern __shared__ __attribute__((aligned(16))) unsigned char res_raw[];
     ResSmem& sm = *reinterpret_cast<ResSmem*>(res_raw);
-    constexpr int NWH = 8 / G;                              // waves per query head
     const H2Scales sc(am.q, am.k, am.v, nullptr, scale * 1.4426950408889634f);
     const AttnDropout rng(p_drop, seed);
-    const int tid = threadIdx.x, w = tid >> 6;
-    const int hg = w / NWH, sub = w % NWH;
+    const int tid = threadIdx.x;
     const int n_all = (S + 31) >> 5;
     const int nblk = (S + RB_KEYS - 1) / RB_KEYS;
-    const int n_chunks = (n_all + NWH - 1) / NWH;
+    const int n_items = G * n_all;                          // (head of the pair, row tile) items of one key block
     const int n_pairs = nbatch * nkv;
+    const int lane = tid & 63, r = lane & 31;
     if (tid == 0) sm.amax_word = 0;
 #if RES_STAMP
     unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -384,17 +404,45 @@ attn_fwd_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
             RES_MARK(5);                                    // 5: loop control between row tiles
             __syncthreads();                                // every wave is done with the previous block's images
             RES_MARK(4);                                    // 4: waiting for the slowest wave of the block
+            if (tid == 0) sm.ctr = 0;
             res_stage_block<DROP>(sm, kbase, ldk, vbase, ldv, klb, kb * RB_KEYS, S, tid, sc, rng);
             __syncthreads();
             RES_MARK(0);                                    // 0: staging of the block (loads, cut, LDS stores, barrier)
-            // row tiles of this wave's head, dealt boustrophedon over its NWH waves, late (long) tiles first
-#pragma unroll 1
-            for (int c = n_chunks - 1; c >= 0; --c) {
-                const int t = (c & 1) ? c * NWH + NWH - 1 - sub : c * NWH + sub;
-                if (t < n_all)
-                    res_fwd_rowtile<G, DROP, ORD>(sm, q, ldq, ql, row_empty, S, nq, scale, rng, o, lse, ro, b, kvh * G + hg, t, kb,
-                                                  amax_out != nullptr, sc RES_STAMP_PASS);
+            // warm the L2 with the K / V rows of the block this workgroup stages NEXT (one 128-byte line per thread and tensor): all
+            // workgroups run in step, so unprefetched the staging is an HBM burst every CU waits for
+            uint32_t tk0 = 0, tk1 = 0;
+            {
+                int npair = pair, nkb = kb + 1;
+                if (nkb == nblk) { nkb = 0; npair += gridDim.x; }
+                if (npair < n_pairs) {
+                    const int j = min(nkb * RB_KEYS + (tid >> 1), S - 1);
+                    const int64_t nrow = (int64_t)(npair / nkv) * S + j;
+                    tk0 = *reinterpret_cast<const uint32_t*>(k + nrow * ldk + (npair % nkv) * 64 + (tid & 1) * 32);
+                    tk1 = *reinterpret_cast<const uint32_t*>(v + nrow * ldv + (npair % nkv) * 64 + (tid & 1) * 32);
+                }
             }
+            // the block's row tiles: late (long) tiles first, taken from a queue - whichever wave is free takes the next one (the
+            // carried state of a tile travels through global memory, workgroup barriers in between: any wave may continue it)
+            int cur = res_grab(sm, lane);
+            int perm_cur = 0;
+            if (ORD && cur < n_items) perm_cur = ro.perm[(int64_t)b * S + min((n_all - 1 - cur / G) * 32 + r, S - 1)];
+#pragma unroll 1
+            while (cur < n_items) {
+                const int nxt = res_grab(sm, lane);
+                const int hg = cur % G, t = n_all - 1 - cur / G;
+                ResNext nx;
+                nx.t = n_all - 1 - nxt / G;
+                nx.head = kvh * G + nxt % G;
+                nx.valid = nxt < n_items && (kb == 0 || sm.ntot[(nxt % G) * RES_MAX_TILES + nx.t] > kb * RB_TILES);
+                nx.perm = 0;
+                if (ORD && nxt < n_items) nx.perm = ro.perm[(int64_t)b * S + min(nx.t * 32 + r, S - 1)];
+                if (kb == 0 || sm.ntot[hg * RES_MAX_TILES + t] > kb * RB_TILES)
+                    res_fwd_rowtile<G, DROP, ORD>(sm, q, ldq, ql, row_empty, S, nq, scale, rng, o, lse, ro, b, kvh * G + hg, t, kb,
+                                                  amax_out != nullptr, sc, perm_cur, nx RES_STAMP_PASS);
+                cur = nxt;
+                perm_cur = nx.perm;
+            }
+            asm volatile("" :: "v"(tk0), "v"(tk1));
         }
     }
     if (amax_out) {
@@ -404,7 +452,7 @@ attn_fwd_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
 #if RES_STAMP
     RES_MARK(5);
     if (g_res_stamp && (tid & 63) == 0) {
-        unsigned long long* rec = g_res_stamp + ((size_t)blockIdx.x * 8 + w) * 8;
+        unsigned long long* rec = g_res_stamp + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 8;
 #pragma unroll
         for (int i_ = 0; i_ < 8; ++i_) rec[i_] += ph_[i_];
     }
@@ -688,6 +736,358 @@ attn_bwd_dq_r_kernel(const float* __restrict__ q, int ldq, const float* __restri
     }
 }
 
+
+// =============================================================================================
+// backward: dK, dV - the mirror image of the forward: the Q and dO rows of ONE query head and a block of 256 (sorted) query slots
+// are resident in LDS as fp16 piece images with their per-row scalars, a wave owns a 32-key tile (key on the lane, its K / V
+// fragments in registers for the whole sweep, dK^T / dV^T in 64 accumulator registers) and walks the block's query tiles with no
+// barrier.  Key tiles are taken from a queue (early keys - seen by the most queries - first).  A key tile's sums continue from
+// stage to stage (the G heads of the kv head x the query blocks, in this fixed order) through dk / dv themselves, raw fp32, so the
+// result does not depend on which wave took which item; the last stage scales and stores every key tile.
+// =============================================================================================
+struct DkvRSmem {
+    bf16_t Q[2][RIMG];
+    bf16_t dO[2][RIMG];
+    float nlse2[RB_KEYS];        // -lse * log2(e) of the staged query rows
+    float ndelta[RB_KEYS];       // -delta
+    uint32_t aw[RB_KEYS];        // dropout row words
+    int32_t ql[RB_KEYS];         // query levels (0 past the end of the sequence)
+    int32_t empty[RB_KEYS];
+    int32_t pos[RB_KEYS];        // position of the row in the sequence = its causal key limit (S past the end)
+    int32_t t_qlmin[RB_TILES];   // per 32-row tile: smallest query level / position over its normal rows (INT_MAX: none),
+    int32_t t_posmin[RB_TILES];
+    int32_t t_maxpos[RB_TILES];  //                  largest position of a normal row (-1: none), has "empty" rows
+    int32_t t_empty[RB_TILES];
+    int32_t started[RES_MAX_TILES];      // key tile has a partial sum in dk / dv
+    uint32_t amax_word;
+    int32_t ctr;
+    int32_t pad_[6];
+};
+
+// Cut and store the Q / dO rows of query slots s0 .. s0 + 255 of one head, their scalars and the per-tile summaries.
+constexpr int DKV_R_THREADS = 256;            // four waves, one per SIMD: the whole 512-register file per wave (K / V fragments, four
+                                              // accumulator tiles and the tile in flight do not fit 256 registers: 85-99 spilled)
+template <bool DROP, bool ORD>
+__device__ __forceinline__ void
+res_stage_queries(DkvRSmem& sm, const float* __restrict__ q, int ldq, const float* __restrict__ d_o, const float* __restrict__ lse,
+                  const float* delta, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty, const RowOrder& ro,
+                  int b, int head, int s0, int S, int nq, int tid, const H2Scales& sc, const AttnDropout& rng) {
+    const int32_t* pmap = ORD ? ro.perm + (int64_t)b * S : nullptr;
+    float4 rq[8], rd[8];
+    auto load8 = [&](int p0) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int f = tid + DKV_R_THREADS * (p0 + p);
+            const int sl = min(s0 + (f >> 4), S - 1);
+            const int64_t tok = (int64_t)b * S + (ORD ? pmap[sl] : sl);
+            rq[p] = *reinterpret_cast<const float4*>(q + tok * ldq + head * 64 + ((f & 15) << 2));
+            rd[p] = *reinterpret_cast<const float4*>(d_o + tok * (int64_t)nq * 64 + head * 64 + ((f & 15) << 2));
+        }
+    };
+    auto store8 = [&](int p0) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int f = tid + DKV_R_THREADS * (p0 + p);
+            const int row = f >> 4;
+            const bool ok = s0 + row < S;
+            const int off = sl_off(row, (f & 15) << 2);
+            uint32_t a0, a1, b0, b1;
+            cut2h_quad(ok ? rq[p].x : 0.f, ok ? rq[p].y : 0.f, ok ? rq[p].z : 0.f, ok ? rq[p].w : 0.f, sc.q, a0, a1, b0, b1);
+            *reinterpret_cast<uint2*>(sm.Q[0] + off) = make_uint2(a0, b0);
+            *reinterpret_cast<uint2*>(sm.Q[1] + off) = make_uint2(a1, b1);
+            cut2h_quad(ok ? rd[p].x : 0.f, ok ? rd[p].y : 0.f, ok ? rd[p].z : 0.f, ok ? rd[p].w : 0.f, sc.d_o, a0, a1, b0, b1);
+            *reinterpret_cast<uint2*>(sm.dO[0] + off) = make_uint2(a0, b0);
+            *reinterpret_cast<uint2*>(sm.dO[1] + off) = make_uint2(a1, b1);
+        }
+    };
+    load8(0);
+    if (tid < RB_KEYS) {
+        const int sl = s0 + tid;
+        const bool in = sl < S;
+        const int pos = in ? (ORD ? pmap[sl] : sl) : 0;
+        const int64_t hrow = ((int64_t)b * nq + head) * S + pos;
+        const int em = in ? row_empty[(int64_t)b * S + pos] : 0;
+        const int qlv = in ? (ql ? ql[(int64_t)b * S + pos] : 1) : 0;
+        sm.nlse2[tid] = in ? -lse[hrow] * 1.4426950408889634f : 0.f;
+        sm.ndelta[tid] = in ? -delta[hrow] : 0.f;
+        if (DROP) sm.aw[tid] = rng.row_word((uint32_t)hrow);
+        sm.ql[tid] = qlv;
+        sm.empty[tid] = em;
+        sm.pos[tid] = in ? pos : S;
+        const bool normal = in && em == 0;
+        int qlmin = normal ? qlv : INT_BIG_A, posmin = normal ? pos : INT_BIG_A, maxpos = normal ? pos : -1, anye = em != 0 ? 1 : 0;
+#pragma unroll
+        for (int o2 = 16; o2 > 0; o2 >>= 1) {
+            qlmin = min(qlmin, __shfl_xor(qlmin, o2, 64));
+            posmin = min(posmin, __shfl_xor(posmin, o2, 64));
+            maxpos = max(maxpos, __shfl_xor(maxpos, o2, 64));
+            anye |= __shfl_xor(anye, o2, 64);
+        }
+        if ((tid & 31) == 0) {
+            sm.t_qlmin[tid >> 5] = qlmin; sm.t_posmin[tid >> 5] = posmin; sm.t_maxpos[tid >> 5] = maxpos; sm.t_empty[tid >> 5] = anye;
+        }
+    }
+    store8(0);
+    load8(8);
+    store8(8);
+}
+
+// One 32-key tile against the resident query block.
+template <bool DROP>
+__device__ __forceinline__ void
+res_dkv_keytile(DkvRSmem& sm, const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv, const int32_t* __restrict__ kl,
+                int S, float scale, const AttnDropout& rng, float* dk, int lddk, float* dv, int lddv, const int b, const int kvh,
+                const int kt, const int n_qt, const bool fresh, const bool final_stage, const bool want_amax, const H2Scales& sc) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const SlOffsets lo(lane);
+    const int jk = kt * 32 + r;                          // this lane's key
+    const bool valid_k = jk < S;
+    const int64_t ktok = (int64_t)b * S + (valid_k ? jk : S - 1);
+
+    bf16x8 kf[2][4], vf[2][4];            // piece x k-step: lane (r, h) holds d = 16 s + 8 h .. + 7 of its key's K / V row
+    {
+        const float* krow = k + ktok * ldk + kvh * 64 + 8 * h;
+        const float* vrow = v + ktok * ldv + kvh * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float4 a4 = *reinterpret_cast<const float4*>(krow + 16 * s);
+            float4 b4 = *reinterpret_cast<const float4*>(krow + 16 * s + 4);
+            float4 c4 = *reinterpret_cast<const float4*>(vrow + 16 * s);
+            float4 d4 = *reinterpret_cast<const float4*>(vrow + 16 * s + 4);
+            if (!valid_k) { a4 = make_float4(0.f, 0.f, 0.f, 0.f); b4 = a4; c4 = a4; d4 = a4; }
+            bf16x8 pc[3];
+            cut8_t<true>(a4, b4, sc.k, pc);
+            kf[0][s] = pc[0]; kf[1][s] = pc[1];
+            cut8_t<true>(c4, d4, sc.v, pc);
+            vf[0][s] = pc[0]; vf[1][s] = pc[1];
+        }
+    }
+    const int my_kl = valid_k ? kl[ktok] : INT_BIG_A;
+    const int wave_kl_max = wave_max_i32(my_kl);
+    const int wave_k_lo = kt * 32, wave_k_hi = wave_k_lo + 31;
+    const float invS = 1.f / (float)S;
+    // (the products carry their operands' scales - folded into the constants that multiply them anyway)
+    const float c2 = scale * 1.4426950408889634f * sc.inv_qk;
+    const uint32_t bw = DROP ? rng.key_word((uint32_t)jk) : 0u;
+    const float cdp = sc.inv_v * sc.inv_do;              // dP = (dO' V'^T) cdp
+    const float sd = rng.scale * cdp;
+    float* dkrow = dk + ktok * lddk + kvh * 64;
+    float* dvrow = dv + ktok * lddv + kvh * 64;
+
+    f32x16 dkacc[2], dvacc[2];
+    if (fresh) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dkacc[0][i] = 0.f; dkacc[1][i] = 0.f; dvacc[0][i] = 0.f; dvacc[1][i] = 0.f; }
+    } else {
+        // the raw sums an earlier stage left (possibly another wave: read past the L1)
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * dh + 8 * g4 + 4 * h;
+                f32x4v a = {0.f, 0.f, 0.f, 0.f}, c = a;
+                if (valid_k) {
+                    a = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(dkrow + d));
+                    c = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(dvrow + d));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { dkacc[dh][4 * g4 + e] = a[e]; dvacc[dh][4 * g4 + e] = c[e]; }
+            }
+    }
+
+#pragma unroll 1
+    for (int qt = 0; qt < n_qt; ++qt) {
+        const bool tile_has_empty = __builtin_amdgcn_readfirstlane(sm.t_empty[qt]) != 0;
+        const int posmin = __builtin_amdgcn_readfirstlane(sm.t_posmin[qt]);
+        const int qlmin = __builtin_amdgcn_readfirstlane(sm.t_qlmin[qt]);
+        const int maxpos = __builtin_amdgcn_readfirstlane(sm.t_maxpos[qt]);
+        const bool tile_all_empty = tile_has_empty && posmin == INT_BIG_A;
+        const bool before = maxpos < wave_k_lo;            // every normal query of the tile precedes this wave's keys
+        if (before && !tile_has_empty) continue;
+        const bf16_t* q0 = sm.Q[0] + qt * SIMG;
+        const bf16_t* q1 = sm.Q[1] + qt * SIMG;
+        const bf16_t* o0 = sm.dO[0] + qt * SIMG;
+        const bf16_t* o1 = sm.dO[1] + qt * SIMG;
+        const float* ndl_t = sm.ndelta + qt * 32;
+        const float* nl_t = sm.nlse2 + qt * 32;
+        f32x16 st, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+        // S[query][key] = sum_d Q[query][d] K[key][d] and dP[query][key] = sum_d dO[query][d] V[key][d]
+        const bool need_s = !before && !tile_all_empty;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 c0 = *reinterpret_cast<const bf16x8*>(o0 + lo.row[s]);
+            const bf16x8 c1 = *reinterpret_cast<const bf16x8*>(o1 + lo.row[s]);
+            dp = mfma_piece<true>(c1, vf[0][s], dp);
+            dp = mfma_piece<true>(c0, vf[1][s], dp);
+            dp = mfma_piece<true>(c0, vf[0][s], dp);
+            if (need_s) {
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(q0 + lo.row[s]);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(q1 + lo.row[s]);
+                st = mfma_piece<true>(a1, kf[0][s], st);
+                st = mfma_piece<true>(a0, kf[1][s], st);
+                st = mfma_piece<true>(a0, kf[0][s], st);
+            }
+        }
+        // per element (query = register, key = lane):  P -> st (for dV, 1/(1-p) applied at the end), dS -> dp (for dK)
+        // Rows past the end of the sequence have Q = dO = 0, lse = delta = 0: p = 1 but dS = 0 and dO = 0.
+        auto elem_tile = [&]<bool MASK, bool EMPTYSEL, bool ALL_EMPTY>() {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int qb = 8 * g4 + 4 * h;
+                const float4 d4 = *reinterpret_cast<const float4*>(ndl_t + qb);
+                const float ndl[4] = {d4.x, d4.y, d4.z, d4.w};
+                float nl[4] = {0.f, 0.f, 0.f, 0.f};
+                int qlv[4] = {0, 0, 0, 0}, posv[4] = {0, 0, 0, 0}, emv[4] = {0, 0, 0, 0};
+                uint32_t awv[4] = {0, 0, 0, 0};
+                if (!ALL_EMPTY) {
+                    const float4 l4 = *reinterpret_cast<const float4*>(nl_t + qb);
+                    nl[0] = l4.x; nl[1] = l4.y; nl[2] = l4.z; nl[3] = l4.w;
+                }
+                if (MASK) {
+                    const int4 q4 = *reinterpret_cast<const int4*>(sm.ql + qt * 32 + qb);
+                    const int4 p4 = *reinterpret_cast<const int4*>(sm.pos + qt * 32 + qb);
+                    qlv[0] = q4.x; qlv[1] = q4.y; qlv[2] = q4.z; qlv[3] = q4.w;
+                    posv[0] = p4.x; posv[1] = p4.y; posv[2] = p4.z; posv[3] = p4.w;
+                }
+                if (EMPTYSEL) {
+                    const int4 e4 = *reinterpret_cast<const int4*>(sm.empty + qt * 32 + qb);
+                    emv[0] = e4.x; emv[1] = e4.y; emv[2] = e4.z; emv[3] = e4.w;
+                }
+                if (DROP) {
+                    const uint4 a4 = *reinterpret_cast<const uint4*>(sm.aw + qt * 32 + qb);
+                    awv[0] = a4.x; awv[1] = a4.y; awv[2] = a4.z; awv[3] = a4.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int reg = 4 * g4 + e;
+                    float pe;
+                    if (ALL_EMPTY) {
+                        pe = invS;
+                    } else {
+                        pe = __builtin_amdgcn_exp2f(fmaf(st[reg], c2, nl[e]));
+                        if (MASK) {
+                            const bool allowed = (jk <= posv[e]) & (my_kl < qlv[e]);
+                            pe = allowed ? pe : 0.f;
+                        }
+                        if (EMPTYSEL) pe = (emv[e] != 0) ? invS : pe;
+                    }
+                    if (DROP) {
+                        const bool keep = rng.keep(awv[e], bw);
+                        const float tt = keep ? dp[reg] : 0.f;
+                        dp[reg] = pe * fmaf(tt, sd, ndl[e]);         // dS[query][key]
+                        st[reg] = keep ? pe : 0.f;                   // dropped P[query][key] * (1 - p)
+                    } else {
+                        dp[reg] = pe * fmaf(dp[reg], cdp, ndl[e]);
+                        st[reg] = pe;
+                    }
+                }
+            }
+        };
+        if (tile_all_empty) {
+            elem_tile.template operator()<false, false, true>();
+        } else if (tile_has_empty) {
+            elem_tile.template operator()<true, true, false>();
+        } else {
+            const bool free_tile = (posmin >= wave_k_hi) && (wave_kl_max < qlmin);
+            if (free_tile) elem_tile.template operator()<false, false, false>();
+            else elem_tile.template operator()<true, false, false>();
+        }
+        // dV^T[d][key] += sum_query dO[query][d] Pd[query][key] ; dK^T[d][key] += sum_query Q[query][d] dS[query][key]
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pf[3], df[3];
+            cut8_regs_t<true>(st, 8 * s2, H2Scales::P, pf);
+            cut8_regs_t<true>(dp, 8 * s2, sc.ds, df);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                bf16x8 of[3], qfr[3];
+                of[0] = read_tr8(o0, lo, 16 * s2, db); of[1] = read_tr8(o1, lo, 16 * s2, db); of[2] = of[1];
+                dvacc[db] = mfma_pieces<true>(of, pf, dvacc[db]);
+                qfr[0] = read_tr8(q0, lo, 16 * s2, db); qfr[1] = read_tr8(q1, lo, 16 * s2, db); qfr[2] = qfr[1];
+                dkacc[db] = mfma_pieces<true>(qfr, df, dkacc[db]);
+            }
+        }
+    }
+
+    float vmax = 0.f;
+    if (valid_k) {
+        const float vs = final_stage ? (DROP ? rng.scale : 1.f) * (sc.inv_do * H2Scales::INV_P) : 1.f;
+        const float ks = final_stage ? scale * (sc.inv_q * sc.inv_ds) : 1.f;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * dh + 8 * g4 + 4 * h;
+                *reinterpret_cast<float4*>(dkrow + d) = make_float4(dkacc[dh][4 * g4] * ks, dkacc[dh][4 * g4 + 1] * ks,
+                                                                    dkacc[dh][4 * g4 + 2] * ks, dkacc[dh][4 * g4 + 3] * ks);
+                const float4 dv4 = make_float4(dvacc[dh][4 * g4] * vs, dvacc[dh][4 * g4 + 1] * vs,
+                                               dvacc[dh][4 * g4 + 2] * vs, dvacc[dh][4 * g4 + 3] * vs);
+                *reinterpret_cast<float4*>(dvrow + d) = dv4;
+                vmax = fmaxf(fmaxf(fmaxf(vmax, fabsf(dv4.x)), fabsf(dv4.y)), fmaxf(fabsf(dv4.z), fabsf(dv4.w)));
+            }
+    }
+    if (final_stage && want_amax) {                       // (gamer_amax_sink: max |dv|, the v columns of d(q|k|v))
+        uint32_t mw = __float_as_uint(vmax);
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) mw = max(mw, (uint32_t)__shfl_xor((int)mw, o2, 64));
+        if (lane == 0 && mw) atomicMax(&sm.amax_word, mw);
+    }
+}
+
+template <int G, bool DROP, bool ORD>
+__global__ void __launch_bounds__(DKV_R_THREADS, 1)
+attn_bwd_dkv_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv,
+                      const float* __restrict__ d_o, const float* __restrict__ lse, const float* delta,
+                      const int32_t* __restrict__ kl, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
+                      int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed, float* dk, int lddk, float* dv,
+                      int lddv, const RowOrder ro, uint32_t* __restrict__ amax_out, const AttnAmax am) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char res_raw[];
+    DkvRSmem& sm = *reinterpret_cast<DkvRSmem*>(res_raw);
+    const H2Scales sc(am.q, am.k, am.v, am.d_o, 1.f, 1.f / (1.f - p_drop));
+    const AttnDropout rng(p_drop, seed);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n_all = (S + 31) >> 5;
+    const int nqb = (S + RB_KEYS - 1) / RB_KEYS;
+    const int n_pairs = nbatch * nkv;
+    if (tid == 0) sm.amax_word = 0;
+#pragma unroll 1
+    for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+        const int b = pair / nkv, kvh = pair % nkv;
+#pragma unroll 1
+        for (int st_i = 0; st_i < G * nqb; ++st_i) {
+            const int g = st_i / nqb, qb = st_i % nqb;
+            __syncthreads();                                // every wave is done with the previous stage's images (and flags)
+            if (tid == 0) sm.ctr = 0;
+            if (st_i == 0 && tid < RES_MAX_TILES) sm.started[tid] = 0;
+            res_stage_queries<DROP, ORD>(sm, q, ldq, d_o, lse, delta, ql, row_empty, ro, b, kvh * G + g, qb * RB_KEYS, S, nq, tid, sc, rng);
+            __syncthreads();
+            const bool final_stage = st_i == G * nqb - 1;
+            const int n_qt = min(RB_TILES, n_all - qb * RB_TILES);
+            int blk_maxpos = -1, blk_empty = 0;
+#pragma unroll 1
+            for (int i = 0; i < n_qt; ++i) { blk_maxpos = max(blk_maxpos, sm.t_maxpos[i]); blk_empty |= sm.t_empty[i]; }
+            blk_maxpos = __builtin_amdgcn_readfirstlane(blk_maxpos);
+            blk_empty = __builtin_amdgcn_readfirstlane(blk_empty);
+            // key tiles from a queue, early keys (seen by the most queries) first; the last stage visits every key tile
+#pragma unroll 1
+            for (int kt = res_grab_ctr(&sm.ctr, lane); kt < n_all; kt = res_grab_ctr(&sm.ctr, lane)) {
+                if (!(final_stage || blk_empty != 0 || blk_maxpos >= kt * 32)) break;      // (nor does any later key tile)
+                const bool fresh = __builtin_amdgcn_readfirstlane(sm.started[kt]) == 0;
+                res_dkv_keytile<DROP>(sm, k, ldk, v, ldv, kl, S, scale, rng, dk, lddk, dv, lddv, b, kvh, kt, n_qt, fresh,
+                                      final_stage, amax_out != nullptr, sc);
+                if (lane == 0) sm.started[kt] = 1;
+            }
+        }
+    }
+    if (amax_out) {
+        __syncthreads();
+        if (tid == 0 && sm.amax_word) amax_publish(sm.amax_word, amax_out, blockIdx.x);
+    }
+}
+
 template <int G, bool DROP, bool ORD>
 static int launch_fwd_r_variant(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl,
                                 const int32_t* ql, const int32_t* row_empty, int B, int S, int nq, int nkv, float scale, float p_drop,
@@ -769,6 +1169,49 @@ int launch_dq_res(const float* q, int ldq, const float* k, int ldk, const float*
         else { if (ro.perm) GAMER_LAUNCH_DQ_R(2, false, true); else GAMER_LAUNCH_DQ_R(2, false, false); }
     }
 #undef GAMER_LAUNCH_DQ_R
+    return -1;      // not reached
+}
+
+template <int G, bool DROP, bool ORD>
+static int launch_dkv_r_variant(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* d_o,
+                                const float* lse, const float* delta, const int32_t* kl, const int32_t* ql, const int32_t* row_empty,
+                                int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed, float* dk, int lddk,
+                                float* dv, int lddv, RowOrder ro, uint32_t* amax_out, AttnAmax am, hipStream_t st) {
+    const size_t shmem = sizeof(DkvRSmem);
+    static bool attr_dev[MAX_DEVICES] = {};
+    bool& attr_set = attr_dev[current_device()];
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_r_kernel<G, DROP, ORD>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) {
+            set_error("gamer_attn_bwd_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    const int n_pairs = B * nkv;
+    const int grid = n_pairs < res_grid_cap() ? n_pairs : res_grid_cap();
+    hipLaunchKernelGGL((attn_bwd_dkv_r_kernel<G, DROP, ORD>), dim3(grid), dim3(DKV_R_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse,
+                       delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro, amax_out, am);
+    GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dkv resident");
+    return 0;
+}
+
+int launch_dkv_res(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* d_o, const float* lse,
+                   const float* delta, const int32_t* kl, const int32_t* ql, const int32_t* row_empty, int B, int S, int nq, int nkv,
+                   float scale, float p_drop, uint64_t seed, float* dk, int lddk, float* dv, int lddv, RowOrder ro, uint32_t* amax_out,
+                   AttnAmax am, hipStream_t st) {
+#define GAMER_LAUNCH_DKV_R(GV, DROPV, ORDV)                                                                                   \
+    return launch_dkv_r_variant<GV, DROPV, ORDV>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale,  \
+                                                 p_drop, seed, dk, lddk, dv, lddv, ro, amax_out, am, st)
+    if (nq / nkv == 1) {
+        if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_DKV_R(1, true, true); else GAMER_LAUNCH_DKV_R(1, true, false); }
+        else { if (ro.perm) GAMER_LAUNCH_DKV_R(1, false, true); else GAMER_LAUNCH_DKV_R(1, false, false); }
+    } else {
+        if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_DKV_R(2, true, true); else GAMER_LAUNCH_DKV_R(2, true, false); }
+        else { if (ro.perm) GAMER_LAUNCH_DKV_R(2, false, true); else GAMER_LAUNCH_DKV_R(2, false, false); }
+    }
+#undef GAMER_LAUNCH_DKV_R
     return -1;      // not reached
 }
 

@@ -1453,7 +1453,7 @@ static int launch_bwd_s_variant(const float* q, int ldq, const float* k, int ldk
         return 0;
     }
     if (ds_work == nullptr) {
-        if (h2 && res_enabled()) {
+        if (h2 && res_enabled() && S <= 2048 && res_part_enabled("GAMER_ATTN_RES_DQ")) {
             // K / V of a (sequence, kv head) resident in LDS (attention_res.hip)
             const int rc_dq = launch_dq_res(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop,
                                             seed, dq, lddq, ro, delta_ready, t_attn_amax, st);
@@ -1490,6 +1490,10 @@ static int launch_bwd_s_variant(const float* q, int ldq, const float* k, int ldk
                            lddk, dv, lddv, ro, ds_work, t_amax_out, t_attn_amax);
         return 0;
     };
+    if (h2 && ds_work == nullptr && res_enabled() && S <= 2048 && res_part_enabled("GAMER_ATTN_RES_DKV"))
+        // Q / dO of a (sequence, head, query block) resident in LDS, key tiles from a queue (attention_res.hip)
+        return launch_dkv_res(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv,
+                              lddv, ro, t_amax_out, t_attn_amax, st);
     const int rc_dkv = h2 ? launch_dkv.template operator()<true>() : launch_dkv.template operator()<false>();
     if (rc_dkv) return rc_dkv;
     GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dkv");
@@ -1554,7 +1558,7 @@ extern "C" int gamer_attn_fwd_split(const float* q, int ldq, const float* k, int
     GAMER_CHECK_ARG(!t_attn_amax.q || p_drop < 0.75f, "gamer_attn_fwd_split: the three-product fp16 form needs p_drop < 0.75 (p_drop=%f): "
                     "its probabilities are cut at a fixed 2^13 scale; do not arm gamer_attn_split_amax for this call", p_drop);
     GAMER_CHECK_ARG(!q_span || t_attn_amax.q, "gamer_attn_fwd_split: q_span is built for the three-product form (arm gamer_attn_split_amax)");
-    if (t_attn_amax.q && !q_span && uspan == S && res_enabled())
+    if (t_attn_amax.q && !q_span && uspan == S && S <= 2048 && res_enabled())
         // the three-product form with training semantics: K / V of a (sequence, kv head) resident in LDS (attention_res.hip)
         rc = launch_fwd_res(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, t_amax_out, t_attn_amax, st);
     else

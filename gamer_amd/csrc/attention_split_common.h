@@ -223,6 +223,10 @@ static inline bool res_enabled() {
     const char* e = getenv("GAMER_ATTN_RES");          // (read per call: tests switch it inside one process)
     return e ? atoi(e) != 0 : true;
 }
+static inline bool res_part_enabled(const char* name) {      // GAMER_ATTN_RES_DQ / _DKV = 0: that kernel stays tiled (A/B runs)
+    const char* e = getenv(name);
+    return e ? atoi(e) != 0 : true;
+}
 // persistent workgroups: one per CU (GAMER_ATTN_RES_GRID overrides)
 static inline int res_grid_cap() {
     static int cap[MAX_DEVICES] = {};
@@ -242,5 +246,9 @@ int launch_dq_res(const float* q, int ldq, const float* k, int ldk, const float*
                   const float* lse, float* delta, const int32_t* kl, const int32_t* ql, const int32_t* row_empty, int B, int S,
                   int nq, int nkv, float scale, float p_drop, uint64_t seed, float* dq, int lddq, RowOrder ro, int delta_ready,
                   AttnAmax am, hipStream_t st);
+int launch_dkv_res(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* d_o, const float* lse,
+                   const float* delta, const int32_t* kl, const int32_t* ql, const int32_t* row_empty, int B, int S, int nq, int nkv,
+                   float scale, float p_drop, uint64_t seed, float* dk, int lddk, float* dv, int lddv, RowOrder ro, uint32_t* amax_out,
+                   AttnAmax am, hipStream_t st);
 
 }  // namespace gamer
