@@ -203,12 +203,12 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
         for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid_q) t4 = *reinterpret_cast<const float4*>(orow + 32 * dh + 8 * g4 + 4 * h);
-                oacc[dh][4 * g4 + 0] = t4.x * up; oacc[dh][4 * g4 + 1] = t4.y * up;
-                oacc[dh][4 * g4 + 2] = t4.z * up; oacc[dh][4 * g4 + 3] = t4.w * up;
+                f32x4v t4 = {0.f, 0.f, 0.f, 0.f};            // (possibly stored by another wave of this workgroup: read past the L1)
+                if (valid_q) t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(orow + 32 * dh + 8 * g4 + 4 * h));
+                oacc[dh][4 * g4 + 0] = t4[0] * up; oacc[dh][4 * g4 + 1] = t4[1] * up;
+                oacc[dh][4 * g4 + 2] = t4[2] * up; oacc[dh][4 * g4 + 3] = t4[3] * up;
             }
-        const float L = normal ? *lse_p : -INFINITY;
+        const float L = normal ? __builtin_nontemporal_load(lse_p) : -INFINITY;
         const bool had = L > -INFINITY;                 // (a row whose keys so far were all blocked: nothing accumulated)
         m_ref = had ? L : 0.f;
         l_run = had ? 1.f : 0.f;
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(RES_THREADS, 1)
 attn_fwd_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv,
                   const int32_t* __restrict__ kl, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
                   int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed, float* o, float* lse,
-                  const RowOrder ro, uint32_t* __restrict__ amax_out, const AttnAmax am) {
+                  const RowOrder ro, uint32_t* __restrict__ amax_out, const AttnAmax am, const int split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char res_raw[];
     ResSmem& sm = *reinterpret_cast<ResSmem*>(res_raw);
     const H2Scales sc(am.q, am.k, am.v, nullptr, scale * 1.4426950408889634f);
@@ -385,8 +385,11 @@ attn_fwd_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
     const int tid = threadIdx.x;
     const int n_all = (S + 31) >> 5;
     const int nblk = (S + RB_KEYS - 1) / RB_KEYS;
-    const int n_items = G * n_all;                          // (head of the pair, row tile) items of one key block
-    const int n_pairs = nbatch * nkv;
+    // unit of a workgroup: a (sequence, kv head) pair with its G query heads, or - split, when the pairs do not fill the CUs evenly
+    // (per-GPU batch 128: 384 pairs on 256 CUs) - ONE query head of it (K / V are then staged once per head)
+    const int hpu = split ? 1 : G, upp = G / hpu;
+    const int n_items = hpu * n_all;                        // (head of the unit, row tile) items of one key block
+    const int n_pairs = nbatch * nkv * upp;                 // (units)
     const int lane = tid & 63, r = lane & 31;
     if (tid == 0) sm.amax_word = 0;
 #if RES_STAMP
@@ -395,7 +398,7 @@ attn_fwd_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
 #endif
 #pragma unroll 1
     for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
-        const int b = pair / nkv, kvh = pair % nkv;
+        const int b = (pair / upp) / nkv, kvh = (pair / upp) % nkv, h0 = (pair % upp) * hpu;
         const float* kbase = k + (int64_t)b * S * ldk + kvh * 64;
         const float* vbase = v + (int64_t)b * S * ldv + kvh * 64;
         const int32_t* klb = kl + (int64_t)b * S;
@@ -416,24 +419,24 @@ attn_fwd_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
                 if (nkb == nblk) { nkb = 0; npair += gridDim.x; }
                 if (npair < n_pairs) {
                     const int j = min(nkb * RB_KEYS + (tid >> 1), S - 1);
-                    const int64_t nrow = (int64_t)(npair / nkv) * S + j;
-                    tk0 = *reinterpret_cast<const uint32_t*>(k + nrow * ldk + (npair % nkv) * 64 + (tid & 1) * 32);
-                    tk1 = *reinterpret_cast<const uint32_t*>(v + nrow * ldv + (npair % nkv) * 64 + (tid & 1) * 32);
+                    const int64_t nrow = (int64_t)((npair / upp) / nkv) * S + j;
+                    tk0 = *reinterpret_cast<const uint32_t*>(k + nrow * ldk + ((npair / upp) % nkv) * 64 + (tid & 1) * 32);
+                    tk1 = *reinterpret_cast<const uint32_t*>(v + nrow * ldv + ((npair / upp) % nkv) * 64 + (tid & 1) * 32);
                 }
             }
             // the block's row tiles: late (long) tiles first, taken from a queue - whichever wave is free takes the next one (the
             // carried state of a tile travels through global memory, workgroup barriers in between: any wave may continue it)
             int cur = res_grab(sm, lane);
             int perm_cur = 0;
-            if (ORD && cur < n_items) perm_cur = ro.perm[(int64_t)b * S + min((n_all - 1 - cur / G) * 32 + r, S - 1)];
+            if (ORD && cur < n_items) perm_cur = ro.perm[(int64_t)b * S + min((n_all - 1 - cur / hpu) * 32 + r, S - 1)];
 #pragma unroll 1
             while (cur < n_items) {
                 const int nxt = res_grab(sm, lane);
-                const int hg = cur % G, t = n_all - 1 - cur / G;
+                const int hg = h0 + cur % hpu, t = n_all - 1 - cur / hpu;
                 ResNext nx;
-                nx.t = n_all - 1 - nxt / G;
-                nx.head = kvh * G + nxt % G;
-                nx.valid = nxt < n_items && (kb == 0 || sm.ntot[(nxt % G) * RES_MAX_TILES + nx.t] > kb * RB_TILES);
+                nx.t = n_all - 1 - nxt / hpu;
+                nx.head = kvh * G + h0 + nxt % hpu;
+                nx.valid = nxt < n_items && (kb == 0 || sm.ntot[(h0 + nxt % hpu) * RES_MAX_TILES + nx.t] > kb * RB_TILES);
                 nx.perm = 0;
                 if (ORD && nxt < n_items) nx.perm = ro.perm[(int64_t)b * S + min(nx.t * 32 + r, S - 1)];
                 if (kb == 0 || sm.ntot[hg * RES_MAX_TILES + t] > kb * RB_TILES)
@@ -503,6 +506,7 @@ res_dq_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const float* _
     if (kb > 0 && jt_lo >= n_total) return;
     const int jt_hi = min(n_total, jt_lo + RB_TILES);
     const bool first = kb == 0, last = jt_lo + RB_TILES >= n_total;
+    if (first && lane == 0) sm.ntot[(head % G) * RES_MAX_TILES + t] = n_total;     // (later blocks skip finished tiles without loading anything)
 
     // log2 domain: q is pre-scaled by scale*log2(e) and the score accumulators start at -lse*log2(e), so p = exp2(accumulator)
     const float qs = scale * 1.4426950408889634f;
@@ -550,9 +554,9 @@ res_dq_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const float* _
         }
         if (need_delta) {
             my_delta += __shfl_xor(my_delta, 32, 64);
-            if (valid_q) *delta_p = my_delta;        // (both lane halves store the same value: each reads back its own store in later passes)
+            if (valid_q && h == 0) *delta_p = my_delta;
         } else {
-            my_delta = *delta_p;
+            my_delta = __builtin_nontemporal_load(delta_p);       // (possibly stored by another wave of this workgroup: past the L1)
         }
     }
     const float neg_lse2 = -lse[((int64_t)b * nq + head) * S + iqc] * 1.4426950408889634f;
@@ -571,9 +575,9 @@ res_dq_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const float* _
         for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid_q) t4 = *reinterpret_cast<const float4*>(dqrow + 32 * dh + 8 * g4 + 4 * h);
-                dqacc[dh][4 * g4 + 0] = t4.x; dqacc[dh][4 * g4 + 1] = t4.y; dqacc[dh][4 * g4 + 2] = t4.z; dqacc[dh][4 * g4 + 3] = t4.w;
+                f32x4v t4 = {0.f, 0.f, 0.f, 0.f};
+                if (valid_q) t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(dqrow + 32 * dh + 8 * g4 + 4 * h));
+                dqacc[dh][4 * g4 + 0] = t4[0]; dqacc[dh][4 * g4 + 1] = t4[1]; dqacc[dh][4 * g4 + 2] = t4[2]; dqacc[dh][4 * g4 + 3] = t4[3];
             }
     }
 
@@ -702,33 +706,34 @@ attn_bwd_dq_r_kernel(const float* __restrict__ q, int ldq, const float* __restri
                      const float* __restrict__ o, const float* __restrict__ d_o, const float* __restrict__ lse, float* delta,
                      const int32_t* __restrict__ kl, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
                      int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed, float* dq, int lddq,
-                     const RowOrder ro, const int delta_ready, const AttnAmax am) {
+                     const RowOrder ro, const int delta_ready, const AttnAmax am, const int split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char res_raw[];
     ResSmem& sm = *reinterpret_cast<ResSmem*>(res_raw);
-    constexpr int NWH = 8 / G;
     const H2Scales sc(am.q, am.k, am.v, am.d_o, scale * 1.4426950408889634f, 1.f / (1.f - p_drop));
     const AttnDropout rng(p_drop, seed);
-    const int tid = threadIdx.x, w = tid >> 6;
-    const int hg = w / NWH, sub = w % NWH;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int n_all = (S + 31) >> 5;
     const int nblk = (S + RB_KEYS - 1) / RB_KEYS;
-    const int n_chunks = (n_all + NWH - 1) / NWH;
-    const int n_pairs = nbatch * nkv;
+    const int hpu = split ? 1 : G, upp = G / hpu;           // (units: see attn_fwd_r_kernel)
+    const int n_items = hpu * n_all;
+    const int n_units = nbatch * nkv * upp;
 #pragma unroll 1
-    for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
-        const int b = pair / nkv, kvh = pair % nkv;
+    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const int b = (unit / upp) / nkv, kvh = (unit / upp) % nkv, h0 = (unit % upp) * hpu;
         const float* kbase = k + (int64_t)b * S * ldk + kvh * 64;
         const float* vbase = v + (int64_t)b * S * ldv + kvh * 64;
         const int32_t* klb = kl + (int64_t)b * S;
 #pragma unroll 1
         for (int kb = 0; kb < nblk; ++kb) {
             __syncthreads();
+            if (tid == 0) sm.ctr = 0;
             res_stage_block<DROP>(sm, kbase, ldk, vbase, ldv, klb, kb * RB_KEYS, S, tid, sc, rng);
             __syncthreads();
+            // row tiles from the block's queue, late (long) tiles first
 #pragma unroll 1
-            for (int c = n_chunks - 1; c >= 0; --c) {
-                const int t = (c & 1) ? c * NWH + NWH - 1 - sub : c * NWH + sub;
-                if (t < n_all)
+            for (int cur = res_grab(sm, lane); cur < n_items; cur = res_grab(sm, lane)) {
+                const int hg = h0 + cur % hpu, t = n_all - 1 - cur / hpu;
+                if (kb == 0 || sm.ntot[hg * RES_MAX_TILES + t] > kb * RB_TILES)
                     res_dq_rowtile<G, DROP, ORD>(sm, q, ldq, o, d_o, lse, delta, ql, row_empty, S, nq, scale, rng, dq, lddq, ro, b,
                                                  kvh * G + hg, t, kb, delta_ready, sc);
             }
@@ -1088,6 +1093,439 @@ attn_bwd_dkv_r_kernel(const float* __restrict__ q, int ldq, const float* __restr
     }
 }
 
+
+// =============================================================================================
+// backward: dK, dV for a GQA group of two query heads - TWO chains per wave.  tools/ubench_fill.hip on MI355X: inside one wave up to
+// ~6 plain vector instructions (or 2 v_exp) issue in the shadow of one 32 x 32 x 16 MFMA at no cost; an in-order wave with ONE chain
+// (products -> element-wise -> products, each depending on the one before) can never use that, and that is where the tiled and the
+// single-chain resident kernels spend 60 % of their cycles.  Here a wave owns 32 keys and, for every 32-query tile, BOTH heads of the
+// kv group (the same rows: Q / dO of both heads for a block of 128 query slots are resident, 128 KB): four slots per tile,
+//     F(A)   |   E(A) beside F(B)   |   S(A) beside E(B)   |   S(B)
+// (F: S = Q K^T and dP = dO V^T, 24 MFMAs; E: the ~230 vector instructions per tile that turn them into the fp16 pieces of P and dS;
+// S: dV^T += dO^T P, dK^T += Q^T dS, 24 MFMAs), so the vector work of one head sits beside the matrix work of the other in one
+// basic block.  Four waves per workgroup = one per SIMD with the whole 512-register file: the wave's K / V fragments (64 registers),
+// dK^T / dV^T of its keys (64; both heads add into them - the GQA sum needs no LDS pass), two heads' S / dP tiles and pieces.
+// Stages (query blocks of 128 slots, in order), the key-tile queue and the carry of a key tile's raw sums through dk / dv are those of
+// the single-chain kernel above.
+// =============================================================================================
+constexpr int QB2 = 128;                      // query slots of one resident block
+constexpr int QB2_TILES = QB2 / 32;
+constexpr int QIMG2 = QB2 * 64;               // 16-bit elements of one piece image of one head
+struct DkvR2Smem {
+    bf16_t Q[2][2][QIMG2];                    // head x piece
+    bf16_t dO[2][2][QIMG2];
+    float nlse2[2][QB2];
+    float ndelta[2][QB2];
+    uint32_t aw[2][QB2];
+    int32_t ql[QB2];
+    int32_t empty[QB2];
+    int32_t pos[QB2];
+    int32_t t_qlmin[QB2_TILES];
+    int32_t t_posmin[QB2_TILES];
+    int32_t t_maxpos[QB2_TILES];
+    int32_t t_empty[QB2_TILES];
+    int32_t started[RES_MAX_TILES];
+    uint32_t amax_word;
+    int32_t ctr;
+    int32_t pad_[6];
+};
+
+template <bool DROP, bool ORD>
+__device__ __forceinline__ void
+res2_stage_queries(DkvR2Smem& sm, const float* __restrict__ q, int ldq, const float* __restrict__ d_o, const float* __restrict__ lse,
+                   const float* delta, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty, const RowOrder& ro,
+                   int b, int head0, int s0, int S, int nq, int tid, const H2Scales& sc, const AttnDropout& rng) {
+    const int32_t* pmap = ORD ? ro.perm + (int64_t)b * S : nullptr;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float4 rq[8], rd[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int f = tid + DKV_R_THREADS * p;
+            const int sl = min(s0 + (f >> 4), S - 1);
+            const int64_t tok = (int64_t)b * S + (ORD ? pmap[sl] : sl);
+            rq[p] = *reinterpret_cast<const float4*>(q + tok * ldq + (head0 + g) * 64 + ((f & 15) << 2));
+            rd[p] = *reinterpret_cast<const float4*>(d_o + tok * (int64_t)nq * 64 + (head0 + g) * 64 + ((f & 15) << 2));
+        }
+        if (g == 0) {
+            // per-row scalars: threads 0..127 head 0 and the rows' own data, threads 128..255 head 1
+            const int row = tid & (QB2 - 1), hh = tid >> 7;
+            const int sl = s0 + row;
+            const bool in = sl < S;
+            const int pos = in ? (ORD ? pmap[sl] : sl) : 0;
+            const int64_t hrow = ((int64_t)b * nq + head0 + hh) * S + pos;
+            sm.nlse2[hh][row] = in ? -lse[hrow] * 1.4426950408889634f : 0.f;
+            sm.ndelta[hh][row] = in ? -delta[hrow] : 0.f;
+            if (DROP) sm.aw[hh][row] = rng.row_word((uint32_t)hrow);
+            if (hh == 0) {
+                const int em = in ? row_empty[(int64_t)b * S + pos] : 0;
+                const int qlv = in ? (ql ? ql[(int64_t)b * S + pos] : 1) : 0;
+                sm.ql[row] = qlv;
+                sm.empty[row] = em;
+                sm.pos[row] = in ? pos : S;
+                const bool normal = in && em == 0;
+                int qlmin = normal ? qlv : INT_BIG_A, posmin = normal ? pos : INT_BIG_A, maxpos = normal ? pos : -1, anye = em != 0 ? 1 : 0;
+#pragma unroll
+                for (int o2 = 16; o2 > 0; o2 >>= 1) {
+                    qlmin = min(qlmin, __shfl_xor(qlmin, o2, 64));
+                    posmin = min(posmin, __shfl_xor(posmin, o2, 64));
+                    maxpos = max(maxpos, __shfl_xor(maxpos, o2, 64));
+                    anye |= __shfl_xor(anye, o2, 64);
+                }
+                if ((row & 31) == 0) {
+                    sm.t_qlmin[row >> 5] = qlmin; sm.t_posmin[row >> 5] = posmin; sm.t_maxpos[row >> 5] = maxpos; sm.t_empty[row >> 5] = anye;
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int f = tid + DKV_R_THREADS * p;
+            const int row = f >> 4;
+            const bool ok = s0 + row < S;
+            const int off = sl_off(row, (f & 15) << 2);
+            uint32_t a0, a1, b0, b1;
+            cut2h_quad(ok ? rq[p].x : 0.f, ok ? rq[p].y : 0.f, ok ? rq[p].z : 0.f, ok ? rq[p].w : 0.f, sc.q, a0, a1, b0, b1);
+            *reinterpret_cast<uint2*>(sm.Q[g][0] + off) = make_uint2(a0, b0);
+            *reinterpret_cast<uint2*>(sm.Q[g][1] + off) = make_uint2(a1, b1);
+            cut2h_quad(ok ? rd[p].x : 0.f, ok ? rd[p].y : 0.f, ok ? rd[p].z : 0.f, ok ? rd[p].w : 0.f, sc.d_o, a0, a1, b0, b1);
+            *reinterpret_cast<uint2*>(sm.dO[g][0] + off) = make_uint2(a0, b0);
+            *reinterpret_cast<uint2*>(sm.dO[g][1] + off) = make_uint2(a1, b1);
+        }
+    }
+}
+
+// classes of a query tile (the same for both heads: they share the rows)
+enum { QT_FREE = 0, QT_MASK = 1, QT_EMPTYSEL = 2, QT_ALL_EMPTY = 3 };
+
+template <bool DROP>
+__device__ __forceinline__ void
+res2_dkv_keytile(DkvR2Smem& sm, const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv,
+                 const int32_t* __restrict__ kl, int S, float scale, const AttnDropout& rng, float* dk, int lddk, float* dv, int lddv,
+                 const int b, const int kvh, const int kt, const int n_qt, const bool fresh, const bool final_stage,
+                 const bool want_amax, const H2Scales& sc RES_STAMP_ARGS) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const SlOffsets lo(lane);
+    const int jk = kt * 32 + r;                          // this lane's key
+    const bool valid_k = jk < S;
+    const int64_t ktok = (int64_t)b * S + (valid_k ? jk : S - 1);
+
+    bf16x8 kf[2][4], vf[2][4];            // piece x k-step: lane (r, h) holds d = 16 s + 8 h .. + 7 of its key's K / V row
+    {
+        const float* krow = k + ktok * ldk + kvh * 64 + 8 * h;
+        const float* vrow = v + ktok * ldv + kvh * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float4 a4 = *reinterpret_cast<const float4*>(krow + 16 * s);
+            float4 b4 = *reinterpret_cast<const float4*>(krow + 16 * s + 4);
+            float4 c4 = *reinterpret_cast<const float4*>(vrow + 16 * s);
+            float4 d4 = *reinterpret_cast<const float4*>(vrow + 16 * s + 4);
+            if (!valid_k) { a4 = make_float4(0.f, 0.f, 0.f, 0.f); b4 = a4; c4 = a4; d4 = a4; }
+            bf16x8 pc[3];
+            cut8_t<true>(a4, b4, sc.k, pc);
+            kf[0][s] = pc[0]; kf[1][s] = pc[1];
+            cut8_t<true>(c4, d4, sc.v, pc);
+            vf[0][s] = pc[0]; vf[1][s] = pc[1];
+        }
+    }
+    const int my_kl = valid_k ? kl[ktok] : INT_BIG_A;
+    const int wave_kl_max = wave_max_i32(my_kl);
+    const int wave_k_lo = kt * 32, wave_k_hi = wave_k_lo + 31;
+    const float invS = 1.f / (float)S;
+    const float c2 = scale * 1.4426950408889634f * sc.inv_qk;
+    const uint32_t bw = DROP ? rng.key_word((uint32_t)jk) : 0u;
+    const float cdp = sc.inv_v * sc.inv_do;              // dP = (dO' V'^T) cdp
+    const float sd = rng.scale * cdp;
+    float* dkrow = dk + ktok * lddk + kvh * 64;
+    float* dvrow = dv + ktok * lddv + kvh * 64;
+
+    f32x16 dkacc[2], dvacc[2];
+    if (fresh) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dkacc[0][i] = 0.f; dkacc[1][i] = 0.f; dvacc[0][i] = 0.f; dvacc[1][i] = 0.f; }
+    } else {
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * dh + 8 * g4 + 4 * h;
+                f32x4v a = {0.f, 0.f, 0.f, 0.f}, c = a;
+                if (valid_k) {
+                    a = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(dkrow + d));
+                    c = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(dvrow + d));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { dkacc[dh][4 * g4 + e] = a[e]; dvacc[dh][4 * g4 + e] = c[e]; }
+            }
+    }
+
+    // ---- the pieces of a tile's work ------------------------------------------------------------------------------------------
+    // F, k-step s of head g / tile qt: the row fragments of dO and Q (A operands)
+    auto f_reads = [&](int g, int qt, int s, bf16x8 (&a)[4]) {
+        a[0] = *reinterpret_cast<const bf16x8*>(sm.dO[g][0] + qt * SIMG + lo.row[s]);
+        a[1] = *reinterpret_cast<const bf16x8*>(sm.dO[g][1] + qt * SIMG + lo.row[s]);
+        a[2] = *reinterpret_cast<const bf16x8*>(sm.Q[g][0] + qt * SIMG + lo.row[s]);
+        a[3] = *reinterpret_cast<const bf16x8*>(sm.Q[g][1] + qt * SIMG + lo.row[s]);
+    };
+    // S, group (s2, db) of head g / tile qt: dV^T += dO^T P, dK^T += Q^T dS (transposing reads of the resident images)
+    auto s_reads = [&](int g, int qt, int s2, int db, bf16x8 (&a)[4]) {
+        a[0] = read_tr8(sm.dO[g][0] + qt * SIMG, lo, 16 * s2, db);
+        a[1] = read_tr8(sm.dO[g][1] + qt * SIMG, lo, 16 * s2, db);
+        a[2] = read_tr8(sm.Q[g][0] + qt * SIMG, lo, 16 * s2, db);
+        a[3] = read_tr8(sm.Q[g][1] + qt * SIMG, lo, 16 * s2, db);
+    };
+    auto e_cut = [&](int s2, const f32x16& st, const f32x16& dp, bf16x8 (&pf)[2][2], bf16x8 (&df)[2][2]) {
+        bf16x8 t3[3];
+        cut8_regs_t<true>(st, 8 * s2, H2Scales::P, t3);
+        pf[s2][0] = t3[0]; pf[s2][1] = t3[1];
+        cut8_regs_t<true>(dp, 8 * s2, sc.ds, t3);
+        df[s2][0] = t3[0]; df[s2][1] = t3[1];
+    };
+
+    RES_MARK(1);                                           // 1: key-tile prologue (K / V rows + cut, key data, carried sums)
+    // F of one k-step / S of one (s2, db) group: six MFMAs each
+    auto f_step = [&]<bool NEED_S>(const bf16x8 (&a)[4], int s, f32x16& st, f32x16& dp) {
+        dp = mfma_piece<true>(a[1], vf[0][s], dp);
+        if (NEED_S) st = mfma_piece<true>(a[3], kf[0][s], st);
+        dp = mfma_piece<true>(a[0], vf[1][s], dp);
+        if (NEED_S) st = mfma_piece<true>(a[2], kf[1][s], st);
+        dp = mfma_piece<true>(a[0], vf[0][s], dp);
+        if (NEED_S) st = mfma_piece<true>(a[2], kf[0][s], st);
+    };
+    auto s_step = [&](const bf16x8 (&a)[4], const bf16x8 (&pf)[2][2], const bf16x8 (&df)[2][2], int s2, int db) {
+        dvacc[db] = mfma_piece<true>(a[1], pf[s2][0], dvacc[db]);
+        dkacc[db] = mfma_piece<true>(a[3], df[s2][0], dkacc[db]);
+        dvacc[db] = mfma_piece<true>(a[0], pf[s2][1], dvacc[db]);
+        dkacc[db] = mfma_piece<true>(a[2], df[s2][1], dkacc[db]);
+        dvacc[db] = mfma_piece<true>(a[0], pf[s2][0], dvacc[db]);
+        dkacc[db] = mfma_piece<true>(a[2], df[s2][0], dkacc[db]);
+    };
+    // E, registers 4 g4 .. 4 g4 + 3 of head g / tile qt (query = register, key = lane):  P -> st (1 / (1 - p) applied at the end), dS -> dp
+    // Rows past the end of the sequence have Q = dO = 0, lse = delta = 0: p = 1 but dS = 0 and dO = 0.
+    auto e_chunk = [&]<int CLS>(int g, int qt, int g4, f32x16& st, f32x16& dp) {
+        constexpr bool MASK = CLS == QT_MASK || CLS == QT_EMPTYSEL, EMPTYSEL = CLS == QT_EMPTYSEL, ALL_EMPTY = CLS == QT_ALL_EMPTY;
+        const int qb = qt * 32 + 8 * g4 + 4 * h;
+        const float4 d4 = *reinterpret_cast<const float4*>(&sm.ndelta[g][qb]);
+        const float ndl[4] = {d4.x, d4.y, d4.z, d4.w};
+        float nl[4] = {0.f, 0.f, 0.f, 0.f};
+        int qlv[4] = {0, 0, 0, 0}, posv[4] = {0, 0, 0, 0}, emv[4] = {0, 0, 0, 0};
+        uint32_t awv[4] = {0, 0, 0, 0};
+        if (!ALL_EMPTY) {
+            const float4 l4 = *reinterpret_cast<const float4*>(&sm.nlse2[g][qb]);
+            nl[0] = l4.x; nl[1] = l4.y; nl[2] = l4.z; nl[3] = l4.w;
+        }
+        if (MASK) {
+            const int4 q4 = *reinterpret_cast<const int4*>(&sm.ql[qb]);
+            const int4 p4 = *reinterpret_cast<const int4*>(&sm.pos[qb]);
+            qlv[0] = q4.x; qlv[1] = q4.y; qlv[2] = q4.z; qlv[3] = q4.w;
+            posv[0] = p4.x; posv[1] = p4.y; posv[2] = p4.z; posv[3] = p4.w;
+        }
+        if (EMPTYSEL) {
+            const int4 e4 = *reinterpret_cast<const int4*>(&sm.empty[qb]);
+            emv[0] = e4.x; emv[1] = e4.y; emv[2] = e4.z; emv[3] = e4.w;
+        }
+        if (DROP) {
+            const uint4 a4 = *reinterpret_cast<const uint4*>(&sm.aw[g][qb]);
+            awv[0] = a4.x; awv[1] = a4.y; awv[2] = a4.z; awv[3] = a4.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int reg = 4 * g4 + e;
+            float pe;
+            if (ALL_EMPTY) {
+                pe = invS;
+            } else {
+                pe = __builtin_amdgcn_exp2f(fmaf(st[reg], c2, nl[e]));
+                if (MASK) {
+                    const bool allowed = (jk <= posv[e]) & (my_kl < qlv[e]);
+                    pe = allowed ? pe : 0.f;
+                }
+                if (EMPTYSEL) pe = (emv[e] != 0) ? invS : pe;
+            }
+            if (DROP) {
+                const bool keep = rng.keep(awv[e], bw);
+                const float tt = keep ? dp[reg] : 0.f;
+                dp[reg] = pe * fmaf(tt, sd, ndl[e]);         // dS[query][key]
+                st[reg] = keep ? pe : 0.f;                   // dropped P[query][key] * (1 - p)
+            } else {
+                dp[reg] = pe * fmaf(dp[reg], cdp, ndl[e]);
+                st[reg] = pe;
+            }
+        }
+    };
+    // first query tile that reaches this wave's keys (slots are sorted: normal rows by position, then the "empty" rows)
+    int q_first = 0;
+    while (q_first < n_qt && sm.t_maxpos[q_first] < wave_k_lo && sm.t_empty[q_first] == 0) ++q_first;
+    q_first = __builtin_amdgcn_readfirstlane(q_first);
+
+#pragma unroll 1
+    for (int qt = q_first; qt < n_qt; ++qt) {
+        const bool tile_has_empty = __builtin_amdgcn_readfirstlane(sm.t_empty[qt]) != 0;
+        const int posmin = __builtin_amdgcn_readfirstlane(sm.t_posmin[qt]);
+        const int qlmin = __builtin_amdgcn_readfirstlane(sm.t_qlmin[qt]);
+        const int maxpos = __builtin_amdgcn_readfirstlane(sm.t_maxpos[qt]);
+        const bool tile_all_empty = tile_has_empty && posmin == INT_BIG_A;
+        const bool before = maxpos < wave_k_lo;            // every normal query of the tile precedes this wave's keys
+        if (before && !tile_has_empty) continue;
+        const bool need_s = !before && !tile_all_empty;
+        const bool free_tile = !tile_has_empty && (posmin >= wave_k_hi) && (wave_kl_max < qlmin);
+
+        f32x16 stA, dpA, stB, dpB;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { stA[i] = 0.f; dpA[i] = 0.f; stB[i] = 0.f; dpB[i] = 0.f; }
+        bf16x8 pfA[2][2], dfA[2][2], pfB[2][2], dfB[2][2];
+
+        // ---- slot 1: F(A) -------------------------------------------------------------------------------------------------
+        {
+            bf16x8 a[4][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) f_reads(0, qt, s, a[s]);
+            if (need_s) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) f_step.template operator()<true>(a[s], s, stA, dpA);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) f_step.template operator()<false>(a[s], s, stA, dpA);
+            }
+        }
+        // ---- slot 2: E(A) beside F(B) -----------------------------------------------------------------------------------
+        auto slot2 = [&]<int CLS, bool NEED_S>() {
+            bf16x8 a[4][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) f_reads(1, qt, s, a[s]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                f_step.template operator()<NEED_S>(a[s], s, stB, dpB);
+                e_chunk.template operator()<CLS>(0, qt, s, stA, dpA);
+                if (s & 1) e_cut(s >> 1, stA, dpA, pfA, dfA);
+            }
+        };
+        // ---- slot 3: S(A) beside E(B) -----------------------------------------------------------------------------------
+        auto slot3 = [&]<int CLS>() {
+            bf16x8 a[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_reads(0, qt, i >> 1, i & 1, a[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s_step(a[i], pfA, dfA, i >> 1, i & 1);
+                e_chunk.template operator()<CLS>(1, qt, i, stB, dpB);
+                if (i & 1) e_cut(i >> 1, stB, dpB, pfB, dfB);
+            }
+        };
+        if (tile_all_empty) { slot2.template operator()<QT_ALL_EMPTY, false>(); slot3.template operator()<QT_ALL_EMPTY>(); }
+        else if (tile_has_empty) {
+            if (need_s) slot2.template operator()<QT_EMPTYSEL, true>(); else slot2.template operator()<QT_EMPTYSEL, false>();
+            slot3.template operator()<QT_EMPTYSEL>();
+        } else if (free_tile) { slot2.template operator()<QT_FREE, true>(); slot3.template operator()<QT_FREE>(); }
+        else { slot2.template operator()<QT_MASK, true>(); slot3.template operator()<QT_MASK>(); }
+        // ---- slot 4: S(B) -------------------------------------------------------------------------------------------------
+        {
+            bf16x8 a[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_reads(1, qt, i >> 1, i & 1, a[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_step(a[i], pfB, dfB, i >> 1, i & 1);
+        }
+#if RES_STAMP
+        ph_[6] += 1;                                       // 6: (query tile x two heads) steps
+#endif
+    }
+    RES_MARK(2);                                           // 2: query-tile loop
+
+    float vmax = 0.f;
+    if (valid_k) {
+        const float vs = final_stage ? (DROP ? rng.scale : 1.f) * (sc.inv_do * H2Scales::INV_P) : 1.f;
+        const float ks = final_stage ? scale * (sc.inv_q * sc.inv_ds) : 1.f;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * dh + 8 * g4 + 4 * h;
+                *reinterpret_cast<float4*>(dkrow + d) = make_float4(dkacc[dh][4 * g4] * ks, dkacc[dh][4 * g4 + 1] * ks,
+                                                                    dkacc[dh][4 * g4 + 2] * ks, dkacc[dh][4 * g4 + 3] * ks);
+                const float4 dv4 = make_float4(dvacc[dh][4 * g4] * vs, dvacc[dh][4 * g4 + 1] * vs,
+                                               dvacc[dh][4 * g4 + 2] * vs, dvacc[dh][4 * g4 + 3] * vs);
+                *reinterpret_cast<float4*>(dvrow + d) = dv4;
+                vmax = fmaxf(fmaxf(fmaxf(vmax, fabsf(dv4.x)), fabsf(dv4.y)), fmaxf(fabsf(dv4.z), fabsf(dv4.w)));
+            }
+    }
+    if (final_stage && want_amax) {                       // (gamer_amax_sink: max |dv|, the v columns of d(q|k|v))
+        uint32_t mw = __float_as_uint(vmax);
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) mw = max(mw, (uint32_t)__shfl_xor((int)mw, o2, 64));
+        if (lane == 0 && mw) atomicMax(&sm.amax_word, mw);
+    }
+    RES_MARK(3);                                           // 3: key-tile epilogue (store)
+}
+
+template <bool DROP, bool ORD>
+__global__ void __launch_bounds__(DKV_R_THREADS, 1)
+attn_bwd_dkv_r2_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv,
+                       const float* __restrict__ d_o, const float* __restrict__ lse, const float* delta,
+                       const int32_t* __restrict__ kl, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
+                       int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed, float* dk, int lddk, float* dv,
+                       int lddv, const RowOrder ro, uint32_t* __restrict__ amax_out, const AttnAmax am, const int split) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char res_raw[];
+    DkvR2Smem& sm = *reinterpret_cast<DkvR2Smem*>(res_raw);
+    const H2Scales sc(am.q, am.k, am.v, am.d_o, 1.f, 1.f / (1.f - p_drop));
+    const AttnDropout rng(p_drop, seed);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n_all = (S + 31) >> 5;
+    const int nqb = (S + QB2 - 1) / QB2;
+    // unit of a workgroup: a (sequence, kv head) pair, or - split - the even / odd key tiles of one (the query blocks are then staged
+    // by both workgroups of the pair)
+    const int upp = split ? 2 : 1;
+    const int n_pairs = nbatch * nkv * upp;                 // (units)
+    if (tid == 0) sm.amax_word = 0;
+#if RES_STAMP
+    unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll 1
+    for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+        const int b = (pair / upp) / nkv, kvh = (pair / upp) % nkv, kt0 = pair % upp;
+#pragma unroll 1
+        for (int qb = 0; qb < nqb; ++qb) {
+            RES_MARK(5);                                    // 5: queue / loop control
+            __syncthreads();                                // every wave is done with the previous stage's images (and flags)
+            RES_MARK(4);                                    // 4: waiting for the slowest wave of the stage
+            if (tid == 0) sm.ctr = 0;
+            if (qb == 0 && tid < RES_MAX_TILES) sm.started[tid] = 0;
+            res2_stage_queries<DROP, ORD>(sm, q, ldq, d_o, lse, delta, ql, row_empty, ro, b, kvh * 2, qb * QB2, S, nq, tid, sc, rng);
+            __syncthreads();
+            RES_MARK(0);                                    // 0: staging (loads, cut, LDS stores, barrier)
+            const bool final_stage = qb == nqb - 1;
+            const int n_qt = min(QB2_TILES, n_all - qb * QB2_TILES);
+            int blk_maxpos = -1, blk_empty = 0;
+#pragma unroll 1
+            for (int i = 0; i < n_qt; ++i) { blk_maxpos = max(blk_maxpos, sm.t_maxpos[i]); blk_empty |= sm.t_empty[i]; }
+            blk_maxpos = __builtin_amdgcn_readfirstlane(blk_maxpos);
+            blk_empty = __builtin_amdgcn_readfirstlane(blk_empty);
+#pragma unroll 1
+            for (int kt = upp * res_grab_ctr(&sm.ctr, lane) + kt0; kt < n_all; kt = upp * res_grab_ctr(&sm.ctr, lane) + kt0) {
+                if (!(final_stage || blk_empty != 0 || blk_maxpos >= kt * 32)) break;      // (nor does any later key tile)
+                const bool fresh = __builtin_amdgcn_readfirstlane(sm.started[kt]) == 0;
+                RES_MARK(5);
+                res2_dkv_keytile<DROP>(sm, k, ldk, v, ldv, kl, S, scale, rng, dk, lddk, dv, lddv, b, kvh, kt,
+                                       n_qt, fresh, final_stage, amax_out != nullptr, sc RES_STAMP_PASS);
+                if (lane == 0) sm.started[kt] = 1;
+            }
+        }
+    }
+    if (amax_out) {
+        __syncthreads();
+        if (tid == 0 && sm.amax_word) amax_publish(sm.amax_word, amax_out, blockIdx.x);
+    }
+#if RES_STAMP
+    RES_MARK(5);
+    if (g_res_stamp && lane == 0) {
+        unsigned long long* rec = g_res_stamp + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 8;
+#pragma unroll
+        for (int i_ = 0; i_ < 8; ++i_) rec[i_] += ph_[i_];
+    }
+#endif
+}
+
 template <int G, bool DROP, bool ORD>
 static int launch_fwd_r_variant(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl,
                                 const int32_t* ql, const int32_t* row_empty, int B, int S, int nq, int nkv, float scale, float p_drop,
@@ -1104,10 +1542,11 @@ static int launch_fwd_r_variant(const float* q, int ldq, const float* k, int ldk
         }
         attr_set = true;
     }
-    const int n_pairs = B * nkv;
-    const int grid = n_pairs < res_grid_cap() ? n_pairs : res_grid_cap();
+    const int split = res_split(B * nkv, G);
+    const int n_units = B * nkv * (split ? G : 1);
+    const int grid = n_units < res_grid_cap() ? n_units : res_grid_cap();
     hipLaunchKernelGGL((attn_fwd_r_kernel<G, DROP, ORD>), dim3(grid), dim3(RES_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, kl, ql,
-                       row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, amax_out, am);
+                       row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, amax_out, am, split);
     GAMER_CHECK_LAUNCH("gamer_attn_fwd_split/resident");
     return 0;
 }
@@ -1146,10 +1585,11 @@ static int launch_dq_r_variant(const float* q, int ldq, const float* k, int ldk,
         }
         attr_set = true;
     }
-    const int n_pairs = B * nkv;
-    const int grid = n_pairs < res_grid_cap() ? n_pairs : res_grid_cap();
+    const int split = res_split(B * nkv, G);
+    const int n_units = B * nkv * (split ? G : 1);
+    const int grid = n_units < res_grid_cap() ? n_units : res_grid_cap();
     hipLaunchKernelGGL((attn_bwd_dq_r_kernel<G, DROP, ORD>), dim3(grid), dim3(RES_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, o, d_o,
-                       lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, ro, delta_ready, am);
+                       lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, ro, delta_ready, am, split);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dq resident");
     return 0;
 }
@@ -1191,6 +1631,28 @@ static int launch_dkv_r_variant(const float* q, int ldq, const float* k, int ldk
     }
     const int n_pairs = B * nkv;
     const int grid = n_pairs < res_grid_cap() ? n_pairs : res_grid_cap();
+    if (G == 2 && res_part_enabled("GAMER_ATTN_RES_DKV2")) {
+        // two heads per wave (the element-wise work of one beside the products of the other)
+        const size_t shmem2 = sizeof(DkvR2Smem);
+        static bool attr2_dev[MAX_DEVICES] = {};
+        bool& attr2_set = attr2_dev[current_device()];
+        if (!attr2_set) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_r2_kernel<DROP, ORD>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2);
+            if (e != hipSuccess) {
+                set_error("gamer_attn_bwd_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                return (int)e;
+            }
+            attr2_set = true;
+        }
+        const int split = res_split(n_pairs, 2);
+        const int n_units = n_pairs * (split ? 2 : 1);
+        const int grid2 = n_units < res_grid_cap() ? n_units : res_grid_cap();
+        hipLaunchKernelGGL((attn_bwd_dkv_r2_kernel<DROP, ORD>), dim3(grid2), dim3(DKV_R_THREADS), shmem2, st, q, ldq, k, ldk, v, ldv, d_o,
+                           lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro, amax_out, am, split);
+        GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dkv resident, two heads per wave");
+        return 0;
+    }
     hipLaunchKernelGGL((attn_bwd_dkv_r_kernel<G, DROP, ORD>), dim3(grid), dim3(DKV_R_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse,
                        delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro, amax_out, am);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dkv resident");

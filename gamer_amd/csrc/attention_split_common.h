@@ -239,6 +239,17 @@ static inline int res_grid_cap() {
     }
     return c;
 }
+// Split a (sequence, kv head) pair's work over `ways` workgroups?  Persistent workgroups take whole units, so the launch lasts
+// ceil(units / CUs) rounds: 384 pairs on 256 CUs (per-GPU batch 128) are two rounds with half the CUs idle in the second, 768 half
+// units three full rounds at ~0.58 of a pair's time each (the split units stage the shared operand once more).  GAMER_ATTN_RES_SPLIT=0/1 forces.
+static inline int res_split(int n_pairs, int ways) {
+    if (ways < 2) return 0;
+    const char* e = getenv("GAMER_ATTN_RES_SPLIT");
+    if (e) return atoi(e) != 0;
+    const int ncu = res_grid_cap();
+    const double whole = (double)((n_pairs + ncu - 1) / ncu), halves = 0.58 * (double)((ways * n_pairs + ncu - 1) / ncu);
+    return halves < whole ? 1 : 0;
+}
 int launch_fwd_res(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl, const int32_t* ql,
                    const int32_t* row_empty, int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed, float* o,
                    float* lse, RowOrder ro, uint32_t* amax_out, AttnAmax am, hipStream_t st);
