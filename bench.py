@@ -297,13 +297,17 @@ def committed_traffic(kernel_substr: str, want: dict):
                 return float(r[col])
         return None
 
-    # newest first: profile sets are tagged per round (r02z_..., r03a_...), so the name order is the age order (file
-    # times are meaningless in a fresh checkout)
-    for meta_path in sorted(glob.glob(os.path.join(prof, "*_pmc_meta.json")), reverse=True):
+    # newest first, by what the profiling script RECORDED in the sidecar: `created` (UTC time stamp) where present, else `seq`;
+    # sets without either sort before all others, by name (file times are meaningless in a fresh checkout, and tags such as
+    # r04final / r04u do not sort by age)
+    metas = []
+    for meta_path in glob.glob(os.path.join(prof, "*_pmc_meta.json")):
         try:
-            meta = json.load(open(meta_path))
+            metas.append((json.load(open(meta_path)), meta_path))
         except (OSError, ValueError):
             continue
+    metas.sort(key=lambda mp: (str(mp[0].get("created", "")), float(mp[0].get("seq", 0) or 0), os.path.basename(mp[1])), reverse=True)
+    for meta, meta_path in metas:
         if any(meta.get(k) != v for k, v in want.items()):
             continue
         tag = meta_path[:-len("_pmc_meta.json")]
@@ -483,7 +487,78 @@ SECONDARY_LEGS = (
     # optimizer step over 512 sequences)
     ("f32_split3_b128_accum4_ragged", "f32", "split3", 128, dict(accum=4, augment=4)),
     ("bf16_b128_accum4_ragged", "bf16", "f32", 128, dict(accum=4, augment=4)),
+    # the Qwen3SessionMulti variant's train step (sessions of 4 items on average), default product form
+    ("session_split3_b1024", "f32", "split3", 1024, dict(variant="session")),
 )
+
+
+def decode_leg(users: int = 256, beams: int = 20, his: int = 100, catalogue: int = 20000, iters: int = 3, cpu_users: int = 1):
+    """BASELINE configs[4]'s shape on one GPU (ref:SeqRec/tasks/test_SMB_decoder.py:141-285): trie-
+    constrained beam search of `users` users x `beams` beams over a 100-item history, 4 new tokens, shipped architecture, default
+    product form.  Reports users/s, the prompt pass and the cached per-token step apart (a run with one new token = prompt pass +
+    first selection; the three cached steps are the rest), the per-token step against the HBM roofline (algorithmic bytes: the
+    prompt K / V of every attention call once per user + the fp32 parameters once), and the CPU decode oracle on `cpu_users`
+    user(s) as the baseline (baseline only: a bounded sample)."""
+    from gamer_amd import synthetic
+    from gamer_amd.config import synthetic_config
+    from gamer_amd.decode import ItemTrie, beam_search
+    from gamer_amd.engine import Engine
+    cfg = synthetic_config()
+    eng = Engine(cfg, temperature=0.7)
+    eng.init_weights(seed=0)
+    cat = synthetic.make_catalogue(catalogue, 256, seed=3)
+    tb = 2
+    items = synthetic.item_tokens(cat, tb, 256).tolist()
+    trie = ItemTrie(items)
+    batch = synthetic.make_eval_batch(users, his, cat, tb, 256, 3, min_his=his, seed=5, behavior_probs=[0.7, 0.25, 0.05])
+
+    def timed(new_tokens):
+        run = lambda: beam_search(eng, batch["input_ids"], batch["attention_mask"], batch["actions"], trie, beams, new_tokens)
+        out = run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            out = run()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters, out
+    ms_all, (seqs, scores) = timed(4)
+    ms_first, _ = timed(1)
+    per_token_ms = max(ms_all - ms_first, 1e-6) / 3.0
+    L0 = batch["input_ids"].shape[1]
+    n_attn = cfg.num_hidden_layers + len(cfg.cross_attention_decoder)
+    kv_bytes = users * n_attn * L0 * cfg.num_key_value_heads * cfg.head_dim * 4 * 2          # prompt K and V, once per user and call
+    param_bytes = sum(int(v.numel()) for v in eng.params.values()) * 4
+    step_bytes = kv_bytes + param_bytes
+    out = {"name": f"decode_bs{users}_beams{beams}", "metric": "evaluation users/s, Qwen3Multi SMB decoder, trie-constrained beam search",
+           "value": users / (ms_all * 1e-3), "unit": "users/s", "ms_per_batch": ms_all, "prefill_plus_first_token_ms": ms_first,
+           "per_token_step_ms": per_token_ms,
+           "per_token_roofline": {"bound": "hbm", "algorithmic_bytes": step_bytes, "achieved": step_bytes / (per_token_ms * 1e-3) / 1e9,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_bytes / (per_token_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+           "workload": f"{users} users x {beams} beams, history {his} items (prompts of {L0} tokens), 4 new tokens, catalogue "
+                       f"{catalogue} items, fp32 tensors (split3 products), K/V cache: prompt once per user, generated positions per beam"}
+    if cpu_users > 0:
+        from oracle import decode_oracle as dec, qwen3multi_oracle as orc
+        ocfg = orc.OracleConfig.from_dict(cfg.to_dict())
+        sd = {k: v.detach().cpu().clone() for k, v in eng.params.items()}
+        cores = usable_cpus()
+        torch.set_num_threads(cores)
+        otrie = dec.ItemTrie(items)
+        t0 = time.perf_counter()
+        oseq, osc = dec.beam_search(sd, ocfg, batch["input_ids"][:cpu_users], batch["attention_mask"][:cpu_users],
+                                    batch["actions"][:cpu_users], otrie, beams, 4)
+        cdt = time.perf_counter() - t0
+        n = cpu_users * beams
+        out["cpu_baseline"] = {"value": cpu_users / cdt, "unit": "users/s", "cores": cores, "kind": "port",
+                               "sample": f"oracle/decode_oracle.py beam search on {cpu_users} of the {users} users ({cdt:.1f} s)",
+                               "sequences_equal_gpu": bool(torch.equal(oseq, seqs[:n].cpu())),
+                               "max_score_diff": float((osc - scores[:n].cpu()).abs().max())}
+    del eng
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
 
 
 def run_leg(args, rank, world, local_rank, force_dist, timer):
@@ -856,6 +931,13 @@ def main(argv=None):
                               "kernels": [{k: row[k] for k in ("kernel", "ms_per_step", "avg_launch_ms", "tflops") if k in row}
                                           for row in r["kernels"][:8]]})
         result["secondary"] = secondary
+        # the evaluation path (BASELINE configs[4]'s shape, one GPU) in the same driver run: under "secondary_eval"
+        try:
+            timer.reset()                                           # (no per-launch events in the evaluation leg)
+            result["secondary_eval"] = [decode_leg(cpu_users=0 if args.no_cpu_baseline else 1)]
+        except Exception as e:
+            log(f"decode leg failed: {e!r}")
+            result["secondary_eval"] = [{"name": "decode_bs256_beams20", "error": repr(e)}]
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

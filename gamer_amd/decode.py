@@ -91,7 +91,10 @@ def trie_from_callable(fn, input_ids, max_new_tokens: int, device="cuda", pad_to
     (ref:SeqRec/tasks/test_SMB_decoder.py:470-500, ref:SeqRec/generation/trie.py:90-104) passed to ``generate`` unchanged.
     The callable is walked depth first from one prompt per distinct final token (its answers only depend on the tokens
     since the last item-ending token, i.e. on [behaviour token] + generated), ``max_new_tokens`` levels deep: one host
-    call per trie node, once - the result is cached on the callable (``fn._gamer_tries``)."""
+    call per trie node, once - the result is cached on the callable (``fn._gamer_tries``).
+    LIMITS (checked where they can be): the callable must not depend on ``batch_id`` or on prompt tokens before the last one -
+    the first level is cross-checked on a second row with the same final token when the batch has one, and a callable that
+    allows nothing after the prompt raises; a callable with other semantics than trie.py:90-104 needs its own ItemTrie."""
     ids = input_ids.detach().cpu()
     cache = getattr(fn, "_gamer_tries", None)
     if cache is None:
@@ -118,6 +121,16 @@ def trie_from_callable(fn, input_ids, max_new_tokens: int, device="cuda", pad_to
                 sequences.append([tok] + prefix)
             for t in allowed:
                 walk(prefix + [t])
+        first = sorted(int(t) for t in fn(b, torch.tensor(prompt)))
+        if not first:
+            raise ValueError(f"prefix_allowed_tokens_fn allows no token after a prompt ending in {tok}: prompts must end with the "
+                             "target behaviour token (ref:SeqRec/tasks/test_SMB_decoder.py:470-500)")
+        others = (last == tok).nonzero().flatten().tolist()
+        if len(others) > 1:                                     # the same final token in another row must give the same first level
+            b2 = int(others[-1])
+            if sorted(int(t) for t in fn(b2, ids[b2])) != first:
+                raise ValueError("prefix_allowed_tokens_fn depends on more than the tokens since the last item-ending token "
+                                 f"(rows {b} and {b2} end in {tok} and get different continuations): build an ItemTrie per row group")
         walk([])
     trie = ItemTrie(sequences, device=device, pad_token_id=pad_token_id)
     cache[key] = trie

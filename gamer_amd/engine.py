@@ -111,6 +111,9 @@ class ParamLayout:
         """A flat buffer (optimizer moments of a checkpoint) written under layout `version` (None: a file from before the
         layouts were numbered = 1) re-ordered to this layout, parameter by parameter; the same tensor if nothing moved."""
         version = 1 if version is None else int(version)
+        if version > ParamLayout.VERSION or version < 1:
+            raise ValueError(f"flat optimizer state was written under parameter layout {version}; this build knows layouts 1.."
+                             f"{ParamLayout.VERSION} (a checkpoint of a newer gamer_amd?)")
         if version == self.version:
             return flat
         if flat.numel() != self.numel:
@@ -393,9 +396,12 @@ class Engine:
         same error against fp64 at half the matrix instructions; the attention products take the same three-product form
         (``self.h2_attention = False`` keeps them in the six-product bf16 form).
         ``deterministic`` (fp32 forms; None = GAMER_DETERMINISTIC=1): EVERY reduction of the step in a fixed order, so that two
-        runs from the same state give the same bits.  The weight gradients (two-pass chunk reduce) and the behaviour-table
-        gradients are ordered by default; what this flag adds is the embedding gradient as an ordered weight-gradient GEMM over
-        a one-hot matrix instead of a scatter with float atomics (+~1.3 ms per step at per-GPU batch 1024).
+        runs from the same state give the same bits.  The weight gradients (two-pass chunk reduce), the behaviour-table
+        gradients and the embedding gradient (stable counting sort + sums in token order, gamer_embedding_bwd_ordered) are
+        ordered by default in the fp32 forms; what this flag adds is that it FORCES those forms whatever the environment says
+        (GAMER_WGRAD_TWO_PASS / GAMER_EMBEDDING_ATOMICS), selects the ordered two-pass weight gradients of the bf16 step
+        (opt-in there: +0.6 ms), and raises instead of falling back when an ordered form cannot be used (vocabulary above
+        8191 rows: the ordered embedding gradient's row index is 13 bits).
         ``share_buffers_of``: another engine of the same configuration whose flat parameter and gradient buffers this one
         uses instead of allocating its own - the nn.Module keeps one set of fp32 masters and runs them through the fp32 or the
         bf16 step depending on the caller's autocast state (gamer_amd/modeling.py)."""
@@ -1011,6 +1017,9 @@ class Engine:
             norm_bwd(xs[0], W.ln1, t3, H, G.ln1, True, branch=(self._seed(l - 1, 5), ws.slot) if l > 0 else None)
             if layer_done is not None:
                 layer_done(l)
+        if self.ordered_embedding_grad and V > 8191 and self.deterministic:
+            raise RuntimeError(f"Engine(deterministic=True): the ordered embedding gradient takes at most 8191 vocabulary rows (V = {V}); "
+                               "the float-atomics scatter it would fall back to is not reproducible")
         if self.ordered_embedding_grad and V <= 8191:
             # the scatter-add of the embedding gradient in a fixed order: a stable counting sort of the tokens by id, then sums in
             # token order (no float atomics: with the ordered weight gradients and table gradients every gradient of the step

@@ -741,7 +741,9 @@ def _tune_kchunk(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups, group_of
 
 
 def linear_wgrad(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups=1, group_offsets=None, strideC=0, kchunk=None):
-    """dW[N_out,K_in] += dy[rows,N_out]^T @ x[rows,K_in]   (dW must be initialised; fp32 atomics)."""
+    """dW[N_out,K_in] += dy[rows,N_out]^T @ x[rows,K_in]   (dW must be initialised).  The token chunks of the split-K form are
+    combined in chunk order through a workspace (two passes, the default in fp32; opt-in for bf16: ``deterministic``) or with fp32
+    atomics (GAMER_WGRAD_TWO_PASS=0)."""
     if kchunk is None:
         key = (rows, N_out, K_in, groups, dy.dtype, F32_MATMUL_TERMS)
         kchunk = _WGRAD_TUNED.get(key)

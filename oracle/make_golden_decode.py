@@ -10,8 +10,13 @@ Stores inputs, the item catalogue, the returned sequences / sequences_scores and
 ``session`` argument: the same through ``Qwen3SessionMultiWithTemperature`` (test_SMB_decoder.py:181-199 passes
 the collator's session_ids / extended_session_ids), histories grouped into sessions of several items.
 
-Usage:  python oracle/make_golden_decode.py [session]   (build container only; writes tests/golden/decode_small.npz
-        or decode_session_small.npz)
+``shipped`` argument: Qwen3MultiWithTemperature at the SHIPPED architecture (hidden 256, 8 layers, 6 / 3 heads, codebook 256,
+V = 1041), max_his_len 100 (prompts of 501 tokens, one left padded), 20 beams, 2 users, target behaviours 0 (every target row
+"empty") and 2 (none): BASELINE configs[4]'s shape.  The 24.5 M weights are not stored: they are ``init_state_dict(seed 17)`` with
+the matrices scaled by 4 (tests/test_decode.py::_shipped_case builds the same), pinned by a checksum in the fixture.
+
+Usage:  python oracle/make_golden_decode.py [session | shipped]   (build container only; writes tests/golden/decode_small.npz,
+        decode_session_small.npz or decode_shipped.npz)
 """
 import functools
 import json
@@ -146,6 +151,64 @@ def main(session: bool = False):
     print("wrote", out_path, os.path.getsize(out_path))
 
 
+def main_shipped():
+    """The reference's generate at the shipped dims on exactly the inputs of tests/test_decode.py::_shipped_case(B=2, tb, 11 + tb)."""
+    from gamer_amd.config import synthetic_config
+    Model, Cfg = _ref_loader.load_reference_classes(session=False)
+    from SeqRec.generation.trie import Trie, prefix_allowed_tokens_fn_by_last_token
+    cb, nb, beams, n_cat, users = 256, 3, 20, 400, 2
+    scfg = synthetic_config()
+    V = synthetic.vocab_size(cb, nb)
+    bmaps = synthetic.behavior_maps(cb, nb)
+    cfg = _ref_loader.reference_config(Cfg, nb, V, bmaps, n_positions=101)          # the reference's own config.json dims
+    cfg.dropout_rate = 0.0
+    cfg.attention_dropout = 0.0
+    ocfg = OracleConfig.from_dict(scfg.to_dict())
+    for f in ("hidden_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads", "head_dim", "intermediate_size",
+              "moe_intermediate_size", "behavior_embedding_dim", "vocab_size"):
+        assert getattr(cfg, f) == getattr(ocfg, f), f                               # synthetic_config() IS the shipped architecture
+    sd = init_state_dict(ocfg, seed=17)
+    for k, v in sd.items():
+        if v.dim() == 2:
+            sd[k] = v * 4.0
+    sd["model.embed_tokens.weight"][synthetic.PAD_ID] = 0
+    model = Model(cfg)
+    model.set_hyper(0.7)
+    model.load_state_dict({**sd, "lm_head.weight": sd["model.embed_tokens.weight"]}, strict=True)
+    model.eval()
+    model.generation_config.pad_token_id = synthetic.PAD_ID
+    cat = synthetic.make_catalogue(n_cat, cb, seed=3)
+    all_item_tokens = [synthetic.item_tokens(cat, b, cb).tolist() for b in range(nb)]
+    last_token_set = set(t[-1] for beh in all_item_tokens for t in beh)
+    last_token_set.add(synthetic.PAD_ID)
+    res = dict(weight_checksum=np.array([float(sum(v.double().abs().sum() for v in sd.values()))]))
+    for tb in (0, 2):
+        batch = synthetic.make_eval_batch(users, 100, cat, tb, codebook=cb, min_his=70, seed=11 + tb)
+        fn = prefix_allowed_tokens_fn_by_last_token(Trie(all_item_tokens[tb]), last_token_set)
+        with torch.no_grad():
+            out = model.generate(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
+                                 session_ids=batch["session_ids"], extended_session_ids=batch["extended_session_ids"],
+                                 actions=batch["actions"], max_new_tokens=4, prefix_allowed_tokens_fn=fn, num_beams=beams,
+                                 num_return_sequences=beams, output_scores=True, return_dict_in_generate=True, early_stopping=True)
+        sc = out.sequences_scores.view(users, beams)
+        print(f"behaviour {tb}: prompt {tuple(batch['input_ids'].shape)}, min score gap between ranked beams "
+              f"{float((sc[:, :-1] - sc[:, 1:]).abs().min()):.3e}")
+        res.update({f"b{tb}_input_ids": batch["input_ids"].numpy(), f"b{tb}_attention_mask": batch["attention_mask"].numpy(),
+                    f"b{tb}_actions": batch["actions"].numpy(), f"b{tb}_sequences": out.sequences.numpy(),
+                    f"b{tb}_scores": out.sequences_scores.numpy().astype(np.float64)})
+    meta = dict(model="Qwen3MultiWithTemperature", codebook=cb, num_behavior=nb, beams=beams, users=users, catalogue=n_cat,
+                weights="oracle.qwen3multi_oracle.init_state_dict(seed=17), matrices x 4, pad row 0",
+                generator=dict(torch=torch.__version__, transformers=__import__("transformers").__version__,
+                               reference="wzf2000/GAMER @ /root/reference"))
+    res["meta_json"] = np.array(json.dumps(meta))
+    out_path = OUT.replace("decode_small", "decode_shipped")
+    np.savez_compressed(out_path, **res)
+    print("wrote", out_path, os.path.getsize(out_path))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    main(session="session" in sys.argv[1:])
+    if "shipped" in sys.argv[1:]:
+        main_shipped()
+    else:
+        main(session="session" in sys.argv[1:])

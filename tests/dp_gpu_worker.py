@@ -72,6 +72,12 @@ def main():
                 res["param_rel"].append(float(dp_.max() / pr.double().abs().max()))
                 # share of the parameters that moved apart by more than rounding (2e-6 of the largest parameter)
                 res.setdefault("param_frac_off", []).append(float((dp_ > 2e-6 * pr.double().abs().max()).double().mean()))
+                # the well-conditioned elements (clipped gradient far above AdamW's eps, where lr g / (|g| + eps) does not amplify a
+                # summation-order difference): the bar of rounds 2-3 stays on them
+                clip = min(1.0, 1.0 / max(float(ref.grad_norm), 1e-30))
+                strong = (gr.abs() * clip) > 1e-5
+                res.setdefault("param_rel_strong", []).append(float(dp_[strong].max() / pr.double().abs().max()) if bool(strong.any()) else 0.0)
+                res.setdefault("strong_frac", []).append(float(strong.double().mean()))
                 res["ref_loss"] += [float(x) for x in ref_losses]
                 if step == 0:
                     # ... and tied DIRECTLY to the CPU oracle: the gradient two HIP ranks reduced over the process group against

@@ -334,6 +334,30 @@ def _shipped_case(B, tb, seed, n_catalogue=400):
     return cfg, ocfg, sd, batch, items
 
 
+def _shipped_fixture(sd, tb, ids, am, act):
+    """tests/golden/decode_shipped.npz: the reference's generate at the shipped architecture (2 users, 20 beams, his 100) on
+    _shipped_case(2, tb, 11 + tb); checks that the inputs and the seeded weights here are the ones the fixture was made from."""
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "decode_shipped.npz"))
+    assert np.array_equal(z[f"b{tb}_input_ids"], ids.numpy()) and np.array_equal(z[f"b{tb}_attention_mask"], am.numpy())
+    assert np.array_equal(z[f"b{tb}_actions"], act.numpy())
+    chk = float(sum(v.double().abs().sum() for v in sd.values()))
+    assert abs(chk - float(z["weight_checksum"][0])) <= 1e-9 * chk, "seeded weights differ from the fixture's"
+    return {"sequences": torch.from_numpy(z[f"b{tb}_sequences"]), "scores": torch.from_numpy(z[f"b{tb}_scores"])}
+
+
+@pytest.mark.parametrize("tb", [0, 2])
+def test_decode_oracle_reproduces_the_reference_at_the_shipped_architecture(tb):
+    """The CPU decode oracle against the reference's own generate at the shipped dims (20 beams, prompts of 501 tokens, one left
+    padded; behaviour 0: every target row "empty", the un-reordered cross cache matters; behaviour 2: none)."""
+    cfg, ocfg, sd, batch, items = _shipped_case(2, tb, seed=11 + tb)
+    ids, am, act = batch["input_ids"], batch["attention_mask"], batch["actions"]
+    fx = _shipped_fixture(sd, tb, ids, am, act)
+    oseq, osc = dec.beam_search(sd, ocfg, ids, am, act, dec.ItemTrie(items), 20, 4)
+    assert torch.equal(oseq, fx["sequences"]), "oracle beams differ from the reference's generate"
+    assert float((osc.double() - fx["scores"]).abs().max()) < 2e-5
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tb", [0, 2])
 def test_beam_search_at_the_shipped_architecture(tb):
@@ -351,6 +375,12 @@ def test_beam_search_at_the_shipped_architecture(tb):
     eng = Engine(cfg, temperature=0.7)
     eng.load_state_dict(sd)
     seq, sc = beam_search(eng, ids, am, act, ItemTrie(items), beams, 4)
+    # pinned DIRECTLY by the reference: tests/golden/decode_shipped.npz holds what the real Qwen3MultiWithTemperature.generate
+    # returned on these inputs and weights (oracle/make_golden_decode.py shipped)
+    fx = _shipped_fixture(sd, tb, ids, am, act)
+    assert torch.equal(seq.cpu(), fx["sequences"]), "beams differ from the reference's generate"
+    err_ref = float((sc.cpu().double() - fx["scores"]).abs().max())
+    assert err_ref < 1e-4, err_ref
     oseq, osc = dec.beam_search(sd, ocfg, ids, am, act, dec.ItemTrie(items), beams, 4)
     assert torch.equal(seq.cpu(), oseq), "beams differ from the oracle's"
     err = float((sc.cpu() - osc).abs().max())

@@ -58,6 +58,8 @@ def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path, accum, dtype):
     # 3e-7).  So: the worst element stays far below one step (lr / max|p| ~ 5e-4), and all but a handful of elements agree to rounding.
     assert r0["grad_rel"][0] < 1e-5, r0
     assert r0["param_rel"][0] < 1e-4 and r0["param_frac_off"][0] < 1e-4, r0
+    # ... and the elements whose gradient is well above eps keep the 1e-5 bar (a reduce-order regression shows there)
+    assert r0["param_rel_strong"][0] < 1e-5 and r0["strong_frac"][0] > 0.01, r0
     tol2 = 1e-4 if dtype == "f32" else 5e-3
     assert r0["grad_rel"][1] < tol2 and r0["param_rel"][1] < tol2, r0
     if dtype == "f32":
