@@ -22,6 +22,13 @@
 
 namespace gamer {
 
+#ifndef RES_WARM
+#define RES_WARM 0        // 1: L2 warm-up loads of the block a workgroup stages next.  Measured SLOWER (batch 1024: forward 1.33 vs 1.28 ms, backward
+                          // 4.14 vs 4.05): vmcnt counts in order, so the next wait for a real load also waits for the warm-up loads
+#endif
+#ifndef RES_TOUCH_Q
+#define RES_TOUCH_Q 0     // 1: L2 warm-up loads of the next row tile q rows and row data in the forward (slower as well: 1.28 -> 1.33 ms)
+#endif
 #ifndef RES_STAMP
 #define RES_STAMP 0       // diagnostic builds (tools/stamp_attn_res.py): every wave of the forward kernel accumulates shader-clock cycles per phase
 #endif                    // into g_res_stamp[(8 * blockIdx.x + wave) * 8 + phase] (set by gamer_debug_res_stamp); never in the shipped library
@@ -70,34 +77,33 @@ template <bool DROP>
 __device__ __forceinline__ void res_stage_block(ResSmem& sm, const float* __restrict__ kbase, int ldk, const float* __restrict__ vbase,
                                                 int ldv, const int32_t* __restrict__ klb, int j0, int S, int tid, const H2Scales& sc,
                                                 const AttnDropout& rng) {
+    // all sixteen loads of a thread are requested before the first cut waits for one (no row-tile state is live here: 64 registers)
+    float4 rk[8], rv[8];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        float4 rk[4], rv[4];
+    for (int p = 0; p < 8; ++p) {
+        const int f = tid + RES_THREADS * p;
+        const int j = min(j0 + (f >> 4), S - 1);
+        rk[p] = *reinterpret_cast<const float4*>(kbase + (int64_t)j * ldk + ((f & 15) << 2));
+        rv[p] = *reinterpret_cast<const float4*>(vbase + (int64_t)j * ldv + ((f & 15) << 2));
+    }
+    int klv = INT_BIG_A;
+    if (tid < RB_KEYS && j0 + tid < S) klv = klb[j0 + tid];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int f = tid + RES_THREADS * (4 * half + p);
-            const int j = min(j0 + (f >> 4), S - 1);
-            rk[p] = *reinterpret_cast<const float4*>(kbase + (int64_t)j * ldk + ((f & 15) << 2));
-            rv[p] = *reinterpret_cast<const float4*>(vbase + (int64_t)j * ldv + ((f & 15) << 2));
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int f = tid + RES_THREADS * (4 * half + p);
-            const int row = f >> 4;
-            const bool ok = j0 + row < S;
-            const int off = sl_off(row, (f & 15) << 2);
-            uint32_t a0, a1, b0, b1;
-            cut2h_quad(ok ? rk[p].x : 0.f, ok ? rk[p].y : 0.f, ok ? rk[p].z : 0.f, ok ? rk[p].w : 0.f, sc.k, a0, a1, b0, b1);
-            *reinterpret_cast<uint2*>(sm.K[0] + off) = make_uint2(a0, b0);
-            *reinterpret_cast<uint2*>(sm.K[1] + off) = make_uint2(a1, b1);
-            cut2h_quad(ok ? rv[p].x : 0.f, ok ? rv[p].y : 0.f, ok ? rv[p].z : 0.f, ok ? rv[p].w : 0.f, sc.v, a0, a1, b0, b1);
-            *reinterpret_cast<uint2*>(sm.V[0] + off) = make_uint2(a0, b0);
-            *reinterpret_cast<uint2*>(sm.V[1] + off) = make_uint2(a1, b1);
-        }
+    for (int p = 0; p < 8; ++p) {
+        const int f = tid + RES_THREADS * p;
+        const int row = f >> 4;
+        const bool ok = j0 + row < S;
+        const int off = sl_off(row, (f & 15) << 2);
+        uint32_t a0, a1, b0, b1;
+        cut2h_quad(ok ? rk[p].x : 0.f, ok ? rk[p].y : 0.f, ok ? rk[p].z : 0.f, ok ? rk[p].w : 0.f, sc.k, a0, a1, b0, b1);
+        *reinterpret_cast<uint2*>(sm.K[0] + off) = make_uint2(a0, b0);
+        *reinterpret_cast<uint2*>(sm.K[1] + off) = make_uint2(a1, b1);
+        cut2h_quad(ok ? rv[p].x : 0.f, ok ? rv[p].y : 0.f, ok ? rv[p].z : 0.f, ok ? rv[p].w : 0.f, sc.v, a0, a1, b0, b1);
+        *reinterpret_cast<uint2*>(sm.V[0] + off) = make_uint2(a0, b0);
+        *reinterpret_cast<uint2*>(sm.V[1] + off) = make_uint2(a1, b1);
     }
     if (tid < RB_KEYS) {
-        const int j = j0 + tid;
-        const int v = j < S ? klb[j] : INT_BIG_A;
+        const int v = klv;
         sm.kl[tid] = v;
         int m = v;
 #pragma unroll
@@ -149,11 +155,34 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
     const int iq = valid_q ? iqc : S;                   // position in the sequence (S: beyond every key)
     const int64_t tok = (int64_t)b * S + iqc;
 
+    // every global load of the prologue is requested before anything waits for one: the q row, the row's data, the carried state
+    // (in source order they came as three dependent round trips: row data -> wave reductions -> q -> state)
+    float4 qraw[8];
+    {
+        const float* qrow = q + tok * ldq + head * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qraw[2 * s] = *reinterpret_cast<const float4*>(qrow + 16 * s);
+            qraw[2 * s + 1] = *reinterpret_cast<const float4*>(qrow + 16 * s + 4);
+        }
+    }
     const int my_ql = ql ? ql[tok] : 1;
     const bool my_empty = valid_q && row_empty[tok] != 0;
+    float* orow = o + tok * (int64_t)nq * 64 + head * 64;
+    float* lse_p = lse + ((int64_t)b * nq + head) * S + iqc;
+    f32x4v carry[8];
+    float carry_l = -INFINITY;
+    if (kb > 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            carry[i] = f32x4v{0.f, 0.f, 0.f, 0.f};         // (possibly stored by another wave of this workgroup: read past the L1)
+            if (valid_q) carry[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(orow + 32 * (i >> 2) + 8 * (i & 3) + 4 * h));
+        }
+        if (valid_q) carry_l = __builtin_nontemporal_load(lse_p);
+    }
     const bool normal = valid_q && !my_empty;
-    const int wave_ql_min = wave_min_i32(normal ? my_ql : INT_BIG_A);
-    const int wave_q_lo = wave_min_i32(normal ? iq : INT_BIG_A);      // every key up to here passes every row's causal limit
+    const int wave_ql_min = wave_min_i32_dpp(normal ? my_ql : INT_BIG_A);
+    const int wave_q_lo = wave_min_i32_dpp(normal ? iq : INT_BIG_A);  // every key up to here passes every row's causal limit
     const bool wave_all_empty = wave_q_lo == INT_BIG_A;               // no normal row: no scores needed at all
     int wave_q_hi;
     bool wave_has_empty;
@@ -175,11 +204,10 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
     const float qs = scale * 1.4426950408889634f;
     bf16x8 qf[2][4];                   // piece x k-step: lane (r, h) holds d = 16 s + 8 h .. + 7 of its query row
     {
-        const float* qrow = q + tok * ldq + head * 64 + 8 * h;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            float4 a4 = *reinterpret_cast<const float4*>(qrow + 16 * s);
-            float4 b4 = *reinterpret_cast<const float4*>(qrow + 16 * s + 4);
+            float4 a4 = qraw[2 * s];
+            float4 b4 = qraw[2 * s + 1];
             a4.x *= qs; a4.y *= qs; a4.z *= qs; a4.w *= qs; b4.x *= qs; b4.y *= qs; b4.z *= qs; b4.w *= qs;
             bf16x8 pq[3];
             cut8_t<true>(a4, b4, sc.q, pq);
@@ -188,8 +216,6 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
     }
     const float invS = 1.f / (float)S;
     const uint32_t aw = DROP ? rng.row_word((uint32_t)(((int64_t)b * nq + head) * S + iqc)) : 0u;
-    float* orow = o + tok * (int64_t)nq * 64 + head * 64;
-    float* lse_p = lse + ((int64_t)b * nq + head) * S + iqc;
 
     float m_ref = 0.f, l_run = 0.f;
     f32x16 oacc[2];
@@ -203,12 +229,11 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
         for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                f32x4v t4 = {0.f, 0.f, 0.f, 0.f};            // (possibly stored by another wave of this workgroup: read past the L1)
-                if (valid_q) t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(orow + 32 * dh + 8 * g4 + 4 * h));
+                const f32x4v t4 = carry[4 * dh + g4];
                 oacc[dh][4 * g4 + 0] = t4[0] * up; oacc[dh][4 * g4 + 1] = t4[1] * up;
                 oacc[dh][4 * g4 + 2] = t4[2] * up; oacc[dh][4 * g4 + 3] = t4[3] * up;
             }
-        const float L = normal ? __builtin_nontemporal_load(lse_p) : -INFINITY;
+        const float L = normal ? carry_l : -INFINITY;
         const bool had = L > -INFINITY;                 // (a row whose keys so far were all blocked: nothing accumulated)
         m_ref = had ? L : 0.f;
         l_run = had ? 1.f : 0.f;
@@ -219,7 +244,7 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
 #pragma unroll 1
     for (int jt = jt_lo; jt < jt_hi; ++jt) {
         const int j0 = jt * 32, tl = jt - jt_lo;
-        if (jt == jt_lo && nx.valid) {
+        if (RES_TOUCH_Q && jt == jt_lo && nx.valid) {
             // one 128-byte line per lane: lane (r, h) takes half h of row r of the next tile's q rows; its row data by lane half
             const int64_t ntok = (int64_t)b * S + (ORD ? nx.perm : min(nx.t * 32 + r, S - 1));
             tq = *reinterpret_cast<const uint32_t*>(q + ntok * ldq + nx.head * 64 + 32 * h);
@@ -417,7 +442,7 @@ attn_fwd_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
             {
                 int npair = pair, nkb = kb + 1;
                 if (nkb == nblk) { nkb = 0; npair += gridDim.x; }
-                if (npair < n_pairs) {
+                if (RES_WARM && npair < n_pairs) {
                     const int j = min(nkb * RB_KEYS + (tid >> 1), S - 1);
                     const int64_t nrow = (int64_t)((npair / upp) / nkv) * S + j;
                     tk0 = *reinterpret_cast<const uint32_t*>(k + nrow * ldk + ((npair / upp) % nkv) * 64 + (tid & 1) * 32);
@@ -486,11 +511,38 @@ res_dq_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const float* _
     const int iq = valid_q ? iqc : S;
     const int64_t tok = (int64_t)b * S + iqc;
 
+    // every global load of the prologue is requested before anything waits for one (see res_fwd_rowtile)
+    const bool need_delta = !delta_ready && kb == 0;
+    float* delta_p = delta + ((int64_t)b * nq + head) * S + iqc;
+    float* dqrow = dq + tok * lddq + head * 64;
+    float4 qraw[8], draw[8];
+    {
+        const float* qrow = q + tok * ldq + head * 64 + 8 * h;
+        const float* drow = d_o + tok * (int64_t)nq * 64 + head * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qraw[2 * s] = *reinterpret_cast<const float4*>(qrow + 16 * s);
+            qraw[2 * s + 1] = *reinterpret_cast<const float4*>(qrow + 16 * s + 4);
+            draw[2 * s] = *reinterpret_cast<const float4*>(drow + 16 * s);
+            draw[2 * s + 1] = *reinterpret_cast<const float4*>(drow + 16 * s + 4);
+        }
+    }
     const int my_ql = ql ? ql[tok] : 1;
     const bool my_empty = valid_q && row_empty[tok] != 0;
+    const float my_lse = lse[((int64_t)b * nq + head) * S + iqc];
+    float my_delta = 0.f;
+    if (!need_delta) my_delta = __builtin_nontemporal_load(delta_p);      // (possibly stored by another wave of this workgroup: past the L1)
+    f32x4v carry[8];
+    if (kb > 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            carry[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (valid_q) carry[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(dqrow + 32 * (i >> 2) + 8 * (i & 3) + 4 * h));
+        }
+    }
     const bool normal = valid_q && !my_empty;
-    const int wave_ql_min = wave_min_i32(normal ? my_ql : INT_BIG_A);
-    const int wave_q_lo = wave_min_i32(normal ? iq : INT_BIG_A);
+    const int wave_ql_min = wave_min_i32_dpp(normal ? my_ql : INT_BIG_A);
+    const int wave_q_lo = wave_min_i32_dpp(normal ? iq : INT_BIG_A);
     const bool wave_all_empty = wave_q_lo == INT_BIG_A;
     int wave_q_hi;
     bool wave_has_empty;
@@ -511,26 +563,21 @@ res_dq_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const float* _
     // log2 domain: q is pre-scaled by scale*log2(e) and the score accumulators start at -lse*log2(e), so p = exp2(accumulator)
     const float qs = scale * 1.4426950408889634f;
     bf16x8 qf[2][4], dof[2][4];           // piece x k-step of the pre-scaled q row and of the dO row (lane = query)
-    float my_delta = 0.f;
     float my_sdo = sc.d_o, my_inv_do = sc.inv_do, my_sds = sc.ds, my_inv_ds = sc.inv_ds;
-    float* delta_p = delta + ((int64_t)b * nq + head) * S + iqc;
     {
-        const float* qrow = q + tok * ldq + head * 64 + 8 * h;
-        const float* drow = d_o + tok * (int64_t)nq * 64 + head * 64 + 8 * h;
         const float* orow = o + tok * (int64_t)nq * 64 + head * 64 + 8 * h;
         float4 du[4], dw[4];
         float rowmax = 0.f;
-        const bool need_delta = !delta_ready && first;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            float4 a4 = *reinterpret_cast<const float4*>(qrow + 16 * s);
-            float4 b4 = *reinterpret_cast<const float4*>(qrow + 16 * s + 4);
+            float4 a4 = qraw[2 * s];
+            float4 b4 = qraw[2 * s + 1];
             a4.x *= qs; a4.y *= qs; a4.z *= qs; a4.w *= qs; b4.x *= qs; b4.y *= qs; b4.z *= qs; b4.w *= qs;
             bf16x8 pq[3];
             cut8_t<true>(a4, b4, sc.q, pq);
             qf[0][s] = pq[0]; qf[1][s] = pq[1];
-            float4 u4 = *reinterpret_cast<const float4*>(drow + 16 * s);
-            float4 w4 = *reinterpret_cast<const float4*>(drow + 16 * s + 4);
+            float4 u4 = draw[2 * s];
+            float4 w4 = draw[2 * s + 1];
             if (need_delta) {
                 const float4 o4 = *reinterpret_cast<const float4*>(orow + 16 * s);
                 const float4 p4 = *reinterpret_cast<const float4*>(orow + 16 * s + 4);
@@ -555,16 +602,13 @@ res_dq_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const float* _
         if (need_delta) {
             my_delta += __shfl_xor(my_delta, 32, 64);
             if (valid_q && h == 0) *delta_p = my_delta;
-        } else {
-            my_delta = __builtin_nontemporal_load(delta_p);       // (possibly stored by another wave of this workgroup: past the L1)
         }
     }
-    const float neg_lse2 = -lse[((int64_t)b * nq + head) * S + iqc] * 1.4426950408889634f;
+    const float neg_lse2 = -my_lse * 1.4426950408889634f;
     const float invS = 1.f / (float)S;
     const uint32_t aw = DROP ? rng.row_word((uint32_t)(((int64_t)b * nq + head) * S + iqc)) : 0u;
     const float sd = rng.scale;
     const float neg_delta = -my_delta;
-    float* dqrow = dq + tok * lddq + head * 64;
 
     f32x16 dqacc[2];
     if (first) {
@@ -575,8 +619,7 @@ res_dq_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const float* _
         for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                f32x4v t4 = {0.f, 0.f, 0.f, 0.f};
-                if (valid_q) t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(dqrow + 32 * dh + 8 * g4 + 4 * h));
+                const f32x4v t4 = carry[4 * dh + g4];
                 dqacc[dh][4 * g4 + 0] = t4[0]; dqacc[dh][4 * g4 + 1] = t4[1]; dqacc[dh][4 * g4 + 2] = t4[2]; dqacc[dh][4 * g4 + 3] = t4[3];
             }
     }
@@ -729,6 +772,18 @@ attn_bwd_dq_r_kernel(const float* __restrict__ q, int ldq, const float* __restri
             if (tid == 0) sm.ctr = 0;
             res_stage_block<DROP>(sm, kbase, ldk, vbase, ldv, klb, kb * RB_KEYS, S, tid, sc, rng);
             __syncthreads();
+            // warm the L2 with the K / V rows of the block this workgroup stages next (see attn_fwd_r_kernel)
+            uint32_t tk0 = 0, tk1 = 0;
+            {
+                int nunit = unit, nkb = kb + 1;
+                if (nkb == nblk) { nkb = 0; nunit += gridDim.x; }
+                if (RES_WARM && nunit < n_units) {
+                    const int j = min(nkb * RB_KEYS + (tid >> 1), S - 1);
+                    const int64_t nrow = (int64_t)((nunit / upp) / nkv) * S + j;
+                    tk0 = *reinterpret_cast<const uint32_t*>(k + nrow * ldk + ((nunit / upp) % nkv) * 64 + (tid & 1) * 32);
+                    tk1 = *reinterpret_cast<const uint32_t*>(v + nrow * ldv + ((nunit / upp) % nkv) * 64 + (tid & 1) * 32);
+                }
+            }
             // row tiles from the block's queue, late (long) tiles first
 #pragma unroll 1
             for (int cur = res_grab(sm, lane); cur < n_items; cur = res_grab(sm, lane)) {
@@ -737,6 +792,7 @@ attn_bwd_dq_r_kernel(const float* __restrict__ q, int ldq, const float* __restri
                     res_dq_rowtile<G, DROP, ORD>(sm, q, ldq, o, d_o, lse, delta, ql, row_empty, S, nq, scale, rng, dq, lddq, ro, b,
                                                  kvh * G + hg, t, kb, delta_ready, sc);
             }
+            asm volatile("" :: "v"(tk0), "v"(tk1));
         }
     }
 }
@@ -1136,17 +1192,20 @@ res2_stage_queries(DkvR2Smem& sm, const float* __restrict__ q, int ldq, const fl
                    const float* delta, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty, const RowOrder& ro,
                    int b, int head0, int s0, int S, int nq, int tid, const H2Scales& sc, const AttnDropout& rng) {
     const int32_t* pmap = ORD ? ro.perm + (int64_t)b * S : nullptr;
+    // all 32 loads of a thread (both heads) are requested before the first cut waits for one
+    float4 rq[2][8], rd[2][8];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        float4 rq[8], rd[8];
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int f = tid + DKV_R_THREADS * p;
             const int sl = min(s0 + (f >> 4), S - 1);
             const int64_t tok = (int64_t)b * S + (ORD ? pmap[sl] : sl);
-            rq[p] = *reinterpret_cast<const float4*>(q + tok * ldq + (head0 + g) * 64 + ((f & 15) << 2));
-            rd[p] = *reinterpret_cast<const float4*>(d_o + tok * (int64_t)nq * 64 + (head0 + g) * 64 + ((f & 15) << 2));
+            rq[g][p] = *reinterpret_cast<const float4*>(q + tok * ldq + (head0 + g) * 64 + ((f & 15) << 2));
+            rd[g][p] = *reinterpret_cast<const float4*>(d_o + tok * (int64_t)nq * 64 + (head0 + g) * 64 + ((f & 15) << 2));
         }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
         if (g == 0) {
             // per-row scalars: threads 0..127 head 0 and the rows' own data, threads 128..255 head 1
             const int row = tid & (QB2 - 1), hh = tid >> 7;
@@ -1184,10 +1243,10 @@ res2_stage_queries(DkvR2Smem& sm, const float* __restrict__ q, int ldq, const fl
             const bool ok = s0 + row < S;
             const int off = sl_off(row, (f & 15) << 2);
             uint32_t a0, a1, b0, b1;
-            cut2h_quad(ok ? rq[p].x : 0.f, ok ? rq[p].y : 0.f, ok ? rq[p].z : 0.f, ok ? rq[p].w : 0.f, sc.q, a0, a1, b0, b1);
+            cut2h_quad(ok ? rq[g][p].x : 0.f, ok ? rq[g][p].y : 0.f, ok ? rq[g][p].z : 0.f, ok ? rq[g][p].w : 0.f, sc.q, a0, a1, b0, b1);
             *reinterpret_cast<uint2*>(sm.Q[g][0] + off) = make_uint2(a0, b0);
             *reinterpret_cast<uint2*>(sm.Q[g][1] + off) = make_uint2(a1, b1);
-            cut2h_quad(ok ? rd[p].x : 0.f, ok ? rd[p].y : 0.f, ok ? rd[p].z : 0.f, ok ? rd[p].w : 0.f, sc.d_o, a0, a1, b0, b1);
+            cut2h_quad(ok ? rd[g][p].x : 0.f, ok ? rd[g][p].y : 0.f, ok ? rd[g][p].z : 0.f, ok ? rd[g][p].w : 0.f, sc.d_o, a0, a1, b0, b1);
             *reinterpret_cast<uint2*>(sm.dO[g][0] + off) = make_uint2(a0, b0);
             *reinterpret_cast<uint2*>(sm.dO[g][1] + off) = make_uint2(a1, b1);
         }
@@ -1210,40 +1269,28 @@ res2_dkv_keytile(DkvR2Smem& sm, const float* __restrict__ k, int ldk, const floa
     const bool valid_k = jk < S;
     const int64_t ktok = (int64_t)b * S + (valid_k ? jk : S - 1);
 
-    bf16x8 kf[2][4], vf[2][4];            // piece x k-step: lane (r, h) holds d = 16 s + 8 h .. + 7 of its key's K / V row
+    // every global load of the prologue is requested before anything waits for one: the K / V rows, the key's level, the carried sums
+    float* dkrow = dk + ktok * lddk + kvh * 64;
+    float* dvrow = dv + ktok * lddv + kvh * 64;
+    float4 kraw[8], vraw[8];
     {
         const float* krow = k + ktok * ldk + kvh * 64 + 8 * h;
         const float* vrow = v + ktok * ldv + kvh * 64 + 8 * h;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            float4 a4 = *reinterpret_cast<const float4*>(krow + 16 * s);
-            float4 b4 = *reinterpret_cast<const float4*>(krow + 16 * s + 4);
-            float4 c4 = *reinterpret_cast<const float4*>(vrow + 16 * s);
-            float4 d4 = *reinterpret_cast<const float4*>(vrow + 16 * s + 4);
-            if (!valid_k) { a4 = make_float4(0.f, 0.f, 0.f, 0.f); b4 = a4; c4 = a4; d4 = a4; }
-            bf16x8 pc[3];
-            cut8_t<true>(a4, b4, sc.k, pc);
-            kf[0][s] = pc[0]; kf[1][s] = pc[1];
-            cut8_t<true>(c4, d4, sc.v, pc);
-            vf[0][s] = pc[0]; vf[1][s] = pc[1];
+            kraw[2 * s] = *reinterpret_cast<const float4*>(krow + 16 * s);
+            kraw[2 * s + 1] = *reinterpret_cast<const float4*>(krow + 16 * s + 4);
+            vraw[2 * s] = *reinterpret_cast<const float4*>(vrow + 16 * s);
+            vraw[2 * s + 1] = *reinterpret_cast<const float4*>(vrow + 16 * s + 4);
         }
     }
     const int my_kl = valid_k ? kl[ktok] : INT_BIG_A;
-    const int wave_kl_max = wave_max_i32(my_kl);
-    const int wave_k_lo = kt * 32, wave_k_hi = wave_k_lo + 31;
-    const float invS = 1.f / (float)S;
-    const float c2 = scale * 1.4426950408889634f * sc.inv_qk;
-    const uint32_t bw = DROP ? rng.key_word((uint32_t)jk) : 0u;
-    const float cdp = sc.inv_v * sc.inv_do;              // dP = (dO' V'^T) cdp
-    const float sd = rng.scale * cdp;
-    float* dkrow = dk + ktok * lddk + kvh * 64;
-    float* dvrow = dv + ktok * lddv + kvh * 64;
-
     f32x16 dkacc[2], dvacc[2];
     if (fresh) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dkacc[0][i] = 0.f; dkacc[1][i] = 0.f; dvacc[0][i] = 0.f; dvacc[1][i] = 0.f; }
     } else {
+        // the raw sums an earlier stage left (possibly another wave: read past the L1)
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
@@ -1258,6 +1305,24 @@ res2_dkv_keytile(DkvR2Smem& sm, const float* __restrict__ k, int ldk, const floa
                 for (int e = 0; e < 4; ++e) { dkacc[dh][4 * g4 + e] = a[e]; dvacc[dh][4 * g4 + e] = c[e]; }
             }
     }
+    bf16x8 kf[2][4], vf[2][4];            // piece x k-step: lane (r, h) holds d = 16 s + 8 h .. + 7 of its key's K / V row
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float4 a4 = kraw[2 * s], b4 = kraw[2 * s + 1], c4 = vraw[2 * s], d4 = vraw[2 * s + 1];
+        if (!valid_k) { a4 = make_float4(0.f, 0.f, 0.f, 0.f); b4 = a4; c4 = a4; d4 = a4; }
+        bf16x8 pc[3];
+        cut8_t<true>(a4, b4, sc.k, pc);
+        kf[0][s] = pc[0]; kf[1][s] = pc[1];
+        cut8_t<true>(c4, d4, sc.v, pc);
+        vf[0][s] = pc[0]; vf[1][s] = pc[1];
+    }
+    const int wave_kl_max = wave_max_i32(my_kl);
+    const int wave_k_lo = kt * 32, wave_k_hi = wave_k_lo + 31;
+    const float invS = 1.f / (float)S;
+    const float c2 = scale * 1.4426950408889634f * sc.inv_qk;
+    const uint32_t bw = DROP ? rng.key_word((uint32_t)jk) : 0u;
+    const float cdp = sc.inv_v * sc.inv_do;              // dP = (dO' V'^T) cdp
+    const float sd = rng.scale * cdp;
 
     // ---- the pieces of a tile's work ------------------------------------------------------------------------------------------
     // F, k-step s of head g / tile qt: the row fragments of dO and Q (A operands)
@@ -1494,6 +1559,23 @@ attn_bwd_dkv_r2_kernel(const float* __restrict__ q, int ldq, const float* __rest
             res2_stage_queries<DROP, ORD>(sm, q, ldq, d_o, lse, delta, ql, row_empty, ro, b, kvh * 2, qb * QB2, S, nq, tid, sc, rng);
             __syncthreads();
             RES_MARK(0);                                    // 0: staging (loads, cut, LDS stores, barrier)
+            // warm the L2 with the Q / dO rows of the block this workgroup stages next: 128 slots x 2 heads x 2 tensors x two 128-byte
+            // lines = 4 per thread (natural row order only: the sorted order would need the permutation first)
+            uint32_t tw[4] = {0, 0, 0, 0};
+            if (RES_WARM && !ORD) {
+                int npair = pair, nqb_ = qb + 1;
+                if (nqb_ == nqb) { nqb_ = 0; npair += gridDim.x; }
+                if (npair < n_pairs) {
+                    const int sl = min(nqb_ * QB2 + (tid >> 1), S - 1);
+                    const int64_t ntok = (int64_t)((npair / upp) / nkv) * S + sl;
+                    const int nh0 = ((npair / upp) % nkv) * 2;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        tw[2 * g] = *reinterpret_cast<const uint32_t*>(q + ntok * ldq + (nh0 + g) * 64 + (tid & 1) * 32);
+                        tw[2 * g + 1] = *reinterpret_cast<const uint32_t*>(d_o + ntok * (int64_t)nq * 64 + (nh0 + g) * 64 + (tid & 1) * 32);
+                    }
+                }
+            }
             const bool final_stage = qb == nqb - 1;
             const int n_qt = min(QB2_TILES, n_all - qb * QB2_TILES);
             int blk_maxpos = -1, blk_empty = 0;
@@ -1510,6 +1592,7 @@ attn_bwd_dkv_r2_kernel(const float* __restrict__ q, int ldq, const float* __rest
                                        n_qt, fresh, final_stage, amax_out != nullptr, sc RES_STAMP_PASS);
                 if (lane == 0) sm.started[kt] = 1;
             }
+            asm volatile("" :: "v"(tw[0]), "v"(tw[1]), "v"(tw[2]), "v"(tw[3]));
         }
     }
     if (amax_out) {

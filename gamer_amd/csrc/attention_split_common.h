@@ -250,6 +250,11 @@ static inline int res_split(int n_pairs, int ways) {
     const double whole = (double)((n_pairs + ncu - 1) / ncu), halves = 0.58 * (double)((ways * n_pairs + ncu - 1) / ncu);
     return halves < whole ? 1 : 0;
 }
+// share of the CU-rounds that whole-pair units keep busy
+static inline double res_fill(int n_pairs) {
+    const int ncu = res_grid_cap();
+    return (double)n_pairs / ((double)((n_pairs + ncu - 1) / ncu) * ncu);
+}
 int launch_fwd_res(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl, const int32_t* ql,
                    const int32_t* row_empty, int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed, float* o,
                    float* lse, RowOrder ro, uint32_t* amax_out, AttnAmax am, hipStream_t st);

@@ -270,6 +270,26 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     return v;
 }
 
+// min / max over the 64 lanes without the LDS crossbar: four DPP steps reduce every row of 16 lanes (quad swaps, half-row and row
+// mirrors: each lane ends with its row's result), four v_readlane fetch the rows, the rest is scalar.  A __shfl_xor chain is six
+// dependent ds_bpermute round trips (~100+ cycles each): it sat in front of every row tile of the resident attention kernels.
+// The result is wave-uniform (an SGPR).
+#define GAMER_DPP_ROW_REDUCE(OP, v)                                                                   \
+    v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));  /* quad_perm [1,0,3,2] */    \
+    v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));  /* quad_perm [2,3,0,1] */    \
+    v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false)); /* row_half_mirror */        \
+    v = OP(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false)); /* row_mirror */
+__device__ __forceinline__ int wave_min_i32_dpp(int v) {
+    GAMER_DPP_ROW_REDUCE(min, v)
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max_i32_dpp(int v) {
+    GAMER_DPP_ROW_REDUCE(max, v)
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 // d/dx silu(x) = s*(1 + x*(1-s)), s = sigmoid(x)
 __device__ __forceinline__ float dsilu_f(float x) {
