@@ -429,6 +429,392 @@ attn_fwd_b_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restric
 }
 
 // =============================================================================================
+// forward with the K and V rows of a (sequence, kv head) RESIDENT in LDS (the structure of csrc/attention_res.hip: one workgroup of
+// eight waves per pair, every wave takes 32-query row tiles of the pair's query heads from a queue and walks the keys with no
+// barrier and no global load in the loop).  In bf16 the whole sequence fits: S <= 576 keys x 128 bytes x (K + V) = 144 KB; longer
+// sequences stay on the tiled kernel above.  The arithmetic of a row tile is the tiled kernel's, 32-key sub-tile by sub-tile in
+// the same order: results are bit-identical.
+// =============================================================================================
+#ifdef BR_THREADS_OVERRIDE
+constexpr int BR_THREADS = BR_THREADS_OVERRIDE;
+#else
+constexpr int BR_THREADS = 512;
+#endif
+constexpr int BR_MAXKEYS = 576;
+struct BrSmem {
+    bf16_t K[BR_MAXKEYS * 64];
+    bf16_t V[BR_MAXKEYS * 64];
+    int32_t kl[BR_MAXKEYS];
+    uint32_t kw[BR_MAXKEYS];
+    int32_t klmax[BR_MAXKEYS / 32];
+    int32_t ctr;
+    int32_t pad_[5];
+};
+static inline bool br_enabled() {
+    const char* e = getenv("GAMER_ATTN_RES");          // (the switch of the fp32 resident kernels: A/B runs)
+    return e ? atoi(e) != 0 : true;
+}
+static inline bool br_part_enabled(const char* name) {
+    const char* e = getenv(name);
+    return e ? atoi(e) != 0 : true;
+}
+static inline int br_grid_cap() {
+    static int cap[MAX_DEVICES] = {};
+    int& c = cap[current_device()];
+    if (c == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess) n = 256;
+        c = n > 0 ? n : 256;
+    }
+    return c;
+}
+// one query head per workgroup when whole pairs do not fill the CUs evenly (see res_split in attention_split_common.h)
+static inline int br_split(int n_pairs, int ways) {
+    if (ways < 2) return 0;
+    const char* e = getenv("GAMER_ATTN_RES_SPLIT");
+    if (e) return atoi(e) != 0;
+    const int ncu = br_grid_cap();
+    const double whole = (double)((n_pairs + ncu - 1) / ncu), halves = 0.58 * (double)((ways * n_pairs + ncu - 1) / ncu);
+    return halves < whole ? 1 : 0;
+}
+
+template <bool DROP>
+__device__ __forceinline__ void br_stage(BrSmem& sm, const bf16_t* __restrict__ kbase, int ldk, const bf16_t* __restrict__ vbase,
+                                         int ldv, const int32_t* __restrict__ klb, int S, int tid, const AttnDropout& rng) {
+    const int n_rows = ((S + 31) >> 5) << 5;
+    // chunks of 16 bytes: n_rows x 8 per tensor; eight of each tensor in flight per thread and pass
+#pragma unroll 1
+    for (int c0 = 0; c0 < n_rows * 8; c0 += BR_THREADS * 8) {
+        uint4 rk[8], rv[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int f = c0 + tid + BR_THREADS * p;
+            const int row = min(f >> 3, S - 1);
+            rk[p] = *reinterpret_cast<const uint4*>(kbase + (int64_t)row * ldk + ((f & 7) << 3));
+            rv[p] = *reinterpret_cast<const uint4*>(vbase + (int64_t)row * ldv + ((f & 7) << 3));
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int f = c0 + tid + BR_THREADS * p;
+            const int row = f >> 3;
+            if (row < n_rows) {
+                const bool ok = row < S;
+                const int off = lds_off(row, (f & 7) << 3);
+                *reinterpret_cast<uint4*>(sm.K + off) = ok ? rk[p] : make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(sm.V + off) = ok ? rv[p] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    }
+    for (int j = tid; j < n_rows; j += BR_THREADS) {
+        const int v = j < S ? klb[j] : INT_BIG_B;
+        sm.kl[j] = v;
+        if (DROP) sm.kw[j] = rng.key_word((uint32_t)j);
+        int m = v;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+        if ((j & 31) == 0) sm.klmax[j >> 5] = m;
+    }
+}
+
+// one 32-query row tile of one query head against the resident keys
+template <bool DROP, bool SPAN, bool ORD>
+__device__ __forceinline__ void
+br_fwd_rowtile(const BrSmem& sm, const bf16_t* __restrict__ q, int ldq, const int32_t* __restrict__ ql, int S, int nq, float scale,
+               const AttnDropout& rng, bf16_t* __restrict__ o, float* __restrict__ lse, const int32_t* __restrict__ span,
+               const QOrdB& ord, const int b, const int head, const int t) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const LdsOffsets lo(lane);
+    const int iq = t * 32 + r;                        // sorted slot (= position without a row order)
+    const bool valid_q = iq < S;
+    const int iqc = ORD ? ord.perm[(int64_t)b * S + (valid_q ? iq : S - 1)] : (valid_q ? iq : S - 1);
+    const int64_t tok = (int64_t)b * S + iqc;
+
+    bf16x8 qf[4];
+    {
+        const bf16_t* qrow = q + tok * ldq + head * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + 16 * s);
+    }
+    const int my_ql = ql ? ql[tok] : 1;
+    QuerySpanB sp = QuerySpanB::load<SPAN>(span, tok, iqc, valid_q);
+    if (ORD && valid_q && ord.row_empty[tok] != 0) sp.hi = -1;
+    const int wave_q_hi = wave_max_i32_dpp(sp.hi);
+    const int wave_q_lo = wave_min_i32_dpp(valid_q ? sp.hi : INT_BIG_B);
+    const int wave_ql_min = wave_min_i32_dpp(valid_q ? my_ql : INT_BIG_B);
+    const int wave_hole_lo = SPAN ? wave_min_i32_dpp(valid_q ? sp.hole_lo : INT_BIG_B) : INT_BIG_B;
+    const int wave_hole_hi = SPAN ? wave_max_i32_dpp(valid_q ? sp.hole_hi : 0) : 0;
+    const int n_sub = wave_q_hi < 0 ? 0 : (min(S - 1, wave_q_hi) >> 5) + 1;     // 32-key sub-tiles up to the last allowed key
+    const float c2 = scale * 1.4426950408889634f;               // scores in the log2 domain
+    const uint32_t aw = DROP ? rng.row_word((uint32_t)(((int64_t)b * nq + head) * S + iqc)) : 0u;
+
+    float m_ref = 0.f, l_run = 0.f;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+
+#pragma unroll 1
+    for (int js = 0; js < n_sub; ++js) {
+        const int j0 = js * 32;
+        f32x16 st;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_row8(sm.K, lo, j0, s), qf[s], st, 0, 0, 0);
+        const int klmax = __builtin_amdgcn_readfirstlane(sm.klmax[js]);
+        const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min) &&
+                               (!SPAN || j0 + 31 < wave_hole_lo || j0 >= wave_hole_hi);
+        if (!free_tile) {
+            int klv[16];
+            read_key_quads_b(sm.kl + j0, h, klv);
+            const int t_pos = sp.hi - j0 - 4 * h;
+            const int t_lo = sp.hole_lo - j0 - 4 * h, t_hi = sp.hole_hi - j0 - 4 * h;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int ko = (reg & 3) + 8 * (reg >> 2);
+                bool allowed = (ko <= t_pos) & (klv[reg] < my_ql);
+                if (SPAN) allowed = allowed & !((ko >= t_lo) & (ko < t_hi));
+                st[reg] = allowed ? st[reg] : -INFINITY;
+            }
+        }
+        float mloc = st[0];
+#pragma unroll
+        for (int reg = 1; reg < 16; ++reg) mloc = fmaxf(mloc, st[reg]);
+        mloc = xor32_max(mloc) * c2;
+        const bool need = (l_run == 0.f) ? (mloc > -INFINITY) : (mloc > m_ref + RESCALE_TAU_B);
+        if (__any(need ? 1 : 0)) {
+            const float alpha = (need && l_run != 0.f) ? __builtin_amdgcn_exp2f(m_ref - mloc) : 1.f;
+            m_ref = need ? mloc : m_ref;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+        }
+        exp2_affine16(st, c2, -m_ref);                          // masked: exp2(-inf) = 0
+        float rowsum = sum16(st);
+        rowsum = xor32_sum(rowsum);
+        l_run += rowsum;
+        if (DROP) {
+            int kwv[16];
+            read_key_quads_b(reinterpret_cast<const int32_t*>(sm.kw) + j0, h, kwv);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) st[reg] = rng.keep(aw, (uint32_t)kwv[reg]) ? st[reg] : 0.f;
+        }
+        // O^T[d][query] += sum_key V[key][d] * P[query][key]
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pf = pack8(st, s2);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr8(sm.V, lo, j0 + 16 * s2, db), pf, oacc[db], 0, 0, 0);
+        }
+    }
+
+    if (valid_q) {
+        float linv = l_run > 0.f ? 1.f / l_run : 0.f;
+        if (DROP) linv *= rng.scale;
+        bf16_t* orow = o + tok * (int64_t)nq * 64 + head * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 t4 = make_float4(oacc[db][4 * g4] * linv, oacc[db][4 * g4 + 1] * linv,
+                                              oacc[db][4 * g4 + 2] * linv, oacc[db][4 * g4 + 3] * linv);
+                st4(orow + 32 * db + 8 * g4 + 4 * h, t4);
+            }
+        // natural-log LSE of the scaled scores; 0 for a row without an allowed key
+        if (h == 0) lse[((int64_t)b * nq + head) * S + iqc] =
+            l_run > 0.f ? (m_ref + __log2f(l_run)) * 0.6931471805599453f : 0.f;
+    }
+}
+
+template <int G, bool DROP, bool SPAN, bool ORD>
+__global__ void __launch_bounds__(BR_THREADS, 1)
+attn_fwd_br_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk, const bf16_t* __restrict__ v, int ldv,
+                   const int32_t* __restrict__ kl, const int32_t* __restrict__ ql, int nbatch, int S, int nq, int nkv, float scale,
+                   float p_drop, uint64_t seed, bf16_t* __restrict__ o, float* __restrict__ lse, const int32_t* __restrict__ span,
+                   const QOrdB ord, const int split) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char br_raw[];
+    BrSmem& sm = *reinterpret_cast<BrSmem*>(br_raw);
+    const AttnDropout rng(p_drop, seed);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n_all = (S + 31) >> 5;
+    const int hpu = split ? 1 : G, upp = G / hpu;
+    const int n_items = hpu * n_all;
+    const int n_units = nbatch * nkv * upp;
+#pragma unroll 1
+    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const int b = (unit / upp) / nkv, kvh = (unit / upp) % nkv, h0 = (unit % upp) * hpu;
+        __syncthreads();                                        // every wave is done with the previous unit's images
+        if (tid == 0) sm.ctr = 0;
+        br_stage<DROP>(sm, k + (int64_t)b * S * ldk + kvh * 64, ldk, v + (int64_t)b * S * ldv + kvh * 64, ldv, kl + (int64_t)b * S, S,
+                       tid, rng);
+        __syncthreads();
+        // row tiles from the unit's queue, late (long) tiles first
+#pragma unroll 1
+        for (;;) {
+            int cur = 0;
+            if (lane == 0) cur = atomicAdd(&sm.ctr, 1);
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            if (cur >= n_items) break;
+            br_fwd_rowtile<DROP, SPAN, ORD>(sm, q, ldq, ql, S, nq, scale, rng, o, lse, span, ord, b, kvh * G + h0 + cur % hpu,
+                                            n_all - 1 - cur / hpu);
+        }
+    }
+}
+
+// resident-K/V dQ (attn_bwd_dq_b_tile's arithmetic, sub-tile by sub-tile in the same order: bit-identical results)
+template <bool DROP, bool SPAN, bool ORD>
+__device__ __forceinline__ void
+br_dq_rowtile(const BrSmem& sm, const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+              const float* __restrict__ delta, const int32_t* __restrict__ ql, int S, int nq, float scale, const AttnDropout& rng,
+              bf16_t* __restrict__ dq, int lddq, const int32_t* __restrict__ span, const QOrdB& ord, const int b, const int head,
+              const int t) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const LdsOffsets lo(lane);
+    const int iq = t * 32 + r;
+    const bool valid_q = iq < S;
+    const int iqc = ORD ? ord.perm[(int64_t)b * S + (valid_q ? iq : S - 1)] : (valid_q ? iq : S - 1);
+    const int64_t tok = (int64_t)b * S + iqc;
+
+    bf16x8 qf[4], dof[4];
+    {
+        const bf16_t* qrow = q + tok * ldq + head * 64 + 8 * h;
+        const bf16_t* drow = d_o + tok * (int64_t)nq * 64 + head * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[s] = *reinterpret_cast<const bf16x8*>(qrow + 16 * s);
+            dof[s] = *reinterpret_cast<const bf16x8*>(drow + 16 * s);
+        }
+    }
+    const int my_ql = ql ? ql[tok] : 1;
+    QuerySpanB sp = QuerySpanB::load<SPAN>(span, tok, iqc, valid_q);
+    if (ORD && valid_q && ord.row_empty[tok] != 0) sp.hi = -1;
+    const float neg_lse2 = -lse[((int64_t)b * nq + head) * S + iqc] * 1.4426950408889634f;
+    const float neg_delta = -delta[((int64_t)b * nq + head) * S + iqc];
+    const int wave_q_hi = wave_max_i32_dpp(sp.hi);
+    const int wave_q_lo = wave_min_i32_dpp(valid_q ? sp.hi : INT_BIG_B);
+    const int wave_ql_min = wave_min_i32_dpp(valid_q ? my_ql : INT_BIG_B);
+    const int wave_hole_lo = SPAN ? wave_min_i32_dpp(valid_q ? sp.hole_lo : INT_BIG_B) : INT_BIG_B;
+    const int wave_hole_hi = SPAN ? wave_max_i32_dpp(valid_q ? sp.hole_hi : 0) : 0;
+    const int n_sub = wave_q_hi < 0 ? 0 : (min(S - 1, wave_q_hi) >> 5) + 1;
+    const float c2 = scale * 1.4426950408889634f;
+    const uint32_t aw = DROP ? rng.row_word((uint32_t)(((int64_t)b * nq + head) * S + iqc)) : 0u;
+    const float sd = rng.scale;
+
+    f32x16 dqacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
+
+#pragma unroll 1
+    for (int js = 0; js < n_sub; ++js) {
+        const int j0 = js * 32;
+        f32x16 st, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+        // S^T = K Q^T and dP^T[key][query] = sum_d V[key][d] dO[query][d]
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_row8(sm.K, lo, j0, s), qf[s], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_row8(sm.V, lo, j0, s), dof[s], dp, 0, 0, 0);
+        }
+        const int klmax = __builtin_amdgcn_readfirstlane(sm.klmax[js]);
+        const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min) &&
+                               (!SPAN || j0 + 31 < wave_hole_lo || j0 >= wave_hole_hi);
+        if (!free_tile) {
+            int klv[16];
+            read_key_quads_b(sm.kl + j0, h, klv);
+            const int t_pos = sp.hi - j0 - 4 * h;
+            const int t_lo = sp.hole_lo - j0 - 4 * h, t_hi = sp.hole_hi - j0 - 4 * h;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int ko = (reg & 3) + 8 * (reg >> 2);
+                bool allowed = (ko <= t_pos) & (klv[reg] < my_ql);
+                if (SPAN) allowed = allowed & !((ko >= t_lo) & (ko < t_hi));
+                st[reg] = allowed ? st[reg] : -INFINITY;
+            }
+        }
+        // dS^T = p * (mult * dP - delta), p = exp2(c2 * s - lse2); a row without an allowed key has p = 0 everywhere
+        if (DROP) {
+            int kwv[16];
+            read_key_quads_b(reinterpret_cast<const int32_t*>(sm.kw) + j0, h, kwv);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) dp[reg] = rng.keep(aw, (uint32_t)kwv[reg]) ? dp[reg] : 0.f;
+        }
+        exp2_affine16(st, c2, neg_lse2);
+        {
+            const f32x2 sdv = {DROP ? sd : 1.f, DROP ? sd : 1.f}, ndv = {neg_delta, neg_delta};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f32x2 tt = {dp[2 * j], dp[2 * j + 1]};
+                tt = __builtin_elementwise_fma(tt, sdv, ndv);
+                st[2 * j] *= tt[0];
+                st[2 * j + 1] *= tt[1];
+            }
+        }
+        // dQ^T[d][query] += sum_key K[key][d] dS^T[key][query]
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 df = pack8(st, s2);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr8(sm.K, lo, j0 + 16 * s2, db), df, dqacc[db], 0, 0, 0);
+        }
+    }
+
+    if (valid_q) {
+        bf16_t* drow = dq + tok * lddq + head * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 t4 = make_float4(dqacc[db][4 * g4] * scale, dqacc[db][4 * g4 + 1] * scale,
+                                              dqacc[db][4 * g4 + 2] * scale, dqacc[db][4 * g4 + 3] * scale);
+                st4(drow + 32 * db + 8 * g4 + 4 * h, t4);
+            }
+    }
+}
+
+template <int G, bool DROP, bool SPAN, bool ORD>
+__global__ void __launch_bounds__(BR_THREADS, 1)
+attn_bwd_dq_br_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk, const bf16_t* __restrict__ v,
+                      int ldv, const bf16_t* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ delta,
+                      const int32_t* __restrict__ kl, const int32_t* __restrict__ ql, int nbatch, int S, int nq, int nkv, float scale,
+                      float p_drop, uint64_t seed, bf16_t* __restrict__ dq, int lddq, const int32_t* __restrict__ span,
+                      const QOrdB ord, const int split) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char br_raw[];
+    BrSmem& sm = *reinterpret_cast<BrSmem*>(br_raw);
+    const AttnDropout rng(p_drop, seed);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n_all = (S + 31) >> 5;
+    const int hpu = split ? 1 : G, upp = G / hpu;
+    const int n_items = hpu * n_all;
+    const int n_units = nbatch * nkv * upp;
+#pragma unroll 1
+    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+        const int b = (unit / upp) / nkv, kvh = (unit / upp) % nkv, h0 = (unit % upp) * hpu;
+        __syncthreads();
+        if (tid == 0) sm.ctr = 0;
+        br_stage<DROP>(sm, k + (int64_t)b * S * ldk + kvh * 64, ldk, v + (int64_t)b * S * ldv + kvh * 64, ldv, kl + (int64_t)b * S, S,
+                       tid, rng);
+        __syncthreads();
+#pragma unroll 1
+        for (;;) {
+            int cur = 0;
+            if (lane == 0) cur = atomicAdd(&sm.ctr, 1);
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            if (cur >= n_items) break;
+            br_dq_rowtile<DROP, SPAN, ORD>(sm, q, ldq, d_o, lse, delta, ql, S, nq, scale, rng, dq, lddq, span, ord, b,
+                                           kvh * G + h0 + cur % hpu, n_all - 1 - cur / hpu);
+        }
+    }
+}
+
+// (A resident dK / dV in the same style - Q and dO of one head resident, four waves owning four key tiles each, the two heads
+// added in registers - was built and measured SLOWER than the tiled kernel below: 2.40 against 2.16 ms per backward at batch 1024;
+// 256 accumulator registers per wave leave one wave per SIMD with nothing to hide its LDS latency.  Not kept.)
+// =============================================================================================
 // backward: delta = dO . O
 // =============================================================================================
 __global__ void __launch_bounds__(AB_THREADS)
@@ -980,6 +1366,31 @@ static int launch_fwd_b(const bf16_t* q, int ldq, const bf16_t* k, int ldk, cons
                         const int32_t* ql, int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
                         bf16_t* o, float* lse, const int32_t* span, const QOrdB ord, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
+    if (S <= BR_MAXKEYS && br_enabled()) {
+        // K / V of a (sequence, kv head) resident in LDS
+        const int split = br_split(B * nkv, G);
+        const int n_units = B * nkv * (split ? G : 1);
+        const dim3 rgrid(n_units < br_grid_cap() ? n_units : br_grid_cap());
+        const size_t shmem = sizeof(BrSmem);
+#define GAMER_LAUNCH_FWD_BR(DROPV, SPANV, ORDV)                                                                             \
+        do {                                                                                                                \
+            static bool attr_dev[MAX_DEVICES] = {};                                                                         \
+            if (!attr_dev[current_device()]) {                                                                              \
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_br_kernel<G, DROPV, SPANV, ORDV>), \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);          \
+                if (e != hipSuccess) { set_error("gamer_attn_fwd_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; } \
+                attr_dev[current_device()] = true;                                                                          \
+            }                                                                                                               \
+            hipLaunchKernelGGL((attn_fwd_br_kernel<G, DROPV, SPANV, ORDV>), rgrid, dim3(BR_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, \
+                               kl, ql, B, S, nq, nkv, scale, p_drop, seed, o, lse, span, ord, split);                       \
+        } while (0)
+        if (ord.perm) { if (p_drop > 0.f) GAMER_LAUNCH_FWD_BR(true, false, true); else GAMER_LAUNCH_FWD_BR(false, false, true); }
+        else if (p_drop > 0.f) { if (span) GAMER_LAUNCH_FWD_BR(true, true, false); else GAMER_LAUNCH_FWD_BR(true, false, false); }
+        else { if (span) GAMER_LAUNCH_FWD_BR(false, true, false); else GAMER_LAUNCH_FWD_BR(false, false, false); }
+#undef GAMER_LAUNCH_FWD_BR
+        GAMER_CHECK_LAUNCH("gamer_attn_fwd_bf16/resident");
+        return 0;
+    }
     dim3 grid(worklist_grid_b(B * nkv, (S + R - 1) / R, AB_OCC_FWD));
 #define GAMER_LAUNCH_FWD_B(DROPV, SPANV, ORDV)                                                                              \
     hipLaunchKernelGGL((attn_fwd_b_kernel<G, DROPV, SPANV, ORDV>), grid, dim3(AB_THREADS), 0, st, q, ldq, k, ldk, v, ldv,   \
@@ -1017,6 +1428,27 @@ static int launch_bwd_b_variant(const bf16_t* q, int ldq, const bf16_t* k, int l
     hipLaunchKernelGGL((attn_bwd_dkv_b_kernel<G, DROP, SPAN, ORD>), grid, dim3(AB_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o,
                        lse, delta, kl, ql, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, span, ord);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd_bf16/dkv");
+    if (S <= BR_MAXKEYS && br_enabled() && br_part_enabled("GAMER_ATTN_RES_DQ")) {
+        // dQ with K / V of a (sequence, kv head) resident in LDS
+        const int split = br_split(B * nkv, G);
+        const int n_units = B * nkv * (split ? G : 1);
+        const size_t rshmem = sizeof(BrSmem);
+        static bool rattr_dev[MAX_DEVICES] = {};
+        if (!rattr_dev[current_device()]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_br_kernel<G, DROP, SPAN, ORD>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)rshmem);
+            if (e != hipSuccess) {
+                set_error("gamer_attn_bwd_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                return (int)e;
+            }
+            rattr_dev[current_device()] = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_dq_br_kernel<G, DROP, SPAN, ORD>), dim3(n_units < br_grid_cap() ? n_units : br_grid_cap()),
+                           dim3(BR_THREADS), rshmem, st, q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, B, S, nq, nkv, scale, p_drop,
+                           seed, dq, lddq, span, ord, split);
+        GAMER_CHECK_LAUNCH("gamer_attn_bwd_bf16/dq resident");
+        return 0;
+    }
     hipLaunchKernelGGL((attn_bwd_dq_b_kernel<G, DROP, SPAN, ORD>), grid, dim3(AB_THREADS), 0, st, q, ldq, k, ldk, v, ldv, d_o, lse,
                        delta, kl, ql, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, span, ord);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd_bf16/dq");

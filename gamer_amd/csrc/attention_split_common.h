@@ -253,6 +253,7 @@ static inline int res_split(int n_pairs, int ways) {
 // share of the CU-rounds that whole-pair units keep busy
 static inline double res_fill(int n_pairs) {
     const int ncu = res_grid_cap();
+    if (n_pairs <= ncu) return 1.0;          // (a single round: nothing to balance)
     return (double)n_pairs / ((double)((n_pairs + ncu - 1) / ncu) * ncu);
 }
 int launch_fwd_res(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl, const int32_t* ql,
