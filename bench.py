@@ -395,7 +395,7 @@ def parse_args(argv=None):
                          "split3 = every fp32 product from a two-way fp16 cut of both operands scaled per tensor, 3 piece products; "
                          "split6 / split9 = every fp32 product from an exact three-way bf16 cut of both operands, 6 / 9 piece "
                          "products on the bf16 pipe, fp32 accumulation (gamer_gemm_f32_split, gamer_attn_*_split; error against "
-                         "fp64 at the fp32 MFMA's level, DESIGN.md section 13); f32 = v_mfma_f32_32x32x2_f32 throughout")
+                         "fp64 at the fp32 MFMA's level, docs/DESIGN_rounds1-4.md section 13); f32 = v_mfma_f32_32x32x2_f32 throughout")
     ap.add_argument("--kernel-rows", type=int, default=12, help="rows of the per-family kernel table in the JSON line")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (and the roofline object)")
     ap.add_argument("--ragged", action="store_true", help="secondary workload: n_items ~ U{2..items}, right padded")

@@ -165,7 +165,7 @@ __device__ __forceinline__ bf16x8 read_tr8(const bf16_t* __restrict__ img, const
 // Two fp32 -> one register of two bf16 (round to nearest even).  Spelled as the instruction: left to the compiler, the
 // conversion of a vector that has just gone through a select came out as one v_cvt_pk_bf16_f32 PER ELEMENT (upper half
 // unused), the select on the 16-bit result and a v_perm_b32 per pair - 40 vector instructions per 16 probabilities where
-// 8 do the work, in kernels whose time is vector-ALU time.
+// 8 do the work, in kernels whose time is vector-ALU time (docs/DESIGN_rounds1-4.md section 11).
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
     uint32_t r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));

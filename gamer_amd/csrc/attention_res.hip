@@ -4,7 +4,7 @@
 // attention_split.hip (predicate masks, "empty" rows uniform over all S keys, lazily rescaled online softmax, row order of the
 // cross attention, dropout mask function, operand maxima / sinks).
 //
-// Why (round 4 measurements): the tiled kernels re-stage the causal prefix of K / V for every 64-query
+// Why (round 4 measurements, docs/DESIGN_rounds1-4.md section 20): the tiled kernels re-stage the causal prefix of K / V for every 64-query
 // tile (4.5 x per sequence at S = 505); per 32 x 32 tile and wave that is ~215 of ~350 vector instructions (address arithmetic of
 // the loads, the cut, the LDS stores) next to 24 MFMAs, plus one workgroup barrier per key tile - 49 % of the wave cycles parked
 // at waits / barriers, 17 % MFMA-busy.  Here one workgroup of eight waves owns a (sequence, kv head) pair:

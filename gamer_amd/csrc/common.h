@@ -55,7 +55,7 @@ typedef float f32x8v __attribute__((ext_vector_type(8)));
 
 // four consecutive elements as a float4 (p aligned to 4 elements): 16-byte access for fp32, 8-byte for bf16
 template <typename T> __device__ __forceinline__ float4 ld4(const T* p);
-// EW_NT=1 (elementwise.hip only): nontemporal 16-byte loads / stores.  Measured (round 3): in isolation SwiGLU
+// EW_NT=1 (elementwise.hip only): nontemporal 16-byte loads / stores.  Measured (round 3, docs/DESIGN_rounds1-4.md section 5): in isolation SwiGLU
 // forward / backward gain 5-11 % (6.3 TB/s), in the train step the GEMMs that read those tensors next lose what was gained.
 #ifndef EW_NT
 #define EW_NT 0

@@ -146,7 +146,7 @@ __device__ __forceinline__ void store_rc_h2(unsigned char* __restrict__ lds, int
 #define SP_PINGPONG 0   // instantiate the eight-wave ping-pong form (PP below); GAMER_GEMM_PP=1 then selects it
 #endif
 // The three forms above are bit-identical to the default one-stage form and were each measured within +-3 % of it on every
-// GEMM shape of the step: the split kernels run against the matrix pipe's POWER limit, not against
+// GEMM shape of the step (docs/DESIGN_rounds1-4.md section 13): the split kernels run against the matrix pipe's POWER limit, not against
 // their loop structure (tools/ubench_memtime.hip: random operand bits sustain 58-67 % of the nominal bf16 rate).
 constexpr int SPH_KC_ROW = 48;
 constexpr int SPH_KC_IMG = BM * SPH_KC_ROW;    // 6,144

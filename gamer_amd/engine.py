@@ -392,7 +392,7 @@ class Engine:
         the fp32 MFMA's, tools/split_error.py).  The attention products take the same form (gamer_attn_fwd_split /
         gamer_attn_bwd_split, csrc/attention_split.hip; ``self.split_attention = False`` keeps them on the fp32 MFMA).
         "split3" (the default) = the Linear sites as THREE fp16 piece products of a two-way cut of both operands, each
-        operand tensor scaled by a power of two from its largest magnitude (gamer_absmax_f32) - the
+        operand tensor scaled by a power of two from its largest magnitude (gamer_absmax_f32; docs/DESIGN_rounds1-4.md section 17) - the
         same error against fp64 at half the matrix instructions; the attention products take the same three-product form
         (``self.h2_attention = False`` keeps them in the six-product bf16 form).
         ``deterministic`` (fp32 forms; None = GAMER_DETERMINISTIC=1): EVERY reduction of the step in a fixed order, so that two
@@ -407,7 +407,7 @@ class Engine:
         bf16 step depending on the caller's autocast state (gamer_amd/modeling.py)."""
         cfg.validate()
         if matmul is None:
-            # default of the fp32 path: products on the 16-bit matrix pipe from piece cuts (DESIGN.md sections 13, 15, 17);
+            # default of the fp32 path: products on the 16-bit matrix pipe from piece cuts (docs/DESIGN_rounds1-4.md sections 13, 15, 17);
             # "f32" = fp32 MFMA
             matmul = "split3" if dtype == "f32" else "f32"
         if matmul not in ops.MATMUL_MODES:
@@ -468,7 +468,7 @@ class Engine:
         # of every forward / input-gradient GEMM is a weight, and without this every row tile of the activations cuts its weight
         # tile again (half of a K-step's cut instructions).  Bit-identical results (tests/test_ops_gpu.py); measured at batch
         # 1024: 320.98 vs 320.55 ms per step, forward GEMMs 36.2 vs 35.1 ms, input-gradient GEMMs 43.6 vs 44.0 - the cut
-        # arithmetic is not what bounds the kernel, so it stays off.
+        # arithmetic is not what bounds the kernel (docs/DESIGN_rounds1-4.md section 13), so it stays off.
         self.weight_planes: Optional[torch.Tensor] = None
         if dtype == "f32" and matmul != "f32" and os.environ.get("GAMER_SPLIT_PLANES", "0") == "1":
             self.weight_planes = torch.zeros(3, _round_up(n, 4), dtype=torch.bfloat16, device=self.device)

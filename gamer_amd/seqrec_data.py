@@ -1,7 +1,7 @@
 """`train_decoder` plumbing of BASELINE configs[0] (TIGER single-behaviour decoder on Beauty, CPU): the reference's
 ``SeqRecDataset`` + ``T5Tokenizer`` + ``EncoderDecoderCollator`` as a pre-tokeniser that emits id tensors directly, and
 TIGER's temperature cross-entropy through the HIP loss kernels.  SURVEY.md section 8(f) row 4 / section 3.4; no T5 kernels
-(the T5 encoder-decoder itself is outside the MI355X path).
+(the T5 encoder-decoder itself is outside the MI355X path, docs/DESIGN_rounds1-4.md section 14).
 
 Reference behaviour restated (bit-exact against ``tests/golden/seqrec_small.npz``, generated from the real classes by
 ``oracle/make_golden_seqrec.py``):
