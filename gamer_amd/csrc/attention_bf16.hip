@@ -459,6 +459,8 @@ static inline bool br_part_enabled(const char* name) {
     return e ? atoi(e) != 0 : true;
 }
 static inline int br_grid_cap() {
+    const char* e = getenv("GAMER_ATTN_RES_GRID");      // (read per call: tests force a few persistent workgroups to walk many units)
+    if (e && atoi(e) > 0) return atoi(e);
     static int cap[MAX_DEVICES] = {};
     int& c = cap[current_device()];
     if (c == 0) {

@@ -29,6 +29,10 @@ namespace gamer {
 #ifndef RES_TOUCH_Q
 #define RES_TOUCH_Q 0     // 1: L2 warm-up loads of the next row tile q rows and row data in the forward (slower as well: 1.28 -> 1.33 ms)
 #endif
+#ifndef RES_PREFETCH_Q
+#define RES_PREFETCH_Q 0  // 1: the next row tile q row is requested into registers at the start of the current tile key loop.  Measured SLOWER (1.31 -> 1.48 ms:
+                          // 32 more live registers in a 256-register kernel spill 14-27 of them in the loop)
+#endif
 #ifndef RES_STAMP
 #define RES_STAMP 0       // diagnostic builds (tools/stamp_attn_res.py): every wave of the forward kernel accumulates shader-clock cycles per phase
 #endif                    // into g_res_stamp[(8 * blockIdx.x + wave) * 8 + phase] (set by gamer_debug_res_stamp); never in the shipped library
@@ -143,7 +147,7 @@ __device__ __forceinline__ void
 res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
                 int S, int nq, float scale, const AttnDropout& rng, float* o, float* lse, const RowOrder& ro, const int b,
                 const int head, const int t, const int kb, const bool want_amax, const H2Scales& sc, const int perm_cur,
-                const ResNext& nx RES_STAMP_ARGS) {
+                const ResNext& nx, float4 (&qraw)[8], const bool q_ready RES_STAMP_ARGS) {
     const int lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
     const SlOffsets lo(lane);
@@ -157,8 +161,8 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
 
     // every global load of the prologue is requested before anything waits for one: the q row, the row's data, the carried state
     // (in source order they came as three dependent round trips: row data -> wave reductions -> q -> state)
-    float4 qraw[8];
-    {
+    // (qraw: this tile's q row, requested by the PREVIOUS tile of this wave right after it had cut its own - RES_PREFETCH_Q - or here)
+    if (!q_ready) {
         const float* qrow = q + tok * ldq + head * 64 + 8 * h;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -212,6 +216,16 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
             bf16x8 pq[3];
             cut8_t<true>(a4, b4, sc.q, pq);
             qf[0][s] = pq[0]; qf[1][s] = pq[1];
+        }
+    }
+    if (RES_PREFETCH_Q && nx.valid) {
+        // the NEXT row tile's q row into the registers this tile's raw q has just left: in flight during this tile's key loop
+        const int64_t ntok = (int64_t)b * S + (ORD ? nx.perm : min(nx.t * 32 + r, S - 1));
+        const float* qrow = q + ntok * ldq + nx.head * 64 + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qraw[2 * s] = *reinterpret_cast<const float4*>(qrow + 16 * s);
+            qraw[2 * s + 1] = *reinterpret_cast<const float4*>(qrow + 16 * s + 4);
         }
     }
     const float invS = 1.f / (float)S;
@@ -453,6 +467,8 @@ attn_fwd_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
             // carried state of a tile travels through global memory, workgroup barriers in between: any wave may continue it)
             int cur = res_grab(sm, lane);
             int perm_cur = 0;
+            float4 qraw[8];
+            bool q_ready = false;
             if (ORD && cur < n_items) perm_cur = ro.perm[(int64_t)b * S + min((n_all - 1 - cur / hpu) * 32 + r, S - 1)];
 #pragma unroll 1
             while (cur < n_items) {
@@ -464,9 +480,13 @@ attn_fwd_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
                 nx.valid = nxt < n_items && (kb == 0 || sm.ntot[(h0 + nxt % hpu) * RES_MAX_TILES + nx.t] > kb * RB_TILES);
                 nx.perm = 0;
                 if (ORD && nxt < n_items) nx.perm = ro.perm[(int64_t)b * S + min(nx.t * 32 + r, S - 1)];
-                if (kb == 0 || sm.ntot[hg * RES_MAX_TILES + t] > kb * RB_TILES)
+                if (kb == 0 || sm.ntot[hg * RES_MAX_TILES + t] > kb * RB_TILES) {
                     res_fwd_rowtile<G, DROP, ORD>(sm, q, ldq, ql, row_empty, S, nq, scale, rng, o, lse, ro, b, kvh * G + hg, t, kb,
-                                                  amax_out != nullptr, sc, perm_cur, nx RES_STAMP_PASS);
+                                                  amax_out != nullptr, sc, perm_cur, nx, qraw, q_ready RES_STAMP_PASS);
+                    q_ready = RES_PREFETCH_Q && nx.valid;       // (nx.valid: the next item is a tile this block's pass processes)
+                } else {
+                    q_ready = false;
+                }
                 cur = nxt;
                 perm_cur = nx.perm;
             }

@@ -229,12 +229,13 @@ static inline bool res_part_enabled(const char* name) {      // GAMER_ATTN_RES_D
 }
 // persistent workgroups: one per CU (GAMER_ATTN_RES_GRID overrides)
 static inline int res_grid_cap() {
+    const char* e = getenv("GAMER_ATTN_RES_GRID");      // (read per call: tests force a few persistent workgroups to walk many units)
+    if (e && atoi(e) > 0) return atoi(e);
     static int cap[MAX_DEVICES] = {};
     int& c = cap[current_device()];
     if (c == 0) {
-        const char* e = getenv("GAMER_ATTN_RES_GRID");
-        int n = e ? atoi(e) : 0;
-        if (n <= 0 && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess) n = 256;
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, current_device()) != hipSuccess) n = 256;
         c = n > 0 ? n : 256;
     }
     return c;
