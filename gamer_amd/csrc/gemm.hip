@@ -1499,6 +1499,8 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     GAMER_CHECK_ARG(!d->resid || (d->group_mode == 0 && !d->accumulate && a_kc && b_kc && d->ldc % 4 == 0 &&
                                   aligned16(d->resid) && aligned16(d->C) && d->p_drop >= 0.f && d->p_drop < 1.f),
                     "gamer_gemm_f32: the fused residual epilogue needs a Linear-forward layout, ldc %% 4 == 0, no accumulate");
+    // short-contraction Linear forward from packed weight pieces: the activation-stationary kernel (csrc/gemm_as.hip)
+    if (split == 3 && gemm_as_eligible(d, a_kc, b_kc, p.b_planes)) return launch_gemm_as(d, p.b_planes, (hipStream_t)stream);
     p.n_tiles = (d->N + BN - 1) / BN;
     hipStream_t st = (hipStream_t)stream;
 

@@ -1,0 +1,312 @@
+// Activation-stationary Linear forward for short contractions (K <= 256: every nn.Linear of the decoder whose input is the hidden
+// state - the q|k|v and output-gate projections, the tied head; ref:SeqRec/models/generative/Qwen3Multi/model.py:93-99, 145-149, 1001),
+// three-product fp16 form (gamer_gemm_f32_split, terms = 3).  Same results contract as csrc/gemm.hip: fp32 in, fp32 out,
+// C[m][n] = alpha * sum_k A[m][k] W[n][k]; error against fp64 at or below the fp32 MFMA's.
+//
+// Why a second kernel.  The 128 x 128 x 32 tile kernel of gemm.hip re-cuts the activation tile for every column tile (six times at
+// N = 768), stages both operands through LDS every K-step with a barrier pair per two slices, and at K = 256 pays its prologue and
+// epilogue every eight K-steps: 26 % MFMA-busy, 5.8 vector instructions per MFMA (profiles/r05a_mfma_busy.md).  The resident
+// attention kernels (attention_res.hip) showed what the same matrix pipe does when nothing is re-staged.  Here:
+//   * a wave owns 32 rows of A for the WHOLE launch: it loads them once (the lane owns a row: 8 k-values per k-step, the layout of
+//     the attention kernels' q fragments), cuts them once into fp16 pieces held in registers (128 registers at K = 256) - with a
+//     power-of-two scale PER ROW (the row index is never contracted, so the scale is a per-lane factor of the epilogue): a row
+//     far below the tensor's maximum keeps its full relative precision by construction, no range guard and no operand maximum needed;
+//   * the workgroup (4 waves = 128 rows) walks the weight matrix in slabs of 32 output columns: a slab's packed pieces
+//     (gamer_split2h_planes_multi: the parameters are cut once per pass) go global -> registers -> LDS into one of two buffers while
+//     the other is multiplied - one barrier per slab of 48 MFMAs per wave (K = 256), no vector work in the loop but the epilogue's scale;
+//   * C^T = W A^T puts the output row on the lane: the tile leaves as 16-byte stores per lane.
+// A is read once, C written once, W (<= 1 MB) comes from the L2 once per 128 rows.
+//
+// Measured (batch 1024 x 505 tokens, tools/dev_gemm_as_time.py): q|k|v [517120 x 256] x [768 x 256]^T 0.94 ms (tile kernel) -> 0.70,
+// tied head (N = 1041) 1.36 -> 0.94; the forward GEMM family 28.4 -> 25.1 ms per step.  Timing-only builds (AS_ABLATE) of the q|k|v
+// launch: without the C stores 0.59, without the MFMAs 0.52, without the W staging 0.55 - no single phase is the bound, the three
+// overlap incompletely inside a wave (ideal: 0.24 ms of MFMAs, 0.27 ms of HBM bytes).
+#include "common.h"
+#include <stdlib.h>
+#include <atomic>
+
+namespace gamer {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4a __attribute__((ext_vector_type(4)));
+
+#ifndef AS_WAVES
+#define AS_WAVES 4        // waves per workgroup (32 rows each).  4: two workgroups per CU, out of step with each other - one loads its rows of A
+#endif                    // while the other multiplies (8 waves = one workgroup per CU measured 0.78 ms against 0.70 for the q|k|v shape)
+#ifndef AS_NT
+#define AS_NT 1           // 32-column MFMA tiles per slab (LDS per workgroup: 2 buffers x 2 pieces x K x 32 AS_NT x 2 bytes)
+#endif
+#ifndef AS_DEPTH
+#define AS_DEPTH 1        // slabs of W in flight in registers (2: three LDS buffers, two register sets; with 8 waves 0.739 against 0.764 ms
+                          // on one box, 4 waves 1.06: the per-slab fetch latency is not what is left)
+#endif
+#ifndef AS_ABLATE
+#define AS_ABLATE 0       // timing-only builds: 1 no C stores, 2 no MFMAs, 4 no W staging after the first slab
+#endif
+constexpr int AS_THREADS = 64 * AS_WAVES;
+constexpr int AS_SLAB = 32 * AS_NT;            // output columns per slab
+constexpr int AS_PANEL = AS_SLAB * 64;         // 16-bit elements of one [slab n][64 k] piece image
+
+// element offset of (row, column) in a [64][64] 16-bit image with swizzled 16-byte chunks (attention_split_common.h: sl_off)
+__device__ __forceinline__ int as_f(int row) { return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1); }
+__device__ __forceinline__ int as_off(int row, int col) { return row * 64 + ((((col >> 3) ^ as_f(row))) << 3) + (col & 7); }
+
+struct AsParams {
+    const float* A; int64_t lda;
+    const uint16_t* Wp;                        // packed pieces at W's offsets: 16 bytes = {h0 x 4 | h1 x 4} of four consecutive k
+    int64_t ldw;                               // elements between rows of W
+    float* C; int64_t ldc;
+    int M, N, K;
+    float alpha;
+    const uint32_t* amax_w;                    // bits of max |W| (the scale the pieces were cut with)
+    uint32_t* amax_c; int amax_c_col0;
+};
+
+// KP = K / 64 panels
+template <int KP>
+__global__ void __launch_bounds__(AS_THREADS, AS_DEPTH == 2 ? 1 : 8 / AS_WAVES)
+gemm_as_kernel(const AsParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char as_raw[];
+    bf16_t* const wimg = reinterpret_cast<bf16_t*>(as_raw);                // [buffer 2][piece 2][panel KP][AS_PANEL]
+    __shared__ uint32_t amax_word;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int m = (blockIdx.x * AS_WAVES + w) * 32 + r;
+    const bool valid_m = m < p.M;
+    if (tid == 0) amax_word = 0;
+
+    // ---- this lane's row of A: 8 k-values per k-step, cut once with the row's own scale --------------------------------------
+    bf16x8 af[2][KP * 4];
+    float row_inv;
+    {
+        const float* arow = p.A + (int64_t)(valid_m ? m : p.M - 1) * p.lda + 8 * h;
+        float4 raw[KP * 8];
+#pragma unroll
+        for (int s = 0; s < KP * 4; ++s) {
+            raw[2 * s] = *reinterpret_cast<const float4*>(arow + 16 * s);
+            raw[2 * s + 1] = *reinterpret_cast<const float4*>(arow + 16 * s + 4);
+        }
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < KP * 8; ++i) {
+            if (!valid_m) raw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            mx = fmaxf(fmaxf(fmaxf(mx, fabsf(raw[i].x)), fabsf(raw[i].y)), fmaxf(fabsf(raw[i].z), fabsf(raw[i].w)));
+        }
+        mx = xor32_max(mx);                                              // the row's other half
+        float s_row = 1.f;
+        row_inv = 1.f;
+        if (mx > 0.f) scale_from_amax(__float_as_uint(mx), s_row, row_inv);
+#pragma unroll
+        for (int s = 0; s < KP * 4; ++s) {
+            u32x4a u0, u1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float4 x = raw[2 * s + j];
+                uint32_t a0, a1, b0, b1;
+                cut2h_quad(x.x, x.y, x.z, x.w, s_row, a0, a1, b0, b1);
+                u0[2 * j] = a0; u0[2 * j + 1] = b0; u1[2 * j] = a1; u1[2 * j + 1] = b1;
+            }
+            af[0][s] = __builtin_bit_cast(bf16x8, u0);
+            af[1][s] = __builtin_bit_cast(bf16x8, u1);
+        }
+    }
+    float w_s, w_inv;
+    scale_from_amax(amax_read(p.amax_w), w_s, w_inv);
+    const float out_scale = row_inv * w_inv * p.alpha;
+
+    // ---- slabs of 64 output columns ---------------------------------------------------------------------------------------------
+    const int n_slabs = (p.N + AS_SLAB - 1) / AS_SLAB;
+    constexpr int QPR = KP * 16;                                         // 16-byte groups (four k) per row of W
+    constexpr int NLD = AS_SLAB * QPR / AS_THREADS;                      // groups per thread and slab (KP * 2)
+    uint4 rw[NLD], rw2[NLD];
+    // per thread: the NLD (row of the slab, four-k group) items it stages, as offsets computed ONCE (a slab later = a constant stride)
+    int lds_off[NLD], nl_[NLD];
+    const uint4* wsrc[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int f = tid + AS_THREADS * i;
+        const int nl = f / QPR, g = f % QPR;
+        nl_[i] = nl;
+        lds_off[i] = (g >> 4) * AS_PANEL + as_off(nl, (4 * g) & 63);
+        wsrc[i] = reinterpret_cast<const uint4*>(p.Wp) + (((int64_t)nl * p.ldw + 4 * g) >> 2);
+    }
+    const int64_t slab_stride = ((int64_t)AS_SLAB * p.ldw) >> 2;         // uint4 between slabs
+    auto load_slab_into = [&](int j, uint4 (&dst)[NLD]) {
+        const bool full = (j + 1) * AS_SLAB <= p.N;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const uint4* src = wsrc[i] + (int64_t)j * slab_stride;
+            if (!full && j * AS_SLAB + nl_[i] >= p.N) src = wsrc[i];       // (rows past N: any valid address; stored as zeros)
+            dst[i] = *src;
+        }
+    };
+    auto store_slab_from = [&](int j, int buf, const uint4 (&rw)[NLD]) {
+        bf16_t* img = wimg + buf * (2 * KP * AS_PANEL);
+        const bool full = (j + 1) * AS_SLAB <= p.N;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const bool ok = full || j * AS_SLAB + nl_[i] < p.N;
+            *reinterpret_cast<uint2*>(img + lds_off[i]) = ok ? make_uint2(rw[i].x, rw[i].y) : make_uint2(0u, 0u);
+            *reinterpret_cast<uint2*>(img + KP * AS_PANEL + lds_off[i]) = ok ? make_uint2(rw[i].z, rw[i].w) : make_uint2(0u, 0u);
+        }
+    };
+    auto load_slab = [&](int j) { load_slab_into(j, rw); };
+    auto store_slab = [&](int j, int buf) { store_slab_from(j, buf, rw); };
+    int row_off[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) row_off[s] = as_off(r, 16 * s + 8 * h);
+
+    float cmax = 0.f;
+    float* crow = p.C + (int64_t)m * p.ldc;
+    auto compute_slab = [&](const int j, const int buf) {
+        const bf16_t* img = wimg + buf * (2 * KP * AS_PANEL);
+            f32x16 acc[AS_NT];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int nt = 0; nt < AS_NT; ++nt) acc[nt][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KP * 4; ++ks) {
+                const int pn = ks >> 2, s = ks & 3;
+#pragma unroll
+                for (int nt = 0; nt < AS_NT; ++nt) {
+                    const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(img + pn * AS_PANEL + nt * 32 * 64 + row_off[s]);
+                    const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(img + (KP + pn) * AS_PANEL + nt * 32 * 64 + row_off[s]);
+                    // smallest piece products first
+                    if (AS_ABLATE & 2) { asm volatile("" :: "v"(w0), "v"(w1)); continue; }
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w1), __builtin_bit_cast(f16x8, af[0][ks]), acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w0), __builtin_bit_cast(f16x8, af[1][ks]), acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w0), __builtin_bit_cast(f16x8, af[0][ks]), acc[nt], 0, 0, 0);
+                }
+            }
+            // epilogue: lane = output row m, acc[nt][reg] = column slab + 32 nt + (reg & 3) + 8 (reg >> 2) + 4 h
+            if (valid_m) {
+                const bool track = p.amax_c != nullptr && j * AS_SLAB >= p.amax_c_col0;
+#pragma unroll
+                for (int nt = 0; nt < AS_NT; ++nt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int col = j * AS_SLAB + nt * 32 + 8 * g4 + 4 * h;
+                        if (col < p.N) {
+                            const float4 t4 = make_float4(acc[nt][4 * g4] * out_scale, acc[nt][4 * g4 + 1] * out_scale,
+                                                          acc[nt][4 * g4 + 2] * out_scale, acc[nt][4 * g4 + 3] * out_scale);
+                            if (AS_ABLATE & 1) { asm volatile("" :: "v"(t4.x), "v"(t4.y), "v"(t4.z), "v"(t4.w)); }
+                            else if (col + 4 <= p.N) {
+                                *reinterpret_cast<float4*>(crow + col) = t4;
+                            } else {                                              // (columns from N on belong to the caller)
+                                const float e[4] = {t4.x, t4.y, t4.z, t4.w};
+                                for (int q = 0; q < 4 && col + q < p.N; ++q) crow[col + q] = e[q];
+                            }
+                            if (track) cmax = fmaxf(fmaxf(fmaxf(cmax, fabsf(t4.x)), fabsf(t4.y)), fmaxf(fabsf(t4.z), fabsf(t4.w)));
+                        }
+                    }
+            }
+    };
+    if (AS_DEPTH == 1) {
+        load_slab(0);
+        store_slab(0, 0);
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < n_slabs; ++j) {
+            const int buf = j & 1;
+            if (j + 1 < n_slabs && !(AS_ABLATE & 4)) load_slab(j + 1);
+            compute_slab(j, buf);
+            if (j + 1 < n_slabs && !(AS_ABLATE & 4)) store_slab(j + 1, buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // two slabs in flight: slab j + 1 waits in one register set, j + 2 in the other; three LDS buffers (slab j in buffer j % 3)
+        load_slab_into(0, rw);
+        store_slab_from(0, 0, rw);
+        if (n_slabs > 1) load_slab_into(1, rw);
+        if (n_slabs > 2) load_slab_into(2, rw2);
+        __syncthreads();
+        int bufc = 0;
+#pragma unroll 1
+        for (int j = 0; j < n_slabs; j += 2) {
+            const int b1 = bufc == 2 ? 0 : bufc + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+            compute_slab(j, bufc);
+            if (j + 1 < n_slabs) store_slab_from(j + 1, b1, rw);
+            if (j + 3 < n_slabs) load_slab_into(j + 3, rw);
+            __syncthreads();
+            if (j + 1 >= n_slabs) break;
+            compute_slab(j + 1, b1);
+            if (j + 2 < n_slabs) store_slab_from(j + 2, b2, rw2);
+            if (j + 4 < n_slabs) load_slab_into(j + 4, rw2);
+            __syncthreads();
+            bufc = b2;
+        }
+    }
+    if (p.amax_c) {
+        uint32_t mw = __float_as_uint(cmax);
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) mw = max(mw, (uint32_t)__shfl_xor((int)mw, o2, 64));
+        if (lane == 0 && mw) atomicMax(&amax_word, mw);
+        __syncthreads();
+        if (tid == 0 && amax_word) amax_publish(amax_word, p.amax_c, blockIdx.x);
+    }
+}
+
+static std::atomic<long long> g_as_launches{0};
+
+static inline bool gemm_as_enabled() {
+    const char* e = getenv("GAMER_GEMM_AS");             // (read per call: tests and A/B runs switch it inside one process)
+    return e ? atoi(e) != 0 : true;
+}
+
+// Does this descriptor take the activation-stationary kernel?  (plain Linear forward, one group, packed weight pieces, K a multiple
+// of 64 up to 256, enough rows to fill the chip)
+bool gemm_as_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint16_t* b_planes) {
+    if (!gemm_as_enabled() || !a_kc || !b_kc || !b_planes || !d->amax_b) return false;
+    if (d->group_mode != 0 || d->groups != 1 || d->accumulate || d->resid || d->rowdot_out || d->qk_q_rot || d->sw_gu) return false;
+    // (a workgroup takes 256 rows: below ~16 k rows the launch leaves most CUs idle and the tile kernel is the better fit;
+    // GAMER_GEMM_AS_MIN_M lowers the bar for tests)
+    const char* mm = getenv("GAMER_GEMM_AS_MIN_M");
+    if (d->K % 64 != 0 || d->K < 64 || d->K > 256 || d->M < (mm ? atoi(mm) : 16384)) return false;
+    if (d->a_rs % 4 != 0 || d->b_rs % 4 != 0 || d->ldc % 4 != 0 || !aligned16(d->C) || !aligned16(b_planes)) return false;
+    if (d->amax_c && d->amax_c_col0 % AS_SLAB != 0) return false;
+    static_assert((AS_SLAB * 16) % AS_THREADS == 0 || AS_THREADS % (AS_SLAB * 16) == 0, "slab groups per thread");
+    return true;
+}
+
+int launch_gemm_as(const gamer_gemm_desc* d, const uint16_t* b_planes, hipStream_t st) {
+    AsParams p;
+    p.A = d->A; p.lda = d->a_rs;
+    p.Wp = b_planes; p.ldw = d->b_rs;
+    p.C = d->C; p.ldc = d->ldc;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.alpha = d->alpha;
+    p.amax_w = d->amax_b;
+    p.amax_c = d->amax_c; p.amax_c_col0 = d->amax_c_col0;
+    const int kp = d->K / 64;
+    const size_t shmem = (size_t)(AS_DEPTH == 2 ? 3 : 2) * 2 * kp * AS_PANEL * sizeof(bf16_t);
+    const dim3 grid((d->M + 32 * AS_WAVES - 1) / (32 * AS_WAVES));
+#define GAMER_LAUNCH_AS(KPV)                                                                                                  \
+    do {                                                                                                                      \
+        static bool attr_dev[MAX_DEVICES] = {};                                                                               \
+        if (!attr_dev[current_device()]) {                                                                                    \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_as_kernel<KPV>),                      \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                 \
+            if (e != hipSuccess) { set_error("gamer_gemm_f32_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; } \
+            attr_dev[current_device()] = true;                                                                                \
+        }                                                                                                                     \
+        hipLaunchKernelGGL(gemm_as_kernel<KPV>, grid, dim3(AS_THREADS), shmem, st, p);                                        \
+    } while (0)
+    switch (kp) {
+        case 1: GAMER_LAUNCH_AS(1); break;
+        case 2: GAMER_LAUNCH_AS(2); break;
+        case 3: GAMER_LAUNCH_AS(3); break;
+        default: GAMER_LAUNCH_AS(4); break;
+    }
+#undef GAMER_LAUNCH_AS
+    GAMER_CHECK_LAUNCH("gamer_gemm_f32_split/activation-stationary");
+    g_as_launches.fetch_add(1, std::memory_order_relaxed);
+    return 0;
+}
+
+}  // namespace gamer
+
+// Diagnostic (not in include/gamer_hip.h): launches of the activation-stationary kernel by this process so far.  On well-scaled data
+// the kernel returns the BITS of the tile kernel (a power-of-two scale does not change an fp16 rounding), so a test cannot tell from
+// the results which of the two ran.
+extern "C" long long gamer_debug_gemm_as_launches(void) { return gamer::g_as_launches.load(std::memory_order_relaxed); }

@@ -1,0 +1,176 @@
+"""Activation-stationary Linear forward (csrc/gemm_as.hip) - the kernel that takes plain nn.Linear forwards with K <= 256 and packed weight
+pieces in the default product form (q|k|v, output gate, tied head: ref:SeqRec/models/generative/Qwen3Multi/model.py:93-99, 145-149, 1001).
+It only engages at >= 16 k rows in production; GAMER_GEMM_AS_MIN_M = 1 brings it down to test sizes.  Reference: fp64 products, at the
+bars of the tile kernel's tests (error relative to sum |a_k| |w_k|); against the tile kernel on the same inputs; exact cases."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gamer_amd import ops  # noqa: E402
+
+DEV = "cuda"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+class _env:
+    def __init__(self, **kw):
+        self.kw = {k: str(v) for k, v in kw.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _weights(N, K, ldw=None, scale=0.05, seed=0):
+    """A weight matrix inside a flat 'parameter' buffer registered as stable, with its piece planes: what Engine does once per pass."""
+    g = torch.Generator().manual_seed(seed)
+    ldw = ldw or K
+    flat = (torch.randn(N * ldw + 8, generator=g) * scale).to(DEV)
+    W = flat[:N * ldw].view(N, ldw)[:, :K]
+    cache = ops.amax_reuse()
+    cache.stable_range(flat.data_ptr(), flat.numel() * 4)
+    cache.planes = torch.zeros(flat.numel(), dtype=torch.float32, device=DEV)
+    return flat, W, ldw, cache
+
+
+def _forward(x, W, ldw, cache, M, N, K, ldy=None, as_on=True, passes=2, **kw):
+    """Two passes inside the cache: the planes exist from the second one on (the first runs the in-kernel cut of the tile kernel)."""
+    ldy = ldy or N
+    y = None
+    with _env(GAMER_GEMM_AS=int(as_on), GAMER_GEMM_AS_MIN_M=1), ops.f32_matmul("split3"), cache:
+        for _ in range(passes):
+            cache.reset()
+            y = torch.full((M, ldy), float("nan"), device=DEV)
+            ops.linear_fwd(x, x.stride(0), W, ldw, y, ldy, M, N, K, **kw)
+        assert len(cache._plane_keys) > 0
+    torch.cuda.synchronize()
+    return y
+
+
+def _err(y, x, W, N):
+    xd, wd = x.double().cpu(), W.double().cpu()
+    ref, sc = xd @ wd.T, xd.abs() @ wd.abs().T
+    e = (y[:, :N].double().cpu() - ref).abs() / sc.clamp_min(1e-300)
+    return float(e.max()), float(e.pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize("K", [64, 128, 192, 256])
+@pytest.mark.parametrize("M,N,ldy", [(1000, 768, 768), (517, 1041, 1056), (32, 32, 32), (4099, 100, 128), (1, 256, 256)])
+def test_gemm_as_against_fp64_and_the_tile_kernel(M, N, ldy, K):
+    """Ragged row counts (a last workgroup with idle waves, a last wave with idle lanes), N with a partial last slab (1041 = 32 x 32 + 17,
+    100), a padded output row stride; every K the kernel instantiates."""
+    flat, W, ldw, cache = _weights(N, K, seed=N + K)
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g))).to(DEV)
+    y_as = _forward(x, W, ldw, cache, M, N, K, ldy=ldy, as_on=True)
+    y_tile = _forward(x, W, ldw, cache, M, N, K, ldy=ldy, as_on=False)
+    e_as, e_tile = _err(y_as, x, W, N), _err(y_tile, x, W, N)
+    assert e_as[0] < 1e-6 and e_as[1] < 6e-8, (e_as, e_tile)
+    assert e_as[0] < 1.5 * e_tile[0] + 1e-8 and e_as[1] < 1.25 * e_tile[1]
+    if ldy > N:                                    # the padding columns are not written
+        assert torch.isnan(y_as[:, N:]).all()
+    assert torch.isfinite(y_as[:, :N]).all()
+
+
+def _as_launches():
+    import ctypes
+    from gamer_amd import _lib
+    fn = _lib.load().gamer_debug_gemm_as_launches
+    fn.restype = ctypes.c_longlong
+    return int(fn())
+
+
+def test_gemm_as_is_really_the_kernel_that_ran():
+    """On well-scaled data the two kernels return the same BITS (a power-of-two scale - per row here, per tensor there - does not change
+    an fp16 rounding, and both add the piece products in the same order), so the results cannot tell which ran: the library counts the
+    launches.  First pass of a cache = no planes yet = tile kernel; GAMER_GEMM_AS=0 and rows below the bar = tile kernel."""
+    M, N, K = 2048, 768, 256
+    flat, W, ldw, cache = _weights(N, K)
+    x = torch.randn(M, K, device=DEV) * 3
+    n0 = _as_launches()
+    y_as = _forward(x, W, ldw, cache, M, N, K, as_on=True)
+    assert _as_launches() == n0 + 1
+    y_tile = _forward(x, W, ldw, cache, M, N, K, as_on=False)
+    assert _as_launches() == n0 + 1
+    assert float((y_as - y_tile).abs().max()) < 2e-6 * float(y_tile.abs().max())
+    assert torch.equal(y_as, _forward(x, W, ldw, cache, M, N, K, as_on=True))          # repeats itself bit for bit
+    assert _as_launches() == n0 + 3                  # (the cache knows the weights by now: both passes had planes)
+    with _env(GAMER_GEMM_AS=1), ops.f32_matmul("split3"), cache:                        # production bar: 16 k rows
+        for _ in range(2):
+            cache.reset()
+            ops.linear_fwd(x, K, W, ldw, torch.empty(M, N, device=DEV), N, M, N, K)
+    assert _as_launches() == n0 + 3
+
+
+def test_gemm_as_rows_of_any_magnitude_keep_their_relative_error():
+    """A per-row power-of-two scale: rows 2^-40 .. 2^+40 apart in one launch come out at the same relative error, with no range guard
+    (the tile kernel redoes such tiles on the fp32 MFMA); small integers exactly; zero rows give zeros; an Inf poisons its row only."""
+    M, N, K = 640, 384, 256
+    flat, W, ldw, cache = _weights(N, K, scale=0.3)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(M, K, generator=g)
+    mag = torch.exp2(torch.randint(-40, 41, (M, 1), generator=g).float())
+    x = x * mag
+    x[5] = 0.0
+    y = _forward(x.to(DEV), W, ldw, cache, M, N, K)
+    xd, wd = x.double(), W.double().cpu()
+    e = (y.double().cpu() - xd @ wd.T).abs() / (xd.abs() @ wd.abs().T).clamp_min(1e-300)
+    assert float(e.max()) < 1e-6 and float(e.pow(2).mean().sqrt()) < 6e-8
+    assert torch.equal(y[5].cpu(), torch.zeros(N))
+    # integers
+    flat2 = torch.zeros(N * K + 8, device=DEV)
+    wi = torch.randint(-30, 31, (N, K)).float()
+    flat2[:N * K] = wi.flatten().to(DEV)
+    cache2 = ops.amax_reuse()
+    cache2.stable_range(flat2.data_ptr(), flat2.numel() * 4)
+    cache2.planes = torch.zeros(flat2.numel(), dtype=torch.float32, device=DEV)
+    xi = torch.randint(-30, 31, (M, K)).float()
+    yi = _forward(xi.to(DEV), flat2[:N * K].view(N, K), K, cache2, M, N, K)
+    assert torch.equal(yi.cpu().double(), xi.double() @ wi.double().T)
+    xinf = xi.clone()
+    xinf[7, 3] = float("inf")
+    yinf = _forward(xinf.to(DEV), flat2[:N * K].view(N, K), K, cache2, M, N, K)
+    assert not torch.isfinite(yinf[7].cpu()).all()
+    ok = torch.ones(M, dtype=torch.bool)
+    ok[7] = False
+    assert torch.equal(yinf.cpu()[ok].double(), (xi.double() @ wi.double().T)[ok])
+
+
+@pytest.mark.parametrize("M", [640, 300])
+def test_gemm_as_reports_the_maximum_of_the_columns_it_is_asked_for(M):
+    """gamer_gemm_desc.amax_c: the v columns of a q|k|v projection (what the attention kernels cut V with)."""
+    from test_ops_gpu import _slot_value
+    H, nq, nkv = 256, 6, 3
+    QKV = (nq + 2 * nkv) * 64
+    g = torch.Generator().manual_seed(1)
+    flat = (torch.randn(QKV * H + 8, generator=g) * 0.3).to(DEV)
+    W = flat[:QKV * H].view(QKV, H)
+    x = torch.randn(M, H, device=DEV)
+    col0 = (nq + nkv) * 64
+    cache = ops.amax_reuse(everything=True)
+    cache.stable_range(flat.data_ptr(), flat.numel() * 4)
+    cache.planes = torch.zeros(flat.numel(), dtype=torch.float32, device=DEV)
+    with _env(GAMER_GEMM_AS=1, GAMER_GEMM_AS_MIN_M=1), ops.f32_matmul("split3"), cache:
+        for _ in range(2):
+            cache.reset()
+            y = torch.zeros(M, QKV, device=DEV)
+            v = y[:, col0:]
+            ops.linear_fwd(x, H, W, H, y, QKV, M, QKV, H, c_amax=(v, col0))
+        assert len(cache._plane_keys) > 0
+        key = cache._key(v.data_ptr(), (1, 0, M, nkv * 64, QKV))
+        assert key in cache.pending, "the producer did not open a slot"
+        torch.cuda.synchronize()
+        assert _slot_value(cache.pending[key]) == float(v.abs().max())
+    ref = x.double().cpu() @ W.double().cpu().T
+    assert float((y.double().cpu() - ref).abs().max() / ref.abs().max()) < 1e-6
