@@ -300,6 +300,8 @@ __device__ __forceinline__ float dsilu_f(float x) {
 // (gemm_as.hip) the activation-stationary Linear forward of gamer_gemm_f32_split(terms = 3): eligibility of a descriptor, launch
 bool gemm_as_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint16_t* b_planes);
 int launch_gemm_as(const gamer_gemm_desc* d, const uint16_t* b_planes, hipStream_t st);
+bool gemm_wg_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc);      // (gemm_wg.hip) weight gradient, 256 x 256 tiles
+int launch_gemm_wg(const gamer_gemm_desc* d, hipStream_t st);
 
 // (gemm.hip) C (+)= the chunk partial tiles of an ordered weight gradient, in chunk order; returns hipGetLastError()
 int launch_wgrad_reduce(const float* ws, float* C, int64_t ldc, int M, int N, int groups, const int32_t* group_offsets, int K,

@@ -579,10 +579,11 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
 #pragma unroll
                     for (int j = 0; j < 2; ++j) bf[j][q] = __builtin_bit_cast(f16x8, read_frag_split<B_KC>(b8 + q * B_IMG, wn * 64 + j * 32, sub, lane));
                 }
-                // a0.b1, a1.b0 (small) first, then a0.b0
+                // a0.b1, a1.b0 (small) first, then a0.b0; the weight-gradient layout: a1.b0, a0.b0, a0.b1 - the order of gemm_wg.hip,
+                // whose single fragment set needs it (the step's sums are added to a running fp32 total either way)
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    const int qa = t == 1 ? 1 : 0, qb = t == 0 ? 1 : 0;
+                    const int qa = MODE == 1 ? (t == 0 ? 1 : 0) : (t == 1 ? 1 : 0), qb = MODE == 1 ? (t == 2 ? 1 : 0) : (t == 0 ? 1 : 0);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1527,7 +1528,9 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
                             (long long)d->wgrad_ws_floats, (long long)need);
             GAMER_CHECK_ARG(!getenv("GAMER_GEMM_PP"), "gamer_gemm_f32: the deterministic weight gradient is not built for the ping-pong form");
         }
-        const int rc = launch_gemm<false, false, 1>(p, (int)blocks, st, split);
+        // three-product form with the chunk workspace: the 256 x 256-tile kernel (csrc/gemm_wg.hip; same partial tiles, same bits)
+        const int rc = (split == 3 && p.wgrad_ws && gemm_wg_eligible(d, a_kc, b_kc)) ? launch_gemm_wg(d, st)
+                                                                                     : launch_gemm<false, false, 1>(p, (int)blocks, st, split);
         if (rc || !p.wgrad_ws) return rc;
         const int64_t rblocks = (int64_t)d->groups * p.m_tiles * p.n_tiles * 16;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)rblocks), dim3(256), 0, st, p.wgrad_ws, d->C, d->ldc, d->M, d->N, p.m_tiles,
