@@ -280,8 +280,10 @@ def log(msg: str):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def committed_traffic(kernel_substr: str, want: dict):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summaries (profiles/<tag>_pmc_{FETCH,WRITE}_SIZE.csv;
+def committed_traffic(kernel_substr, want: dict):
+    """HBM bytes per launch of a kernel - or of a family of kernels (a tuple of name fragments: the weight gradients run on
+    gemm_wg_kernel where dW is whole 256 x 256 tiles and on gemm_f32_kernel elsewhere), averaged over their dispatches -
+    from the committed rocprofv3 PMC summaries (profiles/<tag>_pmc_{FETCH,WRITE}_SIZE.csv;
     separate --pmc passes).  Only a profile set whose sidecar ``profiles/<tag>_pmc_meta.json`` (written by the profiling
     script next to the CSVs: the bench arguments of the profiled command) matches the CURRENT run's workload in every
     key of ``want`` (batch, items, dtype, matmul, variant, ragged) is used; the newest matching set wins.  No match ->
@@ -291,11 +293,16 @@ def committed_traffic(kernel_substr: str, want: dict):
     import glob
     prof = os.path.join(ROOT, "profiles")
 
+    subs = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
+
     def avg(path, col):
+        tot, n = 0.0, 0.0
         for r in csv.DictReader(open(path)):
-            if kernel_substr in r["kernel"]:
-                return float(r[col])
-        return None
+            if any(sub in r["kernel"] for sub in subs):
+                d = float(r.get("dispatches", 1) or 1)
+                tot += float(r[col]) * d
+                n += d
+        return tot / n if n else None
 
     # newest first, by what the profiling script RECORDED in the sidecar: `created` (UTC time stamp) where present, else `seq`;
     # sets without either sort before all others, by name (file times are meaningless in a fresh checkout, and tags such as
@@ -754,7 +761,8 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
         # (substring match: the template list continues with the ping-pong flag)
         kname = {"gemm_fwd": f"gemm_f32_kernel<true, true, 0, false, false, 2, 0, {split_terms},",
                  "gemm_dgrad": f"gemm_f32_kernel<true, false, 0, false, false, 2, 0, {split_terms},",
-                 "gemm_wgrad": f"gemm_f32_kernel<false, false, 1, false, false, 2, 0, {split_terms},"}.get(dom["kernel"] if dom else "", None)
+                 "gemm_wgrad": (f"gemm_f32_kernel<false, false, 1, false, false, 2, 0, {split_terms},", "gemm_wg_kernel<")}.get(
+                     dom["kernel"] if dom else "", None)
         if args.dtype != "f32":
             kname = None
         # HBM bytes per launch from a committed PMC profile of THIS workload (shape / dtype / matmul form checked)
@@ -812,7 +820,9 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": (f"gemm_{'f32' if args.dtype == 'f32' else 'bf16'}_kernel ({dom['kernel']})"
+                "kernel": ((f"gemm_wg_kernel + gemm_f32_kernel ({dom['kernel']}: 256 x 256 tiles where dW is whole tiles, 128 x 128 elsewhere)"
+                            if (dom["kernel"] == "gemm_wgrad" and split_terms == 3) else
+                            f"gemm_{'f32' if args.dtype == 'f32' else 'bf16'}_kernel ({dom['kernel']})")
                            + (f" SPLIT={split_terms}: {'fp16' if split_terms == 3 else 'bf16'} MFMA pipe, peak = "
                               f"{BF16_MATRIX_PEAK_TFLOPS:g} / {split_terms}" if split_terms else "")) if dom else None,
                 "achieved": dom["tflops"] if dom else None,
