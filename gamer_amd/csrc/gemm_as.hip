@@ -60,6 +60,9 @@ struct AsParams {
     float alpha;
     const uint32_t* amax_w;                    // bits of max |W| (the scale the pieces were cut with)
     uint32_t* amax_c; int amax_c_col0;
+    // grouped form (the position-routed experts: rows sorted by expert, group g = rows group_offsets[g] .. group_offsets[g + 1] - 1
+    // with its own weight matrix strideW elements further): a workgroup never crosses a segment boundary
+    int groups; const int32_t* group_offsets; int64_t strideW;
 };
 
 // KP = K / 64 panels
@@ -71,15 +74,30 @@ gemm_as_kernel(const AsParams p) {
     __shared__ uint32_t amax_word;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int m = (blockIdx.x * AS_WAVES + w) * 32 + r;
-    const bool valid_m = m < p.M;
+    int row0 = blockIdx.x * (32 * AS_WAVES), row_end = p.M, grp = 0;
+    if (p.group_offsets) {
+        int prev = p.group_offsets[0], tiles_before = 0;
+        bool found = false;
+        for (int gi = 0; gi < p.groups; ++gi) {
+            const int nxt = p.group_offsets[gi + 1];
+            const int tiles = (nxt - prev + 32 * AS_WAVES - 1) / (32 * AS_WAVES);
+            if (!found && (int)blockIdx.x < tiles_before + tiles) {
+                grp = gi; row0 = prev + ((int)blockIdx.x - tiles_before) * (32 * AS_WAVES); row_end = nxt; found = true;
+            }
+            if (!found) tiles_before += tiles;
+            prev = nxt;
+        }
+        if (!found) return;
+    }
+    const int m = row0 + w * 32 + r;
+    const bool valid_m = m < row_end;
     if (tid == 0) amax_word = 0;
 
     // ---- this lane's row of A: 8 k-values per k-step, cut once with the row's own scale --------------------------------------
     bf16x8 af[2][KP * 4];
     float row_inv;
     {
-        const float* arow = p.A + (int64_t)(valid_m ? m : p.M - 1) * p.lda + 8 * h;
+        const float* arow = p.A + (int64_t)(valid_m ? m : row_end - 1) * p.lda + 8 * h;
         float4 raw[KP * 8];
 #pragma unroll
         for (int s = 0; s < KP * 4; ++s) {
@@ -128,7 +146,7 @@ gemm_as_kernel(const AsParams p) {
         const int nl = f / QPR, g = f % QPR;
         nl_[i] = nl;
         lds_off[i] = (g >> 4) * AS_PANEL + as_off(nl, (4 * g) & 63);
-        wsrc[i] = reinterpret_cast<const uint4*>(p.Wp) + (((int64_t)nl * p.ldw + 4 * g) >> 2);
+        wsrc[i] = reinterpret_cast<const uint4*>(p.Wp) + (((int64_t)grp * p.strideW + (int64_t)nl * p.ldw + 4 * g) >> 2);
     }
     const int64_t slab_stride = ((int64_t)AS_SLAB * p.ldw) >> 2;         // uint4 between slabs
     auto load_slab_into = [&](int j, uint4 (&dst)[NLD]) {
@@ -258,7 +276,10 @@ static inline bool gemm_as_enabled() {
 // of 64 up to 256, enough rows to fill the chip)
 bool gemm_as_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint16_t* b_planes) {
     if (!gemm_as_enabled() || !a_kc || !b_kc || !b_planes || !d->amax_b) return false;
-    if (d->group_mode != 0 || d->groups != 1 || d->accumulate || d->resid || d->rowdot_out || d->qk_q_rot || d->sw_gu) return false;
+    if (d->group_mode != 0 || d->accumulate || d->resid || d->rowdot_out || d->qk_q_rot || d->sw_gu) return false;
+    // (grouped: the experts' gate|up projection at d_in = 256: 1.37 -> 1.30 ms, W is 1 MB per 128 rows there; the injecting layers'
+    // d_in = 320 would need 160 piece registers = one workgroup per CU: measured 1.62 -> 2.4 ms, stays on the tile kernel)
+    if (d->groups != 1 && (!d->group_offsets || d->strideC != 0 || d->amax_c)) return false;
     // (a workgroup takes 256 rows: below ~16 k rows the launch leaves most CUs idle and the tile kernel is the better fit;
     // GAMER_GEMM_AS_MIN_M lowers the bar for tests)
     const char* mm = getenv("GAMER_GEMM_AS_MIN_M");
@@ -278,9 +299,10 @@ int launch_gemm_as(const gamer_gemm_desc* d, const uint16_t* b_planes, hipStream
     p.alpha = d->alpha;
     p.amax_w = d->amax_b;
     p.amax_c = d->amax_c; p.amax_c_col0 = d->amax_c_col0;
+    p.groups = d->groups; p.group_offsets = d->groups > 1 ? d->group_offsets : nullptr; p.strideW = d->strideB;
     const int kp = d->K / 64;
     const size_t shmem = (size_t)(AS_DEPTH == 2 ? 3 : 2) * 2 * kp * AS_PANEL * sizeof(bf16_t);
-    const dim3 grid((d->M + 32 * AS_WAVES - 1) / (32 * AS_WAVES));
+    const dim3 grid((d->M + 32 * AS_WAVES - 1) / (32 * AS_WAVES) + (p.group_offsets ? d->groups : 0));
 #define GAMER_LAUNCH_AS(KPV)                                                                                                  \
     do {                                                                                                                      \
         static bool attr_dev[MAX_DEVICES] = {};                                                                               \

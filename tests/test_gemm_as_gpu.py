@@ -174,3 +174,37 @@ def test_gemm_as_reports_the_maximum_of_the_columns_it_is_asked_for(M):
         assert _slot_value(cache.pending[key]) == float(v.abs().max())
     ref = x.double().cpu() @ W.double().cpu().T
     assert float((y.double().cpu() - ref).abs().max() / ref.abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("K", [256, 320])
+def test_gemm_as_grouped_experts(K):
+    """The experts' gate|up projection: rows sorted by expert, one weight matrix per segment (an empty segment, one shorter than a
+    wave, boundaries that are no multiple of anything); K = 320 = the injecting layers' input width, which the kernel leaves to the tile kernel."""
+    T, N, E = 3000, 1024, 6
+    offs = torch.tensor([0, 700, 700, 717, 1500, 2100, T], dtype=torch.int32, device=DEV)
+    g = torch.Generator().manual_seed(K)
+    flat = (torch.randn(E * N * K + 8, generator=g) * 0.05).to(DEV)
+    W = flat[:E * N * K].view(E * N, K)
+    x = (torch.randn(T, K, generator=g) * torch.exp(torch.randn(T, 1, generator=g))).to(DEV)
+    cache = ops.amax_reuse()
+    cache.stable_range(flat.data_ptr(), flat.numel() * 4)
+    cache.planes = torch.zeros(flat.numel(), dtype=torch.float32, device=DEV)
+    out = {}
+    for as_on in (1, 0):
+        n0 = _as_launches()
+        with _env(GAMER_GEMM_AS=as_on, GAMER_GEMM_AS_MIN_M=1), ops.f32_matmul("split3"), cache:
+            for _ in range(2):
+                cache.reset()
+                y = torch.full((T, N), float("nan"), device=DEV)
+                ops.linear_fwd(x, K, W, K, y, N, T, N, K, strideB=N * K, groups=E, group_offsets=offs)
+        torch.cuda.synchronize()
+        assert (_as_launches() > n0) == bool(as_on and K <= 256)          # (K = 320 stays on the tile kernel)
+        out[as_on] = y
+    o = offs.cpu().tolist()
+    for e in range(E):
+        xe, we = x[o[e]:o[e + 1]].double().cpu(), W[e * N:(e + 1) * N].double().cpu()
+        ref, sc = xe @ we.T, xe.abs() @ we.abs().T
+        err = (out[1][o[e]:o[e + 1]].double().cpu() - ref).abs() / sc.clamp_min(1e-300)
+        if err.numel():
+            assert float(err.max()) < 1e-6, e
+    assert float((out[1] - out[0]).abs().max()) < 2e-6 * float(out[0].abs().max())
