@@ -1,0 +1,134 @@
+"""Output-stationary input gradient (csrc/gemm_os.hip): dX = dY W for nn.Linear layers with 256 input features (q|k|v projections, tied
+head: ref:SeqRec/models/generative/Qwen3Multi/model.py:93-99, 1001), three-product form.  It engages at >= 16 k rows in production;
+GAMER_GEMM_OS_MIN_M = 1 brings it down to test sizes.  Reference: fp64, at the bars of the tile kernel's tests (error relative to
+sum |dy_k| |w_k|), and the tile kernel on the same inputs; the library counts the launches."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gamer_amd import _lib, ops  # noqa: E402
+
+DEV = "cuda"
+
+
+class _env:
+    def __init__(self, **kw):
+        self.kw = {k: str(v) for k, v in kw.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _launches():
+    fn = _lib.load().gamer_debug_gemm_os_launches
+    fn.restype = ctypes.c_longlong
+    return int(fn())
+
+
+def _weights(N_out, H, scale=0.05, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    flat = (torch.randn(N_out * H + 8, generator=g) * scale).to(DEV)
+    cache = ops.amax_reuse()
+    cache.stable_range(flat.data_ptr(), flat.numel() * 4)
+    cache.planes = torch.zeros(flat.numel(), dtype=torch.float32, device=DEV)
+    return flat, flat[:N_out * H].view(N_out, H), cache
+
+
+def _dgrad(dy, ldy, W, cache, M, N_out, H, os_on, **kw):
+    with _env(GAMER_GEMM_OS=int(os_on), GAMER_GEMM_OS_MIN_M=1), ops.f32_matmul("split3"), cache:
+        for _ in range(2):                       # (the planes exist from the second pass of a cache on)
+            cache.reset()
+            dx = torch.full((M, H), float("nan"), device=DEV)
+            ops.linear_dgrad(dy, ldy, W, H, dx, H, M, N_out, H, **kw)
+        assert len(cache._plane_keys) > 0
+    torch.cuda.synchronize()
+    return dx
+
+
+def _err(dx, dy, W, N_out):
+    dyd, wd = dy[:, :N_out].double().cpu(), W.double().cpu()
+    e = (dx.double().cpu() - dyd @ wd).abs() / (dyd.abs() @ wd.abs()).clamp_min(1e-300)
+    return float(e.max()), float(e.pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize("M", [1000, 256, 33, 4099])
+@pytest.mark.parametrize("N_out,ldy", [(768, 768), (1041, 1056), (1024, 1024), (20, 32), (4, 4)])
+def test_gemm_os_against_fp64_and_the_tile_kernel(N_out, ldy, M):
+    """Contractions that are no multiple of the 32-wide block (1041 = 32 x 32 + 17, 20, 4) with a padded row stride whose padding
+    holds NaN (it must never be read into a product), ragged row counts (idle waves, idle lanes)."""
+    H = 256
+    flat, W, cache = _weights(N_out, H, seed=N_out)
+    g = torch.Generator().manual_seed(M + N_out)
+    dy = torch.full((M, ldy), float("nan"))
+    dy[:, :N_out] = torch.randn(M, N_out, generator=g) * torch.exp(torch.randn(M, N_out, generator=g)) * 1e-3
+    dy = dy.to(DEV)
+    n0 = _launches()
+    got = _dgrad(dy, ldy, W, cache, M, N_out, H, True)
+    assert _launches() > n0
+    n1 = _launches()
+    ref = _dgrad(dy, ldy, W, cache, M, N_out, H, False)
+    assert _launches() == n1
+    e_os, e_tile = _err(got, dy, W, N_out), _err(ref, dy, W, N_out)
+    assert torch.isfinite(got).all()
+    assert e_os[0] < 1e-6 and e_os[1] < 7e-8, (e_os, e_tile)          # (rms: 2^-24 = 6e-8 is the rounding of the fp32 result itself)
+    assert e_os[0] < 1.5 * e_tile[0] + 1e-8 and e_os[1] < 1.25 * e_tile[1]
+
+
+@pytest.mark.parametrize("guard", [1, 0])
+def test_gemm_os_rows_far_below_the_tensor_maximum(guard):
+    """The row-range guard: rows 2^-30 below the tensor's largest magnitude (a loss spike elsewhere in the batch) keep their relative
+    precision - the workgroup repeats its contraction with a scale per row; with the guard off (gamer_split3_guard(0)) they do not,
+    which is what tells that the guard is what did it."""
+    M, N_out, H = 1024, 768, 256
+    flat, W, cache = _weights(N_out, H, scale=0.3)
+    g = torch.Generator().manual_seed(7)
+    dy = torch.randn(M, N_out, generator=g)
+    dy[100:400] *= 2.0 ** -30
+    dy[700] = 0.0
+    dy = dy.to(DEV)
+    lib = _lib.load()
+    lib.gamer_split3_guard(guard)
+    try:
+        got = _dgrad(dy, N_out, W, cache, M, N_out, H, True)
+    finally:
+        lib.gamer_split3_guard(1)
+    dyd, wd = dy.double().cpu(), W.double().cpu()
+    e = (got.double().cpu() - dyd @ wd).abs() / (dyd.abs() @ wd.abs()).clamp_min(1e-300)
+    small = float(e[100:400].max())
+    assert float(e[:100].max()) < 1e-6 and float(e[400:].max()) < 1e-6
+    assert torch.equal(got[700].cpu(), torch.zeros(H))
+    if guard:
+        assert small < 1e-6
+    else:
+        assert small > 1e-5
+
+
+def test_gemm_os_integers_and_the_default_bar():
+    M, N_out, H = 512, 192, 256
+    flat = torch.zeros(N_out * H + 8, device=DEV)
+    wi = torch.randint(-30, 31, (N_out, H)).float()
+    flat[:N_out * H] = wi.flatten().to(DEV)
+    cache = ops.amax_reuse()
+    cache.stable_range(flat.data_ptr(), flat.numel() * 4)
+    cache.planes = torch.zeros(flat.numel(), dtype=torch.float32, device=DEV)
+    dyi = torch.randint(-30, 31, (M, N_out)).float()
+    got = _dgrad(dyi.to(DEV), N_out, flat[:N_out * H].view(N_out, H), cache, M, N_out, H, True)
+    assert torch.equal(got.cpu().double(), dyi.double() @ wi.double())
+    n0 = _launches()
+    with _env(GAMER_GEMM_OS=1), ops.f32_matmul("split3"), cache:          # production bar: 16 k rows
+        for _ in range(2):
+            cache.reset()
+            ops.linear_dgrad(dyi.to(DEV), N_out, flat[:N_out * H].view(N_out, H), H, torch.empty(M, H, device=DEV), H, M, N_out, H)
+    assert _launches() == n0
