@@ -278,6 +278,12 @@ int gamer_split3_guard(int on);
  * accumulated in fp32 by v_mfma_f32_32x32x16_f16: |x s - h0 - h1| <= 2^-22 |x s| for elements within 2^17 of the tensor's
  * largest (smaller ones: absolute 2^-25 of the scaled unit).  Against fp64 the result is at the six-product form's error
  * (rms 1.2e-8 of sum |a_k b_k|; fp32 MFMA 4.4e-8) at half its matrix instructions.  Needs d->amax_a / d->amax_b.
+ * Behind this entry point, chosen per descriptor (same layouts, same results contract; environment switches for A/B runs in
+ * brackets): the 128 x 128-tile kernel of csrc/gemm.hip; for a plain Linear forward with K <= 256, packed B pieces and >= 16 k rows
+ * the activation-stationary kernel of csrc/gemm_as.hip, which scales A per ROW (amax_a is not read; no guard needed)
+ * [GAMER_GEMM_AS=0]; for a plain input gradient with N = 256 the output-stationary kernel of csrc/gemm_os.hip, whose guard is a
+ * second pass with a scale per row [GAMER_GEMM_OS=0]; for a weight gradient (group_mode 1) with wgrad_ws whose C is whole
+ * 256 x 256 tiles the large-tile kernel of csrc/gemm_wg.hip, bit-identical to the 128 x 128 kernel [GAMER_GEMM_WG=0].
  *
  * gamer_absmax_f32: *out = max(*out, bits of max |x|) over `batch` matrices [rows, cols] with leading dimension ld
  * (ld % 4 == 0, 16-byte aligned), `stride` elements apart; *out must hold 0 (or an earlier maximum) on entry.  One pass over
