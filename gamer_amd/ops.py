@@ -710,7 +710,7 @@ def _rule_kchunk(dy, rows, N_out, K_in, groups):
 def _tune_kchunk(dy, lddy, x, ldx, dW, lddw, rows, N_out, K_in, groups, group_offsets, strideC):
     rule = _rule_kchunk(dy, rows, N_out, K_in, groups)
     if dy.dtype == torch.bfloat16:
-        cands = {rule, 512, 1024, 2048, 4096, 8192, 16384, 1056, 2080, 3104, 4128, 6176}      # (not only powers of two: see below)
+        cands = {rule, 512, 1024, 2048, 4096, 8192, 16384, 1088, 2112, 3136, 4160, 6208}      # (multiples of 64; not only powers of two: see below)
     else:
         cands = {rule, 384, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096}
         # ... and the chunks that make the grid a whole number of rounds of the chip's 512 workgroup slots (at per-GPU batch 128 a
