@@ -1583,10 +1583,11 @@ silu_gate_bwd_kernel(const TA* __restrict__ a, const TA* __restrict__ gate, cons
 // lm_head produces them; the statistics are fp32 either way, loss_utils.py upcasts)
 // ---------------------------------------------------------------------------------------------
 constexpr int CE_MAXC = 20;              // register-resident rows up to V = 1280 (the shipped vocabulary is 1041)
+constexpr int CE_MAXQ = 5;               // ... as 16-byte quads per lane (fp32 rows)
 template <typename TL>
 __global__ void __launch_bounds__(EW_THREADS)
 ce_fwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labels, int T, int S, int V,
-              float inv_temp, int ignore_index, float* __restrict__ lse_out, float* __restrict__ row_loss) {
+              float inv_temp, int ignore_index, float* __restrict__ lse_out, float* __restrict__ row_loss, int vec4) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * EW_THREADS) >> 6;
@@ -1597,6 +1598,57 @@ ce_fwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labe
         const bool valid = tgt != ignore_index && tgt >= 0 && tgt < V;
         float mx = -INFINITY;
         float zt = 0.f;
+        if constexpr (sizeof(TL) == 4) {
+            if (vec4 && V <= 256 * CE_MAXQ) {
+                // fp32 rows with 16-byte aligned starts: the row in registers as 16-byte quads (one wave instruction moves 1 KB
+                // instead of 256 bytes: 3.6 -> 5+ TB/s); the quad that straddles V is stored element by element - the padding
+                // columns of the row stay as they are
+                float4 z4[CE_MAXQ];
+#pragma unroll
+                for (int i = 0; i < CE_MAXQ; ++i) {
+                    const int c = 4 * (lane + 64 * i);
+                    float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                    if (c < V) {
+                        const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(row) + c);
+                        v.x = x.x * inv_temp;
+                        v.y = c + 1 < V ? x.y * inv_temp : -INFINITY;
+                        v.z = c + 2 < V ? x.z * inv_temp : -INFINITY;
+                        v.w = c + 3 < V ? x.w * inv_temp : -INFINITY;
+                    }
+                    z4[i] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < CE_MAXQ; ++i) {
+                    const int c = 4 * (lane + 64 * i);
+                    float* dst = reinterpret_cast<float*>(row) + c;
+                    if (c + 3 < V) {
+                        *reinterpret_cast<float4*>(dst) = z4[i];
+                    } else if (c < V) {
+                        dst[0] = z4[i].x;
+                        if (c + 1 < V) dst[1] = z4[i].y;
+                        if (c + 2 < V) dst[2] = z4[i].z;
+                    }
+                    mx = fmaxf(fmaxf(fmaxf(mx, z4[i].x), z4[i].y), fmaxf(z4[i].z, z4[i].w));
+                    if (valid && (int)tgt >= c && (int)tgt < c + 4) {
+                        const int e = (int)tgt - c;
+                        zt = e == 0 ? z4[i].x : (e == 1 ? z4[i].y : (e == 2 ? z4[i].z : z4[i].w));
+                    }
+                }
+                mx = wave_max(mx);
+                zt = wave_sum(zt);
+                float se = 0.f;
+#pragma unroll
+                for (int i = 0; i < CE_MAXQ; ++i)
+                    se += (expf(z4[i].x - mx) + expf(z4[i].y - mx)) + (expf(z4[i].z - mx) + expf(z4[i].w - mx));      // exp(-inf) = 0 past the row
+                se = wave_sum(se);
+                const float lse = mx + logf(se);
+                if (lane == 0) {
+                    lse_out[t] = lse;
+                    row_loss[t] = valid ? (lse - zt) : 0.f;
+                }
+                continue;
+            }
+        }
         if (V <= 64 * CE_MAXC) {
             // the whole row in registers: one read (all loads in flight together), one write, no second pass
             float z[CE_MAXC];
@@ -1697,7 +1749,8 @@ template <typename TL>
 __global__ void __launch_bounds__(EW_THREADS)
 ce_bwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labels, int T, int S, int V,
               int ignore_index, const float* __restrict__ lse, const float* __restrict__ count_dev,
-              float denom_host, float dloss_over_temp, const float* __restrict__ dloss_dev, uint32_t* __restrict__ amax_out) {
+              float denom_host, float dloss_over_temp, const float* __restrict__ dloss_dev, uint32_t* __restrict__ amax_out,
+              int vec4) {
     __shared__ uint32_t amax_lds[4];
     uint32_t am = 0;
     const int lane = threadIdx.x & 63;
@@ -1711,6 +1764,33 @@ ce_bwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labe
         const int64_t tgt = (s + 1 < S) ? labels[t + 1] : (int64_t)ignore_index;
         const bool valid = tgt != ignore_index && tgt >= 0 && tgt < V;
         const float l = lse[t];
+        if constexpr (sizeof(TL) == 4) {
+            if (vec4) {                          // fp32 rows, 16 bytes per lane (see ce_fwd_kernel)
+                float* rowf = reinterpret_cast<float*>(row);
+                for (int c = 4 * lane; c < V; c += 256) {
+                    float g[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (valid) {
+                        const float4 x = *reinterpret_cast<const float4*>(rowf + c);
+                        const float xe[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = c + e < V ? expf(xe[e] - l) : 0.f;
+                            if (c + e == (int)tgt) v -= 1.f;
+                            g[e] = c + e < V ? v * gs : 0.f;
+                        }
+                    }
+                    if (c + 3 < V) {
+                        *reinterpret_cast<float4*>(rowf + c) = make_float4(g[0], g[1], g[2], g[3]);
+                    } else {
+                        rowf[c] = g[0];
+                        if (c + 1 < V) rowf[c + 1] = g[1];
+                        if (c + 2 < V) rowf[c + 2] = g[2];
+                    }
+                    am = __float_as_uint(fmaxf(fmaxf(fmaxf(__uint_as_float(am), fabsf(g[0])), fabsf(g[1])), fmaxf(fabsf(g[2]), fabsf(g[3]))));
+                }
+                continue;
+            }
+        }
         for (int c = lane; c < V; c += 64) {
             float g = 0.f;
             if (valid) {
@@ -2268,8 +2348,9 @@ static int ce_fwd_impl(const char* name, TL* logits, int ldl, const int64_t* lab
     GAMER_CHECK_ARG(logits && labels && lse_out && row_loss && loss_sum && count, "%s: null pointer", name);
     GAMER_CHECK_ARG(B > 0 && S > 0 && V > 0 && ldl >= V && temperature > 0.f, "%s: bad shape B=%d S=%d V=%d ldl=%d", name, B, S, V, ldl);
     const int T = B * S;
+    const int vec4 = (sizeof(TL) == 4 && ldl % 4 == 0 && aligned16(logits)) ? 1 : 0;
     hipLaunchKernelGGL(ce_fwd_kernel<TL>, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), logits, ldl, labels, T,
-                       S, V, 1.f / temperature, ignore_index, lse_out, row_loss);
+                       S, V, 1.f / temperature, ignore_index, lse_out, row_loss, vec4);
     GAMER_CHECK_LAUNCH(name);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, ST(stream), row_loss, labels, T, S, V, ignore_index,
                        loss_sum, count);
@@ -2298,7 +2379,8 @@ static int ce_bwd_impl(const char* name, TL* logits, int ldl, const int64_t* lab
     GAMER_CHECK_ARG(count_dev || denom_host > 0.f, "%s: need count_dev or a positive denom_host", name);
     const int T = B * S;
     hipLaunchKernelGGL(ce_bwd_kernel<TL>, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), logits, ldl, labels, T,
-                       S, V, ignore_index, lse, count_dev, denom_host, dloss / temperature, dloss_dev, take_amax_sink().out[0]);
+                       S, V, ignore_index, lse, count_dev, denom_host, dloss / temperature, dloss_dev, take_amax_sink().out[0],
+                       (sizeof(TL) == 4 && ldl % 4 == 0 && aligned16(logits)) ? 1 : 0);
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }
