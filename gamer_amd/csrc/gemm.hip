@@ -1501,7 +1501,7 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
                                   aligned16(d->resid) && aligned16(d->C) && d->p_drop >= 0.f && d->p_drop < 1.f),
                     "gamer_gemm_f32: the fused residual epilogue needs a Linear-forward layout, ldc %% 4 == 0, no accumulate");
     // short-contraction Linear forward from packed weight pieces: the activation-stationary kernel (csrc/gemm_as.hip)
-    if (split == 3 && gemm_as_eligible(d, a_kc, b_kc, p.b_planes)) return launch_gemm_as(d, p.b_planes, (hipStream_t)stream);
+    if (split == 3 && gemm_as_eligible(d, a_kc, b_kc, p.b_planes)) return launch_gemm_as(d, p.b_planes, b_kc, (hipStream_t)stream);
     // plain input gradient with 256 input features: the output-stationary kernel (csrc/gemm_os.hip)
     if (split == 3 && gemm_os_eligible(d, a_kc, b_kc, p.b_planes)) return launch_gemm_os(d, p.b_planes, g_split3_guard, (hipStream_t)stream);
     p.n_tiles = (d->N + BN - 1) / BN;

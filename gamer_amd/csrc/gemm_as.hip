@@ -63,10 +63,17 @@ struct AsParams {
     // grouped form (the position-routed experts: rows sorted by expert, group g = rows group_offsets[g] .. group_offsets[g + 1] - 1
     // with its own weight matrix strideW elements further): a workgroup never crosses a segment boundary
     int groups; const int32_t* group_offsets; int64_t strideW;
+    // W row-contiguous (WRC: the input-gradient layout, W [K][N]): epilogues of csrc/gemm.hip that the layers with 256 OUTPUT features need
+    int accumulate;                            // C += (the cross block's gate)
+    const float* rowdot_other; float* rowdot_out; int rowdot_S;      // EPI 2: per (row, head of 64 columns) dot of C with `other` (o_proj)
+    float* sw_gu; int64_t sw_ld; float p_drop; uint64_t seed;        // EPI 4: SwiGLU backward in place of the store (down projection)
 };
 
-// KP = K / 64 panels
-template <int KP>
+// KP = K / 64 panels.  WRC = false: W [N][K] (k-contiguous, the Linear-forward layout): piece images [n][64 k] per panel, fragments by
+// 16-byte reads.  WRC = true: W [K][N] (the input-gradient layout of a layer with K <= 256 OUTPUT features: o_proj, the experts' down
+// projection, the cross block's gate): piece images [k][32 n], fragments by transposing reads (as gemm_os.hip).  EPI: 0 store (or
+// accumulate), 2 row-dot, 4 SwiGLU backward (the epilogues of csrc/gemm.hip, same definitions).
+template <int KP, bool WRC, int EPI>
 __global__ void __launch_bounds__(AS_THREADS, AS_DEPTH == 2 ? 1 : 8 / AS_WAVES)
 gemm_as_kernel(const AsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char as_raw[];
@@ -143,12 +150,21 @@ gemm_as_kernel(const AsParams p) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int f = tid + AS_THREADS * i;
-        const int nl = f / QPR, g = f % QPR;
-        nl_[i] = nl;
-        lds_off[i] = (g >> 4) * AS_PANEL + as_off(nl, (4 * g) & 63);
-        wsrc[i] = reinterpret_cast<const uint4*>(p.Wp) + (((int64_t)grp * p.strideW + (int64_t)nl * p.ldw + 4 * g) >> 2);
+        if (!WRC) {
+            const int nl = f / QPR, g = f % QPR;
+            nl_[i] = nl;
+            lds_off[i] = (g >> 4) * AS_PANEL + as_off(nl, (4 * g) & 63);
+            wsrc[i] = reinterpret_cast<const uint4*>(p.Wp) + (((int64_t)grp * p.strideW + (int64_t)nl * p.ldw + 4 * g) >> 2);
+        } else {
+            // item f: k row f / (AS_SLAB / 4), quad f % (AS_SLAB / 4) of the slab's columns; image [k][AS_SLAB n] (rows of 2 AS_SLAB bytes:
+            // a half wave's transposing read covers four whole rows = 256 bytes = every bank once)
+            const int k = f / (AS_SLAB / 4), nq = f % (AS_SLAB / 4);
+            nl_[i] = 4 * nq;
+            lds_off[i] = k * AS_SLAB + 4 * nq;                             // (16-bit elements)
+            wsrc[i] = reinterpret_cast<const uint4*>(p.Wp) + (((int64_t)grp * p.strideW + (int64_t)k * p.ldw + 4 * nq) >> 2);
+        }
     }
-    const int64_t slab_stride = ((int64_t)AS_SLAB * p.ldw) >> 2;         // uint4 between slabs
+    const int64_t slab_stride = WRC ? (AS_SLAB >> 2) : (((int64_t)AS_SLAB * p.ldw) >> 2);         // uint4 between slabs
     auto load_slab_into = [&](int j, uint4 (&dst)[NLD]) {
         const bool full = (j + 1) * AS_SLAB <= p.N;
 #pragma unroll
@@ -173,6 +189,19 @@ gemm_as_kernel(const AsParams p) {
     int row_off[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) row_off[s] = as_off(r, 16 * s + 8 * h);
+    // WRC: lane 16 g + 4 q + pp supplies the address of (k row q of a 4-block, columns 4 pp .. 4 pp + 3) of its group's 4 x 16 block
+    const int tr_lane = (8 * h + ((lane >> 2) & 3)) * AS_SLAB + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);      // (16-bit elements)
+    auto read_tr = [&](const bf16_t* base) -> bf16x8 {
+        bf16x8 out;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(base + c * 4 * AS_SLAB));
+            out[4 * c + 0] = v[0]; out[4 * c + 1] = v[1]; out[4 * c + 2] = v[2]; out[4 * c + 3] = v[3];
+        }
+        return out;
+    };
+    float hd_dot = 0.f;                                                   // EPI 2: the head's dot over the slabs seen so far
+    float emax = 0.f;                                                     // EPI 4: max |d gate|, |d up| stored
 
     float cmax = 0.f;
     float* crow = p.C + (int64_t)m * p.ldc;
@@ -188,8 +217,14 @@ gemm_as_kernel(const AsParams p) {
                 const int pn = ks >> 2, s = ks & 3;
 #pragma unroll
                 for (int nt = 0; nt < AS_NT; ++nt) {
-                    const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(img + pn * AS_PANEL + nt * 32 * 64 + row_off[s]);
-                    const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(img + (KP + pn) * AS_PANEL + nt * 32 * 64 + row_off[s]);
+                    bf16x8 w0, w1;
+                    if (!WRC) {
+                        w0 = *reinterpret_cast<const bf16x8*>(img + pn * AS_PANEL + nt * 32 * 64 + row_off[s]);
+                        w1 = *reinterpret_cast<const bf16x8*>(img + (KP + pn) * AS_PANEL + nt * 32 * 64 + row_off[s]);
+                    } else {
+                        w0 = read_tr(img + ks * 16 * AS_SLAB + nt * 32 + tr_lane);
+                        w1 = read_tr(img + KP * AS_PANEL + ks * 16 * AS_SLAB + nt * 32 + tr_lane);
+                    }
                     // smallest piece products first
                     if (AS_ABLATE & 2) { asm volatile("" :: "v"(w0), "v"(w1)); continue; }
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w1), __builtin_bit_cast(f16x8, af[0][ks]), acc[nt], 0, 0, 0);
@@ -198,6 +233,7 @@ gemm_as_kernel(const AsParams p) {
                 }
             }
             // epilogue: lane = output row m, acc[nt][reg] = column slab + 32 nt + (reg & 3) + 8 (reg >> 2) + 4 h
+            float part = 0.f;                                             // EPI 2: this lane's share of the slab's row-dot
             if (valid_m) {
                 const bool track = p.amax_c != nullptr && j * AS_SLAB >= p.amax_c_col0;
 #pragma unroll
@@ -206,18 +242,54 @@ gemm_as_kernel(const AsParams p) {
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int col = j * AS_SLAB + nt * 32 + 8 * g4 + 4 * h;
                         if (col < p.N) {
-                            const float4 t4 = make_float4(acc[nt][4 * g4] * out_scale, acc[nt][4 * g4 + 1] * out_scale,
-                                                          acc[nt][4 * g4 + 2] * out_scale, acc[nt][4 * g4 + 3] * out_scale);
-                            if (AS_ABLATE & 1) { asm volatile("" :: "v"(t4.x), "v"(t4.y), "v"(t4.z), "v"(t4.w)); }
-                            else if (col + 4 <= p.N) {
+                            float4 t4 = make_float4(acc[nt][4 * g4] * out_scale, acc[nt][4 * g4 + 1] * out_scale,
+                                                    acc[nt][4 * g4 + 2] * out_scale, acc[nt][4 * g4 + 3] * out_scale);
+                            if (AS_ABLATE & 1) { asm volatile("" :: "v"(t4.x), "v"(t4.y), "v"(t4.z), "v"(t4.w)); continue; }
+                            if (EPI == 4) {
+                                // C = d(hm) is not stored: with mult = the dropout multiplier of flat element m N + col, the gate | up values
+                                // a, b stored at sw_gu[m][col], sw_gu[m][N + col] become mult C b silu'(a), mult C silu(a)  (gemm.hip, EPI == 4)
+                                float* ga = p.sw_gu + (int64_t)m * p.sw_ld + col;
+                                const float4 a4 = *reinterpret_cast<const float4*>(ga), b4 = *reinterpret_cast<const float4*>(ga + p.N);
+                                const DropoutRng rng(p.p_drop, p.seed);
+                                float mu[4];
+                                rng.mult4((uint32_t)(((int64_t)m * p.N + col) >> 2), mu);
+                                const float d0 = mu[0] * t4.x, d1 = mu[1] * t4.y, d2 = mu[2] * t4.z, d3 = mu[3] * t4.w;
+                                const float4 dg = make_float4(d0 * b4.x * dsilu_f(a4.x), d1 * b4.y * dsilu_f(a4.y), d2 * b4.z * dsilu_f(a4.z),
+                                                              d3 * b4.w * dsilu_f(a4.w));
+                                const float4 du = make_float4(d0 * silu_f(a4.x), d1 * silu_f(a4.y), d2 * silu_f(a4.z), d3 * silu_f(a4.w));
+                                *reinterpret_cast<float4*>(ga) = dg;
+                                *reinterpret_cast<float4*>(ga + p.N) = du;
+                                emax = fmaxf(fmaxf(fmaxf(emax, fmaxf(fabsf(dg.x), fabsf(du.x))), fmaxf(fabsf(dg.y), fabsf(du.y))),
+                                             fmaxf(fmaxf(fabsf(dg.z), fabsf(du.z)), fmaxf(fabsf(dg.w), fabsf(du.w))));
+                                continue;
+                            }
+                            if (p.accumulate) {                           // (N % 4 == 0 with accumulate: checked by the launcher)
+                                const float4 o = *reinterpret_cast<const float4*>(crow + col);
+                                t4.x += o.x; t4.y += o.y; t4.z += o.z; t4.w += o.w;
+                            }
+                            if (col + 4 <= p.N) {
                                 *reinterpret_cast<float4*>(crow + col) = t4;
                             } else {                                              // (columns from N on belong to the caller)
                                 const float e[4] = {t4.x, t4.y, t4.z, t4.w};
                                 for (int q = 0; q < 4 && col + q < p.N; ++q) crow[col + q] = e[q];
                             }
+                            if (EPI == 2) {
+                                const float4 o4 = *reinterpret_cast<const float4*>(p.rowdot_other + (int64_t)m * p.ldc + col);
+                                part += (t4.x * o4.x + t4.y * o4.y) + (t4.z * o4.z + t4.w * o4.w);
+                            }
                             if (track) cmax = fmaxf(fmaxf(fmaxf(cmax, fabsf(t4.x)), fabsf(t4.y)), fmaxf(fabsf(t4.z), fabsf(t4.w)));
                         }
                     }
+            }
+            if (EPI == 2) {
+                // a head = 64 columns = 64 / AS_SLAB slabs: the lane pair (m, h = 0 / 1) holds the slab's two halves
+                const float sl = xor32_sum(part);
+                constexpr int SPH = 64 / AS_SLAB;                          // slabs per head
+                hd_dot = (j % SPH == 0) ? sl : hd_dot + sl;
+                if (j % SPH == SPH - 1 && valid_m && h == 0) {
+                    const int heads = p.N >> 6, head = (j * AS_SLAB) >> 6;
+                    p.rowdot_out[((int64_t)(m / p.rowdot_S) * heads + head) * p.rowdot_S + m % p.rowdot_S] = hd_dot;
+                }
             }
     };
     if (AS_DEPTH == 1) {
@@ -256,7 +328,7 @@ gemm_as_kernel(const AsParams p) {
         }
     }
     if (p.amax_c) {
-        uint32_t mw = __float_as_uint(cmax);
+        uint32_t mw = __float_as_uint(EPI == 4 ? emax : cmax);
 #pragma unroll
         for (int o2 = 32; o2 > 0; o2 >>= 1) mw = max(mw, (uint32_t)__shfl_xor((int)mw, o2, 64));
         if (lane == 0 && mw) atomicMax(&amax_word, mw);
@@ -272,53 +344,84 @@ static inline bool gemm_as_enabled() {
     return e ? atoi(e) != 0 : true;
 }
 
-// Does this descriptor take the activation-stationary kernel?  (plain Linear forward, one group, packed weight pieces, K a multiple
-// of 64 up to 256, enough rows to fill the chip)
+// Does this descriptor take the activation-stationary kernel?  A k-contiguous with K a multiple of 64 up to 256, packed weight pieces,
+// enough rows to fill the chip; W k-contiguous (Linear forward): plain store, one group or the experts' row segments; W row-contiguous
+// (input gradient of a layer with 256 output features): K = 256, store / accumulate, row-dot or SwiGLU-backward epilogue.
 bool gemm_as_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint16_t* b_planes) {
-    if (!gemm_as_enabled() || !a_kc || !b_kc || !b_planes || !d->amax_b) return false;
-    if (d->group_mode != 0 || d->accumulate || d->resid || d->rowdot_out || d->qk_q_rot || d->sw_gu) return false;
-    // (grouped: the experts' gate|up projection at d_in = 256: 1.37 -> 1.30 ms, W is 1 MB per 128 rows there; the injecting layers'
-    // d_in = 320 would need 160 piece registers = one workgroup per CU: measured 1.62 -> 2.4 ms, stays on the tile kernel)
-    if (d->groups != 1 && (!d->group_offsets || d->strideC != 0 || d->amax_c)) return false;
-    // (a workgroup takes 256 rows: below ~16 k rows the launch leaves most CUs idle and the tile kernel is the better fit;
+    if (!gemm_as_enabled() || !a_kc || !b_planes || !d->amax_b) return false;
+    if (d->group_mode != 0 || d->resid || d->qk_q_rot) return false;
+    // (a workgroup takes 128 rows: below ~16 k rows the launch leaves most CUs idle and the tile kernel is the better fit;
     // GAMER_GEMM_AS_MIN_M lowers the bar for tests)
     const char* mm = getenv("GAMER_GEMM_AS_MIN_M");
     if (d->K % 64 != 0 || d->K < 64 || d->K > 256 || d->M < (mm ? atoi(mm) : 16384)) return false;
-    if (d->a_rs % 4 != 0 || d->b_rs % 4 != 0 || d->ldc % 4 != 0 || !aligned16(d->C) || !aligned16(b_planes)) return false;
-    if (d->amax_c && d->amax_c_col0 % AS_SLAB != 0) return false;
+    if (d->a_rs % 4 != 0 || d->ldc % 4 != 0 || !aligned16(d->C) || !aligned16(b_planes)) return false;
+    if (d->groups != 1 && (!d->group_offsets || d->strideC != 0)) return false;
     static_assert((AS_SLAB * 16) % AS_THREADS == 0 || AS_THREADS % (AS_SLAB * 16) == 0, "slab groups per thread");
-    return true;
+    if (b_kc) {
+        if (d->accumulate || d->rowdot_out || d->sw_gu || d->b_rs % 4 != 0) return false;
+        // (grouped: the experts' gate|up projection at d_in = 256: 1.37 -> 1.30 ms, W is 1 MB per 128 rows there; the injecting layers'
+        // d_in = 320 would need 160 piece registers = one workgroup per CU: measured 1.62 -> 2.4 ms, stays on the tile kernel)
+        if (d->groups != 1 && d->amax_c) return false;
+        if (d->amax_c && d->amax_c_col0 % AS_SLAB != 0) return false;
+        return true;
+    }
+    // W row-contiguous.  Measured in the step (same box): the plain / accumulating form (the cross block's gate) 0.22 ms per launch
+    // faster than the tile kernel; the row-dot and SwiGLU-backward epilogues SLOWER (o_proj 0.59 -> 0.66 ms, down projection 1.30 ->
+    // 1.45): their inputs are requested in the epilogue of every 32-column slab and waited for there, and requesting them before the
+    // slab's MFMAs spills (256 registers: 1.30 -> 2.2 ms).  They stay on the tile kernel unless GAMER_GEMM_AS_RC=2 (tests).
+    const char* rc = getenv("GAMER_GEMM_AS_RC");
+    const int rc_mode = rc ? atoi(rc) : 1;
+    if (rc_mode == 0) return false;
+    if (d->K != 256 || d->N % 4 != 0 || d->b_ks % 4 != 0) return false;
+    if ((d->sw_gu || d->rowdot_out) && rc_mode < 2) return false;
+    if (d->sw_gu) {                                    // (gemm.hip checked: alpha = 1, N % 4 == 0, sw_ld >= 2 N, alignment, no other epilogue)
+        return !d->amax_c || d->amax_c_col0 == 0;
+    }
+    if (d->groups != 1) return false;
+    if (d->rowdot_out) return !d->accumulate && d->N % 64 == 0 && 64 % AS_SLAB == 0 && (!d->amax_c || d->amax_c_col0 % AS_SLAB == 0);
+    return !d->amax_c || (!d->accumulate && d->amax_c_col0 % AS_SLAB == 0);
 }
 
-int launch_gemm_as(const gamer_gemm_desc* d, const uint16_t* b_planes, hipStream_t st) {
+int launch_gemm_as(const gamer_gemm_desc* d, const uint16_t* b_planes, bool b_kc, hipStream_t st) {
     AsParams p;
     p.A = d->A; p.lda = d->a_rs;
-    p.Wp = b_planes; p.ldw = d->b_rs;
+    p.Wp = b_planes; p.ldw = b_kc ? d->b_rs : d->b_ks;
     p.C = d->C; p.ldc = d->ldc;
     p.M = d->M; p.N = d->N; p.K = d->K;
     p.alpha = d->alpha;
     p.amax_w = d->amax_b;
     p.amax_c = d->amax_c; p.amax_c_col0 = d->amax_c_col0;
     p.groups = d->groups; p.group_offsets = d->groups > 1 ? d->group_offsets : nullptr; p.strideW = d->strideB;
+    p.accumulate = d->accumulate;
+    p.rowdot_other = d->rowdot_other; p.rowdot_out = d->rowdot_out; p.rowdot_S = d->rowdot_S;
+    p.sw_gu = d->sw_gu; p.sw_ld = d->sw_ld; p.p_drop = d->p_drop; p.seed = d->seed;
     const int kp = d->K / 64;
     const size_t shmem = (size_t)(AS_DEPTH == 2 ? 3 : 2) * 2 * kp * AS_PANEL * sizeof(bf16_t);
     const dim3 grid((d->M + 32 * AS_WAVES - 1) / (32 * AS_WAVES) + (p.group_offsets ? d->groups : 0));
-#define GAMER_LAUNCH_AS(KPV)                                                                                                  \
+#define GAMER_LAUNCH_AS(KPV, WRCV, EPIV)                                                                                      \
     do {                                                                                                                      \
         static bool attr_dev[MAX_DEVICES] = {};                                                                               \
         if (!attr_dev[current_device()]) {                                                                                    \
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_as_kernel<KPV>),                      \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_as_kernel<KPV, WRCV, EPIV>),          \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                 \
             if (e != hipSuccess) { set_error("gamer_gemm_f32_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; } \
             attr_dev[current_device()] = true;                                                                                \
         }                                                                                                                     \
-        hipLaunchKernelGGL(gemm_as_kernel<KPV>, grid, dim3(AS_THREADS), shmem, st, p);                                        \
+        hipLaunchKernelGGL((gemm_as_kernel<KPV, WRCV, EPIV>), grid, dim3(AS_THREADS), shmem, st, p);                          \
     } while (0)
-    switch (kp) {
-        case 1: GAMER_LAUNCH_AS(1); break;
-        case 2: GAMER_LAUNCH_AS(2); break;
-        case 3: GAMER_LAUNCH_AS(3); break;
-        default: GAMER_LAUNCH_AS(4); break;
+    if (b_kc) {
+        switch (kp) {
+            case 1: GAMER_LAUNCH_AS(1, false, 0); break;
+            case 2: GAMER_LAUNCH_AS(2, false, 0); break;
+            case 3: GAMER_LAUNCH_AS(3, false, 0); break;
+            default: GAMER_LAUNCH_AS(4, false, 0); break;
+        }
+    } else if (d->sw_gu) {
+        GAMER_LAUNCH_AS(4, true, 4);
+    } else if (d->rowdot_out) {
+        GAMER_LAUNCH_AS(4, true, 2);
+    } else {
+        GAMER_LAUNCH_AS(4, true, 0);
     }
 #undef GAMER_LAUNCH_AS
     GAMER_CHECK_LAUNCH("gamer_gemm_f32_split/activation-stationary");

@@ -208,3 +208,114 @@ def test_gemm_as_grouped_experts(K):
         if err.numel():
             assert float(err.max()) < 1e-6, e
     assert float((out[1] - out[0]).abs().max()) < 2e-6 * float(out[0].abs().max())
+
+
+# ---- W row-contiguous: input gradients of the layers with 256 output features (o_proj, the cross block's gate, the experts' down projection)
+def _param_cache(flat):
+    cache = ops.amax_reuse(everything=True)
+    cache.stable_range(flat.data_ptr(), flat.numel() * 4)
+    cache.planes = torch.zeros(flat.numel(), dtype=torch.float32, device=DEV)
+    return cache
+
+
+def _both(cache, fn):
+    """fn() under the tile kernel and under the activation-stationary one (second pass of the cache: planes exist); returns their outputs
+    and checks by the launch counter that the second really ran it."""
+    outs = {}
+    for as_on in (0, 1):
+        n0 = _as_launches()
+        with _env(GAMER_GEMM_AS=as_on, GAMER_GEMM_AS_MIN_M=1, GAMER_GEMM_AS_RC=2, GAMER_GEMM_OS=0), ops.f32_matmul("split3"), cache:
+            for _ in range(2):
+                cache.reset()
+                outs[as_on] = fn()
+            assert len(cache._plane_keys) > 0
+        torch.cuda.synchronize()
+        assert (_as_launches() > n0) == bool(as_on)
+    return outs[0], outs[1]
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("M,N", [(1000, 384), (517, 512), (33, 100), (4099, 256)])
+def test_gemm_as_input_gradient_layout(M, N, accumulate):
+    K = 256
+    g = torch.Generator().manual_seed(M + N)
+    flat = (torch.randn(K * N + 8, generator=g) * 0.05).to(DEV)
+    W = flat[:K * N].view(K, N)
+    dy = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g)) * 1e-3).to(DEV)
+    base = torch.randn(M, N, generator=g).to(DEV) * 1e-3
+
+    def run():
+        dx = base.clone() if accumulate else torch.full((M, N), float("nan"), device=DEV)
+        ops.linear_dgrad(dy, K, W, N, dx, N, M, K, N, accumulate=accumulate)
+        return dx
+    tile, got = _both(_param_cache(flat), run)
+    ref = dy.double().cpu() @ W.double().cpu() + (base.double().cpu() if accumulate else 0)
+    sc = dy.double().cpu().abs() @ W.double().cpu().abs() + (base.double().cpu().abs() if accumulate else 0)
+    e = (got.double().cpu() - ref).abs() / sc.clamp_min(1e-300)
+    assert float(e.max()) < 1e-6 and float(e.pow(2).mean().sqrt()) < 7e-8
+    assert float((got - tile).abs().max()) <= 2e-6 * float(tile.abs().max())
+
+
+def test_gemm_as_row_dot_epilogue():
+    """o_proj input gradient: C as without the epilogue and out[b][head][i] = C[m, head] . other[m, head] (the attention backward's delta)."""
+    B, S, heads, K = 20, 64, 6, 256
+    M, N = B * S, heads * 64
+    g = torch.Generator().manual_seed(3)
+    flat = (torch.randn(K * N + 8, generator=g) * 0.05).to(DEV)
+    W = flat[:K * N].view(K, N)
+    dy, other = (torch.randn(M, K, generator=g) * 1e-2).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+
+    def run():
+        dx = torch.full((M, N), float("nan"), device=DEV)
+        out = torch.full((B, heads, S), float("nan"), device=DEV)
+        ops.linear_dgrad(dy, K, W, N, dx, N, M, K, N, rowdot=(other, out, S), c_amax=(dx, 0))
+        return dx, out
+    (dx0, out0), (dx1, out1) = _both(_param_cache(flat), run)
+    ref = dy.double().cpu() @ W.double().cpu()
+    assert float((dx1.double().cpu() - ref).abs().max()) < 2e-6 * float(ref.abs().max())
+    want = (ref.view(B, S, heads, 64) * other.double().cpu().view(B, S, heads, 64)).sum(-1).permute(0, 2, 1)
+    assert float((out1.double().cpu() - want).abs().max()) < 5e-6 * float(want.abs().max())
+    assert float((out1 - out0).abs().max()) < 5e-6 * float(out0.abs().max())
+    assert float((dx1 - dx0).abs().max()) <= 2e-6 * float(dx0.abs().max())
+
+
+@pytest.mark.parametrize("T,offsets", [(1024, None), (700, [0, 0, 130, 131, 389, 389, 700]), (37, None), (900, [64, 64, 200, 333, 600, 600, 850])])
+def test_gemm_as_swiglu_backward_epilogue(T, offsets):
+    """The experts' down-projection input gradient with the SwiGLU backward in its epilogue (d(hm) never stored), plain and grouped
+    (ragged segments, empty experts, rows outside every segment), dropout on: the same d gate | d up as the tile kernel's epilogue (same
+    dropout mask function, same formula) and the same maximum in the slot."""
+    from test_ops_gpu import _slot_value
+    H, I, p_drop, seed = 256, 512, 0.2, 13
+    E = 6 if offsets is not None else 1
+    g = torch.Generator().manual_seed(T)
+    flat = (torch.randn(E * H * I + 8, generator=g) * 0.05).to(DEV)
+    Wd = flat[:E * H * I].view(E * H, I)
+    t0 = (torch.randn(T, H, generator=g) * 0.1).to(DEV)
+    gu0 = torch.randn(T, 2 * I, generator=g)
+    grp = {}
+    if offsets is not None:
+        grp = dict(groups=E, group_offsets=torch.tensor(offsets, dtype=torch.int32, device=DEV), strideB=H * I)
+    cache = _param_cache(flat)
+    slots = {}
+
+    def run():
+        got = gu0.to(DEV)
+        dummy = torch.full((T, I), 5.0, device=DEV)
+        ops.gemm(t0, H, 1, Wd, 1, I, dummy, I, T, I, H, p_drop=p_drop, seed=seed, swiglu_bwd=(got, 2 * I), **grp)
+        key = cache._key(got.data_ptr(), (1, 0, 1, T * 2 * I, T * 2 * I))
+        assert key in cache.pending
+        torch.cuda.synchronize()
+        slots[len(slots)] = (_slot_value(cache.pending[key]), float(got.abs().max()))
+        assert bool((dummy == 5.0).all()), "C must not be written"
+        return got
+    tile, got = _both(cache, run)
+    scale = float(tile.abs().max())
+    assert float((got - tile).abs().max()) <= 2e-6 * scale, float((got - tile).abs().max()) / scale
+    for k_, (slot, mx) in slots.items():
+        if offsets is None or offsets[0] == 0 and offsets[-1] == T:
+            assert slot == mx, k_
+        else:
+            assert slot <= mx            # (rows outside every segment keep their values and are not part of the maximum)
+    if offsets is not None and offsets[0] > 0:
+        assert torch.equal(got[:offsets[0]].cpu(), gu0[:offsets[0]])
+        assert torch.equal(got[offsets[-1]:].cpu(), gu0[offsets[-1]:])
