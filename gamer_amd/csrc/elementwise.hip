@@ -1621,7 +1621,9 @@ ce_fwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labe
                 for (int i = 0; i < CE_MAXQ; ++i) {
                     const int c = 4 * (lane + 64 * i);
                     float* dst = reinterpret_cast<float*>(row) + c;
-                    if (c + 3 < V) {
+                    if (inv_temp == 1.f) {
+                        // the producer already divided by the temperature (the head GEMM's alpha): nothing to write back
+                    } else if (c + 3 < V) {
                         *reinterpret_cast<float4*>(dst) = z4[i];
                     } else if (c < V) {
                         dst[0] = z4[i].x;

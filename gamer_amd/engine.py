@@ -797,11 +797,14 @@ class Engine:
         ops.rmsnorm_fwd(ws.x_final, self.params["model.norm.weight"], eps, ws.xn)
         if hidden_sink is not None:
             hidden_sink.append(ws.xn.view(B, S, H).clone())
-        ops.linear_fwd(ws.xn, H, emb_m, H, ws.logits, ws.ldl, T, V, H)
+        # with labels the logits leave the head GEMM already divided by the temperature (its alpha; model.py:913 divides them in place):
+        # the loss kernel then only reads them (fp32 engine; the bf16 head rounds to bf16 first, as the reference's autocast does)
+        head_alpha = (1.0 / self.temperature) if (lab is not None and ws.logits.dtype == torch.float32) else 1.0
+        ops.linear_fwd(ws.xn, H, emb_m, H, ws.logits, ws.ldl, T, V, H, alpha=head_alpha)
         loss = None
         if lab is not None:
-            ops.ce_fwd(ws.logits, ws.ldl, lab, V, self.temperature, IGNORE_INDEX, ws.lse_ce, ws.row_loss, ws.loss_sum,
-                       ws.count)
+            ops.ce_fwd(ws.logits, ws.ldl, lab, V, 1.0 if head_alpha != 1.0 else self.temperature, IGNORE_INDEX, ws.lse_ce,
+                       ws.row_loss, ws.loss_sum, ws.count)
             if torch.is_tensor(num_items_in_batch):
                 # a device scalar (the label count of the window summed over ranks): never read on the host
                 num_items_in_batch = num_items_in_batch.to(self.device, torch.float32).reshape(1)
