@@ -1583,7 +1583,24 @@ silu_gate_bwd_kernel(const TA* __restrict__ a, const TA* __restrict__ gate, cons
 // lm_head produces them; the statistics are fp32 either way, loss_utils.py upcasts)
 // ---------------------------------------------------------------------------------------------
 constexpr int CE_MAXC = 20;              // register-resident rows up to V = 1280 (the shipped vocabulary is 1041)
-constexpr int CE_MAXQ = 5;               // ... as 16-byte quads per lane (fp32 rows)
+constexpr int CE_MAXQ = 5;               // ... as 16-byte groups per lane (five cover 1280 fp32 / 2560 bf16 values)
+template <typename T> constexpr int CE_EPL = 16 / (int)sizeof(T);      // elements per 16 bytes
+__device__ __forceinline__ void ce_load16(const float* p, float (&x)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+}
+__device__ __forceinline__ void ce_store16(float* p, const float (&x)[4]) { *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]); }
+__device__ __forceinline__ void ce_load16(const bf16_t* p, float (&x)[8]) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
+}
+__device__ __forceinline__ void ce_store16(bf16_t* p, const float (&x)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)x[e];
+    *reinterpret_cast<bf16x8*>(p) = v;
+}
 template <typename TL>
 __global__ void __launch_bounds__(EW_THREADS)
 ce_fwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labels, int T, int S, int V,
@@ -1598,58 +1615,57 @@ ce_fwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labe
         const bool valid = tgt != ignore_index && tgt >= 0 && tgt < V;
         float mx = -INFINITY;
         float zt = 0.f;
-        if constexpr (sizeof(TL) == 4) {
-            if (vec4 && V <= 256 * CE_MAXQ) {
-                // fp32 rows with 16-byte aligned starts: the row in registers as 16-byte quads (one wave instruction moves 1 KB
-                // instead of 256 bytes: 3.6 -> 5+ TB/s); the quad that straddles V is stored element by element - the padding
-                // columns of the row stay as they are
-                float4 z4[CE_MAXQ];
+        if (vec4 && V <= 64 * CE_EPL<TL> * CE_MAXQ) {
+            // rows with 16-byte aligned starts: the row in registers as 16-byte groups per lane (four fp32 / eight bf16 values; one wave
+            // instruction moves 1 KB instead of 256 / 128 bytes: fp32 3.6 -> 5 TB/s, bf16 2.2 -> ...); the group that straddles V is
+            // stored element by element - the padding columns of the row stay as they are
+            constexpr int EPL = CE_EPL<TL>;
+            float z[CE_MAXQ][EPL];
 #pragma unroll
-                for (int i = 0; i < CE_MAXQ; ++i) {
-                    const int c = 4 * (lane + 64 * i);
-                    float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-                    if (c < V) {
-                        const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(row) + c);
-                        v.x = x.x * inv_temp;
-                        v.y = c + 1 < V ? x.y * inv_temp : -INFINITY;
-                        v.z = c + 2 < V ? x.z * inv_temp : -INFINITY;
-                        v.w = c + 3 < V ? x.w * inv_temp : -INFINITY;
-                    }
-                    z4[i] = v;
-                }
+            for (int i = 0; i < CE_MAXQ; ++i) {
+                const int c = EPL * (lane + 64 * i);
+                if (c < V) {
+                    float x[EPL];
+                    ce_load16(row + c, x);
 #pragma unroll
-                for (int i = 0; i < CE_MAXQ; ++i) {
-                    const int c = 4 * (lane + 64 * i);
-                    float* dst = reinterpret_cast<float*>(row) + c;
-                    if (inv_temp == 1.f) {
-                        // the producer already divided by the temperature (the head GEMM's alpha): nothing to write back
-                    } else if (c + 3 < V) {
-                        *reinterpret_cast<float4*>(dst) = z4[i];
-                    } else if (c < V) {
-                        dst[0] = z4[i].x;
-                        if (c + 1 < V) dst[1] = z4[i].y;
-                        if (c + 2 < V) dst[2] = z4[i].z;
-                    }
-                    mx = fmaxf(fmaxf(fmaxf(mx, z4[i].x), z4[i].y), fmaxf(z4[i].z, z4[i].w));
-                    if (valid && (int)tgt >= c && (int)tgt < c + 4) {
-                        const int e = (int)tgt - c;
-                        zt = e == 0 ? z4[i].x : (e == 1 ? z4[i].y : (e == 2 ? z4[i].z : z4[i].w));
-                    }
-                }
-                mx = wave_max(mx);
-                zt = wave_sum(zt);
-                float se = 0.f;
+                    for (int e = 0; e < EPL; ++e) z[i][e] = c + e < V ? round_as<TL>(x[e] * inv_temp) : -INFINITY;
+                } else {
 #pragma unroll
-                for (int i = 0; i < CE_MAXQ; ++i)
-                    se += (expf(z4[i].x - mx) + expf(z4[i].y - mx)) + (expf(z4[i].z - mx) + expf(z4[i].w - mx));      // exp(-inf) = 0 past the row
-                se = wave_sum(se);
-                const float lse = mx + logf(se);
-                if (lane == 0) {
-                    lse_out[t] = lse;
-                    row_loss[t] = valid ? (lse - zt) : 0.f;
+                    for (int e = 0; e < EPL; ++e) z[i][e] = -INFINITY;
                 }
-                continue;
             }
+#pragma unroll
+            for (int i = 0; i < CE_MAXQ; ++i) {
+                const int c = EPL * (lane + 64 * i);
+                if (inv_temp == 1.f) {
+                    // the producer already divided by the temperature (the head GEMM's alpha): nothing to write back
+                } else if (c + EPL <= V) {
+                    ce_store16(row + c, z[i]);
+                } else if (c < V) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e)
+                        if (c + e < V) st1(row + c + e, z[i][e]);
+                }
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    mx = fmaxf(mx, z[i][e]);
+                    if (valid && c + e == (int)tgt) zt = z[i][e];
+                }
+            }
+            mx = wave_max(mx);
+            zt = wave_sum(zt);
+            float se = 0.f;
+#pragma unroll
+            for (int i = 0; i < CE_MAXQ; ++i)
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) se += expf(z[i][e] - mx);           // exp(-inf) = 0 past the row
+            se = wave_sum(se);
+            const float lse = mx + logf(se);
+            if (lane == 0) {
+                lse_out[t] = lse;
+                row_loss[t] = valid ? (lse - zt) : 0.f;
+            }
+            continue;
         }
         if (V <= 64 * CE_MAXC) {
             // the whole row in registers: one read (all loads in flight together), one write, no second pass
@@ -1766,32 +1782,33 @@ ce_bwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labe
         const int64_t tgt = (s + 1 < S) ? labels[t + 1] : (int64_t)ignore_index;
         const bool valid = tgt != ignore_index && tgt >= 0 && tgt < V;
         const float l = lse[t];
-        if constexpr (sizeof(TL) == 4) {
-            if (vec4) {                          // fp32 rows, 16 bytes per lane (see ce_fwd_kernel)
-                float* rowf = reinterpret_cast<float*>(row);
-                for (int c = 4 * lane; c < V; c += 256) {
-                    float g[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (valid) {
-                        const float4 x = *reinterpret_cast<const float4*>(rowf + c);
-                        const float xe[4] = {x.x, x.y, x.z, x.w};
+        if (vec4) {                              // 16 bytes per lane (see ce_fwd_kernel)
+            constexpr int EPL = CE_EPL<TL>;
+            for (int c = EPL * lane; c < V; c += 64 * EPL) {
+                float g[EPL];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = c + e < V ? expf(xe[e] - l) : 0.f;
-                            if (c + e == (int)tgt) v -= 1.f;
-                            g[e] = c + e < V ? v * gs : 0.f;
-                        }
+                for (int e = 0; e < EPL; ++e) g[e] = 0.f;
+                if (valid) {
+                    float x[EPL];
+                    ce_load16(row + c, x);
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        float v = c + e < V ? expf(x[e] - l) : 0.f;
+                        if (c + e == (int)tgt) v -= 1.f;
+                        g[e] = c + e < V ? v * gs : 0.f;
                     }
-                    if (c + 3 < V) {
-                        *reinterpret_cast<float4*>(rowf + c) = make_float4(g[0], g[1], g[2], g[3]);
-                    } else {
-                        rowf[c] = g[0];
-                        if (c + 1 < V) rowf[c + 1] = g[1];
-                        if (c + 2 < V) rowf[c + 2] = g[2];
-                    }
-                    am = __float_as_uint(fmaxf(fmaxf(fmaxf(__uint_as_float(am), fabsf(g[0])), fabsf(g[1])), fmaxf(fabsf(g[2]), fabsf(g[3]))));
                 }
-                continue;
+                if (c + EPL <= V) {
+                    ce_store16(row + c, g);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e)
+                        if (c + e < V) st1(row + c + e, g[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) am = __float_as_uint(fmaxf(__uint_as_float(am), fabsf(g[e])));
             }
+            continue;
         }
         for (int c = lane; c < V; c += 64) {
             float g = 0.f;
@@ -2350,7 +2367,7 @@ static int ce_fwd_impl(const char* name, TL* logits, int ldl, const int64_t* lab
     GAMER_CHECK_ARG(logits && labels && lse_out && row_loss && loss_sum && count, "%s: null pointer", name);
     GAMER_CHECK_ARG(B > 0 && S > 0 && V > 0 && ldl >= V && temperature > 0.f, "%s: bad shape B=%d S=%d V=%d ldl=%d", name, B, S, V, ldl);
     const int T = B * S;
-    const int vec4 = (sizeof(TL) == 4 && ldl % 4 == 0 && aligned16(logits)) ? 1 : 0;
+    const int vec4 = (ldl % (16 / (int)sizeof(TL)) == 0 && aligned16(logits)) ? 1 : 0;
     hipLaunchKernelGGL(ce_fwd_kernel<TL>, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), logits, ldl, labels, T,
                        S, V, 1.f / temperature, ignore_index, lse_out, row_loss, vec4);
     GAMER_CHECK_LAUNCH(name);
@@ -2382,7 +2399,7 @@ static int ce_bwd_impl(const char* name, TL* logits, int ldl, const int64_t* lab
     const int T = B * S;
     hipLaunchKernelGGL(ce_bwd_kernel<TL>, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), logits, ldl, labels, T,
                        S, V, ignore_index, lse, count_dev, denom_host, dloss / temperature, dloss_dev, take_amax_sink().out[0],
-                       (sizeof(TL) == 4 && ldl % 4 == 0 && aligned16(logits)) ? 1 : 0);
+                       (ldl % (16 / (int)sizeof(TL)) == 0 && aligned16(logits)) ? 1 : 0);
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }
