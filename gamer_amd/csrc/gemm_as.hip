@@ -205,9 +205,9 @@ gemm_as_kernel(const AsParams p) {
 
     float cmax = 0.f;
     float* crow = p.C + (int64_t)m * p.ldc;
-    auto compute_slab = [&](const int j, const int buf) {
+    f32x16 acc[AS_NT];
+    auto mfma_slab = [&](const int j, const int buf) {
         const bf16_t* img = wimg + buf * (2 * KP * AS_PANEL);
-            f32x16 acc[AS_NT];
 #pragma unroll
             for (int i = 0; i < 16; ++i)
 #pragma unroll
@@ -232,6 +232,8 @@ gemm_as_kernel(const AsParams p) {
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w0), __builtin_bit_cast(f16x8, af[0][ks]), acc[nt], 0, 0, 0);
                 }
             }
+    };
+    auto epilogue_slab = [&](const int j) {
             // epilogue: lane = output row m, acc[nt][reg] = column slab + 32 nt + (reg & 3) + 8 (reg >> 2) + 4 h
             float part = 0.f;                                             // EPI 2: this lane's share of the slab's row-dot
             if (valid_m) {
@@ -296,12 +298,21 @@ gemm_as_kernel(const AsParams p) {
         load_slab(0);
         store_slab(0, 0);
         __syncthreads();
+        // (the next slab's loads and stores are UNCONDITIONAL - after the last slab it is requested and stored once more, into the buffer
+        // nobody reads any more: under `if (j + 1 < n_slabs)` the loaded registers became a loop-carried merge, the compiler copied
+        // them right behind the loads and the kernel waited vmcnt(0) there - the L2 round trip of W in front of every slab)
+        // Order inside a slab: request slab j + 1 | MFMAs of slab j | slab j + 1 -> LDS | epilogue of slab j.  The LDS store waits for
+        // the W loads with nothing younger in the memory queue; with the epilogue's C stores in front of it the compiler's counted wait
+        // (a variable number of stores in branches: it assumes the worst) also waited for the stores it had just issued.
 #pragma unroll 1
         for (int j = 0; j < n_slabs; ++j) {
-            const int buf = j & 1;
-            if (j + 1 < n_slabs && !(AS_ABLATE & 4)) load_slab(j + 1);
-            compute_slab(j, buf);
-            if (j + 1 < n_slabs && !(AS_ABLATE & 4)) store_slab(j + 1, buf ^ 1);
+            const int buf = j & 1, jn = min(j + 1, n_slabs - 1);
+            if (!(AS_ABLATE & 4)) load_slab(jn);
+            __builtin_amdgcn_sched_barrier(0);             // (or the scheduler sinks the loads to their use, behind the MFMAs)
+            mfma_slab(j, buf);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(AS_ABLATE & 4)) store_slab(jn, buf ^ 1);
+            epilogue_slab(j);
             __syncthreads();
         }
     } else {
@@ -315,12 +326,12 @@ gemm_as_kernel(const AsParams p) {
 #pragma unroll 1
         for (int j = 0; j < n_slabs; j += 2) {
             const int b1 = bufc == 2 ? 0 : bufc + 1, b2 = b1 == 2 ? 0 : b1 + 1;
-            compute_slab(j, bufc);
+            mfma_slab(j, bufc); epilogue_slab(j);
             if (j + 1 < n_slabs) store_slab_from(j + 1, b1, rw);
             if (j + 3 < n_slabs) load_slab_into(j + 3, rw);
             __syncthreads();
             if (j + 1 >= n_slabs) break;
-            compute_slab(j + 1, b1);
+            mfma_slab(j + 1, b1); epilogue_slab(j + 1);
             if (j + 2 < n_slabs) store_slab_from(j + 2, b2, rw2);
             if (j + 4 < n_slabs) load_slab_into(j + 4, rw2);
             __syncthreads();
