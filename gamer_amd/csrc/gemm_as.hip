@@ -18,9 +18,8 @@
 // A is read once, C written once, W (<= 1 MB) comes from the L2 once per 128 rows.
 //
 // Measured (batch 1024 x 505 tokens, tools/dev_gemm_as_time.py): q|k|v [517120 x 256] x [768 x 256]^T 0.94 ms (tile kernel) -> 0.70,
-// tied head (N = 1041) 1.36 -> 0.94; the forward GEMM family 28.4 -> 25.1 ms per step.  Timing-only builds (AS_ABLATE) of the q|k|v
-// launch: without the C stores 0.59, without the MFMAs 0.52, without the W staging 0.55 - no single phase is the bound, the three
-// overlap incompletely inside a wave (ideal: 0.24 ms of MFMAs, 0.27 ms of HBM bytes).
+// tied head (N = 1041) 1.36 -> 0.95, the experts' gate|up (N = 1024, grouped) 1.37 -> 0.97; the forward GEMMs of a step 39.0 -> 33.4 ms
+// (ideal for q|k|v: 0.24 ms of MFMAs, 0.27 ms of HBM bytes).
 #include "common.h"
 #include <stdlib.h>
 #include <atomic>
