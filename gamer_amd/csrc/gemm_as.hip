@@ -376,8 +376,8 @@ bool gemm_as_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint
         return true;
     }
     // W row-contiguous.  Measured in the step (same box): the plain / accumulating form (the cross block's gate) 0.22 ms per launch
-    // faster than the tile kernel; the row-dot and SwiGLU-backward epilogues SLOWER (o_proj 0.59 -> 0.66 ms, down projection 1.30 ->
-    // 1.45): their inputs are requested in the epilogue of every 32-column slab and waited for there, and requesting them before the
+    // faster than the tile kernel; the row-dot and SwiGLU-backward epilogues not (o_proj 0.59 -> 0.65 ms, down projection 1.28 ->
+    // 1.31): their inputs are requested in the epilogue of every 32-column slab and waited for there, and requesting them before the
     // slab's MFMAs spills (256 registers: 1.30 -> 2.2 ms).  They stay on the tile kernel unless GAMER_GEMM_AS_RC=2 (tests).
     const char* rc = getenv("GAMER_GEMM_AS_RC");
     const int rc_mode = rc ? atoi(rc) : 1;
