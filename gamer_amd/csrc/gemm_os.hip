@@ -15,6 +15,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <atomic>
+#include <type_traits>
 
 namespace gamer {
 
@@ -120,40 +121,50 @@ gemm_os_kernel(const OsParams p) {
         for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
-        float4 raw[4], rawn[4];
+        // two register sets of dY, blocks alternate between them: a set is re-requested (for block b + 2) as soon as its last values
+        // are cut, half a block before the block ends - every load is unconditional (clamped: past the end the last block is read once
+        // more and never used) and pinned in place: a load under `if (b + 2 < n_blk)` becomes a loop-carried merge the compiler copies
+        // and waits for right behind the load, a free one is sunk to its use (gemm_as.hip)
+        float4 R[2][4];
         uint4 rw[OS_WLD];
-        load_row(0, raw);
+        load_row(0, R[0]);
         load_w(0, rw);
         store_w(0, os_smem, rw);
-        if (n_blk > 1) { load_row(OS_BK, rawn); load_w(OS_BK, rw); }
+        load_row(OS_BK, R[1]);
+        load_w(OS_BK, rw);
         __syncthreads();
-#pragma unroll 1
-        for (int b = 0; b < n_blk; ++b) {
-            const unsigned char* cur = os_smem + (b & 1) * OS_STAGE;
-            unsigned char* nxt = os_smem + ((b + 1) & 1) * OS_STAGE;
+        auto block = [&](auto par_c, const int b) {
+            constexpr int P = decltype(par_c)::value;
+            const unsigned char* cur = os_smem + P * OS_STAGE;
+            unsigned char* nxt = os_smem + (P ^ 1) * OS_STAGE;
             const int kb = b * OS_BK;
             if (kb + OS_BK > p.K) {              // the last, partial block: zeros past K (wave-uniform branch, no memory access inside)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k0 = kb + 16 * h + 4 * j;
-                    raw[j].x = k0 < p.K ? raw[j].x : 0.f; raw[j].y = k0 + 1 < p.K ? raw[j].y : 0.f;
-                    raw[j].z = k0 + 2 < p.K ? raw[j].z : 0.f; raw[j].w = k0 + 3 < p.K ? raw[j].w : 0.f;
+                    R[P][j].x = k0 < p.K ? R[P][j].x : 0.f; R[P][j].y = k0 + 1 < p.K ? R[P][j].y : 0.f;
+                    R[P][j].z = k0 + 2 < p.K ? R[P][j].z : 0.f; R[P][j].w = k0 + 3 < p.K ? R[P][j].w : 0.f;
                 }
             }
             if (pass == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     asm("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|"
-                        : "+v"(rmax) : "v"(raw[j].x), "v"(raw[j].y), "v"(raw[j].z), "v"(raw[j].w));
+                        : "+v"(rmax) : "v"(R[P][j].x), "v"(R[P][j].y), "v"(R[P][j].z), "v"(R[P][j].w));
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 uint32_t a0, a1, b0, b1, c0, c1, d0, d1;
-                cut2h_quad(raw[2 * s].x, raw[2 * s].y, raw[2 * s].z, raw[2 * s].w, sc, a0, a1, b0, b1);
-                cut2h_quad(raw[2 * s + 1].x, raw[2 * s + 1].y, raw[2 * s + 1].z, raw[2 * s + 1].w, sc, c0, c1, d0, d1);
+                cut2h_quad(R[P][2 * s].x, R[P][2 * s].y, R[P][2 * s].z, R[P][2 * s].w, sc, a0, a1, b0, b1);
+                cut2h_quad(R[P][2 * s + 1].x, R[P][2 * s + 1].y, R[P][2 * s + 1].z, R[P][2 * s + 1].w, sc, c0, c1, d0, d1);
                 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
                 const u32x4v u0 = {a0, b0, c0, d0}, u1 = {a1, b1, c1, d1};
                 const f16x8 y0 = __builtin_bit_cast(f16x8, u0), y1 = __builtin_bit_cast(f16x8, u1);
+                if (s == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(OS_ABLATE & 8)) load_row(kb + 2 * OS_BK, R[P]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) {
                     const f16x8 w0 = read_frag(cur, fw[nt] + s * 8 * OS_ROWB);
@@ -165,16 +176,21 @@ gemm_os_kernel(const OsParams p) {
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, y0, acc[nt], 0, 0, 0);
                 }
             }
-            if (b + 1 < n_blk) {
-                if (!(OS_ABLATE & 4)) store_w(kb + OS_BK, nxt, rw);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) raw[j] = rawn[j];
-                if (b + 2 < n_blk) {
-                    if (!(OS_ABLATE & 8)) load_row(kb + 2 * OS_BK, rawn);
-                    if (!(OS_ABLATE & 4)) load_w(kb + 2 * OS_BK, rw);
-                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(OS_ABLATE & 4)) {
+                store_w(kb + OS_BK, nxt, rw);    // (past the last block: zeros into the buffer nobody reads any more)
+                load_w(kb + 2 * OS_BK, rw);
             }
             __syncthreads();
+        };
+        {
+            int b = 0;
+#pragma unroll 1
+            for (; b + 1 < n_blk; b += 2) {
+                block(std::integral_constant<int, 0>{}, b);
+                block(std::integral_constant<int, 1>{}, b + 1);
+            }
+            if (b < n_blk) block(std::integral_constant<int, 0>{}, b);
         }
         out_scale = inv * i_w * p.alpha;
         if (pass == 1 || !p.guard) break;
