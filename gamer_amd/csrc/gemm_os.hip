@@ -45,6 +45,9 @@ struct OsParams {
     const uint32_t* amax_a; const uint32_t* amax_w;
     uint32_t* amax_c; int amax_c_col0;
     int guard;
+    // grouped form (the experts' gate|up at d_in = 256): rows sorted by expert, group g = rows group_offsets[g] .. group_offsets[g + 1] - 1
+    // with its own W strideW elements further; a workgroup never crosses a segment boundary
+    int groups; const int32_t* group_offsets; int64_t strideW;
 };
 
 // byte offset of (k, n) in a piece image [32 k][256 n] of 16-bit values: the 16-byte chunk (n >> 3) of the k row XORed with (k & 3) << 2
@@ -57,8 +60,23 @@ gemm_os_kernel(const OsParams p) {
     __shared__ uint32_t os_word[2];             // [0] amax of C, [1] guard vote
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int m = (blockIdx.x * OS_WAVES + w) * 32 + r;
-    const bool valid_m = m < p.M;
+    int row0 = blockIdx.x * (32 * OS_WAVES), row_end = p.M, grp = 0;
+    if (p.group_offsets) {
+        int prev = p.group_offsets[0], tiles_before = 0;
+        bool found = false;
+        for (int gi = 0; gi < p.groups; ++gi) {
+            const int nxt = p.group_offsets[gi + 1];
+            const int tiles = (nxt - prev + 32 * OS_WAVES - 1) / (32 * OS_WAVES);
+            if (!found && (int)blockIdx.x < tiles_before + tiles) {
+                grp = gi; row0 = prev + ((int)blockIdx.x - tiles_before) * (32 * OS_WAVES); row_end = nxt; found = true;
+            }
+            if (!found) tiles_before += tiles;
+            prev = nxt;
+        }
+        if (!found) return;
+    }
+    const int m = row0 + w * 32 + r;
+    const bool valid_m = m < row_end;
     if (tid < 2) os_word[tid] = 0;
 
     const uint32_t amax_a_bits = amax_read(p.amax_a);
@@ -68,7 +86,7 @@ gemm_os_kernel(const OsParams p) {
     float sc = s_a, inv = i_a;                  // this lane's scale of dY (pass 0: the tensor's)
 
     // ---- dY: this lane's 16 floats of a block, clamped so that every load is unconditional and in range
-    const float* arow = p.A + (int64_t)(valid_m ? m : p.M - 1) * p.lda;
+    const float* arow = p.A + (int64_t)(valid_m ? m : row_end - 1) * p.lda;
     const int k_last4 = (p.K - 1) & ~3;
     auto load_row = [&](int kb, float4 (&dst)[4]) {
 #pragma unroll
@@ -76,7 +94,7 @@ gemm_os_kernel(const OsParams p) {
     };
     // ---- W: thread f = tid + OS_THREADS i -> k = f >> 6, n = 4 (f & 63): 16 bytes of packed pieces -> two 8-byte stores
     const int wk = tid >> 6, wn4 = (tid & 63) << 2;
-    const uint4* wsrc = reinterpret_cast<const uint4*>(p.Wp) + (((int64_t)wk * p.ldw + wn4) >> 2);
+    const uint4* wsrc = reinterpret_cast<const uint4*>(p.Wp) + (((int64_t)grp * p.strideW + (int64_t)wk * p.ldw + wn4) >> 2);
     const int w_lds = os_off(wk, wn4);                                // (+ OS_WAVES i rows: k & 3 unchanged)
     auto load_w = [&](int kb, uint4 (&dst)[OS_WLD]) {
 #pragma unroll
@@ -244,7 +262,8 @@ static inline bool gemm_os_enabled() {
 // packed pieces, one group, no epilogue, enough rows to fill the chip)
 bool gemm_os_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint16_t* b_planes) {
     if (!gemm_os_enabled() || !a_kc || b_kc || !b_planes || !d->amax_a || !d->amax_b) return false;
-    if (d->group_mode != 0 || d->groups != 1 || d->accumulate || d->resid || d->rowdot_out || d->qk_q_rot || d->sw_gu) return false;
+    if (d->group_mode != 0 || d->accumulate || d->resid || d->rowdot_out || d->qk_q_rot || d->sw_gu) return false;
+    if (d->groups != 1 && (!d->group_offsets || d->strideC != 0 || d->amax_c)) return false;      // (grouped: the experts' gate|up at d_in = 256)
     const char* mm = getenv("GAMER_GEMM_OS_MIN_M");
     if (d->N != OS_N || d->K < 4 || d->M < (mm ? atoi(mm) : 16384)) return false;
     if (d->a_rs % 4 != 0 || d->b_ks % 4 != 0 || d->ldc % 4 != 0 || !aligned16(d->C) || !aligned16(b_planes)) return false;
@@ -263,13 +282,14 @@ int launch_gemm_os(const gamer_gemm_desc* d, const uint16_t* b_planes, int guard
     p.amax_a = d->amax_a; p.amax_w = d->amax_b;
     p.amax_c = d->amax_c; p.amax_c_col0 = d->amax_c_col0;
     p.guard = guard;
+    p.groups = d->groups; p.group_offsets = d->groups > 1 ? d->group_offsets : nullptr; p.strideW = d->strideB;
     static bool attr_dev[MAX_DEVICES] = {};
     if (!attr_dev[current_device()]) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_os_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, OS_LDS);
         if (e != hipSuccess) { set_error("gamer_gemm_f32_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         attr_dev[current_device()] = true;
     }
-    const dim3 grid((d->M + 32 * OS_WAVES - 1) / (32 * OS_WAVES));
+    const dim3 grid((d->M + 32 * OS_WAVES - 1) / (32 * OS_WAVES) + (p.group_offsets ? d->groups : 0));
     hipLaunchKernelGGL(gemm_os_kernel, grid, dim3(OS_THREADS), OS_LDS, st, p);
     GAMER_CHECK_LAUNCH("gamer_gemm_f32_split/output-stationary input gradient");
     g_os_launches.fetch_add(1, std::memory_order_relaxed);

@@ -132,3 +132,28 @@ def test_gemm_os_integers_and_the_default_bar():
             cache.reset()
             ops.linear_dgrad(dyi.to(DEV), N_out, flat[:N_out * H].view(N_out, H), H, torch.empty(M, H, device=DEV), H, M, N_out, H)
     assert _launches() == n0
+
+
+def test_gemm_os_grouped_experts():
+    """The experts' gate|up input gradient at d_in = 256: rows sorted by expert, one W per segment (an empty segment, one shorter than a
+    wave, boundaries that are no multiple of anything)."""
+    T, N_out, H, E = 3000, 1024, 256, 6
+    offs = torch.tensor([0, 700, 700, 717, 1500, 2100, T], dtype=torch.int32, device=DEV)
+    g = torch.Generator().manual_seed(5)
+    flat = (torch.randn(E * N_out * H + 8, generator=g) * 0.05).to(DEV)
+    W = flat[:E * N_out * H].view(E * N_out, H)
+    dy = (torch.randn(T, N_out, generator=g) * 1e-3).to(DEV)
+    cache = ops.amax_reuse()
+    cache.stable_range(flat.data_ptr(), flat.numel() * 4)
+    cache.planes = torch.zeros(flat.numel(), dtype=torch.float32, device=DEV)
+    grp = dict(groups=E, group_offsets=offs, strideB=N_out * H)
+    n0 = _launches()
+    got = _dgrad(dy, N_out, W, cache, T, N_out, H, True, **grp)
+    assert _launches() > n0
+    ref = _dgrad(dy, N_out, W, cache, T, N_out, H, False, **grp)
+    o = offs.cpu().tolist()
+    for e in range(E):
+        want = dy[o[e]:o[e + 1]].double().cpu() @ W[e * N_out:(e + 1) * N_out].double().cpu()
+        if want.numel():
+            assert float((got[o[e]:o[e + 1]].double().cpu() - want).abs().max()) < 2e-6 * float(want.abs().max()), e
+    assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
