@@ -1621,18 +1621,14 @@ ce_fwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labe
             // stored element by element - the padding columns of the row stay as they are
             constexpr int EPL = CE_EPL<TL>;
             float z[CE_MAXQ][EPL];
-#pragma unroll
+            const int c_last = ((V - 1) / EPL) * EPL;      // every load is unconditional (a group past the row reads the row's last group and
+#pragma unroll                                            // is masked): loads under `if (c < V)` were each waited for right behind the load
             for (int i = 0; i < CE_MAXQ; ++i) {
                 const int c = EPL * (lane + 64 * i);
-                if (c < V) {
-                    float x[EPL];
-                    ce_load16(row + c, x);
+                float x[EPL];
+                ce_load16(row + min(c, c_last), x);
 #pragma unroll
-                    for (int e = 0; e < EPL; ++e) z[i][e] = c + e < V ? round_as<TL>(x[e] * inv_temp) : -INFINITY;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) z[i][e] = -INFINITY;
-                }
+                for (int e = 0; e < EPL; ++e) z[i][e] = c + e < V ? round_as<TL>(x[e] * inv_temp) : -INFINITY;
             }
 #pragma unroll
             for (int i = 0; i < CE_MAXQ; ++i) {
@@ -1782,21 +1778,22 @@ ce_bwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labe
         const int64_t tgt = (s + 1 < S) ? labels[t + 1] : (int64_t)ignore_index;
         const bool valid = tgt != ignore_index && tgt >= 0 && tgt < V;
         const float l = lse[t];
-        if (vec4) {                              // 16 bytes per lane (see ce_fwd_kernel)
+        if (vec4 && V <= 64 * CE_EPL<TL> * CE_MAXQ) {       // 16 bytes per lane, the row's loads all in flight (see ce_fwd_kernel)
             constexpr int EPL = CE_EPL<TL>;
-            for (int c = EPL * lane; c < V; c += 64 * EPL) {
+            const int c_last = ((V - 1) / EPL) * EPL;
+            float xs[CE_MAXQ][EPL];
+#pragma unroll
+            for (int i = 0; i < CE_MAXQ; ++i) ce_load16(row + min(EPL * (lane + 64 * i), c_last), xs[i]);
+#pragma unroll
+            for (int i = 0; i < CE_MAXQ; ++i) {
+                const int c = EPL * (lane + 64 * i);
+                if (c >= V) continue;
                 float g[EPL];
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) g[e] = 0.f;
-                if (valid) {
-                    float x[EPL];
-                    ce_load16(row + c, x);
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) {
-                        float v = c + e < V ? expf(x[e] - l) : 0.f;
-                        if (c + e == (int)tgt) v -= 1.f;
-                        g[e] = c + e < V ? v * gs : 0.f;
-                    }
+                for (int e = 0; e < EPL; ++e) {
+                    float v = (valid && c + e < V) ? expf(xs[i][e] - l) : 0.f;
+                    if (valid && c + e == (int)tgt) v -= 1.f;
+                    g[e] = (valid && c + e < V) ? v * gs : 0.f;
                 }
                 if (c + EPL <= V) {
                     ce_store16(row + c, g);
