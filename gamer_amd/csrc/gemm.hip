@@ -1018,14 +1018,40 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
         const int row_first = row0 + wm * 64 + (lane >> 4);
         const int col = col0 + wn * 64 + c4;
         float* dst0 = Cp + (int64_t)row_first * p.ldc + col;
-        const float* res0 = EPI == 1 ? p.resid + (int64_t)row_first * p.ldc + col : nullptr;
         const int64_t step = 4 * p.ldc;
         const int qk_pos0 = EPI == 3 ? row_first % max(p.qk_S, 1) : 0;
         // (a wave's 64-column patch lies on one side of amax_c_col0 when that is a multiple of 64 - the q|k / v boundary is)
         const bool amax_on = GAMER_GEMM_CAMAX_BUILD && p.amax_c != nullptr && !ACCUM && col0 + wn * 64 >= p.amax_c_col0;
         float cmax = 0.f;
+        // The epilogues that read global memory request ALL sixteen rows' values here, before the loop (the accumulators are in the LDS
+        // patch by now: the registers are free).  Requested inside the loop, every iteration waited for its own load - sixteen memory
+        // round trips in a row per tile, thirty-two with the row map (index, then residual) - with nothing but the other resident
+        // workgroup to hide them.
+        int pre_rc[EPI == 1 ? 16 : 1];
+        float4 pre_x[EPI == 1 ? 16 : (EPI == 4 ? 8 : 1)], pre_b[EPI == 4 ? 8 : 1];      // (EPI 4: two rounds of eight rows - 128 registers spill)
+        if (EPI == 1) {
+            if (p.row_map) {
+#pragma unroll
+                for (int it = 0; it < 16; ++it) pre_rc[it] = p.row_map[row_first + 4 * it];
+            } else {
+#pragma unroll
+                for (int it = 0; it < 16; ++it) pre_rc[it] = row_first + 4 * it;
+            }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) pre_x[it] = *reinterpret_cast<const float4*>(p.resid + (int64_t)pre_rc[it] * p.ldc + col);
+        }
+        auto pre_sw = [&](int it0) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const float* ga = p.sw_gu + (int64_t)(row_first + 4 * (it0 + it)) * p.sw_ld + col;
+                pre_x[EPI == 4 ? it : 0] = *reinterpret_cast<const float4*>(ga);
+                pre_b[EPI == 4 ? it : 0] = *reinterpret_cast<const float4*>(ga + p.N);
+            }
+        };
+        if (EPI == 4) pre_sw(0);
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
+            if (EPI == 4 && it == 8) pre_sw(8);
             const int lr = (lane >> 4) + 4 * it;             // row inside the patch
             const float4 v = *reinterpret_cast<const float4*>(patch + lr * 68 + c4);
             if (EPI == 3) {
@@ -1078,7 +1104,7 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
                 const int row = row_first + 4 * it;
                 float* ga = p.sw_gu + (int64_t)row * p.sw_ld + col;
                 float* ua = ga + p.N;
-                const float4 a = *reinterpret_cast<const float4*>(ga), b = *reinterpret_cast<const float4*>(ua);
+                const float4 a = pre_x[EPI == 4 ? (it & 7) : 0], b = pre_b[EPI == 4 ? (it & 7) : 0];
                 float m[4];
                 rng.mult4((uint32_t)(((int64_t)row * p.N + col) >> 2), m);
                 const float d0 = m[0] * v.x, d1 = m[1] * v.y, d2 = m[2] * v.z, d3 = m[3] * v.w;
@@ -1094,16 +1120,9 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
                     asm("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|" : "+v"(cmax) : "v"(du.x), "v"(du.y), "v"(du.z), "v"(du.w));
                 }
             } else if (EPI == 1) {
-                float* dst = dst0 + it * step;
-                const float* rsrc = res0 + it * step;
-                int64_t e = (int64_t)(row_first + 4 * it) * p.ldc + col;
-                if (p.row_map) {
-                    const int64_t rc = p.row_map[row_first + 4 * it];
-                    e = rc * p.ldc + col;
-                    dst = Cp + e;
-                    rsrc = p.resid + e;
-                }
-                const float4 x = *reinterpret_cast<const float4*>(rsrc);
+                const int64_t e = (int64_t)pre_rc[EPI == 1 ? it : 0] * p.ldc + col;
+                float* dst = Cp + e;
+                const float4 x = pre_x[EPI == 1 ? it : 0];
                 float m[4];
                 rng.mult4((uint32_t)(e >> 2), m);
                 float4 o;
