@@ -159,21 +159,24 @@ __device__ __forceinline__ void hb_epilogue(const GemmBf16Params& p, f32x16 (&ac
                     const int row = row0 + wm * 64 + i * 32 + r32;
                     const int64_t rc = p.row_map ? (int64_t)p.row_map[row] : (int64_t)row;
                     const int64_t e0 = rc * p.ldc + col0 + wn * 64 + 4 * h;
+                    // (all eight residual quads of the row requested at once: two at a time - what the 256 x 256 form had registers for, and
+                    // it does not use this epilogue - left four memory round trips in a row per 32-row half)
+                    float4 x[2][4];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) x[j][g4] = *reinterpret_cast<const float4*>(p.resid + e0 + j * 32 + 8 * g4);
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
 #pragma unroll
                         for (int gp = 0; gp < 2; ++gp) {
-                            float4 x[2];                 // (two at a time: the 256 x 256 form has no registers for more)
-#pragma unroll
-                            for (int g2 = 0; g2 < 2; ++g2)
-                                x[g2] = *reinterpret_cast<const float4*>(p.resid + e0 + j * 32 + 8 * (2 * gp + g2));
 #pragma unroll
                             for (int g2 = 0; g2 < 2; ++g2) {
                                 const int g4 = 2 * gp + g2;
                                 const int64_t e = e0 + j * 32 + 8 * g4;
                                 float m[4];
                                 rng.mult4((uint32_t)(e >> 2), m);
-                                const float4 xx = x[g2];
+                                const float4 xx = x[j][g4];
                                 float4 o;
                                 o.x = xx.x + m[0] * acc[i][j][4 * g4 + 0]; o.y = xx.y + m[1] * acc[i][j][4 * g4 + 1];
                                 o.z = xx.z + m[2] * acc[i][j][4 * g4 + 2]; o.w = xx.w + m[3] * acc[i][j][4 * g4 + 3];
@@ -295,6 +298,14 @@ __device__ __forceinline__ void hb_epilogue(const GemmBf16Params& p, f32x16 (&ac
                     const int row = row0 + wm * 64 + i * 32 + r32;
                     const int cbase = col0 + wn * 64 + 8 * h;
                     bf16_t* grow = p.sw_gu + (int64_t)row * p.sw_ld + cbase;
+                    bf16x8 pa[2][2], pb[2][2];       // (the row's gate | up groups requested at once: four round trips -> one)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int t2 = 0; t2 < 2; ++t2) {
+                            pa[j][t2] = *reinterpret_cast<const bf16x8*>(grow + j * 32 + 16 * t2);
+                            pb[j][t2] = *reinterpret_cast<const bf16x8*>(grow + j * 32 + 16 * t2 + p.N);
+                        }
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -309,8 +320,7 @@ __device__ __forceinline__ void hb_epilogue(const GemmBf16Params& p, f32x16 (&ac
                                 v[4 + e] = __uint_as_float(sw[1]);
                             }
                             bf16_t* ga = grow + j * 32 + 16 * t2;
-                            const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(ga);
-                            const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(ga + p.N);
+                            const bf16x8 a8 = pa[j][t2], b8 = pb[j][t2];
                             const int64_t e0 = (int64_t)row * p.N + cbase + j * 32 + 16 * t2;      // flat index of d(hm): the dropout word
                             float m0[4], m1[4];
                             rng.mult4((uint32_t)(e0 >> 2), m0);
