@@ -370,6 +370,13 @@ __device__ __forceinline__ void hb_epilogue(const GemmBf16Params& p, f32x16 (&ac
                     bf16_t* crow = Cp + (int64_t)row * p.ldc + col0 + wn * 64 + 8 * h;
                     const bf16_t* orow = EPI == 2 ? p.rowdot_other + (int64_t)row * p.ldc + col0 + wn * 64 + 8 * h : nullptr;
                     float dot = 0.f;
+                    bf16x8 pot[2][2];                // (row-dot: the row's four groups of `other` requested at once, not one per store)
+                    if (EPI == 2) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int t2 = 0; t2 < 2; ++t2) pot[j][t2] = *reinterpret_cast<const bf16x8*>(orow + j * 32 + 16 * t2);
+                    }
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -394,7 +401,7 @@ __device__ __forceinline__ void hb_epilogue(const GemmBf16Params& p, f32x16 (&ac
                             *reinterpret_cast<bf16x8*>(dst) = o;
                             if (EPI == 2) {
                                 // delta uses the ROUNDED dO (what the attention backward reads), times O
-                                const bf16x8 ot = *reinterpret_cast<const bf16x8*>(orow + j * 32 + 16 * t2);
+                                const bf16x8 ot = pot[j][t2];
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) dot += (float)o[e] * (float)ot[e];
                             }
