@@ -6,6 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 NAME=$1; SRC=$2; shift 2
 L=gamer_amd/lib
+mkdir -p tools/_ab
 OBJ=tools/_ab/${SRC%.hip}.$NAME.o
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++20 -Wno-unused-function "$@" -c gamer_amd/csrc/$SRC -o $OBJ
 OBJS=""
