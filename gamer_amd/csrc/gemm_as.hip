@@ -42,7 +42,6 @@ typedef uint32_t u32x4a __attribute__((ext_vector_type(4)));
 #ifndef AS_ABLATE
 #define AS_ABLATE 0       // timing-only builds: 1 no C stores, 2 no MFMAs, 4 no W staging after the first slab
 #endif
-constexpr int AS_THREADS = 64 * AS_WAVES;
 constexpr int AS_SLAB = 32 * AS_NT;            // output columns per slab
 constexpr int AS_PANEL = AS_SLAB * 64;         // 16-bit elements of one [slab n][64 k] piece image
 
@@ -72,23 +71,26 @@ struct AsParams {
 // 16-byte reads.  WRC = true: W [K][N] (the input-gradient layout of a layer with K <= 256 OUTPUT features: o_proj, the experts' down
 // projection, the cross block's gate): piece images [k][32 n], fragments by transposing reads (as gemm_os.hip).  EPI: 0 store (or
 // accumulate), 2 row-dot, 4 SwiGLU backward (the epilogues of csrc/gemm.hip, same definitions).
-template <int KP, bool WRC, int EPI>
-__global__ void __launch_bounds__(AS_THREADS, AS_DEPTH == 2 ? 1 : 8 / AS_WAVES)
+// NW = waves per workgroup (32 rows each): 4 (two workgroups per CU, out of step) or 8 (one; W is fetched once per 256 rows - faster for
+// the wide ungrouped launches, q|k|v 0.73 -> 0.68 ms, head 0.97 -> 0.93; slower for the grouped gate|up, 0.97 -> 1.15, and the 256-column gate)
+template <int KP, bool WRC, int EPI, int NW>
+__global__ void __launch_bounds__(64 * NW, AS_DEPTH == 2 ? 1 : 8 / NW)
 gemm_as_kernel(const AsParams p) {
+    constexpr int AS_WAVES_K = NW, AS_THREADS_K = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char as_raw[];
     bf16_t* const wimg = reinterpret_cast<bf16_t*>(as_raw);                // [buffer 2][piece 2][panel KP][AS_PANEL]
     __shared__ uint32_t amax_word;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    int row0 = blockIdx.x * (32 * AS_WAVES), row_end = p.M, grp = 0;
+    int row0 = blockIdx.x * (32 * AS_WAVES_K), row_end = p.M, grp = 0;
     if (p.group_offsets) {
         int prev = p.group_offsets[0], tiles_before = 0;
         bool found = false;
         for (int gi = 0; gi < p.groups; ++gi) {
             const int nxt = p.group_offsets[gi + 1];
-            const int tiles = (nxt - prev + 32 * AS_WAVES - 1) / (32 * AS_WAVES);
+            const int tiles = (nxt - prev + 32 * AS_WAVES_K - 1) / (32 * AS_WAVES_K);
             if (!found && (int)blockIdx.x < tiles_before + tiles) {
-                grp = gi; row0 = prev + ((int)blockIdx.x - tiles_before) * (32 * AS_WAVES); row_end = nxt; found = true;
+                grp = gi; row0 = prev + ((int)blockIdx.x - tiles_before) * (32 * AS_WAVES_K); row_end = nxt; found = true;
             }
             if (!found) tiles_before += tiles;
             prev = nxt;
@@ -141,14 +143,14 @@ gemm_as_kernel(const AsParams p) {
     // ---- slabs of 64 output columns ---------------------------------------------------------------------------------------------
     const int n_slabs = (p.N + AS_SLAB - 1) / AS_SLAB;
     constexpr int QPR = KP * 16;                                         // 16-byte groups (four k) per row of W
-    constexpr int NLD = AS_SLAB * QPR / AS_THREADS;                      // groups per thread and slab (KP * 2)
+    constexpr int NLD = AS_SLAB * QPR / AS_THREADS_K;                      // groups per thread and slab (KP * 2)
     uint4 rw[NLD], rw2[NLD];
     // per thread: the NLD (row of the slab, four-k group) items it stages, as offsets computed ONCE (a slab later = a constant stride)
     int lds_off[NLD], nl_[NLD];
     const uint4* wsrc[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        const int f = tid + AS_THREADS * i;
+        const int f = tid + AS_THREADS_K * i;
         if (!WRC) {
             const int nl = f / QPR, g = f % QPR;
             nl_[i] = nl;
@@ -366,7 +368,6 @@ bool gemm_as_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint
     if (d->K % 64 != 0 || d->K < 64 || d->K > 256 || d->M < (mm ? atoi(mm) : 16384)) return false;
     if (d->a_rs % 4 != 0 || d->ldc % 4 != 0 || !aligned16(d->C) || !aligned16(b_planes)) return false;
     if (d->groups != 1 && (!d->group_offsets || d->strideC != 0)) return false;
-    static_assert((AS_SLAB * 16) % AS_THREADS == 0 || AS_THREADS % (AS_SLAB * 16) == 0, "slab groups per thread");
     if (b_kc) {
         if (d->accumulate || d->rowdot_out || d->sw_gu || d->b_rs % 4 != 0) return false;
         // (grouped: the experts' gate|up projection at d_in = 256: 1.37 -> 1.30 ms, W is 1 MB per 128 rows there; the injecting layers'
@@ -407,18 +408,23 @@ int launch_gemm_as(const gamer_gemm_desc* d, const uint16_t* b_planes, bool b_kc
     p.sw_gu = d->sw_gu; p.sw_ld = d->sw_ld; p.p_drop = d->p_drop; p.seed = d->seed;
     const int kp = d->K / 64;
     const size_t shmem = (size_t)(AS_DEPTH == 2 ? 3 : 2) * 2 * kp * AS_PANEL * sizeof(bf16_t);
-    const dim3 grid((d->M + 32 * AS_WAVES - 1) / (32 * AS_WAVES) + (p.group_offsets ? d->groups : 0));
-#define GAMER_LAUNCH_AS(KPV, WRCV, EPIV)                                                                                      \
+    // eight waves per workgroup for the wide ungrouped Linear forwards (q|k|v, head), four otherwise (see the kernel)
+    const char* wv = getenv("GAMER_GEMM_AS_WAVES");
+    const int nw = wv ? (atoi(wv) == 8 ? 8 : 4) : ((b_kc && d->groups == 1 && d->N >= 512 && AS_WAVES == 4) ? 8 : AS_WAVES);
+    const dim3 grid((d->M + 32 * nw - 1) / (32 * nw) + (p.group_offsets ? d->groups : 0));
+#define GAMER_LAUNCH_AS_W(KPV, WRCV, EPIV, NWV)                                                                               \
     do {                                                                                                                      \
         static bool attr_dev[MAX_DEVICES] = {};                                                                               \
         if (!attr_dev[current_device()]) {                                                                                    \
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_as_kernel<KPV, WRCV, EPIV>),          \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_as_kernel<KPV, WRCV, EPIV, NWV>),     \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                 \
             if (e != hipSuccess) { set_error("gamer_gemm_f32_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; } \
             attr_dev[current_device()] = true;                                                                                \
         }                                                                                                                     \
-        hipLaunchKernelGGL((gemm_as_kernel<KPV, WRCV, EPIV>), grid, dim3(AS_THREADS), shmem, st, p);                          \
+        hipLaunchKernelGGL((gemm_as_kernel<KPV, WRCV, EPIV, NWV>), grid, dim3(64 * NWV), shmem, st, p);                        \
     } while (0)
+#define GAMER_LAUNCH_AS(KPV, WRCV, EPIV)                                                                                      \
+    do { if (nw == 8) GAMER_LAUNCH_AS_W(KPV, WRCV, EPIV, 8); else GAMER_LAUNCH_AS_W(KPV, WRCV, EPIV, 4); } while (0)
     if (b_kc) {
         switch (kp) {
             case 1: GAMER_LAUNCH_AS(1, false, 0); break;
@@ -434,6 +440,7 @@ int launch_gemm_as(const gamer_gemm_desc* d, const uint16_t* b_planes, bool b_kc
         GAMER_LAUNCH_AS(4, true, 0);
     }
 #undef GAMER_LAUNCH_AS
+#undef GAMER_LAUNCH_AS_W
     GAMER_CHECK_LAUNCH("gamer_gemm_f32_split/activation-stationary");
     g_as_launches.fetch_add(1, std::memory_order_relaxed);
     return 0;
