@@ -30,8 +30,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4a __attribute__((ext_vector_type(4)));
 
 #ifndef AS_WAVES
-#define AS_WAVES 4        // waves per workgroup (32 rows each).  4: two workgroups per CU, out of step with each other - one loads its rows of A
-#endif                    // while the other multiplies (8 waves = one workgroup per CU measured 0.78 ms against 0.70 for the q|k|v shape)
+#define AS_WAVES 4        // default waves per workgroup (32 rows each): two workgroups per CU, out of step with each other - one loads its rows of
+#endif                    // A while the other multiplies; the launcher takes 8 for the wide ungrouped forwards (template parameter NW of the kernel)
 #ifndef AS_NT
 #define AS_NT 1           // 32-column MFMA tiles per slab (LDS per workgroup: 2 buffers x 2 pieces x K x 32 AS_NT x 2 bytes)
 #endif
