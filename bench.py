@@ -15,8 +15,10 @@ scaling: global batch 1024, per-GPU batch 1024 / N (1024 / 512 / 256 / 128 at 1 
 1024 sequences per GPU (BASELINE configs[2]: 8 x 1024 with ``--dtype bf16``).
 
 Extra objects on the JSON line:
-  roofline     the dominant kernel family (fp32 MFMA GEMM): algorithmic FLOPs of its launches / their
-               summed duration, measured with HIP events on the launch stream inside the timed region
+  roofline     the dominant kernel family = the one with the most time per step among ALL families with a FLOP model
+               (GEMM families and attention forward / backward, self / cross): algorithmic FLOPs of its launches
+                / their summed duration, measured with HIP events on the launch stream inside the timed
+               region; `roofline.gemm` = the same object for the largest GEMM family
   cpu_baseline the CPU oracle (a port of the reference algorithm, oracle/) timed on the host cores,
                rank 0, N=1 only, on a bounded sample (micro-batch 32, 1 warm-up + 3 timed
                steps, same sequence shape)
@@ -78,6 +80,11 @@ def algorithmic_flops(cfg, batch, session: bool = False) -> dict:
     pair = 4 * dh * nq
     f_fwd = t_nonpad * f_tok + pair * (L * p_self + n_cross * p_cross)
     return dict(per_token=f_tok, fwd=f_fwd, step=3 * f_fwd, tokens=t_nonpad, p_self=p_self, p_cross=p_cross)
+
+
+# Attention FLOPs per allowed (query, key) pair and query head (1536 per pair forward at nq = 6, F_step = 3 F_fwd)
+ATTN_FWD_FLOP_PER_PAIR_HEAD = 4.0 * 64
+ATTN_BWD_FLOP_PER_PAIR_HEAD = 8.0 * 64
 
 
 class KernelTimer:
@@ -169,8 +176,9 @@ class KernelTimer:
             r = orig_ab16(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, B, S, nq, *rest, **kw)
             e.record()
             timer.enabled = True
-            # recompute form: S and dP twice, dV, dK, dQ = 7 products of 2 * 64 FLOP per pair and head
-            timer.records.append(("attn_bwd_self" if ql is None else "attn_bwd_cross", s, e, 14.0 * 64 * nq * pairs, 0.0))
+            # algorithmic = SURVEY 8(d): F_step = 3 F_fwd, i.e. the backward is the FOUR products dV, dP, dQ, dK of 2 * 64 FLOP
+            # per allowed pair and head (the recompute form executes seven: S and dP twice)
+            timer.records.append(("attn_bwd_self" if ql is None else "attn_bwd_cross", s, e, ATTN_BWD_FLOP_PER_PAIR_HEAD * nq * pairs, 0.0))
             return r
 
         orig_af, orig_ab = ops.attn_fwd, ops.attn_bwd
@@ -201,7 +209,7 @@ class KernelTimer:
             r = orig_ab(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, *rest, **kw)
             e.record()
             timer.enabled = True
-            timer.records.append(("attn_bwd_self" if ql is None else "attn_bwd_cross", s, e, 10.0 * 64 * nq * pairs, 0.0))
+            timer.records.append(("attn_bwd_self" if ql is None else "attn_bwd_cross", s, e, ATTN_BWD_FLOP_PER_PAIR_HEAD * nq * pairs, 0.0))
             return r
 
         orig_afs, orig_abs = ops.attn_fwd_split, ops.attn_bwd_split
@@ -227,8 +235,8 @@ class KernelTimer:
             r = orig_abs(q, ldq, k, ldk, v, ldv, o, d_o, lse, kl, ql, row_empty, tile_empty, B, S, nq, *rest, **kw)
             e_.record()
             timer.enabled = True
-            # algorithmic = the five products of the backward (the recompute form executes seven)
-            timer.records.append((label, s_, e_, 10.0 * 64 * nq * pairs, 0.0))
+            # algorithmic = SURVEY 8(d): backward = 2 x forward = four products (the two-kernel recompute form executes seven)
+            timer.records.append((label, s_, e_, ATTN_BWD_FLOP_PER_PAIR_HEAD * nq * pairs, 0.0))
             return r
 
         ops.attn_fwd_split = timed_attn_fwd_split
@@ -280,7 +288,7 @@ def log(msg: str):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def committed_traffic(kernel_substr, want: dict):
+def committed_traffic(kernel_substr, want: dict, per_call: bool = False):
     """HBM bytes per launch of a kernel - or of a family of kernels (a tuple of name fragments: the weight gradients run on
     gemm_wg_kernel where dW is whole 256 x 256 tiles and on gemm_f32_kernel elsewhere), averaged over their dispatches -
     from the committed rocprofv3 PMC summaries (profiles/<tag>_pmc_{FETCH,WRITE}_SIZE.csv;
@@ -293,15 +301,28 @@ def committed_traffic(kernel_substr, want: dict):
     import glob
     prof = os.path.join(ROOT, "profiles")
 
-    subs = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
+    import re
+    if isinstance(kernel_substr, re.Pattern):
+        def hit(name):
+            return kernel_substr.search(name) is not None
+    else:
+        subs = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
 
+        def hit(name):
+            return any(sub in name for sub in subs)
+
+    # per_call: the family is SEVERAL kernels launched once each per call of its entry point (attention backward: dQ + dK/dV) -
+    # bytes per call = the sum over its kernels, calls = the largest dispatch count among them
     def avg(path, col):
-        tot, n = 0.0, 0.0
+        tot, n, most = 0.0, 0.0, 0.0
         for r in csv.DictReader(open(path)):
-            if any(sub in r["kernel"] for sub in subs):
+            if hit(r["kernel"]):
                 d = float(r.get("dispatches", 1) or 1)
                 tot += float(r[col]) * d
                 n += d
+                most = max(most, d)
+        if per_call:
+            return tot / most if most else None
         return tot / n if n else None
 
     # newest first, by what the profiling script RECORDED in the sidecar: `created` (UTC time stamp) where present, else `seq`;
@@ -678,8 +699,11 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
     if timer.enabled:
         warm_steps = args.warmup - 1
         warm_kernels = timer.summary(warm_steps)
-        gw = [k for k in warm_kernels if k["kernel"].startswith("gemm")]
-        timer.only = {max(gw, key=lambda k: k["ms_per_step"])["kernel"]} if gw else set()
+        # the timed region carries events on TWO families: the one with the largest time per step among every family with a
+        # FLOP model (GEMMs and attention alike -> "roofline") and the largest GEMM family (-> "roofline.gemm")
+        modelled = [k for k in warm_kernels if "tflops" in k]
+        gw = [k for k in modelled if k["kernel"].startswith("gemm")]
+        timer.only = {max(fam, key=lambda k: k["ms_per_step"])["kernel"] for fam in (modelled, gw) if fam}
         timer.records = []
     log("timed region")
     timer.enabled = not args.no_kernel_timing
@@ -752,28 +776,86 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
         timed = timer.summary(args.steps)                      # the dominant family, measured in the timed region
         kernels = warm_kernels if warm_kernels else timed      # every launch, measured in the warm-up steps
         gemm_rows = [k for k in kernels if k["kernel"].startswith("gemm")]
-        dom = timed[0] if timed else (max(gemm_rows, key=lambda k: k["ms_per_step"]) if gemm_rows else None)
+        timed_gemm = [k for k in timed if k["kernel"].startswith("gemm")]
+        gdom = timed_gemm[0] if timed_gemm else (max(gemm_rows, key=lambda k: k["ms_per_step"]) if gemm_rows else None)
+        modelled = [k for k in (timed if timed else kernels) if "tflops" in k]
+        dom = max(modelled, key=lambda k: k["ms_per_step"]) if modelled else None
         gemm_ms = sum(k["ms_per_step"] for k in gemm_rows)
         gemm_tf = sum(k["tflops"] * k["ms_per_step"] for k in gemm_rows) / max(gemm_ms, 1e-9)
         ms_per_step = elapsed / args.steps * 1e3
-        # (prefixes: the kernel's template list ends with the matmul form, ", 0>" = fp32 MFMA)
         split_terms = {"f32": 0, "split3": 3, "split6": 6, "split9": 9}[args.matmul]
-        # (substring match: the template list continues with the ping-pong flag)
-        kname = {"gemm_fwd": f"gemm_f32_kernel<true, true, 0, false, false, 2, 0, {split_terms},",
-                 "gemm_dgrad": f"gemm_f32_kernel<true, false, 0, false, false, 2, 0, {split_terms},",
-                 "gemm_wgrad": (f"gemm_f32_kernel<false, false, 1, false, false, 2, 0, {split_terms},", "gemm_wg_kernel<")}.get(
-                     dom["kernel"] if dom else "", None)
-        if args.dtype != "f32":
-            kname = None
-        # HBM bytes per launch from a committed PMC profile of THIS workload (shape / dtype / matmul form checked)
-        want = dict(batch=args.batch, items=args.items, dtype=args.dtype, matmul=args.matmul, variant=args.variant,
-                    ragged=bool(args.ragged))
-        traffic = committed_traffic(kname, want) if kname else None
         peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "f32" else BF16_MATRIX_PEAK_TFLOPS
         if split_terms:
-            # every fp32 product is `terms` bf16 MFMA products: the pipe that bounds the kernel is the bf16 one, and its
-            # peak in units of the ALGORITHMIC (fp32 problem) FLOPs is the bf16 peak / terms
+            # every fp32 product is `terms` 16-bit MFMA products: the pipe that bounds the kernel is the 16-bit one, and its
+            # peak in units of the ALGORITHMIC (fp32 problem) FLOPs is the 16-bit peak / terms
             peak = BF16_MATRIX_PEAK_TFLOPS / split_terms
+        want = dict(batch=args.batch, items=args.items, dtype=args.dtype, matmul=args.matmul, variant=args.variant,
+                    ragged=bool(args.ragged))
+
+        def family_roofline(row):
+            """`roofline` object of one kernel family (a row of the timed region's table): algorithmic FLOPs of its launches /
+            their HIP-event time against the matrix peak of the form, HBM bytes per launch (per call for the attention backward:
+            its kernels summed) from the newest committed PMC profile of this workload."""
+            if row is None:
+                return None
+            fam = row["kernel"]
+            if fam.startswith("gemm"):
+                # (substring match: the template list ends with the matmul form, ", 0," = fp32 MFMA, then the ping-pong flag)
+                kname = {"gemm_fwd": f"gemm_f32_kernel<true, true, 0, false, false, 2, 0, {split_terms},",
+                         "gemm_dgrad": f"gemm_f32_kernel<true, false, 0, false, false, 2, 0, {split_terms},",
+                         "gemm_wgrad": (f"gemm_f32_kernel<false, false, 1, false, false, 2, 0, {split_terms},", "gemm_wg_kernel<")}.get(fam)
+                if args.dtype != "f32":
+                    kname = None
+                traffic = committed_traffic(kname, want) if kname else None
+                label = ((f"gemm_wg_kernel + gemm_f32_kernel ({fam}: 256 x 256 tiles where dW is whole tiles, 128 x 128 elsewhere)"
+                          if (fam == "gemm_wgrad" and split_terms == 3) else
+                          f"gemm_{'f32' if args.dtype == 'f32' else 'bf16'}_kernel ({fam})"))
+                note = None
+            else:
+                # attention: every form's kernels carry CROSS as their LAST template argument; the backward is two kernels per call
+                import re
+                stem = "attn_bwd_" if fam.startswith("attn_bwd") else "attn_fwd_"
+                cross = "true" if fam.endswith("cross") else "false"
+                traffic = committed_traffic(re.compile(stem + r"\w+<[^>]*\b" + cross + r">\("), want, per_call=True)
+                label = (f"{stem}*_kernel<..., CROSS = {cross}> ({fam}: " +
+                         ("dQ + dK/dV kernels of one call" if stem == "attn_bwd_" else "one kernel per call") + ")")
+                note = ("algorithmic FLOPs per SURVEY.md 8(d): 1536 per allowed (query, key) pair forward, backward = 2 x forward "
+                        "(four products; the two-kernel recompute form executes seven)")
+            if split_terms:
+                label += (f" SPLIT={split_terms}: {'fp16' if split_terms == 3 else 'bf16'} MFMA pipe, peak = "
+                          f"{BF16_MATRIX_PEAK_TFLOPS:g} / {split_terms}")
+            return {
+                "bound": "mfma",
+                "kernel": label,
+                "achieved": row["tflops"],
+                "peak": peak,
+                "unit": "TFLOP/s",
+                "frac": row["tflops"] / peak,
+                # the same launches against the HBM roofline (operands once + result): at K = 256 the bf16 GEMMs sit
+                # below the MFMA/HBM ridge (SURVEY section 8(d)), so this is the bound that binds them
+                "algorithmic_GBps": row.get("algorithmic_GBps"),
+                "hbm_frac": (row["algorithmic_GBps"] / HBM_PEAK_GBS) if row.get("algorithmic_GBps") else None,
+                "traffic": traffic["bytes_per_launch"] if traffic else None,
+                "traffic_source": traffic["source"] if traffic else None,
+                "traffic_profiled_command": traffic["profiled_command"] if traffic else None,
+                "algorithmic_flop_per_launch": row["tflops"] * 1e12 * row["avg_launch_ms"] * 1e-3,
+                "avg_launch_ms": row["avg_launch_ms"],
+                "ms_per_step": row["ms_per_step"],
+                "flop_convention": note,
+            }
+        roofline = family_roofline(dom)
+        if roofline is not None:
+            roofline.update({
+                "gemm": family_roofline(gdom) if (gdom is not None and gdom is not dom) else None,
+                "all_gemm_tflops": gemm_tf,
+                "all_gemm_ms_per_step": gemm_ms,
+                "step_algorithmic_tflops": step_flops / (ms_per_step * 1e-3) / 1e12,
+                "step_frac_of_matrix_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / peak,
+                # what the 16-bit matrix pipe SUSTAINS with the whole chip busy depends on the operand data (power): measured
+                # 1.43-1.68 PFLOP/s on random bits against the nominal 2.5 (tools/ubench_memtime.hip); `peak` above is nominal
+                "pipe_sustained_random_operands_TFLOPs": ([1430.0 / split_terms, 1680.0 / split_terms] if split_terms else None),
+                "pipe_sustained_source": "profiles/r03_mfma_sustained.txt" if split_terms else None,
+            })
         result = {
             "metric": ("train-step sequences/sec, Qwen3Multi SMB decoder, his_len=100" if args.variant == "multi" else
                        "train-step sequences/sec, Qwen3SessionMulti SMB decoder, his_len=100"),
@@ -818,35 +900,7 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
                 "matmul": args.matmul,
                 "deterministic_wgrad": bool(getattr(args, "deterministic", False)),
             },
-            "roofline": {
-                "bound": "mfma",
-                "kernel": ((f"gemm_wg_kernel + gemm_f32_kernel ({dom['kernel']}: 256 x 256 tiles where dW is whole tiles, 128 x 128 elsewhere)"
-                            if (dom["kernel"] == "gemm_wgrad" and split_terms == 3) else
-                            f"gemm_{'f32' if args.dtype == 'f32' else 'bf16'}_kernel ({dom['kernel']})")
-                           + (f" SPLIT={split_terms}: {'fp16' if split_terms == 3 else 'bf16'} MFMA pipe, peak = "
-                              f"{BF16_MATRIX_PEAK_TFLOPS:g} / {split_terms}" if split_terms else "")) if dom else None,
-                "achieved": dom["tflops"] if dom else None,
-                "peak": peak,
-                "unit": "TFLOP/s",
-                "frac": dom["tflops"] / peak if dom else None,
-                # the same launches against the HBM roofline (operands once + result): at K = 256 the bf16 GEMMs sit
-                # below the MFMA/HBM ridge, so this is the bound that binds them
-                "algorithmic_GBps": dom.get("algorithmic_GBps") if dom else None,
-                "hbm_frac": (dom["algorithmic_GBps"] / HBM_PEAK_GBS) if (dom and dom.get("algorithmic_GBps")) else None,
-                "traffic": traffic["bytes_per_launch"] if traffic else None,
-                "traffic_source": traffic["source"] if traffic else None,
-                "traffic_profiled_command": traffic["profiled_command"] if traffic else None,
-                "algorithmic_flop_per_launch": (dom["tflops"] * 1e12 * dom["avg_launch_ms"] * 1e-3) if dom else None,
-                "avg_launch_ms": dom["avg_launch_ms"] if dom else None,
-                "all_gemm_tflops": gemm_tf,
-                "all_gemm_ms_per_step": gemm_ms,
-                "step_algorithmic_tflops": step_flops / (ms_per_step * 1e-3) / 1e12,
-                "step_frac_of_matrix_peak": step_flops / (ms_per_step * 1e-3) / 1e12 / peak,
-                # what the 16-bit matrix pipe SUSTAINS with the whole chip busy depends on the operand data (power): measured
-                # 1.43-1.68 PFLOP/s on random bits against the nominal 2.5 (tools/ubench_memtime.hip); `peak` above is nominal
-                "pipe_sustained_random_operands_TFLOPs": ([1430.0 / split_terms, 1680.0 / split_terms] if split_terms else None),
-                "pipe_sustained_source": "profiles/r03_mfma_sustained.txt" if split_terms else None,
-            },
+            "roofline": roofline,
             "kernels": kernels[:args.kernel_rows],
             "kernels_measured_in": (f"warm-up steps 2..{args.warmup} (every launch between HIP events)" if warm_kernels
                                     else "timed region"),

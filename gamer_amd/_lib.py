@@ -150,6 +150,7 @@ _SIGNATURES = {
     "gamer_layernorm_bwd": [P, P, P, P, P, I, I, P, P, P, I, P],
     "gamer_attn_dense_fwd": [P, I, P, I, P, I, P, P, I, I, I, I, F, F, U, P, I, P, P],
     "gamer_attn_dense_bwd": [P, I, P, I, P, I, P, P, I, I, I, I, F, F, U, P, P, I, P, P, I, P, I, P, I, P],
+    "gamer_reload_env": [],
     "gamer_trie_logprobs": [P, L, P, P, P, P, P, I, I, P, P],
     "gamer_trie_advance": [P, P, P, P, P, I, P, P],
     "gamer_attn_decode": [P, I, P, I, P, I, P, P, P, I, I, I, I, P, I, I, I, I, I, F, P, P],

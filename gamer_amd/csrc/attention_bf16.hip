@@ -451,16 +451,13 @@ struct BrSmem {
     int32_t pad_[5];
 };
 static inline bool br_enabled() {
-    const char* e = getenv("GAMER_ATTN_RES");          // (the switch of the fp32 resident kernels: A/B runs)
-    return e ? atoi(e) != 0 : true;
+    static EnvSwitch sw("GAMER_ATTN_RES");             // (the switch of the fp32 resident kernels: A/B runs)
+    return sw.get(1) != 0;
 }
-static inline bool br_part_enabled(const char* name) {
-    const char* e = getenv(name);
-    return e ? atoi(e) != 0 : true;
-}
+#define GAMER_BR_PART(name) ([]() -> bool { static EnvSwitch sw(name); return sw.get(1) != 0; }())
 static inline int br_grid_cap() {
-    const char* e = getenv("GAMER_ATTN_RES_GRID");      // (read per call: tests force a few persistent workgroups to walk many units)
-    if (e && atoi(e) > 0) return atoi(e);
+    static EnvSwitch grid("GAMER_ATTN_RES_GRID");       // (tests force a few persistent workgroups to walk many units)
+    if (grid.get(0) > 0) return grid.get(0);
     static int cap[MAX_DEVICES] = {};
     int& c = cap[current_device()];
     if (c == 0) {
@@ -473,8 +470,8 @@ static inline int br_grid_cap() {
 // one query head per workgroup when whole pairs do not fill the CUs evenly (see res_split in attention_split_common.h)
 static inline int br_split(int n_pairs, int ways) {
     if (ways < 2) return 0;
-    const char* e = getenv("GAMER_ATTN_RES_SPLIT");
-    if (e) return atoi(e) != 0;
+    static EnvSwitch sp("GAMER_ATTN_RES_SPLIT");
+    if (sp.is_set()) return sp.get(0) != 0;
     const int ncu = br_grid_cap();
     const double whole = (double)((n_pairs + ncu - 1) / ncu), halves = 0.58 * (double)((ways * n_pairs + ncu - 1) / ncu);
     return halves < whole ? 1 : 0;
@@ -1430,7 +1427,7 @@ static int launch_bwd_b_variant(const bf16_t* q, int ldq, const bf16_t* k, int l
     hipLaunchKernelGGL((attn_bwd_dkv_b_kernel<G, DROP, SPAN, ORD>), grid, dim3(AB_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o,
                        lse, delta, kl, ql, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, span, ord);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd_bf16/dkv");
-    if (S <= BR_MAXKEYS && br_enabled() && br_part_enabled("GAMER_ATTN_RES_DQ")) {
+    if (S <= BR_MAXKEYS && br_enabled() && GAMER_BR_PART("GAMER_ATTN_RES_DQ")) {
         // dQ with K / V of a (sequence, kv head) resident in LDS
         const int split = br_split(B * nkv, G);
         const int n_units = B * nkv * (split ? G : 1);

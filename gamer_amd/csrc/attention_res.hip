@@ -1734,7 +1734,7 @@ static int launch_dkv_r_variant(const float* q, int ldq, const float* k, int ldk
     }
     const int n_pairs = B * nkv;
     const int grid = n_pairs < res_grid_cap() ? n_pairs : res_grid_cap();
-    if (G == 2 && res_part_enabled("GAMER_ATTN_RES_DKV2")) {
+    if (G == 2 && GAMER_RES_PART("GAMER_ATTN_RES_DKV2")) {
         // two heads per wave (the element-wise work of one beside the products of the other)
         const size_t shmem2 = sizeof(DkvR2Smem);
         static bool attr2_dev[MAX_DEVICES] = {};

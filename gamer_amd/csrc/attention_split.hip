@@ -1453,7 +1453,7 @@ static int launch_bwd_s_variant(const float* q, int ldq, const float* k, int ldk
         return 0;
     }
     if (ds_work == nullptr) {
-        if (h2 && res_enabled() && S <= 2048 && res_part_enabled("GAMER_ATTN_RES_DQ")) {
+        if (h2 && res_enabled() && S <= 2048 && GAMER_RES_PART("GAMER_ATTN_RES_DQ")) {
             // K / V of a (sequence, kv head) resident in LDS (attention_res.hip)
             const int rc_dq = launch_dq_res(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop,
                                             seed, dq, lddq, ro, delta_ready, t_attn_amax, st);
@@ -1492,8 +1492,8 @@ static int launch_bwd_s_variant(const float* q, int ldq, const float* k, int ldk
     };
     // (the resident dK/dV kernel takes whole pairs: when they do not fill the CUs evenly - per-GPU batch 128: 384 pairs on 256 CUs -
     // the tiled kernel below is faster than either half-filled rounds or pairs split over two workgroups; measured)
-    if (h2 && ds_work == nullptr && res_enabled() && S <= 2048 && res_part_enabled("GAMER_ATTN_RES_DKV") &&
-        (res_fill(B * nkv) >= 0.85 || getenv("GAMER_ATTN_RES_SPLIT") != nullptr))
+    if (h2 && ds_work == nullptr && res_enabled() && S <= 2048 && GAMER_RES_PART("GAMER_ATTN_RES_DKV") &&
+        (res_fill(B * nkv) >= 0.85 || res_split_forced()))
         // Q / dO of a (sequence, head, query block) resident in LDS, key tiles from a queue (attention_res.hip)
         return launch_dkv_res(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv,
                               lddv, ro, t_amax_out, t_attn_amax, st);

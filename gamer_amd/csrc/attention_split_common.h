@@ -220,17 +220,15 @@ struct AttnAmax { const uint32_t* q; const uint32_t* k; const uint32_t* v; const
 // ---- attention_res.hip: the H2 kernels with K / V of a (sequence, kv head) resident in LDS ------------------------------------------
 // GAMER_ATTN_RES=0 keeps every call on the tiled kernels of attention_split.hip (A/B runs); default on
 static inline bool res_enabled() {
-    const char* e = getenv("GAMER_ATTN_RES");          // (read per call: tests switch it inside one process)
-    return e ? atoi(e) != 0 : true;
+    static EnvSwitch sw("GAMER_ATTN_RES");             // (cached: gamer_reload_env() after a change inside the process)
+    return sw.get(1) != 0;
 }
-static inline bool res_part_enabled(const char* name) {      // GAMER_ATTN_RES_DQ / _DKV = 0: that kernel stays tiled (A/B runs)
-    const char* e = getenv(name);
-    return e ? atoi(e) != 0 : true;
-}
+// GAMER_ATTN_RES_DQ / _DKV / _DKV2 = 0: that kernel stays tiled (A/B runs)
+#define GAMER_RES_PART(name) ([]() -> bool { static EnvSwitch sw(name); return sw.get(1) != 0; }())
 // persistent workgroups: one per CU (GAMER_ATTN_RES_GRID overrides)
 static inline int res_grid_cap() {
-    const char* e = getenv("GAMER_ATTN_RES_GRID");      // (read per call: tests force a few persistent workgroups to walk many units)
-    if (e && atoi(e) > 0) return atoi(e);
+    static EnvSwitch grid("GAMER_ATTN_RES_GRID");       // (tests force a few persistent workgroups to walk many units)
+    if (grid.get(0) > 0) return grid.get(0);
     static int cap[MAX_DEVICES] = {};
     int& c = cap[current_device()];
     if (c == 0) {
@@ -245,12 +243,13 @@ static inline int res_grid_cap() {
 // units three full rounds at ~0.58 of a pair's time each (the split units stage the shared operand once more).  GAMER_ATTN_RES_SPLIT=0/1 forces.
 static inline int res_split(int n_pairs, int ways) {
     if (ways < 2) return 0;
-    const char* e = getenv("GAMER_ATTN_RES_SPLIT");
-    if (e) return atoi(e) != 0;
+    static EnvSwitch sp("GAMER_ATTN_RES_SPLIT");
+    if (sp.is_set()) return sp.get(0) != 0;
     const int ncu = res_grid_cap();
     const double whole = (double)((n_pairs + ncu - 1) / ncu), halves = 0.58 * (double)((ways * n_pairs + ncu - 1) / ncu);
     return halves < whole ? 1 : 0;
 }
+static inline bool res_split_forced() { static EnvSwitch sp("GAMER_ATTN_RES_SPLIT"); return sp.is_set(); }
 // share of the CU-rounds that whole-pair units keep busy
 static inline double res_fill(int n_pairs) {
     const int ncu = res_grid_cap();

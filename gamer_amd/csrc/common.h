@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/gamer_hip.h"
 
@@ -39,6 +40,29 @@ static inline int current_device() {
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- environment switches (A/B runs, tests) ---------------------------------------------------------------------------------
+// Read ONCE per process, not per launch (a step issues hundreds of launches and the kernel choice must not change under a running
+// step because another thread called setenv).  gamer_reload_env() starts a new epoch: every switch is read again at its next use -
+// what tests and the A/B tools call after they change os.environ inside the process.
+unsigned env_epoch();                                   // (prep.hip)
+struct EnvSwitch {
+    const char* name;
+    unsigned seen = 0;                                   // epoch of the cached value (epochs start at 1)
+    bool present = false;
+    int val = 0;
+    explicit EnvSwitch(const char* n) : name(n) {}
+    void sync() {
+        const unsigned e = env_epoch();
+        if (seen == e) return;
+        const char* s = getenv(name);
+        present = s != nullptr;
+        val = s ? atoi(s) : 0;
+        seen = e;
+    }
+    bool is_set() { sync(); return present; }
+    int get(int dflt) { sync(); return present ? val : dflt; }
+};
 
 // ---- device helpers -----------------------------------------------------------------------
 constexpr int WAVE = 64;

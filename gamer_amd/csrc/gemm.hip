@@ -1444,6 +1444,12 @@ extern "C" int gamer_debug_gemm_stamp(void* p) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamp), &v, sizeof(v));
 }
 
+// the diagnostic builds' switches (stamps, one LDS stage, ping-pong) rule out the epilogue forms
+static inline bool diag_build_switches() {
+    static EnvSwitch stamp("GAMER_GEMM_STAMP"), nbuf("GAMER_GEMM_NBUF");
+    return stamp.is_set() || nbuf.is_set();
+}
+static inline bool diag_pp_switch() { static EnvSwitch pp("GAMER_GEMM_PP"); return pp.is_set(); }
 static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     GAMER_CHECK_ARG(d, "gamer_gemm_f32: null descriptor");
     GAMER_CHECK_ARG(d->A && d->B && d->C, "gamer_gemm_f32: null matrix pointer");
@@ -1507,13 +1513,13 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
                                      d->N == (d->qk_nq + 2 * d->qk_nkv) * 64 && d->N % BN == 0 && d->ldc % 4 == 0 &&
                                      aligned16(d->C) && aligned16(d->qk_q_rot) && aligned16(d->qk_k_rot) &&
                                      (!d->qk_bias_q || (d->qk_bias_k && d->qk_bias_v && d->qk_act_idx)) &&
-                                     !getenv("GAMER_GEMM_STAMP") && !getenv("GAMER_GEMM_NBUF")),
+                                     !diag_build_switches()),
                     "gamer_gemm_f32: the q|k|v epilogue needs a Linear-forward layout, one group, M %% 128 == 0 (M=%d), "
                     "N = (nq + 2 nkv) * 64 a multiple of 128 (N=%d), alpha = 1 and no other epilogue", d->M, d->N);
     GAMER_CHECK_ARG(!d->rowdot_out || (d->rowdot_other && d->rowdot_S > 0 && d->group_mode == 0 && d->groups == 1 &&
                                        !d->resid && !d->accumulate && d->M % BM == 0 && d->N % BN == 0 &&
                                        d->M % d->rowdot_S == 0 && d->ldc % 4 == 0 && aligned16(d->rowdot_other) &&
-                                       aligned16(d->C) && !getenv("GAMER_GEMM_STAMP") && !getenv("GAMER_GEMM_NBUF")),
+                                       aligned16(d->C) && !diag_build_switches()),
                     "gamer_gemm_f32: the row-dot epilogue needs full 128 x 128 tiles (M=%d N=%d), one group, ldc %% 4 == 0",
                     d->M, d->N);
     GAMER_CHECK_ARG(!d->resid || (d->group_mode == 0 && !d->accumulate && a_kc && b_kc && d->ldc % 4 == 0 &&
@@ -1547,7 +1553,7 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
             GAMER_CHECK_ARG(d->wgrad_ws_floats >= need && aligned16(d->wgrad_ws),
                             "gamer_gemm_f32: wgrad_ws holds %lld floats, this weight gradient needs %lld (chunks x tiles x 16384)",
                             (long long)d->wgrad_ws_floats, (long long)need);
-            GAMER_CHECK_ARG(!getenv("GAMER_GEMM_PP"), "gamer_gemm_f32: the deterministic weight gradient is not built for the ping-pong form");
+            GAMER_CHECK_ARG(!diag_pp_switch(), "gamer_gemm_f32: the deterministic weight gradient is not built for the ping-pong form");
         }
         // three-product form with the chunk workspace: the 256 x 256-tile kernel (csrc/gemm_wg.hip; same partial tiles, same bits)
         const int rc = (split == 3 && p.wgrad_ws && gemm_wg_eligible(d, a_kc, b_kc)) ? launch_gemm_wg(d, st)

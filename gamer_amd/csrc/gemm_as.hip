@@ -352,8 +352,8 @@ gemm_as_kernel(const AsParams p) {
 static std::atomic<long long> g_as_launches{0};
 
 static inline bool gemm_as_enabled() {
-    const char* e = getenv("GAMER_GEMM_AS");             // (read per call: tests and A/B runs switch it inside one process)
-    return e ? atoi(e) != 0 : true;
+    static EnvSwitch sw("GAMER_GEMM_AS");                // (cached: gamer_reload_env() after a change inside the process)
+    return sw.get(1) != 0;
 }
 
 // Does this descriptor take the activation-stationary kernel?  A k-contiguous with K a multiple of 64 up to 256, packed weight pieces,
@@ -364,10 +364,11 @@ bool gemm_as_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint
     if (d->group_mode != 0 || d->resid || d->qk_q_rot) return false;
     // (a workgroup takes 128 rows: below ~16 k rows the launch leaves most CUs idle and the tile kernel is the better fit;
     // GAMER_GEMM_AS_MIN_M lowers the bar for tests)
-    const char* mm = getenv("GAMER_GEMM_AS_MIN_M");
-    if (d->K % 64 != 0 || d->K < 64 || d->K > 256 || d->M < (mm ? atoi(mm) : 16384)) return false;
+    static EnvSwitch min_m("GAMER_GEMM_AS_MIN_M");
+    if (d->K % 64 != 0 || d->K < 64 || d->K > 256 || d->M < min_m.get(16384)) return false;
     if (d->a_rs % 4 != 0 || d->ldc % 4 != 0 || !aligned16(d->C) || !aligned16(b_planes)) return false;
     if (d->groups != 1 && (!d->group_offsets || d->strideC != 0)) return false;
+    if (d->groups == 1 && d->group_offsets) return false;      // (a one-group row window: the tile kernel honours it, this one would take all M rows)
     if (b_kc) {
         if (d->accumulate || d->rowdot_out || d->sw_gu || d->b_rs % 4 != 0) return false;
         // (grouped: the experts' gate|up projection at d_in = 256: 1.37 -> 1.30 ms, W is 1 MB per 128 rows there; the injecting layers'
@@ -380,8 +381,8 @@ bool gemm_as_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint
     // faster than the tile kernel; the row-dot and SwiGLU-backward epilogues not (o_proj 0.59 -> 0.65 ms, down projection 1.28 ->
     // 1.31): their inputs are requested in the epilogue of every 32-column slab and waited for there, and requesting them before the
     // slab's MFMAs spills (256 registers: 1.30 -> 2.2 ms).  They stay on the tile kernel unless GAMER_GEMM_AS_RC=2 (tests).
-    const char* rc = getenv("GAMER_GEMM_AS_RC");
-    const int rc_mode = rc ? atoi(rc) : 1;
+    static EnvSwitch rc("GAMER_GEMM_AS_RC");
+    const int rc_mode = rc.get(1);
     if (rc_mode == 0) return false;
     if (d->K != 256 || d->N % 4 != 0 || d->b_ks % 4 != 0) return false;
     if ((d->sw_gu || d->rowdot_out) && rc_mode < 2) return false;
@@ -409,8 +410,8 @@ int launch_gemm_as(const gamer_gemm_desc* d, const uint16_t* b_planes, bool b_kc
     const int kp = d->K / 64;
     const size_t shmem = (size_t)(AS_DEPTH == 2 ? 3 : 2) * 2 * kp * AS_PANEL * sizeof(bf16_t);
     // eight waves per workgroup for the wide ungrouped Linear forwards (q|k|v, head), four otherwise (see the kernel)
-    const char* wv = getenv("GAMER_GEMM_AS_WAVES");
-    const int nw = wv ? (atoi(wv) == 8 ? 8 : 4) : ((b_kc && d->groups == 1 && d->N >= 512 && AS_WAVES == 4) ? 8 : AS_WAVES);
+    static EnvSwitch wv("GAMER_GEMM_AS_WAVES");
+    const int nw = wv.is_set() ? (wv.get(4) == 8 ? 8 : 4) : ((b_kc && d->groups == 1 && d->N >= 512 && AS_WAVES == 4) ? 8 : AS_WAVES);
     const dim3 grid((d->M + 32 * nw - 1) / (32 * nw) + (p.group_offsets ? d->groups : 0));
 #define GAMER_LAUNCH_AS_W(KPV, WRCV, EPIV, NWV)                                                                               \
     do {                                                                                                                      \

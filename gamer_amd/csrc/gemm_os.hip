@@ -254,8 +254,8 @@ gemm_os_kernel(const OsParams p) {
 static std::atomic<long long> g_os_launches{0};
 
 static inline bool gemm_os_enabled() {
-    const char* e = getenv("GAMER_GEMM_OS");              // (read per call: tests and A/B runs switch it inside one process)
-    return e ? atoi(e) != 0 : true;
+    static EnvSwitch sw("GAMER_GEMM_OS");                 // (cached: gamer_reload_env() after a change inside the process)
+    return sw.get(1) != 0;
 }
 
 // Does this descriptor take the output-stationary kernel?  (plain input gradient: A k-contiguous, B = W [K][256] row-contiguous with
@@ -264,8 +264,9 @@ bool gemm_os_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint
     if (!gemm_os_enabled() || !a_kc || b_kc || !b_planes || !d->amax_a || !d->amax_b) return false;
     if (d->group_mode != 0 || d->accumulate || d->resid || d->rowdot_out || d->qk_q_rot || d->sw_gu) return false;
     if (d->groups != 1 && (!d->group_offsets || d->strideC != 0 || d->amax_c)) return false;      // (grouped: the experts' gate|up at d_in = 256)
-    const char* mm = getenv("GAMER_GEMM_OS_MIN_M");
-    if (d->N != OS_N || d->K < 4 || d->M < (mm ? atoi(mm) : 16384)) return false;
+    if (d->groups == 1 && d->group_offsets) return false;      // (a one-group row window: stays on the tile kernel, which honours it)
+    static EnvSwitch min_m("GAMER_GEMM_OS_MIN_M");
+    if (d->N != OS_N || d->K < 4 || d->M < min_m.get(16384)) return false;
     if (d->a_rs % 4 != 0 || d->b_ks % 4 != 0 || d->ldc % 4 != 0 || !aligned16(d->C) || !aligned16(b_planes)) return false;
     if (d->a_rs < ((d->K + 3) & ~3)) return false;                   // (the clamped 16-byte loads stay inside a row of dY)
     if (d->amax_c && d->amax_c_col0 % 4 != 0) return false;

@@ -325,8 +325,8 @@ gemm_wg_kernel(const WgParams p) {
 static std::atomic<long long> g_wg_launches{0};
 
 static inline int gemm_wg_mode() {
-    const char* e = getenv("GAMER_GEMM_WG");              // (read per call: tests and A/B runs switch it inside one process)
-    return e ? atoi(e) : 1;                               // 0 off, 1 the shapes it is faster on, 2 every shape it can compute
+    static EnvSwitch sw("GAMER_GEMM_WG");                 // (cached: gamer_reload_env() after a change inside the process)
+    return sw.get(1);                                     // 0 off, 1 the shapes it is faster on, 2 every shape it can compute
 }
 
 // Does this weight gradient take the large-tile kernel?  Three-product form, deterministic chunk workspace, both operands

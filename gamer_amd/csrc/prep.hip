@@ -3,10 +3,13 @@
 // ref:SeqRec/models/generative/Qwen3Multi/model.py:573-630,691-741,
 // ref:SeqRec/models/generative/Qwen3Moe/FFN.py:63-68.
 #include "common.h"
+#include <atomic>
 
 namespace gamer {
 
 static thread_local char g_err[512] = {0};
+static std::atomic<unsigned> g_env_epoch{1};
+unsigned env_epoch() { return g_env_epoch.load(std::memory_order_acquire); }
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -297,6 +300,7 @@ check_labels_kernel(const int64_t* __restrict__ labels, int64_t n, int V, int ig
 using namespace gamer;
 
 extern "C" int gamer_abi_version(void) { return GAMER_ABI_VERSION; }
+extern "C" int gamer_reload_env(void) { gamer::g_env_epoch.fetch_add(1, std::memory_order_acq_rel); return 0; }
 extern "C" const char* gamer_last_error(void) { return gamer::g_err; }
 
 extern "C" int gamer_router_fwd(const int64_t* ids, const int64_t* attn_mask, const int64_t* actions,

@@ -499,7 +499,14 @@ class Engine:
         self._norm_out_table = None                 # (addresses, device array) of the RMSNorm weight gradients in backward order
         self.fuse_swiglu_bwd = os.environ.get("GAMER_FUSE_SWIGLU_BWD", "1") != "0"     # (A/B switch; split3 only)
         self.ordered_embedding_grad = os.environ.get("GAMER_EMBEDDING_ATOMICS", "0") == "0"   # (1: the float-atomics scatter)
+        self._check_deterministic_embedding()
         self._saved = None
+
+    def _check_deterministic_embedding(self):
+        V = self.cfg.vocab_size
+        if self.ordered_embedding_grad and V > 8191 and self.deterministic:
+            raise RuntimeError(f"Engine(deterministic=True): the ordered embedding gradient takes at most 8191 vocabulary rows (V = {V}); "
+                               "the float-atomics scatter it would fall back to is not reproducible")
 
     # ------------------------------------------------------------------------------------------
     def init_weights(self, seed: int = 0):
@@ -1020,9 +1027,7 @@ class Engine:
             norm_bwd(xs[0], W.ln1, t3, H, G.ln1, True, branch=(self._seed(l - 1, 5), ws.slot) if l > 0 else None)
             if layer_done is not None:
                 layer_done(l)
-        if self.ordered_embedding_grad and V > 8191 and self.deterministic:
-            raise RuntimeError(f"Engine(deterministic=True): the ordered embedding gradient takes at most 8191 vocabulary rows (V = {V}); "
-                               "the float-atomics scatter it would fall back to is not reproducible")
+        self._check_deterministic_embedding()        # (raised in __init__ already: nothing has been written when it fires there)
         if self.ordered_embedding_grad and V <= 8191:
             # the scatter-add of the embedding gradient in a fixed order: a stable counting sort of the tokens by id, then sums in
             # token order (no float atomics: with the ordered weight gradients and table gradients every gradient of the step

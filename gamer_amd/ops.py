@@ -33,6 +33,33 @@ def _chk(t: torch.Tensor, dtype, name: str):
 
 
 # ----------------------------------------------------------------------------------------------
+def reload_env():
+    """The library caches its GAMER_* kernel switches (one read per process): call this after changing os.environ in-process."""
+    call("gamer_reload_env")
+
+
+class env_switches:
+    """`with env_switches(GAMER_GEMM_AS=0): ...` - set GAMER_* kernel switches for a block inside a running process (tests, A/B
+    tools) and have the library read them again on entry and exit."""
+
+    def __init__(self, **kw):
+        self.kw = {k: str(v) for k, v in kw.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+        reload_env()
+        return self
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        reload_env()
+
+
 def router_fwd(ids, attn_mask, actions, behavior_lut, num_positions, pad_id, eos_id, out: dict):
     B, S = ids.shape
     _chk(ids, torch.int64, "input_ids")
@@ -667,7 +694,7 @@ def _load_tune_file():
     import json
     out = {}
     for path in (_WGRAD_SHIPPED, _WGRAD_TUNE_FILE):
-        if path == _WGRAD_SHIPPED and os.environ.get("GAMER_WGRAD_IGNORE_SHIPPED"):      # (tools/wgrad_table.py re-measures)
+        if path == _WGRAD_SHIPPED and os.environ.get("GAMER_WGRAD_IGNORE_SHIPPED", "0") not in ("", "0"):      # (tools/wgrad_table.py re-measures)
             continue
         if path and os.path.exists(path):
             try:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GAMER_ABI_VERSION 8
+#define GAMER_ABI_VERSION 9
 #define GAMER_AMAX_WORDS 256      /* words of one maximum slot (1 KB): see gamer_absmax_f32 */
 
 /* bf16 activations of the AMP variant (the reference's --bf16 run, ref:SeqRec/tasks/train_SMB_decoder.py:114-118,
@@ -40,6 +40,10 @@ typedef uint16_t gamer_bf16;
 int gamer_abi_version(void);
 /* Thread-local message for the last <0 / >0 return of any entry point. */
 const char* gamer_last_error(void);
+/* The GAMER_* environment switches that select between kernels of one entry point (INTEGRATION.md lists them) are read once per
+ * process and cached; after changing one inside a running process (tests, A/B tools) call this to have them read again.
+ * Not on the reference's path (it has no such switches).  ABI version 9. */
+int gamer_reload_env(void);
 
 /* ------------------------------------------------------------------------------------------
  * Router + mask predicates + expert lists (integer work).

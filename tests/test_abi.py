@@ -50,7 +50,7 @@ def test_exports_every_declared_symbol(lib):
     assert len(protos) >= 25
     for name in protos:
         assert hasattr(lib, name), f"{name} declared in gamer_hip.h but not exported"
-    assert lib.gamer_abi_version() == 8
+    assert lib.gamer_abi_version() == 9
 
 
 def test_ctypes_signatures_match_header(lib):

@@ -15,26 +15,15 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
+from gamer_amd import ops  # noqa: E402
+
 
 def _helpers():
     import test_ops_gpu as T
     return T
 
 
-class _env:
-    def __init__(self, **kw):
-        self.kw = {k: str(v) for k, v in kw.items()}
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kw}
-        os.environ.update(self.kw)
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+_env = ops.env_switches          # (sets the switches and has the library re-read them: they are cached per process)
 
 
 @pytest.mark.parametrize("grid,split", [(0, None), (3, 0), (3, 1), (5, None)])

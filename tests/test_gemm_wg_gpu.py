@@ -16,20 +16,7 @@ from gamer_amd import _lib, ops  # noqa: E402
 DEV = "cuda"
 
 
-class _env:
-    def __init__(self, **kw):
-        self.kw = {k: str(v) for k, v in kw.items()}
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kw}
-        os.environ.update(self.kw)
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+_env = ops.env_switches          # (sets the switches and has the library re-read them: they are cached per process)
 
 
 def _launches():

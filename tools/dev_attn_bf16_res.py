@@ -38,6 +38,7 @@ for name, kl, ql, od in (("self", r["kl_self"], None, None), ("cross", r["kl_cro
         res = {}
         for form in ("0", "1"):
             os.environ["GAMER_ATTN_RES"] = form
+            ops.reload_env()          # (the library caches its switches)
             o = torch.full((T, nq * 64), float("nan"), device=dev, dtype=bf); lse = torch.full((B, nq, S), float("nan"), device=dev)
             fwd = lambda: ops.attn_fwd_bf16(q, nq * 64, k, nkv * 64, v, qkv.shape[1], kl, ql, B, S, nq, nkv, 0.125, p, 7, o, lse, order=od)
             fwd(); torch.cuda.synchronize()

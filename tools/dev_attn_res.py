@@ -45,6 +45,7 @@ with ops.amax_reuse(everything=True):
             res = {}
             for form in ("0", "1"):
                 os.environ["GAMER_ATTN_RES"] = form
+                ops.reload_env()          # (the library caches its switches)
                 o = torch.full((T, nq * 64), float("nan"), device=dev); lse = torch.full((B, nq, S), float("nan"), device=dev)
                 fwd = lambda: ops.attn_fwd_split(q, nq * 64, k, nkv * 64, v, qkv.shape[1], kl, ql, re_, B, S, nq, nkv, 0.125, p, 7, o, lse, order=od, h2=True)
                 fwd(); torch.cuda.synchronize()

@@ -20,6 +20,7 @@ def timed(name, *a):
     s.record(); r = orig(name, *a); e.record(); rec.append((s, e)); return r
 for form in ("0", "1"):
     os.environ["GAMER_GEMM_AS"] = form
+    ops.reload_env()          # (the library caches its switches)
     for it in range(3):
         if it == 2: ops.call = timed; rec.clear()
         eng.forward(batch["input_ids"], batch["attention_mask"], batch["actions"], labels=batch["labels"], train=True)

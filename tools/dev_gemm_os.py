@@ -32,6 +32,7 @@ for name, N_out, ldy in (("qkv", 768, 768), ("head", 1041, 1056), ("gu-like", 10
     with ops.f32_matmul("split3"), cache:
         for form in ("0", "1"):
             os.environ["GAMER_GEMM_OS"] = form
+            ops.reload_env()          # (the library caches its switches)
             dx = torch.empty(T, H, device=dev)
             run = lambda: ops.linear_dgrad(dy, ldy, W, H, dx, H, T, N_out, H)
             cache.reset(); run(); cache.reset(); run()

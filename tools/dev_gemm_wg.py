@@ -44,6 +44,7 @@ for name, N, K, ldy, E in SHAPES:
             res = {}
             for form in ("0", "1"):
                 os.environ["GAMER_GEMM_WG"] = form
+                ops.reload_env()          # (the library caches its switches)
                 dW = torch.zeros(E * N, K, device=dev)
                 run = lambda: ops.linear_wgrad(dy, ldy, x, K, dW, K, T, N, K, kchunk=kchunk, **grp)
                 run()
