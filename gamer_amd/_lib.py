@@ -58,6 +58,7 @@ class GemmDesc(C.Structure):
         ("amax_c", c_void_p), ("amax_c_col0", c_int),
         ("wgrad_ws", c_void_p), ("wgrad_ws_floats", c_int64),
         ("sw_gu", c_void_p), ("sw_ld", c_int64),
+        ("group_div", c_int), ("sw_tbl", c_void_p),
     ]
 
 
@@ -136,6 +137,12 @@ _SIGNATURES = {
     "gamer_swiglu_bwd": [P, P, P, L, F, U, P],
     "gamer_swiglu_fwd_ld": [P, L, I, I, F, U, P, P],
     "gamer_swiglu_bwd_ld": [P, L, I, I, P, F, U, P],
+    "gamer_swiglu_fwd_ld_tbl": [P, L, I, I, F, U, P, P, P, P],
+    "gamer_swiglu_bwd_ld_tbl": [P, L, I, I, P, F, U, P, P, P],
+    "gamer_inject_table_fwd": [P, P, L, I, I, I, I, I, P, P],
+    "gamer_segment_colsum_ws_floats": [I, I, I],
+    "gamer_segment_colsum": [P, L, I, I, P, I, P, L, P, P],
+    "gamer_inject_table_bwd": [P, P, P, L, I, I, I, I, I, P, P, P, P],
     "gamer_silu_gate_fwd": [P, P, L, P, P, F, U, P],
     "gamer_silu_gate_bwd": [P, P, P, L, P, P, F, U, P],
     "gamer_check_labels": [P, L, I, I, P, P],
@@ -191,6 +198,7 @@ def load(build_if_missing: bool = False) -> C.CDLL:
         fn.restype = c_int
         fn.argtypes = args
     lib.gamer_embedding_bwd_ordered_ws_bytes.restype = c_int64      # (a size, not an error code: call it on the library object)
+    lib.gamer_segment_colsum_ws_floats.restype = c_int64
     _lib = lib
     return lib
 

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgamer_hip.so")
 TORCH_LIB = os.path.join(LIBDIR, "libgamer_torch.so")          # TORCH_LIBRARY(gamer, ...) wrappers over the C ABI
-SOURCES = ["prep.hip", "elementwise.hip", "gemm.hip", "gemm_as.hip", "gemm_wg.hip", "gemm_os.hip", "gemm_bf16.hip", "attention.hip", "attention_split.hip", "attention_res.hip", "attention_bf16.hip", "optim.hip", "decode.hip",
+SOURCES = ["prep.hip", "inject.hip", "elementwise.hip", "gemm.hip", "gemm_as.hip", "gemm_wg.hip", "gemm_os.hip", "gemm_bf16.hip", "attention.hip", "attention_split.hip", "attention_res.hip", "attention_bf16.hip", "optim.hip", "decode.hip",
            "modules.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++20", "-Wall", "-Wno-unused-function"]
 

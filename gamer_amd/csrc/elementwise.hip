@@ -1470,7 +1470,9 @@ swiglu_bwd_kernel(TA* __restrict__ g, TA* __restrict__ u, const TA* __restrict__
 template <typename TA>
 __global__ void __launch_bounds__(EW_THREADS)
 swiglu_fwd_ld_kernel(const TA* __restrict__ gu, int64_t ld, int T, int I4, float p, uint64_t seed, TA* __restrict__ hm,
-                     uint32_t* __restrict__ amax_out) {
+                     uint32_t* __restrict__ amax_out, const float* __restrict__ tbl, const int32_t* __restrict__ row_group) {
+    // tbl != nullptr (fp32 only): row t's gate | up values are gu[t] + tbl[row_group[t]] ([groups][2 I]: the share of the projection
+    // that depends on the row's group only - gamer_inject_table_fwd); the sums are used, not stored
     __shared__ uint32_t amax_lds[4];
     uint32_t am = 0;
     const DropoutRng rng(p, seed);
@@ -1478,8 +1480,13 @@ swiglu_fwd_ld_kernel(const TA* __restrict__ gu, int64_t ld, int T, int I4, float
     const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6, nwaves = (gridDim.x * EW_THREADS) >> 6;
     for (int t = wave; t < T; t += nwaves) {
         const TA* row = gu + (int64_t)t * ld;
+        const float* trow = tbl ? tbl + (int64_t)row_group[t] * 8 * I4 : nullptr;
         for (int c = lane; c < I4; c += 64) {
-            const float4 a = ld4(row + 4 * c), b = ld4(row + 4 * (I4 + c));
+            float4 a = ld4(row + 4 * c), b = ld4(row + 4 * (I4 + c));
+            if (trow) {
+                const float4 ta = *reinterpret_cast<const float4*>(trow + 4 * c), tb = *reinterpret_cast<const float4*>(trow + 4 * (I4 + c));
+                a.x += ta.x; a.y += ta.y; a.z += ta.z; a.w += ta.w; b.x += tb.x; b.y += tb.y; b.z += tb.z; b.w += tb.w;
+            }
             const int64_t i = (int64_t)t * I4 + c;
             float m[4];
             rng.mult4((uint32_t)i, m);
@@ -1498,7 +1505,8 @@ swiglu_fwd_ld_kernel(const TA* __restrict__ gu, int64_t ld, int T, int I4, float
 template <typename TA>
 __global__ void __launch_bounds__(EW_THREADS)
 swiglu_bwd_ld_kernel(TA* __restrict__ gu, int64_t ld, int T, int I4, const TA* __restrict__ dhm, float p, uint64_t seed,
-                     uint32_t* __restrict__ amax_g, uint32_t* __restrict__ amax_u) {
+                     uint32_t* __restrict__ amax_g, uint32_t* __restrict__ amax_u, const float* __restrict__ tbl,
+                     const int32_t* __restrict__ row_group) {
     __shared__ uint32_t amax_lds[2][4];
     uint32_t amg = 0, amu = 0;
     const DropoutRng rng(p, seed);
@@ -1506,9 +1514,15 @@ swiglu_bwd_ld_kernel(TA* __restrict__ gu, int64_t ld, int T, int I4, const TA* _
     const int wave = (blockIdx.x * EW_THREADS + threadIdx.x) >> 6, nwaves = (gridDim.x * EW_THREADS) >> 6;
     for (int t = wave; t < T; t += nwaves) {
         TA* row = gu + (int64_t)t * ld;
+        const float* trow = tbl ? tbl + (int64_t)row_group[t] * 8 * I4 : nullptr;
         for (int c = lane; c < I4; c += 64) {
             const int64_t i = (int64_t)t * I4 + c;
-            const float4 a = ld4(row + 4 * c), b = ld4(row + 4 * (I4 + c)), d = ld4(dhm + 4 * i);
+            float4 a = ld4(row + 4 * c), b = ld4(row + 4 * (I4 + c));
+            const float4 d = ld4(dhm + 4 * i);
+            if (trow) {
+                const float4 ta = *reinterpret_cast<const float4*>(trow + 4 * c), tb = *reinterpret_cast<const float4*>(trow + 4 * (I4 + c));
+                a.x += ta.x; a.y += ta.y; a.z += ta.z; a.w += ta.w; b.x += tb.x; b.y += tb.y; b.z += tb.z; b.w += tb.w;
+            }
             float m[4];
             rng.mult4((uint32_t)i, m);
             const float d0 = m[0] * d.x, d1 = m[1] * d.y, d2 = m[2] * d.z, d3 = m[3] * d.w;
@@ -2282,12 +2296,13 @@ extern "C" int gamer_swiglu_bwd_bf16(gamer_bf16* g, gamer_bf16* u, const gamer_b
 
 template <typename TA>
 static int swiglu_fwd_ld_impl(const char* name, const TA* gu, int64_t ld, int T, int I, float p_drop, uint64_t seed, TA* hm,
-                              void* stream) {
+                              void* stream, const float* tbl = nullptr, const int32_t* row_group = nullptr) {
+    GAMER_CHECK_ARG((tbl == nullptr) == (row_group == nullptr) && aligned16(tbl), "%s: tbl (16-byte aligned) and row_group come together", name);
     GAMER_CHECK_ARG(gu && hm && T > 0 && I > 0 && I % 4 == 0 && ld >= 2 * (int64_t)I && ld % 4 == 0 && p_drop >= 0.f && p_drop < 1.f,
                     "%s: bad arguments (T=%d I=%d ld=%lld)", name, T, I, (long long)ld);
     GAMER_CHECK_ARG(aligned_vec4<TA>(gu) && aligned_vec4<TA>(hm), "%s: pointers must be aligned to four elements", name);
     hipLaunchKernelGGL(swiglu_fwd_ld_kernel<TA>, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), gu, ld, T, I / 4,
-                       p_drop, seed, hm, take_amax_sink().out[0]);
+                       p_drop, seed, hm, take_amax_sink().out[0], tbl, row_group);
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }
@@ -2300,18 +2315,29 @@ extern "C" int gamer_swiglu_fwd_ld_bf16(const gamer_bf16* gu, int64_t ld, int T,
 }
 template <typename TA>
 static int swiglu_bwd_ld_impl(const char* name, TA* gu, int64_t ld, int T, int I, const TA* dhm, float p_drop, uint64_t seed,
-                              void* stream) {
+                              void* stream, const float* tbl = nullptr, const int32_t* row_group = nullptr) {
+    GAMER_CHECK_ARG((tbl == nullptr) == (row_group == nullptr) && aligned16(tbl), "%s: tbl (16-byte aligned) and row_group come together", name);
     GAMER_CHECK_ARG(gu && dhm && T > 0 && I > 0 && I % 4 == 0 && ld >= 2 * (int64_t)I && ld % 4 == 0 && p_drop >= 0.f && p_drop < 1.f,
                     "%s: bad arguments (T=%d I=%d ld=%lld)", name, T, I, (long long)ld);
     GAMER_CHECK_ARG(aligned_vec4<TA>(gu) && aligned_vec4<TA>(dhm), "%s: pointers must be aligned to four elements", name);
     const AmaxSink sink = take_amax_sink();
     hipLaunchKernelGGL(swiglu_bwd_ld_kernel<TA>, dim3(grid_for_waves(T)), dim3(EW_THREADS), 0, ST(stream), gu, ld, T, I / 4, dhm,
-                       p_drop, seed, sink.out[0], sink.out[1]);
+                       p_drop, seed, sink.out[0], sink.out[1], tbl, row_group);
     GAMER_CHECK_LAUNCH(name);
     return 0;
 }
 extern "C" int gamer_swiglu_bwd_ld(float* gu, int64_t ld, int T, int I, const float* dhm, float p_drop, uint64_t seed, void* stream) {
     return swiglu_bwd_ld_impl<float>("gamer_swiglu_bwd_ld", gu, ld, T, I, dhm, p_drop, seed, stream);
+}
+extern "C" int gamer_swiglu_fwd_ld_tbl(const float* gu, int64_t ld, int T, int I, float p_drop, uint64_t seed, float* hm,
+                                       const float* tbl, const int32_t* row_group, void* stream) {
+    GAMER_CHECK_ARG(tbl && row_group, "gamer_swiglu_fwd_ld_tbl: null table");
+    return swiglu_fwd_ld_impl<float>("gamer_swiglu_fwd_ld_tbl", gu, ld, T, I, p_drop, seed, hm, stream, tbl, row_group);
+}
+extern "C" int gamer_swiglu_bwd_ld_tbl(float* gu, int64_t ld, int T, int I, const float* dhm, float p_drop, uint64_t seed,
+                                       const float* tbl, const int32_t* row_group, void* stream) {
+    GAMER_CHECK_ARG(tbl && row_group, "gamer_swiglu_bwd_ld_tbl: null table");
+    return swiglu_bwd_ld_impl<float>("gamer_swiglu_bwd_ld_tbl", gu, ld, T, I, dhm, p_drop, seed, stream, tbl, row_group);
 }
 extern "C" int gamer_swiglu_bwd_ld_bf16(gamer_bf16* gu, int64_t ld, int T, int I, const gamer_bf16* dhm, float p_drop, uint64_t seed,
                                         void* stream) {

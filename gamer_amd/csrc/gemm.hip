@@ -269,6 +269,8 @@ struct GemmParams {
     // SwiGLU-backward epilogue (EPI == 4): C = d(hm) is NOT stored; with m = the dropout multiplier of flat element row N + col,
     // sw_gu[row][col] <- m C b silu'(a), sw_gu[row][N + col] <- m C silu(a) for a, b = the gate / up values stored there
     float* sw_gu; int64_t sw_ld;
+    int group_div;                 // MODE 0 with group_offsets: group g multiplies with B + (g / group_div) * strideB (>= 1)
+    const float* sw_tbl;           // EPI == 4: [groups][2 N] added to the gate | up values of group g's rows before the backward
 };
 
 // SPLIT == 3 scales a whole operand TENSOR by one power of two, so a row of A whose largest magnitude lies more than 2^16 below
@@ -414,6 +416,7 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
     const float* Bsrc = p.B;    // the fp32 values of this tile's B (Bp may point at their packed pieces)
     float* Cp = p.C;
     int64_t ws_block = 0;       // MODE 1: index of this workgroup's partial tile in p.wgrad_ws
+    int tile_group = 0;         // MODE 0: the row group of this tile (EPI 4: its row of sw_tbl)
     if (MODE == 0) {
         const int mt = L / p.n_tiles;
         col0 = (L % p.n_tiles) * BN;
@@ -438,7 +441,8 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
         row_end = seg_end;
         kbeg = 0;
         kend = p.K;
-        Bp += (int64_t)g * p.strideB;
+        tile_group = g;
+        Bp += (int64_t)(g / p.group_div) * p.strideB;
         // SPLIT == 3 with pre-cut parameters: `b_planes` holds, at the SAME offsets as B, 16 bytes per four elements = their four
         // h0 pieces and their four h1 pieces (gamer_split2h_planes_multi) - the loads below stay what they are, the B half of the
         // cut becomes two 8-byte LDS stores
@@ -1040,6 +1044,13 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
 #pragma unroll
             for (int it = 0; it < 16; ++it) pre_x[it] = *reinterpret_cast<const float4*>(p.resid + (int64_t)pre_rc[it] * p.ldc + col);
         }
+        // (EPI 4 with sw_tbl: every row of the tile is in ONE group and the lane's four columns are fixed - two quads per tile)
+        float4 tb_g = make_float4(0.f, 0.f, 0.f, 0.f), tb_u = tb_g;
+        if (EPI == 4 && p.sw_tbl) {
+            const float* tb = p.sw_tbl + (int64_t)tile_group * 2 * p.N + col;
+            tb_g = *reinterpret_cast<const float4*>(tb);
+            tb_u = *reinterpret_cast<const float4*>(tb + p.N);
+        }
         auto pre_sw = [&](int it0) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
@@ -1104,7 +1115,9 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
                 const int row = row_first + 4 * it;
                 float* ga = p.sw_gu + (int64_t)row * p.sw_ld + col;
                 float* ua = ga + p.N;
-                const float4 a = pre_x[EPI == 4 ? (it & 7) : 0], b = pre_b[EPI == 4 ? (it & 7) : 0];
+                float4 a = pre_x[EPI == 4 ? (it & 7) : 0], b = pre_b[EPI == 4 ? (it & 7) : 0];
+                a.x += tb_g.x; a.y += tb_g.y; a.z += tb_g.z; a.w += tb_g.w;
+                b.x += tb_u.x; b.y += tb_u.y; b.z += tb_u.z; b.w += tb_u.w;
                 float m[4];
                 rng.mult4((uint32_t)(((int64_t)row * p.N + col) >> 2), m);
                 const float d0 = m[0] * v.x, d1 = m[1] * v.y, d2 = m[2] * v.z, d3 = m[3] * v.w;
@@ -1174,10 +1187,24 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
             }
     } else {
         float emax = 0.f;
+        if (EPI == 4 && p.sw_tbl != nullptr) {
+            // a partial tile of the SwiGLU-backward epilogue with a row table (at most one per row group): the table row is added to
+            // the tile's gate | up values IN PLACE first (a rolled loop: anything more inside `emit`, which is unrolled 64 times,
+            // keeps the compiler from unrolling it and sends the accumulators to scratch), then the plain epilogue runs on the sums
+            const float* tb0 = p.sw_tbl + (int64_t)tile_group * 2 * p.N;
+            const int nr = min(BM, row_end - row0), nc = min(BN, p.N - col0);
+            for (int i = threadIdx.x; i < nr * nc; i += GEMM_THREADS) {
+                const int rr = row0 + i / nc, cc = col0 + i % nc;
+                float* ga = p.sw_gu + (int64_t)rr * p.sw_ld + cc;
+                ga[0] += tb0[cc];
+                ga[p.N] += tb0[p.N + cc];
+            }
+            __syncthreads();
+        }
         auto emit = [&](int row, int col, float v) {
             if (EPI == 4) {
                 float* ga = p.sw_gu + (int64_t)row * p.sw_ld + col;
-                const float a = ga[0], b = ga[p.N];
+                float a = ga[0], b = ga[p.N];
                 const int64_t e = (int64_t)row * p.N + col;
                 const DropoutRng rng(p.p_drop, p.seed);
                 float m[4];
@@ -1488,6 +1515,10 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     p.amax_c = d->amax_c; p.amax_c_col0 = d->amax_c_col0;
     p.wgrad_ws = nullptr;
     p.sw_gu = d->sw_gu; p.sw_ld = d->sw_ld;
+    p.group_div = d->group_div > 1 ? d->group_div : 1; p.sw_tbl = d->sw_tbl;
+    GAMER_CHECK_ARG(d->group_div <= 1 || (d->group_mode == 0 && d->group_offsets && d->groups % d->group_div == 0),
+                    "gamer_gemm_f32: group_div = %d needs group_mode 0, group_offsets and groups (%d) a multiple of it", d->group_div, d->groups);
+    GAMER_CHECK_ARG(!d->sw_tbl || (d->sw_gu && aligned16(d->sw_tbl)), "gamer_gemm_f32: sw_tbl is an option of the SwiGLU-backward epilogue (sw_gu)");
     GAMER_CHECK_ARG(!d->sw_gu || (split == 3 && d->group_mode == 0 && !d->accumulate && !d->resid && !d->rowdot_out && !d->qk_q_rot &&
                                   d->alpha == 1.f && d->N % 4 == 0 && d->sw_ld >= 2 * (int64_t)d->N && d->sw_ld % 4 == 0 &&
                                   aligned16(d->sw_gu) && d->p_drop >= 0.f && d->p_drop < 1.f),

@@ -361,7 +361,7 @@ static inline bool gemm_as_enabled() {
 // (input gradient of a layer with 256 output features): K = 256, store / accumulate, row-dot or SwiGLU-backward epilogue.
 bool gemm_as_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint16_t* b_planes) {
     if (!gemm_as_enabled() || !a_kc || !b_planes || !d->amax_b) return false;
-    if (d->group_mode != 0 || d->resid || d->qk_q_rot) return false;
+    if (d->group_mode != 0 || d->resid || d->qk_q_rot || d->group_div > 1 || d->sw_tbl) return false;
     // (a workgroup takes 128 rows: below ~16 k rows the launch leaves most CUs idle and the tile kernel is the better fit;
     // GAMER_GEMM_AS_MIN_M lowers the bar for tests)
     static EnvSwitch min_m("GAMER_GEMM_AS_MIN_M");

@@ -262,7 +262,7 @@ static inline bool gemm_os_enabled() {
 // packed pieces, one group, no epilogue, enough rows to fill the chip)
 bool gemm_os_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint16_t* b_planes) {
     if (!gemm_os_enabled() || !a_kc || b_kc || !b_planes || !d->amax_a || !d->amax_b) return false;
-    if (d->group_mode != 0 || d->accumulate || d->resid || d->rowdot_out || d->qk_q_rot || d->sw_gu) return false;
+    if (d->group_mode != 0 || d->accumulate || d->resid || d->rowdot_out || d->qk_q_rot || d->sw_gu || d->group_div > 1) return false;
     if (d->groups != 1 && (!d->group_offsets || d->strideC != 0 || d->amax_c)) return false;      // (grouped: the experts' gate|up at d_in = 256)
     if (d->groups == 1 && d->group_offsets) return false;      // (a one-group row window: stays on the tile kernel, which honours it)
     static EnvSwitch min_m("GAMER_GEMM_OS_MIN_M");

@@ -498,6 +498,13 @@ class Engine:
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._norm_out_table = None                 # (addresses, device array) of the RMSNorm weight gradients in backward order
         self.fuse_swiglu_bwd = os.environ.get("GAMER_FUSE_SWIGLU_BWD", "1") != "0"     # (A/B switch; split3 only)
+        # fp32 forms: the injecting layers' gate|up projection runs on the 256 hidden columns only; the behaviour-embedding columns'
+        # share (NB + 1 different rows per expert) is a table added where gate|up are consumed (csrc/inject.hip).  Rows are then
+        # sorted by (expert, behaviour).  GAMER_SPLIT_INJECT=0: the reference's concatenated [T, 320] input (A/B runs).
+        nb1 = cfg.num_behavior + 1
+        self.split_inject = bool(self.dtype != "bf16" and os.environ.get("GAMER_SPLIT_INJECT", "1") != "0" and
+                                 cfg.behavior_injection_decoder and cfg.num_experts * nb1 <= 64 and nb1 <= 16 and
+                                 cfg.behavior_embedding_dim % 4 == 0 and cfg.behavior_embedding_dim <= 256)
         self.ordered_embedding_grad = os.environ.get("GAMER_EMBEDDING_ATOMICS", "0") == "0"   # (1: the float-atomics scatter)
         self._check_deterministic_embedding()
         self._saved = None
@@ -650,7 +657,20 @@ class Engine:
             act_zero_col = S - 1
         if act_zero_col is not None:
             r["act_idx"][:, act_zero_col] = 0
-        ops.expert_lists(r["expert"], E, ws.perm, ws.slot, ws.offsets, ws.work)
+        NB1 = cfg.num_behavior + 1
+        if self.split_inject:
+            # rows sorted by (expert, behaviour): group g = expert * NB1 + behaviour; the experts' segments are every NB1-th offset
+            ws.grp_key = ws._buf("grp_key", (B, S), torch.int32)
+            ws.grp_offsets = ws._buf("grp_offsets", (E * NB1 + 1,), torch.int32)
+            ws.row_group = ws._buf("row_group", (T,), torch.int32)
+            torch.add(r["beh_idx"], r["expert"], alpha=NB1, out=ws.grp_key)
+            ops.expert_lists(ws.grp_key, E * NB1, ws.perm, ws.slot, ws.grp_offsets, ws._buf("grp_work", ((B + 1) * E * NB1,), torch.int32))
+            ws.offsets.copy_(ws.grp_offsets[::NB1])
+            torch.index_select(ws.grp_key.view(-1), 0, ws.perm, out=ws.row_group)
+            if self._amax is not None:
+                self._amax.register(*[self.W[l].gu for l in cfg.behavior_injection_decoder])
+        else:
+            ops.expert_lists(r["expert"], E, ws.perm, ws.slot, ws.offsets, ws.work)
         span_self = span_cross = pos_ids = None
         if self.variant == "session":
             # Qwen3SessionMulti/model.py:784-806: both masks are rebuilt from session_ids on every forward
@@ -778,14 +798,23 @@ class Engine:
                 x_last = torch.empty(B, H, **f32)
                 ops.gemm(hm, I, 1, W.down[e * H:(e + 1) * H], I, 1, x_last, H, B, H, I, resid=xl)
                 break
-            ops.rmsnorm_fwd(xcur, W.ln3, eps, A["hin"], din, ws.slot)
-            if W.inject:
-                ops.rowtable_fwd(W.beh, r["beh_idx"], A["hin"], din, H, ws.slot)
             grp = dict(groups=E, group_offsets=ws.offsets)
-            # gate_proj and up_proj of the position's expert in ONE grouped GEMM against the stacked [2 I, din] weight (FFN.py:25-27:
-            # both read the same input): A["gu"][:, :I] = gate, [:, I:] = up
-            ops.linear_fwd(A["hin"], din, Wm.gu, din, A["gu"], 2 * I, T, 2 * I, din, strideB=2 * I * din, **grp)
-            ops.swiglu_fwd_ld(A["gu"], 2 * I, T, I, p_res, self._seed(l, 4), A["hm"])
+            if W.inject and self.split_inject:
+                # K = 256 of the 320 input columns; the embedding columns' share comes from the (expert, behaviour) table
+                hin = A["hin"].view(-1)[:T * H].view(T, H)
+                ops.rmsnorm_fwd(xcur, W.ln3, eps, hin, H, ws.slot)
+                tb = ws._buf((f"l{l}_" if train else "l_") + "inject_tbl", (E * NB1, 2 * I))
+                ops.inject_table_fwd(W.beh, W.gu, din, H, E, 2 * I, tb)
+                ops.linear_fwd(hin, H, Wm.gu, din, A["gu"], 2 * I, T, 2 * I, H, strideB=2 * I * din, **grp)
+                ops.swiglu_fwd_ld_tbl(A["gu"], 2 * I, T, I, p_res, self._seed(l, 4), A["hm"], tb, ws.row_group)
+            else:
+                ops.rmsnorm_fwd(xcur, W.ln3, eps, A["hin"], din, ws.slot)
+                if W.inject:
+                    ops.rowtable_fwd(W.beh, r["beh_idx"], A["hin"], din, H, ws.slot)
+                # gate_proj and up_proj of the position's expert in ONE grouped GEMM against the stacked [2 I, din] weight (FFN.py:25-27:
+                # both read the same input): A["gu"][:, :I] = gate, [:, I:] = up
+                ops.linear_fwd(A["hin"], din, Wm.gu, din, A["gu"], 2 * I, T, 2 * I, din, strideB=2 * I * din, **grp)
+                ops.swiglu_fwd_ld(A["gu"], 2 * I, T, I, p_res, self._seed(l, 4), A["hm"])
             xnext = ws.x[l + 1][0] if l + 1 < cfg.num_hidden_layers else ws.x_final
             # down projection: rows are in expert-sorted order, the epilogue scatters them back to token
             # order through perm while adding the residual and applying dropout (FFN.py:25-27, model.py:241)
@@ -961,9 +990,15 @@ class Engine:
             grp = dict(groups=E, group_offsets=ws.offsets)
             xlast = xs[2] if W.cross else xs[1]
             # ---- experts ----   (t0 = d out_sorted, written by the norm backward that completed dx)
+            split_inj = W.inject and self.split_inject
+            tb = ws._buf(f"l{l}_inject_tbl", (E * NB1, 2 * I)) if split_inj else None
             with hold(t0):
                 ops.linear_wgrad(t0, H, A["hm"], I, G.down, I, T, H, I, strideC=H * I, **grp)
-                if fuse_swiglu_bwd:
+                if fuse_swiglu_bwd and split_inj:
+                    # (rows grouped by (expert, behaviour): a tile's rows share one table row; NB1 consecutive groups share an expert)
+                    ops.gemm(t0, H, 1, W.down, 1, I, ws.dhm, I, T, I, H, strideB=H * I, p_drop=p_res, seed=self._seed(l, 4),
+                             swiglu_bwd=(A["gu"], 2 * I), groups=E * NB1, group_offsets=ws.grp_offsets, group_div=NB1, sw_tbl=tb)
+                elif fuse_swiglu_bwd:
                     # the down projection's input gradient with the SwiGLU backward in its epilogue: d(hm) = t0 W_down never goes
                     # to memory, A["gu"] <- d gate | d up (gamer_gemm_desc.sw_gu; ws.dhm is only the descriptor's C)
                     if bf16:
@@ -975,14 +1010,31 @@ class Engine:
                 else:
                     dgrad(t0, H, W.down, WT.down if bf16 else None, I, ws.dhm, I, H, I, strideB=H * I, **grp)
             if not fuse_swiglu_bwd:
-                ops.swiglu_bwd_ld(A["gu"], 2 * I, T, I, ws.dhm, p_res, self._seed(l, 4))    # gu <- d gate | d up
-            with hold(A["gu"]):
-                ops.linear_wgrad(A["gu"], 2 * I, A["hin"], din, G.gu, din, T, 2 * I, din, strideC=2 * I * din, **grp)
-                dgrad(A["gu"], 2 * I, W.gu, WT.gu if bf16 else None, din, ws.dhin, din, 2 * I, din, strideB=2 * I * din, **grp)
-            if W.inject:
-                ops.rowtable_bwd(ws.dhin, din, H, r["beh_idx"], G.beh, ws.slot, partial=NP)
-            norm_bwd(xlast, W.ln3, ws.dhin, din, G.ln3, True, ws.slot,
-                     branch=None if W.cross else (self._seed(l, 1), None))
+                if split_inj:
+                    ops.swiglu_bwd_ld_tbl(A["gu"], 2 * I, T, I, ws.dhm, p_res, self._seed(l, 4), tb, ws.row_group)
+                else:
+                    ops.swiglu_bwd_ld(A["gu"], 2 * I, T, I, ws.dhm, p_res, self._seed(l, 4))    # gu <- d gate | d up
+            if split_inj:
+                hin = A["hin"].view(-1)[:T * H].view(T, H)
+                dhin = ws.dhin.view(-1)[:T * H].view(T, H)
+                with hold(A["gu"]):
+                    ops.linear_wgrad(A["gu"], 2 * I, hin, H, G.gu, din, T, 2 * I, H, strideC=2 * I * din, **grp)
+                    dgrad(A["gu"], 2 * I, W.gu, None, din, dhin, H, 2 * I, H, strideB=2 * I * din, **grp)
+                # the embedding columns' weight gradient and the embedding gradient from the (expert, behaviour) sums of d(gate|up)
+                seg = ws._buf("inject_segsum", (E * NB1, 2 * I))
+                seg_ws = ws._buf("inject_seg_ws", (ops.segment_colsum_ws_floats(T, 2 * I, E * NB1),))
+                ops.segment_colsum(A["gu"], 2 * I, T, 2 * I, ws.grp_offsets, E * NB1, seg_ws, seg)
+                ops.inject_table_bwd(seg, W.beh, W.gu, din, H, E, 2 * I, G.gu, G.beh,
+                                     ws._buf("inject_scratch", (NB1 * E * cfg.behavior_embedding_dim,)))
+                norm_bwd(xlast, W.ln3, dhin, H, G.ln3, True, ws.slot, branch=None if W.cross else (self._seed(l, 1), None))
+            else:
+                with hold(A["gu"]):
+                    ops.linear_wgrad(A["gu"], 2 * I, A["hin"], din, G.gu, din, T, 2 * I, din, strideC=2 * I * din, **grp)
+                    dgrad(A["gu"], 2 * I, W.gu, WT.gu if bf16 else None, din, ws.dhin, din, 2 * I, din, strideB=2 * I * din, **grp)
+                if W.inject:
+                    ops.rowtable_bwd(ws.dhin, din, H, r["beh_idx"], G.beh, ws.slot, partial=NP)
+                norm_bwd(xlast, W.ln3, ws.dhin, din, G.ln3, True, ws.slot,
+                         branch=None if W.cross else (self._seed(l, 1), None))
             # ---- cross attention ----
             if W.cross:
                 C, GC = W.cross_attn, G.cross_attn

@@ -295,6 +295,32 @@ class amax_reuse:
                      stream_ptr())
                 self._plane_keys = {(p_, "dense", n_) for (p_, n_) in self._wkeys}
 
+    def register(self, *tensors):
+        """Dense parameter tensors (inside the first stable range) that GEMMs only ever read VIEWS of (the injecting layers'
+        gate|up weight: its 256 hidden columns): measured and cut with the others from the next pass on (plane_parent)."""
+        if not self.stable_ranges:
+            return
+        b0, n0 = self.stable_ranges[0]
+        for t in tensors:
+            p, n = t.data_ptr(), t.numel()
+            if (b0 <= p and p + 4 * n <= b0 + n0 and n % 4 == 0 and t.is_contiguous() and
+                    not any(p_ < p + 4 * n and p < p_ + 4 * n_ for (p_, n_) in self._wkeys)):
+                self._wkeys.append((p, n))
+                self._wdev = t.device
+
+    def plane_parent(self, p, geom):
+        """Slot of the maximum of the dense parameter tensor with piece planes that contains the operand view (p, geom) - or None
+        (also when the view IS such a tensor: the exact-key path handles that)."""
+        key = self._key(p, geom)
+        if key in self._plane_keys or len(key) == 3:
+            return None
+        batch, stride, rows, cols, ld = geom
+        end = p + 4 * ((batch - 1) * stride + (rows - 1) * ld + cols)
+        for (p_, kind, n_) in self._plane_keys:
+            if p_ <= p and end <= p_ + 4 * n_:
+                return self.slots.get((p_, kind, n_))
+        return None
+
     def hold(self, *tensors):
         cache = self
 
@@ -507,10 +533,12 @@ def set_f32_matmul(mode) -> int:
 
 def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=False, groups=1, group_mode=0,
          group_offsets=None, strideB=0, strideC=0, kchunk=0, resid=None, row_map=None, p_drop=0.0, seed=0,
-         rowdot=None, qknorm=None, c_amax=None, swiglu_bwd=None):
+         rowdot=None, qknorm=None, c_amax=None, swiglu_bwd=None, group_div=0, sw_tbl=None):
     """C[m][n] (=|+=) alpha * sum_k A(m,k) B(n,k); see gamer_gemm_desc in include/gamer_hip.h.  bf16 operands go to
     gamer_gemm_bf16 (k-contiguous x k-contiguous, or the token-major wgrad form; see gamer_gemm_bf16_desc)."""
     if A.dtype == torch.bfloat16:
+        if group_div > 1 or sw_tbl is not None:
+            raise RuntimeError("group_div / sw_tbl are options of the fp32 GEMM")
         return _gemm_bf16(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha, accumulate, groups, group_mode,
                           group_offsets, strideB, strideC, kchunk, resid, row_map, p_drop, seed, rowdot, qknorm, swiglu_bwd)
     d = GemmDesc()
@@ -550,8 +578,10 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
         # (gu, ld): C = d(hm) is consumed by the SwiGLU backward in the epilogue - gu <- d gate | d up - and never stored
         gu, ld_gu = swiglu_bwd
         d.sw_gu, d.sw_ld = ptr(gu), int(ld_gu)
+        d.sw_tbl = ptr(sw_tbl)
         if _AMAX_REUSE is not None and F32_MATMUL_TERMS == 3 and ld_gu == 2 * N:
             d.amax_c, d.amax_c_col0 = _AMAX_REUSE.preset(gu, (1, 0, 1, M * ld_gu, M * ld_gu)), 0
+    d.group_div = int(group_div)
     if group_mode == 1 and DETERMINISTIC_WGRAD:
         n_chunks = (K + kchunk - 1) // kchunk + (groups if group_offsets is not None else 0)
         need = n_chunks * ((M + 127) // 128) * ((N + 127) // 128) * 16384
@@ -561,11 +591,19 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
         # operand extents: A(m, k) at A + m a_rs + k a_ks, B(n, k) at B + n b_rs + k b_ks (one of each stride pair is 1)
         ga = (M, K, a_rs) if a_ks == 1 else (K, M, a_ks)
         gb = (N, K, b_rs) if b_ks == 1 else (K, N, b_ks)
-        nb = groups if (group_mode == 0 and groups > 1) else 1
+        nb = (groups // max(1, int(group_div))) if (group_mode == 0 and groups > 1) else 1
         d.amax_a = absmax_slot(A, 1, 0, *ga)
         geom_b = (nb, strideB if nb > 1 else 0) + gb
-        d.amax_b = absmax_slot(Bm, *geom_b)
         c = _AMAX_REUSE
+        parent = c.plane_parent(Bm.data_ptr(), geom_b) if (c is not None and c.planes is not None and group_mode == 0) else None
+        if parent is not None:
+            # B is a VIEW (some columns of every row) of a parameter tensor with piece planes: the parent's maximum scales it (>= the
+            # view's own; the planes were cut with it) and its pieces lie at the same offsets as the values
+            d.amax_b = parent
+            d.b_planes = c.planes.data_ptr() + (Bm.data_ptr() - c.stable_ranges[0][0])
+            call("gamer_gemm_f32_split", C.byref(d), 3, stream_ptr())
+            return
+        d.amax_b = absmax_slot(Bm, *geom_b)
         if c is not None and c.planes is not None and group_mode == 0 and c._key(Bm.data_ptr(), geom_b) in c._plane_keys:
             # B is a parameter tensor whose fp16 piece planes were built at the start of this pass (same scale as amax_b gives)
             d.b_planes = c.planes.data_ptr() + (Bm.data_ptr() - c.stable_ranges[0][0])      # packed pieces at B's offsets
@@ -960,6 +998,37 @@ def swiglu_bwd_ld(gu, ld, T, I, dhm, p, seed):
         geom = (1, 0, 1, T * ld, T * ld)
         _arm_sink((gu, geom, False), (gu, geom, True))
     call("gamer_swiglu_bwd_ld" + _sfx(gu), ptr(gu), ld, T, I, ptr(dhm), p, seed, stream_ptr())
+
+
+def swiglu_fwd_ld_tbl(gu, ld, T, I, p, seed, hm, tbl, row_group):
+    """hm = drop(silu(g) * u) with g | u = gu[t] + tbl[row_group[t]] (fp32; see gamer_inject_table_fwd)."""
+    _arm_sink((hm, (1, 0, 1, T * I, T * I), False))
+    call("gamer_swiglu_fwd_ld_tbl", ptr(gu), ld, T, I, p, seed, ptr(hm), ptr(tbl), ptr(row_group), stream_ptr())
+
+
+def swiglu_bwd_ld_tbl(gu, ld, T, I, dhm, p, seed, tbl, row_group):
+    if ld == 2 * I:
+        _arm_sink((gu, (1, 0, 1, T * ld, T * ld), False), (gu, (1, 0, 1, T * ld, T * ld), True))
+    call("gamer_swiglu_bwd_ld_tbl", ptr(gu), ld, T, I, ptr(dhm), p, seed, ptr(tbl), ptr(row_group), stream_ptr())
+
+
+def inject_table_fwd(Eb, W, ldw, col0, E, twoI, tbl):
+    """tbl [E * NB1, 2I] <- the behaviour-embedding share of the gate|up projection per (expert, behaviour) (gamer_inject_table_fwd)."""
+    NB1, EB = Eb.shape
+    call("gamer_inject_table_fwd", ptr(Eb), ptr(W), ldw, col0, E, twoI, NB1, EB, ptr(tbl), stream_ptr())
+
+
+def segment_colsum_ws_floats(rows, cols, nseg) -> int:
+    return int(_lib.load().gamer_segment_colsum_ws_floats(rows, cols, nseg))
+
+
+def segment_colsum(x, ld, rows, cols, offsets, nseg, ws, out):
+    call("gamer_segment_colsum", ptr(x), ld, rows, cols, ptr(offsets), nseg, ptr(ws), ws.numel(), ptr(out), stream_ptr())
+
+
+def inject_table_bwd(seg, Eb, W, ldw, col0, E, twoI, dW, dEb, scratch):
+    NB1, EB = Eb.shape
+    call("gamer_inject_table_bwd", ptr(seg), ptr(Eb), ptr(W), ldw, col0, E, twoI, NB1, EB, ptr(dW), ptr(dEb), ptr(scratch), stream_ptr())
 
 
 def silu_gate_fwd(a, gate, out, resid=None, p=0.0, seed=0):

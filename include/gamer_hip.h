@@ -253,6 +253,16 @@ typedef struct {
      * this descriptor): d(hm) never goes to memory.  amax_c (amax_c_col0 = 0) then receives max |d gate|, |d up|.  NULL = off. */
     float* sw_gu;
     int64_t sw_ld;
+    /* (ABI 9) group_mode 0 with group_offsets: several consecutive row groups share one B - group g multiplies with
+     * B + (g / group_div) * strideB.  The injecting layers' experts (ref:SeqRec/models/generative/Qwen3Moe/FFN.py:60-68) sort their
+     * rows by (expert, behaviour): group_div = num_behavior + 1 groups per expert.  0 / 1 = one B per group.  The 128 x 128 kernel
+     * only (the kernels of include-note "kernel choice" take descriptors with group_div <= 1). */
+    int group_div;
+    /* (ABI 9) with sw_gu: a table [groups][2 N] added to the gate | up values of group g's rows BEFORE the SwiGLU backward is
+     * evaluated on them - the share of the gate|up projection that depends on the row's group only (gamer_inject_table_fwd:
+     * the behaviour-embedding columns of the injecting layers), which gamer_swiglu_fwd_ld_tbl added on the fly in the forward
+     * without storing the sums.  NULL = off. */
+    const float* sw_tbl;
 } gamer_gemm_desc;
 
 int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);
@@ -597,6 +607,30 @@ int gamer_swiglu_bwd(float* g, float* u, const float* dhm, int64_t n, float p_dr
  * (pass the same word twice for the maximum of the whole [T][2 I] gradient).                                                    */
 int gamer_swiglu_fwd_ld(const float* gu, int64_t ld, int T, int I, float p_drop, uint64_t seed, float* hm, void* stream);
 int gamer_swiglu_bwd_ld(float* gu, int64_t ld, int T, int I, const float* dhm, float p_drop, uint64_t seed, void* stream);
+/* (ABI 9) The same two with a row table: row t's gate | up values are gu[t] + tbl[row_group[t]] (tbl [groups][2 I] fp32, row_group
+ * int32 [T]) - the sums are used, not stored.  The injecting layers of MyQwen3SparseMLP (ref:SeqRec/models/generative/Qwen3Moe/
+ * FFN.py:60-68) concatenate a behaviour embedding to the expert input; its share of gate|up depends on (expert, behaviour) only
+ * (gamer_inject_table_fwd), so the projection runs on the 256 hidden columns and the table row is added where the values are read. */
+int gamer_swiglu_fwd_ld_tbl(const float* gu, int64_t ld, int T, int I, float p_drop, uint64_t seed, float* hm,
+                            const float* tbl, const int32_t* row_group, void* stream);
+int gamer_swiglu_bwd_ld_tbl(float* gu, int64_t ld, int T, int I, const float* dhm, float p_drop, uint64_t seed,
+                            const float* tbl, const int32_t* row_group, void* stream);
+/* (ABI 9) The behaviour-embedding share of the injecting layers' gate|up projection (FFN.py:60-68: h = cat(x, Eb[beh]); gate|up =
+ * W_e h with W [E * 2I rows][ldw], the embedding columns at col0 .. col0 + EB - 1; plain fp32 FMA arithmetic, fixed summation orders):
+ *   gamer_inject_table_fwd   tbl[(e * NB1 + b) * 2I + n] = sum_j Eb[b][j] W[e * 2I + n][col0 + j]          (Eb [NB1][EB])
+ *   gamer_segment_colsum     out[s][c] = sum over the rows of segment s of x[row][c]; rows sorted by segment, offsets int32 [nseg + 1];
+ *                            ws: gamer_segment_colsum_ws_floats(rows, cols, nseg) floats of scratch
+ *   gamer_inject_table_bwd   with seg = the segment sums of d(gate|up) over the (expert, behaviour) row groups ([E * NB1][2I]):
+ *                            dW[e * 2I + n][col0 + j] += sum_b seg[e * NB1 + b][n] Eb[b][j],
+ *                            dEb[b][j] += sum_e sum_n seg[e * NB1 + b][n] W[e * 2I + n][col0 + j];  scratch: NB1 * E * EB floats
+ * Together they replace the [T, EB] columns of the expert input, of its gradient and gamer_rowtable_fwd / _bwd on them.           */
+int gamer_inject_table_fwd(const float* Eb, const float* W, int64_t ldw, int col0, int E, int twoI, int NB1, int EB, float* tbl,
+                           void* stream);
+int64_t gamer_segment_colsum_ws_floats(int rows, int cols, int nseg);
+int gamer_segment_colsum(const float* x, int64_t ld, int rows, int cols, const int32_t* offsets, int nseg, float* ws,
+                         int64_t ws_floats, float* out, void* stream);
+int gamer_inject_table_bwd(const float* seg, const float* Eb, const float* W, int64_t ldw, int col0, int E, int twoI, int NB1, int EB,
+                           float* dW, float* dEb, float* scratch, void* stream);
 int gamer_swiglu_fwd_ld_bf16(const gamer_bf16* gu, int64_t ld, int T, int I, float p_drop, uint64_t seed, gamer_bf16* hm,
                              void* stream);
 int gamer_swiglu_bwd_ld_bf16(gamer_bf16* gu, int64_t ld, int T, int I, const gamer_bf16* dhm, float p_drop, uint64_t seed,
