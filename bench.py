@@ -520,7 +520,7 @@ SECONDARY_LEGS = (
 )
 
 
-def decode_leg(users: int = 256, beams: int = 20, his: int = 100, catalogue: int = 20000, iters: int = 3, cpu_users: int = 1):
+def decode_leg(users: int = 256, beams: int = 20, his: int = 100, catalogue: int = 20000, iters: int = 4, cpu_users: int = 1):
     """BASELINE configs[4]'s shape on one GPU (ref:SeqRec/tasks/test_SMB_decoder.py:141-285): trie-
     constrained beam search of `users` users x `beams` beams over a 100-item history, 4 new tokens, shipped architecture, default
     product form.  Reports users/s, the prompt pass and the cached per-token step apart (a run with one new token = prompt pass +
@@ -542,7 +542,10 @@ def decode_leg(users: int = 256, beams: int = 20, his: int = 100, catalogue: int
 
     def timed(new_tokens):
         run = lambda: beam_search(eng, batch["input_ids"], batch["attention_mask"], batch["actions"], trie, beams, new_tokens)
-        out = run()
+        # three untimed runs: an evaluation decodes many batches of one shape, and from the third one on the cached per-token step is
+        # a hipGraph replay (gamer_amd/decode.py: _DecodeStatic) - the steady state is what is timed
+        for _ in range(3):
+            out = run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

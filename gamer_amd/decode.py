@@ -137,13 +137,36 @@ def trie_from_callable(fn, input_ids, max_new_tokens: int, device="cuda", pad_to
     return trie
 
 
+class _DecodeStatic:
+    """Buffers of the cached decode path at FIXED addresses, kept on the engine per (batch, prompt length, beams, new tokens, ...):
+    an evaluation run decodes many batches of one shape, and the per-token step - ~350 launches of a few microseconds each - is
+    captured into one hipGraph per step index once two sessions of the shape have run eagerly (kernel attributes set, weight
+    maxima registered), then replayed: the launches leave the host in one call instead of ~11 us each."""
+
+    def __init__(self):
+        self.kp: Dict[Tuple[int, str], torch.Tensor] = {}
+        self.vp: Dict[Tuple[int, str], torch.Tensor] = {}
+        self.gen = None
+        self.buf = None
+        self.small: Dict[str, torch.Tensor] = {}
+        self.graphs: Dict[int, "torch.cuda.CUDAGraph"] = {}
+        self.sessions = 0            # sessions of this shape that have run so far
+        self.sig = None              # state of the engine's maxima cache the graphs were captured against
+
+
+def _graphs_enabled() -> bool:
+    import os
+    return os.environ.get("GAMER_DECODE_GRAPH", "1") != "0"
+
+
 class DecodeSession:
     """K/V cache of one generation run + the single-token forward over it (model.py:118-121, 784-785).
 
     The prompt is run once per SAMPLE (HF expands it to num_beams copies first) and its keys / values are kept
     once per sample; only the generated positions are per beam.  ``step`` pushes one token per beam through the
     layers with the ordinary row kernels (norms, GEMMs with M = B*num_beams rows, SwiGLU) - all new tokens of a
-    step sit at the same position, hence in the same position-routed expert - and ``gamer_attn_decode``."""
+    step sit at the same position, hence in the same position-routed expert - and ``gamer_attn_decode``.
+    From the third session of a shape on the step is a hipGraph replay (``_DecodeStatic``; GAMER_DECODE_GRAPH=0: always eager)."""
 
     def __init__(self, engine, input_ids, attention_mask, actions, num_beams: int, max_new_tokens: int,
                  session_ids=None, extended_session_ids=None, reorder_cross_cache: bool = False):
@@ -164,19 +187,31 @@ class DecodeSession:
         self.B, self.L0 = input_ids.shape
         B, L0, nb = self.B, self.L0, num_beams
         self.N = N = B * nb
+        self.session = engine.variant == "session"
+        statics = engine.__dict__.setdefault("_decode_static", {})
+        key = (B, L0, nb, max_new_tokens, engine.variant, self.reorder_cross_cache, engine.matmul)
+        st = statics.get(key)
+        if st is None:
+            if len(statics) >= 4:                     # (a few shapes at most: the buffers of a shape are ~2.5 GB at 256 users)
+                statics.pop(next(iter(statics)))
+            st = statics[key] = _DecodeStatic()
+        self.st = st
         ids0 = input_ids.to(dev, torch.int64)
         am0 = attention_mask.to(dev, torch.int64)
         act0 = actions.to(dev, torch.int64)
         nq, nkv, dh = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         self.NQ, self.NKV = nq * dh, nkv * dh
         f32 = dict(dtype=torch.float32, device=dev)
-        self.kp: Dict[Tuple[int, str], torch.Tensor] = {}
-        self.vp: Dict[Tuple[int, str], torch.Tensor] = {}
+        self.kp, self.vp = st.kp, st.vp
 
         def sink(layer, kind, k, v):
-            self.kp[(layer, kind)] = k.clone()
-            self.vp[(layer, kind)] = v.contiguous()          # v is a column slice of the qkv buffer
-        self.session = engine.variant == "session"
+            kk = (layer, kind)
+            if kk not in st.kp:
+                st.kp[kk] = k.clone()
+                st.vp[kk] = v.contiguous().clone()       # v is a column slice of the qkv buffer
+            else:
+                st.kp[kk].copy_(k)
+                st.vp[kk].copy_(v)
         if self.session and (session_ids is None or extended_session_ids is None):
             raise ValueError("a session engine needs session_ids and extended_session_ids")
         skw = {}
@@ -190,42 +225,66 @@ class DecodeSession:
             engine.check_inputs()
         # last-row logits of every sample: the head ran on B rows, not on the whole prompt
         self.prefill_logits = engine.last_logits_buf
+
+        def keep(name, value):
+            """the step's small inputs at fixed addresses (the captured step reads them)"""
+            value = value.contiguous()
+            t = st.small.get(name)
+            if t is None or t.shape != value.shape or t.dtype != value.dtype:
+                st.small[name] = t = value.clone()
+            else:
+                t.copy_(value)
+            return t
         # masks of the new rows: self = kept keys; cross = kept keys of a lower level than the target behaviour
         # (the cached last mask row, model.py:603-617); no allowed key -> uniform over every key
         lv = act0[:, -1:]
-        self.ok_self = am0.to(torch.int32).contiguous()
+        self.ok_self = keep("ok_self", am0.to(torch.int32))
         ok_cross = (am0[:, :] != 0) & (act0 < lv)
+        self.pos_last = None
         if self.session:
             ok_cross &= sid0 < sid0[:, -1:]              # Qwen3SessionMulti/model.py:582-584, last prompt row
             # RoPE table row of the token generated at step t: the prompt's largest extended id + t
-            self.pos_last = ext0.max(dim=1).values.to(torch.int32).repeat_interleave(nb).contiguous()
+            self.pos_last = keep("pos_last", ext0.max(dim=1).values.to(torch.int32).repeat_interleave(nb))
         ok_cross[:, -1] = False
-        self.ok_cross = ok_cross.to(torch.int32).contiguous()
-        self.uniform_cross = (~ok_cross.any(1)).to(torch.int32).contiguous()
+        self.ok_cross = keep("ok_cross", ok_cross.to(torch.int32))
+        self.uniform_cross = keep("uniform_cross", (~ok_cross.any(1)).to(torch.int32))
         # router outputs of the generated tokens (router.py:158-195 in decode mode): behaviour index + 1 of the
         # target item's behaviour token, for the FFN injection and for the cross-attention biases
         beh = engine.lut[ids0[:, -1]].to(torch.int32) + 1
-        self.beh = beh.repeat_interleave(nb).contiguous()
-        self.gen = {key: (torch.zeros(N, max_new_tokens, self.NKV, **f32), torch.zeros(N, max_new_tokens, self.NKV, **f32))
-                    for key in self.kp}
-        H, I = cfg.hidden_size, cfg.intermediate_size
-        QKV = self.NQ + 2 * self.NKV
-        din_max = H + cfg.behavior_embedding_dim
-        self.buf = dict(x=[torch.empty(N, H, **f32) for _ in range(3)], h=torch.empty(N, H, **f32),
-                        qkv=torch.empty(N, QKV, **f32), q=torch.empty(N, self.NQ, **f32), k=torch.empty(N, self.NKV, **f32),
-                        ao=torch.empty(N, self.NQ, **f32), op=torch.empty(N, H, **f32), gate=torch.empty(N, H, **f32),
-                        t0=torch.empty(N, H, **f32), hin=torch.empty(N, din_max, **f32), gu=torch.empty(N, 2 * I, **f32),
-                        hm=torch.empty(N, I, **f32), xn=torch.empty(N, H, **f32),
-                        logits=torch.empty(N, engine.ws.ldl, **f32))
+        self.beh = keep("beh", beh.repeat_interleave(nb))
+        if st.gen is None:
+            st.gen = {kk: (torch.zeros(N, max_new_tokens, self.NKV, **f32), torch.zeros(N, max_new_tokens, self.NKV, **f32))
+                      for kk in self.kp}
+            H, I = cfg.hidden_size, cfg.intermediate_size
+            QKV = self.NQ + 2 * self.NKV
+            din_max = H + cfg.behavior_embedding_dim
+            st.buf = dict(x=[torch.empty(N, H, **f32) for _ in range(3)], h=torch.empty(N, H, **f32),
+                          qkv=torch.empty(N, QKV, **f32), q=torch.empty(N, self.NQ, **f32), k=torch.empty(N, self.NKV, **f32),
+                          ao=torch.empty(N, self.NQ, **f32), op=torch.empty(N, H, **f32), gate=torch.empty(N, H, **f32),
+                          t0=torch.empty(N, H, **f32), hin=torch.empty(N, din_max, **f32), gu=torch.empty(N, 2 * I, **f32),
+                          hm=torch.empty(N, I, **f32), xn=torch.empty(N, H, **f32),
+                          logits=torch.empty(N, engine.ws.ldl, **f32),
+                          gen_tmp=torch.empty(N, max(1, max_new_tokens - 1), self.NKV, **f32))
+            st.small["tok"] = torch.zeros(N, dtype=torch.int64, device=dev)
+            st.small["parent"] = torch.arange(N, dtype=torch.int64, device=dev)
+        # (stale generated rows of an earlier session are never read: gamer_attn_decode takes the number of valid positions)
+        self.gen, self.buf = st.gen, st.buf
+        self._pending_reorder = False
         self.t = 0
+        # the maxima cache as this session found it after the prompt pass: what a captured step was recorded against
+        am_ = engine._amax
+        self._sig = None if am_ is None else (len(am_._wkeys), am_.used, 0 if am_.planes is None else am_.planes.data_ptr())
+        if st.graphs and st.sig != self._sig:
+            st.graphs.clear()                       # (another weight set / slot layout: record again)
+            st.sessions = 0
+        st.sessions += 1
 
     def reorder(self, parent: torch.Tensor):
         """Beams were re-ordered: the generated part of the SELF cache follows its beam (the prompt part is shared);
-        the cross cache only with ``reorder_cross_cache`` (see __init__)."""
-        for key, (kg, vg) in self.gen.items():
-            if key[1] == "cross" and not self.reorder_cross_cache:
-                continue
-            self.gen[key] = (kg.index_select(0, parent), vg.index_select(0, parent))
+        the cross cache only with ``reorder_cross_cache`` (see __init__).  The rows move at the start of the next step
+        (in place, the positions generated so far only), so that the move is part of the captured step."""
+        self.st.small["parent"].copy_(parent)
+        self._pending_reorder = True
 
     @ops.scoped_f32_matmul(lambda self, *a: self.eng.matmul)
     @ops.scoped_amax(lambda self, *a: self.eng._amax)
@@ -234,14 +293,51 @@ class DecodeSession:
         (matmul="split3": runs inside the engine's maxima cache - the parameters keep the slots of the prompt pass, which
         measured them once (they cannot change during a generation), the producers of the step's activations hand their
         maxima to the GEMMs (gamer_amax_sink) - instead of two gamer_absmax_f32 launches per GEMM and token.)"""
+        st = self.st
+        st.small["tok"].copy_(tokens)
+        self.t += 1
+        t = self.t
+        reorder = self._pending_reorder
+        self._pending_reorder = False
+        if t >= 2 and not reorder:
+            st.small["parent"].copy_(torch.arange(self.N, dtype=torch.int64, device=tokens.device))
+        g = st.graphs.get(t)
+        if g is not None:
+            g.replay()
+            return self.buf["logits"]
+        if _graphs_enabled() and st.sessions >= 3 and tokens.is_cuda:
+            self.eng.rope(self.L0 + self.tmax)          # (cached tables: nothing may be built on the host during the capture)
+            if self.eng._amax is not None:
+                self.eng._amax.reserve(512)             # (a fresh slot pool is zero-filled at allocation: not inside the graph)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_body(t)
+            st.graphs[t] = g
+            st.sig = self._sig
+            g.replay()
+            return self.buf["logits"]
+        self._step_body(t)
+        return self.buf["logits"]
+
+    def _step_body(self, t: int):
         eng, cfg, b = self.eng, self.eng.cfg, self.buf
         N, B, nb, L0 = self.N, self.B, self.nb, self.L0
         H, I, E = cfg.hidden_size, cfg.intermediate_size, cfg.num_experts
         nq, nkv, NQ, NKV = cfg.num_attention_heads, cfg.num_key_value_heads, self.NQ, self.NKV
         QKV = NQ + 2 * NKV
         eps, scale = float(cfg.rms_norm_eps), float(cfg.head_dim) ** -0.5
-        self.t += 1
-        t = self.t
+        tokens, parent = self.st.small["tok"], self.st.small["parent"]
+        if t >= 2:
+            # the beams were re-ordered after the last step: the t - 1 generated positions follow them
+            for key, (kg, vg) in self.gen.items():
+                if key[1] == "cross" and not self.reorder_cross_cache:
+                    continue
+                tmp = b["gen_tmp"].view(-1)[:N * (t - 1) * NKV].view(N, t - 1, NKV)
+                torch.index_select(kg[:, :t - 1], 0, parent, out=tmp)
+                kg[:, :t - 1] = tmp
+                torch.index_select(vg[:, :t - 1], 0, parent, out=tmp)
+                vg[:, :t - 1] = tmp
         p = L0 + t - 1                                   # position of the new token
         cos, sin = eng.rope(L0 + self.tmax)
         pos_ids = None
@@ -251,7 +347,7 @@ class DecodeSession:
             cos, sin = cos[p:p + 1], sin[p:p + 1]
         e = p % cfg.num_positions + 1                    # position-routed expert (router.py:83-104), same for every row
         x, x1, x2 = b["x"]
-        ops.embedding_fwd(tokens.contiguous(), eng.params["model.embed_tokens.weight"], x)
+        ops.embedding_fwd(tokens, eng.params["model.embed_tokens.weight"], x)
 
         def attend(kind, layer, Wa, hin, xin, xout, act_idx):
             ops.linear_fwd(hin, H, Wa["qkv"], H, b["qkv"], QKV, N, QKV, H)
@@ -295,7 +391,6 @@ class DecodeSession:
         ops.rmsnorm_fwd(cur, eng.params["model.norm.weight"], eps, b["xn"])
         ops.linear_fwd(b["xn"], H, eng.params["model.embed_tokens.weight"], H, b["logits"], b["logits"].stride(0), N,
                        cfg.vocab_size, H)
-        return b["logits"]
 
 
 @torch.no_grad()

@@ -308,6 +308,12 @@ class amax_reuse:
                 self._wkeys.append((p, n))
                 self._wdev = t.device
 
+    def reserve(self, n):
+        """Make sure `n` more slots exist without another pool allocation (a pool is zero-filled when it is allocated: a
+        hipGraph capture must not contain that fill - replayed, it would wipe the maxima of everything measured before)."""
+        while len(self.pools) * 1024 - self.used < n and self.pools:
+            self.pools.append(torch.zeros(1024 * AMAX_WORDS, dtype=torch.int32, device=self.pools[0].device))
+
     def plane_parent(self, p, geom):
         """Slot of the maximum of the dense parameter tensor with piece planes that contains the operand view (p, geom) - or None
         (also when the view IS such a tensor: the exact-key path handles that)."""

@@ -459,3 +459,49 @@ def test_generate_takes_the_reference_callable_and_is_a_generation_mixin():
     model.generate(input_ids=ids, attention_mask=am, actions=act, max_new_tokens=4, prefix_allowed_tokens_fn=by_last_token,
                    num_beams=beams, num_return_sequences=beams)
     assert len(calls) == n_calls                             # the walk is cached on the callable
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reorder_cross", [False, True])
+def test_decode_step_graph_replay_equals_the_eager_step(reorder_cross, monkeypatch):
+    """From the third session of a shape on the cached per-token step is a hipGraph replay over buffers at fixed addresses
+    (gamer_amd/decode.py: _DecodeStatic).  Replayed sessions - on the prompts the graphs were captured with AND on other prompts of
+    the same shape - return the bits of the eager step (GAMER_DECODE_GRAPH=0), and still the reference's beams."""
+    from gamer_amd.config import Qwen3MultiConfig
+    from gamer_amd.decode import beam_search
+    from gamer_amd.engine import Engine
+    fx, meta, ocfg, sd = _load()
+    beams, cb = meta["beams"], meta["codebook"]
+    cfg = Qwen3MultiConfig(**meta["config"])
+    tb = 2
+    ids, am, act = _case(fx, tb)
+    trie = ItemTrie(synthetic.item_tokens(torch.from_numpy(fx["catalogue"]), tb, cb).tolist())
+    # a second batch of the same shape: the users in another order
+    rev = torch.arange(ids.shape[0] - 1, -1, -1)
+    ids2, am2, act2 = ids[rev], am[rev], act[rev]
+
+    def engine():
+        e = Engine(cfg, temperature=0.7)
+        e.load_state_dict(sd)
+        return e
+    monkeypatch.setenv("GAMER_DECODE_GRAPH", "0")
+    eng0 = engine()
+    ref1 = beam_search(eng0, ids, am, act, trie, beams, 4, reorder_cross_cache=reorder_cross)
+    ref2 = beam_search(eng0, ids2, am2, act2, trie, beams, 4, reorder_cross_cache=reorder_cross)
+    assert not eng0._decode_static[next(iter(eng0._decode_static))].graphs
+    monkeypatch.setenv("GAMER_DECODE_GRAPH", "1")
+    eng = engine()
+    outs = [beam_search(eng, ids, am, act, trie, beams, 4, reorder_cross_cache=reorder_cross) for _ in range(4)]
+    st = eng._decode_static[next(iter(eng._decode_static))]
+    assert sorted(st.graphs) == [1, 2, 3]                       # captured in the third session, replayed in the fourth
+    for seq, sc in outs:
+        assert torch.equal(seq, ref1[0]) and torch.equal(sc, ref1[1])
+    seq2, sc2 = beam_search(eng, ids2, am2, act2, trie, beams, 4, reorder_cross_cache=reorder_cross)
+    assert torch.equal(seq2, ref2[0]) and torch.equal(sc2, ref2[1])
+    # an engine forward of another shape in between (the maxima cache is reset and refilled): the graphs stay valid or are dropped and
+    # recorded again - either way the beams are the eager ones
+    eng.forward(ids[:2], am[:2], act[:2], train=False)
+    seq3, sc3 = beam_search(eng, ids, am, act, trie, beams, 4, reorder_cross_cache=reorder_cross)
+    assert torch.equal(seq3, ref1[0]) and torch.equal(sc3, ref1[1])
+    if not reorder_cross:
+        _check(seq3, sc3, fx, tb, "", torch.ones(ids.shape[0], dtype=torch.bool), beams, 1e-4)
