@@ -542,8 +542,8 @@ def decode_leg(users: int = 256, beams: int = 20, his: int = 100, catalogue: int
 
     def timed(new_tokens):
         run = lambda: beam_search(eng, batch["input_ids"], batch["attention_mask"], batch["actions"], trie, beams, new_tokens)
-        # three untimed runs: an evaluation decodes many batches of one shape, and from the third one on the cached per-token step is
-        # a hipGraph replay (gamer_amd/decode.py: _DecodeStatic) - the steady state is what is timed
+        # three untimed runs: an evaluation decodes many batches of one shape (with GAMER_DECODE_GRAPH=1 the cached per-token step
+        # is a hipGraph replay from the third one on - gamer_amd/decode.py: _DecodeStatic) - the steady state is what is timed
         for _ in range(3):
             out = run()
         torch.cuda.synchronize()

@@ -139,9 +139,13 @@ def trie_from_callable(fn, input_ids, max_new_tokens: int, device="cuda", pad_to
 
 class _DecodeStatic:
     """Buffers of the cached decode path at FIXED addresses, kept on the engine per (batch, prompt length, beams, new tokens, ...):
-    an evaluation run decodes many batches of one shape, and the per-token step - ~350 launches of a few microseconds each - is
-    captured into one hipGraph per step index once two sessions of the shape have run eagerly (kernel attributes set, weight
-    maxima registered), then replayed: the launches leave the host in one call instead of ~11 us each."""
+    an evaluation run decodes many batches of one shape and reuses them; with GAMER_DECODE_GRAPH=1 the per-token step - ~350
+    launches - is captured into one hipGraph per step index once two sessions of the shape have run eagerly (kernel attributes
+    set, weight maxima registered) and replayed from then on, bit-identical to the eager step (tests/test_decode.py).
+    MEASURED on MI355X / ROCm 7.2 (tools/decode_leg.py): the replay is no faster than the eager step - 2.45 against 2.40 ms per token
+    at 16 users x 20 beams, 2.28 / 2.28 at 64, 4.08 / 3.98 at 256: a kernel node costs the ~7 us of dispatch an eager launch costs,
+    and at 256 users the step is GPU time anyway (tools/decode_step_kernels.py: gamer_attn_decode 1.73 of 3.6 ms) - so the graph
+    is OFF by default; what would shorten the step is FEWER launches, not cheaper ones."""
 
     def __init__(self):
         self.kp: Dict[Tuple[int, str], torch.Tensor] = {}
@@ -156,7 +160,7 @@ class _DecodeStatic:
 
 def _graphs_enabled() -> bool:
     import os
-    return os.environ.get("GAMER_DECODE_GRAPH", "1") != "0"
+    return os.environ.get("GAMER_DECODE_GRAPH", "0") == "1"
 
 
 class DecodeSession:
@@ -166,7 +170,7 @@ class DecodeSession:
     once per sample; only the generated positions are per beam.  ``step`` pushes one token per beam through the
     layers with the ordinary row kernels (norms, GEMMs with M = B*num_beams rows, SwiGLU) - all new tokens of a
     step sit at the same position, hence in the same position-routed expert - and ``gamer_attn_decode``.
-    From the third session of a shape on the step is a hipGraph replay (``_DecodeStatic``; GAMER_DECODE_GRAPH=0: always eager)."""
+    GAMER_DECODE_GRAPH=1: from the third session of a shape on the step is a hipGraph replay (``_DecodeStatic``: measured neutral)."""
 
     def __init__(self, engine, input_ids, attention_mask, actions, num_beams: int, max_new_tokens: int,
                  session_ids=None, extended_session_ids=None, reorder_cross_cache: bool = False):

@@ -10,7 +10,7 @@ mkdir -p tools/_ab
 OBJ=tools/_ab/${SRC%.hip}.$NAME.o
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++20 -Wno-unused-function "$@" -c gamer_amd/csrc/$SRC -o $OBJ
 OBJS=""
-for o in prep elementwise gemm gemm_as gemm_wg gemm_os gemm_bf16 attention attention_split attention_res attention_bf16 optim decode modules; do
+for o in prep inject elementwise gemm gemm_as gemm_wg gemm_os gemm_bf16 attention attention_split attention_res attention_bf16 optim decode modules; do
   if [ "$o.hip" == "$SRC" ]; then OBJS="$OBJS $OBJ"; else OBJS="$OBJS $L/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/_ab/$NAME.so $OBJS
