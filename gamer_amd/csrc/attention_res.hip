@@ -141,8 +141,9 @@ __device__ __forceinline__ f32x16 res_qk_tile(const ResSmem& sm, int tl, const S
     return st;
 }
 
-// One 32-query row tile of one query head against the resident key block kb.
-template <int G, bool DROP, bool ORD>
+// One 32-query row tile of one query head against the resident key block kb.  SPAN: per-query key spans (Qwen3SessionMulti,
+// attention_common.h: QuerySpan) - the row's causal limit becomes its span end and a hole may be cut out of its keys.
+template <int G, bool DROP, bool ORD, bool SPAN>
 __device__ __forceinline__ void
 res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
                 int S, int nq, float scale, const AttnDropout& rng, float* o, float* lse, const RowOrder& ro, const int b,
@@ -185,9 +186,12 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
         if (valid_q) carry_l = __builtin_nontemporal_load(lse_p);
     }
     const bool normal = valid_q && !my_empty;
+    const QuerySpan sp = QuerySpan::load<SPAN>(ro.span, tok, iq, valid_q, S);     // (no spans: hi = the row's position)
     const int wave_ql_min = wave_min_i32_dpp(normal ? my_ql : INT_BIG_A);
-    const int wave_q_lo = wave_min_i32_dpp(normal ? iq : INT_BIG_A);  // every key up to here passes every row's causal limit
+    const int wave_q_lo = wave_min_i32_dpp(normal ? sp.hi : INT_BIG_A);  // every key up to here passes every row's causal limit
     const bool wave_all_empty = wave_q_lo == INT_BIG_A;               // no normal row: no scores needed at all
+    const int wave_hole_lo = SPAN ? wave_min_i32_dpp(normal ? sp.hole_lo : INT_BIG_A) : INT_BIG_A;
+    const int wave_hole_hi = SPAN ? wave_max_i32_dpp(normal ? sp.hole_hi : 0) : 0;
     int wave_q_hi;
     bool wave_has_empty;
     if (ORD) {
@@ -302,11 +306,13 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
             if (MASK) {
                 int klv[16];
                 read_key_quads(klt, h, klv);
-                const int t_pos = iq - j0 - 4 * h;           // key (reg&3)+8*(reg>>2) of the tile is <= iq
+                const int t_pos = sp.hi - j0 - 4 * h;        // key (reg&3)+8*(reg>>2) of the tile is <= hi (= iq without spans)
+                const int t_lo = sp.hole_lo - j0 - 4 * h, t_hi = sp.hole_hi - j0 - 4 * h;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int ko = (reg & 3) + 8 * (reg >> 2);
-                    const bool allowed = (ko <= t_pos) & (klv[reg] < my_ql);
+                    bool allowed = (ko <= t_pos) & (klv[reg] < my_ql);
+                    if (SPAN) allowed = allowed & !((ko >= t_lo) & (ko < t_hi));
                     st[reg] = allowed ? st[reg] : -INFINITY;
                 }
             }
@@ -357,7 +363,8 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
             softmax_tile.template operator()<true, true>();
         } else {
             const int klmax = __builtin_amdgcn_readfirstlane(sm.klmax[tl]);
-            const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min);
+            const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min) &&
+                                   (!SPAN || j0 + 31 < wave_hole_lo || j0 >= wave_hole_hi);
             if (free_tile) softmax_tile.template operator()<false, false>();
             else softmax_tile.template operator()<true, false>();
         }
@@ -411,7 +418,7 @@ res_fwd_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const int32_t
     RES_MARK(3);                                           // 3: epilogue (final or carried state)
 }
 
-template <int G, bool DROP, bool ORD>
+template <int G, bool DROP, bool SPAN, bool ORD>
 __global__ void __launch_bounds__(RES_THREADS, 1)
 attn_fwd_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv,
                   const int32_t* __restrict__ kl, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
@@ -481,7 +488,7 @@ attn_fwd_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
                 nx.perm = 0;
                 if (ORD && nxt < n_items) nx.perm = ro.perm[(int64_t)b * S + min(nx.t * 32 + r, S - 1)];
                 if (kb == 0 || sm.ntot[hg * RES_MAX_TILES + t] > kb * RB_TILES) {
-                    res_fwd_rowtile<G, DROP, ORD>(sm, q, ldq, ql, row_empty, S, nq, scale, rng, o, lse, ro, b, kvh * G + hg, t, kb,
+                    res_fwd_rowtile<G, DROP, ORD, SPAN>(sm, q, ldq, ql, row_empty, S, nq, scale, rng, o, lse, ro, b, kvh * G + hg, t, kb,
                                                   amax_out != nullptr, sc, perm_cur, nx, qraw, q_ready RES_STAMP_PASS);
                     q_ready = RES_PREFETCH_Q && nx.valid;       // (nx.valid: the next item is a tile this block's pass processes)
                 } else {
@@ -514,7 +521,7 @@ attn_fwd_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict_
 // fragments by transposing reads of the resident image; dO and dS are scaled per query row.  A row tile that needs more than one
 // key block carries its raw accumulators through dq (fp32, exact: the sum continues as if the key loop had not been cut).
 // =============================================================================================
-template <int G, bool DROP, bool ORD>
+template <int G, bool DROP, bool ORD, bool SPAN>
 __device__ __forceinline__ void
 res_dq_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const float* __restrict__ o, const float* __restrict__ d_o,
                const float* __restrict__ lse, float* delta, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty,
@@ -561,9 +568,12 @@ res_dq_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const float* _
         }
     }
     const bool normal = valid_q && !my_empty;
+    const QuerySpan sp = QuerySpan::load<SPAN>(ro.span, tok, iq, valid_q, S);     // (no spans: hi = the row's position)
     const int wave_ql_min = wave_min_i32_dpp(normal ? my_ql : INT_BIG_A);
-    const int wave_q_lo = wave_min_i32_dpp(normal ? iq : INT_BIG_A);
+    const int wave_q_lo = wave_min_i32_dpp(normal ? sp.hi : INT_BIG_A);
     const bool wave_all_empty = wave_q_lo == INT_BIG_A;
+    const int wave_hole_lo = SPAN ? wave_min_i32_dpp(normal ? sp.hole_lo : INT_BIG_A) : INT_BIG_A;
+    const int wave_hole_hi = SPAN ? wave_max_i32_dpp(normal ? sp.hole_hi : 0) : 0;
     int wave_q_hi;
     bool wave_has_empty;
     if (ORD) {
@@ -706,11 +716,13 @@ res_dq_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const float* _
             if (MASK) {
                 int klv[16];
                 read_key_quads(klt, h, klv);
-                const int t_pos = iq - j0 - 4 * h;
+                const int t_pos = sp.hi - j0 - 4 * h;
+                const int t_lo = sp.hole_lo - j0 - 4 * h, t_hi = sp.hole_hi - j0 - 4 * h;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int ko = (reg & 3) + 8 * (reg >> 2);
-                    const bool allowed = (ko <= t_pos) & (klv[reg] < my_ql);
+                    bool allowed = (ko <= t_pos) & (klv[reg] < my_ql);
+                    if (SPAN) allowed = allowed & !((ko >= t_lo) & (ko < t_hi));
                     st[reg] = allowed ? st[reg] : -INFINITY;
                 }
             }
@@ -727,7 +739,8 @@ res_dq_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const float* _
             ds_tile.template operator()<true, true>();
         } else {
             const int klmax = __builtin_amdgcn_readfirstlane(sm.klmax[tl]);
-            const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min);
+            const bool free_tile = (j0 + 31 <= wave_q_lo) && (klmax < wave_ql_min) &&
+                                   (!SPAN || j0 + 31 < wave_hole_lo || j0 >= wave_hole_hi);
             if (free_tile) ds_tile.template operator()<false, false>();
             else ds_tile.template operator()<true, false>();
         }
@@ -763,7 +776,7 @@ res_dq_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const float* _
     }
 }
 
-template <int G, bool DROP, bool ORD>
+template <int G, bool DROP, bool SPAN, bool ORD>
 __global__ void __launch_bounds__(RES_THREADS, 1)
 attn_bwd_dq_r_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv,
                      const float* __restrict__ o, const float* __restrict__ d_o, const float* __restrict__ lse, float* delta,
@@ -809,7 +822,7 @@ attn_bwd_dq_r_kernel(const float* __restrict__ q, int ldq, const float* __restri
             for (int cur = res_grab(sm, lane); cur < n_items; cur = res_grab(sm, lane)) {
                 const int hg = h0 + cur % hpu, t = n_all - 1 - cur / hpu;
                 if (kb == 0 || sm.ntot[hg * RES_MAX_TILES + t] > kb * RB_TILES)
-                    res_dq_rowtile<G, DROP, ORD>(sm, q, ldq, o, d_o, lse, delta, ql, row_empty, S, nq, scale, rng, dq, lddq, ro, b,
+                    res_dq_rowtile<G, DROP, ORD, SPAN>(sm, q, ldq, o, d_o, lse, delta, ql, row_empty, S, nq, scale, rng, dq, lddq, ro, b,
                                                  kvh * G + hg, t, kb, delta_ready, sc);
             }
             asm volatile("" :: "v"(tk0), "v"(tk1));
@@ -1195,7 +1208,7 @@ struct DkvR2Smem {
     uint32_t aw[2][QB2];
     int32_t ql[QB2];
     int32_t empty[QB2];
-    int32_t pos[QB2];
+    int32_t pos[QB2];                         // the row's causal key limit: its position (its span end with key spans), S past the end
     int32_t t_qlmin[QB2_TILES];
     int32_t t_posmin[QB2_TILES];
     int32_t t_maxpos[QB2_TILES];
@@ -1204,9 +1217,13 @@ struct DkvR2Smem {
     uint32_t amax_word;
     int32_t ctr;
     int32_t pad_[6];
+    int32_t hole_lo[QB2];                     // SPAN kernels only: the hole of every staged row, and per 32-row tile the smallest
+    int32_t hole_hi[QB2];                     // hole start / largest hole end over its normal rows
+    int32_t t_hlomin[QB2_TILES];
+    int32_t t_hhimax[QB2_TILES];
 };
 
-template <bool DROP, bool ORD>
+template <bool DROP, bool ORD, bool SPAN>
 __device__ __forceinline__ void
 res2_stage_queries(DkvR2Smem& sm, const float* __restrict__ q, int ldq, const float* __restrict__ d_o, const float* __restrict__ lse,
                    const float* delta, const int32_t* __restrict__ ql, const int32_t* __restrict__ row_empty, const RowOrder& ro,
@@ -1239,20 +1256,25 @@ res2_stage_queries(DkvR2Smem& sm, const float* __restrict__ q, int ldq, const fl
             if (hh == 0) {
                 const int em = in ? row_empty[(int64_t)b * S + pos] : 0;
                 const int qlv = in ? (ql ? ql[(int64_t)b * S + pos] : 1) : 0;
+                const QuerySpan qsp = QuerySpan::load<SPAN>(ro.span, (int64_t)b * S + pos, pos, in, S);   // hi = pos without spans, S past the end
                 sm.ql[row] = qlv;
                 sm.empty[row] = em;
-                sm.pos[row] = in ? pos : S;
+                sm.pos[row] = qsp.hi;
                 const bool normal = in && em == 0;
-                int qlmin = normal ? qlv : INT_BIG_A, posmin = normal ? pos : INT_BIG_A, maxpos = normal ? pos : -1, anye = em != 0 ? 1 : 0;
+                int qlmin = normal ? qlv : INT_BIG_A, posmin = normal ? qsp.hi : INT_BIG_A, maxpos = normal ? qsp.hi : -1, anye = em != 0 ? 1 : 0;
+                int hlomin = normal ? qsp.hole_lo : INT_BIG_A, hhimax = normal ? qsp.hole_hi : 0;
 #pragma unroll
                 for (int o2 = 16; o2 > 0; o2 >>= 1) {
                     qlmin = min(qlmin, __shfl_xor(qlmin, o2, 64));
                     posmin = min(posmin, __shfl_xor(posmin, o2, 64));
                     maxpos = max(maxpos, __shfl_xor(maxpos, o2, 64));
                     anye |= __shfl_xor(anye, o2, 64);
+                    if (SPAN) { hlomin = min(hlomin, __shfl_xor(hlomin, o2, 64)); hhimax = max(hhimax, __shfl_xor(hhimax, o2, 64)); }
                 }
+                if (SPAN) { sm.hole_lo[row] = qsp.hole_lo; sm.hole_hi[row] = qsp.hole_hi; }
                 if ((row & 31) == 0) {
                     sm.t_qlmin[row >> 5] = qlmin; sm.t_posmin[row >> 5] = posmin; sm.t_maxpos[row >> 5] = maxpos; sm.t_empty[row >> 5] = anye;
+                    if (SPAN) { sm.t_hlomin[row >> 5] = hlomin; sm.t_hhimax[row >> 5] = hhimax; }
                 }
             }
         }
@@ -1276,7 +1298,7 @@ res2_stage_queries(DkvR2Smem& sm, const float* __restrict__ q, int ldq, const fl
 // classes of a query tile (the same for both heads: they share the rows)
 enum { QT_FREE = 0, QT_MASK = 1, QT_EMPTYSEL = 2, QT_ALL_EMPTY = 3 };
 
-template <bool DROP>
+template <bool DROP, bool SPAN>
 __device__ __forceinline__ void
 res2_dkv_keytile(DkvR2Smem& sm, const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv,
                  const int32_t* __restrict__ kl, int S, float scale, const AttnDropout& rng, float* dk, int lddk, float* dv, int lddv,
@@ -1399,11 +1421,18 @@ res2_dkv_keytile(DkvR2Smem& sm, const float* __restrict__ k, int ldk, const floa
             const float4 l4 = *reinterpret_cast<const float4*>(&sm.nlse2[g][qb]);
             nl[0] = l4.x; nl[1] = l4.y; nl[2] = l4.z; nl[3] = l4.w;
         }
+        int hlo[4] = {0, 0, 0, 0}, hhi[4] = {0, 0, 0, 0};
         if (MASK) {
             const int4 q4 = *reinterpret_cast<const int4*>(&sm.ql[qb]);
             const int4 p4 = *reinterpret_cast<const int4*>(&sm.pos[qb]);
             qlv[0] = q4.x; qlv[1] = q4.y; qlv[2] = q4.z; qlv[3] = q4.w;
             posv[0] = p4.x; posv[1] = p4.y; posv[2] = p4.z; posv[3] = p4.w;
+            if (SPAN) {
+                const int4 a4 = *reinterpret_cast<const int4*>(&sm.hole_lo[qb]);
+                const int4 b4 = *reinterpret_cast<const int4*>(&sm.hole_hi[qb]);
+                hlo[0] = a4.x; hlo[1] = a4.y; hlo[2] = a4.z; hlo[3] = a4.w;
+                hhi[0] = b4.x; hhi[1] = b4.y; hhi[2] = b4.z; hhi[3] = b4.w;
+            }
         }
         if (EMPTYSEL) {
             const int4 e4 = *reinterpret_cast<const int4*>(&sm.empty[qb]);
@@ -1422,7 +1451,8 @@ res2_dkv_keytile(DkvR2Smem& sm, const float* __restrict__ k, int ldk, const floa
             } else {
                 pe = __builtin_amdgcn_exp2f(fmaf(st[reg], c2, nl[e]));
                 if (MASK) {
-                    const bool allowed = (jk <= posv[e]) & (my_kl < qlv[e]);
+                    bool allowed = (jk <= posv[e]) & (my_kl < qlv[e]);
+                    if (SPAN) allowed = allowed & !((jk >= hlo[e]) & (jk < hhi[e]));
                     pe = allowed ? pe : 0.f;
                 }
                 if (EMPTYSEL) pe = (emv[e] != 0) ? invS : pe;
@@ -1453,7 +1483,11 @@ res2_dkv_keytile(DkvR2Smem& sm, const float* __restrict__ k, int ldk, const floa
         const bool before = maxpos < wave_k_lo;            // every normal query of the tile precedes this wave's keys
         if (before && !tile_has_empty) continue;
         const bool need_s = !before && !tile_all_empty;
-        const bool free_tile = !tile_has_empty && (posmin >= wave_k_hi) && (wave_kl_max < qlmin);
+        bool free_tile = !tile_has_empty && (posmin >= wave_k_hi) && (wave_kl_max < qlmin);
+        if (SPAN && free_tile) {                            // (no normal row's hole may touch this wave's keys)
+            const int hlomin = __builtin_amdgcn_readfirstlane(sm.t_hlomin[qt]), hhimax = __builtin_amdgcn_readfirstlane(sm.t_hhimax[qt]);
+            free_tile = wave_k_hi < hlomin || wave_k_lo >= hhimax;
+        }
 
         f32x16 stA, dpA, stB, dpB;
 #pragma unroll
@@ -1543,7 +1577,7 @@ res2_dkv_keytile(DkvR2Smem& sm, const float* __restrict__ k, int ldk, const floa
     RES_MARK(3);                                           // 3: key-tile epilogue (store)
 }
 
-template <bool DROP, bool ORD>
+template <bool DROP, bool SPAN, bool ORD>
 __global__ void __launch_bounds__(DKV_R_THREADS, 1)
 attn_bwd_dkv_r2_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv,
                        const float* __restrict__ d_o, const float* __restrict__ lse, const float* delta,
@@ -1576,7 +1610,7 @@ attn_bwd_dkv_r2_kernel(const float* __restrict__ q, int ldq, const float* __rest
             RES_MARK(4);                                    // 4: waiting for the slowest wave of the stage
             if (tid == 0) sm.ctr = 0;
             if (qb == 0 && tid < RES_MAX_TILES) sm.started[tid] = 0;
-            res2_stage_queries<DROP, ORD>(sm, q, ldq, d_o, lse, delta, ql, row_empty, ro, b, kvh * 2, qb * QB2, S, nq, tid, sc, rng);
+            res2_stage_queries<DROP, ORD, SPAN>(sm, q, ldq, d_o, lse, delta, ql, row_empty, ro, b, kvh * 2, qb * QB2, S, nq, tid, sc, rng);
             __syncthreads();
             RES_MARK(0);                                    // 0: staging (loads, cut, LDS stores, barrier)
             // warm the L2 with the Q / dO rows of the block this workgroup stages next: 128 slots x 2 heads x 2 tensors x two 128-byte
@@ -1608,7 +1642,7 @@ attn_bwd_dkv_r2_kernel(const float* __restrict__ q, int ldq, const float* __rest
                 if (!(final_stage || blk_empty != 0 || blk_maxpos >= kt * 32)) break;      // (nor does any later key tile)
                 const bool fresh = __builtin_amdgcn_readfirstlane(sm.started[kt]) == 0;
                 RES_MARK(5);
-                res2_dkv_keytile<DROP>(sm, k, ldk, v, ldv, kl, S, scale, rng, dk, lddk, dv, lddv, b, kvh, kt,
+                res2_dkv_keytile<DROP, SPAN>(sm, k, ldk, v, ldv, kl, S, scale, rng, dk, lddk, dv, lddv, b, kvh, kt,
                                        n_qt, fresh, final_stage, amax_out != nullptr, sc RES_STAMP_PASS);
                 if (lane == 0) sm.started[kt] = 1;
             }
@@ -1629,7 +1663,7 @@ attn_bwd_dkv_r2_kernel(const float* __restrict__ q, int ldq, const float* __rest
 #endif
 }
 
-template <int G, bool DROP, bool ORD>
+template <int G, bool DROP, bool SPAN, bool ORD>
 static int launch_fwd_r_variant(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl,
                                 const int32_t* ql, const int32_t* row_empty, int B, int S, int nq, int nkv, float scale, float p_drop,
                                 uint64_t seed, float* o, float* lse, RowOrder ro, uint32_t* amax_out, AttnAmax am, hipStream_t st) {
@@ -1637,7 +1671,7 @@ static int launch_fwd_r_variant(const float* q, int ldq, const float* k, int ldk
     static bool attr_dev[MAX_DEVICES] = {};
     bool& attr_set = attr_dev[current_device()];
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_r_kernel<G, DROP, ORD>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_r_kernel<G, DROP, SPAN, ORD>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) {
             set_error("gamer_attn_fwd_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1648,7 +1682,7 @@ static int launch_fwd_r_variant(const float* q, int ldq, const float* k, int ldk
     const int split = res_split(B * nkv, G);
     const int n_units = B * nkv * (split ? G : 1);
     const int grid = n_units < res_grid_cap() ? n_units : res_grid_cap();
-    hipLaunchKernelGGL((attn_fwd_r_kernel<G, DROP, ORD>), dim3(grid), dim3(RES_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, kl, ql,
+    hipLaunchKernelGGL((attn_fwd_r_kernel<G, DROP, SPAN, ORD>), dim3(grid), dim3(RES_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, kl, ql,
                        row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, amax_out, am, split);
     GAMER_CHECK_LAUNCH("gamer_attn_fwd_split/resident");
     return 0;
@@ -1657,9 +1691,14 @@ static int launch_fwd_r_variant(const float* q, int ldq, const float* k, int ldk
 int launch_fwd_res(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* kl, const int32_t* ql,
                    const int32_t* row_empty, int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed, float* o,
                    float* lse, RowOrder ro, uint32_t* amax_out, AttnAmax am, hipStream_t st) {
-#define GAMER_LAUNCH_FWD_R(GV, DROPV, ORDV)                                                                                   \
-    return launch_fwd_r_variant<GV, DROPV, ORDV>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, \
-                                                 ro, amax_out, am, st)
+#define GAMER_LAUNCH_FWD_RS(GV, DROPV, SPANV, ORDV)                                                                           \
+    return launch_fwd_r_variant<GV, DROPV, SPANV, ORDV>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, \
+                                                        lse, ro, amax_out, am, st)
+#define GAMER_LAUNCH_FWD_R(GV, DROPV, ORDV) GAMER_LAUNCH_FWD_RS(GV, DROPV, false, ORDV)
+    if (ro.span) {                          // per-query key spans (Qwen3SessionMulti): built for the GQA group of two (the caller checks)
+        if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD_RS(2, true, true, true); else GAMER_LAUNCH_FWD_RS(2, true, true, false); }
+        else { if (ro.perm) GAMER_LAUNCH_FWD_RS(2, false, true, true); else GAMER_LAUNCH_FWD_RS(2, false, true, false); }
+    }
     if (nq / nkv == 1) {
         if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_FWD_R(1, true, true); else GAMER_LAUNCH_FWD_R(1, true, false); }
         else { if (ro.perm) GAMER_LAUNCH_FWD_R(1, false, true); else GAMER_LAUNCH_FWD_R(1, false, false); }
@@ -1668,10 +1707,11 @@ int launch_fwd_res(const float* q, int ldq, const float* k, int ldk, const float
         else { if (ro.perm) GAMER_LAUNCH_FWD_R(2, false, true); else GAMER_LAUNCH_FWD_R(2, false, false); }
     }
 #undef GAMER_LAUNCH_FWD_R
+#undef GAMER_LAUNCH_FWD_RS
     return -1;      // not reached
 }
 
-template <int G, bool DROP, bool ORD>
+template <int G, bool DROP, bool SPAN, bool ORD>
 static int launch_dq_r_variant(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
                                const float* d_o, const float* lse, float* delta, const int32_t* kl, const int32_t* ql,
                                const int32_t* row_empty, int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
@@ -1680,7 +1720,7 @@ static int launch_dq_r_variant(const float* q, int ldq, const float* k, int ldk,
     static bool attr_dev[MAX_DEVICES] = {};
     bool& attr_set = attr_dev[current_device()];
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_r_kernel<G, DROP, ORD>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_r_kernel<G, DROP, SPAN, ORD>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) {
             set_error("gamer_attn_bwd_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1691,7 +1731,7 @@ static int launch_dq_r_variant(const float* q, int ldq, const float* k, int ldk,
     const int split = res_split(B * nkv, G);
     const int n_units = B * nkv * (split ? G : 1);
     const int grid = n_units < res_grid_cap() ? n_units : res_grid_cap();
-    hipLaunchKernelGGL((attn_bwd_dq_r_kernel<G, DROP, ORD>), dim3(grid), dim3(RES_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, o, d_o,
+    hipLaunchKernelGGL((attn_bwd_dq_r_kernel<G, DROP, SPAN, ORD>), dim3(grid), dim3(RES_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, o, d_o,
                        lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dq, lddq, ro, delta_ready, am, split);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dq resident");
     return 0;
@@ -1701,9 +1741,14 @@ int launch_dq_res(const float* q, int ldq, const float* k, int ldk, const float*
                   const float* lse, float* delta, const int32_t* kl, const int32_t* ql, const int32_t* row_empty, int B, int S,
                   int nq, int nkv, float scale, float p_drop, uint64_t seed, float* dq, int lddq, RowOrder ro, int delta_ready,
                   AttnAmax am, hipStream_t st) {
-#define GAMER_LAUNCH_DQ_R(GV, DROPV, ORDV)                                                                                    \
-    return launch_dq_r_variant<GV, DROPV, ORDV>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, \
-                                                p_drop, seed, dq, lddq, ro, delta_ready, am, st)
+#define GAMER_LAUNCH_DQ_RS(GV, DROPV, SPANV, ORDV)                                                                            \
+    return launch_dq_r_variant<GV, DROPV, SPANV, ORDV>(q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, \
+                                                       p_drop, seed, dq, lddq, ro, delta_ready, am, st)
+#define GAMER_LAUNCH_DQ_R(GV, DROPV, ORDV) GAMER_LAUNCH_DQ_RS(GV, DROPV, false, ORDV)
+    if (ro.span) {
+        if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_DQ_RS(2, true, true, true); else GAMER_LAUNCH_DQ_RS(2, true, true, false); }
+        else { if (ro.perm) GAMER_LAUNCH_DQ_RS(2, false, true, true); else GAMER_LAUNCH_DQ_RS(2, false, true, false); }
+    }
     if (nq / nkv == 1) {
         if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_DQ_R(1, true, true); else GAMER_LAUNCH_DQ_R(1, true, false); }
         else { if (ro.perm) GAMER_LAUNCH_DQ_R(1, false, true); else GAMER_LAUNCH_DQ_R(1, false, false); }
@@ -1712,10 +1757,11 @@ int launch_dq_res(const float* q, int ldq, const float* k, int ldk, const float*
         else { if (ro.perm) GAMER_LAUNCH_DQ_R(2, false, true); else GAMER_LAUNCH_DQ_R(2, false, false); }
     }
 #undef GAMER_LAUNCH_DQ_R
+#undef GAMER_LAUNCH_DQ_RS
     return -1;      // not reached
 }
 
-template <int G, bool DROP, bool ORD>
+template <int G, bool DROP, bool SPAN, bool ORD>
 static int launch_dkv_r_variant(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* d_o,
                                 const float* lse, const float* delta, const int32_t* kl, const int32_t* ql, const int32_t* row_empty,
                                 int B, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed, float* dk, int lddk,
@@ -1734,13 +1780,13 @@ static int launch_dkv_r_variant(const float* q, int ldq, const float* k, int ldk
     }
     const int n_pairs = B * nkv;
     const int grid = n_pairs < res_grid_cap() ? n_pairs : res_grid_cap();
-    if (G == 2 && GAMER_RES_PART("GAMER_ATTN_RES_DKV2")) {
+    if (G == 2 && (SPAN || GAMER_RES_PART("GAMER_ATTN_RES_DKV2"))) {
         // two heads per wave (the element-wise work of one beside the products of the other)
         const size_t shmem2 = sizeof(DkvR2Smem);
         static bool attr2_dev[MAX_DEVICES] = {};
         bool& attr2_set = attr2_dev[current_device()];
         if (!attr2_set) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_r2_kernel<DROP, ORD>),
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_r2_kernel<DROP, SPAN, ORD>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem2);
             if (e != hipSuccess) {
                 set_error("gamer_attn_bwd_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1751,14 +1797,16 @@ static int launch_dkv_r_variant(const float* q, int ldq, const float* k, int ldk
         const int split = res_split(n_pairs, 2);
         const int n_units = n_pairs * (split ? 2 : 1);
         const int grid2 = n_units < res_grid_cap() ? n_units : res_grid_cap();
-        hipLaunchKernelGGL((attn_bwd_dkv_r2_kernel<DROP, ORD>), dim3(grid2), dim3(DKV_R_THREADS), shmem2, st, q, ldq, k, ldk, v, ldv, d_o,
+        hipLaunchKernelGGL((attn_bwd_dkv_r2_kernel<DROP, SPAN, ORD>), dim3(grid2), dim3(DKV_R_THREADS), shmem2, st, q, ldq, k, ldk, v, ldv, d_o,
                            lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro, amax_out, am, split);
         GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dkv resident, two heads per wave");
         return 0;
     }
-    hipLaunchKernelGGL((attn_bwd_dkv_r_kernel<G, DROP, ORD>), dim3(grid), dim3(DKV_R_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse,
-                       delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro, amax_out, am);
-    GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dkv resident");
+    if constexpr (!SPAN) {                  // (the single-chain kernel takes no spans: SPAN calls are G = 2 and ended above)
+        hipLaunchKernelGGL((attn_bwd_dkv_r_kernel<G, DROP, ORD>), dim3(grid), dim3(DKV_R_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o, lse,
+                           delta, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ro, amax_out, am);
+        GAMER_CHECK_LAUNCH("gamer_attn_bwd_split/dkv resident");
+    }
     return 0;
 }
 
@@ -1766,9 +1814,14 @@ int launch_dkv_res(const float* q, int ldq, const float* k, int ldk, const float
                    const float* delta, const int32_t* kl, const int32_t* ql, const int32_t* row_empty, int B, int S, int nq, int nkv,
                    float scale, float p_drop, uint64_t seed, float* dk, int lddk, float* dv, int lddv, RowOrder ro, uint32_t* amax_out,
                    AttnAmax am, hipStream_t st) {
-#define GAMER_LAUNCH_DKV_R(GV, DROPV, ORDV)                                                                                   \
-    return launch_dkv_r_variant<GV, DROPV, ORDV>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale,  \
-                                                 p_drop, seed, dk, lddk, dv, lddv, ro, amax_out, am, st)
+#define GAMER_LAUNCH_DKV_RS(GV, DROPV, SPANV, ORDV)                                                                           \
+    return launch_dkv_r_variant<GV, DROPV, SPANV, ORDV>(q, ldq, k, ldk, v, ldv, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv, scale, \
+                                                        p_drop, seed, dk, lddk, dv, lddv, ro, amax_out, am, st)
+#define GAMER_LAUNCH_DKV_R(GV, DROPV, ORDV) GAMER_LAUNCH_DKV_RS(GV, DROPV, false, ORDV)
+    if (ro.span) {
+        if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_DKV_RS(2, true, true, true); else GAMER_LAUNCH_DKV_RS(2, true, true, false); }
+        else { if (ro.perm) GAMER_LAUNCH_DKV_RS(2, false, true, true); else GAMER_LAUNCH_DKV_RS(2, false, true, false); }
+    }
     if (nq / nkv == 1) {
         if (p_drop > 0.f) { if (ro.perm) GAMER_LAUNCH_DKV_R(1, true, true); else GAMER_LAUNCH_DKV_R(1, true, false); }
         else { if (ro.perm) GAMER_LAUNCH_DKV_R(1, false, true); else GAMER_LAUNCH_DKV_R(1, false, false); }
@@ -1777,6 +1830,7 @@ int launch_dkv_res(const float* q, int ldq, const float* k, int ldk, const float
         else { if (ro.perm) GAMER_LAUNCH_DKV_R(2, false, true); else GAMER_LAUNCH_DKV_R(2, false, false); }
     }
 #undef GAMER_LAUNCH_DKV_R
+#undef GAMER_LAUNCH_DKV_RS
     return -1;      // not reached
 }
 

@@ -1428,7 +1428,11 @@ static int launch_bwd_s_variant(const float* q, int ldq, const float* k, int ldk
                                 float* dv, int lddv, RowOrder ro, int delta_ready, float* ds_work, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     const bool h2 = t_attn_amax.q != nullptr;       // gamer_attn_split_amax: the three-product fp16 form (recompute form only)
-    if (ro.span) {
+    // key spans on the resident kernels: the GQA group of two, both kernels resident (the conditions of the two launches below)
+    const bool span_res = ro.span && G == 2 && h2 && ds_work == nullptr && res_enabled() && S <= 2048 &&
+                          GAMER_RES_PART("GAMER_ATTN_RES_SPAN") && GAMER_RES_PART("GAMER_ATTN_RES_DQ") &&
+                          GAMER_RES_PART("GAMER_ATTN_RES_DKV") && (res_fill(B * nkv) >= 0.85 || res_split_forced());
+    if (ro.span && !span_res) {
         // per-query key spans (Qwen3SessionMulti): the three-product recompute form (checked by the entry point)
         hipLaunchKernelGGL((attn_bwd_dq_s_kernel<G, DROP, ORD, true, true>), dim3(worklist_grid(B * nkv, (S + R - 1) / R)),
                            dim3(AT_THREADS), 0, st, q, ldq, k, ldk, v, ldv, o, d_o, lse, delta, kl, ql, row_empty, B, S, nq, nkv,
@@ -1561,8 +1565,9 @@ extern "C" int gamer_attn_fwd_split(const float* q, int ldq, const float* k, int
     GAMER_CHECK_ARG(!t_attn_amax.q || p_drop < 0.75f, "gamer_attn_fwd_split: the three-product fp16 form needs p_drop < 0.75 (p_drop=%f): "
                     "its probabilities are cut at a fixed 2^13 scale; do not arm gamer_attn_split_amax for this call", p_drop);
     GAMER_CHECK_ARG(!q_span || t_attn_amax.q, "gamer_attn_fwd_split: q_span is built for the three-product form (arm gamer_attn_split_amax)");
-    if (t_attn_amax.q && !q_span && uspan == S && S <= 2048 && res_enabled())
-        // the three-product form with training semantics: K / V of a (sequence, kv head) resident in LDS (attention_res.hip)
+    if (t_attn_amax.q && (!q_span || (nq / nkv == 2 && GAMER_RES_PART("GAMER_ATTN_RES_SPAN"))) && uspan == S && S <= 2048 && res_enabled())
+        // the three-product form with training semantics: K / V of a (sequence, kv head) resident in LDS (attention_res.hip; key
+        // spans - Qwen3SessionMulti - for the GQA group of two)
         rc = launch_fwd_res(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, t_amax_out, t_attn_amax, st);
     else
     rc = (nq / nkv == 1) ? launch_fwd_s<1>(q, ldq, k, ldk, v, ldv, kl, ql, row_empty, B, S, nq, nkv, scale, p_drop, seed, o, lse, ro, uspan, st)

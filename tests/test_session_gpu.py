@@ -136,7 +136,7 @@ def _attn_ref(q, k, v, ok, nq, nkv, scale):
     return torch.einsum("bnij,bjnd->bind", p, vq), torch.logsumexp(s_eff, -1), empty
 
 
-@pytest.mark.parametrize("spill", [False, True, "split_h2"])
+@pytest.mark.parametrize("spill", [False, True, "split_h2", "split_h2_tiled"])
 @pytest.mark.parametrize("use_order", [False, True])
 @pytest.mark.parametrize("cross", [False, True])
 @pytest.mark.parametrize("n_items,B,nq,nkv,mean", [(7, 3, 2, 1, 2.0), (14, 2, 2, 1, 3.0), (41, 3, 2, 1, 1.0),
@@ -145,7 +145,20 @@ def _attn_ref(q, k, v, ok, nq, nkv, scale):
 def test_session_attention_fwd_bwd(cross, n_items, B, nq, nkv, mean, use_order, spill):
     """Attention kernels with per-query key spans (SPAN instantiations) against the dense reference with the
     reference's session masks; same shapes as test_ops_gpu.test_attention_fwd_bwd plus one-item sessions.
-    "split_h2": the three-product fp16 form of csrc/attention_split.hip (what the default engine runs for Qwen3SessionMulti)."""
+    "split_h2": the three-product fp16 form (what the default engine runs for Qwen3SessionMulti) - since round 6 the resident kernels
+    of csrc/attention_res.hip (SPAN instantiations) for the GQA group of two; "split_h2_tiled": the same call kept on the tiled
+    SPAN kernels of csrc/attention_split.hip (GAMER_ATTN_RES_SPAN=0: what other group sizes and uneven CU fills run)."""
+    import contextlib
+    tiled = ops.env_switches(GAMER_ATTN_RES_SPAN=0) if spill == "split_h2_tiled" else contextlib.nullcontext()
+    if spill == "split_h2_tiled":
+        spill = "split_h2"
+        if nq // nkv != 2:
+            pytest.skip("only the GQA group of two has resident SPAN kernels: the plain case already ran tiled")
+    with tiled:
+        _session_attention_case(cross, n_items, B, nq, nkv, mean, use_order, spill, tiled=not isinstance(tiled, contextlib.nullcontext))
+
+
+def _session_attention_case(cross, n_items, B, nq, nkv, mean, use_order, spill, tiled=False):
     batch = _session_batch(B, n_items, 7 + n_items, mean, pad_rows={0: max(1, n_items // 3)})
     S = batch["input_ids"].shape[1]
     T = B * S
@@ -201,7 +214,7 @@ def test_session_attention_fwd_bwd(cross, n_items, B, nq, nkv, mean, use_order, 
              lse=float((lse.cpu().permute(0, 2, 1)[ne].double() - lse_ref.detach().permute(0, 2, 1)[ne]).abs().max()),
              dq=_rel(dq, leaves[0].grad.reshape(T, -1)), dk=_rel(dk, leaves[1].grad.reshape(T, -1)),
              dv=_rel(dvv, leaves[2].grad.reshape(T, -1)), empty_rows=int(empty.sum()))
-    _record(f"session_attn_cross{int(cross)}_S{S}_B{B}_h{nq}_ord{int(use_order)}_spill{spill}", e)
+    _record(f"session_attn_cross{int(cross)}_S{S}_B{B}_h{nq}_ord{int(use_order)}_spill{spill}{'_tiled' if tiled else ''}", e)
     assert int((empty & batch["attention_mask"].bool()).sum()) > 0 or not cross, "fixture must contain empty rows"
     assert e["o"] < 2e-5 and e["lse"] < 2e-5
     assert e["dq"] < 5e-5 and e["dk"] < 5e-5 and e["dv"] < 5e-5
