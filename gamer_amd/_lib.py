@@ -58,7 +58,7 @@ class GemmDesc(C.Structure):
         ("amax_c", c_void_p), ("amax_c_col0", c_int),
         ("wgrad_ws", c_void_p), ("wgrad_ws_floats", c_int64),
         ("sw_gu", c_void_p), ("sw_ld", c_int64),
-        ("group_div", c_int), ("sw_tbl", c_void_p),
+        ("group_div", c_int), ("sw_tbl", c_void_p), ("b_planes_t", c_void_p),
     ]
 
 
@@ -158,6 +158,7 @@ _SIGNATURES = {
     "gamer_attn_dense_fwd": [P, I, P, I, P, I, P, P, I, I, I, I, F, F, U, P, I, P, P],
     "gamer_attn_dense_bwd": [P, I, P, I, P, I, P, P, I, I, I, I, F, F, U, P, P, I, P, P, I, P, I, P, I, P],
     "gamer_reload_env": [],
+    "gamer_split2h_transpose_multi": [P, P, I, P, P],
     "gamer_trie_logprobs": [P, L, P, P, P, P, P, I, I, P, P],
     "gamer_trie_advance": [P, P, P, P, P, I, P, P],
     "gamer_attn_decode": [P, I, P, I, P, I, P, P, P, I, I, I, I, P, I, I, I, I, I, F, P, P],

@@ -325,7 +325,8 @@ __device__ __forceinline__ float dsilu_f(float x) {
 bool gemm_as_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint16_t* b_planes);
 int launch_gemm_as(const gamer_gemm_desc* d, const uint16_t* b_planes, bool b_kc, hipStream_t st);
 bool gemm_os_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint16_t* b_planes);      // (gemm_os.hip) input gradient, output-stationary
-int launch_gemm_os(const gamer_gemm_desc* d, const uint16_t* b_planes, int guard, hipStream_t st);
+int launch_gemm_os(const gamer_gemm_desc* d, const uint16_t* b_planes, int guard, hipStream_t st, bool fwd_t = false);
+bool gemm_os_fwd_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc);        // (gemm_os.hip) Linear forward with 256 outputs on W's transposed pieces
 bool gemm_wg_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc);      // (gemm_wg.hip) weight gradient, 256 x 256 tiles
 int launch_gemm_wg(const gamer_gemm_desc* d, hipStream_t st);
 

@@ -1560,6 +1560,9 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     if (split == 3 && gemm_as_eligible(d, a_kc, b_kc, p.b_planes)) return launch_gemm_as(d, p.b_planes, b_kc, (hipStream_t)stream);
     // plain input gradient with 256 input features: the output-stationary kernel (csrc/gemm_os.hip)
     if (split == 3 && gemm_os_eligible(d, a_kc, b_kc, p.b_planes)) return launch_gemm_os(d, p.b_planes, g_split3_guard, (hipStream_t)stream);
+    // Linear forward with 256 output features and K > 256 (o_proj, the experts' down projection): the same kernel on W's transposed pieces
+    if (split == 3 && gemm_os_fwd_eligible(d, a_kc, b_kc))
+        return launch_gemm_os(d, reinterpret_cast<const uint16_t*>(d->b_planes_t), g_split3_guard, (hipStream_t)stream, true);
     p.n_tiles = (d->N + BN - 1) / BN;
     hipStream_t st = (hipStream_t)stream;
 
@@ -1717,6 +1720,38 @@ extern "C" int gamer_split2h_planes_multi(const float* base, const int64_t* tabl
     hipLaunchKernelGGL(split2h_planes_multi_kernel, dim3(n * bpe), dim3(256), 0, (hipStream_t)stream, base, table, bpe, slots,
                        reinterpret_cast<uint16_t*>(planes));
     GAMER_CHECK_LAUNCH("gamer_split2h_planes_multi");
+    return 0;
+}
+
+// The packed pieces of W^T from the packed pieces of W: table = n entries (element offset of a row-major [rows][cols] matrix, rows,
+// cols), rows and cols multiples of 4; planes_t receives, at the SAME offset, the pieces of the [cols][rows] transpose - unit (c, r4) =
+// {h0 of elements (4 r4 .. 4 r4 + 3, c) | their h1}.  Same bits as the source (nothing is cut again).
+__global__ void __launch_bounds__(256)
+split2h_transpose_multi_kernel(const uint4* __restrict__ planes, const int64_t* __restrict__ table, int bpe, uint4* __restrict__ planes_t) {
+    const int e = blockIdx.x / bpe, part = blockIdx.x % bpe;
+    const int64_t off4 = table[3 * e] >> 2;
+    const int rows = (int)table[3 * e + 1], cols = (int)table[3 * e + 2];
+    const int r4n = rows >> 2, c4n = cols >> 2;
+    const int64_t units = (int64_t)r4n * cols;
+    for (int64_t u = (int64_t)part * 256 + threadIdx.x; u < units; u += (int64_t)bpe * 256) {
+        const int r4 = (int)(u / cols), c = (int)(u % cols);      // (consecutive threads: consecutive columns of four source rows)
+        uint32_t h0[4], h1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 s = planes[off4 + (int64_t)(4 * r4 + i) * c4n + (c >> 2)];
+            const uint32_t w0 = (c & 2) ? s.y : s.x, w1 = (c & 2) ? s.w : s.z;
+            h0[i] = (c & 1) ? (w0 >> 16) : (w0 & 0xffffu);
+            h1[i] = (c & 1) ? (w1 >> 16) : (w1 & 0xffffu);
+        }
+        planes_t[off4 + (int64_t)c * r4n + r4] = make_uint4(h0[0] | (h0[1] << 16), h0[2] | (h0[3] << 16), h1[0] | (h1[1] << 16), h1[2] | (h1[3] << 16));
+    }
+}
+extern "C" int gamer_split2h_transpose_multi(const gamer_bf16* planes, const int64_t* table, int n, gamer_bf16* planes_t, void* stream) {
+    GAMER_CHECK_ARG(planes && table && planes_t && n >= 1 && aligned16(planes) && aligned16(planes_t), "gamer_split2h_transpose_multi: bad arguments");
+    const int bpe = 16;
+    hipLaunchKernelGGL(split2h_transpose_multi_kernel, dim3(n * bpe), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint4*>(planes),
+                       table, bpe, reinterpret_cast<uint4*>(planes_t));
+    GAMER_CHECK_LAUNCH("gamer_split2h_transpose_multi");
     return 0;
 }
 

@@ -48,6 +48,10 @@ struct OsParams {
     // grouped form (the experts' gate|up at d_in = 256): rows sorted by expert, group g = rows group_offsets[g] .. group_offsets[g + 1] - 1
     // with its own W strideW elements further; a workgroup never crosses a segment boundary
     int groups; const int32_t* group_offsets; int64_t strideW;
+    // Linear FORWARD of a layer with 256 output features and a long contraction (o_proj K = 384, the experts' down projection K = 512):
+    // the same kernel on the TRANSPOSED packed pieces of W (gamer_split2h_transpose_multi: [K][256] from W [256][K]), with the residual
+    // epilogue of csrc/gemm.hip: C[map(m)] = resid[map(m)] + dropout(alpha * acc)  (row_map: the expert rows back to token order)
+    const float* resid; const int32_t* row_map; float p_drop; uint64_t seed;
 };
 
 // byte offset of (k, n) in a piece image [32 k][256 n] of 16-bit values: the 16-byte chunk (n >> 3) of the k row XORed with (k & 3) << 2
@@ -224,7 +228,37 @@ gemm_os_kernel(const OsParams p) {
 
     // ---- epilogue: lane = output row m, acc[nt][reg] = column 32 nt + (reg & 3) + 8 (reg >> 2) + 4 h
     float cmax = 0.f;
-    if (valid_m && !(OS_ABLATE & 1)) {
+    if (p.resid) {
+        // residual add + dropout (+ scatter through row_map): the residual quads of TWO column tiles are requested together, one pair
+        // ahead of the pair being stored (loads issued inside the store loop would each wait for their own round trip: the stores
+        // may alias them as far as the compiler knows)
+        const int64_t orow = valid_m ? (p.row_map ? (int64_t)p.row_map[m] : (int64_t)m) : 0;
+        const float* rrow = p.resid + orow * p.ldc;
+        float* crow = p.C + orow * p.ldc;
+        const DropoutRng rng(p.p_drop, p.seed);
+        float4 rq[2][8];
+        auto request = [&](int pr, float4 (&dst)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const float4*>(rrow + (2 * pr + (i >> 2)) * 32 + 8 * (i & 3) + 4 * h);
+        };
+        request(0, rq[0]);
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            if (pr + 1 < 4) request(pr + 1, rq[(pr + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int nt = 2 * pr + (i >> 2), g4 = i & 3;
+                const int col = nt * 32 + 8 * g4 + 4 * h;
+                float mu[4];
+                rng.mult4((uint32_t)((orow * p.ldc + col) >> 2), mu);
+                const float4 x = rq[pr & 1][i];
+                const float4 t4 = make_float4(x.x + mu[0] * (acc[nt][4 * g4] * out_scale), x.y + mu[1] * (acc[nt][4 * g4 + 1] * out_scale),
+                                              x.z + mu[2] * (acc[nt][4 * g4 + 2] * out_scale), x.w + mu[3] * (acc[nt][4 * g4 + 3] * out_scale));
+                if (valid_m) *reinterpret_cast<float4*>(crow + col) = t4;
+            }
+        }
+    } else if (valid_m && !(OS_ABLATE & 1)) {
         float* crow = p.C + (int64_t)m * p.ldc;
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt)
@@ -260,6 +294,23 @@ static inline bool gemm_os_enabled() {
 
 // Does this descriptor take the output-stationary kernel?  (plain input gradient: A k-contiguous, B = W [K][256] row-contiguous with
 // packed pieces, one group, no epilogue, enough rows to fill the chip)
+// Does this Linear-FORWARD descriptor (both operands k-contiguous) take the kernel on W's transposed pieces?  256 output features, the
+// plain store or the residual epilogue (+ row map, dropout), one group or the experts' row segments.
+bool gemm_os_fwd_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc) {
+    static EnvSwitch sw("GAMER_GEMM_OSF");                // (0: those launches stay on the 128 x 128 kernel - A/B runs)
+    if (!gemm_os_enabled() || sw.get(1) == 0 || !a_kc || !b_kc || !d->b_planes_t || !d->amax_a || !d->amax_b) return false;
+    if (d->group_mode != 0 || d->accumulate || d->rowdot_out || d->qk_q_rot || d->sw_gu || d->group_div > 1 || d->amax_c) return false;
+    if (d->groups != 1 && (!d->group_offsets || d->strideC != 0)) return false;
+    if (d->groups == 1 && d->group_offsets) return false;
+    static EnvSwitch min_m("GAMER_GEMM_OS_MIN_M");
+    if (d->N != OS_N || d->K < 4 || d->K % 4 != 0 || d->b_rs != d->K || d->M < min_m.get(16384)) return false;
+    if (d->a_rs % 4 != 0 || d->ldc % 4 != 0 || !aligned16(d->C) || !aligned16(d->b_planes_t) || d->alpha != 1.f) return false;
+    if (d->a_rs < d->K) return false;
+    if (d->resid && (!aligned16(d->resid) || d->p_drop < 0.f || d->p_drop >= 1.f)) return false;
+    if (!d->resid && d->row_map) return false;
+    return true;
+}
+
 bool gemm_os_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint16_t* b_planes) {
     if (!gemm_os_enabled() || !a_kc || b_kc || !b_planes || !d->amax_a || !d->amax_b) return false;
     if (d->group_mode != 0 || d->accumulate || d->resid || d->rowdot_out || d->qk_q_rot || d->sw_gu || d->group_div > 1) return false;
@@ -273,10 +324,12 @@ bool gemm_os_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint
     return true;
 }
 
-int launch_gemm_os(const gamer_gemm_desc* d, const uint16_t* b_planes, int guard, hipStream_t st) {
+int launch_gemm_os(const gamer_gemm_desc* d, const uint16_t* b_planes, int guard, hipStream_t st, bool fwd_t) {
     OsParams p;
     p.A = d->A; p.lda = d->a_rs;
-    p.Wp = b_planes; p.ldw = d->b_ks;
+    // (fwd_t: W's TRANSPOSED pieces [K][256], dense - the Linear forward; else W [K][256] row-contiguous itself - the input gradient)
+    p.Wp = b_planes; p.ldw = fwd_t ? OS_N : d->b_ks;
+    p.resid = fwd_t ? d->resid : nullptr; p.row_map = fwd_t ? d->row_map : nullptr; p.p_drop = d->p_drop; p.seed = d->seed;
     p.C = d->C; p.ldc = d->ldc;
     p.M = d->M; p.K = d->K;
     p.alpha = d->alpha;

@@ -50,7 +50,7 @@ inject_table_fwd_kernel(const float* __restrict__ Eb, const float* __restrict__ 
 // pass 1: a workgroup takes one chunk of SEG_CH rows of ONE segment (chunks never cross a segment boundary: the grid holds
 // ceil(rows / SEG_CH) + nseg workgroups, the surplus ones leave) and writes its column sums to partial[workgroup]; pass 2 adds a
 // segment's partial rows in workgroup order - a fixed summation order, no atomics.
-constexpr int SEG_CH = 128;
+constexpr int SEG_CH = 256;
 __device__ __forceinline__ bool seg_find(const int32_t* __restrict__ offsets, int nseg, int wg, int& seg, int& r0, int& r1) {
     int prev = offsets[0], before = 0;
     for (int s = 0; s < nseg; ++s) {
@@ -74,15 +74,8 @@ segment_colsum_partial_kernel(const float* __restrict__ x, int64_t ld, int cols4
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
         const float* p = x + (int64_t)r0 * ld + 4 * c;
         int r = r0;
-        for (; r + 7 < r1; r += 8, p += 8 * ld) {                  // eight independent loads in flight, fixed combination order
-            float4 v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(p + i * ld);
-            a0.x += v[0].x; a0.y += v[0].y; a0.z += v[0].z; a0.w += v[0].w; a1.x += v[1].x; a1.y += v[1].y; a1.z += v[1].z; a1.w += v[1].w;
-            a2.x += v[2].x; a2.y += v[2].y; a2.z += v[2].z; a2.w += v[2].w; a3.x += v[3].x; a3.y += v[3].y; a3.z += v[3].z; a3.w += v[3].w;
-            a0.x += v[4].x; a0.y += v[4].y; a0.z += v[4].z; a0.w += v[4].w; a1.x += v[5].x; a1.y += v[5].y; a1.z += v[5].z; a1.w += v[5].w;
-            a2.x += v[6].x; a2.y += v[6].y; a2.z += v[6].z; a2.w += v[6].w; a3.x += v[7].x; a3.y += v[7].y; a3.z += v[7].z; a3.w += v[7].w;
-        }
+        // (four independent loads in flight, fixed combination order.  Measured: eight in flight with chunks of 128 rows 2.83 ms per step
+        // against 2.17 for this form - 3.9 TB/s)
         for (; r + 3 < r1; r += 4, p += 4 * ld) {
             const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + ld);
             const float4 v2 = *reinterpret_cast<const float4*>(p + 2 * ld), v3 = *reinterpret_cast<const float4*>(p + 3 * ld);

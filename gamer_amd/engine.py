@@ -487,6 +487,12 @@ class Engine:
                 # the parameters' fp16 pieces, packed at their values' offsets and rebuilt at the start of every pass (98 MB read,
                 # 98 MB written): the B operand of the forward and input-gradient GEMMs is then staged without its cut
                 self._amax.planes = torch.zeros(_round_up(n, 4), dtype=torch.float32, device=self.device)
+                if cfg.hidden_size == 256 and os.environ.get("GAMER_GEMM_OSF", "0") == "1":
+                    # GAMER_GEMM_OSF=1 (A/B): ... and the pieces of the TRANSPOSES of the weights with 256 output rows and a longer
+                    # contraction (o_proj, the experts' down projection): their forward then runs on the output-stationary kernel
+                    # (gamer_gemm_desc.b_planes_t).  MEASURED slower than the 128 x 128 kernel's residual epilogue (same box: 9.6
+                    # against 9.4 ms per step for the sixteen launches, 210.8 against 210.2 ms per step) - off by default.
+                    self._amax.planes_t = torch.zeros(_round_up(n, 4), dtype=torch.float32, device=self.device)
         self.lut = cfg.behavior_lut().to(self.device)
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._ws: Dict[bool, _Workspace] = {}
@@ -671,6 +677,12 @@ class Engine:
                 self._amax.register(*[self.W[l].gu for l in cfg.behavior_injection_decoder])
         else:
             ops.expert_lists(r["expert"], E, ws.perm, ws.slot, ws.offsets, ws.work)
+        if self._amax is not None and self._amax.planes_t is not None:
+            for Wl in self.W:
+                self._amax.register_transposed(Wl.self_attn["o"], 1, H, NQ)
+                self._amax.register_transposed(Wl.down, E, H, I)
+                if Wl.cross:
+                    self._amax.register_transposed(Wl.cross_attn["o"], 1, H, NQ)
         span_self = span_cross = pos_ids = None
         if self.variant == "session":
             # Qwen3SessionMulti/model.py:784-806: both masks are rebuilt from session_ids on every forward

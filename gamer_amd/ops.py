@@ -249,6 +249,10 @@ class amax_reuse:
         # (a buffer of the parameter buffer's size, or None): the fp16 pieces of those tensors packed at their values' offsets,
         # rebuilt by the same pass-start launch pair; a GEMM whose B operand is exactly one of them reads them instead of cutting
         self.planes, self._plane_keys = None, set()
+        # (a second buffer of the same size, or None): the packed pieces of the TRANSPOSES of registered matrices at their values'
+        # offsets (register_transposed: the layers with 256 output features and a long contraction - their forward runs on the
+        # output-stationary kernel, which wants W^T [K][256]); rebuilt from `planes` right after them
+        self.planes_t, self._tkeys, self._ttable, self._tplane_keys = None, [], None, set()
         self.everything = everything          # tools: every tensor counts as unchanging (kernel timing)
 
     def __enter__(self):
@@ -294,6 +298,17 @@ class amax_reuse:
                 call("gamer_split2h_planes_multi", base, self._wtable.data_ptr(), len(self._wkeys), first, self.planes.data_ptr(),
                      stream_ptr())
                 self._plane_keys = {(p_, "dense", n_) for (p_, n_) in self._wkeys}
+                self._tplane_keys = set()
+                if self.planes_t is not None and self._tkeys:
+                    # every registered matrix whose tensor has pieces in this pass: one launch transposes them all
+                    live = [(p_, b_, r_, c_) for (p_, b_, r_, c_) in self._tkeys if (p_, "dense", b_ * r_ * c_) in self._plane_keys]
+                    if live:
+                        if self._ttable is None or self._ttable[0] != live:
+                            tab = [v for (p_, b_, r_, c_) in live for i in range(b_) for v in ((p_ - base) // 4 + i * r_ * c_, r_, c_)]
+                            self._ttable = (live, torch.tensor(tab, dtype=torch.int64, device=dev), len(tab) // 3)
+                        call("gamer_split2h_transpose_multi", self.planes.data_ptr(), self._ttable[1].data_ptr(), self._ttable[2],
+                             self.planes_t.data_ptr(), stream_ptr())
+                        self._tplane_keys = {(p_, "dense", b_ * r_ * c_) for (p_, b_, r_, c_) in live}
 
     def register(self, *tensors):
         """Dense parameter tensors (inside the first stable range) that GEMMs only ever read VIEWS of (the injecting layers'
@@ -313,6 +328,16 @@ class amax_reuse:
         hipGraph capture must not contain that fill - replayed, it would wipe the maxima of everything measured before)."""
         while len(self.pools) * 1024 - self.used < n and self.pools:
             self.pools.append(torch.zeros(1024 * AMAX_WORDS, dtype=torch.int32, device=self.pools[0].device))
+
+    def register_transposed(self, t, batch, rows, cols):
+        """The dense parameter tensor `t` = `batch` row-major [rows][cols] matrices: from the next pass on the pieces of their
+        transposes are kept beside the pieces of `t` (planes_t; see __init__)."""
+        if self.planes_t is None or not t.is_contiguous() or t.numel() != batch * rows * cols or rows % 4 or cols % 4:
+            return
+        key = (t.data_ptr(), int(batch), int(rows), int(cols))
+        if key not in self._tkeys:
+            self._tkeys.append(key)
+            self.register(t)
 
     def plane_parent(self, p, geom):
         """Slot of the maximum of the dense parameter tensor with piece planes that contains the operand view (p, geom) - or None
@@ -613,6 +638,8 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
         if c is not None and c.planes is not None and group_mode == 0 and c._key(Bm.data_ptr(), geom_b) in c._plane_keys:
             # B is a parameter tensor whose fp16 piece planes were built at the start of this pass (same scale as amax_b gives)
             d.b_planes = c.planes.data_ptr() + (Bm.data_ptr() - c.stable_ranges[0][0])      # packed pieces at B's offsets
+            if a_ks == 1 and b_ks == 1 and c._key(Bm.data_ptr(), geom_b) in c._tplane_keys:
+                d.b_planes_t = c.planes_t.data_ptr() + (Bm.data_ptr() - c.stable_ranges[0][0])    # ... and of B^T
         call("gamer_gemm_f32_split", C.byref(d), 3, stream_ptr())
         return
     if F32_MATMUL_TERMS:

@@ -263,9 +263,17 @@ typedef struct {
      * the behaviour-embedding columns of the injecting layers), which gamer_swiglu_fwd_ld_tbl added on the fly in the forward
      * without storing the sums.  NULL = off. */
     const float* sw_tbl;
+    /* (ABI 9) gamer_gemm_f32_split(terms = 3), Linear-forward layout (both operands k-contiguous) with N = 256 and b_planes given:
+     * the packed pieces of B^T ([K][256], dense; gamer_split2h_transpose_multi from b_planes) at B's offset in their buffer.  Lets
+     * the output-stationary kernel (csrc/gemm_os.hip) take the forwards with 256 output features and a long contraction - o_proj
+     * (K = 384), the experts' down projection (K = 512, grouped) - with the plain store or the residual epilogue.  NULL = off. */
+    const gamer_bf16* b_planes_t;
 } gamer_gemm_desc;
 
 int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);
+/* (ABI 9) planes_t <- the packed pieces (see b_planes) of the TRANSPOSES of n row-major matrices whose pieces are in `planes`:
+ * table = int64 [n][3] = (element offset, rows, cols), rows and cols multiples of 4; the transpose's pieces land at the same offset. */
+int gamer_split2h_transpose_multi(const gamer_bf16* planes, const int64_t* table, int n, gamer_bf16* planes_t, void* stream);
 
 /* The same GEMM (same descriptor, same layouts, epilogues and fp32 inputs / outputs) with the products formed on the
  * bf16 matrix pipe: every operand value is cut EXACTLY into three bf16 pieces (x = x0 + x1 + x2, 8 + 8 + 8 significant

@@ -144,3 +144,77 @@ def test_gemm_os_grouped_experts():
         if want.numel():
             assert float((got[o[e]:o[e + 1]].double().cpu() - want).abs().max()) < 2e-6 * float(want.abs().max()), e
     assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+# ---- the Linear FORWARD of layers with 256 output features on W's transposed pieces (gamer_gemm_desc.b_planes_t) -------------------
+def _fwd_case(M, K, E, resid, p_drop, osf, seed):
+    """y = (resid +) dropout(x W^T) through ops.gemm in the forward layout; osf: the output-stationary kernel on / off."""
+    H = 256
+    g = torch.Generator().manual_seed(seed)
+    flat = (torch.randn(E * H * K + 8, generator=g) * 0.05).to(DEV)
+    W = flat[:E * H * K].view(E * H, K)
+    x = (torch.randn(M, K + 4, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).to(DEV)[:, :K]      # (padded row stride)
+    cache = ops.amax_reuse()
+    cache.stable_range(flat.data_ptr(), flat.numel() * 4)
+    cache.planes = torch.zeros(flat.numel(), dtype=torch.float32, device=DEV)
+    cache.planes_t = torch.zeros(flat.numel(), dtype=torch.float32, device=DEV)
+    kw = {}
+    offs = None
+    if E > 1:
+        cuts = sorted(torch.randint(0, M + 1, (E - 1,), generator=g).tolist())
+        cuts[1] = cuts[0]                                       # an empty segment
+        offs = torch.tensor([0] + cuts + [M], dtype=torch.int32, device=DEV)
+        kw = dict(groups=E, group_offsets=offs, strideB=H * K)
+    r = perm = None
+    if resid:
+        r = torch.randn(M, H, generator=g).to(DEV)
+        perm = torch.randperm(M, generator=g).to(torch.int32).to(DEV) if E > 1 else None
+        kw.update(resid=r, row_map=perm, p_drop=p_drop, seed=1234)
+    n0 = _launches()
+    with _env(GAMER_GEMM_OSF=int(osf), GAMER_GEMM_OS_MIN_M=1), ops.f32_matmul("split3"), cache:
+        for _ in range(2):
+            cache.reset()
+            cache.register_transposed(W, E, H, K)
+            y = torch.full((M, H), float("nan"), device=DEV)
+            ops.gemm(x, x.stride(0), 1, W, K, 1, y, H, M, H, K, **kw)
+    torch.cuda.synchronize()
+    assert (_launches() > n0) == bool(osf)
+    return x, W, y, r, perm, offs
+
+
+@pytest.mark.parametrize("M", [1000, 4099, 37])
+@pytest.mark.parametrize("K,E", [(384, 1), (512, 6), (64, 1)])
+def test_gemm_os_forward_on_transposed_pieces_plain_store(K, E, M):
+    x, W, y, _, _, offs = _fwd_case(M, K, E, False, 0.0, True, seed=K + M)
+    _, _, y_tile, _, _, _ = _fwd_case(M, K, E, False, 0.0, False, seed=K + M)
+    o = [0, M] if offs is None else offs.cpu().tolist()
+    for e in range(E):
+        xs = x[o[e]:o[e + 1]].double().cpu()
+        if xs.numel() == 0:
+            continue
+        wd = W[e * 256:(e + 1) * 256].double().cpu()
+        ref, sc = xs @ wd.T, xs.abs() @ wd.abs().T
+        err = ((y[o[e]:o[e + 1]].double().cpu() - ref).abs() / sc.clamp_min(1e-300))
+        assert float(err.max()) < 1.5e-6 and float(err.pow(2).mean().sqrt()) < 1e-7, (e, float(err.max()))
+    assert float((y - y_tile).abs().max()) <= 3e-6 * float(y_tile.abs().max())
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.2])
+@pytest.mark.parametrize("K,E", [(384, 1), (512, 6)])
+def test_gemm_os_forward_residual_epilogue_equals_the_tile_kernels(K, E, p_drop):
+    """resid + dropout(x W^T), scattered through the row map for the experts: the same dropout mask function as csrc/gemm.hip (the
+    element's flat index in the OUTPUT), so the two kernels agree to the rounding of the product."""
+    M = 3000
+    x, W, y, r, perm, offs = _fwd_case(M, K, E, True, p_drop, True, seed=7 + K)
+    _, _, y_tile, _, _, _ = _fwd_case(M, K, E, True, p_drop, False, seed=7 + K)
+    assert bool(torch.isfinite(y).all())
+    d = (y - y_tile).abs()
+    assert float(d.max()) <= 5e-6 * float(y_tile.abs().max())
+    if p_drop == 0.0:
+        o = [0, M] if offs is None else offs.cpu().tolist()
+        rows = torch.arange(M) if perm is None else perm.cpu().long()
+        want = torch.empty(M, 256, dtype=torch.float64)
+        for e in range(E):
+            seg = slice(o[e], o[e + 1])
+            want[rows[seg]] = r.double().cpu()[rows[seg]] + x[seg].double().cpu() @ W[e * 256:(e + 1) * 256].double().cpu().T
+        assert float((y.double().cpu() - want).abs().max()) < 5e-6 * float(want.abs().max())
