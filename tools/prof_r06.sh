@@ -9,7 +9,7 @@ if [ $# -eq 0 ]; then set -- "f32 split3" "f32 f32" "bf16 f32"; fi
 CFGS=("$@")
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out
-python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err; tail -2 $O/${TAG}_bench_default.err
+python bench.py --steps 20 --warmup 5 --kernel-rows 60 > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err; tail -2 $O/${TAG}_bench_default.err
 export TMPDIR=/tmp; cd /tmp
 export GAMER_WGRAD_TUNE_FILE=$O/${TAG}_wgrad_tune.json
 for cfg in "${CFGS[@]}"; do set -- $cfg; python3 $GRAFT_REPO_ROOT/bench.py --dtype $1 --matmul $2 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-secondary > /dev/null 2>&1; done
