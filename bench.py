@@ -269,6 +269,18 @@ class KernelTimer:
         return out
 
 
+def _kernel_choice_counters() -> dict:
+    """Launch counters of the kernels that replace the 128 x 128 GEMM on their shapes (diagnostic exports of the library)."""
+    import ctypes
+    from gamer_amd import _lib
+    lib, out = _lib.load(), {}
+    for name in ("gemm_as", "gemm_os", "gemm_wg"):
+        fn = getattr(lib, f"gamer_debug_{name}_launches")
+        fn.restype, fn.argtypes = ctypes.c_longlong, []
+        out[name] = int(fn())
+    return out
+
+
 def usable_cpus() -> int:
     """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota."""
     try:
@@ -710,11 +722,13 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
         timer.records = []
     log("timed region")
     timer.enabled = not args.no_kernel_timing
+    choice0 = _kernel_choice_counters()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         loss = step(i)
     barrier()
     elapsed = time.perf_counter() - t0
+    choice1 = _kernel_choice_counters()
     timer.enabled = False
     final_loss = float(loss)
     log(f"timed region done: {elapsed / args.steps * 1e3:.1f} ms/step")
@@ -905,6 +919,11 @@ def run_leg(args, rank, world, local_rank, force_dist, timer):
             },
             "roofline": roofline,
             "kernels": kernels[:args.kernel_rows],
+            # which of the alternative kernels ran (launches per step inside the timed region) and the switches in effect: A/B numbers
+            # are attributable to a kernel set from the line alone
+            "kernel_choice": {"launches_per_step": {k: (choice1[k] - choice0[k]) / args.steps for k in choice1},
+                              "split_inject": bool(getattr(eng, "split_inject", False)),
+                              "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("GAMER_")}},
             "kernels_measured_in": (f"warm-up steps 2..{args.warmup} (every launch between HIP events)" if warm_kernels
                                     else "timed region"),
             "loss": final_loss,
