@@ -146,6 +146,9 @@ class KernelTimer:
                 kind = "gemm_fwd_resid"                 # fused residual + dropout epilogue (a different instantiation)
             if kw.get("rowdot") is not None:
                 kind = "gemm_dgrad_delta"               # o_proj dgrad that also emits the attention backward's delta
+            if kw.get("swiglu_fwd") is not None:
+                kind = "gemm_fwd_swiglu"                # gate|up projection with the SwiGLU forward in its epilogue: C and hm are stored
+                timer._bytes = (M * K + N * K) * esz + (M * N + M * N // 2) * esz
             if kw.get("swiglu_bwd") is not None:
                 kind = "gemm_dgrad_swiglu"              # down-projection dgrad with the SwiGLU backward in its epilogue: C is not
                 timer._bytes = (M * K + N * K) * esz + 4 * M * N * esz     # stored; gate | up are read and overwritten (4 M N)

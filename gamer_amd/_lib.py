@@ -59,6 +59,7 @@ class GemmDesc(C.Structure):
         ("wgrad_ws", c_void_p), ("wgrad_ws_floats", c_int64),
         ("sw_gu", c_void_p), ("sw_ld", c_int64),
         ("group_div", c_int), ("sw_tbl", c_void_p), ("b_planes_t", c_void_p),
+        ("sw_hm", c_void_p), ("sw_row_group", c_void_p),
     ]
 
 

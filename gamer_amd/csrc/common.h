@@ -314,10 +314,14 @@ __device__ __forceinline__ int wave_max_i32_dpp(int v) {
                max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+// silu(x) = x sigmoid(x) with the hardware reciprocal (v_rcp_f32: 1 ulp) instead of an IEEE division (ten instructions): since round 6 the
+// SwiGLU forward also runs in a GEMM epilogue (gemm_as.hip, EPI 5), where vector instructions are matrix time; every kernel uses this one
+// definition, so a fused epilogue and the stand-alone kernel still produce the same bits
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 // d/dx silu(x) = s*(1 + x*(1-s)), s = sigmoid(x)
 __device__ __forceinline__ float dsilu_f(float x) {
-    float s = 1.f / (1.f + __expf(-x));
+    const float s = sigmoid_f(x);
     return s * (1.f + x * (1.f - s));
 }
 

@@ -1518,7 +1518,8 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     p.group_div = d->group_div > 1 ? d->group_div : 1; p.sw_tbl = d->sw_tbl;
     GAMER_CHECK_ARG(d->group_div <= 1 || (d->group_mode == 0 && d->group_offsets && d->groups % d->group_div == 0),
                     "gamer_gemm_f32: group_div = %d needs group_mode 0, group_offsets and groups (%d) a multiple of it", d->group_div, d->groups);
-    GAMER_CHECK_ARG(!d->sw_tbl || (d->sw_gu && aligned16(d->sw_tbl)), "gamer_gemm_f32: sw_tbl is an option of the SwiGLU-backward epilogue (sw_gu)");
+    GAMER_CHECK_ARG(!d->sw_tbl || ((d->sw_gu || d->sw_hm) && aligned16(d->sw_tbl)),
+                    "gamer_gemm_f32: sw_tbl is an option of the SwiGLU epilogues (sw_gu, sw_hm)");
     GAMER_CHECK_ARG(!d->sw_gu || (split == 3 && d->group_mode == 0 && !d->accumulate && !d->resid && !d->rowdot_out && !d->qk_q_rot &&
                                   d->alpha == 1.f && d->N % 4 == 0 && d->sw_ld >= 2 * (int64_t)d->N && d->sw_ld % 4 == 0 &&
                                   aligned16(d->sw_gu) && d->p_drop >= 0.f && d->p_drop < 1.f),
@@ -1556,8 +1557,24 @@ static int gemm_entry(const gamer_gemm_desc* d, void* stream, int split) {
     GAMER_CHECK_ARG(!d->resid || (d->group_mode == 0 && !d->accumulate && a_kc && b_kc && d->ldc % 4 == 0 &&
                                   aligned16(d->resid) && aligned16(d->C) && d->p_drop >= 0.f && d->p_drop < 1.f),
                     "gamer_gemm_f32: the fused residual epilogue needs a Linear-forward layout, ldc %% 4 == 0, no accumulate");
+    GAMER_CHECK_ARG(!d->sw_hm || (d->group_mode == 0 && a_kc && b_kc && !d->accumulate && !d->resid && !d->rowdot_out && !d->qk_q_rot &&
+                                  !d->sw_gu && d->alpha == 1.f && d->N % 8 == 0 && d->ldc >= d->N && d->ldc % 4 == 0 && aligned16(d->sw_hm) &&
+                                  aligned16(d->C) && (!d->sw_tbl || d->sw_row_group) && d->p_drop >= 0.f && d->p_drop < 1.f),
+                    "gamer_gemm_f32: the SwiGLU-forward epilogue (sw_hm) needs a Linear-forward layout with N = 2 I (N=%d), alpha = 1, no other "
+                    "epilogue, and sw_row_group with sw_tbl", d->N);
     // short-contraction Linear forward from packed weight pieces: the activation-stationary kernel (csrc/gemm_as.hip)
     if (split == 3 && gemm_as_eligible(d, a_kc, b_kc, p.b_planes)) return launch_gemm_as(d, p.b_planes, b_kc, (hipStream_t)stream);
+    if (d->sw_hm) {
+        // sw_hm not taken by that kernel (few rows, no packed pieces yet, another product form): the projection as it would run without
+        // it, then gamer_swiglu_fwd_ld(_tbl) on its output - the same results by definition
+        gamer_gemm_desc d2 = *d;
+        d2.sw_hm = nullptr; d2.sw_row_group = nullptr; d2.sw_tbl = nullptr; d2.amax_c = nullptr;
+        const int rc = gemm_entry(&d2, stream, split);
+        if (rc) return rc;
+        if (d->amax_c) gamer_amax_sink(d->amax_c, nullptr);
+        return d->sw_tbl ? gamer_swiglu_fwd_ld_tbl(d->C, d->ldc, d->M, d->N / 2, d->p_drop, d->seed, d->sw_hm, d->sw_tbl, d->sw_row_group, stream)
+                         : gamer_swiglu_fwd_ld(d->C, d->ldc, d->M, d->N / 2, d->p_drop, d->seed, d->sw_hm, stream);
+    }
     // plain input gradient with 256 input features: the output-stationary kernel (csrc/gemm_os.hip)
     if (split == 3 && gemm_os_eligible(d, a_kc, b_kc, p.b_planes)) return launch_gemm_os(d, p.b_planes, g_split3_guard, (hipStream_t)stream);
     // Linear forward with 256 output features and K > 256 (o_proj, the experts' down projection): the same kernel on W's transposed pieces

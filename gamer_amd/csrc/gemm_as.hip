@@ -65,6 +65,11 @@ struct AsParams {
     int accumulate;                            // C += (the cross block's gate)
     const float* rowdot_other; float* rowdot_out; int rowdot_S;      // EPI 2: per (row, head of 64 columns) dot of C with `other` (o_proj)
     float* sw_gu; int64_t sw_ld; float p_drop; uint64_t seed;        // EPI 4: SwiGLU backward in place of the store (down projection)
+    // EPI 5 (W k-contiguous, N = 2 I, the experts' fused gate|up projection): besides C = gate | up the kernel stores
+    // hm[m][c] = dropout(silu(gate[m][c] + tg) * (up[m][c] + tu)) - gamer_swiglu_fwd_ld(_tbl)'s result without its pass over C.
+    // The slabs are walked gate 0, up 0, gate 1, up 1, ...; tbl (optional): [groups][N] added to the values hm is computed from (not to
+    // C); group_div: that many consecutive row groups share one W.
+    float* hm; const float* tbl; int group_div;
 };
 
 // KP = K / 64 panels.  WRC = false: W [N][K] (k-contiguous, the Linear-forward layout): piece images [n][64 k] per panel, fragments by
@@ -155,14 +160,14 @@ gemm_as_kernel(const AsParams p) {
             const int nl = f / QPR, g = f % QPR;
             nl_[i] = nl;
             lds_off[i] = (g >> 4) * AS_PANEL + as_off(nl, (4 * g) & 63);
-            wsrc[i] = reinterpret_cast<const uint4*>(p.Wp) + (((int64_t)grp * p.strideW + (int64_t)nl * p.ldw + 4 * g) >> 2);
+            wsrc[i] = reinterpret_cast<const uint4*>(p.Wp) + (((int64_t)(grp / p.group_div) * p.strideW + (int64_t)nl * p.ldw + 4 * g) >> 2);
         } else {
             // item f: k row f / (AS_SLAB / 4), quad f % (AS_SLAB / 4) of the slab's columns; image [k][AS_SLAB n] (rows of 2 AS_SLAB bytes:
             // a half wave's transposing read covers four whole rows = 256 bytes = every bank once)
             const int k = f / (AS_SLAB / 4), nq = f % (AS_SLAB / 4);
             nl_[i] = 4 * nq;
             lds_off[i] = k * AS_SLAB + 4 * nq;                             // (16-bit elements)
-            wsrc[i] = reinterpret_cast<const uint4*>(p.Wp) + (((int64_t)grp * p.strideW + (int64_t)k * p.ldw + 4 * nq) >> 2);
+            wsrc[i] = reinterpret_cast<const uint4*>(p.Wp) + (((int64_t)(grp / p.group_div) * p.strideW + (int64_t)k * p.ldw + 4 * nq) >> 2);
         }
     }
     const int64_t slab_stride = WRC ? (AS_SLAB >> 2) : (((int64_t)AS_SLAB * p.ldw) >> 2);         // uint4 between slabs
@@ -202,7 +207,14 @@ gemm_as_kernel(const AsParams p) {
         return out;
     };
     float hd_dot = 0.f;                                                   // EPI 2: the head's dot over the slabs seen so far
-    float emax = 0.f;                                                     // EPI 4: max |d gate|, |d up| stored
+    float emax = 0.f;                                                     // EPI 4: max |d gate|, |d up| stored; EPI 5: max |hm|
+    float4 gsave[EPI == 5 ? 4 * AS_NT : 1];                               // EPI 5: the gate slab's values (+ table) until the up slab is done
+    // EPI 5 with a table: this workgroup's rows are ONE group - its table row waits in LDS (behind the W buffers)
+    float* const tbl_lds = reinterpret_cast<float*>(as_raw + (size_t)(AS_DEPTH == 2 ? 3 : 2) * 2 * KP * AS_PANEL * sizeof(bf16_t));
+    if (EPI == 5 && p.tbl) {
+        const float4* src = reinterpret_cast<const float4*>(p.tbl + (int64_t)grp * p.N);
+        for (int i = tid; i < p.N / 4; i += AS_THREADS_K) reinterpret_cast<float4*>(tbl_lds)[i] = src[i];
+    }
 
     float cmax = 0.f;
     float* crow = p.C + (int64_t)m * p.ldc;
@@ -238,7 +250,7 @@ gemm_as_kernel(const AsParams p) {
             // epilogue: lane = output row m, acc[nt][reg] = column slab + 32 nt + (reg & 3) + 8 (reg >> 2) + 4 h
             float part = 0.f;                                             // EPI 2: this lane's share of the slab's row-dot
             if (valid_m) {
-                const bool track = p.amax_c != nullptr && j * AS_SLAB >= p.amax_c_col0;
+                const bool track = EPI != 5 && p.amax_c != nullptr && j * AS_SLAB >= p.amax_c_col0;
 #pragma unroll
                 for (int nt = 0; nt < AS_NT; ++nt)
 #pragma unroll
@@ -280,6 +292,27 @@ gemm_as_kernel(const AsParams p) {
                                 const float4 o4 = *reinterpret_cast<const float4*>(p.rowdot_other + (int64_t)m * p.ldc + col);
                                 part += (t4.x * o4.x + t4.y * o4.y) + (t4.z * o4.z + t4.w * o4.w);
                             }
+                            if (EPI == 5) {
+                                const int half = p.N >> 1;
+                                float4 x4 = t4;
+                                if (p.tbl) {
+                                    const float4 tb = *reinterpret_cast<const float4*>(tbl_lds + col);
+                                    x4.x += tb.x; x4.y += tb.y; x4.z += tb.z; x4.w += tb.w;
+                                }
+                                if (col < half) {
+                                    gsave[EPI == 5 ? nt * 4 + g4 : 0] = x4;
+                                } else {
+                                    const float4 g = gsave[EPI == 5 ? nt * 4 + g4 : 0];
+                                    const int hc = col - half;
+                                    const DropoutRng rng(p.p_drop, p.seed);
+                                    float mu[4];
+                                    rng.mult4((uint32_t)(((int64_t)m * half + hc) >> 2), mu);
+                                    const float4 o = make_float4(mu[0] * (silu_f(g.x) * x4.x), mu[1] * (silu_f(g.y) * x4.y),
+                                                                 mu[2] * (silu_f(g.z) * x4.z), mu[3] * (silu_f(g.w) * x4.w));
+                                    *reinterpret_cast<float4*>(p.hm + (int64_t)m * half + hc) = o;
+                                    emax = fmaxf(fmaxf(fmaxf(emax, fabsf(o.x)), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
+                                }
+                            }
                             if (track) cmax = fmaxf(fmaxf(fmaxf(cmax, fabsf(t4.x)), fabsf(t4.y)), fmaxf(fabsf(t4.z), fabsf(t4.w)));
                         }
                     }
@@ -305,9 +338,11 @@ gemm_as_kernel(const AsParams p) {
         // Order inside a slab: request slab j + 1 | MFMAs of slab j | slab j + 1 -> LDS | epilogue of slab j.  The LDS store waits for
         // the W loads with nothing younger in the memory queue; with the epilogue's C stores in front of it the compiler's counted wait
         // (a variable number of stores in branches: it assumes the worst) also waited for the stores it had just issued.
+        // EPI 5 walks the slabs gate 0, up 0, gate 1, up 1, ... (the up slab of a column meets its gate slab's values in gsave)
+        auto slab_of = [&](int i) { return EPI == 5 ? (i >> 1) + (i & 1) * (n_slabs >> 1) : i; };
 #pragma unroll 1
-        for (int j = 0; j < n_slabs; ++j) {
-            const int buf = j & 1, jn = min(j + 1, n_slabs - 1);
+        for (int i = 0; i < n_slabs; ++i) {
+            const int j = slab_of(i), buf = i & 1, jn = slab_of(min(i + 1, n_slabs - 1));
             if (!(AS_ABLATE & 4)) load_slab(jn);
             __builtin_amdgcn_sched_barrier(0);             // (or the scheduler sinks the loads to their use, behind the MFMAs)
             mfma_slab(j, buf);
@@ -340,7 +375,7 @@ gemm_as_kernel(const AsParams p) {
         }
     }
     if (p.amax_c) {
-        uint32_t mw = __float_as_uint(EPI == 4 ? emax : cmax);
+        uint32_t mw = __float_as_uint((EPI == 4 || EPI == 5) ? emax : cmax);
 #pragma unroll
         for (int o2 = 32; o2 > 0; o2 >>= 1) mw = max(mw, (uint32_t)__shfl_xor((int)mw, o2, 64));
         if (lane == 0 && mw) atomicMax(&amax_word, mw);
@@ -361,7 +396,16 @@ static inline bool gemm_as_enabled() {
 // (input gradient of a layer with 256 output features): K = 256, store / accumulate, row-dot or SwiGLU-backward epilogue.
 bool gemm_as_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint16_t* b_planes) {
     if (!gemm_as_enabled() || !a_kc || !b_planes || !d->amax_b) return false;
-    if (d->group_mode != 0 || d->resid || d->qk_q_rot || d->group_div > 1 || d->sw_tbl) return false;
+    if (d->group_mode != 0 || d->resid || d->qk_q_rot) return false;
+    if ((d->group_div > 1 || d->sw_tbl) && !d->sw_hm) return false;      // (row groups that share a W / the row table: the fused SwiGLU forward only)
+    if (d->sw_hm) {
+        // the experts' gate|up projection with the SwiGLU forward in its epilogue: W k-contiguous, N = 2 I in whole slab pairs, no other epilogue
+        static EnvSwitch sw5("GAMER_GEMM_AS_SWIGLU");        // (0: the projection and gamer_swiglu_fwd_ld(_tbl) as two launches - A/B runs)
+        if (sw5.get(1) == 0 || !b_kc || d->accumulate || d->rowdot_out || d->sw_gu || d->N % (2 * AS_SLAB) != 0 || d->alpha != 1.f ||
+            !aligned16(d->sw_hm) || (d->sw_tbl && (!aligned16(d->sw_tbl) || !d->group_offsets)) || d->p_drop < 0.f || d->p_drop >= 1.f)
+            return false;
+        if (d->group_div > 1 && (!d->group_offsets || d->groups % d->group_div != 0)) return false;
+    }
     // (a workgroup takes 128 rows: below ~16 k rows the launch leaves most CUs idle and the tile kernel is the better fit;
     // GAMER_GEMM_AS_MIN_M lowers the bar for tests)
     static EnvSwitch min_m("GAMER_GEMM_AS_MIN_M");
@@ -373,8 +417,8 @@ bool gemm_as_eligible(const gamer_gemm_desc* d, bool a_kc, bool b_kc, const uint
         if (d->accumulate || d->rowdot_out || d->sw_gu || d->b_rs % 4 != 0) return false;
         // (grouped: the experts' gate|up projection at d_in = 256: 1.37 -> 1.30 ms, W is 1 MB per 128 rows there; the injecting layers'
         // d_in = 320 would need 160 piece registers = one workgroup per CU: measured 1.62 -> 2.4 ms, stays on the tile kernel)
-        if (d->groups != 1 && d->amax_c) return false;
-        if (d->amax_c && d->amax_c_col0 % AS_SLAB != 0) return false;
+        if (d->groups != 1 && d->amax_c && !d->sw_hm) return false;      // (with sw_hm amax_c is the slot of max |hm|)
+        if (d->amax_c && !d->sw_hm && d->amax_c_col0 % AS_SLAB != 0) return false;
         return true;
     }
     // W row-contiguous.  Measured in the step (same box): the plain / accumulating form (the cross block's gate) 0.22 ms per launch
@@ -407,11 +451,12 @@ int launch_gemm_as(const gamer_gemm_desc* d, const uint16_t* b_planes, bool b_kc
     p.accumulate = d->accumulate;
     p.rowdot_other = d->rowdot_other; p.rowdot_out = d->rowdot_out; p.rowdot_S = d->rowdot_S;
     p.sw_gu = d->sw_gu; p.sw_ld = d->sw_ld; p.p_drop = d->p_drop; p.seed = d->seed;
+    p.hm = d->sw_hm; p.tbl = d->sw_hm ? d->sw_tbl : nullptr; p.group_div = d->group_div > 1 ? d->group_div : 1;
     const int kp = d->K / 64;
-    const size_t shmem = (size_t)(AS_DEPTH == 2 ? 3 : 2) * 2 * kp * AS_PANEL * sizeof(bf16_t);
+    const size_t shmem = (size_t)(AS_DEPTH == 2 ? 3 : 2) * 2 * kp * AS_PANEL * sizeof(bf16_t) + (d->sw_hm ? (size_t)d->N * sizeof(float) : 0);
     // eight waves per workgroup for the wide ungrouped Linear forwards (q|k|v, head), four otherwise (see the kernel)
     static EnvSwitch wv("GAMER_GEMM_AS_WAVES");
-    const int nw = wv.is_set() ? (wv.get(4) == 8 ? 8 : 4) : ((b_kc && d->groups == 1 && d->N >= 512 && AS_WAVES == 4) ? 8 : AS_WAVES);
+    const int nw = d->sw_hm ? 4 : (wv.is_set() ? (wv.get(4) == 8 ? 8 : 4) : ((b_kc && d->groups == 1 && d->N >= 512 && AS_WAVES == 4) ? 8 : AS_WAVES));
     const dim3 grid((d->M + 32 * nw - 1) / (32 * nw) + (p.group_offsets ? d->groups : 0));
 #define GAMER_LAUNCH_AS_W(KPV, WRCV, EPIV, NWV)                                                                               \
     do {                                                                                                                      \
@@ -426,7 +471,15 @@ int launch_gemm_as(const gamer_gemm_desc* d, const uint16_t* b_planes, bool b_kc
     } while (0)
 #define GAMER_LAUNCH_AS(KPV, WRCV, EPIV)                                                                                      \
     do { if (nw == 8) GAMER_LAUNCH_AS_W(KPV, WRCV, EPIV, 8); else GAMER_LAUNCH_AS_W(KPV, WRCV, EPIV, 4); } while (0)
-    if (b_kc) {
+    if (b_kc && d->sw_hm) {
+        // (one shared-memory size per instantiation is registered once: always ask for the table's room)
+        switch (kp) {
+            case 1: GAMER_LAUNCH_AS_W(1, false, 5, 4); break;
+            case 2: GAMER_LAUNCH_AS_W(2, false, 5, 4); break;
+            case 3: GAMER_LAUNCH_AS_W(3, false, 5, 4); break;
+            default: GAMER_LAUNCH_AS_W(4, false, 5, 4); break;
+        }
+    } else if (b_kc) {
         switch (kp) {
             case 1: GAMER_LAUNCH_AS(1, false, 0); break;
             case 2: GAMER_LAUNCH_AS(2, false, 0); break;

@@ -726,6 +726,9 @@ class Engine:
         # attention adds its behaviour bias to v afterwards (qknorm_rope_fwd), so only the self attention's v can take it
         h2_now = split_attn and self.h2_attention and self.matmul == "split3" and p_att < 0.75
 
+        # (three-product form) the SwiGLU forward as the epilogue of the experts' gate|up projection (gamer_gemm_desc.sw_hm); A/B switch
+        fuse_swiglu_fwd = (not bf16 and self.matmul == "split3" and os.environ.get("GAMER_FUSE_SWIGLU_FWD", "1") != "0")
+
         def v_amax(qkv_buf):
             return dict(c_amax=(qkv_buf[:, NQ + NKV:], NQ + NKV)) if (h2_now and not bf16 and self.gemm_c_amax) else {}
 
@@ -817,16 +820,26 @@ class Engine:
                 ops.rmsnorm_fwd(xcur, W.ln3, eps, hin, H, ws.slot)
                 tb = ws._buf((f"l{l}_" if train else "l_") + "inject_tbl", (E * NB1, 2 * I))
                 ops.inject_table_fwd(W.beh, W.gu, din, H, E, 2 * I, tb)
-                ops.linear_fwd(hin, H, Wm.gu, din, A["gu"], 2 * I, T, 2 * I, H, strideB=2 * I * din, **grp)
-                ops.swiglu_fwd_ld_tbl(A["gu"], 2 * I, T, I, p_res, self._seed(l, 4), A["hm"], tb, ws.row_group)
+                if fuse_swiglu_fwd:
+                    # one call: gate|up AND hm (the SwiGLU forward as the projection's epilogue; rows grouped by (expert, behaviour))
+                    ops.gemm(hin, H, 1, Wm.gu, din, 1, A["gu"], 2 * I, T, 2 * I, H, strideB=2 * I * din, groups=E * NB1,
+                             group_offsets=ws.grp_offsets, group_div=NB1, p_drop=p_res, seed=self._seed(l, 4),
+                             swiglu_fwd=(A["hm"], tb, ws.row_group))
+                else:
+                    ops.linear_fwd(hin, H, Wm.gu, din, A["gu"], 2 * I, T, 2 * I, H, strideB=2 * I * din, **grp)
+                    ops.swiglu_fwd_ld_tbl(A["gu"], 2 * I, T, I, p_res, self._seed(l, 4), A["hm"], tb, ws.row_group)
             else:
                 ops.rmsnorm_fwd(xcur, W.ln3, eps, A["hin"], din, ws.slot)
                 if W.inject:
                     ops.rowtable_fwd(W.beh, r["beh_idx"], A["hin"], din, H, ws.slot)
                 # gate_proj and up_proj of the position's expert in ONE grouped GEMM against the stacked [2 I, din] weight (FFN.py:25-27:
                 # both read the same input): A["gu"][:, :I] = gate, [:, I:] = up
-                ops.linear_fwd(A["hin"], din, Wm.gu, din, A["gu"], 2 * I, T, 2 * I, din, strideB=2 * I * din, **grp)
-                ops.swiglu_fwd_ld(A["gu"], 2 * I, T, I, p_res, self._seed(l, 4), A["hm"])
+                if fuse_swiglu_fwd and din == H:
+                    ops.gemm(A["hin"], din, 1, Wm.gu, din, 1, A["gu"], 2 * I, T, 2 * I, din, strideB=2 * I * din, p_drop=p_res,
+                             seed=self._seed(l, 4), swiglu_fwd=(A["hm"], None, None), **grp)
+                else:
+                    ops.linear_fwd(A["hin"], din, Wm.gu, din, A["gu"], 2 * I, T, 2 * I, din, strideB=2 * I * din, **grp)
+                    ops.swiglu_fwd_ld(A["gu"], 2 * I, T, I, p_res, self._seed(l, 4), A["hm"])
             xnext = ws.x[l + 1][0] if l + 1 < cfg.num_hidden_layers else ws.x_final
             # down projection: rows are in expert-sorted order, the epilogue scatters them back to token
             # order through perm while adding the residual and applying dropout (FFN.py:25-27, model.py:241)

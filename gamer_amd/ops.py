@@ -564,12 +564,12 @@ def set_f32_matmul(mode) -> int:
 
 def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=False, groups=1, group_mode=0,
          group_offsets=None, strideB=0, strideC=0, kchunk=0, resid=None, row_map=None, p_drop=0.0, seed=0,
-         rowdot=None, qknorm=None, c_amax=None, swiglu_bwd=None, group_div=0, sw_tbl=None):
+         rowdot=None, qknorm=None, c_amax=None, swiglu_bwd=None, group_div=0, sw_tbl=None, swiglu_fwd=None):
     """C[m][n] (=|+=) alpha * sum_k A(m,k) B(n,k); see gamer_gemm_desc in include/gamer_hip.h.  bf16 operands go to
     gamer_gemm_bf16 (k-contiguous x k-contiguous, or the token-major wgrad form; see gamer_gemm_bf16_desc)."""
     if A.dtype == torch.bfloat16:
-        if group_div > 1 or sw_tbl is not None:
-            raise RuntimeError("group_div / sw_tbl are options of the fp32 GEMM")
+        if group_div > 1 or sw_tbl is not None or swiglu_fwd is not None:
+            raise RuntimeError("group_div / sw_tbl / swiglu_fwd are options of the fp32 GEMM")
         return _gemm_bf16(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha, accumulate, groups, group_mode,
                           group_offsets, strideB, strideC, kchunk, resid, row_map, p_drop, seed, rowdot, qknorm, swiglu_bwd)
     d = GemmDesc()
@@ -613,6 +613,13 @@ def gemm(A, a_rs, a_ks, Bm, b_rs, b_ks, Cm, ldc, M, N, K, alpha=1.0, accumulate=
         if _AMAX_REUSE is not None and F32_MATMUL_TERMS == 3 and ld_gu == 2 * N:
             d.amax_c, d.amax_c_col0 = _AMAX_REUSE.preset(gu, (1, 0, 1, M * ld_gu, M * ld_gu)), 0
     d.group_div = int(group_div)
+    if swiglu_fwd is not None:
+        # (hm, tbl or None, row_group or None): C = gate | up AND hm = dropout(silu(gate + tg) * (up + tu)) from one call
+        # (gamer_gemm_desc.sw_hm); the maximum of hm goes to the slot its consumer GEMM will take
+        hm, tbl, row_group = swiglu_fwd
+        d.sw_hm, d.sw_tbl, d.sw_row_group = ptr(hm), ptr(tbl), ptr(row_group)
+        if _AMAX_REUSE is not None and F32_MATMUL_TERMS == 3:
+            d.amax_c, d.amax_c_col0 = _AMAX_REUSE.preset(hm, (1, 0, 1, M * (N // 2), M * (N // 2))), 0
     if group_mode == 1 and DETERMINISTIC_WGRAD:
         n_chunks = (K + kchunk - 1) // kchunk + (groups if group_offsets is not None else 0)
         need = n_chunks * ((M + 127) // 128) * ((N + 127) // 128) * 16384

@@ -268,6 +268,15 @@ typedef struct {
      * the output-stationary kernel (csrc/gemm_os.hip) take the forwards with 256 output features and a long contraction - o_proj
      * (K = 384), the experts' down projection (K = 512, grouped) - with the plain store or the residual epilogue.  NULL = off. */
     const gamer_bf16* b_planes_t;
+    /* (ABI 9) SwiGLU FORWARD in the epilogue (gamer_gemm_f32_split, terms = 3; Linear-forward layout, N = 2 I: the experts' fused
+     * gate|up projection, ref:SeqRec/models/generative/Qwen3Moe/FFN.py:25-27): besides C = gate | up the call leaves
+     * sw_hm[m][c] = dropout(silu(gate[m][c] + tg) * (up[m][c] + tu)), [M][N / 2] contiguous, exactly what
+     * gamer_swiglu_fwd_ld(C, ldc, M, N / 2, p_drop, seed, sw_hm) - with sw_tbl: gamer_swiglu_fwd_ld_tbl(..., sw_tbl, sw_row_group) -
+     * computes from C (same arithmetic, same dropout masks), without the pass over C when the activation-stationary kernel takes the
+     * call; otherwise the library runs that kernel itself after the GEMM.  amax_c then receives max |sw_hm|.  sw_tbl here is
+     * [groups][N] with the row groups of group_offsets (group_div groups per B); sw_row_group: int32 [M], the group of every row.  */
+    float* sw_hm;
+    const int32_t* sw_row_group;
 } gamer_gemm_desc;
 
 int gamer_gemm_f32(const gamer_gemm_desc* d, void* stream);

@@ -306,3 +306,78 @@ def test_gemm_as_swiglu_backward_epilogue(T, offsets):
     if offsets is not None and offsets[0] > 0:
         assert torch.equal(got[:offsets[0]].cpu(), gu0[:offsets[0]])
         assert torch.equal(got[offsets[-1]:].cpu(), gu0[offsets[-1]:])
+
+
+# ---- the SwiGLU forward as the epilogue of the experts' gate|up projection (gamer_gemm_desc.sw_hm) ---------------------------------
+@pytest.mark.parametrize("p_drop", [0.0, 0.2])
+@pytest.mark.parametrize("table", [False, True])
+def test_gemm_as_swiglu_forward_epilogue_equals_the_two_launches(table, p_drop):
+    """One call leaves gate|up AND hm = dropout(silu(gate + tg) * (up + tu)): the bits of the projection followed by
+    gamer_swiglu_fwd_ld(_tbl) - the epilogue runs the same arithmetic on the values it stores - with the rows grouped by (expert,
+    behaviour) (24 groups, four per weight matrix, an empty group, ragged boundaries) when the row table is given; the maximum of hm
+    reaches the slot its consumer will take.  Without packed pieces (first pass) / with GAMER_GEMM_AS_SWIGLU=0 the library runs
+    the two launches itself: same results."""
+    from test_ops_gpu import _slot_value
+    T, I, K, E, NB1 = 3000, 512, 256, 6, 4
+    N = 2 * I
+    g = torch.Generator().manual_seed(11 + int(table))
+    flat = (torch.randn(E * N * K + 8, generator=g) * 0.05).to(DEV)
+    W = flat[:E * N * K].view(E * N, K)
+    x = (torch.randn(T, K, generator=g) * torch.exp(torch.randn(T, 1, generator=g))).to(DEV)
+    G = E * NB1 if table else E
+    cuts = sorted(torch.randint(0, T + 1, (G - 1,), generator=g).tolist())
+    cuts[3] = cuts[2]                                               # an empty group
+    offs = torch.tensor([0] + cuts + [T], dtype=torch.int32, device=DEV)
+    tbl = torch.randn(G, N, generator=g).to(DEV) if table else None
+    o = offs.cpu().tolist()
+    row_group = torch.cat([torch.full((o[i + 1] - o[i],), i, dtype=torch.int32) for i in range(G)]).to(DEV) if table else None
+    grp = dict(strideB=N * K, groups=G, group_offsets=offs, group_div=NB1 if table else 0)
+    cache = ops.amax_reuse()
+    cache.stable_range(flat.data_ptr(), flat.numel() * 4)
+    cache.planes = torch.zeros(flat.numel(), dtype=torch.float32, device=DEV)
+
+    def run(fused_call, swiglu_kernel_on):
+        gu = hm = None
+        slot = None
+        with _env(GAMER_GEMM_AS=1, GAMER_GEMM_AS_MIN_M=1, GAMER_GEMM_AS_SWIGLU=int(swiglu_kernel_on)), ops.f32_matmul("split3"), cache:
+            for _ in range(2):
+                cache.reset()
+                gu = torch.full((T, N), float("nan"), device=DEV)
+                hm = torch.full((T, I), float("nan"), device=DEV)
+                if fused_call:
+                    ops.gemm(x, K, 1, W, K, 1, gu, N, T, N, K, p_drop=p_drop, seed=77, swiglu_fwd=(hm, tbl, row_group), **grp)
+                else:
+                    ops.gemm(x, K, 1, W, K, 1, gu, N, T, N, K, **grp)
+                    if table:
+                        ops.swiglu_fwd_ld_tbl(gu, N, T, I, p_drop, 77, hm, tbl, row_group)
+                    else:
+                        ops.swiglu_fwd_ld(gu, N, T, I, p_drop, 77, hm)
+            key = cache._key(hm.data_ptr(), (1, 0, 1, T * I, T * I))
+            slot = cache.pending.get(key)
+            torch.cuda.synchronize()
+            smax = _slot_value(slot) if slot is not None else None
+        return gu, hm, smax
+    n0 = _as_launches()
+    gu_f, hm_f, smax_f = run(True, True)
+    assert _as_launches() > n0
+    gu_r, hm_r, _ = run(False, True)
+    if table:
+        # (rows in groups that share a weight matrix are a form of the 128 x 128 kernel when the projection runs alone: its gate|up agree to
+        # rounding; the epilogue's hm must be the bits of the stand-alone kernel on the gate|up values the SAME call stored)
+        assert float((gu_f - gu_r).abs().max()) < 2e-6 * float(gu_r.abs().max())
+        hm_own = torch.empty_like(hm_f)
+        ops.swiglu_fwd_ld_tbl(gu_f, N, T, I, p_drop, 77, hm_own, tbl, row_group)
+        assert torch.equal(hm_f, hm_own)
+    else:
+        assert torch.equal(gu_f, gu_r) and torch.equal(hm_f, hm_r)
+    assert smax_f is not None and smax_f == float(hm_f.abs().max())
+    gu_b, hm_b, smax_b = run(True, False)                           # the library's own two launches behind the same call
+    assert torch.equal(gu_b, gu_r) and torch.equal(hm_b, hm_r) and smax_b == float(hm_b.abs().max())
+    # and against fp64
+    wsel = torch.cat([torch.full((o[i + 1] - o[i],), (i // NB1) if table else i, dtype=torch.long) for i in range(G)])
+    ref = torch.einsum("tk,tnk->tn", x.double().cpu(), W.double().cpu().view(E, N, K)[wsel])
+    assert float((gu_f.double().cpu() - ref).abs().max()) < 2e-6 * float(ref.abs().max())
+    if p_drop == 0.0:
+        full = ref + (tbl.double().cpu()[row_group.cpu().long()] if table else 0.0)
+        want = torch.nn.functional.silu(full[:, :I]) * full[:, I:]
+        assert float((hm_f.double().cpu() - want).abs().max()) < 5e-6 * float(want.abs().max())
