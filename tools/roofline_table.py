@@ -69,7 +69,8 @@ def main():
         sfx = f", {terms}," if terms else ", 0,"
         sym_flops = {
             "gemm_as_kernel<4, false, 0, 8>": avg((12, mm(768, 256)), (1, mm(1041, 256))),            # q|k|v, head
-            "gemm_as_kernel<4, false, 0, 4>": avg((4, mm(256, 256)), (8, mm(1024, 256))),             # cross gate, experts' gate|up (K = 256)
+            "gemm_as_kernel<4, false, 0, 4>": mm(256, 256),                                          # cross gate (r06b and earlier: also the experts' gate|up)
+            "gemm_as_kernel<4, false, 5, 4>": mm(1024, 256),                                         # experts' gate|up with the SwiGLU forward in its epilogue
             "gemm_as_kernel<4, true, 0, 4>": mm(256, 256),                                           # cross gate input gradient
             "gemm_os_kernel": avg((12, mm(768, 256)), (1, mm(1041, 256)), (8, mm(1024, 256))),       # input gradients with 256 input features
             "gemm_wg_kernel<true>": avg((12, mm(768, 256)), (4, mm(256, 256)), (8, mm(256, 512)), (8, mm(1024, 256))),
