@@ -5,7 +5,7 @@
 // (ref:SeqRec/generation/trie.py:5-104, ref:SeqRec/tasks/test_SMB_decoder.py:120,470-500): the reference walks a
 // Python dict per (batch, beam) row on the host; here the item trie is a CSR array on the device and one
 // wave scores one row.  Integer work + one HBM pass over the row's logits.
-#include "common.h"
+#include "attention_split_common.h"
 
 namespace gamer {
 
@@ -255,6 +255,246 @@ attn_decode_kernel(const float* __restrict__ q, int ldq, const float* __restrict
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// The same kernel with its two products in the three-piece fp16 form of the train step (csrc/attention_split.hip, H2): the prompt K / V
+// tiles are cut into fp16 piece images (per-TENSOR scales from the maxima of the prompt caches, measured once per session), the query
+// fragments once per workgroup with the workgroup's own scale, P at the fixed 2^13.  12 + 12 MFMAs of 32 cycles per (32 keys x 32 query
+// columns) instead of 32 + 32 fp32 MFMAs of 64: the fp32 kernel ran 144 us per call at 256 users x 20 beams, bound by the fp32 matrix
+// pipe (6.3 GFLOP per call on a 157 TFLOP/s pipe shared with the loads it waits for).  Tail (merge of the four key ranges, the <= 4
+// generated positions in fp32 on the vector unit) as in attn_decode_kernel.
+constexpr int DEC2_WAVE_BYTES = 4 * SIMG * (int)sizeof(bf16_t) + 32 * (int)sizeof(int32_t);          // K h0 | K h1 | V h0 | V h1 | key_ok
+constexpr int DEC2_LDS_BYTES = (DEC_MERGE_LDS * (int)sizeof(float) > 4 * DEC2_WAVE_BYTES) ? DEC_MERGE_LDS * (int)sizeof(float) : 4 * DEC2_WAVE_BYTES;
+
+#ifndef DEC2_WGS
+#define DEC2_WGS 2          // workgroups per CU the kernel is built for
+#endif
+#ifndef DEC2_PREFETCH
+#define DEC2_PREFETCH 0     // 1: the next tile's K / V rows are requested before the current tile is multiplied (64 more live registers)
+#endif
+template <int G>
+__global__ void __launch_bounds__(256, DEC2_WGS)
+attn_decode_h2_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ kp, int ldkp,
+                      const float* __restrict__ vp, int ldvp, const int32_t* __restrict__ key_ok,
+                      const float* __restrict__ kg, const float* __restrict__ vg, int ldg, int tmax, int t, int gen_ok,
+                      const int32_t* __restrict__ uniform, int nb, int L0, int nq, int nkv, float scale,
+                      float* __restrict__ o, const uint32_t* __restrict__ amax_k, const uint32_t* __restrict__ amax_v) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dec2_raw[];
+    float* dec_lds = reinterpret_cast<float*>(dec2_raw);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x / nkv, kvh = blockIdx.x % nkv;
+    const int Qn = nb * G;
+    const bool uni = uniform != nullptr && uniform[b] != 0;
+    const float c2 = scale * 1.4426950408889634f;               // scores live in the log2 domain
+    float* mrg_m = dec_lds;                                     // [4][64] running max of every wave
+    float* mrg_l = dec_lds + 256;                               // [4][64] running sum
+    float* mrg_o = dec_lds + 512;                               // [4][64][DEC_OLD] partial O
+
+    if (uni) {
+        float vsum = 0.f;
+        for (int j = w; j < L0; j += 4) vsum += vp[((int64_t)b * L0 + j) * ldvp + kvh * 64 + lane];
+        mrg_o[w * 64 + lane] = vsum;
+        __syncthreads();
+    } else {
+        bf16_t* Kw = reinterpret_cast<bf16_t*>(dec2_raw + (size_t)w * DEC2_WAVE_BYTES);      // pieces h0 | h1, SIMG apart
+        bf16_t* Vw = Kw + 2 * SIMG;
+        int32_t* okw = reinterpret_cast<int32_t*>(Vw + 2 * SIMG);
+        const SlOffsets lo(lane);
+        float sk, isk, sv, isv;
+        scale_from_amax(amax_read(amax_k), sk, isk);
+        scale_from_amax(amax_read(amax_v), sv, isv);
+        // query fragments of the two 32-column tiles (columns past Qn are zero and never stored): B operands, lane = query column,
+        // 8 d-values per k-step; one scale for the workgroup's queries (every wave derives the same one from the same rows)
+        float4 qraw[2][8];
+        float qmax = 0.f;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int qi = qt * 32 + r;
+            const bool live = qi < Qn;
+            const int qc = live ? qi : 0;
+            const float* qrow = q + (int64_t)(b * nb + qc / G) * ldq + (kvh * G + qc % G) * 64 + 8 * h;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float4 a4 = *reinterpret_cast<const float4*>(qrow + 16 * s), b4 = *reinterpret_cast<const float4*>(qrow + 16 * s + 4);
+                if (!live) { a4 = make_float4(0.f, 0.f, 0.f, 0.f); b4 = a4; }
+                a4.x *= c2; a4.y *= c2; a4.z *= c2; a4.w *= c2; b4.x *= c2; b4.y *= c2; b4.z *= c2; b4.w *= c2;
+                qraw[qt][2 * s] = a4; qraw[qt][2 * s + 1] = b4;
+                qmax = fmaxf(fmaxf(fmaxf(qmax, fabsf(a4.x)), fabsf(a4.y)), fmaxf(fabsf(a4.z), fabsf(a4.w)));
+                qmax = fmaxf(fmaxf(fmaxf(qmax, fabsf(b4.x)), fabsf(b4.y)), fmaxf(fabsf(b4.z), fabsf(b4.w)));
+            }
+        }
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) qmax = fmaxf(qmax, __shfl_xor(qmax, o2, 64));
+        float sq = 1.f, isq = 1.f;
+        if (qmax > 0.f) scale_from_amax(__float_as_uint(qmax), sq, isq);
+        bf16x8 qf[2][2][4];                                     // query tile x piece x k-step
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 pq[3];
+                cut8_t<true>(qraw[qt][2 * s], qraw[qt][2 * s + 1], sq, pq);
+                qf[qt][0][s] = pq[0]; qf[qt][1][s] = pq[1];
+            }
+        const float inv_qk = isq * isk;
+        float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+        f32x16 oacc[2][2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oacc[0][0][i] = 0.f; oacc[0][1][i] = 0.f; oacc[1][0][i] = 0.f; oacc[1][1][i] = 0.f; }
+        const int n_tiles = (L0 + 31) >> 5;
+        float4 kr[8], vr[8];
+        int okv_g = 0;
+        auto request = [&](int jt_) {
+            const int jb = jt_ * 32;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int f = lane + 64 * i, row = f >> 4, c4 = (f & 15) << 2;
+                const int j = min(jb + row, L0 - 1);
+                kr[i] = *reinterpret_cast<const float4*>(kp + ((int64_t)b * L0 + j) * ldkp + kvh * 64 + c4);
+                vr[i] = *reinterpret_cast<const float4*>(vp + ((int64_t)b * L0 + j) * ldvp + kvh * 64 + c4);
+            }
+            okv_g = key_ok[(int64_t)b * L0 + min(jb + (lane & 31), L0 - 1)];
+        };
+        if (DEC2_PREFETCH && w < n_tiles) request(w);
+        for (int jt = w; jt < n_tiles; jt += 4) {
+            const int j0 = jt * 32;
+            // this wave's K / V tile: 512 float4 each, 8 per lane, cut into the two piece images; rows past the prompt are zero.  Every
+            // load is unconditional (clamped row) and requested before the first cut.
+            if (!DEC2_PREFETCH) request(jt);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int f = lane + 64 * i, row = f >> 4, c4 = (f & 15) << 2;
+                const bool in = j0 + row < L0;
+                uint32_t a0, a1, b0, b1;
+                cut2h_quad(in ? kr[i].x : 0.f, in ? kr[i].y : 0.f, in ? kr[i].z : 0.f, in ? kr[i].w : 0.f, sk, a0, a1, b0, b1);
+                bf16_t* dk_ = Kw + sl_off(row, c4);
+                *reinterpret_cast<uint2*>(dk_) = make_uint2(a0, b0);
+                *reinterpret_cast<uint2*>(dk_ + SIMG) = make_uint2(a1, b1);
+                cut2h_quad(in ? vr[i].x : 0.f, in ? vr[i].y : 0.f, in ? vr[i].z : 0.f, in ? vr[i].w : 0.f, sv, a0, a1, b0, b1);
+                bf16_t* dv_ = Vw + sl_off(row, c4);
+                *reinterpret_cast<uint2*>(dv_) = make_uint2(a0, b0);
+                *reinterpret_cast<uint2*>(dv_ + SIMG) = make_uint2(a1, b1);
+            }
+            if (lane < 32) okw[lane] = (j0 + lane < L0) ? okv_g : 0;
+            if (DEC2_PREFETCH) request(min(jt + 4, n_tiles - 1));           // (past the last tile: its rows once more, never used)
+            __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes landed
+            __builtin_amdgcn_wave_barrier();
+            int okv[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int4 t4 = *reinterpret_cast<const int4*>(okw + 8 * g4 + 4 * h);
+                okv[4 * g4] = t4.x; okv[4 * g4 + 1] = t4.y; okv[4 * g4 + 2] = t4.z; okv[4 * g4 + 3] = t4.w;
+            }
+            // the tile's K row fragments (A operands: lane = key) serve both query tiles
+            bf16x8 kf[2][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { kf[0][s] = read_row8(Kw, lo, 0, s); kf[1][s] = read_row8(Kw + SIMG, lo, 0, s); }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x16 st;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) st[i] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {                 // smallest piece products first
+                    st = mfma_piece<true>(kf[1][s], qf[qt][0][s], st);
+                    st = mfma_piece<true>(kf[0][s], qf[qt][1][s], st);
+                    st = mfma_piece<true>(kf[0][s], qf[qt][0][s], st);
+                }
+                // register reg of lane (r, h) = score of key (reg&3) + 8*(reg>>2) + 4*h for query column r
+                float mloc = -INFINITY;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    st[reg] = okv[reg] != 0 ? st[reg] * inv_qk : -INFINITY;
+                    mloc = fmaxf(mloc, st[reg]);
+                }
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                const float mn = fmaxf(m_run[qt], mloc);
+                const float base = mn == -INFINITY ? 0.f : mn;               // nothing allowed so far: p = 0
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - base);     // m = -inf -> 0
+                float rowsum = 0.f;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    st[reg] = __builtin_amdgcn_exp2f(st[reg] - base);
+                    rowsum += st[reg];
+                }
+                rowsum += __shfl_xor(rowsum, 32, 64);
+                l_run[qt] = l_run[qt] * alpha + rowsum;
+                m_run[qt] = mn;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { oacc[qt][0][i] *= alpha; oacc[qt][1][i] *= alpha; }
+                // O^T[d][query] += sum_key V[key][d] * P[query][key]
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 pf[3];
+                    cut8_regs_t<true>(st, 8 * s2, H2Scales::P, pf);
+                    pf[2] = pf[1];
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        bf16x8 vf[3];
+                        vf[0] = read_tr8(Vw, lo, 16 * s2, db);
+                        vf[1] = read_tr8(Vw + SIMG, lo, 16 * s2, db);
+                        vf[2] = vf[1];
+                        oacc[qt][db] = mfma_pieces<true>(vf, pf, oacc[qt][db]);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                  // the tile is consumed before the next one overwrites it
+        }
+        __syncthreads();                                      // every wave is done with its tile region
+        // publish this wave's state: O[query qt*32 + r][d = 32*dh + (reg&3) + 8*(reg>>2) + 4*h] (the products' scales taken out)
+        const float osc = isv * H2Scales::INV_P;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            if (h == 0) { mrg_m[w * 64 + qt * 32 + r] = m_run[qt]; mrg_l[w * 64 + qt * 32 + r] = l_run[qt]; }
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    mrg_o[(w * 64 + qt * 32 + r) * DEC_OLD + 32 * dh + (reg & 3) + 8 * (reg >> 2) + 4 * h] = oacc[qt][dh][reg] * osc;
+        }
+        __syncthreads();
+    }
+    // tail: as attn_decode_kernel
+#pragma unroll 1
+    for (int i = 0; i < DEC_MAXQ; ++i) {
+        const int qi = w + 4 * i;
+        if (qi >= Qn) break;
+        const int n = b * nb + qi / G, head = kvh * G + qi % G;
+        float res;
+        if (uni) {
+            float a = mrg_o[lane] + mrg_o[64 + lane] + mrg_o[128 + lane] + mrg_o[192 + lane];
+            for (int g = 0; g < t; ++g) a += vg[((int64_t)n * tmax + g) * ldg + kvh * 64 + lane];
+            res = a / (float)(L0 + t);
+        } else {
+            float mi = fmaxf(fmaxf(mrg_m[qi], mrg_m[64 + qi]), fmaxf(mrg_m[128 + qi], mrg_m[192 + qi]));
+            float li = 0.f, a = 0.f;
+            if (mi > -INFINITY) {
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) {
+                    const float sc = __builtin_amdgcn_exp2f(mrg_m[ww * 64 + qi] - mi);        // -inf -> 0
+                    li += mrg_l[ww * 64 + qi] * sc;
+                    a += mrg_o[(ww * 64 + qi) * DEC_OLD + lane] * sc;
+                }
+            }
+            if (gen_ok) {
+                const float qd = q[(int64_t)n * ldq + head * 64 + lane] * c2;
+                for (int g = 0; g < t; ++g) {
+                    const float* krow = kg + ((int64_t)n * tmax + g) * ldg + kvh * 64;
+                    const float s = wave_sum(qd * krow[lane]);
+                    const float mn = fmaxf(mi, s);
+                    const float alpha = __builtin_amdgcn_exp2f(mi - mn), pe = __builtin_amdgcn_exp2f(s - mn);
+                    li = li * alpha + pe;
+                    a = a * alpha + pe * vg[((int64_t)n * tmax + g) * ldg + kvh * 64 + lane];
+                    mi = mn;
+                }
+            }
+            res = li > 0.f ? a / li : 0.f;
+        }
+        o[(int64_t)n * nq * 64 + head * 64 + lane] = res;
+    }
+}
+
 }  // namespace gamer
 
 using namespace gamer;
@@ -283,10 +523,10 @@ extern "C" int gamer_trie_advance(const int32_t* node, const int64_t* token, con
     return 0;
 }
 
-extern "C" int gamer_attn_decode(const float* q, int ldq, const float* kp, int ldkp, const float* vp, int ldvp,
-                                 const int32_t* key_ok, const float* kg, const float* vg, int ldg, int tmax, int t,
-                                 int gen_ok, const int32_t* uniform, int B, int nb, int L0, int nq, int nkv,
-                                 float scale, float* o, void* stream) {
+static int attn_decode_impl(const float* q, int ldq, const float* kp, int ldkp, const float* vp, int ldvp,
+                            const int32_t* key_ok, const float* kg, const float* vg, int ldg, int tmax, int t,
+                            int gen_ok, const int32_t* uniform, int B, int nb, int L0, int nq, int nkv,
+                            float scale, float* o, const uint32_t* amax_k, const uint32_t* amax_v, void* stream) {
     GAMER_CHECK_ARG(q && kp && vp && key_ok && kg && vg && o, "gamer_attn_decode: null pointer");
     GAMER_CHECK_ARG(B > 0 && nb > 0 && L0 > 0 && nq > 0 && nkv > 0 && nq % nkv == 0 && t >= 1 && t <= tmax,
                     "gamer_attn_decode: bad shape B=%d nb=%d L0=%d nq=%d nkv=%d t=%d tmax=%d", B, nb, L0, nq, nkv, t, tmax);
@@ -296,6 +536,31 @@ extern "C" int gamer_attn_decode(const float* q, int ldq, const float* kp, int l
     GAMER_CHECK_ARG(ldq % 4 == 0 && ldkp % 4 == 0 && ldvp % 4 == 0 && aligned16(q) && aligned16(kp) && aligned16(vp),
                     "gamer_attn_decode: q / prompt K / V need 16-byte alignment and leading dims %% 4 == 0");
     dim3 grid(B * nkv);
+    if (amax_k && amax_v) {
+        // the three-piece fp16 form (prompt K / V maxima given)
+        static bool attr2_dev[MAX_DEVICES] = {};
+        bool& attr2 = attr2_dev[current_device()];
+        if (!attr2) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_h2_kernel<1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, DEC2_LDS_BYTES);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_h2_kernel<2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, DEC2_LDS_BYTES);
+            if (e != hipSuccess) {
+                set_error("gamer_attn_decode_split: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                return (int)e;
+            }
+            attr2 = true;
+        }
+        if (G == 1)
+            hipLaunchKernelGGL(attn_decode_h2_kernel<1>, grid, dim3(256), DEC2_LDS_BYTES, (hipStream_t)stream, q, ldq, kp, ldkp, vp, ldvp,
+                               key_ok, kg, vg, ldg, tmax, t, gen_ok, uniform, nb, L0, nq, nkv, scale, o, amax_k, amax_v);
+        else
+            hipLaunchKernelGGL(attn_decode_h2_kernel<2>, grid, dim3(256), DEC2_LDS_BYTES, (hipStream_t)stream, q, ldq, kp, ldkp, vp, ldvp,
+                               key_ok, kg, vg, ldg, tmax, t, gen_ok, uniform, nb, L0, nq, nkv, scale, o, amax_k, amax_v);
+        GAMER_CHECK_LAUNCH("gamer_attn_decode_split");
+        return 0;
+    }
     const size_t shmem = (size_t)DEC_LDS_FLOATS * sizeof(float);
     static bool attr_dev[MAX_DEVICES] = {};
     bool& attr = attr_dev[current_device()];
@@ -319,4 +584,20 @@ extern "C" int gamer_attn_decode(const float* q, int ldq, const float* kp, int l
                            key_ok, kg, vg, ldg, tmax, t, gen_ok, uniform, nb, L0, nq, nkv, scale, o);
     GAMER_CHECK_LAUNCH("gamer_attn_decode");
     return 0;
+}
+
+extern "C" int gamer_attn_decode(const float* q, int ldq, const float* kp, int ldkp, const float* vp, int ldvp,
+                                 const int32_t* key_ok, const float* kg, const float* vg, int ldg, int tmax, int t,
+                                 int gen_ok, const int32_t* uniform, int B, int nb, int L0, int nq, int nkv,
+                                 float scale, float* o, void* stream) {
+    return attn_decode_impl(q, ldq, kp, ldkp, vp, ldvp, key_ok, kg, vg, ldg, tmax, t, gen_ok, uniform, B, nb, L0, nq, nkv, scale, o,
+                            nullptr, nullptr, stream);
+}
+extern "C" int gamer_attn_decode_split(const float* q, int ldq, const float* kp, int ldkp, const float* vp, int ldvp,
+                                       const int32_t* key_ok, const float* kg, const float* vg, int ldg, int tmax, int t,
+                                       int gen_ok, const int32_t* uniform, int B, int nb, int L0, int nq, int nkv,
+                                       float scale, float* o, const uint32_t* amax_k, const uint32_t* amax_v, void* stream) {
+    GAMER_CHECK_ARG(amax_k && amax_v, "gamer_attn_decode_split: the maxima of the prompt K and V caches (gamer_absmax_f32 slots) are required");
+    return attn_decode_impl(q, ldq, kp, ldkp, vp, ldvp, key_ok, kg, vg, ldg, tmax, t, gen_ok, uniform, B, nb, L0, nq, nkv, scale, o,
+                            amax_k, amax_v, stream);
 }

@@ -275,6 +275,16 @@ class DecodeSession:
         self.gen, self.buf = st.gen, st.buf
         self._pending_reorder = False
         self.t = 0
+        # matmul = "split3": the decode attention in the three-piece fp16 form too - the maxima of the prompt K / V caches, which do not
+        # change during the generation, measured once (GAMER_DECODE_ATTN_SPLIT=0: the fp32-MFMA kernel)
+        import os
+        self.kv_amax = {}
+        if engine._amax is not None and engine.matmul == "split3" and os.environ.get("GAMER_DECODE_ATTN_SPLIT", "1") != "0":
+            with ops.f32_matmul("split3"), engine._amax:
+                for kk in self.kp:
+                    kpt, vpt = self.kp[kk], self.vp[kk]
+                    self.kv_amax[kk] = (ops.absmax_slot(kpt, 1, 0, kpt.shape[0], kpt.shape[1], kpt.stride(0)),
+                                        ops.absmax_slot(vpt, 1, 0, vpt.shape[0], vpt.shape[1], vpt.stride(0)))
         # the maxima cache as this session found it after the prompt pass: what a captured step was recorded against
         am_ = engine._amax
         self._sig = None if am_ is None else (len(am_._wkeys), am_.used, 0 if am_.planes is None else am_.planes.data_ptr())
@@ -366,7 +376,8 @@ class DecodeSession:
             vg[:, t - 1] = b["qkv"][:, NQ + NKV:]
             ops.attn_decode(b["q"], self.kp[(layer, kind)], self.vp[(layer, kind)],
                             self.ok_self if kind == "self" else self.ok_cross, kg, vg, t, kind == "self",
-                            None if kind == "self" else self.uniform_cross, B, nb, L0, nq, nkv, scale, b["ao"])
+                            None if kind == "self" else self.uniform_cross, B, nb, L0, nq, nkv, scale, b["ao"],
+                            amax=self.kv_amax.get((layer, kind)))
             if kind == "self":
                 ops.gemm(b["ao"], NQ, 1, Wa["o"], NQ, 1, xout, H, N, H, NQ, resid=xin)
             else:

@@ -1127,9 +1127,15 @@ def trie_advance(node, token, child_start, child_tok, child_node, out):
          node.numel(), ptr(out), stream_ptr())
 
 
-def attn_decode(q, kp, vp, key_ok, kg, vg, t, gen_ok, uniform, B, nb, L0, nq, nkv, scale, o):
-    """One new token per beam against the prompt cache (per sample) + generated cache (per beam)."""
+def attn_decode(q, kp, vp, key_ok, kg, vg, t, gen_ok, uniform, B, nb, L0, nq, nkv, scale, o, amax=None):
+    """One new token per beam against the prompt cache (per sample) + generated cache (per beam).
+    amax = (slot of max |kp|, slot of max |vp|): the three-piece fp16 form (gamer_attn_decode_split)."""
     tmax = kg.shape[1]
+    if amax is not None:
+        call("gamer_attn_decode_split", ptr(q), q.stride(0), ptr(kp), kp.stride(0), ptr(vp), vp.stride(0), ptr(key_ok), ptr(kg),
+             ptr(vg), kg.stride(1), tmax, t, 1 if gen_ok else 0, ptr(uniform), B, nb, L0, nq, nkv, scale, ptr(o), amax[0], amax[1],
+             stream_ptr())
+        return
     call("gamer_attn_decode", ptr(q), q.stride(0), ptr(kp), kp.stride(0), ptr(vp), vp.stride(0), ptr(key_ok), ptr(kg),
          ptr(vg), kg.stride(1), tmax, t, 1 if gen_ok else 0, ptr(uniform), B, nb, L0, nq, nkv, scale, ptr(o),
          stream_ptr())

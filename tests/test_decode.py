@@ -276,10 +276,12 @@ def test_evaluate_behavior_matches_reference_metrics():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("nq,nkv,nb,L0,t", [(2, 1, 6, 31, 1), (6, 3, 20, 130, 3), (2, 2, 5, 64, 4)])
-def test_attn_decode_kernel_against_dense(nq, nkv, nb, L0, t):
-    """gamer_attn_decode vs fp64 softmax attention: self (generated keys attended) and cross (generated keys
-    masked, samples without an allowed key uniform over all L0 + t keys)."""
+def test_attn_decode_kernel_against_dense(nq, nkv, nb, L0, t, split):
+    """gamer_attn_decode (fp32 MFMA) and gamer_attn_decode_split (three fp16 piece products, the default engine's) vs fp64 softmax
+    attention: self (generated keys attended) and cross (generated keys masked, samples without an allowed key uniform over all
+    L0 + t keys); the prompt values span four orders of magnitude between rows in the split case (one scale per tensor)."""
     from gamer_amd import ops
     dev, B, tmax = "cuda", 3, 4
     N, G = B * nb, nq // nkv
@@ -293,13 +295,19 @@ def test_attn_decode_kernel_against_dense(nq, nkv, nb, L0, t):
     ok_self = ok.clone()
     ok_self[1, -3:] = 1                                      # self attention always has kept keys
     uniform = (ok.sum(1) == 0).to(torch.int32)
+    if split:
+        vp = vp * torch.exp(2.3 * torch.randn(B * L0, 1, generator=g))
     vbuf = torch.zeros(B * L0, (nq + 2 * nkv) * 64)          # v lives inside a wider buffer in the engine
     vbuf[:, (nq + nkv) * 64:] = vp
+    kp_d, v_d = kp.to(dev), vbuf.to(dev)[:, (nq + nkv) * 64:]
+    amax = None
+    if split:
+        amax = (ops.absmax_slot(kp_d, 1, 0, B * L0, nkv * 64, nkv * 64), ops.absmax_slot(v_d, 1, 0, B * L0, nkv * 64, v_d.stride(0)))
     for kind in ("self", "cross"):
         o = torch.empty(N, nq * 64, device=dev)
         kok = ok_self if kind == "self" else ok
-        ops.attn_decode(q.to(dev), kp.to(dev), vbuf.to(dev)[:, (nq + nkv) * 64:], kok.to(dev), kg.to(dev), vg.to(dev), t,
-                        kind == "self", None if kind == "self" else uniform.to(dev), B, nb, L0, nq, nkv, 0.125, o)
+        ops.attn_decode(q.to(dev), kp_d, v_d, kok.to(dev), kg.to(dev), vg.to(dev), t,
+                        kind == "self", None if kind == "self" else uniform.to(dev), B, nb, L0, nq, nkv, 0.125, o, amax=amax)
         ref = torch.empty(N, nq, 64, dtype=torch.float64)
         for n in range(N):
             b = n // nb
