@@ -83,11 +83,11 @@ attn_fwd_tile(const float* __restrict__ q, int ldq, const float* __restrict__ k,
     const bool my_empty = valid_q && row_empty[tok] != 0;
     const bool normal = valid_q && !my_empty;
     const QuerySpan sp = QuerySpan::load<SPAN>(ro.span, tok, iq_raw, valid_q, S);
-    const int wave_ql_min = wave_min_i32(normal ? my_ql : INT_BIG_A);
-    const int wave_q_lo = wave_min_i32(normal ? sp.hi : INT_BIG_A);   // every key up to here passes every row's limit
+    const int wave_ql_min = wave_min_i32_dpp(normal ? my_ql : INT_BIG_A);
+    const int wave_q_lo = wave_min_i32_dpp(normal ? sp.hi : INT_BIG_A);   // every key up to here passes every row's limit
     const bool wave_all_empty = wave_q_lo == INT_BIG_A;          // no normal row: no scores needed at all
-    const int wave_hole_lo = SPAN ? wave_min_i32(normal ? sp.hole_lo : INT_BIG_A) : INT_BIG_A;
-    const int wave_hole_hi = SPAN ? wave_max_i32(normal ? sp.hole_hi : 0) : 0;
+    const int wave_hole_lo = SPAN ? wave_min_i32_dpp(normal ? sp.hole_lo : INT_BIG_A) : INT_BIG_A;
+    const int wave_hole_hi = SPAN ? wave_max_i32_dpp(normal ? sp.hole_hi : 0) : 0;
     const int n_all = (S + 31) / 32;
     int wave_q_hi, n_causal;
     bool wave_has_empty;
@@ -379,7 +379,7 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
             const float4 o4 = *reinterpret_cast<const float4*>(orow + 8 * kk + 4 * h);
             my_delta += u4.x * o4.x + u4.y * o4.y + u4.z * o4.z + u4.w * o4.w;
         }
-        my_delta += __shfl_xor(my_delta, 32, 64);
+        my_delta = xor32_sum(my_delta);
         if (valid_q && h == 0) delta[((int64_t)b * nq + head) * S + iqc] = my_delta;
     }
     const int my_ql = ql ? ql[tok] : 1;
@@ -387,11 +387,11 @@ attn_bwd_dq_tile(const float* __restrict__ q, int ldq, const float* __restrict__
     const bool normal = valid_q && !my_empty;
     const QuerySpan sp = QuerySpan::load<SPAN>(ro.span, tok, iq_raw, valid_q, S);
     const float neg_lse2 = -lse[((int64_t)b * nq + head) * S + iqc] * 1.4426950408889634f;
-    const int wave_ql_min = wave_min_i32(normal ? my_ql : INT_BIG_A);
-    const int wave_q_lo = wave_min_i32(normal ? sp.hi : INT_BIG_A);
+    const int wave_ql_min = wave_min_i32_dpp(normal ? my_ql : INT_BIG_A);
+    const int wave_q_lo = wave_min_i32_dpp(normal ? sp.hi : INT_BIG_A);
     const bool wave_all_empty = wave_q_lo == INT_BIG_A;
-    const int wave_hole_lo = SPAN ? wave_min_i32(normal ? sp.hole_lo : INT_BIG_A) : INT_BIG_A;
-    const int wave_hole_hi = SPAN ? wave_max_i32(normal ? sp.hole_hi : 0) : 0;
+    const int wave_hole_lo = SPAN ? wave_min_i32_dpp(normal ? sp.hole_lo : INT_BIG_A) : INT_BIG_A;
+    const int wave_hole_hi = SPAN ? wave_max_i32_dpp(normal ? sp.hole_hi : 0) : 0;
     const int n_all = (S + 31) / 32;
     int wave_q_hi, n_causal;
     bool wave_has_empty;
@@ -650,7 +650,7 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
     const float* Kw = &sm.Kt[(sub * 32 + r) * KLD + 4 * h];
     const float* Vw = &sm.Vt[(sub * 32 + r) * KLD + 4 * h];
     const int my_kl = valid_k ? kl[ktok] : INT_BIG_A;
-    const int wave_kl_max = wave_max_i32(my_kl);
+    const int wave_kl_max = wave_max_i32_dpp(my_kl);
     const int wave_k_lo = k0 + sub * 32, wave_k_hi = wave_k_lo + 31;
     const float invS = 1.f / (float)S;
     const float c2 = scale * 1.4426950408889634f;
@@ -713,14 +713,7 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
                 rem = in ? row_empty[(int64_t)b * S + i] : 0;
                 const QuerySpan qs = QuerySpan::load<SPAN>(ro.span, (int64_t)b * S + i, i, in, S);
                 rpos = qs.hi;
-                const bool normal = in && rem == 0;
-                rqlmin = wave_min_i32(normal ? rql : INT_BIG_A);
-                rposmin = wave_min_i32(normal ? rpos : INT_BIG_A);
-                if (SPAN) {
-                    rhlo = qs.hole_lo; rhhi = qs.hole_hi;
-                    rhlomin = wave_min_i32(normal ? rhlo : INT_BIG_A);
-                    rhhimax = wave_max_i32(normal ? rhhi : 0);
-                }
+                if (SPAN) { rhlo = qs.hole_lo; rhhi = qs.hole_hi; }
             }
         }
     };
@@ -729,6 +722,15 @@ attn_bwd_dkv_tile(const float* __restrict__ q, int ldq, const float* __restrict_
         for (int g = 0; g < G; ++g) {
             store_tile32<KLD>(sm.Qs[g], tid, rq[g], S - qt * 32);
             store_tile32<KLD>(sm.dOs[g], tid, rdo[g], S - qt * 32);
+        }
+        if (w == 0) {                    // (the tile's statistics: DPP reductions over the values wave 0 loaded for head 0)
+            const bool normal = qt * 32 + (lane & 31) < S && rem == 0;
+            rqlmin = wave_min_i32_dpp(normal ? rql : INT_BIG_A);
+            rposmin = wave_min_i32_dpp(normal ? rpos : INT_BIG_A);
+            if (SPAN) {
+                rhlomin = wave_min_i32_dpp(normal ? rhlo : INT_BIG_A);
+                rhhimax = wave_max_i32_dpp(normal ? rhhi : 0);
+            }
         }
         if (w < G && lane < 32) {
             const int g = w, row = lane;

@@ -270,11 +270,11 @@ attn_fwd_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict_
     const int my_ql = ql ? ql[tok] : 1;
     QuerySpanB sp = QuerySpanB::load<SPAN>(span, tok, iqc, valid_q);
     if (ORD && valid_q && ord.row_empty[tok] != 0) sp.hi = -1;
-    const int wave_q_hi = wave_max_i32(sp.hi);
-    const int wave_q_lo = wave_min_i32(valid_q ? sp.hi : INT_BIG_B);
-    const int wave_ql_min = wave_min_i32(valid_q ? my_ql : INT_BIG_B);
-    const int wave_hole_lo = SPAN ? wave_min_i32(valid_q ? sp.hole_lo : INT_BIG_B) : INT_BIG_B;
-    const int wave_hole_hi = SPAN ? wave_max_i32(valid_q ? sp.hole_hi : 0) : 0;
+    const int wave_q_hi = wave_max_i32_dpp(sp.hi);
+    const int wave_q_lo = wave_min_i32_dpp(valid_q ? sp.hi : INT_BIG_B);
+    const int wave_ql_min = wave_min_i32_dpp(valid_q ? my_ql : INT_BIG_B);
+    const int wave_hole_lo = SPAN ? wave_min_i32_dpp(valid_q ? sp.hole_lo : INT_BIG_B) : INT_BIG_B;
+    const int wave_hole_hi = SPAN ? wave_max_i32_dpp(valid_q ? sp.hole_hi : 0) : 0;
     int n_iter = (min(S, q0 + R) + 63) / 64;                    // allowed keys are <= the query position
     if (ORD) {                                                  // ... = the largest position of a normal row of the tile
         const int n32 = (S + 31) >> 5;
@@ -885,11 +885,11 @@ attn_bwd_dq_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restri
     if (ORD && valid_q && ord.row_empty[tok] != 0) sp.hi = -1;
     const float neg_lse2 = -lse[((int64_t)b * nq + head) * S + iqc] * 1.4426950408889634f;
     const float neg_delta = -delta[((int64_t)b * nq + head) * S + iqc];
-    const int wave_q_hi = wave_max_i32(sp.hi);
-    const int wave_q_lo = wave_min_i32(valid_q ? sp.hi : INT_BIG_B);
-    const int wave_ql_min = wave_min_i32(valid_q ? my_ql : INT_BIG_B);
-    const int wave_hole_lo = SPAN ? wave_min_i32(valid_q ? sp.hole_lo : INT_BIG_B) : INT_BIG_B;
-    const int wave_hole_hi = SPAN ? wave_max_i32(valid_q ? sp.hole_hi : 0) : 0;
+    const int wave_q_hi = wave_max_i32_dpp(sp.hi);
+    const int wave_q_lo = wave_min_i32_dpp(valid_q ? sp.hi : INT_BIG_B);
+    const int wave_ql_min = wave_min_i32_dpp(valid_q ? my_ql : INT_BIG_B);
+    const int wave_hole_lo = SPAN ? wave_min_i32_dpp(valid_q ? sp.hole_lo : INT_BIG_B) : INT_BIG_B;
+    const int wave_hole_hi = SPAN ? wave_max_i32_dpp(valid_q ? sp.hole_hi : 0) : 0;
     int n_iter = (min(S, q0 + R) + 63) / 64;
     if (ORD) {                                                  // ... = the largest position of a normal row of the tile
         const int n32 = (S + 31) >> 5;
@@ -1097,7 +1097,7 @@ attn_bwd_dkv_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restr
         *reinterpret_cast<uint4*>(sm.Vt + lds_off(row, (f & 7) << 3)) = c;
     }
     const int my_kl = valid_k ? kl[ktok] : INT_BIG_B;
-    const int wave_kl_max = wave_max_i32(my_kl);
+    const int wave_kl_max = wave_max_i32_dpp(my_kl);
     const int wave_k_lo = k0 + sub * 32, wave_k_hi = wave_k_lo + 31;
     const float c2 = scale * 1.4426950408889634f;
     const AttnDropout rng(p_drop, seed);
@@ -1154,14 +1154,7 @@ attn_bwd_dkv_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restr
                 const QuerySpanB qs = QuerySpanB::load<SPAN>(span, (int64_t)b * S + ic, ic, in);
                 rpos = qs.hi;
                 if (ORD && in && ord.row_empty[(int64_t)b * S + ic] != 0) rpos = -1;
-                rqlmin = wave_min_i32(in ? rql : INT_BIG_B);
-                rposmin = wave_min_i32(in ? rpos : INT_BIG_B);
-                rposmax = wave_max_i32(rpos);
-                if (SPAN) {
-                    rhlo = qs.hole_lo; rhhi = qs.hole_hi;
-                    rhlomin = wave_min_i32(in ? rhlo : INT_BIG_B);
-                    rhhimax = wave_max_i32(in ? rhhi : 0);
-                }
+                if (SPAN) { rhlo = qs.hole_lo; rhhi = qs.hole_hi; }
             }
         }
     };
@@ -1174,6 +1167,19 @@ attn_bwd_dkv_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restr
             if (row >= n_valid) { a = make_uint4(0u, 0u, 0u, 0u); c = a; }
             *reinterpret_cast<uint4*>(sm.Qs[buf][g] + lds_off(row, (tid & 7) << 3)) = a;
             *reinterpret_cast<uint4*>(sm.dOs[buf][g] + lds_off(row, (tid & 7) << 3)) = c;
+        }
+        if (w == 0) {
+            // the tile's statistics, here and not behind the loads: the values have arrived by now (the loads were issued a whole tile
+            // ago), and the reductions are DPP steps - as ds_bpermute chains behind the loads they were ~2000 cycles in wave 0 for
+            // which the other three waves waited at every tile's barrier
+            const bool in = qt * 32 + (lane & 31) < S;
+            rqlmin = wave_min_i32_dpp(in ? rql : INT_BIG_B);
+            rposmin = wave_min_i32_dpp(in ? rpos : INT_BIG_B);
+            rposmax = wave_max_i32_dpp(rpos);
+            if (SPAN) {
+                rhlomin = wave_min_i32_dpp(in ? rhlo : INT_BIG_B);
+                rhhimax = wave_max_i32_dpp(in ? rhhi : 0);
+            }
         }
         if (w < G && lane < 32) {
             const int g = w, row = lane;

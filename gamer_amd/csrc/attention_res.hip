@@ -618,7 +618,7 @@ res_dq_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const float* _
             rowmax = fmaxf(fmaxf(fmaxf(rowmax, fabsf(u4.x)), fabsf(u4.y)), fmaxf(fabsf(u4.z), fabsf(u4.w)));
             rowmax = fmaxf(fmaxf(fmaxf(rowmax, fabsf(w4.x)), fabsf(w4.y)), fmaxf(fabsf(w4.z), fabsf(w4.w)));
         }
-        rowmax = fmaxf(rowmax, __shfl_xor(rowmax, 32, 64));          // the row's other 32 columns
+        rowmax = xor32_max(rowmax);                                    // the row's other 32 columns
         if (rowmax > 0.f) {                                          // (an all-zero row keeps the tensor's scales: its pieces are 0)
             scale_from_amax(__float_as_uint(rowmax), my_sdo, my_inv_do);
             scale_from_amax(__float_as_uint(sc.ds_coef * rowmax), my_sds, my_inv_ds);
@@ -630,7 +630,7 @@ res_dq_rowtile(ResSmem& sm, const float* __restrict__ q, int ldq, const float* _
             dof[0][s] = dpc[0]; dof[1][s] = dpc[1];
         }
         if (need_delta) {
-            my_delta += __shfl_xor(my_delta, 32, 64);
+            my_delta = xor32_sum(my_delta);
             if (valid_q && h == 0) *delta_p = my_delta;
         }
     }

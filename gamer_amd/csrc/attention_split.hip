@@ -486,7 +486,7 @@ attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict
             }
         }
         if (H2) {
-            rowmax = fmaxf(rowmax, __shfl_xor(rowmax, 32, 64));          // the row's other 32 columns
+            rowmax = xor32_max(rowmax);                                    // the row's other 32 columns
             if (rowmax > 0.f) {                                          // (an all-zero row keeps the tensor's scales: its pieces are 0)
                 scale_from_amax(__float_as_uint(rowmax), my_sdo, my_inv_do);
                 scale_from_amax(__float_as_uint(sc.ds_coef * rowmax), my_sds, my_inv_ds);
@@ -501,7 +501,7 @@ attn_bwd_dq_s_tile(const float* __restrict__ q, int ldq, const float* __restrict
             for (int pc = 0; pc < NP; ++pc) *reinterpret_cast<bf16x8*>(dimg + pc * SIMG + lo.row[s]) = dpc[pc];
         }
         if (!delta_ready) {
-            my_delta += __shfl_xor(my_delta, 32, 64);
+            my_delta = xor32_sum(my_delta);
             if (valid_q && h == 0) delta[((int64_t)b * nq + head) * S + iqc] = my_delta;
         } else {
             my_delta = delta[((int64_t)b * nq + head) * S + iqc];

@@ -314,6 +314,19 @@ __device__ __forceinline__ int wave_max_i32_dpp(int v) {
                max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
+// sum over each row of 16 lanes (every lane ends with its row's sum) in four DPP adds; the partners are those of the xor 1, 2, 4, 8
+// butterfly (after the two quad steps a quad's lanes hold the same value, so "mirror" and "xor" pick equal operands): the bits are those of the
+// __shfl_xor chain it replaces, without its four dependent ds_bpermute round trips
+__device__ __forceinline__ float row16_sum_dpp(float v) {
+#define GAMER_DPP_F(ctrl) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xf, 0xf, false))
+    v += GAMER_DPP_F(0xB1);
+    v += GAMER_DPP_F(0x4E);
+    v += GAMER_DPP_F(0x141);
+    v += GAMER_DPP_F(0x140);
+#undef GAMER_DPP_F
+    return v;
+}
+
 // silu(x) = x sigmoid(x) with the hardware reciprocal (v_rcp_f32: 1 ulp) instead of an IEEE division (ten instructions): since round 6 the
 // SwiGLU forward also runs in a GEMM epilogue (gemm_as.hip, EPI 5), where vector instructions are matrix time; every kernel uses this one
 // definition, so a fused epilogue and the stand-alone kernel still produce the same bits

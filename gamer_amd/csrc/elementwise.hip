@@ -1597,8 +1597,10 @@ silu_gate_bwd_kernel(const TA* __restrict__ a, const TA* __restrict__ gate, cons
 // lm_head produces them; the statistics are fp32 either way, loss_utils.py upcasts)
 // ---------------------------------------------------------------------------------------------
 constexpr int CE_MAXC = 20;              // register-resident rows up to V = 1280 (the shipped vocabulary is 1041)
-constexpr int CE_MAXQ = 5;               // ... as 16-byte groups per lane (five cover 1280 fp32 / 2560 bf16 values)
 template <typename T> constexpr int CE_EPL = 16 / (int)sizeof(T);      // elements per 16 bytes
+// ... as 16-byte groups per lane: five cover 1280 fp32 values, three 1536 bf16 values (five for bf16 too meant 40 exponentials per
+// lane for the 17 values it owns at V = 1041)
+template <typename T> constexpr int CE_MAXQ = sizeof(T) == 2 ? 3 : 5;
 __device__ __forceinline__ void ce_load16(const float* p, float (&x)[4]) {
     const float4 v = *reinterpret_cast<const float4*>(p);
     x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
@@ -1629,15 +1631,15 @@ ce_fwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labe
         const bool valid = tgt != ignore_index && tgt >= 0 && tgt < V;
         float mx = -INFINITY;
         float zt = 0.f;
-        if (vec4 && V <= 64 * CE_EPL<TL> * CE_MAXQ) {
+        if (vec4 && V <= 64 * CE_EPL<TL> * CE_MAXQ<TL>) {
             // rows with 16-byte aligned starts: the row in registers as 16-byte groups per lane (four fp32 / eight bf16 values; one wave
             // instruction moves 1 KB instead of 256 / 128 bytes: fp32 3.6 -> 5 TB/s, bf16 2.2 -> ...); the group that straddles V is
             // stored element by element - the padding columns of the row stay as they are
             constexpr int EPL = CE_EPL<TL>;
-            float z[CE_MAXQ][EPL];
+            float z[CE_MAXQ<TL>][EPL];
             const int c_last = ((V - 1) / EPL) * EPL;      // every load is unconditional (a group past the row reads the row's last group and
 #pragma unroll                                            // is masked): loads under `if (c < V)` were each waited for right behind the load
-            for (int i = 0; i < CE_MAXQ; ++i) {
+            for (int i = 0; i < CE_MAXQ<TL>; ++i) {
                 const int c = EPL * (lane + 64 * i);
                 float x[EPL];
                 ce_load16(row + min(c, c_last), x);
@@ -1645,7 +1647,7 @@ ce_fwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labe
                 for (int e = 0; e < EPL; ++e) z[i][e] = c + e < V ? round_as<TL>(x[e] * inv_temp) : -INFINITY;
             }
 #pragma unroll
-            for (int i = 0; i < CE_MAXQ; ++i) {
+            for (int i = 0; i < CE_MAXQ<TL>; ++i) {
                 const int c = EPL * (lane + 64 * i);
                 if (inv_temp == 1.f) {
                     // the producer already divided by the temperature (the head GEMM's alpha): nothing to write back
@@ -1666,7 +1668,7 @@ ce_fwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labe
             zt = wave_sum(zt);
             float se = 0.f;
 #pragma unroll
-            for (int i = 0; i < CE_MAXQ; ++i)
+            for (int i = 0; i < CE_MAXQ<TL>; ++i)
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) se += expf(z[i][e] - mx);           // exp(-inf) = 0 past the row
             se = wave_sum(se);
@@ -1792,14 +1794,14 @@ ce_bwd_kernel(TL* __restrict__ logits, int ldl, const int64_t* __restrict__ labe
         const int64_t tgt = (s + 1 < S) ? labels[t + 1] : (int64_t)ignore_index;
         const bool valid = tgt != ignore_index && tgt >= 0 && tgt < V;
         const float l = lse[t];
-        if (vec4 && V <= 64 * CE_EPL<TL> * CE_MAXQ) {       // 16 bytes per lane, the row's loads all in flight (see ce_fwd_kernel)
+        if (vec4 && V <= 64 * CE_EPL<TL> * CE_MAXQ<TL>) {       // 16 bytes per lane, the row's loads all in flight (see ce_fwd_kernel)
             constexpr int EPL = CE_EPL<TL>;
             const int c_last = ((V - 1) / EPL) * EPL;
-            float xs[CE_MAXQ][EPL];
+            float xs[CE_MAXQ<TL>][EPL];
 #pragma unroll
-            for (int i = 0; i < CE_MAXQ; ++i) ce_load16(row + min(EPL * (lane + 64 * i), c_last), xs[i]);
+            for (int i = 0; i < CE_MAXQ<TL>; ++i) ce_load16(row + min(EPL * (lane + 64 * i), c_last), xs[i]);
 #pragma unroll
-            for (int i = 0; i < CE_MAXQ; ++i) {
+            for (int i = 0; i < CE_MAXQ<TL>; ++i) {
                 const int c = EPL * (lane + 64 * i);
                 if (c >= V) continue;
                 float g[EPL];

@@ -1081,7 +1081,7 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
                     }
                     *reinterpret_cast<float4*>(dst0 + it * step) = x;         // raw (biased) q / k: what the backward reads
                     float ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
-                    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64);
+                    ss = row16_sum_dpp(ss);
                     const float rstd = rsqrtf(ss * (1.f / 64.f) + p.qk_eps);
                     const float4 w4 = reinterpret_cast<const float4*>(isq ? p.qk_wq : p.qk_wk)[g];
                     float4 y;
@@ -1149,7 +1149,7 @@ gemm_f32_tile(const GemmParams& p, float* __restrict__ smem_all, const int vbloc
                     // the wave's 64-column patch is exactly one head: 16 lanes hold one row of it
                     const float4 o4 = oth[EPI == 2 ? it : 0];
                     float d = v.x * o4.x + v.y * o4.y + v.z * o4.z + v.w * o4.w;
-                    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+                    d = row16_sum_dpp(d);
                     if ((lane & 15) == 0) {
                         const int row = row_first + 4 * it;
                         const int heads = p.N >> 6, head = (col0 + wn * 64) >> 6;

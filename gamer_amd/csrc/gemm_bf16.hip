@@ -261,7 +261,7 @@ __device__ __forceinline__ void hb_epilogue(const GemmBf16Params& p, f32x16 (&ac
                         }
                     }
                 if (isq || isk) {
-                    ss += __shfl_xor(ss, 32, 64);
+                    ss = xor32_sum(ss);
                     const float rstd = rsqrtf(ss * (1.f / 64.f) + p.qk_eps);
                     const float* wn_ = isq ? p.qk_wq : p.qk_wk;
                     const int pos = p.qk_pos_ids ? p.qk_pos_ids[row] : row % p.qk_S;
@@ -408,7 +408,7 @@ __device__ __forceinline__ void hb_epilogue(const GemmBf16Params& p, f32x16 (&ac
                         }
                     if (EPI == 2) {
                         // the wave's 64-column patch is exactly one head; the two lane halves hold its two halves
-                        dot += __shfl_xor(dot, 32, 64);
+                        dot = xor32_sum(dot);
                         if (h == 0) {
                             const int heads = p.N >> 6, head = (col0 + wn * 64) >> 6;
                             p.rowdot_out[((int64_t)(row / p.rowdot_S) * heads + head) * p.rowdot_S + row % p.rowdot_S] = dot;
