@@ -37,6 +37,9 @@ constexpr int AB_THREADS = 256;
 #ifndef AB_OCC_DQ
 #define AB_OCC_DQ 2
 #endif
+#ifndef AB_ABLATE_DKV
+#define AB_ABLATE_DKV 0   // timing-only builds of attn_bwd_dkv_b_kernel (tools/ablate_attn_bf16_dkv.sh): bits 1 S/dP products, 2 element-wise, 4 dV/dK products, 8 loads, 16 barriers, 32 LDS stores
+#endif
 #ifndef AB_OCC_DKV
 #define AB_OCC_DKV 2
 #endif
@@ -1205,7 +1208,7 @@ attn_bwd_dkv_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restr
     for (int qt = qt_first; qt < n_qt; ++qt) {
         const int cur = (qt - qt_first) & 1;
         const bool more = qt + 1 < n_qt;
-        if (more) load_q_tile(qt + 1);
+        if (more && !(AB_ABLATE_DKV & 8)) load_q_tile(qt + 1);
         const int posmax = __builtin_amdgcn_readfirstlane(sm.posmax[cur]);
         if (posmax >= wave_k_lo) {                     // some query of the tile reaches this wave's first key
             const bf16_t* Qh = sm.Qs[cur][hg];
@@ -1214,6 +1217,7 @@ attn_bwd_dkv_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restr
 #pragma unroll
             for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
             // S[query][key] = sum_d Q[query][d] K[key][d],  dP[query][key] = sum_d dO[query][d] V[key][d]
+            if (!(AB_ABLATE_DKV & 1))
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_row8(Qh, lo, 0, s), read_row8(sm.Kt, lo, 32 * sub, s), st, 0, 0, 0);
@@ -1228,6 +1232,7 @@ attn_bwd_dkv_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restr
                 free_tile = free_tile && (wave_k_hi < hl || wave_k_lo >= hh);
             }
             // per element (query = register, key = lane): P -> st (for dV, 1/(1-p) applied at the end), dS -> dp (for dK)
+            if (!(AB_ABLATE_DKV & 2))
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 __builtin_amdgcn_sched_barrier(0);       // one group of four queries at a time (register pressure)
@@ -1275,6 +1280,7 @@ attn_bwd_dkv_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restr
                 }
             }
             // dV^T[d][key] += sum_query dO[query][d] Pd[query][key];  dK^T[d][key] += sum_query Q[query][d] dS[query][key]
+            if (!(AB_ABLATE_DKV & 4))
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 pf = pack8(st, s2);
@@ -1286,8 +1292,8 @@ attn_bwd_dkv_b_tile(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restr
                 }
             }
         }
-        if (more) store_q_tile(qt + 1, cur ^ 1);
-        __syncthreads();
+        if (more && !(AB_ABLATE_DKV & 32)) store_q_tile(qt + 1, cur ^ 1);
+        if (!(AB_ABLATE_DKV & 16)) __syncthreads();
     }
 
     // ---- sum the G query heads of this kv head through LDS, then store ---------------------------
@@ -1365,6 +1371,266 @@ attn_bwd_dkv_b_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __res
     }
 }
 
+// =============================================================================================
+// backward: dK, dV with ONE QUERY HEAD'S Q / dO resident in LDS (S <= 512, no key spans)
+//   The tiled kernel above re-stages a 32-query tile of Q / dO through registers and LDS for every 64 keys and synchronises its four
+//   waves per tile; timing-only builds (tools/ablate_attn_bf16_dkv.sh) price that skeleton - loads, LDS stores, barriers, the K / V
+//   prologue and the head reduction of 24,576 work items - at 0.86 of the kernel's 1.45 ms, the products and the element-wise work at
+//   0.59.  Here a workgroup (8 waves, one per CU) takes a whole (sequence, kv head): per query head it stages all rows of Q and dO once
+//   (2 x 64 KB, in the order of the row permutation if there is one), then every wave sweeps the query tiles for its TWO key tiles
+//   (w and 15 - w: 17 tile visits per wave under the causal mask) with K / V fragments in registers and no barrier; the heads of the
+//   group add into the same accumulators (no head reduction), dK / dV leave once per pair.
+// =============================================================================================
+constexpr int BH_THREADS = 512, BH_ROWS = 512, BH_TILES = BH_ROWS / 32;
+struct BhSmem {
+    bf16_t Q[BH_ROWS * 64];       // slot-major (slot = position, or the row permutation's slot), chunks swizzled as everywhere here
+    bf16_t dO[BH_ROWS * 64];
+    float nlse2[BH_ROWS];         // -lse * log2(e) of the slot's row, current head
+    float ndelta[BH_ROWS];
+    uint32_t aw[BH_ROWS];         // dropout row words, current head
+    int32_t ql[BH_ROWS];          // (head independent)
+    int32_t pos[BH_ROWS];         // key limit of the slot's row; -1: none (past the end, or an "empty" row)
+    int32_t t_qlmin[BH_TILES], t_posmin[BH_TILES], t_posmax[BH_TILES];
+};
+static_assert(sizeof(BhSmem) <= 160 * 1024, "BhSmem must fit the CU's LDS");
+
+template <int G, bool DROP, bool ORD>
+__global__ void __launch_bounds__(BH_THREADS, 1)
+attn_bwd_dkv_bh_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                       const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                       const float* __restrict__ delta, const int32_t* __restrict__ kl, const int32_t* __restrict__ ql,
+                       int nbatch, int S, int nq, int nkv, float scale, float p_drop, uint64_t seed,
+                       bf16_t* __restrict__ dk, int lddk, bf16_t* __restrict__ dv, int lddv, const QOrdB ord) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bh_raw[];
+    BhSmem& sm = *reinterpret_cast<BhSmem*>(bh_raw);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const LdsOffsets lo(lane);
+    const int n_qt_all = (S + 31) >> 5;
+    const float c2 = scale * 1.4426950408889634f;
+    const AttnDropout rng(p_drop, seed);
+    const float sd = rng.scale;
+
+    for (int pair = blockIdx.x; pair < nbatch * nkv; pair += gridDim.x) {
+        const int b = pair / nkv, kvh = pair % nkv;
+        const int32_t* mp = ORD ? ord.tile_maxpos + (int64_t)b * n_qt_all : nullptr;
+        int n_qt = n_qt_all;
+        if (ORD) {                                         // sorted tiles: the tiles with a normal row come first
+            int end = 0;
+            while (end < n_qt_all && mp[end] >= 0) ++end;
+            n_qt = end;
+        }
+        const int n_slots = n_qt * 32;
+
+        // ONE set of accumulators: the tile being swept.  Heads alternate the order of the wave's two tiles (A B | B A | ...), so the
+        // sums of the tile swept last continue into the next head; the other tile's sums wait in `park` (private memory, written and
+        // read once per head boundary).  With both sets in registers (128 + the loop's ~130) the compiler kept three of the ACTIVE
+        // tile's four accumulators in scratch and moved them in and out around every query tile: 2.1 ms against the tiled kernel's 1.45.
+        f32x16 dkacc[2], dvacc[2];                         // [columns 32 db ..]
+        float park_mem[64];
+        float __attribute__((address_space(5)))* park = (float __attribute__((address_space(5)))*)park_mem;
+        asm volatile("" : "+v"(park));                     // (the array stays in memory: plain 16-byte scratch stores / loads, one wait)
+
+#pragma unroll 1
+        for (int g = 0; g < G; ++g) {
+            const int hd = kvh * G + g;
+            __syncthreads();                               // the previous head's (pair's) sweeps are done with the images
+            // ---- stage the head's Q / dO rows and per-row scalars: two rounds of four 16-byte chunks per thread and operand.  (Issuing
+            // the loads in front of the barrier - so that they fly while the slower waves finish - measured 2.27-2.30 against 1.90 ms:
+            // the values that stay live across the barrier push the address arithmetic of the whole head loop into scratch.)
+#pragma unroll 1
+            for (int half = 0; half < ((AB_ABLATE_DKV & 8) ? 0 : 2); ++half) {
+                uint4 rq[4], rdo[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int f = tid + BH_THREADS * (4 * half + jj);
+                    const int slot = min(f >> 3, S - 1);   // (slots past the sequence re-read its last row: masked through pos = -1)
+                    const int row = ORD ? ord.perm[(int64_t)b * S + slot] : slot;
+                    rq[jj] = *reinterpret_cast<const uint4*>(q + ((int64_t)b * S + row) * ldq + hd * 64 + ((f & 7) << 3));
+                    rdo[jj] = *reinterpret_cast<const uint4*>(d_o + ((int64_t)b * S + row) * (int64_t)nq * 64 + hd * 64 + ((f & 7) << 3));
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int f = tid + BH_THREADS * (4 * half + jj);
+                    if ((f >> 3) < n_slots) {
+                        *reinterpret_cast<uint4*>(sm.Q + lds_off(f >> 3, (f & 7) << 3)) = rq[jj];
+                        *reinterpret_cast<uint4*>(sm.dO + lds_off(f >> 3, (f & 7) << 3)) = rdo[jj];
+                    }
+                }
+            }
+            if (tid < n_slots) {
+                const int slot = tid;
+                const bool in = slot < S;
+                int ic = in ? slot : S - 1;
+                if (ORD) ic = ord.perm[(int64_t)b * S + ic];
+                sm.nlse2[slot] = in ? -lse[((int64_t)b * nq + hd) * S + ic] * 1.4426950408889634f : 0.f;
+                sm.ndelta[slot] = in ? -delta[((int64_t)b * nq + hd) * S + ic] : 0.f;
+                if (DROP) sm.aw[slot] = rng.row_word((uint32_t)(((int64_t)b * nq + hd) * S) + (uint32_t)ic);
+                if (g == 0) {
+                    const int rql = in ? (ql ? ql[(int64_t)b * S + ic] : 1) : 0;
+                    int rpos = in ? ic : -1;
+                    if (ORD && in && ord.row_empty[(int64_t)b * S + ic] != 0) rpos = -1;
+                    sm.ql[slot] = rql;
+                    sm.pos[slot] = rpos;
+                    // the statistics of the wave's two tiles (a tile = two rows of 16 lanes)
+                    int a = in ? rql : INT_BIG_B, c = in ? rpos : INT_BIG_B, d = rpos;
+                    GAMER_DPP_ROW_REDUCE(min, a)
+                    GAMER_DPP_ROW_REDUCE(min, c)
+                    GAMER_DPP_ROW_REDUCE(max, d)
+                    const int a0 = min(__builtin_amdgcn_readlane(a, 0), __builtin_amdgcn_readlane(a, 16));
+                    const int a1 = min(__builtin_amdgcn_readlane(a, 32), __builtin_amdgcn_readlane(a, 48));
+                    const int c0 = min(__builtin_amdgcn_readlane(c, 0), __builtin_amdgcn_readlane(c, 16));
+                    const int c1 = min(__builtin_amdgcn_readlane(c, 32), __builtin_amdgcn_readlane(c, 48));
+                    const int d0 = max(__builtin_amdgcn_readlane(d, 0), __builtin_amdgcn_readlane(d, 16));
+                    const int d1 = max(__builtin_amdgcn_readlane(d, 32), __builtin_amdgcn_readlane(d, 48));
+                    if (lane == 0) {
+                        sm.t_qlmin[2 * w] = a0; sm.t_posmin[2 * w] = c0; sm.t_posmax[2 * w] = d0;
+                        sm.t_qlmin[2 * w + 1] = a1; sm.t_posmin[2 * w + 1] = c1; sm.t_posmax[2 * w + 1] = d1;
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- the wave's two key tiles ------------------------------------------------------------------------------
+#pragma unroll 1
+            for (int step = 0; step < 2; ++step) {
+                const int kk = (g & 1) ? 1 - step : step;
+                const int kt = kk == 0 ? w : BH_TILES - 1 - w;
+                const int k0 = kt * 32;
+                if (k0 >= S) continue;                     // (then the wave has one tile: its sums simply continue from head to head)
+                const bool two_tiles = (BH_TILES - 1 - w) * 32 < S;
+                if (g == 0 || (step == 1 && !two_tiles)) {
+                    if (g == 0) {
+#pragma unroll
+                        for (int db = 0; db < 2; ++db)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) { dkacc[db][i] = 0.f; dvacc[db][i] = 0.f; }
+                    }
+                } else if (step == 1) {                    // back to the tile that waited since the previous head
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { dkacc[db][i] = park[32 * db + i]; dvacc[db][i] = park[32 * db + 16 + i]; }
+                }
+                const int jk = k0 + r;
+                const bool valid_k = jk < S;
+                const int64_t ktok = (int64_t)b * S + (valid_k ? jk : S - 1);
+                bf16x8 kf[4], vf[4];                       // B operands: the lane's key, columns 16 s + 8 h ..
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    uint4 a = *reinterpret_cast<const uint4*>(k + ktok * ldk + kvh * 64 + 16 * s4 + 8 * h);
+                    uint4 c = *reinterpret_cast<const uint4*>(v + ktok * ldv + kvh * 64 + 16 * s4 + 8 * h);
+                    if (!valid_k) { a = make_uint4(0u, 0u, 0u, 0u); c = a; }
+                    kf[s4] = __builtin_bit_cast(bf16x8, a);
+                    vf[s4] = __builtin_bit_cast(bf16x8, c);
+                }
+                const int my_kl = valid_k ? kl[ktok] : INT_BIG_B;
+                const int wave_kl_max = wave_max_i32_dpp(my_kl);
+                const uint32_t bw = DROP ? rng.key_word((uint32_t)jk) : 0u;
+                int qt_first = kt;                         // earlier query tiles only hold queries before every key of the tile
+                if (ORD) {
+                    int first = 0;
+                    while (first < n_qt && mp[first] < k0) ++first;
+                    qt_first = first;
+                }
+#pragma unroll 1
+                for (int qt = qt_first; qt < n_qt; ++qt) {
+                    const int posmax = __builtin_amdgcn_readfirstlane(sm.t_posmax[qt]);
+                    if (posmax < k0) continue;             // no query of the tile reaches the wave's first key
+                    const bf16_t* Qh = sm.Q + qt * 32 * 64;
+                    const bf16_t* dOh = sm.dO + qt * 32 * 64;
+                    f32x16 st, dp;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+                    if (!(AB_ABLATE_DKV & 1))
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_row8(Qh, lo, 0, s4), kf[s4], st, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_row8(dOh, lo, 0, s4), vf[s4], dp, 0, 0, 0);
+                    }
+                    const int posmin = __builtin_amdgcn_readfirstlane(sm.t_posmin[qt]);
+                    const int qlmin = __builtin_amdgcn_readfirstlane(sm.t_qlmin[qt]);
+                    const bool free_tile = (posmin >= k0 + 31) && (wave_kl_max < qlmin) && (qt * 32 + 32 <= S);
+                    if (!(AB_ABLATE_DKV & 2))
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        __builtin_amdgcn_sched_barrier(0);   // one group of four queries at a time (register pressure)
+                        const int qb = qt * 32 + 8 * g4 + 4 * h;
+                        const float4 d4 = *reinterpret_cast<const float4*>(&sm.ndelta[qb]);
+                        const float4 l4 = *reinterpret_cast<const float4*>(&sm.nlse2[qb]);
+                        const float ndl[4] = {d4.x, d4.y, d4.z, d4.w};
+                        const float nl[4] = {l4.x, l4.y, l4.z, l4.w};
+                        int qlv[4] = {0, 0, 0, 0}, posv[4] = {0, 0, 0, 0};
+                        uint32_t awv[4] = {0, 0, 0, 0};
+                        if (!free_tile) {
+                            const int4 q4 = *reinterpret_cast<const int4*>(&sm.ql[qb]);
+                            const int4 p4 = *reinterpret_cast<const int4*>(&sm.pos[qb]);
+                            qlv[0] = q4.x; qlv[1] = q4.y; qlv[2] = q4.z; qlv[3] = q4.w;
+                            posv[0] = p4.x; posv[1] = p4.y; posv[2] = p4.z; posv[3] = p4.w;
+                        }
+                        if (DROP) {
+                            const uint4 a4 = *reinterpret_cast<const uint4*>(&sm.aw[qb]);
+                            awv[0] = a4.x; awv[1] = a4.y; awv[2] = a4.z; awv[3] = a4.w;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int reg = 4 * g4 + e;
+                            float pe = __builtin_amdgcn_exp2f(fmaf(st[reg], c2, nl[e]));
+                            if (!free_tile) {
+                                const bool allowed = (jk <= posv[e]) & (my_kl < qlv[e]);
+                                pe = allowed ? pe : 0.f;
+                            }
+                            if (DROP) {
+                                const bool keep = rng.keep(awv[e], bw);
+                                const float t = keep ? dp[reg] : 0.f;
+                                dp[reg] = pe * fmaf(t, sd, ndl[e]);          // dS[query][key]
+                                st[reg] = keep ? pe : 0.f;                   // dropped P[query][key] * (1 - p)
+                            } else {
+                                dp[reg] = pe * (dp[reg] + ndl[e]);
+                                st[reg] = pe;
+                            }
+                        }
+                    }
+                    if (!(AB_ABLATE_DKV & 4))
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8 pf = pack8(st, s2);
+                        const bf16x8 df = pack8(dp, s2);
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr8(dOh, lo, 16 * s2, db), pf, dvacc[db], 0, 0, 0);
+                            dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(read_tr8(Qh, lo, 16 * s2, db), df, dkacc[db], 0, 0, 0);
+                        }
+                    }
+                }
+                if (g == G - 1) {
+                    // ---- dK, dV of the tile: every head of the group is in the sums ----
+                    if (valid_k) {
+                        bf16_t* dkrow = dk + ktok * lddk + kvh * 64;
+                        bf16_t* dvrow = dv + ktok * lddv + kvh * 64;
+                        const float vs = DROP ? sd : 1.f;
+#pragma unroll
+                        for (int db = 0; db < 2; ++db)
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) {
+                                const int d = 32 * db + 8 * g4 + 4 * h;
+                                st4(dkrow + d, make_float4(dkacc[db][4 * g4] * scale, dkacc[db][4 * g4 + 1] * scale,
+                                                           dkacc[db][4 * g4 + 2] * scale, dkacc[db][4 * g4 + 3] * scale));
+                                st4(dvrow + d, make_float4(dvacc[db][4 * g4] * vs, dvacc[db][4 * g4 + 1] * vs,
+                                                           dvacc[db][4 * g4 + 2] * vs, dvacc[db][4 * g4 + 3] * vs));
+                            }
+                    }
+                } else if (step == 0 && two_tiles) {
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) { park[32 * db + i] = dkacc[db][i]; park[32 * db + 16 + i] = dvacc[db][i]; }
+                }
+            }
+        }
+    }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 template <int G>
 static int launch_fwd_b(const bf16_t* q, int ldq, const bf16_t* k, int ldk, const bf16_t* v, int ldv, const int32_t* kl,
@@ -1416,6 +1682,32 @@ static int launch_bwd_b_variant(const bf16_t* q, int ldq, const bf16_t* k, int l
                                 const QOrdB ord, hipStream_t st) {
     constexpr int R = (4 / G) * 32;
     dim3 grid(worklist_grid_b(B * nkv, (S + R - 1) / R, 2));
+    bool dkv_done = false;
+    if constexpr (!SPAN) {
+        // dK / dV with a query head's Q / dO resident in LDS: whole (sequence, kv head) pairs on persistent workgroups, one per CU;
+        // taken when the pairs fill the CUs' rounds (384 pairs on 256 CUs - per-GPU batch 128 - would leave the second round half empty)
+        const int pairs = B * nkv, cap = br_grid_cap();
+        const int rounds = (pairs + cap - 1) / cap;
+        const bool fills = (double)pairs >= 0.85 * (double)rounds * (double)cap || pairs <= cap;
+        if (S <= BH_ROWS && br_enabled() && GAMER_BR_PART("GAMER_ATTN_RES_DKV_BF16") && fills) {
+            const size_t hshmem = sizeof(BhSmem);
+            static bool hattr_dev[MAX_DEVICES] = {};
+            if (!hattr_dev[current_device()]) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_bh_kernel<G, DROP, ORD>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)hshmem);
+                if (e != hipSuccess) {
+                    set_error("gamer_attn_bwd_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                    return (int)e;
+                }
+                hattr_dev[current_device()] = true;
+            }
+            hipLaunchKernelGGL((attn_bwd_dkv_bh_kernel<G, DROP, ORD>), dim3(pairs < cap ? pairs : cap), dim3(BH_THREADS), hshmem, st, q, ldq,
+                               k, ldk, v, ldv, d_o, lse, delta, kl, ql, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, ord);
+            GAMER_CHECK_LAUNCH("gamer_attn_bwd_bf16/dkv head-resident");
+            dkv_done = true;
+        }
+    }
+    if (!dkv_done) {
     size_t shmem = sizeof(DkvSmemB<G>);
     const size_t red_bytes = (size_t)R * 132 * sizeof(float);
     if (shmem < red_bytes) shmem = red_bytes;
@@ -1433,6 +1725,7 @@ static int launch_bwd_b_variant(const bf16_t* q, int ldq, const bf16_t* k, int l
     hipLaunchKernelGGL((attn_bwd_dkv_b_kernel<G, DROP, SPAN, ORD>), grid, dim3(AB_THREADS), shmem, st, q, ldq, k, ldk, v, ldv, d_o,
                        lse, delta, kl, ql, B, S, nq, nkv, scale, p_drop, seed, dk, lddk, dv, lddv, span, ord);
     GAMER_CHECK_LAUNCH("gamer_attn_bwd_bf16/dkv");
+    }
     if (S <= BR_MAXKEYS && br_enabled() && GAMER_BR_PART("GAMER_ATTN_RES_DQ")) {
         // dQ with K / V of a (sequence, kv head) resident in LDS
         const int split = br_split(B * nkv, G);

@@ -89,6 +89,7 @@ def test_resident_and_tiled_kernels_draw_the_same_dropout_mask(cross):
 @pytest.mark.parametrize("cross", [False, True])
 @pytest.mark.parametrize("p_drop", [0.0, 0.25])
 def test_bf16_resident_forward_and_dq_are_bit_identical_to_the_tiled_kernels(cross, p_drop):
+    """(and the head-resident dK / dV kernel against the tiled one, to rounding)"""
     from gamer_amd import ops, synthetic
     from gamer_amd.config import synthetic_config
     B, items, nq, nkv = 9, 101, 6, 3
@@ -130,5 +131,10 @@ def test_bf16_resident_forward_and_dq_are_bit_identical_to_the_tiled_kernels(cro
                               nq * 64, dk, nkv * 64, dv, qkv.shape[1], order=od)
             torch.cuda.synchronize()
             out[form] = dict(o=o, lse=lse, dq=dq, dk=dk, dv=dv.clone())
-    for key in ("o", "lse", "dq", "dk", "dv"):
+    for key in ("o", "lse", "dq"):
         assert torch.equal(out[0][key], out[1][key]), key
+    # dK / dV: the head-resident kernel (attn_bwd_dkv_bh_kernel) adds the heads of a kv group and the query tiles in another order than
+    # the tiled one - same products, fp32 sums, one rounding to bf16 at the end: the two agree to an ulp of bf16 on the tensor's scale
+    for key in ("dk", "dv"):
+        a, b_ = out[0][key].float(), out[1][key].float()
+        assert float((a - b_).abs().max()) <= 2.0 ** -7 * float(a.abs().max()), key
