@@ -38,7 +38,7 @@ constexpr int AB_THREADS = 256;
 #define AB_OCC_DQ 2
 #endif
 #ifndef AB_ABLATE_DKV
-#define AB_ABLATE_DKV 0   // timing-only builds of attn_bwd_dkv_b_kernel (tools/ablate_attn_bf16_dkv.sh): bits 1 S/dP products, 2 element-wise, 4 dV/dK products, 8 loads, 16 barriers, 32 LDS stores
+#define AB_ABLATE_DKV 0   // timing-only builds of attn_bwd_dkv_b_kernel (tools/ablate_attn_bf16_dkv.sh): bits 1 S/dP products, 2 element-wise, 4 dV/dK products, 8 Q/dO loads, 16 barriers | final stores, 32 LDS stores | K/V fragment loads, 64 park, 128 row scalars (tiled | head-resident kernel)
 #endif
 #ifndef AB_OCC_DKV
 #define AB_OCC_DKV 2
@@ -1463,8 +1463,8 @@ attn_bwd_dkv_bh_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __re
                 const bool in = slot < S;
                 int ic = in ? slot : S - 1;
                 if (ORD) ic = ord.perm[(int64_t)b * S + ic];
-                sm.nlse2[slot] = in ? -lse[((int64_t)b * nq + hd) * S + ic] * 1.4426950408889634f : 0.f;
-                sm.ndelta[slot] = in ? -delta[((int64_t)b * nq + hd) * S + ic] : 0.f;
+                sm.nlse2[slot] = (in && !(AB_ABLATE_DKV & 128)) ? -lse[((int64_t)b * nq + hd) * S + ic] * 1.4426950408889634f : 0.f;
+                sm.ndelta[slot] = (in && !(AB_ABLATE_DKV & 128)) ? -delta[((int64_t)b * nq + hd) * S + ic] : 0.f;
                 if (DROP) sm.aw[slot] = rng.row_word((uint32_t)(((int64_t)b * nq + hd) * S) + (uint32_t)ic);
                 if (g == 0) {
                     const int rql = in ? (ql ? ql[(int64_t)b * S + ic] : 1) : 0;
@@ -1506,7 +1506,7 @@ attn_bwd_dkv_bh_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __re
 #pragma unroll
                             for (int i = 0; i < 16; ++i) { dkacc[db][i] = 0.f; dvacc[db][i] = 0.f; }
                     }
-                } else if (step == 1) {                    // back to the tile that waited since the previous head
+                } else if (step == 1 && !(AB_ABLATE_DKV & 64)) {   // back to the tile that waited since the previous head
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -1518,13 +1518,16 @@ attn_bwd_dkv_bh_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __re
                 bf16x8 kf[4], vf[4];                       // B operands: the lane's key, columns 16 s + 8 h ..
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
-                    uint4 a = *reinterpret_cast<const uint4*>(k + ktok * ldk + kvh * 64 + 16 * s4 + 8 * h);
-                    uint4 c = *reinterpret_cast<const uint4*>(v + ktok * ldv + kvh * 64 + 16 * s4 + 8 * h);
+                    uint4 a = make_uint4(0u, 0u, 0u, 0u), c = a;
+                    if (!(AB_ABLATE_DKV & 32)) {
+                        a = *reinterpret_cast<const uint4*>(k + ktok * ldk + kvh * 64 + 16 * s4 + 8 * h);
+                        c = *reinterpret_cast<const uint4*>(v + ktok * ldv + kvh * 64 + 16 * s4 + 8 * h);
+                    }
                     if (!valid_k) { a = make_uint4(0u, 0u, 0u, 0u); c = a; }
                     kf[s4] = __builtin_bit_cast(bf16x8, a);
                     vf[s4] = __builtin_bit_cast(bf16x8, c);
                 }
-                const int my_kl = valid_k ? kl[ktok] : INT_BIG_B;
+                const int my_kl = (valid_k && !(AB_ABLATE_DKV & 32)) ? kl[ktok] : INT_BIG_B;
                 const int wave_kl_max = wave_max_i32_dpp(my_kl);
                 const uint32_t bw = DROP ? rng.key_word((uint32_t)jk) : 0u;
                 int qt_first = kt;                         // earlier query tiles only hold queries before every key of the tile
@@ -1605,7 +1608,7 @@ attn_bwd_dkv_bh_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __re
                 }
                 if (g == G - 1) {
                     // ---- dK, dV of the tile: every head of the group is in the sums ----
-                    if (valid_k) {
+                    if (valid_k && !(AB_ABLATE_DKV & 16)) {
                         bf16_t* dkrow = dk + ktok * lddk + kvh * 64;
                         bf16_t* dvrow = dv + ktok * lddv + kvh * 64;
                         const float vs = DROP ? sd : 1.f;
@@ -1620,7 +1623,7 @@ attn_bwd_dkv_bh_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __re
                                                            dvacc[db][4 * g4 + 2] * vs, dvacc[db][4 * g4 + 3] * vs));
                             }
                     }
-                } else if (step == 0 && two_tiles) {
+                } else if (step == 0 && two_tiles && !(AB_ABLATE_DKV & 64)) {
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
 #pragma unroll
