@@ -278,7 +278,8 @@ attn_decode_h2_kernel(const float* __restrict__ q, int ldq, const float* __restr
                       const float* __restrict__ vp, int ldvp, const int32_t* __restrict__ key_ok,
                       const float* __restrict__ kg, const float* __restrict__ vg, int ldg, int tmax, int t, int gen_ok,
                       const int32_t* __restrict__ uniform, int nb, int L0, int nq, int nkv, float scale,
-                      float* __restrict__ o, const uint32_t* __restrict__ amax_k, const uint32_t* __restrict__ amax_v) {
+                      float* __restrict__ o, const uint32_t* __restrict__ amax_k, const uint32_t* __restrict__ amax_v,
+                      uint32_t* __restrict__ amax_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dec2_raw[];
     float* dec_lds = reinterpret_cast<float*>(dec2_raw);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -456,6 +457,7 @@ attn_decode_h2_kernel(const float* __restrict__ q, int ldq, const float* __restr
         __syncthreads();
     }
     // tail: as attn_decode_kernel
+    float omax = 0.f;
 #pragma unroll 1
     for (int i = 0; i < DEC_MAXQ; ++i) {
         const int qi = w + 4 * i;
@@ -492,6 +494,15 @@ attn_decode_h2_kernel(const float* __restrict__ q, int ldq, const float* __restr
             res = li > 0.f ? a / li : 0.f;
         }
         o[(int64_t)n * nq * 64 + head * 64 + lane] = res;
+        omax = fmaxf(omax, fabsf(res));
+    }
+    if (amax_out) {                                           // (gamer_amax_sink: max |o| for the o_proj GEMM's scale)
+        uint32_t mw = __float_as_uint(omax);
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) mw = max(mw, (uint32_t)__shfl_xor((int)mw, o2, 64));
+        // one word, thousands of waves: an atomic only when it would raise the maximum (a stale read costs one atomic more, never a wrong
+        // result - the maximum only grows); unconditional, the 3072 atomics on one address took 19 us of a 85-us kernel
+        if (lane == 0 && mw > __atomic_load_n(amax_out, __ATOMIC_RELAXED)) atomicMax(amax_out, mw);
     }
 }
 
@@ -537,7 +548,8 @@ static int attn_decode_impl(const float* q, int ldq, const float* kp, int ldkp, 
                     "gamer_attn_decode: q / prompt K / V need 16-byte alignment and leading dims %% 4 == 0");
     dim3 grid(B * nkv);
     if (amax_k && amax_v) {
-        // the three-piece fp16 form (prompt K / V maxima given)
+        // the three-piece fp16 form (prompt K / V maxima given); max |o| goes to the slot gamer_amax_sink armed, if any
+        uint32_t* sink_o = take_amax_sink().out[0];
         static bool attr2_dev[MAX_DEVICES] = {};
         bool& attr2 = attr2_dev[current_device()];
         if (!attr2) {
@@ -554,10 +566,10 @@ static int attn_decode_impl(const float* q, int ldq, const float* kp, int ldkp, 
         }
         if (G == 1)
             hipLaunchKernelGGL(attn_decode_h2_kernel<1>, grid, dim3(256), DEC2_LDS_BYTES, (hipStream_t)stream, q, ldq, kp, ldkp, vp, ldvp,
-                               key_ok, kg, vg, ldg, tmax, t, gen_ok, uniform, nb, L0, nq, nkv, scale, o, amax_k, amax_v);
+                               key_ok, kg, vg, ldg, tmax, t, gen_ok, uniform, nb, L0, nq, nkv, scale, o, amax_k, amax_v, sink_o);
         else
             hipLaunchKernelGGL(attn_decode_h2_kernel<2>, grid, dim3(256), DEC2_LDS_BYTES, (hipStream_t)stream, q, ldq, kp, ldkp, vp, ldvp,
-                               key_ok, kg, vg, ldg, tmax, t, gen_ok, uniform, nb, L0, nq, nkv, scale, o, amax_k, amax_v);
+                               key_ok, kg, vg, ldg, tmax, t, gen_ok, uniform, nb, L0, nq, nkv, scale, o, amax_k, amax_v, sink_o);
         GAMER_CHECK_LAUNCH("gamer_attn_decode_split");
         return 0;
     }

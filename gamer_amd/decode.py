@@ -360,6 +360,12 @@ class DecodeSession:
         else:
             cos, sin = cos[p:p + 1], sin[p:p + 1]
         e = p % cfg.num_positions + 1                    # position-routed expert (router.py:83-104), same for every row
+        grp = None
+        if eng._amax is not None and eng.matmul == "split3":
+            key = f"expert_offsets_{e}"
+            if key not in self.st.small:           # rows [0, N) belong to expert e, every other group is empty
+                self.st.small[key] = torch.tensor([0] * (e + 1) + [N] * (E - e), dtype=torch.int32, device=tokens.device)
+            grp = dict(groups=E, group_offsets=self.st.small[key])
         x, x1, x2 = b["x"]
         ops.embedding_fwd(tokens, eng.params["model.embed_tokens.weight"], x)
 
@@ -399,6 +405,14 @@ class DecodeSession:
             ops.rmsnorm_fwd(xc, W.ln3, eps, b["hin"], din)
             if W.inject:
                 ops.rowtable_fwd(W.beh, self.beh, b["hin"], din, H)
+            if grp is not None:
+                # the whole stacked weight with every row in expert e's group: the tensor the prompt pass measured and cut (its maximum
+                # slot and packed pieces are reused; a row slice is another tensor to the maxima cache - two gamer_absmax_f32 launches
+                # and two cuts of the weight per layer and token)
+                ops.linear_fwd(b["hin"], din, W.gu, din, b["gu"], 2 * I, N, 2 * I, din, strideB=2 * I * din, **grp)
+                ops.swiglu_fwd_ld(b["gu"], 2 * I, N, I, 0.0, 0, b["hm"])
+                ops.gemm(b["hm"], I, 1, W.down, I, 1, x, H, N, H, I, strideB=H * I, resid=xc, **grp)
+                continue
             ops.linear_fwd(b["hin"], din, W.gu[e * 2 * I:(e + 1) * 2 * I], din, b["gu"], 2 * I, N, 2 * I, din)      # gate | up of expert e
             ops.swiglu_fwd_ld(b["gu"], 2 * I, N, I, 0.0, 0, b["hm"])
             ops.gemm(b["hm"], I, 1, W.down[e * H:(e + 1) * H], I, 1, x, H, N, H, I, resid=xc)

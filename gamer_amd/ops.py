@@ -1132,6 +1132,8 @@ def attn_decode(q, kp, vp, key_ok, kg, vg, t, gen_ok, uniform, B, nb, L0, nq, nk
     amax = (slot of max |kp|, slot of max |vp|): the three-piece fp16 form (gamer_attn_decode_split)."""
     tmax = kg.shape[1]
     if amax is not None:
+        n = o.numel()
+        _arm_sink((o, (1, 0, 1, n, n), False))
         call("gamer_attn_decode_split", ptr(q), q.stride(0), ptr(kp), kp.stride(0), ptr(vp), vp.stride(0), ptr(key_ok), ptr(kg),
              ptr(vg), kg.stride(1), tmax, t, 1 if gen_ok else 0, ptr(uniform), B, nb, L0, nq, nkv, scale, ptr(o), amax[0], amax[1],
              stream_ptr())
