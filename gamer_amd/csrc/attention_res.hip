@@ -48,6 +48,10 @@ __device__ unsigned long long* g_res_stamp = nullptr;
 #define RES_STAMP_PASS
 #endif
 
+#ifndef RES_KEEP
+#define RES_KEEP 1        // attn_bwd_dkv_r2_kernel: a wave keeps the key tile it swept last across the stage boundary (0: round-5 order)
+#endif
+
 constexpr int RB_KEYS = 256;                 // keys of one resident block
 constexpr int RB_TILES = RB_KEYS / 32;
 constexpr int RES_THREADS = 512;
@@ -1217,6 +1221,7 @@ struct DkvR2Smem {
     uint32_t amax_word;
     int32_t ctr;
     int32_t pad_[6];
+    int32_t keeper_stage[RES_MAX_TILES];      // stage in which the tile is swept by the wave that kept it (-1: nobody's)
     int32_t hole_lo[QB2];                     // SPAN kernels only: the hole of every staged row, and per 32-row tile the smallest
     int32_t hole_hi[QB2];                     // hole start / largest hole end over its normal rows
     int32_t t_hlomin[QB2_TILES];
@@ -1298,67 +1303,118 @@ res2_stage_queries(DkvR2Smem& sm, const float* __restrict__ q, int ldq, const fl
 // classes of a query tile (the same for both heads: they share the rows)
 enum { QT_FREE = 0, QT_MASK = 1, QT_EMPTYSEL = 2, QT_ALL_EMPTY = 3 };
 
+// What a wave holds of its key tile between calls: the K / V fragments and the raw dK / dV sums.  A wave keeps the tile it swept last
+// across the stage boundary (RES_KEEP): the next stage sweeps it first, without the prologue (K / V rows, cut, carried sums) and
+// without the carry through dk / dv in between.
+struct DkvTileState {
+    bf16x8 kf[2][4], vf[2][4];            // piece x k-step: lane (r, h) holds d = 16 s + 8 h .. + 7 of its key's K / V row
+    f32x16 dkacc[2], dvacc[2];
+    int my_kl;
+};
+
+// One step of a wave: `release` - the sums of the held tile kt_rel leave (raw, or final: scaled, with the maximum); then, for kt >= 0,
+// `acquire` - its K / V fragments and carried sums are fetched (else T already holds them) - and the sweep over the staged query tiles.
 template <bool DROP, bool SPAN>
 __device__ __forceinline__ void
-res2_dkv_keytile(DkvR2Smem& sm, const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv,
-                 const int32_t* __restrict__ kl, int S, float scale, const AttnDropout& rng, float* dk, int lddk, float* dv, int lddv,
-                 const int b, const int kvh, const int kt, const int n_qt, const bool fresh, const bool final_stage,
-                 const bool want_amax, const H2Scales& sc RES_STAMP_ARGS) {
+res2_dkv_step(DkvR2Smem& sm, const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv,
+              const int32_t* __restrict__ kl, int S, float scale, const AttnDropout& rng, float* dk, int lddk, float* dv, int lddv,
+              const int b, const int kvh, const int kt_rel, const bool release, const bool final_stage, const int kt,
+              const bool acquire, const bool fresh, const int n_qt, const bool want_amax, const H2Scales& sc,
+              DkvTileState& T RES_STAMP_ARGS) {
     const int lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
+    if (release) {
+        const int jr = kt_rel * 32 + r;
+        const bool valid_r = jr < S;
+        const int64_t rtok = (int64_t)b * S + (valid_r ? jr : S - 1);
+        float* dkrow_r = dk + rtok * lddk + kvh * 64;
+        float* dvrow_r = dv + rtok * lddv + kvh * 64;
+        float vmax = 0.f;
+        if (valid_r) {
+            const float vs = final_stage ? (DROP ? rng.scale : 1.f) * (sc.inv_do * H2Scales::INV_P) : 1.f;
+            const float ks = final_stage ? scale * (sc.inv_q * sc.inv_ds) : 1.f;
+    #pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+    #pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d = 32 * dh + 8 * g4 + 4 * h;
+                    *reinterpret_cast<float4*>(dkrow_r + d) = make_float4(T.dkacc[dh][4 * g4] * ks, T.dkacc[dh][4 * g4 + 1] * ks,
+                                                                        T.dkacc[dh][4 * g4 + 2] * ks, T.dkacc[dh][4 * g4 + 3] * ks);
+                    const float4 dv4 = make_float4(T.dvacc[dh][4 * g4] * vs, T.dvacc[dh][4 * g4 + 1] * vs,
+                                                   T.dvacc[dh][4 * g4 + 2] * vs, T.dvacc[dh][4 * g4 + 3] * vs);
+                    *reinterpret_cast<float4*>(dvrow_r + d) = dv4;
+                    vmax = fmaxf(fmaxf(fmaxf(vmax, fabsf(dv4.x)), fabsf(dv4.y)), fmaxf(fabsf(dv4.z), fabsf(dv4.w)));
+                }
+        }
+        if (final_stage && want_amax) {                       // (gamer_amax_sink: max |dv|, the v columns of d(q|k|v))
+            uint32_t mw = __float_as_uint(vmax);
+    #pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) mw = max(mw, (uint32_t)__shfl_xor((int)mw, o2, 64));
+            if (lane == 0 && mw) atomicMax(&sm.amax_word, mw);
+        }
+        RES_MARK(3);                                           // 3: key-tile epilogue (store)
+
+    }
+    if (kt < 0) return;
     const SlOffsets lo(lane);
     const int jk = kt * 32 + r;                          // this lane's key
     const bool valid_k = jk < S;
     const int64_t ktok = (int64_t)b * S + (valid_k ? jk : S - 1);
 
-    // every global load of the prologue is requested before anything waits for one: the K / V rows, the key's level, the carried sums
-    float* dkrow = dk + ktok * lddk + kvh * 64;
-    float* dvrow = dv + ktok * lddv + kvh * 64;
-    float4 kraw[8], vraw[8];
-    {
-        const float* krow = k + ktok * ldk + kvh * 64 + 8 * h;
-        const float* vrow = v + ktok * ldv + kvh * 64 + 8 * h;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            kraw[2 * s] = *reinterpret_cast<const float4*>(krow + 16 * s);
-            kraw[2 * s + 1] = *reinterpret_cast<const float4*>(krow + 16 * s + 4);
-            vraw[2 * s] = *reinterpret_cast<const float4*>(vrow + 16 * s);
-            vraw[2 * s + 1] = *reinterpret_cast<const float4*>(vrow + 16 * s + 4);
-        }
-    }
-    const int my_kl = valid_k ? kl[ktok] : INT_BIG_A;
-    f32x16 dkacc[2], dvacc[2];
-    if (fresh) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { dkacc[0][i] = 0.f; dkacc[1][i] = 0.f; dvacc[0][i] = 0.f; dvacc[1][i] = 0.f; }
-    } else {
-        // the raw sums an earlier stage left (possibly another wave: read past the L1)
-#pragma unroll
-        for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d = 32 * dh + 8 * g4 + 4 * h;
-                f32x4v a = {0.f, 0.f, 0.f, 0.f}, c = a;
-                if (valid_k) {
-                    a = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(dkrow + d));
-                    c = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(dvrow + d));
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { dkacc[dh][4 * g4 + e] = a[e]; dvacc[dh][4 * g4 + e] = c[e]; }
+    if (acquire) {
+        // every global load of the prologue is requested before anything waits for one: the K / V rows, the key's level, the carried sums
+        float* dkrow = dk + ktok * lddk + kvh * 64;
+        float* dvrow = dv + ktok * lddv + kvh * 64;
+        float4 kraw[8], vraw[8];
+        {
+            const float* krow = k + ktok * ldk + kvh * 64 + 8 * h;
+            const float* vrow = v + ktok * ldv + kvh * 64 + 8 * h;
+    #pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                kraw[2 * s] = *reinterpret_cast<const float4*>(krow + 16 * s);
+                kraw[2 * s + 1] = *reinterpret_cast<const float4*>(krow + 16 * s + 4);
+                vraw[2 * s] = *reinterpret_cast<const float4*>(vrow + 16 * s);
+                vraw[2 * s + 1] = *reinterpret_cast<const float4*>(vrow + 16 * s + 4);
             }
+        }
+        T.my_kl = valid_k ? kl[ktok] : INT_BIG_A;
+        if (fresh) {
+    #pragma unroll
+            for (int i = 0; i < 16; ++i) { T.dkacc[0][i] = 0.f; T.dkacc[1][i] = 0.f; T.dvacc[0][i] = 0.f; T.dvacc[1][i] = 0.f; }
+        } else {
+            // the raw sums an earlier stage left (possibly another wave: read past the L1)
+    #pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+    #pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d = 32 * dh + 8 * g4 + 4 * h;
+                    f32x4v a = {0.f, 0.f, 0.f, 0.f}, c = a;
+                    if (valid_k) {
+                        a = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(dkrow + d));
+                        c = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(dvrow + d));
+                    }
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) { T.dkacc[dh][4 * g4 + e] = a[e]; T.dvacc[dh][4 * g4 + e] = c[e]; }
+                }
+        }
+    #pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float4 a4 = kraw[2 * s], b4 = kraw[2 * s + 1], c4 = vraw[2 * s], d4 = vraw[2 * s + 1];
+            if (!valid_k) { a4 = make_float4(0.f, 0.f, 0.f, 0.f); b4 = a4; c4 = a4; d4 = a4; }
+            bf16x8 pc[3];
+            cut8_t<true>(a4, b4, sc.k, pc);
+            T.kf[0][s] = pc[0]; T.kf[1][s] = pc[1];
+            cut8_t<true>(c4, d4, sc.v, pc);
+            T.vf[0][s] = pc[0]; T.vf[1][s] = pc[1];
+        }
+
     }
-    bf16x8 kf[2][4], vf[2][4];            // piece x k-step: lane (r, h) holds d = 16 s + 8 h .. + 7 of its key's K / V row
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        float4 a4 = kraw[2 * s], b4 = kraw[2 * s + 1], c4 = vraw[2 * s], d4 = vraw[2 * s + 1];
-        if (!valid_k) { a4 = make_float4(0.f, 0.f, 0.f, 0.f); b4 = a4; c4 = a4; d4 = a4; }
-        bf16x8 pc[3];
-        cut8_t<true>(a4, b4, sc.k, pc);
-        kf[0][s] = pc[0]; kf[1][s] = pc[1];
-        cut8_t<true>(c4, d4, sc.v, pc);
-        vf[0][s] = pc[0]; vf[1][s] = pc[1];
-    }
-    const int wave_kl_max = wave_max_i32(my_kl);
+    bf16x8 (&kf)[2][4] = T.kf;
+    bf16x8 (&vf)[2][4] = T.vf;
+    f32x16 (&dkacc)[2] = T.dkacc;
+    f32x16 (&dvacc)[2] = T.dvacc;
+    const int my_kl = T.my_kl;
+    const int wave_kl_max = wave_max_i32_dpp(my_kl);
     const int wave_k_lo = kt * 32, wave_k_hi = wave_k_lo + 31;
     const float invS = 1.f / (float)S;
     const float c2 = scale * 1.4426950408889634f * sc.inv_qk;
@@ -1551,30 +1607,6 @@ res2_dkv_keytile(DkvR2Smem& sm, const float* __restrict__ k, int ldk, const floa
     }
     RES_MARK(2);                                           // 2: query-tile loop
 
-    float vmax = 0.f;
-    if (valid_k) {
-        const float vs = final_stage ? (DROP ? rng.scale : 1.f) * (sc.inv_do * H2Scales::INV_P) : 1.f;
-        const float ks = final_stage ? scale * (sc.inv_q * sc.inv_ds) : 1.f;
-#pragma unroll
-        for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d = 32 * dh + 8 * g4 + 4 * h;
-                *reinterpret_cast<float4*>(dkrow + d) = make_float4(dkacc[dh][4 * g4] * ks, dkacc[dh][4 * g4 + 1] * ks,
-                                                                    dkacc[dh][4 * g4 + 2] * ks, dkacc[dh][4 * g4 + 3] * ks);
-                const float4 dv4 = make_float4(dvacc[dh][4 * g4] * vs, dvacc[dh][4 * g4 + 1] * vs,
-                                               dvacc[dh][4 * g4 + 2] * vs, dvacc[dh][4 * g4 + 3] * vs);
-                *reinterpret_cast<float4*>(dvrow + d) = dv4;
-                vmax = fmaxf(fmaxf(fmaxf(vmax, fabsf(dv4.x)), fabsf(dv4.y)), fmaxf(fabsf(dv4.z), fabsf(dv4.w)));
-            }
-    }
-    if (final_stage && want_amax) {                       // (gamer_amax_sink: max |dv|, the v columns of d(q|k|v))
-        uint32_t mw = __float_as_uint(vmax);
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) mw = max(mw, (uint32_t)__shfl_xor((int)mw, o2, 64));
-        if (lane == 0 && mw) atomicMax(&sm.amax_word, mw);
-    }
-    RES_MARK(3);                                           // 3: key-tile epilogue (store)
 }
 
 template <bool DROP, bool SPAN, bool ORD>
@@ -1600,16 +1632,18 @@ attn_bwd_dkv_r2_kernel(const float* __restrict__ q, int ldq, const float* __rest
     unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
 #endif
+    DkvTileState T;
 #pragma unroll 1
     for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
         const int b = (pair / upp) / nkv, kvh = (pair / upp) % nkv, kt0 = pair % upp;
+        int held = -1;                                      // the key tile this wave's registers hold (T), -1: none
 #pragma unroll 1
         for (int qb = 0; qb < nqb; ++qb) {
             RES_MARK(5);                                    // 5: queue / loop control
             __syncthreads();                                // every wave is done with the previous stage's images (and flags)
             RES_MARK(4);                                    // 4: waiting for the slowest wave of the stage
             if (tid == 0) sm.ctr = 0;
-            if (qb == 0 && tid < RES_MAX_TILES) sm.started[tid] = 0;
+            if (qb == 0 && tid < RES_MAX_TILES) { sm.started[tid] = 0; sm.keeper_stage[tid] = -1; }
             res2_stage_queries<DROP, ORD, SPAN>(sm, q, ldq, d_o, lse, delta, ql, row_empty, ro, b, kvh * 2, qb * QB2, S, nq, tid, sc, rng);
             __syncthreads();
             RES_MARK(0);                                    // 0: staging (loads, cut, LDS stores, barrier)
@@ -1637,15 +1671,41 @@ attn_bwd_dkv_r2_kernel(const float* __restrict__ q, int ldq, const float* __rest
             for (int i = 0; i < n_qt; ++i) { blk_maxpos = max(blk_maxpos, sm.t_maxpos[i]); blk_empty |= sm.t_empty[i]; }
             blk_maxpos = __builtin_amdgcn_readfirstlane(blk_maxpos);
             blk_empty = __builtin_amdgcn_readfirstlane(blk_empty);
+            // Key tiles from the stage's queue, early keys (seen by the most queries) first; the last stage visits every key tile.  A wave
+            // keeps the tile it swept last in its registers across the stage boundary (RES_KEEP): it stamps the tile as its own for the
+            // next stage (the queue's other takers skip it), sweeps it first there - no K / V prologue, no carried sums - and lets it go
+            // when it takes another tile, or for good at the end of the last stage.
+            auto needed = [&](int kt_) { return final_stage || blk_empty != 0 || blk_maxpos >= kt_ * 32; };
+            bool first = true;
 #pragma unroll 1
-            for (int kt = upp * res_grab_ctr(&sm.ctr, lane) + kt0; kt < n_all; kt = upp * res_grab_ctr(&sm.ctr, lane) + kt0) {
-                if (!(final_stage || blk_empty != 0 || blk_maxpos >= kt * 32)) break;      // (nor does any later key tile)
-                const bool fresh = __builtin_amdgcn_readfirstlane(sm.started[kt]) == 0;
+            while (true) {
+                int kt = -1;
+                if (RES_KEEP && first && held >= 0 && needed(held)) {
+                    kt = held;
+                } else {
+                    int c = upp * res_grab_ctr(&sm.ctr, lane) + kt0;
+                    while (RES_KEEP && c < n_all && __builtin_amdgcn_readfirstlane(sm.keeper_stage[c]) == qb) c = upp * res_grab_ctr(&sm.ctr, lane) + kt0;
+                    if (c < n_all && needed(c)) kt = c;             // (else: nor does any later key tile)
+                }
+                first = false;
+                const bool release = held >= 0 && kt != held && (kt >= 0 || final_stage);
+                const bool acquire = kt >= 0 && kt != held;
+                if (!release && kt < 0) break;
+                const bool fresh = acquire && __builtin_amdgcn_readfirstlane(sm.started[kt]) == 0;
                 RES_MARK(5);
-                res2_dkv_keytile<DROP, SPAN>(sm, k, ldk, v, ldv, kl, S, scale, rng, dk, lddk, dv, lddv, b, kvh, kt,
-                                       n_qt, fresh, final_stage, amax_out != nullptr, sc RES_STAMP_PASS);
-                if (lane == 0) sm.started[kt] = 1;
+                res2_dkv_step<DROP, SPAN>(sm, k, ldk, v, ldv, kl, S, scale, rng, dk, lddk, dv, lddv, b, kvh, held, release, final_stage, kt,
+                                          acquire, fresh, n_qt, amax_out != nullptr, sc, T RES_STAMP_PASS);
+                if (release) held = -1;
+                if (kt < 0) break;
+                if (acquire && lane == 0) sm.started[kt] = 1;
+                held = kt;
+                if (!RES_KEEP) {                                    // (the round-5 order: every tile leaves right behind its sweep)
+                    res2_dkv_step<DROP, SPAN>(sm, k, ldk, v, ldv, kl, S, scale, rng, dk, lddk, dv, lddv, b, kvh, held, true, final_stage, -1,
+                                              false, false, n_qt, amax_out != nullptr, sc, T RES_STAMP_PASS);
+                    held = -1;
+                }
             }
+            if (RES_KEEP && held >= 0 && lane == 0) sm.keeper_stage[held] = qb + 1;      // (not the last stage: it let every tile go)
             asm volatile("" :: "v"(tw[0]), "v"(tw[1]), "v"(tw[2]), "v"(tw[3]));
         }
     }
