@@ -750,7 +750,8 @@ int gamer_attn_decode(const float* q, int ldq, const float* kp, int ldkp, const 
                       void* stream);
 /* (ABI 9) The same with its two products in the three-piece fp16 form of the train step (gamer_attn_fwd_split with
  * gamer_attn_split_amax): amax_k / amax_v = gamer_absmax_f32 slots holding max |kp|, max |vp| (the prompt caches do not change during a
- * generation: measured once per session); the queries are scaled per workgroup inside the kernel, the generated positions stay in fp32. */
+ * generation: measured once per session); the queries are scaled per workgroup inside the kernel, the generated positions stay in fp32.
+ * gamer_amax_sink: out0 = max |o| (the operand of the o_proj GEMM that follows). */
 int gamer_attn_decode_split(const float* q, int ldq, const float* kp, int ldkp, const float* vp, int ldvp,
                             const int32_t* key_ok, const float* kg, const float* vg, int ldg, int tmax, int t, int gen_ok,
                             const int32_t* uniform, int B, int nb, int L0, int nq, int nkv, float scale, float* o,
