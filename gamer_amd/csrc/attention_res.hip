@@ -1684,7 +1684,8 @@ attn_bwd_dkv_r2_kernel(const float* __restrict__ q, int ldq, const float* __rest
                     kt = held;
                 } else {
                     int c = upp * res_grab_ctr(&sm.ctr, lane) + kt0;
-                    while (RES_KEEP && c < n_all && __builtin_amdgcn_readfirstlane(sm.keeper_stage[c]) == qb) c = upp * res_grab_ctr(&sm.ctr, lane) + kt0;
+                    // (>= qb: a keeper that ends the stage still holding its tile re-stamps it qb + 1 while others may still be reading the stamp)
+                    while (RES_KEEP && c < n_all && __builtin_amdgcn_readfirstlane(sm.keeper_stage[c]) >= qb) c = upp * res_grab_ctr(&sm.ctr, lane) + kt0;
                     if (c < n_all && needed(c)) kt = c;             // (else: nor does any later key tile)
                 }
                 first = false;
