@@ -150,6 +150,7 @@ class _DecodeStatic:
     def __init__(self):
         self.kp: Dict[Tuple[int, str], torch.Tensor] = {}
         self.vp: Dict[Tuple[int, str], torch.Tensor] = {}
+        self.qkvp: Dict[Tuple[int, str], torch.Tensor] = {}     # fp32 engines: the layers' own q|k|v buffers (vp = their v columns)
         self.gen = None
         self.buf = None
         self.small: Dict[str, torch.Tensor] = {}
@@ -208,8 +209,34 @@ class DecodeSession:
         f32 = dict(dtype=torch.float32, device=dev)
         self.kp, self.vp = st.kp, st.vp
 
+        # fp32 engines: the prompt pass writes every layer's q|k|v projection and rotated keys straight into the session's buffers
+        # (Engine.forward(kv_dest=...): the V cache is the v columns of the layer's own q|k|v buffer, row stride QKV) - no copy of 2 x
+        # 98 MB per layer and kind - and the maxima the three-piece decode attention needs are the ones the prompt pass's own
+        # attention used (the producers left them in the engine's maxima cache): no gamer_absmax_f32 pass over the caches either
+        import os
+        QKV = self.NQ + 2 * self.NKV
+        T0 = ids0.shape[0] * ids0.shape[1]
+        direct = engine.dtype == "f32"
+        want_amax = (engine._amax is not None and engine.matmul == "split3" and os.environ.get("GAMER_DECODE_ATTN_SPLIT", "1") != "0")
+        prompt_amax = {}
+
+        def dest(layer, kind):
+            kk = (layer, kind)
+            if kk not in st.qkvp or st.qkvp[kk].shape[0] != T0:
+                st.qkvp[kk] = torch.empty(T0, QKV, **f32)
+                st.kp[kk] = torch.empty(T0, self.NKV, **f32)
+                st.vp[kk] = st.qkvp[kk][:, self.NQ + self.NKV:]
+            return st.qkvp[kk], st.kp[kk]
+
         def sink(layer, kind, k, v):
             kk = (layer, kind)
+            if direct:
+                if want_amax:       # (called in front of the layer's attention: the slots the producers of k / v left for it, if they did)
+                    sk = engine._amax.peek(k, (1, 0, T0, self.NKV, k.stride(0)))
+                    sv = engine._amax.peek(v, (1, 0, T0, self.NKV, v.stride(0)))
+                    if sk and sv:
+                        prompt_amax[kk] = (sk, sv)
+                return
             if kk not in st.kp:
                 st.kp[kk] = k.clone()
                 st.vp[kk] = v.contiguous().clone()       # v is a column slice of the qkv buffer
@@ -224,7 +251,7 @@ class DecodeSession:
             ext0 = extended_session_ids.to(dev, torch.int64)
             skw = dict(session_ids=sid0, extended_session_ids=ext0)
         engine.forward(ids0, am0, act0, train=False, act_zero_col=L0 - 1, uniform_len=L0, kv_sink=sink,
-                       last_row_logits=True, **skw)
+                       kv_dest=dest if direct else None, last_row_logits=True, **skw)
         if self.session:
             engine.check_inputs()
         # last-row logits of every sample: the head ran on B rows, not on the whole prompt
@@ -277,14 +304,16 @@ class DecodeSession:
         self.t = 0
         # matmul = "split3": the decode attention in the three-piece fp16 form too - the maxima of the prompt K / V caches, which do not
         # change during the generation, measured once (GAMER_DECODE_ATTN_SPLIT=0: the fp32-MFMA kernel)
-        import os
         self.kv_amax = {}
-        if engine._amax is not None and engine.matmul == "split3" and os.environ.get("GAMER_DECODE_ATTN_SPLIT", "1") != "0":
-            with ops.f32_matmul("split3"), engine._amax:
-                for kk in self.kp:
-                    kpt, vpt = self.kp[kk], self.vp[kk]
-                    self.kv_amax[kk] = (ops.absmax_slot(kpt, 1, 0, kpt.shape[0], kpt.shape[1], kpt.stride(0)),
-                                        ops.absmax_slot(vpt, 1, 0, vpt.shape[0], vpt.shape[1], vpt.stride(0)))
+        if want_amax:
+            if len(prompt_amax) == len(self.kp):
+                self.kv_amax = prompt_amax
+            else:
+                with ops.f32_matmul("split3"), engine._amax:
+                    for kk in self.kp:
+                        kpt, vpt = self.kp[kk], self.vp[kk]
+                        self.kv_amax[kk] = (ops.absmax_slot(kpt, 1, 0, kpt.shape[0], kpt.shape[1], kpt.stride(0)),
+                                            ops.absmax_slot(vpt, 1, 0, vpt.shape[0], vpt.shape[1], vpt.stride(0)))
         # the maxima cache as this session found it after the prompt pass: what a captured step was recorded against
         am_ = engine._amax
         self._sig = None if am_ is None else (len(am_._wkeys), am_.used, 0 if am_.planes is None else am_.planes.data_ptr())

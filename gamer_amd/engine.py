@@ -585,7 +585,7 @@ class Engine:
     @ops.scoped_amax(lambda self, *a: self._amax)
     def forward(self, input_ids, attention_mask=None, actions=None, labels=None, num_items_in_batch=None,
                 train: bool = False, dropout: Optional[bool] = None, act_zero_col: Optional[int] = None,
-                uniform_len: int = 0, kv_sink=None, session_ids=None, extended_session_ids=None,
+                uniform_len: int = 0, kv_sink=None, kv_dest=None, session_ids=None, extended_session_ids=None,
                 last_row_logits: bool = False, hidden_sink: Optional[list] = None):
         """Returns (loss or None, logits view [B,S,V]).  With labels the logits are divided by the
         temperature in place, as the reference does (model.py:913).  The view aliases a workspace
@@ -598,7 +598,8 @@ class Engine:
         Evaluation only (gamer_amd/decode.py re-runs the whole sequence every generation step): ``act_zero_col``
         is the column of the prompt's final behaviour token, which the reference's router gives action index 0
         when the prompt has 5n+1 tokens (router.py:160-163) and which stays that way in its K/V cache;
-        ``uniform_len`` is the prompt length (see gamer_attn_fwd in include/gamer_hip.h); ``kv_sink(layer, kind, k, v)``
+        ``uniform_len`` is the prompt length (see gamer_attn_fwd in include/gamer_hip.h); ``kv_dest(layer, kind)`` -> (q|k|v buffer [T, QKV],
+        rotated-key buffer [T, NKV]) makes the layer write them there; ``kv_sink(layer, kind, k, v)``
         receives the keys (after k-norm + RoPE) and values of every attention ("self" / "cross") - the K/V cache of
         gamer_amd.decode.DecodeSession; ``last_row_logits``: the prompt pass of a generation needs the logits of the
         last position only (HF's ``logits_to_keep``): final norm and head run on B rows instead of B*S and the
@@ -614,6 +615,8 @@ class Engine:
                              "(the router assumes item-aligned sequences, router.py:78-81)")
         if train and (act_zero_col is not None or uniform_len not in (0, S)):
             raise ValueError("act_zero_col / uniform_len are evaluation-only options")
+        if kv_dest is not None and train:
+            raise ValueError("kv_dest is an evaluation-only option (the backward reads the workspace's q|k|v and keys)")
         if last_row_logits and (train or labels is not None):
             raise ValueError("last_row_logits is an evaluation-only option")
         if hidden_sink is not None and last_row_logits:
@@ -753,18 +756,21 @@ class Engine:
                 hidden_sink.append(xs[0].view(B, S, H).clone())
             # ---- self attention (model.py:204-217) ----
             ops.rmsnorm_fwd(xs[0], W.ln1, eps, A["h1"])
+            # (kv_dest: the q|k|v projection and the rotated keys of this layer are written where the caller keeps them - a
+            # generation's prompt caches - instead of the workspace's buffers and a copy)
+            qkv_s, k_s = kv_dest(l, "self") if kv_dest is not None else (A["qkv"], A["k"])
             if fuse_qkv:
                 # per-head RMSNorm + RoPE of q / k in the projection's epilogue (model.py:88-101 in one kernel)
-                ops.gemm(A["h1"], H, 1, Wm.self_attn["qkv"], H, 1, A["qkv"], QKV, T, QKV, H,
+                ops.gemm(A["h1"], H, 1, Wm.self_attn["qkv"], H, 1, qkv_s, QKV, T, QKV, H,
                          qknorm=dict(wq=W.self_attn["qn"], wk=W.self_attn["kn"], eps=eps, cos=cos, sin=sin, q_rot=A["q"],
-                                     k_rot=A["k"], pos_ids=pos_ids, S=S, nq=nq, nkv=nkv))
+                                     k_rot=k_s, pos_ids=pos_ids, S=S, nq=nq, nkv=nkv))
             else:
-                ops.linear_fwd(A["h1"], H, Wm.self_attn["qkv"], H, A["qkv"], QKV, T, QKV, H, **v_amax(A["qkv"]))
-                ops.qknorm_rope_fwd(A["qkv"], S, nq, nkv, W.self_attn["qn"], W.self_attn["kn"], eps, cos, sin, A["q"], A["k"],
+                ops.linear_fwd(A["h1"], H, Wm.self_attn["qkv"], H, qkv_s, QKV, T, QKV, H, **v_amax(qkv_s))
+                ops.qknorm_rope_fwd(qkv_s, S, nq, nkv, W.self_attn["qn"], W.self_attn["kn"], eps, cos, sin, A["q"], k_s,
                                     pos_ids=pos_ids)
             if kv_sink is not None:
-                kv_sink(l, "self", A["k"], A["qkv"][:, NQ + NKV:])
-            attention(A["q"], A["k"], A["qkv"][:, NQ + NKV:], r["kl_self"], None, r["empty_self"], r["tile_empty_self"],
+                kv_sink(l, "self", k_s, qkv_s[:, NQ + NKV:])
+            attention(A["q"], k_s, qkv_s[:, NQ + NKV:], r["kl_self"], None, r["empty_self"], r["tile_empty_self"],
                       self._seed(l, 0), A["ao"], A["lse"], None, span_self)
             # o_proj with the residual add + dropout fused into the GEMM epilogue (model.py:149,217)
             ops.gemm(A["ao"], NQ, 1, Wm.self_attn["o"], NQ, 1, xs[1], H, T, H, NQ, resid=xs[0], p_drop=p_res,
@@ -774,19 +780,20 @@ class Engine:
             if W.cross:
                 C, Cm = W.cross_attn, Wm.cross_attn
                 ops.rmsnorm_fwd(xs[1], W.ln2, eps, A["h2"])
+                qkv_x, k_x = kv_dest(l, "cross") if kv_dest is not None else (A["qkv_c"], A["k_c"])
                 if fuse_qkv:
-                    ops.gemm(A["h2"], H, 1, Cm["qkv"], H, 1, A["qkv_c"], QKV, T, QKV, H,
-                             qknorm=dict(wq=C["qn"], wk=C["kn"], eps=eps, cos=cos, sin=sin, q_rot=A["q_c"], k_rot=A["k_c"],
+                    ops.gemm(A["h2"], H, 1, Cm["qkv"], H, 1, qkv_x, QKV, T, QKV, H,
+                             qknorm=dict(wq=C["qn"], wk=C["kn"], eps=eps, cos=cos, sin=sin, q_rot=A["q_c"], k_rot=k_x,
                                          bias_q=C["bq"], bias_k=C["bk"], bias_v=C["bv"], act_idx=r["act_idx"],
                                          pos_ids=pos_ids, S=S, nq=nq, nkv=nkv))
                 else:
-                    ops.linear_fwd(A["h2"], H, Cm["qkv"], H, A["qkv_c"], QKV, T, QKV, H)
-                    ops.qknorm_rope_fwd(A["qkv_c"], S, nq, nkv, C["qn"], C["kn"], eps, cos, sin, A["q_c"], A["k_c"],
+                    ops.linear_fwd(A["h2"], H, Cm["qkv"], H, qkv_x, QKV, T, QKV, H)
+                    ops.qknorm_rope_fwd(qkv_x, S, nq, nkv, C["qn"], C["kn"], eps, cos, sin, A["q_c"], k_x,
                                         bias_q=C["bq"], bias_k=C["bk"], bias_v=C["bv"], act_idx=r["act_idx"],
                                         pos_ids=pos_ids)
                 if kv_sink is not None:
-                    kv_sink(l, "cross", A["k_c"], A["qkv_c"][:, NQ + NKV:])
-                attention(A["q_c"], A["k_c"], A["qkv_c"][:, NQ + NKV:], r["kl_cross"], r["ql_cross"], r["empty_cross"],
+                    kv_sink(l, "cross", k_x, qkv_x[:, NQ + NKV:])
+                attention(A["q_c"], k_x, qkv_x[:, NQ + NKV:], r["kl_cross"], r["ql_cross"], r["empty_cross"],
                           r["tile_empty_cross"], self._seed(l, 2), A["ao_c"], A["lse_c"], ws.cross_order, span_cross)
                 ops.linear_fwd(A["ao_c"], NQ, Cm["o"], NQ, A["op_c"], H, T, H, NQ)
                 ops.linear_fwd(A["h2"], H, Cm["gate"], H, A["gate_c"], H, T, H, H)

@@ -402,6 +402,12 @@ class amax_reuse:
         ptr_ = self.pending[key] = self._new_slot(x.device)
         return ptr_
 
+    def peek(self, x, geom):
+        """The slot `slot(x, geom)` would return without measuring - its producer's, or a cached one - or None; nothing is consumed
+        (a generation's prompt pass notes the maxima of the keys / values it caches before the layer's attention takes them)."""
+        key = self._key(x.data_ptr(), geom)
+        return self.pending.get(key) or self.slots.get(key)
+
     def slot(self, x, geom):
         p = x.data_ptr()
         key = self._key(p, geom)
