@@ -539,7 +539,7 @@ static int attn_decode_impl(const float* q, int ldq, const float* kp, int ldkp, 
                             int gen_ok, const int32_t* uniform, int B, int nb, int L0, int nq, int nkv,
                             float scale, float* o, const uint32_t* amax_k, const uint32_t* amax_v, void* stream) {
     GAMER_CHECK_ARG(q && kp && vp && key_ok && kg && vg && o, "gamer_attn_decode: null pointer");
-    GAMER_CHECK_ARG(B > 0 && nb > 0 && L0 > 0 && nq > 0 && nkv > 0 && nq % nkv == 0 && t >= 1 && t <= tmax,
+    GAMER_CHECK_ARG(B > 0 && nb > 0 && L0 > 0 && nq > 0 && nkv > 0 && nq % nkv == 0 && t >= 0 && t <= tmax,
                     "gamer_attn_decode: bad shape B=%d nb=%d L0=%d nq=%d nkv=%d t=%d tmax=%d", B, nb, L0, nq, nkv, t, tmax);
     const int G = nq / nkv;
     GAMER_CHECK_ARG((G == 1 || G == 2) && nb * G <= 4 * DEC_MAXQ, "gamer_attn_decode: num_beams * (nq/nkv) = %d > %d",

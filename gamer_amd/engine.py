@@ -793,13 +793,34 @@ class Engine:
                                         pos_ids=pos_ids)
                 if kv_sink is not None:
                     kv_sink(l, "cross", k_x, qkv_x[:, NQ + NKV:])
-                attention(A["q_c"], k_x, qkv_x[:, NQ + NKV:], r["kl_cross"], r["ql_cross"], r["empty_cross"],
-                          r["tile_empty_cross"], self._seed(l, 2), A["ao_c"], A["lse_c"], ws.cross_order, span_cross)
-                ops.linear_fwd(A["ao_c"], NQ, Cm["o"], NQ, A["op_c"], H, T, H, NQ)
-                ops.linear_fwd(A["h2"], H, Cm["gate"], H, A["gate_c"], H, T, H, H)
-                # output gate + residual add + dropout in one pass (model.py:147, 235)
-                ops.silu_gate_fwd(A["op_c"], A["gate_c"], xs[2], resid=xs[1], p=p_res, seed=self._seed(l, 3))
-                xcur = xs[2]
+                if (last_row_logits and l == cfg.num_hidden_layers - 1 and span_cross is None and not bf16 and
+                        os.environ.get("GAMER_PREFILL_LAST_ROW", "1") != "0"):
+                    # prompt pass of a generation, last layer: its keys / values are cached (above), and of its cross block's OUTPUT only
+                    # the last position of every sample is still needed - one query row per sample against the prompt keys
+                    # (gamer_attn_decode with no generated position), the output projection, gate and residual on B rows
+                    rows = torch.arange(B, device=self.device) * S + (S - 1)
+                    f32 = dict(dtype=torch.float32, device=self.device)
+                    q_l = A["q_c"].index_select(0, rows).contiguous()
+                    key_ok = (r["kl_cross"].view(B, S) < r["ql_cross"].view(B, S)[:, S - 1:S]).to(torch.int32).contiguous()
+                    uni = (r["empty_cross"].view(B, S)[:, S - 1] != 0).to(torch.int32).contiguous()
+                    kg0 = torch.zeros(B, 1, NKV, **f32)
+                    ao_l = torch.empty(B, NQ, **f32)
+                    ops.attn_decode(q_l, k_x, qkv_x[:, NQ + NKV:], key_ok, kg0, kg0, 0, False, uni, B, 1, S, nq, nkv, scale, ao_l)
+                    op_l, gate_l, x_cross_last = torch.empty(B, H, **f32), torch.empty(B, H, **f32), torch.empty(B, H, **f32)
+                    ops.linear_fwd(ao_l, NQ, Cm["o"], NQ, op_l, H, B, H, NQ)
+                    ops.linear_fwd(A["h2"].index_select(0, rows).contiguous(), H, Cm["gate"], H, gate_l, H, B, H, H)
+                    ops.silu_gate_fwd(op_l, gate_l, x_cross_last, resid=xs[1].index_select(0, rows).contiguous())
+                    xcur = None                  # (only the last rows of this layer's cross output exist)
+                else:
+                    x_cross_last = None
+                    attention(A["q_c"], k_x, qkv_x[:, NQ + NKV:], r["kl_cross"], r["ql_cross"], r["empty_cross"],
+                              r["tile_empty_cross"], self._seed(l, 2), A["ao_c"], A["lse_c"], ws.cross_order, span_cross)
+                if x_cross_last is None:
+                    ops.linear_fwd(A["ao_c"], NQ, Cm["o"], NQ, A["op_c"], H, T, H, NQ)
+                    ops.linear_fwd(A["h2"], H, Cm["gate"], H, A["gate_c"], H, T, H, H)
+                    # output gate + residual add + dropout in one pass (model.py:147, 235)
+                    ops.silu_gate_fwd(A["op_c"], A["gate_c"], xs[2], resid=xs[1], p=p_res, seed=self._seed(l, 3))
+                    xcur = xs[2]
             # ---- position-routed SwiGLU experts (model.py:238-241, FFN.py:53-72) ----
             din = W.din
             if last_row_logits and l == cfg.num_hidden_layers - 1:
@@ -808,7 +829,7 @@ class Engine:
                 # so the expert is the position's: router.py:83-104)
                 rows = torch.arange(B, device=self.device) * S + (S - 1)
                 e = (S - 1) % cfg.num_positions + 1
-                xl = xcur.index_select(0, rows).contiguous()
+                xl = x_cross_last if (W.cross and x_cross_last is not None) else xcur.index_select(0, rows).contiguous()
                 f32 = dict(dtype=torch.float32, device=self.device)
                 hin = torch.empty(B, din, **f32)
                 ops.rmsnorm_fwd(xl, W.ln3, eps, hin, din)

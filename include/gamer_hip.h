@@ -743,7 +743,9 @@ int gamer_trie_advance(const int32_t* node, const int64_t* token, const int32_t*
  *   kg/vg  generated keys / values, row n*tmax + g (g < t, the new token itself is g = t-1), leading dim ldg
  *   gen_ok 1 = generated keys are attended (self attention), 0 = masked (cross attention)
  *   uniform int32 [B] or NULL: 1 = the new rows of sample b have no allowed key -> mean of V over all L0+t keys
- *   o  [N, nq*64]                                                                                       */
+ *   o  [N, nq*64]
+ * t = 0 (no generated position: kg / vg are not read): the rows of q are prompt rows attending the prompt keys key_ok allows - the
+ * last prompt row of the last layer's cross attention in a generation's prompt pass (Engine.forward(last_row_logits=True)).       */
 int gamer_attn_decode(const float* q, int ldq, const float* kp, int ldkp, const float* vp, int ldvp,
                       const int32_t* key_ok, const float* kg, const float* vg, int ldg, int tmax, int t, int gen_ok,
                       const int32_t* uniform, int B, int nb, int L0, int nq, int nkv, float scale, float* o,
