@@ -781,6 +781,11 @@ class Engine:
                 C, Cm = W.cross_attn, Wm.cross_attn
                 ops.rmsnorm_fwd(xs[1], W.ln2, eps, A["h2"])
                 qkv_x, k_x = kv_dest(l, "cross") if kv_dest is not None else (A["qkv_c"], A["k_c"])
+                # (evaluation: no workspace tensor is declared unchanging - the layers share the buffers - but h2 is read by two GEMMs
+                # of this block, the q|k|v projection and the gate: its maximum is kept between them instead of measured twice)
+                h2_hold = self._amax.hold(A["h2"]) if (self._amax is not None and not train) else None
+                if h2_hold is not None:
+                    h2_hold.__enter__()
                 if fuse_qkv:
                     ops.gemm(A["h2"], H, 1, Cm["qkv"], H, 1, qkv_x, QKV, T, QKV, H,
                              qknorm=dict(wq=C["qn"], wk=C["kn"], eps=eps, cos=cos, sin=sin, q_rot=A["q_c"], k_rot=k_x,
@@ -818,6 +823,9 @@ class Engine:
                 if x_cross_last is None:
                     ops.linear_fwd(A["ao_c"], NQ, Cm["o"], NQ, A["op_c"], H, T, H, NQ)
                     ops.linear_fwd(A["h2"], H, Cm["gate"], H, A["gate_c"], H, T, H, H)
+                if h2_hold is not None:
+                    h2_hold.__exit__(None, None, None)
+                if x_cross_last is None:
                     # output gate + residual add + dropout in one pass (model.py:147, 235)
                     ops.silu_gate_fwd(A["op_c"], A["gate_c"], xs[2], resid=xs[1], p=p_res, seed=self._seed(l, 3))
                     xcur = xs[2]
