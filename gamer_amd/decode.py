@@ -216,7 +216,7 @@ class DecodeSession:
         import os
         QKV = self.NQ + 2 * self.NKV
         T0 = ids0.shape[0] * ids0.shape[1]
-        direct = engine.dtype == "f32"
+        direct = engine.dtype == "f32" and os.environ.get("GAMER_DECODE_DIRECT_KV", "1") != "0"      # (0: the copying path, A/B and tests)
         want_amax = (engine._amax is not None and engine.matmul == "split3" and os.environ.get("GAMER_DECODE_ATTN_SPLIT", "1") != "0")
         prompt_amax = {}
 

@@ -277,11 +277,12 @@ def test_evaluate_behavior_matches_reference_metrics():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("split", [False, True])
-@pytest.mark.parametrize("nq,nkv,nb,L0,t", [(2, 1, 6, 31, 1), (6, 3, 20, 130, 3), (2, 2, 5, 64, 4)])
+@pytest.mark.parametrize("nq,nkv,nb,L0,t", [(2, 1, 6, 31, 1), (6, 3, 20, 130, 3), (2, 2, 5, 64, 4), (6, 3, 1, 130, 0), (2, 1, 1, 40, 0)])
 def test_attn_decode_kernel_against_dense(nq, nkv, nb, L0, t, split):
     """gamer_attn_decode (fp32 MFMA) and gamer_attn_decode_split (three fp16 piece products, the default engine's) vs fp64 softmax
     attention: self (generated keys attended) and cross (generated keys masked, samples without an allowed key uniform over all
-    L0 + t keys); the prompt values span four orders of magnitude between rows in the split case (one scale per tensor)."""
+    L0 + t keys); the prompt values span four orders of magnitude between rows in the split case (one scale per tensor).
+    t = 0: no generated position - a prompt row against the prompt keys (the last layer's cross block in a generation's prompt pass)."""
     from gamer_amd import ops
     dev, B, tmax = "cuda", 3, 4
     N, G = B * nb, nq // nkv
@@ -324,6 +325,42 @@ def test_attn_decode_kernel_against_dense(nq, nkv, nb, L0, t, split):
                 ref[n, hd] = torch.softmax(s, 0) @ vals
         err = float((o.cpu().double().view(N, nq, 64) - ref).abs().max() / ref.abs().max())
         assert err < 2e-6, (kind, err)
+
+
+@pytest.mark.gpu
+def test_prompt_pass_shortcuts_agree_with_the_plain_pass(monkeypatch):
+    """The prompt pass of a generation as built (K / V caches written in place by the layers, their maxima taken from the pass's own
+    attention, the last layer's cross block on the last positions only) against the plain one (copies, measured maxima, the whole
+    block): same caches bit for bit, prompt logits and the first cached step's logits to fp32 rounding."""
+    from gamer_amd.config import synthetic_config
+    from gamer_amd.decode import DecodeSession
+    from gamer_amd.engine import Engine
+    cfg = synthetic_config()
+    eng = Engine(cfg, temperature=0.7)
+    eng.init_weights(seed=3)
+    cat = synthetic.make_catalogue(300, 256, seed=3)
+    batch = synthetic.make_eval_batch(5, 30, cat, 2, 256, 3, min_his=12, seed=9, behavior_probs=[0.6, 0.3, 0.1])
+    nb = 4
+    tok = torch.randint(14, 14 + 256, (5 * nb,), device="cuda")
+    out = {}
+    for form in ("built", "plain"):
+        if form == "plain":
+            monkeypatch.setenv("GAMER_DECODE_DIRECT_KV", "0")
+            monkeypatch.setenv("GAMER_PREFILL_LAST_ROW", "0")
+        eng._decode_static = {}                      # (a fresh set of session buffers for either form)
+        s = DecodeSession(eng, batch["input_ids"], batch["attention_mask"], batch["actions"], nb, 3)
+        pre = s.prefill_logits.clone()
+        caches = {kk: (s.kp[kk].clone(), s.vp[kk].clone()) for kk in s.kp}
+        step = s.step(tok).clone()
+        torch.cuda.synchronize()
+        out[form] = (pre, caches, step)
+    V = cfg.vocab_size
+    for kk in out["built"][1]:
+        assert torch.equal(out["built"][1][kk][0], out["plain"][1][kk][0]), kk
+        assert torch.equal(out["built"][1][kk][1], out["plain"][1][kk][1]), kk
+    for i in (0, 2):
+        a, b = out["built"][i][:, :V].double(), out["plain"][i][:, :V].double()
+        assert float((a - b).abs().max()) < 2e-5 * float(b.abs().max()), i
 
 
 # ---- BASELINE configs[4] at the shipped architecture ------------------------------------------------------------------
