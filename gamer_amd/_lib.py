@@ -162,6 +162,7 @@ _SIGNATURES = {
     "gamer_split2h_transpose_multi": [P, P, I, P, P],
     "gamer_trie_logprobs": [P, L, P, P, P, P, P, I, I, P, P],
     "gamer_trie_advance": [P, P, P, P, P, I, P, P],
+    "gamer_kv_append": [P, I, P, I, P, P, I, I, I, I, I, P],
     "gamer_attn_decode": [P, I, P, I, P, I, P, P, P, I, I, I, I, P, I, I, I, I, I, F, P, P],
     "gamer_attn_decode_split": [P, I, P, I, P, I, P, P, P, I, I, I, I, P, I, I, I, I, I, F, P, P, P, P],
 }

@@ -506,9 +506,37 @@ attn_decode_h2_kernel(const float* __restrict__ q, int ldq, const float* __restr
     }
 }
 
+// the new token's rotated keys and (biased) values join the generated part of the cache: kg / vg [N][tmax][C] <- k / v rows, position g
+__global__ void __launch_bounds__(256)
+kv_append_kernel(const float4* __restrict__ k, int ldk4, const float4* __restrict__ v, int ldv4, float4* __restrict__ kg,
+                 float4* __restrict__ vg, int ldg4, int tmax, int g, int N, int C4) {
+    const int64_t total = (int64_t)N * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int n = (int)(i / C4), c = (int)(i % C4);
+        const int64_t dst = ((int64_t)n * tmax + g) * ldg4 + c;
+        kg[dst] = k[(int64_t)n * ldk4 + c];
+        vg[dst] = v[(int64_t)n * ldv4 + c];
+    }
+}
+
 }  // namespace gamer
 
 using namespace gamer;
+
+extern "C" int gamer_kv_append(const float* k, int ldk, const float* v, int ldv, float* kg, float* vg, int ldg, int tmax, int g,
+                               int N, int C, void* stream) {
+    GAMER_CHECK_ARG(k && v && kg && vg, "gamer_kv_append: null pointer");
+    GAMER_CHECK_ARG(N > 0 && C > 0 && C % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldg % 4 == 0 && tmax > 0 && g >= 0 && g < tmax,
+                    "gamer_kv_append: bad shape N=%d C=%d ldk=%d ldv=%d ldg=%d tmax=%d g=%d (multiples of 4)", N, C, ldk, ldv, ldg, tmax, g);
+    GAMER_CHECK_ARG(aligned16(k) && aligned16(v) && aligned16(kg) && aligned16(vg), "gamer_kv_append: pointers must be 16-byte aligned");
+    const int64_t total = (int64_t)N * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(kv_append_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(k), ldk / 4,
+                       reinterpret_cast<const float4*>(v), ldv / 4, reinterpret_cast<float4*>(kg), reinterpret_cast<float4*>(vg), ldg / 4,
+                       tmax, g, N, C / 4);
+    GAMER_CHECK_LAUNCH("gamer_kv_append");
+    return 0;
+}
 
 extern "C" int gamer_trie_logprobs(const float* logits, int64_t ld, const int32_t* row_index, const float* beam_score,
                                    const int32_t* node, const int32_t* child_start, const int32_t* child_tok, int N,

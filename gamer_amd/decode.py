@@ -395,20 +395,27 @@ class DecodeSession:
             if key not in self.st.small:           # rows [0, N) belong to expert e, every other group is empty
                 self.st.small[key] = torch.tensor([0] * (e + 1) + [N] * (E - e), dtype=torch.int32, device=tokens.device)
             grp = dict(groups=E, group_offsets=self.st.small[key])
+        import os
+        fused_ok = eng.dtype == "f32" and os.environ.get("GAMER_DECODE_FUSE_QK", "1") != "0"
         x, x1, x2 = b["x"]
         ops.embedding_fwd(tokens, eng.params["model.embed_tokens.weight"], x)
 
+        # the per-head RMSNorm + RoPE as the q|k|v projection's epilogue: at these row counts the projection runs on the 128 x 128 kernel
+        # either way (the activation-stationary kernel starts at 16 k rows), so the epilogue only removes a launch and a pass per
+        # attention and token (in the train step, where it would displace the faster kernel, it measured 9 ms slower)
+        fuse_qk = fused_ok and ops.qkv_fused_ok(b["h"], N, QKV)
+
         def attend(kind, layer, Wa, hin, xin, xout, act_idx):
-            ops.linear_fwd(hin, H, Wa["qkv"], H, b["qkv"], QKV, N, QKV, H)
-            if kind == "cross":
-                ops.qknorm_rope_fwd(b["qkv"], 1, nq, nkv, Wa["qn"], Wa["kn"], eps, cos, sin, b["q"], b["k"],
-                                    bias_q=Wa["bq"], bias_k=Wa["bk"], bias_v=Wa["bv"], act_idx=act_idx, pos_ids=pos_ids)
+            bias = dict(bias_q=Wa["bq"], bias_k=Wa["bk"], bias_v=Wa["bv"], act_idx=act_idx) if kind == "cross" else {}
+            if fuse_qk:
+                ops.gemm(hin, H, 1, Wa["qkv"], H, 1, b["qkv"], QKV, N, QKV, H,
+                         qknorm=dict(wq=Wa["qn"], wk=Wa["kn"], eps=eps, cos=cos, sin=sin, q_rot=b["q"], k_rot=b["k"], pos_ids=pos_ids,
+                                     S=1, nq=nq, nkv=nkv, **bias))
             else:
-                ops.qknorm_rope_fwd(b["qkv"], 1, nq, nkv, Wa["qn"], Wa["kn"], eps, cos, sin, b["q"], b["k"],
-                                    pos_ids=pos_ids)
+                ops.linear_fwd(hin, H, Wa["qkv"], H, b["qkv"], QKV, N, QKV, H)
+                ops.qknorm_rope_fwd(b["qkv"], 1, nq, nkv, Wa["qn"], Wa["kn"], eps, cos, sin, b["q"], b["k"], pos_ids=pos_ids, **bias)
             kg, vg = self.gen[(layer, kind)]
-            kg[:, t - 1] = b["k"]
-            vg[:, t - 1] = b["qkv"][:, NQ + NKV:]
+            ops.kv_append(b["k"], b["qkv"][:, NQ + NKV:], kg, vg, t - 1)
             ops.attn_decode(b["q"], self.kp[(layer, kind)], self.vp[(layer, kind)],
                             self.ok_self if kind == "self" else self.ok_cross, kg, vg, t, kind == "self",
                             None if kind == "self" else self.uniform_cross, B, nb, L0, nq, nkv, scale, b["ao"],

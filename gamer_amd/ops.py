@@ -1133,6 +1133,12 @@ def trie_advance(node, token, child_start, child_tok, child_node, out):
          node.numel(), ptr(out), stream_ptr())
 
 
+def kv_append(k, v, kg, vg, g):
+    """kg / vg [N, tmax, C] <- k [N, C], v [N, C] (row-strided views) at generated position g."""
+    N, tmax, C = kg.shape
+    call("gamer_kv_append", ptr(k), k.stride(0), ptr(v), v.stride(0), ptr(kg), ptr(vg), kg.stride(1), tmax, g, N, C, stream_ptr())
+
+
 def attn_decode(q, kp, vp, key_ok, kg, vg, t, gen_ok, uniform, B, nb, L0, nq, nkv, scale, o, amax=None):
     """One new token per beam against the prompt cache (per sample) + generated cache (per beam).
     amax = (slot of max |kp|, slot of max |vp|): the three-piece fp16 form (gamer_attn_decode_split)."""

@@ -750,6 +750,11 @@ int gamer_attn_decode(const float* q, int ldq, const float* kp, int ldkp, const 
                       const int32_t* key_ok, const float* kg, const float* vg, int ldg, int tmax, int t, int gen_ok,
                       const int32_t* uniform, int B, int nb, int L0, int nq, int nkv, float scale, float* o,
                       void* stream);
+/* (ABI 9, round 6) The new token's keys / values join the generated part of the cache in one launch: kg / vg [N][tmax][C] (row stride
+ * ldg) <- k [N][C] (ldk), v [N][C] (ldv: the v columns of the q|k|v buffer) at position g; C, the leading dims % 4 == 0, 16-byte aligned.
+ * Replaces two strided tensor copies per attention and token of the cached decode step (ref:.../Qwen3Multi/model.py:118-121). */
+int gamer_kv_append(const float* k, int ldk, const float* v, int ldv, float* kg, float* vg, int ldg, int tmax, int g, int N, int C,
+                    void* stream);
 /* (ABI 9) The same with its two products in the three-piece fp16 form of the train step (gamer_attn_fwd_split with
  * gamer_attn_split_amax): amax_k / amax_v = gamer_absmax_f32 slots holding max |kp|, max |vp| (the prompt caches do not change during a
  * generation: measured once per session); the queries are scaled per workgroup inside the kernel, the generated positions stay in fp32.
