@@ -76,6 +76,24 @@ trie_advance_kernel(const int32_t* __restrict__ node, const int64_t* __restrict_
 //   cross attention: prompt key j allowed iff key_ok[b][j] (= kept and lower level than the target behaviour, the
 //                    cached last mask row of model.py:603-617); generated keys masked; uniform[b] = 1 when no key
 //                    is allowed: the row is then the mean of V over ALL L0 + t keys (finfo.min quirk)
+// Sum over the 64 lanes for the tail's dot products with the generated keys (up to tmax per query row, one after the other): the pairs of
+// the xor 32, 16, 8, 4, 2, 1 butterfly in that order - v_permlane32_swap / v_permlane16_swap exchange the halves / the odd and even rows
+// of 16, the rest are DPP row rotations and quad permutations (their partners hold the xor partner's VALUE once the earlier steps have
+// made the lanes 8- and 4-periodic) - so the bits are those of wave_sum's __shfl_xor chain (checked on random data), without its six
+// dependent ds_bpermute round trips per dot product.
+__device__ __forceinline__ float wave_sum_x(float v) {
+#define GAMER_DEC_DPP(ctrl) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xf, 0xf, false))
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    v += GAMER_DEC_DPP(0x128);            // row_ror:8
+    v += GAMER_DEC_DPP(0x124);            // row_ror:4
+    v += GAMER_DEC_DPP(0x4E);             // quad_perm [2,3,0,1]
+    v += GAMER_DEC_DPP(0xB1);             // quad_perm [1,0,3,2]
+#undef GAMER_DEC_DPP
+    return v;
+}
 constexpr int DEC_MAXQ = 16;            // query rows per wave in the tail (4 waves): num_beams * G <= 64
 constexpr int DEC_KLD = 68;             // floats per row of the K tile image (16-byte aligned rows, conflict-free)
 constexpr int DEC_WAVE_LDS = 32 * DEC_KLD + 32 * 64 + 32;          // K tile + V tile + key_ok tile
@@ -238,15 +256,28 @@ attn_decode_kernel(const float* __restrict__ q, int ldq, const float* __restrict
                 }
             }
             if (gen_ok) {
+                // the generated positions' key / value rows of this beam, four at a time, all requested before the first dot product
+                // waits for one (a load per position inside the dependent softmax update was a memory round trip per position and row)
                 const float qd = q[(int64_t)n * ldq + head * 64 + lane] * c2;
-                for (int g = 0; g < t; ++g) {
-                    const float* krow = kg + ((int64_t)n * tmax + g) * ldg + kvh * 64;
-                    const float s = wave_sum(qd * krow[lane]);
-                    const float mn = fmaxf(mi, s);
-                    const float alpha = __builtin_amdgcn_exp2f(mi - mn), pe = __builtin_amdgcn_exp2f(s - mn);
-                    li = li * alpha + pe;
-                    a = a * alpha + pe * vg[((int64_t)n * tmax + g) * ldg + kvh * 64 + lane];
-                    mi = mn;
+                for (int g0 = 0; g0 < t; g0 += 4) {
+                    float kv4[4], vv4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int64_t row = ((int64_t)n * tmax + min(g0 + u, t - 1)) * ldg + kvh * 64 + lane;
+                        kv4[u] = kg[row];
+                        vv4[u] = vg[row];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (g0 + u < t) {
+                            const float s = wave_sum_x(qd * kv4[u]);
+                            const float mn = fmaxf(mi, s);
+                            const float alpha = __builtin_amdgcn_exp2f(mi - mn), pe = __builtin_amdgcn_exp2f(s - mn);
+                            li = li * alpha + pe;
+                            a = a * alpha + pe * vv4[u];
+                            mi = mn;
+                        }
+                    }
                 }
             }
             res = li > 0.f ? a / li : 0.f;
@@ -480,15 +511,28 @@ attn_decode_h2_kernel(const float* __restrict__ q, int ldq, const float* __restr
                 }
             }
             if (gen_ok) {
+                // the generated positions' key / value rows of this beam, four at a time, all requested before the first dot product
+                // waits for one (a load per position inside the dependent softmax update was a memory round trip per position and row)
                 const float qd = q[(int64_t)n * ldq + head * 64 + lane] * c2;
-                for (int g = 0; g < t; ++g) {
-                    const float* krow = kg + ((int64_t)n * tmax + g) * ldg + kvh * 64;
-                    const float s = wave_sum(qd * krow[lane]);
-                    const float mn = fmaxf(mi, s);
-                    const float alpha = __builtin_amdgcn_exp2f(mi - mn), pe = __builtin_amdgcn_exp2f(s - mn);
-                    li = li * alpha + pe;
-                    a = a * alpha + pe * vg[((int64_t)n * tmax + g) * ldg + kvh * 64 + lane];
-                    mi = mn;
+                for (int g0 = 0; g0 < t; g0 += 4) {
+                    float kv4[4], vv4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int64_t row = ((int64_t)n * tmax + min(g0 + u, t - 1)) * ldg + kvh * 64 + lane;
+                        kv4[u] = kg[row];
+                        vv4[u] = vg[row];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (g0 + u < t) {
+                            const float s = wave_sum_x(qd * kv4[u]);
+                            const float mn = fmaxf(mi, s);
+                            const float alpha = __builtin_amdgcn_exp2f(mi - mn), pe = __builtin_amdgcn_exp2f(s - mn);
+                            li = li * alpha + pe;
+                            a = a * alpha + pe * vv4[u];
+                            mi = mn;
+                        }
+                    }
                 }
             }
             res = li > 0.f ? a / li : 0.f;
